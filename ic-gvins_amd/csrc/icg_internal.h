@@ -1,0 +1,185 @@
+// Internal definitions shared by the HIP translation units of libicgvins_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/icgvins_hip.h"
+
+#define ICG_MAX_LEVELS 4
+#define ICG_LK_WIN 21
+#define ICG_LK_HALF 10
+#define ICG_CLAHE_TILES 21
+
+struct icg_level {
+    int w, h, pitch;
+    size_t off; // byte offset inside a slot
+};
+
+struct icg_prof_rec {
+    int launches  = 0;
+    double total_ms = 0;
+};
+
+struct icg_ctx {
+    icg_ctx_config cfg{};
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // frame slots: CLAHE image + LK pyramid, u8, per-level pitch
+    int n_levels = 0;
+    icg_level lv[ICG_MAX_LEVELS]{};
+    size_t slot_bytes = 0;
+    uint8_t *d_frames = nullptr;
+
+    // preprocessing workspace (per batch lane)
+    int raw_pitch      = 0;
+    uint8_t *d_raw     = nullptr; // max_batch x raw_pitch x h  gray input
+    uint8_t *d_bgr     = nullptr; // lazily: max_batch x w*3 x h
+    uint8_t *d_lut     = nullptr; // max_batch x tiles^2 x 256
+    double *d_histmean = nullptr; // max_batch
+
+    // detection workspace (lazily allocated)
+    float *d_eig          = nullptr; // max_batch x w x h
+    uint8_t *d_mask       = nullptr; // max_batch x pitch0 x h
+    uint32_t *d_roi_max   = nullptr;
+    unsigned long long *d_cand = nullptr;
+    int32_t *d_cand_cnt   = nullptr;
+    size_t cand_cap_per_roi = 0;
+
+    // mirrored staging arena (pinned host <-> device), bump-allocated per call
+    char *h_arena = nullptr;
+    char *d_arena = nullptr;
+    size_t arena_cap = 0, arena_off = 0;
+
+    // reprojection back-end resident state
+    double *d_obs = nullptr;
+    int32_t *d_fidx = nullptr; // 3 x n
+    int n_factors_resident = 0, factors_cap = 0;
+    double *d_rJ = nullptr; // n x 48 packed results (r2 + J46)
+    int rJ_valid = 0, rJ_has_jac = 0;
+    double *d_params = nullptr; // poses, ext, invdepth, td (device copy)
+    size_t params_cap = 0;
+    int last_n_poses = 0, last_n_lm = 0;
+
+    icg_camera cam{};
+    bool has_cam = false;
+
+    // profiling
+    bool prof_on = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct pending {
+        std::string name;
+        hipEvent_t a, b;
+    };
+    std::vector<pending> prof_pending;
+    std::map<std::string, icg_prof_rec> prof;
+};
+
+int icg_fail(icg_ctx *ctx, int code, const char *fmt, ...);
+int icg_hip_check(icg_ctx *ctx, hipError_t e, const char *what);
+#define ICG_HIP(ctx, call)                                                                                             \
+    do {                                                                                                               \
+        int _rc = icg_hip_check((ctx), (call), #call);                                                                 \
+        if (_rc) return _rc;                                                                                           \
+    } while (0)
+
+// arena ---------------------------------------------------------------------------------------------------
+int icg_arena_reserve(icg_ctx *ctx, size_t bytes); // ensure capacity (may reallocate; only when arena_off == 0)
+static inline size_t icg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// returns offset; host pointer = h_arena+off, device pointer = d_arena+off
+size_t icg_arena_alloc(icg_ctx *ctx, size_t bytes);
+template <typename T> static inline T *icg_h(icg_ctx *ctx, size_t off) { return reinterpret_cast<T *>(ctx->h_arena + off); }
+template <typename T> static inline T *icg_d(icg_ctx *ctx, size_t off) { return reinterpret_cast<T *>(ctx->d_arena + off); }
+int icg_arena_h2d(icg_ctx *ctx, size_t begin, size_t end);
+int icg_arena_d2h(icg_ctx *ctx, size_t begin, size_t end);
+
+// profiling -----------------------------------------------------------------------------------------------
+struct icg_prof_scope {
+    icg_ctx *ctx;
+    hipEvent_t a = nullptr, b = nullptr;
+    const char *name;
+    icg_prof_scope(icg_ctx *c, const char *n);
+    ~icg_prof_scope();
+};
+void icg_prof_collect(icg_ctx *ctx); // call after stream sync
+
+// slot helpers ---------------------------------------------------------------------------------------------
+struct icg_pyr_desc { // passed by value to kernels
+    uint8_t *base;    // d_frames
+    unsigned long long slot_bytes;
+    int n_levels;
+    int w[ICG_MAX_LEVELS], h[ICG_MAX_LEVELS], pitch[ICG_MAX_LEVELS];
+    unsigned int off[ICG_MAX_LEVELS];
+};
+icg_pyr_desc icg_make_pyr_desc(const icg_ctx *ctx);
+
+__host__ __device__ static inline int icg_reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        if (i >= n) i = 2 * (n - 1) - i;
+    }
+    return i;
+}
+
+// Per-call staging helper: inputs are packed into the pinned arena and shipped with ONE H2D copy; outputs are
+// reserved behind them and fetched with ONE D2H copy at finish().
+struct icg_call {
+    icg_ctx *ctx;
+    size_t in_end = 0, out_begin = 0;
+    bool sealed = false;
+    struct outrec {
+        void *user;
+        size_t off, bytes;
+    };
+    std::vector<outrec> outs;
+    explicit icg_call(icg_ctx *c) : ctx(c) { ctx->arena_off = 0; }
+    int reserve(size_t bytes) { return icg_arena_reserve(ctx, bytes + 8192); }
+    template <typename T> T *in(const T *src, size_t n) {
+        size_t off = icg_arena_alloc(ctx, sizeof(T) * n);
+        if (n) memcpy(ctx->h_arena + off, src, sizeof(T) * n);
+        return reinterpret_cast<T *>(ctx->d_arena + off);
+    }
+    template <typename T> T *in_host(size_t n, T **host) { // caller fills *host before seal()
+        size_t off = icg_arena_alloc(ctx, sizeof(T) * n);
+        *host      = reinterpret_cast<T *>(ctx->h_arena + off);
+        return reinterpret_cast<T *>(ctx->d_arena + off);
+    }
+    int seal() {
+        in_end    = ctx->arena_off;
+        sealed    = true;
+        out_begin = icg_align_up(in_end, 256);
+        return icg_arena_h2d(ctx, 0, in_end);
+    }
+    template <typename T> T *out(T *user, size_t n) {
+        size_t off = icg_arena_alloc(ctx, sizeof(T) * n);
+        if (user) outs.push_back({(void *) user, off, sizeof(T) * n});
+        return reinterpret_cast<T *>(ctx->d_arena + off);
+    }
+    template <typename T> T *host_of(T *dev) { return reinterpret_cast<T *>(ctx->h_arena + ((char *) dev - ctx->d_arena)); }
+    int finish() {
+        int rc = 0;
+        if (!outs.empty()) {
+            size_t lo = (size_t) -1, hi = 0;
+            for (auto &o : outs) {
+                if (o.off < lo) lo = o.off;
+                if (o.off + o.bytes > hi) hi = o.off + o.bytes;
+            }
+            rc = icg_arena_d2h(ctx, lo, hi);
+        }
+        if (rc) return rc;
+        rc = icg_hip_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        if (rc) return rc;
+        icg_prof_collect(ctx);
+        for (auto &o : outs) memcpy(o.user, ctx->h_arena + o.off, o.bytes);
+        ctx->arena_off = 0;
+        return 0;
+    }
+};

@@ -1,0 +1,405 @@
+// F2/F3: pyramidal Lucas-Kanade exactly as cv::calcOpticalFlowPyrLK is parameterised by the reference
+// (tracking/tracking.cc:385-393, 487-496: win 21x21, maxLevel 3, (COUNT+EPS,30,0.01), USE_INITIAL_FLOW,
+// minEigThreshold 1e-4), plus the forward/backward/border cull of tracking.cc:396-403 / 499-506.
+// Arithmetic definition: SURVEY.md Appendix B.4/B.5 (OpenCV LKTrackerInvoker): Q14 bilinear weights, patch samples
+// with 5 fractional bits, Scharr derivatives, window sums accumulated as EXACT integers (wave-reduced in int64), one
+// conversion to float, 2x2 solve in float without FMA contraction -> bit-identical to the CPU restatement.
+//
+// MI355X mapping: ONE 64-lane wavefront per feature (one workgroup = one wave, so LDS staging needs no cross-wave
+// barrier and thousands of features from many camera streams fill the 256 CUs).
+//   * per level the 24x24 u8 neighbourhood of the previous image is staged in LDS (reflect-101 applied at load),
+//     Scharr derivatives of the 22x22 support are computed ON THE FLY into LDS (the derivative planes are never
+//     materialised in HBM: -5.3 B/px of traffic per frame vs OpenCV's layout),
+//   * each lane owns a 7-pixel horizontal run of the 21x21 window (63 lanes x 7 = 441): I, Ix, Iy stay in VGPRs
+//     for all <=30 Gauss-Newton iterations,
+//   * the next image is read through a 32x32 u8 LDS tile that is re-staged only when the window leaves it,
+//   * A11/A12/A22 and b1/b2 are per-lane int32 partials (bounded: 7*4080^2 < 2^31) reduced with 64-bit butterflies.
+// Algorithmic HBM bytes per point and direction: 4 levels x (24^2 + 22^2) B; everything else is
+// LDS/VGPR traffic.
+#include <cfloat>
+
+#include "dev_camera.h"
+#include "icg_internal.h"
+
+using namespace icgd;
+
+#define LK_IT 24   // I tile side (22 support + 1 halo each side)
+#define LK_DT 22   // derivative tile side
+#define LK_JT 32   // J tile side
+#define LK_JM 5    // J tile margin around the 22x22 support
+#define LK_MAX_ITERS 30
+
+struct lk_smem {
+    unsigned char I[LK_IT * LK_IT];
+    short2 dI[LK_DT * LK_DT];
+    unsigned char J[LK_JT * LK_JT];
+};
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ int lk_descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01, int &w10, int &w11) {
+    w00 = (int) rintf((1.f - a) * (1.f - b) * (float) (1 << 14));
+    w01 = (int) rintf(a * (1.f - b) * (float) (1 << 14));
+    w10 = (int) rintf((1.f - a) * b * (float) (1 << 14));
+    w11 = (1 << 14) - w00 - w01 - w10;
+}
+
+__device__ __forceinline__ void lk_stage_J(lk_smem &S, const unsigned char *J, int W, int H, int pitch, int jx0, int jy0,
+                                           int lane) {
+    // 32x32 tile: lane -> (row = lane>>1, 16 pixels at column (lane&1)*16)
+    const int r  = lane >> 1;
+    const int c0 = (lane & 1) * 16;
+    const int sy = icg_reflect101(jy0 + r, H);
+    const unsigned char *row = J + (size_t) sy * pitch;
+#pragma unroll
+    for (int c = 0; c < 16; c++) S.J[r * LK_JT + c0 + c] = row[icg_reflect101(jx0 + c0 + c, W)];
+}
+
+// One calcOpticalFlowPyrLK point, executed cooperatively by a full wave. Returns status.
+__device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI, const unsigned char *slotJ,
+                              float2 prevPt, float2 &nextIO, lk_smem &S, int lane, float *err_out) {
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const double eps2     = 0.01 * 0.01;
+    bool status           = true;
+    float errv            = 0.f;
+    float2 nextStore      = nextIO;
+    const int maxLevel    = P.n_levels - 1;
+    const int ly          = lane / 3;
+    const int lx0         = (lane - ly * 3) * 7;
+    const bool active     = lane < 63;
+
+    for (int level = maxLevel; level >= 0; --level) {
+        const int W = P.w[level], H = P.h[level], pitch = P.pitch[level];
+        const unsigned char *I = slotI + P.off[level];
+        const unsigned char *J = slotJ + P.off[level];
+        const float scale      = (float) (1. / (1 << level));
+        float prevx = prevPt.x * scale, prevy = prevPt.y * scale;
+        float nptx, npty;
+        if (level == maxLevel) {
+            nptx = nextStore.x * scale;
+            npty = nextStore.y * scale;
+        } else {
+            nptx = nextStore.x * 2.f;
+            npty = nextStore.y * 2.f;
+        }
+        nextStore = make_float2(nptx, npty);
+
+        prevx -= (float) ICG_LK_HALF;
+        prevy -= (float) ICG_LK_HALF;
+        const int ipx = (int) floorf(prevx), ipy = (int) floorf(prevy);
+        if (ipx < -ICG_LK_WIN || ipx >= W || ipy < -ICG_LK_WIN || ipy >= H) {
+            if (level == 0) {
+                status = false;
+                errv   = 0.f;
+            }
+            continue;
+        }
+        int w00, w01, w10, w11;
+        lk_weights(prevx - ipx, prevy - ipy, w00, w01, w10, w11);
+
+        __syncthreads(); // previous level's LDS readers are done
+        for (int i = lane; i < LK_IT * LK_IT; i += 64) {
+            int r = i / LK_IT, c = i - r * LK_IT;
+            S.I[i] = I[(size_t) icg_reflect101(ipy - 1 + r, H) * pitch + icg_reflect101(ipx - 1 + c, W)];
+        }
+        __syncthreads();
+        for (int i = lane; i < LK_DT * LK_DT; i += 64) {
+            int r = i / LK_DT, c = i - r * LK_DT;
+            int X = ipx + c, Y = ipy + r;
+            short2 d = make_short2(0, 0);
+            if (X >= 0 && X < W && Y >= 0 && Y < H) {
+                const unsigned char *t = &S.I[r * LK_IT + c];
+                int p00 = t[0], p01 = t[1], p02 = t[2];
+                int p10 = t[LK_IT], p12 = t[LK_IT + 2];
+                int p20 = t[2 * LK_IT], p21 = t[2 * LK_IT + 1], p22 = t[2 * LK_IT + 2];
+                int t0m = 3 * (p00 + p20) + 10 * p10;
+                int t0p = 3 * (p02 + p22) + 10 * p12;
+                int t1m = p20 - p00, t1c = p21 - p01, t1p = p22 - p02;
+                d.x     = (short) (t0p - t0m);
+                d.y     = (short) (3 * (t1m + t1p) + 10 * t1c);
+            }
+            S.dI[i] = d;
+        }
+        __syncthreads();
+
+        int iv[7], ix[7], iy[7];
+        int sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            iv[k] = 0;
+            ix[k] = 0;
+            iy[k] = 0;
+        }
+        if (active) {
+            const unsigned char *t0 = &S.I[(ly + 1) * LK_IT + lx0 + 1];
+            const unsigned char *t1 = t0 + LK_IT;
+            const short2 *d0        = &S.dI[ly * LK_DT + lx0];
+            const short2 *d1        = d0 + LK_DT;
+            int a0 = t0[0], a1 = t1[0];
+            short2 e0 = d0[0], e1 = d1[0];
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                int b0 = t0[k + 1], b1 = t1[k + 1];
+                short2 f0 = d0[k + 1], f1 = d1[k + 1];
+                iv[k] = lk_descale(a0 * w00 + b0 * w01 + a1 * w10 + b1 * w11, 14 - 5);
+                ix[k] = lk_descale(e0.x * w00 + f0.x * w01 + e1.x * w10 + f1.x * w11, 14);
+                iy[k] = lk_descale(e0.y * w00 + f0.y * w01 + e1.y * w10 + f1.y * w11, 14);
+                sA11 += ix[k] * ix[k];
+                sA12 += ix[k] * iy[k];
+                sA22 += iy[k] * iy[k];
+                a0 = b0;
+                a1 = b1;
+                e0 = f0;
+                e1 = f1;
+            }
+        }
+        const long long iA11 = wave_sum_i64(sA11), iA12 = wave_sum_i64(sA12), iA22 = wave_sum_i64(sA22);
+        const float A11 = (float) iA11 * FLT_SCALE, A12 = (float) iA12 * FLT_SCALE, A22 = (float) iA22 * FLT_SCALE;
+        float D            = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float) (2 * ICG_LK_WIN * ICG_LK_WIN);
+        if (minEig < 1e-4f || D < FLT_EPSILON) {
+            if (level == 0) status = false;
+            continue;
+        }
+        D = 1.f / D;
+        nptx -= (float) ICG_LK_HALF;
+        npty -= (float) ICG_LK_HALF;
+        float pdx = 0.f, pdy = 0.f;
+        int jx0 = -1000000, jy0 = -1000000;
+
+        for (int j = 0; j < LK_MAX_ITERS; j++) {
+            const int inx = (int) floorf(nptx), iny = (int) floorf(npty);
+            if (inx < -ICG_LK_WIN || inx >= W || iny < -ICG_LK_WIN || iny >= H) {
+                if (level == 0) status = false;
+                break;
+            }
+            if (!(inx >= jx0 && inx <= jx0 + (LK_JT - LK_DT) && iny >= jy0 && iny <= jy0 + (LK_JT - LK_DT))) {
+                jx0 = inx - LK_JM;
+                jy0 = iny - LK_JM;
+                __syncthreads();
+                lk_stage_J(S, J, W, H, pitch, jx0, jy0, lane);
+                __syncthreads();
+            }
+            lk_weights(nptx - inx, npty - iny, w00, w01, w10, w11);
+            int sb1 = 0, sb2 = 0;
+            if (active) {
+                const unsigned char *t0 = &S.J[(iny - jy0 + ly) * LK_JT + (inx - jx0) + lx0];
+                const unsigned char *t1 = t0 + LK_JT;
+                int a0 = t0[0], a1 = t1[0];
+#pragma unroll
+                for (int k = 0; k < 7; k++) {
+                    int b0 = t0[k + 1], b1 = t1[k + 1];
+                    int diff = lk_descale(a0 * w00 + b0 * w01 + a1 * w10 + b1 * w11, 14 - 5) - iv[k];
+                    sb1 += diff * ix[k];
+                    sb2 += diff * iy[k];
+                    a0 = b0;
+                    a1 = b1;
+                }
+            }
+            const long long ib1 = wave_sum_i64(sb1), ib2 = wave_sum_i64(sb2);
+            const float b1 = (float) ib1 * FLT_SCALE, b2 = (float) ib2 * FLT_SCALE;
+            const float dx = (float) ((A12 * b2 - A22 * b1) * D);
+            const float dy = (float) ((A12 * b1 - A11 * b2) * D);
+            nptx += dx;
+            npty += dy;
+            nextStore = make_float2(nptx + (float) ICG_LK_HALF, npty + (float) ICG_LK_HALF);
+            if ((double) dx * dx + (double) dy * dy <= eps2) break;
+            if (j > 0 && fabs((double) (dx + pdx)) < 0.01 && fabs((double) (dy + pdy)) < 0.01) {
+                nextStore.x -= dx * 0.5f;
+                nextStore.y -= dy * 0.5f;
+                break;
+            }
+            pdx = dx;
+            pdy = dy;
+        }
+
+        if (status && level == 0) {
+            // OpenCV >= 3.4 epilogue (taken because the reference passes an err vector, tracking.cc:381,386,391)
+            const float ex = nextStore.x - (float) ICG_LK_HALF, ey = nextStore.y - (float) ICG_LK_HALF;
+            const int inx = (int) floorf(ex), iny = (int) floorf(ey);
+            if (inx < -ICG_LK_WIN || inx >= W || iny < -ICG_LK_WIN || iny >= H) {
+                status = false;
+                continue;
+            }
+            if (err_out) {
+                if (!(inx >= jx0 && inx <= jx0 + (LK_JT - LK_DT) && iny >= jy0 && iny <= jy0 + (LK_JT - LK_DT))) {
+                    jx0 = inx - LK_JM;
+                    jy0 = iny - LK_JM;
+                    __syncthreads();
+                    lk_stage_J(S, J, W, H, pitch, jx0, jy0, lane);
+                    __syncthreads();
+                }
+                lk_weights(ex - inx, ey - iny, w00, w01, w10, w11);
+                int se = 0;
+                if (active) {
+                    const unsigned char *t0 = &S.J[(iny - jy0 + ly) * LK_JT + (inx - jx0) + lx0];
+                    const unsigned char *t1 = t0 + LK_JT;
+#pragma unroll
+                    for (int k = 0; k < 7; k++) {
+                        int diff = lk_descale(t0[k] * w00 + t0[k + 1] * w01 + t1[k] * w10 + t1[k + 1] * w11, 14 - 5) - iv[k];
+                        se += diff < 0 ? -diff : diff;
+                    }
+                }
+                const long long ie = wave_sum_i64(se);
+                errv               = (float) ie * 1.f / (float) (32 * ICG_LK_WIN * ICG_LK_WIN);
+            }
+        }
+    }
+    nextIO = nextStore;
+    if (err_out && lane == 0) *err_out = errv;
+    return status;
+}
+
+__global__ __launch_bounds__(64) void k_lk_track(icg_pyr_desc P, int n, const int32_t *prev_slot, const int32_t *next_slot,
+                                                 const float2 *prev_pts, float2 *next_pts, unsigned char *status, float *err) {
+    __shared__ lk_smem S;
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const int lane = threadIdx.x;
+    const unsigned char *sI = P.base + (size_t) prev_slot[i] * P.slot_bytes;
+    const unsigned char *sJ = P.base + (size_t) next_slot[i] * P.slot_bytes;
+    float2 nx = next_pts[i];
+    bool st   = lk_track_wave(P, sI, sJ, prev_pts[i], nx, S, lane, err ? err + i : nullptr);
+    if (lane == 0) {
+        next_pts[i] = nx;
+        status[i]   = st ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_lk_track_fb(icg_pyr_desc P, int n, const int32_t *prev_slot,
+                                                    const int32_t *next_slot, const float2 *prev_pts,
+                                                    const float2 *guess_pts, float2 *out_pts, unsigned char *status,
+                                                    int has_cam, icg_camera cam, float2 *out_undist, int img_w, int img_h) {
+    __shared__ lk_smem S;
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const int lane = threadIdx.x;
+    const unsigned char *sP = P.base + (size_t) prev_slot[i] * P.slot_bytes;
+    const unsigned char *sN = P.base + (size_t) next_slot[i] * P.slot_bytes;
+    const float2 p0 = prev_pts[i];
+    float2 fwd      = guess_pts[i];
+    const bool st_f = lk_track_wave(P, sP, sN, p0, fwd, S, lane, nullptr);
+    float2 bwd      = p0;
+    const bool st_b = lk_track_wave(P, sN, sP, fwd, bwd, S, lane, nullptr);
+    if (lane == 0) {
+        // isOnBorder (tracking.cc:847-849) and ptsDistance (tracking.cc:841-845)
+        const bool border = (double) fwd.x < 5.0 || (double) fwd.y < 5.0 || ((double) fwd.x > (img_w - 5.0)) ||
+                            ((double) fwd.y > (img_h - 5.0));
+        const double ddx = (double) (bwd.x - p0.x), ddy = (double) (bwd.y - p0.y);
+        const double dist = sqrt(ddx * ddx + ddy * ddy);
+        out_pts[i]        = fwd;
+        status[i]         = (st_f && st_b && !border && dist < 0.5) ? 1 : 0;
+        if (out_undist) out_undist[i] = has_cam ? cam_undistort(cam, fwd) : fwd;
+    }
+}
+
+// order-preserving compaction indices (what reduceVector keeps, tracking.cc:831-839); single workgroup scan.
+__global__ __launch_bounds__(1024) void k_keep_indices(int n, const unsigned char *status, int32_t *keep_idx, int32_t *n_keep) {
+    __shared__ int wave_tot[16];
+    __shared__ int base;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int start = 0; start < n; start += 1024) {
+        const int i   = start + t;
+        const bool k  = i < n && status[i];
+        const unsigned long long m = __ballot(k);
+        const int pre = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wv] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; w++) off += wave_tot[w];
+        if (k) keep_idx[off + pre] = i;
+        __syncthreads();
+        if (t == 0) {
+            int s = 0;
+            for (int w = 0; w < 16; w++) s += wave_tot[w];
+            base += s;
+        }
+        __syncthreads();
+    }
+    if (t == 0) *n_keep = base;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+static int check_slots(icg_ctx *ctx, int n, const int32_t *a, const int32_t *b) {
+    for (int i = 0; i < n; i++)
+        if (a[i] < 0 || a[i] >= ctx->cfg.n_slots || b[i] < 0 || b[i] >= ctx->cfg.n_slots)
+            return icg_fail(ctx, ICG_ERR_INVALID, "slot index out of range at point %d", i);
+    return 0;
+}
+
+extern "C" int icg_lk_track(icg_ctx *ctx, int n, const int32_t *prev_slot, const int32_t *next_slot, const float *prev_pts,
+                            float *next_pts, uint8_t *status, float *err) {
+    if (!ctx || n < 0) return ICG_ERR_INVALID;
+    if (n == 0) return ICG_OK;
+    if (!prev_slot || !next_slot || !prev_pts || !next_pts || !status) return ICG_ERR_INVALID;
+    if (n > ctx->cfg.max_points) return icg_fail(ctx, ICG_ERR_CAPACITY, "%d points > max_points %d", n, ctx->cfg.max_points);
+    int rc = check_slots(ctx, n, prev_slot, next_slot);
+    if (rc) return rc;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    icg_call c(ctx);
+    if ((rc = c.reserve((size_t) n * 64))) return rc;
+    const int32_t *d_ps = c.in(prev_slot, (size_t) n);
+    const int32_t *d_ns = c.in(next_slot, (size_t) n);
+    const float2 *d_pp  = (const float2 *) c.in(prev_pts, 2 * (size_t) n);
+    const float2 *d_gs  = (const float2 *) c.in(next_pts, 2 * (size_t) n);
+    if ((rc = c.seal())) return rc;
+    float2 *d_np      = (float2 *) c.out(next_pts, 2 * (size_t) n);
+    unsigned char *d_st = c.out(status, (size_t) n);
+    float *d_err      = err ? c.out(err, (size_t) n) : nullptr;
+    ICG_HIP(ctx, hipMemcpyAsync(d_np, d_gs, sizeof(float2) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    {
+        icg_prof_scope ps(ctx, "lk_track");
+        hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp, d_np,
+                           d_st, d_err);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}
+
+extern "C" int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, const int32_t *next_slot,
+                               const float *prev_pts, const float *guess_pts, float *out_pts, uint8_t *status,
+                               float *out_undist, int32_t *keep_idx, int32_t *n_keep) {
+    if (!ctx || n < 0) return ICG_ERR_INVALID;
+    if (n == 0) {
+        if (n_keep) *n_keep = 0;
+        return ICG_OK;
+    }
+    if (!prev_slot || !next_slot || !prev_pts || !guess_pts || !out_pts || !status) return ICG_ERR_INVALID;
+    if ((keep_idx == nullptr) != (n_keep == nullptr)) return ICG_ERR_INVALID;
+    if (out_undist && !ctx->has_cam) return icg_fail(ctx, ICG_ERR_INVALID, "out_undist requested but camera not set");
+    if (n > ctx->cfg.max_points) return icg_fail(ctx, ICG_ERR_CAPACITY, "%d points > max_points %d", n, ctx->cfg.max_points);
+    int rc = check_slots(ctx, n, prev_slot, next_slot);
+    if (rc) return rc;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    icg_call c(ctx);
+    if ((rc = c.reserve((size_t) n * 96))) return rc;
+    const int32_t *d_ps = c.in(prev_slot, (size_t) n);
+    const int32_t *d_ns = c.in(next_slot, (size_t) n);
+    const float2 *d_pp  = (const float2 *) c.in(prev_pts, 2 * (size_t) n);
+    const float2 *d_gs  = (const float2 *) c.in(guess_pts, 2 * (size_t) n);
+    if ((rc = c.seal())) return rc;
+    float2 *d_out       = (float2 *) c.out(out_pts, 2 * (size_t) n);
+    unsigned char *d_st = c.out(status, (size_t) n);
+    float2 *d_und       = out_undist ? (float2 *) c.out(out_undist, 2 * (size_t) n) : nullptr;
+    int32_t *d_keep     = keep_idx ? c.out(keep_idx, (size_t) n) : nullptr;
+    int32_t *d_nkeep    = keep_idx ? c.out(n_keep, 1) : nullptr;
+    {
+        icg_prof_scope ps(ctx, "lk_track_fb");
+        hipLaunchKernelGGL(k_lk_track_fb, dim3(n), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp,
+                           d_gs, d_out, d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height);
+    }
+    if (keep_idx) {
+        icg_prof_scope ps(ctx, "keep_indices");
+        hipLaunchKernelGGL(k_keep_indices, dim3(1), dim3(1024), 0, ctx->stream, n, d_st, d_keep, d_nkeep);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}

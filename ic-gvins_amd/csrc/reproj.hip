@@ -1,0 +1,312 @@
+// R1/R2: batched ReprojectionFactor::Evaluate (+ ResidualBlockInfo robust correction) on gfx950.
+//
+// Reference: factors/reprojection_factor.h:55-147 (residual + 5 Jacobian blocks),
+//            factors/residual_block_info.h:59-87 (Huber corrector used by marginalization).
+// Design (HBM-bound, FP64, no MFMA — SURVEY.md §8(d)): one lane per factor, observation constants read
+// component-major (15 coalesced 512-B wave loads), shared parameter blocks gathered through L2, the 48 output
+// doubles of each factor transposed through LDS (row stride 49 to spread banks) so a 64-factor wave writes its
+// r[64x2] and J[64x46] slabs as contiguous 16-B-per-lane stores.
+// Algorithmic bytes per factor with Jacobians: 120 (obs) + 12 (indices) + 384 (out) = 516 B.
+#include "dev_math.h"
+#include "icg_internal.h"
+
+using namespace icgd;
+
+#define RPJ_TILE 64
+#define RPJ_LDS_STRIDE 49
+
+struct rpj_args {
+    int n;
+    const double *obs;    // 15 x n
+    const int32_t *idx_i; // n
+    const int32_t *idx_j;
+    const int32_t *idx_lm;
+    const double *poses; // K x 7
+    const double *ext;   // 7
+    const double *invdepth;
+    double td;
+    int want_jac;
+    double huber_delta;
+    double *out_r; // n x 2
+    double *out_J; // n x 46
+};
+
+__device__ __forceinline__ void put23(double *row0, double *row1, const double red[6], const m33 &m, int col0) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        row0[col0 + j] = red[0] * m.a[0 * 3 + j] + red[1] * m.a[1 * 3 + j] + red[2] * m.a[2 * 3 + j];
+        row1[col0 + j] = red[3] * m.a[0 * 3 + j] + red[4] * m.a[1 * 3 + j] + red[5] * m.a[2 * 3 + j];
+    }
+}
+
+__global__ __launch_bounds__(RPJ_TILE) void k_reproj_eval(rpj_args A) {
+    __shared__ double tile[RPJ_TILE * RPJ_LDS_STRIDE];
+    const int lane = threadIdx.x;
+    const int f0   = blockIdx.x * RPJ_TILE;
+    const int k    = f0 + lane;
+    double *o      = &tile[lane * RPJ_LDS_STRIDE]; // o[0..1] residual, o[2..47] Jacobians
+
+    if (k < A.n) {
+        const size_t n = (size_t) A.n;
+        d3 pts0        = mk3(A.obs[0 * n + k], A.obs[1 * n + k], A.obs[2 * n + k]);
+        d3 pts1        = mk3(A.obs[3 * n + k], A.obs[4 * n + k], A.obs[5 * n + k]);
+        d3 vel0        = mk3(A.obs[6 * n + k], A.obs[7 * n + k], A.obs[8 * n + k]);
+        d3 vel1        = mk3(A.obs[9 * n + k], A.obs[10 * n + k], A.obs[11 * n + k]);
+        double td0 = A.obs[12 * n + k], td1 = A.obs[13 * n + k];
+        double sinfo = 1.0 / A.obs[14 * n + k];
+
+        const double *pi = A.poses + 7 * (size_t) A.idx_i[k];
+        const double *pj = A.poses + 7 * (size_t) A.idx_j[k];
+        d3 p0  = mk3(pi[0], pi[1], pi[2]);
+        dq q0  = q_from_xyzw(pi + 3);
+        d3 p1  = mk3(pj[0], pj[1], pj[2]);
+        dq q1  = q_from_xyzw(pj + 3);
+        d3 tic = mk3(A.ext[0], A.ext[1], A.ext[2]);
+        dq qic = q_from_xyzw(A.ext + 3);
+        double id0 = A.invdepth[A.idx_lm[k]];
+        double td  = A.td;
+
+        d3 pts_0_td = sub(pts0, scl(td - td0, vel0));
+        d3 pts_1_td = sub(pts1, scl(td - td1, vel1));
+        d3 pts_c_0  = dvd(pts_0_td, id0);
+        d3 pts_b_0  = add(q_rot(qic, pts_c_0), tic);
+        d3 pts_n    = add(q_rot(q0, pts_b_0), p0);
+        d3 pts_b_1  = q_rot(q_inv(q1), sub(pts_n, p1));
+        d3 pts_1    = q_rot(q_inv(qic), sub(pts_b_1, tic));
+        double d1   = pts_1.z;
+
+        double r0 = sinfo * (pts_1.x / d1 - pts_1_td.x);
+        double r1 = sinfo * (pts_1.y / d1 - pts_1_td.y);
+        o[0]      = r0;
+        o[1]      = r1;
+
+        if (A.want_jac) {
+            m33 cb0n = q_mat(q0);
+            m33 cnb1 = m_T(q_mat(q1));
+            m33 cbc  = m_T(q_mat(qic));
+            double red[6];
+            red[0] = sinfo * (1.0 / d1);
+            red[1] = sinfo * 0.0;
+            red[2] = sinfo * (-pts_1.x / (d1 * d1));
+            red[3] = sinfo * 0.0;
+            red[4] = sinfo * (1.0 / d1);
+            red[5] = sinfo * (-pts_1.y / (d1 * d1));
+
+            double *Ji0 = o + 2, *Ji1 = o + 2 + 7;
+            double *Jj0 = o + 16, *Jj1 = o + 16 + 7;
+            double *Je0 = o + 30, *Je1 = o + 30 + 7;
+
+            m33 cbc_cnb1  = m_mul(cbc, cnb1);
+            m33 ncbc_cnb1 = m_mul(m_neg(cbc), cnb1);
+            // pose i
+            put23(Ji0, Ji1, red, cbc_cnb1, 0);
+            put23(Ji0, Ji1, red, m_mul(m_mul(ncbc_cnb1, cb0n), m_skew(pts_b_0)), 3);
+            Ji0[6] = 0;
+            Ji1[6] = 0;
+            // pose j
+            put23(Jj0, Jj1, red, ncbc_cnb1, 0);
+            put23(Jj0, Jj1, red, m_mul(cbc, m_skew(pts_b_1)), 3);
+            Jj0[6] = 0;
+            Jj1[6] = 0;
+            // extrinsic
+            m33 tmp_r = m_mul(m_mul(cbc_cnb1, cb0n), m_T(cbc));
+            put23(Je0, Je1, red, m_mul(cbc, m_sub(m_mul(cnb1, cb0n), m_eye())), 0);
+            d3 inner  = sub(m_vec(cnb1, sub(add(m_vec(cb0n, tic), p0), p1)), tic);
+            m33 right = m_add(m_add(m_mul(m_neg(tmp_r), m_skew(pts_c_0)), m_skew(m_vec(tmp_r, pts_c_0))),
+                              m_skew(m_vec(cbc, inner)));
+            put23(Je0, Je1, red, right, 3);
+            Je0[6] = 0;
+            Je1[6] = 0;
+            // inverse depth and td: t = -reduce * tmp_r
+            double nred[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) nred[i] = -red[i];
+            double t0[3], t1[3];
+            put23(t0, t1, nred, tmp_r, 0);
+            double idsq = id0 * id0;
+            o[44]       = (t0[0] * pts_0_td.x + t0[1] * pts_0_td.y + t0[2] * pts_0_td.z) / idsq;
+            o[45]       = (t1[0] * pts_0_td.x + t1[1] * pts_0_td.y + t1[2] * pts_0_td.z) / idsq;
+            o[46]       = (t0[0] * vel0.x + t0[1] * vel0.y + t0[2] * vel0.z) / id0 + sinfo * vel1.x;
+            o[47]       = (t1[0] * vel0.x + t1[1] * vel0.y + t1[2] * vel0.z) / id0 + sinfo * vel1.y;
+        }
+
+        if (A.huber_delta > 0) {
+            // residual_block_info.h:59-87 with ceres::HuberLoss(delta)
+            double a = A.huber_delta, b = a * a;
+            double s = r0 * r0 + r1 * r1;
+            double rho1, rho2;
+            if (s > b) {
+                double r = sqrt(s);
+                rho1     = fmax(2.2250738585072014e-308, a / r);
+                rho2     = -rho1 / (2.0 * s);
+            } else {
+                rho1 = 1.0;
+                rho2 = 0.0;
+            }
+            double sqrt_rho1 = sqrt(rho1);
+            double residual_scaling, alpha_sq_norm;
+            if ((s == 0.0) || (rho2 <= 0.0)) {
+                residual_scaling = sqrt_rho1;
+                alpha_sq_norm    = 0.0;
+            } else {
+                const double D     = 1.0 + 2.0 * s * rho2 / rho1;
+                const double alpha = 1.0 - sqrt(D);
+                residual_scaling   = sqrt_rho1 / (1 - alpha);
+                alpha_sq_norm      = alpha / s;
+            }
+            if (A.want_jac) {
+                // columns: three 2x7 blocks (row stride 7) and two 2x1 blocks (row stride 1)
+#pragma unroll
+                for (int blk = 0; blk < 3; blk++) {
+                    double *B = o + 2 + 14 * blk;
+#pragma unroll
+                    for (int c = 0; c < 7; c++) {
+                        double j0 = B[c], j1 = B[7 + c];
+                        double rtj = r0 * j0 + r1 * j1;
+                        B[c]       = sqrt_rho1 * (j0 - alpha_sq_norm * r0 * rtj);
+                        B[7 + c]   = sqrt_rho1 * (j1 - alpha_sq_norm * r1 * rtj);
+                    }
+                }
+#pragma unroll
+                for (int blk = 0; blk < 2; blk++) {
+                    double *B  = o + 44 + 2 * blk;
+                    double j0 = B[0], j1 = B[1];
+                    double rtj = r0 * j0 + r1 * j1;
+                    B[0]       = sqrt_rho1 * (j0 - alpha_sq_norm * r0 * rtj);
+                    B[1]       = sqrt_rho1 * (j1 - alpha_sq_norm * r1 * rtj);
+                }
+            }
+            o[0] = r0 * residual_scaling;
+            o[1] = r1 * residual_scaling;
+        }
+    }
+    __syncthreads();
+
+    const int nvalid = min(RPJ_TILE, A.n - f0);
+    // residual slab: nvalid x 2 doubles, contiguous
+    {
+        int e = lane * 2;
+        if (lane < nvalid) {
+            double2 v = make_double2(tile[lane * RPJ_LDS_STRIDE + 0], tile[lane * RPJ_LDS_STRIDE + 1]);
+            *reinterpret_cast<double2 *>(A.out_r + (size_t) f0 * 2 + e) = v;
+        }
+    }
+    if (A.want_jac) {
+        const int total2 = nvalid * 23; // double2 elements in the J slab
+        double *dst      = A.out_J + (size_t) f0 * 46;
+        for (int i2 = lane; i2 < total2; i2 += RPJ_TILE) {
+            int e = i2 * 2;
+            int f = e / 46, c = e - f * 46;
+            double2 v = make_double2(tile[f * RPJ_LDS_STRIDE + 2 + c], tile[f * RPJ_LDS_STRIDE + 3 + c]);
+            *reinterpret_cast<double2 *>(dst + e) = v;
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+static int ensure_factor_capacity(icg_ctx *ctx, int n) {
+    if (n <= ctx->factors_cap) return 0;
+    ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_obs) (void) hipFree(ctx->d_obs);
+    if (ctx->d_fidx) (void) hipFree(ctx->d_fidx);
+    if (ctx->d_rJ) (void) hipFree(ctx->d_rJ);
+    ctx->d_obs = nullptr;
+    ctx->d_fidx = nullptr;
+    ctx->d_rJ = nullptr;
+    ctx->factors_cap = 0;
+    int cap = n + n / 4 + 64;
+    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_obs, sizeof(double) * 15 * (size_t) cap));
+    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_fidx, sizeof(int32_t) * 3 * (size_t) cap));
+    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_rJ, sizeof(double) * 48 * (size_t) cap));
+    ctx->factors_cap = cap;
+    return 0;
+}
+
+extern "C" int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa, const int32_t *idx_i,
+                                      const int32_t *idx_j, const int32_t *idx_lm) {
+    if (!ctx || n < 0 || (n > 0 && (!obs_soa || !idx_i || !idx_j || !idx_lm))) return ICG_ERR_INVALID;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = ensure_factor_capacity(ctx, n);
+    if (rc) return rc;
+    ctx->n_factors_resident = n;
+    ctx->rJ_valid           = 0;
+    if (n == 0) return ICG_OK;
+    // component-major obs is already the device layout; indices packed as 3 x n
+    ICG_HIP(ctx, hipMemcpyAsync(ctx->d_obs, obs_soa, sizeof(double) * 15 * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+    ICG_HIP(ctx, hipMemcpyAsync(ctx->d_fidx, idx_i, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    ICG_HIP(ctx, hipMemcpyAsync(ctx->d_fidx + n, idx_j, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    ICG_HIP(ctx, hipMemcpyAsync(ctx->d_fidx + 2 * (size_t) n, idx_lm, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICG_OK;
+}
+
+extern "C" int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm,
+                                        const double *invdepth, double td, int want_jac, double huber_delta,
+                                        double *out_r, double *out_J) {
+    if (!ctx || !poses || !ext || !invdepth || n_poses <= 0 || n_lm <= 0) return ICG_ERR_INVALID;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const int n = ctx->n_factors_resident;
+    if (n == 0) return ICG_OK;
+    // parameters: poses | ext | invdepth  packed in the staging arena
+    size_t pbytes = sizeof(double) * ((size_t) n_poses * 7 + 7 + (size_t) n_lm);
+    size_t rbytes = sizeof(double) * 2 * (size_t) n, jbytes = want_jac ? sizeof(double) * 46 * (size_t) n : 0;
+    ctx->arena_off = 0;
+    int rc         = icg_arena_reserve(ctx, pbytes + rbytes + jbytes + 4096);
+    if (rc) return rc;
+    size_t o_par = icg_arena_alloc(ctx, pbytes);
+    double *hp   = icg_h<double>(ctx, o_par);
+    memcpy(hp, poses, sizeof(double) * 7 * (size_t) n_poses);
+    memcpy(hp + 7 * (size_t) n_poses, ext, sizeof(double) * 7);
+    memcpy(hp + 7 * (size_t) n_poses + 7, invdepth, sizeof(double) * (size_t) n_lm);
+    size_t in_end = ctx->arena_off;
+    size_t o_r    = icg_arena_alloc(ctx, rbytes);
+    size_t o_J    = want_jac ? icg_arena_alloc(ctx, jbytes) : 0;
+    if ((rc = icg_arena_h2d(ctx, o_par, in_end))) return rc;
+
+    rpj_args A;
+    A.n           = n;
+    A.obs         = ctx->d_obs;
+    A.idx_i       = ctx->d_fidx;
+    A.idx_j       = ctx->d_fidx + n;
+    A.idx_lm      = ctx->d_fidx + 2 * (size_t) n;
+    double *dp    = icg_d<double>(ctx, o_par);
+    A.poses       = dp;
+    A.ext         = dp + 7 * (size_t) n_poses;
+    A.invdepth    = dp + 7 * (size_t) n_poses + 7;
+    A.td          = td;
+    A.want_jac    = want_jac;
+    A.huber_delta = huber_delta;
+    // device-resident results (kept for icg_reproj_accumulate_normal): r at d_rJ, J after it
+    A.out_r = ctx->d_rJ;
+    A.out_J = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
+    {
+        icg_prof_scope ps(ctx, "reproj_eval");
+        hipLaunchKernelGGL(k_reproj_eval, dim3((n + RPJ_TILE - 1) / RPJ_TILE), dim3(RPJ_TILE), 0, ctx->stream, A);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    ctx->rJ_valid     = 1;
+    ctx->rJ_has_jac   = want_jac;
+    ctx->last_n_poses = n_poses;
+    ctx->last_n_lm    = n_lm;
+    if (out_r) {
+        ICG_HIP(ctx, hipMemcpyAsync(icg_h<double>(ctx, o_r), A.out_r, rbytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (out_J && want_jac) {
+        ICG_HIP(ctx, hipMemcpyAsync(icg_h<double>(ctx, o_J), A.out_J, jbytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    icg_prof_collect(ctx);
+    if (out_r) memcpy(out_r, icg_h<double>(ctx, o_r), rbytes);
+    if (out_J && want_jac) memcpy(out_J, icg_h<double>(ctx, o_J), jbytes);
+    ctx->arena_off = 0;
+    return ICG_OK;
+}
+
+extern "C" int icg_reproj_eval_batch(icg_ctx *ctx, int n, const double *obs_soa, const int32_t *idx_i,
+                                     const int32_t *idx_j, const int32_t *idx_lm, int n_poses, const double *poses,
+                                     const double *ext, int n_lm, const double *invdepth, double td, int want_jac,
+                                     double huber_delta, double *out_r, double *out_J) {
+    int rc = icg_reproj_set_factors(ctx, n, obs_soa, idx_i, idx_j, idx_lm);
+    if (rc) return rc;
+    return icg_reproj_eval_resident(ctx, n_poses, poses, ext, n_lm, invdepth, td, want_jac, huber_delta, out_r, out_J);
+}

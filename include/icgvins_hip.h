@@ -1,0 +1,185 @@
+/*
+ * icgvins_hip.h — C ABI of the MI355X-native IC-GVINS hot path (libicgvins_hip.so).
+ *
+ * This is the drop-in boundary B3 of SURVEY.md §8(b): plain pointers and sizes, no C++/torch types, no exceptions.
+ * Every entry point names the reference interface it replaces (paths relative to /root/reference/ic_gvins/ic_gvins/).
+ *
+ * Conventions
+ *   - return value: 0 = ICG_OK, <0 = error code; icg_last_error(ctx) gives a message.
+ *   - an icg_ctx owns one HIP stream + all device buffers for one (GPU, image size); it is NOT thread-safe;
+ *     distinct contexts are independent.  Caller owns every host buffer passed in.
+ *   - every call is batched: "jobs" index frame *slots* (device-resident CLAHE image + pyramid), so one call can
+ *     serve many independent camera streams at once (the unit that fills an MI355X; SURVEY.md §0 "scale honesty").
+ *   - calls are synchronous unless stated: results are in the host buffers when the call returns.
+ *   - points are float pairs (x,y) == cv::Point2f; status bytes are 0/1 == the reference's vector<uint8_t>.
+ *   - there is NO CPU fallback: without a HIP device icg_ctx_create fails with ICG_ERR_NODEVICE.
+ */
+#ifndef ICGVINS_HIP_H
+#define ICGVINS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct icg_ctx icg_ctx;
+
+enum {
+    ICG_OK           = 0,
+    ICG_ERR_INVALID  = -1, /* bad argument */
+    ICG_ERR_HIP      = -2, /* HIP runtime error (see icg_last_error) */
+    ICG_ERR_NOMEM    = -3,
+    ICG_ERR_NODEVICE = -4, /* no usable gfx950 device: the product path refuses to run */
+    ICG_ERR_CAPACITY = -5  /* batch larger than the capacity given at icg_ctx_create */
+};
+
+/* Camera intrinsics/distortion, tracking/camera.h:88-93 (fx,fy,cx,cy,skew ; k1,k2,p1,p2,k3). */
+typedef struct icg_camera {
+    double fx, fy, cx, cy, skew;
+    double k1, k2, p1, p2, k3;
+} icg_camera;
+
+typedef struct icg_ctx_config {
+    int device;     /* HIP device ordinal */
+    int width;      /* image width  (camera_->width())  */
+    int height;     /* image height (camera_->height()) */
+    int n_slots;    /* frame slots kept resident (>= 2 per stream: frame_pre_ and frame_cur_, +1 per ref frame) */
+    int max_batch;  /* max frames per icg_frames_preprocess / icg_detect call */
+    int max_points; /* max points per point-batched call */
+    int max_factors;/* max reprojection factors per icg_reproj_eval_batch call (0 = back-end unused) */
+} icg_ctx_config;
+
+/* ---- context ----------------------------------------------------------------------------------------- */
+int icg_ctx_create(const icg_ctx_config *cfg, icg_ctx **out);
+void icg_ctx_destroy(icg_ctx *ctx);
+const char *icg_last_error(const icg_ctx *ctx);
+int icg_ctx_sync(icg_ctx *ctx);
+/* hipStream_t of the context (for callers that want to record their own HIP events on it). */
+void *icg_ctx_stream(icg_ctx *ctx);
+int icg_set_camera(icg_ctx *ctx, const icg_camera *cam);
+const char *icg_version(void);
+/* number of pyramid levels built for the context's image size (== maxLevel+1 of calcOpticalFlowPyrLK). */
+int icg_pyramid_levels(const icg_ctx *ctx);
+
+/* Per-kernel timing with HIP events recorded on the context stream around every launch of `kernel_name`
+ * (e.g. "lk_track_fb"); used by bench.py for the roofline figures.  enable=0 disables and clears. */
+int icg_prof_enable(icg_ctx *ctx, int enable);
+int icg_prof_get(icg_ctx *ctx, const char *kernel_name, int *launches, double *total_ms);
+/* names of profiled kernels, '\n' separated, into buf */
+int icg_prof_names(icg_ctx *ctx, char *buf, int buflen);
+
+/* Device scratch for callers that keep inputs resident in HBM (bench harness): plain hipMalloc/hipFree/hipMemcpy. */
+int icg_dev_alloc(icg_ctx *ctx, size_t bytes, void **dptr);
+int icg_dev_free(icg_ctx *ctx, void *dptr);
+int icg_dev_upload(icg_ctx *ctx, void *dptr, const void *host, size_t bytes);
+int icg_dev_download(icg_ctx *ctx, void *host, const void *dptr, size_t bytes);
+
+/* ---- F1: Tracking::preprocessing (tracking/tracking.cc:107-142) ----------------------------------------
+ * For each job k: BGR->gray if channels==3 (tracking.cc:112), CLAHE(3.0, 21x21) (tracking.cc:63,139), then the
+ * LK pyramid (the buildOpticalFlowPyramid every calcOpticalFlowPyrLK call redoes, tracking.cc:385-393) into slot
+ * slots[k].  images[k] points to host memory (src_on_device=0) or device memory (src_on_device=1).
+ * hist_mean (optional, n doubles) receives calculateHistigram() of the gray image (tracking.cc:88-105). */
+int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, const uint8_t *const *images, int stride,
+                          int channels, int src_on_device, double *hist_mean);
+/* copy pyramid level `level` of a slot back to the host (Frame::image() == level 0, after CLAHE). */
+int icg_frame_download(icg_ctx *ctx, int slot, int level, uint8_t *dst, int dst_stride);
+
+/* ---- F2: cv::calcOpticalFlowPyrLK as called at tracking.cc:385-393 / 487-496 ---------------------------
+ * win 21x21, maxLevel 3, (COUNT+EPS, 30, 0.01), OPTFLOW_USE_INITIAL_FLOW, minEigThreshold 1e-4.
+ * next_pts: initial flow in, result out.  status/err as OpenCV (err may be NULL). */
+int icg_lk_track(icg_ctx *ctx, int n, const int32_t *prev_slot, const int32_t *next_slot, const float *prev_pts,
+                 float *next_pts, uint8_t *status, float *err);
+
+/* ---- F2+F3(+F4): the fused forward/backward track of tracking.cc:380-403 and :482-506 --------------------
+ * forward LK prev->next from guess_pts, backward LK next->prev from prev_pts, then
+ * status = fwd && bwd && !isOnBorder(fwd) (tracking.cc:847-849) && ptsDistance(bwd, prev) < 0.5 (:841-845).
+ * out_undist (optional) = Camera::undistortPoints(out_pts) (camera.cc:72-74), needs icg_set_camera.
+ * keep_idx/n_keep (optional) = order-preserving compaction indices, i.e. what reduceVector (tracking.cc:831-839)
+ * keeps, computed on device. */
+int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, const int32_t *next_slot, const float *prev_pts,
+                    const float *guess_pts, float *out_pts, uint8_t *status, float *out_undist, int32_t *keep_idx,
+                    int32_t *n_keep);
+
+/* ---- F4: Camera point maps (tracking/camera.cc) -------------------------------------------------------- */
+int icg_undistort_points(icg_ctx *ctx, int n, float *pts);                 /* camera.cc:72-74  in place */
+int icg_distort_points(icg_ctx *ctx, int n, float *pts);                   /* camera.cc:76-89  in place */
+/* ---- F5: INS-aided predictions --------------------------------------------------------------------------
+ * map points: world2pixel(pos, pose_cur) then distortPoints (tracking.cc:367-378).  pose = R(9 row-major), t(3);
+ * pose_idx[k] selects the pose of point k (one pose per stream). */
+int icg_predict_mappoints(icg_ctx *ctx, int n, const double *pw, const int32_t *pose_idx, int n_poses,
+                          const double *poses12, float *pts_out);
+/* reference features: distortCameraPoint(R_cur^T R_pre * pixel2cam(undistort(p))) (tracking.cc:465-479).
+ * rot_idx[k] selects r_cur_pre (n_rots x 9 row-major, already R_cur^T*R_pre). */
+int icg_predict_rotation(icg_ctx *ctx, int n, const float *pts_in, const int32_t *rot_idx, int n_rots,
+                         const double *rots9, float *pts_out);
+
+/* ---- F6: cv::findFundamentalMat(FM_RANSAC, thresh, conf, mask) as used at tracking.cc:547-555 -----------
+ * Batched over independent point sets: set s owns points [offsets[s], offsets[s+1]).  Sets with fewer than 15
+ * points are left untouched (mask = 1), as the reference skips them.  mask: 0/1 per point. */
+int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, const float *pts1, const float *pts2,
+                  double thresh, double conf, uint8_t *mask);
+
+/* ---- F7: Tracking::featuresDetection (tracking.cc:576-688) ----------------------------------------------
+ * Gridded cv::goodFeaturesToTrack(quality 0.01, minDistance, mask) + cv::cornerSubPix((5,5),(-1,-1),(20,0.01))
+ * per block ROI, for n jobs at once.  Job k detects on slot slots[k]; its mask discs (cv::circle radius
+ * min_dist, tracking.cc:609-620) are centred on mask_pts[mask_off[k]..mask_off[k+1]); its per-block quotas
+ * (track_max_block_features_ - features_cnts[b], tracking.cc:629) are quota[k*n_blocks + b] (<=0: skip block).
+ * Output: out_pts holds up to max_per_job points per job in block order with block origin already added
+ * (tracking.cc:669-685); out_count[k] = points found; out_block (optional) = block id per point. */
+typedef struct icg_detect_grid {
+    int block_cols, block_rows; /* block_cols_, block_rows_  tracking.cc:66-67 */
+    int block_w, block_h;       /* block_indexs_[0]          tracking.cc:71-73 */
+    int min_dist;               /* track_min_pixel_distance_ tracking.cc:85    */
+    int max_per_block;          /* track_max_block_features_ tracking.cc:81    */
+} icg_detect_grid;
+int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_detect_grid *grid, const int32_t *mask_off,
+               const float *mask_pts, const int32_t *quota, int max_per_job, float *out_pts, int32_t *out_count,
+               int32_t *out_block);
+
+/* ---- F8: Tracking::triangulatePoint (tracking.cc:800-811), batched ---------------------------------------
+ * T0/T1: per-point indices into Tcw (n_T x 12, row-major 3x4 == pose2Tcw(pose).topRows<3>()); pc0/pc1: pixel2cam. */
+int icg_triangulate(icg_ctx *ctx, int n, const int32_t *T0_idx, const int32_t *T1_idx, int n_T, const double *Tcw12,
+                    const double *pc0, const double *pc1, double *pw);
+
+/* ---- R1: ReprojectionFactor::Evaluate (factors/reprojection_factor.h:55-147), batched ---------------------
+ * obs_soa: 15 x n doubles, component-major: pts0[3], pts1[3], vel0[3], vel1[3], td0, td1, std (ctor :42-53).
+ * poses: K x 7 [px,py,pz,qx,qy,qz,qw] (parameters[0], parameters[1]); ext: 7 (parameters[2]);
+ * invdepth: L (parameters[3]); td (parameters[4]).
+ * out_r: n x 2.  out_J (want_jac): n x 46 = J_pose_i[2x7], J_pose_j[2x7], J_ext[2x7] row-major (7th col 0),
+ * J_invdepth[2], J_td[2] — exactly the blocks Ceres hands to Evaluate.
+ * huber_delta > 0 additionally applies ResidualBlockInfo's robust correction (factors/residual_block_info.h:59-87),
+ * i.e. R2 as used by marginalization; 0 = plain Evaluate. */
+int icg_reproj_eval_batch(icg_ctx *ctx, int n, const double *obs_soa, const int32_t *idx_i, const int32_t *idx_j,
+                          const int32_t *idx_lm, int n_poses, const double *poses, const double *ext, int n_lm,
+                          const double *invdepth, double td, int want_jac, double huber_delta, double *out_r,
+                          double *out_J);
+/* Same with the static part (obs, indices) already resident: upload once per Ceres problem, evaluate many times. */
+int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa, const int32_t *idx_i, const int32_t *idx_j,
+                           const int32_t *idx_lm);
+int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm,
+                             const double *invdepth, double td, int want_jac, double huber_delta, double *out_r,
+                             double *out_J);
+
+/* ---- M2: MarginalizationInfo::constructEquation (factors/marginalization_info.h:195-230) for the reprojection
+ * factors of the last icg_reproj_eval_* call (Jacobians still resident): accumulates H0 += J^T J, b0 -= J^T e into
+ * a dense (local_size x local_size) system on device and adds it to the host arrays H0/b0.
+ * col_pose[k] (n_poses), col_ext, col_lm[l] (n_lm), col_td: local column index of each parameter block, -1 = constant. */
+int icg_reproj_accumulate_normal(icg_ctx *ctx, int local_size, const int32_t *col_pose, int32_t col_ext,
+                                 const int32_t *col_lm, int32_t col_td, double *H0, double *b0);
+
+/* ---- P1: preintegration inner loop (preintegration/preintegration_base.cc:39-70, preintegration_earth.cc:205-303,
+ * preintegration_normal.cc:183-232), batched over independent intervals.
+ * imu: total x 8 doubles (time, dt, dtheta[3], dvel[3]); interval s owns samples [offsets[s], offsets[s+1]) with
+ * sample 0 = imu0.  state0: n x 16 (p3, q4 xyzw, v3, bg3, ba3).  params: 9 doubles
+ * (gyr_arw, acc_vrw, gyr_bias_std, acc_bias_std, corr_time, gravity, iewn[3]).  variant: 0 Normal, 1 Earth.
+ * outputs per interval: cur_state 16, delta_state 16, jac 225, cov 225, delta_time 1. */
+int icg_preint_batch(icg_ctx *ctx, int variant, int n_intervals, const int32_t *offsets, const double *imu,
+                     const double *state0, const double *params, double *cur_state, double *delta_state, double *jac,
+                     double *cov, double *delta_time);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICGVINS_HIP_H */

@@ -1,0 +1,152 @@
+"""ctypes wrappers around oracle/liboracle.so (TEST INFRASTRUCTURE ONLY: tests/, smoke(), bench cpu_baseline)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.orc_histogram_mean.restype = C.c_double
+
+    # ---- factors
+    def reproj_eval(self, obs_soa, idx_i, idx_j, idx_lm, poses, ext, invdepth, td, want_jac=True, huber=0.0):
+        obs_soa = _f64(obs_soa)
+        n = obs_soa.shape[1]
+        r = np.zeros((n, 2))
+        J = np.zeros((n, 46))
+        self.lib.orc_reproj_eval_batch(n, _p(obs_soa), _p(_i32(idx_i)), _p(_i32(idx_j)), _p(_i32(idx_lm)), _p(_f64(poses)),
+                                       _p(_f64(ext)), _p(_f64(invdepth)), C.c_double(td), 1 if want_jac else 0, _p(r), _p(J))
+        if huber > 0:
+            self.lib.orc_huber_correct_2x46(n, C.c_double(huber), _p(r), _p(J) if want_jac else None)
+        return r, (J if want_jac else None)
+
+    def reproj_eval_one(self, obs15, pose_i, pose_j, ext, invdepth, td, want_jac=True):
+        r = np.zeros(2)
+        J = np.zeros(46)
+        self.lib.orc_reproj_eval_one(_p(_f64(obs15)), _p(_f64(pose_i)), _p(_f64(pose_j)), _p(_f64(ext)), C.c_double(invdepth),
+                                     C.c_double(td), 1 if want_jac else 0, _p(r), _p(J))
+        return r, J
+
+    # ---- image
+    def bgr2gray(self, bgr):
+        bgr = _u8(bgr)
+        h, w, _ = bgr.shape
+        out = np.zeros((h, w), np.uint8)
+        self.lib.orc_bgr2gray(_p(bgr), w, h, w * 3, _p(out), w)
+        return out
+
+    def histogram_mean(self, img):
+        img = _u8(img)
+        h, w = img.shape
+        return self.lib.orc_histogram_mean(_p(img), w, h, w)
+
+    def clahe(self, img, clip=3.0, tiles=21, want_lut=False):
+        img = _u8(img)
+        h, w = img.shape
+        out = np.zeros_like(img)
+        lut = np.zeros((tiles * tiles, 256), np.uint8)
+        self.lib.orc_clahe(_p(img), w, h, w, C.c_double(clip), tiles, _p(out), w, _p(lut))
+        return (out, lut) if want_lut else out
+
+    def pyrdown(self, img):
+        img = _u8(img)
+        h, w = img.shape
+        out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        self.lib.orc_pyrdown(_p(img), w, h, w, _p(out), out.shape[1])
+        return out
+
+    def scharr(self, img):
+        img = _u8(img)
+        h, w = img.shape
+        out = np.zeros((h, w, 2), np.int16)
+        self.lib.orc_scharr(_p(img), w, h, w, _p(out))
+        return out
+
+    # ---- LK
+    def lk_track(self, prev, nxt, prev_pts, guess):
+        prev, nxt = _u8(prev), _u8(nxt)
+        h, w = prev.shape
+        prev_pts = _f32(prev_pts).reshape(-1, 2)
+        n = prev_pts.shape[0]
+        out = _f32(guess).reshape(-1, 2).copy()
+        st = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        self.lib.orc_lk_track(_p(prev), _p(nxt), w, h, w, n, _p(prev_pts), _p(out), _p(st), _p(err))
+        return out, st, err
+
+    def lk_track_fb(self, prev, nxt, prev_pts, guess):
+        prev, nxt = _u8(prev), _u8(nxt)
+        h, w = prev.shape
+        prev_pts = _f32(prev_pts).reshape(-1, 2)
+        guess = _f32(guess).reshape(-1, 2)
+        n = prev_pts.shape[0]
+        out = np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        self.lib.orc_lk_track_fb(_p(prev), _p(nxt), w, h, w, n, _p(prev_pts), _p(guess), _p(out), _p(st))
+        return out, st
+
+    # ---- camera
+    def undistort(self, cam, pts):
+        p = _f32(pts).reshape(-1, 2).copy()
+        self.lib.orc_undistort_points(_p(_f64(cam)), p.shape[0], _p(p))
+        return p
+
+    def distort(self, cam, pts):
+        p = _f32(pts).reshape(-1, 2).copy()
+        self.lib.orc_distort_points(_p(_f64(cam)), p.shape[0], _p(p))
+        return p
+
+    def world2pixel(self, cam, pose12, pw):
+        pw = _f64(pw).reshape(-1, 3)
+        out = np.zeros((pw.shape[0], 2), np.float32)
+        self.lib.orc_world2pixel(_p(_f64(cam)), _p(_f64(pose12)), pw.shape[0], _p(pw), _p(out))
+        return out
+
+    def pixel2cam(self, cam, pts):
+        pts = _f32(pts).reshape(-1, 2)
+        out = np.zeros((pts.shape[0], 3))
+        self.lib.orc_pixel2cam(_p(_f64(cam)), pts.shape[0], _p(pts), _p(out))
+        return out
+
+    def predict_rotation(self, cam, R_cur, R_pre, pts):
+        pts = _f32(pts).reshape(-1, 2)
+        out = np.zeros_like(pts)
+        self.lib.orc_predict_rotation(_p(_f64(cam)), _p(_f64(R_cur)), _p(_f64(R_pre)), pts.shape[0], _p(pts), _p(out))
+        return out
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def load():
+    if not os.path.exists(ORACLE_SO):
+        build()
+    return Oracle(C.CDLL(ORACLE_SO))
