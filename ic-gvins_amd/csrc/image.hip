@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint8_t *raw, int strid
 }
 
 #define CLAHE_CHUNK 256 // pixels per workgroup row segment (64 lanes x uchar4)
-#define CLAHE_MAXCOLS 12
+#define CLAHE_MAXCOLS 24
 
 __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *raw, int stride, size_t batch, clahe_geom g,
                                                      const uint8_t *lut, uint8_t *frames, size_t slot_bytes,
