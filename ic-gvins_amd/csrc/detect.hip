@@ -1,0 +1,467 @@
+// F7: Tracking::featuresDetection on device — mask discs, gridded Shi-Tomasi (cv::goodFeaturesToTrack) and
+// cv::cornerSubPix, batched over frames of many streams.
+//
+// Reference: tracking/tracking.cc:576-688 (mask :609-620, ROI per block :632-645, GFTT :647, subpix :651).
+// Arithmetic definition: SURVEY.md Appendix B.7/B.8 with the formulation pinned in oracle/orc_detect.cc:
+// exact-integer Sobel x (1/3060) in float, covariance products in float, 3x3 box sums accumulated in double in raster
+// order (reflect-101 at the ROI edge), min-eigenvalue in float; threshold 0.01*max over unmasked ROI pixels; 3x3
+// non-maximum test inside the ROI; candidates ordered by (response desc, raster address desc); greedy minimum-distance
+// selection; sub-pixel refinement with sequential double accumulation (bit-identical to the CPU restatement).
+//
+// Kernels (HBM/L2-bound stencils, no MFMA shape):
+//   k_mask_discs  one workgroup per existing feature: midpoint-circle span table -> zero spans in the u8 mask
+//   k_min_eig     32x8 response tile per workgroup; (34x10) covariance halo in LDS; per-ROI masked maximum by an
+//                 order-preserving uint atomicMax
+//   k_candidates  threshold + 3x3 NMS + mask -> (key = response bits << 32 | raster index) appended per ROI
+//   k_select      one workgroup per ROI: repeated block-wide arg-max over live candidates + min-distance kill
+//                 (equivalent to sort + greedy grid test, needs no sort and no capacity cap)
+//   k_subpix      one wavefront per corner: 13x13 bilinear patch and the 121 gradient terms in parallel through LDS,
+//                 the five 121-term sums sequentially on one lane in raster order (keeps IEEE order == CPU order)
+#include <cfloat>
+
+#include "icg_internal.h"
+
+struct det_roi {
+    int job, block, rx, ry, rw, rh, quota, cand_base; // cand_base: offset into the job's candidate plane
+};
+
+__device__ __forceinline__ unsigned int f32_order_key(float f) {
+    unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_order_key(unsigned int k) {
+    unsigned int b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mask_discs(int n_pts, const float2 *pts, const int32_t *pt_job, int radius,
+                                                    const int32_t *halfw /*radius+1*/, uint8_t *mask, int pitch, int w,
+                                                    int h, size_t plane) {
+    const int i = blockIdx.x;
+    if (i >= n_pts) return;
+    const float2 p = pts[i];
+    const int cx = (int) rintf(p.x), cy = (int) rintf(p.y);
+    uint8_t *m   = mask + (size_t) pt_job[i] * plane;
+    const int side = 2 * radius + 1;
+    for (int t = threadIdx.x; t < side * side; t += 256) {
+        int r = t / side, c = t - r * side;
+        int dy = r - radius, dx = c - radius;
+        int hw = halfw[dy < 0 ? -dy : dy];
+        int ax = dx < 0 ? -dx : dx;
+        int x = cx + dx, y = cy + dy;
+        if (ax <= hw && x >= 0 && x < w && y >= 0 && y < h) m[(size_t) y * pitch + x] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+#define EIG_TW 32
+#define EIG_TH 8
+
+__global__ __launch_bounds__(256) void k_min_eig(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
+                                                 const int32_t *slots, int pitch, int w, int h, const uint8_t *mask,
+                                                 size_t mask_plane, float *eig, size_t eig_plane,
+                                                 unsigned int *roi_max) {
+    __shared__ float cxx[EIG_TH + 2][EIG_TW + 2], cxy[EIG_TH + 2][EIG_TW + 2], cyy[EIG_TH + 2][EIG_TW + 2];
+    __shared__ unsigned int wmax[4];
+    const det_roi R = rois[blockIdx.z];
+    const int tx0 = blockIdx.x * EIG_TW, ty0 = blockIdx.y * EIG_TH;
+    if (tx0 >= R.rw || ty0 >= R.rh) return;
+    const uint8_t *img = frames + (size_t) slots[R.job] * slot_bytes;
+    const float s      = (float) (1.0 / 3060.0);
+    const int t        = threadIdx.x;
+    for (int i = t; i < (EIG_TH + 2) * (EIG_TW + 2); i += 256) {
+        int r = i / (EIG_TW + 2), c = i - r * (EIG_TW + 2);
+        // ROI coordinate with reflect-101 at the ROI edge (cov is a fresh ROI-sized Mat in OpenCV)
+        int x = icg_reflect101(tx0 - 1 + c, R.rw), y = icg_reflect101(ty0 - 1 + r, R.rh);
+        int X = R.rx + x, Y = R.ry + y;
+        // Sobel on REAL image pixels (peeks outside the ROI); reflect-101 only at true image borders
+        int xm = icg_reflect101(X - 1, w), xp = icg_reflect101(X + 1, w);
+        int ym = icg_reflect101(Y - 1, h), yp = icg_reflect101(Y + 1, h);
+        const uint8_t *r0 = img + (size_t) ym * pitch, *r1 = img + (size_t) Y * pitch, *r2 = img + (size_t) yp * pitch;
+        int p00 = r0[xm], p01 = r0[X], p02 = r0[xp];
+        int p10 = r1[xm], p12 = r1[xp];
+        int p20 = r2[xm], p21 = r2[X], p22 = r2[xp];
+        int gx = (p02 - p00) + 2 * (p12 - p10) + (p22 - p20);
+        int gy = (p20 - p00) + 2 * (p21 - p01) + (p22 - p02);
+        float dx = (float) gx * s, dy = (float) gy * s;
+        cxx[r][c] = dx * dx;
+        cxy[r][c] = dx * dy;
+        cyy[r][c] = dy * dy;
+    }
+    __syncthreads();
+    const int lx = t & (EIG_TW - 1), ly = t / EIG_TW;
+    const int x = tx0 + lx, y = ty0 + ly;
+    unsigned int key = 0;
+    if (x < R.rw && y < R.rh) {
+        double sa = 0, sb = 0, sc = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                sa += cxx[ly + j][lx + i];
+                sb += cxy[ly + j][lx + i];
+                sc += cyy[ly + j][lx + i];
+            }
+        float a = (float) sa * 0.5f, b = (float) sb, c = (float) sc * 0.5f;
+        float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+        const int X = R.rx + x, Y = R.ry + y;
+        eig[(size_t) R.job * eig_plane + (size_t) Y * w + X] = e;
+        if (mask[(size_t) R.job * mask_plane + (size_t) Y * pitch + X]) key = f32_order_key(e);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        unsigned int o = __shfl_xor(key, m, 64);
+        key            = o > key ? o : key;
+    }
+    if ((t & 63) == 0) wmax[t >> 6] = key;
+    __syncthreads();
+    if (t == 0) {
+        unsigned int k = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        if (k) atomicMax(&roi_max[blockIdx.z], k);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_candidates(const det_roi *rois, int pitch, int w, const uint8_t *mask,
+                                                    size_t mask_plane, const float *eig, size_t eig_plane,
+                                                    const unsigned int *roi_max, unsigned long long *cand,
+                                                    size_t cand_plane, int32_t *cand_cnt) {
+    const det_roi R = rois[blockIdx.z];
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < 1 || x >= R.rw - 1 || y < 1 || y >= R.rh - 1) return;
+    const unsigned int mk = roi_max[blockIdx.z];
+    const double maxVal   = mk ? (double) f32_from_order_key(mk) : 0.0;
+    const float thresh    = (float) (maxVal * 0.01);
+    const float *e        = eig + (size_t) R.job * eig_plane + (size_t) (R.ry + y) * w + (R.rx + x);
+    float v               = e[0];
+    v                     = v > thresh ? v : 0.f;
+    if (v == 0.f) return;
+    float mx = v;
+#pragma unroll
+    for (int j = -1; j <= 1; j++)
+#pragma unroll
+        for (int i = -1; i <= 1; i++) {
+            float n = e[j * w + i];
+            n       = n > thresh ? n : 0.f;
+            mx      = n > mx ? n : mx;
+        }
+    if (v != mx) return;
+    if (!mask[(size_t) R.job * mask_plane + (size_t) (R.ry + y) * pitch + (R.rx + x)]) return;
+    const int slot = atomicAdd(&cand_cnt[blockIdx.z], 1);
+    cand[(size_t) R.job * cand_plane + R.cand_base + slot] =
+        ((unsigned long long) f32_order_key(v) << 32) | (unsigned int) (y * R.rw + x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+#define DET_MAX_PER_BLOCK 64
+
+__global__ __launch_bounds__(256) void k_select(const det_roi *rois, unsigned long long *cand, size_t cand_plane,
+                                                const int32_t *cand_cnt, int min_dist, float2 *corners /*roi x max_pb*/,
+                                                int32_t *corner_cnt, int max_pb) {
+    __shared__ unsigned long long wbest[4];
+    __shared__ unsigned long long best;
+    const det_roi R = rois[blockIdx.x];
+    unsigned long long *C = cand + (size_t) R.job * cand_plane + R.cand_base;
+    const int n = cand_cnt[blockIdx.x];
+    const int t = threadIdx.x;
+    const double md2 = (double) min_dist * (double) min_dist;
+    int quota = R.quota < max_pb ? R.quota : max_pb;
+    int acc   = 0;
+    while (acc < quota) {
+        unsigned long long k = 0;
+        for (int i = t; i < n; i += 256) {
+            unsigned long long c = C[i];
+            k                    = c > k ? c : k;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            unsigned long long o = __shfl_xor(k, m, 64);
+            k                    = o > k ? o : k;
+        }
+        if ((t & 63) == 0) wbest[t >> 6] = k;
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long b = wbest[0];
+            for (int i = 1; i < 4; i++) b = wbest[i] > b ? wbest[i] : b;
+            best = b;
+        }
+        __syncthreads();
+        const unsigned long long b = best;
+        if (b == 0) break; // no live candidate left
+        const int idx = (int) (b & 0xffffffffu);
+        const int by = idx / R.rw, bx = idx - by * R.rw;
+        if (t == 0) corners[(size_t) blockIdx.x * max_pb + acc] = make_float2((float) bx, (float) by);
+        acc++;
+        if (min_dist >= 1) {
+            for (int i = t; i < n; i += 256) {
+                unsigned long long c = C[i];
+                if (!c) continue;
+                int ci = (int) (c & 0xffffffffu);
+                int cy = ci / R.rw, cx = ci - cy * R.rw;
+                float dx = (float) (cx - bx), dy = (float) (cy - by);
+                if (c == b || (double) (dx * dx + dy * dy) < md2) C[i] = 0;
+            }
+        } else {
+            for (int i = t; i < n; i += 256)
+                if (C[i] == b) C[i] = 0;
+        }
+        __syncthreads();
+    }
+    if (t == 0) corner_cnt[blockIdx.x] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct subpix_mask_t {
+    float m[121];
+};
+
+__global__ __launch_bounds__(64) void k_subpix(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
+                                               const int32_t *slots, int pitch, float2 *corners,
+                                               const int32_t *corner_cnt, int max_pb, subpix_mask_t M) {
+    __shared__ float patch[13][13];
+    __shared__ double terms[121][5];
+    __shared__ float cur[2];
+    __shared__ int stop;
+    const int roi = blockIdx.x / max_pb, ci = blockIdx.x - roi * max_pb;
+    if (ci >= corner_cnt[roi]) return;
+    const det_roi R    = rois[roi];
+    const uint8_t *img = frames + (size_t) slots[R.job] * slot_bytes;
+    const int lane     = threadIdx.x;
+    const float2 cT    = corners[(size_t) roi * max_pb + ci];
+    float cIx = cT.x, cIy = cT.y;
+    int iter = 0;
+    while (true) {
+        const float ox = cIx - 6.f, oy = cIy - 6.f;
+        const int iox = (int) floorf(ox), ioy = (int) floorf(oy);
+        const float fa = ox - iox, fb = oy - ioy;
+        const float w00 = (1.f - fa) * (1.f - fb), w01 = fa * (1.f - fb), w10 = (1.f - fa) * fb, w11 = fa * fb;
+        for (int i = lane; i < 169; i += 64) {
+            int r = i / 13, c = i - r * 13;
+            int x0 = min(max(iox + c, 0), R.rw - 1), x1 = min(max(iox + c + 1, 0), R.rw - 1);
+            int y0 = min(max(ioy + r, 0), R.rh - 1), y1 = min(max(ioy + r + 1, 0), R.rh - 1);
+            const uint8_t *p0 = img + (size_t) (R.ry + y0) * pitch + R.rx;
+            const uint8_t *p1 = img + (size_t) (R.ry + y1) * pitch + R.rx;
+            float s00 = p0[x0], s01 = p0[x1], s10 = p1[x0], s11 = p1[x1];
+            patch[r][c] = s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11;
+        }
+        __syncthreads();
+        for (int i = lane; i < 121; i += 64) {
+            int r = i / 11, c = i - r * 11;
+            double m   = M.m[i];
+            double tgx = patch[r + 1][c + 2] - patch[r + 1][c];
+            double tgy = patch[r + 2][c + 1] - patch[r][c + 1];
+            double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+            double px = c - 5, py = r - 5;
+            terms[i][0] = gxx;
+            terms[i][1] = gxy;
+            terms[i][2] = gyy;
+            terms[i][3] = gxx * px + gxy * py;
+            terms[i][4] = gxy * px + gyy * py;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+            for (int i = 0; i < 121; i++) {
+                a += terms[i][0];
+                b += terms[i][1];
+                c += terms[i][2];
+                bb1 += terms[i][3];
+                bb2 += terms[i][4];
+            }
+            int st     = 0;
+            double det = a * c - b * b;
+            if (fabs(det) <= DBL_EPSILON * DBL_EPSILON) {
+                st = 1; // break before updating
+            } else {
+                double scale = 1.0 / det;
+                float c2x    = (float) (cIx + c * scale * bb1 - b * scale * bb2);
+                float c2y    = (float) (cIy - b * scale * bb1 + a * scale * bb2);
+                double err   = (double) ((c2x - cIx) * (c2x - cIx) + (c2y - cIy) * (c2y - cIy));
+                cur[0]       = c2x;
+                cur[1]       = c2y;
+                if (c2x < 0 || c2x >= R.rw || c2y < 0 || c2y >= R.rh)
+                    st = 2;
+                else if (!(iter + 1 < 20 && err > 0.01 * 0.01))
+                    st = 2;
+            }
+            stop = st;
+        }
+        __syncthreads();
+        const int st = stop;
+        if (st != 1) {
+            cIx = cur[0];
+            cIy = cur[1];
+        }
+        ++iter;
+        __syncthreads();
+        if (st) break;
+    }
+    if (lane == 0) {
+        if (fabsf(cIx - cT.x) > 5 || fabsf(cIy - cT.y) > 5) {
+            cIx = cT.x;
+            cIy = cT.y;
+        }
+        corners[(size_t) roi * max_pb + ci] = make_float2(cIx, cIy);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+static void circle_halfwidths(int radius, std::vector<int32_t> &hw) {
+    // spans of OpenCV drawing.cpp Circle() (midpoint algorithm) for a filled circle, per |row offset|
+    hw.assign((size_t) radius + 1, -1);
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        if (dx > hw[dy]) hw[dy] = dx;
+        if (dy > hw[dx]) hw[dx] = dy;
+        dy++;
+        err += plus;
+        plus += 2;
+        int m = (err <= 0) - 1;
+        err -= minus & m;
+        dx += m;
+        minus -= m & 2;
+    }
+}
+
+static int ensure_detect_ws(icg_ctx *ctx) {
+    if (ctx->d_eig) return 0;
+    const size_t w = ctx->cfg.width, h = ctx->cfg.height, nb = ctx->cfg.max_batch;
+    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_eig, sizeof(float) * w * h * nb));
+    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_mask, (size_t) ctx->lv[0].pitch * h * nb));
+    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_cand, sizeof(unsigned long long) * w * h * nb));
+    return 0;
+}
+
+extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_detect_grid *grid, const int32_t *mask_off,
+                          const float *mask_pts, const int32_t *quota, int max_per_job, float *out_pts,
+                          int32_t *out_count, int32_t *out_block) {
+    if (!ctx || n < 0) return ICG_ERR_INVALID;
+    if (n == 0) return ICG_OK;
+    if (!slots || !grid || !mask_off || !quota || !out_pts || !out_count || max_per_job <= 0) return ICG_ERR_INVALID;
+    if (n > ctx->cfg.max_batch) return icg_fail(ctx, ICG_ERR_CAPACITY, "detect batch %d > max_batch %d", n, ctx->cfg.max_batch);
+    const int w = ctx->cfg.width, h = ctx->cfg.height, pitch = ctx->lv[0].pitch;
+    const int nblk = grid->block_cols * grid->block_rows;
+    if (nblk <= 0 || grid->block_w <= 6 || grid->block_h <= 6 || grid->block_cols * grid->block_w > w ||
+        grid->block_rows * grid->block_h > h || grid->min_dist < 0 || grid->max_per_block <= 0 ||
+        grid->max_per_block > DET_MAX_PER_BLOCK)
+        return icg_fail(ctx, ICG_ERR_INVALID, "bad detection grid");
+    for (int k = 0; k < n; k++)
+        if (slots[k] < 0 || slots[k] >= ctx->cfg.n_slots) return icg_fail(ctx, ICG_ERR_INVALID, "bad slot");
+    const int n_mask = mask_off[n];
+    if (n_mask < 0 || (n_mask > 0 && !mask_pts)) return ICG_ERR_INVALID;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = ensure_detect_ws(ctx);
+    if (rc) return rc;
+
+    // ROI list (tracking.cc:629-645)
+    std::vector<det_roi> rois;
+    for (int b = 0; b < n; b++)
+        for (int k = 0; k < nblk; k++) {
+            int q = quota[(size_t) b * nblk + k];
+            if (q <= 0) continue;
+            if (q > grid->max_per_block) q = grid->max_per_block;
+            int cols = k % grid->block_cols, rows = k / grid->block_cols;
+            det_roi R;
+            R.job   = b;
+            R.block = k;
+            R.rx    = cols * grid->block_w;
+            R.ry    = rows * grid->block_h;
+            R.rw    = grid->block_w;
+            R.rh    = grid->block_h;
+            if (k != nblk - 1) {
+                R.rw -= 5;
+                R.rh -= 5;
+            }
+            R.quota     = q;
+            R.cand_base = k * grid->block_w * grid->block_h;
+            rois.push_back(R);
+        }
+    const int n_roi = (int) rois.size();
+    for (int b = 0; b < n; b++) out_count[b] = 0;
+    if (n_roi == 0) return ICG_OK;
+    const int max_pb = grid->max_per_block;
+
+    std::vector<int32_t> hw;
+    circle_halfwidths(grid->min_dist, hw);
+    std::vector<int32_t> pt_job((size_t) n_mask);
+    for (int b = 0; b < n; b++)
+        for (int i = mask_off[b]; i < mask_off[b + 1]; i++) pt_job[i] = b;
+
+    icg_call c(ctx);
+    size_t need = sizeof(det_roi) * n_roi + sizeof(int32_t) * (n + hw.size() + n_mask) + sizeof(float) * 2 * n_mask +
+                  (sizeof(float2) * max_pb + 16) * (size_t) n_roi + 8192;
+    if ((rc = c.reserve(need))) return rc;
+    const det_roi *d_rois  = c.in(rois.data(), (size_t) n_roi);
+    const int32_t *d_slots = c.in(slots, (size_t) n);
+    const int32_t *d_hw    = c.in(hw.data(), hw.size());
+    const float2 *d_mpts   = (const float2 *) c.in(mask_pts, 2 * (size_t) n_mask);
+    const int32_t *d_ptjob = c.in(pt_job.data(), (size_t) n_mask);
+    if ((rc = c.seal())) return rc;
+    std::vector<float> h_corners((size_t) n_roi * max_pb * 2);
+    std::vector<int32_t> h_cnt((size_t) n_roi);
+    float2 *d_corners    = (float2 *) c.out(h_corners.data(), (size_t) n_roi * max_pb * 2);
+    int32_t *d_cnt       = c.out(h_cnt.data(), (size_t) n_roi);
+    unsigned int *d_rmax = c.out((unsigned int *) nullptr, (size_t) n_roi);
+    int32_t *d_ccnt      = c.out((int32_t *) nullptr, (size_t) n_roi);
+
+    const size_t mask_plane = (size_t) pitch * h, eig_plane = (size_t) w * h, cand_plane = (size_t) w * h;
+    ICG_HIP(ctx, hipMemsetAsync(ctx->d_mask, 255, mask_plane * n, ctx->stream));
+    ICG_HIP(ctx, hipMemsetAsync(d_rmax, 0, sizeof(unsigned int) * n_roi, ctx->stream));
+    ICG_HIP(ctx, hipMemsetAsync(d_ccnt, 0, sizeof(int32_t) * n_roi, ctx->stream));
+    if (n_mask > 0) {
+        icg_prof_scope ps(ctx, "detect_mask");
+        hipLaunchKernelGGL(k_mask_discs, dim3(n_mask), dim3(256), 0, ctx->stream, n_mask, d_mpts, d_ptjob, grid->min_dist,
+                           d_hw, ctx->d_mask, pitch, w, h, mask_plane);
+    }
+    {
+        icg_prof_scope ps(ctx, "detect_min_eig");
+        hipLaunchKernelGGL(k_min_eig, dim3((grid->block_w + EIG_TW - 1) / EIG_TW, (grid->block_h + EIG_TH - 1) / EIG_TH, n_roi),
+                           dim3(256), 0, ctx->stream, d_rois, ctx->d_frames, ctx->slot_bytes, d_slots, pitch, w, h,
+                           ctx->d_mask, mask_plane, ctx->d_eig, eig_plane, d_rmax);
+    }
+    {
+        icg_prof_scope ps(ctx, "detect_candidates");
+        hipLaunchKernelGGL(k_candidates, dim3((grid->block_w + 63) / 64, (grid->block_h + 3) / 4, n_roi), dim3(256), 0,
+                           ctx->stream, d_rois, pitch, w, ctx->d_mask, mask_plane, ctx->d_eig, eig_plane, d_rmax, ctx->d_cand,
+                           cand_plane, d_ccnt);
+    }
+    {
+        icg_prof_scope ps(ctx, "detect_select");
+        hipLaunchKernelGGL(k_select, dim3(n_roi), dim3(256), 0, ctx->stream, d_rois, ctx->d_cand, cand_plane, d_ccnt,
+                           grid->min_dist, d_corners, d_cnt, max_pb);
+    }
+    {
+        subpix_mask_t M;
+        for (int i = 0; i < 11; i++) {
+            float y  = (float) (i - 5) / 5;
+            float vy = std::exp(-y * y);
+            for (int j = 0; j < 11; j++) {
+                float x         = (float) (j - 5) / 5;
+                M.m[i * 11 + j] = (float) (vy * std::exp(-x * x));
+            }
+        }
+        icg_prof_scope ps(ctx, "detect_subpix");
+        hipLaunchKernelGGL(k_subpix, dim3(n_roi * max_pb), dim3(64), 0, ctx->stream, d_rois, ctx->d_frames, ctx->slot_bytes,
+                           d_slots, pitch, d_corners, d_cnt, max_pb, M);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    if ((rc = c.finish())) return rc;
+
+    // block-order assembly with the block origin added (tracking.cc:669-685)
+    for (int r = 0; r < n_roi; r++) {
+        const det_roi &R = rois[r];
+        for (int i = 0; i < h_cnt[r]; i++) {
+            int &cnt = out_count[R.job];
+            if (cnt >= max_per_job) break;
+            float x = (float) R.rx + h_corners[((size_t) r * max_pb + i) * 2];
+            float y = (float) R.ry + h_corners[((size_t) r * max_pb + i) * 2 + 1];
+            out_pts[((size_t) R.job * max_per_job + cnt) * 2]     = x;
+            out_pts[((size_t) R.job * max_per_job + cnt) * 2 + 1] = y;
+            if (out_block) out_block[(size_t) R.job * max_per_job + cnt] = R.block;
+            cnt++;
+        }
+    }
+    return ICG_OK;
+}

@@ -1,0 +1,508 @@
+// F6: cv::findFundamentalMat(FM_RANSAC, 1.5 px, 0.99) outlier cull (tracking/tracking.cc:547-555) and
+// F8: Tracking::triangulatePoint (tracking/tracking.cc:800-811), batched.
+//
+// Algorithm definition: SURVEY.md Appendix B.9/B.10 with the formulation pinned in oracle/orc_ransac.cc
+// (one-sided Jacobi null space, transcendental-free cubic, double scoring with float compare, sequential
+// best/niters replay).  Mapping:
+//   * the hypothesis index stream depends only on cv::RNG's state, not on scores, so it is generated up front on the
+//     host (same LCG as cv::RNG((uint64)-1)) for a chunk of hypotheses;
+//   * k_seven_point: ONE LANE per hypothesis; the 7x9 system and the 9x9 rotation accumulator live in LDS laid out
+//     [element][lane] (conflict-free), only + - * / sqrt are used so results match the CPU restatement bit-for-bit;
+//   * k_fm_score: ONE WAVEFRONT per (hypothesis, model): 64 points per step, symmetric epipolar distance in double,
+//     inlier bits by wave ballot, count by popcount;
+//   * the host replays the `best / niters` recurrence over the score array in hypothesis order, which makes the result
+//     identical to the sequential algorithm; further chunks are generated only if niters demands them.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+#include "icg_internal.h"
+
+#define SP_LANES 64
+#define SP_G(k, j) sG[((k) * 9 + (j)) * SP_LANES + lane]
+#define SP_V(k, j) sV[((k) * 9 + (j)) * SP_LANES + lane]
+
+struct fm_set {
+    int pt_begin, n_pts; // range in the concatenated point arrays
+    int hyp_begin;       // first hypothesis slot of this set in this launch
+    int n_hyp;
+    int word_begin; // first u64 word of this set's inlier bit masks (per model: words_per_model)
+    int words_per_model;
+};
+
+__device__ int dev_solve_cubic_real(const double c[4], double roots[3]) {
+    double a = c[0], b = c[1], cc = c[2], d = c[3];
+    double scale = fmax(fmax(fabs(a), fabs(b)), fmax(fabs(cc), fabs(d)));
+    if (scale == 0) return 0;
+    int n = 0;
+    if (fabs(a) <= 1e-14 * scale) {
+        if (fabs(b) <= 1e-14 * scale) {
+            if (fabs(cc) <= 1e-14 * scale) return 0;
+            roots[0] = -d / cc;
+            return 1;
+        }
+        double disc = cc * cc - 4 * b * d;
+        if (disc < 0) return 0;
+        double sq = sqrt(disc);
+        double q  = -0.5 * (cc + (cc >= 0 ? sq : -sq));
+        double r1 = q / b, r2 = (q != 0) ? d / q : r1;
+        roots[0] = fmin(r1, r2);
+        roots[1] = fmax(r1, r2);
+        return 2;
+    }
+    const double p = b / a, q = cc / a, r = d / a;
+    const double B = 1.0 + fmax(fabs(p), fmax(fabs(q), fabs(r)));
+    double lo = -B, hi = B;
+    for (int it = 0; it < 200; it++) {
+        double mid = 0.5 * (lo + hi);
+        if (mid == lo || mid == hi) break;
+        double fm = ((mid + p) * mid + q) * mid + r;
+        if (fm < 0)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    double x1 = 0.5 * (lo + hi);
+    for (int it = 0; it < 2; it++) {
+        double dfx = (3 * x1 + 2 * p) * x1 + q;
+        if (dfx != 0) {
+            double fx = ((x1 + p) * x1 + q) * x1 + r;
+            double xn = x1 - fx / dfx;
+            if (xn >= -B && xn <= B) x1 = xn;
+        }
+    }
+    roots[n++] = x1;
+    double b2 = p + x1, c2 = q + b2 * x1;
+    double disc = b2 * b2 - 4 * c2;
+    if (disc >= 0) {
+        double sq = sqrt(disc);
+        double qq = -0.5 * (b2 + (b2 >= 0 ? sq : -sq));
+        double r1 = qq, r2 = (qq != 0) ? c2 / qq : qq;
+        roots[n++] = r1;
+        roots[n++] = r2;
+    }
+    // ascending insertion sort (n <= 3)
+    for (int i = 1; i < n; i++) {
+        double v = roots[i];
+        int j    = i - 1;
+        while (j >= 0 && roots[j] > v) {
+            roots[j + 1] = roots[j];
+            j--;
+        }
+        roots[j + 1] = v;
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(SP_LANES) void k_seven_point(int n_hyp_total, const fm_set *sets, const int32_t *hyp_set,
+                                                          const int32_t *hyp_idx /*n_hyp x 7 (set-local)*/,
+                                                          const float2 *pts1, const float2 *pts2,
+                                                          double *models /*n_hyp x 3 x 9*/, int32_t *n_models) {
+    __shared__ double sG[7 * 9 * SP_LANES];
+    __shared__ double sV[9 * 9 * SP_LANES];
+    const int lane = threadIdx.x;
+    const int hyp  = blockIdx.x * SP_LANES + lane;
+    if (hyp >= n_hyp_total) return;
+    const fm_set S     = sets[hyp_set[hyp]];
+    const int32_t *idx = hyp_idx + 7 * (size_t) hyp;
+    for (int i = 0; i < 7; i++) {
+        const float2 a = pts1[S.pt_begin + idx[i]], b = pts2[S.pt_begin + idx[i]];
+        const double x1 = a.x, y1 = a.y, x2 = b.x, y2 = b.y;
+        SP_G(i, 0) = x2 * x1;
+        SP_G(i, 1) = x2 * y1;
+        SP_G(i, 2) = x2;
+        SP_G(i, 3) = y2 * x1;
+        SP_G(i, 4) = y2 * y1;
+        SP_G(i, 5) = y2;
+        SP_G(i, 6) = x1;
+        SP_G(i, 7) = y1;
+        SP_G(i, 8) = 1;
+    }
+    for (int i = 0; i < 9; i++)
+        for (int j = 0; j < 9; j++) SP_V(i, j) = (i == j) ? 1.0 : 0.0;
+    // one-sided Jacobi, cyclic (p,q) order, <= 30 sweeps
+    for (int sweep = 0; sweep < 30; sweep++) {
+        bool changed = false;
+        for (int p = 0; p < 8; p++)
+            for (int q = p + 1; q < 9; q++) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < 7; k++) {
+                    double gp = SP_G(k, p), gq = SP_G(k, q);
+                    alpha += gp * gp;
+                    beta += gq * gq;
+                    gamma += gp * gq;
+                }
+                if (gamma == 0.0) continue;
+                if (fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) continue;
+                changed     = true;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t    = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                if (zeta < 0) t = -t;
+                double c = 1.0 / sqrt(1.0 + t * t);
+                double s = c * t;
+                for (int k = 0; k < 7; k++) {
+                    double gp = SP_G(k, p), gq = SP_G(k, q);
+                    SP_G(k, p) = c * gp - s * gq;
+                    SP_G(k, q) = s * gp + c * gq;
+                }
+                for (int k = 0; k < 9; k++) {
+                    double vp = SP_V(k, p), vq = SP_V(k, q);
+                    SP_V(k, p) = c * vp - s * vq;
+                    SP_V(k, q) = s * vp + c * vq;
+                }
+            }
+        if (!changed) break;
+    }
+    double nrm[9];
+    for (int j = 0; j < 9; j++) {
+        double s = 0;
+        for (int k = 0; k < 7; k++) s += SP_G(k, j) * SP_G(k, j);
+        nrm[j] = s;
+    }
+    int i2 = 0;
+    for (int j = 1; j < 9; j++)
+        if (nrm[j] < nrm[i2]) i2 = j;
+    int i1 = (i2 == 0) ? 1 : 0;
+    for (int j = 0; j < 9; j++)
+        if (j != i2 && nrm[j] < nrm[i1]) i1 = j;
+    double f1[9], f2[9];
+    for (int k = 0; k < 9; k++) {
+        f1[k] = SP_V(k, i1);
+        f2[k] = SP_V(k, i2);
+    }
+    for (int i = 0; i < 9; i++) f1[i] -= f2[i];
+    double c[4], t0, t1, t2;
+    t0   = f2[4] * f2[8] - f2[5] * f2[7];
+    t1   = f2[3] * f2[8] - f2[5] * f2[6];
+    t2   = f2[3] * f2[7] - f2[4] * f2[6];
+    c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
+    c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 - f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) +
+           f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) - f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) +
+           f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+           f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+    t0   = f1[4] * f1[8] - f1[5] * f1[7];
+    t1   = f1[3] * f1[8] - f1[5] * f1[6];
+    t2   = f1[3] * f1[7] - f1[4] * f1[6];
+    c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+    c[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 - f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) +
+           f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) - f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) +
+           f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+           f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+    double roots[3];
+    const int n = dev_solve_cubic_real(c, roots);
+    double *out = models + 27 * (size_t) hyp;
+    for (int k = 0; k < n; k++) {
+        double lambda = roots[k], mu = 1.;
+        double s   = f1[8] * roots[k] + f2[8];
+        double *Fk = out + 9 * k;
+        if (fabs(s) > DBL_EPSILON) {
+            mu = 1. / s;
+            lambda *= mu;
+            Fk[8] = 1.;
+        } else
+            Fk[8] = 0.;
+        for (int i = 0; i < 8; i++) Fk[i] = f1[i] * lambda + f2[i] * mu;
+    }
+    n_models[hyp] = n;
+}
+
+// grid: (3 models, n_hyp_total); one wave per (hypothesis, model)
+__global__ __launch_bounds__(64) void k_fm_score(const fm_set *sets, const int32_t *hyp_set, const float2 *pts1,
+                                                 const float2 *pts2, const double *models, const int32_t *n_models,
+                                                 float thresh2, int32_t *good /*n_hyp x 3*/,
+                                                 unsigned long long *bits) {
+    const int model = blockIdx.x, hyp = blockIdx.y, lane = threadIdx.x;
+    if (model >= n_models[hyp]) {
+        if (lane == 0) good[hyp * 3 + model] = -1;
+        return;
+    }
+    const fm_set S  = sets[hyp_set[hyp]];
+    const double *F = models + 27 * (size_t) hyp + 9 * model;
+    const double F0 = F[0], F1 = F[1], F2 = F[2], F3 = F[3], F4 = F[4], F5 = F[5], F6 = F[6], F7 = F[7], F8 = F[8];
+    unsigned long long *w = bits + S.word_begin + ((size_t) (hyp - S.hyp_begin) * 3 + model) * S.words_per_model;
+    int count = 0;
+    for (int base = 0; base < S.n_pts; base += 64) {
+        const int i = base + lane;
+        bool in     = false;
+        if (i < S.n_pts) {
+            const float2 p1 = pts1[S.pt_begin + i], p2 = pts2[S.pt_begin + i];
+            const double x1 = p1.x, y1 = p1.y, x2 = p2.x, y2 = p2.y;
+            double a = F0 * x1 + F1 * y1 + F2;
+            double b = F3 * x1 + F4 * y1 + F5;
+            double c = F6 * x1 + F7 * y1 + F8;
+            double s2 = 1. / (a * a + b * b);
+            double d2 = x2 * a + y2 * b + c;
+            a         = F0 * x2 + F3 * y2 + F6;
+            b         = F1 * x2 + F4 * y2 + F7;
+            c         = F2 * x2 + F5 * y2 + F8;
+            double s1 = 1. / (a * a + b * b);
+            double d1 = x1 * a + y1 * b + c;
+            float e   = (float) fmax(d1 * d1 * s1, d2 * d2 * s2);
+            in        = e <= thresh2;
+        }
+        const unsigned long long m = __ballot(in);
+        if (lane == 0) w[base >> 6] = m;
+        count += __popcll(m);
+    }
+    if (lane == 0) good[hyp * 3 + model] = count;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct cv_rng { // cv::RNG (core/operations.hpp): MWC generator, coefficient 4164903690
+    uint64_t state;
+    explicit cv_rng(uint64_t s) : state(s ? s : 0xffffffffULL) {}
+    unsigned next() {
+        state = (uint64_t) (unsigned) state * 4164903690U + (unsigned) (state >> 32);
+        return (unsigned) state;
+    }
+    int uniform(int a, int b) { return a == b ? a : (int) (next() % (unsigned) (b - a) + a); }
+};
+
+int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) { // ptsetreg.cpp RANSACUpdateNumIters
+    p  = std::max(p, 0.);
+    p  = std::min(p, 1.);
+    ep = std::max(ep, 0.);
+    ep = std::min(ep, 1.);
+    double num   = std::max(1. - p, DBL_MIN);
+    double denom = 1. - std::pow(1. - ep, modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num   = std::log(num);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int) lrint(num / denom);
+}
+
+struct set_state {
+    int begin, n;
+    cv_rng rng{(uint64_t) -1};
+    int iter = 0, niters = 1000, max_good = 0;
+    bool done = false;
+    std::vector<uint8_t> best;
+};
+} // namespace
+
+extern "C" int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, const float *pts1, const float *pts2,
+                             double thresh, double conf, uint8_t *mask) {
+    if (!ctx || n_sets < 0) return ICG_ERR_INVALID;
+    if (n_sets == 0) return ICG_OK;
+    if (!offsets || !pts1 || !pts2 || !mask) return ICG_ERR_INVALID;
+    const int total = offsets[n_sets];
+    if (total > ctx->cfg.max_points) return icg_fail(ctx, ICG_ERR_CAPACITY, "%d points > max_points %d", total, ctx->cfg.max_points);
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (thresh <= 0) thresh = 3;
+    if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
+
+    std::vector<set_state> st((size_t) n_sets);
+    int active = 0;
+    for (int s = 0; s < n_sets; s++) {
+        st[s].begin = offsets[s];
+        st[s].n     = offsets[s + 1] - offsets[s];
+        if (st[s].n < 0) return ICG_ERR_INVALID;
+        if (st[s].n < 15) { // the reference only calls findFundamentalMat with >= 15 points: leave untouched
+            for (int i = 0; i < st[s].n; i++) mask[st[s].begin + i] = 1;
+            st[s].done = true;
+        } else {
+            st[s].best.assign((size_t) st[s].n, 0);
+            active++;
+        }
+    }
+    int chunk = 16;
+    while (active > 0) {
+        // hypotheses of this round: each active set gets min(chunk, niters - iter)
+        std::vector<fm_set> sets;
+        std::vector<int> set_of;       // launch set -> global set
+        std::vector<int32_t> hyp_set;  // per hypothesis -> launch set
+        std::vector<int32_t> hyp_idx;  // 7 per hypothesis
+        int words = 0;
+        for (int s = 0; s < n_sets; s++) {
+            set_state &S = st[s];
+            if (S.done) continue;
+            int nh = std::min(chunk, S.niters - S.iter);
+            fm_set f;
+            f.pt_begin        = S.begin;
+            f.n_pts           = S.n;
+            f.hyp_begin       = (int) hyp_set.size();
+            f.n_hyp           = nh;
+            f.words_per_model = (S.n + 63) / 64;
+            f.word_begin      = words;
+            words += nh * 3 * f.words_per_model;
+            for (int h = 0; h < nh; h++) {
+                int idx[7];
+                for (int i = 0; i < 7; i++) { // getSubset (OpenCV 4.x)
+                    int v;
+                    for (v = S.rng.uniform(0, S.n); std::find(idx, idx + i, v) != idx + i; v = S.rng.uniform(0, S.n)) {
+                    }
+                    idx[i] = v;
+                }
+                hyp_set.push_back((int32_t) sets.size());
+                hyp_idx.insert(hyp_idx.end(), idx, idx + 7);
+            }
+            set_of.push_back(s);
+            sets.push_back(f);
+        }
+        const int nh_total = (int) hyp_set.size();
+        icg_call c(ctx);
+        size_t need = sizeof(fm_set) * sets.size() + sizeof(int32_t) * 8 * (size_t) nh_total + sizeof(float) * 4 * (size_t) total +
+                      (size_t) nh_total * (27 * 8 + 4 + 12) + (size_t) words * 8 + 16384;
+        int rc = c.reserve(need);
+        if (rc) return rc;
+        const fm_set *d_sets  = c.in(sets.data(), sets.size());
+        const int32_t *d_hset = c.in(hyp_set.data(), (size_t) nh_total);
+        const int32_t *d_hidx = c.in(hyp_idx.data(), 7 * (size_t) nh_total);
+        const float2 *d_p1    = (const float2 *) c.in(pts1, 2 * (size_t) total);
+        const float2 *d_p2    = (const float2 *) c.in(pts2, 2 * (size_t) total);
+        if ((rc = c.seal())) return rc;
+        std::vector<int32_t> h_good((size_t) nh_total * 3);
+        std::vector<unsigned long long> h_bits((size_t) words);
+        double *d_models  = c.out((double *) nullptr, 27 * (size_t) nh_total);
+        int32_t *d_nm     = c.out((int32_t *) nullptr, (size_t) nh_total);
+        int32_t *d_good   = c.out(h_good.data(), (size_t) nh_total * 3);
+        unsigned long long *d_bits = c.out(h_bits.data(), (size_t) words);
+        {
+            icg_prof_scope ps(ctx, "fm_seven_point");
+            hipLaunchKernelGGL(k_seven_point, dim3((nh_total + SP_LANES - 1) / SP_LANES), dim3(SP_LANES), 0, ctx->stream,
+                               nh_total, d_sets, d_hset, d_hidx, d_p1, d_p2, d_models, d_nm);
+        }
+        {
+            icg_prof_scope ps(ctx, "fm_score");
+            hipLaunchKernelGGL(k_fm_score, dim3(3, nh_total), dim3(64), 0, ctx->stream, d_sets, d_hset, d_p1, d_p2, d_models,
+                               d_nm, (float) (thresh * thresh), d_good, d_bits);
+        }
+        ICG_HIP(ctx, hipGetLastError());
+        if ((rc = c.finish())) return rc;
+
+        // sequential replay of RANSACPointSetRegistrator::run over the scores (ptsetreg.cpp)
+        for (size_t ls = 0; ls < sets.size(); ls++) {
+            set_state &S    = st[set_of[ls]];
+            const fm_set &f = sets[ls];
+            for (int h = 0; h < f.n_hyp && S.iter < S.niters; h++, S.iter++) {
+                for (int m = 0; m < 3; m++) {
+                    int good = h_good[(size_t) (f.hyp_begin + h) * 3 + m];
+                    if (good < 0) break;
+                    if (good > std::max(S.max_good, 7 - 1)) {
+                        const unsigned long long *w = &h_bits[f.word_begin + ((size_t) h * 3 + m) * f.words_per_model];
+                        for (int i = 0; i < S.n; i++) S.best[i] = (uint8_t) ((w[i >> 6] >> (i & 63)) & 1ull);
+                        S.max_good = good;
+                        S.niters   = ransac_update_num_iters(conf, (double) (S.n - good) / S.n, 7, S.niters);
+                    }
+                }
+            }
+            if (S.iter >= S.niters) {
+                S.done = true;
+                active--;
+                if (S.max_good > 0)
+                    memcpy(mask + S.begin, S.best.data(), (size_t) S.n);
+                else
+                    memset(mask + S.begin, 0, (size_t) S.n);
+            }
+        }
+        if (chunk < 256) chunk *= 2;
+    }
+    return ICG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F8: 4x4 DLT, smallest right singular vector by one-sided Jacobi (registers), one lane per point.
+__global__ void k_triangulate(int n, const int32_t *T0_idx, const int32_t *T1_idx, const double *Tcw12, const double *pc0,
+                              const double *pc1, double *pw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *T0 = Tcw12 + 12 * (size_t) T0_idx[i], *T1 = Tcw12 + 12 * (size_t) T1_idx[i];
+    double D[4][4], V[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        D[0][j] = pc0[3 * i] * T0[2 * 4 + j] - T0[0 * 4 + j];
+        D[1][j] = pc0[3 * i + 1] * T0[2 * 4 + j] - T0[1 * 4 + j];
+        D[2][j] = pc1[3 * i] * T1[2 * 4 + j] - T1[0 * 4 + j];
+        D[3][j] = pc1[3 * i + 1] * T1[2 * 4 + j] - T1[1 * 4 + j];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) V[a][b] = (a == b) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        bool changed = false;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = p + 1; q < 4; q++) {
+                double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    alpha += D[k][p] * D[k][p];
+                    beta += D[k][q] * D[k][q];
+                    gamma += D[k][p] * D[k][q];
+                }
+                if (gamma == 0.0) continue;
+                if (fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) continue;
+                changed     = true;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t    = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                if (zeta < 0) t = -t;
+                double c = 1.0 / sqrt(1.0 + t * t);
+                double s = c * t;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    double gp = D[k][p], gq = D[k][q];
+                    D[k][p] = c * gp - s * gq;
+                    D[k][q] = s * gp + c * gq;
+                    double vp = V[k][p], vq = V[k][q];
+                    V[k][p] = c * vp - s * vq;
+                    V[k][q] = s * vp + c * vq;
+                }
+            }
+        if (!changed) break;
+    }
+    int best  = 0;
+    double bn = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) s += D[k][j] * D[k][j];
+        if (j == 0 || s < bn) {
+            bn   = s;
+            best = j;
+        }
+    }
+    double v0 = V[0][0], v1 = V[1][0], v2 = V[2][0], v3 = V[3][0];
+#pragma unroll
+    for (int j = 1; j < 4; j++)
+        if (best == j) {
+            v0 = V[0][j];
+            v1 = V[1][j];
+            v2 = V[2][j];
+            v3 = V[3][j];
+        }
+    pw[3 * i]     = v0 / v3;
+    pw[3 * i + 1] = v1 / v3;
+    pw[3 * i + 2] = v2 / v3;
+}
+
+extern "C" int icg_triangulate(icg_ctx *ctx, int n, const int32_t *T0_idx, const int32_t *T1_idx, int n_T,
+                               const double *Tcw12, const double *pc0, const double *pc1, double *pw) {
+    if (!ctx || n < 0) return ICG_ERR_INVALID;
+    if (n == 0) return ICG_OK;
+    if (!T0_idx || !T1_idx || !Tcw12 || !pc0 || !pc1 || !pw || n_T <= 0) return ICG_ERR_INVALID;
+    if (n > ctx->cfg.max_points) return icg_fail(ctx, ICG_ERR_CAPACITY, "%d points > max_points %d", n, ctx->cfg.max_points);
+    for (int i = 0; i < n; i++)
+        if (T0_idx[i] < 0 || T0_idx[i] >= n_T || T1_idx[i] < 0 || T1_idx[i] >= n_T)
+            return icg_fail(ctx, ICG_ERR_INVALID, "pose index out of range at point %d", i);
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    icg_call c(ctx);
+    int rc = c.reserve((size_t) n * (8 + 48 + 24) + (size_t) n_T * 96);
+    if (rc) return rc;
+    const int32_t *d_i0 = c.in(T0_idx, (size_t) n);
+    const int32_t *d_i1 = c.in(T1_idx, (size_t) n);
+    const double *d_T   = c.in(Tcw12, 12 * (size_t) n_T);
+    const double *d_p0  = c.in(pc0, 3 * (size_t) n);
+    const double *d_p1  = c.in(pc1, 3 * (size_t) n);
+    if ((rc = c.seal())) return rc;
+    double *d_pw = c.out(pw, 3 * (size_t) n);
+    {
+        icg_prof_scope ps(ctx, "triangulate");
+        hipLaunchKernelGGL(k_triangulate, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, n, d_i0, d_i1, d_T, d_p0, d_p1, d_pw);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}

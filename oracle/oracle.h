@@ -54,14 +54,17 @@ int orc_good_features(const uint8_t *img, int w, int h, int stride, const uint8_
                       int rw, int rh, int max_corners, double quality, double min_dist, float *corners);
 void orc_corner_subpix(const uint8_t *img, int w, int h, int stride, int rx, int ry, int rw, int rh, int n,
                        float *corners);
-int orc_features_detection(const uint8_t *img, int w, int h, int stride, int max_features, int n_frame_feats,
-                           const float *frame_feats, int n_new, const float *pts_new, int n_ref, int ismask,
-                           int n_mask_feats, const float *mask_feats, float *out_pts, int *out_block);
+void orc_circle_halfwidths(int radius, int *hw /* radius+1 */);
+void orc_subpix_mask(float *mask121);
+int orc_detect(const uint8_t *img, int w, int h, int stride, const int *grid6, int n_mask, const float *mask_pts,
+               const int *quota, int max_out, float *out_pts, int *out_block);
 
 // ---- RANSAC (orc_ransac.cc) --------------------------------------------------------------------------
 int orc_find_fundamental_ransac(int n, const float *pts1, const float *pts2, double thresh, double conf,
                                 uint8_t *mask, double *F_out, int *iters_out);
 int orc_seven_point(const double *m1 /*7x2*/, const double *m2 /*7x2*/, double *F /*up to 3 x 9*/);
+int orc_fm_score(const double *F, int n, const float *pts1, const float *pts2, double thresh, uint8_t *mask);
+void orc_ransac_subsets(int n_points, int n_hyp, int32_t *idx_out);
 
 // ---- triangulation (orc_triang.cc) -------------------------------------------------------------------
 void orc_triangulate_point(const double *T0 /*3x4 row-major*/, const double *T1, const double *pc0, const double *pc1,

@@ -1,0 +1,331 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. CPU restatement of
+//   cv::findFundamentalMat(pts1, pts2, FM_RANSAC, 1.5, 0.99, status)   reference call site tracking/tracking.cc:547-555
+// following OpenCV calib3d/src/fundam.cpp (FMEstimatorCallback::run7Point / computeError) and ptsetreg.cpp
+// (RANSACPointSetRegistrator::run, getSubset, RANSACUpdateNumIters) as defined in SURVEY.md Appendix B.9.
+// Formulation fixed here (mirrored by the HIP path so that decisions agree bit-for-bit):
+//   * null space of the 7x9 system by one-sided (Hestenes) Jacobi on the columns, fixed cyclic order, using only
+//     + - * / sqrt (OpenCV: JacobiSVD on the same matrix; the two-dimensional null space is basis independent);
+//   * cubic solved WITHOUT libm transcendentals (bisection on a Cauchy bracket + Newton polish + deflation), roots in
+//     ascending order (OpenCV's solveCubic uses acos/cos/cbrt which differ between host and device libm);
+//   * scoring in double, compared as float against (float)(thresh^2), exactly as computeError/findInliers;
+//   * the best/niters recurrence is replayed sequentially, so the result equals the sequential algorithm.
+// PARITY UNPINNED (no upstream golden vectors, OpenCV absent offline).
+#include "oracle.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+// One-sided Jacobi on an m x n matrix stored row-major in G (m rows, n cols); V (n x n) accumulates rotations.
+// After convergence columns of G are orthogonal; their norms are the singular values.
+void hestenes(double *G, int m, int n, double *V, int max_sweeps) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < max_sweeps; sweep++) {
+        bool changed = false;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < m; k++) {
+                    double gp = G[k * n + p], gq = G[k * n + q];
+                    alpha += gp * gp;
+                    beta += gq * gq;
+                    gamma += gp * gq;
+                }
+                if (gamma == 0.0) continue;
+                if (std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta)) continue;
+                changed     = true;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t    = 1.0 / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                if (zeta < 0) t = -t;
+                double c = 1.0 / std::sqrt(1.0 + t * t);
+                double s = c * t;
+                for (int k = 0; k < m; k++) {
+                    double gp = G[k * n + p], gq = G[k * n + q];
+                    G[k * n + p] = c * gp - s * gq;
+                    G[k * n + q] = s * gp + c * gq;
+                }
+                for (int k = 0; k < n; k++) {
+                    double vp = V[k * n + p], vq = V[k * n + q];
+                    V[k * n + p] = c * vp - s * vq;
+                    V[k * n + q] = s * vp + c * vq;
+                }
+            }
+        if (!changed) break;
+    }
+}
+
+// Real roots of c0 x^3 + c1 x^2 + c2 x + c3 = 0 without transcendentals; ascending order; returns count (0..3).
+int solve_cubic_real(const double c[4], double roots[3]) {
+    double a = c[0], b = c[1], cc = c[2], d = c[3];
+    double scale = std::fmax(std::fmax(std::fabs(a), std::fabs(b)), std::fmax(std::fabs(cc), std::fabs(d)));
+    if (scale == 0) return 0;
+    int n = 0;
+    if (std::fabs(a) <= 1e-14 * scale) {
+        // quadratic (or linear)
+        if (std::fabs(b) <= 1e-14 * scale) {
+            if (std::fabs(cc) <= 1e-14 * scale) return 0;
+            roots[0] = -d / cc;
+            return 1;
+        }
+        double disc = cc * cc - 4 * b * d;
+        if (disc < 0) return 0;
+        double sq = std::sqrt(disc);
+        double q  = -0.5 * (cc + (cc >= 0 ? sq : -sq));
+        double r1 = q / b, r2 = (q != 0) ? d / q : r1;
+        roots[0] = std::fmin(r1, r2);
+        roots[1] = std::fmax(r1, r2);
+        return 2;
+    }
+    double p = b / a, q = cc / a, r = d / a; // x^3 + p x^2 + q x + r
+    auto f  = [&](double x) { return ((x + p) * x + q) * x + r; };
+    auto df = [&](double x) { return (3 * x + 2 * p) * x + q; };
+    double B  = 1.0 + std::fmax(std::fabs(p), std::fmax(std::fabs(q), std::fabs(r)));
+    double lo = -B, hi = B; // f(lo) < 0 < f(hi)
+    for (int it = 0; it < 200; it++) {
+        double mid = 0.5 * (lo + hi);
+        if (mid == lo || mid == hi) break;
+        if (f(mid) < 0)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    double x1 = 0.5 * (lo + hi);
+    for (int it = 0; it < 2; it++) {
+        double dfx = df(x1);
+        if (dfx != 0) {
+            double xn = x1 - f(x1) / dfx;
+            if (xn >= -B && xn <= B) x1 = xn;
+        }
+    }
+    roots[n++] = x1;
+    // deflate: x^2 + (p + x1) x + (q + (p + x1) x1)
+    double b2 = p + x1, c2 = q + b2 * x1;
+    double disc = b2 * b2 - 4 * c2;
+    if (disc >= 0) {
+        double sq = std::sqrt(disc);
+        double qq = -0.5 * (b2 + (b2 >= 0 ? sq : -sq));
+        double r1 = qq, r2 = (qq != 0) ? c2 / qq : qq;
+        roots[n++] = r1;
+        roots[n++] = r2;
+    }
+    std::sort(roots, roots + n);
+    return n;
+}
+
+struct Rng {
+    uint64_t state;
+    explicit Rng(uint64_t s) : state(s ? s : 0xffffffffULL) {}
+    unsigned next() {
+        state = (uint64_t) (unsigned) state * 4164903690U + (unsigned) (state >> 32);
+        return (unsigned) state;
+    }
+    int uniform(int a, int b) { return a == b ? a : (int) (next() % (unsigned) (b - a) + a); }
+};
+
+int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
+    p  = std::max(p, 0.);
+    p  = std::min(p, 1.);
+    ep = std::max(ep, 0.);
+    ep = std::min(ep, 1.);
+    double num   = std::max(1. - p, DBL_MIN);
+    double denom = 1. - std::pow(1. - ep, modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num   = std::log(num);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int) lrint(num / denom);
+}
+
+} // namespace
+
+extern "C" {
+
+// 7-point algorithm on 7 correspondences (m1,m2: 7x2 doubles holding float-valued pixel coordinates).
+// F: up to 3 row-major 3x3 matrices. Returns the number of models.
+int orc_seven_point(const double *m1, const double *m2, double *F) {
+    double A[7 * 9], V[81];
+    for (int i = 0; i < 7; i++) {
+        double x1 = m1[2 * i], y1 = m1[2 * i + 1], x2 = m2[2 * i], y2 = m2[2 * i + 1];
+        double *r = A + 9 * i;
+        r[0] = x2 * x1;
+        r[1] = x2 * y1;
+        r[2] = x2;
+        r[3] = y2 * x1;
+        r[4] = y2 * y1;
+        r[5] = y2;
+        r[6] = x1;
+        r[7] = y1;
+        r[8] = 1;
+    }
+    hestenes(A, 7, 9, V, 30);
+    // the two columns with the smallest norms span the null space: f2 = smallest, f1 = second smallest
+    double nrm[9];
+    for (int j = 0; j < 9; j++) {
+        double s = 0;
+        for (int k = 0; k < 7; k++) s += A[k * 9 + j] * A[k * 9 + j];
+        nrm[j] = s;
+    }
+    int i2 = 0;
+    for (int j = 1; j < 9; j++)
+        if (nrm[j] < nrm[i2]) i2 = j;
+    int i1 = (i2 == 0) ? 1 : 0;
+    for (int j = 0; j < 9; j++)
+        if (j != i2 && nrm[j] < nrm[i1]) i1 = j;
+    double f1[9], f2[9];
+    for (int k = 0; k < 9; k++) {
+        f1[k] = V[k * 9 + i1];
+        f2[k] = V[k * 9 + i2];
+    }
+    for (int i = 0; i < 9; i++) f1[i] -= f2[i];
+    double c[4], t0, t1, t2;
+    t0   = f2[4] * f2[8] - f2[5] * f2[7];
+    t1   = f2[3] * f2[8] - f2[5] * f2[6];
+    t2   = f2[3] * f2[7] - f2[4] * f2[6];
+    c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
+    c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 - f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) +
+           f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) - f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) +
+           f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+           f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+    t0   = f1[4] * f1[8] - f1[5] * f1[7];
+    t1   = f1[3] * f1[8] - f1[5] * f1[6];
+    t2   = f1[3] * f1[7] - f1[4] * f1[6];
+    c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+    c[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 - f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) +
+           f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) - f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) +
+           f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+           f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+    double roots[3];
+    int n = solve_cubic_real(c, roots);
+    for (int k = 0; k < n; k++) {
+        double lambda = roots[k], mu = 1.;
+        double s   = f1[8] * roots[k] + f2[8];
+        double *Fk = F + 9 * k;
+        if (std::fabs(s) > DBL_EPSILON) {
+            mu = 1. / s;
+            lambda *= mu;
+            Fk[8] = 1.;
+        } else
+            Fk[8] = 0.;
+        for (int i = 0; i < 8; i++) Fk[i] = f1[i] * lambda + f2[i] * mu;
+    }
+    return n;
+}
+
+// inlier mask of one model (computeError + findInliers); returns the inlier count
+int orc_fm_score(const double *F, int n, const float *pts1, const float *pts2, double thresh, uint8_t *mask) {
+    float t = (float) (thresh * thresh);
+    int nz  = 0;
+    for (int i = 0; i < n; i++) {
+        double x1 = pts1[2 * i], y1 = pts1[2 * i + 1], x2 = pts2[2 * i], y2 = pts2[2 * i + 1];
+        double a = F[0] * x1 + F[1] * y1 + F[2];
+        double b = F[3] * x1 + F[4] * y1 + F[5];
+        double c = F[6] * x1 + F[7] * y1 + F[8];
+        double s2 = 1. / (a * a + b * b);
+        double d2 = x2 * a + y2 * b + c;
+        a         = F[0] * x2 + F[3] * y2 + F[6];
+        b         = F[1] * x2 + F[4] * y2 + F[7];
+        c         = F[2] * x2 + F[5] * y2 + F[8];
+        double s1 = 1. / (a * a + b * b);
+        double d1 = x1 * a + y1 * b + c;
+        float e   = (float) std::max(d1 * d1 * s1, d2 * d2 * s2);
+        int f     = e <= t;
+        if (mask) mask[i] = (uint8_t) f;
+        nz += f;
+    }
+    return nz;
+}
+
+// the hypothesis index stream of RANSACPointSetRegistrator (getSubset, OpenCV 4.x): idx_out = n_hyp x 7
+void orc_ransac_subsets(int n_points, int n_hyp, int32_t *idx_out) {
+    Rng rng((uint64_t) -1);
+    for (int h = 0; h < n_hyp; h++) {
+        int *idx = idx_out + 7 * h;
+        for (int i = 0; i < 7; i++) {
+            int v;
+            for (v = rng.uniform(0, n_points); std::find(idx, idx + i, v) != idx + i; v = rng.uniform(0, n_points)) {
+            }
+            idx[i] = v;
+        }
+    }
+}
+
+// Full findFundamentalMat(FM_RANSAC). Returns 1 if a model was found. mask: n bytes (all zero on failure).
+int orc_find_fundamental_ransac(int n, const float *pts1, const float *pts2, double thresh, double conf,
+                                uint8_t *mask, double *F_out, int *iters_out) {
+    const int modelPoints = 7;
+    int niters            = 1000;
+    int maxGood           = 0;
+    memset(mask, 0, n);
+    if (n < 15) return 0; // findFundamentalMat switches to LMedS below 15 points; the reference never calls it then
+    if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
+    if (thresh <= 0) thresh = 3;
+    Rng rng((uint64_t) -1);
+    std::vector<uint8_t> cur(n);
+    double bestF[9] = {0};
+    int iter;
+    for (iter = 0; iter < niters; iter++) {
+        int idx[7];
+        for (int i = 0; i < 7; i++) {
+            int v;
+            for (v = rng.uniform(0, n); std::find(idx, idx + i, v) != idx + i; v = rng.uniform(0, n)) {
+            }
+            idx[i] = v;
+        }
+        double m1[14], m2[14], F[27];
+        for (int i = 0; i < 7; i++) {
+            m1[2 * i]     = pts1[2 * idx[i]];
+            m1[2 * i + 1] = pts1[2 * idx[i] + 1];
+            m2[2 * i]     = pts2[2 * idx[i]];
+            m2[2 * i + 1] = pts2[2 * idx[i] + 1];
+        }
+        int nmodels = orc_seven_point(m1, m2, F);
+        for (int k = 0; k < nmodels; k++) {
+            int good = orc_fm_score(F + 9 * k, n, pts1, pts2, thresh, cur.data());
+            if (good > std::max(maxGood, modelPoints - 1)) {
+                memcpy(mask, cur.data(), n);
+                memcpy(bestF, F + 9 * k, sizeof bestF);
+                maxGood = good;
+                niters  = update_num_iters(conf, (double) (n - good) / n, modelPoints, niters);
+            }
+        }
+    }
+    if (iters_out) *iters_out = iter;
+    if (F_out) memcpy(F_out, bestF, sizeof bestF);
+    if (maxGood == 0) {
+        memset(mask, 0, n);
+        return 0;
+    }
+    return 1;
+}
+
+// Tracking::triangulatePoint (tracking.cc:800-811): smallest right singular vector of the 4x4 DLT matrix
+// (Eigen jacobiSvd in the reference; one-sided Jacobi here), dehomogenised.
+void orc_triangulate_point(const double *T0, const double *T1, const double *pc0, const double *pc1, double *pw) {
+    double D[16], V[16];
+    for (int j = 0; j < 4; j++) {
+        D[0 * 4 + j] = pc0[0] * T0[2 * 4 + j] - T0[0 * 4 + j];
+        D[1 * 4 + j] = pc0[1] * T0[2 * 4 + j] - T0[1 * 4 + j];
+        D[2 * 4 + j] = pc1[0] * T1[2 * 4 + j] - T1[0 * 4 + j];
+        D[3 * 4 + j] = pc1[1] * T1[2 * 4 + j] - T1[1 * 4 + j];
+    }
+    hestenes(D, 4, 4, V, 30);
+    int best = 0;
+    double bn = 0;
+    for (int j = 0; j < 4; j++) {
+        double s = 0;
+        for (int k = 0; k < 4; k++) s += D[k * 4 + j] * D[k * 4 + j];
+        if (j == 0 || s < bn) {
+            bn   = s;
+            best = j;
+        }
+    }
+    double wv = V[3 * 4 + best];
+    pw[0]     = V[0 * 4 + best] / wv;
+    pw[1]     = V[1 * 4 + best] / wv;
+    pw[2]     = V[2 * 4 + best] / wv;
+}
+
+} // extern "C"

@@ -142,6 +142,90 @@ class Oracle:
         return out
 
 
+    # ---- detection
+    def draw_circle(self, mask, cx, cy, r, value=0):
+        h, w = mask.shape
+        self.lib.orc_draw_filled_circle(_p(mask), w, h, mask.strides[0], int(cx), int(cy), int(r), int(value))
+
+    def circle_halfwidths(self, r):
+        hw = np.zeros(r + 1, np.int32)
+        self.lib.orc_circle_halfwidths(int(r), _p(hw))
+        return hw
+
+    def min_eigen_map(self, img, roi):
+        img = _u8(img)
+        h, w = img.shape
+        rx, ry, rw, rh = roi
+        eig = np.zeros((rh, rw), np.float32)
+        self.lib.orc_min_eigen_map(_p(img), w, h, w, rx, ry, rw, rh, _p(eig))
+        return eig
+
+    def good_features(self, img, mask, roi, max_corners, quality, min_dist):
+        img = _u8(img)
+        h, w = img.shape
+        rx, ry, rw, rh = roi
+        out = np.zeros((max_corners, 2), np.float32)
+        m = None if mask is None else _u8(mask)
+        n = self.lib.orc_good_features(_p(img), w, h, w, _p(m), w, rx, ry, rw, rh, max_corners, C.c_double(quality),
+                                       C.c_double(min_dist), _p(out))
+        return out[:n]
+
+    def corner_subpix(self, img, roi, corners):
+        img = _u8(img)
+        h, w = img.shape
+        rx, ry, rw, rh = roi
+        c = _f32(corners).reshape(-1, 2).copy()
+        self.lib.orc_corner_subpix(_p(img), w, h, w, rx, ry, rw, rh, c.shape[0], _p(c))
+        return c
+
+    def subpix_mask(self):
+        m = np.zeros(121, np.float32)
+        self.lib.orc_subpix_mask(_p(m))
+        return m
+
+    def detect(self, img, grid6, mask_pts, quota, max_out):
+        img = _u8(img)
+        h, w = img.shape
+        mask_pts = _f32(mask_pts).reshape(-1, 2)
+        out = np.zeros((max_out, 2), np.float32)
+        blk = np.zeros(max_out, np.int32)
+        n = self.lib.orc_detect(_p(img), w, h, w, _p(_i32(grid6)), mask_pts.shape[0], _p(mask_pts), _p(_i32(quota)), max_out,
+                                _p(out), _p(blk))
+        return out[:n], blk[:n]
+
+    # ---- RANSAC / triangulation
+    def seven_point(self, m1, m2):
+        F = np.zeros((3, 9))
+        n = self.lib.orc_seven_point(_p(_f64(m1)), _p(_f64(m2)), _p(F))
+        return F[:n].reshape(n, 3, 3)
+
+    def fm_score(self, F, pts1, pts2, thresh):
+        pts1, pts2 = _f32(pts1).reshape(-1, 2), _f32(pts2).reshape(-1, 2)
+        mask = np.zeros(pts1.shape[0], np.uint8)
+        n = self.lib.orc_fm_score(_p(_f64(F)), pts1.shape[0], _p(pts1), _p(pts2), C.c_double(thresh), _p(mask))
+        return n, mask
+
+    def ransac_subsets(self, n_points, n_hyp):
+        idx = np.zeros((n_hyp, 7), np.int32)
+        self.lib.orc_ransac_subsets(n_points, n_hyp, _p(idx))
+        return idx
+
+    def fm_ransac(self, pts1, pts2, thresh=1.5, conf=0.99):
+        pts1, pts2 = _f32(pts1).reshape(-1, 2), _f32(pts2).reshape(-1, 2)
+        n = pts1.shape[0]
+        mask = np.zeros(n, np.uint8)
+        F = np.zeros(9)
+        it = C.c_int(0)
+        ok = self.lib.orc_find_fundamental_ransac(n, _p(pts1), _p(pts2), C.c_double(thresh), C.c_double(conf), _p(mask), _p(F),
+                                                  C.byref(it))
+        return ok, mask, F.reshape(3, 3), it.value
+
+    def triangulate(self, T0, T1, pc0, pc1):
+        pw = np.zeros(3)
+        self.lib.orc_triangulate_point(_p(_f64(T0)), _p(_f64(T1)), _p(_f64(pc0)), _p(_f64(pc1)), _p(pw))
+        return pw
+
+
 def build():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
 

@@ -1,0 +1,122 @@
+"""GPU parity: detection (F7), fundamental-matrix RANSAC (F6) and triangulation (F8) vs the CPU oracle.
+Index-like outputs (inlier masks, corner sets and their order, block ids) must be bit-exact; corner coordinates and
+triangulated points are also required bit-exact here because both sides use the same IEEE operation order."""
+import numpy as np
+import pytest
+
+import synth
+from test_oracle_geometry import two_view
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx1280():
+    import icgvins
+    c = icgvins.Context(1280, 720, n_slots=3, max_batch=3, max_points=8192)
+    c.set_camera(synth.CAM_1280)
+    yield c
+    c.close()
+
+
+def grid_for(w, h, max_features):
+    """Tracking ctor arithmetic, tracking.cc:66-85."""
+    lround = lambda v: int(np.floor(v + 0.5))  # C lround/round: half away from zero (positive arguments here)
+    bc, br = lround(w / 200.0), lround(h / 200.0)
+    bw, bh = w // bc, h // br
+    per = lround(max_features / (bc * br))
+    md = lround(200.0 / np.sqrt(per * 1.5))
+    return [bc, br, bw, bh, md, per]
+
+
+def test_grid_arithmetic_matches_survey():
+    assert grid_for(1280, 720, 300) == [6, 4, 213, 180, 45, 13]
+    assert grid_for(640, 480, 100) == [3, 2, 213, 240, 40, 17]
+    assert grid_for(1920, 1080, 500) == [10, 5, 192, 216, 52, 10]
+
+
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_detect_matches_oracle_c2(oracle, ctx1280, with_mask):
+    w, h = 1280, 720
+    imgs = [synth.texture(w, h, seed=80), synth.texture(w, h, seed=81)]
+    ctx1280.preprocess([0, 2], imgs)
+    grid = grid_for(w, h, 300)
+    nblk = grid[0] * grid[1]
+    rng = np.random.RandomState(5)
+    quotas, masks = [], []
+    for j in range(2):
+        q = np.full(nblk, grid[5], np.int32)
+        if with_mask:
+            q -= rng.randint(0, grid[5] + 2, nblk)  # some blocks full (<=0), some partially filled
+            masks.append(synth.random_points(120, w, h, 0, seed=90 + j))
+        else:
+            masks.append(np.zeros((0, 2), np.float32))
+        quotas.append(q)
+    mask_off = np.cumsum([0] + [len(m) for m in masks]).astype(np.int32)
+    out, cnt, blk = ctx1280.detect([0, 2], grid, mask_off, np.concatenate(masks), np.concatenate(quotas), 400)
+    for j, img in enumerate(imgs):
+        exp_pts, exp_blk = oracle.detect(oracle.clahe(img), grid, masks[j], quotas[j], 400)
+        assert cnt[j] == len(exp_pts) and cnt[j] > 50
+        assert np.array_equal(blk[j, :cnt[j]], exp_blk)
+        assert np.array_equal(out[j, :cnt[j]].view(np.uint32), exp_pts.view(np.uint32))
+
+
+def test_detect_small_image_and_last_block(oracle):
+    import icgvins
+    w, h = 640, 480
+    c = icgvins.Context(w, h, n_slots=1, max_batch=1, max_points=64)
+    try:
+        img = synth.texture(w, h, seed=82)
+        c.preprocess([0], [img])
+        grid = grid_for(w, h, 100)
+        q = np.full(6, grid[5], np.int32)
+        out, cnt, blk = c.detect([0], grid, [0, 0], np.zeros((0, 2)), q, 200)
+        exp_pts, exp_blk = oracle.detect(oracle.clahe(img), grid, np.zeros((0, 2)), q, 200)
+        assert cnt[0] == len(exp_pts)
+        assert np.array_equal(blk[0, :cnt[0]], exp_blk)
+        assert np.array_equal(out[0, :cnt[0]].view(np.uint32), exp_pts.view(np.uint32))
+        # all quotas <= 0 -> nothing
+        out, cnt, _ = c.detect([0], grid, [0, 0], np.zeros((0, 2)), np.zeros(6, np.int32), 200)
+        assert cnt[0] == 0
+    finally:
+        c.close()
+
+
+def test_fm_ransac_matches_oracle(oracle, ctx1280):
+    sets = []
+    for seed, n, frac in ((1, 200, 0.25), (2, 60, 0.4), (3, 15, 0.0), (4, 10, 0.0), (5, 300, 0.6), (6, 120, 0.1)):
+        p1, p2, _, _ = two_view(n, seed=seed, outlier_frac=frac, noise=0.3)
+        sets.append((p1, p2))
+    offsets = np.cumsum([0] + [len(s[0]) for s in sets]).astype(np.int32)
+    mask = ctx1280.fm_ransac(offsets, np.concatenate([s[0] for s in sets]), np.concatenate([s[1] for s in sets]))
+    for k, (p1, p2) in enumerate(sets):
+        got = mask[offsets[k]:offsets[k + 1]]
+        if len(p1) < 15:
+            assert np.all(got == 1)  # the reference skips RANSAC below 15 points (tracking.cc:547)
+            continue
+        ok, exp, _, iters = oracle.fm_ransac(p1, p2)
+        assert ok == 1
+        assert np.array_equal(got, exp), (k, iters, got.sum(), exp.sum())
+
+
+def test_fm_ransac_degenerate_all_identical(oracle, ctx1280):
+    # all correspondences identical: the 7-point system is rank deficient; must not crash and must agree
+    p = np.tile(np.array([[100.0, 200.0]], np.float32), (20, 1))
+    mask = ctx1280.fm_ransac([0, 20], p, p)
+    ok, exp, _, _ = oracle.fm_ransac(p, p)
+    assert np.array_equal(mask, exp)
+
+
+def test_triangulate_matches_oracle(oracle, ctx1280):
+    _, _, _, (K, R, t, X) = two_view(300, seed=7)
+    T0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    T1 = np.hstack([R, t[:, None]])
+    pc0 = X / X[:, 2:]
+    c1 = (R @ X.T).T + t
+    pc1 = c1 / c1[:, 2:]
+    rng = np.random.RandomState(0)
+    pc1[:, :2] += rng.normal(0, 1e-3, (300, 2))
+    got = ctx1280.triangulate(0, 1, np.stack([T0.ravel(), T1.ravel()]), pc0, pc1)
+    exp = np.stack([oracle.triangulate(T0, T1, a, b) for a, b in zip(pc0, pc1)])
+    assert np.array_equal(got, exp)
+    assert np.median(np.abs(got - X)) < 0.5  # ~1 px of noise at 6-40 m depth

@@ -1,0 +1,168 @@
+"""Known-answer tests pinning the ORACLE's detection / RANSAC / triangulation restatements
+(SURVEY.md Appendix B.7-B.10); the reference ships no tests for them."""
+import numpy as np
+
+import synth
+
+
+def two_view(n, seed, outlier_frac=0.0, noise=0.0):
+    rng = np.random.RandomState(seed)
+    K = np.array([[787.0, 0, 640], [0, 787.0, 360], [0, 0, 1]])
+    X = np.stack([rng.uniform(-8, 8, n), rng.uniform(-5, 5, n), rng.uniform(6, 40, n)], 1)
+    ang = 0.05
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([0.5, 0.05, 0.1])
+    x1 = (K @ X.T).T
+    x2 = (K @ (R @ X.T + t[:, None])).T
+    p1 = x1[:, :2] / x1[:, 2:]
+    p2 = x2[:, :2] / x2[:, 2:]
+    p2 += rng.normal(0, noise, p2.shape) if noise > 0 else 0
+    nout = int(n * outlier_frac)
+    out_idx = rng.choice(n, nout, replace=False)
+    p2[out_idx] += rng.uniform(15, 60, (nout, 2)) * rng.choice([-1, 1], (nout, 2))
+    truth = np.ones(n, bool)
+    truth[out_idx] = False
+    return p1.astype(np.float32), p2.astype(np.float32), truth, (K, R, t, X)
+
+
+def test_circle_table_matches_drawing(oracle):
+    for r in (1, 5, 40, 45, 52, 62):
+        m = np.full((2 * r + 9, 2 * r + 9), 255, np.uint8)
+        c = r + 4
+        oracle.draw_circle(m, c, c, r, 0)
+        hw = oracle.circle_halfwidths(r)
+        exp = np.full_like(m, 255)
+        for dy in range(-r, r + 1):
+            w = hw[abs(dy)]
+            if w >= 0:
+                exp[c + dy, c - w:c + w + 1] = 0
+        assert np.array_equal(m, exp), r
+        # roughly a disc, symmetric, radius r on the axes
+        assert m[c, c - r] == 0 and m[c, c - r - 1] == 255 and m[c - r, c] == 0 and m[c - r - 1, c] == 255
+        assert np.array_equal(m, m[::-1]) and np.array_equal(m, m[:, ::-1]) and np.array_equal(m, m.T)
+    # clipping at the image border must not crash or wrap
+    m = np.full((30, 30), 255, np.uint8)
+    oracle.draw_circle(m, 2, 27, 10, 0)
+    assert m[27, 0] == 0 and m[29, 2] == 0 and m[10, 20] == 255
+
+
+def test_min_eigen_is_high_on_corners_low_on_edges(oracle):
+    img = np.zeros((80, 80), np.uint8)
+    img[40:, 40:] = 200  # one corner at (40,40), edges along x=40 and y=40
+    eig = oracle.min_eigen_map(img, (0, 0, 80, 80))
+    assert eig[39:42, 39:42].max() > 50 * max(eig[60, 39:42].max(), 1e-9)  # vertical edge: min eigenvalue ~0
+    assert eig[10, 10] == 0
+    # ROI evaluation peeks at real pixels outside the ROI: interior of a ROI equals the full-image map
+    img2 = synth.texture(200, 150, seed=3)
+    full = oracle.min_eigen_map(img2, (0, 0, 200, 150))
+    roi = oracle.min_eigen_map(img2, (30, 20, 100, 90))
+    assert np.array_equal(roi[1:-1, 1:-1], full[21:109, 31:129])
+
+
+def test_good_features_respects_quota_distance_mask(oracle):
+    img = synth.texture(400, 300, seed=4)
+    mask = np.full((300, 400), 255, np.uint8)
+    oracle.draw_circle(mask, 200, 150, 60, 0)
+    roi = (10, 10, 380, 280)
+    pts = oracle.good_features(img, mask, roi, 25, 0.01, 30)
+    assert 5 < len(pts) <= 25
+    d = np.linalg.norm(pts[:, None] - pts[None], axis=2) + np.eye(len(pts)) * 1e9
+    assert d.min() >= 30
+    for x, y in pts:
+        assert mask[int(y) + roi[1], int(x) + roi[0]] == 255
+        assert 1 <= x <= roi[2] - 2 and 1 <= y <= roi[3] - 2
+    # strongest first
+    eig = oracle.min_eigen_map(img, roi)
+    vals = [eig[int(y), int(x)] for x, y in pts]
+    assert all(vals[i] >= vals[i + 1] for i in range(len(vals) - 1))
+    # every corner is a 3x3 local maximum of the response
+    for x, y in pts:
+        x, y = int(x), int(y)
+        assert eig[y, x] == eig[y - 1:y + 2, x - 1:x + 2].max()
+
+
+def test_subpix_converges_to_true_corner(oracle):
+    # anti-aliased checker corner at a known sub-pixel location
+    cx, cy = 50.3, 47.6
+    ss = 8
+    hi = np.zeros((100 * ss, 100 * ss))
+    X, Y = np.meshgrid((np.arange(100 * ss) + 0.5) / ss, (np.arange(100 * ss) + 0.5) / ss)
+    hi[((X < cx) & (Y < cy)) | ((X >= cx) & (Y >= cy))] = 200
+    img = hi.reshape(100, ss, 100, ss).mean((1, 3)).astype(np.uint8)
+    out = oracle.corner_subpix(img, (0, 0, 100, 100), np.array([[50.0, 48.0], [52.0, 46.0]], np.float32))
+    # pixel centres are at integer coordinates: continuous corner (cx,cy) sits at (cx-0.5, cy-0.5)
+    assert np.abs(out - np.array([cx - 0.5, cy - 0.5])).max() < 0.15
+    # a point on a flat area stays where it is (singular system)
+    flat = oracle.corner_subpix(img, (0, 0, 100, 100), np.array([[20.0, 20.0]], np.float32))
+    assert np.array_equal(flat, np.array([[20.0, 20.0]], np.float32))
+
+
+def test_detect_block_order_and_offsets(oracle):
+    w, h = 640, 480
+    img = synth.texture(w, h, seed=5)
+    grid = [3, 2, 213, 240, 40, 17]
+    quota = [17, 0, 5, 17, 17, 3]
+    pts, blk = oracle.detect(img, grid, np.zeros((0, 2)), quota, 200)
+    assert len(pts) > 20
+    assert np.all(np.diff(blk) >= 0) and 1 not in blk
+    for k in range(6):
+        sel = pts[blk == k]
+        assert len(sel) <= max(quota[k], 0)
+        if len(sel):
+            c, r = k % 3, k // 3
+            assert np.all(sel[:, 0] >= c * 213) and np.all(sel[:, 0] < (c + 1) * 213)
+            assert np.all(sel[:, 1] >= r * 240) and np.all(sel[:, 1] < (r + 1) * 240)
+    # masking existing features keeps new corners at least ~min_dist away from them
+    pts2, _ = oracle.detect(img, grid, pts[:10], [17] * 6, 200)
+    d = np.linalg.norm(pts2[:, None] - pts[None, :10], axis=2)
+    assert d.min() > 33.0  # disc radius 40 around the rounded point, minus <=5 px sub-pixel refinement
+
+
+def test_seven_point_models_fit_their_sample(oracle):
+    p1, p2, _, _ = two_view(7, seed=1)
+    F = oracle.seven_point(p1.astype(np.float64), p2.astype(np.float64))
+    assert 1 <= len(F) <= 3
+    for Fk in F:
+        for a, b in zip(p1, p2):
+            x1 = np.array([a[0], a[1], 1.0])
+            x2 = np.array([b[0], b[1], 1.0])
+            l = Fk @ x1
+            assert abs(x2 @ l) / np.hypot(l[0], l[1]) < 1e-6
+        assert abs(np.linalg.det(Fk / np.linalg.norm(Fk))) < 1e-10
+
+
+def test_ransac_rng_stream(oracle):
+    idx = oracle.ransac_subsets(300, 50)
+    assert idx.min() >= 0 and idx.max() < 300
+    assert all(len(set(r)) == 7 for r in idx)
+    # cv::RNG((uint64)-1): first draw = (0xFFFFFFFF * 4164903690 + 0xFFFFFFFF) & 0xFFFFFFFF
+    st = (0xFFFFFFFF * 4164903690 + 0xFFFFFFFF)
+    assert idx[0, 0] == (st & 0xFFFFFFFF) % 300
+
+
+def test_ransac_flags_outliers(oracle):
+    p1, p2, truth, _ = two_view(200, seed=2, outlier_frac=0.25, noise=0.2)
+    ok, mask, F, iters = oracle.fm_ransac(p1, p2, 1.5, 0.99)
+    assert ok == 1 and iters < 1000
+    m = mask.astype(bool)
+    assert (m & ~truth).sum() <= 2          # outliers rejected
+    assert (m & truth).sum() >= 0.9 * truth.sum()  # inliers kept
+    # fewer than 15 points: not run (all-zero mask, rc 0)
+    ok2, mask2, _, _ = oracle.fm_ransac(p1[:10], p2[:10])
+    assert ok2 == 0 and mask2.sum() == 0
+    # clean data terminates after very few hypotheses
+    p1c, p2c, _, _ = two_view(100, seed=3)
+    ok3, mask3, _, it3 = oracle.fm_ransac(p1c, p2c)
+    assert ok3 == 1 and mask3.sum() == 100 and it3 <= 5
+
+
+def test_triangulation_recovers_point(oracle):
+    _, _, _, (K, R, t, X) = two_view(20, seed=4)
+    T0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    T1 = np.hstack([R, t[:, None]])
+    for Xw in X:
+        pc0 = Xw / Xw[2]
+        c1 = R @ Xw + t
+        pc1 = c1 / c1[2]
+        pw = oracle.triangulate(T0, T1, pc0, pc1)
+        assert np.abs(pw - Xw).max() < 1e-8 * max(1, np.abs(Xw).max())
