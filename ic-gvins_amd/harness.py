@@ -1,0 +1,148 @@
+"""Replay harness (plumbing for tests and bench.py): synthetic camera streams + a ctypes driver for the host
+layer's multi-stream executor (libicgvins_host.so, C entry points in host/capi.cc).
+
+The library path is a parameter: the product path loads ic-gvins_amd/libicgvins_host.so (HIP-backed, no fallback);
+tests and bench.py's cpu_baseline leg may pass oracle/libicgvins_host_oracle.so (same host code linked on the CPU
+restatement) — never the other way round.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB = os.path.join(_HERE, "libicgvins_host.so")
+
+TRACK_STATES = ["FIRST_FRAME", "INITIALIZING", "TRACKING", "PASSED", "LOST"]
+
+
+def camera_for(width, height):
+    """Reference intrinsics/distortion (config/gvins.yaml:65,69) with the principal point at the image centre and the
+    focal length scaled with the image width relative to 1280."""
+    s = width / 1280.0
+    return [787.1611861559479 * s, 787.3928431375225 * s, width / 2.0, height / 2.0, 0.0, -0.0917403092279957,
+            0.08134715036932794, 0.00017620136958692255, 0.00016737385248865412, 0.0]
+
+
+def _rot_yp(yaw, pitch):
+    cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])       # about camera y (down)
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])       # about camera x (right)
+    return Ry @ Rx
+
+
+class SynthScene:
+    """A slanted textured wall ~20 m in front of a camera that flies past it (x right, y down, z forward)."""
+
+    def __init__(self, lib, width, height, cam10, tex_size=2048, seed=7, threads=8):
+        self.lib, self.w, self.h, self.cam = lib, width, height, np.asarray(cam10, np.float64)
+        self.tex_size, self.threads = tex_size, threads
+        self.tex = np.zeros((tex_size, tex_size), np.uint8)
+        lib.icgs_make_texture(tex_size, C.c_uint32(seed), self.tex.ctypes.data_as(C.c_void_p))
+        self.rays = np.zeros((height, width, 2), np.float32)
+        lib.icgs_ray_table(self.cam.ctypes.data_as(C.c_void_p), width, height, self.rays.ctypes.data_as(C.c_void_p))
+        a = np.deg2rad(25.0)
+        self.n = np.array([-np.sin(a), 0.0, np.cos(a)])
+        self.plane = np.array([*self.n, 20.0 * np.cos(a)])
+        self.e1 = np.array([np.cos(a), 0.0, np.sin(a)])
+        self.e2 = np.array([0.0, 1.0, 0.0])
+        self.texels_per_m = 40.0 * width / 1280.0
+
+    def pose(self, k, fps=20.0, stream=0):
+        """True camera pose of frame k: (R camera->world 3x3, t 3)."""
+        tau = k / fps
+        ph = 0.37 * stream
+        t = np.array([4.0 * tau + 7.3 * stream, 0.3 * np.sin(0.7 * tau + ph), 1.0 * tau])
+        R = _rot_yp(0.05 * np.sin(0.5 * tau + ph), 0.03 * np.sin(0.8 * tau + ph))
+        return R, t
+
+    def ins_pose(self, k, fps=20.0, stream=0, seed=0):
+        """INS prior = truth + N(0, 0.02 m / 0.1 deg), deterministic per (stream, frame)."""
+        R, t = self.pose(k, fps, stream)
+        rng = np.random.RandomState((seed * 1000003 + stream * 7919 + k) & 0x7fffffff)
+        dt = rng.normal(0, 0.02, 3)
+        dy, dp = rng.normal(0, np.deg2rad(0.1), 2)
+        return R @ _rot_yp(dy, dp), t + dt
+
+    def render(self, k, fps=20.0, stream=0):
+        R, t = self.pose(k, fps, stream)
+        pose12 = np.concatenate([R.ravel(), t]).astype(np.float64)
+        out = np.zeros((self.h, self.w), np.uint8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.lib.icgs_render(p(self.tex), self.tex_size, C.c_double(self.texels_per_m), p(self.rays), self.w, self.h, p(pose12),
+                             p(self.plane), p(self.e1), p(self.e2), p(out), self.w, self.threads)
+        return out
+
+
+def pingpong(k, n):
+    """frame index sequence 0,1,..,n-1,n-2,..,1,0,1,.. (continuous motion for arbitrarily long runs)"""
+    period = 2 * (n - 1)
+    m = k % period
+    return m if m < n else period - m
+
+
+class StreamBatch:
+    """ctypes driver of icgh_batch (host/capi.cc): N independent streams tracked in lock-step on one device."""
+
+    def __init__(self, lib_path, n_streams, width, height, cam10, max_features=300, window=10, min_parallax=20.0,
+                 max_interval=0.5, check_hist=False, reproj_std=1.5, device=0, host_threads=1):
+        if not os.path.exists(lib_path):
+            raise RuntimeError(f"{lib_path} not found (build first; there is no fallback)")
+        self.lib = C.CDLL(lib_path)
+        self.lib.icgh_batch_create.restype = C.c_void_p
+        self.lib.icgh_batch_ctx.restype = C.c_void_p
+        self.lib.icgh_batch_ctx.argtypes = [C.c_void_p]
+        self.lib.icgh_batch_destroy.argtypes = [C.c_void_p]
+        self.n, self.w, self.h = n_streams, width, height
+        err = C.create_string_buffer(512)
+        cam = np.asarray(cam10, np.float64)
+        self.h_ = self.lib.icgh_batch_create(device, n_streams, cam.ctypes.data_as(C.c_void_p), width, height, max_features,
+                                             C.c_double(min_parallax), C.c_double(max_interval), 1 if check_hist else 0,
+                                             C.c_double(reproj_std), window, host_threads, err, 512)
+        if not self.h_:
+            raise RuntimeError("icgh_batch_create failed: " + err.value.decode())
+        self._err = err
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.lib.icgh_batch_destroy(C.c_void_p(self.h_))
+            self.h_ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ctx_handle(self):
+        return self.lib.icgh_batch_ctx(C.c_void_p(self.h_))
+
+    def step(self, image_ptrs, stride, stamps, poses12, on_device=False, channels=1):
+        """image_ptrs: list of int addresses (host or device) or None per stream."""
+        ptrs = (C.c_void_p * self.n)(*[(p if p else None) for p in image_ptrs])
+        stamps = np.ascontiguousarray(stamps, np.float64)
+        poses12 = np.ascontiguousarray(poses12, np.float64)
+        states = np.zeros(self.n, np.int32)
+        rc = self.lib.icgh_batch_step(C.c_void_p(self.h_), ptrs, stride, channels, 1 if on_device else 0,
+                                      stamps.ctypes.data_as(C.c_void_p), poses12.ctypes.data_as(C.c_void_p),
+                                      states.ctypes.data_as(C.c_void_p), self._err, 512)
+        if rc != 0:
+            raise RuntimeError("icgh_batch_step failed: " + self._err.value.decode())
+        return states
+
+    def stats(self, stream):
+        out = np.zeros(8, np.uint64)
+        self.lib.icgh_batch_stats(C.c_void_p(self.h_), stream, out.ctypes.data_as(C.c_void_p))
+        keys = ["frames", "keyframes", "tracked_sum", "digest", "mappoints_created", "window_keyframes", "landmarks", "last_state"]
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def features(self, stream, max_n=2048):
+        ids = np.zeros(max_n, np.uint64)
+        px = np.zeros((max_n, 2), np.float32)
+        n = self.lib.icgh_batch_features(C.c_void_p(self.h_), stream, max_n, ids.ctypes.data_as(C.c_void_p),
+                                         px.ctypes.data_as(C.c_void_p))
+        return ids[:n], px[:n]
+
+
+def pose12(R, t):
+    return np.concatenate([np.asarray(R, np.float64).ravel(), np.asarray(t, np.float64)])

@@ -1,0 +1,202 @@
+#include "tracking_batch.h"
+
+#include <atomic>
+
+namespace icg {
+
+TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &intrinsic, const vector<double> &distortion,
+                             const vector<int> &size, const TrackingConfig &cfg, int window_size, int host_threads)
+    : host_threads_(host_threads < 1 ? 1 : host_threads) {
+    device_ = std::make_shared<DeviceContext>(device, size[0], size[1], n_streams, cfg.track_max_features);
+    streams_.resize((size_t) n_streams);
+    for (int i = 0; i < n_streams; i++) {
+        Stream &s  = streams_[(size_t) i];
+        s.camera   = Camera::createCamera(intrinsic, distortion, size);
+        s.map      = std::make_shared<Map>((size_t) window_size);
+        s.ids      = std::make_shared<IdSpace>();
+        s.tracking = std::make_shared<Tracking>(s.camera, s.map, nullptr, cfg, "", device_, s.ids);
+        s.keeper   = std::make_shared<WindowKeeper>(s.map);
+    }
+    device_->setCamera(*streams_[0].camera);
+    grid_        = streams_[0].tracking->grid();
+    max_per_job_ = streams_[0].tracking->maxFeaturesPerJob();
+}
+
+template <typename F> void TrackingBatch::forEachStream(F &&f) {
+    const int n = (int) streams_.size();
+    if (host_threads_ <= 1 || n < 2) {
+        for (int i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            int i = next.fetch_add(1);
+            if (i >= n) break;
+            f(i);
+        }
+    };
+    int nt = std::min(host_threads_, n);
+    vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+}
+
+template <typename T> static void append(vector<T> &dst, const vector<T> &src) { dst.insert(dst.end(), src.begin(), src.end()); }
+
+// bases[i] = {pre, det, mask_pts, lk, rs_set, rs_pts, tri, tri_T}
+void TrackingBatch::gather(int cur, StageBatch &g, vector<std::array<int, 8>> &bases) {
+    g.clear();
+    bases.assign(streams_.size(), {});
+    for (size_t i = 0; i < streams_.size(); i++) {
+        const StageBatch &b = streams_[i].box[cur];
+        auto &B             = bases[i];
+        B[0] = (int) g.pre_slots.size();
+        B[1] = (int) g.det_slots.size();
+        B[2] = (int) (g.det_mask_pts.size() / 2);
+        B[3] = (int) g.lk_prev_slot.size();
+        B[4] = (int) g.rs_off.size() - 1;
+        B[5] = (int) (g.rs_p1.size() / 2);
+        B[6] = (int) g.tri_T0.size();
+        B[7] = (int) (g.tri_Tcw.size() / 12);
+        if (!b.pre_slots.empty()) {
+            append(g.pre_slots, b.pre_slots);
+            append(g.pre_imgs, b.pre_imgs);
+            g.pre_stride   = b.pre_stride;
+            g.pre_channels = b.pre_channels;
+            g.pre_device   = b.pre_device;
+            g.pre_want_hist |= b.pre_want_hist;
+        }
+        if (!b.det_slots.empty()) {
+            append(g.det_slots, b.det_slots);
+            append(g.det_quota, b.det_quota);
+            append(g.det_mask_pts, b.det_mask_pts);
+            for (size_t k = 1; k < b.det_mask_off.size(); k++) g.det_mask_off.push_back(b.det_mask_off[k] + B[2]);
+        }
+        if (!b.lk_prev_slot.empty()) {
+            append(g.lk_prev_slot, b.lk_prev_slot);
+            append(g.lk_next_slot, b.lk_next_slot);
+            append(g.lk_prev, b.lk_prev);
+            append(g.lk_guess, b.lk_guess);
+        }
+        if (b.rs_off.size() > 1) {
+            append(g.rs_p1, b.rs_p1);
+            append(g.rs_p2, b.rs_p2);
+            for (size_t k = 1; k < b.rs_off.size(); k++) g.rs_off.push_back(b.rs_off[k] + B[5]);
+            g.rs_thresh = b.rs_thresh;
+            g.rs_conf   = b.rs_conf;
+        }
+        if (!b.tri_T0.empty()) {
+            for (int v : b.tri_T0) g.tri_T0.push_back(v + B[7]);
+            for (int v : b.tri_T1) g.tri_T1.push_back(v + B[7]);
+            append(g.tri_pc0, b.tri_pc0);
+            append(g.tri_pc1, b.tri_pc1);
+        }
+        append(g.tri_Tcw, b.tri_Tcw);
+    }
+}
+
+void TrackingBatch::scatter(int cur, const StageBatch &g, const vector<std::array<int, 8>> &bases) {
+    for (size_t i = 0; i < streams_.size(); i++) {
+        StageBatch &b = streams_[i].box[cur];
+        const auto &B = bases[i];
+        if (!b.pre_slots.empty() && !g.pre_hist.empty())
+            b.pre_hist.assign(g.pre_hist.begin() + B[0], g.pre_hist.begin() + B[0] + (long) b.pre_slots.size());
+        if (!b.det_slots.empty()) {
+            size_t n = b.det_slots.size();
+            b.det_count.assign(g.det_count.begin() + B[1], g.det_count.begin() + B[1] + (long) n);
+            b.det_out.assign(g.det_out.begin() + (size_t) B[1] * max_per_job_ * 2,
+                             g.det_out.begin() + ((size_t) B[1] + n) * max_per_job_ * 2);
+        }
+        if (!b.lk_prev_slot.empty()) {
+            size_t n = b.lk_prev_slot.size();
+            b.lk_status.assign(g.lk_status.begin() + B[3], g.lk_status.begin() + B[3] + (long) n);
+            b.lk_out.assign(g.lk_out.begin() + 2 * (size_t) B[3], g.lk_out.begin() + 2 * ((size_t) B[3] + n));
+            b.lk_undist.assign(g.lk_undist.begin() + 2 * (size_t) B[3], g.lk_undist.begin() + 2 * ((size_t) B[3] + n));
+        }
+        if (b.rs_off.size() > 1) {
+            size_t n = (size_t) b.rs_off.back();
+            b.rs_mask.assign(g.rs_mask.begin() + B[5], g.rs_mask.begin() + B[5] + (long) n);
+        }
+        if (!b.tri_T0.empty()) {
+            size_t n = b.tri_T0.size();
+            b.tri_pw.assign(g.tri_pw.begin() + 3 * (size_t) B[6], g.tri_pw.begin() + 3 * ((size_t) B[6] + n));
+        }
+    }
+}
+
+static inline void fnv(uint64_t &h, const void *p, size_t n) {
+    const unsigned char *c = (const unsigned char *) p;
+    for (size_t i = 0; i < n; i++) {
+        h ^= c[i];
+        h *= 1099511628211ull;
+    }
+}
+
+void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &states) {
+    const int n = (int) streams_.size();
+    states.assign((size_t) n, TRACK_PASSED);
+    vector<char> active((size_t) n, 0);
+    int cur = 0;
+    forEachStream([&](int i) {
+        Stream &s = streams_[(size_t) i];
+        s.box[0].clear();
+        s.box[1].clear();
+        if (frames[(size_t) i]) {
+            active[(size_t) i] = 1;
+            s.tracking->beginFrame(frames[(size_t) i], s.box[0]);
+        }
+    });
+    StageBatch global;
+    vector<std::array<int, 8>> bases;
+    for (int stage = 1; stage < Tracking::N_STAGES; stage++) {
+        gather(cur, global, bases);
+        device_->execute(global, grid_, max_per_job_);
+        scatter(cur, global, bases);
+        const int nxt = cur ^ 1;
+        bool any      = false;
+        forEachStream([&](int i) {
+            Stream &s = streams_[(size_t) i];
+            s.box[nxt].clear();
+            if (active[(size_t) i] && !s.tracking->frameDone()) s.tracking->advance(stage, s.box[cur], s.box[nxt]);
+        });
+        for (int i = 0; i < n; i++)
+            if (active[(size_t) i] && !streams_[(size_t) i].tracking->frameDone()) any = true;
+        cur = nxt;
+        if (!any) break;
+    }
+    forEachStream([&](int i) {
+        if (!active[(size_t) i]) return;
+        Stream &s  = streams_[(size_t) i];
+        TrackState st = s.tracking->result();
+        states[(size_t) i] = st;
+        s.last_state       = st;
+        s.frames++;
+        if (s.tracking->isNewKeyFrame() || st == TRACK_FIRST_FRAME || st == TRACK_LOST) s.keyframes++;
+        // digest of everything index-like this frame produced: state, frame id, (map-point id, pixel bits) per feature
+        // in id order, and the surviving un-triangulated reference points
+        auto frame = frames[(size_t) i];
+        int sti    = (int) st;
+        fnv(s.digest, &sti, sizeof sti);
+        ulong fid = frame->id();
+        fnv(s.digest, &fid, sizeof fid);
+        if (st != TRACK_PASSED) {
+            auto feats = frame->features();
+            vector<ulong> idsv;
+            for (auto &kv : feats) idsv.push_back(kv.first);
+            std::sort(idsv.begin(), idsv.end());
+            for (ulong id : idsv) {
+                const Point2f &kp = feats[id]->distortedKeyPoint();
+                fnv(s.digest, &id, sizeof id);
+                fnv(s.digest, &kp, sizeof kp);
+            }
+            s.tracked_sum += feats.size();
+            uint64_t nref = s.tracking->numTrackedRefPoints();
+            fnv(s.digest, &nref, sizeof nref);
+        }
+        s.keeper->onFrame(*s.tracking, frame, st);
+    });
+}
+
+} // namespace icg

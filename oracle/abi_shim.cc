@@ -1,0 +1,237 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+// The C ABI of include/icgvins_hip.h implemented on the CPU restatement (orc_*), so that the SAME host layer
+// (ic-gvins_amd/host/*.cc: Tracking, TrackingBatch, ...) can be linked a second time against the oracle:
+//   oracle/libicgvins_host_oracle.so = host sources + this shim + orc_*.o
+// Used by tests/ for end-to-end parity (HIP-backed vs oracle-backed streams must produce identical track ids,
+// states and digests) and by bench.py's cpu_baseline leg (kind "port").  It is never linked into, loaded by or
+// shipped with the product libraries (libicgvins_hip.so / libicgvins_host.so).
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/icgvins_hip.h"
+#include "oracle.h"
+
+struct icg_ctx {
+    icg_ctx_config cfg;
+    std::string err;
+    std::vector<std::vector<uint8_t>> slots; // CLAHE image (level 0), w*h
+    icg_camera cam{};
+    bool has_cam = false;
+    int threads  = 1;
+};
+
+static std::string g_err;
+
+template <typename F> static void parallel_for(int n, int threads, F &&f) {
+    if (threads <= 1 || n < 2) {
+        for (int i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            int i = next.fetch_add(1);
+            if (i >= n) break;
+            f(i);
+        }
+    };
+    std::vector<std::thread> th;
+    int nt = std::min(threads, n);
+    for (int t = 1; t < nt; t++) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+}
+
+extern "C" {
+
+const char *icg_version(void) { return "icgvins ORACLE shim (CPU restatement, test infrastructure)"; }
+const char *icg_last_error(const icg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int icg_ctx_create(const icg_ctx_config *cfg, icg_ctx **out) {
+    if (!cfg || !out) return ICG_ERR_INVALID;
+    icg_ctx *c = new icg_ctx();
+    c->cfg     = *cfg;
+    c->slots.resize((size_t) cfg->n_slots);
+    const char *t = getenv("ICG_ORACLE_THREADS");
+    c->threads    = t ? std::max(1, atoi(t)) : 1;
+    *out          = c;
+    return ICG_OK;
+}
+void icg_ctx_destroy(icg_ctx *ctx) { delete ctx; }
+int icg_ctx_sync(icg_ctx *) { return ICG_OK; }
+void *icg_ctx_stream(icg_ctx *) { return nullptr; }
+int icg_set_camera(icg_ctx *ctx, const icg_camera *cam) {
+    ctx->cam     = *cam;
+    ctx->has_cam = true;
+    return ICG_OK;
+}
+int icg_pyramid_levels(const icg_ctx *ctx) { return orc_pyramid_levels(ctx->cfg.width, ctx->cfg.height, 3, 21); }
+int icg_prof_enable(icg_ctx *, int) { return ICG_OK; }
+int icg_prof_get(icg_ctx *, const char *, int *l, double *ms) {
+    if (l) *l = 0;
+    if (ms) *ms = 0;
+    return ICG_OK;
+}
+int icg_prof_names(icg_ctx *, char *buf, int n) {
+    if (buf && n > 0) buf[0] = 0;
+    return ICG_OK;
+}
+
+int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, const uint8_t *const *images, int stride, int channels,
+                          int src_on_device, double *hist_mean) {
+    if (src_on_device) {
+        ctx->err = "oracle shim: device images are not supported";
+        return ICG_ERR_INVALID;
+    }
+    const int w = ctx->cfg.width, h = ctx->cfg.height;
+    parallel_for(n, ctx->threads, [&](int k) {
+        std::vector<uint8_t> gray((size_t) w * h);
+        if (channels == 3)
+            orc_bgr2gray(images[k], w, h, stride, gray.data(), w);
+        else
+            for (int y = 0; y < h; y++) memcpy(&gray[(size_t) y * w], images[k] + (size_t) y * stride, (size_t) w);
+        if (hist_mean) hist_mean[k] = orc_histogram_mean(gray.data(), w, h, w);
+        auto &dst = ctx->slots[(size_t) slots[k]];
+        dst.resize((size_t) w * h);
+        orc_clahe(gray.data(), w, h, w, 3.0, 21, dst.data(), w, nullptr);
+    });
+    return ICG_OK;
+}
+
+int icg_frame_download(icg_ctx *ctx, int slot, int level, uint8_t *dst, int dst_stride) {
+    int w = ctx->cfg.width, h = ctx->cfg.height;
+    std::vector<uint8_t> cur = ctx->slots[(size_t) slot], nxt;
+    for (int l = 0; l < level; l++) {
+        nxt.resize((size_t) ((w + 1) / 2) * ((h + 1) / 2));
+        orc_pyrdown(cur.data(), w, h, w, nxt.data(), (w + 1) / 2);
+        w = (w + 1) / 2;
+        h = (h + 1) / 2;
+        cur.swap(nxt);
+    }
+    for (int y = 0; y < h; y++) memcpy(dst + (size_t) y * dst_stride, &cur[(size_t) y * w], (size_t) w);
+    return ICG_OK;
+}
+
+int icg_lk_track(icg_ctx *ctx, int n, const int32_t *prev_slot, const int32_t *next_slot, const float *prev_pts,
+                 float *next_pts, uint8_t *status, float *err) {
+    const int w = ctx->cfg.width, h = ctx->cfg.height;
+    std::map<std::pair<int, int>, std::vector<int>> groups;
+    for (int i = 0; i < n; i++) groups[{prev_slot[i], next_slot[i]}].push_back(i);
+    std::vector<std::pair<std::pair<int, int>, std::vector<int>>> G(groups.begin(), groups.end());
+    parallel_for((int) G.size(), ctx->threads, [&](int g) {
+        auto &idx = G[(size_t) g].second;
+        int m     = (int) idx.size();
+        std::vector<float> pp(2 * (size_t) m), np(2 * (size_t) m), e((size_t) m);
+        std::vector<uint8_t> st((size_t) m);
+        for (int k = 0; k < m; k++) {
+            pp[2 * k] = prev_pts[2 * idx[k]], pp[2 * k + 1] = prev_pts[2 * idx[k] + 1];
+            np[2 * k] = next_pts[2 * idx[k]], np[2 * k + 1] = next_pts[2 * idx[k] + 1];
+        }
+        orc_lk_track(ctx->slots[(size_t) G[g].first.first].data(), ctx->slots[(size_t) G[g].first.second].data(), w, h, w, m,
+                     pp.data(), np.data(), st.data(), e.data());
+        for (int k = 0; k < m; k++) {
+            next_pts[2 * idx[k]] = np[2 * k], next_pts[2 * idx[k] + 1] = np[2 * k + 1];
+            status[idx[k]] = st[k];
+            if (err) err[idx[k]] = e[k];
+        }
+    });
+    return ICG_OK;
+}
+
+int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, const int32_t *next_slot, const float *prev_pts,
+                    const float *guess_pts, float *out_pts, uint8_t *status, float *out_undist, int32_t *keep_idx,
+                    int32_t *n_keep) {
+    const int w = ctx->cfg.width, h = ctx->cfg.height;
+    std::map<std::pair<int, int>, std::vector<int>> groups;
+    for (int i = 0; i < n; i++) groups[{prev_slot[i], next_slot[i]}].push_back(i);
+    std::vector<std::pair<std::pair<int, int>, std::vector<int>>> G(groups.begin(), groups.end());
+    parallel_for((int) G.size(), ctx->threads, [&](int g) {
+        auto &idx = G[(size_t) g].second;
+        int m     = (int) idx.size();
+        std::vector<float> pp(2 * (size_t) m), gs(2 * (size_t) m), op(2 * (size_t) m);
+        std::vector<uint8_t> st((size_t) m);
+        for (int k = 0; k < m; k++) {
+            pp[2 * k] = prev_pts[2 * idx[k]], pp[2 * k + 1] = prev_pts[2 * idx[k] + 1];
+            gs[2 * k] = guess_pts[2 * idx[k]], gs[2 * k + 1] = guess_pts[2 * idx[k] + 1];
+        }
+        orc_lk_track_fb(ctx->slots[(size_t) G[g].first.first].data(), ctx->slots[(size_t) G[g].first.second].data(), w, h, w, m,
+                        pp.data(), gs.data(), op.data(), st.data());
+        for (int k = 0; k < m; k++) {
+            out_pts[2 * idx[k]] = op[2 * k], out_pts[2 * idx[k] + 1] = op[2 * k + 1];
+            status[idx[k]] = st[k];
+        }
+    });
+    if (out_undist) {
+        memcpy(out_undist, out_pts, sizeof(float) * 2 * (size_t) n);
+        orc_undistort_points(&ctx->cam.fx, n, out_undist);
+    }
+    if (keep_idx) {
+        int c = 0;
+        for (int i = 0; i < n; i++)
+            if (status[i]) keep_idx[c++] = i;
+        *n_keep = c;
+    }
+    return ICG_OK;
+}
+
+int icg_undistort_points(icg_ctx *ctx, int n, float *pts) {
+    orc_undistort_points(&ctx->cam.fx, n, pts);
+    return ICG_OK;
+}
+int icg_distort_points(icg_ctx *ctx, int n, float *pts) {
+    orc_distort_points(&ctx->cam.fx, n, pts);
+    return ICG_OK;
+}
+
+int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, const float *pts1, const float *pts2, double thresh,
+                  double conf, uint8_t *mask) {
+    parallel_for(n_sets, ctx->threads, [&](int s) {
+        int b = offsets[s], n = offsets[s + 1] - offsets[s];
+        if (n < 15) {
+            for (int i = 0; i < n; i++) mask[b + i] = 1;
+            return;
+        }
+        orc_find_fundamental_ransac(n, pts1 + 2 * (size_t) b, pts2 + 2 * (size_t) b, thresh, conf, mask + b, nullptr, nullptr);
+    });
+    return ICG_OK;
+}
+
+int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_detect_grid *grid, const int32_t *mask_off,
+               const float *mask_pts, const int32_t *quota, int max_per_job, float *out_pts, int32_t *out_count,
+               int32_t *out_block) {
+    const int w = ctx->cfg.width, h = ctx->cfg.height;
+    const int g6[6] = {grid->block_cols, grid->block_rows, grid->block_w, grid->block_h, grid->min_dist, grid->max_per_block};
+    const int nblk  = grid->block_cols * grid->block_rows;
+    parallel_for(n, ctx->threads, [&](int k) {
+        std::vector<int> q((size_t) nblk);
+        for (int b = 0; b < nblk; b++) q[(size_t) b] = std::min(quota[(size_t) k * nblk + b], grid->max_per_block);
+        out_count[k] = orc_detect(ctx->slots[(size_t) slots[k]].data(), w, h, w, g6, mask_off[k + 1] - mask_off[k],
+                                  mask_pts + 2 * (size_t) mask_off[k], q.data(), max_per_job,
+                                  out_pts + (size_t) k * max_per_job * 2, out_block ? out_block + (size_t) k * max_per_job : nullptr);
+    });
+    return ICG_OK;
+}
+
+int icg_triangulate(icg_ctx *, int n, const int32_t *T0_idx, const int32_t *T1_idx, int, const double *Tcw12, const double *pc0,
+                    const double *pc1, double *pw) {
+    for (int i = 0; i < n; i++)
+        orc_triangulate_point(Tcw12 + 12 * (size_t) T0_idx[i], Tcw12 + 12 * (size_t) T1_idx[i], pc0 + 3 * (size_t) i,
+                              pc1 + 3 * (size_t) i, pw + 3 * (size_t) i);
+    return ICG_OK;
+}
+
+int icg_reproj_eval_batch(icg_ctx *, int n, const double *obs_soa, const int32_t *idx_i, const int32_t *idx_j,
+                          const int32_t *idx_lm, int, const double *poses, const double *ext, int, const double *invdepth,
+                          double td, int want_jac, double huber_delta, double *out_r, double *out_J) {
+    orc_reproj_eval_batch(n, obs_soa, idx_i, idx_j, idx_lm, poses, ext, invdepth, td, want_jac, out_r, out_J);
+    if (huber_delta > 0) orc_huber_correct_2x46(n, huber_delta, out_r, want_jac ? out_J : nullptr);
+    return ICG_OK;
+}
+
+} // extern "C"

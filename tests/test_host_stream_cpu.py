@@ -1,0 +1,48 @@
+"""CPU tests of the host layer (Tracking state machine, TrackingBatch, WindowKeeper) linked against the oracle ABI shim:
+exercises exactly the host code that ships, with the CPU restatement standing in for the GPU."""
+import numpy as np
+
+import harness as H
+from stream_utils import ensure_oracle_host, run_streams
+
+
+def test_single_stream_initialises_and_tracks():
+    lib = ensure_oracle_host()
+    rec, stats, _ = run_streams(lib, 1, 640, 480, 24, 100)
+    states = [H.TRACK_STATES[r[0][0]] for r in rec]
+    assert states[0] == "FIRST_FRAME"
+    assert "INITIALIZING" in states and states[-1] == "TRACKING"
+    first_tracking = states.index("TRACKING")
+    assert 1 < first_tracking < 12
+    assert all(s == "TRACKING" for s in states[first_tracking:])
+    # map points were triangulated and keep being tracked
+    assert stats[0]["mappoints_created"] > 50
+    assert len(rec[-1][0][1]) > 50
+    # ids are stable: features of consecutive frames share most map-point ids
+    a, b = set(rec[-2][0][1].tolist()), set(rec[-1][0][1].tolist())
+    assert len(a & b) > 0.8 * len(b)
+    assert stats[0]["keyframes"] >= 3 and stats[0]["window_keyframes"] <= 11
+
+
+def test_window_keeper_bounds_the_window():
+    lib = ensure_oracle_host()
+    rec, stats, _ = run_streams(lib, 1, 640, 480, 40, 100, window=3)
+    assert stats[0]["keyframes"] > 4
+    assert stats[0]["window_keyframes"] <= 4
+
+
+def test_batch_equals_individual_streams():
+    """Shard invariance: 3 streams in one lock-step batch == the same streams run one by one,
+    with and without host threads."""
+    lib = ensure_oracle_host()
+    rec_b, stats_b, frames = run_streams(lib, 3, 640, 480, 14, 100)
+    rec_t, stats_t, _ = run_streams(lib, 3, 640, 480, 14, 100, scene_frames=frames, host_threads=3)
+    for s in range(3):
+        rec_1, stats_1, _ = run_streams(lib, 1, 640, 480, 14, 100, scene_frames=frames, stream_ids=[s])
+        assert stats_1[0]["digest"] == stats_b[s]["digest"] == stats_t[s]["digest"]
+        for k in range(14):
+            assert rec_1[k][0][0] == rec_b[k][s][0]
+            assert np.array_equal(rec_1[k][0][1], rec_b[k][s][1])
+            assert np.array_equal(rec_1[k][0][2].view(np.uint32), rec_b[k][s][2].view(np.uint32))
+    # different streams see different imagery
+    assert stats_b[0]["digest"] != stats_b[1]["digest"]
