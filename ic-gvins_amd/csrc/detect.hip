@@ -128,30 +128,43 @@ __global__ __launch_bounds__(256) void k_candidates(const det_roi *rois, int pit
                                                     const unsigned int *roi_max, unsigned long long *cand,
                                                     size_t cand_plane, int32_t *cand_cnt) {
     const det_roi R = rois[blockIdx.z];
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane;
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < 1 || x >= R.rw - 1 || y < 1 || y >= R.rh - 1) return;
-    const unsigned int mk = roi_max[blockIdx.z];
-    const double maxVal   = mk ? (double) f32_from_order_key(mk) : 0.0;
-    const float thresh    = (float) (maxVal * 0.01);
-    const float *e        = eig + (size_t) R.job * eig_plane + (size_t) (R.ry + y) * w + (R.rx + x);
-    float v               = e[0];
-    v                     = v > thresh ? v : 0.f;
-    if (v == 0.f) return;
-    float mx = v;
+    bool is_cand = false;
+    float v      = 0.f;
+    if (!(x < 1 || x >= R.rw - 1 || y < 1 || y >= R.rh - 1)) {
+        const unsigned int mk = roi_max[blockIdx.z];
+        const double maxVal   = mk ? (double) f32_from_order_key(mk) : 0.0;
+        const float thresh    = (float) (maxVal * 0.01);
+        const float *e        = eig + (size_t) R.job * eig_plane + (size_t) (R.ry + y) * w + (R.rx + x);
+        v                     = e[0];
+        v                     = v > thresh ? v : 0.f;
+        if (v != 0.f) {
+            float mx = v;
 #pragma unroll
-    for (int j = -1; j <= 1; j++)
+            for (int j = -1; j <= 1; j++)
 #pragma unroll
-        for (int i = -1; i <= 1; i++) {
-            float n = e[j * w + i];
-            n       = n > thresh ? n : 0.f;
-            mx      = n > mx ? n : mx;
+                for (int i = -1; i <= 1; i++) {
+                    float n = e[j * w + i];
+                    n       = n > thresh ? n : 0.f;
+                    mx      = n > mx ? n : mx;
+                }
+            is_cand = (v == mx) && mask[(size_t) R.job * mask_plane + (size_t) (R.ry + y) * pitch + (R.rx + x)];
         }
-    if (v != mx) return;
-    if (!mask[(size_t) R.job * mask_plane + (size_t) (R.ry + y) * pitch + (R.rx + x)]) return;
-    const int slot = atomicAdd(&cand_cnt[blockIdx.z], 1);
-    cand[(size_t) R.job * cand_plane + R.cand_base + slot] =
-        ((unsigned long long) f32_order_key(v) << 32) | (unsigned int) (y * R.rw + x);
+    }
+    // wave-aggregated append: one atomic per wavefront instead of one per candidate
+    const unsigned long long m = __ballot(is_cand);
+    if (m == 0) return;
+    int base = 0;
+    const int leader = __ffsll((long long) m) - 1;
+    if (lane == leader) base = atomicAdd(&cand_cnt[blockIdx.z], __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (is_cand) {
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        cand[(size_t) R.job * cand_plane + R.cand_base + slot] =
+            ((unsigned long long) f32_order_key(v) << 32) | (unsigned int) (y * R.rw + x);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

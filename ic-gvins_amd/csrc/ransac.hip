@@ -6,8 +6,9 @@
 // best/niters replay).  Mapping:
 //   * the hypothesis index stream depends only on cv::RNG's state, not on scores, so it is generated up front on the
 //     host (same LCG as cv::RNG((uint64)-1)) for a chunk of hypotheses;
-//   * k_seven_point: ONE LANE per hypothesis; the 7x9 system and the 9x9 rotation accumulator live in LDS laid out
-//     [element][lane] (conflict-free), only + - * / sqrt are used so results match the CPU restatement bit-for-bit;
+//   * k_seven_point: ONE LANE per hypothesis; as cv::SVDecomp does for m < n, the one-sided Jacobi runs on the 7
+//     full-rank columns of A^T (9x7, REGISTER resident, fully unrolled) and the two null vectors come from completing the
+//     orthonormal basis; only + - * / sqrt are used so results match the CPU restatement bit-for-bit;
 //   * k_fm_score: ONE WAVEFRONT per (hypothesis, model): 64 points per step, symmetric epipolar distance in double,
 //     inlier bits by wave ballot, count by popcount;
 //   * the host replays the `best / niters` recurrence over the score array in hypothesis order, which makes the result
@@ -19,8 +20,6 @@
 #include "icg_internal.h"
 
 #define SP_LANES 64
-#define SP_G(k, j) sG[((k) * 9 + (j)) * SP_LANES + lane]
-#define SP_V(k, j) sV[((k) * 9 + (j)) * SP_LANES + lane]
 
 struct fm_set {
     int pt_begin, n_pts; // range in the concatenated point arrays
@@ -94,81 +93,112 @@ __device__ int dev_solve_cubic_real(const double c[4], double roots[3]) {
     return n;
 }
 
-__global__ __launch_bounds__(SP_LANES) void k_seven_point(int n_hyp_total, const fm_set *sets, const int32_t *hyp_set,
-                                                          const int32_t *hyp_idx /*n_hyp x 7 (set-local)*/,
-                                                          const float2 *pts1, const float2 *pts2,
-                                                          double *models /*n_hyp x 3 x 9*/, int32_t *n_models) {
-    __shared__ double sG[7 * 9 * SP_LANES];
-    __shared__ double sV[9 * 9 * SP_LANES];
+__global__ __launch_bounds__(SP_LANES, 1) void k_seven_point(int n_hyp_total, const fm_set *sets, const int32_t *hyp_set,
+                                                             const int32_t *hyp_idx /*n_hyp x 7 (set-local)*/,
+                                                             const float2 *pts1, const float2 *pts2,
+                                                             double *models /*n_hyp x 3 x 9*/, int32_t *n_models) {
     const int lane = threadIdx.x;
     const int hyp  = blockIdx.x * SP_LANES + lane;
     if (hyp >= n_hyp_total) return;
     const fm_set S     = sets[hyp_set[hyp]];
     const int32_t *idx = hyp_idx + 7 * (size_t) hyp;
+    // M = A^T (9 x 7) register resident; see oracle/orc_ransac.cc null_space_9x7 for the definition this mirrors.
+    double M[9][7];
+#pragma unroll
     for (int i = 0; i < 7; i++) {
         const float2 a = pts1[S.pt_begin + idx[i]], b = pts2[S.pt_begin + idx[i]];
         const double x1 = a.x, y1 = a.y, x2 = b.x, y2 = b.y;
-        SP_G(i, 0) = x2 * x1;
-        SP_G(i, 1) = x2 * y1;
-        SP_G(i, 2) = x2;
-        SP_G(i, 3) = y2 * x1;
-        SP_G(i, 4) = y2 * y1;
-        SP_G(i, 5) = y2;
-        SP_G(i, 6) = x1;
-        SP_G(i, 7) = y1;
-        SP_G(i, 8) = 1;
+        M[0][i] = x2 * x1;
+        M[1][i] = x2 * y1;
+        M[2][i] = x2;
+        M[3][i] = y2 * x1;
+        M[4][i] = y2 * y1;
+        M[5][i] = y2;
+        M[6][i] = x1;
+        M[7][i] = y1;
+        M[8][i] = 1;
     }
-    for (int i = 0; i < 9; i++)
-        for (int j = 0; j < 9; j++) SP_V(i, j) = (i == j) ? 1.0 : 0.0;
-    // one-sided Jacobi, cyclic (p,q) order, <= 30 sweeps
     for (int sweep = 0; sweep < 30; sweep++) {
         bool changed = false;
-        for (int p = 0; p < 8; p++)
-            for (int q = p + 1; q < 9; q++) {
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int q = p + 1; q < 7; q++) {
                 double alpha = 0, beta = 0, gamma = 0;
-                for (int k = 0; k < 7; k++) {
-                    double gp = SP_G(k, p), gq = SP_G(k, q);
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    double gp = M[k][p], gq = M[k][q];
                     alpha += gp * gp;
                     beta += gq * gq;
                     gamma += gp * gq;
                 }
-                if (gamma == 0.0) continue;
-                if (fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) continue;
-                changed     = true;
-                double zeta = (beta - alpha) / (2.0 * gamma);
-                double t    = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                if (zeta < 0) t = -t;
-                double c = 1.0 / sqrt(1.0 + t * t);
-                double s = c * t;
-                for (int k = 0; k < 7; k++) {
-                    double gp = SP_G(k, p), gq = SP_G(k, q);
-                    SP_G(k, p) = c * gp - s * gq;
-                    SP_G(k, q) = s * gp + c * gq;
-                }
-                for (int k = 0; k < 9; k++) {
-                    double vp = SP_V(k, p), vq = SP_V(k, q);
-                    SP_V(k, p) = c * vp - s * vq;
-                    SP_V(k, q) = s * vp + c * vq;
+                if (gamma != 0.0 && !(fabs(gamma) <= 1e-15 * sqrt(alpha * beta))) {
+                    changed     = true;
+                    double zeta = (beta - alpha) / (2.0 * gamma);
+                    double t    = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    if (zeta < 0) t = -t;
+                    double c = 1.0 / sqrt(1.0 + t * t);
+                    double s = c * t;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) {
+                        double gp = M[k][p], gq = M[k][q];
+                        M[k][p] = c * gp - s * gq;
+                        M[k][q] = s * gp + c * gq;
+                    }
                 }
             }
         if (!changed) break;
     }
-    double nrm[9];
-    for (int j = 0; j < 9; j++) {
+    double B[9][9]; // B[c][k]: basis vector c, coordinate k
+#pragma unroll
+    for (int c = 0; c < 7; c++) {
         double s = 0;
-        for (int k = 0; k < 7; k++) s += SP_G(k, j) * SP_G(k, j);
-        nrm[j] = s;
+#pragma unroll
+        for (int k = 0; k < 9; k++) s += M[k][c] * M[k][c];
+        double w = sqrt(s);
+#pragma unroll
+        for (int k = 0; k < 9; k++) B[c][k] = (w > 0) ? M[k][c] / w : 0.0;
     }
-    int i2 = 0;
-    for (int j = 1; j < 9; j++)
-        if (nrm[j] < nrm[i2]) i2 = j;
-    int i1 = (i2 == 0) ? 1 : 0;
-    for (int j = 0; j < 9; j++)
-        if (j != i2 && nrm[j] < nrm[i1]) i1 = j;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int nb = 7 + t;
+        int js = 0;
+        double best = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            double d = 0;
+#pragma unroll
+            for (int c = 0; c < nb; c++) d += B[c][j] * B[c][j];
+            if (j == 0 || d < best) {
+                best = d;
+                js   = j;
+            }
+        }
+        double v[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) v[k] = (k == js) ? 1.0 : 0.0;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++)
+#pragma unroll
+            for (int c = 0; c < nb; c++) {
+                double d = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) d += B[c][k] * v[k];
+#pragma unroll
+                for (int k = 0; k < 9; k++) v[k] -= d * B[c][k];
+            }
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) s += v[k] * v[k];
+        double w = sqrt(s);
+#pragma unroll
+        for (int k = 0; k < 9; k++) B[nb][k] = (w > 0) ? v[k] / w : 0.0;
+    }
     double f1[9], f2[9];
+#pragma unroll
     for (int k = 0; k < 9; k++) {
-        f1[k] = SP_V(k, i1);
-        f2[k] = SP_V(k, i2);
+        f1[k] = B[7][k];
+        f2[k] = B[8][k];
     }
     for (int i = 0; i < 9; i++) f1[i] -= f2[i];
     double c[4], t0, t1, t2;

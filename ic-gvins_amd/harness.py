@@ -85,20 +85,20 @@ class StreamBatch:
     """ctypes driver of icgh_batch (host/capi.cc): N independent streams tracked in lock-step on one device."""
 
     def __init__(self, lib_path, n_streams, width, height, cam10, max_features=300, window=10, min_parallax=20.0,
-                 max_interval=0.5, check_hist=False, reproj_std=1.5, device=0, host_threads=1):
+                 max_interval=0.5, check_hist=False, reproj_std=1.5, device=0, host_threads=1, groups=1):
         if not os.path.exists(lib_path):
             raise RuntimeError(f"{lib_path} not found (build first; there is no fallback)")
         self.lib = C.CDLL(lib_path)
         self.lib.icgh_batch_create.restype = C.c_void_p
         self.lib.icgh_batch_ctx.restype = C.c_void_p
-        self.lib.icgh_batch_ctx.argtypes = [C.c_void_p]
+        self.lib.icgh_batch_ctx.argtypes = [C.c_void_p, C.c_int]
         self.lib.icgh_batch_destroy.argtypes = [C.c_void_p]
         self.n, self.w, self.h = n_streams, width, height
         err = C.create_string_buffer(512)
         cam = np.asarray(cam10, np.float64)
         self.h_ = self.lib.icgh_batch_create(device, n_streams, cam.ctypes.data_as(C.c_void_p), width, height, max_features,
                                              C.c_double(min_parallax), C.c_double(max_interval), 1 if check_hist else 0,
-                                             C.c_double(reproj_std), window, host_threads, err, 512)
+                                             C.c_double(reproj_std), window, host_threads, groups, err, 512)
         if not self.h_:
             raise RuntimeError("icgh_batch_create failed: " + err.value.decode())
         self._err = err
@@ -114,8 +114,11 @@ class StreamBatch:
         except Exception:
             pass
 
-    def ctx_handle(self):
-        return self.lib.icgh_batch_ctx(C.c_void_p(self.h_))
+    def n_groups(self):
+        return self.lib.icgh_batch_groups(C.c_void_p(self.h_))
+
+    def ctx_handle(self, group=0):
+        return self.lib.icgh_batch_ctx(C.c_void_p(self.h_), group)
 
     def step(self, image_ptrs, stride, stamps, poses12, on_device=False, channels=1):
         """image_ptrs: list of int addresses (host or device) or None per stream."""
@@ -135,6 +138,11 @@ class StreamBatch:
         self.lib.icgh_batch_stats(C.c_void_p(self.h_), stream, out.ctypes.data_as(C.c_void_p))
         keys = ["frames", "keyframes", "tracked_sum", "digest", "mappoints_created", "window_keyframes", "landmarks", "last_state"]
         return dict(zip(keys, [int(v) for v in out]))
+
+    def timing(self, reset=True):
+        out = np.zeros(5, np.float64)
+        self.lib.icgh_batch_timing(C.c_void_p(self.h_), out.ctypes.data_as(C.c_void_p), 1 if reset else 0)
+        return dict(zip(["host_logic", "gather", "device_execute", "scatter", "finalize"], [float(v) for v in out]))
 
     def features(self, stream, max_n=2048):
         ids = np.zeros(max_n, np.uint64)

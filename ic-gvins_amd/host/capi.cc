@@ -7,7 +7,7 @@
 using namespace icg;
 
 struct icgh_batch {
-    std::unique_ptr<TrackingBatch> tb;
+    std::unique_ptr<StreamGroups> tb;
     int w, h;
 };
 
@@ -19,7 +19,7 @@ extern "C" {
 
 icgh_batch *icgh_batch_create(int device, int n_streams, const double *cam10, int w, int h, int max_features,
                               double min_parallax, double max_interval, int check_hist, double reproj_std, int window,
-                              int host_threads, char *err, int errlen) {
+                              int host_threads, int n_groups, char *err, int errlen) {
     try {
         TrackingConfig cfg;
         cfg.track_max_features     = max_features;
@@ -32,7 +32,7 @@ icgh_batch *icgh_batch_create(int device, int n_streams, const double *cam10, in
         auto *b = new icgh_batch();
         b->w    = w;
         b->h    = h;
-        b->tb.reset(new TrackingBatch(device, n_streams, intr, dist, {w, h}, cfg, window, host_threads));
+        b->tb.reset(new StreamGroups(device, n_streams, n_groups, intr, dist, {w, h}, cfg, window, host_threads));
         return b;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());
@@ -42,7 +42,10 @@ icgh_batch *icgh_batch_create(int device, int n_streams, const double *cam10, in
 
 void icgh_batch_destroy(icgh_batch *b) { delete b; }
 
-void *icgh_batch_ctx(icgh_batch *b) { return b ? (void *) b->tb->device()->ctx() : nullptr; }
+int icgh_batch_groups(icgh_batch *b) { return b ? b->tb->groups() : 0; }
+void *icgh_batch_ctx(icgh_batch *b, int group) {
+    return (b && group >= 0 && group < b->tb->groups()) ? (void *) b->tb->group(group).device()->ctx() : nullptr;
+}
 
 // images[i]: pointer to the i-th stream's frame (host or device memory), NULL to idle the stream this step.
 // poses12: n x 12 = R (camera->world, row-major) | t, the INS prior the reference sets with frame->setPose().
@@ -83,6 +86,17 @@ int icgh_batch_stats(icgh_batch *b, int stream, uint64_t *out8) {
     out8[5] = s.map->keyframes().size();
     out8[6] = s.map->landmarks().size();
     out8[7] = (uint64_t) s.last_state;
+    return 0;
+}
+
+int icgh_batch_timing(icgh_batch *b, double *out5, int reset) {
+    if (!b) return -1;
+    for (int i = 0; i < 5; i++) out5[i] = 0;
+    for (int g = 0; g < b->tb->groups(); g++)
+        for (int i = 0; i < 5; i++) {
+            out5[i] += b->tb->group(g).timing[i] / b->tb->groups(); // mean over groups (they run concurrently)
+            if (reset) b->tb->group(g).timing[i] = 0;
+        }
     return 0;
 }
 

@@ -237,6 +237,13 @@ public:
         std::unique_lock<std::mutex> lock(mappoint_mutex_);
         return observations_;
     }
+    // observations().back() without copying the whole list (same result; the list grows with every tracked frame)
+    bool lastObservation(std::shared_ptr<Feature> &out) {
+        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        if (observations_.empty()) return false;
+        out = observations_.back().lock();
+        return true;
+    }
     void setOutlier(bool isoutlier) {
         std::unique_lock<std::mutex> lock(mappoint_mutex_);
         isoutlier_ = isoutlier;

@@ -1,5 +1,7 @@
 #include "tracking_batch.h"
 
+#include <stdexcept>
+
 #include <atomic>
 
 namespace icg {
@@ -134,8 +136,13 @@ static inline void fnv(uint64_t &h, const void *p, size_t n) {
     }
 }
 
+static inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &states) {
     const int n = (int) streams_.size();
+    double t0 = now_s(), t1;
     states.assign((size_t) n, TRACK_PASSED);
     vector<char> active((size_t) n, 0);
     int cur = 0;
@@ -148,12 +155,24 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
             s.tracking->beginFrame(frames[(size_t) i], s.box[0]);
         }
     });
+    t1 = now_s();
+    timing[0] += t1 - t0;
+    t0 = t1;
     StageBatch global;
     vector<std::array<int, 8>> bases;
     for (int stage = 1; stage < Tracking::N_STAGES; stage++) {
         gather(cur, global, bases);
+        t1 = now_s();
+        timing[1] += t1 - t0;
+        t0 = t1;
         device_->execute(global, grid_, max_per_job_);
+        t1 = now_s();
+        timing[2] += t1 - t0;
+        t0 = t1;
         scatter(cur, global, bases);
+        t1 = now_s();
+        timing[3] += t1 - t0;
+        t0 = t1;
         const int nxt = cur ^ 1;
         bool any      = false;
         forEachStream([&](int i) {
@@ -164,6 +183,9 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
         for (int i = 0; i < n; i++)
             if (active[(size_t) i] && !streams_[(size_t) i].tracking->frameDone()) any = true;
         cur = nxt;
+        t1  = now_s();
+        timing[0] += t1 - t0;
+        t0 = t1;
         if (!any) break;
     }
     forEachStream([&](int i) {
@@ -197,6 +219,89 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
         }
         s.keeper->onFrame(*s.tracking, frame, st);
     });
+    timing[4] += now_s() - t0;
+}
+
+// ---- StreamGroups -----------------------------------------------------------------------------------------------------
+StreamGroups::StreamGroups(int device, int n_streams, int n_groups, const vector<double> &intrinsic,
+                           const vector<double> &distortion, const vector<int> &size, const TrackingConfig &cfg,
+                           int window_size, int host_threads_per_group)
+    : n_streams_(n_streams) {
+    if (n_groups < 1) n_groups = 1;
+    if (n_groups > n_streams) n_groups = n_streams;
+    group_of_.resize((size_t) n_streams);
+    local_of_.resize((size_t) n_streams);
+    int begin = 0;
+    for (int g = 0; g < n_groups; g++) {
+        int cnt = n_streams / n_groups + (g < n_streams % n_groups ? 1 : 0);
+        group_begin_.push_back(begin);
+        groups_.emplace_back(new TrackingBatch(device, cnt, intrinsic, distortion, size, cfg, window_size, host_threads_per_group));
+        for (int k = 0; k < cnt; k++) {
+            group_of_[(size_t) (begin + k)] = g;
+            local_of_[(size_t) (begin + k)] = k;
+        }
+        begin += cnt;
+    }
+    group_begin_.push_back(begin);
+    if (n_groups > 1)
+        for (int g = 0; g < n_groups; g++) workers_.emplace_back(&StreamGroups::workerLoop, this, g);
+}
+
+StreamGroups::~StreamGroups() {
+    {
+        std::unique_lock<std::mutex> lock(m_);
+        stop_ = true;
+        generation_++;
+    }
+    cv_go_.notify_all();
+    for (auto &t : workers_) t.join();
+}
+
+void StreamGroups::workerLoop(int g) {
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lock(m_);
+            cv_go_.wait(lock, [&] { return generation_ != seen; });
+            seen = generation_;
+            if (stop_) return;
+        }
+        const int b = group_begin_[(size_t) g], e = group_begin_[(size_t) g + 1];
+        std::string err;
+        try {
+            vector<Frame::Ptr> fr(frames_->begin() + b, frames_->begin() + e);
+            vector<TrackState> st;
+            groups_[(size_t) g]->step(fr, st);
+            for (int i = b; i < e; i++) (*states_)[(size_t) i] = st[(size_t) (i - b)];
+        } catch (const std::exception &ex) {
+            err = ex.what();
+        }
+        {
+            std::unique_lock<std::mutex> lock(m_);
+            if (!err.empty()) error_ = err;
+            if (--pending_ == 0) cv_done_.notify_all();
+        }
+    }
+}
+
+void StreamGroups::step(const vector<Frame::Ptr> &frames, vector<TrackState> &states) {
+    states.assign((size_t) n_streams_, TRACK_PASSED);
+    if (workers_.empty()) {
+        groups_[0]->step(frames, states);
+        return;
+    }
+    {
+        std::unique_lock<std::mutex> lock(m_);
+        frames_  = &frames;
+        states_  = &states;
+        pending_ = (int) groups_.size();
+        error_.clear();
+        generation_++;
+    }
+    cv_go_.notify_all();
+    std::unique_lock<std::mutex> lock(m_);
+    cv_done_.wait(lock, [&] { return pending_ == 0; });
+    if (!error_.empty()) throw std::runtime_error(error_);
 }
 
 } // namespace icg

@@ -3,6 +3,7 @@
 // batched ABI call (one kernel launch set) for all streams.  Streams never exchange data; results are split back by
 // offset, so per-stream outputs are identical to running the streams one at a time (shard invariance).
 #pragma once
+#include <condition_variable>
 #include <thread>
 
 #include "tracking.h"
@@ -31,6 +32,9 @@ public:
     Stream &stream(int i) { return streams_[(size_t) i]; }
     int size() const { return (int) streams_.size(); }
     DeviceContext::Ptr device() { return device_; }
+    // wall-clock breakdown of step(): [0] begin+advance (host logic), [1] gather, [2] device execute, [3] scatter,
+    // [4] finalize (digest + window keeper); seconds, accumulated
+    double timing[5]{0, 0, 0, 0, 0};
 
 private:
     void gather(int cur, StageBatch &global, vector<std::array<int, 8>> &bases);
@@ -42,6 +46,39 @@ private:
     int host_threads_;
     icg_detect_grid grid_{};
     int max_per_job_{0};
+};
+
+// Several TrackingBatch groups, each with its own icg_ctx (own HIP stream) and its own persistent host thread: while one
+// group's kernels run, the other groups' host stages and kernels proceed, so host bookkeeping overlaps device work and
+// latency-bound kernels of different groups overlap on the GPU.  Streams stay independent; results are identical to a
+// single batch (and to one-by-one execution).
+class StreamGroups {
+public:
+    StreamGroups(int device, int n_streams, int n_groups, const vector<double> &intrinsic, const vector<double> &distortion,
+                 const vector<int> &size, const TrackingConfig &cfg, int window_size, int host_threads_per_group);
+    ~StreamGroups();
+    void step(const vector<Frame::Ptr> &frames, vector<TrackState> &states);
+    int size() const { return n_streams_; }
+    int groups() const { return (int) groups_.size(); }
+    TrackingBatch &group(int g) { return *groups_[(size_t) g]; }
+    // global stream index -> (group, local index)
+    TrackingBatch::Stream &stream(int i) { return groups_[(size_t) group_of_[(size_t) i]]->stream(local_of_[(size_t) i]); }
+    std::string error() const { return error_; }
+
+private:
+    void workerLoop(int g);
+    int n_streams_;
+    vector<std::unique_ptr<TrackingBatch>> groups_;
+    vector<int> group_of_, local_of_, group_begin_;
+    vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_go_, cv_done_;
+    uint64_t generation_{0};
+    int pending_{0};
+    bool stop_{false};
+    const vector<Frame::Ptr> *frames_{nullptr};
+    vector<TrackState> *states_{nullptr};
+    std::string error_;
 };
 
 } // namespace icg

@@ -249,9 +249,8 @@ int Tracking::parallaxFromReferenceMapPoints(double &parallax) { // :873-905
     for (auto &feature : features) {
         auto mappoint = feature.second->getMapPoint();
         if (mappoint && !mappoint->isOutlier()) {
-            auto observations = mappoint->observations();
-            if (observations.empty()) continue;
-            auto feat = observations.back().lock();
+            std::shared_ptr<Feature> feat; // == observations().back().lock() (:883-887)
+            if (!mappoint->lastObservation(feat)) continue;
             if (feat && !feat->isOutlier()) {
                 auto frame = feat->getFrame();
                 if (frame && (frame == frame_cur_)) {

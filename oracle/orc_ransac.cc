@@ -3,7 +3,7 @@
 // following OpenCV calib3d/src/fundam.cpp (FMEstimatorCallback::run7Point / computeError) and ptsetreg.cpp
 // (RANSACPointSetRegistrator::run, getSubset, RANSACUpdateNumIters) as defined in SURVEY.md Appendix B.9.
 // Formulation fixed here (mirrored by the HIP path so that decisions agree bit-for-bit):
-//   * null space of the 7x9 system by one-sided (Hestenes) Jacobi on the columns, fixed cyclic order, using only
+//   * null space of the 7x9 system: one-sided (Hestenes) Jacobi on the 7 columns of A^T + basis completion, using only
 //     + - * / sqrt (OpenCV: JacobiSVD on the same matrix; the two-dimensional null space is basis independent);
 //   * cubic solved WITHOUT libm transcendentals (bisection on a Cauchy bracket + Newton polish + deflation), roots in
 //     ascending order (OpenCV's solveCubic uses acos/cos/cbrt which differ between host and device libm);
@@ -116,6 +116,78 @@ int solve_cubic_real(const double c[4], double roots[3]) {
     return n;
 }
 
+// Null space of the 7x9 system A, given M = A^T (9x7, row-major).  As cv::SVDecomp does for m < n, the one-sided Jacobi
+// runs on the 7 full-rank columns of A^T (fast convergence); the two missing right singular vectors of A are then
+// obtained by completing the orthonormal basis of R^9 (twice-repeated Gram-Schmidt from the least-represented
+// coordinate axes).  Only + - * / sqrt; fixed operation order.
+void null_space_9x7(double *M, double *f1, double *f2) {
+    const int m = 9, n = 7;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        bool changed = false;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < m; k++) {
+                    double gp = M[k * n + p], gq = M[k * n + q];
+                    alpha += gp * gp;
+                    beta += gq * gq;
+                    gamma += gp * gq;
+                }
+                if (gamma == 0.0) continue;
+                if (std::fabs(gamma) <= 1e-15 * std::sqrt(alpha * beta)) continue;
+                changed     = true;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t    = 1.0 / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                if (zeta < 0) t = -t;
+                double c = 1.0 / std::sqrt(1.0 + t * t);
+                double s = c * t;
+                for (int k = 0; k < m; k++) {
+                    double gp = M[k * n + p], gq = M[k * n + q];
+                    M[k * n + p] = c * gp - s * gq;
+                    M[k * n + q] = s * gp + c * gq;
+                }
+            }
+        if (!changed) break;
+    }
+    // basis B: 9 vectors of length 9 (columns 0..6 = normalised columns of M, 7..8 = completion)
+    double B[9][9];
+    for (int c = 0; c < n; c++) {
+        double s = 0;
+        for (int k = 0; k < m; k++) s += M[k * n + c] * M[k * n + c];
+        double w = std::sqrt(s);
+        for (int k = 0; k < m; k++) B[c][k] = (w > 0) ? M[k * n + c] / w : 0.0;
+    }
+    for (int t = 0; t < 2; t++) {
+        const int nb = n + t;
+        int js = 0;
+        double best = 0;
+        for (int j = 0; j < m; j++) {
+            double d = 0;
+            for (int c = 0; c < nb; c++) d += B[c][j] * B[c][j];
+            if (j == 0 || d < best) {
+                best = d;
+                js   = j;
+            }
+        }
+        double v[9];
+        for (int k = 0; k < m; k++) v[k] = (k == js) ? 1.0 : 0.0;
+        for (int pass = 0; pass < 2; pass++)
+            for (int c = 0; c < nb; c++) {
+                double d = 0;
+                for (int k = 0; k < m; k++) d += B[c][k] * v[k];
+                for (int k = 0; k < m; k++) v[k] -= d * B[c][k];
+            }
+        double s = 0;
+        for (int k = 0; k < m; k++) s += v[k] * v[k];
+        double w = std::sqrt(s);
+        for (int k = 0; k < m; k++) B[nb][k] = (w > 0) ? v[k] / w : 0.0;
+    }
+    for (int k = 0; k < m; k++) {
+        f1[k] = B[7][k];
+        f2[k] = B[8][k];
+    }
+}
+
 struct Rng {
     uint64_t state;
     explicit Rng(uint64_t s) : state(s ? s : 0xffffffffULL) {}
@@ -146,39 +218,21 @@ extern "C" {
 // 7-point algorithm on 7 correspondences (m1,m2: 7x2 doubles holding float-valued pixel coordinates).
 // F: up to 3 row-major 3x3 matrices. Returns the number of models.
 int orc_seven_point(const double *m1, const double *m2, double *F) {
-    double A[7 * 9], V[81];
+    // M = A^T (9 x 7): row r, column c = coefficient r of equation c
+    double M[9 * 7], f1[9], f2[9];
     for (int i = 0; i < 7; i++) {
         double x1 = m1[2 * i], y1 = m1[2 * i + 1], x2 = m2[2 * i], y2 = m2[2 * i + 1];
-        double *r = A + 9 * i;
-        r[0] = x2 * x1;
-        r[1] = x2 * y1;
-        r[2] = x2;
-        r[3] = y2 * x1;
-        r[4] = y2 * y1;
-        r[5] = y2;
-        r[6] = x1;
-        r[7] = y1;
-        r[8] = 1;
+        M[0 * 7 + i] = x2 * x1;
+        M[1 * 7 + i] = x2 * y1;
+        M[2 * 7 + i] = x2;
+        M[3 * 7 + i] = y2 * x1;
+        M[4 * 7 + i] = y2 * y1;
+        M[5 * 7 + i] = y2;
+        M[6 * 7 + i] = x1;
+        M[7 * 7 + i] = y1;
+        M[8 * 7 + i] = 1;
     }
-    hestenes(A, 7, 9, V, 30);
-    // the two columns with the smallest norms span the null space: f2 = smallest, f1 = second smallest
-    double nrm[9];
-    for (int j = 0; j < 9; j++) {
-        double s = 0;
-        for (int k = 0; k < 7; k++) s += A[k * 9 + j] * A[k * 9 + j];
-        nrm[j] = s;
-    }
-    int i2 = 0;
-    for (int j = 1; j < 9; j++)
-        if (nrm[j] < nrm[i2]) i2 = j;
-    int i1 = (i2 == 0) ? 1 : 0;
-    for (int j = 0; j < 9; j++)
-        if (j != i2 && nrm[j] < nrm[i1]) i1 = j;
-    double f1[9], f2[9];
-    for (int k = 0; k < 9; k++) {
-        f1[k] = V[k * 9 + i1];
-        f2[k] = V[k * 9 + i2];
-    }
+    null_space_9x7(M, f1, f2);
     for (int i = 0; i < 9; i++) f1[i] -= f2[i];
     double c[4], t0, t1, t2;
     t0   = f2[4] * f2[8] - f2[5] * f2[7];

@@ -17,10 +17,11 @@ def ensure_oracle_host():
 
 
 def run_streams(lib_path, n_streams, w, h, n_frames, max_features, scene_frames=None, host_threads=1, stream_ids=None,
-                window=10):
+                window=10, groups=1):
     """Runs n_streams synthetic streams for n_frames; returns (per-frame records, stats, rendered frames)."""
     cam = H.camera_for(w, h)
-    sb = H.StreamBatch(lib_path, n_streams, w, h, cam, max_features=max_features, host_threads=host_threads, window=window)
+    sb = H.StreamBatch(lib_path, n_streams, w, h, cam, max_features=max_features, host_threads=host_threads, window=window,
+                       groups=groups)
     stream_ids = list(range(n_streams)) if stream_ids is None else stream_ids
     if scene_frames is None:
         scene = H.SynthScene(sb.lib, w, h, cam, tex_size=1024, threads=4)

@@ -30,6 +30,6 @@ def test_stream_parity_hip_vs_oracle(cfg):
 def test_multi_stream_batch_on_gpu_equals_oracle():
     w, h, nfeat, nframes, ns = 640, 480, 100, 12, 4
     rec_o, stats_o, frames = run_streams(ensure_oracle_host(), ns, w, h, nframes, nfeat)
-    rec_g, stats_g, _ = run_streams(H.HOST_LIB, ns, w, h, nframes, nfeat, scene_frames=frames, host_threads=2)
+    rec_g, stats_g, _ = run_streams(H.HOST_LIB, ns, w, h, nframes, nfeat, scene_frames=frames, host_threads=2, groups=2)
     for s in range(ns):
         assert stats_o[s]["digest"] == stats_g[s]["digest"], s

@@ -37,7 +37,9 @@ def test_batch_equals_individual_streams():
     lib = ensure_oracle_host()
     rec_b, stats_b, frames = run_streams(lib, 3, 640, 480, 14, 100)
     rec_t, stats_t, _ = run_streams(lib, 3, 640, 480, 14, 100, scene_frames=frames, host_threads=3)
+    rec_g, stats_g, _ = run_streams(lib, 3, 640, 480, 14, 100, scene_frames=frames, groups=2)  # group threads
     for s in range(3):
+        assert stats_g[s]["digest"] == stats_b[s]["digest"]
         rec_1, stats_1, _ = run_streams(lib, 1, 640, 480, 14, 100, scene_frames=frames, stream_ids=[s])
         assert stats_1[0]["digest"] == stats_b[s]["digest"] == stats_t[s]["digest"]
         for k in range(14):
