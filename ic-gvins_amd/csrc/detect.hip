@@ -414,15 +414,15 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     if ((rc = c.seal())) return rc;
     std::vector<float> h_corners((size_t) n_roi * max_pb * 2);
     std::vector<int32_t> h_cnt((size_t) n_roi);
+    // corners are re-read by k_subpix: keep them in device memory, fetch with the single D2H of finish()
     float2 *d_corners    = (float2 *) c.out(h_corners.data(), (size_t) n_roi * max_pb * 2);
     int32_t *d_cnt       = c.out(h_cnt.data(), (size_t) n_roi);
-    unsigned int *d_rmax = c.out((unsigned int *) nullptr, (size_t) n_roi);
-    int32_t *d_ccnt      = c.out((int32_t *) nullptr, (size_t) n_roi);
+    unsigned int *d_rmax = c.out((unsigned int *) nullptr, 2 * (size_t) n_roi); // [roi_max | cand_cnt] zeroed together
+    int32_t *d_ccnt      = (int32_t *) (d_rmax + n_roi);
 
     const size_t mask_plane = (size_t) pitch * h, eig_plane = (size_t) w * h, cand_plane = (size_t) w * h;
     ICG_HIP(ctx, hipMemsetAsync(ctx->d_mask, 255, mask_plane * n, ctx->stream));
-    ICG_HIP(ctx, hipMemsetAsync(d_rmax, 0, sizeof(unsigned int) * n_roi, ctx->stream));
-    ICG_HIP(ctx, hipMemsetAsync(d_ccnt, 0, sizeof(int32_t) * n_roi, ctx->stream));
+    ICG_HIP(ctx, hipMemsetAsync(d_rmax, 0, sizeof(unsigned int) * 2 * n_roi, ctx->stream));
     if (n_mask > 0) {
         icg_prof_scope ps(ctx, "detect_mask");
         hipLaunchKernelGGL(k_mask_discs, dim3(n_mask), dim3(256), 0, ctx->stream, n_mask, d_mpts, d_ptjob, grid->min_dist,

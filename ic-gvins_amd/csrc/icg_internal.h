@@ -129,15 +129,18 @@ __host__ __device__ static inline int icg_reflect101(int i, int n) {
     return i;
 }
 
-// Per-call staging helper: inputs are packed into the pinned arena and shipped with ONE H2D copy; outputs are
-// reserved behind them and fetched with ONE D2H copy at finish().
+// Per-call staging helper.  The arena is pinned host memory that the GPU can address directly (hipHostMalloc), mirrored
+// by a device arena at the same offsets:
+//   in()/out()       mirrored: ONE H2D copy at seal(), ONE D2H copy at finish() — for data many workgroups re-read
+//   in_zc()/out_zc() zero-copy: kernels read/write the pinned host memory over PCIe — for data touched once per
+//                    lane/wave (point lists, status bytes); saves the copy API calls, which dominate at small batches
 struct icg_call {
     icg_ctx *ctx;
-    size_t in_end = 0, out_begin = 0;
-    bool sealed = false;
+    size_t mirror_lo = (size_t) -1, mirror_hi = 0;
     struct outrec {
         void *user;
         size_t off, bytes;
+        bool zc;
     };
     std::vector<outrec> outs;
     explicit icg_call(icg_ctx *c) : ctx(c) { ctx->arena_off = 0; }
@@ -145,35 +148,35 @@ struct icg_call {
     template <typename T> T *in(const T *src, size_t n) {
         size_t off = icg_arena_alloc(ctx, sizeof(T) * n);
         if (n) memcpy(ctx->h_arena + off, src, sizeof(T) * n);
+        if (off < mirror_lo) mirror_lo = off;
+        if (off + sizeof(T) * n > mirror_hi) mirror_hi = off + sizeof(T) * n;
         return reinterpret_cast<T *>(ctx->d_arena + off);
     }
-    template <typename T> T *in_host(size_t n, T **host) { // caller fills *host before seal()
+    template <typename T> T *in_zc(const T *src, size_t n) {
         size_t off = icg_arena_alloc(ctx, sizeof(T) * n);
-        *host      = reinterpret_cast<T *>(ctx->h_arena + off);
-        return reinterpret_cast<T *>(ctx->d_arena + off);
+        if (n) memcpy(ctx->h_arena + off, src, sizeof(T) * n);
+        return reinterpret_cast<T *>(ctx->h_arena + off);
     }
-    int seal() {
-        in_end    = ctx->arena_off;
-        sealed    = true;
-        out_begin = icg_align_up(in_end, 256);
-        return icg_arena_h2d(ctx, 0, in_end);
-    }
+    int seal() { return mirror_hi > mirror_lo ? icg_arena_h2d(ctx, mirror_lo, mirror_hi) : 0; }
     template <typename T> T *out(T *user, size_t n) {
         size_t off = icg_arena_alloc(ctx, sizeof(T) * n);
-        if (user) outs.push_back({(void *) user, off, sizeof(T) * n});
+        if (user) outs.push_back({(void *) user, off, sizeof(T) * n, false});
         return reinterpret_cast<T *>(ctx->d_arena + off);
     }
-    template <typename T> T *host_of(T *dev) { return reinterpret_cast<T *>(ctx->h_arena + ((char *) dev - ctx->d_arena)); }
+    template <typename T> T *out_zc(T *user, size_t n) {
+        size_t off = icg_arena_alloc(ctx, sizeof(T) * n);
+        if (user) outs.push_back({(void *) user, off, sizeof(T) * n, true});
+        return reinterpret_cast<T *>(ctx->h_arena + off);
+    }
     int finish() {
-        int rc = 0;
-        if (!outs.empty()) {
-            size_t lo = (size_t) -1, hi = 0;
-            for (auto &o : outs) {
+        int rc    = 0;
+        size_t lo = (size_t) -1, hi = 0;
+        for (auto &o : outs)
+            if (!o.zc) {
                 if (o.off < lo) lo = o.off;
                 if (o.off + o.bytes > hi) hi = o.off + o.bytes;
             }
-            rc = icg_arena_d2h(ctx, lo, hi);
-        }
+        if (hi > lo) rc = icg_arena_d2h(ctx, lo, hi);
         if (rc) return rc;
         rc = icg_hip_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
         if (rc) return rc;

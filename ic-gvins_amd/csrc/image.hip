@@ -14,7 +14,17 @@
 //   k_pyrdown     64x16 output tile per workgroup, (2*64+3)x(2*16+3) input tile staged in LDS, separable
 //                 [1 4 6 4 1] in exact integers
 // Algorithmic bytes per frame: CLAHE 3*W*H, pyramid 1.640625*W*H.
+#include <algorithm>
+
 #include "icg_internal.h"
+
+// per-launch job list passed BY VALUE in the kernel arguments (no staging copy, no host sync needed)
+#define PRE_MAX_JOBS 64
+struct pre_jobs {
+    const uint8_t *src[PRE_MAX_JOBS]; // gray source image per job (device memory)
+    int32_t slot[PRE_MAX_JOBS];       // destination frame slot per job
+    int stride;                       // source row stride in bytes
+};
 
 // ---------------------------------------------------------------------------------------------------------
 __global__ void k_bgr2gray(const uint8_t *bgr, int w, int h, int sstride, size_t sbatch, uint8_t *gray, int gstride,
@@ -28,12 +38,13 @@ __global__ void k_bgr2gray(const uint8_t *bgr, int w, int h, int sstride, size_t
         (uint8_t) ((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14);
 }
 
-__global__ void k_hist256(const uint8_t *img, int w, int h, int stride, size_t batch, unsigned int *hist /*n x 256*/) {
+__global__ void k_hist256(pre_jobs jobs, int w, int h, unsigned int *hist /*n x 256*/) {
     __shared__ unsigned int sh[256];
     int b = blockIdx.y;
     sh[threadIdx.x] = 0;
     __syncthreads();
-    const uint8_t *src = img + (size_t) b * batch;
+    const uint8_t *src = jobs.src[b];
+    const int stride   = jobs.stride;
     int total          = w * h;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         int y = i / w, x = i - y * w;
@@ -49,8 +60,7 @@ struct clahe_geom {
     float lut_scale, inv_tw, inv_th;
 };
 
-__global__ __launch_bounds__(256) void k_clahe_lut(const uint8_t *raw, int stride, size_t batch, clahe_geom g,
-                                                   uint8_t *lut /* n x tiles^2 x 256 */) {
+__global__ __launch_bounds__(256) void k_clahe_lut(pre_jobs jobs, clahe_geom g, uint8_t *lut /* n x tiles^2 x 256 */) {
     __shared__ int hist[256];
     __shared__ int scan[2][256];
     __shared__ int red[256];
@@ -58,7 +68,8 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint8_t *raw, int strid
     const int tile = blockIdx.x;
     const int b    = blockIdx.y;
     const int ty = tile / ICG_CLAHE_TILES, tx = tile - ty * ICG_CLAHE_TILES;
-    const uint8_t *src = raw + (size_t) b * batch;
+    const uint8_t *src = jobs.src[b];
+    const int stride   = jobs.stride;
     hist[t] = 0;
     __syncthreads();
     const int area = g.tw * g.th;
@@ -108,9 +119,8 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint8_t *raw, int strid
 #define CLAHE_CHUNK 256 // pixels per workgroup row segment (64 lanes x uchar4)
 #define CLAHE_MAXCOLS 24
 
-__global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *raw, int stride, size_t batch, clahe_geom g,
-                                                     const uint8_t *lut, uint8_t *frames, size_t slot_bytes,
-                                                     const int32_t *slots, int dpitch) {
+__global__ __launch_bounds__(256) void k_clahe_apply(pre_jobs jobs, clahe_geom g, const uint8_t *lut, uint8_t *frames,
+                                                     size_t slot_bytes, int dpitch) {
     __shared__ uint8_t slut[2][CLAHE_MAXCOLS][256];
     const int strip = blockIdx.x; // ty1_raw = strip-1
     const int chunk = blockIdx.y;
@@ -169,8 +179,9 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *raw, int str
     int y_hi = strip * g.th + g.th / 2 + 3;
     if (y_lo < 0) y_lo = 0;
     if (y_hi > g.h) y_hi = g.h;
-    const uint8_t *src = raw + (size_t) b * batch;
-    uint8_t *dst       = frames + (size_t) slots[b] * slot_bytes;
+    const uint8_t *src = jobs.src[b];
+    const int stride   = jobs.stride;
+    uint8_t *dst       = frames + (size_t) jobs.slot[b] * slot_bytes;
     for (int y = y_lo + wave; y < y_hi; y += 4) {
         float tyf = y * g.inv_th - 0.5f;
         int tyr   = (int) floorf(tyf);
@@ -198,13 +209,13 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *raw, int str
 #define PD_IW (2 * PD_TW + 3)
 #define PD_IH (2 * PD_TH + 3)
 
-__global__ __launch_bounds__(256) void k_pyrdown(uint8_t *frames, size_t slot_bytes, const int32_t *slots,
+__global__ __launch_bounds__(256) void k_pyrdown(uint8_t *frames, size_t slot_bytes, pre_jobs jobs,
                                                  unsigned int src_off, int sw, int sh, int spitch,
                                                  unsigned int dst_off, int dw, int dh, int dpitch) {
     __shared__ uint8_t in[PD_IH][PD_IW + 1];
     __shared__ int tmp[PD_IH][PD_TW];
     const int b      = blockIdx.z;
-    uint8_t *slot    = frames + (size_t) slots[b] * slot_bytes;
+    uint8_t *slot    = frames + (size_t) jobs.slot[b] * slot_bytes;
     const uint8_t *s = slot + src_off;
     uint8_t *d       = slot + dst_off;
     const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH; // output tile origin
@@ -245,41 +256,6 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
         if (slots[k] < 0 || slots[k] >= ctx->cfg.n_slots || !images[k]) return icg_fail(ctx, ICG_ERR_INVALID, "bad slot/image %d", k);
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
 
-    const size_t raw_batch = (size_t) ctx->raw_pitch * h;
-    hipMemcpyKind kind     = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (channels == 3) {
-        if (!ctx->d_bgr) ICG_HIP(ctx, hipMalloc((void **) &ctx->d_bgr, (size_t) w * 3 * h * ctx->cfg.max_batch));
-        for (int k = 0; k < n; k++)
-            ICG_HIP(ctx, hipMemcpy2DAsync(ctx->d_bgr + (size_t) k * w * 3 * h, (size_t) w * 3, images[k], stride,
-                                          (size_t) w * 3, h, kind, ctx->stream));
-        icg_prof_scope ps(ctx, "bgr2gray");
-        hipLaunchKernelGGL(k_bgr2gray, dim3((w + 255) / 256, h, n), dim3(256), 0, ctx->stream, ctx->d_bgr, w, h, w * 3,
-                           (size_t) w * 3 * h, ctx->d_raw, ctx->raw_pitch, raw_batch);
-    } else {
-        for (int k = 0; k < n; k++)
-            ICG_HIP(ctx, hipMemcpy2DAsync(ctx->d_raw + (size_t) k * raw_batch, ctx->raw_pitch, images[k], stride, w, h,
-                                          kind, ctx->stream));
-    }
-
-    // staging: slots (+ optional histogram counts)
-    ctx->arena_off = 0;
-    int rc         = icg_arena_reserve(ctx, sizeof(int32_t) * n + sizeof(unsigned int) * 256 * n + 4096);
-    if (rc) return rc;
-    size_t o_slots = icg_arena_alloc(ctx, sizeof(int32_t) * n);
-    memcpy(icg_h<int32_t>(ctx, o_slots), slots, sizeof(int32_t) * n);
-    size_t in_end = ctx->arena_off;
-    size_t o_hist = 0;
-    if (hist_mean) o_hist = icg_arena_alloc(ctx, sizeof(unsigned int) * 256 * n);
-    if ((rc = icg_arena_h2d(ctx, o_slots, in_end))) return rc;
-    const int32_t *d_slots = icg_d<int32_t>(ctx, o_slots);
-
-    if (hist_mean) {
-        ICG_HIP(ctx, hipMemsetAsync(icg_d<unsigned int>(ctx, o_hist), 0, sizeof(unsigned int) * 256 * n, ctx->stream));
-        icg_prof_scope ps(ctx, "hist256");
-        hipLaunchKernelGGL(k_hist256, dim3(64, n), dim3(256), 0, ctx->stream, ctx->d_raw, w, h, ctx->raw_pitch, raw_batch,
-                           icg_d<unsigned int>(ctx, o_hist));
-    }
-
     // CLAHE geometry
     const int T = ICG_CLAHE_TILES;
     int ew = w, eh = h;
@@ -300,41 +276,88 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
     g.inv_th = 1.0f / g.th;
     if (CLAHE_CHUNK / g.tw + 3 > CLAHE_MAXCOLS)
         return icg_fail(ctx, ICG_ERR_INVALID, "image too small for CLAHE chunking (tile width %d)", g.tw);
-    {
-        icg_prof_scope ps(ctx, "clahe_lut");
-        hipLaunchKernelGGL(k_clahe_lut, dim3(T * T, n), dim3(256), 0, ctx->stream, ctx->d_raw, ctx->raw_pitch, raw_batch, g,
-                           ctx->d_lut);
+
+    const size_t raw_batch = (size_t) ctx->raw_pitch * h;
+    hipMemcpyKind kind     = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    unsigned int *d_hist   = nullptr;
+    if (hist_mean) {
+        ctx->arena_off = 0;
+        int rc         = icg_arena_reserve(ctx, sizeof(unsigned int) * 256 * (size_t) n + 4096);
+        if (rc) return rc;
+        d_hist = icg_d<unsigned int>(ctx, icg_arena_alloc(ctx, sizeof(unsigned int) * 256 * (size_t) n));
+        ICG_HIP(ctx, hipMemsetAsync(d_hist, 0, sizeof(unsigned int) * 256 * (size_t) n, ctx->stream));
     }
-    {
-        icg_prof_scope ps(ctx, "clahe_apply");
-        hipLaunchKernelGGL(k_clahe_apply, dim3(T + 1, (w + CLAHE_CHUNK - 1) / CLAHE_CHUNK, n), dim3(256), 0, ctx->stream,
-                           ctx->d_raw, ctx->raw_pitch, raw_batch, g, ctx->d_lut, ctx->d_frames, ctx->slot_bytes, d_slots,
-                           ctx->lv[0].pitch);
-    }
-    for (int l = 1; l < ctx->n_levels; l++) {
-        icg_prof_scope ps(ctx, "pyrdown");
-        const icg_level &a = ctx->lv[l - 1], &bb = ctx->lv[l];
-        hipLaunchKernelGGL(k_pyrdown, dim3((bb.w + PD_TW - 1) / PD_TW, (bb.h + PD_TH - 1) / PD_TH, n), dim3(256), 0,
-                           ctx->stream, ctx->d_frames, ctx->slot_bytes, d_slots, (unsigned int) a.off, a.w, a.h, a.pitch,
-                           (unsigned int) bb.off, bb.w, bb.h, bb.pitch);
+
+    for (int base = 0; base < n; base += PRE_MAX_JOBS) {
+        const int m = std::min(PRE_MAX_JOBS, n - base);
+        pre_jobs jobs;
+        memset(&jobs, 0, sizeof jobs);
+        for (int k = 0; k < m; k++) jobs.slot[k] = slots[base + k];
+        if (channels == 3) {
+            if (!ctx->d_bgr) ICG_HIP(ctx, hipMalloc((void **) &ctx->d_bgr, (size_t) w * 3 * h * ctx->cfg.max_batch));
+            for (int k = 0; k < m; k++)
+                ICG_HIP(ctx, hipMemcpy2DAsync(ctx->d_bgr + (size_t) (base + k) * w * 3 * h, (size_t) w * 3, images[base + k], stride,
+                                              (size_t) w * 3, h, kind, ctx->stream));
+            icg_prof_scope ps(ctx, "bgr2gray");
+            hipLaunchKernelGGL(k_bgr2gray, dim3((w + 255) / 256, h, m), dim3(256), 0, ctx->stream,
+                               ctx->d_bgr + (size_t) base * w * 3 * h, w, h, w * 3, (size_t) w * 3 * h,
+                               ctx->d_raw + (size_t) base * raw_batch, ctx->raw_pitch, raw_batch);
+            for (int k = 0; k < m; k++) jobs.src[k] = ctx->d_raw + (size_t) (base + k) * raw_batch;
+            jobs.stride = ctx->raw_pitch;
+        } else {
+            // device-resident gray frames are consumed in place when uchar4 loads are aligned; otherwise (and for host
+            // frames) they are first brought into the pitched staging planes
+            bool direct = src_on_device && (stride % 4 == 0);
+            for (int k = 0; k < m && direct; k++) direct = (((uintptr_t) images[base + k]) % 4) == 0;
+            if (direct) {
+                for (int k = 0; k < m; k++) jobs.src[k] = images[base + k];
+                jobs.stride = stride;
+            } else {
+                for (int k = 0; k < m; k++) {
+                    ICG_HIP(ctx, hipMemcpy2DAsync(ctx->d_raw + (size_t) (base + k) * raw_batch, ctx->raw_pitch, images[base + k],
+                                                  stride, w, h, kind, ctx->stream));
+                    jobs.src[k] = ctx->d_raw + (size_t) (base + k) * raw_batch;
+                }
+                jobs.stride = ctx->raw_pitch;
+            }
+        }
+        if (hist_mean) {
+            icg_prof_scope ps(ctx, "hist256");
+            hipLaunchKernelGGL(k_hist256, dim3(64, m), dim3(256), 0, ctx->stream, jobs, w, h, d_hist + (size_t) base * 256);
+        }
+        uint8_t *lut = ctx->d_lut + (size_t) base * T * T * 256;
+        {
+            icg_prof_scope ps(ctx, "clahe_lut");
+            hipLaunchKernelGGL(k_clahe_lut, dim3(T * T, m), dim3(256), 0, ctx->stream, jobs, g, lut);
+        }
+        {
+            icg_prof_scope ps(ctx, "clahe_apply");
+            hipLaunchKernelGGL(k_clahe_apply, dim3(T + 1, (w + CLAHE_CHUNK - 1) / CLAHE_CHUNK, m), dim3(256), 0, ctx->stream, jobs,
+                               g, lut, ctx->d_frames, ctx->slot_bytes, ctx->lv[0].pitch);
+        }
+        for (int l = 1; l < ctx->n_levels; l++) {
+            icg_prof_scope ps(ctx, "pyrdown");
+            const icg_level &a = ctx->lv[l - 1], &bb = ctx->lv[l];
+            hipLaunchKernelGGL(k_pyrdown, dim3((bb.w + PD_TW - 1) / PD_TW, (bb.h + PD_TH - 1) / PD_TH, m), dim3(256), 0,
+                               ctx->stream, ctx->d_frames, ctx->slot_bytes, jobs, (unsigned int) a.off, a.w, a.h, a.pitch,
+                               (unsigned int) bb.off, bb.w, bb.h, bb.pitch);
+        }
     }
     ICG_HIP(ctx, hipGetLastError());
-    if (hist_mean) {
-        if ((rc = icg_arena_d2h(ctx, o_hist, o_hist + sizeof(unsigned int) * 256 * n))) return rc;
-    }
+    if (!hist_mean) return ICG_OK; // asynchronous: later calls on this context are stream-ordered behind these kernels
+
+    std::vector<unsigned int> hc((size_t) n * 256);
+    ICG_HIP(ctx, hipMemcpyAsync(hc.data(), d_hist, sizeof(unsigned int) * 256 * (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
     ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     icg_prof_collect(ctx);
-    if (hist_mean) {
-        // tracking.cc:98-102: float histogram, (float)k product in float, /256.0 and accumulation in double
-        const unsigned int *hc = icg_h<unsigned int>(ctx, o_hist);
-        for (int k = 0; k < n; k++) {
-            double acc = 0;
-            for (int i = 0; i < 256; i++) {
-                float hf = (float) hc[(size_t) k * 256 + i];
-                acc += hf * (float) i / 256.0;
-            }
-            hist_mean[k] = acc / ((double) w * h);
+    // tracking.cc:98-102: float histogram, (float)k product in float, /256.0 and accumulation in double
+    for (int k = 0; k < n; k++) {
+        double acc = 0;
+        for (int i = 0; i < 256; i++) {
+            float hf = (float) hc[(size_t) k * 256 + i];
+            acc += hf * (float) i / 256.0;
         }
+        hist_mean[k] = acc / ((double) w * h);
     }
     ctx->arena_off = 0;
     return ICG_OK;

@@ -13,7 +13,9 @@
 //   * each lane owns a 7-pixel horizontal run of the 21x21 window (63 lanes x 7 = 441): I, Ix, Iy stay in VGPRs
 //     for all <=30 Gauss-Newton iterations,
 //   * the next image is read through a 32x32 u8 LDS tile that is re-staged only when the window leaves it,
-//   * A11/A12/A22 and b1/b2 are per-lane int32 partials (bounded: 7*4080^2 < 2^31) reduced with 64-bit butterflies.
+//   * A11/A12/A22 and b1/b2 are per-lane int32 partials (bounded: 7*4080^2 < 2^27, 7*8160*4080 < 2^28) reduced exactly:
+//     DPP butterflies in 32 bits up to 16 / 8 lanes, then v_readlane + 64-bit scalar adds (uniform result in SGPRs);
+//     every multiply has 24-bit operands -> full-rate v_mul_i32_i24 / v_mad_i32_i24.
 // Algorithmic HBM bytes per point and direction: 4 levels x (24^2 + 22^2) B; everything else is
 // LDS/VGPR traffic.
 #include <cfloat>
@@ -35,10 +37,34 @@ struct lk_smem {
     unsigned char J[LK_JT * LK_JT];
 };
 
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
+// Exact wave-wide integer sums, result uniform (SGPRs).  The per-lane partials are bounded (see the kernel comment), so
+// the first butterfly stages run in 32 bits as fused DPP adds (quad_perm xor1, xor2, row_half_mirror[, row_mirror]); the
+// 8 (or 4) group sums are then read with v_readlane and added as 64-bit SCALAR integers — no LDS crossbar round trips.
+__device__ __forceinline__ int dpp_add_xor1(int v) { return v + __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_add_xor2(int v) { return v + __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_add_half_mirror(int v) { return v + __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_add_mirror(int v) { return v + __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false); }
+
+// |per-lane partial| <= 2^28: sums of 8 lanes fit in int32
+__device__ __forceinline__ long long wave_sum_i32x8(int v) {
+    v = dpp_add_xor1(v);
+    v = dpp_add_xor2(v);
+    v = dpp_add_half_mirror(v);
+    long long s = 0;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    for (int g = 0; g < 8; g++) s += (long long) __builtin_amdgcn_readlane(v, g * 8);
+    return s;
+}
+// |per-lane partial| <= 2^27: sums of 16 lanes fit in int32
+__device__ __forceinline__ long long wave_sum_i32x16(int v) {
+    v = dpp_add_xor1(v);
+    v = dpp_add_xor2(v);
+    v = dpp_add_half_mirror(v);
+    v = dpp_add_mirror(v);
+    long long s = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) s += (long long) __builtin_amdgcn_readlane(v, g * 16);
+    return s;
 }
 
 __device__ __forceinline__ int lk_descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
@@ -147,19 +173,19 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
             for (int k = 0; k < 7; k++) {
                 int b0 = t0[k + 1], b1 = t1[k + 1];
                 short2 f0 = d0[k + 1], f1 = d1[k + 1];
-                iv[k] = lk_descale(a0 * w00 + b0 * w01 + a1 * w10 + b1 * w11, 14 - 5);
-                ix[k] = lk_descale(e0.x * w00 + f0.x * w01 + e1.x * w10 + f1.x * w11, 14);
-                iy[k] = lk_descale(e0.y * w00 + f0.y * w01 + e1.y * w10 + f1.y * w11, 14);
-                sA11 += ix[k] * ix[k];
-                sA12 += ix[k] * iy[k];
-                sA22 += iy[k] * iy[k];
+                iv[k] = lk_descale(__mul24(a0, w00) + __mul24(b0, w01) + __mul24(a1, w10) + __mul24(b1, w11), 14 - 5);
+                ix[k] = lk_descale(__mul24(e0.x, w00) + __mul24(f0.x, w01) + __mul24(e1.x, w10) + __mul24(f1.x, w11), 14);
+                iy[k] = lk_descale(__mul24(e0.y, w00) + __mul24(f0.y, w01) + __mul24(e1.y, w10) + __mul24(f1.y, w11), 14);
+                sA11 += __mul24(ix[k], ix[k]);
+                sA12 += __mul24(ix[k], iy[k]);
+                sA22 += __mul24(iy[k], iy[k]);
                 a0 = b0;
                 a1 = b1;
                 e0 = f0;
                 e1 = f1;
             }
         }
-        const long long iA11 = wave_sum_i64(sA11), iA12 = wave_sum_i64(sA12), iA22 = wave_sum_i64(sA22);
+        const long long iA11 = wave_sum_i32x16(sA11), iA12 = wave_sum_i32x16(sA12), iA22 = wave_sum_i32x16(sA22);
         const float A11 = (float) iA11 * FLT_SCALE, A12 = (float) iA12 * FLT_SCALE, A22 = (float) iA22 * FLT_SCALE;
         float D            = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float) (2 * ICG_LK_WIN * ICG_LK_WIN);
@@ -195,14 +221,14 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
 #pragma unroll
                 for (int k = 0; k < 7; k++) {
                     int b0 = t0[k + 1], b1 = t1[k + 1];
-                    int diff = lk_descale(a0 * w00 + b0 * w01 + a1 * w10 + b1 * w11, 14 - 5) - iv[k];
-                    sb1 += diff * ix[k];
-                    sb2 += diff * iy[k];
+                    int diff = lk_descale(__mul24(a0, w00) + __mul24(b0, w01) + __mul24(a1, w10) + __mul24(b1, w11), 14 - 5) - iv[k];
+                    sb1 += __mul24(diff, ix[k]);
+                    sb2 += __mul24(diff, iy[k]);
                     a0 = b0;
                     a1 = b1;
                 }
             }
-            const long long ib1 = wave_sum_i64(sb1), ib2 = wave_sum_i64(sb2);
+            const long long ib1 = wave_sum_i32x8(sb1), ib2 = wave_sum_i32x8(sb2);
             const float b1 = (float) ib1 * FLT_SCALE, b2 = (float) ib2 * FLT_SCALE;
             const float dx = (float) ((A12 * b2 - A22 * b1) * D);
             const float dy = (float) ((A12 * b1 - A11 * b2) * D);
@@ -242,11 +268,11 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                     const unsigned char *t1 = t0 + LK_JT;
 #pragma unroll
                     for (int k = 0; k < 7; k++) {
-                        int diff = lk_descale(t0[k] * w00 + t0[k + 1] * w01 + t1[k] * w10 + t1[k + 1] * w11, 14 - 5) - iv[k];
+                        int diff = lk_descale(__mul24(t0[k], w00) + __mul24(t0[k + 1], w01) + __mul24(t1[k], w10) + __mul24(t1[k + 1], w11), 14 - 5) - iv[k];
                         se += diff < 0 ? -diff : diff;
                     }
                 }
-                const long long ie = wave_sum_i64(se);
+                const long long ie = wave_sum_i32x16(se);
                 errv               = (float) ie * 1.f / (float) (32 * ICG_LK_WIN * ICG_LK_WIN);
             }
         }
@@ -346,15 +372,13 @@ extern "C" int icg_lk_track(icg_ctx *ctx, int n, const int32_t *prev_slot, const
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
     icg_call c(ctx);
     if ((rc = c.reserve((size_t) n * 64))) return rc;
-    const int32_t *d_ps = c.in(prev_slot, (size_t) n);
-    const int32_t *d_ns = c.in(next_slot, (size_t) n);
-    const float2 *d_pp  = (const float2 *) c.in(prev_pts, 2 * (size_t) n);
-    const float2 *d_gs  = (const float2 *) c.in(next_pts, 2 * (size_t) n);
-    if ((rc = c.seal())) return rc;
-    float2 *d_np      = (float2 *) c.out(next_pts, 2 * (size_t) n);
-    unsigned char *d_st = c.out(status, (size_t) n);
-    float *d_err      = err ? c.out(err, (size_t) n) : nullptr;
-    ICG_HIP(ctx, hipMemcpyAsync(d_np, d_gs, sizeof(float2) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    const int32_t *d_ps = c.in_zc(prev_slot, (size_t) n);
+    const int32_t *d_ns = c.in_zc(next_slot, (size_t) n);
+    const float2 *d_pp  = (const float2 *) c.in_zc(prev_pts, 2 * (size_t) n);
+    float2 *d_np        = (float2 *) c.out_zc(next_pts, 2 * (size_t) n); // in/out: initial flow in, result out
+    memcpy(d_np, next_pts, sizeof(float) * 2 * (size_t) n);
+    unsigned char *d_st = c.out_zc(status, (size_t) n);
+    float *d_err        = err ? c.out_zc(err, (size_t) n) : nullptr;
     {
         icg_prof_scope ps(ctx, "lk_track");
         hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp, d_np,
@@ -381,16 +405,15 @@ extern "C" int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, co
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
     icg_call c(ctx);
     if ((rc = c.reserve((size_t) n * 96))) return rc;
-    const int32_t *d_ps = c.in(prev_slot, (size_t) n);
-    const int32_t *d_ns = c.in(next_slot, (size_t) n);
-    const float2 *d_pp  = (const float2 *) c.in(prev_pts, 2 * (size_t) n);
-    const float2 *d_gs  = (const float2 *) c.in(guess_pts, 2 * (size_t) n);
-    if ((rc = c.seal())) return rc;
-    float2 *d_out       = (float2 *) c.out(out_pts, 2 * (size_t) n);
-    unsigned char *d_st = c.out(status, (size_t) n);
-    float2 *d_und       = out_undist ? (float2 *) c.out(out_undist, 2 * (size_t) n) : nullptr;
-    int32_t *d_keep     = keep_idx ? c.out(keep_idx, (size_t) n) : nullptr;
-    int32_t *d_nkeep    = keep_idx ? c.out(n_keep, 1) : nullptr;
+    const int32_t *d_ps = c.in_zc(prev_slot, (size_t) n);
+    const int32_t *d_ns = c.in_zc(next_slot, (size_t) n);
+    const float2 *d_pp  = (const float2 *) c.in_zc(prev_pts, 2 * (size_t) n);
+    const float2 *d_gs  = (const float2 *) c.in_zc(guess_pts, 2 * (size_t) n);
+    float2 *d_out       = (float2 *) c.out_zc(out_pts, 2 * (size_t) n);
+    unsigned char *d_st = c.out_zc(status, (size_t) n);
+    float2 *d_und       = out_undist ? (float2 *) c.out_zc(out_undist, 2 * (size_t) n) : nullptr;
+    int32_t *d_keep     = keep_idx ? c.out_zc(keep_idx, (size_t) n) : nullptr;
+    int32_t *d_nkeep    = keep_idx ? c.out_zc(n_keep, 1) : nullptr;
     {
         icg_prof_scope ps(ctx, "lk_track_fb");
         hipLaunchKernelGGL(k_lk_track_fb, dim3(n), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp,

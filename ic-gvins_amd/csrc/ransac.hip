@@ -386,8 +386,8 @@ extern "C" int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, c
         std::vector<unsigned long long> h_bits((size_t) words);
         double *d_models  = c.out((double *) nullptr, 27 * (size_t) nh_total);
         int32_t *d_nm     = c.out((int32_t *) nullptr, (size_t) nh_total);
-        int32_t *d_good   = c.out(h_good.data(), (size_t) nh_total * 3);
-        unsigned long long *d_bits = c.out(h_bits.data(), (size_t) words);
+        int32_t *d_good   = c.out_zc(h_good.data(), (size_t) nh_total * 3);
+        unsigned long long *d_bits = c.out_zc(h_bits.data(), (size_t) words);
         {
             icg_prof_scope ps(ctx, "fm_seven_point");
             hipLaunchKernelGGL(k_seven_point, dim3((nh_total + SP_LANES - 1) / SP_LANES), dim3(SP_LANES), 0, ctx->stream,
@@ -522,13 +522,12 @@ extern "C" int icg_triangulate(icg_ctx *ctx, int n, const int32_t *T0_idx, const
     icg_call c(ctx);
     int rc = c.reserve((size_t) n * (8 + 48 + 24) + (size_t) n_T * 96);
     if (rc) return rc;
-    const int32_t *d_i0 = c.in(T0_idx, (size_t) n);
-    const int32_t *d_i1 = c.in(T1_idx, (size_t) n);
-    const double *d_T   = c.in(Tcw12, 12 * (size_t) n_T);
-    const double *d_p0  = c.in(pc0, 3 * (size_t) n);
-    const double *d_p1  = c.in(pc1, 3 * (size_t) n);
-    if ((rc = c.seal())) return rc;
-    double *d_pw = c.out(pw, 3 * (size_t) n);
+    const int32_t *d_i0 = c.in_zc(T0_idx, (size_t) n);
+    const int32_t *d_i1 = c.in_zc(T1_idx, (size_t) n);
+    const double *d_T   = c.in_zc(Tcw12, 12 * (size_t) n_T);
+    const double *d_p0  = c.in_zc(pc0, 3 * (size_t) n);
+    const double *d_p1  = c.in_zc(pc1, 3 * (size_t) n);
+    double *d_pw = c.out_zc(pw, 3 * (size_t) n);
     {
         icg_prof_scope ps(ctx, "triangulate");
         hipLaunchKernelGGL(k_triangulate, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, n, d_i0, d_i1, d_T, d_p0, d_p1, d_pw);

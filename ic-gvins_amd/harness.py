@@ -133,6 +133,21 @@ class StreamBatch:
             raise RuntimeError("icgh_batch_step failed: " + self._err.value.decode())
         return states
 
+    def run(self, image_ptrs, stride, stamps, poses12, on_device=False, channels=1):
+        """K steps in one call. image_ptrs: K x n nested list of addresses; stamps (K,n); poses12 (K,n,12)."""
+        K = len(image_ptrs)
+        flat = [(p if p else None) for row in image_ptrs for p in row]
+        ptrs = (C.c_void_p * (K * self.n))(*flat)
+        stamps = np.ascontiguousarray(stamps, np.float64).reshape(K, self.n)
+        poses12 = np.ascontiguousarray(poses12, np.float64).reshape(K, self.n, 12)
+        states = np.zeros((K, self.n), np.int32)
+        rc = self.lib.icgh_batch_run(C.c_void_p(self.h_), K, ptrs, stride, channels, 1 if on_device else 0,
+                                     stamps.ctypes.data_as(C.c_void_p), poses12.ctypes.data_as(C.c_void_p),
+                                     states.ctypes.data_as(C.c_void_p), self._err, 512)
+        if rc != 0:
+            raise RuntimeError("icgh_batch_run failed: " + self._err.value.decode())
+        return states
+
     def stats(self, stream):
         out = np.zeros(8, np.uint64)
         self.lib.icgh_batch_stats(C.c_void_p(self.h_), stream, out.ctypes.data_as(C.c_void_p))

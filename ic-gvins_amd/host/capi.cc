@@ -47,31 +47,41 @@ void *icgh_batch_ctx(icgh_batch *b, int group) {
     return (b && group >= 0 && group < b->tb->groups()) ? (void *) b->tb->group(group).device()->ctx() : nullptr;
 }
 
-// images[i]: pointer to the i-th stream's frame (host or device memory), NULL to idle the stream this step.
-// poses12: n x 12 = R (camera->world, row-major) | t, the INS prior the reference sets with frame->setPose().
-int icgh_batch_step(icgh_batch *b, const void *const *images, int stride, int channels, int on_device, const double *stamps,
-                    const double *poses12, int32_t *states, char *err, int errlen) {
+// K lock-step frames for every stream in one call (K = 1: the classic per-frame step).
+// images[k*n + i]: pointer to the frame of stream i at step k (host or device memory), NULL to idle the stream that step.
+// stamps[k*n + i]; poses12[(k*n + i)*12 ..] = R (camera->world, row-major) | t, the INS prior the reference sets with
+// frame->setPose().  states[k*n + i] receives the TrackState.  Groups do not wait for each other between the K steps.
+int icgh_batch_run(icgh_batch *b, int K, const void *const *images, int stride, int channels, int on_device,
+                   const double *stamps, const double *poses12, int32_t *states, char *err, int errlen) {
     try {
         const int n = b->tb->size();
-        vector<Frame::Ptr> frames((size_t) n);
-        for (int i = 0; i < n; i++) {
-            if (!images[i]) continue;
-            Mat img  = Mat::wrap((uint8_t *) images[i], b->h, b->w, channels, (size_t) stride, on_device != 0);
-            auto f   = Frame::createFrame(stamps[i], img, b->tb->stream(i).ids);
-            Pose p;
-            memcpy(p.R.m, poses12 + 12 * (size_t) i, sizeof(double) * 9);
-            memcpy(p.t.v, poses12 + 12 * (size_t) i + 9, sizeof(double) * 3);
-            f->setPose(p);
-            frames[(size_t) i] = f;
-        }
-        vector<TrackState> st;
-        b->tb->step(frames, st);
-        for (int i = 0; i < n; i++) states[i] = (int32_t) st[(size_t) i];
+        vector<vector<Frame::Ptr>> frames((size_t) K, vector<Frame::Ptr>((size_t) n));
+        for (int k = 0; k < K; k++)
+            for (int i = 0; i < n; i++) {
+                const size_t j = (size_t) k * n + i;
+                if (!images[j]) continue;
+                Mat img = Mat::wrap((uint8_t *) images[j], b->h, b->w, channels, (size_t) stride, on_device != 0);
+                auto f  = Frame::createFrame(stamps[j], img, b->tb->stream(i).ids);
+                Pose p;
+                memcpy(p.R.m, poses12 + 12 * j, sizeof(double) * 9);
+                memcpy(p.t.v, poses12 + 12 * j + 9, sizeof(double) * 3);
+                f->setPose(p);
+                frames[(size_t) k][(size_t) i] = f;
+            }
+        vector<vector<TrackState>> st;
+        b->tb->stepMany(frames, st);
+        for (int k = 0; k < K; k++)
+            for (int i = 0; i < n; i++) states[(size_t) k * n + i] = (int32_t) st[(size_t) k][(size_t) i];
         return 0;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());
         return -1;
     }
+}
+
+int icgh_batch_step(icgh_batch *b, const void *const *images, int stride, int channels, int on_device, const double *stamps,
+                    const double *poses12, int32_t *states, char *err, int errlen) {
+    return icgh_batch_run(b, 1, images, stride, channels, on_device, stamps, poses12, states, err, errlen);
 }
 
 // out: frames, keyframes, tracked_sum, digest, mappoints created, keyframes in window, landmarks in map, last state

@@ -269,10 +269,12 @@ void StreamGroups::workerLoop(int g) {
         const int b = group_begin_[(size_t) g], e = group_begin_[(size_t) g + 1];
         std::string err;
         try {
-            vector<Frame::Ptr> fr(frames_->begin() + b, frames_->begin() + e);
-            vector<TrackState> st;
-            groups_[(size_t) g]->step(fr, st);
-            for (int i = b; i < e; i++) (*states_)[(size_t) i] = st[(size_t) (i - b)];
+            for (size_t k = 0; k < frames_->size(); k++) {
+                vector<Frame::Ptr> fr((*frames_)[k].begin() + b, (*frames_)[k].begin() + e);
+                vector<TrackState> st;
+                groups_[(size_t) g]->step(fr, st);
+                for (int i = b; i < e; i++) (*states_)[k][(size_t) i] = st[(size_t) (i - b)];
+            }
         } catch (const std::exception &ex) {
             err = ex.what();
         }
@@ -285,9 +287,16 @@ void StreamGroups::workerLoop(int g) {
 }
 
 void StreamGroups::step(const vector<Frame::Ptr> &frames, vector<TrackState> &states) {
-    states.assign((size_t) n_streams_, TRACK_PASSED);
+    vector<vector<Frame::Ptr>> f1(1, frames);
+    vector<vector<TrackState>> s1;
+    stepMany(f1, s1);
+    states = s1[0];
+}
+
+void StreamGroups::stepMany(const vector<vector<Frame::Ptr>> &frames, vector<vector<TrackState>> &states) {
+    states.assign(frames.size(), vector<TrackState>((size_t) n_streams_, TRACK_PASSED));
     if (workers_.empty()) {
-        groups_[0]->step(frames, states);
+        for (size_t k = 0; k < frames.size(); k++) groups_[0]->step(frames[k], states[k]);
         return;
     }
     {

@@ -58,6 +58,9 @@ public:
                  const vector<int> &size, const TrackingConfig &cfg, int window_size, int host_threads_per_group);
     ~StreamGroups();
     void step(const vector<Frame::Ptr> &frames, vector<TrackState> &states);
+    // K consecutive steps without a cross-group barrier in between: every group walks through its own K frames at its
+    // own pace (streams are independent, so the per-stream results equal K calls of step()).
+    void stepMany(const vector<vector<Frame::Ptr>> &frames, vector<vector<TrackState>> &states);
     int size() const { return n_streams_; }
     int groups() const { return (int) groups_.size(); }
     TrackingBatch &group(int g) { return *groups_[(size_t) g]; }
@@ -76,8 +79,8 @@ private:
     uint64_t generation_{0};
     int pending_{0};
     bool stop_{false};
-    const vector<Frame::Ptr> *frames_{nullptr};
-    vector<TrackState> *states_{nullptr};
+    const vector<vector<Frame::Ptr>> *frames_{nullptr};
+    vector<vector<TrackState>> *states_{nullptr};
     std::string error_;
 };
 
