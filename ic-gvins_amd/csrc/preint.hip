@@ -1,0 +1,249 @@
+// P1: IMU preintegration inner loop, batched over independent intervals (one 64-lane wavefront per interval).
+//
+// Reference: preintegration/preintegration_base.cc:39-70,86-92 (two-sample coning/sculling integration, bias
+// compensation), preintegration_normal.cc:183-253 and preintegration_earth.cc:205-335 (per-sample error-state transition
+// phi = I + F dt, jacobian_ = phi jacobian_, covariance_ = phi P phi^T + 0.5 dt (phi G Q G^T + G Q G^T phi^T)).
+// The reference does this with heap-allocated dynamic Eigen matrices, one IMU sample at a time.  Here the 15x15 Jacobian
+// and covariance stay in LDS for the whole interval; every lane carries the (uniform) navigation state redundantly and
+// owns <=4 of the 225 matrix entries in each of the six dense 15x15 products per sample.  Strictly sequential over the
+// samples of an interval (quaternion renormalisation), embarrassingly parallel across intervals/streams.
+// Compute/latency bound (72 B in per sample, state on chip): reported as IMU samples/s, not against the HBM roofline.
+#include "dev_math.h"
+#include "icg_internal.h"
+
+using namespace icgd;
+
+namespace {
+struct nav_state {
+    d3 p;
+    dq q;
+    d3 v, bg, ba;
+};
+__device__ __forceinline__ nav_state load_state(const double *s) {
+    nav_state st;
+    st.p  = mk3(s[0], s[1], s[2]);
+    st.q  = dq{s[3], s[4], s[5], s[6]};
+    st.v  = mk3(s[7], s[8], s[9]);
+    st.bg = mk3(s[10], s[11], s[12]);
+    st.ba = mk3(s[13], s[14], s[15]);
+    return st;
+}
+__device__ __forceinline__ void store_state(const nav_state &st, double *s) {
+    s[0] = st.p.x, s[1] = st.p.y, s[2] = st.p.z;
+    s[3] = st.q.x, s[4] = st.q.y, s[5] = st.q.z, s[6] = st.q.w;
+    s[7] = st.v.x, s[8] = st.v.y, s[9] = st.v.z;
+    s[10] = st.bg.x, s[11] = st.bg.y, s[12] = st.bg.z;
+    s[13] = st.ba.x, s[14] = st.ba.y, s[15] = st.ba.z;
+}
+__device__ __forceinline__ dq q_normalized(dq q) {
+    double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    return dq{q.x / n, q.y / n, q.z / n, q.w / n};
+}
+// Rotation::rotvec2quaternion (common/rotation.h:72-76)
+__device__ __forceinline__ dq rotvec2quat(d3 rv) {
+    double angle = sqrt(rv.x * rv.x + rv.y * rv.y + rv.z * rv.z);
+    d3 axis      = rv;
+    if (angle > 0) axis = dvd(rv, angle);
+    double s = sin(0.5 * angle), c = cos(0.5 * angle);
+    return dq{s * axis.x, s * axis.y, s * axis.z, c};
+}
+__device__ __forceinline__ d3 neg3(d3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ m33 m_scale(const m33 &m, double s) {
+    m33 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.a[i] = m.a[i] * s;
+    return r;
+}
+} // namespace
+
+#define PI_IDX(i, j) ((i) * 15 + (j))
+
+__global__ __launch_bounds__(64) void k_preint(int variant, const int32_t *offsets, const double *imu, const double *state0,
+                                               const double *params, double *cur_state, double *delta_state, double *jac_out,
+                                               double *cov_out, double *delta_time_out, double *pn_out) {
+    __shared__ double J[225], P[225], PHI[225], M[225], T1[225], T2[225], GT[15 * 12];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int begin = offsets[s], n = offsets[s + 1] - offsets[s];
+    const double gyr_arw = params[0], acc_vrw = params[1], gbstd = params[2], abstd = params[3], corr_time = params[4];
+    const d3 gravity = mk3(0, 0, params[5]);
+    const d3 iewn    = mk3(params[6], params[7], params[8]);
+    nav_state cur = load_state(state0 + 16 * (size_t) s);
+    nav_state del;
+    del.p = del.v = mk3(0, 0, 0);
+    del.q         = dq{0, 0, 0, 1};
+    del.bg        = cur.bg;
+    del.ba        = cur.ba;
+    const dq q0   = cur.q;
+    double delta_time = 0;
+    double noise[12];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        noise[i]     = gyr_arw * gyr_arw;
+        noise[3 + i] = acc_vrw * acc_vrw;
+        noise[6 + i] = 2 * gbstd * gbstd / corr_time;
+        noise[9 + i] = 2 * abstd * abstd / corr_time;
+    }
+    for (int e = lane; e < 225; e += 64) {
+        J[e] = (e / 15 == e % 15) ? 1.0 : 0.0;
+        P[e] = 0.0;
+    }
+    __syncthreads();
+
+    for (int index = 1; index < n; index++) {
+        const double *pp = imu + 8 * (size_t) (begin + index - 1), *pc = imu + 8 * (size_t) (begin + index);
+        d3 pre_dtheta = mk3(pp[2], pp[3], pp[4]), pre_dvel = mk3(pp[5], pp[6], pp[7]);
+        d3 cur_dtheta = mk3(pc[2], pc[3], pc[4]), cur_dvel = mk3(pc[5], pc[6], pc[7]);
+        const double pre_dt = pp[1], dt = pc[1];
+        pre_dtheta = sub(pre_dtheta, scl(pre_dt, del.bg));
+        pre_dvel   = sub(pre_dvel, scl(pre_dt, del.ba));
+        cur_dtheta = sub(cur_dtheta, scl(dt, del.bg));
+        cur_dvel   = sub(cur_dvel, scl(dt, del.ba));
+        delta_time += dt;
+        d3 dvfb   = add(add(cur_dvel, scl(0.5, crs(cur_dtheta, cur_dvel))),
+                        scl(1.0 / 12.0, add(crs(pre_dtheta, cur_dvel), crs(pre_dvel, cur_dtheta))));
+        d3 dtheta = add(cur_dtheta, scl(1.0 / 12.0, crs(pre_dtheta, cur_dtheta)));
+        m33 blk36, blk312; // phi(3,6) and phi(3,12) blocks
+        m33 gblk;          // gt(3,3) block
+        double g60;        // gt(6,0) diagonal sign
+        if (variant == 0) {
+            d3 dvel = add(m_vec(q_mat(cur.q), dvfb), scl(dt, gravity));
+            cur.p   = add(add(cur.p, scl(dt, cur.v)), scl(0.5 * dt, dvel));
+            cur.v   = add(cur.v, dvel);
+            cur.q   = q_normalized(q_mul(cur.q, rotvec2quat(dtheta)));
+            dvel    = m_vec(q_mat(del.q), dvfb);
+            del.p   = add(add(del.p, scl(dt, del.v)), scl(0.5 * dt, dvel));
+            del.v   = add(del.v, dvel);
+            del.q   = q_normalized(q_mul(del.q, rotvec2quat(dtheta)));
+            m33 Rq  = q_mat(del.q);
+            blk36   = m_mul(m_neg(Rq), m_skew(cur_dvel));
+            blk312  = m_scale(m_neg(Rq), dt);
+            gblk    = Rq;
+            g60     = 1.0;
+        } else {
+            d3 dv_cor_g = scl(dt, sub(gravity, scl(2.0, crs(iewn, cur.v))));
+            d3 dnn      = scl(dt, neg3(iewn));
+            dq qnn      = rotvec2quat(dnn);
+            m33 half    = m_scale(m_add(m_eye(), q_mat(qnn)), 0.5);
+            d3 dvel     = add(m_vec(m_mul(half, q_mat(cur.q)), dvfb), dv_cor_g);
+            cur.p       = add(add(cur.p, scl(dt, cur.v)), scl(0.5 * dt, dvel));
+            cur.v       = add(cur.v, dvel);
+            if (pn_out && lane == 0) { // pn_ (earth :235): (dt, position) per sample, row begin+index-1
+                double *pn = pn_out + 4 * (size_t) (begin + index - 1);
+                pn[0] = dt, pn[1] = cur.p.x, pn[2] = cur.p.y, pn[3] = cur.p.z;
+            }
+            cur.q       = q_normalized(q_mul(q_mul(qnn, cur.q), rotvec2quat(dtheta)));
+            dnn         = scl(-(delta_time - 0.5 * dt), iewn);
+            dvel        = m_vec(q_mat(q_mul(q_mul(q_mul(q_inv(q0), rotvec2quat(dnn)), q0), del.q)), dvfb);
+            del.p       = add(add(del.p, scl(dt, del.v)), scl(0.5 * dt, dvel));
+            del.v       = add(del.v, dvel);
+            del.q       = q_normalized(q_mul(del.q, rotvec2quat(dtheta)));
+            d3 dnn2     = scl(delta_time, neg3(iewn));
+            m33 cbb0    = m_neg(q_mat(q_mul(q_mul(q_mul(q_inv(q0), rotvec2quat(dnn2)), q0), del.q)));
+            blk36       = m_mul(cbb0, m_skew(cur_dvel));
+            blk312      = m_scale(cbb0, dt);
+            gblk        = cbb0;
+            g60         = -1.0;
+        }
+        // phi and gt into LDS (each lane fills its entries)
+        const m33 sk  = m_skew(cur_dtheta);
+        const double decay = 1 - dt / corr_time;
+        for (int e = lane; e < 225; e += 64) {
+            const int i = e / 15, j = e - i * 15;
+            const int bi = i / 3, bj = j / 3, ii = i - bi * 3, jj = j - bj * 3;
+            double v = 0.0;
+            if (bi == 0 && bj == 0) v = (ii == jj) ? 1.0 : 0.0;
+            else if (bi == 0 && bj == 1) v = (ii == jj) ? dt : 0.0;
+            else if (bi == 1 && bj == 1) v = (ii == jj) ? 1.0 : 0.0;
+            else if (bi == 1 && bj == 2) v = blk36.a[ii * 3 + jj];
+            else if (bi == 1 && bj == 4) v = blk312.a[ii * 3 + jj];
+            else if (bi == 2 && bj == 2) v = ((ii == jj) ? 1.0 : 0.0) - sk.a[ii * 3 + jj];
+            else if (bi == 2 && bj == 3) v = (ii == jj) ? -dt : 0.0;
+            else if (bi == 3 && bj == 3) v = (ii == jj) ? decay : 0.0;
+            else if (bi == 4 && bj == 4) v = (ii == jj) ? decay : 0.0;
+            PHI[e] = v;
+        }
+        for (int e = lane; e < 180; e += 64) {
+            const int i = e / 12, j = e - i * 12;
+            const int bi = i / 3, bj = j / 3, ii = i - bi * 3, jj = j - bj * 3;
+            double v = 0.0;
+            if (bi == 1 && bj == 1) v = gblk.a[ii * 3 + jj];
+            else if (bi == 2 && bj == 0) v = (ii == jj) ? g60 : 0.0;
+            else if (bi == 3 && bj == 2) v = (ii == jj) ? 1.0 : 0.0;
+            else if (bi == 4 && bj == 3) v = (ii == jj) ? 1.0 : 0.0;
+            GT[e] = v;
+        }
+        __syncthreads();
+        // T1 = phi*J ; M = gt noise gt^T ; T2 = phi*P
+        for (int e = lane; e < 225; e += 64) {
+            const int i = e / 15, j = e - i * 15;
+            double a = 0, b = 0, m = 0;
+#pragma unroll
+            for (int k = 0; k < 15; k++) {
+                a += PHI[PI_IDX(i, k)] * J[PI_IDX(k, j)];
+                b += PHI[PI_IDX(i, k)] * P[PI_IDX(k, j)];
+            }
+#pragma unroll
+            for (int k = 0; k < 12; k++) m += GT[i * 12 + k] * noise[k] * GT[j * 12 + k];
+            T1[e] = a;
+            T2[e] = b;
+            M[e]  = m;
+        }
+        __syncthreads();
+        // J = T1 ; P = T2*phi^T + 0.5 dt (phi*M + M*phi^T)
+        for (int e = lane; e < 225; e += 64) {
+            const int i = e / 15, j = e - i * 15;
+            double pc2 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+            for (int k = 0; k < 15; k++) {
+                pc2 += T2[PI_IDX(i, k)] * PHI[PI_IDX(j, k)];
+                t1 += PHI[PI_IDX(i, k)] * M[PI_IDX(k, j)];
+                t2 += M[PI_IDX(i, k)] * PHI[PI_IDX(j, k)];
+            }
+            J[e] = T1[e];
+            P[e] = pc2 + 0.5 * dt * (t1 + t2);
+        }
+        __syncthreads();
+    }
+    for (int e = lane; e < 225; e += 64) {
+        jac_out[225 * (size_t) s + e] = J[e];
+        cov_out[225 * (size_t) s + e] = P[e];
+    }
+    if (lane == 0) {
+        store_state(cur, cur_state + 16 * (size_t) s);
+        store_state(del, delta_state + 16 * (size_t) s);
+        delta_time_out[s] = delta_time;
+    }
+}
+
+extern "C" int icg_preint_batch(icg_ctx *ctx, int variant, int n_intervals, const int32_t *offsets, const double *imu,
+                                const double *state0, const double *params, double *cur_state, double *delta_state, double *jac,
+                                double *cov, double *delta_time, double *pn) {
+    if (!ctx || n_intervals < 0 || (variant != 0 && variant != 1)) return ICG_ERR_INVALID;
+    if (n_intervals == 0) return ICG_OK;
+    if (!offsets || !imu || !state0 || !params || !cur_state || !delta_state || !jac || !cov || !delta_time) return ICG_ERR_INVALID;
+    const int total = offsets[n_intervals];
+    for (int s = 0; s < n_intervals; s++)
+        if (offsets[s + 1] - offsets[s] < 1) return icg_fail(ctx, ICG_ERR_INVALID, "interval %d has no IMU sample", s);
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    icg_call c(ctx);
+    int rc = c.reserve((size_t) total * 96 + (size_t) n_intervals * (16 * 8 * 3 + 225 * 8 * 2 + 16) + 1024);
+    if (rc) return rc;
+    const int32_t *d_off = c.in(offsets, (size_t) n_intervals + 1);
+    const double *d_imu  = c.in(imu, 8 * (size_t) total);
+    const double *d_s0   = c.in(state0, 16 * (size_t) n_intervals);
+    const double *d_par  = c.in(params, 9);
+    if ((rc = c.seal())) return rc;
+    double *d_cur = c.out_zc(cur_state, 16 * (size_t) n_intervals);
+    double *d_del = c.out_zc(delta_state, 16 * (size_t) n_intervals);
+    double *d_jac = c.out_zc(jac, 225 * (size_t) n_intervals);
+    double *d_cov = c.out_zc(cov, 225 * (size_t) n_intervals);
+    double *d_dt  = c.out_zc(delta_time, (size_t) n_intervals);
+    double *d_pn  = pn ? c.out_zc(pn, 4 * (size_t) total) : nullptr;
+    {
+        icg_prof_scope ps(ctx, "preint");
+        hipLaunchKernelGGL(k_preint, dim3(n_intervals), dim3(64), 0, ctx->stream, variant, d_off, d_imu, d_s0, d_par, d_cur, d_del,
+                           d_jac, d_cov, d_dt, d_pn);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}

@@ -310,3 +310,103 @@ extern "C" int icg_reproj_eval_batch(icg_ctx *ctx, int n, const double *obs_soa,
     if (rc) return rc;
     return icg_reproj_eval_resident(ctx, n_poses, poses, ext, n_lm, invdepth, td, want_jac, huber_delta, out_r, out_J);
 }
+
+// ---- M2: MarginalizationInfo::constructEquation for the resident reprojection factors -------------------------------
+// Reference: factors/marginalization_info.h:195-230 — H0 += Ji^T Jj over all block pairs of a factor, b0 -= Ji^T e.
+// One lane per factor.  Entries that every factor of the launch shares (extrinsic x extrinsic, extrinsic x td, td x td
+// and their b0 rows) are first reduced in LDS with ds_add_f64 and flushed with ONE global atomic per entry and
+// workgroup; pose / landmark blocks go straight to hardware FP64 atomics (addresses differ between factors).
+// Summation order is not fixed -> results equal the sequential sum to ~1e-15 relative (tolerance-tested, not bit-tested).
+#define NRM_BLOCK 256
+
+__global__ __launch_bounds__(NRM_BLOCK) void k_reproj_normal(int n, const double *r, const double *J, const int32_t *idx_i,
+                                                             const int32_t *idx_j, const int32_t *idx_lm,
+                                                             const int32_t *col_pose, int col_ext, const int32_t *col_lm,
+                                                             int col_td, int L, double *H, double *b) {
+    __shared__ double sh[7 * 7 + 7]; // shared (ext|td) x (ext|td) block and its b rows
+    const int t = threadIdx.x;
+    for (int e = t; e < 56; e += NRM_BLOCK) sh[e] = 0.0;
+    __syncthreads();
+    const int f = blockIdx.x * NRM_BLOCK + t;
+    if (f < n) {
+        const double *Jf = J + 46 * (size_t) f;
+        const double r0 = r[2 * (size_t) f], r1 = r[2 * (size_t) f + 1];
+        const int col[5] = {col_pose[idx_i[f]], col_pose[idx_j[f]], col_ext, col_lm[idx_lm[f]], col_td};
+        const int sz[5]  = {6, 6, 6, 1, 1};
+        const int off[5] = {0, 14, 28, 42, 44};
+        const int ld[5]  = {7, 7, 7, 1, 1};
+        const int shoff[5] = {-1, -1, 0, -1, 6}; // position of the block inside the shared 7-vector
+#pragma unroll
+        for (int a = 0; a < 5; a++) {
+            if (col[a] < 0) continue;
+#pragma unroll
+            for (int bb = 0; bb < 5; bb++) {
+                if (col[bb] < 0) continue;
+                const bool shared_pair = shoff[a] >= 0 && shoff[bb] >= 0;
+                for (int x = 0; x < sz[a]; x++)
+                    for (int y = 0; y < sz[bb]; y++) {
+                        double v = Jf[off[a] + x] * Jf[off[bb] + y] + Jf[off[a] + ld[a] + x] * Jf[off[bb] + ld[bb] + y];
+                        if (shared_pair)
+                            atomicAdd(&sh[(shoff[a] + x) * 7 + shoff[bb] + y], v);
+                        else
+                            unsafeAtomicAdd(&H[(size_t) (col[a] + x) * L + col[bb] + y], v);
+                    }
+            }
+            for (int x = 0; x < sz[a]; x++) {
+                double v = -(Jf[off[a] + x] * r0 + Jf[off[a] + ld[a] + x] * r1);
+                if (shoff[a] >= 0)
+                    atomicAdd(&sh[49 + shoff[a] + x], v);
+                else
+                    unsafeAtomicAdd(&b[col[a] + x], v);
+            }
+        }
+    }
+    __syncthreads();
+    // flush the shared block
+    for (int e = t; e < 56; e += NRM_BLOCK) {
+        double v = sh[e];
+        if (v == 0.0) continue;
+        if (e < 49) {
+            int x = e / 7, y = e - x * 7;
+            int cx = x < 6 ? col_ext + x : col_td, cy = y < 6 ? col_ext + y : col_td;
+            if ((x < 6 ? col_ext : col_td) >= 0 && (y < 6 ? col_ext : col_td) >= 0) unsafeAtomicAdd(&H[(size_t) cx * L + cy], v);
+        } else {
+            int x = e - 49;
+            int cx = x < 6 ? col_ext + x : col_td;
+            if ((x < 6 ? col_ext : col_td) >= 0) unsafeAtomicAdd(&b[cx], v);
+        }
+    }
+}
+
+extern "C" int icg_reproj_accumulate_normal(icg_ctx *ctx, int local_size, const int32_t *col_pose, int32_t col_ext,
+                                            const int32_t *col_lm, int32_t col_td, double *H0, double *b0) {
+    if (!ctx || local_size <= 0 || !col_pose || !col_lm || !H0 || !b0) return ICG_ERR_INVALID;
+    if (!ctx->rJ_valid || !ctx->rJ_has_jac) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Jacobians: call icg_reproj_eval_* with want_jac first");
+    const int n = ctx->n_factors_resident;
+    if (n == 0) return ICG_OK;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t L = (size_t) local_size;
+    icg_call c(ctx);
+    int rc = c.reserve(sizeof(int32_t) * ((size_t) ctx->last_n_poses + ctx->last_n_lm) + sizeof(double) * (L * L + L) * 2 + 4096);
+    if (rc) return rc;
+    const int32_t *d_cp = c.in(col_pose, (size_t) ctx->last_n_poses);
+    const int32_t *d_cl = c.in(col_lm, (size_t) ctx->last_n_lm);
+    if ((rc = c.seal())) return rc;
+    std::vector<double> hH(L * L), hb(L);
+    double *d_H = c.out(hH.data(), L * L);
+    double *d_b = c.out(hb.data(), L);
+    ICG_HIP(ctx, hipMemsetAsync(d_H, 0, sizeof(double) * L * L, ctx->stream));
+    ICG_HIP(ctx, hipMemsetAsync(d_b, 0, sizeof(double) * L, ctx->stream));
+    {
+        icg_prof_scope ps(ctx, "reproj_normal");
+        hipLaunchKernelGGL(k_reproj_normal, dim3((n + NRM_BLOCK - 1) / NRM_BLOCK), dim3(NRM_BLOCK), 0, ctx->stream, n,
+                           (const double *) ctx->d_rJ, (const double *) (ctx->d_rJ + 2 * (size_t) ctx->factors_cap),
+                           (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n),
+                           (const int32_t *) (ctx->d_fidx + 2 * (size_t) n), d_cp, (int) col_ext, d_cl, (int) col_td, local_size, d_H, d_b);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    if ((rc = c.finish())) return rc;
+    for (size_t i = 0; i < L * L; i++) H0[i] += hH[i];
+    for (size_t i = 0; i < L; i++) b0[i] += hb[i];
+    return ICG_OK;
+}

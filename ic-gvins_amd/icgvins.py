@@ -313,6 +313,7 @@ class Context:
         jac = np.zeros((n, 15, 15))
         cov = np.zeros((n, 15, 15))
         dt = np.zeros(n)
+        pn = np.zeros((imu.shape[0], 4))
         self._ck(self.lib.icg_preint_batch(self.h, int(variant), n, _p(offsets), _p(imu), _p(state0), _p(_f64(params)),
-                                            _p(cur), _p(delta), _p(jac), _p(cov), _p(dt)), "icg_preint_batch")
-        return cur, delta, jac, cov, dt
+                                            _p(cur), _p(delta), _p(jac), _p(cov), _p(dt), _p(pn)), "icg_preint_batch")
+        return cur, delta, jac, cov, dt, pn

@@ -174,10 +174,12 @@ int icg_reproj_accumulate_normal(icg_ctx *ctx, int local_size, const int32_t *co
  * imu: total x 8 doubles (time, dt, dtheta[3], dvel[3]); interval s owns samples [offsets[s], offsets[s+1]) with
  * sample 0 = imu0.  state0: n x 16 (p3, q4 xyzw, v3, bg3, ba3).  params: 9 doubles
  * (gyr_arw, acc_vrw, gyr_bias_std, acc_bias_std, corr_time, gravity, iewn[3]).  variant: 0 Normal, 1 Earth.
- * outputs per interval: cur_state 16, delta_state 16, jac 225, cov 225, delta_time 1. */
+ * outputs per interval: cur_state 16, delta_state 16, jac 225, cov 225, delta_time 1.
+ * pn (optional, total x 4): the Earth variant's pn_ list (preintegration_earth.cc:235) — (dt, position) after sample
+ * index of interval s is stored at row offsets[s] + index - 1. */
 int icg_preint_batch(icg_ctx *ctx, int variant, int n_intervals, const int32_t *offsets, const double *imu,
                      const double *state0, const double *params, double *cur_state, double *delta_state, double *jac,
-                     double *cov, double *delta_time);
+                     double *cov, double *delta_time, double *pn);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,9 @@ void orc_triangulate_point(const double *T0 /*3x4 row-major*/, const double *T1,
 
 // ---- marginalization (orc_marg.cc) -------------------------------------------------------------------
 int orc_sym_eigen(int n, const double *A, double *evals, double *evecs);
+void orc_reproj_accumulate_normal(int n, const double *r, const double *J, const int32_t *idx_i, const int32_t *idx_j,
+                                  const int32_t *idx_lm, const int32_t *col_pose, int col_ext, const int32_t *col_lm, int col_td,
+                                  int local_size, double *H0, double *b0);
 int orc_marginalize(int n_total, int m, const double *H0, const double *b0, double eps, double *J0 /*r x r*/,
                     double *e0 /*r*/, double *Hp /*r x r*/, double *bp /*r*/);
 void orc_marg_factor_eval(int r, int n_blocks, const int *block_size, const int *block_index /*local idx - m*/,

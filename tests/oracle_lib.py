@@ -226,6 +226,62 @@ class Oracle:
         return pw
 
 
+    # ---- preintegration
+    def preint_integrate(self, variant, imu, state0, params):
+        imu = _f64(imu).reshape(-1, 8)
+        n = imu.shape[0]
+        cur, delta = np.zeros(16), np.zeros(16)
+        jac, cov = np.zeros((15, 15)), np.zeros((15, 15))
+        dt = C.c_double(0)
+        pn = np.zeros((max(n - 1, 1), 4))
+        self.lib.orc_preint_integrate(int(variant), n, _p(imu), _p(_f64(state0)), _p(_f64(params)), _p(cur), _p(delta), _p(jac),
+                                      _p(cov), C.byref(dt), _p(pn))
+        return dict(cur=cur, delta=delta, jac=jac, cov=cov, dt=dt.value, pn=pn[:n - 1])
+
+    def preint_evaluate(self, variant, pre, gravity3, iewn3, pose0, mix0, pose1, mix1, want_jac=True):
+        r = np.zeros(15)
+        J = np.zeros(15 * 32) if want_jac else None
+        pn = _f64(pre["pn"])
+        self.lib.orc_preint_evaluate(int(variant), _p(_f64(pre["delta"])), _p(_f64(pre["jac"])), _p(_f64(pre["cov"])),
+                                     C.c_double(pre["dt"]), _p(_f64(gravity3)), _p(_f64(iewn3)), pn.shape[0], _p(pn), None,
+                                     _p(_f64(pose0)), _p(_f64(mix0)), _p(_f64(pose1)), _p(_f64(mix1)), _p(r), _p(J))
+        if not want_jac:
+            return r, None
+        return r, (J[:105].reshape(15, 7), J[105:240].reshape(15, 9), J[240:345].reshape(15, 7), J[345:].reshape(15, 9))
+
+
+    # ---- marginalization
+    def sym_eigen(self, A):
+        A = _f64(A)
+        n = A.shape[0]
+        ev, V = np.zeros(n), np.zeros((n, n))
+        self.lib.orc_sym_eigen(n, _p(A), _p(ev), _p(V))
+        return ev, V
+
+    def reproj_accumulate_normal(self, r, J, idx_i, idx_j, idx_lm, col_pose, col_ext, col_lm, col_td, local_size):
+        H, b = np.zeros((local_size, local_size)), np.zeros(local_size)
+        r, J = _f64(r), _f64(J)
+        self.lib.orc_reproj_accumulate_normal(r.shape[0], _p(r), _p(J), _p(_i32(idx_i)), _p(_i32(idx_j)), _p(_i32(idx_lm)),
+                                              _p(_i32(col_pose)), int(col_ext), _p(_i32(col_lm)), int(col_td), local_size, _p(H), _p(b))
+        return H, b
+
+    def marginalize(self, H0, b0, m, eps=1e-8):
+        H0, b0 = _f64(H0), _f64(b0)
+        n = H0.shape[0]
+        r = n - m
+        J0, e0, Hp, bp = np.zeros((r, r)), np.zeros(r), np.zeros((r, r)), np.zeros(r)
+        self.lib.orc_marginalize(n, m, _p(H0), _p(b0), C.c_double(eps), _p(J0), _p(e0), _p(Hp), _p(bp))
+        return J0, e0, Hp, bp
+
+    def marg_factor_eval(self, block_size, block_index, x0, x, J0, e0, want_jac=True):
+        r = J0.shape[0]
+        res = np.zeros(r)
+        jac = np.zeros(r * int(np.sum(block_size))) if want_jac else None
+        self.lib.orc_marg_factor_eval(r, len(block_size), _p(_i32(block_size)), _p(_i32(block_index)), _p(_f64(x0)), _p(_f64(x)),
+                                      _p(_f64(J0)), _p(_f64(e0)), _p(res), _p(jac))
+        return res, jac
+
+
 def build():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
 

@@ -58,3 +58,23 @@ def test_reproj_resident_reevaluation(oracle, ctx):
         r_exp, J_exp = oracle.reproj_eval(w["obs_soa"], w["idx_i"], w["idx_j"], w["idx_lm"], poses, w["ext"], inv, w["td"])
         r, J = ctx.reproj_eval_resident(poses, w["ext"], inv, w["td"])
         assert _close(r, r_exp) and _close(J, J_exp)
+
+
+def test_normal_equation_assembly_matches_oracle(oracle, ctx):
+    """M2: constructEquation over the resident (Huber-corrected) reprojection Jacobians."""
+    import marg_data as md
+    P = md.make_problem(n_lm=120, n_kf=8, seed=4)
+    w = P["w"]
+    r_exp, J_exp = oracle.reproj_eval(P["obs"], P["ii"], P["jj"], P["ll"], w["poses"], w["ext"], w["invdepth"], w["td"], huber=1.0)
+    H_exp, b_exp = oracle.reproj_accumulate_normal(r_exp, J_exp, P["ii"], P["jj"], P["ll"], P["col_pose"], P["col_ext"], P["col_lm"],
+                                                   P["col_td"], P["local_size"])
+    ctx.reproj_set_factors(P["obs"], P["ii"], P["jj"], P["ll"])
+    ctx.reproj_eval_resident(w["poses"], w["ext"], w["invdepth"], w["td"], want_jac=True, huber=1.0)
+    H, b = ctx.reproj_accumulate_normal(P["local_size"], P["col_pose"], P["col_ext"], P["col_lm"], P["col_td"])
+    assert np.abs(H - H_exp).max() <= 1e-9 * np.abs(H_exp).max()
+    assert np.abs(b - b_exp).max() <= 1e-9 * np.abs(b_exp).max()
+    # constant extrinsic / td (optimize_estimate_extrinsic=false): their rows and columns vanish
+    P2 = md.make_problem(n_lm=120, n_kf=8, seed=4, estimate_ext=False, estimate_td=False)
+    H2, b2 = ctx.reproj_accumulate_normal(P2["local_size"], P2["col_pose"], -1, P2["col_lm"], -1)
+    H2e, b2e = oracle.reproj_accumulate_normal(r_exp, J_exp, P["ii"], P["jj"], P["ll"], P2["col_pose"], -1, P2["col_lm"], -1, P2["local_size"])
+    assert np.abs(H2 - H2e).max() <= 1e-9 * np.abs(H2e).max() and np.abs(b2 - b2e).max() <= 1e-9 * np.abs(b2e).max()
