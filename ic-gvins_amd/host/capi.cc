@@ -131,3 +131,253 @@ int icgh_batch_features(icgh_batch *b, int stream, int max, uint64_t *ids, float
 }
 
 } // extern "C"
+
+// ---- back-end test/driver entry points -----------------------------------------------------------------------------------
+#include "factors.h"
+
+namespace {
+// simple generic host factor used to exercise the non-reprojection path of MarginalizationInfo:
+// residual = w * [p - p0 ; 2 vec(q0^-1 q)] on one pose block (6 residuals, 7 parameters)
+class PosePriorFactor : public ceres::SizedCostFunction<6, 7> {
+public:
+    PosePriorFactor(const double *pose0, double weight) : w_(weight) { memcpy(x0_, pose0, sizeof x0_); }
+    bool Evaluate(const double *const *parameters, double *residuals, double **jacobians) const override {
+        const double *x = parameters[0];
+        const double n2 = x0_[3] * x0_[3] + x0_[4] * x0_[4] + x0_[5] * x0_[5] + x0_[6] * x0_[6];
+        const double ax = -x0_[3] / n2, ay = -x0_[4] / n2, az = -x0_[5] / n2, aw = x0_[6] / n2;
+        const double bx = x[3], by = x[4], bz = x[5], bw = x[6];
+        const double dq[4] = {aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz,
+                              aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz};
+        for (int k = 0; k < 3; k++) {
+            residuals[k]     = w_ * (x[k] - x0_[k]);
+            residuals[3 + k] = w_ * 2.0 * dq[k];
+        }
+        if (jacobians && jacobians[0]) {
+            memset(jacobians[0], 0, sizeof(double) * 42);
+            for (int k = 0; k < 3; k++) {
+                jacobians[0][k * 7 + k]           = w_;
+                jacobians[0][(3 + k) * 7 + 3 + k] = w_ * dq[3]; // d(2 vec(dq * exp(phi/2)))/dphi ~ w I at dq ~ identity
+            }
+        }
+        return true;
+    }
+
+private:
+    double x0_[7], w_;
+};
+} // namespace
+
+extern "C" {
+
+// R1 through the ceres::CostFunction surface: factors + EvaluationCallback, one Evaluate() per factor.
+// rc: 0 ok, 1 = an unprepared factor did NOT fail (contract violation), <0 = error.
+int icgh_backend_reproj(int n, const double *obs_soa, const int32_t *idx_i, const int32_t *idx_j, const int32_t *idx_lm,
+                        int n_poses, const double *poses, const double *ext, int n_lm, const double *invdepth, double td,
+                        double *out_r, double *out_J, char *err, int errlen) {
+    try {
+        vector<double> P(poses, poses + 7 * (size_t) n_poses), E(ext, ext + 7), D(invdepth, invdepth + n_lm);
+        double TD = td;
+        vector<std::unique_ptr<ReprojectionFactor>> factors;
+        ReprojectionBatch batch(0);
+        for (int k = 0; k < n; k++) {
+            auto o = [&](int c) { return obs_soa[(size_t) c * n + k]; };
+            factors.emplace_back(new ReprojectionFactor(Vector3d(o(0), o(1), o(2)), Vector3d(o(3), o(4), o(5)), Vector3d(o(6), o(7), o(8)),
+                                                        Vector3d(o(9), o(10), o(11)), o(12), o(13), o(14)));
+        }
+        // before registration / preparation Evaluate must fail
+        {
+            double r[2];
+            const double *params[5] = {&P[0], &P[0], E.data(), &D[0], &TD};
+            if (n > 0 && factors[0]->Evaluate(params, r, nullptr)) return 1;
+        }
+        for (int k = 0; k < n; k++)
+            batch.add(factors[(size_t) k].get(), &P[7 * (size_t) idx_i[k]], &P[7 * (size_t) idx_j[k]], E.data(), &D[(size_t) idx_lm[k]], &TD);
+        batch.finalize();
+        {
+            double r[2];
+            const double *params[5] = {&P[0], &P[0], E.data(), &D[0], &TD};
+            if (n > 0 && factors[0]->Evaluate(params, r, nullptr)) return 1; // registered but not prepared
+        }
+        batch.PrepareForEvaluation(true, true);
+        for (int k = 0; k < n; k++) {
+            const double *params[5] = {&P[7 * (size_t) idx_i[k]], &P[7 * (size_t) idx_j[k]], E.data(), &D[(size_t) idx_lm[k]], &TD};
+            double *J              = out_J + 46 * (size_t) k;
+            double *jac[5]         = {J, J + 14, J + 28, J + 42, J + 44};
+            if (!factors[(size_t) k]->Evaluate(params, out_r + 2 * (size_t) k, jac)) {
+                set_err(err, errlen, batch.error().c_str());
+                return -2;
+            }
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
+// M1-M4 through the reference's API: marginalize pose 0 and the landmarks it references.  Parameter ids: pose k -> k,
+// landmark l -> 100000 + l, extrinsic -> 900000, td -> 900001.  estimate_ext/td = 0 keeps those blocks out (constant).
+// Outputs: sizes[0..1] = marginalized, remained local sizes; rem_ids/rem_index/rem_size per retained block (caller
+// allocates n_poses + n_lm + 2 entries); Hp, bp, J0, e0 sized by the caller to (6*n_poses + n_lm + 7)^2 etc.
+// Then evaluates MarginalizationFactor at x = current parameters perturbed by `perturb` (applied as p += d, per block by
+// id order of rem_ids) and writes residuals to marg_res.
+int icgh_backend_marginalize(int n, const double *obs_soa, const int32_t *idx_i, const int32_t *idx_j, const int32_t *idx_lm,
+                             int n_poses, const double *poses, const double *ext, int n_lm, const double *invdepth, double td,
+                             double huber_delta, double prior_weight, int estimate_ext, int estimate_td, int32_t *sizes,
+                             int64_t *rem_ids, int32_t *rem_index, int32_t *rem_size, int32_t *n_rem, double *Hp, double *bp,
+                             double *J0, double *e0, const double *x_eval /* concatenated by rem order, may be NULL */,
+                             double *marg_res, char *err, int errlen) {
+    try {
+        vector<double> P(poses, poses + 7 * (size_t) n_poses), E(ext, ext + 7), D(invdepth, invdepth + n_lm);
+        double TD = td;
+        std::unordered_map<long, long> ids;
+        std::unordered_map<long, double *> address;
+        auto reg = [&](double *p, long id) {
+            ids[reinterpret_cast<long>(p)] = id;
+            address[id]                     = p;
+        };
+        for (int k = 0; k < n_poses; k++) reg(&P[7 * (size_t) k], k);
+        for (int l = 0; l < n_lm; l++) reg(&D[(size_t) l], 100000 + l);
+        reg(E.data(), 900000);
+        reg(&TD, 900001);
+        (void) estimate_ext;
+        (void) estimate_td;
+
+        auto info = std::make_shared<MarginalizationInfo>();
+        info->updateParamtersIds(ids);
+        ReprojectionBatch batch(0);
+        info->setReprojectionBatch(&batch);
+        auto loss = huber_delta > 0 ? std::make_shared<HuberLossHip>(huber_delta) : nullptr;
+        for (int k = 0; k < n; k++) {
+            auto o = [&](int c) { return obs_soa[(size_t) c * n + k]; };
+            auto f = std::make_shared<ReprojectionFactor>(Vector3d(o(0), o(1), o(2)), Vector3d(o(3), o(4), o(5)), Vector3d(o(6), o(7), o(8)),
+                                                          Vector3d(o(9), o(10), o(11)), o(12), o(13), o(14));
+            double *pi = &P[7 * (size_t) idx_i[k]], *pj = &P[7 * (size_t) idx_j[k]], *lm = &D[(size_t) idx_lm[k]];
+            batch.add(f.get(), pi, pj, E.data(), lm, &TD);
+            // marginalize {pose_ref, invdepth} as ic_gvins.cc:1600-1606 does
+            info->addResidualBlockInfo(std::make_shared<ResidualBlockInfo>(f, loss, vector<double *>{pi, pj, E.data(), lm, &TD}, vector<int>{0, 3}));
+        }
+        batch.finalize();
+        // host-evaluated generic factor on the marginalized pose (stands in for prior/IMU factors of the real window)
+        vector<double> pose0_prior(P.begin(), P.begin() + 7);
+        pose0_prior[0] += 0.01; // non-zero residual
+        info->addResidualBlockInfo(std::make_shared<ResidualBlockInfo>(std::make_shared<PosePriorFactor>(pose0_prior.data(), prior_weight),
+                                                                       nullptr, vector<double *>{&P[0]}, vector<int>{0}));
+        if (!info->marginalization()) {
+            set_err(err, errlen, ("marginalization failed: " + batch.error()).c_str());
+            return -2;
+        }
+        auto blocks = info->getParamterBlocks(address);
+        sizes[0]    = info->marginalizedSize();
+        sizes[1]    = info->remainedSize();
+        *n_rem      = (int32_t) blocks.size();
+        for (size_t b = 0; b < blocks.size(); b++) {
+            rem_ids[b]   = ids[reinterpret_cast<long>(blocks[b])];
+            rem_index[b] = info->remainedBlockIndex()[b];
+            rem_size[b]  = info->remainedBlockSize()[b];
+        }
+        const size_t r = (size_t) info->remainedSize();
+        memcpy(Hp, info->Hp().data(), sizeof(double) * r * r);
+        memcpy(bp, info->bp().data(), sizeof(double) * r);
+        memcpy(J0, info->linearizedJacobians().data(), sizeof(double) * r * r);
+        memcpy(e0, info->linearizedResiduals().data(), sizeof(double) * r);
+        if (x_eval && marg_res) {
+            MarginalizationFactor factor(info);
+            vector<const double *> params;
+            size_t off = 0;
+            for (size_t b = 0; b < blocks.size(); b++) {
+                params.push_back(x_eval + off);
+                off += (size_t) rem_size[b];
+            }
+            if (!factor.Evaluate(params.data(), marg_res, nullptr)) return -3;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
+// P1 (device batch) + P2 (host evaluate) through the Preintegration / PreintegrationFactor classes.
+// imu: total x 8; offsets: n+1; state0: n x 16; params9 as icg_preint_batch; pose/mix: the evaluation point per interval
+// (pose0[7], mix0[9], pose1[7], mix1[9] concatenated = 32 doubles per interval).  Outputs: cur_state n x 16, residuals
+// n x 15, jacobians n x 480 (15x7 | 15x9 | 15x7 | 15x9).
+int icgh_backend_preint(int variant, int n, const int32_t *offsets, const double *imu, const double *state0, const double *params9,
+                        const double *eval_point, double *cur_state, double *residuals, double *jacobians, char *err, int errlen) {
+    try {
+        auto P           = std::make_shared<IntegrationParameters>();
+        P->gyr_arw       = params9[0];
+        P->acc_vrw       = params9[1];
+        P->gyr_bias_std  = params9[2];
+        P->acc_bias_std  = params9[3];
+        P->corr_time     = params9[4];
+        P->gravity       = params9[5];
+        P->iewn          = Vector3d(params9[6], params9[7], params9[8]);
+        icg_ctx_config cfg{};
+        cfg.device = 0, cfg.width = 64, cfg.height = 64, cfg.n_slots = 1, cfg.max_batch = 1, cfg.max_points = 64;
+        icg_ctx *ctx = nullptr;
+        if (icg_ctx_create(&cfg, &ctx) != ICG_OK) {
+            set_err(err, errlen, icg_last_error(nullptr));
+            return -1;
+        }
+        auto mk_imu = [&](int row) {
+            const double *p = imu + 8 * (size_t) row;
+            IMU s;
+            s.time = p[0], s.dt = p[1];
+            s.dtheta = Vector3d(p[2], p[3], p[4]);
+            s.dvel   = Vector3d(p[5], p[6], p[7]);
+            return s;
+        };
+        vector<std::shared_ptr<Preintegration>> pre;
+        vector<Preintegration *> raw;
+        for (int k = 0; k < n; k++) {
+            const double *s = state0 + 16 * (size_t) k;
+            IntegrationState st;
+            st.p = Vector3d(s[0], s[1], s[2]);
+            st.q = Quaterniond{s[3], s[4], s[5], s[6]};
+            st.v = Vector3d(s[7], s[8], s[9]), st.bg = Vector3d(s[10], s[11], s[12]), st.ba = Vector3d(s[13], s[14], s[15]);
+            auto p = std::make_shared<Preintegration>(P, mk_imu(offsets[k]), st, variant ? Preintegration::EARTH : Preintegration::NORMAL);
+            for (int row = offsets[k] + 1; row < offsets[k + 1]; row++) p->addNewImu(mk_imu(row));
+            pre.push_back(p);
+            raw.push_back(p.get());
+        }
+        // unintegrated factors must fail
+        {
+            PreintegrationFactor f(pre[0]);
+            double r[15];
+            const double *pp[4] = {eval_point, eval_point + 7, eval_point + 16, eval_point + 23};
+            if (f.Evaluate(pp, r, nullptr)) {
+                icg_ctx_destroy(ctx);
+                return 1;
+            }
+        }
+        std::string e;
+        if (!Preintegration::integrateBatch(ctx, raw, &e)) {
+            set_err(err, errlen, e.c_str());
+            icg_ctx_destroy(ctx);
+            return -2;
+        }
+        for (int k = 0; k < n; k++) {
+            const IntegrationState &c = pre[(size_t) k]->currentState();
+            double *o = cur_state + 16 * (size_t) k;
+            o[0] = c.p[0], o[1] = c.p[1], o[2] = c.p[2], o[3] = c.q.x, o[4] = c.q.y, o[5] = c.q.z, o[6] = c.q.w;
+            for (int i = 0; i < 3; i++) o[7 + i] = c.v[i], o[10 + i] = c.bg[i], o[13 + i] = c.ba[i];
+            PreintegrationFactor f(pre[(size_t) k]);
+            const double *ep   = eval_point + 32 * (size_t) k;
+            const double *pp[4] = {ep, ep + 7, ep + 16, ep + 23};
+            double *J           = jacobians + 480 * (size_t) k;
+            double *jj[4]       = {J, J + 105, J + 240, J + 345};
+            if (!f.Evaluate(pp, residuals + 15 * (size_t) k, jj)) {
+                icg_ctx_destroy(ctx);
+                return -3;
+            }
+        }
+        icg_ctx_destroy(ctx);
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,509 @@
+// Host side of the back-end boundary (see factors.h for the reference lines each class mirrors).
+#include "factors.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+namespace icg {
+
+void HuberLossHip::Evaluate(double s, double rho[3]) const {
+    if (s > b_) {
+        const double r = std::sqrt(s);
+        rho[0]         = 2.0 * a_ * r - b_;
+        rho[1]         = std::max(std::numeric_limits<double>::min(), a_ / r);
+        rho[2]         = -rho[1] / (2.0 * s);
+    } else {
+        rho[0] = s;
+        rho[1] = 1.0;
+        rho[2] = 0.0;
+    }
+}
+
+// ---- ReprojectionFactor / ReprojectionBatch ---------------------------------------------------------------------------
+ReprojectionFactor::ReprojectionFactor(Vector3d pts0, Vector3d pts1, Vector3d vel0, Vector3d vel1, double td0, double td1,
+                                       double std) {
+    for (int i = 0; i < 3; i++) {
+        obs_[i]     = pts0[i];
+        obs_[3 + i] = pts1[i];
+        obs_[6 + i] = vel0[i];
+        obs_[9 + i] = vel1[i];
+    }
+    obs_[12] = td0;
+    obs_[13] = td1;
+    obs_[14] = std; // sqrt_info = 1/std on the diagonal (reprojection_factor.h:50-52)
+}
+
+bool ReprojectionFactor::Evaluate(const double *const *, double *residuals, double **jacobians) const {
+    // The values were computed by ReprojectionBatch::PrepareForEvaluation for the state currently stored in the user
+    // parameter arrays (which is what Ceres passes here).  No batch / not prepared -> evaluation failed, loudly.
+    if (!batch_ || slot_ < 0 || !batch_->prepared(jacobians != nullptr)) return false;
+    const double *r = batch_->residual(slot_);
+    residuals[0]    = r[0];
+    residuals[1]    = r[1];
+    if (jacobians) {
+        const double *J = batch_->jacobian(slot_);
+        if (jacobians[0]) memcpy(jacobians[0], J, sizeof(double) * 14);
+        if (jacobians[1]) memcpy(jacobians[1], J + 14, sizeof(double) * 14);
+        if (jacobians[2]) memcpy(jacobians[2], J + 28, sizeof(double) * 14);
+        if (jacobians[3]) memcpy(jacobians[3], J + 42, sizeof(double) * 2);
+        if (jacobians[4]) memcpy(jacobians[4], J + 44, sizeof(double) * 2);
+    }
+    return true;
+}
+
+ReprojectionBatch::ReprojectionBatch(int device) {
+    icg_ctx_config cfg{};
+    cfg.device      = device;
+    cfg.width       = 64; // the back-end context holds no images
+    cfg.height      = 64;
+    cfg.n_slots     = 1;
+    cfg.max_batch   = 1;
+    cfg.max_points  = 64;
+    cfg.max_factors = 4096;
+    if (icg_ctx_create(&cfg, &ctx_) != ICG_OK) throw std::runtime_error(std::string("ReprojectionBatch: ") + icg_last_error(nullptr));
+}
+
+ReprojectionBatch::~ReprojectionBatch() {
+    for (auto *f : factors_) {
+        f->batch_ = nullptr;
+        f->slot_  = -1;
+    }
+    icg_ctx_destroy(ctx_);
+}
+
+void ReprojectionBatch::clear() {
+    for (auto *f : factors_) {
+        f->batch_ = nullptr;
+        f->slot_  = -1;
+    }
+    factors_.clear();
+    pose_ptrs_.clear();
+    lm_ptrs_.clear();
+    pose_index_.clear();
+    lm_index_.clear();
+    idx_i_.clear();
+    idx_j_.clear();
+    idx_lm_.clear();
+    ext_ = td_ = nullptr;
+    finalized_ = prepared_ = has_jac_ = false;
+}
+
+void ReprojectionBatch::add(ReprojectionFactor *factor, double *pose_i, double *pose_j, double *extrinsic, double *invdepth,
+                            double *td) {
+    auto index_of = [](std::unordered_map<const double *, int> &m, vector<double *> &v, double *p) {
+        auto it = m.find(p);
+        if (it != m.end()) return it->second;
+        int k = (int) v.size();
+        v.push_back(p);
+        m[p] = k;
+        return k;
+    };
+    if (ext_ && (ext_ != extrinsic || td_ != td)) throw std::runtime_error("ReprojectionBatch: one extrinsic/td block per batch");
+    ext_ = extrinsic;
+    td_  = td;
+    factor->batch_ = this;
+    factor->slot_  = (int) factors_.size();
+    factors_.push_back(factor);
+    idx_i_.push_back(index_of(pose_index_, pose_ptrs_, pose_i));
+    idx_j_.push_back(index_of(pose_index_, pose_ptrs_, pose_j));
+    idx_lm_.push_back(index_of(lm_index_, lm_ptrs_, invdepth));
+    finalized_ = prepared_ = false;
+}
+
+void ReprojectionBatch::finalize() {
+    const int n = (int) factors_.size();
+    vector<double> obs((size_t) 15 * n);
+    for (int k = 0; k < n; k++)
+        for (int c = 0; c < 15; c++) obs[(size_t) c * n + k] = factors_[(size_t) k]->obs_[c];
+    if (icg_reproj_set_factors(ctx_, n, obs.data(), idx_i_.data(), idx_j_.data(), idx_lm_.data()) != ICG_OK)
+        throw std::runtime_error(std::string("icg_reproj_set_factors: ") + icg_last_error(ctx_));
+    r_.assign((size_t) 2 * n, 0.0);
+    J_.assign((size_t) 46 * n, 0.0);
+    finalized_ = true;
+    prepared_  = false;
+}
+
+bool ReprojectionBatch::run(bool want_jac, double huber) {
+    prepared_ = false;
+    if (factors_.empty()) {
+        prepared_ = has_jac_ = true;
+        return true;
+    }
+    if (!finalized_) finalize();
+    vector<double> poses(7 * pose_ptrs_.size()), inv(lm_ptrs_.size());
+    for (size_t k = 0; k < pose_ptrs_.size(); k++) memcpy(&poses[7 * k], pose_ptrs_[k], sizeof(double) * 7);
+    for (size_t k = 0; k < lm_ptrs_.size(); k++) inv[k] = *lm_ptrs_[k];
+    int rc = icg_reproj_eval_resident(ctx_, (int) pose_ptrs_.size(), poses.data(), ext_, (int) lm_ptrs_.size(), inv.data(), *td_,
+                                      want_jac ? 1 : 0, huber, r_.data(), want_jac ? J_.data() : nullptr);
+    if (rc != ICG_OK) {
+        error_ = icg_last_error(ctx_);
+        return false;
+    }
+    prepared_ = true;
+    has_jac_  = want_jac;
+    return true;
+}
+
+void ReprojectionBatch::PrepareForEvaluation(bool evaluate_jacobians, bool /*new_evaluation_point*/) { run(evaluate_jacobians, 0.0); }
+
+bool ReprojectionBatch::evaluateCorrected(double huber_delta) { return run(true, huber_delta); }
+
+bool ReprojectionBatch::accumulateNormal(const std::unordered_map<const double *, int> &column_of, int local_size, double *H0,
+                                         double *b0) {
+    if (factors_.empty()) return true;
+    auto col = [&](const double *p) {
+        auto it = column_of.find(p);
+        return it == column_of.end() ? -1 : it->second;
+    };
+    vector<int32_t> cp(pose_ptrs_.size()), cl(lm_ptrs_.size());
+    for (size_t k = 0; k < pose_ptrs_.size(); k++) cp[k] = col(pose_ptrs_[k]);
+    for (size_t k = 0; k < lm_ptrs_.size(); k++) cl[k] = col(lm_ptrs_[k]);
+    int rc = icg_reproj_accumulate_normal(ctx_, local_size, cp.data(), col(ext_), cl.data(), col(td_), H0, b0);
+    if (rc != ICG_OK) {
+        error_ = icg_last_error(ctx_);
+        return false;
+    }
+    return true;
+}
+
+// ---- ResidualBlockInfo (generic host path) ------------------------------------------------------------------------------
+bool ResidualBlockInfo::Evaluate() {
+    const int nr = cost_function_->num_residuals();
+    residuals_.assign((size_t) nr, 0.0);
+    const vector<int32_t> &block_sizes = cost_function_->parameter_block_sizes();
+    vector<double *> raw(block_sizes.size());
+    jacobians_.resize(block_sizes.size());
+    for (size_t i = 0; i < block_sizes.size(); i++) {
+        jacobians_[i].assign((size_t) nr * block_sizes[i], 0.0);
+        raw[i] = jacobians_[i].data();
+    }
+    if (!cost_function_->Evaluate(parameter_blocks_.data(), residuals_.data(), raw.data())) return false;
+    if (loss_function_) { // Ceres corrector (residual_block_info.h:59-87)
+        double sq_norm = 0, rho[3];
+        for (double v : residuals_) sq_norm += v * v;
+        loss_function_->Evaluate(sq_norm, rho);
+        const double sqrt_rho1 = std::sqrt(rho[1]);
+        double residual_scaling, alpha_sq_norm;
+        if ((sq_norm == 0.0) || (rho[2] <= 0.0)) {
+            residual_scaling = sqrt_rho1;
+            alpha_sq_norm    = 0.0;
+        } else {
+            const double D     = 1.0 + 2.0 * sq_norm * rho[2] / rho[1];
+            const double alpha = 1.0 - std::sqrt(D);
+            residual_scaling   = sqrt_rho1 / (1 - alpha);
+            alpha_sq_norm      = alpha / sq_norm;
+        }
+        for (size_t i = 0; i < jacobians_.size(); i++) {
+            const int nc = block_sizes[i];
+            for (int c = 0; c < nc; c++) {
+                double rtj = 0;
+                for (int k = 0; k < nr; k++) rtj += residuals_[(size_t) k] * jacobians_[i][(size_t) k * nc + c];
+                for (int k = 0; k < nr; k++) {
+                    double &j = jacobians_[i][(size_t) k * nc + c];
+                    j         = sqrt_rho1 * (j - alpha_sq_norm * residuals_[(size_t) k] * rtj);
+                }
+            }
+        }
+        for (double &v : residuals_) v *= residual_scaling;
+    }
+    return true;
+}
+
+// ---- symmetric eigen-solver ------------------------------------------------------------------------------------------
+void symmetricEigen(int n, const vector<double> &A, vector<double> &evals, vector<double> &evecs) {
+    vector<double> a(A), v((size_t) n * n, 0.0);
+    for (int i = 0; i < n; i++) v[(size_t) i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 100; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) (i == j ? diag : off) += a[(size_t) i * n + j] * a[(size_t) i * n + j];
+        if (off <= 1e-30 * diag || off == 0.0) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = a[(size_t) p * n + q];
+                if (apq == 0.0) continue;
+                const double app = a[(size_t) p * n + p], aqq = a[(size_t) q * n + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                double t           = 1.0 / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                if (theta < 0) t = -t;
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    double akp = a[(size_t) k * n + p], akq = a[(size_t) k * n + q];
+                    a[(size_t) k * n + p] = c * akp - s * akq;
+                    a[(size_t) k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    double apk = a[(size_t) p * n + k], aqk = a[(size_t) q * n + k];
+                    a[(size_t) p * n + k] = c * apk - s * aqk;
+                    a[(size_t) q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    double vkp = v[(size_t) k * n + p], vkq = v[(size_t) k * n + q];
+                    v[(size_t) k * n + p] = c * vkp - s * vkq;
+                    v[(size_t) k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    vector<int> order((size_t) n);
+    for (int i = 0; i < n; i++) order[(size_t) i] = i;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return a[(size_t) x * n + x] < a[(size_t) y * n + y]; });
+    evals.assign((size_t) n, 0.0);
+    evecs.assign((size_t) n * n, 0.0);
+    for (int k = 0; k < n; k++) {
+        evals[(size_t) k] = a[(size_t) order[(size_t) k] * n + order[(size_t) k]];
+        for (int i = 0; i < n; i++) evecs[(size_t) i * n + k] = v[(size_t) i * n + order[(size_t) k]];
+    }
+}
+
+// ---- MarginalizationInfo ------------------------------------------------------------------------------------------------
+MarginalizationInfo::~MarginalizationInfo() {
+    for (auto &block : parameter_block_data_) delete[] block.second;
+}
+
+void MarginalizationInfo::addResidualBlockInfo(const std::shared_ptr<ResidualBlockInfo> &blockinfo) { // :53-67
+    factors_.push_back(blockinfo);
+    const auto &parameter_blocks = blockinfo->parameterBlocks();
+    const auto &block_sizes      = blockinfo->parameterBlockSizes();
+    for (size_t k = 0; k < parameter_blocks.size(); k++) parameter_block_size_[idOf(parameter_blocks[k])] = block_sizes[k];
+    for (int index : blockinfo->marginalizationParametersIndex()) parameter_block_index_[idOf(parameter_blocks[(size_t) index])] = 0;
+}
+
+bool MarginalizationInfo::marginalization() { // :73-101
+    if (!updateParameterBlocksIndex()) {
+        isvalid_ = false;
+        releaseMemory();
+        return false;
+    }
+    if (!preMarginalization() || !constructEquation()) {
+        isvalid_ = false;
+        releaseMemory();
+        return false;
+    }
+    schurElimination();
+    linearization();
+    releaseMemory();
+    return true;
+}
+
+vector<double *> MarginalizationInfo::getParamterBlocks(std::unordered_map<long, double *> &address) { // :103-122
+    vector<double *> remained_block_addr;
+    remained_block_data_.clear();
+    remained_block_index_.clear();
+    remained_block_size_.clear();
+    for (const auto &block : parameter_block_index_) {
+        if (block.second >= marginalized_size_) {
+            remained_block_data_.push_back(parameter_block_data_[block.first]);
+            remained_block_size_.push_back(parameter_block_size_[block.first]);
+            remained_block_index_.push_back(parameter_block_index_[block.first]);
+            remained_block_addr.push_back(address[block.first]);
+        }
+    }
+    return remained_block_addr;
+}
+
+bool MarginalizationInfo::updateParameterBlocksIndex() { // :232-253
+    int index = 0;
+    for (auto &block : parameter_block_index_) {
+        block.second = index;
+        index += localSize(parameter_block_size_[block.first]);
+    }
+    marginalized_size_ = index;
+    for (const auto &block : parameter_block_size_) {
+        if (parameter_block_index_.find(block.first) == parameter_block_index_.end()) {
+            parameter_block_index_[block.first] = index;
+            index += localSize(block.second);
+        }
+    }
+    remained_size_ = index - marginalized_size_;
+    local_size_    = index;
+    return marginalized_size_ > 0;
+}
+
+static bool onBatch(const std::shared_ptr<ResidualBlockInfo> &f, ReprojectionBatch *batch) {
+    if (!batch) return false;
+    auto *rf = dynamic_cast<ReprojectionFactor *>(f->costFunction().get());
+    if (rf == nullptr || rf->batch() != batch) return false;
+    return f->lossFunction() == nullptr || dynamic_cast<HuberLossHip *>(f->lossFunction().get()) != nullptr;
+}
+
+bool MarginalizationInfo::preMarginalization() { // :256-273
+    // every reprojection factor of the batch: ONE device launch incl. the robust correction
+    double delta = 0;
+    for (const auto &factor : factors_)
+        if (onBatch(factor, batch_)) {
+            auto *hl = dynamic_cast<HuberLossHip *>(factor->lossFunction().get());
+            delta    = hl ? hl->delta() : 0.0;
+            break;
+        }
+    if (batch_ && batch_->size() > 0 && !batch_->evaluateCorrected(delta)) return false;
+    for (const auto &factor : factors_) {
+        if (!onBatch(factor, batch_) && !factor->Evaluate()) return false;
+        const vector<int32_t> &block_sizes = factor->parameterBlockSizes();
+        for (size_t k = 0; k < block_sizes.size(); k++) {
+            long id  = idOf(factor->parameterBlocks()[k]);
+            int size = block_sizes[k];
+            if (parameter_block_data_.find(id) == parameter_block_data_.end()) {
+                auto *data = new double[(size_t) size];
+                memcpy(data, factor->parameterBlocks()[k], sizeof(double) * (size_t) size);
+                parameter_block_data_[id] = data;
+            }
+        }
+    }
+    return true;
+}
+
+bool MarginalizationInfo::constructEquation() { // :195-230
+    const size_t L = (size_t) local_size_;
+    H0_.assign(L * L, 0.0);
+    b0_.assign(L, 0.0);
+    std::unordered_map<const double *, int> column_of;
+    bool any_device = false;
+    for (const auto &factor : factors_) {
+        const auto &blocks = factor->parameterBlocks();
+        if (onBatch(factor, batch_)) {
+            any_device = true;
+            for (double *p : blocks) column_of[p] = parameter_block_index_[idOf(p)];
+            continue;
+        }
+        const int nr = (int) factor->residuals().size();
+        for (size_t i = 0; i < blocks.size(); i++) {
+            const int row0 = parameter_block_index_[idOf(blocks[i])];
+            const int gi   = parameter_block_size_[idOf(blocks[i])];
+            const int rows = localSize(gi);
+            const vector<double> &Ji = factor->jacobians()[i];
+            for (size_t j = i; j < blocks.size(); ++j) {
+                const int col0 = parameter_block_index_[idOf(blocks[j])];
+                const int gj   = parameter_block_size_[idOf(blocks[j])];
+                const int cols = localSize(gj);
+                const vector<double> &Jj = factor->jacobians()[j];
+                for (int x = 0; x < rows; x++)
+                    for (int y = 0; y < cols; y++) {
+                        double s = 0;
+                        for (int k = 0; k < nr; k++) s += Ji[(size_t) k * gi + x] * Jj[(size_t) k * gj + y];
+                        H0_[(size_t) (row0 + x) * L + col0 + y] += s;
+                        if (i != j) H0_[(size_t) (col0 + y) * L + row0 + x] = H0_[(size_t) (row0 + x) * L + col0 + y];
+                    }
+            }
+            for (int x = 0; x < rows; x++) {
+                double s = 0;
+                for (int k = 0; k < nr; k++) s += Ji[(size_t) k * gi + x] * factor->residuals()[(size_t) k];
+                b0_[(size_t) row0 + x] -= s;
+            }
+        }
+    }
+    if (any_device && !batch_->accumulateNormal(column_of, local_size_, H0_.data(), b0_.data())) return false;
+    return true;
+}
+
+void MarginalizationInfo::schurElimination() { // :170-192
+    const int m = marginalized_size_, r = remained_size_;
+    const size_t L = (size_t) local_size_;
+    auto H = [&](int i, int j) { return H0_[(size_t) i * L + j]; };
+    vector<double> Hmm((size_t) m * m), ev, V, Hinv((size_t) m * m, 0.0);
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < m; j++) Hmm[(size_t) i * m + j] = 0.5 * (H(i, j) + H(j, i));
+    symmetricEigen(m, Hmm, ev, V);
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < m; j++) {
+            double s = 0;
+            for (int k = 0; k < m; k++) {
+                double inv = ev[(size_t) k] > EPS ? 1.0 / ev[(size_t) k] : 0.0;
+                s += V[(size_t) i * m + k] * inv * V[(size_t) j * m + k];
+            }
+            Hinv[(size_t) i * m + j] = s;
+        }
+    vector<double> T((size_t) r * m);
+    for (int i = 0; i < r; i++)
+        for (int j = 0; j < m; j++) {
+            double s = 0;
+            for (int k = 0; k < m; k++) s += H(m + i, k) * Hinv[(size_t) k * m + j];
+            T[(size_t) i * m + j] = s;
+        }
+    Hp_.assign((size_t) r * r, 0.0);
+    bp_.assign((size_t) r, 0.0);
+    for (int i = 0; i < r; i++) {
+        for (int j = 0; j < r; j++) {
+            double s = 0;
+            for (int k = 0; k < m; k++) s += T[(size_t) i * m + k] * H(k, m + j);
+            Hp_[(size_t) i * r + j] = H(m + i, m + j) - s;
+        }
+        double s = 0;
+        for (int k = 0; k < m; k++) s += T[(size_t) i * m + k] * b0_[(size_t) k];
+        bp_[(size_t) i] = b0_[(size_t) m + i] - s;
+    }
+}
+
+void MarginalizationInfo::linearization() { // :153-167
+    const int r = remained_size_;
+    vector<double> ev, V;
+    symmetricEigen(r, Hp_, ev, V);
+    linearized_jacobians_.assign((size_t) r * r, 0.0);
+    linearized_residuals_.assign((size_t) r, 0.0);
+    for (int k = 0; k < r; k++) {
+        const double S = ev[(size_t) k] > EPS ? ev[(size_t) k] : 0.0, Sinv = ev[(size_t) k] > EPS ? 1.0 / ev[(size_t) k] : 0.0;
+        const double ss = std::sqrt(S), si = std::sqrt(Sinv);
+        double vb = 0;
+        for (int i = 0; i < r; i++) {
+            linearized_jacobians_[(size_t) k * r + i] = ss * V[(size_t) i * r + k];
+            vb += V[(size_t) i * r + k] * -bp_[(size_t) i];
+        }
+        linearized_residuals_[(size_t) k] = si * vb;
+    }
+}
+
+// ---- MarginalizationFactor (marginalization_factor.h:31-105) ----------------------------------------------------------
+MarginalizationFactor::MarginalizationFactor(std::shared_ptr<MarginalizationInfo> marg_info) : marg_info_(std::move(marg_info)) {
+    for (auto size : marg_info_->remainedBlockSize()) mutable_parameter_block_sizes()->push_back(size);
+    set_num_residuals(marg_info_->remainedSize());
+}
+
+bool MarginalizationFactor::Evaluate(const double *const *parameters, double *residuals, double **jacobians) const {
+    const int marginalizaed_size = marg_info_->marginalizedSize();
+    const int remained_size      = marg_info_->remainedSize();
+    const vector<int> &remained_block_index     = marg_info_->remainedBlockIndex();
+    const vector<int> &remained_block_size      = marg_info_->remainedBlockSize();
+    const vector<double *> &remained_block_data = marg_info_->remainedBlockData();
+    const vector<double> &J0 = marg_info_->linearizedJacobians();
+    const vector<double> &e0 = marg_info_->linearizedResiduals();
+    vector<double> dx((size_t) remained_size, 0.0);
+    for (size_t i = 0; i < remained_block_size.size(); i++) {
+        const int size = remained_block_size[i], index = remained_block_index[i] - marginalizaed_size;
+        const double *x = parameters[i], *x0 = remained_block_data[i];
+        if (size == POSE_GLOBAL_SIZE) { // :64-72
+            const double n2 = x0[3] * x0[3] + x0[4] * x0[4] + x0[5] * x0[5] + x0[6] * x0[6];
+            const double ax = -x0[3] / n2, ay = -x0[4] / n2, az = -x0[5] / n2, aw = x0[6] / n2;
+            const double bx = x[3], by = x[4], bz = x[5], bw = x[6];
+            const double dqx = aw * bx + ax * bw + ay * bz - az * by;
+            const double dqy = aw * by + ay * bw + az * bx - ax * bz;
+            const double dqz = aw * bz + az * bw + ax * by - ay * bx;
+            const double dqw = aw * bw - ax * bx - ay * by - az * bz;
+            for (int k = 0; k < 3; k++) dx[(size_t) index + k] = x[k] - x0[k];
+            const double sgn      = dqw < 0 ? -2.0 : 2.0;
+            dx[(size_t) index + 3] = sgn * dqx;
+            dx[(size_t) index + 4] = sgn * dqy;
+            dx[(size_t) index + 5] = sgn * dqz;
+        } else {
+            for (int k = 0; k < size; k++) dx[(size_t) index + k] = x[k] - x0[k];
+        }
+    }
+    for (int i = 0; i < remained_size; i++) { // e = e0 + J0 * dx  (:79-80)
+        double s = 0;
+        for (int k = 0; k < remained_size; k++) s += J0[(size_t) i * remained_size + k] * dx[(size_t) k];
+        residuals[i] = e0[(size_t) i] + s;
+    }
+    if (jacobians) {
+        for (size_t b = 0; b < remained_block_size.size(); b++) {
+            if (!jacobians[b]) continue;
+            const int size = remained_block_size[b], index = remained_block_index[b] - marginalizaed_size;
+            const int local_size = MarginalizationInfo::localSize(size);
+            for (int i = 0; i < remained_size; i++)
+                for (int j = 0; j < size; j++)
+                    jacobians[b][(size_t) i * size + j] = j < local_size ? J0[(size_t) i * remained_size + index + j] : 0.0;
+        }
+    }
+    return true;
+}
+
+} // namespace icg

@@ -1,0 +1,237 @@
+// Back-end boundary B1: the reference's ceres::CostFunction subclasses re-built on the HIP C ABI.
+//
+//   ReprojectionFactor     reference factors/reprojection_factor.h:36-158   (SizedCostFunction<2,7,7,7,1,1>)
+//   ReprojectionBatch      NEW: a ceres::EvaluationCallback that evaluates ALL registered reprojection factors with one
+//                          batched kernel per evaluation point; each factor's Evaluate() copies its slice out
+//   ResidualBlockInfo      reference factors/residual_block_info.h:29-120
+//   MarginalizationInfo    reference factors/marginalization_info.h:30-316
+//   MarginalizationFactor  reference factors/marginalization_factor.h:31-105
+//   Preintegration*        reference preintegration/preintegration{,_base,_normal,_earth}.{h,cc}, preintegration_factor.h
+//
+// There is no CPU fallback for the reprojection math: a ReprojectionFactor whose batch has not been prepared for the
+// current evaluation point makes Evaluate() return false (Ceres' "evaluation failed").
+#pragma once
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/icgvins_hip.h"
+#include "ceres_compat.h"
+#include "types.h"
+
+#define POSE_LOCAL_SIZE 6
+#define POSE_GLOBAL_SIZE 7
+
+namespace icg {
+
+using std::vector;
+
+// ceres::HuberLoss with a readable delta (the device corrector needs it)
+class HuberLossHip : public ceres::LossFunction {
+public:
+    explicit HuberLossHip(double a) : a_(a), b_(a * a) {}
+    void Evaluate(double s, double rho[3]) const override;
+    double delta() const { return a_; }
+
+private:
+    const double a_, b_;
+};
+
+class ReprojectionBatch;
+
+class ReprojectionFactor : public ceres::SizedCostFunction<2, 7, 7, 7, 1, 1> {
+public:
+    ReprojectionFactor() = delete;
+    // same constructor as the reference (reprojection_factor.h:42-53); std = pixel error / focal length
+    ReprojectionFactor(Vector3d pts0, Vector3d pts1, Vector3d vel0, Vector3d vel1, double td0, double td1, double std);
+    bool Evaluate(const double *const *parameters, double *residuals, double **jacobians) const override;
+    const ReprojectionBatch *batch() const { return batch_; }
+
+private:
+    friend class ReprojectionBatch;
+    double obs_[15];
+    ReprojectionBatch *batch_{nullptr};
+    int slot_{-1};
+};
+
+// Owns one icg_ctx.  Usage with Ceres: options.evaluation_callback = &batch; problem.AddResidualBlock(factor, loss, blocks)
+// and batch.add(factor, blocks) for every reprojection factor; call finalize() once before solving.
+class ReprojectionBatch : public ceres::EvaluationCallback {
+public:
+    explicit ReprojectionBatch(int device = 0);
+    ~ReprojectionBatch() override;
+    // parameter blocks exactly as passed to AddResidualBlock: pose_ref[7], pose_obs[7], extrinsic[7], invdepth[1], td[1]
+    void add(ReprojectionFactor *factor, double *pose_i, double *pose_j, double *extrinsic, double *invdepth, double *td);
+    void finalize();
+    void clear();
+    int size() const { return (int) factors_.size(); }
+    // ceres::EvaluationCallback: gathers the CURRENT values of the user parameter arrays and launches one batch
+    void PrepareForEvaluation(bool evaluate_jacobians, bool new_evaluation_point) override;
+    // marginalization support: evaluate with the robust correction applied on device (residual_block_info.h:59-87)
+    bool evaluateCorrected(double huber_delta);
+    // H0 += J^T J, b0 -= J^T e of the last evaluation (marginalization_info.h:195-230); columns by parameter address
+    bool accumulateNormal(const std::unordered_map<const double *, int> &column_of, int local_size, double *H0, double *b0);
+    const double *residual(int slot) const { return r_.data() + 2 * (size_t) slot; }
+    const double *jacobian(int slot) const { return J_.data() + 46 * (size_t) slot; }
+    bool prepared(bool with_jacobians) const { return prepared_ && (!with_jacobians || has_jac_); }
+    const std::string &error() const { return error_; }
+
+private:
+    bool run(bool want_jac, double huber);
+    icg_ctx *ctx_{nullptr};
+    vector<ReprojectionFactor *> factors_;
+    vector<double *> pose_ptrs_, lm_ptrs_; // unique blocks in first-seen order
+    std::unordered_map<const double *, int> pose_index_, lm_index_;
+    vector<int32_t> idx_i_, idx_j_, idx_lm_;
+    double *ext_{nullptr}, *td_{nullptr};
+    vector<double> r_, J_;
+    bool finalized_{false}, prepared_{false}, has_jac_{false};
+    std::string error_;
+};
+
+// ---- marginalization ------------------------------------------------------------------------------------------------
+class ResidualBlockInfo {
+public:
+    ResidualBlockInfo(std::shared_ptr<ceres::CostFunction> cost_function, std::shared_ptr<ceres::LossFunction> loss_function,
+                      vector<double *> parameter_blocks, vector<int> marg_para_index)
+        : cost_function_(std::move(cost_function)), loss_function_(std::move(loss_function)),
+          parameter_blocks_(std::move(parameter_blocks)), marg_para_index_(std::move(marg_para_index)) {}
+    bool Evaluate(); // generic host path (residual_block_info.h:44-88)
+    const vector<vector<double>> &jacobians() const { return jacobians_; } // row-major num_residuals x block size
+    const vector<int32_t> &parameterBlockSizes() const { return cost_function_->parameter_block_sizes(); }
+    const vector<double *> &parameterBlocks() const { return parameter_blocks_; }
+    const vector<double> &residuals() const { return residuals_; }
+    const vector<int> &marginalizationParametersIndex() const { return marg_para_index_; }
+    const std::shared_ptr<ceres::CostFunction> &costFunction() const { return cost_function_; }
+    const std::shared_ptr<ceres::LossFunction> &lossFunction() const { return loss_function_; }
+
+private:
+    std::shared_ptr<ceres::CostFunction> cost_function_;
+    std::shared_ptr<ceres::LossFunction> loss_function_;
+    vector<double *> parameter_blocks_;
+    vector<int> marg_para_index_;
+    vector<vector<double>> jacobians_;
+    vector<double> residuals_;
+};
+
+class MarginalizationInfo {
+public:
+    MarginalizationInfo() = default;
+    ~MarginalizationInfo();
+    bool isValid() const { return isvalid_; }
+    static int localSize(int size) { return size == POSE_GLOBAL_SIZE ? POSE_LOCAL_SIZE : size; }
+    static int globalSize(int size) { return size == POSE_LOCAL_SIZE ? POSE_GLOBAL_SIZE : size; }
+    void addResidualBlockInfo(const std::shared_ptr<ResidualBlockInfo> &blockinfo);
+    void updateParamtersIds(const std::unordered_map<long, long> &parameters_ids) { parameters_ids_ = parameters_ids; }
+    // reprojection factors registered in `batch` are evaluated (with their Huber loss) and assembled on the GPU
+    void setReprojectionBatch(ReprojectionBatch *batch) { batch_ = batch; }
+    bool marginalization();
+    vector<double *> getParamterBlocks(std::unordered_map<long, double *> &address);
+    const vector<double> &linearizedJacobians() const { return linearized_jacobians_; } // remained x remained, row-major
+    const vector<double> &linearizedResiduals() const { return linearized_residuals_; }
+    int marginalizedSize() const { return marginalized_size_; }
+    int remainedSize() const { return remained_size_; }
+    const vector<int> &remainedBlockSize() const { return remained_block_size_; }
+    const vector<int> &remainedBlockIndex() const { return remained_block_index_; }
+    const vector<double *> &remainedBlockData() const { return remained_block_data_; }
+    // exposed for tests: the Schur complement before linearization
+    const vector<double> &Hp() const { return Hp_; }
+    const vector<double> &bp() const { return bp_; }
+
+private:
+    bool updateParameterBlocksIndex();
+    bool preMarginalization();
+    bool constructEquation();
+    void schurElimination();
+    void linearization();
+    void releaseMemory() { factors_.clear(); }
+    long idOf(const double *p) { return parameters_ids_[reinterpret_cast<long>(p)]; }
+
+    vector<double> H0_, Hp_, b0_, bp_;
+    std::unordered_map<long, long> parameters_ids_;
+    std::unordered_map<long, int> parameter_block_size_;
+    std::unordered_map<long, int> parameter_block_index_;
+    std::unordered_map<long, double *> parameter_block_data_;
+    vector<int> remained_block_size_, remained_block_index_;
+    vector<double *> remained_block_data_;
+    int marginalized_size_{0}, remained_size_{0}, local_size_{0};
+    vector<std::shared_ptr<ResidualBlockInfo>> factors_;
+    const double EPS = 1e-8;
+    vector<double> linearized_jacobians_, linearized_residuals_;
+    bool isvalid_{true};
+    ReprojectionBatch *batch_{nullptr};
+};
+
+class MarginalizationFactor : public ceres::CostFunction {
+public:
+    MarginalizationFactor() = delete;
+    explicit MarginalizationFactor(std::shared_ptr<MarginalizationInfo> marg_info);
+    bool Evaluate(const double *const *parameters, double *residuals, double **jacobians) const override;
+
+private:
+    std::shared_ptr<MarginalizationInfo> marg_info_;
+};
+
+// symmetric eigen-decomposition (cyclic Jacobi), eigenvalues ascending, evecs row-major with eigenvectors in columns
+void symmetricEigen(int n, const vector<double> &A, vector<double> &evals, vector<double> &evecs);
+
+// ---- preintegration (P1 on device, P2 on host) -------------------------------------------------------------------------
+struct IMU { // common/types.h:48-56
+    double time, dt;
+    Vector3d dtheta, dvel;
+    double odovel{0};
+};
+struct Quaterniond {
+    double x{0}, y{0}, z{0}, w{1};
+};
+struct IntegrationState { // preintegration/integration_state.h:35-52 (fields used by the Normal/Earth variants)
+    double time{0};
+    Vector3d p;
+    Quaterniond q;
+    Vector3d v, bg, ba;
+};
+struct IntegrationParameters { // integration_state.h:67-88
+    double acc_vrw{0}, gyr_arw{0}, gyr_bias_std{0}, acc_bias_std{0}, corr_time{1}, gravity{9.8};
+    Vector3d iewn; // Earth rotation in the local frame, Earth::iewn(station, p) — explicit here (SURVEY.md hazard H9)
+};
+
+// One IMU interval between two time nodes.  (Re)integration of many intervals is ONE batched device call.
+class Preintegration {
+public:
+    enum Variant { NORMAL = 0, EARTH = 1 };
+    Preintegration(std::shared_ptr<IntegrationParameters> parameters, const IMU &imu0, const IntegrationState &state, Variant v);
+    void addNewImu(const IMU &imu) { imu_buffer_.push_back(imu); dirty_ = true; }
+    void reintegration(const IntegrationState &state) { start_state_ = state; dirty_ = true; }
+    // integrate every dirty interval of the list with a single icg_preint_batch launch
+    static bool integrateBatch(icg_ctx *ctx, const vector<Preintegration *> &list, std::string *err = nullptr);
+    const IntegrationState &currentState() const { return current_state_; }
+    const IntegrationState &deltaState() const { return delta_state_; }
+    double deltaTime() const { return delta_time_; }
+    const vector<IMU> &imuBuffer() const { return imu_buffer_; }
+    // PreintegrationFactor::Evaluate body (preintegration_factor.h:45-69): residual 15, Jacobians 15x7,15x9,15x7,15x9
+    bool evaluate(const double *const *parameters, double *residuals, double **jacobians) const;
+    Variant variant() const { return variant_; }
+
+private:
+    std::shared_ptr<IntegrationParameters> parameters_;
+    Variant variant_;
+    vector<IMU> imu_buffer_;
+    IntegrationState start_state_, current_state_, delta_state_;
+    double delta_time_{0};
+    vector<double> jacobian_, covariance_, pn_; // 15x15, 15x15, (n-1)x4
+    bool dirty_{true};
+};
+
+class PreintegrationFactor : public ceres::CostFunction {
+public:
+    explicit PreintegrationFactor(std::shared_ptr<Preintegration> preintegration);
+    bool Evaluate(const double *const *parameters, double *residuals, double **jacobians) const override {
+        return preintegration_->evaluate(parameters, residuals, jacobians);
+    }
+
+private:
+    std::shared_ptr<Preintegration> preintegration_;
+};
+
+} // namespace icg

@@ -235,3 +235,65 @@ int icg_reproj_eval_batch(icg_ctx *, int n, const double *obs_soa, const int32_t
 }
 
 } // extern "C"
+
+// ---- back-end entry points on the oracle (resident factor state kept per context) -------------------------------------
+#include <unordered_map>
+namespace {
+struct shim_backend {
+    int n = 0, n_poses = 0, n_lm = 0;
+    std::vector<double> obs, r, J;
+    std::vector<int32_t> ii, jj, ll;
+};
+std::unordered_map<icg_ctx *, shim_backend> g_backend;
+} // namespace
+
+extern "C" {
+
+int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa, const int32_t *idx_i, const int32_t *idx_j,
+                           const int32_t *idx_lm) {
+    shim_backend &B = g_backend[ctx];
+    B.n = n;
+    B.obs.assign(obs_soa, obs_soa + 15 * (size_t) n);
+    B.ii.assign(idx_i, idx_i + n);
+    B.jj.assign(idx_j, idx_j + n);
+    B.ll.assign(idx_lm, idx_lm + n);
+    return ICG_OK;
+}
+
+int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm, const double *invdepth,
+                             double td, int want_jac, double huber_delta, double *out_r, double *out_J) {
+    shim_backend &B = g_backend[ctx];
+    B.n_poses = n_poses;
+    B.n_lm    = n_lm;
+    B.r.assign(2 * (size_t) B.n, 0.0);
+    B.J.assign(46 * (size_t) B.n, 0.0);
+    orc_reproj_eval_batch(B.n, B.obs.data(), B.ii.data(), B.jj.data(), B.ll.data(), poses, ext, invdepth, td, want_jac, B.r.data(),
+                          B.J.data());
+    if (huber_delta > 0) orc_huber_correct_2x46(B.n, huber_delta, B.r.data(), want_jac ? B.J.data() : nullptr);
+    if (out_r) memcpy(out_r, B.r.data(), sizeof(double) * B.r.size());
+    if (out_J && want_jac) memcpy(out_J, B.J.data(), sizeof(double) * B.J.size());
+    return ICG_OK;
+}
+
+int icg_reproj_accumulate_normal(icg_ctx *ctx, int local_size, const int32_t *col_pose, int32_t col_ext, const int32_t *col_lm,
+                                 int32_t col_td, double *H0, double *b0) {
+    shim_backend &B = g_backend[ctx];
+    orc_reproj_accumulate_normal(B.n, B.r.data(), B.J.data(), B.ii.data(), B.jj.data(), B.ll.data(), col_pose, col_ext, col_lm, col_td,
+                                 local_size, H0, b0);
+    return ICG_OK;
+}
+
+int icg_preint_batch(icg_ctx *, int variant, int n_intervals, const int32_t *offsets, const double *imu, const double *state0,
+                     const double *params, double *cur_state, double *delta_state, double *jac, double *cov, double *delta_time,
+                     double *pn) {
+    for (int s = 0; s < n_intervals; s++) {
+        int b = offsets[s], n = offsets[s + 1] - offsets[s];
+        std::vector<double> pnl((size_t) 4 * std::max(n - 1, 1));
+        orc_preint_integrate(variant, n, imu + 8 * (size_t) b, state0 + 16 * (size_t) s, params, cur_state + 16 * (size_t) s,
+                             delta_state + 16 * (size_t) s, jac + 225 * (size_t) s, cov + 225 * (size_t) s, delta_time + s, pnl.data());
+        if (pn && n > 1) memcpy(pn + 4 * (size_t) b, pnl.data(), sizeof(double) * 4 * (size_t) (n - 1));
+    }
+    return ICG_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,169 @@
+"""ctypes drivers for the back-end entry points of the host layer (host/capi.cc: icgh_backend_*), plus the shared test
+bodies that are run twice: on the oracle-backed host library (CPU, not gpu) and on the product library (gpu)."""
+import ctypes as C
+
+import numpy as np
+
+import marg_data as md
+import preint_data as pd
+import reproj_data as rd
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def backend_reproj(lib, w):
+    obs = _f64(w["obs_soa"])
+    n = obs.shape[1]
+    r, J = np.zeros((n, 2)), np.zeros((n, 46))
+    err = C.create_string_buffer(512)
+    poses, inv = _f64(w["poses"]), _f64(w["invdepth"])
+    rc = lib.icgh_backend_reproj(n, _p(obs), _p(_i32(w["idx_i"])), _p(_i32(w["idx_j"])), _p(_i32(w["idx_lm"])), poses.shape[0],
+                                 _p(poses), _p(_f64(w["ext"])), inv.shape[0], _p(inv), C.c_double(w["td"]), _p(r), _p(J), err, 512)
+    assert rc == 0, (rc, err.value)
+    return r, J
+
+
+def check_reproj_costfunction_surface(lib, oracle):
+    w = rd.make_window(120, 7, seed=11)
+    r, J = backend_reproj(lib, w)
+    r_exp, J_exp = oracle.reproj_eval(w["obs_soa"], w["idx_i"], w["idx_j"], w["idx_lm"], w["poses"], w["ext"], w["invdepth"], w["td"])
+    assert np.abs(r - r_exp).max() < 1e-9 * max(1, np.abs(r_exp).max())
+    assert np.abs(J - J_exp).max() < 1e-9 * max(1, np.abs(J_exp).max())
+
+
+def backend_marginalize(lib, P, huber=1.0, prior_weight=100.0, x_eval=None):
+    w = P["w"]
+    obs = _f64(P["obs"])
+    n = obs.shape[1]
+    poses, inv = _f64(w["poses"]), _f64(w["invdepth"])
+    K, L = poses.shape[0], inv.shape[0]
+    cap = 6 * K + L + 7
+    sizes = np.zeros(2, np.int32)
+    rem_ids, rem_index, rem_size = np.zeros(K + L + 2, np.int64), np.zeros(K + L + 2, np.int32), np.zeros(K + L + 2, np.int32)
+    n_rem = np.zeros(1, np.int32)
+    Hp, bp, J0, e0 = np.zeros(cap * cap), np.zeros(cap), np.zeros(cap * cap), np.zeros(cap)
+    res = np.zeros(cap)
+    err = C.create_string_buffer(512)
+    xe = None if x_eval is None else _f64(x_eval)
+    rc = lib.icgh_backend_marginalize(n, _p(obs), _p(_i32(P["ii"])), _p(_i32(P["jj"])), _p(_i32(P["ll"])), K, _p(poses), _p(_f64(w["ext"])), L,
+                                      _p(inv), C.c_double(w["td"]), C.c_double(huber), C.c_double(prior_weight), 1, 1, _p(sizes),
+                                      _p(rem_ids), _p(rem_index), _p(rem_size), _p(n_rem), _p(Hp), _p(bp), _p(J0), _p(e0), _p(xe),
+                                      _p(res) if xe is not None else None, err, 512)
+    assert rc == 0, (rc, err.value)
+    m, r = int(sizes[0]), int(sizes[1])
+    nb = int(n_rem[0])
+    return dict(m=m, r=r, ids=rem_ids[:nb], index=rem_index[:nb], size=rem_size[:nb], Hp=Hp[:r * r].reshape(r, r), bp=bp[:r],
+                J0=J0[:r * r].reshape(r, r), e0=e0[:r], res=res[:r])
+
+
+def check_marginalization(lib, oracle):
+    P = md.make_problem(n_lm=80, n_kf=6, seed=2)
+    w = P["w"]
+    out = backend_marginalize(lib, P, huber=1.0, prior_weight=100.0)
+    # rebuild the same system with the oracle in OUR column layout, then permute to the library's retained order
+    r_, J_ = oracle.reproj_eval(P["obs"], P["ii"], P["jj"], P["ll"], w["poses"], w["ext"], w["invdepth"], w["td"], huber=1.0)
+    H, b = oracle.reproj_accumulate_normal(r_, J_, P["ii"], P["jj"], P["ll"], P["col_pose"], P["col_ext"], P["col_lm"], P["col_td"], P["local_size"])
+    # PosePriorFactor of capi.cc: residual w*[dp ; 2 vec(dq)], prior translated by +0.01 in x -> r = (-w*0.01, 0, ...)
+    wgt = 100.0
+    Jp = np.zeros((6, 6))
+    Jp[:3, :3] = wgt * np.eye(3)
+    Jp[3:, 3:] = wgt * np.eye(3)
+    rp = np.zeros(6)
+    rp[0] = wgt * -0.01
+    c0 = P["col_pose"][0]
+    H[c0:c0 + 6, c0:c0 + 6] += Jp.T @ Jp
+    b[c0:c0 + 6] -= Jp.T @ rp
+    m = P["m"]
+    assert out["m"] == m and out["r"] == P["local_size"] - m
+    _, _, Hp_o, bp_o = oracle.marginalize(H, b, m)
+    # our retained column of each id
+    def our_col(i):
+        if i < 100000:
+            return P["col_pose"][i]
+        if i < 900000:
+            return P["col_lm"][i - 100000]
+        return P["col_ext"] if i == 900000 else P["col_td"]
+    perm = []
+    for i, idx, sz in zip(out["ids"], out["index"], out["size"]):
+        ls = 6 if sz == 7 else sz
+        perm.append((idx - out["m"], our_col(int(i)) - m, ls))
+    r = out["r"]
+    Pm = np.zeros((r, r))  # lib index <- our index
+    for li, oi, ls in perm:
+        for k in range(ls):
+            Pm[li + k, oi + k] = 1.0
+    assert np.allclose(Pm.sum(0), 1) and np.allclose(Pm.sum(1), 1)
+    Hp_exp = Pm @ Hp_o @ Pm.T
+    bp_exp = Pm @ bp_o
+    scale = np.abs(Hp_exp).max()
+    assert np.abs(out["Hp"] - Hp_exp).max() < 1e-8 * scale
+    assert np.abs(out["bp"] - bp_exp).max() < 1e-8 * max(1.0, np.abs(bp_exp).max())
+    # linearization identities on the library's own J0/e0
+    ev, V = np.linalg.eigh(0.5 * (out["Hp"] + out["Hp"].T))
+    Hp_trunc = V @ np.diag(np.where(ev > 1e-8, ev, 0)) @ V.T
+    assert np.abs(out["J0"].T @ out["J0"] - Hp_trunc).max() < 1e-6 * scale
+    proj = V @ np.diag((ev > 1e-8).astype(float)) @ V.T
+    assert np.abs(out["J0"].T @ out["e0"] + proj @ out["bp"]).max() < 1e-6 * max(1.0, np.abs(out["bp"]).max())
+    # MarginalizationFactor::Evaluate at a perturbed point == oracle's evaluation with the same J0/e0
+    rng = np.random.RandomState(5)
+    x0, x = [], []
+    for i, sz in zip(out["ids"], out["size"]):
+        i = int(i)
+        if i < 100000:
+            base = w["poses"][i]
+            x0.append(base)
+            x.append(rd.pose_plus(base, rng.normal(0, 1e-3, 6)))
+        elif i < 900000:
+            base = np.array([w["invdepth"][i - 100000]])
+            x0.append(base)
+            x.append(base + rng.normal(0, 1e-4, 1))
+        elif i == 900000:
+            x0.append(w["ext"])
+            x.append(rd.pose_plus(w["ext"], rng.normal(0, 1e-3, 6)))
+        else:
+            x0.append(np.array([w["td"]]))
+            x.append(np.array([w["td"] + 1e-4]))
+    out2 = backend_marginalize(lib, P, huber=1.0, prior_weight=100.0, x_eval=np.concatenate(x))
+    res_exp, _ = oracle.marg_factor_eval(out["size"], out["index"] - out["m"], np.concatenate(x0), np.concatenate(x), out2["J0"], out2["e0"],
+                                         want_jac=False)
+    assert np.abs(out2["res"] - res_exp).max() < 1e-9 * max(1.0, np.abs(res_exp).max())
+
+
+def check_preintegration(lib, oracle):
+    for variant in (0, 1):
+        lens = [41, 17, 60]
+        imus = [pd.make_interval(n, seed=20 + i) for i, n in enumerate(lens)]
+        states = [pd.state(p=(i, 1, 0), v=(2, 0.1 * i, 0)) for i in range(len(lens))]
+        offsets = np.cumsum([0] + lens).astype(np.int32)
+        pres = [oracle.preint_integrate(variant, imus[i], states[i], pd.PARAMS) for i in range(len(lens))]
+        evalp = []
+        for i in range(len(lens)):
+            pose0, mix0 = pd.split(states[i])
+            pose1, mix1 = pd.split(pres[i]["cur"])
+            pose1 = rd.pose_plus(pose1, np.array([0.01, -0.02, 0.01, 0.001, 0.002, -0.001]))
+            evalp.append(np.concatenate([pose0, mix0, pose1, mix1]))
+        n = len(lens)
+        cur, res, jac = np.zeros((n, 16)), np.zeros((n, 15)), np.zeros((n, 480))
+        err = C.create_string_buffer(512)
+        imu = _f64(np.concatenate(imus))
+        rc = lib.icgh_backend_preint(variant, n, _p(offsets), _p(imu), _p(_f64(np.stack(states))), _p(_f64(pd.PARAMS)),
+                                     _p(_f64(np.stack(evalp))), _p(cur), _p(res), _p(jac), err, 512)
+        assert rc == 0, (rc, err.value)
+        for i in range(n):
+            ep = evalp[i]
+            r_exp, J_exp = oracle.preint_evaluate(variant, pres[i], [0, 0, pd.PARAMS[5]], pd.PARAMS[6:9], ep[:7], ep[7:16], ep[16:23], ep[23:32])
+            assert np.abs(cur[i] - pres[i]["cur"]).max() < 1e-9 * np.abs(pres[i]["cur"]).max()
+            J_cat = np.concatenate([J_exp[0].ravel(), J_exp[1].ravel(), J_exp[2].ravel(), J_exp[3].ravel()])
+            # whitening by the inverse covariance amplifies libm-level differences of the integration: 1e-6 relative
+            assert np.abs(res[i] - r_exp).max() < 1e-6 * max(1.0, np.abs(r_exp).max())
+            assert np.abs(jac[i] - J_cat).max() < 1e-6 * max(1.0, np.abs(J_cat).max())
