@@ -79,14 +79,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("ICG_BENCH_STREAMS", "32")), help="camera streams per GPU")
-    ap.add_argument("--ring", type=int, default=12, help="rendered frames per stream (ping-pong replay)")
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("ICG_BENCH_STREAMS", "64")), help="camera streams per GPU")
+    ap.add_argument("--ring", type=int, default=64, help="rendered frames per stream (ping-pong replay)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--features", type=int, default=300)
     ap.add_argument("--host-threads", type=int, default=1, help="host threads inside each group")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("ICG_BENCH_GROUPS", "8")),
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("ICG_BENCH_GROUPS", "16")),
                     help="stream groups per GPU (own HIP stream + host thread each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproj", action="store_true")
@@ -287,7 +287,7 @@ def main():
         from stream_utils import ensure_oracle_host
         lib = ensure_oracle_host()
         sbc = H.StreamBatch(lib, 1, w, h, cam, max_features=nfeat, window=10)
-        nwarm, ntime = 10, 24
+        nwarm, ntime = 30, 30
         kk = 0
         for _ in range(nwarm):
             f = H.pingpong(kk, args.ring)

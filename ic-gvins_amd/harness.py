@@ -47,12 +47,13 @@ class SynthScene:
         self.e1 = np.array([np.cos(a), 0.0, np.sin(a)])
         self.e2 = np.array([0.0, 1.0, 0.0])
         self.texels_per_m = 40.0 * width / 1280.0
+        self.vx, self.vz = 16.0, 1.0  # sideways / forward speed, m/s
 
     def pose(self, k, fps=20.0, stream=0):
         """True camera pose of frame k: (R camera->world 3x3, t 3)."""
         tau = k / fps
         ph = 0.37 * stream
-        t = np.array([4.0 * tau + 7.3 * stream, 0.3 * np.sin(0.7 * tau + ph), 1.0 * tau])
+        t = np.array([self.vx * tau + 7.3 * stream, 0.3 * np.sin(0.7 * tau + ph), self.vz * tau])
         R = _rot_yp(0.05 * np.sin(0.5 * tau + ph), 0.03 * np.sin(0.8 * tau + ph))
         return R, t
 
