@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "ic-gvins_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import harness as H  # noqa: E402
+import sharding  # noqa: E402
 import icgvins  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
@@ -64,7 +65,7 @@ def build_streams(sb, scene, n_streams, n_ring, rank, ctx_dev_upload):
     dev = []
     host0 = []
     for s in range(n_streams):
-        sid = rank * n_streams + s
+        sid = sharding.shard_stream_ids(rank, 0, n_streams)[s]
         ptrs = []
         for k in range(n_ring):
             img = scene.render(k, stream=sid)
@@ -155,6 +156,7 @@ def main():
     k += args.warmup
     barrier()
     sb.timing(reset=True)
+    tracked_before = sum(sb.stats(s)["tracked_sum"] for s in range(B))
     t0 = time.perf_counter()
     st = run_steps(k, args.steps)  # EXACTLY args.steps lock-step frames for every stream
     k += args.steps
@@ -166,17 +168,9 @@ def main():
 
     # terminal exchange: max elapsed, summed counters, gathered digests
     stats = [sb.stats(s) for s in range(B)]
-    tracked = sum(s["tracked_sum"] for s in stats)
-    counters = torch.tensor([float(B * args.steps), float(tracked), float(states_hist[2])], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dig = torch.tensor([s["digest"] & 0x7fffffffffffffff for s in stats], dtype=torch.int64, device="cuda")
-        gathered = [torch.zeros_like(dig) for _ in range(world)]
-        dist.all_gather(gathered, dig)
-    total_frames, total_tracked, total_tracking_states = [float(x) for x in counters.cpu()]
-    elapsed_max = float(tmax.cpu()[0])
+    tracked = sum(s["tracked_sum"] for s in stats) - tracked_before
+    (total_frames, total_tracked, total_tracking_states), elapsed_max, all_digests = sharding.terminal_exchange(
+        dist, "cuda", [B * args.steps, tracked, states_hist[2]], elapsed, [s["digest"] for s in stats])
     fps = total_frames / elapsed_max
 
     # ---- profiled pass (HIP events on the ABI stream) for the roofline of the dominant kernel -------------------------

@@ -1,0 +1,49 @@
+"""The C-ABI shared library loads without a GPU and exports every entry point include/icgvins_hip.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "icgvins_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(icg_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported():
+    import icgvins
+    lib = icgvins.load_library()
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(icgvins.EXPORTS) <= set(syms)
+
+
+def test_no_cpu_fallback_without_device():
+    """On a box without a GPU context creation must fail loudly (ICG_ERR_NODEVICE), never compute on the CPU."""
+    import icgvins
+    lib = icgvins.load_library()
+    ndev = ctypes.c_int(0)
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        rc = hip.hipGetDeviceCount(ctypes.byref(ndev))
+        has_gpu = rc == 0 and ndev.value > 0
+    except OSError:
+        has_gpu = False
+    if has_gpu:
+        return  # covered by the gpu tests
+    cfg = icgvins.CtxConfig(0, 640, 480, 2, 1, 64, 0)
+    h = ctypes.c_void_p()
+    assert lib.icg_ctx_create(ctypes.byref(cfg), ctypes.byref(h)) == -4
+    assert b"no CPU fallback" in lib.icg_last_error(None)
+
+
+def test_host_library_exports_driver_entry_points():
+    import harness
+    lib = ctypes.CDLL(harness.HOST_LIB)
+    for s in ("icgh_batch_create", "icgh_batch_run", "icgh_batch_step", "icgh_batch_stats", "icgh_batch_features", "icgh_backend_reproj",
+              "icgh_backend_marginalize", "icgh_backend_preint", "icgs_render"):
+        assert hasattr(lib, s), s

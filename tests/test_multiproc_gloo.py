@@ -1,0 +1,53 @@
+"""N>1 path on CPU: two gloo ranks each track their shard of the streams (oracle-backed host layer) and run the same
+terminal exchange bench.py uses over RCCL; the gathered per-stream digests must equal a single-process run of all streams
+(placement invariance) and the reduced counters must add up."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, nframes, per_rank, out_q):
+    sys.path.insert(0, os.path.join(ROOT, "ic-gvins_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    import sharding
+    from stream_utils import ensure_oracle_host, run_streams
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = sharding.shard_stream_ids(rank, world, per_rank)
+    rec, stats, _ = run_streams(ensure_oracle_host(), per_rank, 320, 240, nframes, 60, stream_ids=ids)
+    tracked = sum(s["tracked_sum"] for s in stats)
+    counters, tmax, digests = sharding.terminal_exchange(dist, "cpu", [per_rank * nframes, tracked], 0.5 + rank, [s["digest"] for s in stats])
+    if rank == 0:
+        out_q.put((counters, tmax, digests, tracked))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process():
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "ic-gvins_amd"))
+    from stream_utils import ensure_oracle_host, run_streams
+    ensure_oracle_host()
+    world, per_rank, nframes = 2, 2, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nframes, per_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    counters, tmax, digests, tracked0 = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rec, stats, _ = run_streams(ensure_oracle_host(), world * per_rank, 320, 240, nframes, 60)
+    assert digests == [s["digest"] & 0x7fffffffffffffff for s in stats]
+    assert counters[0] == world * per_rank * nframes
+    assert counters[1] == sum(s["tracked_sum"] for s in stats)
+    assert tmax == 1.5  # MAX over ranks
