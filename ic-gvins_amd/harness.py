@@ -160,6 +160,14 @@ class StreamBatch:
         self.lib.icgh_batch_timing(C.c_void_p(self.h_), out.ctypes.data_as(C.c_void_p), 1 if reset else 0)
         return dict(zip(["host_logic", "gather", "device_execute", "scatter", "finalize"], [float(v) for v in out]))
 
+    def timing_groups(self):
+        out = []
+        for g in range(self.n_groups()):
+            t = np.zeros(5, np.float64)
+            self.lib.icgh_batch_timing_group(C.c_void_p(self.h_), g, t.ctypes.data_as(C.c_void_p))
+            out.append(t.copy())
+        return np.stack(out)
+
     def features(self, stream, max_n=2048):
         ids = np.zeros(max_n, np.uint64)
         px = np.zeros((max_n, 2), np.float32)

@@ -1,4 +1,6 @@
 // C entry points of libicgvins_host.so for harnesses that cannot speak C++ (tests, bench.py): drive a TrackingBatch.
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -55,6 +57,7 @@ int icgh_batch_run(icgh_batch *b, int K, const void *const *images, int stride, 
                    const double *stamps, const double *poses12, int32_t *states, char *err, int errlen) {
     try {
         const int n = b->tb->size();
+        auto t0     = std::chrono::steady_clock::now();
         vector<vector<Frame::Ptr>> frames((size_t) K, vector<Frame::Ptr>((size_t) n));
         for (int k = 0; k < K; k++)
             for (int i = 0; i < n; i++) {
@@ -69,9 +72,17 @@ int icgh_batch_run(icgh_batch *b, int K, const void *const *images, int stride, 
                 frames[(size_t) k][(size_t) i] = f;
             }
         vector<vector<TrackState>> st;
+        auto t1 = std::chrono::steady_clock::now();
         b->tb->stepMany(frames, st);
+        auto t2 = std::chrono::steady_clock::now();
         for (int k = 0; k < K; k++)
             for (int i = 0; i < n; i++) states[(size_t) k * n + i] = (int32_t) st[(size_t) k][(size_t) i];
+        frames.clear();
+        auto t3 = std::chrono::steady_clock::now();
+        if (getenv("ICG_DEBUG_TIMING"))
+            fprintf(stderr, "[icgh_batch_run] K=%d create %.2f ms, stepMany %.2f ms, teardown %.2f ms\n", K,
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                    std::chrono::duration<double, std::milli>(t3 - t2).count());
         return 0;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());
@@ -107,6 +118,12 @@ int icgh_batch_timing(icgh_batch *b, double *out5, int reset) {
             out5[i] += b->tb->group(g).timing[i] / b->tb->groups(); // mean over groups (they run concurrently)
             if (reset) b->tb->group(g).timing[i] = 0;
         }
+    return 0;
+}
+
+int icgh_batch_timing_group(icgh_batch *b, int g, double *out5) {
+    if (!b || g < 0 || g >= b->tb->groups()) return -1;
+    for (int i = 0; i < 5; i++) out5[i] = b->tb->group(g).timing[i];
     return 0;
 }
 

@@ -1,5 +1,6 @@
 #include "tracking_batch.h"
 
+#include <cstdlib>
 #include <stdexcept>
 
 #include <atomic>
@@ -268,15 +269,24 @@ void StreamGroups::workerLoop(int g) {
         }
         const int b = group_begin_[(size_t) g], e = group_begin_[(size_t) g + 1];
         std::string err;
+        const double tw0 = now_s();
         try {
             for (size_t k = 0; k < frames_->size(); k++) {
                 vector<Frame::Ptr> fr((*frames_)[k].begin() + b, (*frames_)[k].begin() + e);
                 vector<TrackState> st;
                 groups_[(size_t) g]->step(fr, st);
-                for (int i = b; i < e; i++) (*states_)[k][(size_t) i] = st[(size_t) (i - b)];
+                for (int i = b; i < e; i++) {
+                    (*states_)[k][(size_t) i] = st[(size_t) (i - b)];
+                    (*frames_)[k][(size_t) i].reset(); // drop the caller's reference here, on this worker
+                }
             }
         } catch (const std::exception &ex) {
             err = ex.what();
+        }
+        if (getenv("ICG_DEBUG_TIMING") && frames_->size() > 1) {
+            const double *t = groups_[(size_t) g]->timing;
+            fprintf(stderr, "[group %d] worker wall %.2f ms, in-step accumulated %.2f ms\n", g, 1e3 * (now_s() - tw0),
+                    1e3 * (t[0] + t[1] + t[2] + t[3] + t[4]));
         }
         {
             std::unique_lock<std::mutex> lock(m_);
@@ -293,10 +303,13 @@ void StreamGroups::step(const vector<Frame::Ptr> &frames, vector<TrackState> &st
     states = s1[0];
 }
 
-void StreamGroups::stepMany(const vector<vector<Frame::Ptr>> &frames, vector<vector<TrackState>> &states) {
+void StreamGroups::stepMany(vector<vector<Frame::Ptr>> &frames, vector<vector<TrackState>> &states) {
     states.assign(frames.size(), vector<TrackState>((size_t) n_streams_, TRACK_PASSED));
     if (workers_.empty()) {
-        for (size_t k = 0; k < frames.size(); k++) groups_[0]->step(frames[k], states[k]);
+        for (size_t k = 0; k < frames.size(); k++) {
+            groups_[0]->step(frames[k], states[k]);
+            for (auto &f : frames[k]) f.reset();
+        }
         return;
     }
     {

@@ -60,7 +60,8 @@ public:
     void step(const vector<Frame::Ptr> &frames, vector<TrackState> &states);
     // K consecutive steps without a cross-group barrier in between: every group walks through its own K frames at its
     // own pace (streams are independent, so the per-stream results equal K calls of step()).
-    void stepMany(const vector<vector<Frame::Ptr>> &frames, vector<vector<TrackState>> &states);
+    // (each group releases its reference to a frame as soon as the frame has been processed)
+    void stepMany(vector<vector<Frame::Ptr>> &frames, vector<vector<TrackState>> &states);
     int size() const { return n_streams_; }
     int groups() const { return (int) groups_.size(); }
     TrackingBatch &group(int g) { return *groups_[(size_t) g]; }
@@ -79,7 +80,7 @@ private:
     uint64_t generation_{0};
     int pending_{0};
     bool stop_{false};
-    const vector<vector<Frame::Ptr>> *frames_{nullptr};
+    vector<vector<Frame::Ptr>> *frames_{nullptr};
     vector<vector<TrackState>> *states_{nullptr};
     std::string error_;
 };
