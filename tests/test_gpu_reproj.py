@@ -78,3 +78,13 @@ def test_normal_equation_assembly_matches_oracle(oracle, ctx):
     H2, b2 = ctx.reproj_accumulate_normal(P2["local_size"], P2["col_pose"], -1, P2["col_lm"], -1)
     H2e, b2e = oracle.reproj_accumulate_normal(r_exp, J_exp, P["ii"], P["jj"], P["ll"], P2["col_pose"], -1, P2["col_lm"], -1, P2["local_size"])
     assert np.abs(H2 - H2e).max() <= 1e-9 * np.abs(H2e).max() and np.abs(b2 - b2e).max() <= 1e-9 * np.abs(b2e).max()
+
+
+def test_reproj_matches_reference_golden(ctx):
+    """HIP kernel vs outputs of the reference's own ReprojectionFactor::Evaluate (tests/golden/reproj_ref_golden.npz,
+    generated from /root/reference by tests/golden/make_reproj_golden.py). north_star tolerance 1e-5; asserted 1e-10."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reproj_ref_golden.npz"))
+    r, J = ctx.reproj_eval(g["obs"], g["idx_i"], g["idx_j"], g["idx_lm"], g["poses"], g["ext"], g["invdepth"], float(g["td"]))
+    assert np.abs(r - g["r"]).max() <= 1e-10 * max(1.0, np.abs(g["r"]).max())
+    assert np.abs(J - g["J"]).max() <= 1e-10 * max(1.0, np.abs(g["J"]).max())
