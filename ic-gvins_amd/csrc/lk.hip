@@ -10,9 +10,12 @@
 //   * per level the 24x24 u8 neighbourhood of the previous image is staged in LDS (reflect-101 applied at load),
 //     Scharr derivatives of the 22x22 support are computed ON THE FLY into LDS (the derivative planes are never
 //     materialised in HBM: -5.3 B/px of traffic per frame vs OpenCV's layout),
-//   * each lane owns a 7-pixel horizontal run of the 21x21 window (63 lanes x 7 = 441): I, Ix, Iy stay in VGPRs
-//     for all <=30 Gauss-Newton iterations,
-//   * the next image is read through a 32x32 u8 LDS tile that is re-staged only when the window leaves it,
+//   * each lane owns a 7-pixel horizontal run of the 21x21 window (63 lanes x 7 = 441): it reads its 4x10-byte patch of
+//     the staged tile as aligned dwords (+ v_alignbyte), computes its Scharr derivatives and I/Ix/Iy samples in
+//     registers and keeps them there for all <=30 Gauss-Newton iterations,
+//   * the next image is read through a 32x32 u8 LDS tile (re-staged only when the window leaves it); the lane's 2x8
+//     bytes of it are CACHED IN REGISTERS and re-fetched only when the integer window position changes, so a typical
+//     iteration touches no LDS at all (v1 spent 39% of its wave cycles in LDS issue stalls: rocprofv3 SQ_WAIT_INST_LDS),
 //   * A11/A12/A22 and b1/b2 are per-lane int32 partials (bounded: 7*4080^2 < 2^27, 7*8160*4080 < 2^28) reduced exactly:
 //     DPP butterflies in 32 bits up to 16 / 8 lanes, then v_readlane + 64-bit scalar adds (uniform result in SGPRs);
 //     every multiply has 24-bit operands -> full-rate v_mul_i32_i24 / v_mad_i32_i24.
@@ -26,15 +29,15 @@
 using namespace icgd;
 
 #define LK_IT 24   // I tile side (22 support + 1 halo each side)
-#define LK_DT 22   // derivative tile side
+#define LK_IS 28   // I tile row stride in bytes (7 dwords: every lane reads 4 aligned dwords per row)
 #define LK_JT 32   // J tile side
+#define LK_JS 36   // J tile row stride in bytes (9 dwords: 3 aligned dwords cover any 8-byte run)
 #define LK_JM 5    // J tile margin around the 22x22 support
 #define LK_MAX_ITERS 30
 
 struct lk_smem {
-    unsigned char I[LK_IT * LK_IT];
-    short2 dI[LK_DT * LK_DT];
-    unsigned char J[LK_JT * LK_JT];
+    unsigned int I[LK_IT * LK_IS / 4];
+    unsigned int J[LK_JT * LK_JS / 4 + 1];
 };
 
 // Exact wave-wide integer sums, result uniform (SGPRs).  The per-lane partials are bounded (see the kernel comment), so
@@ -76,15 +79,43 @@ __device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01,
     w11 = (1 << 14) - w00 - w01 - w10;
 }
 
+// 4 consecutive pixels of row `row` starting at image column x (reflect-101 outside the image), packed little-endian
+__device__ __forceinline__ unsigned int lk_load4(const unsigned char *row, int x, int W) {
+    if (x >= 0 && x + 3 < W) {
+        typedef unsigned int __attribute__((aligned(1))) u32u;
+        return *reinterpret_cast<const u32u *>(row + x);
+    }
+    unsigned int v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v |= (unsigned int) row[icg_reflect101(x + k, W)] << (8 * k);
+    return v;
+}
+__device__ __forceinline__ int lk_byte(unsigned int w, int k) { return (int) ((w >> (8 * k)) & 0xffu); }
+
+// 32x32 u8 tile of the next image: lane -> (row lane>>1, 16 pixels at column (lane&1)*16) = 4 packed dwords
 __device__ __forceinline__ void lk_stage_J(lk_smem &S, const unsigned char *J, int W, int H, int pitch, int jx0, int jy0,
                                            int lane) {
-    // 32x32 tile: lane -> (row = lane>>1, 16 pixels at column (lane&1)*16)
     const int r  = lane >> 1;
     const int c0 = (lane & 1) * 16;
-    const int sy = icg_reflect101(jy0 + r, H);
-    const unsigned char *row = J + (size_t) sy * pitch;
+    const unsigned char *row = J + (size_t) icg_reflect101(jy0 + r, H) * pitch;
+    unsigned int *dst        = &S.J[(r * LK_JS + c0) >> 2];
 #pragma unroll
-    for (int c = 0; c < 16; c++) S.J[r * LK_JT + c0 + c] = row[icg_reflect101(jx0 + c0 + c, W)];
+    for (int q = 0; q < 4; q++) dst[q] = lk_load4(row, jx0 + c0 + 4 * q, W);
+}
+
+// the lane's two 8-pixel rows of the window at integer position (inx, iny), from the staged tile (3 aligned dwords + a
+// byte funnel shift per row)
+__device__ __forceinline__ void lk_fetch_J(const lk_smem &S, int row0, int o, unsigned int &a0, unsigned int &a1,
+                                           unsigned int &b0, unsigned int &b1) {
+    const int idx = o >> 2, sh = o & 3;
+    const unsigned int *r0 = &S.J[(row0 * LK_JS >> 2) + idx];
+    const unsigned int *r1 = r0 + (LK_JS >> 2);
+    const unsigned int d0 = r0[0], d1 = r0[1], d2 = r0[2];
+    const unsigned int e0 = r1[0], e1 = r1[1], e2 = r1[2];
+    a0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    a1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    b0 = __builtin_amdgcn_alignbyte(e1, e0, sh);
+    b1 = __builtin_amdgcn_alignbyte(e2, e1, sh);
 }
 
 // One calcOpticalFlowPyrLK point, executed cooperatively by a full wave. Returns status.
@@ -96,9 +127,9 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
     float errv            = 0.f;
     float2 nextStore      = nextIO;
     const int maxLevel    = P.n_levels - 1;
-    const int ly          = lane / 3;
-    const int lx0         = (lane - ly * 3) * 7;
     const bool active     = lane < 63;
+    const int ly          = active ? lane / 3 : 0;
+    const int lx0         = active ? (lane - ly * 3) * 7 : 0;
 
     for (int level = maxLevel; level >= 0; --level) {
         const int W = P.w[level], H = P.h[level], pitch = P.pitch[level];
@@ -129,61 +160,67 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
         int w00, w01, w10, w11;
         lk_weights(prevx - ipx, prevy - ipy, w00, w01, w10, w11);
 
+        // ---- stage the 24x24 neighbourhood of the previous image (tile (r,c) <-> image (ipx-1+c, ipy-1+r)) ----
         __syncthreads(); // previous level's LDS readers are done
-        for (int i = lane; i < LK_IT * LK_IT; i += 64) {
-            int r = i / LK_IT, c = i - r * LK_IT;
-            S.I[i] = I[(size_t) icg_reflect101(ipy - 1 + r, H) * pitch + icg_reflect101(ipx - 1 + c, W)];
-        }
-        __syncthreads();
-        for (int i = lane; i < LK_DT * LK_DT; i += 64) {
-            int r = i / LK_DT, c = i - r * LK_DT;
-            int X = ipx + c, Y = ipy + r;
-            short2 d = make_short2(0, 0);
-            if (X >= 0 && X < W && Y >= 0 && Y < H) {
-                const unsigned char *t = &S.I[r * LK_IT + c];
-                int p00 = t[0], p01 = t[1], p02 = t[2];
-                int p10 = t[LK_IT], p12 = t[LK_IT + 2];
-                int p20 = t[2 * LK_IT], p21 = t[2 * LK_IT + 1], p22 = t[2 * LK_IT + 2];
-                int t0m = 3 * (p00 + p20) + 10 * p10;
-                int t0p = 3 * (p02 + p22) + 10 * p12;
-                int t1m = p20 - p00, t1c = p21 - p01, t1p = p22 - p02;
-                d.x     = (short) (t0p - t0m);
-                d.y     = (short) (3 * (t1m + t1p) + 10 * t1c);
-            }
-            S.dI[i] = d;
+        for (int i = lane; i < LK_IT * 6; i += 64) {
+            const int r = i / 6, cd = i - r * 6;
+            const unsigned char *row = I + (size_t) icg_reflect101(ipy - 1 + r, H) * pitch;
+            S.I[(r * LK_IS >> 2) + cd] = lk_load4(row, ipx - 1 + 4 * cd, W);
         }
         __syncthreads();
 
+        // ---- per lane: 4 rows x 10 bytes -> I samples and on-the-fly Scharr derivatives of its 7-pixel run ----
         int iv[7], ix[7], iy[7];
         int sA11 = 0, sA12 = 0, sA22 = 0;
+        {
+            // rows ly..ly+3, byte columns lx0..lx0+9 of the tile
+            const int idx = lx0 >> 2, sh = lx0 & 3;
+            unsigned int wv[4][3];
 #pragma unroll
-        for (int k = 0; k < 7; k++) {
-            iv[k] = 0;
-            ix[k] = 0;
-            iy[k] = 0;
-        }
-        if (active) {
-            const unsigned char *t0 = &S.I[(ly + 1) * LK_IT + lx0 + 1];
-            const unsigned char *t1 = t0 + LK_IT;
-            const short2 *d0        = &S.dI[ly * LK_DT + lx0];
-            const short2 *d1        = d0 + LK_DT;
-            int a0 = t0[0], a1 = t1[0];
-            short2 e0 = d0[0], e1 = d1[0];
+            for (int r = 0; r < 4; r++) {
+                const unsigned int *p = &S.I[((ly + r) * LK_IS >> 2) + idx];
+                const unsigned int d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
+                wv[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                wv[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                wv[r][2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            }
+#define LK_T(r, j) lk_byte(wv[r][(j) >> 2], (j) &3)
+            // derivative at support position (c = lx0+j, r = ly+rr): 3x3 neighbourhood = tile rows rr..rr+2, cols j..j+2
+            int dxv[2][8], dyv[2][8];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int Y = ipy + ly + rr;
+                const bool yin = Y >= 0 && Y < H;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int X = ipx + lx0 + j;
+                    const int p00 = LK_T(rr, j), p01 = LK_T(rr, j + 1), p02 = LK_T(rr, j + 2);
+                    const int p10 = LK_T(rr + 1, j), p12 = LK_T(rr + 1, j + 2);
+                    const int p20 = LK_T(rr + 2, j), p21 = LK_T(rr + 2, j + 1), p22 = LK_T(rr + 2, j + 2);
+                    const int t0m = 3 * (p00 + p20) + 10 * p10;
+                    const int t0p = 3 * (p02 + p22) + 10 * p12;
+                    const int t1m = p20 - p00, t1c = p21 - p01, t1p = p22 - p02;
+                    const bool in = yin && X >= 0 && X < W; // derivative plane is ZERO outside the image
+                    dxv[rr][j]    = in ? (t0p - t0m) : 0;
+                    dyv[rr][j]    = in ? (3 * (t1m + t1p) + 10 * t1c) : 0;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 7; k++) {
-                int b0 = t0[k + 1], b1 = t1[k + 1];
-                short2 f0 = d0[k + 1], f1 = d1[k + 1];
+                const int a0 = LK_T(1, k + 1), b0 = LK_T(1, k + 2), a1 = LK_T(2, k + 1), b1 = LK_T(2, k + 2);
                 iv[k] = lk_descale(__mul24(a0, w00) + __mul24(b0, w01) + __mul24(a1, w10) + __mul24(b1, w11), 14 - 5);
-                ix[k] = lk_descale(__mul24(e0.x, w00) + __mul24(f0.x, w01) + __mul24(e1.x, w10) + __mul24(f1.x, w11), 14);
-                iy[k] = lk_descale(__mul24(e0.y, w00) + __mul24(f0.y, w01) + __mul24(e1.y, w10) + __mul24(f1.y, w11), 14);
+                ix[k] = lk_descale(__mul24(dxv[0][k], w00) + __mul24(dxv[0][k + 1], w01) + __mul24(dxv[1][k], w10) + __mul24(dxv[1][k + 1], w11), 14);
+                iy[k] = lk_descale(__mul24(dyv[0][k], w00) + __mul24(dyv[0][k + 1], w01) + __mul24(dyv[1][k], w10) + __mul24(dyv[1][k + 1], w11), 14);
+                if (!active) {
+                    iv[k] = 0;
+                    ix[k] = 0;
+                    iy[k] = 0;
+                }
                 sA11 += __mul24(ix[k], ix[k]);
                 sA12 += __mul24(ix[k], iy[k]);
                 sA22 += __mul24(iy[k], iy[k]);
-                a0 = b0;
-                a1 = b1;
-                e0 = f0;
-                e1 = f1;
             }
+#undef LK_T
         }
         const long long iA11 = wave_sum_i32x16(sA11), iA12 = wave_sum_i32x16(sA12), iA22 = wave_sum_i32x16(sA22);
         const float A11 = (float) iA11 * FLT_SCALE, A12 = (float) iA12 * FLT_SCALE, A22 = (float) iA22 * FLT_SCALE;
@@ -198,6 +235,8 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
         npty -= (float) ICG_LK_HALF;
         float pdx = 0.f, pdy = 0.f;
         int jx0 = -1000000, jy0 = -1000000;
+        int cinx = -1000000, ciny = -1000000;     // integer window position whose bytes are cached in ja/jb
+        unsigned int ja0 = 0, ja1 = 0, jb0 = 0, jb1 = 0; // the lane's 2 x 8 bytes of the next image
 
         for (int j = 0; j < LK_MAX_ITERS; j++) {
             const int inx = (int) floorf(nptx), iny = (int) floorf(npty);
@@ -205,28 +244,27 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                 if (level == 0) status = false;
                 break;
             }
-            if (!(inx >= jx0 && inx <= jx0 + (LK_JT - LK_DT) && iny >= jy0 && iny <= jy0 + (LK_JT - LK_DT))) {
-                jx0 = inx - LK_JM;
-                jy0 = iny - LK_JM;
-                __syncthreads();
-                lk_stage_J(S, J, W, H, pitch, jx0, jy0, lane);
-                __syncthreads();
+            if (inx != cinx || iny != ciny) {
+                if (!(inx >= jx0 && inx <= jx0 + (LK_JT - 22) && iny >= jy0 && iny <= jy0 + (LK_JT - 22))) {
+                    jx0 = inx - LK_JM;
+                    jy0 = iny - LK_JM;
+                    __syncthreads();
+                    lk_stage_J(S, J, W, H, pitch, jx0, jy0, lane);
+                    __syncthreads();
+                }
+                lk_fetch_J(S, iny - jy0 + ly, (inx - jx0) + lx0, ja0, ja1, jb0, jb1);
+                cinx = inx;
+                ciny = iny;
             }
             lk_weights(nptx - inx, npty - iny, w00, w01, w10, w11);
             int sb1 = 0, sb2 = 0;
-            if (active) {
-                const unsigned char *t0 = &S.J[(iny - jy0 + ly) * LK_JT + (inx - jx0) + lx0];
-                const unsigned char *t1 = t0 + LK_JT;
-                int a0 = t0[0], a1 = t1[0];
 #pragma unroll
-                for (int k = 0; k < 7; k++) {
-                    int b0 = t0[k + 1], b1 = t1[k + 1];
-                    int diff = lk_descale(__mul24(a0, w00) + __mul24(b0, w01) + __mul24(a1, w10) + __mul24(b1, w11), 14 - 5) - iv[k];
-                    sb1 += __mul24(diff, ix[k]);
-                    sb2 += __mul24(diff, iy[k]);
-                    a0 = b0;
-                    a1 = b1;
-                }
+            for (int k = 0; k < 7; k++) {
+                const int a0 = lk_byte(k < 4 ? ja0 : ja1, k & 3), b0 = lk_byte(k + 1 < 4 ? ja0 : ja1, (k + 1) & 3);
+                const int a1 = lk_byte(k < 4 ? jb0 : jb1, k & 3), b1 = lk_byte(k + 1 < 4 ? jb0 : jb1, (k + 1) & 3);
+                const int diff = lk_descale(__mul24(a0, w00) + __mul24(b0, w01) + __mul24(a1, w10) + __mul24(b1, w11), 14 - 5) - iv[k];
+                sb1 += __mul24(diff, ix[k]);
+                sb2 += __mul24(diff, iy[k]);
             }
             const long long ib1 = wave_sum_i32x8(sb1), ib2 = wave_sum_i32x8(sb2);
             const float b1 = (float) ib1 * FLT_SCALE, b2 = (float) ib2 * FLT_SCALE;
@@ -254,23 +292,25 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                 continue;
             }
             if (err_out) {
-                if (!(inx >= jx0 && inx <= jx0 + (LK_JT - LK_DT) && iny >= jy0 && iny <= jy0 + (LK_JT - LK_DT))) {
-                    jx0 = inx - LK_JM;
-                    jy0 = iny - LK_JM;
-                    __syncthreads();
-                    lk_stage_J(S, J, W, H, pitch, jx0, jy0, lane);
-                    __syncthreads();
+                if (inx != cinx || iny != ciny) {
+                    if (!(inx >= jx0 && inx <= jx0 + (LK_JT - 22) && iny >= jy0 && iny <= jy0 + (LK_JT - 22))) {
+                        jx0 = inx - LK_JM;
+                        jy0 = iny - LK_JM;
+                        __syncthreads();
+                        lk_stage_J(S, J, W, H, pitch, jx0, jy0, lane);
+                        __syncthreads();
+                    }
+                    lk_fetch_J(S, iny - jy0 + ly, (inx - jx0) + lx0, ja0, ja1, jb0, jb1);
                 }
                 lk_weights(ex - inx, ey - iny, w00, w01, w10, w11);
                 int se = 0;
-                if (active) {
-                    const unsigned char *t0 = &S.J[(iny - jy0 + ly) * LK_JT + (inx - jx0) + lx0];
-                    const unsigned char *t1 = t0 + LK_JT;
 #pragma unroll
-                    for (int k = 0; k < 7; k++) {
-                        int diff = lk_descale(__mul24(t0[k], w00) + __mul24(t0[k + 1], w01) + __mul24(t1[k], w10) + __mul24(t1[k + 1], w11), 14 - 5) - iv[k];
-                        se += diff < 0 ? -diff : diff;
-                    }
+                for (int k = 0; k < 7; k++) {
+                    const int a0 = lk_byte(k < 4 ? ja0 : ja1, k & 3), b0 = lk_byte(k + 1 < 4 ? ja0 : ja1, (k + 1) & 3);
+                    const int a1 = lk_byte(k < 4 ? jb0 : jb1, k & 3), b1 = lk_byte(k + 1 < 4 ? jb0 : jb1, (k + 1) & 3);
+                    int diff = lk_descale(__mul24(a0, w00) + __mul24(b0, w01) + __mul24(a1, w10) + __mul24(b1, w11), 14 - 5) - iv[k];
+                    if (!active) diff = 0;
+                    se += diff < 0 ? -diff : diff;
                 }
                 const long long ie = wave_sum_i32x16(se);
                 errv               = (float) ie * 1.f / (float) (32 * ICG_LK_WIN * ICG_LK_WIN);
