@@ -51,6 +51,7 @@ def algorithmic_bytes(kernel, w, h, n_streams, pts_per_launch):
         "clahe_lut": px * n_streams,                      # read image once for the tile histograms
         "clahe_apply": 2 * px * n_streams,                # read + write
         "pyrdown": None,                                  # per level, filled below
+        "pyramid3": sum(a * b for a, b in pyr) * n_streams,  # read level 0, write levels 1..3
         "lk_track_fb": lk_bytes_per_point() * pts_per_launch,
         "detect_min_eig": 2 * px * n_streams,             # image + mask
         "detect_candidates": (4 + 1) * px * n_streams,    # response map + mask

@@ -11,8 +11,8 @@
 //                 redistribute, 256-bin block scan -> LUT (441 x 256 B per frame, stays in L2)
 //   k_clahe_apply one workgroup per (interpolation strip, 256-px chunk, frame): the <=2x8 LUTs the chunk needs are
 //                 staged in LDS, rows are read/written as coalesced uchar4 per lane
-//   k_pyrdown     64x16 output tile per workgroup, (2*64+3)x(2*16+3) input tile staged in LDS, separable
-//                 [1 4 6 4 1] in exact integers
+//   k_pyramid3    all three pyrDown steps of the usual 4-level pyramid in one launch (LDS -> LDS, see below)
+//   k_pyrdown     single step, used only when the image is too small for 4 levels
 // Algorithmic bytes per frame: CLAHE 3*W*H, pyramid 1.640625*W*H.
 #include <algorithm>
 
@@ -60,68 +60,115 @@ struct clahe_geom {
     float lut_scale, inv_tw, inv_th;
 };
 
-__global__ __launch_bounds__(256) void k_clahe_lut(pre_jobs jobs, clahe_geom g, uint8_t *lut /* n x tiles^2 x 256 */) {
-    __shared__ int hist[256];
-    __shared__ int scan[2][256];
-    __shared__ int red[256];
-    const int t    = threadIdx.x;
+// one WAVE per (tile, frame): rows are read as aligned dwords (reflect-101 only on the padded right/bottom border),
+// the 256-bin histogram lives in LDS, and clip / redistribute / prefix-sum run inside the wave (4 bins per lane)
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_clahe_lut(pre_jobs jobs, clahe_geom g, uint8_t *lut /* n x tiles^2 x 256 */) {
+    __shared__ __attribute__((aligned(16))) unsigned int hist[256];
+    const int lane = threadIdx.x;
     const int tile = blockIdx.x;
     const int b    = blockIdx.y;
     const int ty = tile / ICG_CLAHE_TILES, tx = tile - ty * ICG_CLAHE_TILES;
     const uint8_t *src = jobs.src[b];
     const int stride   = jobs.stride;
-    hist[t] = 0;
+    reinterpret_cast<uint4 *>(hist)[lane] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    const int area = g.tw * g.th;
-    for (int i = t; i < area; i += 256) {
-        int yy = i / g.tw, xx = i - yy * g.tw;
-        int sx = icg_reflect101(tx * g.tw + xx, g.w);
-        int sy = icg_reflect101(ty * g.th + yy, g.h);
-        atomicAdd(&hist[src[(size_t) sy * stride + sx]], 1);
+
+    const int x_begin = tx * g.tw, x_end = x_begin + g.tw, y_begin = ty * g.th;
+    const int xa  = x_begin & ~3;
+    const int ndw = (((x_end + 3) & ~3) - xa) >> 2;
+    const int items = g.th * ndw;
+    constexpr int CH = 10; // dwords in flight per lane
+    for (int base = 0; base < items; base += 64 * CH) {
+        unsigned int v[CH];
+        int xs[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int i = base + k * 64 + lane;
+            v[k]  = 0;
+            xs[k] = -0x40000000;
+            if (i < items) {
+                const int r = i / ndw, d = i - r * ndw;
+                const int x = xa + 4 * d;
+                const uint8_t *row = src + (size_t) icg_reflect101(y_begin + r, g.h) * stride;
+                xs[k] = x;
+                if (x + 3 < g.w) {
+                    v[k] = *reinterpret_cast<const unsigned int *>(row + x);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[k] |= (unsigned int) row[icg_reflect101(x + j, g.w)] << (8 * j);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int xx = xs[k] + j;
+                if (xx >= x_begin && xx < x_end) atomicAdd(&hist[(v[k] >> (8 * j)) & 0xff], 1u);
+            }
+        }
     }
     __syncthreads();
-    int hv     = hist[t];
-    int excess = hv > g.clip ? hv - g.clip : 0;
-    if (hv > g.clip) hv = g.clip;
-    red[t] = excess;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (t < s) red[t] += red[t + s];
-        __syncthreads();
+
+    const uint4 h4 = reinterpret_cast<const uint4 *>(hist)[lane];
+    int hv[4]      = {(int) h4.x, (int) h4.y, (int) h4.z, (int) h4.w};
+    int excess     = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (hv[j] > g.clip) {
+            excess += hv[j] - g.clip;
+            hv[j] = g.clip;
+        }
     }
-    const int clipped  = red[0];
+    const int clipped   = wave_sum_i32(excess);
     const int batch_add = clipped / 256;
-    const int residual = clipped - batch_add * 256;
-    hv += batch_add;
-    if (residual != 0) {
-        int step = 256 / residual;
-        if (step < 1) step = 1;
-        if ((t % step) == 0 && (t / step) < residual) hv++;
+    const int residual  = clipped - batch_add * 256;
+    int step            = residual ? 256 / residual : 1;
+    if (step < 1) step = 1;
+    int run = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int t = 4 * lane + j;
+        hv[j] += batch_add;
+        if (residual != 0 && (t % step) == 0 && (t / step) < residual) hv[j]++;
+        run += hv[j];
+        hv[j] = run; // inclusive prefix inside the lane
     }
-    // inclusive scan over 256 bins (Hillis-Steele, double buffered)
-    int cur = 0;
-    scan[0][t] = hv;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        int v = scan[cur][t];
-        if (t >= d) v += scan[cur][t - d];
-        scan[cur ^ 1][t] = v;
-        cur ^= 1;
-        __syncthreads();
+    // exclusive scan of the lane totals across the wave
+    int incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
     }
-    int sum = scan[cur][t];
-    float f = rintf((float) sum * g.lut_scale);
-    int iv  = (int) f;
-    iv      = iv < 0 ? 0 : (iv > 255 ? 255 : iv);
-    lut[((size_t) b * ICG_CLAHE_TILES * ICG_CLAHE_TILES + tile) * 256 + t] = (uint8_t) iv;
+    const int excl = incl - run;
+    unsigned int packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float f = rintf((float) (excl + hv[j]) * g.lut_scale);
+        int iv        = (int) f;
+        iv            = iv < 0 ? 0 : (iv > 255 ? 255 : iv);
+        packed |= (unsigned int) iv << (8 * j);
+    }
+    reinterpret_cast<unsigned int *>(lut + ((size_t) b * ICG_CLAHE_TILES * ICG_CLAHE_TILES + tile) * 256)[lane] = packed;
 }
 
 #define CLAHE_CHUNK 256 // pixels per workgroup row segment (64 lanes x uchar4)
 #define CLAHE_MAXCOLS 24
 
+// LDS holds, per interpolation column pair p (= tx1+1) and grey level v, the FOUR LUT values the bilinear blend needs as
+// one dword {L[ty1][c1][v], L[ty1][c2][v], L[ty2][c1][v], L[ty2][c2][v]}: one ds_read_b32 + v_cvt_f32_ubyte0..3 per pixel
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(256) void k_clahe_apply(pre_jobs jobs, clahe_geom g, const uint8_t *lut, uint8_t *frames,
                                                      size_t slot_bytes, int dpitch) {
-    __shared__ uint8_t slut[2][CLAHE_MAXCOLS][256];
+    __shared__ __attribute__((aligned(16))) unsigned int slut[CLAHE_MAXCOLS * 256];
     const int strip = blockIdx.x; // ty1_raw = strip-1
     const int chunk = blockIdx.y;
     const int b     = blockIdx.z;
@@ -135,42 +182,45 @@ __global__ __launch_bounds__(256) void k_clahe_apply(pre_jobs jobs, clahe_geom g
     const int x_begin = chunk * CLAHE_CHUNK;
     int x_end         = x_begin + CLAHE_CHUNK;
     if (x_end > g.w) x_end = g.w;
-    // tile-column range touched by this chunk
-    int c_lo = (int) floorf(x_begin * g.inv_tw - 0.5f);
-    int c_hi = (int) floorf((x_end - 1) * g.inv_tw - 0.5f) + 1;
-    if (c_lo < 0) c_lo = 0;
-    if (c_hi > T - 1) c_hi = T - 1;
-    const int ncols = c_hi - c_lo + 1; // <= CLAHE_MAXCOLS by construction of the launch (checked on host)
+    // pair range touched by this chunk: p = floor(x*inv_tw - 0.5) + 1
+    const int p_lo   = (int) floorf(x_begin * g.inv_tw - 0.5f) + 1;
+    const int p_hi   = (int) floorf((x_end - 1) * g.inv_tw - 0.5f) + 1;
+    const int npairs = p_hi - p_lo + 1; // <= CLAHE_MAXCOLS by construction of the launch (checked on host)
 
-    const uint8_t *blut = lut + (size_t) b * T * T * 256;
-    for (int i = t; i < 2 * ncols * 256; i += 256) {
-        int r   = i / (ncols * 256);
-        int rem = i - r * ncols * 256;
-        int c   = rem >> 8;
-        int v   = rem & 255;
-        slut[r][c][v] = blut[((size_t) (r == 0 ? ty1 : ty2) * T + (c_lo + c)) * 256 + v];
+    const unsigned int *blut = reinterpret_cast<const unsigned int *>(lut + (size_t) b * T * T * 256);
+    for (int i = t; i < npairs * 64; i += 256) {
+        const int p = p_lo + (i >> 6), v4 = i & 63;
+        int c1 = p - 1, c2 = p;
+        if (c1 < 0) c1 = 0;
+        if (c2 > T - 1) c2 = T - 1;
+        const unsigned int A = blut[(ty1 * T + c1) * 64 + v4], B = blut[(ty1 * T + c2) * 64 + v4];
+        const unsigned int C = blut[(ty2 * T + c1) * 64 + v4], D = blut[(ty2 * T + c2) * 64 + v4];
+        // transpose 4 LUT dwords (4 consecutive grey levels each) into 4 per-level entries
+        const unsigned int ab01 = __builtin_amdgcn_perm(B, A, 0x05010400u), ab23 = __builtin_amdgcn_perm(B, A, 0x07030602u);
+        const unsigned int cd01 = __builtin_amdgcn_perm(D, C, 0x05010400u), cd23 = __builtin_amdgcn_perm(D, C, 0x07030602u);
+        uint4 e;
+        e.x = __builtin_amdgcn_perm(cd01, ab01, 0x05040100u);
+        e.y = __builtin_amdgcn_perm(cd01, ab01, 0x07060302u);
+        e.z = __builtin_amdgcn_perm(cd23, ab23, 0x05040100u);
+        e.w = __builtin_amdgcn_perm(cd23, ab23, 0x07060302u);
+        reinterpret_cast<uint4 *>(slut)[i] = e;
     }
     __syncthreads();
 
     const int wave = t >> 6, lane = t & 63;
     const int x0 = x_begin + lane * 4;
-    int c1[4], c2[4];
+    int pofs[4];
     float xa[4], xa1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        int x     = x0 + k;
-        float txf = x * g.inv_tw - 0.5f;
-        int tx1   = (int) floorf(txf);
-        int tx2   = tx1 + 1;
-        xa[k]     = txf - tx1;
-        xa1[k]    = 1.0f - xa[k];
-        if (tx1 < 0) tx1 = 0;
-        if (tx2 > T - 1) tx2 = T - 1;
-        c1[k] = tx1 - c_lo;
-        c2[k] = tx2 - c_lo;
-        if (c1[k] < 0) c1[k] = 0;
-        if (c2[k] > ncols - 1) c2[k] = ncols - 1;
-        if (c1[k] > ncols - 1) c1[k] = ncols - 1;
+        const int x     = x0 + k;
+        const float txf = x * g.inv_tw - 0.5f;
+        const int tx1   = (int) floorf(txf);
+        xa[k]           = txf - tx1;
+        xa1[k]          = 1.0f - xa[k];
+        int p           = tx1 + 1 - p_lo;
+        p               = p < 0 ? 0 : (p > npairs - 1 ? npairs - 1 : p); // only lanes beyond the image clamp
+        pofs[k]         = p << 8;
     }
     if (x0 >= g.w) return;
 
@@ -182,24 +232,32 @@ __global__ __launch_bounds__(256) void k_clahe_apply(pre_jobs jobs, clahe_geom g
     const uint8_t *src = jobs.src[b];
     const int stride   = jobs.stride;
     uint8_t *dst       = frames + (size_t) jobs.slot[b] * slot_bytes;
+    const f32x2 XA01 = {xa[0], xa[1]}, XA23 = {xa[2], xa[3]}, XB01 = {xa1[0], xa1[1]}, XB23 = {xa1[2], xa1[3]};
     for (int y = y_lo + wave; y < y_hi; y += 4) {
-        float tyf = y * g.inv_th - 0.5f;
-        int tyr   = (int) floorf(tyf);
+        const float tyf = y * g.inv_th - 0.5f;
+        const int tyr   = (int) floorf(tyf);
         if (tyr != strip - 1) continue;
-        float ya = tyf - tyr, ya1 = 1.0f - ya;
-        uchar4 p = *reinterpret_cast<const uchar4 *>(src + (size_t) y * stride + x0);
-        unsigned char in[4] = {p.x, p.y, p.z, p.w};
-        unsigned char out[4];
+        const float ya = tyf - tyr, ya1 = 1.0f - ya;
+        const unsigned int pin = *reinterpret_cast<const unsigned int *>(src + (size_t) y * stride + x0);
+        const unsigned int e0 = slut[pofs[0] + (pin & 0xff)], e1 = slut[pofs[1] + ((pin >> 8) & 0xff)];
+        const unsigned int e2 = slut[pofs[2] + ((pin >> 16) & 0xff)], e3 = slut[pofs[3] + (pin >> 24)];
+#define CL_B(e, k) ((float) (((e) >> (8 * (k))) & 0xffu))
+        const f32x2 A01 = {CL_B(e0, 0), CL_B(e1, 0)}, B01 = {CL_B(e0, 1), CL_B(e1, 1)};
+        const f32x2 C01 = {CL_B(e0, 2), CL_B(e1, 2)}, D01 = {CL_B(e0, 3), CL_B(e1, 3)};
+        const f32x2 A23 = {CL_B(e2, 0), CL_B(e3, 0)}, B23 = {CL_B(e2, 1), CL_B(e3, 1)};
+        const f32x2 C23 = {CL_B(e2, 2), CL_B(e3, 2)}, D23 = {CL_B(e2, 3), CL_B(e3, 3)};
+#undef CL_B
+        // (l11*xa1 + l12*xa)*ya1 + (l21*xa1 + l22*xa)*ya — OpenCV's association order, no contraction
+        const f32x2 r01 = (A01 * XB01 + B01 * XA01) * ya1 + (C01 * XB01 + D01 * XA01) * ya;
+        const f32x2 r23 = (A23 * XB23 + B23 * XA23) * ya1 + (C23 * XB23 + D23 * XA23) * ya;
+        const float res[4] = {r01.x, r01.y, r23.x, r23.y};
+        unsigned int pout = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            int v     = in[k];
-            float l11 = slut[0][c1[k]][v], l12 = slut[0][c2[k]][v];
-            float l21 = slut[1][c1[k]][v], l22 = slut[1][c2[k]][v];
-            float res = (l11 * xa1[k] + l12 * xa[k]) * ya1 + (l21 * xa1[k] + l22 * xa[k]) * ya;
-            int iv    = (int) rintf(res);
-            out[k]    = (unsigned char) (iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+            const int iv = (int) rintf(res[k]);
+            pout |= (unsigned int) (iv < 0 ? 0 : (iv > 255 ? 255 : iv)) << (8 * k);
         }
-        *reinterpret_cast<uchar4 *>(dst + (size_t) y * dpitch + x0) = make_uchar4(out[0], out[1], out[2], out[3]);
+        *reinterpret_cast<unsigned int *>(dst + (size_t) y * dpitch + x0) = pout;
     }
 }
 
@@ -241,6 +299,119 @@ __global__ __launch_bounds__(256) void k_pyrdown(uint8_t *frames, size_t slot_by
             d[(size_t) y * dpitch + x] = (uint8_t) ((v + 128) >> 8);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused 3-step pyramid (the common 4-level case): one workgroup owns a 16x8 tile of level 3 and everything below it
+// (32x16 of level 2, 64x32 of level 1); the 164x85 level-0 neighbourhood is staged once as dwords and the three
+// pyrDown steps run LDS -> LDS, so level 0 is read ~1.7x (mostly L2 hits) instead of the per-level kernels' three
+// dependent launches.  Exact integers throughout: the horizontal [1 4 6 4 1] sums (<= 4080) are kept as packed u16
+// pairs and the vertical pass is plain 32-bit SWAR arithmetic on those pairs (<= 65408 per field: no cross-field carry).
+//
+// Region geometry, columns chosen so that every level's OWNED columns start on a dword of both its LDS tile and its
+// image row (X3 = 16*blockIdx.x, Y3 = 8*blockIdx.y):
+//   level 3 tile  16 x 8    x3 = X3 + c            y3 = Y3 + r
+//   level 2 tile  40 x 19   x2 = 2*X3 - 4 + c      y2 = 2*Y3 - 2 + r    (owned: c 4..35, r 2..17)
+//   level 1 tile  80 x 41   x1 = 4*X3 - 12 + c     y1 = 4*Y3 - 6 + r    (owned: c 12..75, r 6..37)
+//   level 0 tile 168 x 85   x0 = 8*X3 - 28 + c     y0 = 8*Y3 - 14 + r
+// so output column j of a step reads input columns 2j+2 .. 2j+6 (D = 2) and output row i reads input rows 2i .. 2i+4.
+// Tile entries that fall outside their level's image are replaced by their reflect-101 partner before the next step
+// (pyrDown's BORDER_REFLECT_101 applies to each level's own image).
+#define P3_L0S 168
+#define P3_L0H 85
+#define P3_L1S 88
+#define P3_L1W 80
+#define P3_L1H 41
+#define P3_L2S 40
+#define P3_L2H 19
+
+__device__ __forceinline__ unsigned int p3_load4(const uint8_t *row, int x, int w) {
+    if (x >= 0 && x + 3 < w) return *reinterpret_cast<const unsigned int *>(row + x); // x % 4 == 0 by construction
+    unsigned int v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v |= (unsigned int) row[icg_reflect101(x + k, w)] << (8 * k);
+    return v;
+}
+
+template <int IH, int IS, int OH, int OS, int OWQ>
+__device__ __forceinline__ void p3_step(const unsigned int *in, unsigned int *tmp, unsigned int *out, int t, uint8_t *dst,
+                                        int dpitch, int dw, int dh, int gx0, int gy0, int own_q0, int own_q1, int own_r0,
+                                        int own_r1) {
+    constexpr int TS = 2 * OWQ; // packed pairs per tmp row
+    static_assert(IS % 4 == 0 && IS / 4 >= TS + 2, "input tile too narrow");
+    static_assert(IH >= 2 * OH + 3 && OS % 4 == 0 && OS / 4 >= OWQ, "tile geometry");
+    // horizontal [1 4 6 4 1] at even input columns: pair m = output columns 2m, 2m+1 <- input bytes 4m+2 .. 4m+8
+    for (int i = t; i < IH * TS; i += 256) {
+        const int r = i / TS, m = i - r * TS;
+        const unsigned int *p = in + r * (IS / 4) + m;
+        const unsigned int d0 = p[0], d1 = p[1], d2 = p[2];
+        const unsigned int lo = __builtin_amdgcn_alignbyte(d1, d0, 2), hi = __builtin_amdgcn_alignbyte(d2, d1, 2);
+        const unsigned int p0 = lo & 0xff, p1 = (lo >> 8) & 0xff, p2 = (lo >> 16) & 0xff, p3 = lo >> 24;
+        const unsigned int p4 = hi & 0xff, p5 = (hi >> 8) & 0xff, p6 = (hi >> 16) & 0xff;
+        const unsigned int h0 = p0 + p4 + 4 * (p1 + p3) + 6 * p2;
+        const unsigned int h1 = p2 + p6 + 4 * (p3 + p5) + 6 * p4;
+        tmp[i] = h0 | (h1 << 16);
+    }
+    __syncthreads();
+    // vertical pass on packed pairs, 4 output columns per item; (v + 128) >> 8 as in OpenCV's u8 pyrDown
+    for (int i = t; i < OH * OWQ; i += 256) {
+        const int r = i / OWQ, q = i - r * OWQ;
+        const uint2 *c = reinterpret_cast<const uint2 *>(tmp + (2 * r) * TS + 2 * q);
+        const uint2 t0 = c[0], t1 = c[TS / 2], t2 = c[TS], t3 = c[3 * TS / 2], t4 = c[2 * TS];
+        const unsigned int a = t0.x + t4.x + ((t1.x + t3.x) << 2) + (t2.x << 2) + (t2.x << 1) + 0x00800080u;
+        const unsigned int b = t0.y + t4.y + ((t1.y + t3.y) << 2) + (t2.y << 2) + (t2.y << 1) + 0x00800080u;
+        const unsigned int v = __builtin_amdgcn_perm(b >> 8, a >> 8, 0x06040200u);
+        out[r * (OS / 4) + q] = v;
+        const int x = gx0 + 4 * q, y = gy0 + r;
+        if (q >= own_q0 && q < own_q1 && r >= own_r0 && r < own_r1 && x < dw && y < dh)
+            *reinterpret_cast<unsigned int *>(dst + (size_t) y * dpitch + x) = v; // row padding (pitch % 128 == 0) absorbs x+3 >= dw
+    }
+    __syncthreads();
+}
+
+template <int OH, int OS, int OW>
+__device__ __forceinline__ void p3_reflect_fix(unsigned int *tile32, int t, int gx0, int gy0, int dw, int dh) {
+    if (gx0 >= 0 && gy0 >= 0 && gx0 + OW <= dw && gy0 + OH <= dh) return; // workgroup-uniform
+    uint8_t *tile = reinterpret_cast<uint8_t *>(tile32);
+    for (int i = t; i < OH * OW; i += 256) {
+        const int r = i / OW, c = i - r * OW;
+        const int x = gx0 + c, y = gy0 + r;
+        if (x < 0 || x >= dw || y < 0 || y >= dh) {
+            const int rx = icg_reflect101(x, dw) - gx0, ry = icg_reflect101(y, dh) - gy0;
+            // a partner outside the tile is only ever needed by entries that are themselves out of range one level up
+            tile[r * OS + c] = (rx >= 0 && rx < OW && ry >= 0 && ry < OH) ? tile[ry * OS + rx] : (uint8_t) 0;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_pyramid3(icg_pyr_desc P, pre_jobs jobs) {
+    __shared__ __attribute__((aligned(16))) unsigned int L0[P3_L0H * P3_L0S / 4];
+    __shared__ __attribute__((aligned(16))) unsigned int TMP[P3_L0H * (P3_L1W / 2)];
+    __shared__ __attribute__((aligned(16))) unsigned int L1[P3_L1H * P3_L1S / 4];
+    __shared__ __attribute__((aligned(16))) unsigned int L2[P3_L2H * P3_L2S / 4];
+    __shared__ __attribute__((aligned(16))) unsigned int L3[8 * 16 / 4];
+    const int t   = threadIdx.x;
+    uint8_t *slot = P.base + (size_t) jobs.slot[blockIdx.z] * P.slot_bytes;
+    const int X3 = blockIdx.x * 16, Y3 = blockIdx.y * 8;
+
+    {
+        const uint8_t *s = slot + P.off[0];
+        const int w = P.w[0], h = P.h[0], pitch = P.pitch[0];
+        const int x0 = 8 * X3 - 28, y0 = 8 * Y3 - 14;
+        for (int i = t; i < P3_L0H * (P3_L0S / 4); i += 256) {
+            const int r = i / (P3_L0S / 4), d = i - r * (P3_L0S / 4);
+            L0[i] = p3_load4(s + (size_t) icg_reflect101(y0 + r, h) * pitch, x0 + 4 * d, w);
+        }
+        __syncthreads();
+    }
+    p3_step<P3_L0H, P3_L0S, P3_L1H, P3_L1S, P3_L1W / 4>(L0, TMP, L1, t, slot + P.off[1], P.pitch[1], P.w[1], P.h[1], 4 * X3 - 12,
+                                                       4 * Y3 - 6, 3, 19, 6, 38);
+    p3_reflect_fix<P3_L1H, P3_L1S, P3_L1W>(L1, t, 4 * X3 - 12, 4 * Y3 - 6, P.w[1], P.h[1]);
+    p3_step<P3_L1H, P3_L1S, P3_L2H, P3_L2S, P3_L2S / 4>(L1, TMP, L2, t, slot + P.off[2], P.pitch[2], P.w[2], P.h[2], 2 * X3 - 4,
+                                                       2 * Y3 - 2, 1, 9, 2, 18);
+    p3_reflect_fix<P3_L2H, P3_L2S, P3_L2S>(L2, t, 2 * X3 - 4, 2 * Y3 - 2, P.w[2], P.h[2]);
+    p3_step<P3_L2H, P3_L2S, 8, 16, 4>(L2, TMP, L3, t, slot + P.off[3], P.pitch[3], P.w[3], P.h[3], X3, Y3, 0, 4, 0, 8);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -328,19 +499,25 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
         uint8_t *lut = ctx->d_lut + (size_t) base * T * T * 256;
         {
             icg_prof_scope ps(ctx, "clahe_lut");
-            hipLaunchKernelGGL(k_clahe_lut, dim3(T * T, m), dim3(256), 0, ctx->stream, jobs, g, lut);
+            hipLaunchKernelGGL(k_clahe_lut, dim3(T * T, m), dim3(64), 0, ctx->stream, jobs, g, lut);
         }
         {
             icg_prof_scope ps(ctx, "clahe_apply");
             hipLaunchKernelGGL(k_clahe_apply, dim3(T + 1, (w + CLAHE_CHUNK - 1) / CLAHE_CHUNK, m), dim3(256), 0, ctx->stream, jobs,
                                g, lut, ctx->d_frames, ctx->slot_bytes, ctx->lv[0].pitch);
         }
-        for (int l = 1; l < ctx->n_levels; l++) {
-            icg_prof_scope ps(ctx, "pyrdown");
-            const icg_level &a = ctx->lv[l - 1], &bb = ctx->lv[l];
-            hipLaunchKernelGGL(k_pyrdown, dim3((bb.w + PD_TW - 1) / PD_TW, (bb.h + PD_TH - 1) / PD_TH, m), dim3(256), 0,
-                               ctx->stream, ctx->d_frames, ctx->slot_bytes, jobs, (unsigned int) a.off, a.w, a.h, a.pitch,
-                               (unsigned int) bb.off, bb.w, bb.h, bb.pitch);
+        if (ctx->n_levels == 4) {
+            icg_prof_scope ps(ctx, "pyramid3");
+            hipLaunchKernelGGL(k_pyramid3, dim3((ctx->lv[3].w + 15) / 16, (ctx->lv[3].h + 7) / 8, m), dim3(256), 0, ctx->stream,
+                               icg_make_pyr_desc(ctx), jobs);
+        } else {
+            for (int l = 1; l < ctx->n_levels; l++) {
+                icg_prof_scope ps(ctx, "pyrdown");
+                const icg_level &a = ctx->lv[l - 1], &bb = ctx->lv[l];
+                hipLaunchKernelGGL(k_pyrdown, dim3((bb.w + PD_TW - 1) / PD_TW, (bb.h + PD_TH - 1) / PD_TH, m), dim3(256), 0,
+                                   ctx->stream, ctx->d_frames, ctx->slot_bytes, jobs, (unsigned int) a.off, a.w, a.h, a.pitch,
+                                   (unsigned int) bb.off, bb.w, bb.h, bb.pitch);
+            }
         }
     }
     ICG_HIP(ctx, hipGetLastError());
