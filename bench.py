@@ -24,7 +24,7 @@ import numpy as np
 
 # Each stream group owns a HIP stream; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of
 # streams that share a queue serialise.  8 queues measured best on MI355X for 16 groups.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ic-gvins_amd"))
@@ -86,13 +86,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("ICG_BENCH_STREAMS", "128")), help="camera streams per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("ICG_BENCH_STREAMS", "256")), help="camera streams per GPU")
     ap.add_argument("--ring", type=int, default=64, help="rendered frames per stream (ping-pong replay)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--features", type=int, default=300)
     ap.add_argument("--host-threads", type=int, default=1, help="host threads inside each group")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("ICG_BENCH_GROUPS", "16")),
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("ICG_BENCH_GROUPS", "32")),
                     help="stream groups per GPU (own HIP stream + host thread each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproj", action="store_true")
@@ -173,15 +173,27 @@ def main():
     prep = prepare_steps(k, args.steps)
     barrier()
     sb.timing(reset=True)
+    if os.environ.get("ICG_HOST_PROF"):
+        _hp = np.zeros(64, np.float64)
+        sb.lib.icgh_hostprof(_hp.ctypes.data_as(C.c_void_p), 32, None, 0, 1)
     tracked_before = sum(sb.stats(s)["tracked_sum"] for s in range(B))
+    c0 = time.process_time()
     t0 = time.perf_counter()
     st = run_prepared(args.steps, prep)  # EXACTLY args.steps lock-step frames for every stream
     k += args.steps
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    cpu_cores_used = (time.process_time() - c0) / elapsed  # host cores busy during the timed region (all threads)
     states_hist = np.bincount(st.ravel(), minlength=5).astype(np.int64)
+    if os.environ.get("ICG_HOST_PROF") and rank == 0:  # diagnostic: host-layer section timers, us per frame, to stderr
+        _nm = C.create_string_buffer(1024)
+        _n = sb.lib.icgh_hostprof(_hp.ctypes.data_as(C.c_void_p), 32, _nm, 1024, 0)
+        for _k, _name in enumerate(_nm.value.decode().split(";")[:_n]):
+            print(f"[hostprof] {_name:16s} {1e6 * _hp[2 * _k] / (B * args.steps):9.2f} us/frame  calls/frame "
+                  f"{_hp[2 * _k + 1] / (B * args.steps):.3f}", file=sys.stderr)
     tg = sb.timing_groups().sum(1) * 1e3 / args.steps  # per-group in-step wall time, ms per step
     host_breakdown = {k: round(1e3 * v / args.steps, 4) for k, v in sb.timing().items()}
+    host_breakdown["cpu_cores_busy"] = round(cpu_cores_used, 2)
     host_breakdown["group_step_ms_min_mean_max"] = [round(float(tg.min()), 3), round(float(tg.mean()), 3), round(float(tg.max()), 3)]
     barrier()
 

@@ -1,6 +1,9 @@
 // Context, memory arenas and per-kernel HIP-event profiling for libicgvins_hip.so.
 #include <cstdarg>
 
+#include <sys/prctl.h>
+#include <time.h>
+
 #include "icg_internal.h"
 
 int icg_fail(icg_ctx *ctx, int code, const char *fmt, ...) {
@@ -23,6 +26,31 @@ static thread_local std::string g_create_error;
 extern "C" const char *icg_version(void) { return "icgvins-hip 0.1 (gfx950)"; }
 
 extern "C" const char *icg_last_error(const icg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+// Completion wait that does not occupy a host core: hipStreamSynchronize (and blocking events) busy-wait on this stack,
+// which starves other contexts' threads when there are more contexts than cores.  Query a few times back to back (short
+// kernels), then sleep between queries with a tight timer slack.
+int icg_stream_wait_poll(icg_ctx *ctx) {
+    static thread_local bool slack_set = false;
+    if (!slack_set) {
+        (void) prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+        slack_set = true;
+    }
+    struct timespec ts = {0, ctx->poll_sleep_ns};
+    for (int it = 0;; it++) {
+        hipError_t e = hipStreamQuery(ctx->stream);
+        if (e == hipSuccess) return ICG_OK;
+        if (e != hipErrorNotReady) return icg_hip_check(ctx, e, "hipStreamQuery");
+        if (it >= 4) nanosleep(&ts, nullptr);
+    }
+}
+
+extern "C" int icg_ctx_set_wait_mode(icg_ctx *ctx, int mode, int sleep_us) {
+    if (!ctx || (mode != ICG_WAIT_SPIN && mode != ICG_WAIT_POLL) || (mode == ICG_WAIT_POLL && sleep_us <= 0)) return ICG_ERR_INVALID;
+    if (ctx->wait_mode_env) return ICG_OK; // ICG_WAIT_MODE wins
+    ctx->poll_sleep_ns = mode == ICG_WAIT_POLL ? 1000L * sleep_us : 0;
+    return ICG_OK;
+}
 
 icg_pyr_desc icg_make_pyr_desc(const icg_ctx *ctx) {
     icg_pyr_desc d{};
@@ -61,6 +89,15 @@ extern "C" int icg_ctx_create(const icg_ctx_config *cfg, icg_ctx **out) {
     if ((rc = icg_hip_check(ctx, hipSetDevice(cfg->device), "hipSetDevice"))) return bail(rc);
     if ((rc = icg_hip_check(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate")))
         return bail(rc);
+
+    {
+        const char *wm = getenv("ICG_WAIT_MODE");
+        if (wm && strncmp(wm, "poll", 4) == 0) ctx->poll_sleep_ns = (wm[4] == ':' ? atol(wm + 5) : 20) * 1000L;
+        ctx->wait_mode_env = wm != nullptr;
+        if (wm && strcmp(wm, "block") == 0 &&
+            (rc = icg_hip_check(ctx, hipEventCreateWithFlags(&ctx->ev_wait, hipEventBlockingSync | hipEventDisableTiming), "hipEventCreate")))
+            return bail(rc);
+    }
 
     // pyramid geometry: SURVEY.md Appendix B.3 — level l is ((w+1)/2, (h+1)/2); stop when <= win.
     int w = cfg->width, h = cfg->height;
@@ -103,6 +140,7 @@ extern "C" void icg_ctx_destroy(icg_ctx *ctx) {
     (void) hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     for (auto e : ctx->ev_pool) (void) hipEventDestroy(e);
+    if (ctx->ev_wait) (void) hipEventDestroy(ctx->ev_wait);
     void *dev[] = {ctx->d_frames, ctx->d_raw,     ctx->d_bgr,  ctx->d_lut,      ctx->d_histmean, ctx->d_eig,
                    ctx->d_mask,   ctx->d_roi_max, ctx->d_cand, ctx->d_cand_cnt, ctx->d_arena,    ctx->d_obs,
                    ctx->d_fidx,   ctx->d_rJ,      ctx->d_params};

@@ -30,6 +30,11 @@ struct icg_ctx {
     icg_ctx_config cfg{};
     hipStream_t stream = nullptr;
     std::string err;
+    // completion wait of a call: spin on the stream (lowest latency) or sleep on a blocking event (frees the host core for
+    // other contexts' threads; ICG_WAIT_MODE=block)
+    hipEvent_t ev_wait = nullptr;
+    bool wait_mode_env = false;
+    long poll_sleep_ns = 0; // > 0: query the stream and sleep in between (ICG_WAIT_MODE=poll[:<us>])
 
     // frame slots: CLAHE image + LK pyramid, u8, per-level pitch
     int n_levels = 0;
@@ -129,6 +134,17 @@ __host__ __device__ static inline int icg_reflect101(int i, int n) {
     return i;
 }
 
+int icg_stream_wait_poll(icg_ctx *ctx);
+static inline int icg_stream_wait(icg_ctx *ctx) {
+    if (ctx->poll_sleep_ns > 0) return icg_stream_wait_poll(ctx);
+    if (ctx->ev_wait) {
+        int rc = icg_hip_check(ctx, hipEventRecord(ctx->ev_wait, ctx->stream), "hipEventRecord");
+        if (rc) return rc;
+        return icg_hip_check(ctx, hipEventSynchronize(ctx->ev_wait), "hipEventSynchronize");
+    }
+    return icg_hip_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+}
+
 // Per-call staging helper.  The arena is pinned host memory that the GPU can address directly (hipHostMalloc), mirrored
 // by a device arena at the same offsets:
 //   in()/out()       mirrored: ONE H2D copy at seal(), ONE D2H copy at finish() — for data many workgroups re-read
@@ -178,7 +194,7 @@ struct icg_call {
             }
         if (hi > lo) rc = icg_arena_d2h(ctx, lo, hi);
         if (rc) return rc;
-        rc = icg_hip_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        rc = icg_stream_wait(ctx);
         if (rc) return rc;
         icg_prof_collect(ctx);
         for (auto &o : outs) memcpy(o.user, ctx->h_arena + o.off, o.bytes);

@@ -5,6 +5,7 @@
 #include <stdexcept>
 
 #include "tracking_batch.h"
+#include "hostprof.h"
 
 using namespace icg;
 
@@ -125,6 +126,24 @@ int icgh_batch_timing_group(icgh_batch *b, int g, double *out5) {
     if (!b || g < 0 || g >= b->tb->groups()) return -1;
     for (int i = 0; i < 5; i++) out5[i] = b->tb->group(g).timing[i];
     return 0;
+}
+
+// section timers of the host layer (ICG_HOST_PROF=1): out[2k] = seconds, out[2k+1] = calls; names are ';'-separated
+int icgh_hostprof(double *out, int max_sections, char *names, int names_len, int reset) {
+    int n = std::min(max_sections, (int) icg::hostprof::N_SECTIONS);
+    std::string nm;
+    for (int k = 0; k < n; k++) {
+        out[2 * k]     = 1e-9 * (double) icg::hostprof::ns()[k].load();
+        out[2 * k + 1] = (double) icg::hostprof::calls()[k].load();
+        nm += icg::hostprof::name(k);
+        nm += ';';
+        if (reset) {
+            icg::hostprof::ns()[k]    = 0;
+            icg::hostprof::calls()[k] = 0;
+        }
+    }
+    if (names && names_len > 0) snprintf(names, (size_t) names_len, "%s", nm.c_str());
+    return n;
 }
 
 // features of the stream's current frame, sorted by map-point id: ids[k], px[2k..2k+1] (distorted keypoint)

@@ -1,0 +1,52 @@
+// Section timers for the host layer (enabled with ICG_HOST_PROF=1; two clock reads per section otherwise skipped).
+// Accumulators are process-wide atomics: sections are coarse (per stream per stage), so contention is negligible.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdlib>
+
+namespace icg {
+namespace hostprof {
+
+enum Section {
+    BEGIN_FRAME = 0, ON_PREPROCESS, ON_DETECT_A, ON_LK, ON_RANSAC, ON_TRIANGULATE, ON_DETECT_B, DIGEST, KEEPER,
+    DEV_PREPROCESS, DEV_DETECT, DEV_LK, DEV_RANSAC, DEV_TRIANGULATE, GATHER, SCATTER, X0, X1, X2, X3, X4, X5, X6, X7, N_SECTIONS
+};
+
+inline std::atomic<uint64_t> *ns() {
+    static std::atomic<uint64_t> a[N_SECTIONS];
+    return a;
+}
+inline std::atomic<uint64_t> *calls() {
+    static std::atomic<uint64_t> a[N_SECTIONS];
+    return a;
+}
+inline bool enabled() {
+    static const bool on = getenv("ICG_HOST_PROF") != nullptr;
+    return on;
+}
+inline uint64_t now_ns() {
+    return (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct Scope {
+    int id;
+    uint64_t t0;
+    explicit Scope(int s) : id(s), t0(enabled() ? now_ns() : 0) {}
+    ~Scope() {
+        if (t0) {
+            ns()[id].fetch_add(now_ns() - t0, std::memory_order_relaxed);
+            calls()[id].fetch_add(1, std::memory_order_relaxed);
+        }
+    }
+};
+inline const char *name(int s) {
+    static const char *n[N_SECTIONS] = {"begin_frame", "on_preprocess", "on_detect_a", "on_lk", "on_ransac", "on_triangulate",
+                                        "on_detect_b", "digest", "keeper", "dev_preprocess", "dev_detect", "dev_lk",
+                                        "dev_ransac", "dev_triangulate", "gather", "scatter", "x0", "x1", "x2", "x3", "x4",
+                                        "x5", "x6", "x7"};
+    return n[s];
+}
+
+} // namespace hostprof
+} // namespace icg

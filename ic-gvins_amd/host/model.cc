@@ -113,7 +113,7 @@ Frame::Ptr Frame::createFrame(double stamp, const Mat &image, const std::shared_
 }
 
 void Frame::setKeyFrame(int state) {
-    std::unique_lock<std::mutex> lock(frame_mutex_);
+    ModelLock lock(frame_mutex_);
     if (!iskeyframe_) {
         iskeyframe_     = true;
         keyframe_id_    = ids_->keyframe_id++;
@@ -127,6 +127,7 @@ MapPoint::MapPoint(ulong id, const std::shared_ptr<Frame> &ref_frame, Vector3d p
     : pos_(pos), depth_(depth), ref_frame_keypoint_(keypoint), ref_frame_(ref_frame), optimized_times_(0), used_times_(0),
       observed_times_(0), isoutlier_(false), id_(id), mappoint_type_(type) {
     if ((depth_ < NEAREST_DEPTH) || (depth_ > FARTHEST_DEPTH)) depth_ = DEFAULT_DEPTH;
+    observations_.reserve(16); // one observation per tracked frame: skip the 1-2-4-8 reallocation ladder
 }
 
 MapPoint::Ptr MapPoint::createMapPoint(std::shared_ptr<Frame> &ref_frame, Vector3d &pos, Point2f &feature, double depth,
@@ -135,14 +136,14 @@ MapPoint::Ptr MapPoint::createMapPoint(std::shared_ptr<Frame> &ref_frame, Vector
 }
 
 void MapPoint::addObservation(const Feature::Ptr &feature) {
-    std::unique_lock<std::mutex> lock(mappoint_mutex_);
+    ModelLock lock(mappoint_mutex_);
     observations_.push_back(feature);
     observed_times_++;
 }
 
 void MapPoint::setReferenceFrame(const std::shared_ptr<Frame> &frame, Vector3d pos, Point2f keypoint, double depth,
                                  MapPointType type) {
-    std::unique_lock<std::mutex> lock(mappoint_mutex_);
+    ModelLock lock(mappoint_mutex_);
     depth_tmp_ = depth;
     if (depth_tmp_ < 1.0) depth_tmp_ = DEFAULT_DEPTH;
     pos_tmp_                = pos;
@@ -153,14 +154,14 @@ void MapPoint::setReferenceFrame(const std::shared_ptr<Frame> &frame, Vector3d p
 }
 
 ulong MapPoint::referenceFrameId() {
-    std::unique_lock<std::mutex> lock(mappoint_mutex_);
+    ModelLock lock(mappoint_mutex_);
     auto frame = ref_frame_.lock();
     return frame ? frame->id() : 0;
 }
 
 // ---- Map (tracking/map.cc) -----------------------------------------------------------------------------------
 void Map::insertKeyFrame(const Frame::Ptr &frame) {
-    std::unique_lock<std::mutex> lock(map_mutex_);
+    ModelLock lock(map_mutex_);
     latest_keyframe_ = frame;
     if (keyframes_.find(frame->keyFrameId()) == keyframes_.end())
         keyframes_.insert(std::make_pair(frame->keyFrameId(), frame));
@@ -177,7 +178,7 @@ void Map::insertKeyFrame(const Frame::Ptr &frame) {
 }
 
 vector<ulong> Map::orderedKeyFrames() {
-    std::unique_lock<std::mutex> lock(map_mutex_);
+    ModelLock lock(map_mutex_);
     vector<ulong> keyframeid;
     for (auto &keyframe : keyframes_) keyframeid.push_back(keyframe.first);
     std::sort(keyframeid.begin(), keyframeid.end());
@@ -186,17 +187,17 @@ vector<ulong> Map::orderedKeyFrames() {
 
 Frame::Ptr Map::oldestKeyFrame() {
     auto ids = orderedKeyFrames();
-    std::unique_lock<std::mutex> lock(map_mutex_);
+    ModelLock lock(map_mutex_);
     return ids.empty() ? nullptr : keyframes_.at(ids[0]);
 }
 
 const Frame::Ptr &Map::latestKeyFrame() {
-    std::unique_lock<std::mutex> lock(map_mutex_);
+    ModelLock lock(map_mutex_);
     return latest_keyframe_;
 }
 
 void Map::removeMappoint(MapPoint::Ptr &mappoint) {
-    std::unique_lock<std::mutex> lock(map_mutex_);
+    ModelLock lock(map_mutex_);
     mappoint->setOutlier(true);
     mappoint->removeAllObservations();
     if (landmarks_.find(mappoint->id()) != landmarks_.end()) landmarks_.erase(mappoint->id());
@@ -204,10 +205,11 @@ void Map::removeMappoint(MapPoint::Ptr &mappoint) {
 }
 
 void Map::removeKeyFrame(Frame::Ptr &frame, bool isremovemappoint) {
-    std::unique_lock<std::mutex> lock(map_mutex_);
+    ModelLock lock(map_mutex_);
     if (isremovemappoint) {
         vector<ulong> mappointid;
-        auto features = frame->features();
+        Frame::FeatureList features;
+        frame->featureSnapshot(features);
         for (auto &feature : features) {
             auto mappoint = feature.second->getMapPoint();
             if (mappoint) {
@@ -234,7 +236,7 @@ void Map::removeKeyFrame(Frame::Ptr &frame, bool isremovemappoint) {
 }
 
 double Map::mappointObservedRate(const MapPoint::Ptr &mappoint) {
-    std::unique_lock<std::mutex> lock(map_mutex_);
+    ModelLock lock(map_mutex_);
     size_t num_keyframes = keyframes_.size();
     size_t num_observed  = 0;
     auto features        = mappoint->observations();

@@ -11,8 +11,10 @@
 // the reference's process-wide static counters.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -22,6 +24,32 @@
 namespace icg {
 
 using std::vector;
+
+// The reference guards every accessor of Frame / MapPoint / Map with a std::mutex (tracking vs optimisation thread).  The
+// critical sections are a handful of loads/stores and the front-end takes ~10 of them per feature per frame, so the same
+// protection is provided by a test-and-set lock (one atomic exchange to acquire, one store to release; yields under
+// contention) instead of a pthread mutex.
+class SpinLock {
+public:
+    void lock() {
+        int spins = 0;
+        while (flag_.exchange(true, std::memory_order_acquire)) {
+            while (flag_.load(std::memory_order_relaxed)) {
+                if (++spins > 64) {
+                    std::this_thread::yield();
+                    spins = 0;
+                } else
+                    __builtin_ia32_pause();
+            }
+        }
+    }
+    bool try_lock() { return !flag_.exchange(true, std::memory_order_acquire); }
+    void unlock() { flag_.store(false, std::memory_order_release); }
+
+private:
+    std::atomic<bool> flag_{false};
+};
+typedef std::lock_guard<SpinLock> ModelLock;
 
 struct IdSpace {
     ulong frame_id{0}, keyframe_id{0}, mappoint_id{0};
@@ -106,43 +134,57 @@ public:
     static Frame::Ptr createFrame(double stamp, const Mat &image, const std::shared_ptr<IdSpace> &ids = IdSpace::global());
     void setKeyFrame(int state);
     void resetKeyFrame() {
-        std::unique_lock<std::mutex> lock(frame_mutex_);
+        ModelLock lock(frame_mutex_);
         iskeyframe_     = false;
         keyframe_state_ = KEYFRAME_NONE;
     }
     Mat &image() { return image_; }
     Mat &rawImage() { return raw_image_; }
     Pose pose() {
-        std::unique_lock<std::mutex> lock(frame_mutex_);
+        ModelLock lock(frame_mutex_);
         return pose_;
     }
     void setPose(Pose pose) {
-        std::unique_lock<std::mutex> lock(frame_mutex_);
+        ModelLock lock(frame_mutex_);
         pose_ = pose;
     }
     std::unordered_map<ulong, Feature::Ptr> features() {
-        std::unique_lock<std::mutex> lock(frame_mutex_);
+        ModelLock lock(frame_mutex_);
         return features_;
     }
+    // the entries of features() in the same (container) order, without copying the hash table: the front-end walks a
+    // frame's features several times per frame and only needs a stable view of the shared_ptrs
+    typedef vector<std::pair<ulong, Feature::Ptr>> FeatureList;
+    void featureSnapshot(FeatureList &out) {
+        ModelLock lock(frame_mutex_);
+        out.clear();
+        out.reserve(features_.size());
+        for (const auto &kv : features_) out.emplace_back(kv.first, kv.second);
+    }
+    // bucket space for n more features up front (no incremental rehashing while a frame is being filled)
+    void reserveFeatures(size_t n) {
+        ModelLock lock(frame_mutex_);
+        features_.reserve(features_.size() + n);
+    }
     void clearFeatures() {
-        std::unique_lock<std::mutex> lock(frame_mutex_);
+        ModelLock lock(frame_mutex_);
         features_.clear();
         unupdated_mappoints_.clear();
     }
     size_t numFeatures() {
-        std::unique_lock<std::mutex> lock(frame_mutex_);
+        ModelLock lock(frame_mutex_);
         return features_.size();
     }
     const vector<std::shared_ptr<MapPoint>> &unupdatedMappoints() {
-        std::unique_lock<std::mutex> lock(frame_mutex_);
+        ModelLock lock(frame_mutex_);
         return unupdated_mappoints_;
     }
     void addNewUnupdatedMappoint(const std::shared_ptr<MapPoint> &mappoint) {
-        std::unique_lock<std::mutex> lock(frame_mutex_);
+        ModelLock lock(frame_mutex_);
         unupdated_mappoints_.push_back(mappoint);
     }
     void addFeature(ulong mappointid, const Feature::Ptr &feature) {
-        std::unique_lock<std::mutex> lock(frame_mutex_);
+        ModelLock lock(frame_mutex_);
         features_.insert(std::make_pair(mappointid, feature));
     }
     double stamp() const { return stamp_; }
@@ -153,11 +195,11 @@ public:
     ulong id() const { return id_; }
     ulong keyFrameId() const { return keyframe_id_; }
     void setKeyFrameState(int state) {
-        std::unique_lock<std::mutex> lock(frame_mutex_);
+        ModelLock lock(frame_mutex_);
         keyframe_state_ = state;
     }
     int keyFrameState() {
-        std::unique_lock<std::mutex> lock(frame_mutex_);
+        ModelLock lock(frame_mutex_);
         return keyframe_state_;
     }
     // device residency (new): slot of the CLAHE image + pyramid inside the stream's icg_ctx, -1 when not resident
@@ -166,7 +208,7 @@ public:
 
 private:
     int keyframe_state_{KEYFRAME_NORMAL};
-    std::mutex frame_mutex_;
+    SpinLock frame_mutex_;
     ulong id_, keyframe_id_;
     double stamp_;
     double td_{0};
@@ -199,89 +241,104 @@ public:
     static MapPoint::Ptr createMapPoint(std::shared_ptr<Frame> &ref_frame, Vector3d &pos, Point2f &keypoint, double depth,
                                         MapPointType type, const std::shared_ptr<IdSpace> &ids = IdSpace::global());
     Vector3d &pos() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         return pos_;
     }
     void setPos(const Vector3d &p) { // the optimizer's write-back path (ic_gvins.cc:1299)
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         pos_ = p;
     }
     int observedTimes() const { return observed_times_; }
     ulong id() const { return id_; }
     void addObservation(const Feature::Ptr &feature);
     void increaseUsedTimes() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         used_times_++;
     }
     void decreaseUsedTimes() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         if (used_times_) used_times_--;
     }
     int usedTimes() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         return used_times_;
     }
     void addOptimizedTimes() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         optimized_times_++;
     }
     int optimizedTimes() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         return optimized_times_;
     }
     void removeAllObservations() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         observations_.clear();
     }
     vector<std::weak_ptr<Feature>> observations() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         return observations_;
     }
     // observations().back() without copying the whole list (same result; the list grows with every tracked frame)
     bool lastObservation(std::shared_ptr<Feature> &out) {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         if (observations_.empty()) return false;
         out = observations_.back().lock();
         return true;
     }
+    // !isOutlier() together with lastObservation(), one critical section (parallaxFromReferenceMapPoints)
+    bool lastObservationUnlessOutlier(std::shared_ptr<Feature> &out) {
+        ModelLock lock(mappoint_mutex_);
+        if (isoutlier_ || observations_.empty()) return false;
+        out = observations_.back().lock();
+        return true;
+    }
+    // !isOutlier() together with pos() and mapPointType(), one critical section (trackMappoint's candidate scan)
+    bool trackingView(Vector3d &pos, MapPointType &type) {
+        ModelLock lock(mappoint_mutex_);
+        if (isoutlier_) return false;
+        pos  = pos_;
+        type = mappoint_type_;
+        return true;
+    }
     void setOutlier(bool isoutlier) {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         isoutlier_ = isoutlier;
     }
     bool isOutlier() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         return isoutlier_;
     }
     void setReferenceFrame(const std::shared_ptr<Frame> &frame, Vector3d pos, Point2f keypoint, double depth, MapPointType type);
     double depth() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         return depth_;
     }
     void updateDepth(double depth) {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         depth_ = depth;
     }
     ulong referenceFrameId();
     MapPointType &mapPointType() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         return mappoint_type_;
     }
     std::shared_ptr<Frame> referenceFrame() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         return ref_frame_.lock();
     }
     const Point2f &referenceKeypoint() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         return ref_frame_keypoint_;
     }
     bool isNeedUpdate() {
-        std::unique_lock<std::mutex> lock(mappoint_mutex_);
+        ModelLock lock(mappoint_mutex_);
         return isneedupdate_;
     }
 
 private:
     vector<std::weak_ptr<Feature>> observations_;
-    std::mutex mappoint_mutex_;
+    SpinLock mappoint_mutex_;
     bool isneedupdate_{false};
     Vector3d pos_, pos_tmp_;
     double depth_{DEFAULT_DEPTH}, depth_tmp_{DEFAULT_DEPTH};
@@ -312,24 +369,24 @@ public:
     void removeKeyFrame(Frame::Ptr &frame, bool isremovemappoint);
     double mappointObservedRate(const MapPoint::Ptr &mappoint);
     bool isMaximumKeframes() {
-        std::unique_lock<std::mutex> lock(map_mutex_);
+        ModelLock lock(map_mutex_);
         return keyframes_.size() > window_size_;
     }
     bool isKeyFrameInMap(const Frame::Ptr &frame) {
-        std::unique_lock<std::mutex> lock(map_mutex_);
+        ModelLock lock(map_mutex_);
         return keyframes_.find(frame->keyFrameId()) != keyframes_.end();
     }
     bool isWindowFull() {
-        std::unique_lock<std::mutex> lock(map_mutex_);
+        ModelLock lock(map_mutex_);
         return is_window_full_;
     }
     bool isWindowNormal() {
-        std::unique_lock<std::mutex> lock(map_mutex_);
+        ModelLock lock(map_mutex_);
         return keyframes_.size() == window_size_;
     }
 
 private:
-    std::mutex map_mutex_;
+    SpinLock map_mutex_;
     KeyFrames keyframes_;
     LandMarks landmarks_;
     Frame::Ptr latest_keyframe_;

@@ -149,6 +149,8 @@ private:
     int parallaxFromReferenceKeyPoints(const vector<Point2f> &ref, const vector<Point2f> &cur, double &parallax);
     int parallaxFromReferenceMapPoints(double &parallax);
     double keyPointParallax(const Point2f &pp0, const Point2f &pp1, const Pose &pose0, const Pose &pose1);
+    double keyPointParallax(const Point2f &pp0, const Point2f &pp1, const Matrix3d &R10); // R10 = pose1.R^T * pose0.R
+    void checkCarriedUndistortion(const char *where);
     bool isOnBorder(const Point2f &pts);
     template <typename T> static void reduceVector(T &vec, const vector<uint8_t> &status);
     void assignSlot(const Frame::Ptr &f);
@@ -168,6 +170,12 @@ private:
     std::shared_ptr<IdSpace> ids_;
 
     vector<Point2f> pts2d_cur_, pts2d_new_, pts2d_ref_;
+    // undistorted twins of pts2d_ref_ / pts2d_new_, carried through every reduceVector instead of re-running
+    // Camera::undistortPoints on unchanged points each frame (tracking.cc:469,520-524,542-544,712-713): a reference point
+    // is undistorted once when detected / re-anchored, and a tracked point's undistorted position comes back from the LK
+    // kernel (same iteration, bit-identical; ICG_HOST_CHECK=1 re-derives them on the host and compares)
+    vector<Point2f> pts2d_ref_undis_, pts2d_new_undis_;
+    Frame::FeatureList feat_snap_; // scratch for Frame::featureSnapshot
     vector<Frame::Ptr> pts2d_ref_frame_;
     vector<Vector2d> velocity_ref_, velocity_cur_;
     vector<MapPoint::Ptr> tracked_mappoint_, mappoint_matched_;

@@ -1,4 +1,5 @@
 #include "tracking_batch.h"
+#include "hostprof.h"
 
 #include <cstdlib>
 #include <stdexcept>
@@ -20,6 +21,7 @@ TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &in
         s.tracking = std::make_shared<Tracking>(s.camera, s.map, nullptr, cfg, "", device_, s.ids);
         s.keeper   = std::make_shared<WindowKeeper>(s.map);
     }
+    if (host_threads_ > 1 && n_streams > 1) pool_.reset(new HostPool(std::min(host_threads_, n_streams)));
     device_->setCamera(*streams_[0].camera);
     grid_        = streams_[0].tracking->grid();
     max_per_job_ = streams_[0].tracking->maxFeaturesPerJob();
@@ -27,23 +29,88 @@ TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &in
 
 template <typename F> void TrackingBatch::forEachStream(F &&f) {
     const int n = (int) streams_.size();
-    if (host_threads_ <= 1 || n < 2) {
+    if (!pool_ || n < 2) {
         for (int i = 0; i < n; i++) f(i);
         return;
     }
-    std::atomic<int> next{0};
-    auto worker = [&]() {
-        for (;;) {
-            int i = next.fetch_add(1);
-            if (i >= n) break;
-            f(i);
+    const std::function<void(int)> fn = std::ref(f);
+    pool_->parallelFor(n, fn);
+}
+
+// ---- HostPool -----------------------------------------------------------------------------------------------------------
+HostPool::HostPool(int n_threads) {
+    for (int t = 1; t < n_threads; t++) helpers_.emplace_back([this] { helperLoop(); });
+}
+
+HostPool::~HostPool() {
+    {
+        std::lock_guard<std::mutex> lock(m_);
+        stop_ = true;
+        gen_.fetch_add(1, std::memory_order_release);
+    }
+    cv_.notify_all();
+    for (auto &t : helpers_) t.join();
+}
+
+void HostPool::drain() {
+    for (;;) {
+        const int i = next_.fetch_add(1, std::memory_order_relaxed);
+        if (i >= n_) break;
+        try {
+            (*fn_)(i);
+        } catch (const std::exception &ex) {
+            std::lock_guard<std::mutex> lock(m_);
+            if (error_.empty()) error_ = ex.what();
         }
-    };
-    int nt = std::min(host_threads_, n);
-    vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(worker);
-    worker();
-    for (auto &t : th) t.join();
+    }
+}
+
+void HostPool::helperLoop() {
+    uint64_t seen = 0;
+    for (;;) {
+        int spins = 0;
+        while (gen_.load(std::memory_order_acquire) == seen) {
+            if (++spins < 20000) {
+                __builtin_ia32_pause();
+                continue;
+            }
+            std::unique_lock<std::mutex> lock(m_);
+            sleepers_.fetch_add(1);
+            cv_.wait(lock, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+            sleepers_.fetch_sub(1);
+        }
+        seen = gen_.load(std::memory_order_acquire);
+        if (stop_) return;
+        drain();
+        acks_.fetch_add(1, std::memory_order_release); // this helper no longer touches fn_/n_/next_ of this generation
+    }
+}
+
+// Full barrier per dispatch: returns only after every helper has left drain(), so fn_/n_/next_ are never rewritten
+// under a straggler.
+void HostPool::parallelFor(int n, const std::function<void(int)> &f) {
+    if (n <= 0) return;
+    fn_ = &f;
+    n_  = n;
+    next_.store(0, std::memory_order_relaxed);
+    acks_.store(0, std::memory_order_relaxed);
+    {
+        // the generation bump publishes fn_/n_/next_; taking the mutex orders it against helpers about to sleep
+        std::lock_guard<std::mutex> lock(m_);
+        gen_.fetch_add(1, std::memory_order_release);
+    }
+    if (sleepers_.load() > 0) cv_.notify_all();
+    drain();
+    const int helpers = (int) helpers_.size();
+    while (acks_.load(std::memory_order_acquire) < helpers) __builtin_ia32_pause();
+    if (!error_.empty()) {
+        std::string e;
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            e.swap(error_);
+        }
+        throw std::runtime_error(e);
+    }
 }
 
 template <typename T> static void append(vector<T> &dst, const vector<T> &src) { dst.insert(dst.end(), src.begin(), src.end()); }
@@ -153,6 +220,7 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
         s.box[1].clear();
         if (frames[(size_t) i]) {
             active[(size_t) i] = 1;
+            hostprof::Scope hp(hostprof::BEGIN_FRAME);
             s.tracking->beginFrame(frames[(size_t) i], s.box[0]);
         }
     });
@@ -179,7 +247,10 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
         forEachStream([&](int i) {
             Stream &s = streams_[(size_t) i];
             s.box[nxt].clear();
-            if (active[(size_t) i] && !s.tracking->frameDone()) s.tracking->advance(stage, s.box[cur], s.box[nxt]);
+            if (active[(size_t) i] && !s.tracking->frameDone()) {
+                hostprof::Scope hp(stage);
+                s.tracking->advance(stage, s.box[cur], s.box[nxt]);
+            }
         });
         for (int i = 0; i < n; i++)
             if (active[(size_t) i] && !streams_[(size_t) i].tracking->frameDone()) any = true;
@@ -200,17 +271,19 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
         // digest of everything index-like this frame produced: state, frame id, (map-point id, pixel bits) per feature
         // in id order, and the surviving un-triangulated reference points
         auto frame = frames[(size_t) i];
+        {
+        hostprof::Scope hpd(hostprof::DIGEST);
         int sti    = (int) st;
         fnv(s.digest, &sti, sizeof sti);
         ulong fid = frame->id();
         fnv(s.digest, &fid, sizeof fid);
         if (st != TRACK_PASSED) {
-            auto feats = frame->features();
-            vector<ulong> idsv;
-            for (auto &kv : feats) idsv.push_back(kv.first);
-            std::sort(idsv.begin(), idsv.end());
-            for (ulong id : idsv) {
-                const Point2f &kp = feats[id]->distortedKeyPoint();
+            Frame::FeatureList &feats = s.feat_scratch;
+            frame->featureSnapshot(feats);
+            std::sort(feats.begin(), feats.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+            for (auto &kv : feats) {
+                const ulong id    = kv.first;
+                const Point2f &kp = kv.second->distortedKeyPoint();
                 fnv(s.digest, &id, sizeof id);
                 fnv(s.digest, &kp, sizeof kp);
             }
@@ -218,6 +291,8 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
             uint64_t nref = s.tracking->numTrackedRefPoints();
             fnv(s.digest, &nref, sizeof nref);
         }
+        }
+        hostprof::Scope hpk(hostprof::KEEPER);
         s.keeper->onFrame(*s.tracking, frame, st);
     });
     timing[4] += now_s() - t0;
@@ -244,8 +319,12 @@ StreamGroups::StreamGroups(int device, int n_streams, int n_groups, const vector
         begin += cnt;
     }
     group_begin_.push_back(begin);
-    if (n_groups > 1)
+    if (n_groups > 1) {
+        // many contexts share the host cores: waits must not spin (a spinning wait burns the core another group needs;
+        // 20 us between stream queries costs little against stage times of 100s of us)
+        for (auto &g : groups_) (void) icg_ctx_set_wait_mode(g->device()->ctx(), ICG_WAIT_POLL, 20);
         for (int g = 0; g < n_groups; g++) workers_.emplace_back(&StreamGroups::workerLoop, this, g);
+    }
 }
 
 StreamGroups::~StreamGroups() {

@@ -3,12 +3,38 @@
 // batched ABI call (one kernel launch set) for all streams.  Streams never exchange data; results are split back by
 // offset, so per-stream outputs are identical to running the streams one at a time (shard invariance).
 #pragma once
+#include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <thread>
 
 #include "tracking.h"
 
 namespace icg {
+
+// Persistent helpers for the per-stream host stages of one group: parallelFor(n, f) runs f(0..n-1) on the caller plus the
+// helper threads (dynamic index claiming).  Helpers spin briefly between dispatches (stages follow each other every
+// ~100 us) and sleep on a condition variable when the group is idle.
+class HostPool {
+public:
+    explicit HostPool(int n_threads);
+    ~HostPool();
+    void parallelFor(int n, const std::function<void(int)> &f);
+    int threads() const { return (int) helpers_.size() + 1; }
+
+private:
+    void helperLoop();
+    void drain();
+    vector<std::thread> helpers_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> next_{0}, acks_{0}, sleepers_{0};
+    int n_{0};
+    const std::function<void(int)> *fn_{nullptr};
+    std::atomic<bool> stop_{false};
+    std::string error_;
+};
 
 class TrackingBatch {
 public:
@@ -19,6 +45,7 @@ public:
         std::shared_ptr<WindowKeeper> keeper;
         std::shared_ptr<IdSpace> ids;
         StageBatch box[2];
+        Frame::FeatureList feat_scratch;
         // statistics / digest
         uint64_t frames{0}, keyframes{0}, tracked_sum{0}, digest{1469598103934665603ull};
         TrackState last_state{TRACK_PASSED};
@@ -44,6 +71,7 @@ private:
     DeviceContext::Ptr device_;
     vector<Stream> streams_;
     int host_threads_;
+    std::unique_ptr<HostPool> pool_;
     icg_detect_grid grid_{};
     int max_per_job_{0};
 };

@@ -5,11 +5,13 @@
 // stages keeps the reference's containers and iteration order (std::unordered_map copies, push_back order, stable
 // reduceVector) so indices and ids are reproduced.
 #include <cmath>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
 
 #include "tracking.h"
+#include "hostprof.h"
 
 namespace icg {
 
@@ -114,6 +116,7 @@ void DeviceContext::freeSlot(int s) {
 
 void DeviceContext::execute(StageBatch &b, const icg_detect_grid &grid, int max_per_job) {
     if (!b.pre_slots.empty()) {
+        hostprof::Scope hp(hostprof::DEV_PREPROCESS);
         int n = (int) b.pre_slots.size();
         b.pre_hist.assign((size_t) n, 0.0);
         abi_check(ctx_,
@@ -122,6 +125,7 @@ void DeviceContext::execute(StageBatch &b, const icg_detect_grid &grid, int max_
                   "icg_frames_preprocess");
     }
     if (!b.det_slots.empty()) {
+        hostprof::Scope hp(hostprof::DEV_DETECT);
         int n = (int) b.det_slots.size();
         b.det_out.assign((size_t) n * max_per_job * 2, 0.f);
         b.det_count.assign((size_t) n, 0);
@@ -131,6 +135,7 @@ void DeviceContext::execute(StageBatch &b, const icg_detect_grid &grid, int max_
                   "icg_detect");
     }
     if (!b.lk_prev_slot.empty()) {
+        hostprof::Scope hp(hostprof::DEV_LK);
         int n = (int) b.lk_prev_slot.size();
         b.lk_out.assign((size_t) n * 2, 0.f);
         b.lk_undist.assign((size_t) n * 2, 0.f);
@@ -141,12 +146,14 @@ void DeviceContext::execute(StageBatch &b, const icg_detect_grid &grid, int max_
                   "icg_lk_track_fb");
     }
     if (b.rs_off.size() > 1) {
+        hostprof::Scope hp(hostprof::DEV_RANSAC);
         int n = (int) b.rs_off.size() - 1;
         b.rs_mask.assign((size_t) b.rs_off.back(), 1);
         abi_check(ctx_, icg_fm_ransac(ctx_, n, b.rs_off.data(), b.rs_p1.data(), b.rs_p2.data(), b.rs_thresh, b.rs_conf, b.rs_mask.data()),
                   "icg_fm_ransac");
     }
     if (!b.tri_T0.empty()) {
+        hostprof::Scope hp(hostprof::DEV_TRIANGULATE);
         int n = (int) b.tri_T0.size();
         b.tri_pw.assign((size_t) n * 3, 0.0);
         abi_check(ctx_,
@@ -242,19 +249,27 @@ double Tracking::keyPointParallax(const Point2f &pp0, const Point2f &pp1, const 
     return Vector2d(pc01[0] - pc1[0], pc01[1] - pc1[1]).norm() * camera_->focalLength();
 }
 
+double Tracking::keyPointParallax(const Point2f &pp0, const Point2f &pp1, const Matrix3d &R10) {
+    Vector3d pc0  = camera_->pixel2cam(pp0);
+    Vector3d pc1  = camera_->pixel2cam(pp1);
+    Vector3d pc01 = R10 * pc0;
+    return Vector2d(pc01[0] - pc1[0], pc01[1] - pc1[1]).norm() * camera_->focalLength();
+}
+
 int Tracking::parallaxFromReferenceMapPoints(double &parallax) { // :873-905
-    parallax      = 0;
-    int counts    = 0;
-    auto features = frame_ref_->features();
-    for (auto &feature : features) {
+    parallax   = 0;
+    int counts = 0;
+    frame_ref_->featureSnapshot(feat_snap_);
+    const Matrix3d R10 = frame_cur_->pose().R.transpose() * frame_ref_->pose().R; // loop invariant of :890
+    for (auto &feature : feat_snap_) {
         auto mappoint = feature.second->getMapPoint();
-        if (mappoint && !mappoint->isOutlier()) {
-            std::shared_ptr<Feature> feat; // == observations().back().lock() (:883-887)
-            if (!mappoint->lastObservation(feat)) continue;
+        if (mappoint) {
+            std::shared_ptr<Feature> feat; // !isOutlier() && observations().back().lock() (:880-887)
+            if (!mappoint->lastObservationUnlessOutlier(feat)) continue;
             if (feat && !feat->isOutlier()) {
                 auto frame = feat->getFrame();
                 if (frame && (frame == frame_cur_)) {
-                    parallax += keyPointParallax(feature.second->keyPoint(), feat->keyPoint(), frame_ref_->pose(), frame_cur_->pose());
+                    parallax += keyPointParallax(feature.second->keyPoint(), feat->keyPoint(), R10);
                     counts++;
                 }
             }
@@ -264,12 +279,33 @@ int Tracking::parallaxFromReferenceMapPoints(double &parallax) { // :873-905
     return counts;
 }
 
+// ICG_HOST_CHECK=1: the carried undistorted twins must equal a fresh Camera::undistortPoints of their sources, bit for bit
+void Tracking::checkCarriedUndistortion(const char *where) {
+    static const bool on = getenv("ICG_HOST_CHECK") != nullptr;
+    if (!on) return;
+    auto same = [&](const vector<Point2f> &src, const vector<Point2f> &carried, const char *what) {
+        if (src.size() != carried.size())
+            throw std::runtime_error(std::string("carried undistortion size mismatch (") + what + ") at " + where);
+        vector<Point2f> u = src;
+        camera_->undistortPoints(u);
+        for (size_t k = 0; k < u.size(); k++)
+            if (memcmp(&u[k], &carried[k], sizeof(Point2f)) != 0)
+                throw std::runtime_error(std::string("carried undistortion differs (") + what + ") at " + where);
+    };
+    same(pts2d_ref_, pts2d_ref_undis_, "ref");
+    if (where[0] == 't' && where[2] == 'i') // "triangulation": pts2d_new_ is stale here, pts2d_cur_ is live
+        same(pts2d_cur_, tr_cur_undis_, "cur");
+    else
+        same(pts2d_new_, pts2d_new_undis_, "new");
+}
+
 int Tracking::parallaxFromReferenceKeyPoints(const vector<Point2f> &ref, const vector<Point2f> &cur, double &parallax) { // :907-922
     parallax   = 0;
     int counts = 0;
+    const Matrix3d R10 = frame_cur_->pose().R.transpose() * frame_ref_->pose().R;
     for (size_t k = 0; k < pts2d_ref_frame_.size(); k++) {
         if (pts2d_ref_frame_[k] == frame_ref_) {
-            parallax += keyPointParallax(ref[k], cur[k], frame_ref_->pose(), frame_cur_->pose());
+            parallax += keyPointParallax(ref[k], cur[k], R10);
             counts++;
         }
     }
@@ -296,6 +332,8 @@ bool Tracking::doResetTracking() { // :317-329
         frame_ref_      = frame_cur_;
         pts2d_new_.clear();
         pts2d_ref_.clear();
+        pts2d_ref_undis_.clear();
+        pts2d_new_undis_.clear();
         pts2d_ref_frame_.clear();
         velocity_ref_.clear();
         return true;
@@ -304,7 +342,7 @@ bool Tracking::doResetTracking() { // :317-329
 }
 
 void Tracking::writeLoggingMessage() { // :309-315 ; FileSaver text format "%-15.9lf " (fileio/filesaver.cc:51-66)
-    logging_data_.push_back(static_cast<double>(frame_cur_->features().size()));
+    logging_data_.push_back(static_cast<double>(frame_cur_->numFeatures()));
     logging_data_.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start_).count());
     if (logfile_) {
         for (double v : logging_data_) fprintf(logfile_, "%-15.9lf ", v);
@@ -536,7 +574,7 @@ void Tracking::makeNewFrameQueue(int state, StageBatch &next) {
 // ---- featuresDetection (:576-688) ------------------------------------------------------------------------------------
 bool Tracking::queueDetection(Frame::Ptr &frame, bool ismask, StageBatch &next) {
     det_job_ = -1;
-    int num_features = static_cast<int>(frame->features().size() + pts2d_ref_.size()); // :579
+    int num_features = static_cast<int>(frame->numFeatures() + pts2d_ref_.size()); // :579
     if (num_features > (cfg_.track_max_features - 5)) return false;                     // :580
     vector<int> features_cnts((size_t) block_cnts_, 0);
     auto count = [&](float x, float y) {
@@ -548,14 +586,16 @@ bool Tracking::queueDetection(Frame::Ptr &frame, bool ismask, StageBatch &next) 
         if (row < 0) row = 0;
         features_cnts[(size_t) row * block_cols_ + col]++;
     };
-    for (const auto &feature : frame->features()) count(feature.second->keyPoint().x, feature.second->keyPoint().y);
+    frame->featureSnapshot(feat_snap_);
+    for (const auto &feature : feat_snap_) count(feature.second->keyPoint().x, feature.second->keyPoint().y);
     for (auto &pts2d : pts2d_new_) count(pts2d.x, pts2d.y);
     det_job_     = (int) next.det_slots.size();
     det_ismask_  = ismask;
     det_frame_   = frame;
     next.det_slots.push_back(frame->deviceSlot());
     if (ismask) { // :610-620
-        for (const auto &pt : frame_cur_->features()) {
+        if (frame != frame_cur_) frame_cur_->featureSnapshot(feat_snap_);
+        for (const auto &pt : feat_snap_) {
             next.det_mask_pts.push_back(pt.second->keyPoint().x);
             next.det_mask_pts.push_back(pt.second->keyPoint().y);
         }
@@ -573,16 +613,23 @@ void Tracking::integrateDetection(StageBatch &done) { // :659-685
     if (!det_ismask_) {
         pts2d_new_.clear();
         pts2d_ref_.clear();
+        pts2d_ref_undis_.clear();
+        pts2d_new_undis_.clear();
         pts2d_ref_frame_.clear();
         velocity_ref_.clear();
     }
     const int max_per_job = maxFeaturesPerJob();
     const int n           = done.det_count[(size_t) det_job_];
     const float *p        = done.det_out.data() + (size_t) det_job_ * max_per_job * 2;
+    vector<Point2f> fresh((size_t) n);
+    for (int i = 0; i < n; i++) fresh[(size_t) i] = Point2f(p[2 * i], p[2 * i + 1]);
+    vector<Point2f> fresh_undis = fresh;
+    camera_->undistortPoints(fresh_undis); // the one undistortion a detected corner ever needs
     for (int i = 0; i < n; i++) {
-        Point2f pts2d(p[2 * i], p[2 * i + 1]);
-        pts2d_ref_.push_back(pts2d);
-        pts2d_new_.push_back(pts2d);
+        pts2d_ref_.push_back(fresh[(size_t) i]);
+        pts2d_new_.push_back(fresh[(size_t) i]);
+        pts2d_ref_undis_.push_back(fresh_undis[(size_t) i]);
+        pts2d_new_undis_.push_back(fresh_undis[(size_t) i]);
         pts2d_ref_frame_.push_back(det_frame_);
         velocity_ref_.emplace_back(0, 0);
     }
@@ -597,16 +644,19 @@ void Tracking::queueTrackMappoint(StageBatch &next) {
     tm_pts2d_map_undis_.clear();
     tm_type_.clear();
     vector<Point2f> pts2d_matched;
-    auto features = frame_pre_->features();
+    frame_pre_->featureSnapshot(feat_snap_);
     Pose pose_cur = frame_cur_->pose();
-    for (auto &feature : features) {
+    pts2d_matched.reserve(feat_snap_.size());
+    for (auto &feature : feat_snap_) {
         auto mappoint = feature.second->getMapPoint();
-        if (mappoint && !mappoint->isOutlier()) {
-            mappoint_matched_.push_back(mappoint);
+        Vector3d pos;
+        MapPointType type;
+        if (mappoint && mappoint->trackingView(pos, type)) { // !isOutlier(), pos(), mapPointType() in one critical section
             tm_pts2d_map_undis_.push_back(feature.second->keyPoint());
             tm_pts2d_map_.push_back(feature.second->distortedKeyPoint());
-            tm_type_.push_back(mappoint->mapPointType());
-            pts2d_matched.emplace_back(camera_->world2pixel(mappoint->pos(), pose_cur)); // INS-aided prediction :367
+            tm_type_.push_back(type);
+            pts2d_matched.emplace_back(camera_->world2pixel(pos, pose_cur)); // INS-aided prediction :367
+            mappoint_matched_.push_back(std::move(mappoint));
         }
     }
     lk_map_begin_ = (int) next.lk_prev_slot.size();
@@ -648,7 +698,9 @@ bool Tracking::finishTrackMappoint(StageBatch &done) {
         return false;
     }
     frame_cur_->clearFeatures(); // :426
+    frame_cur_->reserveFeatures(pts2d_matched_undis.size() + 64);
     tracked_mappoint_.clear();
+    tracked_mappoint_.reserve(pts2d_matched_undis.size());
     double dt = frame_cur_->stamp() - frame_pre_->stamp();
     for (size_t k = 0; k < pts2d_matched_undis.size(); k++) {
         auto mappoint = mappoint_matched_[k];
@@ -671,10 +723,9 @@ void Tracking::queueTrackReference(StageBatch &next) {
     lk_ref_n_     = 0;
     if (pts2d_ref_.empty()) return; // :459-462
     Matrix3d r_cur_pre = frame_cur_->pose().R.transpose() * frame_pre_->pose().R; // :465
-    auto pts2d_new_undis = pts2d_new_;
-    camera_->undistortPoints(pts2d_new_undis); // :469
+    checkCarriedUndistortion("trackReferenceFrame");
     pts2d_cur_.clear();
-    for (const auto &pp_pre : pts2d_new_undis) { // :472-479
+    for (const auto &pp_pre : pts2d_new_undis_) { // :469 (carried), :472-479
         Vector3d pc_pre = camera_->pixel2cam(pp_pre);
         Vector3d pc_cur = r_cur_pre * pc_pre;
         pts2d_cur_.emplace_back(camera_->distortCameraPoint(pc_cur));
@@ -706,13 +757,14 @@ bool Tracking::midTrackReference(StageBatch &done, StageBatch &next) {
     reduceVector(pts2d_ref_frame_, status);
     reduceVector(velocity_ref_, status);
     reduceVector(cur_undis_all, status);
+    reduceVector(pts2d_ref_undis_, status);
+    reduceVector(pts2d_new_undis_, status);
     if (pts2d_ref_.empty()) { // :513-517
         drawer_->updateTrackedRefPoints({}, {});
         return false;
     }
-    tr_new_undis_ = pts2d_new_; // :520-524
-    tr_cur_undis_ = cur_undis_all;
-    camera_->undistortPoints(tr_new_undis_);
+    tr_new_undis_ = pts2d_new_undis_; // :520-524 (carried)
+    tr_cur_undis_.swap(cur_undis_all);
 
     velocity_cur_.clear(); // :527-539
     double dt = frame_cur_->stamp() - frame_pre_->stamp();
@@ -722,9 +774,7 @@ bool Tracking::midTrackReference(StageBatch &done, StageBatch &next) {
         velocity_cur_.push_back(velocity);
         if (pts2d_ref_frame_[k]->id() > frame_ref_->id()) velocity_ref_[k] = velocity;
     }
-    auto pts2d_ref_undis = pts2d_ref_; // :542-544
-    camera_->undistortPoints(pts2d_ref_undis);
-    parallax_ref_counts_ = parallaxFromReferenceKeyPoints(pts2d_ref_undis, tr_cur_undis_, parallax_ref_);
+    parallax_ref_counts_ = parallaxFromReferenceKeyPoints(pts2d_ref_undis_, tr_cur_undis_, parallax_ref_); // :542-544
 
     if (pts2d_cur_.size() >= 15) { // :547-548
         rs_set_        = (int) next.rs_off.size() - 1;
@@ -748,6 +798,8 @@ bool Tracking::finishTrackReference(StageBatch &done) {
         reduceVector(pts2d_ref_frame_, status);
         reduceVector(velocity_cur_, status);
         reduceVector(velocity_ref_, status);
+        reduceVector(pts2d_ref_undis_, status);
+        reduceVector(tr_cur_undis_, status);
         rs_set_ = -1;
     }
     if (pts2d_cur_.empty()) { // :557-561
@@ -755,7 +807,8 @@ bool Tracking::finishTrackReference(StageBatch &done) {
         return false;
     }
     if (cfg_.is_use_visualization) drawer_->updateTrackedRefPoints(pts2d_ref_, pts2d_cur_);
-    pts2d_new_ = pts2d_cur_; // :569
+    pts2d_new_       = pts2d_cur_; // :569
+    pts2d_new_undis_ = tr_cur_undis_;
     return !pts2d_new_.empty();
 }
 
@@ -765,10 +818,17 @@ bool Tracking::queueTriangulation(StageBatch &next) {
     if (pts2d_cur_.empty()) return false; // :692-694
     tri_queued_ = true;
     Pose pose1  = frame_cur_->pose();
-    tri_ref_undis_ = pts2d_ref_;
-    tri_cur_undis_ = pts2d_cur_;
-    camera_->undistortPoints(tri_ref_undis_); // :712-713
-    camera_->undistortPoints(tri_cur_undis_);
+    if (tr_cur_undis_.size() != pts2d_cur_.size()) { // no reference tracking ran this frame: derive them on the host
+        tr_cur_undis_ = pts2d_cur_;
+        camera_->undistortPoints(tr_cur_undis_);
+    }
+    if (pts2d_ref_undis_.size() != pts2d_ref_.size()) {
+        pts2d_ref_undis_ = pts2d_ref_;
+        camera_->undistortPoints(pts2d_ref_undis_);
+    }
+    checkCarriedUndistortion("triangulation");
+    tri_ref_undis_ = pts2d_ref_undis_; // :712-713 (carried)
+    tri_cur_undis_ = tr_cur_undis_;
     tri_status_.assign(pts2d_cur_.size(), 0);
     tri_action_.assign(pts2d_cur_.size(), 0);
     tri_point_index_.clear();
@@ -785,6 +845,7 @@ bool Tracking::queueTriangulation(StageBatch &next) {
         if (frame_ref->id() > frame_ref_->id()) { // :723-730 feature added after the reference keyframe: re-anchor
             pts2d_ref_frame_[k] = frame_cur_;
             pts2d_ref_[k]       = pts2d_cur_[k];
+            pts2d_ref_undis_[k] = tri_cur_undis_[k];
             tri_status_[k]      = 1;
             continue;
         }
@@ -853,7 +914,10 @@ void Tracking::finishTriangulation(StageBatch &done) {
     reduceVector(pts2d_ref_frame_, tri_status_);
     reduceVector(pts2d_cur_, tri_status_);
     reduceVector(velocity_ref_, tri_status_);
-    pts2d_new_ = pts2d_cur_;
+    reduceVector(pts2d_ref_undis_, tri_status_);
+    reduceVector(tr_cur_undis_, tri_status_);
+    pts2d_new_       = pts2d_cur_;
+    pts2d_new_undis_ = tr_cur_undis_;
 }
 
 // ---- single-stream synchronous API (tracking.cc:144) ------------------------------------------------------------------
@@ -882,7 +946,7 @@ void WindowKeeper::onFrame(Tracking &tracking, const Frame::Ptr &frame, TrackSta
         auto it = map_->keyframes().find(id);
         if (it == map_->keyframes().end()) continue;
         auto f = it->second;
-        if ((f->keyFrameState() == KEYFRAME_REMOVE_SECOND_NEW) || (f->features().empty() && (id != ids.back()))) {
+        if ((f->keyFrameState() == KEYFRAME_REMOVE_SECOND_NEW) || ((f->numFeatures() == 0) && (id != ids.back()))) {
             f->resetKeyFrame();
             map_->removeKeyFrame(f, false);
         }

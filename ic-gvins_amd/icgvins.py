@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libicgvins_hip.so")
 
 EXPORTS = [
-    "icg_ctx_create", "icg_ctx_destroy", "icg_last_error", "icg_ctx_sync", "icg_ctx_stream", "icg_set_camera",
+    "icg_ctx_create", "icg_ctx_destroy", "icg_last_error", "icg_ctx_sync", "icg_ctx_set_wait_mode", "icg_ctx_stream", "icg_set_camera",
     "icg_version", "icg_pyramid_levels", "icg_prof_enable", "icg_prof_get", "icg_prof_names", "icg_dev_alloc",
     "icg_dev_free", "icg_dev_upload", "icg_dev_download", "icg_frames_preprocess", "icg_frame_download",
     "icg_lk_track", "icg_lk_track_fb", "icg_undistort_points", "icg_distort_points", "icg_predict_mappoints",

@@ -56,6 +56,14 @@ int icg_ctx_create(const icg_ctx_config *cfg, icg_ctx **out);
 void icg_ctx_destroy(icg_ctx *ctx);
 const char *icg_last_error(const icg_ctx *ctx);
 int icg_ctx_sync(icg_ctx *ctx);
+/* How a call waits for its kernels (no reference counterpart; the reference's OpenCV calls are synchronous CPU code):
+ *   ICG_WAIT_SPIN   busy-wait on the stream: lowest latency, occupies a host core (default; one tracker per process)
+ *   ICG_WAIT_POLL   query + sleep sleep_us between queries: the core is free for other contexts' threads (many contexts
+ *                   per host core, see host/tracking_batch.h)
+ * The environment variable ICG_WAIT_MODE=spin|poll[:us] overrides the setting of every context. */
+#define ICG_WAIT_SPIN 0
+#define ICG_WAIT_POLL 1
+int icg_ctx_set_wait_mode(icg_ctx *ctx, int mode, int sleep_us);
 /* hipStream_t of the context (for callers that want to record their own HIP events on it). */
 void *icg_ctx_stream(icg_ctx *ctx);
 int icg_set_camera(icg_ctx *ctx, const icg_camera *cam);

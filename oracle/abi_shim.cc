@@ -65,6 +65,7 @@ int icg_ctx_create(const icg_ctx_config *cfg, icg_ctx **out) {
 }
 void icg_ctx_destroy(icg_ctx *ctx) { delete ctx; }
 int icg_ctx_sync(icg_ctx *) { return ICG_OK; }
+int icg_ctx_set_wait_mode(icg_ctx *, int, int) { return ICG_OK; }
 void *icg_ctx_stream(icg_ctx *) { return nullptr; }
 int icg_set_camera(icg_ctx *ctx, const icg_camera *cam) {
     ctx->cam     = *cam;
