@@ -16,7 +16,7 @@
 //   k_select      one workgroup per ROI: repeated block-wide arg-max over live candidates + min-distance kill
 //                 (equivalent to sort + greedy grid test, needs no sort and no capacity cap)
 //   k_subpix      one wavefront per corner: 13x13 bilinear patch and the 121 gradient terms in parallel through LDS,
-//                 the five 121-term sums sequentially on one lane in raster order (keeps IEEE order == CPU order)
+//                 the five 121-term sums each sequentially in raster order (IEEE order == CPU order), one lane per sum
 #include <cfloat>
 
 #include "icg_internal.h"
@@ -274,15 +274,15 @@ __global__ __launch_bounds__(64) void k_subpix(const det_roi *rois, const uint8_
             terms[i][4] = gxy * px + gyy * py;
         }
         __syncthreads();
+        // the five 121-term sums keep the CPU's sequential raster order, but run side by side on lanes 0..4
+        double acc = 0;
+        if (lane < 5) {
+#pragma unroll 11
+            for (int i = 0; i < 121; i++) acc += terms[i][lane];
+        }
+        const double a = __shfl(acc, 0, 64), b = __shfl(acc, 1, 64), c = __shfl(acc, 2, 64);
+        const double bb1 = __shfl(acc, 3, 64), bb2 = __shfl(acc, 4, 64);
         if (lane == 0) {
-            double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
-            for (int i = 0; i < 121; i++) {
-                a += terms[i][0];
-                b += terms[i][1];
-                c += terms[i][2];
-                bb1 += terms[i][3];
-                bb2 += terms[i][4];
-            }
             int st     = 0;
             double det = a * c - b * b;
             if (fabs(det) <= DBL_EPSILON * DBL_EPSILON) {

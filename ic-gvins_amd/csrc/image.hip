@@ -340,31 +340,41 @@ __device__ __forceinline__ void p3_step(const unsigned int *in, unsigned int *tm
     constexpr int TS = 2 * OWQ; // packed pairs per tmp row
     static_assert(IS % 4 == 0 && IS / 4 >= TS + 2, "input tile too narrow");
     static_assert(IH >= 2 * OH + 3 && OS % 4 == 0 && OS / 4 >= OWQ, "tile geometry");
-    // horizontal [1 4 6 4 1] at even input columns: pair m = output columns 2m, 2m+1 <- input bytes 4m+2 .. 4m+8
-    for (int i = t; i < IH * TS; i += 256) {
-        const int r = i / TS, m = i - r * TS;
-        const unsigned int *p = in + r * (IS / 4) + m;
-        const unsigned int d0 = p[0], d1 = p[1], d2 = p[2];
-        const unsigned int lo = __builtin_amdgcn_alignbyte(d1, d0, 2), hi = __builtin_amdgcn_alignbyte(d2, d1, 2);
-        const unsigned int p0 = lo & 0xff, p1 = (lo >> 8) & 0xff, p2 = (lo >> 16) & 0xff, p3 = lo >> 24;
-        const unsigned int p4 = hi & 0xff, p5 = (hi >> 8) & 0xff, p6 = (hi >> 16) & 0xff;
-        const unsigned int h0 = p0 + p4 + 4 * (p1 + p3) + 6 * p2;
-        const unsigned int h1 = p2 + p6 + 4 * (p3 + p5) + 6 * p4;
-        tmp[i] = h0 | (h1 << 16);
+    // horizontal [1 4 6 4 1] at even input columns: pair m = output columns 2m, 2m+1 <- input bytes 4m+2 .. 4m+8.
+    // Fixed (row, pair) mapping per thread (no per-item division); the 4 inner taps are one v_dot4_u32_u8 each:
+    //   h0 = [1 4 6 4].(b2..b5) + b6,   h1 = [1 4 6 4].(b4..b7) + b8     (b0..b11 = bytes of dwords m, m+1, m+2)
+    {
+        constexpr int RPP = 256 / TS; // rows per pass
+        const int rr = t / TS, m = t - rr * TS;
+        if (rr < RPP) {
+            for (int r = rr; r < IH; r += RPP) {
+                const unsigned int *p = in + r * (IS / 4) + m;
+                const unsigned int d0 = p[0], d1 = p[1], d2 = p[2];
+                const unsigned int lo = __builtin_amdgcn_alignbyte(d1, d0, 2), hi = __builtin_amdgcn_alignbyte(d2, d1, 2);
+                const unsigned int h0 = __builtin_amdgcn_udot4(lo, 0x04060401u, hi & 0xffu, false);
+                const unsigned int h1 = __builtin_amdgcn_udot4(d1, 0x04060401u, (hi >> 16) & 0xffu, false);
+                tmp[r * TS + m] = h0 | (h1 << 16);
+            }
+        }
     }
     __syncthreads();
     // vertical pass on packed pairs, 4 output columns per item; (v + 128) >> 8 as in OpenCV's u8 pyrDown
-    for (int i = t; i < OH * OWQ; i += 256) {
-        const int r = i / OWQ, q = i - r * OWQ;
-        const uint2 *c = reinterpret_cast<const uint2 *>(tmp + (2 * r) * TS + 2 * q);
-        const uint2 t0 = c[0], t1 = c[TS / 2], t2 = c[TS], t3 = c[3 * TS / 2], t4 = c[2 * TS];
-        const unsigned int a = t0.x + t4.x + ((t1.x + t3.x) << 2) + (t2.x << 2) + (t2.x << 1) + 0x00800080u;
-        const unsigned int b = t0.y + t4.y + ((t1.y + t3.y) << 2) + (t2.y << 2) + (t2.y << 1) + 0x00800080u;
-        const unsigned int v = __builtin_amdgcn_perm(b >> 8, a >> 8, 0x06040200u);
-        out[r * (OS / 4) + q] = v;
-        const int x = gx0 + 4 * q, y = gy0 + r;
-        if (q >= own_q0 && q < own_q1 && r >= own_r0 && r < own_r1 && x < dw && y < dh)
-            *reinterpret_cast<unsigned int *>(dst + (size_t) y * dpitch + x) = v; // row padding (pitch % 128 == 0) absorbs x+3 >= dw
+    {
+        constexpr int RPP = 256 / OWQ;
+        const int rr = t / OWQ, q = t - rr * OWQ;
+        if (rr < RPP) {
+            for (int r = rr; r < OH; r += RPP) {
+                const uint2 *c = reinterpret_cast<const uint2 *>(tmp + (2 * r) * TS + 2 * q);
+                const uint2 t0 = c[0], t1 = c[TS / 2], t2 = c[TS], t3 = c[3 * TS / 2], t4 = c[2 * TS];
+                const unsigned int a = t0.x + t4.x + ((t1.x + t3.x) << 2) + (t2.x << 2) + (t2.x << 1) + 0x00800080u;
+                const unsigned int b = t0.y + t4.y + ((t1.y + t3.y) << 2) + (t2.y << 2) + (t2.y << 1) + 0x00800080u;
+                const unsigned int v = __builtin_amdgcn_perm(b >> 8, a >> 8, 0x06040200u);
+                out[r * (OS / 4) + q] = v;
+                const int x = gx0 + 4 * q, y = gy0 + r;
+                if (q >= own_q0 && q < own_q1 && r >= own_r0 && r < own_r1 && x < dw && y < dh)
+                    *reinterpret_cast<unsigned int *>(dst + (size_t) y * dpitch + x) = v; // row padding absorbs x+3 >= dw
+            }
+        }
     }
     __syncthreads();
 }
@@ -399,9 +409,25 @@ __global__ __launch_bounds__(256) void k_pyramid3(icg_pyr_desc P, pre_jobs jobs)
         const uint8_t *s = slot + P.off[0];
         const int w = P.w[0], h = P.h[0], pitch = P.pitch[0];
         const int x0 = 8 * X3 - 28, y0 = 8 * Y3 - 14;
-        for (int i = t; i < P3_L0H * (P3_L0S / 4); i += 256) {
-            const int r = i / (P3_L0S / 4), d = i - r * (P3_L0S / 4);
-            L0[i] = p3_load4(s + (size_t) icg_reflect101(y0 + r, h) * pitch, x0 + 4 * d, w);
+        constexpr int DW = P3_L0S / 4, RPP = 256 / DW, NP = (P3_L0H + RPP - 1) / RPP; // 42 dwords/row, 6 rows/pass, 15 passes
+        const int rr = t / DW, d = t - rr * DW;
+        const bool inside = x0 >= 0 && x0 + P3_L0S <= w && y0 >= 0 && y0 + P3_L0H <= h; // workgroup-uniform
+        unsigned int v[NP]; // all loads in flight before the first LDS write (one memory round trip per workgroup)
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int r = rr + k * RPP;
+            v[k]        = 0;
+            if (rr < RPP && r < P3_L0H) {
+                if (inside)
+                    v[k] = *reinterpret_cast<const unsigned int *>(s + (size_t) (y0 + r) * pitch + (x0 + 4 * d));
+                else
+                    v[k] = p3_load4(s + (size_t) icg_reflect101(y0 + r, h) * pitch, x0 + 4 * d, w);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int r = rr + k * RPP;
+            if (rr < RPP && r < P3_L0H) L0[r * DW + d] = v[k];
         }
         __syncthreads();
     }

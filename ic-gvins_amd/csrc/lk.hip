@@ -17,8 +17,11 @@
 //     bytes of it are CACHED IN REGISTERS and re-fetched only when the integer window position changes, so a typical
 //     iteration touches no LDS at all (v1 spent 39% of its wave cycles in LDS issue stalls: rocprofv3 SQ_WAIT_INST_LDS),
 //   * A11/A12/A22 and b1/b2 are per-lane int32 partials (bounded: 7*4080^2 < 2^27, 7*8160*4080 < 2^28) reduced exactly:
-//     DPP butterflies in 32 bits up to 16 / 8 lanes, then v_readlane + 64-bit scalar adds (uniform result in SGPRs);
-//     every multiply has 24-bit operands -> full-rate v_mul_i32_i24 / v_mad_i32_i24.
+//     DPP butterflies in 32 bits up to 16 / 8 lanes, then exact doubles through row_mirror/row_bcast DPP stages;
+//   * the kernel is VALU-issue bound (rocprofv3: ~11k VALU instructions per point in v2), so the integer math is packed:
+//     pixels, Scharr terms and Q14 weights all fit 16 bits -> v_pk_{add,sub,mul_lo}_u16 for the derivative stencil and
+//     v_dot2_i32_i16 for every bilinear blend (2 taps per instruction) and for the window products; the patch sample is
+//     folded into the blend's rounding constant (c0 = 256 - 512*I) so a residual costs 2 dot2 + 1 shift.
 // Algorithmic HBM bytes per point and direction: 4 levels x (24^2 + 22^2) B; everything else is
 // LDS/VGPR traffic.
 #include <cfloat>
@@ -40,42 +43,54 @@ struct lk_smem {
     unsigned int J[LK_JT * LK_JS / 4 + 1];
 };
 
-// Exact wave-wide integer sums, result uniform (SGPRs).  The per-lane partials are bounded (see the kernel comment), so
-// the first butterfly stages run in 32 bits as fused DPP adds (quad_perm xor1, xor2, row_half_mirror[, row_mirror]); the
-// 8 (or 4) group sums are then read with v_readlane and added as 64-bit SCALAR integers — no LDS crossbar round trips.
+// Exact wave-wide integer sums.  The per-lane partials are bounded (see the kernel comment), so the first butterfly
+// stages run in 32 bits as fused DPP adds (quad_perm xor1, xor2, row_half_mirror[, row_mirror]).
 __device__ __forceinline__ int dpp_add_xor1(int v) { return v + __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false); }
 __device__ __forceinline__ int dpp_add_xor2(int v) { return v + __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false); }
 __device__ __forceinline__ int dpp_add_half_mirror(int v) { return v + __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false); }
 __device__ __forceinline__ int dpp_add_mirror(int v) { return v + __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false); }
 
+// Exact wave-wide sum of bounded int32 partials, returned as (float) of the exact integer (what the CPU restatement's
+// (float)(int64 sum) produces).  Stages: 32-bit DPP butterflies while the group sums still fit int32 (8 lanes for
+// |partial| <= 2^28, 16 lanes for <= 2^27), then the group sums continue as DOUBLES (exact below 2^53) through
+// row_mirror / row_bcast15 / row_bcast31, lane 63 holds the total, one v_cvt_f32_f64 rounds once (RNE) like i64->f32.
+// No scalar-ALU carry chains: v2 spent a third of its issue slots on s_add/s_addc/s_ashr + the i64->f32 emulation.
+#define LK_DPP_ADD_F64(d, ctrl, rowmask)                                                                                  \
+    (d) + __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(d), (ctrl), (rowmask), 0xF, false),              \
+                           __builtin_amdgcn_update_dpp(0, __double2loint(d), (ctrl), (rowmask), 0xF, false))
+__device__ __forceinline__ float wave_sum_tail_f32(double d) {
+    d = LK_DPP_ADD_F64(d, 0x142, 0xA); // row_bcast15: rows 1,3 += lane 15 of rows 0,2
+    d = LK_DPP_ADD_F64(d, 0x143, 0xC); // row_bcast31: rows 2,3 += lane 31
+    const double total = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), 63), __builtin_amdgcn_readlane(__double2loint(d), 63));
+    return (float) total;
+}
 // |per-lane partial| <= 2^28: sums of 8 lanes fit in int32
-__device__ __forceinline__ long long wave_sum_i32x8(int v) {
+__device__ __forceinline__ float wave_sum_i32x8_f32(int v) {
     v = dpp_add_xor1(v);
     v = dpp_add_xor2(v);
     v = dpp_add_half_mirror(v);
-    long long s = 0;
-#pragma unroll
-    for (int g = 0; g < 8; g++) s += (long long) __builtin_amdgcn_readlane(v, g * 8);
-    return s;
+    double d = (double) v;
+    d        = LK_DPP_ADD_F64(d, 0x140, 0xF); // row_mirror
+    return wave_sum_tail_f32(d);
 }
 // |per-lane partial| <= 2^27: sums of 16 lanes fit in int32
-__device__ __forceinline__ long long wave_sum_i32x16(int v) {
+__device__ __forceinline__ float wave_sum_i32x16_f32(int v) {
     v = dpp_add_xor1(v);
     v = dpp_add_xor2(v);
     v = dpp_add_half_mirror(v);
     v = dpp_add_mirror(v);
-    long long s = 0;
-#pragma unroll
-    for (int g = 0; g < 4; g++) s += (long long) __builtin_amdgcn_readlane(v, g * 16);
-    return s;
+    return wave_sum_tail_f32((double) v);
 }
 
 __device__ __forceinline__ int lk_descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
 
 __device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01, int &w10, int &w11) {
-    w00 = (int) rintf((1.f - a) * (1.f - b) * (float) (1 << 14));
-    w01 = (int) rintf(a * (1.f - b) * (float) (1 << 14));
-    w10 = (int) rintf((1.f - a) * b * (float) (1 << 14));
+    // rint((1-a)(1-b) 2^14) etc.; the power-of-two scale commutes with every rounding, so it is applied to a once:
+    // fl(fl(1-a) fl(1-b)) 2^14 == fl((2^14 - a 2^14) fl(1-b))   (bit-identical, 8 fewer VALU ops per iteration)
+    const float A = a * (float) (1 << 14), A1 = (float) (1 << 14) - A, b1 = 1.f - b;
+    w00 = (int) rintf(A1 * b1);
+    w01 = (int) rintf(A * b1);
+    w10 = (int) rintf(A1 * b);
     w11 = (1 << 14) - w00 - w01 - w10;
 }
 
@@ -92,30 +107,104 @@ __device__ __forceinline__ unsigned int lk_load4(const unsigned char *row, int x
 }
 __device__ __forceinline__ int lk_byte(unsigned int w, int k) { return (int) ((w >> (8 * k)) & 0xffu); }
 
-// 32x32 u8 tile of the next image: lane -> (row lane>>1, 16 pixels at column (lane&1)*16) = 4 packed dwords
+typedef unsigned int __attribute__((aligned(1))) lk_u32u;
+
+// Tile loads are split into "issue all global loads into registers" and "write them to LDS", so that the loads of the
+// previous-image tile and of the next-image tile of a level fly together (one HBM/L2 round trip per level instead of
+// two or more back-to-back ones: the wave has few siblings to hide latency behind at 84 VGPRs).
+// 24x24 I tile: dword i = lane + 64*q -> (row i/6, dword column i%6), tile (r,c) <-> image (ipx-1+c, ipy-1+r)
+__device__ __forceinline__ void lk_load_I(unsigned int (&v)[3], const unsigned char *I, int W, int H, int pitch, int ipx, int ipy,
+                                          int lane) {
+    const bool inside = ipx - 1 >= 0 && ipx - 1 + LK_IT <= W && ipy - 1 >= 0 && ipy - 1 + LK_IT <= H; // wave-uniform
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int i = lane + 64 * q;
+        const int r = i / 6, cd = i - r * 6;
+        v[q] = 0;
+        if (i < LK_IT * 6) {
+            if (inside)
+                v[q] = *reinterpret_cast<const lk_u32u *>(I + (size_t) (ipy - 1 + r) * pitch + (ipx - 1 + 4 * cd));
+            else
+                v[q] = lk_load4(I + (size_t) icg_reflect101(ipy - 1 + r, H) * pitch, ipx - 1 + 4 * cd, W);
+        }
+    }
+}
+__device__ __forceinline__ void lk_store_I(lk_smem &S, const unsigned int (&v)[3], int lane) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int i = lane + 64 * q;
+        const int r = i / 6, cd = i - r * 6;
+        if (i < LK_IT * 6) S.I[(r * LK_IS >> 2) + cd] = v[q];
+    }
+}
+// 32x32 J tile: lane -> (row lane>>1, 16 pixels at column (lane&1)*16) = 4 packed dwords, tile (r,c) <-> image (jx0+c, jy0+r)
+__device__ __forceinline__ void lk_load_J(unsigned int (&v)[4], const unsigned char *J, int W, int H, int pitch, int jx0, int jy0,
+                                          int lane) {
+    const int r = lane >> 1, c0 = (lane & 1) * 16;
+    const bool inside = jx0 >= 0 && jx0 + LK_JT <= W && jy0 >= 0 && jy0 + LK_JT <= H; // wave-uniform
+    if (inside) {
+        const unsigned char *row = J + (size_t) (jy0 + r) * pitch + (jx0 + c0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const lk_u32u *>(row + 4 * q);
+    } else {
+        const unsigned char *row = J + (size_t) icg_reflect101(jy0 + r, H) * pitch;
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = lk_load4(row, jx0 + c0 + 4 * q, W);
+    }
+}
+__device__ __forceinline__ void lk_store_J(lk_smem &S, const unsigned int (&v)[4], int lane) {
+    const int r = lane >> 1, c0 = (lane & 1) * 16;
+    unsigned int *dst = &S.J[(r * LK_JS + c0) >> 2];
+#pragma unroll
+    for (int q = 0; q < 4; q++) dst[q] = v[q];
+}
 __device__ __forceinline__ void lk_stage_J(lk_smem &S, const unsigned char *J, int W, int H, int pitch, int jx0, int jy0,
                                            int lane) {
-    const int r  = lane >> 1;
-    const int c0 = (lane & 1) * 16;
-    const unsigned char *row = J + (size_t) icg_reflect101(jy0 + r, H) * pitch;
-    unsigned int *dst        = &S.J[(r * LK_JS + c0) >> 2];
-#pragma unroll
-    for (int q = 0; q < 4; q++) dst[q] = lk_load4(row, jx0 + c0 + 4 * q, W);
+    unsigned int v[4];
+    lk_load_J(v, J, W, H, pitch, jx0, jy0, lane);
+    lk_store_J(S, v, lane);
 }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// packed 16-bit helpers (all operands stay inside 16 bits: pixels <= 255, Scharr terms <= 4080, Q14 weights <= 16384)
+__device__ __forceinline__ unsigned int pk_add(unsigned int a, unsigned int b) {
+    return __builtin_bit_cast(unsigned int, (u16x2) (__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned int pk_sub(unsigned int a, unsigned int b) {
+    return __builtin_bit_cast(unsigned int, (u16x2) (__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned int pk_mul(unsigned int a, unsigned short k) {
+    return __builtin_bit_cast(unsigned int, (u16x2) (__builtin_bit_cast(u16x2, a) * k));
+}
+// exact a.lo*b.lo + a.hi*b.hi + c on signed 16-bit halves (v_dot2_i32_i16)
+__device__ __forceinline__ int dot2(unsigned int a, unsigned int b, int c) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+// (lo16(a), lo16(b)) as one packed register
+__device__ __forceinline__ unsigned int pk_lo16(int a, int b) {
+    return __builtin_amdgcn_perm((unsigned int) b, (unsigned int) a, 0x05040100u);
+}
+// the pair one 16-bit element further: (a.hi, b.lo)
+__device__ __forceinline__ unsigned int pk_shift(unsigned int a, unsigned int b) { return __builtin_amdgcn_alignbit(b, a, 16); }
+
 // the lane's two 8-pixel rows of the window at integer position (inx, iny), from the staged tile (3 aligned dwords + a
-// byte funnel shift per row)
-__device__ __forceinline__ void lk_fetch_J(const lk_smem &S, int row0, int o, unsigned int &a0, unsigned int &a1,
-                                           unsigned int &b0, unsigned int &b1) {
+// byte funnel shift per row), expanded to the 7 horizontally adjacent u16 pixel pairs the bilinear blend consumes
+__device__ __forceinline__ void lk_fetch_J(const lk_smem &S, int row0, int o, unsigned int (&JA)[7], unsigned int (&JB)[7]) {
     const int idx = o >> 2, sh = o & 3;
     const unsigned int *r0 = &S.J[(row0 * LK_JS >> 2) + idx];
     const unsigned int *r1 = r0 + (LK_JS >> 2);
     const unsigned int d0 = r0[0], d1 = r0[1], d2 = r0[2];
     const unsigned int e0 = r1[0], e1 = r1[1], e2 = r1[2];
-    a0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    a1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    b0 = __builtin_amdgcn_alignbyte(e1, e0, sh);
-    b1 = __builtin_amdgcn_alignbyte(e2, e1, sh);
+    const unsigned int a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    const unsigned int b0 = __builtin_amdgcn_alignbyte(e1, e0, sh), b1 = __builtin_amdgcn_alignbyte(e2, e1, sh);
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const unsigned int sel = 0x0c000c00u | (unsigned int) k | ((unsigned int) (k + 1) << 16); // (byte k, 0, byte k+1, 0)
+        JA[k] = __builtin_amdgcn_perm(a1, a0, sel);
+        JB[k] = __builtin_amdgcn_perm(b1, b0, sel);
+    }
 }
 
 // One calcOpticalFlowPyrLK point, executed cooperatively by a full wave. Returns status.
@@ -159,71 +248,116 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
         }
         int w00, w01, w10, w11;
         lk_weights(prevx - ipx, prevy - ipy, w00, w01, w10, w11);
+        unsigned int W0 = pk_lo16(w00, w01), W1 = pk_lo16(w10, w11);
 
-        // ---- stage the 24x24 neighbourhood of the previous image (tile (r,c) <-> image (ipx-1+c, ipy-1+r)) ----
-        __syncthreads(); // previous level's LDS readers are done
-        for (int i = lane; i < LK_IT * 6; i += 64) {
-            const int r = i / 6, cd = i - r * 6;
-            const unsigned char *row = I + (size_t) icg_reflect101(ipy - 1 + r, H) * pitch;
-            S.I[(r * LK_IS >> 2) + cd] = lk_load4(row, ipx - 1 + 4 * cd, W);
+        // ---- stage the 24x24 neighbourhood of the previous image AND the 32x32 tile of the next image around the
+        //      level's starting estimate in one go (both address sets are known here) ----
+        int jx0 = -1000000, jy0 = -1000000;
+        {
+            const int inx0 = (int) floorf(nptx - (float) ICG_LK_HALF), iny0 = (int) floorf(npty - (float) ICG_LK_HALF);
+            const bool jok = !(inx0 < -ICG_LK_WIN || inx0 >= W || iny0 < -ICG_LK_WIN || iny0 >= H); // else iteration 0 bails out
+            unsigned int vi[3], vj[4] = {0, 0, 0, 0};
+            lk_load_I(vi, I, W, H, pitch, ipx, ipy, lane);
+            if (jok) {
+                jx0 = inx0 - LK_JM;
+                jy0 = iny0 - LK_JM;
+                lk_load_J(vj, J, W, H, pitch, jx0, jy0, lane);
+            }
+            __syncthreads(); // previous level's LDS readers are done
+            lk_store_I(S, vi, lane);
+            if (jok) lk_store_J(S, vj, lane);
+            __syncthreads();
         }
-        __syncthreads();
 
         // ---- per lane: 4 rows x 10 bytes -> I samples and on-the-fly Scharr derivatives of its 7-pixel run ----
-        int iv[7], ix[7], iy[7];
-        int sA11 = 0, sA12 = 0, sA22 = 0;
+        // c0[k] = 256 - 512*Ival[k]: the patch sample folded into the rounding constant of the J blend, so that
+        //         diff = ((Jblend + 256) >> 9) - Ival == (Jblend + c0) >> 9 exactly (Ival is an integer)
+        // IXP/IYP: the derivative samples as packed i16 pairs (k, k+1), k = 0,2,4,6 (upper half of the last pair is 0)
+        int c0[7];
+        unsigned int IXP[4], IYP[4];
+        int sA11, sA12, sA22;
         {
-            // rows ly..ly+3, byte columns lx0..lx0+9 of the tile
             const int idx = lx0 >> 2, sh = lx0 & 3;
-            unsigned int wv[4][3];
+            unsigned int Pp[4][5]; // pixel pairs (col 2m, 2m+1) of tile rows ly..ly+3, cols lx0..lx0+9
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const unsigned int *p = &S.I[((ly + r) * LK_IS >> 2) + idx];
                 const unsigned int d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-                wv[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
-                wv[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
-                wv[r][2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                const unsigned int b0 = __builtin_amdgcn_alignbyte(d1, d0, sh), b1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                const unsigned int b2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                Pp[r][0] = __builtin_amdgcn_perm(0u, b0, 0x0c010c00u);
+                Pp[r][1] = __builtin_amdgcn_perm(0u, b0, 0x0c030c02u);
+                Pp[r][2] = __builtin_amdgcn_perm(0u, b1, 0x0c010c00u);
+                Pp[r][3] = __builtin_amdgcn_perm(0u, b1, 0x0c030c02u);
+                Pp[r][4] = __builtin_amdgcn_perm(0u, b2, 0x0c010c00u);
             }
-#define LK_T(r, j) lk_byte(wv[r][(j) >> 2], (j) &3)
-            // derivative at support position (c = lx0+j, r = ly+rr): 3x3 neighbourhood = tile rows rr..rr+2, cols j..j+2
-            int dxv[2][8], dyv[2][8];
+            // derivative at support position (c = lx0+j, r = ly+rr): 3x3 neighbourhood = tile rows rr..rr+2, cols j..j+2.
+            // The derivative plane is ZERO outside the image: X = ipx+lx0+j in [0,W), Y = ipy+ly+rr in [0,H).
+            const bool all_in = ipx >= 0 && ipx + 22 <= W && ipy >= 0 && ipy + 22 <= H; // wave-uniform fast path
+            unsigned int CM[4] = {~0u, ~0u, ~0u, ~0u};
+            if (!all_in) {
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
-                const int Y = ipy + ly + rr;
-                const bool yin = Y >= 0 && Y < H;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const int X = ipx + lx0 + j;
-                    const int p00 = LK_T(rr, j), p01 = LK_T(rr, j + 1), p02 = LK_T(rr, j + 2);
-                    const int p10 = LK_T(rr + 1, j), p12 = LK_T(rr + 1, j + 2);
-                    const int p20 = LK_T(rr + 2, j), p21 = LK_T(rr + 2, j + 1), p22 = LK_T(rr + 2, j + 2);
-                    const int t0m = 3 * (p00 + p20) + 10 * p10;
-                    const int t0p = 3 * (p02 + p22) + 10 * p12;
-                    const int t1m = p20 - p00, t1c = p21 - p01, t1p = p22 - p02;
-                    const bool in = yin && X >= 0 && X < W; // derivative plane is ZERO outside the image
-                    dxv[rr][j]    = in ? (t0p - t0m) : 0;
-                    dyv[rr][j]    = in ? (3 * (t1m + t1p) + 10 * t1c) : 0;
+                for (int m = 0; m < 4; m++) {
+                    const int X0 = ipx + lx0 + 2 * m, X1 = X0 + 1;
+                    CM[m] = ((X0 >= 0 && X0 < W) ? 0x0000ffffu : 0u) | ((X1 >= 0 && X1 < W) ? 0xffff0000u : 0u);
                 }
             }
+            unsigned int DX[2][4], DY[2][4];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                unsigned int T0[5], T1[5];
+#pragma unroll
+                for (int m = 0; m < 5; m++) {
+                    T0[m] = pk_add(pk_mul(pk_add(Pp[rr][m], Pp[rr + 2][m]), 3), pk_mul(Pp[rr + 1][m], 10)); // 3*(p0+p2) + 10*p1
+                    T1[m] = pk_sub(Pp[rr + 2][m], Pp[rr][m]);                                                // p2 - p0
+                }
+                unsigned int RM = ~0u;
+                if (!all_in) {
+                    const int Y = ipy + ly + rr;
+                    RM          = (Y >= 0 && Y < H) ? ~0u : 0u;
+                }
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    DX[rr][m] = pk_sub(T0[m + 1], T0[m]);                                                       // t0[j+2] - t0[j]
+                    DY[rr][m] = pk_add(pk_mul(pk_add(T1[m], T1[m + 1]), 3), pk_mul(pk_shift(T1[m], T1[m + 1]), 10)); // 3*(t1[j]+t1[j+2]) + 10*t1[j+1]
+                    if (!all_in) {
+                        DX[rr][m] &= CM[m] & RM;
+                        DY[rr][m] &= CM[m] & RM;
+                    }
+                }
+            }
+            int ix[7], iy[7];
 #pragma unroll
             for (int k = 0; k < 7; k++) {
-                const int a0 = LK_T(1, k + 1), b0 = LK_T(1, k + 2), a1 = LK_T(2, k + 1), b1 = LK_T(2, k + 2);
-                iv[k] = lk_descale(__mul24(a0, w00) + __mul24(b0, w01) + __mul24(a1, w10) + __mul24(b1, w11), 14 - 5);
-                ix[k] = lk_descale(__mul24(dxv[0][k], w00) + __mul24(dxv[0][k + 1], w01) + __mul24(dxv[1][k], w10) + __mul24(dxv[1][k + 1], w11), 14);
-                iy[k] = lk_descale(__mul24(dyv[0][k], w00) + __mul24(dyv[0][k + 1], w01) + __mul24(dyv[1][k], w10) + __mul24(dyv[1][k + 1], w11), 14);
+                const int m = k >> 1;
+                // (v[k], v[k+1]) pairs of the two derivative rows and of tile rows 1, 2 at columns k+1, k+2
+                const unsigned int dx0 = (k & 1) ? pk_shift(DX[0][m], DX[0][m + 1]) : DX[0][m];
+                const unsigned int dx1 = (k & 1) ? pk_shift(DX[1][m], DX[1][m + 1]) : DX[1][m];
+                const unsigned int dy0 = (k & 1) ? pk_shift(DY[0][m], DY[0][m + 1]) : DY[0][m];
+                const unsigned int dy1 = (k & 1) ? pk_shift(DY[1][m], DY[1][m + 1]) : DY[1][m];
+                const int m1 = (k + 1) >> 1;
+                const unsigned int i1 = ((k + 1) & 1) ? pk_shift(Pp[1][m1], Pp[1][m1 + 1]) : Pp[1][m1];
+                const unsigned int i2 = ((k + 1) & 1) ? pk_shift(Pp[2][m1], Pp[2][m1 + 1]) : Pp[2][m1];
+                ix[k]        = dot2(dx1, W1, dot2(dx0, W0, 1 << 13)) >> 14;
+                iy[k]        = dot2(dy1, W1, dot2(dy0, W0, 1 << 13)) >> 14;
+                const int iv = dot2(i2, W1, dot2(i1, W0, 1 << 8)) >> 9;
+                c0[k]        = 256 - 512 * iv;
                 if (!active) {
-                    iv[k] = 0;
                     ix[k] = 0;
                     iy[k] = 0;
                 }
-                sA11 += __mul24(ix[k], ix[k]);
-                sA12 += __mul24(ix[k], iy[k]);
-                sA22 += __mul24(iy[k], iy[k]);
             }
-#undef LK_T
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                IXP[m] = pk_lo16(ix[2 * m], m < 3 ? ix[2 * m + 1] : 0);
+                IYP[m] = pk_lo16(iy[2 * m], m < 3 ? iy[2 * m + 1] : 0);
+            }
+            sA11 = dot2(IXP[3], IXP[3], dot2(IXP[2], IXP[2], dot2(IXP[1], IXP[1], dot2(IXP[0], IXP[0], 0))));
+            sA12 = dot2(IXP[3], IYP[3], dot2(IXP[2], IYP[2], dot2(IXP[1], IYP[1], dot2(IXP[0], IYP[0], 0))));
+            sA22 = dot2(IYP[3], IYP[3], dot2(IYP[2], IYP[2], dot2(IYP[1], IYP[1], dot2(IYP[0], IYP[0], 0))));
         }
-        const long long iA11 = wave_sum_i32x16(sA11), iA12 = wave_sum_i32x16(sA12), iA22 = wave_sum_i32x16(sA22);
-        const float A11 = (float) iA11 * FLT_SCALE, A12 = (float) iA12 * FLT_SCALE, A22 = (float) iA22 * FLT_SCALE;
+        const float A11 = wave_sum_i32x16_f32(sA11) * FLT_SCALE, A12 = wave_sum_i32x16_f32(sA12) * FLT_SCALE;
+        const float A22 = wave_sum_i32x16_f32(sA22) * FLT_SCALE;
         float D            = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float) (2 * ICG_LK_WIN * ICG_LK_WIN);
         if (minEig < 1e-4f || D < FLT_EPSILON) {
@@ -234,9 +368,10 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
         nptx -= (float) ICG_LK_HALF;
         npty -= (float) ICG_LK_HALF;
         float pdx = 0.f, pdy = 0.f;
-        int jx0 = -1000000, jy0 = -1000000;
-        int cinx = -1000000, ciny = -1000000;     // integer window position whose bytes are cached in ja/jb
-        unsigned int ja0 = 0, ja1 = 0, jb0 = 0, jb1 = 0; // the lane's 2 x 8 bytes of the next image
+        int cinx = -1000000, ciny = -1000000; // integer window position whose pixel pairs are cached in JA/JB
+        unsigned int JA[7], JB[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) JA[k] = JB[k] = 0;
 
         for (int j = 0; j < LK_MAX_ITERS; j++) {
             const int inx = (int) floorf(nptx), iny = (int) floorf(npty);
@@ -252,22 +387,24 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                     lk_stage_J(S, J, W, H, pitch, jx0, jy0, lane);
                     __syncthreads();
                 }
-                lk_fetch_J(S, iny - jy0 + ly, (inx - jx0) + lx0, ja0, ja1, jb0, jb1);
+                lk_fetch_J(S, iny - jy0 + ly, (inx - jx0) + lx0, JA, JB);
                 cinx = inx;
                 ciny = iny;
             }
             lk_weights(nptx - inx, npty - iny, w00, w01, w10, w11);
+            W0 = pk_lo16(w00, w01);
+            W1 = pk_lo16(w10, w11);
+            int diff[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) diff[k] = dot2(JB[k], W1, dot2(JA[k], W0, c0[k])) >> 9;
             int sb1 = 0, sb2 = 0;
 #pragma unroll
-            for (int k = 0; k < 7; k++) {
-                const int a0 = lk_byte(k < 4 ? ja0 : ja1, k & 3), b0 = lk_byte(k + 1 < 4 ? ja0 : ja1, (k + 1) & 3);
-                const int a1 = lk_byte(k < 4 ? jb0 : jb1, k & 3), b1 = lk_byte(k + 1 < 4 ? jb0 : jb1, (k + 1) & 3);
-                const int diff = lk_descale(__mul24(a0, w00) + __mul24(b0, w01) + __mul24(a1, w10) + __mul24(b1, w11), 14 - 5) - iv[k];
-                sb1 += __mul24(diff, ix[k]);
-                sb2 += __mul24(diff, iy[k]);
+            for (int m = 0; m < 4; m++) {
+                const unsigned int dp = m < 3 ? pk_lo16(diff[2 * m], diff[2 * m + 1]) : (unsigned int) diff[6]; // IXP[3].hi == 0
+                sb1 = dot2(dp, IXP[m], sb1);
+                sb2 = dot2(dp, IYP[m], sb2);
             }
-            const long long ib1 = wave_sum_i32x8(sb1), ib2 = wave_sum_i32x8(sb2);
-            const float b1 = (float) ib1 * FLT_SCALE, b2 = (float) ib2 * FLT_SCALE;
+            const float b1 = wave_sum_i32x8_f32(sb1) * FLT_SCALE, b2 = wave_sum_i32x8_f32(sb2) * FLT_SCALE;
             const float dx = (float) ((A12 * b2 - A22 * b1) * D);
             const float dy = (float) ((A12 * b1 - A11 * b2) * D);
             nptx += dx;
@@ -300,20 +437,19 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                         lk_stage_J(S, J, W, H, pitch, jx0, jy0, lane);
                         __syncthreads();
                     }
-                    lk_fetch_J(S, iny - jy0 + ly, (inx - jx0) + lx0, ja0, ja1, jb0, jb1);
+                    lk_fetch_J(S, iny - jy0 + ly, (inx - jx0) + lx0, JA, JB);
                 }
                 lk_weights(ex - inx, ey - iny, w00, w01, w10, w11);
+                W0 = pk_lo16(w00, w01);
+                W1 = pk_lo16(w10, w11);
                 int se = 0;
 #pragma unroll
                 for (int k = 0; k < 7; k++) {
-                    const int a0 = lk_byte(k < 4 ? ja0 : ja1, k & 3), b0 = lk_byte(k + 1 < 4 ? ja0 : ja1, (k + 1) & 3);
-                    const int a1 = lk_byte(k < 4 ? jb0 : jb1, k & 3), b1 = lk_byte(k + 1 < 4 ? jb0 : jb1, (k + 1) & 3);
-                    int diff = lk_descale(__mul24(a0, w00) + __mul24(b0, w01) + __mul24(a1, w10) + __mul24(b1, w11), 14 - 5) - iv[k];
+                    int diff = dot2(JB[k], W1, dot2(JA[k], W0, c0[k])) >> 9;
                     if (!active) diff = 0;
                     se += diff < 0 ? -diff : diff;
                 }
-                const long long ie = wave_sum_i32x16(se);
-                errv               = (float) ie * 1.f / (float) (32 * ICG_LK_WIN * ICG_LK_WIN);
+                errv = wave_sum_i32x16_f32(se) * 1.f / (float) (32 * ICG_LK_WIN * ICG_LK_WIN);
             }
         }
     }
@@ -350,9 +486,22 @@ __global__ __launch_bounds__(64) void k_lk_track_fb(icg_pyr_desc P, int n, const
     const unsigned char *sN = P.base + (size_t) next_slot[i] * P.slot_bytes;
     const float2 p0 = prev_pts[i];
     float2 fwd      = guess_pts[i];
-    const bool st_f = lk_track_wave(P, sP, sN, p0, fwd, S, lane, nullptr);
     float2 bwd      = p0;
-    const bool st_b = lk_track_wave(P, sN, sP, fwd, bwd, S, lane, nullptr);
+    bool st_f = false, st_b = false;
+    // forward then backward through ONE copy of the tracker body (16 KB of code instead of 32 KB in the shared I-cache)
+    for (int dir = 0; dir < 2; dir++) {
+        const unsigned char *a = dir ? sN : sP, *b = dir ? sP : sN;
+        const float2 from      = dir ? fwd : p0;
+        float2 io              = dir ? bwd : fwd;
+        const bool st          = lk_track_wave(P, a, b, from, io, S, lane, nullptr);
+        if (dir) {
+            bwd  = io;
+            st_b = st;
+        } else {
+            fwd  = io;
+            st_f = st;
+        }
+    }
     if (lane == 0) {
         // isOnBorder (tracking.cc:847-849) and ptsDistance (tracking.cc:841-845)
         const bool border = (double) fwd.x < 5.0 || (double) fwd.y < 5.0 || ((double) fwd.x > (img_w - 5.0)) ||

@@ -2,7 +2,12 @@ import os
 import subprocess
 import sys
 
+import os
+
 import pytest
+
+# host layer self-check: carried undistorted coordinates are re-derived on the host and compared bit for bit
+os.environ.setdefault("ICG_HOST_CHECK", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ic-gvins_amd"))
