@@ -23,7 +23,7 @@ import time
 import numpy as np
 
 # Each stream group owns a HIP stream; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of
-# streams that share a queue serialise.  8 queues measured best on MI355X for 16 groups.
+# streams that share a queue serialise.  16 queues measured best on MI355X for 32 groups.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -96,6 +96,7 @@ def main():
                     help="stream groups per GPU (own HIP stream + host thread each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproj", action="store_true")
+    ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event pass (used under rocprofv3 --pmc)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -207,13 +208,15 @@ def main():
     # ---- profiled pass (HIP events on the ABI stream) for the roofline of the dominant kernel -------------------------
     roofline = None
     kernel_table = {}
-    if rank == 0:
+    if rank == 0 and not args.no_profile_pass:
         for c in ctx_all:
             hip.icg_prof_enable(c, 1)
         nprof = min(20, max(8, args.steps // 2))
+        sb.counters(reset=True)
         run_prepared(nprof, prepare_steps(k, nprof))  # same free-running groups as the timed region, HIP events on
         k += nprof
         torch.cuda.synchronize()
+        work = sb.counters(reset=True)
         for c in ctx_all:
             names = C.create_string_buffer(4096)
             hip.icg_prof_names(c, names, 4096)
@@ -232,15 +235,31 @@ def main():
         if kernel_table:
             dom = max(kernel_table, key=lambda kk: kernel_table[kk]["total_ms"])
             avg_s = kernel_table[dom]["avg_us"] * 1e-6
-            # points per LK launch: every stream contributes its tracked map points + reference points (~features)
             per_launch_streams = B / float(len(ctx_all))  # each group launches for its own streams
-            pts = max(1.0, total_tracked / max(1.0, total_frames)) * per_launch_streams * 1.25
+            pts = work["lk_points"] / max(1, work["lk_calls"])  # exact: points handed to icg_lk_track_fb per call
             ab = algorithmic_bytes(dom, w, h, per_launch_streams, pts)
             if ab is not None and avg_s > 0:
                 ach = ab / avg_s / 1e9
                 roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-                            "algorithmic_bytes_per_launch": int(ab), "avg_launch_us": kernel_table[dom]["avg_us"]}
+                            "algorithmic_bytes_per_launch": int(ab), "avg_launch_us": kernel_table[dom]["avg_us"],
+                            "units_per_launch": round(pts, 1) if dom == "lk_track_fb" else per_launch_streams,
+                            "launch_concurrency": "launches of %d stream groups overlap on the GPU; avg_launch_us is the "
+                                                  "HIP-event duration of one launch while the others run" % len(ctx_all)}
+                # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (profiles/collect.sh):
+                # bytes per unit x the units of one launch here
+                pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+                if os.path.exists(pmc_path):
+                    pmc = json.load(open(pmc_path)).get("k_" + dom)
+                    if pmc and "hbm_bytes_per_launch" in pmc and dom == "lk_track_fb":
+                        per_point = pmc["hbm_bytes_per_launch"] / (pmc["grid_threads"] / 64.0)
+                        roofline["traffic"] = int(per_point * pts)
+                        roofline["traffic_source"] = ("profiles/r01_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) per point "
+                                                      "x points per launch (gfx950 correction of MI355X_MICROARCH.md)")
+                if dom == "lk_track_fb":
+                    roofline["note"] = ("LK keeps its working set in LDS/VGPRs by design (8.5 KB of image per point, ~6k VALU "
+                                        "instructions on it): it is instruction-issue bound (rocprofv3 SQ_ACTIVE_INST_ANY ~89% "
+                                        "of SIMD cycles, profiles/r01_lk_pmc.md), not HBM bound")
             else:
                 roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                             "traffic": None}

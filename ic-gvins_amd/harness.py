@@ -155,6 +155,12 @@ class StreamBatch:
         keys = ["frames", "keyframes", "tracked_sum", "digest", "mappoints_created", "window_keyframes", "landmarks", "last_state"]
         return dict(zip(keys, [int(v) for v in out]))
 
+    def counters(self, reset=True):
+        out = np.zeros(8, np.uint64)
+        self.lib.icgh_batch_counters(C.c_void_p(self.h_), out.ctypes.data_as(C.c_void_p), 1 if reset else 0)
+        keys = ["lk_points", "lk_calls", "detect_jobs", "detect_calls", "ransac_sets", "ransac_calls", "frames", "tri_points"]
+        return dict(zip(keys, [int(v) for v in out]))
+
     def timing(self, reset=True):
         out = np.zeros(5, np.float64)
         self.lib.icgh_batch_timing(C.c_void_p(self.h_), out.ctypes.data_as(C.c_void_p), 1 if reset else 0)

@@ -122,6 +122,18 @@ int icgh_batch_timing(icgh_batch *b, double *out5, int reset) {
     return 0;
 }
 
+// work counters summed over the groups (see TrackingBatch::counters); reset != 0 clears them
+int icgh_batch_counters(icgh_batch *b, uint64_t *out8, int reset) {
+    if (!b) return -1;
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    for (int g = 0; g < b->tb->groups(); g++)
+        for (int i = 0; i < 8; i++) {
+            out8[i] += b->tb->group(g).counters[i];
+            if (reset) b->tb->group(g).counters[i] = 0;
+        }
+    return 0;
+}
+
 int icgh_batch_timing_group(icgh_batch *b, int g, double *out5) {
     if (!b || g < 0 || g >= b->tb->groups()) return -1;
     for (int i = 0; i < 5; i++) out5[i] = b->tb->group(g).timing[i];

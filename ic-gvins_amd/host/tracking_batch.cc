@@ -234,6 +234,20 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
         t1 = now_s();
         timing[1] += t1 - t0;
         t0 = t1;
+        if (!global.lk_prev_slot.empty()) {
+            counters[0] += global.lk_prev_slot.size();
+            counters[1]++;
+        }
+        if (!global.det_slots.empty()) {
+            counters[2] += global.det_slots.size();
+            counters[3]++;
+        }
+        if (global.rs_off.size() > 1) {
+            counters[4] += global.rs_off.size() - 1;
+            counters[5]++;
+        }
+        counters[6] += global.pre_slots.size();
+        counters[7] += global.tri_T0.size();
         device_->execute(global, grid_, max_per_job_);
         t1 = now_s();
         timing[2] += t1 - t0;

@@ -62,6 +62,9 @@ public:
     // wall-clock breakdown of step(): [0] begin+advance (host logic), [1] gather, [2] device execute, [3] scatter,
     // [4] finalize (digest + window keeper); seconds, accumulated
     double timing[5]{0, 0, 0, 0, 0};
+    // work counters of the batched device calls: [0] LK points, [1] LK calls, [2] detection jobs, [3] detection calls,
+    // [4] RANSAC point sets, [5] RANSAC calls, [6] preprocessed frames, [7] triangulated points
+    uint64_t counters[8]{0, 0, 0, 0, 0, 0, 0, 0};
 
 private:
     void gather(int cur, StageBatch &global, vector<std::array<int, 8>> &bases);

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Per-kernel averages of rocprofv3 --pmc passes (counter_collection.csv under each given directory).
+
+Output JSON: {kernel: {"launches": n, "<COUNTER>": mean per launch, "grid_threads": mean grid size, ...}}.
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; "hbm_bytes_per_launch" applies the gfx950 correction of
+MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B request: doubled; WRITE_SIZE taken as is, uncalibrated)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def main(dirs):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.Counter())
+    grid = collections.defaultdict(list)
+    for d in dirs:
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"].split("(")[0]
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                cnt[k][r["Counter_Name"]] += 1
+                grid[k].append(int(r["Grid_Size"]))
+    out = {}
+    for k in sorted(acc):
+        e = {}
+        for c, v in acc[k].items():
+            e[c] = v / cnt[k][c]
+            e.setdefault("launches", cnt[k][c])
+        e["grid_threads"] = sum(grid[k]) / len(grid[k])
+        if "FETCH_SIZE" in e or "WRITE_SIZE" in e:
+            e["hbm_bytes_per_launch"] = 2.0 * 1024.0 * e.get("FETCH_SIZE", 0.0) + 1024.0 * e.get("WRITE_SIZE", 0.0)
+        out[k] = e
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

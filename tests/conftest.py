@@ -2,8 +2,6 @@ import os
 import subprocess
 import sys
 
-import os
-
 import pytest
 
 # host layer self-check: carried undistorted coordinates are re-derived on the host and compared bit for bit
