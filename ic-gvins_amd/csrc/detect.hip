@@ -12,7 +12,7 @@
 //   k_mask_discs  one workgroup per existing feature: midpoint-circle span table -> zero spans in the u8 mask
 //   k_min_eig     32x8 response tile per workgroup; (34x10) covariance halo in LDS; per-ROI masked maximum by an
 //                 order-preserving uint atomicMax
-//   k_candidates  threshold + 3x3 NMS + mask -> (key = response bits << 32 | raster index) appended per ROI
+//   k_candidates  threshold + 3x3 NMS + mask, 4 rows per lane -> (key = response bits << 32 | raster index) appended per ROI
 //   k_select      one workgroup per ROI: repeated block-wide arg-max over live candidates + min-distance kill
 //                 (equivalent to sort + greedy grid test, needs no sort and no capacity cap)
 //   k_subpix      one wavefront per corner: 13x13 bilinear patch and the 121 gradient terms in parallel through LDS,
@@ -35,22 +35,32 @@ __device__ __forceinline__ float f32_from_order_key(unsigned int k) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mask_discs(int n_pts, const float2 *pts, const int32_t *pt_job, int radius,
-                                                    const int32_t *halfw /*radius+1*/, uint8_t *mask, int pitch, int w,
-                                                    int h, size_t plane) {
+// The mask plane is GENERATION-TAGGED: a pixel is masked in this call iff mask[p] == gen (gen cycles 1..255 per context;
+// the plane is cleared only when gen wraps).  This removes the 0.9 MB-per-frame memset launch of the 255/0 formulation.
+// One 64-lane workgroup per existing feature; each lane fills whole rows of the midpoint-circle span table with
+// dword stores (head/tail bytes) instead of testing every pixel of the bounding square.
+__global__ __launch_bounds__(64) void k_mask_discs(int n_pts, const float2 *pts, const int32_t *pt_job, int radius,
+                                                   const int32_t *halfw /*radius+1*/, uint8_t *mask, int pitch, int w,
+                                                   int h, size_t plane, unsigned int gen) {
     const int i = blockIdx.x;
     if (i >= n_pts) return;
     const float2 p = pts[i];
     const int cx = (int) rintf(p.x), cy = (int) rintf(p.y);
     uint8_t *m   = mask + (size_t) pt_job[i] * plane;
-    const int side = 2 * radius + 1;
-    for (int t = threadIdx.x; t < side * side; t += 256) {
-        int r = t / side, c = t - r * side;
-        int dy = r - radius, dx = c - radius;
-        int hw = halfw[dy < 0 ? -dy : dy];
-        int ax = dx < 0 ? -dx : dx;
-        int x = cx + dx, y = cy + dy;
-        if (ax <= hw && x >= 0 && x < w && y >= 0 && y < h) m[(size_t) y * pitch + x] = 0;
+    const unsigned int g4 = gen * 0x01010101u;
+    for (int r = threadIdx.x; r <= 2 * radius; r += 64) {
+        const int dy = r - radius, y = cy + dy;
+        if (y < 0 || y >= h) continue;
+        const int hw = halfw[dy < 0 ? -dy : dy];
+        if (hw < 0) continue;
+        int x0 = cx - hw, x1 = cx + hw; // inclusive span
+        if (x0 < 0) x0 = 0;
+        if (x1 > w - 1) x1 = w - 1;
+        uint8_t *row = m + (size_t) y * pitch;
+        int x = x0;
+        for (; x <= x1 && (x & 3); x++) row[x] = (uint8_t) gen;
+        for (; x + 3 <= x1; x += 4) *reinterpret_cast<unsigned int *>(row + x) = g4; // pitch % 128 == 0: aligned
+        for (; x <= x1; x++) row[x] = (uint8_t) gen;
     }
 }
 
@@ -60,9 +70,11 @@ __global__ __launch_bounds__(256) void k_mask_discs(int n_pts, const float2 *pts
 
 __global__ __launch_bounds__(256) void k_min_eig(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
                                                  const int32_t *slots, int pitch, int w, int h, const uint8_t *mask,
-                                                 size_t mask_plane, float *eig, size_t eig_plane,
+                                                 size_t mask_plane, unsigned int gen, float *eig, size_t eig_plane,
                                                  unsigned int *roi_max) {
-    __shared__ float cxx[EIG_TH + 2][EIG_TW + 2], cxy[EIG_TH + 2][EIG_TW + 2], cyy[EIG_TH + 2][EIG_TW + 2];
+    // covariance products as doubles: the 3x3 box sums below accumulate in double (raster order), so the conversion is
+    // done once per halo entry instead of nine times per pixel
+    __shared__ double cxx[EIG_TH + 2][EIG_TW + 2], cxy[EIG_TH + 2][EIG_TW + 2], cyy[EIG_TH + 2][EIG_TW + 2];
     __shared__ unsigned int wmax[4];
     const det_roi R = rois[blockIdx.z];
     const int tx0 = blockIdx.x * EIG_TW, ty0 = blockIdx.y * EIG_TH;
@@ -70,24 +82,36 @@ __global__ __launch_bounds__(256) void k_min_eig(const det_roi *rois, const uint
     const uint8_t *img = frames + (size_t) slots[R.job] * slot_bytes;
     const float s      = (float) (1.0 / 3060.0);
     const int t        = threadIdx.x;
+    // workgroup-uniform: the covariance halo lies inside the ROI and its Sobel support inside the image -> no reflections
+    const bool interior = tx0 >= 1 && tx0 + EIG_TW <= R.rw - 1 && ty0 >= 1 && ty0 + EIG_TH <= R.rh - 1 && R.rx + tx0 >= 2 &&
+                          R.rx + tx0 + EIG_TW + 1 <= w - 1 && R.ry + ty0 >= 2 && R.ry + ty0 + EIG_TH + 1 <= h - 1;
     for (int i = t; i < (EIG_TH + 2) * (EIG_TW + 2); i += 256) {
-        int r = i / (EIG_TW + 2), c = i - r * (EIG_TW + 2);
-        // ROI coordinate with reflect-101 at the ROI edge (cov is a fresh ROI-sized Mat in OpenCV)
-        int x = icg_reflect101(tx0 - 1 + c, R.rw), y = icg_reflect101(ty0 - 1 + r, R.rh);
-        int X = R.rx + x, Y = R.ry + y;
-        // Sobel on REAL image pixels (peeks outside the ROI); reflect-101 only at true image borders
-        int xm = icg_reflect101(X - 1, w), xp = icg_reflect101(X + 1, w);
-        int ym = icg_reflect101(Y - 1, h), yp = icg_reflect101(Y + 1, h);
-        const uint8_t *r0 = img + (size_t) ym * pitch, *r1 = img + (size_t) Y * pitch, *r2 = img + (size_t) yp * pitch;
-        int p00 = r0[xm], p01 = r0[X], p02 = r0[xp];
-        int p10 = r1[xm], p12 = r1[xp];
-        int p20 = r2[xm], p21 = r2[X], p22 = r2[xp];
-        int gx = (p02 - p00) + 2 * (p12 - p10) + (p22 - p20);
-        int gy = (p20 - p00) + 2 * (p21 - p01) + (p22 - p02);
-        float dx = (float) gx * s, dy = (float) gy * s;
-        cxx[r][c] = dx * dx;
-        cxy[r][c] = dx * dy;
-        cyy[r][c] = dy * dy;
+        const int r = i / (EIG_TW + 2), c = i - r * (EIG_TW + 2);
+        int p00, p01, p02, p10, p12, p20, p21, p22;
+        if (interior) {
+            const uint8_t *r1 = img + (size_t) (R.ry + ty0 - 1 + r) * pitch + (R.rx + tx0 - 1 + c);
+            const uint8_t *r0 = r1 - pitch, *r2 = r1 + pitch;
+            p00 = r0[-1], p01 = r0[0], p02 = r0[1];
+            p10 = r1[-1], p12 = r1[1];
+            p20 = r2[-1], p21 = r2[0], p22 = r2[1];
+        } else {
+            // ROI coordinate with reflect-101 at the ROI edge (cov is a fresh ROI-sized Mat in OpenCV)
+            const int x = icg_reflect101(tx0 - 1 + c, R.rw), y = icg_reflect101(ty0 - 1 + r, R.rh);
+            const int X = R.rx + x, Y = R.ry + y;
+            // Sobel on REAL image pixels (peeks outside the ROI); reflect-101 only at true image borders
+            const int xm = icg_reflect101(X - 1, w), xp = icg_reflect101(X + 1, w);
+            const int ym = icg_reflect101(Y - 1, h), yp = icg_reflect101(Y + 1, h);
+            const uint8_t *r0 = img + (size_t) ym * pitch, *r1 = img + (size_t) Y * pitch, *r2 = img + (size_t) yp * pitch;
+            p00 = r0[xm], p01 = r0[X], p02 = r0[xp];
+            p10 = r1[xm], p12 = r1[xp];
+            p20 = r2[xm], p21 = r2[X], p22 = r2[xp];
+        }
+        const int gx = (p02 - p00) + 2 * (p12 - p10) + (p22 - p20);
+        const int gy = (p20 - p00) + 2 * (p21 - p01) + (p22 - p02);
+        const float dx = (float) gx * s, dy = (float) gy * s;
+        cxx[r][c] = (double) (dx * dx);
+        cxy[r][c] = (double) (dx * dy);
+        cyy[r][c] = (double) (dy * dy);
     }
     __syncthreads();
     const int lx = t & (EIG_TW - 1), ly = t / EIG_TW;
@@ -107,7 +131,7 @@ __global__ __launch_bounds__(256) void k_min_eig(const det_roi *rois, const uint
         float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
         const int X = R.rx + x, Y = R.ry + y;
         eig[(size_t) R.job * eig_plane + (size_t) Y * w + X] = e;
-        if (mask[(size_t) R.job * mask_plane + (size_t) Y * pitch + X]) key = f32_order_key(e);
+        if (mask[(size_t) R.job * mask_plane + (size_t) Y * pitch + X] != (uint8_t) gen) key = f32_order_key(e);
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -123,47 +147,72 @@ __global__ __launch_bounds__(256) void k_min_eig(const det_roi *rois, const uint
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// 4 vertically adjacent pixels per lane (one wave = a 64 x 4 strip, one workgroup = 64 x 16): the 6x3 response values a
+// lane needs are loaded once for its 4 pixels and every load is a fully coalesced row segment.  OpenCV's test
+// "thresholded value equals the 3x3 maximum of the thresholded map" is evaluated as
+// v > thresh && v >= every RAW neighbour  (identical: a neighbour at or below the threshold is below v, a neighbour
+// above it keeps its value).
+#define CAND_PY 4
 __global__ __launch_bounds__(256) void k_candidates(const det_roi *rois, int pitch, int w, const uint8_t *mask,
-                                                    size_t mask_plane, const float *eig, size_t eig_plane,
+                                                    size_t mask_plane, unsigned int gen, const float *eig, size_t eig_plane,
                                                     const unsigned int *roi_max, unsigned long long *cand,
                                                     size_t cand_plane, int32_t *cand_cnt) {
     const det_roi R = rois[blockIdx.z];
     const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    bool is_cand = false;
-    float v      = 0.f;
-    if (!(x < 1 || x >= R.rw - 1 || y < 1 || y >= R.rh - 1)) {
-        const unsigned int mk = roi_max[blockIdx.z];
-        const double maxVal   = mk ? (double) f32_from_order_key(mk) : 0.0;
-        const float thresh    = (float) (maxVal * 0.01);
-        const float *e        = eig + (size_t) R.job * eig_plane + (size_t) (R.ry + y) * w + (R.rx + x);
-        v                     = e[0];
-        v                     = v > thresh ? v : 0.f;
-        if (v != 0.f) {
-            float mx = v;
+    const int x  = blockIdx.x * 64 + lane;
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * CAND_PY;
+    if (y0 >= R.rh - 1) return; // wave-uniform
+    const unsigned int mk = roi_max[blockIdx.z];
+    const double maxVal   = mk ? (double) f32_from_order_key(mk) : 0.0;
+    const float thresh    = (float) (maxVal * 0.01);
+    bool is_cand[CAND_PY];
+    float v[CAND_PY];
 #pragma unroll
-            for (int j = -1; j <= 1; j++)
+    for (int k = 0; k < CAND_PY; k++) {
+        is_cand[k] = false;
+        v[k]       = 0.f;
+    }
+    if (x >= 1 && x < R.rw - 1) {
+        const float *e = eig + (size_t) R.job * eig_plane + (size_t) R.ry * w + (R.rx + x);
+        float a[CAND_PY + 2][3];
 #pragma unroll
-                for (int i = -1; i <= 1; i++) {
-                    float n = e[j * w + i];
-                    n       = n > thresh ? n : 0.f;
-                    mx      = n > mx ? n : mx;
-                }
-            is_cand = (v == mx) && mask[(size_t) R.job * mask_plane + (size_t) (R.ry + y) * pitch + (R.rx + x)];
+        for (int j = 0; j < CAND_PY + 2; j++) {
+            // ROI row y0-1+j; rows outside [0, rh) are never a valid centre's neighbour (clamped load, unused)
+            int yj = y0 - 1 + j;
+            yj     = yj < 0 ? 0 : (yj > R.rh - 1 ? R.rh - 1 : yj);
+            const float *row = e + (size_t) yj * w;
+            a[j][0] = row[-1];
+            a[j][1] = row[0];
+            a[j][2] = row[1];
+        }
+        const uint8_t *mcol = mask + (size_t) R.job * mask_plane + (size_t) R.ry * pitch + (R.rx + x);
+#pragma unroll
+        for (int k = 0; k < CAND_PY; k++) {
+            const int y = y0 + k;
+            if (y < 1 || y >= R.rh - 1) continue;
+            const float c = a[k + 1][1];
+            if (!(c > thresh) || c == 0.f) continue; // THRESH_TOZERO leaves 0 below the threshold, and 0 is never a corner
+            float mx = fmaxf(fmaxf(a[k][0], a[k][1]), a[k][2]);
+            mx       = fmaxf(mx, fmaxf(a[k + 1][0], a[k + 1][2]));
+            mx       = fmaxf(mx, fmaxf(fmaxf(a[k + 2][0], a[k + 2][1]), a[k + 2][2]));
+            v[k]       = c;
+            is_cand[k] = (c >= mx) && mcol[(size_t) y * pitch] != (uint8_t) gen;
         }
     }
-    // wave-aggregated append: one atomic per wavefront instead of one per candidate
-    const unsigned long long m = __ballot(is_cand);
-    if (m == 0) return;
-    int base = 0;
-    const int leader = __ffsll((long long) m) - 1;
-    if (lane == leader) base = atomicAdd(&cand_cnt[blockIdx.z], __popcll(m));
-    base = __shfl(base, leader, 64);
-    if (is_cand) {
-        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-        cand[(size_t) R.job * cand_plane + R.cand_base + slot] =
-            ((unsigned long long) f32_order_key(v) << 32) | (unsigned int) (y * R.rw + x);
+    // wave-aggregated append: one atomic per wavefront and row instead of one per candidate
+#pragma unroll
+    for (int k = 0; k < CAND_PY; k++) {
+        const unsigned long long m = __ballot(is_cand[k]);
+        if (m == 0) continue;
+        int base = 0;
+        const int leader = __ffsll((long long) m) - 1;
+        if (lane == leader) base = atomicAdd(&cand_cnt[blockIdx.z], __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (is_cand[k]) {
+            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            cand[(size_t) R.job * cand_plane + R.cand_base + slot] =
+                ((unsigned long long) f32_order_key(v[k]) << 32) | (unsigned int) ((y0 + k) * R.rw + x);
+        }
     }
 }
 
@@ -343,6 +392,8 @@ static int ensure_detect_ws(icg_ctx *ctx) {
     const size_t w = ctx->cfg.width, h = ctx->cfg.height, nb = ctx->cfg.max_batch;
     ICG_HIP(ctx, hipMalloc((void **) &ctx->d_eig, sizeof(float) * w * h * nb));
     ICG_HIP(ctx, hipMalloc((void **) &ctx->d_mask, (size_t) ctx->lv[0].pitch * h * nb));
+    ICG_HIP(ctx, hipMemsetAsync(ctx->d_mask, 0, (size_t) ctx->lv[0].pitch * h * nb, ctx->stream));
+    ctx->mask_gen = 0;
     ICG_HIP(ctx, hipMalloc((void **) &ctx->d_cand, sizeof(unsigned long long) * w * h * nb));
     return 0;
 }
@@ -411,33 +462,39 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     const int32_t *d_hw    = c.in(hw.data(), hw.size());
     const float2 *d_mpts   = (const float2 *) c.in(mask_pts, 2 * (size_t) n_mask);
     const int32_t *d_ptjob = c.in(pt_job.data(), (size_t) n_mask);
+    // [roi_max | cand_cnt] start at zero: staged with the inputs (rides on the single H2D copy, no memset launch)
+    std::vector<unsigned int> zeros(2 * (size_t) n_roi, 0u);
+    unsigned int *d_rmax = const_cast<unsigned int *>(c.in(zeros.data(), zeros.size()));
+    int32_t *d_ccnt      = (int32_t *) (d_rmax + n_roi);
     if ((rc = c.seal())) return rc;
     std::vector<float> h_corners((size_t) n_roi * max_pb * 2);
     std::vector<int32_t> h_cnt((size_t) n_roi);
     // corners are re-read by k_subpix: keep them in device memory, fetch with the single D2H of finish()
     float2 *d_corners    = (float2 *) c.out(h_corners.data(), (size_t) n_roi * max_pb * 2);
     int32_t *d_cnt       = c.out(h_cnt.data(), (size_t) n_roi);
-    unsigned int *d_rmax = c.out((unsigned int *) nullptr, 2 * (size_t) n_roi); // [roi_max | cand_cnt] zeroed together
-    int32_t *d_ccnt      = (int32_t *) (d_rmax + n_roi);
 
     const size_t mask_plane = (size_t) pitch * h, eig_plane = (size_t) w * h, cand_plane = (size_t) w * h;
-    ICG_HIP(ctx, hipMemsetAsync(ctx->d_mask, 255, mask_plane * n, ctx->stream));
-    ICG_HIP(ctx, hipMemsetAsync(d_rmax, 0, sizeof(unsigned int) * 2 * n_roi, ctx->stream));
+    // mask generation (see k_mask_discs): a full clear only when the 8-bit tag wraps
+    if (++ctx->mask_gen > 255) {
+        ICG_HIP(ctx, hipMemsetAsync(ctx->d_mask, 0, mask_plane * ctx->cfg.max_batch, ctx->stream));
+        ctx->mask_gen = 1;
+    }
+    const unsigned int gen = (unsigned int) ctx->mask_gen;
     if (n_mask > 0) {
         icg_prof_scope ps(ctx, "detect_mask");
-        hipLaunchKernelGGL(k_mask_discs, dim3(n_mask), dim3(256), 0, ctx->stream, n_mask, d_mpts, d_ptjob, grid->min_dist,
-                           d_hw, ctx->d_mask, pitch, w, h, mask_plane);
+        hipLaunchKernelGGL(k_mask_discs, dim3(n_mask), dim3(64), 0, ctx->stream, n_mask, d_mpts, d_ptjob, grid->min_dist,
+                           d_hw, ctx->d_mask, pitch, w, h, mask_plane, gen);
     }
     {
         icg_prof_scope ps(ctx, "detect_min_eig");
         hipLaunchKernelGGL(k_min_eig, dim3((grid->block_w + EIG_TW - 1) / EIG_TW, (grid->block_h + EIG_TH - 1) / EIG_TH, n_roi),
                            dim3(256), 0, ctx->stream, d_rois, ctx->d_frames, ctx->slot_bytes, d_slots, pitch, w, h,
-                           ctx->d_mask, mask_plane, ctx->d_eig, eig_plane, d_rmax);
+                           ctx->d_mask, mask_plane, gen, ctx->d_eig, eig_plane, d_rmax);
     }
     {
         icg_prof_scope ps(ctx, "detect_candidates");
-        hipLaunchKernelGGL(k_candidates, dim3((grid->block_w + 63) / 64, (grid->block_h + 3) / 4, n_roi), dim3(256), 0,
-                           ctx->stream, d_rois, pitch, w, ctx->d_mask, mask_plane, ctx->d_eig, eig_plane, d_rmax, ctx->d_cand,
+        hipLaunchKernelGGL(k_candidates, dim3((grid->block_w + 63) / 64, (grid->block_h + 4 * CAND_PY - 1) / (4 * CAND_PY), n_roi), dim3(256), 0,
+                           ctx->stream, d_rois, pitch, w, ctx->d_mask, mask_plane, gen, ctx->d_eig, eig_plane, d_rmax, ctx->d_cand,
                            cand_plane, d_ccnt);
     }
     {

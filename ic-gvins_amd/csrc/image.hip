@@ -83,6 +83,7 @@ __global__ __launch_bounds__(64) void k_clahe_lut(pre_jobs jobs, clahe_geom g, u
     const int xa  = x_begin & ~3;
     const int ndw = (((x_end + 3) & ~3) - xa) >> 2;
     const int items = g.th * ndw;
+    const unsigned int magic = ((1u << 20) + (unsigned int) ndw - 1u) / (unsigned int) ndw; // i / ndw == (i * magic) >> 20 for i < 43690
     constexpr int CH = 10; // dwords in flight per lane
     for (int base = 0; base < items; base += 64 * CH) {
         unsigned int v[CH];
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(64) void k_clahe_lut(pre_jobs jobs, clahe_geom g, u
             v[k]  = 0;
             xs[k] = -0x40000000;
             if (i < items) {
-                const int r = i / ndw, d = i - r * ndw;
+                const int r = (int) (((unsigned int) i * magic) >> 20), d = i - r * ndw;
                 const int x = xa + 4 * d;
                 const uint8_t *row = src + (size_t) icg_reflect101(y_begin + r, g.h) * stride;
                 xs[k] = x;
@@ -107,10 +108,15 @@ __global__ __launch_bounds__(64) void k_clahe_lut(pre_jobs jobs, clahe_geom g, u
         }
 #pragma unroll
         for (int k = 0; k < CH; k++) {
+            if (xs[k] >= x_begin && xs[k] + 3 < x_end) { // dword entirely inside the tile (all but the row ends)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int xx = xs[k] + j;
-                if (xx >= x_begin && xx < x_end) atomicAdd(&hist[(v[k] >> (8 * j)) & 0xff], 1u);
+                for (int j = 0; j < 4; j++) atomicAdd(&hist[(v[k] >> (8 * j)) & 0xff], 1u);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int xx = xs[k] + j;
+                    if (xx >= x_begin && xx < x_end) atomicAdd(&hist[(v[k] >> (8 * j)) & 0xff], 1u);
+                }
             }
         }
     }
@@ -344,26 +350,34 @@ __device__ __forceinline__ void p3_step(const unsigned int *in, unsigned int *tm
     // Fixed (row, pair) mapping per thread (no per-item division); the 4 inner taps are one v_dot4_u32_u8 each:
     //   h0 = [1 4 6 4].(b2..b5) + b6,   h1 = [1 4 6 4].(b4..b7) + b8     (b0..b11 = bytes of dwords m, m+1, m+2)
     {
-        constexpr int RPP = 256 / TS; // rows per pass
+        constexpr int RPP = 256 / TS, NP = (IH + RPP - 1) / RPP; // rows per pass, passes (fully unrolled: constant offsets)
         const int rr = t / TS, m = t - rr * TS;
         if (rr < RPP) {
-            for (int r = rr; r < IH; r += RPP) {
-                const unsigned int *p = in + r * (IS / 4) + m;
-                const unsigned int d0 = p[0], d1 = p[1], d2 = p[2];
-                const unsigned int lo = __builtin_amdgcn_alignbyte(d1, d0, 2), hi = __builtin_amdgcn_alignbyte(d2, d1, 2);
-                const unsigned int h0 = __builtin_amdgcn_udot4(lo, 0x04060401u, hi & 0xffu, false);
-                const unsigned int h1 = __builtin_amdgcn_udot4(d1, 0x04060401u, (hi >> 16) & 0xffu, false);
-                tmp[r * TS + m] = h0 | (h1 << 16);
+            const unsigned int *pin = in + rr * (IS / 4) + m;
+            unsigned int *pout      = tmp + rr * TS + m;
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                if (rr + k * RPP < IH) {
+                    const unsigned int *p = pin + k * RPP * (IS / 4);
+                    const unsigned int d0 = p[0], d1 = p[1], d2 = p[2];
+                    const unsigned int lo = __builtin_amdgcn_alignbyte(d1, d0, 2), hi = __builtin_amdgcn_alignbyte(d2, d1, 2);
+                    const unsigned int h0 = __builtin_amdgcn_udot4(lo, 0x04060401u, hi & 0xffu, false);
+                    const unsigned int h1 = __builtin_amdgcn_udot4(d1, 0x04060401u, (hi >> 16) & 0xffu, false);
+                    pout[k * RPP * TS] = h0 | (h1 << 16);
+                }
             }
         }
     }
     __syncthreads();
     // vertical pass on packed pairs, 4 output columns per item; (v + 128) >> 8 as in OpenCV's u8 pyrDown
     {
-        constexpr int RPP = 256 / OWQ;
+        constexpr int RPP = 256 / OWQ, NP = (OH + RPP - 1) / RPP;
         const int rr = t / OWQ, q = t - rr * OWQ;
         if (rr < RPP) {
-            for (int r = rr; r < OH; r += RPP) {
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                const int r = rr + k * RPP;
+                if (r >= OH) break;
                 const uint2 *c = reinterpret_cast<const uint2 *>(tmp + (2 * r) * TS + 2 * q);
                 const uint2 t0 = c[0], t1 = c[TS / 2], t2 = c[TS], t3 = c[3 * TS / 2], t4 = c[2 * TS];
                 const unsigned int a = t0.x + t4.x + ((t1.x + t3.x) << 2) + (t2.x << 2) + (t2.x << 1) + 0x00800080u;
