@@ -17,7 +17,7 @@
 //     bytes of it are CACHED IN REGISTERS and re-fetched only when the integer window position changes, so a typical
 //     iteration touches no LDS at all (v1 spent 39% of its wave cycles in LDS issue stalls: rocprofv3 SQ_WAIT_INST_LDS),
 //   * A11/A12/A22 and b1/b2 are per-lane int32 partials (bounded: 7*4080^2 < 2^27, 7*8160*4080 < 2^28) reduced exactly:
-//     DPP butterflies in 32 bits up to 16 / 8 lanes, then exact doubles through row_mirror/row_bcast DPP stages;
+//     DPP butterflies in 32 bits up to 16 / 8 lanes, then 16-bit halves through row_mirror/row_bcast DPP stages;
 //   * the kernel is VALU-issue bound (rocprofv3: ~11k VALU instructions per point in v2), so the integer math is packed:
 //     pixels, Scharr terms and Q14 weights all fit 16 bits -> v_pk_{add,sub,mul_lo}_u16 for the derivative stencil and
 //     v_dot2_i32_i16 for every bilinear blend (2 taps per instruction) and for the window products; the patch sample is
@@ -52,26 +52,27 @@ __device__ __forceinline__ int dpp_add_mirror(int v) { return v + __builtin_amdg
 
 // Exact wave-wide sum of bounded int32 partials, returned as (float) of the exact integer (what the CPU restatement's
 // (float)(int64 sum) produces).  Stages: 32-bit DPP butterflies while the group sums still fit int32 (8 lanes for
-// |partial| <= 2^28, 16 lanes for <= 2^27), then the group sums continue as DOUBLES (exact below 2^53) through
-// row_mirror / row_bcast15 / row_bcast31, lane 63 holds the total, one v_cvt_f32_f64 rounds once (RNE) like i64->f32.
-// No scalar-ALU carry chains: v2 spent a third of its issue slots on s_add/s_addc/s_ashr + the i64->f32 emulation.
-#define LK_DPP_ADD_F64(d, ctrl, rowmask)                                                                                  \
-    (d) + __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(d), (ctrl), (rowmask), 0xF, false),              \
-                           __builtin_amdgcn_update_dpp(0, __double2loint(d), (ctrl), (rowmask), 0xF, false))
-__device__ __forceinline__ float wave_sum_tail_f32(double d) {
-    d = LK_DPP_ADD_F64(d, 0x142, 0xA); // row_bcast15: rows 1,3 += lane 15 of rows 0,2
-    d = LK_DPP_ADD_F64(d, 0x143, 0xC); // row_bcast31: rows 2,3 += lane 31
-    const double total = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), 63), __builtin_amdgcn_readlane(__double2loint(d), 63));
-    return (float) total;
+// |partial| <= 2^28, 16 lanes for <= 2^27); the group sums are then split into a signed high and an unsigned low 16-bit
+// half, which both survive the remaining cross-row stages (row_mirror / row_bcast15 / row_bcast31, one fused
+// v_add_u32_dpp each) without overflow; lane 63 holds both totals, hi*65536 + lo is formed exactly in double and one
+// v_cvt_f32_f64 rounds once (RNE) like i64->f32.  No scalar carry chains, no 64-bit DPP moves.
+__device__ __forceinline__ float wave_sum_tail_f32(int hi, int lo) {
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false); // row_bcast15: rows 1,3 += lane 15 of rows 0,2
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false); // row_bcast31: rows 2,3 += lane 31
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);
+    const int th = __builtin_amdgcn_readlane(hi, 63), tl = __builtin_amdgcn_readlane(lo, 63);
+    return (float) ((double) th * 65536.0 + (double) tl);
 }
 // |per-lane partial| <= 2^28: sums of 8 lanes fit in int32
 __device__ __forceinline__ float wave_sum_i32x8_f32(int v) {
     v = dpp_add_xor1(v);
     v = dpp_add_xor2(v);
     v = dpp_add_half_mirror(v);
-    double d = (double) v;
-    d        = LK_DPP_ADD_F64(d, 0x140, 0xF); // row_mirror
-    return wave_sum_tail_f32(d);
+    int hi = v >> 16, lo = v & 0xffff;
+    hi     = dpp_add_mirror(hi);
+    lo     = dpp_add_mirror(lo);
+    return wave_sum_tail_f32(hi, lo);
 }
 // |per-lane partial| <= 2^27: sums of 16 lanes fit in int32
 __device__ __forceinline__ float wave_sum_i32x16_f32(int v) {
@@ -79,7 +80,7 @@ __device__ __forceinline__ float wave_sum_i32x16_f32(int v) {
     v = dpp_add_xor2(v);
     v = dpp_add_half_mirror(v);
     v = dpp_add_mirror(v);
-    return wave_sum_tail_f32((double) v);
+    return wave_sum_tail_f32(v >> 16, v & 0xffff);
 }
 
 __device__ __forceinline__ int lk_descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
@@ -490,6 +491,12 @@ __global__ __launch_bounds__(64) void k_lk_track_fb(icg_pyr_desc P, int n, const
     bool st_f = false, st_b = false;
     // forward then backward through ONE copy of the tracker body (16 KB of code instead of 32 KB in the shared I-cache)
     for (int dir = 0; dir < 2; dir++) {
+        if (dir) {
+            // the cull of tracking.cc:396-403 needs the backward track only for points that are still alive
+            const bool border = (double) fwd.x < 5.0 || (double) fwd.y < 5.0 || ((double) fwd.x > (img_w - 5.0)) ||
+                                ((double) fwd.y > (img_h - 5.0));
+            if (!st_f || border) break; // wave-uniform
+        }
         const unsigned char *a = dir ? sN : sP, *b = dir ? sP : sN;
         const float2 from      = dir ? fwd : p0;
         float2 io              = dir ? bwd : fwd;

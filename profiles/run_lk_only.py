@@ -16,7 +16,8 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 560
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 w, h = 1280, 720
-c = icgvins.Context(w, h, n_slots=2 * S, max_batch=2, max_points=S * N + 16)
+_lib = icgvins.load_library(os.environ["ICG_LK_LIB"]) if os.environ.get("ICG_LK_LIB") else None
+c = icgvins.Context(w, h, n_slots=2 * S, max_batch=2, max_points=S * N + 16, lib=_lib)
 c.set_camera(synth.CAM_1280)
 base = synth.texture(w, h, seed=1)
 for s in range(S):
