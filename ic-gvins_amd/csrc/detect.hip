@@ -96,11 +96,13 @@ __global__ __launch_bounds__(256) void k_min_eig(const det_roi *rois, const uint
             p20 = r2[-1], p21 = r2[0], p22 = r2[1];
         } else {
             // ROI coordinate with reflect-101 at the ROI edge (cov is a fresh ROI-sized Mat in OpenCV)
-            const int x = icg_reflect101(tx0 - 1 + c, R.rw), y = icg_reflect101(ty0 - 1 + r, R.rh);
+            // (halo coordinates overshoot by one pixel: a single reflection is exact; partial tiles beyond the ROI are
+            // clamped first, their outputs are never stored)
+            const int x = icg_reflect1(min(tx0 - 1 + c, R.rw), R.rw), y = icg_reflect1(min(ty0 - 1 + r, R.rh), R.rh);
             const int X = R.rx + x, Y = R.ry + y;
             // Sobel on REAL image pixels (peeks outside the ROI); reflect-101 only at true image borders
-            const int xm = icg_reflect101(X - 1, w), xp = icg_reflect101(X + 1, w);
-            const int ym = icg_reflect101(Y - 1, h), yp = icg_reflect101(Y + 1, h);
+            const int xm = icg_reflect1(X - 1, w), xp = icg_reflect1(X + 1, w);
+            const int ym = icg_reflect1(Y - 1, h), yp = icg_reflect1(Y + 1, h);
             const uint8_t *r0 = img + (size_t) ym * pitch, *r1 = img + (size_t) Y * pitch, *r2 = img + (size_t) yp * pitch;
             p00 = r0[xm], p01 = r0[X], p02 = r0[xp];
             p10 = r1[xm], p12 = r1[xp];

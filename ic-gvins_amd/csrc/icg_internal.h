@@ -126,6 +126,12 @@ struct icg_pyr_desc { // passed by value to kernels
 };
 icg_pyr_desc icg_make_pyr_desc(const icg_ctx *ctx);
 
+// single reflection, branch-free: valid for -n < i < 2n-1 (all stencil halos here overshoot by a few pixels at most)
+__host__ __device__ static inline int icg_reflect1(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+
 __host__ __device__ static inline int icg_reflect101(int i, int n) {
     if (n == 1) return 0;
     while (i < 0 || i >= n) {

@@ -82,41 +82,53 @@ __global__ __launch_bounds__(64) void k_clahe_lut(pre_jobs jobs, clahe_geom g, u
     const int x_begin = tx * g.tw, x_end = x_begin + g.tw, y_begin = ty * g.th;
     const int xa  = x_begin & ~3;
     const int ndw = (((x_end + 3) & ~3) - xa) >> 2;
-    const int items = g.th * ndw;
-    const unsigned int magic = ((1u << 20) + (unsigned int) ndw - 1u) / (unsigned int) ndw; // i / ndw == (i * magic) >> 20 for i < 43690
-    constexpr int CH = 10; // dwords in flight per lane
-    for (int base = 0; base < items; base += 64 * CH) {
-        unsigned int v[CH];
-        int xs[CH];
+    const bool pad_small = g.th * ICG_CLAHE_TILES < 2 * g.h - 1; // bottom padding reflects at most once (always, for real images)
+    auto load_row_dword = [&](int r, int x) -> unsigned int {
+        const uint8_t *row = src + (size_t) (pad_small ? icg_reflect1(y_begin + r, g.h) : icg_reflect101(y_begin + r, g.h)) * stride;
+        if (x + 3 < g.w) return *reinterpret_cast<const unsigned int *>(row + x);
+        unsigned int v = 0; // right padding of the last tile column
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int i = base + k * 64 + lane;
-            v[k]  = 0;
-            xs[k] = -0x40000000;
-            if (i < items) {
-                const int r = (int) (((unsigned int) i * magic) >> 20), d = i - r * ndw;
-                const int x = xa + 4 * d;
-                const uint8_t *row = src + (size_t) icg_reflect101(y_begin + r, g.h) * stride;
-                xs[k] = x;
-                if (x + 3 < g.w) {
-                    v[k] = *reinterpret_cast<const unsigned int *>(row + x);
-                } else {
+        for (int j = 0; j < 4; j++) v |= (unsigned int) row[icg_reflect101(x + j, g.w)] << (8 * j);
+        return v;
+    };
+    // pass A: the dwords that lie entirely inside the tile (all but the first and last of each row): no per-byte tests
+    {
+        const int nin = ndw - 2, items = g.th * (nin > 0 ? nin : 0);
+        const unsigned int magic = nin > 0 ? ((1u << 20) + (unsigned int) nin - 1u) / (unsigned int) nin : 0u; // i/nin == (i*magic)>>20, i < 43690
+        constexpr int CH = 9; // dwords in flight per lane
+        for (int base = 0; base < items; base += 64 * CH) {
+            unsigned int v[CH];
+            bool ok[CH];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) v[k] |= (unsigned int) row[icg_reflect101(x + j, g.w)] << (8 * j);
+            for (int k = 0; k < CH; k++) {
+                const int i = base + k * 64 + lane;
+                ok[k]       = i < items;
+                v[k]        = 0;
+                if (ok[k]) {
+                    const int r = (int) (((unsigned int) i * magic) >> 20), d = 1 + i - r * nin;
+                    v[k]        = load_row_dword(r, xa + 4 * d);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                if (ok[k]) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) atomicAdd(&hist[(v[k] >> (8 * j)) & 0xff], 1u);
                 }
             }
         }
+    }
+    // pass B: first and last dword of each row, byte-wise against the tile's column range
+    {
+        const int nedge = ndw >= 2 ? 2 : 1, items = g.th * nedge;
+        for (int i = lane; i < items; i += 64) {
+            const int r = nedge == 2 ? (i >> 1) : i, d = (nedge == 2 && (i & 1)) ? ndw - 1 : 0;
+            const int x = xa + 4 * d;
+            const unsigned int v = load_row_dword(r, x);
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            if (xs[k] >= x_begin && xs[k] + 3 < x_end) { // dword entirely inside the tile (all but the row ends)
-#pragma unroll
-                for (int j = 0; j < 4; j++) atomicAdd(&hist[(v[k] >> (8 * j)) & 0xff], 1u);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int xx = xs[k] + j;
-                    if (xx >= x_begin && xx < x_end) atomicAdd(&hist[(v[k] >> (8 * j)) & 0xff], 1u);
-                }
+            for (int j = 0; j < 4; j++) {
+                const int xx = x + j;
+                if (xx >= x_begin && xx < x_end) atomicAdd(&hist[(v >> (8 * j)) & 0xff], 1u);
             }
         }
     }
