@@ -53,7 +53,9 @@ class SynthScene:
         """True camera pose of frame k: (R camera->world 3x3, t 3)."""
         tau = k / fps
         ph = 0.37 * stream
-        t = np.array([self.vx * tau + 7.3 * stream, 0.3 * np.sin(0.7 * tau + ph), self.vz * tau])
+        # streams start 7.3 m apart ALONG the wall (in-plane direction e1), so every stream sees the wall at the same
+        # depth and only the texture patch differs (an offset along x would push stream k 3.4*k m further from the wall)
+        t = np.array([self.vx * tau, 0.3 * np.sin(0.7 * tau + ph), self.vz * tau]) + 7.3 * stream * self.e1
         R = _rot_yp(0.05 * np.sin(0.5 * tau + ph), 0.03 * np.sin(0.8 * tau + ph))
         return R, t
 
