@@ -166,6 +166,11 @@ public:
         ModelLock lock(frame_mutex_);
         features_.reserve(features_.size() + n);
     }
+    // visit (map-point id, feature) pairs in place (the lock is held: the visitor must not call back into this frame)
+    template <typename F> void forEachFeature(F &&f) {
+        ModelLock lock(frame_mutex_);
+        for (const auto &kv : features_) f(kv.first, *kv.second);
+    }
     void clearFeatures() {
         ModelLock lock(frame_mutex_);
         features_.clear();

@@ -292,16 +292,19 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
         ulong fid = frame->id();
         fnv(s.digest, &fid, sizeof fid);
         if (st != TRACK_PASSED) {
-            Frame::FeatureList &feats = s.feat_scratch;
-            frame->featureSnapshot(feats);
-            std::sort(feats.begin(), feats.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-            for (auto &kv : feats) {
-                const ulong id    = kv.first;
-                const Point2f &kp = kv.second->distortedKeyPoint();
-                fnv(s.digest, &id, sizeof id);
-                fnv(s.digest, &kp, sizeof kp);
-            }
-            s.tracked_sum += feats.size();
+            // order-independent combination of per-feature hashes (the container order is not part of the result)
+            uint64_t acc = 0, cnt = 0;
+            frame->forEachFeature([&](ulong id, Feature &f) {
+                uint64_t hf = 1469598103934665603ull;
+                const Point2f &kp = f.distortedKeyPoint();
+                fnv(hf, &id, sizeof id);
+                fnv(hf, &kp, sizeof kp);
+                acc += hf * 0x9E3779B97F4A7C15ull + (hf >> 29);
+                cnt++;
+            });
+            fnv(s.digest, &acc, sizeof acc);
+            fnv(s.digest, &cnt, sizeof cnt);
+            s.tracked_sum += cnt;
             uint64_t nref = s.tracking->numTrackedRefPoints();
             fnv(s.digest, &nref, sizeof nref);
         }

@@ -45,7 +45,6 @@ public:
         std::shared_ptr<WindowKeeper> keeper;
         std::shared_ptr<IdSpace> ids;
         StageBatch box[2];
-        Frame::FeatureList feat_scratch;
         // statistics / digest
         uint64_t frames{0}, keyframes{0}, tracked_sum{0}, digest{1469598103934665603ull};
         TrackState last_state{TRACK_PASSED};
