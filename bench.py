@@ -64,6 +64,26 @@ def algorithmic_bytes(kernel, w, h, n_streams, pts_per_launch):
     return table.get(kernel)
 
 
+def usable_host_cores():
+    """Host cores this container may actually use: min(affinity mask, cgroup CPU quota).  The MI355X boxes of this pool expose
+    256 logical CPUs but cap the container at 16 (cpu.max), which is what sizes the number of stream-group threads."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1.0, float(txt[0]) / float(txt[1])))
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    n = min(n, max(1.0, q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return float(n)
+
+
 def build_streams(sb, scene, n_streams, n_ring, rank, ctx_dev_upload):
     """Render n_ring frames per stream and park them in HBM. Returns (device ptr table, host frames of stream 0)."""
     w, h = scene.w, scene.h
@@ -86,14 +106,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("ICG_BENCH_STREAMS", "256")), help="camera streams per GPU")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("ICG_BENCH_STREAMS", "0")),
+                    help="camera streams per GPU (0 = 8 per stream group)")
     ap.add_argument("--ring", type=int, default=64, help="rendered frames per stream (ping-pong replay)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--features", type=int, default=300)
     ap.add_argument("--host-threads", type=int, default=1, help="host threads inside each group")
-    ap.add_argument("--groups", type=int, default=int(os.environ.get("ICG_BENCH_GROUPS", "32")),
-                    help="stream groups per GPU (own HIP stream + host thread each)")
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("ICG_BENCH_GROUPS", "0")),
+                    help="stream groups per GPU (own HIP stream + host thread each); 0 = sized to the host cores this rank "
+                         "may use: 2 per core, at most 32, at least 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproj", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event pass (used under rocprofv3 --pmc)")
@@ -112,10 +134,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    w, h, nfeat, B = args.width, args.height, args.features, args.streams
+    w, h, nfeat = args.width, args.height, args.features
     ncpu = os.cpu_count() or 1
     host_threads = max(1, args.host_threads)
-    G = max(1, min(args.groups, B))
+    cores_rank = usable_host_cores() / float(world)
+    G = args.groups if args.groups > 0 else int(max(8, min(32, 2 * round(cores_rank))))
+    B = args.streams if args.streams > 0 else 8 * G
+    G = max(1, min(G, B))
     cam = H.camera_for(w, h)
     sb = H.StreamBatch(H.HOST_LIB, B, w, h, cam, max_features=nfeat, window=10, device=local_rank, host_threads=host_threads,
                        groups=G)
@@ -372,6 +397,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"C2: {w}x{h} synthetic stream, {nfeat} features, 10-keyframe window, 1 MI355X",
                        "streams_per_gpu": B, "groups_per_gpu": G, "frames_per_step": B * world, "host_threads_per_group": host_threads,
+                       "usable_host_cores_per_rank": round(cores_rank, 1),
                        "input_residency": "raw frames in HBM", "sharding": "independent streams per GPU, no data-path collective"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

@@ -120,3 +120,51 @@ def test_triangulate_matches_oracle(oracle, ctx1280):
     exp = np.stack([oracle.triangulate(T0, T1, a, b) for a, b in zip(pc0, pc1)])
     assert np.array_equal(got, exp)
     assert np.median(np.abs(got - X)) < 0.5  # ~1 px of noise at 6-40 m depth
+
+
+def test_detect_mask_generation_wraps(oracle):
+    """The detection mask is generation-tagged (8-bit tag, cleared only when it wraps): results must stay identical to
+    the CPU restatement across the wrap, with a different mask every call."""
+    import icgvins
+    w, h = 640, 480
+    c = icgvins.Context(w, h, n_slots=1, max_batch=1, max_points=256)
+    try:
+        img = synth.texture(w, h, seed=83)
+        c.preprocess([0], [img])
+        clahe = oracle.clahe(img)
+        grid = grid_for(w, h, 100)
+        q = np.full(6, grid[5], np.int32)
+        rng = np.random.RandomState(5)
+        for call in range(262):  # crosses generation 255 -> 1
+            m = rng.uniform([20, 20], [w - 20, h - 20], (3 + call % 5, 2)).astype(np.float32)
+            out, cnt, blk = c.detect([0], grid, [0, len(m)], m, q, 200)
+            if call in (0, 1, 2, 100) or call >= 252:
+                exp_pts, exp_blk = oracle.detect(clahe, grid, m, q, 200)
+                assert cnt[0] == len(exp_pts), call
+                assert np.array_equal(blk[0, :cnt[0]], exp_blk), call
+                assert np.array_equal(out[0, :cnt[0]].view(np.uint32), exp_pts.view(np.uint32)), call
+    finally:
+        c.close()
+
+
+def test_wait_modes_give_identical_results(oracle):
+    """icg_ctx_set_wait_mode only changes how the host waits (spin vs query+sleep), never the results."""
+    import ctypes as C
+    import icgvins
+    w, h = 640, 480
+    c = icgvins.Context(w, h, n_slots=2, max_batch=2, max_points=512)
+    try:
+        a = synth.texture(w, h, seed=84)
+        b = synth.shift_image(a, 2.25, -1.5)
+        c.preprocess([0, 1], [a, b])
+        pts = synth.random_points(200, w, h, 12, seed=9)
+        ref_out, ref_st = c.lk_track_fb([0] * 200, [1] * 200, pts, pts)
+        assert c.lib.icg_ctx_set_wait_mode(c.h, 7, 20) == -1
+        assert c.lib.icg_ctx_set_wait_mode(c.h, 1, 0) == -1
+        for mode, us in ((1, 20), (1, 200), (0, 0), (1, 5)):
+            assert c.lib.icg_ctx_set_wait_mode(c.h, mode, us) == 0
+            out, st = c.lk_track_fb([0] * 200, [1] * 200, pts, pts)
+            assert np.array_equal(st, ref_st)
+            assert np.array_equal(out.view(np.uint32), ref_out.view(np.uint32))
+    finally:
+        c.close()
