@@ -3,9 +3,10 @@
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so; the product library
 // (libicgvins_hip.so / libicgvins_host.so) never links, loads or calls anything from this directory.
 // Every function cites the reference file:line it follows in its .cc file.
-// PARITY STATUS: "parity unpinned" at the OpenCV boundary (reference has no tests, OpenCV absent offline);
-// in-tree factor math is additionally pinned by oracle/_ref (reference headers compiled against an Eigen shim)
-// when that has been built.
+// PARITY STATUS: "parity unpinned" at the OpenCV boundary (front-end rows F1-F8: the reference has no tests and OpenCV is
+// absent offline).  The in-tree back-end math (R1/R2 reprojection + robust corrector, M1-M4 marginalization, P1/P2
+// preintegration, both variants) IS pinned against the reference's own sources: oracle/ref_build compiles them unmodified
+// against interface shims into oracle/_ref/, golden outputs are committed under tests/golden/ (generators next to them).
 #pragma once
 #include <stdint.h>
 

@@ -6,6 +6,8 @@
 // The reference uses Eigen::SelfAdjointEigenSolver; here a cyclic Jacobi eigen-solver (eigenvalues ascending, like
 // Eigen).  J0/e0 depend on the eigenvector basis (sign / degenerate subspaces), so tests compare the basis-invariant
 // quantities J0^T J0 = Hp and J0^T e0 = -bp and direct values only where the basis is shared.
+// PINNED against the reference's own pipeline compiled unmodified (oracle/ref_build -> oracle/_ref/libref_marg.so,
+// tests/golden/marg_ref_golden.npz: Hp, bp, marginalization-factor cost and gradient at a perturbed point).
 #include "oracle.h"
 #include <algorithm>
 #include <cmath>

@@ -6,8 +6,10 @@
 //                         evaluate :37-90, residualJacobian* :92-164                             (preintegration_earth.cc)
 // Odo / EarthOdo variants are dead in the reference build (isuseodo=false, ic_gvins.cc:100) and out of scope.
 // `iewn` is an explicit input (SURVEY.md hazard H9: the reference reads an unset `station`, i.e. effectively lat 0).
-// Fully specified in-tree; pinned by the analytic tests in tests/test_oracle_preint.py (constant-rate closed forms,
-// finite-difference Jacobians) and by oracle/_ref when built.
+// Fully specified in-tree.  PINNED against the reference's own sources compiled unmodified (oracle/ref_build ->
+// oracle/_ref/libref_preint.so; tests/golden/preint_ref_golden.npz: state/Jacobian/covariance 1e-12, whitened residual and
+// Jacobians 1e-9, both variants) and by the analytic tests in tests/test_oracle_preint.py (constant-rate closed forms,
+// finite-difference Jacobians).
 #include "oracle.h"
 #include "orc_math.h"
 #include <vector>

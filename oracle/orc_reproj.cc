@@ -1,9 +1,10 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md). CPU restatement of
 //   ReprojectionFactor::Evaluate        reference ic_gvins/ic_gvins/factors/reprojection_factor.h:55-147
 //   ResidualBlockInfo robust correction reference ic_gvins/ic_gvins/factors/residual_block_info.h:59-87
-// Parity status: no golden vectors exist upstream — pinned only by the
-// finite-difference / algebraic known-answer tests in tests/test_oracle_reproj.py and, when built,
-// by oracle/_ref (reference header compiled against a minimal Eigen interface shim).
+// Parity status: no golden vectors exist upstream.  PINNED against the reference's own header compiled
+// unmodified (oracle/ref_build -> oracle/_ref/libref_reproj.so, tests/golden/reproj_ref_golden.npz, 1e-12) and by the
+// finite-difference / algebraic known-answer tests in tests/test_oracle_reproj.py; the robust corrector additionally
+// through the reference's ResidualBlockInfo in the marginalization golden (tests/golden/marg_ref_golden.npz).
 #include "oracle.h"
 #include "orc_math.h"
 

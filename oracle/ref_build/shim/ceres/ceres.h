@@ -1,8 +1,14 @@
 // ORACLE / TEST INFRASTRUCTURE ONLY — the slice of the Ceres interface the reference factor headers are written against
 // (ceres::CostFunction / SizedCostFunction), so reference headers compile unmodified into oracle/_ref/.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <limits>
 #include <vector>
+
+#include <Eigen/Geometry> // real Ceres headers pull Eigen in; residual_block_info.h relies on that
+
 namespace ceres {
 class CostFunction {
 public:
@@ -23,5 +29,29 @@ public:
         set_num_residuals(kNumResiduals);
         *mutable_parameter_block_sizes() = std::vector<int32_t>{Ns...};
     }
+};
+// robust kernels (ceres/loss_function.h): rho[0] = rho(s), rho[1] = rho'(s), rho[2] = rho''(s)
+class LossFunction {
+public:
+    virtual ~LossFunction() = default;
+    virtual void Evaluate(double sq_norm, double out[3]) const = 0;
+};
+class HuberLoss : public LossFunction {
+public:
+    explicit HuberLoss(double a) : a_(a), b_(a * a) {}
+    void Evaluate(double s, double rho[3]) const override {
+        if (s > b_) {
+            const double r = std::sqrt(s);
+            rho[0]         = 2.0 * a_ * r - b_;
+            rho[1]         = std::max(std::numeric_limits<double>::min(), a_ / r);
+            rho[2]         = -rho[1] / (2.0 * s);
+        } else {
+            rho[0] = s;
+            rho[1] = 1.0;
+            rho[2] = 0.0;
+        }
+    }
+private:
+    const double a_, b_;
 };
 } // namespace ceres

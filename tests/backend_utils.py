@@ -167,3 +167,71 @@ def check_preintegration(lib, oracle):
             # whitening by the inverse covariance amplifies libm-level differences of the integration: 1e-6 relative
             assert np.abs(res[i] - r_exp).max() < 1e-6 * max(1.0, np.abs(r_exp).max())
             assert np.abs(jac[i] - J_cat).max() < 1e-6 * max(1.0, np.abs(J_cat).max())
+
+
+def check_preintegration_golden(lib):
+    """icg::Preintegration + PreintegrationFactor (device P1 + host P2) against outputs of the REFERENCE's own code
+    (tests/golden/preint_ref_golden.npz): current state 1e-9, whitened residual / Jacobians 1e-6 relative."""
+    from test_oracle_vs_reference import preint_golden_cases
+    for k, c in preint_golden_cases():
+        variant = int(c["variant"])
+        offsets = np.array([0, len(c["imu"])], np.int32)
+        pose0, mix0 = pd.split(c["s0"])
+        pose1, mix1 = pd.split(c["s1"])
+        ep = np.concatenate([pose0, mix0, pose1, mix1])
+        cur, res, jac = np.zeros((1, 16)), np.zeros((1, 15)), np.zeros((1, 480))
+        err = C.create_string_buffer(512)
+        rc = lib.icgh_backend_preint(variant, 1, _p(offsets), _p(_f64(c["imu"])), _p(_f64(c["s0"][None, :])), _p(_f64(c["params"])),
+                                     _p(_f64(ep[None, :])), _p(cur), _p(res), _p(jac), err, 512)
+        assert rc == 0, (rc, err.value)
+        assert np.abs(cur[0] - c["cur"]).max() < 1e-9 * np.abs(c["cur"]).max(), k
+        assert np.abs(res[0] - c["r"]).max() < 1e-6 * max(1.0, np.abs(c["r"]).max()), k
+        assert np.abs(jac[0] - c["J"]).max() < 1e-6 * max(1.0, np.abs(c["J"]).max()), k
+
+
+# ---- marginalization against the REFERENCE's own pipeline (golden) -------------------------------------------------------
+MARG_GOLDEN_ARGS = dict(n_lm=80, n_kf=6, seed=2)
+
+
+def _marg_perturbation(i, w):
+    """deterministic evaluation point per parameter id (independent of the library's block order)"""
+    rng = np.random.RandomState(1000 + int(i) % 100003)
+    if i < 100000:
+        return rd.pose_plus(w["poses"][i], rng.normal(0, 1e-3, 6))
+    if i < 900000:
+        return np.array([w["invdepth"][i - 100000]]) + rng.normal(0, 1e-4, 1)
+    if i == 900000:
+        return rd.pose_plus(w["ext"], rng.normal(0, 1e-3, 6))
+    return np.array([w["td"] + 1e-4])
+
+
+def marginalize_canonical(lib):
+    """Runs the standard scenario through `lib` and returns quantities that do not depend on the library's block order or
+    on the sign / basis choices of its eigen-solver: Hp, bp in id-sorted column order and, for the marginalization factor at
+    a fixed perturbed point, the cost |e|^2 and the gradient J0^T e (id-sorted)."""
+    P = md.make_problem(**MARG_GOLDEN_ARGS)
+    w = P["w"]
+    out = backend_marginalize(lib, P, huber=1.0, prior_weight=100.0)
+    x = np.concatenate([_marg_perturbation(int(i), w) for i in out["ids"]])
+    out2 = backend_marginalize(lib, P, huber=1.0, prior_weight=100.0, x_eval=x)
+    order = np.argsort(out["ids"])
+    cols = []
+    for k in order:
+        ls = 6 if out["size"][k] == 7 else int(out["size"][k])
+        c0 = int(out["index"][k] - out["m"])
+        cols.extend(range(c0, c0 + ls))
+    cols = np.array(cols)
+    e = out2["res"]
+    return dict(m=out["m"], r=out["r"], ids=np.sort(out["ids"]), Hp=out["Hp"][np.ix_(cols, cols)], bp=out["bp"][cols],
+                cost=float(e @ e), grad=(out2["J0"].T @ e)[cols])
+
+
+def check_marginalization_golden(lib, path):
+    g = np.load(path)
+    c = marginalize_canonical(lib)
+    assert c["m"] == int(g["m"]) and c["r"] == int(g["r"]) and np.array_equal(c["ids"], g["ids"])
+    scale = np.abs(g["Hp"]).max()
+    assert np.abs(c["Hp"] - g["Hp"]).max() < 1e-8 * scale
+    assert np.abs(c["bp"] - g["bp"]).max() < 1e-8 * max(1.0, np.abs(g["bp"]).max())
+    assert abs(c["cost"] - float(g["cost"])) < 1e-8 * max(1.0, float(g["cost"]))
+    assert np.abs(c["grad"] - g["grad"]).max() < 1e-7 * max(1.0, np.abs(g["grad"]).max())

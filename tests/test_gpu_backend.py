@@ -24,3 +24,13 @@ def test_marginalization_pipeline(oracle):
 
 def test_preintegration_factor(oracle):
     bu.check_preintegration(_lib(), oracle)
+
+
+def test_preintegration_factor_matches_reference_golden():
+    bu.check_preintegration_golden(_lib())
+
+
+def test_marginalization_matches_reference_golden():
+    """host MarginalizationInfo with the GPU-evaluated / GPU-assembled reprojection factors vs the REFERENCE's own pipeline"""
+    import os
+    bu.check_marginalization_golden(_lib(), os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "marg_ref_golden.npz"))

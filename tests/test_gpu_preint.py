@@ -34,3 +34,17 @@ def test_preint_batch_matches_oracle(oracle, ctx, variant):
         assert _close(jac[i], exp["jac"]) and _close(cov[i], exp["cov"], 1e-8)
         if variant == 1 and n > 1:
             assert _close(pn[offsets[i]:offsets[i] + n - 1], exp["pn"])
+
+
+def test_preint_kernel_matches_reference_golden(ctx):
+    """k_preint against outputs of the REFERENCE's own preintegration code (tests/golden/preint_ref_golden.npz, generator
+    tests/golden/make_preint_golden.py): state, Jacobian and covariance of both variants, 1e-9 relative."""
+    from test_oracle_vs_reference import preint_golden_cases
+    for variant in (0, 1):
+        cases = [c for _, c in preint_golden_cases() if int(c["variant"]) == variant]
+        for c in cases:  # the Earth rate is a per-launch parameter: one case per launch
+            offsets = np.array([0, len(c["imu"])], np.int32)
+            cur, delta, jac, cov, dt, _ = ctx.preint_batch(variant, offsets, c["imu"], c["s0"][None, :], c["params"])
+            assert _close(cur[0], c["cur"]) and _close(delta[0], c["delta"])
+            assert abs(dt[0] - float(c["dt"])) < 1e-12
+            assert _close(jac[0], c["jac"]) and _close(cov[0], c["cov"], 1e-8)
