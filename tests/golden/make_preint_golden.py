@@ -20,14 +20,14 @@ import preint_data as pd  # noqa: E402
 STATION = np.array([30.5 * np.pi / 180, 114.3 * np.pi / 180, 20.0])
 
 
-def run_case(lib, variant, imu, s0, s1_offset):
+def run_case(lib, variant, imu, s0, s1_offset, station):
     p = lambda a: np.ascontiguousarray(a, np.float64).ctypes.data_as(C.c_void_p)
     cur, delta, jac, cov = np.zeros(16), np.zeros(16), np.zeros((15, 15)), np.zeros((15, 15))
     dt, iewn = C.c_double(), np.zeros(3)
     if variant == 0:
         assert lib.ref_preint_integrate(len(imu), p(imu), p(s0), p(pd.PARAMS), p(cur), p(delta), p(jac), p(cov), C.byref(dt)) == 0
     else:
-        assert lib.ref_preint_integrate_earth(len(imu), p(imu), p(s0), p(pd.PARAMS), p(STATION), p(cur), p(delta), p(jac), p(cov),
+        assert lib.ref_preint_integrate_earth(len(imu), p(imu), p(s0), p(pd.PARAMS), p(station), p(cur), p(delta), p(jac), p(cov),
                                               C.byref(dt), p(iewn)) == 0
     s1 = cur + s1_offset
     pose0, mix0 = pd.split(s0)
@@ -36,7 +36,7 @@ def run_case(lib, variant, imu, s0, s1_offset):
     if variant == 0:
         assert lib.ref_preint_factor(len(imu), p(imu), p(s0), p(pd.PARAMS), p(pose0), p(mix0), p(pose1), p(mix1), p(r), p(J)) == 0
     else:
-        assert lib.ref_preint_factor_earth(len(imu), p(imu), p(s0), p(pd.PARAMS), p(STATION), p(pose0), p(mix0), p(pose1), p(mix1),
+        assert lib.ref_preint_factor_earth(len(imu), p(imu), p(s0), p(pd.PARAMS), p(station), p(pose0), p(mix0), p(pose1), p(mix1),
                                            p(r), p(J)) == 0
     return dict(cur=cur, delta=delta, jac=jac, cov=cov, dt=dt.value, iewn=iewn, s1=s1, r=r, J=J)
 
@@ -55,7 +55,10 @@ def main():
             off[7:10] = 0.01
             off[10:13] = 1e-5
             off[13:] = 1e-4
-            c = run_case(lib, variant, imu, s0, off)
+            # SURVEY.md hazard H9: the reference never assigns IntegrationParameters::station, so in the shipped system it is
+            # (0, 0, 0) (value-initialised); half of the Earth cases use that effective value, half a real origin
+            station = np.zeros(3) if seed >= 2 else STATION
+            c = run_case(lib, variant, imu, s0, off, station)
             out.update({f"c{k}_variant": variant, f"c{k}_imu": imu, f"c{k}_s0": s0})
             out.update({f"c{k}_{name}": val for name, val in c.items()})
             k += 1
