@@ -102,11 +102,16 @@ __device__ __forceinline__ void eig_sobel_slow(const uint8_t *img, int pitch, in
 __global__ __launch_bounds__(64 * EIG_WAVES) void k_min_eig(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
                                                             const int32_t *slots, int pitch, int w, int h,
                                                             const uint8_t *mask, size_t mask_plane, unsigned int gen, float *eig,
-                                                            size_t eig_plane, unsigned int *roi_max) {
+                                                            size_t eig_plane, unsigned int *roi_max, int gx, int gy, int n_blocks) {
     __shared__ float cov[EIG_WAVES][3][EIG_TH + 2][64];
-    const det_roi R = rois[blockIdx.z];
+    // 1-D launch, ROI-major and XCD-chunked: a ROI's blocks (and later its k_candidates blocks) share one XCD's L2
+    const int bl = icg_xcd_chunked(blockIdx.x, n_blocks);
+    if (bl >= n_blocks) return; // whole workgroup
+    const int roi = bl / (gx * gy), rem = bl - roi * (gx * gy);
+    const int by = rem / gx, bx = rem - by * gx;
+    const det_roi R = rois[roi];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int tx0 = blockIdx.x * EIG_TW, ty0 = (blockIdx.y * EIG_WAVES + wv) * EIG_TH;
+    const int tx0 = bx * EIG_TW, ty0 = (by * EIG_WAVES + wv) * EIG_TH;
     const bool live = tx0 < R.rw && ty0 < R.rh; // wave-uniform; dead waves still join the barrier
     const uint8_t *img = frames + (size_t) slots[R.job] * slot_bytes;
     const float s      = (float) (1.0 / 3060.0);
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(64 * EIG_WAVES) void k_min_eig(const det_roi *rois,
         const unsigned int o = __shfl_xor(key, m, 64);
         key                  = o > key ? o : key;
     }
-    if (lane == 0 && key) atomicMax(&roi_max[blockIdx.z], key);
+    if (lane == 0 && key) atomicMax(&roi_max[roi], key);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -197,13 +202,17 @@ __global__ __launch_bounds__(64 * EIG_WAVES) void k_min_eig(const det_roi *rois,
 __global__ __launch_bounds__(256) void k_candidates(const det_roi *rois, int pitch, int w, const uint8_t *mask,
                                                     size_t mask_plane, unsigned int gen, const float *eig, size_t eig_plane,
                                                     const unsigned int *roi_max, unsigned long long *cand,
-                                                    size_t cand_plane, int32_t *cand_cnt) {
-    const det_roi R = rois[blockIdx.z];
+                                                    size_t cand_plane, int32_t *cand_cnt, int gx, int gy, int n_blocks) {
+    const int bl = icg_xcd_chunked(blockIdx.x, n_blocks); // ROI-major, XCD-chunked like k_min_eig
+    if (bl >= n_blocks) return;
+    const int roi = bl / (gx * gy), rem = bl - roi * (gx * gy);
+    const int by = rem / gx, bx = rem - by * gx;
+    const det_roi R = rois[roi];
     const int lane = threadIdx.x & 63;
-    const int x  = blockIdx.x * 64 + lane;
-    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * CAND_PY;
+    const int x  = bx * 64 + lane;
+    const int y0 = (by * 4 + (threadIdx.x >> 6)) * CAND_PY;
     if (y0 >= R.rh - 1) return; // wave-uniform
-    const unsigned int mk = roi_max[blockIdx.z];
+    const unsigned int mk = roi_max[roi];
     const double maxVal   = mk ? (double) f32_from_order_key(mk) : 0.0;
     const float thresh    = (float) (maxVal * 0.01);
     bool is_cand[CAND_PY];
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(256) void k_candidates(const det_roi *rois, int pit
         if (m == 0) continue;
         int base = 0;
         const int leader = __ffsll((long long) m) - 1;
-        if (lane == leader) base = atomicAdd(&cand_cnt[blockIdx.z], __popcll(m));
+        if (lane == leader) base = atomicAdd(&cand_cnt[roi], __popcll(m));
         base = __shfl(base, leader, 64);
         if (is_cand[k]) {
             const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
@@ -528,16 +537,16 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     }
     {
         icg_prof_scope ps(ctx, "detect_min_eig");
-        hipLaunchKernelGGL(k_min_eig,
-                           dim3((grid->block_w + EIG_TW - 1) / EIG_TW, (grid->block_h + EIG_TH * EIG_WAVES - 1) / (EIG_TH * EIG_WAVES), n_roi),
-                           dim3(64 * EIG_WAVES), 0, ctx->stream, d_rois, ctx->d_frames, ctx->slot_bytes, d_slots, pitch, w, h,
-                           ctx->d_mask, mask_plane, gen, ctx->d_eig, eig_plane, d_rmax);
+        const int gx = (grid->block_w + EIG_TW - 1) / EIG_TW, gy = (grid->block_h + EIG_TH * EIG_WAVES - 1) / (EIG_TH * EIG_WAVES);
+        hipLaunchKernelGGL(k_min_eig, dim3(icg_xcd_grid(gx * gy * n_roi)), dim3(64 * EIG_WAVES), 0, ctx->stream, d_rois, ctx->d_frames,
+                           ctx->slot_bytes, d_slots, pitch, w, h, ctx->d_mask, mask_plane, gen, ctx->d_eig, eig_plane, d_rmax, gx, gy,
+                           gx * gy * n_roi);
     }
     {
         icg_prof_scope ps(ctx, "detect_candidates");
-        hipLaunchKernelGGL(k_candidates, dim3((grid->block_w + 63) / 64, (grid->block_h + 4 * CAND_PY - 1) / (4 * CAND_PY), n_roi), dim3(256), 0,
-                           ctx->stream, d_rois, pitch, w, ctx->d_mask, mask_plane, gen, ctx->d_eig, eig_plane, d_rmax, ctx->d_cand,
-                           cand_plane, d_ccnt);
+        const int gx = (grid->block_w + 63) / 64, gy = (grid->block_h + 4 * CAND_PY - 1) / (4 * CAND_PY);
+        hipLaunchKernelGGL(k_candidates, dim3(icg_xcd_grid(gx * gy * n_roi)), dim3(256), 0, ctx->stream, d_rois, pitch, w, ctx->d_mask,
+                           mask_plane, gen, ctx->d_eig, eig_plane, d_rmax, ctx->d_cand, cand_plane, d_ccnt, gx, gy, gx * gy * n_roi);
     }
     {
         icg_prof_scope ps(ctx, "detect_select");

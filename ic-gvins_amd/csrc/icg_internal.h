@@ -126,6 +126,16 @@ struct icg_pyr_desc { // passed by value to kernels
 };
 icg_pyr_desc icg_make_pyr_desc(const icg_ctx *ctx);
 
+// XCD-aware work mapping.  MI355X dispatches consecutive workgroups round-robin over its 8 XCDs, each with a private 4 MB
+// L2.  Work items that share data (the LK points of one camera stream read the same two pyramids) are contiguous in the
+// batch, so handing workgroup b the item  (b % 8) * ceil(n/8) + b / 8  gives every XCD one contiguous eighth of the batch
+// (one stream's images per L2 instead of all of them in every L2).
+// Launch 8*ceil(n/8) workgroups; items >= n exit.  A pure permutation: placement only, results unchanged.
+#ifdef __HIPCC__
+__device__ static inline int icg_xcd_chunked(int b, int n) { return (b & 7) * ((n + 7) >> 3) + (b >> 3); }
+#endif
+static inline int icg_xcd_grid(int n) { return 8 * ((n + 7) >> 3); }
+
 // single reflection, branch-free: valid for -n < i < 2n-1 (all stencil halos here overshoot by a few pixels at most)
 __host__ __device__ static inline int icg_reflect1(int i, int n) {
     i = i < 0 ? -i : i;

@@ -421,15 +421,20 @@ __device__ __forceinline__ void p3_reflect_fix(unsigned int *tile32, int t, int 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_pyramid3(icg_pyr_desc P, pre_jobs jobs) {
+__global__ __launch_bounds__(256) void k_pyramid3(icg_pyr_desc P, pre_jobs jobs, int gx, int gy, int n_tiles) {
     __shared__ __attribute__((aligned(16))) unsigned int L0[P3_L0H * P3_L0S / 4];
     __shared__ __attribute__((aligned(16))) unsigned int TMP[P3_L0H * (P3_L1W / 2)];
     __shared__ __attribute__((aligned(16))) unsigned int L1[P3_L1H * P3_L1S / 4];
     __shared__ __attribute__((aligned(16))) unsigned int L2[P3_L2H * P3_L2S / 4];
     __shared__ __attribute__((aligned(16))) unsigned int L3[8 * 16 / 4];
     const int t   = threadIdx.x;
-    uint8_t *slot = P.base + (size_t) jobs.slot[blockIdx.z] * P.slot_bytes;
-    const int X3 = blockIdx.x * 16, Y3 = blockIdx.y * 8;
+    // 1-D launch, XCD-chunked: every XCD gets whole frames, so the 1.7x halo overlap of neighbouring tiles hits its L2
+    const int b = icg_xcd_chunked(blockIdx.x, n_tiles);
+    if (b >= n_tiles) return;
+    const int job = b / (gx * gy), rem = b - job * (gx * gy);
+    const int by = rem / gx, bx = rem - by * gx;
+    uint8_t *slot = P.base + (size_t) jobs.slot[job] * P.slot_bytes;
+    const int X3 = bx * 16, Y3 = by * 8;
 
     {
         const uint8_t *s = slot + P.off[0];
@@ -560,8 +565,9 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
         }
         if (ctx->n_levels == 4) {
             icg_prof_scope ps(ctx, "pyramid3");
-            hipLaunchKernelGGL(k_pyramid3, dim3((ctx->lv[3].w + 15) / 16, (ctx->lv[3].h + 7) / 8, m), dim3(256), 0, ctx->stream,
-                               icg_make_pyr_desc(ctx), jobs);
+            const int gx = (ctx->lv[3].w + 15) / 16, gy = (ctx->lv[3].h + 7) / 8, n_tiles = gx * gy * m;
+            hipLaunchKernelGGL(k_pyramid3, dim3(icg_xcd_grid(n_tiles)), dim3(256), 0, ctx->stream, icg_make_pyr_desc(ctx), jobs, gx,
+                               gy, n_tiles);
         } else {
             for (int l = 1; l < ctx->n_levels; l++) {
                 icg_prof_scope ps(ctx, "pyrdown");

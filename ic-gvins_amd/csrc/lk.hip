@@ -462,7 +462,7 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
 __global__ __launch_bounds__(64) void k_lk_track(icg_pyr_desc P, int n, const int32_t *prev_slot, const int32_t *next_slot,
                                                  const float2 *prev_pts, float2 *next_pts, unsigned char *status, float *err) {
     __shared__ lk_smem S;
-    const int i = blockIdx.x;
+    const int i = icg_xcd_chunked(blockIdx.x, n);
     if (i >= n) return;
     const int lane = threadIdx.x;
     const unsigned char *sI = P.base + (size_t) prev_slot[i] * P.slot_bytes;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(64) void k_lk_track_fb(icg_pyr_desc P, int n, const
                                                     const float2 *guess_pts, float2 *out_pts, unsigned char *status,
                                                     int has_cam, icg_camera cam, float2 *out_undist, int img_w, int img_h) {
     __shared__ lk_smem S;
-    const int i = blockIdx.x;
+    const int i = icg_xcd_chunked(blockIdx.x, n);
     if (i >= n) return;
     const int lane = threadIdx.x;
     const unsigned char *sP = P.base + (size_t) prev_slot[i] * P.slot_bytes;
@@ -577,7 +577,7 @@ extern "C" int icg_lk_track(icg_ctx *ctx, int n, const int32_t *prev_slot, const
     float *d_err        = err ? c.out_zc(err, (size_t) n) : nullptr;
     {
         icg_prof_scope ps(ctx, "lk_track");
-        hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp, d_np,
+        hipLaunchKernelGGL(k_lk_track, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp, d_np,
                            d_st, d_err);
     }
     ICG_HIP(ctx, hipGetLastError());
@@ -612,7 +612,7 @@ extern "C" int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, co
     int32_t *d_nkeep    = keep_idx ? c.out_zc(n_keep, 1) : nullptr;
     {
         icg_prof_scope ps(ctx, "lk_track_fb");
-        hipLaunchKernelGGL(k_lk_track_fb, dim3(n), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp,
+        hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp,
                            d_gs, d_out, d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height);
     }
     if (keep_idx) {
