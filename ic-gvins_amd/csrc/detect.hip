@@ -102,13 +102,14 @@ __device__ __forceinline__ void eig_sobel_slow(const uint8_t *img, int pitch, in
 __global__ __launch_bounds__(64 * EIG_WAVES) void k_min_eig(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
                                                             const int32_t *slots, int pitch, int w, int h,
                                                             const uint8_t *mask, size_t mask_plane, unsigned int gen, float *eig,
-                                                            size_t eig_plane, unsigned int *roi_max, int gx, int gy, int n_blocks) {
+                                                            size_t eig_plane, unsigned int *roi_max, int gx, int gy, int n_blocks,
+                                                            unsigned int m_roi, unsigned int m_gx) {
     __shared__ float cov[EIG_WAVES][3][EIG_TH + 2][64];
     // 1-D launch, ROI-major and XCD-chunked: a ROI's blocks (and later its k_candidates blocks) share one XCD's L2
     const int bl = icg_xcd_chunked(blockIdx.x, n_blocks);
     if (bl >= n_blocks) return; // whole workgroup
-    const int roi = bl / (gx * gy), rem = bl - roi * (gx * gy);
-    const int by = rem / gx, bx = rem - by * gx;
+    const int roi = icg_div_by_magic(bl, m_roi), rem = bl - roi * (gx * gy);
+    const int by = icg_div_by_magic(rem, m_gx), bx = rem - by * gx;
     const det_roi R = rois[roi];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tx0 = bx * EIG_TW, ty0 = (by * EIG_WAVES + wv) * EIG_TH;
@@ -202,11 +203,12 @@ __global__ __launch_bounds__(64 * EIG_WAVES) void k_min_eig(const det_roi *rois,
 __global__ __launch_bounds__(256) void k_candidates(const det_roi *rois, int pitch, int w, const uint8_t *mask,
                                                     size_t mask_plane, unsigned int gen, const float *eig, size_t eig_plane,
                                                     const unsigned int *roi_max, unsigned long long *cand,
-                                                    size_t cand_plane, int32_t *cand_cnt, int gx, int gy, int n_blocks) {
+                                                    size_t cand_plane, int32_t *cand_cnt, int gx, int gy, int n_blocks,
+                                                    unsigned int m_roi, unsigned int m_gx) {
     const int bl = icg_xcd_chunked(blockIdx.x, n_blocks); // ROI-major, XCD-chunked like k_min_eig
     if (bl >= n_blocks) return;
-    const int roi = bl / (gx * gy), rem = bl - roi * (gx * gy);
-    const int by = rem / gx, bx = rem - by * gx;
+    const int roi = icg_div_by_magic(bl, m_roi), rem = bl - roi * (gx * gy);
+    const int by = icg_div_by_magic(rem, m_gx), bx = rem - by * gx;
     const det_roi R = rois[roi];
     const int lane = threadIdx.x & 63;
     const int x  = bx * 64 + lane;
@@ -540,13 +542,14 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
         const int gx = (grid->block_w + EIG_TW - 1) / EIG_TW, gy = (grid->block_h + EIG_TH * EIG_WAVES - 1) / (EIG_TH * EIG_WAVES);
         hipLaunchKernelGGL(k_min_eig, dim3(icg_xcd_grid(gx * gy * n_roi)), dim3(64 * EIG_WAVES), 0, ctx->stream, d_rois, ctx->d_frames,
                            ctx->slot_bytes, d_slots, pitch, w, h, ctx->d_mask, mask_plane, gen, ctx->d_eig, eig_plane, d_rmax, gx, gy,
-                           gx * gy * n_roi);
+                           gx * gy * n_roi, icg_div_magic(gx * gy), icg_div_magic(gx));
     }
     {
         icg_prof_scope ps(ctx, "detect_candidates");
         const int gx = (grid->block_w + 63) / 64, gy = (grid->block_h + 4 * CAND_PY - 1) / (4 * CAND_PY);
         hipLaunchKernelGGL(k_candidates, dim3(icg_xcd_grid(gx * gy * n_roi)), dim3(256), 0, ctx->stream, d_rois, pitch, w, ctx->d_mask,
-                           mask_plane, gen, ctx->d_eig, eig_plane, d_rmax, ctx->d_cand, cand_plane, d_ccnt, gx, gy, gx * gy * n_roi);
+                           mask_plane, gen, ctx->d_eig, eig_plane, d_rmax, ctx->d_cand, cand_plane, d_ccnt, gx, gy, gx * gy * n_roi,
+                           icg_div_magic(gx * gy), icg_div_magic(gx));
     }
     {
         icg_prof_scope ps(ctx, "detect_select");

@@ -135,6 +135,12 @@ icg_pyr_desc icg_make_pyr_desc(const icg_ctx *ctx);
 __device__ static inline int icg_xcd_chunked(int b, int n) { return (b & 7) * ((n + 7) >> 3) + (b >> 3); }
 #endif
 static inline int icg_xcd_grid(int n) { return 8 * ((n + 7) >> 3); }
+// b / d for workgroup-index decoding without an integer division per thread: q = mulhi(b, ceil(2^32 / d)), exact for
+// b < 2^32 / d (workgroup counts are far below that)
+static inline unsigned int icg_div_magic(int d) { return (unsigned int) ((0x100000000ull + (unsigned int) d - 1u) / (unsigned int) d); }
+#ifdef __HIPCC__
+__device__ static inline int icg_div_by_magic(int b, unsigned int magic) { return (int) __umulhi((unsigned int) b, magic); }
+#endif
 
 // single reflection, branch-free: valid for -n < i < 2n-1 (all stencil halos here overshoot by a few pixels at most)
 __host__ __device__ static inline int icg_reflect1(int i, int n) {

@@ -421,7 +421,7 @@ __device__ __forceinline__ void p3_reflect_fix(unsigned int *tile32, int t, int 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_pyramid3(icg_pyr_desc P, pre_jobs jobs, int gx, int gy, int n_tiles) {
+__global__ __launch_bounds__(256) void k_pyramid3(icg_pyr_desc P, pre_jobs jobs, int gx, int gy, int n_tiles, unsigned int m_tile, unsigned int m_gx) {
     __shared__ __attribute__((aligned(16))) unsigned int L0[P3_L0H * P3_L0S / 4];
     __shared__ __attribute__((aligned(16))) unsigned int TMP[P3_L0H * (P3_L1W / 2)];
     __shared__ __attribute__((aligned(16))) unsigned int L1[P3_L1H * P3_L1S / 4];
@@ -431,8 +431,8 @@ __global__ __launch_bounds__(256) void k_pyramid3(icg_pyr_desc P, pre_jobs jobs,
     // 1-D launch, XCD-chunked: every XCD gets whole frames, so the 1.7x halo overlap of neighbouring tiles hits its L2
     const int b = icg_xcd_chunked(blockIdx.x, n_tiles);
     if (b >= n_tiles) return;
-    const int job = b / (gx * gy), rem = b - job * (gx * gy);
-    const int by = rem / gx, bx = rem - by * gx;
+    const int job = icg_div_by_magic(b, m_tile), rem = b - job * (gx * gy);
+    const int by = icg_div_by_magic(rem, m_gx), bx = rem - by * gx;
     uint8_t *slot = P.base + (size_t) jobs.slot[job] * P.slot_bytes;
     const int X3 = bx * 16, Y3 = by * 8;
 
@@ -567,7 +567,7 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
             icg_prof_scope ps(ctx, "pyramid3");
             const int gx = (ctx->lv[3].w + 15) / 16, gy = (ctx->lv[3].h + 7) / 8, n_tiles = gx * gy * m;
             hipLaunchKernelGGL(k_pyramid3, dim3(icg_xcd_grid(n_tiles)), dim3(256), 0, ctx->stream, icg_make_pyr_desc(ctx), jobs, gx,
-                               gy, n_tiles);
+                               gy, n_tiles, icg_div_magic(gx * gy), icg_div_magic(gx));
         } else {
             for (int l = 1; l < ctx->n_levels; l++) {
                 icg_prof_scope ps(ctx, "pyrdown");
