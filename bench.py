@@ -291,7 +291,7 @@ def main():
                         roofline["traffic_source"] = ("profiles/r01_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) per point "
                                                       "x points per launch (gfx950 correction of MI355X_MICROARCH.md)")
                 if dom == "lk_track_fb":
-                    roofline["note"] = ("LK keeps its working set in LDS/VGPRs by design (8.5 KB of image per point, ~6k VALU "
+                    roofline["note"] = ("LK keeps its working set in LDS/VGPRs by design (8.5 KB of image per point, ~10k VALU "
                                         "instructions on it): it is instruction-issue bound (rocprofv3 SQ_ACTIVE_INST_ANY ~89% "
                                         "of SIMD cycles, profiles/r01_lk_pmc.md), not HBM bound")
             else:
