@@ -369,7 +369,7 @@ __device__ __forceinline__ void p3_step(const unsigned int *in, unsigned int *tm
             unsigned int *pout      = tmp + rr * TS + m;
 #pragma unroll
             for (int k = 0; k < NP; k++) {
-                if (rr + k * RPP < IH) {
+                if (k < IH / RPP || rr + k * RPP < IH) { // only the last pass is partial (compile-time for the others)
                     const unsigned int *p = pin + k * RPP * (IS / 4);
                     const unsigned int d0 = p[0], d1 = p[1], d2 = p[2];
                     const unsigned int lo = __builtin_amdgcn_alignbyte(d1, d0, 2), hi = __builtin_amdgcn_alignbyte(d2, d1, 2);
@@ -389,7 +389,7 @@ __device__ __forceinline__ void p3_step(const unsigned int *in, unsigned int *tm
 #pragma unroll
             for (int k = 0; k < NP; k++) {
                 const int r = rr + k * RPP;
-                if (r >= OH) break;
+                if (k >= OH / RPP && r >= OH) break; // only the last pass is partial
                 const uint2 *c = reinterpret_cast<const uint2 *>(tmp + (2 * r) * TS + 2 * q);
                 const uint2 t0 = c[0], t1 = c[TS / 2], t2 = c[TS], t3 = c[3 * TS / 2], t4 = c[2 * TS];
                 const unsigned int a = t0.x + t4.x + ((t1.x + t3.x) << 2) + (t2.x << 2) + (t2.x << 1) + 0x00800080u;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void k_pyramid3(icg_pyr_desc P, pre_jobs jobs,
         for (int k = 0; k < NP; k++) {
             const int r = rr + k * RPP;
             v[k]        = 0;
-            if (rr < RPP && r < P3_L0H) {
+            if (rr < RPP && (k < P3_L0H / RPP || r < P3_L0H)) {
                 if (inside)
                     v[k] = *reinterpret_cast<const unsigned int *>(s + (size_t) (y0 + r) * pitch + (x0 + 4 * d));
                 else
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void k_pyramid3(icg_pyr_desc P, pre_jobs jobs,
 #pragma unroll
         for (int k = 0; k < NP; k++) {
             const int r = rr + k * RPP;
-            if (rr < RPP && r < P3_L0H) L0[r * DW + d] = v[k];
+            if (rr < RPP && (k < P3_L0H / RPP || r < P3_L0H)) L0[r * DW + d] = v[k];
         }
         __syncthreads();
     }
