@@ -157,6 +157,14 @@ class StreamBatch:
         keys = ["frames", "keyframes", "tracked_sum", "digest", "mappoints_created", "window_keyframes", "landmarks", "last_state"]
         return dict(zip(keys, [int(v) for v in out]))
 
+    def candidates(self, stream, cap=4096):
+        """un-triangulated candidate points of the tracker (current and reference pixel), list order"""
+        cur, ref = np.zeros((cap, 2), np.float32), np.zeros((cap, 2), np.float32)
+        n = self.lib.icgh_batch_candidates(C.c_void_p(self.h_), stream, cap, cur.ctypes.data_as(C.c_void_p), ref.ctypes.data_as(C.c_void_p))
+        if n < 0:
+            raise RuntimeError(f"icgh_batch_candidates failed: {n}")
+        return cur[:n].copy(), ref[:n].copy()
+
     def counters(self, reset=True):
         out = np.zeros(8, np.uint64)
         self.lib.icgh_batch_counters(C.c_void_p(self.h_), out.ctypes.data_as(C.c_void_p), 1 if reset else 0)

@@ -158,6 +158,20 @@ int icgh_hostprof(double *out, int max_sections, char *names, int names_len, int
     return n;
 }
 
+// the tracker's un-triangulated candidate points in list order: cur[2k..] (pts2d_new_), ref[2k..] (pts2d_ref_)
+int icgh_batch_candidates(icgh_batch *b, int stream, int max, float *cur, float *ref) {
+    if (!b || stream < 0 || stream >= b->tb->size()) return -1;
+    const auto &pn = b->tb->stream(stream).tracking->trackedRefPoints();
+    const auto &pr = b->tb->stream(stream).tracking->referencePoints();
+    int n = (int) std::min(pn.size(), pr.size());
+    if (n > max) n = max;
+    for (int k = 0; k < n; k++) {
+        cur[2 * k] = pn[(size_t) k].x, cur[2 * k + 1] = pn[(size_t) k].y;
+        ref[2 * k] = pr[(size_t) k].x, ref[2 * k + 1] = pr[(size_t) k].y;
+    }
+    return (pn.size() == pr.size()) ? n : -2;
+}
+
 // features of the stream's current frame, sorted by map-point id: ids[k], px[2k..2k+1] (distorted keypoint)
 int icgh_batch_features(icgh_batch *b, int stream, int max, uint64_t *ids, float *px) {
     if (!b || stream < 0 || stream >= b->tb->size()) return -1;

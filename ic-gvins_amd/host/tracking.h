@@ -109,6 +109,9 @@ public:
     int maxFeaturesPerJob() const { return grid_.max_per_block * block_cnts_; }
     const std::shared_ptr<IdSpace> &ids() const { return ids_; }
     size_t numTrackedRefPoints() const { return pts2d_new_.size(); }
+    // the un-triangulated candidates carried to the next frame (tracking.h:129 pts2d_new_ / pts2d_ref_), for tests
+    const vector<Point2f> &trackedRefPoints() const { return pts2d_new_; }
+    const vector<Point2f> &referencePoints() const { return pts2d_ref_; }
     const Frame::Ptr &currentFrame() const { return frame_cur_; }
     const Frame::Ptr &referenceFrame() const { return frame_ref_; }
 

@@ -279,6 +279,13 @@ int Tracking::parallaxFromReferenceMapPoints(double &parallax) { // :873-905
     return counts;
 }
 
+// ICG_DEBUG_TRI=1: per-candidate triangulation / detection decisions on stderr (used to localise divergences from the
+// reference tracker build, tests/ref_tracking_utils.py)
+static bool debugTriangulation() {
+    static const bool on = getenv("ICG_DEBUG_TRI") != nullptr;
+    return on;
+}
+
 // ICG_HOST_CHECK=1: the carried undistorted twins must equal a fresh Camera::undistortPoints of their sources, bit for bit
 void Tracking::checkCarriedUndistortion(const char *where) {
     static const bool on = getenv("ICG_HOST_CHECK") != nullptr;
@@ -580,11 +587,13 @@ bool Tracking::queueDetection(Frame::Ptr &frame, bool ismask, StageBatch &next) 
     auto count = [&](float x, float y) {
         int col = int(x / (float) block_w_); // :598
         int row = int(y / (float) block_h_);
-        if (col >= block_cols_) col = block_cols_ - 1; // SURVEY.md hazard H5: clamp instead of indexing past the row
-        if (row >= block_rows_) row = block_rows_ - 1;
-        if (col < 0) col = 0;
-        if (row < 0) row = 0;
-        features_cnts[(size_t) row * block_cols_ + col]++;
+        // SURVEY.md hazard H5: the reference indexes features_cnts[row * block_cols_ + col] with the UNCLAMPED column.  The key
+        // points counted here are undistorted, so near the right edge x can reach block_cols_ * block_w_ and beyond
+        // (col == block_cols_): the reference then counts the feature in the FIRST block of the NEXT row.  That effective
+        // behaviour is reproduced (pinned by tests/golden/tracking_ref_*.npz); only indices outside the array — undefined
+        // behaviour in the reference (stack VLA overrun) — are dropped.
+        const long idx = (long) row * block_cols_ + col;
+        if (idx >= 0 && idx < (long) block_cnts_) features_cnts[(size_t) idx]++;
     };
     frame->featureSnapshot(feat_snap_);
     for (const auto &feature : feat_snap_) count(feature.second->keyPoint().x, feature.second->keyPoint().y);
@@ -633,6 +642,7 @@ void Tracking::integrateDetection(StageBatch &done) { // :659-685
         pts2d_ref_frame_.push_back(det_frame_);
         velocity_ref_.emplace_back(0, 0);
     }
+    if (debugTriangulation()) fprintf(stderr, "[det] Add %d new features (ref list now %zu)\n", n, pts2d_ref_.size());
     det_job_ = -1;
     det_frame_.reset();
 }
@@ -847,14 +857,17 @@ bool Tracking::queueTriangulation(StageBatch &next) {
             pts2d_ref_[k]       = pts2d_cur_[k];
             pts2d_ref_undis_[k] = tri_cur_undis_[k];
             tri_status_[k]      = 1;
+            if (debugTriangulation()) fprintf(stderr, "[tri] k=%zu reset\n", k);
             continue;
         }
         if (map_->isWindowNormal() && !map_->isKeyFrameInMap(frame_ref)) { // :733-737
+            if (debugTriangulation()) fprintf(stderr, "[tri] k=%zu outtime (ref frame id %lu kf %lu iskf %d)\n", k, frame_ref->id(), frame_ref->keyFrameId(), (int) frame_ref->isKeyFrame());
             tri_status_[k] = 0;
             continue;
         }
         Pose pose0      = frame_ref->pose();
         double parallax = keyPointParallax(tri_ref_undis_[k], tri_cur_undis_[k], pose0, pose1); // :741
+        if (debugTriangulation()) fprintf(stderr, "[tri] k=%zu parallax=%.17g\n", k, parallax);
         if (parallax < TRACK_MIN_PARALLAX) {
             tri_status_[k] = 1;
             continue;
@@ -890,6 +903,12 @@ void Tracking::finishTriangulation(StageBatch &done) {
         auto frame_ref = pts2d_ref_frame_[k];
         Pose pose0     = frame_ref->pose();
         auto pp0 = tri_ref_undis_[k], pp1 = tri_cur_undis_[k];
+        if (debugTriangulation()) {
+            Vector3d pc0d = Camera::world2cam(pw, pose0), pc1d = Camera::world2cam(pw, pose1);
+            fprintf(stderr, "[tri] k=%zu pw=(%.17g %.17g %.17g) z0=%.17g z1=%.17g e0=%.17g e1=%.17g good=%d/%d\n", k, pw[0], pw[1], pw[2],
+                    pc0d[2], pc1d[2], camera_->reprojectionError(pose0, pw, pp0).norm(), camera_->reprojectionError(pose1, pw, pp1).norm(),
+                    (int) isGoodToTrack(pp0, pose0, pw, 1.0, 3.0), (int) isGoodToTrack(pp1, pose1, pw, 1.0, 3.0));
+        }
         if (!isGoodToTrack(pp0, pose0, pw, 1.0, 3.0) || !isGoodToTrack(pp1, pose1, pw, 1.0, 3.0)) { // :756-760
             tri_status_[k] = 0;
             continue;

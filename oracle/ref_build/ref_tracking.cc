@@ -1,0 +1,274 @@
+// ORACLE / TEST INFRASTRUCTURE ONLY — runs the REFERENCE's own front-end (Tracking, Frame, Feature, MapPoint, Map, Camera:
+// /root/reference/ic_gvins/ic_gvins/tracking/*.{h,cc}, fileio/filesaver.cc, common/*.h, compiled unmodified from where they lie)
+// behind C entry points.  Third-party headers are interface shims (shim/): Eigen, tbb (serial), yaml-cpp (flat reader), absl,
+// glog, and OpenCV — whose image-processing entry points are implemented HERE by forwarding to the CPU restatement in
+// oracle/orc_*.cc.  So this build does NOT pin the OpenCV primitives (they stay "unpinned"); it pins
+// everything the reference does around them: tracking.cc's control flow and state machine, INS-aided prediction, fwd/bwd and
+// border culls, reduceVector bookkeeping, parallax and keyframe selection, triangulation gates, feature/map-point/frame graph,
+// container iteration orders, id factories.  tests/ compare it frame by frame with the product's host layer
+// (ic-gvins_amd/host) running on the same primitives.
+#include <cstdio>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// test harness only: read the tracker's private candidate lists (pts2d_new_, pts2d_ref_); the sources are untouched
+#define private public
+#include "tracking/tracking.h"
+#undef private
+
+#include "fileio/filesaver.cc"
+#include "tracking/camera.cc"
+#include "tracking/frame.cc"
+#include "tracking/map.cc"
+#include "tracking/mappoint.cc"
+#include "tracking/tracking.cc"
+
+// ---- OpenCV entry points on the oracle primitives --------------------------------------------------------------------------
+namespace cv {
+
+void CLAHE::apply(const Mat &src, Mat &dst) {
+    assert(src.type() == CV_8UC1 && tiles_.width == tiles_.height);
+    Mat in = src.clone(); // the reference applies it in place
+    if (dst.empty() || dst.rows != src.rows || dst.cols != src.cols || dst.type() != CV_8UC1) dst.create(src.rows, src.cols, CV_8UC1);
+    orc_clahe(in.data, in.cols, in.rows, (int) in.step, clip_, tiles_.width, dst.data, (int) dst.step, nullptr);
+}
+
+void cvtColor(const Mat &src, Mat &dst, int code) {
+    assert(code == COLOR_BGR2GRAY && src.type() == CV_8UC3);
+    Mat out(src.rows, src.cols, CV_8UC1);
+    orc_bgr2gray(src.data, src.cols, src.rows, (int) src.step, out.data, (int) out.step);
+    dst = out;
+}
+
+void calcHist(const Mat *images, int nimages, const int *, const Mat &, Mat &hist, int dims, const int *histSize, const float **, bool,
+              bool) {
+    assert(nimages == 1 && dims == 1 && histSize[0] == 256 && images[0].type() == CV_8UC1);
+    hist.create(256, 1, CV_32FC1);
+    std::vector<unsigned int> h(256, 0);
+    for (int r = 0; r < images[0].rows; r++) {
+        const uint8_t *p = images[0].data + images[0].step * (size_t) r;
+        for (int c = 0; c < images[0].cols; c++) h[p[c]]++;
+    }
+    for (int k = 0; k < 256; k++) hist.at<float>(k) = (float) h[(size_t) k];
+}
+
+void calcOpticalFlowPyrLK(const Mat &prevImg, const Mat &nextImg, const std::vector<Point2f> &prevPts, std::vector<Point2f> &nextPts,
+                          std::vector<uint8_t> &status, std::vector<float> &err, Size winSize, int maxLevel, TermCriteria criteria,
+                          int flags) {
+    // the one parameterisation the reference uses (tracking.cc:385-393, 487-496), which is what orc_lk_track restates
+    assert(winSize.width == 21 && winSize.height == 21 && maxLevel == 3 && criteria.maxCount == 30 && criteria.epsilon == 0.01);
+    assert((flags & OPTFLOW_USE_INITIAL_FLOW) && nextPts.size() == prevPts.size());
+    assert(prevImg.step == nextImg.step && prevImg.cols == nextImg.cols && prevImg.rows == nextImg.rows);
+    const int n = (int) prevPts.size();
+    status.assign((size_t) n, 0);
+    err.assign((size_t) n, 0.f);
+    if (n == 0) return;
+    orc_lk_track(prevImg.data, nextImg.data, prevImg.cols, prevImg.rows, (int) prevImg.step, n, &prevPts[0].x, &nextPts[0].x, status.data(),
+                 err.data());
+}
+
+Mat findFundamentalMat(const std::vector<Point2f> &points1, const std::vector<Point2f> &points2, int method, double thresh, double conf,
+                       std::vector<uint8_t> &mask) {
+    assert(method == FM_RANSAC && points1.size() == points2.size());
+    const int n = (int) points1.size();
+    mask.assign((size_t) n, 0);
+    Mat F(3, 3, CV_64FC1);
+    int iters = 0;
+    if (n > 0) orc_find_fundamental_ransac(n, &points1[0].x, &points2[0].x, thresh, conf, mask.data(), (double *) F.data, &iters);
+    return F;
+}
+
+void goodFeaturesToTrack(const Mat &image, std::vector<Point2f> &corners, int maxCorners, double quality, double minDistance,
+                         const Mat &mask) {
+    std::vector<float> out((size_t) std::max(1, maxCorners) * 2);
+    const int n = orc_good_features(image.origin(), image.fullW(), image.fullH(), (int) image.step, mask.empty() ? nullptr : mask.origin(),
+                                    (int) mask.step, image.offX(), image.offY(), image.cols, image.rows, maxCorners, quality, minDistance,
+                                    out.data());
+    assert(mask.empty() || (mask.offX() == image.offX() && mask.offY() == image.offY()));
+    corners.clear();
+    for (int i = 0; i < n; i++) corners.emplace_back(out[2 * (size_t) i], out[2 * (size_t) i + 1]);
+}
+
+void cornerSubPix(const Mat &image, std::vector<Point2f> &corners, Size win, Size zero, TermCriteria crit) {
+    assert(win.width == 5 && win.height == 5 && zero.width == -1 && crit.maxCount == 20 && crit.epsilon == 0.01);
+    if (corners.empty()) return;
+    orc_corner_subpix(image.origin(), image.fullW(), image.fullH(), (int) image.step, image.offX(), image.offY(), image.cols, image.rows,
+                      (int) corners.size(), &corners[0].x);
+}
+
+void circle(Mat &img, Point2f center, int radius, const Scalar &color, int thickness) {
+    assert(thickness == FILLED && img.type() == CV_8UC1);
+    // cv::circle takes an integer Point: Point2f -> Point conversion rounds (saturate_cast<int>(float) == cvRound)
+    orc_draw_filled_circle(img.data, img.cols, img.rows, (int) img.step, cvRound(center.x), cvRound(center.y), radius, (uint8_t) color.v[0]);
+}
+
+void undistortPoints(const std::vector<Point2f> &src, std::vector<Point2f> &dst, const Mat &K, const Mat &D, const Mat &, const Mat &P) {
+    // Camera::undistortPoints passes P == K (camera.cc:73)
+    const double cam[10] = {K.at<double>(0, 0), K.at<double>(1, 1), K.at<double>(0, 2), K.at<double>(1, 2), K.at<double>(0, 1),
+                            D.at<double>(0),    D.at<double>(1),    D.at<double>(2),    D.at<double>(3),    D.at<double>(4)};
+    assert(P.at<double>(0, 0) == K.at<double>(0, 0));
+    std::vector<Point2f> tmp = src;
+    if (!tmp.empty()) orc_undistort_points(cam, (int) tmp.size(), &tmp[0].x);
+    dst = tmp;
+}
+
+} // namespace cv
+
+// ---- driver -------------------------------------------------------------------------------------------------------------------
+namespace {
+
+class NullDrawer : public Drawer { // the tracker dereferences drawer_ unconditionally (tracking.cc:515,559)
+public:
+    void run() override {}
+    void setFinished() override {}
+    void addNewFixedMappoint(Vector3d) override {}
+    void updateMap(const Eigen::Matrix4d &) override {}
+    void updateFrame(Frame::Ptr) override {}
+    void updateTrackedMapPoints(vector<cv::Point2f>, vector<cv::Point2f>, vector<MapPointType>) override {}
+    void updateTrackedRefPoints(vector<cv::Point2f>, vector<cv::Point2f>) override {}
+};
+
+struct RefTracker {
+    Camera::Ptr camera;
+    Map::Ptr map;
+    Tracking::Ptr tracking;
+    Frame::Ptr last_frame;
+    TrackState last_state{TRACK_PASSED};
+    uint64_t frames{0}, keyframes{0}, tracked_sum{0};
+};
+
+// the part of GVINS that owns the sliding window, identical in effect to icg::WindowKeeper (ic-gvins_amd/host/tracking_hip.cc):
+// ic_gvins.cc:542 (new keyframe / first frame / lost -> insertKeyFrame :743), gvinsRemoveAllSecondNewFrame :1391-1410,
+// marginalization's map side effect :445-448, 1675 (drop the oldest keyframe with its landmarks when the window overflows)
+void window_keeper(RefTracker &T, const Frame::Ptr &frame, TrackState st) {
+    if (!(T.tracking->isNewKeyFrame() || st == TRACK_FIRST_FRAME || st == TRACK_LOST)) return;
+    T.map->insertKeyFrame(frame);
+    vector<ulong> ids = T.map->orderedKeyFrames();
+    for (auto id : ids) {
+        auto it = T.map->keyframes().find(id);
+        if (it == T.map->keyframes().end()) continue;
+        auto f = it->second;
+        if ((f->keyFrameState() == KEYFRAME_REMOVE_SECOND_NEW) || (f->features().empty() && (id != ids.back()))) {
+            f->resetKeyFrame();
+            T.map->removeKeyFrame(f, false);
+        }
+    }
+    while (T.map->isMaximumKeframes()) {
+        ids    = T.map->orderedKeyFrames();
+        auto f = T.map->keyframes().find(ids[0])->second;
+        T.map->removeKeyFrame(f, true);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+// cam10 = fx, fy, cx, cy, skew, k1, k2, p1, p2, k3; configfile: flat yaml with the track_* keys of config/gvins.yaml;
+// outputpath must be writable (the reference constructor bails out when it cannot open <outputpath>/tracking.txt)
+void *ref_tracker_create(const double *cam10, int w, int h, const char *configfile, const char *outputpath, int window) {
+    auto T    = new RefTracker();
+    T->camera = Camera::createCamera({cam10[0], cam10[1], cam10[2], cam10[3], cam10[4]}, {cam10[5], cam10[6], cam10[7], cam10[8], cam10[9]},
+                                     {w, h});
+    T->map    = std::make_shared<Map>((size_t) window);
+    T->tracking = std::make_shared<Tracking>(T->camera, T->map, std::make_shared<NullDrawer>(), configfile, outputpath);
+    return T;
+}
+void ref_tracker_destroy(void *h) { delete (RefTracker *) h; }
+
+// one frame: gray (channels 1) or BGR (3) image, stamp, INS pose prior (R row-major 9 camera->world, t 3).  Returns the state.
+int ref_tracker_track(void *h, const uint8_t *image, int w, int hh, int stride, int channels, double stamp, const double *pose12) {
+    auto &T = *(RefTracker *) h;
+    cv::Mat img(hh, w, channels == 3 ? CV_8UC3 : CV_8UC1);
+    for (int r = 0; r < hh; r++) memcpy(img.data + img.step * (size_t) r, image + (size_t) stride * r, (size_t) w * channels);
+    auto frame = Frame::createFrame(stamp, img);
+    Pose pose;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) pose.R(i, j) = pose12[3 * i + j];
+        pose.t[i] = pose12[9 + i];
+    }
+    frame->setPose(pose);
+    TrackState st = T.tracking->track(frame);
+    if (st != TRACK_PASSED) T.last_frame = frame; // a skipped frame never becomes the tracker's current frame (tracking.cc:131)
+    T.last_state = st;
+    T.frames++;
+    if (T.tracking->isNewKeyFrame() || st == TRACK_FIRST_FRAME || st == TRACK_LOST) T.keyframes++;
+    if (st != TRACK_PASSED) T.tracked_sum += frame->features().size();
+    window_keeper(T, frame, st);
+    return (int) st;
+}
+
+// features of the last frame sorted by map-point id: ids[k], px[4k..4k+3] = distorted keypoint (x, y), undistorted keypoint (x, y);
+// type[k], vel[2k..]
+int ref_tracker_features(void *h, int max, uint64_t *ids, float *px4, int32_t *type, double *vel2) {
+    auto &T = *(RefTracker *) h;
+    if (!T.last_frame) return 0;
+    auto feats = T.last_frame->features();
+    vector<ulong> v;
+    for (auto &kv : feats) v.push_back(kv.first);
+    std::sort(v.begin(), v.end());
+    int n = 0;
+    for (ulong id : v) {
+        if (n >= max) break;
+        auto &f        = feats[id];
+        ids[n]         = id;
+        px4[4 * n]     = f->distortedKeyPoint().x;
+        px4[4 * n + 1] = f->distortedKeyPoint().y;
+        px4[4 * n + 2] = f->keyPoint().x;
+        px4[4 * n + 3] = f->keyPoint().y;
+        type[n]        = (int) f->featureType();
+        vel2[2 * n]     = f->velocityInPixel()[0];
+        vel2[2 * n + 1] = f->velocityInPixel()[1];
+        n++;
+    }
+    return n;
+}
+
+// out8: frames, keyframes, tracked_sum, last frame id, last keyframe flag, window keyframes, landmarks, last state
+void ref_tracker_stats(void *h, uint64_t *out8) {
+    auto &T = *(RefTracker *) h;
+    out8[0] = T.frames;
+    out8[1] = T.keyframes;
+    out8[2] = T.tracked_sum;
+    out8[3] = T.last_frame ? T.last_frame->id() : 0;
+    out8[4] = T.last_frame ? (T.last_frame->isKeyFrame() ? 1 + (uint64_t) T.last_frame->keyFrameState() : 0) : 0;
+    out8[5] = T.map->keyframes().size();
+    out8[6] = T.map->landmarks().size();
+    out8[7] = (uint64_t) T.last_state;
+}
+
+// the tracker's un-triangulated candidate points in list order: cur[2k..] (pts2d_new_), ref[2k..] (pts2d_ref_)
+int ref_tracker_candidates(void *h, int max, float *cur, float *ref) {
+    auto &T = *(RefTracker *) h;
+    const auto &pn = T.tracking->pts2d_new_;
+    const auto &pr = T.tracking->pts2d_ref_;
+    int n = (int) std::min(pn.size(), pr.size());
+    if (n > max) n = max;
+    for (int k = 0; k < n; k++) {
+        cur[2 * k] = pn[(size_t) k].x, cur[2 * k + 1] = pn[(size_t) k].y;
+        ref[2 * k] = pr[(size_t) k].x, ref[2 * k + 1] = pr[(size_t) k].y;
+    }
+    return (pn.size() == pr.size()) ? n : -2;
+}
+
+// landmarks of the map sorted by id: ids[k], pos[3k..], depth[k], used_times[k], ref frame id[k]
+int ref_tracker_landmarks(void *h, int max, uint64_t *ids, double *pos3, double *depth, int32_t *used, uint64_t *ref_frame) {
+    auto &T = *(RefTracker *) h;
+    vector<ulong> v;
+    for (auto &kv : T.map->landmarks()) v.push_back(kv.first);
+    std::sort(v.begin(), v.end());
+    int n = 0;
+    for (ulong id : v) {
+        if (n >= max) break;
+        auto mp = T.map->landmarks().find(id)->second;
+        ids[n]  = id;
+        for (int k = 0; k < 3; k++) pos3[3 * n + k] = mp->pos()[k];
+        depth[n]     = mp->depth();
+        used[n]      = mp->usedTimes();
+        ref_frame[n] = mp->referenceFrameId();
+        n++;
+    }
+    return n;
+}
+}

@@ -33,3 +33,11 @@ def test_multi_stream_batch_on_gpu_equals_oracle():
     rec_g, stats_g, _ = run_streams(H.HOST_LIB, ns, w, h, nframes, nfeat, scene_frames=frames, host_threads=2, groups=2)
     for s in range(ns):
         assert stats_o[s]["digest"] == stats_g[s]["digest"], s
+
+
+@pytest.mark.parametrize("scenario", ["c1_640x480_100", "c2_1280x720_300", "c1_histgate", "c1_lost_and_reinit", "c1_lost_histgate"])
+def test_gpu_host_layer_matches_reference_tracker_golden(scenario):
+    """icg::Tracking on the HIP kernels vs what the REFERENCE's own tracking.cc produced on the oracle primitives
+    (tests/golden/tracking_ref_*.npz): track states, map-point ids, key-point float bits, window bookkeeping per frame."""
+    import ref_tracking_utils as rt
+    rt.compare_scenario(H.HOST_LIB, scenario)

@@ -1,6 +1,7 @@
 """CPU tests of the host layer (Tracking state machine, TrackingBatch, WindowKeeper) linked against the oracle ABI shim:
 exercises exactly the host code that ships, with the CPU restatement standing in for the GPU."""
 import numpy as np
+import pytest
 
 import harness as H
 from stream_utils import ensure_oracle_host, run_streams
@@ -48,3 +49,12 @@ def test_batch_equals_individual_streams():
             assert np.array_equal(rec_1[k][0][2].view(np.uint32), rec_b[k][s][2].view(np.uint32))
     # different streams see different imagery
     assert stats_b[0]["digest"] != stats_b[1]["digest"]
+
+
+@pytest.mark.parametrize("scenario", ["c1_640x480_100", "c2_1280x720_300", "c1_histgate", "c1_lost_and_reinit", "c1_lost_histgate"])
+def test_host_layer_matches_reference_tracker_golden(scenario):
+    """The product's host layer (icg::Tracking on the oracle primitives) reproduces, frame by frame and bit for bit, what the
+    REFERENCE's own tracking.cc produced on the same primitives (tests/golden/tracking_ref_*.npz, generator
+    tests/golden/make_tracking_golden.py): track states, map-point ids, key-point floats, window bookkeeping."""
+    import ref_tracking_utils as rt
+    rt.compare_scenario(ensure_oracle_host(), scenario)

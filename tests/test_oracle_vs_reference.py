@@ -131,3 +131,20 @@ def test_oracle_marginalization_matches_reference_library(oracle):
 def test_marginalization_golden_is_current():
     import backend_utils as bu
     bu.check_marginalization_golden(C.CDLL(REF_MARG_SO), os.path.join(ROOT, "tests", "golden", "marg_ref_golden.npz"))
+
+
+# ---- the front-end around the OpenCV calls: reference tracking/*.{h,cc} compiled against shims ------------------------------
+REF_TRACKING_SO = os.path.join(ROOT, "oracle", "_ref", "libref_tracking.so")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TRACKING_SO), reason="oracle/_ref not built (needs /root/reference)")
+def test_tracking_golden_is_current(tmp_path):
+    """Re-runs the reference tracker (fresh process: its id factories are process-wide statics) and checks the committed
+    golden file of the C1 scenario is what it produces."""
+    import ref_tracking_utils as rt
+    out = str(tmp_path / "t.npz")
+    rt.run_scenario_in_subprocess("c1_640x480_100", out)
+    a, b = rt.load(out), rt.load(rt.golden_path("c1_640x480_100"))
+    assert np.array_equal(a["states"], b["states"]) and np.array_equal(a["stats"], b["stats"])
+    for k in range(len(a["states"])):
+        assert np.array_equal(a["ids"][k], b["ids"][k]) and np.array_equal(a["px"][k].view(np.uint32), b["px"][k].view(np.uint32))
