@@ -23,6 +23,20 @@ def scene_and_frames(lib, w, h, n_frames, stream):
     import harness as H
     cam = H.camera_for(w, h)
     scene = H.SynthScene(lib, w, h, cam, tex_size=1024, threads=4)
+    scene.vx *= SPEED.get(_current_scenario[0], 1.0)
+    scene.vz *= SPEED.get(_current_scenario[0], 1.0)
+    slow = SLOW_AFTER.get(_current_scenario[0])
+    if slow:
+        k0, f = slow
+        warp = lambda k: float(k) if k < k0 else k0 + (k - k0) * f
+        frames, poses = [], []
+        for k in range(n_frames):
+            frames.append(scene.render(warp(k), stream=stream))
+            R, t = scene.pose(warp(k), stream=stream)
+            rng = np.random.RandomState(7000 + k)
+            poses.append(H.pose12(R @ H._rot_yp(*rng.normal(0, np.deg2rad(0.1), 2)), t + rng.normal(0, 0.02, 3)))
+        stamps = [100.0 + k / 20.0 for k in range(n_frames)]
+        return cam, frames, poses, stamps
     frames = [scene.render(k, stream=stream) for k in range(n_frames)]
     for k in BLANK_FRAMES.get(_current_scenario[0], ()):
         frames[k] = np.full_like(frames[k], BLANK_VALUE[_current_scenario[0]])
@@ -39,7 +53,14 @@ SCENARIOS = {  # name -> (w, h, n_frames, max_features, stream, check_hist)
     "c1_lost_and_reinit": (640, 480, 30, 100, 3, False),
     # same with the histogram gate on: the brightness jump makes the gate skip frames (TRACK_PASSED) first
     "c1_lost_histgate": (640, 480, 30, 100, 3, True),
+    "c1_slow_second_new": (640, 480, 36, 100, 4, False),
+    "c4_1920x1080_500": (1920, 1080, 10, 500, 5, False),
 }
+# camera speed scale per scenario (1.0 = the harness default 16 m/s fly-by); slow motion never reaches the parallax threshold,
+# so keyframes come from the time-out branch (KEYFRAME_REMOVE_SECOND_NEW, tracking.cc:283-286) and the window keeper drops them
+SPEED = {}
+# frame index -> scene time (in frames): normal fly-by for the first frames (initialisation succeeds), then almost stationary
+SLOW_AFTER = {"c1_slow_second_new": (8, 0.02)}
 BLANK_FRAMES = {"c1_lost_and_reinit": (12, 13, 14), "c1_lost_histgate": (12, 13, 14)}
 BLANK_VALUE = {"c1_lost_and_reinit": 90, "c1_lost_histgate": 235}
 _current_scenario = [None]
