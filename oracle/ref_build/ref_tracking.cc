@@ -252,6 +252,58 @@ int ref_tracker_candidates(void *h, int max, float *cur, float *ref) {
     return (pn.size() == pr.size()) ? n : -2;
 }
 
+// ---- the reference Camera's closed-form point maps (tracking/camera.cc:76-157), for pinning oracle/orc_camera.cc and the
+// device point kernels; undistortPoints is NOT here (it is cv::undistortPoints, i.e. the oracle itself in this build)
+static Camera::Ptr make_camera(const double *cam10, int w, int h) {
+    return Camera::createCamera({cam10[0], cam10[1], cam10[2], cam10[3], cam10[4]}, {cam10[5], cam10[6], cam10[7], cam10[8], cam10[9]}, {w, h});
+}
+static Pose make_pose(const double *pose12) {
+    Pose pose;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) pose.R(i, j) = pose12[3 * i + j];
+        pose.t[i] = pose12[9 + i];
+    }
+    return pose;
+}
+void ref_camera_distort_points(const double *cam10, int w, int h, int n, float *pts) {
+    auto cam = make_camera(cam10, w, h);
+    std::vector<cv::Point2f> v((size_t) n);
+    for (int i = 0; i < n; i++) v[(size_t) i] = cv::Point2f(pts[2 * i], pts[2 * i + 1]);
+    cam->distortPoints(v);
+    for (int i = 0; i < n; i++) pts[2 * i] = v[(size_t) i].x, pts[2 * i + 1] = v[(size_t) i].y;
+}
+void ref_camera_distort_camera_points(const double *cam10, int w, int h, int n, const double *pc, float *pts) {
+    auto cam = make_camera(cam10, w, h);
+    for (int i = 0; i < n; i++) {
+        cv::Point2f p = cam->distortCameraPoint(Vector3d(pc[3 * i], pc[3 * i + 1], pc[3 * i + 2]));
+        pts[2 * i] = p.x, pts[2 * i + 1] = p.y;
+    }
+}
+void ref_camera_pixel2cam(const double *cam10, int w, int h, int n, const float *pts, double *pc) {
+    auto cam = make_camera(cam10, w, h);
+    for (int i = 0; i < n; i++) {
+        Vector3d c = cam->pixel2cam(cv::Point2f(pts[2 * i], pts[2 * i + 1]));
+        pc[3 * i] = c[0], pc[3 * i + 1] = c[1], pc[3 * i + 2] = c[2];
+    }
+}
+void ref_camera_world2pixel(const double *cam10, int w, int h, const double *pose12, int n, const double *pw, float *pts) {
+    auto cam  = make_camera(cam10, w, h);
+    Pose pose = make_pose(pose12);
+    for (int i = 0; i < n; i++) {
+        cv::Point2f p = cam->world2pixel(Vector3d(pw[3 * i], pw[3 * i + 1], pw[3 * i + 2]), pose);
+        pts[2 * i] = p.x, pts[2 * i + 1] = p.y;
+    }
+}
+void ref_camera_reprojection_error(const double *cam10, int w, int h, const double *pose12, int n, const double *pw, const float *pp,
+                                   double *err2) {
+    auto cam  = make_camera(cam10, w, h);
+    Pose pose = make_pose(pose12);
+    for (int i = 0; i < n; i++) {
+        Vector2d e = cam->reprojectionError(pose, Vector3d(pw[3 * i], pw[3 * i + 1], pw[3 * i + 2]), cv::Point2f(pp[2 * i], pp[2 * i + 1]));
+        err2[2 * i] = e[0], err2[2 * i + 1] = e[1];
+    }
+}
+
 // landmarks of the map sorted by id: ids[k], pos[3k..], depth[k], used_times[k], ref frame id[k]
 int ref_tracker_landmarks(void *h, int max, uint64_t *ids, double *pos3, double *depth, int32_t *used, uint64_t *ref_frame) {
     auto &T = *(RefTracker *) h;

@@ -154,3 +154,19 @@ def test_camera_point_ops_bit_exact(oracle, ctx1280):
     got = ctx1280.predict_rotation(pts, 0, (R.T @ R_pre).ravel())
     # r_cur_pre is formed by the caller here (numpy matmul) vs inside the oracle: same ops, same order -> exact
     assert np.abs(got - exp).max() < 1e-3
+
+
+def test_camera_point_kernels_match_reference_golden():
+    """icg_distort_points and icg_predict_mappoints (world2pixel + distort, tracking.cc:367-378) against outputs of the
+    REFERENCE's own Camera class (tests/golden/camera_ref_golden.npz): float bit patterns."""
+    import os
+    import icgvins
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "camera_ref_golden.npz"))
+    c = icgvins.Context(int(g["w"]), int(g["h"]), n_slots=1, max_batch=1, max_points=1024)
+    try:
+        c.set_camera(g["cam"])
+        same = lambda a, b: np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+        assert same(c.distort(g["pts"]), g["distorted"])
+        assert same(c.predict_mappoints(g["pw"], 0, g["pose12"][None, :]), g["predicted"])
+    finally:
+        c.close()

@@ -148,3 +148,23 @@ def test_tracking_golden_is_current(tmp_path):
     assert np.array_equal(a["states"], b["states"]) and np.array_equal(a["stats"], b["stats"])
     for k in range(len(a["states"])):
         assert np.array_equal(a["ids"][k], b["ids"][k]) and np.array_equal(a["px"][k].view(np.uint32), b["px"][k].view(np.uint32))
+
+
+# ---- camera closed forms: reference tracking/camera.cc:76-157 -----------------------------------------------------------------
+CAMERA_GOLDEN = os.path.join(ROOT, "tests", "golden", "camera_ref_golden.npz")
+
+
+def _same_f32(a, b):
+    return np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+
+
+def test_oracle_camera_matches_reference_golden(oracle):
+    """distortPoints, pixel2cam, world2pixel and the tracker's INS-aided prediction (world2pixel + distortPoints) of the
+    REFERENCE's Camera class: float outputs bit-identical, double outputs equal."""
+    g = np.load(CAMERA_GOLDEN)
+    cam = g["cam"]
+    assert _same_f32(oracle.distort(cam, g["pts"]), g["distorted"])
+    assert np.array_equal(oracle.pixel2cam(cam, g["pts"]), g["pixel2cam"])
+    w2p = oracle.world2pixel(cam, g["pose12"], g["pw"])
+    assert _same_f32(w2p, g["world2pixel"])
+    assert _same_f32(oracle.distort(cam, w2p), g["predicted"])
