@@ -1,7 +1,10 @@
 #include "tracking_batch.h"
 #include "hostprof.h"
 
+#include <cerrno>
 #include <cstdlib>
+#include <string>
+#include <sys/stat.h>
 #include <stdexcept>
 
 #include <atomic>
@@ -18,7 +21,14 @@ TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &in
         s.camera   = Camera::createCamera(intrinsic, distortion, size);
         s.map      = std::make_shared<Map>((size_t) window_size);
         s.ids      = std::make_shared<IdSpace>();
-        s.tracking = std::make_shared<Tracking>(s.camera, s.map, nullptr, cfg, "", device_, s.ids);
+        // tracking.txt (tracking.cc:309-315) per stream under $ICG_TRACKING_LOG_DIR/stream<i>/ when that is set
+        std::string outputpath;
+        if (const char *dir = getenv("ICG_TRACKING_LOG_DIR")) {
+            outputpath = std::string(dir) + "/stream" + std::to_string(i);
+            if (mkdir(outputpath.c_str(), 0755) != 0 && errno != EEXIST)
+                throw std::runtime_error("TrackingBatch: cannot create " + outputpath);
+        }
+        s.tracking = std::make_shared<Tracking>(s.camera, s.map, nullptr, cfg, outputpath, device_, s.ids);
         s.keeper   = std::make_shared<WindowKeeper>(s.map);
     }
     if (host_threads_ > 1 && n_streams > 1) pool_.reset(new HostPool(std::min(host_threads_, n_streams)));

@@ -183,7 +183,10 @@ Tracking::Tracking(Camera::Ptr camera, Map::Ptr map, Drawer::Ptr drawer, const T
 
 void Tracking::init(const std::string &outputpath) {
     if (!drawer_) drawer_ = std::make_shared<Drawer>(); // the reference dereferences it unconditionally (:515,:559)
-    if (!outputpath.empty()) logfile_ = fopen((outputpath + "/tracking.txt").c_str(), "w");
+    if (!outputpath.empty()) { // :44-50; the reference logs an error and leaves the tracker half-constructed, this one throws
+        logfile_ = fopen((outputpath + "/tracking.txt").c_str(), "w");
+        if (!logfile_) throw std::runtime_error("Tracking: failed to open " + outputpath + "/tracking.txt");
+    }
     track_max_interval_ = cfg_.track_max_interval * 0.95; // :57
     block_cols_ = static_cast<int>(lround(camera_->width() / TRACK_BLOCK_SIZE));  // :66
     block_rows_ = static_cast<int>(lround(camera_->height() / TRACK_BLOCK_SIZE)); // :67

@@ -108,7 +108,24 @@ def run_reference(w, h, n_frames, max_features, stream=0):
         und_l.append(px4[:n, 2:].copy())
         stats_l.append(s8.copy())
     lib.ref_tracker_destroy(T)
-    return dict(states=np.array(states, np.int32), ids=ids_l, px=px_l, und=und_l, stats=np.stack(stats_l), cand=cand_l)
+    # tracking.txt as the reference's own FileSaver wrote it (tracking.cc:309-315, fileio/filesaver.cc:51-66); the last column is
+    # a wall-clock time cost and is dropped
+    log = read_tracking_log(os.path.join(tmp, "tracking.txt"))
+    return dict(states=np.array(states, np.int32), ids=ids_l, px=px_l, und=und_l, stats=np.stack(stats_l), cand=cand_l, log=log)
+
+
+def read_tracking_log(path):
+    """-> array of strings, one per keyframe decision: the first six columns (stamp, dt, parallax, relative translation, relative
+    rotation, feature count) as written; the seventh (time cost in ms) is not deterministic"""
+    rows = []
+    if os.path.exists(path):
+        with open(path) as f:
+            for line in f:
+                t = line.split()
+                if t:
+                    assert len(t) == 7, line
+                    rows.append(" ".join(t[:6]))
+    return np.array(rows, dtype=str)
 
 
 def save(path, r):
@@ -117,7 +134,8 @@ def save(path, r):
     np.savez(path, states=r["states"], counts=counts, ids=np.concatenate(r["ids"]) if n else np.zeros(0, np.uint64),
              px=np.concatenate(r["px"]) if n else np.zeros((0, 2), np.float32),
              und=np.concatenate(r["und"]) if n else np.zeros((0, 2), np.float32), stats=r["stats"],
-             cand_counts=np.array([len(a) for a in r["cand"]], np.int32), cand=np.concatenate(r["cand"]) if n else np.zeros((0, 4), np.float32))
+             cand_counts=np.array([len(a) for a in r["cand"]], np.int32), cand=np.concatenate(r["cand"]) if n else np.zeros((0, 4), np.float32),
+             log=r["log"])
 
 
 def load(path):
@@ -126,7 +144,7 @@ def load(path):
     n = len(g["states"])
     coff = np.concatenate([[0], np.cumsum(g["cand_counts"])])
     return dict(cand=[g["cand"][coff[k]:coff[k + 1]] for k in range(n)], states=g["states"], ids=[g["ids"][off[k]:off[k + 1]] for k in range(n)], px=[g["px"][off[k]:off[k + 1]] for k in range(n)],
-                und=[g["und"][off[k]:off[k + 1]] for k in range(n)], stats=g["stats"])
+                und=[g["und"][off[k]:off[k + 1]] for k in range(n)], stats=g["stats"], log=g["log"])
 
 
 def compare_scenario(lib_path, name, ref=None):
@@ -148,8 +166,13 @@ def compare_with_host(lib_path, ref, w, h, n_frames, max_features, stream=0):
     window size, landmark count)."""
     import harness as H
     cam = H.camera_for(w, h)
-    sb = H.StreamBatch(lib_path, 1, w, h, cam, max_features=max_features, window=CONFIG["window"], min_parallax=CONFIG["min_parallax"],
-                       max_interval=CONFIG["max_interval"], check_hist=CONFIG["check_hist"], reproj_std=CONFIG["reproj_std"])
+    logdir = tempfile.mkdtemp(prefix="icgtrk_")
+    os.environ["ICG_TRACKING_LOG_DIR"] = logdir
+    try:
+        sb = H.StreamBatch(lib_path, 1, w, h, cam, max_features=max_features, window=CONFIG["window"], min_parallax=CONFIG["min_parallax"],
+                           max_interval=CONFIG["max_interval"], check_hist=CONFIG["check_hist"], reproj_std=CONFIG["reproj_std"])
+    finally:
+        del os.environ["ICG_TRACKING_LOG_DIR"]
     _, frames, poses, stamps = scene_and_frames(sb.lib, w, h, n_frames, stream)
     for k in range(n_frames):
         st = sb.step([frames[k].ctypes.data], w, [stamps[k]], poses[k])
@@ -165,6 +188,11 @@ def compare_with_host(lib_path, ref, w, h, n_frames, max_features, stream=0):
         assert cand.shape == ref["cand"][k].shape, (k, cand.shape, ref["cand"][k].shape)
         assert np.array_equal(cand.view(np.uint32), ref["cand"][k].view(np.uint32)), k
     sb.close()
+    # tracking.txt: same rows, same text in the six deterministic columns
+    log = read_tracking_log(os.path.join(logdir, "stream0", "tracking.txt"))
+    assert len(log) == len(ref["log"]), (len(log), len(ref["log"]))
+    for a, b in zip(log, ref["log"]):
+        assert a == str(b), (a, str(b))
 
 
 def run_scenario_in_subprocess(name, out_path):
