@@ -40,6 +40,8 @@ def scene_and_frames(lib, w, h, n_frames, stream):
     frames = [scene.render(k, stream=stream) for k in range(n_frames)]
     for k in BLANK_FRAMES.get(_current_scenario[0], ()):
         frames[k] = np.full_like(frames[k], BLANK_VALUE[_current_scenario[0]])
+    if _current_scenario[0] in BGR_SCENARIOS:
+        frames = [to_bgr(f) for f in frames]
     poses = [H.pose12(*scene.ins_pose(k, stream=stream)) for k in range(n_frames)]
     stamps = [100.0 + k / 20.0 for k in range(n_frames)]
     return cam, frames, poses, stamps
@@ -55,7 +57,21 @@ SCENARIOS = {  # name -> (w, h, n_frames, max_features, stream, check_hist)
     "c1_lost_histgate": (640, 480, 30, 100, 3, True),
     "c1_slow_second_new": (640, 480, 36, 100, 4, False),
     "c4_1920x1080_500": (1920, 1080, 10, 500, 5, False),
+    # three-channel input: the BGR->gray conversion in front of everything else (tracking.cc:135-137, F1)
+    "c1_bgr": (640, 480, 14, 100, 6, False),
 }
+BGR_SCENARIOS = ("c1_bgr",)
+
+
+def to_bgr(gray):
+    """deterministic colourisation of a rendered gray frame: three different affine maps of the texture, so that the gray image
+    the tracker sees is the fixed-point BGR mix (not any single channel)"""
+    g = gray.astype(np.int32)
+    b = np.clip(g + 20, 0, 255)
+    gg = np.clip((g * 7) // 8 + 10, 0, 255)
+    r = np.clip(255 - (g * 3) // 4, 0, 255) // 2 + g // 2
+    return np.ascontiguousarray(np.stack([b, gg, r], axis=-1).astype(np.uint8))
+
 # camera speed scale per scenario (1.0 = the harness default 16 m/s fly-by); slow motion never reaches the parallax threshold,
 # so keyframes come from the time-out branch (KEYFRAME_REMOVE_SECOND_NEW, tracking.cc:283-286) and the window keeper drops them
 SPEED = {}
@@ -91,7 +107,8 @@ def run_reference(w, h, n_frames, max_features, stream=0):
     for k in range(n_frames):
         img = np.ascontiguousarray(frames[k])
         p = np.ascontiguousarray(poses[k], np.float64)
-        st = lib.ref_tracker_track(T, img.ctypes.data_as(C.c_void_p), w, h, w, 1, C.c_double(stamps[k]), p.ctypes.data_as(C.c_void_p))
+        ch = 3 if img.ndim == 3 else 1
+        st = lib.ref_tracker_track(T, img.ctypes.data_as(C.c_void_p), w, h, w * ch, ch, C.c_double(stamps[k]), p.ctypes.data_as(C.c_void_p))
         ids, px4 = np.zeros(cap, np.uint64), np.zeros((cap, 4), np.float32)
         typ, vel = np.zeros(cap, np.int32), np.zeros((cap, 2), np.float64)
         n = lib.ref_tracker_features(T, cap, ids.ctypes.data_as(C.c_void_p), px4.ctypes.data_as(C.c_void_p),
@@ -175,7 +192,8 @@ def compare_with_host(lib_path, ref, w, h, n_frames, max_features, stream=0):
         del os.environ["ICG_TRACKING_LOG_DIR"]
     _, frames, poses, stamps = scene_and_frames(sb.lib, w, h, n_frames, stream)
     for k in range(n_frames):
-        st = sb.step([frames[k].ctypes.data], w, [stamps[k]], poses[k])
+        ch = 3 if frames[k].ndim == 3 else 1
+        st = sb.step([frames[k].ctypes.data], w * ch, [stamps[k]], poses[k], channels=ch)
         ids, px = sb.features(0)
         assert int(st[0]) == int(ref["states"][k]), (k, int(st[0]), int(ref["states"][k]))
         assert np.array_equal(ids.astype(np.uint64), ref["ids"][k]), (k, len(ids), len(ref["ids"][k]))

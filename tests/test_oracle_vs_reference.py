@@ -138,14 +138,16 @@ REF_TRACKING_SO = os.path.join(ROOT, "oracle", "_ref", "libref_tracking.so")
 
 
 @pytest.mark.skipif(not os.path.exists(REF_TRACKING_SO), reason="oracle/_ref not built (needs /root/reference)")
-def test_tracking_golden_is_current(tmp_path):
+@pytest.mark.parametrize("scenario", ["c1_640x480_100", "c1_bgr", "c1_lost_histgate"])
+def test_tracking_golden_is_current(tmp_path, scenario):
     """Re-runs the reference tracker (fresh process: its id factories are process-wide statics) and checks the committed
-    golden file of the C1 scenario is what it produces."""
+    golden file of the scenario is what it produces (states, ids, key points, window bookkeeping, tracking.txt rows)."""
     import ref_tracking_utils as rt
     out = str(tmp_path / "t.npz")
-    rt.run_scenario_in_subprocess("c1_640x480_100", out)
-    a, b = rt.load(out), rt.load(rt.golden_path("c1_640x480_100"))
+    rt.run_scenario_in_subprocess(scenario, out)
+    a, b = rt.load(out), rt.load(rt.golden_path(scenario))
     assert np.array_equal(a["states"], b["states"]) and np.array_equal(a["stats"], b["stats"])
+    assert list(a["log"]) == list(b["log"])
     for k in range(len(a["states"])):
         assert np.array_equal(a["ids"][k], b["ids"][k]) and np.array_equal(a["px"][k].view(np.uint32), b["px"][k].view(np.uint32))
 
