@@ -118,6 +118,9 @@ def main():
                          "may use: 2 per core, at most 32, at least 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproj", action="store_true")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="diagnostic: frames stay in pinned host memory and are uploaded inside the timed region (the PCIe-inclusive "
+                         "rate quoted in DESIGN.md; never the contract's value)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event pass (used under rocprofv3 --pmc)")
     args = ap.parse_args()
 
@@ -151,7 +154,13 @@ def main():
     ctxh = C.c_void_p(sb.ctx_handle(0))
     ctx_all = [C.c_void_p(sb.ctx_handle(g)) for g in range(sb.n_groups())]
 
+    pinned = []  # keeps the pinned host frames of --host-frames alive
+
     def dev_upload(img):
+        if args.host_frames:
+            t = torch.from_numpy(img).pin_memory()
+            pinned.append(t)
+            return t.data_ptr()
         p = C.c_void_p()
         rc = hip.icg_dev_alloc(ctxh, C.c_size_t(img.nbytes), C.byref(p))
         assert rc == 0
@@ -168,7 +177,7 @@ def main():
         f = H.pingpong(k, args.ring)
         ptrs = [dev[s][f] for s in range(B)]
         P = np.stack([poses[s][f] for s in range(B)])
-        return sb.step(ptrs, w, np.full(B, 1000.0 + k / 20.0), P, on_device=True)
+        return sb.step(ptrs, w, np.full(B, 1000.0 + k / 20.0), P, on_device=not args.host_frames)
 
     def barrier():
         torch.cuda.synchronize()
@@ -187,7 +196,7 @@ def main():
 
     def run_prepared(K, prep):
         ptrs, stamps, P, states = prep
-        rc = sb.lib.icgh_batch_run(C.c_void_p(sb.h_), K, ptrs, w, 1, 1, stamps.ctypes.data_as(C.c_void_p), P.ctypes.data_as(C.c_void_p),
+        rc = sb.lib.icgh_batch_run(C.c_void_p(sb.h_), K, ptrs, w, 1, 0 if args.host_frames else 1, stamps.ctypes.data_as(C.c_void_p), P.ctypes.data_as(C.c_void_p),
                                    states.ctypes.data_as(C.c_void_p), sb._err, 512)
         if rc != 0:
             raise RuntimeError("icgh_batch_run failed: " + sb._err.value.decode())
@@ -358,6 +367,44 @@ def main():
         ctx.close()
         ctx1.close()
 
+    # ---- f4: INS mechanization + pose prior in front of the tracker (one lane per stream) ---------------------------------
+    ins = None
+    if rank == 0 and not args.no_reproj:
+        import ins_utils as iu
+        nS, nI = 1024, 201  # streams per launch x one second of 200 Hz IMU each
+        base = iu.make_imu(nI, seed=1, jitter=True)
+        imu_all = np.tile(base, (nS, 1))
+        off = (np.arange(nS + 1) * nI).astype(np.int32)
+        s0 = np.stack([iu.make_state(base[0, 0], seed=i % 64, scale=True) for i in range(nS)])
+        cfg8 = iu.make_cfg(True, True)
+        ctxi = icgvins.Context(640, 480, n_slots=1, max_batch=1, max_points=64, device=local_rank)
+        for _ in range(2):
+            ctxi.ins_mechanize_batch(off, imu_all, cfg8, s0, want_traj=False)
+        ctxi.prof_enable(True)
+        nrep = 10
+        t1 = time.perf_counter()
+        for _ in range(nrep):
+            ctxi.ins_mechanize_batch(off, imu_all, cfg8, s0, want_traj=False)
+        wall = (time.perf_counter() - t1) / nrep
+        n_launch, ms = ctxi.prof()["ins_mechanize"]
+        kern_s = ms * 1e-3 / n_launch
+        nsamp = nS * (nI - 1)
+        ins = {"metric": "INS mechanization steps/s (MISC::insMechanization, Earth + scale-factor terms)", "streams_per_launch": nS,
+               "samples_per_stream": nI - 1, "value": round(nsamp / kern_s, 1), "unit": "samples/s", "kernel_us": round(kern_s * 1e6, 1),
+               "call_wall_us_incl_imu_upload": round(wall * 1e6, 1),
+               "bound": "latency: strictly sequential FP64 chain per stream, one lane per stream (64 B in per sample)"}
+        if not args.no_cpu_baseline:
+            import oracle_lib
+            om = iu.OrcMisc(oracle_lib.load().lib)
+            t1 = time.perf_counter()
+            nloop = 0
+            while time.perf_counter() - t1 < 2.0:
+                om.mechanize(cfg8, base, s0[0])
+                nloop += 1
+            ins["cpu_baseline"] = {"value": round(nloop * (nI - 1) / (time.perf_counter() - t1), 1), "unit": "samples/s", "cores": 1,
+                                   "kind": "port", "sample": f"{nloop} x one {nI - 1}-sample series, oracle, 1 thread"}
+        ctxi.close()
+
     # ---- CPU baseline of the front-end: same host layer on the CPU restatement (kind "port") ---------------------------
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -398,11 +445,12 @@ def main():
             "config": {"workload": f"C2: {w}x{h} synthetic stream, {nfeat} features, 10-keyframe window, 1 MI355X",
                        "streams_per_gpu": B, "groups_per_gpu": G, "frames_per_step": B * world, "host_threads_per_group": host_threads,
                        "usable_host_cores_per_rank": round(cores_rank, 1),
-                       "input_residency": "raw frames in HBM", "sharding": "independent streams per GPU, no data-path collective"},
+                       "input_residency": "pinned host frames, uploaded per frame (PCIe-inclusive diagnostic)" if args.host_frames else "raw frames in HBM", "sharding": "independent streams per GPU, no data-path collective"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "speedup_vs_cpu_baseline": (round(fps / cpu_baseline["value"], 2) if cpu_baseline else None),
             "reproj": reproj,
+            "ins": ins,
             "kernels": kernel_table,
             "host_ms_per_step": host_breakdown,
             "quality": {"mean_tracked_mappoints_per_frame": round(total_tracked / max(1.0, total_frames), 1),

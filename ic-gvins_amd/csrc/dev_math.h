@@ -116,5 +116,34 @@ __device__ __forceinline__ m33 m_skew(d3 v) {
     r.a[8] = 0;
     return r;
 }
+__device__ __forceinline__ dq q_normalized(dq q) {
+    double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    return dq{q.x / n, q.y / n, q.z / n, q.w / n};
+}
+// Rotation::rotvec2quaternion (common/rotation.h:72-76)
+__device__ __forceinline__ dq rotvec2quat(d3 rv) {
+    double angle = sqrt(rv.x * rv.x + rv.y * rv.y + rv.z * rv.z);
+    d3 axis      = rv;
+    if (angle > 0) axis = dvd(rv, angle);
+    double s = sin(0.5 * angle), c = cos(0.5 * angle);
+    return dq{s * axis.x, s * axis.y, s * axis.z, c};
+}
+// Rotation::quaternion2vector (common/rotation.h:78-81): Eigen AngleAxis(q), angle * axis
+__device__ __forceinline__ d3 quat2rotvec(dq q) {
+    d3 vec   = mk3(q.x, q.y, q.z);
+    double n = sqrt(vec.x * vec.x + vec.y * vec.y + vec.z * vec.z);
+    if (n != 0.0) {
+        double angle = 2.0 * atan2(n, fabs(q.w));
+        if (q.w < 0) n = -n;
+        return scl(angle, dvd(vec, n));
+    }
+    return mk3(0.0, 0.0, 0.0);
+}
+__device__ __forceinline__ m33 m_scale(const m33 &m, double s) {
+    m33 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.a[i] = m.a[i] * s;
+    return r;
+}
 
 } // namespace icgd

@@ -35,25 +35,7 @@ __device__ __forceinline__ void store_state(const nav_state &st, double *s) {
     s[10] = st.bg.x, s[11] = st.bg.y, s[12] = st.bg.z;
     s[13] = st.ba.x, s[14] = st.ba.y, s[15] = st.ba.z;
 }
-__device__ __forceinline__ dq q_normalized(dq q) {
-    double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    return dq{q.x / n, q.y / n, q.z / n, q.w / n};
-}
-// Rotation::rotvec2quaternion (common/rotation.h:72-76)
-__device__ __forceinline__ dq rotvec2quat(d3 rv) {
-    double angle = sqrt(rv.x * rv.x + rv.y * rv.y + rv.z * rv.z);
-    d3 axis      = rv;
-    if (angle > 0) axis = dvd(rv, angle);
-    double s = sin(0.5 * angle), c = cos(0.5 * angle);
-    return dq{s * axis.x, s * axis.y, s * axis.z, c};
-}
 __device__ __forceinline__ d3 neg3(d3 a) { return mk3(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ m33 m_scale(const m33 &m, double s) {
-    m33 r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.a[i] = m.a[i] * s;
-    return r;
-}
 } // namespace
 
 #define PI_IDX(i, j) ((i) * 15 + (j))

@@ -196,6 +196,7 @@ int icgh_batch_features(icgh_batch *b, int stream, int max, uint64_t *ids, float
 
 // ---- back-end test/driver entry points -----------------------------------------------------------------------------------
 #include "factors.h"
+#include "misc_hip.h"
 
 namespace {
 // simple generic host factor used to exercise the non-reprojection path of MarginalizationInfo:
@@ -435,6 +436,168 @@ int icgh_backend_preint(int variant, int n, const int32_t *offsets, const double
             }
         }
         icg_ctx_destroy(ctx);
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
+// ---- f4: MISC (misc_hip.h) driven through flat arrays: imu rows of 8, state rows of 23 (see include/icgvins_hip.h) ----------
+namespace {
+icg::IMU ins_imu(const double *p) {
+    icg::IMU s;
+    s.time = p[0], s.dt = p[1];
+    s.dtheta = icg::Vector3d(p[2], p[3], p[4]);
+    s.dvel   = icg::Vector3d(p[5], p[6], p[7]);
+    return s;
+}
+void ins_put_imu(const icg::IMU &m, double *r) {
+    r[0] = m.time, r[1] = m.dt;
+    for (int k = 0; k < 3; k++) r[2 + k] = m.dtheta[k], r[5 + k] = m.dvel[k];
+}
+icg::IntegrationState ins_state(const double *r) {
+    icg::IntegrationState s;
+    s.time = r[0];
+    for (int k = 0; k < 3; k++) s.p[k] = r[1 + k], s.v[k] = r[8 + k], s.bg[k] = r[11 + k], s.ba[k] = r[14 + k], s.sg[k] = r[17 + k], s.sa[k] = r[20 + k];
+    s.q = icg::Quaterniond{r[4], r[5], r[6], r[7]};
+    return s;
+}
+void ins_put_state(const icg::IntegrationState &s, double *r) {
+    r[0] = s.time;
+    for (int k = 0; k < 3; k++) r[1 + k] = s.p[k], r[8 + k] = s.v[k], r[11 + k] = s.bg[k], r[14 + k] = s.ba[k], r[17 + k] = s.sg[k], r[20 + k] = s.sa[k];
+    r[4] = s.q.x, r[5] = s.q.y, r[6] = s.q.z, r[7] = s.q.w;
+}
+icg::IntegrationConfiguration ins_config(const double *c) {
+    icg::IntegrationConfiguration cfg;
+    cfg.gravity     = icg::Vector3d(c[0], c[1], c[2]);
+    cfg.iewn        = icg::Vector3d(c[3], c[4], c[5]);
+    cfg.iswithearth = c[6] != 0, cfg.iswithscale = c[7] != 0;
+    return cfg;
+}
+icg::InsWindow ins_window(int n, const double *imu, const double *states) {
+    icg::InsWindow w;
+    for (int k = 0; k < n; k++) w.emplace_back(ins_imu(imu + 8 * (size_t) k), states ? ins_state(states + 23 * (size_t) k) : icg::IntegrationState());
+    return w;
+}
+struct TempCtx {
+    icg_ctx *ctx = nullptr;
+    explicit TempCtx(int device) {
+        icg_ctx_config cfg{};
+        cfg.device = device, cfg.width = 64, cfg.height = 64, cfg.n_slots = 1, cfg.max_batch = 1, cfg.max_points = 64;
+        if (icg_ctx_create(&cfg, &ctx) != ICG_OK) throw std::runtime_error(icg_last_error(nullptr));
+    }
+    ~TempCtx() { icg_ctx_destroy(ctx); }
+};
+} // namespace
+
+int icgh_ins_mechanize(int n_streams, const int32_t *offsets, const double *imu, const double *cfg8, double *states23, double *traj23,
+                       char *err, int errlen) {
+    try {
+        TempCtx T(0);
+        std::vector<std::vector<icg::IMU>> series((size_t) n_streams);
+        std::vector<icg::IntegrationState> st((size_t) n_streams);
+        std::vector<const std::vector<icg::IMU> *> sp;
+        std::vector<icg::IntegrationState *> stp;
+        for (int s = 0; s < n_streams; s++) {
+            for (int r = offsets[s]; r < offsets[s + 1]; r++) series[(size_t) s].push_back(ins_imu(imu + 8 * (size_t) r));
+            st[(size_t) s] = ins_state(states23 + 23 * (size_t) s);
+            sp.push_back(&series[(size_t) s]);
+            stp.push_back(&st[(size_t) s]);
+        }
+        std::vector<std::vector<icg::IntegrationState>> traj;
+        std::string e;
+        if (!icg::MISC::insMechanizationBatch(T.ctx, ins_config(cfg8), sp, stp, traj23 ? &traj : nullptr, &e)) {
+            set_err(err, errlen, e.c_str());
+            return -2;
+        }
+        for (int s = 0; s < n_streams; s++) {
+            ins_put_state(st[(size_t) s], states23 + 23 * (size_t) s);
+            if (traj23)
+                for (size_t k = 0; k < traj[(size_t) s].size(); k++) ins_put_state(traj[(size_t) s][k], traj23 + 23 * ((size_t) offsets[s] + 1 + k));
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
+// one (window, time) query per stream; windows are concatenated, stream s owns rows [win_offsets[s], win_offsets[s+1])
+int icgh_ins_camera_pose(int n_streams, const int32_t *win_offsets, const double *imu, const double *states, const double *pose_b_c12,
+                         const double *times, double *pose12_out, uint8_t *found_out, char *err, int errlen) {
+    try {
+        TempCtx T(0);
+        std::vector<icg::InsWindow> w;
+        std::vector<const icg::InsWindow *> wp;
+        for (int s = 0; s < n_streams; s++)
+            w.push_back(ins_window(win_offsets[s + 1] - win_offsets[s], imu + 8 * (size_t) win_offsets[s], states + 23 * (size_t) win_offsets[s]));
+        for (auto &x : w) wp.push_back(&x);
+        icg::Pose pbc;
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) pbc.R(i, j) = pose_b_c12[3 * i + j];
+            pbc.t[i] = pose_b_c12[9 + i];
+        }
+        std::vector<icg::Pose> poses;
+        std::vector<uint8_t> found;
+        std::string e;
+        if (!icg::MISC::getCameraPoseFromInsWindowBatch(T.ctx, wp, pbc, std::vector<double>(times, times + n_streams), poses, found, &e)) {
+            set_err(err, errlen, e.c_str());
+            return -2;
+        }
+        for (int s = 0; s < n_streams; s++) {
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++) pose12_out[12 * (size_t) s + 3 * i + j] = poses[(size_t) s].R(i, j);
+                pose12_out[12 * (size_t) s + 9 + i] = poses[(size_t) s].t[i];
+            }
+            found_out[s] = found[(size_t) s];
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
+long icgh_ins_window_index(int n_win, const double *imu, double time) {
+    return (long) icg::MISC::getInsWindowIndex(ins_window(n_win, imu, nullptr), time);
+}
+
+// MISC::getImuSeriesFromTo: number of samples written, -1 on failure, -2 when cap is too small
+int icgh_ins_imu_series(int n_win, const double *imu, double start, double end, int cap, double *series) {
+    std::vector<icg::IMU> out;
+    if (!icg::MISC::getImuSeriesFromTo(ins_window(n_win, imu, nullptr), start, end, out)) return -1;
+    if ((int) out.size() > cap) return -2;
+    for (size_t k = 0; k < out.size(); k++) ins_put_imu(out[k], series + 8 * k);
+    return (int) out.size();
+}
+
+// MISC::redoInsMechanizationBatch: windows concatenated like icgh_ins_camera_pose; states updated in place, new_len[s] = the
+// window length after the expired front entries were dropped (rows compacted to the front of each stream's slice)
+int icgh_ins_redo(int n_streams, const double *cfg8, const double *updated23, int reserved, const int32_t *win_offsets, double *imu,
+                  double *states, int32_t *new_len, char *err, int errlen) {
+    try {
+        TempCtx T(0);
+        std::vector<icg::InsWindow> w;
+        std::vector<icg::InsWindow *> wp;
+        std::vector<icg::IntegrationState> upd;
+        for (int s = 0; s < n_streams; s++) {
+            w.push_back(ins_window(win_offsets[s + 1] - win_offsets[s], imu + 8 * (size_t) win_offsets[s], states + 23 * (size_t) win_offsets[s]));
+            upd.push_back(ins_state(updated23 + 23 * (size_t) s));
+        }
+        for (auto &x : w) wp.push_back(&x);
+        std::string e;
+        if (!icg::MISC::redoInsMechanizationBatch(T.ctx, ins_config(cfg8), upd, (size_t) reserved, wp, &e)) {
+            set_err(err, errlen, e.c_str());
+            return -2;
+        }
+        for (int s = 0; s < n_streams; s++) {
+            new_len[s] = (int32_t) w[(size_t) s].size();
+            for (size_t k = 0; k < w[(size_t) s].size(); k++) {
+                ins_put_imu(w[(size_t) s][k].first, imu + 8 * ((size_t) win_offsets[s] + k));
+                ins_put_state(w[(size_t) s][k].second, states + 23 * ((size_t) win_offsets[s] + k));
+            }
+        }
         return 0;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());

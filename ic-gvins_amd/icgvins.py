@@ -18,6 +18,7 @@ EXPORTS = [
     "icg_lk_track", "icg_lk_track_fb", "icg_undistort_points", "icg_distort_points", "icg_predict_mappoints",
     "icg_predict_rotation", "icg_fm_ransac", "icg_detect", "icg_triangulate", "icg_reproj_eval_batch",
     "icg_reproj_set_factors", "icg_reproj_eval_resident", "icg_reproj_accumulate_normal", "icg_preint_batch",
+    "icg_ins_mechanize_batch", "icg_ins_camera_pose_batch",
 ]
 
 
@@ -317,3 +318,22 @@ class Context:
         self._ck(self.lib.icg_preint_batch(self.h, int(variant), n, _p(offsets), _p(imu), _p(state0), _p(_f64(params)),
                                             _p(cur), _p(delta), _p(jac), _p(cov), _p(dt), _p(pn)), "icg_preint_batch")
         return cur, delta, jac, cov, dt, pn
+
+    # ---- f4
+    def ins_mechanize_batch(self, offsets, imu, cfg8, states23, want_traj=True):
+        offsets = _i32(offsets)
+        n = len(offsets) - 1
+        imu = _f64(imu).reshape(-1, 8)
+        st = _f64(states23).reshape(n, 23).copy()
+        traj = np.zeros((imu.shape[0], 23)) if want_traj else None
+        self._ck(self.lib.icg_ins_mechanize_batch(self.h, n, _p(offsets), _p(imu), _p(_f64(cfg8)), _p(st), _p(traj)),
+                 "icg_ins_mechanize_batch")
+        return st, traj
+
+    def ins_camera_pose_batch(self, brackets16, interp, pose_b_c12, times):
+        b = _f64(brackets16).reshape(-1, 16)
+        n = b.shape[0]
+        out = np.zeros((n, 12))
+        self._ck(self.lib.icg_ins_camera_pose_batch(self.h, n, _p(b), _p(_i32(interp)), _p(_f64(pose_b_c12)), _p(_f64(times)), _p(out)),
+                 "icg_ins_camera_pose_batch")
+        return out

@@ -189,6 +189,26 @@ int icg_preint_batch(icg_ctx *ctx, int variant, int n_intervals, const int32_t *
                      const double *state0, const double *params, double *cur_state, double *delta_state, double *jac,
                      double *cov, double *delta_time, double *pn);
 
+/* ---- f4 (SURVEY.md §8 "next" row): the INS steps in front of the tracker, batched over independent streams -----------
+ * Layouts: imu rows of 8 doubles (time, dt, dtheta[3], dvel[3]); state rows of 23 doubles (time, p3, q4 xyzw, v3, bg3, ba3,
+ * sg3, sa3 = IntegrationState, preintegration/integration_state.h:35-52 without the odometer fields);
+ * cfg8 = gravity[3], iewn[3], iswithearth, iswithscale (IntegrationConfiguration, integration_state.h:91-99).
+ *
+ * icg_ins_mechanize_batch: MISC::insMechanization (misc.cc:151-206) applied in sequence to the samples
+ * offsets[s]+1 .. offsets[s+1]-1 of stream s (sample offsets[s] is imu_pre of the first step), starting from states23[s]
+ * (updated in place to the state after the last sample).  traj23 (optional, total x 23): row offsets[s] = the start state,
+ * row offsets[s]+k = the state after sample k — i.e. the (IMU, state) window the reference keeps in ins_window_
+ * (ic_gvins.cc:653-700) and re-propagates in MISC::redoInsMechanization (misc.cc:208-261). */
+int icg_ins_mechanize_batch(icg_ctx *ctx, int n_streams, const int32_t *offsets, const double *imu, const double *cfg8,
+                            double *states23, double *traj23);
+/* icg_ins_camera_pose_batch: the INS pose prior of n frames, MISC::getCameraPoseFromInsWindow (misc.cc:67-83) after its
+ * bracket search: brackets16[i] = (time, p3, q4) of the window states before and after times[i]; interp[i] != 0 ->
+ * statePoseInterpolation (misc.cc:85-100), interp[i] == 0 -> the first state as is (the reference's fallback to the newest
+ * state when the time is outside the window); then stateToCameraPose (misc.cc:102-108) with the body->camera extrinsic
+ * pose_b_c12 (R row-major 9, t 3).  pose12_out: n x 12, same layout (camera->world). */
+int icg_ins_camera_pose_batch(icg_ctx *ctx, int n, const double *brackets16, const int32_t *interp, const double *pose_b_c12,
+                              const double *times, double *pose12_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -297,4 +297,35 @@ int icg_preint_batch(icg_ctx *, int variant, int n_intervals, const int32_t *off
     return ICG_OK;
 }
 
+int icg_ins_mechanize_batch(icg_ctx *, int n_streams, const int32_t *offsets, const double *imu, const double *cfg8, double *states23,
+                            double *traj23) {
+    for (int s = 0; s < n_streams; s++) {
+        int b = offsets[s], n = offsets[s + 1] - offsets[s];
+        if (traj23 && n > 0) memcpy(traj23 + 23 * (size_t) b, states23 + 23 * (size_t) s, sizeof(double) * 23);
+        orc_ins_mechanize(cfg8, n, imu + 8 * (size_t) b, states23 + 23 * (size_t) s, (traj23 && n > 1) ? traj23 + 23 * (size_t) (b + 1) : nullptr);
+    }
+    return ICG_OK;
+}
+
+int icg_ins_camera_pose_batch(icg_ctx *, int n, const double *brackets16, const int32_t *interp, const double *pose_b_c12,
+                              const double *times, double *pose12_out) {
+    for (int i = 0; i < n; i++) { // a two-state window reproduces the bracketed interpolation of orc_ins_camera_pose
+        const double *b = brackets16 + 16 * (size_t) i;
+        double imu[16] = {0}, st[46] = {0};
+        imu[0] = b[0], imu[8] = b[8];
+        st[0]  = b[0], st[23] = b[8];
+        memcpy(st + 1, b + 1, sizeof(double) * 7);
+        memcpy(st + 24, b + 9, sizeof(double) * 7);
+        if (interp[i]) {
+            // times[i] lies in [t0, t1): index 1 of the two-state window
+            double t = times[i];
+            if (!(b[0] <= t && t < b[8])) return ICG_ERR_INVALID;
+            orc_ins_camera_pose(2, imu, st, pose_b_c12, t, pose12_out + 12 * (size_t) i);
+        } else {
+            orc_ins_camera_pose(1, imu, st, pose_b_c12, b[0] - 1.0, pose12_out + 12 * (size_t) i); // outside -> newest state as is
+        }
+    }
+    return ICG_OK;
+}
+
 } // extern "C"

@@ -92,6 +92,17 @@ void orc_preint_evaluate(int variant, const double *delta_state, const double *j
                          const double *pose0, const double *mix0, const double *pose1, const double *mix1,
                          double *residuals /*15*/, double *jacobians /*15x7,15x9,15x7,15x9 concatenated, may be NULL*/);
 
+// ---- INS helpers in front of the tracker (orc_ins.cc) ---------------------------------
+// imu rows of 8 (time, dt, dtheta3, dvel3); state rows of 23 (time, p3, q4 xyzw, v3, bg3, ba3, sg3, sa3);
+// cfg8 = gravity3, iewn3, iswithearth, iswithscale; poses 12 = R row-major 9, t 3
+void orc_ins_mechanize(const double *cfg8, int n_imu, const double *imu, double *state23 /*in/out*/,
+                       double *traj /* (n_imu-1) x 23, may be NULL */);
+int64_t orc_ins_window_index(int n_win, const double *imu, double time);
+int orc_ins_camera_pose(int n_win, const double *imu, const double *states, const double *pose_b_c12, double time,
+                        double *pose12);
+int orc_imu_series(int n_win, const double *imu, double start, double end, int cap, double *series /* cap x 8 */);
+int orc_redo_ins(const double *cfg8, const double *updated_state23, int reserved, int n_win, double *imu, double *states);
+
 #ifdef __cplusplus
 }
 #endif
