@@ -541,10 +541,16 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
                 for (int k = 0; k < m; k++) jobs.src[k] = images[base + k];
                 jobs.stride = stride;
             } else {
+                // contiguous frames (stride == width == staging pitch) go as ONE linear copy: the 2-D path of the runtime is several
+                // times slower for pinned host memory
+                const bool linear = stride == w && ctx->raw_pitch == w;
                 for (int k = 0; k < m; k++) {
-                    ICG_HIP(ctx, hipMemcpy2DAsync(ctx->d_raw + (size_t) (base + k) * raw_batch, ctx->raw_pitch, images[base + k],
-                                                  stride, w, h, kind, ctx->stream));
-                    jobs.src[k] = ctx->d_raw + (size_t) (base + k) * raw_batch;
+                    uint8_t *dst = ctx->d_raw + (size_t) (base + k) * raw_batch;
+                    if (linear)
+                        ICG_HIP(ctx, hipMemcpyAsync(dst, images[base + k], (size_t) w * h, kind, ctx->stream));
+                    else
+                        ICG_HIP(ctx, hipMemcpy2DAsync(dst, ctx->raw_pitch, images[base + k], stride, w, h, kind, ctx->stream));
+                    jobs.src[k] = dst;
                 }
                 jobs.stride = ctx->raw_pitch;
             }

@@ -1,6 +1,8 @@
 // Host-side data model implementation (see model.h for the reference lines each class mirrors).
 #include "model.h"
 
+#include <atomic>
+
 namespace icg {
 
 std::shared_ptr<IdSpace> IdSpace::global() {
@@ -103,9 +105,17 @@ Vector2d Camera::reprojectionError(const Pose &pose, const Vector3d &pw, const P
 }
 
 // ---- Frame (tracking/frame.cc) -------------------------------------------------------------------------------
+namespace {
+std::atomic<bool> g_retain_raw_images{false};
+}
+void Frame::retainRawImages(bool on) { g_retain_raw_images.store(on); }
+
 Frame::Frame(ulong id, double stamp, Mat image, std::shared_ptr<IdSpace> ids)
     : id_(id), keyframe_id_(0), stamp_(stamp), image_(std::move(image)), iskeyframe_(false), ids_(std::move(ids)) {
-    image_.copyTo(raw_image_);
+    if (g_retain_raw_images.load(std::memory_order_relaxed))
+        image_.copyTo(raw_image_);
+    else
+        raw_image_ = image_;
 }
 
 Frame::Ptr Frame::createFrame(double stamp, const Mat &image, const std::shared_ptr<IdSpace> &ids) {

@@ -139,6 +139,10 @@ public:
         keyframe_state_ = KEYFRAME_NONE;
     }
     Mat &image() { return image_; }
+    // frame.cc:34 deep-copies every incoming image into raw_image_ for the drawer.  Here the copy (0.9 MB per C2 frame on the
+    // ingest thread) is made only when someone asked for it — Tracking does when is_use_visualization is set; otherwise
+    // rawImage() aliases the caller's buffer and is only valid while that buffer is.
+    static void retainRawImages(bool on);
     Mat &rawImage() { return raw_image_; }
     Pose pose() {
         ModelLock lock(frame_mutex_);

@@ -183,6 +183,7 @@ Tracking::Tracking(Camera::Ptr camera, Map::Ptr map, Drawer::Ptr drawer, const T
 
 void Tracking::init(const std::string &outputpath) {
     if (!drawer_) drawer_ = std::make_shared<Drawer>(); // the reference dereferences it unconditionally (:515,:559)
+    if (cfg_.is_use_visualization) Frame::retainRawImages(true); // the drawer reads frame->rawImage()
     if (!outputpath.empty()) { // :44-50; the reference logs an error and leaves the tracker half-constructed, this one throws
         logfile_ = fopen((outputpath + "/tracking.txt").c_str(), "w");
         if (!logfile_) throw std::runtime_error("Tracking: failed to open " + outputpath + "/tracking.txt");
