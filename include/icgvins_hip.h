@@ -198,7 +198,7 @@ int icg_preint_batch(icg_ctx *ctx, int variant, int n_intervals, const int32_t *
  * offsets[s]+1 .. offsets[s+1]-1 of stream s (sample offsets[s] is imu_pre of the first step), starting from states23[s]
  * (updated in place to the state after the last sample).  traj23 (optional, total x 23): row offsets[s] = the start state,
  * row offsets[s]+k = the state after sample k — i.e. the (IMU, state) window the reference keeps in ins_window_
- * (ic_gvins.cc:653-700) and re-propagates in MISC::redoInsMechanization (misc.cc:208-261). */
+ * (ic_gvins.cc:270-290) and re-propagates in MISC::redoInsMechanization (misc.cc:208-261). */
 int icg_ins_mechanize_batch(icg_ctx *ctx, int n_streams, const int32_t *offsets, const double *imu, const double *cfg8,
                             double *states23, double *traj23);
 /* icg_ins_camera_pose_batch: the INS pose prior of n frames, MISC::getCameraPoseFromInsWindow (misc.cc:67-83) after its
