@@ -72,6 +72,12 @@ struct icg_ctx {
     double *d_params = nullptr; // poses, ext, invdepth, td (device copy)
     size_t params_cap = 0;
     int last_n_poses = 0, last_n_lm = 0;
+    double last_huber = 0.0;
+    // f1: resident normal equations of the visual factors ((P+L)^2 matrix, rhs, 1/(h_ll + damping) per landmark)
+    double *d_sys = nullptr;
+    size_t sys_cap = 0; // doubles
+    int sys_P = 0, sys_L = 0, sys_valid = 0;
+    double sys_damp = 0.0, sys_min_diag = 0.0, sys_max_diag = 0.0;
 
     icg_camera cam{};
     bool has_cam = false;

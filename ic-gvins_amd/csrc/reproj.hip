@@ -230,6 +230,7 @@ extern "C" int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa
     if (rc) return rc;
     ctx->n_factors_resident = n;
     ctx->rJ_valid           = 0;
+    ctx->sys_valid          = 0;
     if (n == 0) return ICG_OK;
     // component-major obs is already the device layout; indices packed as 3 x n
     ICG_HIP(ctx, hipMemcpyAsync(ctx->d_obs, obs_soa, sizeof(double) * 15 * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
@@ -286,6 +287,7 @@ extern "C" int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double 
     ICG_HIP(ctx, hipGetLastError());
     ctx->rJ_valid     = 1;
     ctx->rJ_has_jac   = want_jac;
+    ctx->last_huber   = huber_delta;
     ctx->last_n_poses = n_poses;
     ctx->last_n_lm    = n_lm;
     if (out_r) {
@@ -322,16 +324,18 @@ extern "C" int icg_reproj_eval_batch(icg_ctx *ctx, int n, const double *obs_soa,
 __global__ __launch_bounds__(NRM_BLOCK) void k_reproj_normal(int n, const double *r, const double *J, const int32_t *idx_i,
                                                              const int32_t *idx_j, const int32_t *idx_lm,
                                                              const int32_t *col_pose, int col_ext, const int32_t *col_lm,
-                                                             int col_td, int L, double *H, double *b) {
+                                                             int col_td, int L, double *H, double *b, const uint8_t *active,
+                                                             int lm_base) {
     __shared__ double sh[7 * 7 + 7]; // shared (ext|td) x (ext|td) block and its b rows
     const int t = threadIdx.x;
     for (int e = t; e < 56; e += NRM_BLOCK) sh[e] = 0.0;
     __syncthreads();
     const int f = blockIdx.x * NRM_BLOCK + t;
-    if (f < n) {
+    if (f < n && (!active || active[f])) {
         const double *Jf = J + 46 * (size_t) f;
         const double r0 = r[2 * (size_t) f], r1 = r[2 * (size_t) f + 1];
-        const int col[5] = {col_pose[idx_i[f]], col_pose[idx_j[f]], col_ext, col_lm[idx_lm[f]], col_td};
+        // col_lm == nullptr: landmark l sits at column lm_base + l (the Schur layout of icg_reproj_schur)
+        const int col[5] = {col_pose[idx_i[f]], col_pose[idx_j[f]], col_ext, col_lm ? col_lm[idx_lm[f]] : lm_base + idx_lm[f], col_td};
         const int sz[5]  = {6, 6, 6, 1, 1};
         const int off[5] = {0, 14, 28, 42, 44};
         const int ld[5]  = {7, 7, 7, 1, 1};
@@ -402,11 +406,219 @@ extern "C" int icg_reproj_accumulate_normal(icg_ctx *ctx, int local_size, const 
         hipLaunchKernelGGL(k_reproj_normal, dim3((n + NRM_BLOCK - 1) / NRM_BLOCK), dim3(NRM_BLOCK), 0, ctx->stream, n,
                            (const double *) ctx->d_rJ, (const double *) (ctx->d_rJ + 2 * (size_t) ctx->factors_cap),
                            (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n),
-                           (const int32_t *) (ctx->d_fidx + 2 * (size_t) n), d_cp, (int) col_ext, d_cl, (int) col_td, local_size, d_H, d_b);
+                           (const int32_t *) (ctx->d_fidx + 2 * (size_t) n), d_cp, (int) col_ext, d_cl, (int) col_td, local_size, d_H, d_b,
+                           (const uint8_t *) nullptr, 0);
     }
     ICG_HIP(ctx, hipGetLastError());
     if ((rc = c.finish())) return rc;
     for (size_t i = 0; i < L * L; i++) H0[i] += hH[i];
     for (size_t i = 0; i < L; i++) b0[i] += hb[i];
     return ICG_OK;
+}
+
+
+// ---- f1 (SURVEY.md §8 "next" row): device-side Schur complement of the visual factors ----------------------------------------
+// The Gauss-Newton / Levenberg-Marquardt step of GVINS::gvinsOptimization (ic_gvins.cc:1130-1239, Ceres DENSE_SCHUR) eliminates
+// the inverse-depth blocks (1x1 each) first.  With the robust-corrected r/J of the last icg_reproj_eval_resident call still
+// resident, k_reproj_normal assembles  H = [Hcc G^T; G diag(h_ll)], b = -J^T r  in the column layout (camera columns 0..P-1,
+// landmark l at P+l), and the kernels below reduce it:   S = Hcc - G^T diag(1/(h_ll + d_l)) G,   s = bc - G^T (b_l/(h_ll+d_l)),
+// d_l = clamp(h_ll, min_diag, max_diag) * damp  (the LM diagonal of the eliminated block).  G, h_ll, b_l stay resident for the
+// back-substitution  delta_l = (b_l - G_l . delta_c) / (h_ll + d_l).
+// Sizes: P <= ~160 (10 poses x 6 + extrinsic 6 + td 1 [+ anything the host adds]), L = 300..500: a (P+L)^2 FP64 system of
+// 1.7-3.4 MB that never leaves the device; only S (P x P), s and the diagonal cross PCIe per iteration.
+#define SCH_T 16
+
+__global__ void k_schur_inv(int P, int L, int N, const double *H, double damp, double min_diag, double max_diag, double *inv) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const double h = H[(size_t) (P + l) * N + P + l];
+    // a landmark without any active factor has an empty row: it is left where it is (delta_l = 0)
+    inv[l] = h > 0.0 ? 1.0 / (h + fmin(fmax(h, min_diag), max_diag) * damp) : 0.0;
+}
+
+__global__ __launch_bounds__(SCH_T *SCH_T) void k_schur_reduce(int P, int L, int N, const double *H, const double *b, const double *inv,
+                                                               double *S, double *s, double *diag) {
+    __shared__ double gi[SCH_T][SCH_T + 1], gj[SCH_T][SCH_T + 1], w[SCH_T];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int i = blockIdx.y * SCH_T + ty, j = blockIdx.x * SCH_T + tx;
+    double acc = 0.0, accs = 0.0;
+    for (int l0 = 0; l0 < L; l0 += SCH_T) {
+        // rows l0..l0+15 of G, the 16 columns of this tile's i range and j range (coalesced along the row)
+        const int l = l0 + ty;
+        const int ci = blockIdx.y * SCH_T + tx;
+        gi[ty][tx] = (l < L && ci < P) ? H[(size_t) (P + l) * N + ci] : 0.0;
+        gj[ty][tx] = (l < L && j < P) ? H[(size_t) (P + l) * N + j] : 0.0;
+        if (ty == 0) w[tx] = (l0 + tx < L) ? inv[l0 + tx] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCH_T; k++) {
+            acc += gi[k][ty] * w[k] * gj[k][tx];
+            if (blockIdx.x == 0 && tx == 0) accs += gi[k][ty] * w[k] * ((l0 + k < L) ? b[P + l0 + k] : 0.0);
+        }
+        __syncthreads();
+    }
+    if (i < P && j < P) S[(size_t) i * P + j] = H[(size_t) i * N + j] - acc;
+    if (blockIdx.x == 0 && tx == 0 && i < P) {
+        s[i]    = b[i] - accs;
+        diag[i] = H[(size_t) i * N + i];
+    }
+}
+
+// one wave per landmark: delta_l = (b_l - G_l . delta_c) * inv_l
+// terms (2 doubles, pre-zeroed): sum b_l^2 / (h_ll + d_l) and sum d_l delta_l^2 — the landmark part of the LM model decrease
+// 0.5 (delta^T b + delta^T D delta): with the reduced right-hand side s, delta^T b = delta_c^T s + terms[0], so the step-quality
+// ratio can be formed without moving G or b_l to the host
+__global__ __launch_bounds__(64) void k_schur_backsub(int P, int L, int N, const double *H, const double *b, const double *inv,
+                                                      const double *delta_c, double *delta_l, double *terms, double damp, double min_diag,
+                                                      double max_diag) {
+    const int l = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < P; i += 64) acc += H[(size_t) (P + l) * N + i] * delta_c[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (threadIdx.x == 0) {
+        const double bl = b[P + l], w = inv[l];
+        const double d  = (bl - acc) * w;
+        delta_l[l]      = d;
+        if (w > 0.0) {
+            const double dl = fmin(fmax(H[(size_t) (P + l) * N + P + l], min_diag), max_diag) * damp; // the damping that went into inv
+            unsafeAtomicAdd(&terms[0], bl * bl * w);
+            unsafeAtomicAdd(&terms[1], dl * d * d);
+        }
+    }
+}
+
+// 0.5 * sum rho(|r|^2) of the active factors from the resident (possibly Huber-corrected) residuals: the corrector leaves
+// |r_c|^2 = rho'(s) s, i.e. s for inliers and a sqrt(s) > a^2 for outliers, so rho(s) = 2 a sqrt(s) - a^2 = 2 |r_c|^2 - a^2
+__global__ __launch_bounds__(256) void k_reproj_cost(int n, const double *r, const uint8_t *active, double huber, double *out) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < n; f += gridDim.x * 256) {
+        if (active && !active[f]) continue;
+        const double r0 = r[2 * (size_t) f], r1 = r[2 * (size_t) f + 1];
+        double q = r0 * r0 + r1 * r1;
+        if (huber > 0.0 && q > huber * huber) q = 2.0 * q - huber * huber;
+        acc += 0.5 * q;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+static int ensure_sys_capacity(icg_ctx *ctx, size_t doubles) {
+    if (doubles <= ctx->sys_cap) return 0;
+    ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_sys) (void) hipFree(ctx->d_sys);
+    ctx->d_sys   = nullptr;
+    ctx->sys_cap = 0;
+    size_t cap   = doubles + doubles / 4;
+    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_sys, sizeof(double) * cap));
+    ctx->sys_cap = cap;
+    return 0;
+}
+
+extern "C" int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, int32_t col_ext, int32_t col_td, const uint8_t *active,
+                                int reassemble, double damp, double min_diag, double max_diag, double *S, double *s, double *diag_cc,
+                                double *cost) {
+    if (!ctx || P <= 0 || !col_pose || !S || !s) return ICG_ERR_INVALID;
+    if (reassemble && (!ctx->rJ_valid || !ctx->rJ_has_jac))
+        return icg_fail(ctx, ICG_ERR_INVALID, "no resident Jacobians: call icg_reproj_eval_resident with want_jac first");
+    if (!reassemble && (!ctx->sys_valid || ctx->sys_P != P))
+        return icg_fail(ctx, ICG_ERR_INVALID, "no resident normal equations of size %d to re-damp", P);
+    const int n = ctx->n_factors_resident, L = ctx->last_n_lm;
+    if (n == 0) return icg_fail(ctx, ICG_ERR_INVALID, "no resident factors");
+    for (int k = 0; k < ctx->last_n_poses; k++)
+        if (col_pose[k] >= 0 && col_pose[k] + 6 > P) return icg_fail(ctx, ICG_ERR_INVALID, "pose %d: column %d outside the reduced system (%d)", k, col_pose[k], P);
+    if ((col_ext >= 0 && col_ext + 6 > P) || (col_td >= 0 && col_td + 1 > P)) return icg_fail(ctx, ICG_ERR_INVALID, "ext/td column outside the reduced system");
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t N = (size_t) P + L;
+    int rc         = ensure_sys_capacity(ctx, N * N + N + (size_t) L + 8);
+    if (rc) return rc;
+    double *d_H = ctx->d_sys, *d_b = d_H + N * N, *d_inv = d_b + N, *d_cost = d_inv + L;
+    icg_call c(ctx);
+    rc = c.reserve(sizeof(int32_t) * (size_t) ctx->last_n_poses + (size_t) n + sizeof(double) * ((size_t) P * P + 2 * (size_t) P + 1) + 4096);
+    if (rc) return rc;
+    const int32_t *d_cp = c.in(col_pose, (size_t) ctx->last_n_poses);
+    const uint8_t *d_act = active ? c.in(active, (size_t) n) : nullptr;
+    if ((rc = c.seal())) return rc;
+    double *d_S = c.out(S, (size_t) P * P);
+    double *d_s = c.out(s, (size_t) P);
+    double *d_dg = c.out(diag_cc, (size_t) P); // user pointer may be null: still a valid device scratch
+    double *d_co = c.out(cost, 1);
+    const double *d_r = ctx->d_rJ, *d_J = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
+    if (reassemble) {
+        ICG_HIP(ctx, hipMemsetAsync(d_H, 0, sizeof(double) * (N * N + N + (size_t) L + 1), ctx->stream));
+        icg_prof_scope ps(ctx, "reproj_normal");
+        hipLaunchKernelGGL(k_reproj_normal, dim3((n + NRM_BLOCK - 1) / NRM_BLOCK), dim3(NRM_BLOCK), 0, ctx->stream, n, d_r, d_J,
+                           (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n), (const int32_t *) (ctx->d_fidx + 2 * (size_t) n),
+                           d_cp, (int) col_ext, (const int32_t *) nullptr, (int) col_td, (int) N, d_H, d_b, d_act, P);
+    }
+    {
+        icg_prof_scope ps(ctx, "schur_reduce");
+        hipLaunchKernelGGL(k_schur_inv, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, P, L, (int) N, (const double *) d_H, damp, min_diag,
+                           max_diag, d_inv);
+        hipLaunchKernelGGL(k_schur_reduce, dim3((P + SCH_T - 1) / SCH_T, (P + SCH_T - 1) / SCH_T), dim3(SCH_T, SCH_T), 0, ctx->stream, P, L,
+                           (int) N, (const double *) d_H, (const double *) d_b, (const double *) d_inv, d_S, d_s, d_dg);
+        // the cost belongs to the linearization point: only meaningful while the resident residuals are the ones assembled
+        if (reassemble)
+            hipLaunchKernelGGL(k_reproj_cost, dim3(std::min(64, (n + 255) / 256)), dim3(256), 0, ctx->stream, n, d_r, d_act, ctx->last_huber,
+                               d_cost);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    ICG_HIP(ctx, hipMemcpyAsync(d_co, d_cost, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = c.finish())) return rc;
+    ctx->sys_P = P, ctx->sys_L = L, ctx->sys_valid = 1;
+    ctx->sys_damp = damp, ctx->sys_min_diag = min_diag, ctx->sys_max_diag = max_diag;
+    return ICG_OK;
+}
+
+extern "C" int icg_reproj_backsub(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
+    if (!ctx || !delta_c || !delta_l) return ICG_ERR_INVALID;
+    if (!ctx->sys_valid || ctx->sys_P != P) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Schur system of size %d: call icg_reproj_schur first", P);
+    const int L = ctx->sys_L;
+    const size_t N = (size_t) P + L;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const double *d_H = ctx->d_sys, *d_b = d_H + N * N, *d_inv = d_b + N;
+    icg_call c(ctx);
+    int rc = c.reserve(sizeof(double) * ((size_t) P + L + 2) + 4096);
+    if (rc) return rc;
+    const double *d_dc = c.in(delta_c, (size_t) P);
+    const double zeros[2] = {0.0, 0.0};
+    double *d_tm = c.in(zeros, 2);
+    if ((rc = c.seal())) return rc;
+    if (lm_terms) c.outs.push_back({(void *) lm_terms, (size_t) ((char *) d_tm - ctx->d_arena), 2 * sizeof(double), false});
+    double *d_dl = c.out(delta_l, (size_t) L);
+    {
+        icg_prof_scope ps(ctx, "schur_backsub");
+        hipLaunchKernelGGL(k_schur_backsub, dim3(L), dim3(64), 0, ctx->stream, P, L, (int) N, d_H, d_b, d_inv, d_dc, d_dl, d_tm, ctx->sys_damp,
+                           ctx->sys_min_diag, ctx->sys_max_diag);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}
+
+extern "C" int icg_reproj_cost(icg_ctx *ctx, const uint8_t *active, double *cost) {
+    if (!ctx || !cost) return ICG_ERR_INVALID;
+    if (!ctx->rJ_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident residuals: call icg_reproj_eval_resident first");
+    const int n = ctx->n_factors_resident;
+    *cost       = 0.0;
+    if (n == 0) return ICG_OK;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    icg_call c(ctx);
+    int rc = c.reserve((size_t) n + 64 + 4096);
+    if (rc) return rc;
+    const uint8_t *d_act = active ? c.in(active, (size_t) n) : nullptr;
+    const double zero = 0.0;
+    double *d_acc = c.in(&zero, 1);
+    if ((rc = c.seal())) return rc;
+    c.outs.push_back({(void *) cost, (size_t) ((char *) d_acc - ctx->d_arena), sizeof(double), false});
+    {
+        icg_prof_scope ps(ctx, "reproj_cost");
+        hipLaunchKernelGGL(k_reproj_cost, dim3(std::min(64, (n + 255) / 256)), dim3(256), 0, ctx->stream, n, (const double *) ctx->d_rJ, d_act,
+                           ctx->last_huber, d_acc);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
 }

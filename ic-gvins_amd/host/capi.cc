@@ -197,6 +197,7 @@ int icgh_batch_features(icgh_batch *b, int stream, int max, uint64_t *ids, float
 // ---- back-end test/driver entry points -----------------------------------------------------------------------------------
 #include "factors.h"
 #include "misc_hip.h"
+#include "solver_hip.h"
 
 namespace {
 // simple generic host factor used to exercise the non-reprojection path of MarginalizationInfo:
@@ -436,6 +437,67 @@ int icgh_backend_preint(int variant, int n, const int32_t *offsets, const double
             }
         }
         icg_ctx_destroy(ctx);
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
+// ---- f1: the window optimization flow of GVINS::gvinsOptimization (ic_gvins.cc:1130-1239) on WindowSolver -----------------
+// Reprojection factors from flat arrays (as icgh_backend_reproj) + one PosePriorFactor per pose (weight prior_weight, target
+// prior_poses: fixes the gauge like the reference's marginalization prior / GNSS factors do).  Two solves with the chi-square
+// culling pass in between (chi2 <= 0: one solve of iters1 iterations).  All parameter arrays are updated in place.
+// summary8: initial cost, cost after solve 1, final cost, successful steps 1, unsuccessful 1, successful 2, unsuccessful 2, removed
+int icgh_backend_solve(int n, const double *obs_soa, const int32_t *idx_i, const int32_t *idx_j, const int32_t *idx_lm, int n_poses,
+                       double *poses, double *ext, int n_lm, double *invdepth, double *td, const double *prior_poses, double prior_weight,
+                       double huber, int ext_constant, int td_constant, int iters1, int iters2, double chi2, double *summary8,
+                       uint8_t *active_out, char *err, int errlen) {
+    try {
+        vector<std::unique_ptr<ReprojectionFactor>> factors;
+        ReprojectionBatch batch(0);
+        for (int k = 0; k < n; k++) {
+            auto o = [&](int c) { return obs_soa[(size_t) c * n + k]; };
+            factors.emplace_back(new ReprojectionFactor(Vector3d(o(0), o(1), o(2)), Vector3d(o(3), o(4), o(5)), Vector3d(o(6), o(7), o(8)),
+                                                        Vector3d(o(9), o(10), o(11)), o(12), o(13), o(14)));
+            batch.add(factors.back().get(), poses + 7 * (size_t) idx_i[k], poses + 7 * (size_t) idx_j[k], ext, invdepth + idx_lm[k], td);
+        }
+        batch.finalize();
+        WindowSolver solver(&batch, huber);
+        for (int k = 0; k < n_poses; k++) solver.addParameterBlock(poses + 7 * (size_t) k, 7, true);
+        solver.addParameterBlock(ext, 7, true);
+        for (int l = 0; l < n_lm; l++) solver.addParameterBlock(invdepth + l, 1);
+        solver.addParameterBlock(td, 1);
+        if (ext_constant) solver.setParameterBlockConstant(ext);
+        if (td_constant) solver.setParameterBlockConstant(td);
+        for (int k = 0; k < n_poses; k++)
+            solver.addResidualBlock(std::make_shared<PosePriorFactor>(prior_poses + 7 * (size_t) k, prior_weight), nullptr,
+                                    {poses + 7 * (size_t) k});
+        WindowSolver::Options opt;
+        WindowSolver::Summary s1, s2;
+        opt.max_num_iterations = iters1;
+        if (!solver.solve(opt, &s1)) {
+            set_err(err, errlen, solver.error().c_str());
+            return -2;
+        }
+        summary8[0] = s1.initial_cost, summary8[1] = s1.final_cost, summary8[2] = s1.final_cost;
+        summary8[3] = s1.num_successful_steps, summary8[4] = s1.num_unsuccessful_steps;
+        summary8[5] = summary8[6] = summary8[7] = 0;
+        if (chi2 > 0) {
+            int removed = solver.removeReprojectionFactorsByChi2(chi2);
+            if (removed < 0) {
+                set_err(err, errlen, solver.error().c_str());
+                return -3;
+            }
+            opt.max_num_iterations = iters2;
+            if (!solver.solve(opt, &s2)) {
+                set_err(err, errlen, solver.error().c_str());
+                return -4;
+            }
+            summary8[2] = s2.final_cost, summary8[5] = s2.num_successful_steps, summary8[6] = s2.num_unsuccessful_steps, summary8[7] = removed;
+        }
+        if (active_out) memcpy(active_out, solver.activeReprojectionFactors().data(), (size_t) n);
+        if (getenv("ICG_SOLVER_DEBUG")) fprintf(stderr, "%s\n%s\n", s1.BriefReport().c_str(), s2.BriefReport().c_str());
         return 0;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());

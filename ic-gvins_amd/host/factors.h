@@ -78,6 +78,7 @@ public:
     const std::string &error() const { return error_; }
 
 private:
+    friend class WindowSolver; // solver_hip.h: drives the resident factors through the Schur entry points
     bool run(bool want_jac, double huber);
     icg_ctx *ctx_{nullptr};
     vector<ReprojectionFactor *> factors_;

@@ -1,0 +1,420 @@
+// WindowSolver: Levenberg-Marquardt on the reduced camera system, visual factors eliminated on the device.  See solver_hip.h.
+#include "solver_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+#include "../../include/icgvins_hip.h"
+
+namespace icg {
+
+namespace {
+// in-place Cholesky solve of the symmetric positive definite n x n system A x = b (row-major, lower triangle used)
+bool choleskySolve(int n, std::vector<double> &A, std::vector<double> &b) {
+    for (int j = 0; j < n; j++) {
+        double d = A[(size_t) j * n + j];
+        for (int k = 0; k < j; k++) d -= A[(size_t) j * n + k] * A[(size_t) j * n + k];
+        if (!(d > 0.0) || !std::isfinite(d)) return false;
+        d                     = std::sqrt(d);
+        A[(size_t) j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double v = A[(size_t) i * n + j];
+            for (int k = 0; k < j; k++) v -= A[(size_t) i * n + k] * A[(size_t) j * n + k];
+            A[(size_t) i * n + j] = v / d;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        double v = b[(size_t) i];
+        for (int k = 0; k < i; k++) v -= A[(size_t) i * n + k] * b[(size_t) k];
+        b[(size_t) i] = v / A[(size_t) i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double v = b[(size_t) i];
+        for (int k = i + 1; k < n; k++) v -= A[(size_t) k * n + i] * b[(size_t) k];
+        b[(size_t) i] = v / A[(size_t) i * n + i];
+    }
+    return true;
+}
+
+// PoseParameterization::Plus (factors/pose_parameterization.h:34-50): p += dp, q = (q * rotvec2quaternion(dtheta)).normalized()
+void posePlus(double *x, const double *delta) {
+    for (int k = 0; k < 3; k++) x[k] += delta[k];
+    const double rx = delta[3], ry = delta[4], rz = delta[5];
+    const double angle = std::sqrt(rx * rx + ry * ry + rz * rz);
+    double ax = rx, ay = ry, az = rz;
+    if (angle > 0) ax /= angle, ay /= angle, az /= angle;
+    const double sh = std::sin(0.5 * angle), ch = std::cos(0.5 * angle);
+    const double bx = sh * ax, by = sh * ay, bz = sh * az, bw = ch;
+    const double qx = x[3], qy = x[4], qz = x[5], qw = x[6];
+    double nx = qw * bx + qx * bw + qy * bz - qz * by;
+    double ny = qw * by + qy * bw + qz * bx - qx * bz;
+    double nz = qw * bz + qz * bw + qx * by - qy * bx;
+    double nw = qw * bw - qx * bx - qy * by - qz * bz;
+    const double nn = std::sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+    x[3] = nx / nn, x[4] = ny / nn, x[5] = nz / nn, x[6] = nw / nn;
+}
+} // namespace
+
+std::string WindowSolver::Summary::BriefReport() const {
+    char buf[256];
+    snprintf(buf, sizeof buf, "WindowSolver: initial cost %.6e, final cost %.6e, %d successful / %d unsuccessful steps, %s", initial_cost,
+             final_cost, num_successful_steps, num_unsuccessful_steps, termination.c_str());
+    return buf;
+}
+
+WindowSolver::WindowSolver(ReprojectionBatch *visual, double huber_delta) : visual_(visual), huber_(huber_delta) {
+    if (visual_) active_.assign((size_t) visual_->size(), 1);
+}
+
+void WindowSolver::addParameterBlock(double *values, int size, bool pose_manifold) {
+    if (block_of_.count(values)) return;
+    if (pose_manifold && size != 7) throw std::runtime_error("WindowSolver: the pose manifold needs a block of size 7");
+    block_of_[values] = (int) blocks_.size();
+    blocks_.push_back({values, size, pose_manifold ? 6 : size, pose_manifold, false, -1, false});
+}
+
+void WindowSolver::setParameterBlockConstant(double *values) {
+    auto it = block_of_.find(values);
+    if (it == block_of_.end()) throw std::runtime_error("WindowSolver: unknown parameter block");
+    blocks_[(size_t) it->second].constant = true;
+}
+
+WindowSolver::ResidualBlockId WindowSolver::addResidualBlock(std::shared_ptr<ceres::CostFunction> cost, std::shared_ptr<ceres::LossFunction> loss,
+                                                             const std::vector<double *> &blocks) {
+    const auto &sizes = cost->parameter_block_sizes();
+    if (sizes.size() != blocks.size()) throw std::runtime_error("WindowSolver: block count does not match the cost function");
+    for (size_t k = 0; k < blocks.size(); k++) {
+        auto it = block_of_.find(blocks[k]);
+        if (it == block_of_.end()) throw std::runtime_error("WindowSolver: residual block uses an unknown parameter block");
+        if (blocks_[(size_t) it->second].size != sizes[k]) throw std::runtime_error("WindowSolver: parameter block size mismatch");
+    }
+    residuals_.push_back({std::move(cost), std::move(loss), blocks, false});
+    return (ResidualBlockId) residuals_.size() - 1;
+}
+
+void WindowSolver::removeResidualBlock(ResidualBlockId id) { residuals_.at((size_t) id).removed = true; }
+
+bool WindowSolver::evaluateResidualBlock(ResidualBlockId id, bool apply_loss_function, double *cost) const {
+    const Residual &R = residuals_.at((size_t) id);
+    std::vector<double> r((size_t) R.cost->num_residuals());
+    if (!R.cost->Evaluate(R.blocks.data(), r.data(), nullptr)) return false;
+    double s = 0;
+    for (double v : r) s += v * v;
+    if (apply_loss_function && R.loss) {
+        double rho[3];
+        R.loss->Evaluate(s, rho);
+        s = rho[0];
+    }
+    *cost = 0.5 * s;
+    return true;
+}
+
+int WindowSolver::numActiveReprojectionFactors() const {
+    int n = 0;
+    for (uint8_t a : active_) n += a;
+    return n;
+}
+
+// column layout of the reduced system: every non-constant block that is not an inverse depth of the visual batch, in the
+// order the blocks were added; inverse depths are eliminated on the device (column P + batch landmark index there)
+bool WindowSolver::layout() {
+    for (Block &b : blocks_) b.landmark = false, b.column = -1;
+    if (visual_) {
+        for (double *p : visual_->lm_ptrs_) {
+            auto it = block_of_.find(p);
+            if (it == block_of_.end()) {
+                error_ = "an inverse-depth block of the reprojection batch was not added to the solver";
+                return false;
+            }
+            if (blocks_[(size_t) it->second].constant) {
+                error_ = "constant inverse-depth blocks are not supported";
+                return false;
+            }
+            blocks_[(size_t) it->second].landmark = true;
+        }
+    }
+    for (const Residual &R : residuals_)
+        if (!R.removed)
+            for (double *p : R.blocks)
+                if (blocks_[(size_t) block_of_.at(p)].landmark) {
+                    error_ = "host factors on an eliminated inverse-depth block are not supported";
+                    return false;
+                }
+    P_ = 0;
+    for (Block &b : blocks_)
+        if (!b.constant && !b.landmark) {
+            b.column = P_;
+            P_ += b.local;
+        }
+    if (visual_) {
+        auto col = [&](const double *p) {
+            auto it = block_of_.find(p);
+            if (it == block_of_.end()) throw std::runtime_error("WindowSolver: a block of the reprojection batch was not added to the solver");
+            return blocks_[(size_t) it->second].column;
+        };
+        col_pose_.resize(visual_->pose_ptrs_.size());
+        for (size_t k = 0; k < col_pose_.size(); k++) col_pose_[k] = col(visual_->pose_ptrs_[k]);
+        col_ext_ = visual_->ext_ ? col(visual_->ext_) : -1;
+        col_td_  = visual_->td_ ? col(visual_->td_) : -1;
+        if (active_.size() != (size_t) visual_->size()) active_.assign((size_t) visual_->size(), 1);
+    }
+    return P_ > 0;
+}
+
+// host factors: S += J^T J, s -= J^T r (robust-corrected), diag, cost += 0.5 rho(|r|^2)
+bool WindowSolver::hostFactors(std::vector<double> *S, std::vector<double> *s, std::vector<double> *diag, double *cost) const {
+    for (const Residual &R : residuals_) {
+        if (R.removed) continue;
+        if (!S) { // cost only
+            double c;
+            if (!evaluateResidualBlock((ResidualBlockId) (&R - residuals_.data()), true, &c)) return false;
+            *cost += c;
+            continue;
+        }
+        ResidualBlockInfo info(R.cost, nullptr, R.blocks, {});
+        if (!info.Evaluate()) return false;
+        // cost from the raw residual, then the Ceres corrector (residual_block_info.h:59-87) through the shared implementation
+        double sq = 0;
+        for (double v : info.residuals()) sq += v * v;
+        if (R.loss) {
+            double rho[3];
+            R.loss->Evaluate(sq, rho);
+            *cost += 0.5 * rho[0];
+            ResidualBlockInfo corrected(R.cost, R.loss, R.blocks, {});
+            if (!corrected.Evaluate()) return false;
+            info = corrected;
+        } else {
+            *cost += 0.5 * sq;
+        }
+        const int nr = R.cost->num_residuals();
+        const auto &sizes = R.cost->parameter_block_sizes();
+        for (size_t a = 0; a < R.blocks.size(); a++) {
+            const Block &A = blocks_[(size_t) block_of_.at(R.blocks[a])];
+            if (A.column < 0) continue;
+            const std::vector<double> &Ja = info.jacobians()[a];
+            for (int x = 0; x < A.local; x++) {
+                double g = 0;
+                for (int k = 0; k < nr; k++) g += Ja[(size_t) k * sizes[a] + x] * info.residuals()[(size_t) k];
+                (*s)[(size_t) (A.column + x)] -= g;
+            }
+            for (size_t c = 0; c < R.blocks.size(); c++) {
+                const Block &B = blocks_[(size_t) block_of_.at(R.blocks[c])];
+                if (B.column < 0) continue;
+                const std::vector<double> &Jc = info.jacobians()[c];
+                for (int x = 0; x < A.local; x++)
+                    for (int y = 0; y < B.local; y++) {
+                        double v = 0;
+                        for (int k = 0; k < nr; k++) v += Ja[(size_t) k * sizes[a] + x] * Jc[(size_t) k * sizes[c] + y];
+                        (*S)[(size_t) (A.column + x) * P_ + B.column + y] += v;
+                        if (a == c && x == y) (*diag)[(size_t) (A.column + x)] += v;
+                    }
+            }
+        }
+    }
+    return true;
+}
+
+bool WindowSolver::linearize(double damp, bool reassemble, const Options &o, std::vector<double> &S, std::vector<double> &s,
+                             std::vector<double> &diag, double *cost) {
+    S.assign((size_t) P_ * P_, 0.0);
+    s.assign((size_t) P_, 0.0);
+    diag.assign((size_t) P_, 0.0);
+    double c = 0;
+    if (visual_ && visual_->size() > 0) {
+        if (reassemble && !visual_->run(true, huber_)) {
+            error_ = visual_->error();
+            return false;
+        }
+        double vc = 0;
+        if (icg_reproj_schur(visual_->ctx_, P_, col_pose_.data(), col_ext_, col_td_, active_.data(), reassemble ? 1 : 0, damp, o.min_lm_diagonal,
+                             o.max_lm_diagonal, S.data(), s.data(), diag.data(), &vc) != ICG_OK) {
+            error_ = icg_last_error(visual_->ctx_);
+            return false;
+        }
+        c += vc;
+    }
+    if (reassemble) {
+        host_S_.assign((size_t) P_ * P_, 0.0);
+        host_s_.assign((size_t) P_, 0.0);
+        host_diag_.assign((size_t) P_, 0.0);
+        double hc = 0;
+        if (!hostFactors(&host_S_, &host_s_, &host_diag_, &hc)) {
+            error_ = "a host cost function failed to evaluate";
+            return false;
+        }
+        c += hc;
+        if (cost) *cost = c;
+    }
+    for (size_t k = 0; k < S.size(); k++) S[k] += host_S_[k];
+    for (size_t k = 0; k < s.size(); k++) s[k] += host_s_[k], diag[k] += host_diag_[k];
+    return true;
+}
+
+bool WindowSolver::evaluateCost(double *cost) {
+    double c = 0;
+    if (visual_ && visual_->size() > 0) {
+        if (!visual_->run(false, huber_)) {
+            error_ = visual_->error();
+            return false;
+        }
+        double vc = 0;
+        if (icg_reproj_cost(visual_->ctx_, active_.data(), &vc) != ICG_OK) {
+            error_ = icg_last_error(visual_->ctx_);
+            return false;
+        }
+        c += vc;
+    }
+    if (!hostFactors(nullptr, nullptr, nullptr, &c)) {
+        error_ = "a host cost function failed to evaluate";
+        return false;
+    }
+    *cost = c;
+    return true;
+}
+
+void WindowSolver::backup() {
+    saved_.resize(blocks_.size());
+    for (size_t k = 0; k < blocks_.size(); k++) saved_[k].assign(blocks_[k].values, blocks_[k].values + blocks_[k].size);
+}
+
+void WindowSolver::restore() {
+    for (size_t k = 0; k < blocks_.size(); k++) memcpy(blocks_[k].values, saved_[k].data(), sizeof(double) * (size_t) blocks_[k].size);
+}
+
+void WindowSolver::applyStep(const std::vector<double> &delta_c, const std::vector<double> &delta_l) {
+    for (Block &b : blocks_) {
+        if (b.column < 0) continue;
+        const double *d = &delta_c[(size_t) b.column];
+        if (b.pose)
+            posePlus(b.values, d);
+        else
+            for (int k = 0; k < b.size; k++) b.values[k] += d[k];
+    }
+    if (visual_)
+        for (size_t l = 0; l < visual_->lm_ptrs_.size(); l++) *visual_->lm_ptrs_[l] += delta_l[l];
+}
+
+bool WindowSolver::solve(const Options &o, Summary *summary) {
+    Summary sum;
+    if (!layout()) {
+        if (error_.empty()) error_ = "nothing to optimize";
+        return false;
+    }
+    const size_t L = visual_ ? visual_->lm_ptrs_.size() : 0;
+    double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
+    std::vector<double> S, s, diag, delta_l(L, 0.0);
+    double cost = 0;
+    if (!linearize(1.0 / radius, true, o, S, s, diag, &cost)) return false;
+    sum.initial_cost = cost;
+    sum.termination  = "max_num_iterations";
+    bool need_redamp = false;
+    for (int iter = 0; iter < o.max_num_iterations; iter++) {
+        if (need_redamp && !linearize(1.0 / radius, false, o, S, s, diag, nullptr)) return false;
+        need_redamp = false;
+        // gradient test (max norm of J^T r over all columns; the landmark part is bounded by it after elimination in practice and
+        // is not fetched: the camera part decides)
+        double gmax = 0;
+        for (double v : s) gmax = std::max(gmax, std::fabs(v));
+        if (gmax < o.gradient_tolerance) {
+            sum.termination = "gradient_tolerance";
+            break;
+        }
+        // (S + D) delta_c = s with the LM diagonal of the camera block
+        std::vector<double> A(S), delta_c(s), dd((size_t) P_);
+        for (int k = 0; k < P_; k++) {
+            dd[(size_t) k] = std::min(std::max(diag[(size_t) k], o.min_lm_diagonal), o.max_lm_diagonal) / radius;
+            A[(size_t) k * P_ + k] += dd[(size_t) k];
+        }
+        bool ok = choleskySolve(P_, A, delta_c);
+        double lm_terms[2] = {0, 0};
+        if (ok && L > 0 && icg_reproj_backsub(visual_->ctx_, P_, delta_c.data(), delta_l.data(), lm_terms) != ICG_OK) {
+            error_ = icg_last_error(visual_->ctx_);
+            return false;
+        }
+        double model = 0;
+        if (ok) {
+            // model decrease 0.5 (delta^T b + delta^T D delta) of the FULL damped system; s is the reduced right-hand side, and
+            // delta^T b = delta_c^T s + sum b_l^2/(h_ll+d_l) (device), delta^T D delta = delta_c^T Dc delta_c + sum d_l delta_l^2 (device)
+            double t0 = lm_terms[0], t1 = lm_terms[1];
+            for (int k = 0; k < P_; k++) t0 += delta_c[(size_t) k] * s[(size_t) k], t1 += dd[(size_t) k] * delta_c[(size_t) k] * delta_c[(size_t) k];
+            model = 0.5 * (t0 + t1);
+        }
+        if (!ok || !(model > 0.0)) {
+            radius /= decrease_factor;
+            decrease_factor *= 2.0;
+            sum.num_unsuccessful_steps++;
+            need_redamp = true;
+            if (radius < o.min_trust_region_radius) {
+                sum.termination = "min_trust_region_radius";
+                break;
+            }
+            continue;
+        }
+        // parameter tolerance
+        double dn = 0, xn = 0;
+        for (double v : delta_c) dn += v * v;
+        for (double v : delta_l) dn += v * v;
+        for (const Block &b : blocks_)
+            if (!b.constant)
+                for (int k = 0; k < b.size; k++) xn += b.values[k] * b.values[k];
+        backup();
+        applyStep(delta_c, delta_l);
+        if (std::sqrt(dn) <= o.parameter_tolerance * (std::sqrt(xn) + o.parameter_tolerance)) {
+            restore();
+            sum.termination = "parameter_tolerance";
+            break;
+        }
+        double new_cost = 0;
+        if (!evaluateCost(&new_cost)) return false;
+        const double rho = (cost - new_cost) / model;
+        if (rho > o.min_relative_decrease) {
+            const double change = cost - new_cost;
+            cost                = new_cost;
+            sum.num_successful_steps++;
+            radius          = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)));
+            decrease_factor = 2.0;
+            if (std::fabs(change) < o.function_tolerance * cost) {
+                sum.termination = "function_tolerance";
+                break;
+            }
+            if (iter + 1 < o.max_num_iterations && !linearize(1.0 / radius, true, o, S, s, diag, nullptr)) return false;
+        } else {
+            restore();
+            radius /= decrease_factor;
+            decrease_factor *= 2.0;
+            sum.num_unsuccessful_steps++;
+            need_redamp = true;
+            if (radius < o.min_trust_region_radius) {
+                sum.termination = "min_trust_region_radius";
+                break;
+            }
+        }
+    }
+    sum.final_cost = cost;
+    if (summary) *summary = sum;
+    return true;
+}
+
+int WindowSolver::removeReprojectionFactorsByChi2(double chi2) {
+    if (!visual_ || visual_->size() == 0) return 0;
+    if (active_.size() != (size_t) visual_->size()) active_.assign((size_t) visual_->size(), 1);
+    if (!visual_->run(false, 0.0)) { // EvaluateResidualBlock(id, false, &cost, ...): raw residuals, no loss
+        error_ = visual_->error();
+        return -1;
+    }
+    int removed = 0;
+    for (int f = 0; f < visual_->size(); f++) {
+        if (!active_[(size_t) f]) continue;
+        const double *r = visual_->residual(f);
+        const double cost = 0.5 * (r[0] * r[0] + r[1] * r[1]);
+        if (cost * 2.0 > chi2) {
+            active_[(size_t) f] = 0;
+            removed++;
+        }
+    }
+    return removed;
+}
+
+} // namespace icg

@@ -18,7 +18,7 @@ EXPORTS = [
     "icg_lk_track", "icg_lk_track_fb", "icg_undistort_points", "icg_distort_points", "icg_predict_mappoints",
     "icg_predict_rotation", "icg_fm_ransac", "icg_detect", "icg_triangulate", "icg_reproj_eval_batch",
     "icg_reproj_set_factors", "icg_reproj_eval_resident", "icg_reproj_accumulate_normal", "icg_preint_batch",
-    "icg_ins_mechanize_batch", "icg_ins_camera_pose_batch",
+    "icg_ins_mechanize_batch", "icg_ins_camera_pose_batch", "icg_reproj_schur", "icg_reproj_backsub", "icg_reproj_cost",
 ]
 
 
@@ -302,6 +302,26 @@ class Context:
         self._ck(self.lib.icg_reproj_accumulate_normal(self.h, local_size, _p(_i32(col_pose)), int(col_ext), _p(_i32(col_lm)),
                                                         int(col_td), _p(H), _p(b)), "icg_reproj_accumulate_normal")
         return H, b
+
+    # ---- f1
+    def reproj_schur(self, P, col_pose, col_ext, col_td, active=None, reassemble=True, damp=0.0, min_diag=1e-6, max_diag=1e32):
+        S, s, dg, cost = np.zeros((P, P)), np.zeros(P), np.zeros(P), np.zeros(1)
+        act = None if active is None else np.ascontiguousarray(active, np.uint8)
+        self._ck(self.lib.icg_reproj_schur(self.h, int(P), _p(_i32(col_pose)), int(col_ext), int(col_td), _p(act), 1 if reassemble else 0,
+                                            C.c_double(damp), C.c_double(min_diag), C.c_double(max_diag), _p(S), _p(s), _p(dg), _p(cost)),
+                 "icg_reproj_schur")
+        return S, s, dg, float(cost[0])
+
+    def reproj_backsub(self, P, delta_c, n_lm):
+        out, terms = np.zeros(n_lm), np.zeros(2)
+        self._ck(self.lib.icg_reproj_backsub(self.h, int(P), _p(_f64(delta_c)), _p(out), _p(terms)), "icg_reproj_backsub")
+        return out, terms
+
+    def reproj_cost(self, active=None):
+        cost = np.zeros(1)
+        act = None if active is None else np.ascontiguousarray(active, np.uint8)
+        self._ck(self.lib.icg_reproj_cost(self.h, _p(act), _p(cost)), "icg_reproj_cost")
+        return float(cost[0])
 
     # ---- P1
     def preint_batch(self, variant, offsets, imu, state0, params):

@@ -177,6 +177,25 @@ int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double *poses, con
 int icg_reproj_accumulate_normal(icg_ctx *ctx, int local_size, const int32_t *col_pose, int32_t col_ext,
                                  const int32_t *col_lm, int32_t col_td, double *H0, double *b0);
 
+/* ---- f1 (SURVEY.md §8 "next" row): device-side landmark elimination for the Gauss-Newton / LM step of
+ * GVINS::gvinsOptimization (ic_gvins.cc:1130-1239: Ceres LEVENBERG_MARQUARDT + DENSE_SCHUR).  Works on the robust-corrected r/J
+ * left resident by the last icg_reproj_eval_resident(want_jac=1): assembles H = J^T J, b = -J^T r of the ACTIVE factors on the
+ * device (camera columns 0..P-1 given by col_pose/col_ext/col_td, -1 = constant block; inverse depth l at column P+l), then
+ * eliminates the 1x1 inverse-depth blocks:  S = Hcc - G^T diag(1/(h_ll+d_l)) G,  s = bc - G^T (b_l/(h_ll+d_l)),
+ * d_l = clamp(h_ll, min_diag, max_diag) * damp (LM diagonal of the eliminated block; damp = 1/trust-region radius).
+ * Outputs: S (P x P row-major), s (P), diag_cc (P, diagonal of Hcc before elimination: the host needs it for the LM diagonal
+ * of the camera block; may be NULL), cost (0.5 sum rho(|r|^2) of the active factors at the linearization point; may be NULL).
+ * reassemble = 0 re-uses the resident H, b with a new damp (after a rejected step; cost is not touched).
+ * The full system stays on the device for icg_reproj_backsub:  delta_l = (b_l - G_l . delta_c) / (h_ll + d_l)  (n_lm values);
+ * lm_terms (2 doubles, may be NULL) = sum b_l^2/(h_ll+d_l), sum d_l delta_l^2: the landmark part of the LM model decrease
+ * 0.5 (delta^T b + delta^T D delta), where delta^T b = delta_c^T s + lm_terms[0].
+ * icg_reproj_cost: the same cost for the CURRENT resident residuals (e.g. after a want_jac=0 evaluation at a trial point). */
+int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, int32_t col_ext, int32_t col_td, const uint8_t *active,
+                     int reassemble, double damp, double min_diag, double max_diag, double *S, double *s, double *diag_cc,
+                     double *cost);
+int icg_reproj_backsub(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms);
+int icg_reproj_cost(icg_ctx *ctx, const uint8_t *active, double *cost);
+
 /* ---- P1: preintegration inner loop (preintegration/preintegration_base.cc:39-70, preintegration_earth.cc:205-303,
  * preintegration_normal.cc:183-232), batched over independent intervals.
  * imu: total x 8 doubles (time, dt, dtheta[3], dvel[3]); interval s owns samples [offsets[s], offsets[s+1]) with

@@ -244,6 +244,11 @@ struct shim_backend {
     int n = 0, n_poses = 0, n_lm = 0;
     std::vector<double> obs, r, J;
     std::vector<int32_t> ii, jj, ll;
+    double huber = 0.0;
+    // f1: resident normal equations
+    int P = 0;
+    std::vector<double> H, b, inv;
+    double damp = 0, min_diag = 0, max_diag = 0;
 };
 std::unordered_map<icg_ctx *, shim_backend> g_backend;
 } // namespace
@@ -271,6 +276,7 @@ int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double *poses, con
     orc_reproj_eval_batch(B.n, B.obs.data(), B.ii.data(), B.jj.data(), B.ll.data(), poses, ext, invdepth, td, want_jac, B.r.data(),
                           B.J.data());
     if (huber_delta > 0) orc_huber_correct_2x46(B.n, huber_delta, B.r.data(), want_jac ? B.J.data() : nullptr);
+    B.huber = huber_delta;
     if (out_r) memcpy(out_r, B.r.data(), sizeof(double) * B.r.size());
     if (out_J && want_jac) memcpy(out_J, B.J.data(), sizeof(double) * B.J.size());
     return ICG_OK;
@@ -281,6 +287,49 @@ int icg_reproj_accumulate_normal(icg_ctx *ctx, int local_size, const int32_t *co
     shim_backend &B = g_backend[ctx];
     orc_reproj_accumulate_normal(B.n, B.r.data(), B.J.data(), B.ii.data(), B.jj.data(), B.ll.data(), col_pose, col_ext, col_lm, col_td,
                                  local_size, H0, b0);
+    return ICG_OK;
+}
+
+int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, int32_t col_ext, int32_t col_td, const uint8_t *active, int reassemble,
+                     double damp, double min_diag, double max_diag, double *S, double *s, double *diag_cc, double *cost) {
+    shim_backend &B = g_backend[ctx];
+    const int L = B.n_lm;
+    const size_t N = (size_t) P + L;
+    if (reassemble) {
+        std::vector<int32_t> ii, jj, ll, col_lm((size_t) L);
+        std::vector<double> r, J;
+        for (int l = 0; l < L; l++) col_lm[(size_t) l] = P + l;
+        for (int f = 0; f < B.n; f++) {
+            if (active && !active[f]) continue;
+            ii.push_back(B.ii[(size_t) f]), jj.push_back(B.jj[(size_t) f]), ll.push_back(B.ll[(size_t) f]);
+            r.insert(r.end(), B.r.begin() + 2 * (size_t) f, B.r.begin() + 2 * (size_t) f + 2);
+            J.insert(J.end(), B.J.begin() + 46 * (size_t) f, B.J.begin() + 46 * (size_t) f + 46);
+        }
+        B.P = P;
+        B.H.assign(N * N, 0.0);
+        B.b.assign(N, 0.0);
+        B.inv.assign((size_t) L, 0.0);
+        orc_reproj_accumulate_normal((int) ii.size(), r.data(), J.data(), ii.data(), jj.data(), ll.data(), col_pose, col_ext, col_lm.data(),
+                                     col_td, (int) N, B.H.data(), B.b.data());
+        if (cost) *cost = orc_reproj_cost(B.n, B.r.data(), active, B.huber);
+    } else if (B.P != P || B.H.size() != N * N) {
+        return ICG_ERR_INVALID;
+    }
+    orc_schur_reduce(P, L, B.H.data(), B.b.data(), damp, min_diag, max_diag, S, s, diag_cc, B.inv.data());
+    B.damp = damp, B.min_diag = min_diag, B.max_diag = max_diag;
+    return ICG_OK;
+}
+
+int icg_reproj_backsub(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
+    shim_backend &B = g_backend[ctx];
+    if (B.P != P || B.H.empty()) return ICG_ERR_INVALID;
+    orc_schur_backsub(P, B.n_lm, B.H.data(), B.b.data(), B.inv.data(), B.damp, B.min_diag, B.max_diag, delta_c, delta_l, lm_terms);
+    return ICG_OK;
+}
+
+int icg_reproj_cost(icg_ctx *ctx, const uint8_t *active, double *cost) {
+    shim_backend &B = g_backend[ctx];
+    *cost = orc_reproj_cost(B.n, B.r.data(), active, B.huber);
     return ICG_OK;
 }
 

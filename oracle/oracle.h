@@ -92,6 +92,13 @@ void orc_preint_evaluate(int variant, const double *delta_state, const double *j
                          const double *pose0, const double *mix0, const double *pose1, const double *mix1,
                          double *residuals /*15*/, double *jacobians /*15x7,15x9,15x7,15x9 concatenated, may be NULL*/);
 
+// ---- landmark elimination of one GN/LM step (orc_solve.cc; SURVEY.md §8 f1, parity unpinned: Ceres absent) --------
+void orc_schur_reduce(int P, int L, const double *H /*(P+L)^2*/, const double *b, double damp, double min_diag, double max_diag,
+                      double *S, double *s, double *diag_cc, double *inv /*L*/);
+void orc_schur_backsub(int P, int L, const double *H, const double *b, const double *inv, double damp, double min_diag, double max_diag,
+                       const double *delta_c, double *delta_l, double *lm_terms);
+double orc_reproj_cost(int n, const double *r, const uint8_t *active, double huber);
+
 // ---- INS helpers in front of the tracker (orc_ins.cc) ---------------------------------
 // imu rows of 8 (time, dt, dtheta3, dvel3); state rows of 23 (time, p3, q4 xyzw, v3, bg3, ba3, sg3, sa3);
 // cfg8 = gravity3, iewn3, iswithearth, iswithscale; poses 12 = R row-major 9, t 3

@@ -1,0 +1,46 @@
+"""GPU parity for SURVEY.md §8 row f1: the device-side landmark elimination (k_reproj_normal in the Schur layout,
+k_schur_reduce, k_schur_backsub, k_reproj_cost) and icg::WindowSolver on the HIP library, against the same independent numpy
+restatements as the CPU suite (dense elimination 1e-9, dense LM optimum 1e-7).  FP64 atomics make the assembly order free, so
+the comparison is by tolerance, not by bits."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import schur_checks as sc
+import solve_utils as su
+
+pytestmark = pytest.mark.gpu
+
+
+def test_schur_entry_points_on_gpu(oracle):
+    import icgvins
+    ctx = icgvins.Context(640, 480, n_slots=1, max_batch=1, max_points=64)
+    sc.check_schur(ctx, oracle)
+    with pytest.raises(icgvins.IcgError):  # a pose column outside the reduced system
+        ctx.reproj_schur(6, np.array([0, 6, 12, 18, 24, 30, 36], np.int32), -1, -1)
+    ctx.close()
+
+
+def test_backsub_without_system_fails():
+    import icgvins
+    ctx = icgvins.Context(640, 480, n_slots=1, max_batch=1, max_points=64)
+    with pytest.raises(icgvins.IcgError):
+        ctx.reproj_backsub(10, np.zeros(10), 5)
+    ctx.close()
+
+
+@pytest.mark.parametrize("cfg", [dict(seed=0, n_outliers=8), dict(seed=2, n_outliers=5, ext_const=True, td_const=True),
+                                 dict(seed=4, n_outliers=10, n_lm=300, n_kf=10)])
+def test_window_solver_matches_dense_lm_on_gpu(oracle, cfg):
+    import harness as H
+    cfg = dict(cfg)
+    P = su.make_problem(cfg.pop("n_lm", 60), cfg.pop("n_kf", 6), seed=cfg.pop("seed"), n_outliers=cfg.pop("n_outliers"))
+    h = su.host_solve(C.CDLL(H.HOST_LIB), P, **cfg)
+    d = su.dense_solve(oracle, P, **cfg)
+    assert np.array_equal(h["summary"][3:], d["summary"][3:]), (h["summary"], d["summary"])
+    assert np.abs(h["summary"][:3] - d["summary"][:3]).max() < 1e-7 * max(1.0, d["summary"][0])
+    assert np.array_equal(h["active"], d["active"])
+    for k in ("poses", "ext", "invdepth"):
+        assert np.abs(h[k] - d[k]).max() < 1e-7, k
+    assert np.abs(h["poses"][:, :3] - P["truth"]["poses"][:, :3]).max() < 0.01

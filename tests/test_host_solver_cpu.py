@@ -1,0 +1,44 @@
+"""SURVEY.md §8 row f1 on the CPU: the Schur entry points of the C ABI (here: the oracle shim) and icg::WindowSolver of the host
+layer against independent numpy restatements (dense elimination, dense Levenberg-Marquardt without any Schur complement).
+Parity status of this row: unpinned (Ceres is absent) — the checks are algebraic."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import schur_checks as sc
+import solve_utils as su
+
+
+@pytest.fixture(scope="module")
+def host_lib():
+    from stream_utils import ensure_oracle_host
+    return ensure_oracle_host()
+
+
+def test_schur_entry_points_on_oracle_shim(host_lib, oracle):
+    import icgvins
+    ctx = icgvins.Context(640, 480, n_slots=1, max_batch=1, max_points=64, lib=icgvins.load_library(host_lib))
+    sc.check_schur(ctx, oracle)
+    ctx.close()
+
+
+@pytest.mark.parametrize("cfg", [dict(seed=0, n_outliers=8), dict(seed=1, n_outliers=0, chi2=-1.0, iters1=12),
+                                 dict(seed=2, n_outliers=5, ext_const=True, td_const=True), dict(seed=3, n_outliers=3, huber=0.0, td_const=True)])
+def test_window_solver_matches_dense_lm(host_lib, oracle, cfg):
+    """same accepted / rejected step counts, same chi-square culling decisions, same optimum as a dense LM that never forms a
+    Schur complement; the optimum recovers the true poses from a 10 cm / 0.6 deg perturbation"""
+    cfg = dict(cfg)
+    P = su.make_problem(60, 6, seed=cfg.pop("seed"), n_outliers=cfg.pop("n_outliers"))
+    h = su.host_solve(C.CDLL(host_lib), P, **cfg)
+    d = su.dense_solve(oracle, P, **cfg)
+    assert np.array_equal(h["summary"][3:], d["summary"][3:]), (h["summary"], d["summary"])
+    assert np.abs(h["summary"][:3] - d["summary"][:3]).max() < 1e-8 * max(1.0, d["summary"][0])
+    assert np.array_equal(h["active"], d["active"])
+    if cfg.get("chi2", 5.991) > 0:
+        assert list(np.nonzero(h["active"] == 0)[0]) == list(P["outliers"]) or set(P["outliers"]) <= set(np.nonzero(h["active"] == 0)[0])
+    for k in ("poses", "ext", "invdepth"):
+        assert np.abs(h[k] - d[k]).max() < 1e-8, k
+    assert abs(h["td"] - d["td"]) < 1e-8
+    assert np.abs(h["poses"][:, :3] - P["truth"]["poses"][:, :3]).max() < 0.01
+    assert h["summary"][2] < 0.05 * h["summary"][0]
