@@ -448,12 +448,14 @@ int icgh_backend_preint(int variant, int n, const int32_t *offsets, const double
 // Reprojection factors from flat arrays (as icgh_backend_reproj) + one PosePriorFactor per pose (weight prior_weight, target
 // prior_poses: fixes the gauge like the reference's marginalization prior / GNSS factors do).  Two solves with the chi-square
 // culling pass in between (chi2 <= 0: one solve of iters1 iterations).  All parameter arrays are updated in place.
-// summary8: initial cost, cost after solve 1, final cost, successful steps 1, unsuccessful 1, successful 2, unsuccessful 2, removed
+// summary10: initial cost, cost after solve 1, final cost, successful steps 1, unsuccessful 1, successful 2, unsuccessful 2, removed,
+// ms spent in solve + culling, ms spent building the problem (context, factor upload)
 int icgh_backend_solve(int n, const double *obs_soa, const int32_t *idx_i, const int32_t *idx_j, const int32_t *idx_lm, int n_poses,
                        double *poses, double *ext, int n_lm, double *invdepth, double *td, const double *prior_poses, double prior_weight,
                        double huber, int ext_constant, int td_constant, int iters1, int iters2, double chi2, double *summary8,
                        uint8_t *active_out, char *err, int errlen) {
     try {
+        auto t_begin = std::chrono::steady_clock::now();
         vector<std::unique_ptr<ReprojectionFactor>> factors;
         ReprojectionBatch batch(0);
         for (int k = 0; k < n; k++) {
@@ -463,6 +465,7 @@ int icgh_backend_solve(int n, const double *obs_soa, const int32_t *idx_i, const
             batch.add(factors.back().get(), poses + 7 * (size_t) idx_i[k], poses + 7 * (size_t) idx_j[k], ext, invdepth + idx_lm[k], td);
         }
         batch.finalize();
+        auto t_built = std::chrono::steady_clock::now();
         WindowSolver solver(&batch, huber);
         for (int k = 0; k < n_poses; k++) solver.addParameterBlock(poses + 7 * (size_t) k, 7, true);
         solver.addParameterBlock(ext, 7, true);
@@ -496,6 +499,8 @@ int icgh_backend_solve(int n, const double *obs_soa, const int32_t *idx_i, const
             }
             summary8[2] = s2.final_cost, summary8[5] = s2.num_successful_steps, summary8[6] = s2.num_unsuccessful_steps, summary8[7] = removed;
         }
+        summary8[8] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_built).count();
+        summary8[9] = std::chrono::duration<double, std::milli>(t_built - t_begin).count();
         if (active_out) memcpy(active_out, solver.activeReprojectionFactors().data(), (size_t) n);
         if (getenv("ICG_SOLVER_DEBUG")) fprintf(stderr, "%s\n%s\n", s1.BriefReport().c_str(), s2.BriefReport().c_str());
         return 0;

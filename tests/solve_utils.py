@@ -35,7 +35,7 @@ def host_solve(lib, P, prior_weight=30.0, huber=1.0, ext_const=False, td_const=F
     s = P["start"]
     poses, ext, inv, td = s["poses"].copy(), s["ext"].copy(), s["invdepth"].copy(), np.array([s["td"]])
     n = P["obs"].shape[1]
-    summ, active = np.zeros(8), np.zeros(n, np.uint8)
+    summ, active = np.zeros(10), np.zeros(n, np.uint8)
     err = C.create_string_buffer(512)
     obs = np.ascontiguousarray(P["obs"])
     rc = lib.icgh_backend_solve(n, _p(obs), _p(np.ascontiguousarray(P["ii"], np.int32)), _p(np.ascontiguousarray(P["jj"], np.int32)),
@@ -43,7 +43,7 @@ def host_solve(lib, P, prior_weight=30.0, huber=1.0, ext_const=False, td_const=F
                                 _p(np.ascontiguousarray(P["prior"])), C.c_double(prior_weight), C.c_double(huber), int(ext_const), int(td_const),
                                 int(iters1), int(iters2), C.c_double(chi2), _p(summ), _p(active), err, 512)
     assert rc == 0, (rc, err.value)
-    return dict(poses=poses, ext=ext, invdepth=inv, td=float(td[0]), summary=summ, active=active)
+    return dict(poses=poses, ext=ext, invdepth=inv, td=float(td[0]), summary=summ[:8], active=active, solve_ms=float(summ[8]), setup_ms=float(summ[9]))
 
 
 # ---- independent dense LM -------------------------------------------------------------------------------------------------------
