@@ -507,6 +507,98 @@ __global__ __launch_bounds__(256) void k_reproj_cost(int n, const double *r, con
     if (threadIdx.x == 0) unsafeAtomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// Assembly for the Schur layout with the camera-camera block privatised in LDS.  k_reproj_normal sends every J^T J entry to a
+// global FP64 atomic; in a sliding window ~270 factors share each pose block and ALL factors share the extrinsic/td block, so
+// those atomics serialise in L2 (measured: ~0.9 ms for 2 651 factors).  Here each workgroup accumulates its 256 factors into an
+// LDS copy of the compact camera system (V = 6 x poses + 7 columns touched by visual factors, V^2 doubles), the fully shared
+// (ext|td)^2 block is first reduced across the wave with shuffles, and one pass of global atomics per workgroup flushes the tile.
+// Landmark rows (G_l, h_ll, b_l: 21 values per factor, <= ~10 factors per landmark) go straight to global atomics.
+__global__ __launch_bounds__(NRM_BLOCK) void k_reproj_normal_schur(int n, const double *r, const double *J, const int32_t *idx_i,
+                                                                   const int32_t *idx_j, const int32_t *idx_lm, const int32_t *vcol_pose,
+                                                                   int vcol_ext, int vcol_td, const int32_t *vmap, int V, int P, int N,
+                                                                   double *H, double *b, const uint8_t *active) {
+    extern __shared__ double sm[]; // Hs[V*V] | bs[V]
+    double *Hs = sm, *bs = sm + (size_t) V * V;
+    const int t = threadIdx.x;
+    for (int e = t; e < V * V + V; e += NRM_BLOCK) sm[e] = 0.0;
+    __syncthreads();
+    const int f   = blockIdx.x * NRM_BLOCK + t;
+    const bool on = f < n && (!active || active[f]);
+    // the factor's 19 camera columns: pose_i (6), pose_j (6), ext (6), td (1); compact column or -1
+    double j0[19], j1[19];
+    int cc[19];
+    double r0 = 0.0, r1 = 0.0, jl0 = 0.0, jl1 = 0.0;
+    int lm = 0;
+    if (on) {
+        const double *Jf = J + 46 * (size_t) f;
+        r0 = r[2 * (size_t) f], r1 = r[2 * (size_t) f + 1];
+        const int ci = vcol_pose[idx_i[f]], cj = vcol_pose[idx_j[f]];
+#pragma unroll
+        for (int x = 0; x < 6; x++) {
+            j0[x] = Jf[x], j1[x] = Jf[7 + x], cc[x] = ci < 0 ? -1 : ci + x;
+            j0[6 + x] = Jf[14 + x], j1[6 + x] = Jf[21 + x], cc[6 + x] = cj < 0 ? -1 : cj + x;
+            j0[12 + x] = Jf[28 + x], j1[12 + x] = Jf[35 + x], cc[12 + x] = vcol_ext < 0 ? -1 : vcol_ext + x;
+        }
+        j0[18] = Jf[44], j1[18] = Jf[45], cc[18] = vcol_td;
+        jl0 = Jf[42], jl1 = Jf[43];
+        lm  = idx_lm[f];
+    } else {
+#pragma unroll
+        for (int x = 0; x < 19; x++) j0[x] = j1[x] = 0.0, cc[x] = -1;
+    }
+    // pose rows against all 19 columns, and the shared rows against the pose columns: LDS atomics
+#pragma unroll
+    for (int x = 0; x < 19; x++) {
+        if (cc[x] < 0) continue;
+#pragma unroll
+        for (int y = 0; y < 19; y++) {
+            if (x >= 12 && y >= 12) continue; // (ext|td)^2: wave-reduced below
+            if (cc[y] < 0) continue;
+            atomicAdd(&Hs[cc[x] * V + cc[y]], j0[x] * j0[y] + j1[x] * j1[y]);
+        }
+        if (x < 12) atomicAdd(&bs[cc[x]], -(j0[x] * r0 + j1[x] * r1));
+    }
+    // shared block: every active lane contributes to the same 49 + 7 addresses -> butterfly over the wave, lane 0 adds
+#pragma unroll
+    for (int x = 12; x < 19; x++) {
+#pragma unroll
+        for (int y = 12; y < 20; y++) { // y == 19: the right-hand side entry
+            double v = (y < 19) ? j0[x] * j0[y] + j1[x] * j1[y] : -(j0[x] * r0 + j1[x] * r1);
+            if (!on) v = 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if ((t & 63) == 0) {
+                const int cx = (x < 18) ? (vcol_ext < 0 ? -1 : vcol_ext + x - 12) : vcol_td;
+                const int cy = (y < 18) ? (vcol_ext < 0 ? -1 : vcol_ext + y - 12) : (y == 18 ? vcol_td : 0);
+                if (cx >= 0 && cy >= 0 && v != 0.0) {
+                    if (y < 19)
+                        atomicAdd(&Hs[cx * V + cy], v);
+                    else
+                        atomicAdd(&bs[cx], v);
+                }
+            }
+        }
+    }
+    // landmark row: G_l (camera columns), h_ll, b_l
+    if (on) {
+        double *row = H + (size_t) (P + lm) * N;
+#pragma unroll
+        for (int x = 0; x < 19; x++)
+            if (cc[x] >= 0) unsafeAtomicAdd(&row[vmap[cc[x]]], jl0 * j0[x] + jl1 * j1[x]);
+        unsafeAtomicAdd(&row[P + lm], jl0 * jl0 + jl1 * jl1);
+        unsafeAtomicAdd(&b[P + lm], -(jl0 * r0 + jl1 * r1));
+    }
+    __syncthreads();
+    for (int e = t; e < V * V; e += NRM_BLOCK) {
+        const double v = Hs[e];
+        if (v != 0.0) unsafeAtomicAdd(&H[(size_t) vmap[e / V] * N + vmap[e % V]], v);
+    }
+    for (int e = t; e < V; e += NRM_BLOCK) {
+        const double v = bs[e];
+        if (v != 0.0) unsafeAtomicAdd(&b[vmap[e]], v);
+    }
+}
+
 static int ensure_sys_capacity(icg_ctx *ctx, size_t doubles) {
     if (doubles <= ctx->sys_cap) return 0;
     ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -538,10 +630,30 @@ extern "C" int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, in
     if (rc) return rc;
     double *d_H = ctx->d_sys, *d_b = d_H + N * N, *d_inv = d_b + N, *d_cost = d_inv + L;
     icg_call c(ctx);
-    rc = c.reserve(sizeof(int32_t) * (size_t) ctx->last_n_poses + (size_t) n + sizeof(double) * ((size_t) P * P + 2 * (size_t) P + 1) + 4096);
+    rc = c.reserve(sizeof(int32_t) * (8 * (size_t) ctx->last_n_poses + 16) + (size_t) n + sizeof(double) * ((size_t) P * P + 2 * (size_t) P + 1) + 4096);
     if (rc) return rc;
     const int32_t *d_cp = c.in(col_pose, (size_t) ctx->last_n_poses);
     const uint8_t *d_act = active ? c.in(active, (size_t) n) : nullptr;
+    // compact camera space of the visual factors: free poses (6 columns each), then ext, then td
+    std::vector<int32_t> vcol_pose((size_t) ctx->last_n_poses, -1), vmap;
+    for (int k = 0; k < ctx->last_n_poses; k++)
+        if (col_pose[k] >= 0) {
+            vcol_pose[(size_t) k] = (int32_t) vmap.size();
+            for (int x = 0; x < 6; x++) vmap.push_back(col_pose[k] + x);
+        }
+    int vcol_ext = -1, vcol_td = -1;
+    if (col_ext >= 0) {
+        vcol_ext = (int) vmap.size();
+        for (int x = 0; x < 6; x++) vmap.push_back(col_ext + x);
+    }
+    if (col_td >= 0) {
+        vcol_td = (int) vmap.size();
+        vmap.push_back(col_td);
+    }
+    const int V = (int) vmap.size();
+    if (V == 0) return icg_fail(ctx, ICG_ERR_INVALID, "every camera block of the visual factors is constant");
+    const int32_t *d_vp = c.in(vcol_pose.data(), vcol_pose.size());
+    const int32_t *d_vm = c.in(vmap.data(), vmap.size());
     if ((rc = c.seal())) return rc;
     double *d_S = c.out(S, (size_t) P * P);
     double *d_s = c.out(s, (size_t) P);
@@ -551,9 +663,16 @@ extern "C" int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, in
     if (reassemble) {
         ICG_HIP(ctx, hipMemsetAsync(d_H, 0, sizeof(double) * (N * N + N + (size_t) L + 1), ctx->stream));
         icg_prof_scope ps(ctx, "reproj_normal");
-        hipLaunchKernelGGL(k_reproj_normal, dim3((n + NRM_BLOCK - 1) / NRM_BLOCK), dim3(NRM_BLOCK), 0, ctx->stream, n, d_r, d_J,
-                           (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n), (const int32_t *) (ctx->d_fidx + 2 * (size_t) n),
-                           d_cp, (int) col_ext, (const int32_t *) nullptr, (int) col_td, (int) N, d_H, d_b, d_act, P);
+        const size_t lds = sizeof(double) * ((size_t) V * V + V);
+        if (lds <= 60 * 1024) {
+            hipLaunchKernelGGL(k_reproj_normal_schur, dim3((n + NRM_BLOCK - 1) / NRM_BLOCK), dim3(NRM_BLOCK), lds, ctx->stream, n, d_r, d_J,
+                               (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n), (const int32_t *) (ctx->d_fidx + 2 * (size_t) n),
+                               d_vp, vcol_ext, vcol_td, d_vm, V, P, (int) N, d_H, d_b, d_act);
+        } else { // windows with more than ~14 free poses: the camera block does not fit the default LDS budget
+            hipLaunchKernelGGL(k_reproj_normal, dim3((n + NRM_BLOCK - 1) / NRM_BLOCK), dim3(NRM_BLOCK), 0, ctx->stream, n, d_r, d_J,
+                               (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n), (const int32_t *) (ctx->d_fidx + 2 * (size_t) n),
+                               d_cp, (int) col_ext, (const int32_t *) nullptr, (int) col_td, (int) N, d_H, d_b, d_act, P);
+        }
     }
     {
         icg_prof_scope ps(ctx, "schur_reduce");

@@ -125,7 +125,7 @@ void ReprojectionBatch::finalize() {
     prepared_  = false;
 }
 
-bool ReprojectionBatch::run(bool want_jac, double huber) {
+bool ReprojectionBatch::run(bool want_jac, double huber, bool fetch) {
     prepared_ = false;
     if (factors_.empty()) {
         prepared_ = has_jac_ = true;
@@ -136,13 +136,13 @@ bool ReprojectionBatch::run(bool want_jac, double huber) {
     for (size_t k = 0; k < pose_ptrs_.size(); k++) memcpy(&poses[7 * k], pose_ptrs_[k], sizeof(double) * 7);
     for (size_t k = 0; k < lm_ptrs_.size(); k++) inv[k] = *lm_ptrs_[k];
     int rc = icg_reproj_eval_resident(ctx_, (int) pose_ptrs_.size(), poses.data(), ext_, (int) lm_ptrs_.size(), inv.data(), *td_,
-                                      want_jac ? 1 : 0, huber, r_.data(), want_jac ? J_.data() : nullptr);
+                                      want_jac ? 1 : 0, huber, fetch ? r_.data() : nullptr, (fetch && want_jac) ? J_.data() : nullptr);
     if (rc != ICG_OK) {
         error_ = icg_last_error(ctx_);
         return false;
     }
-    prepared_ = true;
-    has_jac_  = want_jac;
+    prepared_ = fetch;
+    has_jac_  = fetch && want_jac;
     return true;
 }
 

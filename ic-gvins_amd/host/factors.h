@@ -79,7 +79,8 @@ public:
 
 private:
     friend class WindowSolver; // solver_hip.h: drives the resident factors through the Schur entry points
-    bool run(bool want_jac, double huber);
+    // fetch = false leaves the results on the device only (WindowSolver): the per-factor Evaluate() surface is then NOT prepared
+    bool run(bool want_jac, double huber, bool fetch = true);
     icg_ctx *ctx_{nullptr};
     vector<ReprojectionFactor *> factors_;
     vector<double *> pose_ptrs_, lm_ptrs_; // unique blocks in first-seen order

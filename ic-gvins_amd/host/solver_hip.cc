@@ -1,7 +1,9 @@
 // WindowSolver: Levenberg-Marquardt on the reduced camera system, visual factors eliminated on the device.  See solver_hip.h.
 #include "solver_hip.h"
 
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -11,6 +13,26 @@
 namespace icg {
 
 namespace {
+// ICG_SOLVER_DEBUG=1: wall time per phase of the LM loop, printed by solve()
+struct PhaseClock {
+    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int calls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool on = getenv("ICG_SOLVER_DEBUG") != nullptr;
+};
+PhaseClock g_clock;
+struct PhaseScope {
+    int k;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseScope(int k_) : k(k_), t0(std::chrono::steady_clock::now()) {}
+    ~PhaseScope() {
+        if (g_clock.on) {
+            g_clock.ms[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            g_clock.calls[k]++;
+        }
+    }
+};
+enum { PH_EVAL_JAC = 0, PH_SCHUR, PH_HOST_FACTORS, PH_CHOLESKY, PH_BACKSUB, PH_EVAL_TRIAL, PH_COST, PH_CHI2 };
+
 // in-place Cholesky solve of the symmetric positive definite n x n system A x = b (row-major, lower triangle used)
 bool choleskySolve(int n, std::vector<double> &A, std::vector<double> &b) {
     for (int j = 0; j < n; j++) {
@@ -223,11 +245,15 @@ bool WindowSolver::linearize(double damp, bool reassemble, const Options &o, std
     diag.assign((size_t) P_, 0.0);
     double c = 0;
     if (visual_ && visual_->size() > 0) {
-        if (reassemble && !visual_->run(true, huber_)) {
-            error_ = visual_->error();
-            return false;
+        if (reassemble) {
+            PhaseScope ps(PH_EVAL_JAC);
+            if (!visual_->run(true, huber_, false)) {
+                error_ = visual_->error();
+                return false;
+            }
         }
         double vc = 0;
+        PhaseScope ps(PH_SCHUR);
         if (icg_reproj_schur(visual_->ctx_, P_, col_pose_.data(), col_ext_, col_td_, active_.data(), reassemble ? 1 : 0, damp, o.min_lm_diagonal,
                              o.max_lm_diagonal, S.data(), s.data(), diag.data(), &vc) != ICG_OK) {
             error_ = icg_last_error(visual_->ctx_);
@@ -240,6 +266,7 @@ bool WindowSolver::linearize(double damp, bool reassemble, const Options &o, std
         host_s_.assign((size_t) P_, 0.0);
         host_diag_.assign((size_t) P_, 0.0);
         double hc = 0;
+        PhaseScope ps(PH_HOST_FACTORS);
         if (!hostFactors(&host_S_, &host_s_, &host_diag_, &hc)) {
             error_ = "a host cost function failed to evaluate";
             return false;
@@ -255,11 +282,15 @@ bool WindowSolver::linearize(double damp, bool reassemble, const Options &o, std
 bool WindowSolver::evaluateCost(double *cost) {
     double c = 0;
     if (visual_ && visual_->size() > 0) {
-        if (!visual_->run(false, huber_)) {
-            error_ = visual_->error();
-            return false;
+        {
+            PhaseScope ps(PH_EVAL_TRIAL);
+            if (!visual_->run(false, huber_, false)) {
+                error_ = visual_->error();
+                return false;
+            }
         }
         double vc = 0;
+        PhaseScope ps(PH_COST);
         if (icg_reproj_cost(visual_->ctx_, active_.data(), &vc) != ICG_OK) {
             error_ = icg_last_error(visual_->ctx_);
             return false;
@@ -327,11 +358,18 @@ bool WindowSolver::solve(const Options &o, Summary *summary) {
             dd[(size_t) k] = std::min(std::max(diag[(size_t) k], o.min_lm_diagonal), o.max_lm_diagonal) / radius;
             A[(size_t) k * P_ + k] += dd[(size_t) k];
         }
-        bool ok = choleskySolve(P_, A, delta_c);
+        bool ok;
+        {
+            PhaseScope ps(PH_CHOLESKY);
+            ok = choleskySolve(P_, A, delta_c);
+        }
         double lm_terms[2] = {0, 0};
-        if (ok && L > 0 && icg_reproj_backsub(visual_->ctx_, P_, delta_c.data(), delta_l.data(), lm_terms) != ICG_OK) {
-            error_ = icg_last_error(visual_->ctx_);
-            return false;
+        if (ok && L > 0) {
+            PhaseScope psb(PH_BACKSUB);
+            if (icg_reproj_backsub(visual_->ctx_, P_, delta_c.data(), delta_l.data(), lm_terms) != ICG_OK) {
+                error_ = icg_last_error(visual_->ctx_);
+                return false;
+            }
         }
         double model = 0;
         if (ok) {
@@ -394,6 +432,12 @@ bool WindowSolver::solve(const Options &o, Summary *summary) {
     }
     sum.final_cost = cost;
     if (summary) *summary = sum;
+    if (g_clock.on) {
+        static const char *names[8] = {"eval+jac", "schur", "host_factors", "cholesky", "backsub", "eval_trial", "cost", "chi2"};
+        for (int k = 0; k < 8; k++)
+            if (g_clock.calls[k]) fprintf(stderr, "[WindowSolver] %-28s %3d calls %8.3f ms\n", names[k], g_clock.calls[k], g_clock.ms[k]);
+        g_clock = PhaseClock();
+    }
     return true;
 }
 
