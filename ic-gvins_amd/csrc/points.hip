@@ -42,6 +42,29 @@ __global__ void k_predict_rotation(icg_camera cam, int n, const float2 *in, cons
     out[i] = cam_distort_campoint(cam, pc[0], pc[1], pc[2]);
 }
 
+// f3: per-observation arithmetic of GVINS::gvinsOutlierCulling (ic_gvins.cc:1068-1078) and parametersStatistic
+// (:985): |Camera::reprojectionError| (camera.cc:153-157) and Tracking::isGoodToTrack (tracking.cc:813-829), one lane per
+// observation.  The reference walks the weak_ptr graph under locks and calls both per observation; here the host flattens the
+// window's observations once and the decisions run on the returned arrays.
+__global__ void k_reproj_error(icg_camera cam, int n, const int32_t *pose_idx, const int32_t *lm_idx, const double *poses12, const double *pw,
+                               const float2 *pix, double max_error, double min_depth, double max_depth, double *err, uint8_t *good) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *R = poses12 + 12 * (size_t) pose_idx[i];
+    const double *t = R + 9;
+    const double *p = pw + 3 * (size_t) lm_idx[i];
+    double d0 = p[0] - t[0], d1 = p[1] - t[1], d2 = p[2] - t[2];
+    double pc[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) pc[j] = R[0 * 3 + j] * d0 + R[1 * 3 + j] * d1 + R[2 * 3 + j] * d2;
+    float2 px = cam_cam2pixel(cam, pc[0], pc[1], pc[2]);
+    float2 pp = pix[i];
+    const double ex = (double) (px.x - pp.x), ey = (double) (px.y - pp.y);
+    const double e  = sqrt(ex * ex + ey * ey);
+    err[i]  = e;
+    good[i] = ((pc[2] > min_depth) && (pc[2] < max_depth) && !(e > max_error)) ? 1 : 0;
+}
+
 static int check_pts(icg_ctx *ctx, int n) {
     if (!ctx) return ICG_ERR_INVALID;
     if (!ctx->has_cam) return icg_fail(ctx, ICG_ERR_INVALID, "camera not set (icg_set_camera)");
@@ -131,6 +154,38 @@ extern "C" int icg_predict_rotation(icg_ctx *ctx, int n, const float *pts_in, co
         icg_prof_scope ps(ctx, "predict_rotation");
         hipLaunchKernelGGL(k_predict_rotation, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_in, d_ri, d_r,
                            d_out);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}
+
+extern "C" int icg_reproj_error_batch(icg_ctx *ctx, int n, const int32_t *pose_idx, const int32_t *lm_idx, int n_poses, const double *poses12,
+                                      int n_lm, const double *pw, const float *pix, double max_error, double min_depth, double max_depth,
+                                      double *err_out, uint8_t *good_out) {
+    if (!ctx) return ICG_ERR_INVALID;
+    if (!ctx->has_cam) return icg_fail(ctx, ICG_ERR_INVALID, "camera not set (icg_set_camera)");
+    if (n < 0) return ICG_ERR_INVALID;
+    if (n == 0) return ICG_OK;
+    if (!pose_idx || !lm_idx || !poses12 || !pw || !pix || n_poses <= 0 || n_lm <= 0) return ICG_ERR_INVALID;
+    for (int i = 0; i < n; i++)
+        if (pose_idx[i] < 0 || pose_idx[i] >= n_poses || lm_idx[i] < 0 || lm_idx[i] >= n_lm)
+            return icg_fail(ctx, ICG_ERR_INVALID, "observation %d: pose/landmark index out of range", i);
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    icg_call c(ctx);
+    int rc = c.reserve((size_t) n * (4 + 4 + 8 + 8 + 1) + sizeof(double) * (12 * (size_t) n_poses + 3 * (size_t) n_lm) + 4096);
+    if (rc) return rc;
+    const double *d_po = c.in(poses12, 12 * (size_t) n_poses);
+    const double *d_pw = c.in(pw, 3 * (size_t) n_lm);
+    const int32_t *d_pi = c.in_zc(pose_idx, (size_t) n);
+    const int32_t *d_li = c.in_zc(lm_idx, (size_t) n);
+    const float2 *d_px = (const float2 *) c.in_zc(pix, 2 * (size_t) n);
+    if ((rc = c.seal())) return rc;
+    double *d_e  = c.out_zc(err_out, (size_t) n);
+    uint8_t *d_g = c.out_zc(good_out, (size_t) n);
+    {
+        icg_prof_scope ps(ctx, "reproj_error");
+        hipLaunchKernelGGL(k_reproj_error, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_pi, d_li, d_po, d_pw, d_px, max_error,
+                           min_depth, max_depth, d_e, d_g);
     }
     ICG_HIP(ctx, hipGetLastError());
     return c.finish();

@@ -198,6 +198,7 @@ int icgh_batch_features(icgh_batch *b, int stream, int max, uint64_t *ids, float
 #include "factors.h"
 #include "misc_hip.h"
 #include "solver_hip.h"
+#include "culling_hip.h"
 
 namespace {
 // simple generic host factor used to exercise the non-reprojection path of MarginalizationInfo:
@@ -437,6 +438,116 @@ int icgh_backend_preint(int variant, int n, const int32_t *offsets, const double
             }
         }
         icg_ctx_destroy(ctx);
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
+// ---- f3: outlier culling / statistics (culling_hip.h) on the maps the tracker built -------------------------------------------
+// Raw dump of a stream's landmark graph, NO filtering (the test re-derives the reference's filters and decisions from it):
+// landmarks sorted by id: lm_id, lm_pos[3], lm_flags (bit0 outlier), lm_ref_frame (frame id), lm_obs_off[n+1];
+// observations in list order: obs_frame (frame id, ~0 = expired), obs_flags (bit0 feature expired, bit1 feature outlier,
+// bit2 frame is keyframe, bit3 keyframe in map), obs_pose12, obs_pix[2] (undistorted key point).  Returns the landmark count.
+int icgh_batch_landmark_table(icgh_batch *b, int stream, int max_lm, int max_obs, uint64_t *lm_id, double *lm_pos, int32_t *lm_flags,
+                              uint64_t *lm_ref_frame, int32_t *lm_obs_off, uint64_t *obs_frame, int32_t *obs_flags, double *obs_pose12,
+                              float *obs_pix) {
+    if (!b || stream < 0 || stream >= b->tb->size()) return -1;
+    auto &S = b->tb->stream(stream);
+    vector<ulong> ids;
+    for (auto &kv : S.map->landmarks()) ids.push_back(kv.first);
+    std::sort(ids.begin(), ids.end());
+    if ((int) ids.size() > max_lm) return -2;
+    int no = 0;
+    for (size_t k = 0; k < ids.size(); k++) {
+        auto mp      = S.map->landmarks().at(ids[k]);
+        lm_id[k]     = ids[k];
+        Vector3d pos = mp->pos();
+        for (int c = 0; c < 3; c++) lm_pos[3 * k + c] = pos[c];
+        lm_flags[k]     = mp->isOutlier() ? 1 : 0;
+        lm_ref_frame[k] = mp->referenceFrameId();
+        lm_obs_off[k]   = no;
+        for (auto &w : mp->observations()) {
+            if (no >= max_obs) return -3;
+            auto feat = w.lock();
+            int fl    = 0;
+            obs_frame[no] = ~0ull;
+            for (int c = 0; c < 12; c++) obs_pose12[12 * (size_t) no + c] = 0;
+            obs_pix[2 * no] = obs_pix[2 * no + 1] = 0;
+            if (!feat) {
+                fl |= 1;
+            } else {
+                if (feat->isOutlier()) fl |= 2;
+                obs_pix[2 * no] = feat->keyPoint().x, obs_pix[2 * no + 1] = feat->keyPoint().y;
+                auto frame = feat->getFrame();
+                if (frame) {
+                    obs_frame[no] = frame->id();
+                    if (frame->isKeyFrame()) fl |= 4;
+                    if (frame->isKeyFrame() && S.map->isKeyFrameInMap(frame)) fl |= 8;
+                    Pose p = frame->pose();
+                    memcpy(obs_pose12 + 12 * (size_t) no, p.R.m, sizeof(double) * 9);
+                    memcpy(obs_pose12 + 12 * (size_t) no + 9, p.t.v, sizeof(double) * 3);
+                }
+            }
+            obs_flags[no] = fl;
+            no++;
+        }
+    }
+    lm_obs_off[ids.size()] = no;
+    return (int) ids.size();
+}
+
+// moves landmarks (by id) to new positions: stands in for the optimizer's write-back (ic_gvins.cc:1299-1357) in the tests
+int icgh_batch_set_landmark_pos(icgh_batch *b, int stream, int n, const uint64_t *ids, const double *pos3) {
+    if (!b || stream < 0 || stream >= b->tb->size()) return -1;
+    auto &S = b->tb->stream(stream);
+    for (int k = 0; k < n; k++) {
+        auto it = S.map->landmarks().find(ids[k]);
+        if (it == S.map->landmarks().end()) return -2;
+        it->second->setPos(Vector3d(pos3[3 * k], pos3[3 * k + 1], pos3[3 * k + 2]));
+    }
+    return 0;
+}
+
+// WindowCulling over ALL streams of the batch with one device launch.  in_list: per stream the landmark ids that "took part in
+// the optimization" (invdepthlist_), concatenated, list_off[n_streams+1].  mode 0: gvinsOutlierCulling -> out5[s*5..] =
+// outlier mappoints, outlier features, num1, num2, num3;  mode 1: reprojectionStatistics -> stats5[s*5..] = min, max, avg, rms, count
+int icgh_batch_culling(icgh_batch *b, int mode, const int32_t *list_off, const uint64_t *in_list, double reprojection_error_std, int32_t *out5,
+                       double *stats5, char *err, int errlen) {
+    try {
+        const int n = b->tb->size();
+        vector<std::unordered_map<ulong, double>> lists((size_t) n);
+        vector<WindowCulling::Stream> streams;
+        for (int s = 0; s < n; s++) {
+            for (int k = list_off[s]; k < list_off[s + 1]; k++) lists[(size_t) s][in_list[k]] = 0.0;
+            streams.push_back({b->tb->stream(s).map, &lists[(size_t) s]});
+        }
+        icg_ctx *ctx = b->tb->group(0).device()->ctx();
+        std::string e;
+        if (mode == 0) {
+            vector<CullingResult> R;
+            if (!WindowCulling::gvinsOutlierCulling(ctx, streams, reprojection_error_std, R, &e)) {
+                set_err(err, errlen, e.c_str());
+                return -2;
+            }
+            for (int s = 0; s < n; s++) {
+                const CullingResult &r = R[(size_t) s];
+                const int32_t v[5]     = {r.outlier_mappoints, r.outlier_features, r.by_reference_frame, r.by_observation_count, r.by_mean_error};
+                memcpy(out5 + 5 * s, v, sizeof v);
+            }
+        } else {
+            vector<ReprojectionStatistics> R;
+            if (!WindowCulling::reprojectionStatistics(ctx, streams, R, &e)) {
+                set_err(err, errlen, e.c_str());
+                return -2;
+            }
+            for (int s = 0; s < n; s++) {
+                const ReprojectionStatistics &r = R[(size_t) s];
+                const double v[5]               = {r.min_error, r.max_error, r.avg_error, r.rms_error, (double) r.landmarks};
+                memcpy(stats5 + 5 * s, v, sizeof v);
+            }
+        }
         return 0;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());

@@ -19,6 +19,7 @@ EXPORTS = [
     "icg_predict_rotation", "icg_fm_ransac", "icg_detect", "icg_triangulate", "icg_reproj_eval_batch",
     "icg_reproj_set_factors", "icg_reproj_eval_resident", "icg_reproj_accumulate_normal", "icg_preint_batch",
     "icg_ins_mechanize_batch", "icg_ins_camera_pose_batch", "icg_reproj_schur", "icg_reproj_backsub", "icg_reproj_cost",
+    "icg_reproj_error_batch",
 ]
 
 
@@ -302,6 +303,18 @@ class Context:
         self._ck(self.lib.icg_reproj_accumulate_normal(self.h, local_size, _p(_i32(col_pose)), int(col_ext), _p(_i32(col_lm)),
                                                         int(col_td), _p(H), _p(b)), "icg_reproj_accumulate_normal")
         return H, b
+
+    # ---- f3
+    def reproj_error_batch(self, pose_idx, lm_idx, poses12, pw, pix, max_error, min_depth=1.0, max_depth=200.0):
+        poses12 = _f64(poses12).reshape(-1, 12)
+        pw = _f64(pw).reshape(-1, 3)
+        pix = _f32(pix).reshape(-1, 2)
+        n = pix.shape[0]
+        err, good = np.zeros(n), np.zeros(n, np.uint8)
+        self._ck(self.lib.icg_reproj_error_batch(self.h, n, _p(_i32(pose_idx)), _p(_i32(lm_idx)), poses12.shape[0], _p(poses12), pw.shape[0],
+                                                  _p(pw), _p(pix), C.c_double(max_error), C.c_double(min_depth), C.c_double(max_depth), _p(err),
+                                                  _p(good)), "icg_reproj_error_batch")
+        return err, good
 
     # ---- f1
     def reproj_schur(self, P, col_pose, col_ext, col_td, active=None, reassemble=True, damp=0.0, min_diag=1e-6, max_diag=1e32):

@@ -208,6 +208,18 @@ int icg_preint_batch(icg_ctx *ctx, int variant, int n_intervals, const int32_t *
                      const double *state0, const double *params, double *cur_state, double *delta_state, double *jac,
                      double *cov, double *delta_time, double *pn);
 
+/* ---- f3 (SURVEY.md §8 "next" row): per-observation arithmetic of GVINS::gvinsOutlierCulling (ic_gvins.cc:1035-1128) and
+ * GVINS::parametersStatistic (ic_gvins.cc:930-1033).  Observation i = landmark lm_idx[i] (world position pw, n_lm x 3) seen in
+ * keyframe pose_idx[i] (poses12: n_poses x 12, R row-major camera->world | t) at the undistorted key point pix[i]:
+ *   err_out[i]  = |Camera::reprojectionError(pose, pw, pp)|                (tracking/camera.cc:153-157)
+ *   good_out[i] = Tracking::isGoodToTrack(pp, pose, pw, scale, depth_scale)  (tracking/tracking.cc:813-829) with
+ *                 max_error = reprojection_error_std * scale, min_depth = MapPoint::NEAREST_DEPTH,
+ *                 max_depth = MapPoint::FARTHEST_DEPTH * depth_scale.
+ * The camera set with icg_set_camera is used. */
+int icg_reproj_error_batch(icg_ctx *ctx, int n, const int32_t *pose_idx, const int32_t *lm_idx, int n_poses, const double *poses12,
+                           int n_lm, const double *pw, const float *pix, double max_error, double min_depth, double max_depth,
+                           double *err_out, uint8_t *good_out);
+
 /* ---- f4 (SURVEY.md §8 "next" row): the INS steps in front of the tracker, batched over independent streams -----------
  * Layouts: imu rows of 8 doubles (time, dt, dtheta[3], dvel[3]); state rows of 23 doubles (time, p3, q4 xyzw, v3, bg3, ba3,
  * sg3, sa3 = IntegrationState, preintegration/integration_state.h:35-52 without the odometer fields);

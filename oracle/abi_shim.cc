@@ -190,6 +190,12 @@ int icg_distort_points(icg_ctx *ctx, int n, float *pts) {
     return ICG_OK;
 }
 
+int icg_reproj_error_batch(icg_ctx *ctx, int n, const int32_t *pose_idx, const int32_t *lm_idx, int, const double *poses12, int, const double *pw,
+                           const float *pix, double max_error, double min_depth, double max_depth, double *err_out, uint8_t *good_out) {
+    orc_reproj_error_batch(&ctx->cam.fx, n, pose_idx, lm_idx, poses12, pw, pix, max_error, min_depth, max_depth, err_out, good_out);
+    return ICG_OK;
+}
+
 int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, const float *pts1, const float *pts2, double thresh,
                   double conf, uint8_t *mask) {
     parallel_for(n_sets, ctx->threads, [&](int s) {

@@ -48,6 +48,10 @@ void orc_world2pixel(const double *cam10, const double *pose12, int n, const dou
 void orc_predict_rotation(const double *cam10, const double *R_cur, const double *R_pre, int n, const float *pts_in,
                           float *pts_out);
 
+void orc_reproj_error_batch(const double *cam10, int n, const int32_t *pose_idx, const int32_t *lm_idx, const double *poses12,
+                            const double *pw, const float *pix, double max_error, double min_depth, double max_depth, double *err_out,
+                            uint8_t *good_out);
+
 // ---- detection (orc_detect.cc) -----------------------------------------------------------------------
 void orc_draw_filled_circle(uint8_t *mask, int w, int h, int stride, int cx, int cy, int radius, uint8_t value);
 void orc_min_eigen_map(const uint8_t *img, int w, int h, int stride, int rx, int ry, int rw, int rh, float *eig);

@@ -132,4 +132,24 @@ void orc_predict_rotation(const double *cam, const double *R_cur, const double *
     }
 }
 
+// Per-observation arithmetic of GVINS::gvinsOutlierCulling (ic_gvins.cc:1068-1078) / parametersStatistic (:985), SURVEY.md §8 f3:
+//   err[i]  = |Camera::reprojectionError(pose, pw, pp)|  (camera.cc:153-157: world2pixel in float, float differences, double norm)
+//   good[i] = Tracking::isGoodToTrack(pp, pose, pw, scale, depth_scale)  (tracking.cc:813-829, isGoodDepth :247-249):
+//             min_depth < z < max_depth  &&  !(err > max_error)      (max_error = reprojection_error_std * scale)
+// PINNED against the reference's own Camera / Tracking code (oracle/_ref/libref_tracking.so, tests/golden/cull_ref_golden.npz).
+void orc_reproj_error_batch(const double *cam, int n, const int32_t *pose_idx, const int32_t *lm_idx, const double *poses12, const double *pw,
+                            const float *pix, double max_error, double min_depth, double max_depth, double *err_out, uint8_t *good_out) {
+    Cam c = load(cam);
+    for (int i = 0; i < n; i++) {
+        double pc[3];
+        orc_world2cam(poses12 + 12 * (size_t) pose_idx[i], 1, pw + 3 * (size_t) lm_idx[i], pc);
+        float px, py;
+        cam2pixel(c, pc[0], pc[1], pc[2], px, py);
+        const double ex = (double) (px - pix[2 * i]), ey = (double) (py - pix[2 * i + 1]);
+        const double e  = std::sqrt(ex * ex + ey * ey);
+        if (err_out) err_out[i] = e;
+        if (good_out) good_out[i] = ((pc[2] > min_depth) && (pc[2] < max_depth) && !(e > max_error)) ? 1 : 0;
+    }
+}
+
 } // extern "C"

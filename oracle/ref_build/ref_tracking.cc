@@ -304,6 +304,20 @@ void ref_camera_reprojection_error(const double *cam10, int w, int h, const doub
     }
 }
 
+// per-observation arithmetic of GVINS::gvinsOutlierCulling (ic_gvins.cc:1068-1078) and parametersStatistic (:985): the norm of
+// Camera::reprojectionError and Tracking::isGoodToTrack of the reference, for observation i = (pose_idx[i], lm_idx[i], pix[i])
+void ref_cull_eval(void *h, int n, const int32_t *pose_idx, const int32_t *lm_idx, const double *poses12, const double *pw, const float *pix,
+                   double scale, double depth_scale, double *err_out, uint8_t *good_out) {
+    auto &T = *(RefTracker *) h;
+    for (int i = 0; i < n; i++) {
+        Pose pose = make_pose(poses12 + 12 * (size_t) pose_idx[i]);
+        Vector3d p(pw[3 * (size_t) lm_idx[i]], pw[3 * (size_t) lm_idx[i] + 1], pw[3 * (size_t) lm_idx[i] + 2]);
+        cv::Point2f pp(pix[2 * i], pix[2 * i + 1]);
+        err_out[i]  = T.camera->reprojectionError(pose, p, pp).norm();
+        good_out[i] = T.tracking->isGoodToTrack(pp, pose, p, scale, depth_scale) ? 1 : 0;
+    }
+}
+
 // landmarks of the map sorted by id: ids[k], pos[3k..], depth[k], used_times[k], ref frame id[k]
 int ref_tracker_landmarks(void *h, int max, uint64_t *ids, double *pos3, double *depth, int32_t *used, uint64_t *ref_frame) {
     auto &T = *(RefTracker *) h;
