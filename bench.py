@@ -430,6 +430,46 @@ def main():
             solve["cpu_baseline"] = {"value": round(su.host_solve(ol, Pz)["solve_ms"], 3), "unit": "ms per window", "cores": 1, "kind": "port",
                                      "sample": "the same solver on the oracle shim (dense (P+L)^2 assembly + elimination on one core)"}
 
+    # ---- f3: per-observation reprojection error + isGoodToTrack gate of the culling / statistics pass ---------------------------
+    cull = None
+    if rank == 0 and not args.no_reproj:
+        import cull_utils as cu
+        dz = cu.make_observations(n_poses=10, n_lm=300, seed=1)
+        reps = 256  # the windows of 256 streams in one launch
+        nobs1 = len(dz["pose_idx"])
+        pose_idx = np.concatenate([dz["pose_idx"] + 10 * r for r in range(reps)]).astype(np.int32)
+        lm_idx = np.concatenate([dz["lm_idx"] + 300 * r for r in range(reps)]).astype(np.int32)
+        poses12 = np.tile(dz["poses12"], (reps, 1))
+        pwz = np.tile(dz["pw"], (reps, 1))
+        pixz = np.tile(dz["pix"], (reps, 1))
+        ctxc = icgvins.Context(w, h, n_slots=1, max_batch=1, max_points=64, device=local_rank)
+        ctxc.set_camera(dz["cam"])
+        for _ in range(2):
+            ctxc.reproj_error_batch(pose_idx, lm_idx, poses12, pwz, pixz, 4.5)
+        ctxc.prof_enable(True)
+        t1 = time.perf_counter()
+        for _ in range(10):
+            ctxc.reproj_error_batch(pose_idx, lm_idx, poses12, pwz, pixz, 4.5)
+        wall = (time.perf_counter() - t1) / 10
+        n_launch, ms = ctxc.prof()["reproj_error"]
+        kern_s = ms * 1e-3 / n_launch
+        nobs = len(pose_idx)
+        cull = {"metric": "culling/statistics observations evaluated per second (reprojection error + isGoodToTrack gate)",
+                "observations_per_launch": int(nobs), "value": round(nobs / kern_s, 1), "unit": "observations/s", "kernel_us": round(kern_s * 1e6, 1),
+                "call_wall_us": round(wall * 1e6, 1),
+                "note": "point lists are read zero-copy over PCIe (25 B/observation): the call is transfer bound, the kernel itself is trivial"}
+        if not args.no_cpu_baseline:
+            import oracle_lib
+            orc = oracle_lib.load()
+            t1 = time.perf_counter()
+            nloop = 0
+            while time.perf_counter() - t1 < 1.0:
+                cu.oracle_eval(orc, dz, 3.0, 1.0)
+                nloop += 1
+            cull["cpu_baseline"] = {"value": round(nloop * nobs1 / (time.perf_counter() - t1), 1), "unit": "observations/s", "cores": 1, "kind": "port",
+                                    "sample": f"{nloop} x one window ({nobs1} observations), oracle, 1 thread"}
+        ctxc.close()
+
     # ---- CPU baseline of the front-end: same host layer on the CPU restatement (kind "port") ---------------------------
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -477,6 +517,7 @@ def main():
             "reproj": reproj,
             "ins": ins,
             "solve": solve,
+            "cull": cull,
             "kernels": kernel_table,
             "host_ms_per_step": host_breakdown,
             "quality": {"mean_tracked_mappoints_per_frame": round(total_tracked / max(1.0, total_frames), 1),
