@@ -783,4 +783,107 @@ int icgh_ins_redo(int n_streams, const double *cfg8, const double *updated23, in
     }
 }
 
+namespace {
+// r = w (x - x0) on one 9-vector block (velocity, gyroscope bias, accelerometer bias): stands in for the part of the
+// marginalization prior that anchors the first state's velocity and biases
+class MixPriorFactor : public ceres::SizedCostFunction<9, 9> {
+public:
+    MixPriorFactor(const double *x0, double weight) : w_(weight) { memcpy(x0_, x0, sizeof x0_); }
+    bool Evaluate(const double *const *parameters, double *residuals, double **jacobians) const override {
+        for (int k = 0; k < 9; k++) residuals[k] = w_ * (parameters[0][k] - x0_[k]);
+        if (jacobians && jacobians[0]) {
+            memset(jacobians[0], 0, sizeof(double) * 81);
+            for (int k = 0; k < 9; k++) jacobians[0][k * 9 + k] = w_;
+        }
+        return true;
+    }
+
+private:
+    double x0_[9], w_;
+};
+} // namespace
+
+// f1 with the factor mix of the real window: K preintegration factors (device P1 + host P2) between K+1 states, reprojection
+// factors on the same pose blocks (device), a pose prior and a velocity/bias prior on state 0 (what the marginalization prior
+// provides in the real window).  states: (K+1) x 16 (p3, q4 xyzw, v3, bg3, ba3) in/out;
+// imu rows of 8, interval k owns rows [offsets[k], offsets[k+1]).  summary4: initial cost, final cost, successful, unsuccessful steps.
+int icgh_backend_solve_vio(int n_intervals, const int32_t *offsets, const double *imu, const double *params9, double *states16, int n,
+                           const double *obs_soa, const int32_t *idx_i, const int32_t *idx_j, const int32_t *idx_lm, double *ext, int n_lm,
+                           double *invdepth, double *td, const double *prior_pose0, const double *prior_mix0, double prior_weight, double huber,
+                           int iters, double *summary4, char *err, int errlen) {
+    try {
+        const int K = n_intervals + 1;
+        vector<double> pose((size_t) K * 7), mix((size_t) K * 9);
+        for (int k = 0; k < K; k++) {
+            memcpy(&pose[7 * (size_t) k], states16 + 16 * (size_t) k, sizeof(double) * 7);
+            memcpy(&mix[9 * (size_t) k], states16 + 16 * (size_t) k + 7, sizeof(double) * 9);
+        }
+        vector<std::unique_ptr<ReprojectionFactor>> factors;
+        ReprojectionBatch batch(0);
+        for (int f = 0; f < n; f++) {
+            auto o = [&](int c) { return obs_soa[(size_t) c * n + f]; };
+            factors.emplace_back(new ReprojectionFactor(Vector3d(o(0), o(1), o(2)), Vector3d(o(3), o(4), o(5)), Vector3d(o(6), o(7), o(8)),
+                                                        Vector3d(o(9), o(10), o(11)), o(12), o(13), o(14)));
+            batch.add(factors.back().get(), &pose[7 * (size_t) idx_i[f]], &pose[7 * (size_t) idx_j[f]], ext, invdepth + idx_lm[f], td);
+        }
+        batch.finalize();
+        // preintegration of every interval from its start state: one icg_preint_batch launch on a context of its own
+        auto P           = std::make_shared<IntegrationParameters>();
+        P->gyr_arw = params9[0], P->acc_vrw = params9[1], P->gyr_bias_std = params9[2], P->acc_bias_std = params9[3], P->corr_time = params9[4];
+        P->gravity = params9[5];
+        P->iewn    = Vector3d(params9[6], params9[7], params9[8]);
+        TempCtx T(0);
+        vector<std::shared_ptr<Preintegration>> pre;
+        vector<Preintegration *> raw;
+        for (int k = 0; k < n_intervals; k++) {
+            const double *s0 = states16 + 16 * (size_t) k;
+            IntegrationState st;
+            st.p = Vector3d(s0[0], s0[1], s0[2]);
+            st.q = Quaterniond{s0[3], s0[4], s0[5], s0[6]};
+            st.v = Vector3d(s0[7], s0[8], s0[9]), st.bg = Vector3d(s0[10], s0[11], s0[12]), st.ba = Vector3d(s0[13], s0[14], s0[15]);
+            auto p = std::make_shared<Preintegration>(P, ins_imu(imu + 8 * (size_t) offsets[k]), st, Preintegration::NORMAL);
+            for (int row = offsets[k] + 1; row < offsets[k + 1]; row++) p->addNewImu(ins_imu(imu + 8 * (size_t) row));
+            pre.push_back(p);
+            raw.push_back(p.get());
+        }
+        std::string e;
+        if (!Preintegration::integrateBatch(T.ctx, raw, &e)) {
+            set_err(err, errlen, e.c_str());
+            return -2;
+        }
+        WindowSolver solver(&batch, huber);
+        for (int k = 0; k < K; k++) {
+            solver.addParameterBlock(&pose[7 * (size_t) k], 7, true);
+            solver.addParameterBlock(&mix[9 * (size_t) k], 9);
+        }
+        solver.addParameterBlock(ext, 7, true);
+        for (int l = 0; l < n_lm; l++) solver.addParameterBlock(invdepth + l, 1);
+        solver.addParameterBlock(td, 1);
+        solver.setParameterBlockConstant(ext); // estimated off-line in the default configuration (optimize_estimate_extrinsic: false)
+        solver.setParameterBlockConstant(td);
+        for (int k = 0; k < n_intervals; k++)
+            solver.addResidualBlock(std::make_shared<PreintegrationFactor>(pre[(size_t) k]), nullptr,
+                                    {&pose[7 * (size_t) k], &mix[9 * (size_t) k], &pose[7 * (size_t) (k + 1)], &mix[9 * (size_t) (k + 1)]});
+        solver.addResidualBlock(std::make_shared<PosePriorFactor>(prior_pose0, prior_weight), nullptr, {&pose[0]});
+        solver.addResidualBlock(std::make_shared<MixPriorFactor>(prior_mix0, prior_weight), nullptr, {&mix[0]});
+        WindowSolver::Options opt;
+        WindowSolver::Summary sum;
+        opt.max_num_iterations = iters;
+        if (!solver.solve(opt, &sum)) {
+            set_err(err, errlen, solver.error().c_str());
+            return -3;
+        }
+        summary4[0] = sum.initial_cost, summary4[1] = sum.final_cost, summary4[2] = sum.num_successful_steps, summary4[3] = sum.num_unsuccessful_steps;
+        for (int k = 0; k < K; k++) {
+            memcpy(states16 + 16 * (size_t) k, &pose[7 * (size_t) k], sizeof(double) * 7);
+            memcpy(states16 + 16 * (size_t) k + 7, &mix[9 * (size_t) k], sizeof(double) * 9);
+        }
+        if (getenv("ICG_SOLVER_DEBUG")) fprintf(stderr, "%s\n", sum.BriefReport().c_str());
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
 } // extern "C"

@@ -44,3 +44,19 @@ def test_window_solver_matches_dense_lm_on_gpu(oracle, cfg):
     for k in ("poses", "ext", "invdepth"):
         assert np.abs(h[k] - d[k]).max() < 1e-7, k
     assert np.abs(h["poses"][:, :3] - P["truth"]["poses"][:, :3]).max() < 0.01
+
+
+def test_window_solver_visual_inertial_window_on_gpu(oracle):
+    """preintegration + reprojection + priors in one solve on the HIP library: same optimum as the same host layer on the oracle
+    shim (1e-6), back at the IMU-consistent truth"""
+    import harness as H
+    import vio_data as vd
+    from stream_utils import ensure_oracle_host
+    W = vd.make_vio_window(oracle)
+    s, inv0 = vd.perturbed_start(W)
+    st, inv, summ = vd.host_solve_vio(C.CDLL(H.HOST_LIB), W, s, inv0)
+    st_c, inv_c, summ_c = vd.host_solve_vio(C.CDLL(ensure_oracle_host()), W, s, inv0)
+    assert np.array_equal(summ[2:], summ_c[2:]), (summ, summ_c)
+    assert np.abs(st - st_c).max() < 1e-6 and np.abs(inv - inv_c).max() < 1e-6
+    assert np.abs(st[:, :3] - W["states"][:, :3]).max() < 5e-3
+    assert np.abs(st[:, 7:10] - W["states"][:, 7:10]).max() < 1e-2
