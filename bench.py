@@ -423,6 +423,10 @@ def main():
                  "removed_by_chi2": int(hs["summary"][7]), "value": round(wall * 1e3, 3), "unit": "ms per window", "problem_setup_ms": round(setup_ms, 3),
                  "ms_per_lm_step": round(wall * 1e3 / max(1, steps), 3),
                  "bound": "latency: ~6 small launches + one reduced-system (P x P) transfer per LM step for a single window"}
+        nthr = int(max(2, min(16, round(cores_rank))))
+        su.host_solve_throughput(hl, Pz, nthr, 2)
+        solve["concurrent"] = {"solvers_in_flight": nthr, "value": round(su.host_solve_throughput(hl, Pz, nthr, 20), 1), "unit": "windows/s",
+                               "note": "one host thread + device context + HIP stream per solver, as the stream groups of the front-end"}
         if not args.no_cpu_baseline:
             from stream_utils import ensure_oracle_host
             ol = C.CDLL(ensure_oracle_host())

@@ -3,6 +3,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <thread>
+#include <atomic>
 
 #include "tracking_batch.h"
 #include "hostprof.h"
@@ -780,6 +782,76 @@ int icgh_ins_redo(int n_streams, const double *cfg8, const double *updated23, in
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());
         return -1;
+    }
+}
+
+// Aggregate solve throughput with many windows in flight: `threads` host threads, each with its own ReprojectionBatch (own icg_ctx
+// and HIP stream, like the stream groups of the front-end) and its own copy of the problem, each solving it `repeat` times from
+// the same start (problem construction outside the timed region).  Returns the wall time in seconds for threads x repeat solves,
+// < 0 on error.  Same flow as icgh_backend_solve (two solves with the chi-square pass).
+double icgh_backend_solve_throughput(int n, const double *obs_soa, const int32_t *idx_i, const int32_t *idx_j, const int32_t *idx_lm, int n_poses,
+                                     const double *poses, const double *ext, int n_lm, const double *invdepth, double td,
+                                     const double *prior_poses, double prior_weight, double huber, int iters1, int iters2, double chi2, int threads,
+                                     int repeat, char *err, int errlen) {
+    try {
+        struct Job {
+            vector<double> P, E, D;
+            double TD;
+            vector<std::unique_ptr<ReprojectionFactor>> factors;
+            std::unique_ptr<ReprojectionBatch> batch;
+        };
+        vector<std::unique_ptr<Job>> jobs;
+        for (int t = 0; t < threads; t++) {
+            std::unique_ptr<Job> J(new Job);
+            J->P.assign(poses, poses + 7 * (size_t) n_poses), J->E.assign(ext, ext + 7), J->D.assign(invdepth, invdepth + n_lm), J->TD = td;
+            J->batch.reset(new ReprojectionBatch(0));
+            for (int k = 0; k < n; k++) {
+                auto o = [&](int c) { return obs_soa[(size_t) c * n + k]; };
+                J->factors.emplace_back(new ReprojectionFactor(Vector3d(o(0), o(1), o(2)), Vector3d(o(3), o(4), o(5)), Vector3d(o(6), o(7), o(8)),
+                                                               Vector3d(o(9), o(10), o(11)), o(12), o(13), o(14)));
+                J->batch->add(J->factors.back().get(), &J->P[7 * (size_t) idx_i[k]], &J->P[7 * (size_t) idx_j[k]], J->E.data(), &J->D[(size_t) idx_lm[k]],
+                              &J->TD);
+            }
+            J->batch->finalize();
+            jobs.push_back(std::move(J));
+        }
+        std::atomic<int> failed{0};
+        auto work = [&](int t) {
+            Job &J = *jobs[(size_t) t];
+            for (int r = 0; r < repeat; r++) {
+                J.P.assign(poses, poses + 7 * (size_t) n_poses), J.E.assign(ext, ext + 7), J.D.assign(invdepth, invdepth + n_lm), J.TD = td;
+                WindowSolver solver(J.batch.get(), huber);
+                for (int k = 0; k < n_poses; k++) solver.addParameterBlock(&J.P[7 * (size_t) k], 7, true);
+                solver.addParameterBlock(J.E.data(), 7, true);
+                for (int l = 0; l < n_lm; l++) solver.addParameterBlock(&J.D[(size_t) l], 1);
+                solver.addParameterBlock(&J.TD, 1);
+                for (int k = 0; k < n_poses; k++)
+                    solver.addResidualBlock(std::make_shared<PosePriorFactor>(prior_poses + 7 * (size_t) k, prior_weight), nullptr, {&J.P[7 * (size_t) k]});
+                WindowSolver::Options opt;
+                WindowSolver::Summary s1;
+                opt.max_num_iterations = iters1;
+                if (!solver.solve(opt, &s1)) failed++;
+                if (chi2 > 0) {
+                    solver.removeReprojectionFactorsByChi2(chi2);
+                    opt.max_num_iterations = iters2;
+                    if (!solver.solve(opt, &s1)) failed++;
+                }
+            }
+        };
+        auto t0 = std::chrono::steady_clock::now();
+        vector<std::thread> th;
+        for (int t = 1; t < threads; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+        double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (failed.load()) {
+            set_err(err, errlen, "a solve failed");
+            return -2.0;
+        }
+        return sec;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1.0;
     }
 }
 

@@ -244,6 +244,7 @@ int icg_reproj_eval_batch(icg_ctx *, int n, const double *obs_soa, const int32_t
 } // extern "C"
 
 // ---- back-end entry points on the oracle (resident factor state kept per context) -------------------------------------
+#include <mutex>
 #include <unordered_map>
 namespace {
 struct shim_backend {
@@ -256,7 +257,15 @@ struct shim_backend {
     std::vector<double> H, b, inv;
     double damp = 0, min_diag = 0, max_diag = 0;
 };
-std::unordered_map<icg_ctx *, shim_backend> g_backend;
+std::unordered_map<icg_ctx *, shim_backend> g_backend_map;
+std::mutex g_backend_mutex;
+// element references stay valid across insertions (node-based container); only the lookup/insert itself needs the lock
+struct backend_accessor {
+    shim_backend &operator[](icg_ctx *ctx) {
+        std::lock_guard<std::mutex> lock(g_backend_mutex);
+        return g_backend_map[ctx];
+    }
+} g_backend;
 } // namespace
 
 extern "C" {

@@ -46,6 +46,22 @@ def host_solve(lib, P, prior_weight=30.0, huber=1.0, ext_const=False, td_const=F
     return dict(poses=poses, ext=ext, invdepth=inv, td=float(td[0]), summary=summ[:8], active=active, solve_ms=float(summ[8]), setup_ms=float(summ[9]))
 
 
+def host_solve_throughput(lib, P, threads, repeat, prior_weight=30.0, huber=1.0, iters1=6, iters2=18, chi2=5.991):
+    """-> windows per second with `threads` solvers in flight (each its own device context), problem construction excluded"""
+    s = P["start"]
+    n = P["obs"].shape[1]
+    err = C.create_string_buffer(512)
+    lib.icgh_backend_solve_throughput.restype = C.c_double
+    sec = lib.icgh_backend_solve_throughput(n, _p(np.ascontiguousarray(P["obs"])), _p(np.ascontiguousarray(P["ii"], np.int32)),
+                                            _p(np.ascontiguousarray(P["jj"], np.int32)), _p(np.ascontiguousarray(P["ll"], np.int32)), s["poses"].shape[0],
+                                            _p(np.ascontiguousarray(s["poses"])), _p(np.ascontiguousarray(s["ext"])), len(s["invdepth"]),
+                                            _p(np.ascontiguousarray(s["invdepth"])), C.c_double(s["td"]), _p(np.ascontiguousarray(P["prior"])),
+                                            C.c_double(prior_weight), C.c_double(huber), int(iters1), int(iters2), C.c_double(chi2), int(threads), int(repeat),
+                                            err, 512)
+    assert sec > 0, (sec, err.value)
+    return threads * repeat / sec
+
+
 # ---- independent dense LM -------------------------------------------------------------------------------------------------------
 def _prior_eval(x, x0, w):
     """PosePriorFactor of host/capi.cc: r = w [p - p0; 2 vec(q0^-1 q)], J (6x6 tangent) = w diag(1,1,1, dq_w, dq_w, dq_w)"""
