@@ -426,7 +426,9 @@ def main():
         nthr = int(max(2, min(16, round(cores_rank))))
         su.host_solve_throughput(hl, Pz, nthr, 2)
         solve["concurrent"] = {"solvers_in_flight": nthr, "value": round(su.host_solve_throughput(hl, Pz, nthr, 20), 1), "unit": "windows/s",
-                               "note": "one host thread + device context + HIP stream per solver, as the stream groups of the front-end"}
+                               "note": "one host thread + device context + HIP stream per solver (poll waits), as the stream groups of the front-end; "
+                                       "bounded by the HIP runtime's launch/copy rate (~100 small operations per window), not by the kernels: "
+                                       "batching many windows per launch is the round-2 item"}
         if not args.no_cpu_baseline:
             from stream_utils import ensure_oracle_host
             ol = C.CDLL(ensure_oracle_host())

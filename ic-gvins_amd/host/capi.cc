@@ -805,6 +805,7 @@ double icgh_backend_solve_throughput(int n, const double *obs_soa, const int32_t
             std::unique_ptr<Job> J(new Job);
             J->P.assign(poses, poses + 7 * (size_t) n_poses), J->E.assign(ext, ext + 7), J->D.assign(invdepth, invdepth + n_lm), J->TD = td;
             J->batch.reset(new ReprojectionBatch(0));
+            if (threads > 4) J->batch->setWaitMode(ICG_WAIT_POLL, 5); // more solvers than spare host cores: do not spin on completion
             for (int k = 0; k < n; k++) {
                 auto o = [&](int c) { return obs_soa[(size_t) c * n + k]; };
                 J->factors.emplace_back(new ReprojectionFactor(Vector3d(o(0), o(1), o(2)), Vector3d(o(3), o(4), o(5)), Vector3d(o(6), o(7), o(8)),

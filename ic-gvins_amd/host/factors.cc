@@ -73,6 +73,8 @@ ReprojectionBatch::~ReprojectionBatch() {
     icg_ctx_destroy(ctx_);
 }
 
+void ReprojectionBatch::setWaitMode(int icg_wait_mode, int sleep_us) { (void) icg_ctx_set_wait_mode(ctx_, icg_wait_mode, sleep_us); }
+
 void ReprojectionBatch::clear() {
     for (auto *f : factors_) {
         f->batch_ = nullptr;

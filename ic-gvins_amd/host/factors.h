@@ -76,6 +76,9 @@ public:
     const double *jacobian(int slot) const { return J_.data() + 46 * (size_t) slot; }
     bool prepared(bool with_jacobians) const { return prepared_ && (!with_jacobians || has_jac_); }
     const std::string &error() const { return error_; }
+    // completion waits of this batch's context: busy-wait (default, lowest latency for one solver) or poll + sleep (many solvers
+    // in flight on few host cores: see icg_ctx_set_wait_mode)
+    void setWaitMode(int icg_wait_mode, int sleep_us);
 
 private:
     friend class WindowSolver; // solver_hip.h: drives the resident factors through the Schur entry points
