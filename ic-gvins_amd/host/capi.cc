@@ -739,6 +739,19 @@ int icgh_ins_camera_pose(int n_streams, const int32_t *win_offsets, const double
     }
 }
 
+// MISC::writeNavResult into <dir>/nav.txt, err.txt, traj.txt: `calls` consecutive calls with the same state (a row every 10th call)
+int icgh_ins_write_nav_result(const double *cfg8, const double *origin3, const double *state23, double sodo, const char *dir, int calls) {
+    icg::IntegrationConfiguration cfg = ins_config(cfg8);
+    cfg.origin                        = icg::Vector3d(origin3[0], origin3[1], origin3[2]);
+    icg::IntegrationState st          = ins_state(state23);
+    st.sodo                           = sodo;
+    std::string d(dir);
+    auto nav = icg::FileSaver::create(d + "/nav.txt", 11), errf = icg::FileSaver::create(d + "/err.txt", 7), traj = icg::FileSaver::create(d + "/traj.txt", 8);
+    if (!nav->isOpen() || !errf->isOpen() || !traj->isOpen()) return -1;
+    for (int k = 0; k < calls; k++) icg::MISC::writeNavResult(cfg, st, nav, errf, traj);
+    return 0;
+}
+
 long icgh_ins_window_index(int n_win, const double *imu, double time) {
     return (long) icg::MISC::getInsWindowIndex(ins_window(n_win, imu, nullptr), time);
 }

@@ -136,6 +136,33 @@ bool WindowCulling::gvinsOutlierCulling(icg_ctx *ctx, const std::vector<Stream> 
     return true;
 }
 
+std::vector<double> WindowCulling::statisticsRow(const Map::Ptr &map, const ReprojectionStatistics &stats, const int iterations[2],
+                                                 const double timecosts[3], const int outliers[2]) {
+    std::vector<double> parameters;
+    std::vector<ulong> keyframeids = map->orderedKeyFrames();
+    size_t size                    = keyframeids.size();
+    if (size < 2) return parameters;
+    auto keyframes = map->keyframes();
+    auto frame_cur = keyframes.at(keyframeids[size - 1]);
+    auto frame_pre = keyframes.at(keyframeids[size - 2]);
+    parameters.push_back(frame_cur->stamp());
+    parameters.push_back(frame_cur->stamp() - frame_pre->stamp());
+    parameters.push_back(static_cast<double>(frame_cur->id() - frame_pre->id()));
+    parameters.push_back(static_cast<double>(frame_cur->numFeatures()));
+    parameters.push_back(stats.min_error);
+    parameters.push_back(stats.max_error);
+    parameters.push_back(stats.avg_error);
+    parameters.push_back(stats.rms_error);
+    parameters.push_back(iterations[0]);
+    parameters.push_back(iterations[1]);
+    parameters.push_back(timecosts[0]);
+    parameters.push_back(timecosts[1]);
+    parameters.push_back(timecosts[2]);
+    parameters.push_back(outliers[0]);
+    parameters.push_back(outliers[1]);
+    return parameters;
+}
+
 bool WindowCulling::reprojectionStatistics(icg_ctx *ctx, const std::vector<Stream> &streams, std::vector<ReprojectionStatistics> &stats,
                                            std::string *err) {
     Flat F;

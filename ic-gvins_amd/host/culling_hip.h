@@ -36,6 +36,11 @@ public:
     // gvinsOutlierCulling for every stream with ONE device launch; results[s] as the reference's counters
     static bool gvinsOutlierCulling(icg_ctx *ctx, const std::vector<Stream> &streams, double reprojection_error_std,
                                     std::vector<CullingResult> &results, std::string *err = nullptr);
+    // the line parametersStatistic appends to statistics.txt (ic_gvins.cc:949-1032), in the reference's column order:
+    // stamp, dt to the previous keyframe, frame-id difference, feature count, min / max / mean / rms reprojection error,
+    // iterations[2], timecosts[3], outliers[2].  Empty when the map holds fewer than two keyframes (:938-940).
+    static std::vector<double> statisticsRow(const Map::Ptr &map, const ReprojectionStatistics &stats, const int iterations[2],
+                                             const double timecosts[3], const int outliers[2]);
     // the reprojection-error block of parametersStatistic for every stream with ONE device launch
     static bool reprojectionStatistics(icg_ctx *ctx, const std::vector<Stream> &streams, std::vector<ReprojectionStatistics> &stats,
                                        std::string *err = nullptr);

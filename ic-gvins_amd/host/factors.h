@@ -196,6 +196,7 @@ struct IntegrationState { // preintegration/integration_state.h:35-52 (fields us
     Quaterniond q;
     Vector3d v, bg, ba;
     Vector3d sg, sa; // gyroscope / accelerometer scale factors (used by MISC::insMechanization when iswithscale)
+    double sodo{0};  // odometer scale factor (only written out by MISC::writeNavResult)
 };
 struct IntegrationParameters { // integration_state.h:67-88
     double acc_vrw{0}, gyr_arw{0}, gyr_bias_std{0}, acc_bias_std{0}, corr_time{1}, gravity{9.8};

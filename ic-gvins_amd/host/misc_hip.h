@@ -6,7 +6,9 @@
 // launch (icg_ins_mechanize_batch / icg_ins_camera_pose_batch).  No CPU fallback: the *Batch entry points fail when the ABI
 // call fails.
 #pragma once
+#include <cstdio>
 #include <deque>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -23,6 +25,22 @@ struct IntegrationConfiguration { // preintegration/integration_state.h:91-99
 
 typedef std::deque<std::pair<IMU, IntegrationState>> InsWindow;
 
+// fileio/filesaver.h:35-66, text mode: one "%-15.9lf " per value, newline per dump()
+class FileSaver {
+public:
+    typedef std::shared_ptr<FileSaver> Ptr;
+    FileSaver(const std::string &filename, int columns);
+    ~FileSaver();
+    static Ptr create(const std::string &filename, int columns) { return std::make_shared<FileSaver>(filename, columns); }
+    bool isOpen() const { return fp_ != nullptr; }
+    void dump(const std::vector<double> &data);
+    void flush();
+
+private:
+    FILE *fp_{nullptr};
+    int columns_;
+};
+
 class MISC {
 public:
     static constexpr double MINIMUM_TIME_INTERVAL = 0.0001; // misc.h:72
@@ -32,6 +50,12 @@ public:
     static int isNeedInterpolation(const IMU &imu0, const IMU &imu1, double mid);
     static void imuInterpolation(const IMU &imu01, IMU &imu00, IMU &imu11, double mid);
     static bool getImuSeriesFromTo(const InsWindow &ins_windows, double start, double end, std::vector<IMU> &series);
+
+    // misc.cc:417-499: every 10th call (process-wide counter, as in the reference) appends one line to the navigation file
+    // (0, time, lat/lon [deg], h, v, roll/pitch/heading [deg]), the IMU error file (time, bg [deg/h], ba [mGal], (sg, sa [ppm],) sodo)
+    // and the trajectory file (time, p, q xyzw).  Host only: three text lines per 10 IMU epochs.
+    static void writeNavResult(const IntegrationConfiguration &config, const IntegrationState &state, const FileSaver::Ptr &navfile,
+                               const FileSaver::Ptr &errfile, const FileSaver::Ptr &trajfile);
 
     // ---- device, batched over streams ----
     // insMechanization (misc.cc:151-206) over series[s] (series[s][0] = imu_pre of the first step) starting from *states[s],

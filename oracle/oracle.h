@@ -113,6 +113,8 @@ int orc_ins_camera_pose(int n_win, const double *imu, const double *states, cons
                         double *pose12);
 int orc_imu_series(int n_win, const double *imu, double start, double end, int cap, double *series /* cap x 8 */);
 int orc_redo_ins(const double *cfg8, const double *updated_state23, int reserved, int n_win, double *imu, double *states);
+// rows of MISC::writeNavResult (misc.cc:417-499): nav[11], errrow[<=14], traj[8]; returns the number of err values
+int orc_nav_result_rows(const double *origin3, int iswithscale, const double *state23, double sodo, double *nav, double *errrow, double *traj);
 
 #ifdef __cplusplus
 }

@@ -254,3 +254,94 @@ int orc_redo_ins(const double *cfg8, const double *updated_state23, int reserved
     return n_win - (int) counts;
 }
 }
+
+// ---- result rows of MISC::writeNavResult (misc.cc:417-499): the three text lines the reference dumps through FileSaver ----------
+//   nav  (11): 0, time, lat [deg], lon [deg], h, v3, roll, pitch, heading [deg]     (Earth::local2global earth.h:194-208,
+//                                                                                      Rotation::matrix2euler rotation.h:44-66)
+//   err  (7 | 13 values + sodo): time, bg [deg/h], ba [mGal] (, sg, sa [ppm]), sodo
+//   traj (8): time, p3, q4 (x y z w)
+// PINNED against the reference's own misc.cc + filesaver.cc (oracle/_ref/libref_misc.so): the text of the rows is compared.
+namespace {
+const double WGS84_RA = 6378137.0000000000, WGS84_E1 = 0.0066943799901413156; // earth.h:36-39
+const double R2D = 180.0 / M_PI;                                                // angle.h:30
+double earth_RN(double lat) { // earth.h:66-69
+    double sinlat = std::sin(lat);
+    return WGS84_RA / std::sqrt(1.0 - WGS84_E1 * sinlat * sinlat);
+}
+M3 earth_cne(V3 blh) { // earth.h:71-93
+    double sinlat = std::sin(blh.x), sinlon = std::sin(blh.y), coslat = std::cos(blh.x), coslon = std::cos(blh.y);
+    M3 d;
+    d.m[0][0] = -sinlat * coslon, d.m[0][1] = -sinlon, d.m[0][2] = -coslat * coslon;
+    d.m[1][0] = -sinlat * sinlon, d.m[1][1] = coslon, d.m[1][2] = -coslat * sinlon;
+    d.m[2][0] = coslat, d.m[2][1] = 0, d.m[2][2] = -sinlat;
+    return d;
+}
+V3 earth_blh2ecef(V3 blh) { // earth.h:117-130
+    double coslat = std::cos(blh.x), sinlat = std::sin(blh.x), coslon = std::cos(blh.y), sinlon = std::sin(blh.y);
+    double rn = earth_RN(blh.x), rnh = rn + blh.z;
+    return v3(rnh * coslat * coslon, rnh * coslat * sinlon, (rnh - rn * WGS84_E1) * sinlat);
+}
+V3 earth_ecef2blh(V3 ecef) { // earth.h:132-150
+    double p = std::sqrt(ecef.x * ecef.x + ecef.y * ecef.y);
+    double rn, lat, lon, h = 0, h2;
+    lat = std::atan(ecef.z / (p * (1.0 - WGS84_E1)));
+    lon = 2.0 * std::atan2(ecef.y, ecef.x + p);
+    do {
+        h2  = h;
+        rn  = earth_RN(lat);
+        h   = p / std::cos(lat) - rn;
+        lat = std::atan(ecef.z / (p * (1.0 - WGS84_E1 * rn / (rn + h))));
+    } while (std::fabs(h - h2) > 1.0e-4);
+    return v3(lat, lon, h);
+}
+V3 matrix2euler(const M3 &dcm) { // rotation.h:44-66
+    V3 e;
+    e.y = std::atan(-dcm.m[2][0] / std::sqrt(dcm.m[2][1] * dcm.m[2][1] + dcm.m[2][2] * dcm.m[2][2]));
+    if (dcm.m[2][0] <= -0.999) {
+        e.x = std::atan2(dcm.m[2][1], dcm.m[2][2]);
+        e.z = std::atan2((dcm.m[1][2] - dcm.m[0][1]), (dcm.m[0][2] + dcm.m[1][1]));
+    } else if (dcm.m[2][0] >= 0.999) {
+        e.x = std::atan2(dcm.m[2][1], dcm.m[2][2]);
+        e.z = M_PI + std::atan2((dcm.m[1][2] + dcm.m[0][1]), (dcm.m[0][2] - dcm.m[1][1]));
+    } else {
+        e.x = std::atan2(dcm.m[2][1], dcm.m[2][2]);
+        e.z = std::atan2(dcm.m[1][0], dcm.m[0][0]);
+    }
+    if (e.z < 0) e.z = M_PI * 2 + e.z;
+    return e;
+}
+} // namespace
+
+extern "C" {
+// nav[11], errrow[14] (n_err values used), traj[8]; returns n_err (8 without scale factors, 14 with)
+int orc_nav_result_rows(const double *origin3, int iswithscale, const double *state23, double sodo, double *nav, double *errrow, double *traj) {
+    State st   = load_state(state23);
+    V3 origin  = v3(origin3[0], origin3[1], origin3[2]);
+    V3 ecef0   = earth_blh2ecef(origin); // Earth::local2global(origin, Pose{R, p})
+    M3 cn0e    = earth_cne(origin);
+    V3 ecef1   = ecef0 + m3_vec(cn0e, st.p);
+    V3 blh1    = earth_ecef2blh(ecef1);
+    M3 cn1e    = earth_cne(blh1);
+    M3 Rg      = m3_mul(m3_mul(m3_T(cn1e), cn0e), qmat(st.q));
+    V3 pos     = blh1;
+    pos.x *= R2D, pos.y *= R2D; // pos.segment(0, 2) *= R2D
+    V3 att = matrix2euler(Rg) * R2D;
+    V3 bg  = st.bg * R2D * 3600;
+    V3 ba  = st.ba * 1e5;
+    const double n[11] = {0, st.time, pos.x, pos.y, pos.z, st.v.x, st.v.y, st.v.z, att.x, att.y, att.z};
+    memcpy(nav, n, sizeof n);
+    int k = 0;
+    errrow[k++] = st.time;
+    errrow[k++] = bg.x, errrow[k++] = bg.y, errrow[k++] = bg.z;
+    errrow[k++] = ba.x, errrow[k++] = ba.y, errrow[k++] = ba.z;
+    if (iswithscale) {
+        V3 sg = st.sg * 1e6, sa = st.sa * 1e6;
+        errrow[k++] = sg.x, errrow[k++] = sg.y, errrow[k++] = sg.z;
+        errrow[k++] = sa.x, errrow[k++] = sa.y, errrow[k++] = sa.z;
+    }
+    errrow[k++] = sodo;
+    const double t[8] = {st.time, st.p.x, st.p.y, st.p.z, st.q.x, st.q.y, st.q.z, st.q.w};
+    memcpy(traj, t, sizeof t);
+    return k;
+}
+}

@@ -115,6 +115,23 @@ int ref_imu_series(int n_win, const double *imu, double start, double end, int c
     for (size_t k = 0; k < out.size(); k++) put_imu(out[k], series + 8 * k);
     return (int) out.size();
 }
+// MISC::writeNavResult (misc.cc:417-499) through the reference's own FileSaver: writes <dir>/nav.txt, err.txt, traj.txt (text).  The
+// function keeps a static call counter and only writes every 10th call: `calls` consecutive calls are made with the same state,
+// so ceil(calls / 10) rows appear (call it with multiples of 10 to keep the counter aligned between invocations).  origin = config.origin (lat, lon [rad], h).  sodo is state.sodo.
+int ref_write_nav_result(const double *cfg8, const double *origin3, const double *state23, double sodo, const char *dir, int calls) {
+    IntegrationConfiguration cfg = make_config(cfg8);
+    cfg.origin                   = Vector3d(origin3[0], origin3[1], origin3[2]);
+    IntegrationState st          = make_state(state23);
+    st.sodo                      = sodo;
+    std::string d(dir);
+    auto nav  = FileSaver::create(d + "/nav.txt", 11);
+    auto errf = FileSaver::create(d + "/err.txt", 7);
+    auto traj = FileSaver::create(d + "/traj.txt", 8);
+    if (!nav->isOpen() || !errf->isOpen() || !traj->isOpen()) return -1;
+    for (int k = 0; k < calls; k++) MISC::writeNavResult(cfg, st, nav, errf, traj);
+    return 0;
+}
+
 // MISC::redoInsMechanization (misc.cc:208-261): window (imu n x 8, states n x 23) updated in place; returns the new window length
 // (expired entries are dropped from the front: imu/states are compacted to the front of the arrays)
 int ref_redo_ins(const double *cfg8, const double *updated_state23, int reserved, int n_win, double *imu, double *states) {

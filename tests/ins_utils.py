@@ -8,6 +8,7 @@ dvel3; state rows of 23: time, p3, q4 xyzw, v3, bg3, ba3, sg3, sa3; cfg8: gravit
 """
 import ctypes as C
 import os
+import tempfile
 
 import numpy as np
 
@@ -107,6 +108,34 @@ def query_times(imu):
     return np.array(q)
 
 
+def _read_rows(d):
+    """the single line each of nav.txt, err.txt, traj.txt holds after 10 calls of writeNavResult (trailing newline dropped)"""
+    rows = []
+    for name in ("nav.txt", "err.txt", "traj.txt"):
+        with open(os.path.join(d, name)) as f:
+            lines = f.read().split("\n")
+        assert len(lines) == 2 and lines[1] == "", (name, lines)
+        rows.append(lines[0])
+    return np.array(rows, dtype=str)
+
+
+ORIGIN = np.array([np.deg2rad(30.5278), np.deg2rad(114.3557), 21.3])
+
+
+def nav_cases():
+    """(cfg8, state23, sodo): a scale-factor state far from the origin, a plain state, a state pitched up 89.6 deg (the
+    dcm(2,0) <= -0.999 branch of Rotation::matrix2euler)"""
+    a = mech_case("earth_scale_jitter")
+    s1 = a["s0"].copy()
+    s1[1:4] += [820.5, -431.2, 12.7]
+    b = mech_case("normal")
+    s2 = b["s0"].copy()
+    s3 = s2.copy()
+    ang = np.deg2rad(89.6)
+    s3[4:8] = [0.0, np.sin(ang / 2), 0.0, np.cos(ang / 2)]
+    return [(a["cfg"], s1, 0.0123), (b["cfg"], s2, 0.0), (b["cfg"], s3, -0.004)]
+
+
 # ---- drivers ------------------------------------------------------------------------------------------------------------
 class _Flat:
     """common call layout; subclasses bind the symbols"""
@@ -139,6 +168,11 @@ class RefMisc(_Flat):
         n = self.lib.ref_imu_series(len(imu), _p(_f64(imu)), C.c_double(start), C.c_double(end), len(out), _p(out))
         return None if n < 0 else out[:n].copy()
 
+    def nav_rows(self, cfg8, origin, state23, sodo):
+        d = tempfile.mkdtemp(prefix="refnav_")
+        assert self.lib.ref_write_nav_result(_p(_f64(cfg8)), _p(_f64(origin)), _p(_f64(state23)), C.c_double(sodo), d.encode(), 10) == 0
+        return _read_rows(d)
+
     def redo(self, cfg8, updated, reserved, imu, states):
         imu, states = _f64(imu).copy(), _f64(states).copy()
         n = self.lib.ref_redo_ins(_p(_f64(cfg8)), _p(_f64(updated)), int(reserved), len(imu), _p(imu), _p(states))
@@ -168,6 +202,12 @@ class OrcMisc(_Flat):
         out = np.zeros((len(imu) + 4, 8))
         n = self.lib.orc_imu_series(len(imu), _p(_f64(imu)), C.c_double(start), C.c_double(end), len(out), _p(out))
         return None if n < 0 else out[:n].copy()
+
+    def nav_rows(self, cfg8, origin, state23, sodo):
+        nav, errrow, traj = np.zeros(11), np.zeros(14), np.zeros(8)
+        n = self.lib.orc_nav_result_rows(_p(_f64(origin)), int(cfg8[7] != 0), _p(_f64(state23)), C.c_double(sodo), _p(nav), _p(errrow), _p(traj))
+        fmt = lambda row: "".join("%-15.9f " % v for v in row)
+        return np.array([fmt(nav), fmt(errrow[:n]), fmt(traj)], dtype=str)
 
     def redo(self, cfg8, updated, reserved, imu, states):
         imu, states = _f64(imu).copy(), _f64(states).copy()
@@ -216,6 +256,11 @@ class HostMisc(_Flat):
         out = np.zeros((len(imu) + 4, 8))
         n = self.lib.icgh_ins_imu_series(len(imu), _p(_f64(imu)), C.c_double(start), C.c_double(end), len(out), _p(out))
         return None if n < 0 else out[:n].copy()
+
+    def nav_rows(self, cfg8, origin, state23, sodo):
+        d = tempfile.mkdtemp(prefix="icgnav_")
+        assert self.lib.icgh_ins_write_nav_result(_p(_f64(cfg8)), _p(_f64(origin)), _p(_f64(state23)), C.c_double(sodo), d.encode(), 10) == 0
+        return _read_rows(d)
 
     def redo_batch(self, cfg8, updated, reserved, imus, states):
         off = np.concatenate([[0], np.cumsum([len(i) for i in imus])]).astype(np.int32)
@@ -290,6 +335,8 @@ def run_all(impl):
                 im, stt = impl.redo(c["cfg"], u, reserved, c["imu"], states)
                 out[f"redo_{name}_{j}_{reserved}_imu"] = im
                 out[f"redo_{name}_{j}_{reserved}_states"] = stt
+    for k, (cfg, st, sodo) in enumerate(nav_cases()):
+        out[f"navrows_{k}"] = impl.nav_rows(cfg, ORIGIN, st, sodo)
     return out
 
 
@@ -299,7 +346,9 @@ def compare(got, exp, tol_state=1e-12, tol_pose=1e-12, exact_series=True):
     for k in sorted(exp.keys()):
         g, e = np.asarray(got[k]), np.asarray(exp[k])
         assert g.shape == e.shape, (k, g.shape, e.shape)
-        if k.startswith(("idx_", "found_")) or k.endswith("_count"):
+        if k.startswith("navrows_"):  # the text of the three result lines (9 decimals)
+            assert list(g) == [str(x) for x in e], (k, list(g), list(e))
+        elif k.startswith(("idx_", "found_")) or k.endswith("_count"):
             assert np.array_equal(g, e), k
         elif k.startswith("series_") or k.endswith("_imu"):
             if exact_series:
