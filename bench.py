@@ -104,7 +104,8 @@ def build_streams(sb, scene, n_streams, n_ring, rank, ctx_dev_upload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed lock-step frames per stream (default 200: ~1 s timed region; 40 steps gave +-5 %% run-to-run noise)")
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("ICG_BENCH_STREAMS", "0")),
                     help="camera streams per GPU (0 = 8 per stream group)")
