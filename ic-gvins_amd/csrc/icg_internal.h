@@ -202,6 +202,13 @@ struct icg_call {
         if (n) memcpy(ctx->h_arena + off, src, sizeof(T) * n);
         return reinterpret_cast<T *>(ctx->h_arena + off);
     }
+    // mirrored in-place block: uploaded at seal(), the same bytes copied back to `user` at finish() (pass user = nullptr to the
+    // second argument to keep the result on the host side private: accumulators that the caller reads through another pointer)
+    template <typename T> T *inout(const T *src, T *user, size_t n) {
+        T *d = in(src, n);
+        if (user) outs.push_back({(void *) user, (size_t) (reinterpret_cast<char *>(d) - ctx->d_arena), sizeof(T) * n, false});
+        return d;
+    }
     int seal() { return mirror_hi > mirror_lo ? icg_arena_h2d(ctx, mirror_lo, mirror_hi) : 0; }
     template <typename T> T *out(T *user, size_t n) {
         size_t off = icg_arena_alloc(ctx, sizeof(T) * n);

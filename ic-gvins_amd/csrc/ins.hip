@@ -138,10 +138,8 @@ extern "C" int icg_ins_mechanize_batch(icg_ctx *ctx, int n_streams, const int32_
     const int32_t *d_off = c.in(offsets, (size_t) n_streams + 1);
     const double *d_imu  = c.in(imu, 8 * (size_t) total);
     const double *d_cfg  = c.in(cfg8, 8);
-    double *d_st         = c.in(states23, 23 * (size_t) n_streams);
+    double *d_st         = c.inout(states23, states23, 23 * (size_t) n_streams); // read and written in place
     if ((rc = c.seal())) return rc;
-    // the state block is read and written in place in the device arena; its output record reuses the same offset
-    c.outs.push_back({(void *) states23, (size_t) ((char *) d_st - ctx->d_arena), sizeof(double) * 23 * (size_t) n_streams, false});
     double *d_traj = traj23 ? c.out(traj23, 23 * (size_t) total) : nullptr;
     {
         icg_prof_scope ps(ctx, "ins_mechanize");

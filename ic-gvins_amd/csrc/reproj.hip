@@ -705,9 +705,8 @@ extern "C" int icg_reproj_backsub(icg_ctx *ctx, int P, const double *delta_c, do
     if (rc) return rc;
     const double *d_dc = c.in(delta_c, (size_t) P);
     const double zeros[2] = {0.0, 0.0};
-    double *d_tm = c.in(zeros, 2);
+    double *d_tm = c.inout(zeros, lm_terms, 2); // device accumulators, pre-zeroed
     if ((rc = c.seal())) return rc;
-    if (lm_terms) c.outs.push_back({(void *) lm_terms, (size_t) ((char *) d_tm - ctx->d_arena), 2 * sizeof(double), false});
     double *d_dl = c.out(delta_l, (size_t) L);
     {
         icg_prof_scope ps(ctx, "schur_backsub");
@@ -730,9 +729,8 @@ extern "C" int icg_reproj_cost(icg_ctx *ctx, const uint8_t *active, double *cost
     if (rc) return rc;
     const uint8_t *d_act = active ? c.in(active, (size_t) n) : nullptr;
     const double zero = 0.0;
-    double *d_acc = c.in(&zero, 1);
+    double *d_acc = c.inout(&zero, cost, 1); // device accumulator, pre-zeroed
     if ((rc = c.seal())) return rc;
-    c.outs.push_back({(void *) cost, (size_t) ((char *) d_acc - ctx->d_arena), sizeof(double), false});
     {
         icg_prof_scope ps(ctx, "reproj_cost");
         hipLaunchKernelGGL(k_reproj_cost, dim3(std::min(64, (n + 255) / 256)), dim3(256), 0, ctx->stream, n, (const double *) ctx->d_rJ, d_act,
