@@ -500,6 +500,44 @@ def main():
                                   f"oracle-backed host layer, single thread ({ncpu} host cores available)"}
         sbc.close()
 
+    # the REFERENCE's own tracker sources (oracle/_ref/libref_tracking.so: tracking/*.cc compiled unmodified on interface shims, its
+    # OpenCV calls forwarded to the oracle primitives) on the same frames: includes the reference's call pattern (the LK pyramids
+    # are rebuilt by every calcOpticalFlowPyrLK call, features() map copies, ...).  Reported next to the port, never as the target.
+    cpu_reference = None
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref_tracking.so")
+    if rank == 0 and not args.no_cpu_baseline and os.path.exists(ref_so):
+        import tempfile
+        rl = C.CDLL(ref_so)
+        rl.ref_tracker_create.restype = C.c_void_p
+        tmp = tempfile.mkdtemp(prefix="benchref_")
+        cfgf = os.path.join(tmp, "track.yaml")
+        with open(cfgf, "w") as f_:
+            f_.write(f"track_check_histogram: false\ntrack_min_parallax: 10\ntrack_max_features: {nfeat}\ntrack_max_interval: 0.5\n"
+                     "is_use_visualization: false\nreprojection_error_std: 1.5\n")
+        cam_a = np.asarray(cam, np.float64)
+        T = C.c_void_p(rl.ref_tracker_create(cam_a.ctypes.data_as(C.c_void_p), w, h, cfgf.encode(), tmp.encode(), 10))
+        nwarm, ntime = 30, 30
+        kk = 0
+
+        def ref_step(kk):
+            f = H.pingpong(kk, args.ring)
+            img = np.ascontiguousarray(host0[f])
+            p12 = np.ascontiguousarray(poses[0][f], np.float64)
+            rl.ref_tracker_track(T, img.ctypes.data_as(C.c_void_p), w, h, w, 1, C.c_double(1000.0 + kk / 20.0), p12.ctypes.data_as(C.c_void_p))
+
+        for _ in range(nwarm):
+            ref_step(kk)
+            kk += 1
+        t1 = time.perf_counter()
+        for _ in range(ntime):
+            ref_step(kk)
+            kk += 1
+        dt = time.perf_counter() - t1
+        rl.ref_tracker_destroy(T)
+        cpu_reference = {"value": round(ntime / dt, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+                         "sample": f"1 stream x {ntime} steady-state frames, the reference's tracking/*.cc (oracle/_ref/libref_tracking.so) with its OpenCV "
+                                   "entry points served by the oracle primitives, single thread"}
+
     if rank == 0:
         out = {
             "metric": "frames/s at 1280x720, 300 feats, 10-KF window; residual/Jacobian eval/s",
@@ -520,6 +558,7 @@ def main():
                        "input_residency": "pinned host frames, uploaded per frame (PCIe-inclusive diagnostic)" if args.host_frames else "raw frames in HBM", "sharding": "independent streams per GPU, no data-path collective"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "cpu_baseline_reference_tracker": cpu_reference,
             "speedup_vs_cpu_baseline": (round(fps / cpu_baseline["value"], 2) if cpu_baseline else None),
             "reproj": reproj,
             "ins": ins,
