@@ -201,6 +201,7 @@ int icgh_batch_features(icgh_batch *b, int stream, int max, uint64_t *ids, float
 #include "misc_hip.h"
 #include "solver_hip.h"
 #include "culling_hip.h"
+#include "window_visual.h"
 
 namespace {
 // simple generic host factor used to exercise the non-reprojection path of MarginalizationInfo:
@@ -549,6 +550,77 @@ int icgh_batch_culling(icgh_batch *b, int mode, const int32_t *list_off, const u
                 const double v[5]               = {r.min_error, r.max_error, r.avg_error, r.rms_error, (double) r.landmarks};
                 memcpy(stats5 + 5 * s, v, sizeof v);
             }
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
+// ---- map -> optimizer -> map on the windows the tracker built (window_visual.h + solver_hip.h + culling_hip.h) ----------------
+// For every stream: VisualWindow::build (addReprojectionParameters / addReprojectionFactors), pose priors at the current keyframe
+// poses (weight prior_weight; they stand in for the IMU / GNSS / marginalization factors), LM solve - chi-square culling - LM solve,
+// updateParametersFromOptimizer, gvinsOutlierCulling.  out7[s*7..] = keyframes, factors, initial cost, final cost, removed by chi2,
+// culled map points, culled features.  kf_out (optional, max_kf rows of 14 per stream): keyframe stamp, frame id, camera pose12.
+int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td, double reprojection_error_std, double prior_weight, int iters1,
+                              int iters2, double chi2, double *out7, int max_kf, double *kf_out, char *err, int errlen) {
+    try {
+        const int n = b->tb->size();
+        Pose pbc;
+        memcpy(pbc.R.m, pose_b_c12, sizeof(double) * 9);
+        memcpy(pbc.t.v, pose_b_c12 + 9, sizeof(double) * 3);
+        icg_ctx *ctx = b->tb->group(0).device()->ctx();
+        for (int s = 0; s < n; s++) {
+            auto &S = b->tb->stream(s);
+            double *o = out7 + 7 * (size_t) s;
+            for (int k = 0; k < 7; k++) o[k] = 0;
+            VisualWindow win(S.camera, S.map, pbc, td, reprojection_error_std);
+            win.build();
+            o[0] = win.numKeyFrames(), o[1] = win.numFactors();
+            if (win.numKeyFrames() >= 2 && win.numFactors() > 0) {
+                WindowSolver solver(win.batch(), 1.0);
+                win.addTo(solver);
+                vector<vector<double>> prior((size_t) win.numKeyFrames());
+                for (int k = 0; k < win.numKeyFrames(); k++) {
+                    prior[(size_t) k].assign(win.pose(k), win.pose(k) + 7);
+                    solver.addResidualBlock(std::make_shared<PosePriorFactor>(prior[(size_t) k].data(), prior_weight), nullptr, {win.pose(k)});
+                }
+                WindowSolver::Options opt;
+                WindowSolver::Summary s1, s2;
+                opt.max_num_iterations = iters1;
+                if (!solver.solve(opt, &s1)) {
+                    set_err(err, errlen, solver.error().c_str());
+                    return -2;
+                }
+                o[2] = s1.initial_cost, o[3] = s1.final_cost;
+                if (chi2 > 0) {
+                    o[4] = solver.removeReprojectionFactorsByChi2(chi2);
+                    opt.max_num_iterations = iters2;
+                    if (!solver.solve(opt, &s2)) {
+                        set_err(err, errlen, solver.error().c_str());
+                        return -3;
+                    }
+                    o[3] = s2.final_cost;
+                }
+                win.updateParametersFromOptimizer();
+                vector<WindowCulling::Stream> one = {{S.map, &win.invdepthlist()}};
+                vector<CullingResult> R;
+                std::string e;
+                if (!WindowCulling::gvinsOutlierCulling(ctx, one, reprojection_error_std, R, &e)) {
+                    set_err(err, errlen, e.c_str());
+                    return -4;
+                }
+                o[5] = R[0].outlier_mappoints, o[6] = R[0].outlier_features;
+            }
+            if (kf_out)
+                for (int k = 0; k < std::min(max_kf, win.numKeyFrames()); k++) {
+                    double *r = kf_out + 14 * ((size_t) s * max_kf + k);
+                    r[0] = win.frame(k)->stamp(), r[1] = (double) win.frame(k)->id();
+                    Pose p = win.frame(k)->pose();
+                    memcpy(r + 2, p.R.m, sizeof(double) * 9);
+                    memcpy(r + 11, p.t.v, sizeof(double) * 3);
+                }
         }
         return 0;
     } catch (const std::exception &e) {

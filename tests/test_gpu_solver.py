@@ -60,3 +60,9 @@ def test_window_solver_visual_inertial_window_on_gpu(oracle):
     assert np.abs(st - st_c).max() < 1e-6 and np.abs(inv - inv_c).max() < 1e-6
     assert np.abs(st[:, :3] - W["states"][:, :3]).max() < 5e-3
     assert np.abs(st[:, 7:10] - W["states"][:, 7:10]).max() < 1e-2
+
+
+def test_map_to_optimizer_to_map_on_tracked_windows_on_gpu():
+    import harness as H
+    import refine_checks as rc
+    rc.check_refinement(H.HOST_LIB)

@@ -59,3 +59,10 @@ def test_window_solver_visual_inertial_window(host_lib, oracle):
     assert np.abs(st[:, 7:10] - W["states"][:, 7:10]).max() < 1e-2
     assert np.abs(st[:, 10:] - W["states"][:, 10:]).max() < 2e-3
     assert np.abs(inv / W["invdepth"] - 1).max() < 0.05
+
+
+def test_map_to_optimizer_to_map_on_tracked_windows(host_lib):
+    """VisualWindow (addReprojectionParameters / addReprojectionFactors / updateParametersFromOptimizer of GVINS) + WindowSolver +
+    WindowCulling on the maps the tracker built from noisy INS priors"""
+    import refine_checks as rc
+    rc.check_refinement(host_lib)
