@@ -437,6 +437,28 @@ def main():
             solve["cpu_baseline"] = {"value": round(su.host_solve(ol, Pz)["solve_ms"], 3), "unit": "ms per window", "cores": 1, "kind": "port",
                                      "sample": "the same solver on the oracle shim (dense (P+L)^2 assembly + elimination on one core)"}
 
+    # ---- M1-M4: one marginalization of a C2-size window (device: factor evaluation + normal equations; host: Schur, eigen) -------
+    marg = None
+    if rank == 0 and not args.no_reproj:
+        import backend_utils as bu
+        import marg_data as md
+        Pm = md.make_problem(n_lm=300, n_kf=10, seed=2)
+        hl = C.CDLL(H.HOST_LIB)
+        bu.backend_marginalize(hl, Pm)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            bu.backend_marginalize(hl, Pm)
+        marg = {"metric": "marginalization of the oldest keyframe of a C2 window (M1-M4)", "factors": int(Pm["obs"].shape[1]),
+                "value": round((time.perf_counter() - t1) / 5 * 1e3, 3), "unit": "ms per marginalization (incl. problem construction through the C API)"}
+        if not args.no_cpu_baseline:
+            from stream_utils import ensure_oracle_host
+            ol = C.CDLL(ensure_oracle_host())
+            bu.backend_marginalize(ol, Pm)
+            t1 = time.perf_counter()
+            bu.backend_marginalize(ol, Pm)
+            marg["cpu_baseline"] = {"value": round((time.perf_counter() - t1) * 1e3, 3), "unit": "ms per marginalization", "cores": 1, "kind": "port",
+                                    "sample": "the same host layer on the oracle shim"}
+
     # ---- f3: per-observation reprojection error + isGoodToTrack gate of the culling / statistics pass ---------------------------
     cull = None
     if rank == 0 and not args.no_reproj:
@@ -564,6 +586,7 @@ def main():
             "ins": ins,
             "solve": solve,
             "cull": cull,
+            "marg": marg,
             "kernels": kernel_table,
             "host_ms_per_step": host_breakdown,
             "quality": {"mean_tracked_mappoints_per_frame": round(total_tracked / max(1.0, total_frames), 1),
