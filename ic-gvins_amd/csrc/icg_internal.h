@@ -78,6 +78,16 @@ struct icg_ctx {
     size_t sys_cap = 0; // doubles
     int sys_P = 0, sys_L = 0, sys_valid = 0;
     double sys_damp = 0.0, sys_min_diag = 0.0, sys_max_diag = 0.0;
+    // f1, many windows per launch: partition of the resident factors / landmarks (icg_reproj_set_windows)
+    int n_windows = 0;
+    std::vector<int32_t> w_fac_off, w_lm_off; // W+1 each
+    std::vector<int32_t> w_pose_win;          // window of every pose index used by the resident factors
+    std::vector<int64_t> w_sys_off;           // W+1: start of window w's (H | b | inv) block inside d_sys, in doubles
+    int32_t *d_fwin = nullptr;                // window of every factor (factors_cap)
+    int32_t *d_lmwin = nullptr;               // window of every landmark
+    int lmwin_cap = 0, wsys_P = 0, wsys_valid = 0;
+    std::vector<double> w_damp;               // damping that went into each window's inv
+
 
     icg_camera cam{};
     bool has_cam = false;

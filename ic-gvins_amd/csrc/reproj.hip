@@ -29,6 +29,9 @@ struct rpj_args {
     double huber_delta;
     double *out_r; // n x 2
     double *out_J; // n x 46
+    // many windows per launch (icg_reproj_eval_windows): factor k belongs to window win[k]; ext is W x 7, tdv has W entries
+    const int32_t *win;
+    const double *tdv;
 };
 
 __device__ __forceinline__ void put23(double *row0, double *row1, const double red[6], const m33 &m, int col0) {
@@ -61,10 +64,12 @@ __global__ __launch_bounds__(RPJ_TILE) void k_reproj_eval(rpj_args A) {
         dq q0  = q_from_xyzw(pi + 3);
         d3 p1  = mk3(pj[0], pj[1], pj[2]);
         dq q1  = q_from_xyzw(pj + 3);
-        d3 tic = mk3(A.ext[0], A.ext[1], A.ext[2]);
-        dq qic = q_from_xyzw(A.ext + 3);
+        const int wk      = A.win ? A.win[k] : 0;
+        const double *ext = A.ext + 7 * (size_t) wk;
+        d3 tic = mk3(ext[0], ext[1], ext[2]);
+        dq qic = q_from_xyzw(ext + 3);
         double id0 = A.invdepth[A.idx_lm[k]];
-        double td  = A.td;
+        double td  = A.win ? A.tdv[wk] : A.td;
 
         d3 pts_0_td = sub(pts0, scl(td - td0, vel0));
         d3 pts_1_td = sub(pts1, scl(td - td1, vel1));
@@ -210,6 +215,8 @@ static int ensure_factor_capacity(icg_ctx *ctx, int n) {
     if (ctx->d_obs) (void) hipFree(ctx->d_obs);
     if (ctx->d_fidx) (void) hipFree(ctx->d_fidx);
     if (ctx->d_rJ) (void) hipFree(ctx->d_rJ);
+    if (ctx->d_fwin) (void) hipFree(ctx->d_fwin);
+    ctx->d_fwin = nullptr;
     ctx->d_obs = nullptr;
     ctx->d_fidx = nullptr;
     ctx->d_rJ = nullptr;
@@ -218,6 +225,7 @@ static int ensure_factor_capacity(icg_ctx *ctx, int n) {
     ICG_HIP(ctx, hipMalloc((void **) &ctx->d_obs, sizeof(double) * 15 * (size_t) cap));
     ICG_HIP(ctx, hipMalloc((void **) &ctx->d_fidx, sizeof(int32_t) * 3 * (size_t) cap));
     ICG_HIP(ctx, hipMalloc((void **) &ctx->d_rJ, sizeof(double) * 48 * (size_t) cap));
+    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_fwin, sizeof(int32_t) * (size_t) cap));
     ctx->factors_cap = cap;
     return 0;
 }
@@ -231,6 +239,8 @@ extern "C" int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa
     ctx->n_factors_resident = n;
     ctx->rJ_valid           = 0;
     ctx->sys_valid          = 0;
+    ctx->n_windows          = 0;
+    ctx->wsys_valid         = 0;
     if (n == 0) return ICG_OK;
     // component-major obs is already the device layout; indices packed as 3 x n
     ICG_HIP(ctx, hipMemcpyAsync(ctx->d_obs, obs_soa, sizeof(double) * 15 * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
@@ -277,6 +287,8 @@ extern "C" int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double 
     A.td          = td;
     A.want_jac    = want_jac;
     A.huber_delta = huber_delta;
+    A.win         = nullptr;
+    A.tdv         = nullptr;
     // device-resident results (kept for icg_reproj_accumulate_normal): r at d_rJ, J after it
     A.out_r = ctx->d_rJ;
     A.out_J = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
@@ -735,6 +747,471 @@ extern "C" int icg_reproj_cost(icg_ctx *ctx, const uint8_t *active, double *cost
         icg_prof_scope ps(ctx, "reproj_cost");
         hipLaunchKernelGGL(k_reproj_cost, dim3(std::min(64, (n + 255) / 256)), dim3(256), 0, ctx->stream, n, (const double *) ctx->d_rJ, d_act,
                            ctx->last_huber, d_acc);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}
+
+
+// ---- f1, many windows per launch ------------------------------------------------------------------------------------------------
+// One solver in flight per stream is bounded by the runtime's rate of small launches and copies (~100 per window and solve, DESIGN.md
+// §6).  Here the windows of many streams advance in lock-step: ONE evaluation, ONE assembly, ONE reduction, ONE back-substitution
+// launch per LM step for all of them.  The resident factor set is partitioned into W windows (factors sorted by window, landmarks
+// contiguous per window, poses indexed globally); every window has its own extrinsic / td, its own reduced system of the common
+// size P and its own damping.  Window w's system lives at d_sys + w_sys_off[w]: H (N_w x N_w, N_w = P + L_w) | b (N_w) | inv (L_w).
+struct win_desc {
+    int32_t fac_begin, fac_end, lm_begin, L;
+    int64_t sys_off;
+    int32_t vcol_ext, vcol_td, V, reassemble;
+    double damp;
+};
+
+__global__ __launch_bounds__(NRM_BLOCK) void k_reproj_normal_schur_w(const win_desc *wd, const int32_t *blk_win, const int32_t *blk_first,
+                                                                     const double *r, const double *J, const int32_t *idx_i, const int32_t *idx_j,
+                                                                     const int32_t *idx_lm, const int32_t *vcol_pose, const int32_t *vmap_all, int Vmax,
+                                                                     int P, double *sys, const uint8_t *active) {
+    extern __shared__ double sm[]; // Hs[V*V] | bs[V]
+    const win_desc W = wd[blk_win[blockIdx.x]];
+    if (!W.reassemble) return; // uniform per workgroup
+    const int V = W.V, N = P + W.L;
+    const int32_t *vmap = vmap_all + (size_t) blk_win[blockIdx.x] * Vmax;
+    double *H = sys + W.sys_off, *b = H + (size_t) N * N;
+    double *Hs = sm, *bs = sm + (size_t) V * V;
+    const int t = threadIdx.x;
+    for (int e = t; e < V * V + V; e += NRM_BLOCK) sm[e] = 0.0;
+    __syncthreads();
+    const int f   = blk_first[blockIdx.x] + t;
+    const bool on = f < W.fac_end && (!active || active[f]);
+    double j0[19], j1[19];
+    int cc[19];
+    double r0 = 0.0, r1 = 0.0, jl0 = 0.0, jl1 = 0.0;
+    int lm = 0;
+    if (on) {
+        const double *Jf = J + 46 * (size_t) f;
+        r0 = r[2 * (size_t) f], r1 = r[2 * (size_t) f + 1];
+        const int ci = vcol_pose[idx_i[f]], cj = vcol_pose[idx_j[f]];
+#pragma unroll
+        for (int x = 0; x < 6; x++) {
+            j0[x] = Jf[x], j1[x] = Jf[7 + x], cc[x] = ci < 0 ? -1 : ci + x;
+            j0[6 + x] = Jf[14 + x], j1[6 + x] = Jf[21 + x], cc[6 + x] = cj < 0 ? -1 : cj + x;
+            j0[12 + x] = Jf[28 + x], j1[12 + x] = Jf[35 + x], cc[12 + x] = W.vcol_ext < 0 ? -1 : W.vcol_ext + x;
+        }
+        j0[18] = Jf[44], j1[18] = Jf[45], cc[18] = W.vcol_td;
+        jl0 = Jf[42], jl1 = Jf[43];
+        lm  = idx_lm[f] - W.lm_begin;
+    } else {
+#pragma unroll
+        for (int x = 0; x < 19; x++) j0[x] = j1[x] = 0.0, cc[x] = -1;
+    }
+#pragma unroll
+    for (int x = 0; x < 19; x++) {
+        if (cc[x] < 0) continue;
+#pragma unroll
+        for (int y = 0; y < 19; y++) {
+            if (x >= 12 && y >= 12) continue;
+            if (cc[y] < 0) continue;
+            atomicAdd(&Hs[cc[x] * V + cc[y]], j0[x] * j0[y] + j1[x] * j1[y]);
+        }
+        if (x < 12) atomicAdd(&bs[cc[x]], -(j0[x] * r0 + j1[x] * r1));
+    }
+#pragma unroll
+    for (int x = 12; x < 19; x++) {
+#pragma unroll
+        for (int y = 12; y < 20; y++) {
+            double v = (y < 19) ? j0[x] * j0[y] + j1[x] * j1[y] : -(j0[x] * r0 + j1[x] * r1);
+            if (!on) v = 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if ((t & 63) == 0) {
+                const int cx = (x < 18) ? (W.vcol_ext < 0 ? -1 : W.vcol_ext + x - 12) : W.vcol_td;
+                const int cy = (y < 18) ? (W.vcol_ext < 0 ? -1 : W.vcol_ext + y - 12) : (y == 18 ? W.vcol_td : 0);
+                if (cx >= 0 && cy >= 0 && v != 0.0) {
+                    if (y < 19)
+                        atomicAdd(&Hs[cx * V + cy], v);
+                    else
+                        atomicAdd(&bs[cx], v);
+                }
+            }
+        }
+    }
+    if (on) {
+        double *row = H + (size_t) (P + lm) * N;
+#pragma unroll
+        for (int x = 0; x < 19; x++)
+            if (cc[x] >= 0) unsafeAtomicAdd(&row[vmap[cc[x]]], jl0 * j0[x] + jl1 * j1[x]);
+        unsafeAtomicAdd(&row[P + lm], jl0 * jl0 + jl1 * jl1);
+        unsafeAtomicAdd(&b[P + lm], -(jl0 * r0 + jl1 * r1));
+    }
+    __syncthreads();
+    for (int e = t; e < V * V; e += NRM_BLOCK) {
+        const double v = Hs[e];
+        if (v != 0.0) unsafeAtomicAdd(&H[(size_t) vmap[e / V] * N + vmap[e % V]], v);
+    }
+    for (int e = t; e < V; e += NRM_BLOCK) {
+        const double v = bs[e];
+        if (v != 0.0) unsafeAtomicAdd(&b[vmap[e]], v);
+    }
+}
+
+// zeroes the (H | b) part of every window that is re-assembled (one workgroup column per window)
+__global__ void k_sys_clear_w(const win_desc *wd, int P, double *sys) {
+    const win_desc W = wd[blockIdx.y];
+    if (!W.reassemble) return;
+    const size_t N = (size_t) P + W.L, total = N * N + N;
+    double *H = sys + W.sys_off;
+    for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t) gridDim.x * blockDim.x) H[e] = 0.0;
+}
+
+__global__ void k_schur_inv_w(const win_desc *wd, int P, double *sys, double min_diag, double max_diag) {
+    const win_desc W = wd[blockIdx.y];
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= W.L) return;
+    const int N = P + W.L;
+    const double *H = sys + W.sys_off;
+    double *inv = sys + W.sys_off + (size_t) N * N + N;
+    const double h = H[(size_t) (P + l) * N + P + l];
+    inv[l] = h > 0.0 ? 1.0 / (h + fmin(fmax(h, min_diag), max_diag) * W.damp) : 0.0;
+}
+
+__global__ __launch_bounds__(SCH_T *SCH_T) void k_schur_reduce_w(const win_desc *wd, int P, const double *sys, double *S, double *s, double *diag) {
+    __shared__ double gi[SCH_T][SCH_T + 1], gj[SCH_T][SCH_T + 1], w[SCH_T];
+    const win_desc W = wd[blockIdx.z];
+    const int L = W.L, N = P + L;
+    const double *H = sys + W.sys_off, *b = H + (size_t) N * N, *inv = b + N;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int i = blockIdx.y * SCH_T + ty, j = blockIdx.x * SCH_T + tx;
+    double acc = 0.0, accs = 0.0;
+    for (int l0 = 0; l0 < L; l0 += SCH_T) {
+        const int l  = l0 + ty;
+        const int ci = blockIdx.y * SCH_T + tx;
+        gi[ty][tx] = (l < L && ci < P) ? H[(size_t) (P + l) * N + ci] : 0.0;
+        gj[ty][tx] = (l < L && j < P) ? H[(size_t) (P + l) * N + j] : 0.0;
+        if (ty == 0) w[tx] = (l0 + tx < L) ? inv[l0 + tx] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCH_T; k++) {
+            acc += gi[k][ty] * w[k] * gj[k][tx];
+            if (blockIdx.x == 0 && tx == 0) accs += gi[k][ty] * w[k] * ((l0 + k < L) ? b[P + l0 + k] : 0.0);
+        }
+        __syncthreads();
+    }
+    double *Sw = S + (size_t) blockIdx.z * P * P;
+    if (i < P && j < P) Sw[(size_t) i * P + j] = H[(size_t) i * N + j] - acc;
+    if (blockIdx.x == 0 && tx == 0 && i < P) {
+        s[(size_t) blockIdx.z * P + i]    = b[i] - accs;
+        diag[(size_t) blockIdx.z * P + i] = H[(size_t) i * N + i];
+    }
+}
+
+// one wave per landmark (global index); terms[w][2] pre-zeroed
+__global__ __launch_bounds__(64) void k_schur_backsub_w(const win_desc *wd, const int32_t *lm_win, int P, const double *sys, const double *delta_c,
+                                                        double *delta_l, double *terms, double min_diag, double max_diag) {
+    const int lg = blockIdx.x, wi = lm_win[lg];
+    const win_desc W = wd[wi];
+    const int l = lg - W.lm_begin, N = P + W.L;
+    const double *H = sys + W.sys_off, *b = H + (size_t) N * N, *inv = b + N;
+    const double *dc = delta_c + (size_t) wi * P;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < P; i += 64) acc += H[(size_t) (P + l) * N + i] * dc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (threadIdx.x == 0) {
+        const double bl = b[P + l], wv = inv[l];
+        const double d  = (bl - acc) * wv;
+        delta_l[lg]     = d;
+        if (wv > 0.0) {
+            const double dl = fmin(fmax(H[(size_t) (P + l) * N + P + l], min_diag), max_diag) * W.damp;
+            unsafeAtomicAdd(&terms[2 * wi], bl * bl * wv);
+            unsafeAtomicAdd(&terms[2 * wi + 1], dl * d * d);
+        }
+    }
+}
+
+// grid (chunks, W): cost[w] += 0.5 sum rho over the window's active factors
+__global__ __launch_bounds__(256) void k_reproj_cost_w(const win_desc *wd, const double *r, const uint8_t *active, double huber, double *out) {
+    __shared__ double sh[4];
+    const win_desc W = wd[blockIdx.y];
+    double acc = 0.0;
+    for (int f = W.fac_begin + blockIdx.x * 256 + threadIdx.x; f < W.fac_end; f += gridDim.x * 256) {
+        if (active && !active[f]) continue;
+        const double r0 = r[2 * (size_t) f], r1 = r[2 * (size_t) f + 1];
+        double q = r0 * r0 + r1 * r1;
+        if (huber > 0.0 && q > huber * huber) q = 2.0 * q - huber * huber;
+        acc += 0.5 * q;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(&out[blockIdx.y], sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+extern "C" int icg_reproj_set_windows(icg_ctx *ctx, int n_windows, const int32_t *fac_off, const int32_t *lm_off) {
+    if (!ctx || n_windows <= 0 || !fac_off || !lm_off) return ICG_ERR_INVALID;
+    const int n = ctx->n_factors_resident;
+    if (fac_off[0] != 0 || fac_off[n_windows] != n) return icg_fail(ctx, ICG_ERR_INVALID, "fac_off must cover the %d resident factors", n);
+    for (int w = 0; w < n_windows; w++)
+        if (fac_off[w + 1] < fac_off[w] || lm_off[w + 1] < lm_off[w]) return icg_fail(ctx, ICG_ERR_INVALID, "window %d: offsets not monotone", w);
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const int n_lm = lm_off[n_windows];
+    if (n_lm > ctx->lmwin_cap) {
+        ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_lmwin) (void) hipFree(ctx->d_lmwin);
+        ctx->d_lmwin   = nullptr;
+        ctx->lmwin_cap = 0;
+        ICG_HIP(ctx, hipMalloc((void **) &ctx->d_lmwin, sizeof(int32_t) * (size_t) (n_lm + n_lm / 4 + 64)));
+        ctx->lmwin_cap = n_lm + n_lm / 4 + 64;
+    }
+    std::vector<int32_t> fwin((size_t) n), lwin((size_t) std::max(n_lm, 1));
+    for (int w = 0; w < n_windows; w++) {
+        for (int f = fac_off[w]; f < fac_off[w + 1]; f++) fwin[(size_t) f] = w;
+        for (int l = lm_off[w]; l < lm_off[w + 1]; l++) lwin[(size_t) l] = w;
+    }
+    if (n) ICG_HIP(ctx, hipMemcpyAsync(ctx->d_fwin, fwin.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+    if (n_lm) ICG_HIP(ctx, hipMemcpyAsync(ctx->d_lmwin, lwin.data(), sizeof(int32_t) * (size_t) n_lm, hipMemcpyHostToDevice, ctx->stream));
+    ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // pose -> window from the resident index arrays (one read-back per partition)
+    std::vector<int32_t> h_idx((size_t) 2 * std::max(n, 1));
+    if (n) {
+        ICG_HIP(ctx, hipMemcpyAsync(h_idx.data(), ctx->d_fidx, sizeof(int32_t) * 2 * (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+        ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    int max_pose = -1;
+    for (int f = 0; f < 2 * n; f++) max_pose = std::max(max_pose, (int) h_idx[(size_t) f]);
+    ctx->w_pose_win.assign((size_t) (max_pose + 1), -1);
+    for (int w = 0; w < n_windows; w++)
+        for (int f = fac_off[w]; f < fac_off[w + 1]; f++) {
+            for (int side = 0; side < 2; side++) {
+                int32_t &pw = ctx->w_pose_win[(size_t) h_idx[(size_t) side * n + f]];
+                if (pw >= 0 && pw != w) return icg_fail(ctx, ICG_ERR_INVALID, "pose %d is used by windows %d and %d", (int) h_idx[(size_t) side * n + f], pw, w);
+                pw = w;
+            }
+        }
+    ctx->n_windows = n_windows;
+    ctx->w_fac_off.assign(fac_off, fac_off + n_windows + 1);
+    ctx->w_lm_off.assign(lm_off, lm_off + n_windows + 1);
+    ctx->wsys_valid = 0;
+    return ICG_OK;
+}
+
+extern "C" int icg_reproj_eval_windows(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm, const double *invdepth,
+                                       const double *td, int want_jac, double huber_delta) {
+    if (!ctx || !poses || !ext || !invdepth || !td || n_poses <= 0 || n_lm <= 0) return ICG_ERR_INVALID;
+    if (ctx->n_windows <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition: call icg_reproj_set_windows first");
+    if (n_lm != ctx->w_lm_off[(size_t) ctx->n_windows]) return icg_fail(ctx, ICG_ERR_INVALID, "n_lm does not match the window partition");
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const int n = ctx->n_factors_resident, W = ctx->n_windows;
+    if (n == 0) return ICG_OK;
+    icg_call c(ctx);
+    int rc = c.reserve(sizeof(double) * ((size_t) n_poses * 7 + 8 * (size_t) W + (size_t) n_lm) + 4096);
+    if (rc) return rc;
+    rpj_args A;
+    A.n           = n;
+    A.obs         = ctx->d_obs;
+    A.idx_i       = ctx->d_fidx;
+    A.idx_j       = ctx->d_fidx + n;
+    A.idx_lm      = ctx->d_fidx + 2 * (size_t) n;
+    A.poses       = c.in(poses, 7 * (size_t) n_poses);
+    A.ext         = c.in(ext, 7 * (size_t) W);
+    A.invdepth    = c.in(invdepth, (size_t) n_lm);
+    A.tdv         = c.in(td, (size_t) W);
+    A.td          = 0.0;
+    A.win         = ctx->d_fwin;
+    A.want_jac    = want_jac;
+    A.huber_delta = huber_delta;
+    A.out_r       = ctx->d_rJ;
+    A.out_J       = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
+    if ((rc = c.seal())) return rc;
+    {
+        icg_prof_scope ps(ctx, "reproj_eval");
+        hipLaunchKernelGGL(k_reproj_eval, dim3((n + RPJ_TILE - 1) / RPJ_TILE), dim3(RPJ_TILE), 0, ctx->stream, A);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    ctx->rJ_valid     = 1;
+    ctx->rJ_has_jac   = want_jac;
+    ctx->last_huber   = huber_delta;
+    ctx->last_n_poses = n_poses;
+    ctx->last_n_lm    = n_lm;
+    return c.finish();
+}
+
+// builds the per-window descriptors (host) for the current partition; reassemble / damp may be null (all re-assembled / keep damping)
+static void build_win_desc(icg_ctx *ctx, int P, const int32_t *vcol_ext, const int32_t *vcol_td, const int32_t *V, const uint8_t *reassemble,
+                           const double *damp, std::vector<win_desc> &out) {
+    const int W = ctx->n_windows;
+    out.resize((size_t) W);
+    for (int w = 0; w < W; w++) {
+        win_desc &d = out[(size_t) w];
+        d.fac_begin = ctx->w_fac_off[(size_t) w], d.fac_end = ctx->w_fac_off[(size_t) w + 1];
+        d.lm_begin = ctx->w_lm_off[(size_t) w], d.L = ctx->w_lm_off[(size_t) w + 1] - ctx->w_lm_off[(size_t) w];
+        d.sys_off    = ctx->w_sys_off[(size_t) w];
+        d.vcol_ext   = vcol_ext ? vcol_ext[w] : -1;
+        d.vcol_td    = vcol_td ? vcol_td[w] : -1;
+        d.V          = V ? V[w] : 0;
+        d.reassemble = reassemble ? reassemble[w] : 1;
+        d.damp       = damp ? damp[w] : ctx->w_damp[(size_t) w];
+    }
+}
+
+extern "C" int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td,
+                                        const uint8_t *active, const uint8_t *reassemble, const double *damp, double min_diag, double max_diag,
+                                        double *S, double *s, double *diag_cc, double *cost) {
+    if (!ctx || P <= 0 || !col_pose || !col_ext || !col_td || !reassemble || !damp || !S || !s) return ICG_ERR_INVALID;
+    const int W = ctx->n_windows, n = ctx->n_factors_resident;
+    if (W <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition: call icg_reproj_set_windows first");
+    bool any_new = false;
+    for (int w = 0; w < W; w++) any_new |= reassemble[w] != 0;
+    if (any_new && (!ctx->rJ_valid || !ctx->rJ_has_jac)) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Jacobians: call icg_reproj_eval_windows first");
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    // system layout
+    if (!ctx->wsys_valid || ctx->wsys_P != P) {
+        for (int w = 0; w < W; w++)
+            if (!reassemble[w]) return icg_fail(ctx, ICG_ERR_INVALID, "window %d: nothing resident to re-damp", w);
+        ctx->w_sys_off.assign((size_t) W + 1, 0);
+        for (int w = 0; w < W; w++) {
+            const int64_t N = P + (ctx->w_lm_off[(size_t) w + 1] - ctx->w_lm_off[(size_t) w]);
+            ctx->w_sys_off[(size_t) w + 1] = ctx->w_sys_off[(size_t) w] + N * N + N + (N - P);
+        }
+        ctx->w_damp.assign((size_t) W, 0.0);
+    }
+    int rc = ensure_sys_capacity(ctx, (size_t) ctx->w_sys_off[(size_t) W] + 8);
+    if (rc) return rc;
+    // compact camera space per window (free poses in pose order, then ext, then td)
+    std::vector<int32_t> vcol_pose((size_t) ctx->last_n_poses, -1), Vw((size_t) W, 0), vce((size_t) W, -1), vct((size_t) W, -1);
+    std::vector<std::vector<int32_t>> vmaps((size_t) W);
+    // window of every pose (recorded at icg_reproj_set_windows from the resident index arrays): a pose column is compact within
+    // the window whose factors use the pose
+    std::vector<int32_t> pose_win((size_t) ctx->last_n_poses, -1);
+    for (int k = 0; k < ctx->last_n_poses && k < (int) ctx->w_pose_win.size(); k++) pose_win[(size_t) k] = ctx->w_pose_win[(size_t) k];
+    for (int k = 0; k < ctx->last_n_poses; k++) {
+        const int w = pose_win[(size_t) k];
+        if (w < 0 || col_pose[k] < 0) continue;
+        if (col_pose[k] + 6 > P) return icg_fail(ctx, ICG_ERR_INVALID, "pose %d: column %d outside the reduced system (%d)", k, col_pose[k], P);
+        vcol_pose[(size_t) k] = (int32_t) vmaps[(size_t) w].size();
+        for (int x = 0; x < 6; x++) vmaps[(size_t) w].push_back(col_pose[k] + x);
+    }
+    int Vmax = 1;
+    for (int w = 0; w < W; w++) {
+        if ((col_ext[w] >= 0 && col_ext[w] + 6 > P) || (col_td[w] >= 0 && col_td[w] + 1 > P))
+            return icg_fail(ctx, ICG_ERR_INVALID, "window %d: ext/td column outside the reduced system", w);
+        if (col_ext[w] >= 0) {
+            vce[(size_t) w] = (int32_t) vmaps[(size_t) w].size();
+            for (int x = 0; x < 6; x++) vmaps[(size_t) w].push_back(col_ext[w] + x);
+        }
+        if (col_td[w] >= 0) {
+            vct[(size_t) w] = (int32_t) vmaps[(size_t) w].size();
+            vmaps[(size_t) w].push_back(col_td[w]);
+        }
+        Vw[(size_t) w] = (int32_t) vmaps[(size_t) w].size();
+        Vmax           = std::max(Vmax, (int) Vw[(size_t) w]);
+    }
+    const size_t lds = sizeof(double) * ((size_t) Vmax * Vmax + Vmax);
+    if (lds > 60 * 1024) return icg_fail(ctx, ICG_ERR_CAPACITY, "a window has %d free camera columns: more than the LDS tile of the batched assembly holds", Vmax);
+    std::vector<int32_t> vmap_all((size_t) W * Vmax, 0);
+    for (int w = 0; w < W; w++) std::copy(vmaps[(size_t) w].begin(), vmaps[(size_t) w].end(), vmap_all.begin() + (size_t) w * Vmax);
+    for (int w = 0; w < W; w++)
+        if (reassemble[w] || damp[w] != ctx->w_damp[(size_t) w]) ctx->w_damp[(size_t) w] = damp[w];
+    std::vector<win_desc> wd;
+    build_win_desc(ctx, P, vce.data(), vct.data(), Vw.data(), reassemble, damp, wd);
+    // block tables of the assembly launch
+    std::vector<int32_t> blk_win, blk_first;
+    int Lmax = 1;
+    for (int w = 0; w < W; w++) {
+        Lmax = std::max(Lmax, (int) wd[(size_t) w].L);
+        if (!reassemble[w]) continue;
+        for (int f = wd[(size_t) w].fac_begin; f < wd[(size_t) w].fac_end; f += NRM_BLOCK) {
+            blk_win.push_back(w);
+            blk_first.push_back(f);
+        }
+    }
+    icg_call c(ctx);
+    rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(int32_t) * (vcol_pose.size() + vmap_all.size() + 2 * blk_win.size() + 16) + (size_t) n +
+                   sizeof(double) * ((size_t) W * ((size_t) P * P + 2 * (size_t) P + 1)) + 8192);
+    if (rc) return rc;
+    const win_desc *d_wd  = c.in(wd.data(), (size_t) W);
+    const int32_t *d_vp   = c.in(vcol_pose.data(), vcol_pose.size());
+    const int32_t *d_vm   = c.in(vmap_all.data(), vmap_all.size());
+    const int32_t *d_bw   = blk_win.empty() ? nullptr : c.in(blk_win.data(), blk_win.size());
+    const int32_t *d_bf   = blk_first.empty() ? nullptr : c.in(blk_first.data(), blk_first.size());
+    const uint8_t *d_act  = active ? c.in(active, (size_t) n) : nullptr;
+    std::vector<double> zeros((size_t) W, 0.0);
+    double *d_cost = c.inout(zeros.data(), any_new ? cost : (double *) nullptr, (size_t) W);
+    if ((rc = c.seal())) return rc;
+    double *d_S  = c.out(S, (size_t) W * P * P);
+    double *d_s  = c.out(s, (size_t) W * P);
+    double *d_dg = c.out(diag_cc, (size_t) W * P);
+    const double *d_r = ctx->d_rJ, *d_J = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
+    if (any_new) {
+        icg_prof_scope ps(ctx, "reproj_normal");
+        hipLaunchKernelGGL(k_sys_clear_w, dim3(32, W), dim3(256), 0, ctx->stream, d_wd, P, ctx->d_sys);
+        hipLaunchKernelGGL(k_reproj_normal_schur_w, dim3((unsigned) blk_win.size()), dim3(NRM_BLOCK), lds, ctx->stream, d_wd, d_bw, d_bf, d_r, d_J,
+                           (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n), (const int32_t *) (ctx->d_fidx + 2 * (size_t) n), d_vp,
+                           d_vm, Vmax, P, ctx->d_sys, d_act);
+    }
+    {
+        icg_prof_scope ps(ctx, "schur_reduce");
+        hipLaunchKernelGGL(k_schur_inv_w, dim3((Lmax + 255) / 256, W), dim3(256), 0, ctx->stream, d_wd, P, ctx->d_sys, min_diag, max_diag);
+        hipLaunchKernelGGL(k_schur_reduce_w, dim3((P + SCH_T - 1) / SCH_T, (P + SCH_T - 1) / SCH_T, W), dim3(SCH_T, SCH_T), 0, ctx->stream, d_wd, P,
+                           (const double *) ctx->d_sys, d_S, d_s, d_dg);
+        if (any_new) {
+            // cost only of the windows that were re-assembled is meaningful; the others keep their previous value on the host side
+            hipLaunchKernelGGL(k_reproj_cost_w, dim3(4, W), dim3(256), 0, ctx->stream, d_wd, d_r, d_act, ctx->last_huber, d_cost);
+        }
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    if ((rc = c.finish())) return rc;
+    ctx->wsys_P = P, ctx->wsys_valid = 1;
+    ctx->sys_min_diag = min_diag, ctx->sys_max_diag = max_diag;
+    return ICG_OK;
+}
+
+extern "C" int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
+    if (!ctx || !delta_c || !delta_l) return ICG_ERR_INVALID;
+    if (!ctx->wsys_valid || ctx->wsys_P != P) return icg_fail(ctx, ICG_ERR_INVALID, "no resident window systems of size %d: call icg_reproj_schur_windows first", P);
+    const int W = ctx->n_windows, n_lm = ctx->w_lm_off[(size_t) W];
+    if (n_lm == 0) return ICG_OK;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    std::vector<win_desc> wd;
+    build_win_desc(ctx, P, nullptr, nullptr, nullptr, nullptr, nullptr, wd);
+    icg_call c(ctx);
+    int rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(double) * ((size_t) W * P + (size_t) n_lm + 2 * (size_t) W) + 4096);
+    if (rc) return rc;
+    const win_desc *d_wd = c.in(wd.data(), (size_t) W);
+    const double *d_dc   = c.in(delta_c, (size_t) W * P);
+    std::vector<double> zeros(2 * (size_t) W, 0.0);
+    double *d_tm = c.inout(zeros.data(), lm_terms, 2 * (size_t) W);
+    if ((rc = c.seal())) return rc;
+    double *d_dl = c.out(delta_l, (size_t) n_lm);
+    {
+        icg_prof_scope ps(ctx, "schur_backsub");
+        hipLaunchKernelGGL(k_schur_backsub_w, dim3(n_lm), dim3(64), 0, ctx->stream, d_wd, (const int32_t *) ctx->d_lmwin, P, (const double *) ctx->d_sys, d_dc,
+                           d_dl, d_tm, ctx->sys_min_diag, ctx->sys_max_diag);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}
+
+extern "C" int icg_reproj_cost_windows(icg_ctx *ctx, const uint8_t *active, double *cost) {
+    if (!ctx || !cost) return ICG_ERR_INVALID;
+    if (!ctx->rJ_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident residuals: call icg_reproj_eval_windows first");
+    const int W = ctx->n_windows, n = ctx->n_factors_resident;
+    if (W <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition");
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (ctx->w_sys_off.size() != (size_t) W + 1) ctx->w_sys_off.assign((size_t) W + 1, 0);
+    if (ctx->w_damp.size() != (size_t) W) ctx->w_damp.assign((size_t) W, 0.0);
+    std::vector<win_desc> wd;
+    build_win_desc(ctx, 0, nullptr, nullptr, nullptr, nullptr, nullptr, wd);
+    icg_call c(ctx);
+    int rc = c.reserve(sizeof(win_desc) * (size_t) W + (size_t) n + sizeof(double) * (size_t) W + 4096);
+    if (rc) return rc;
+    const win_desc *d_wd = c.in(wd.data(), (size_t) W);
+    const uint8_t *d_act = active ? c.in(active, (size_t) n) : nullptr;
+    std::vector<double> zeros((size_t) W, 0.0);
+    double *d_cost = c.inout(zeros.data(), cost, (size_t) W);
+    if ((rc = c.seal())) return rc;
+    {
+        icg_prof_scope ps(ctx, "reproj_cost");
+        hipLaunchKernelGGL(k_reproj_cost_w, dim3(4, W), dim3(256), 0, ctx->stream, d_wd, (const double *) ctx->d_rJ, d_act, ctx->last_huber, d_cost);
     }
     ICG_HIP(ctx, hipGetLastError());
     return c.finish();

@@ -19,7 +19,8 @@ EXPORTS = [
     "icg_predict_rotation", "icg_fm_ransac", "icg_detect", "icg_triangulate", "icg_reproj_eval_batch",
     "icg_reproj_set_factors", "icg_reproj_eval_resident", "icg_reproj_accumulate_normal", "icg_preint_batch",
     "icg_ins_mechanize_batch", "icg_ins_camera_pose_batch", "icg_reproj_schur", "icg_reproj_backsub", "icg_reproj_cost",
-    "icg_reproj_error_batch",
+    "icg_reproj_error_batch", "icg_reproj_set_windows", "icg_reproj_eval_windows", "icg_reproj_schur_windows",
+    "icg_reproj_backsub_windows", "icg_reproj_cost_windows",
 ]
 
 
@@ -335,6 +336,39 @@ class Context:
         act = None if active is None else np.ascontiguousarray(active, np.uint8)
         self._ck(self.lib.icg_reproj_cost(self.h, _p(act), _p(cost)), "icg_reproj_cost")
         return float(cost[0])
+
+    # ---- f1, many windows per launch
+    def reproj_set_windows(self, fac_off, lm_off):
+        fac_off, lm_off = _i32(fac_off), _i32(lm_off)
+        self._nwin = len(fac_off) - 1
+        self._ck(self.lib.icg_reproj_set_windows(self.h, self._nwin, _p(fac_off), _p(lm_off)), "icg_reproj_set_windows")
+
+    def reproj_eval_windows(self, poses, ext, invdepth, td, want_jac=True, huber=0.0):
+        poses, ext, invdepth, td = _f64(poses).reshape(-1, 7), _f64(ext).reshape(-1, 7), _f64(invdepth).reshape(-1), _f64(td).reshape(-1)
+        self._ck(self.lib.icg_reproj_eval_windows(self.h, poses.shape[0], _p(poses), _p(ext), invdepth.shape[0], _p(invdepth), _p(td),
+                                                   1 if want_jac else 0, C.c_double(huber)), "icg_reproj_eval_windows")
+
+    def reproj_schur_windows(self, P, col_pose, col_ext, col_td, active=None, reassemble=None, damp=None, min_diag=1e-6, max_diag=1e32):
+        W = self._nwin
+        S, s, dg, cost = np.zeros((W, P, P)), np.zeros((W, P)), np.zeros((W, P)), np.zeros(W)
+        act = None if active is None else np.ascontiguousarray(active, np.uint8)
+        re = np.ones(W, np.uint8) if reassemble is None else np.ascontiguousarray(reassemble, np.uint8)
+        dm = np.zeros(W) if damp is None else _f64(damp)
+        self._ck(self.lib.icg_reproj_schur_windows(self.h, int(P), _p(_i32(col_pose)), _p(_i32(col_ext)), _p(_i32(col_td)), _p(act), _p(re), _p(dm),
+                                                    C.c_double(min_diag), C.c_double(max_diag), _p(S), _p(s), _p(dg), _p(cost)),
+                 "icg_reproj_schur_windows")
+        return S, s, dg, cost
+
+    def reproj_backsub_windows(self, P, delta_c, n_lm):
+        out, terms = np.zeros(n_lm), np.zeros((self._nwin, 2))
+        self._ck(self.lib.icg_reproj_backsub_windows(self.h, int(P), _p(_f64(delta_c)), _p(out), _p(terms)), "icg_reproj_backsub_windows")
+        return out, terms
+
+    def reproj_cost_windows(self, active=None):
+        cost = np.zeros(self._nwin)
+        act = None if active is None else np.ascontiguousarray(active, np.uint8)
+        self._ck(self.lib.icg_reproj_cost_windows(self.h, _p(act), _p(cost)), "icg_reproj_cost_windows")
+        return cost
 
     # ---- P1
     def preint_batch(self, variant, offsets, imu, state0, params):

@@ -196,6 +196,24 @@ int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, int32_t col_e
 int icg_reproj_backsub(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms);
 int icg_reproj_cost(icg_ctx *ctx, const uint8_t *active, double *cost);
 
+/* f1, many windows per launch: the windows of many camera streams advance through their LM steps together, ONE evaluation / assembly /
+ * reduction / back-substitution launch per step for all of them (a solver per stream is bounded by the runtime's launch rate).
+ * icg_reproj_set_windows partitions the resident factor set: factors [fac_off[w], fac_off[w+1]) and landmarks [lm_off[w], lm_off[w+1])
+ * belong to window w (factors sorted by window, landmarks contiguous per window, every pose used by one window only; poses and
+ * landmarks keep their global indices).  The *_windows calls mirror icg_reproj_eval_resident / _schur / _backsub / _cost with one
+ * extrinsic (ext: W x 7) and td per window, one reduced system of the common size P per window (S: W x P x P, s / diag_cc: W x P; a
+ * window simply leaves the columns it does not use empty), per-window damping and per-window reassemble flags (0 = keep the window's
+ * resident H, b and only apply the new damping).  cost (W) is written for the re-assembled windows only (0 elsewhere); lm_terms is
+ * W x 2.  col_pose[k] is the column of pose k INSIDE its window's system. */
+int icg_reproj_set_windows(icg_ctx *ctx, int n_windows, const int32_t *fac_off, const int32_t *lm_off);
+int icg_reproj_eval_windows(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm, const double *invdepth,
+                            const double *td, int want_jac, double huber_delta);
+int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
+                             const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, double *S, double *s,
+                             double *diag_cc, double *cost);
+int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms);
+int icg_reproj_cost_windows(icg_ctx *ctx, const uint8_t *active, double *cost);
+
 /* ---- P1: preintegration inner loop (preintegration/preintegration_base.cc:39-70, preintegration_earth.cc:205-303,
  * preintegration_normal.cc:183-232), batched over independent intervals.
  * imu: total x 8 doubles (time, dt, dtheta[3], dvel[3]); interval s owns samples [offsets[s], offsets[s+1]) with

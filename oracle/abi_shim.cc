@@ -256,6 +256,12 @@ struct shim_backend {
     int P = 0;
     std::vector<double> H, b, inv;
     double damp = 0, min_diag = 0, max_diag = 0;
+    // many windows per launch
+    int W = 0;
+    std::vector<int32_t> fac_off, lm_off;
+    std::vector<std::vector<double>> wH, wb, winv;
+    std::vector<double> wdamp;
+    int wP = 0;
 };
 std::unordered_map<icg_ctx *, shim_backend> g_backend_map;
 std::mutex g_backend_mutex;
@@ -345,6 +351,95 @@ int icg_reproj_backsub(icg_ctx *ctx, int P, const double *delta_c, double *delta
 int icg_reproj_cost(icg_ctx *ctx, const uint8_t *active, double *cost) {
     shim_backend &B = g_backend[ctx];
     *cost = orc_reproj_cost(B.n, B.r.data(), active, B.huber);
+    return ICG_OK;
+}
+
+int icg_reproj_set_windows(icg_ctx *ctx, int n_windows, const int32_t *fac_off, const int32_t *lm_off) {
+    shim_backend &B = g_backend[ctx];
+    if (fac_off[0] != 0 || fac_off[n_windows] != B.n) return ICG_ERR_INVALID;
+    B.W = n_windows;
+    B.fac_off.assign(fac_off, fac_off + n_windows + 1);
+    B.lm_off.assign(lm_off, lm_off + n_windows + 1);
+    B.wH.assign((size_t) n_windows, {}), B.wb.assign((size_t) n_windows, {}), B.winv.assign((size_t) n_windows, {});
+    B.wdamp.assign((size_t) n_windows, 0.0);
+    B.wP = 0;
+    return ICG_OK;
+}
+
+int icg_reproj_eval_windows(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm, const double *invdepth, const double *td,
+                            int want_jac, double huber_delta) {
+    shim_backend &B = g_backend[ctx];
+    if (B.W <= 0) return ICG_ERR_INVALID;
+    B.n_poses = n_poses, B.n_lm = n_lm, B.huber = huber_delta;
+    B.r.assign(2 * (size_t) B.n, 0.0);
+    B.J.assign(46 * (size_t) B.n, 0.0);
+    for (int w = 0; w < B.W; w++) {
+        const int f0 = B.fac_off[(size_t) w], nf = B.fac_off[(size_t) w + 1] - f0;
+        if (nf == 0) continue;
+        std::vector<double> obs(15 * (size_t) nf); // the component-major slab of this window
+        for (int c = 0; c < 15; c++) memcpy(&obs[(size_t) c * nf], &B.obs[(size_t) c * B.n + f0], sizeof(double) * (size_t) nf);
+        orc_reproj_eval_batch(nf, obs.data(), &B.ii[(size_t) f0], &B.jj[(size_t) f0], &B.ll[(size_t) f0], poses, ext + 7 * (size_t) w, invdepth, td[w],
+                              want_jac, &B.r[2 * (size_t) f0], &B.J[46 * (size_t) f0]);
+        if (huber_delta > 0) orc_huber_correct_2x46(nf, huber_delta, &B.r[2 * (size_t) f0], want_jac ? &B.J[46 * (size_t) f0] : nullptr);
+    }
+    return ICG_OK;
+}
+
+int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
+                             const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, double *S, double *s, double *diag_cc,
+                             double *cost) {
+    shim_backend &B = g_backend[ctx];
+    if (B.W <= 0) return ICG_ERR_INVALID;
+    if (B.wP != P)
+        for (int w = 0; w < B.W; w++)
+            if (!reassemble[w]) return ICG_ERR_INVALID;
+    B.wP = P, B.min_diag = min_diag, B.max_diag = max_diag;
+    for (int w = 0; w < B.W; w++) {
+        const int f0 = B.fac_off[(size_t) w], f1 = B.fac_off[(size_t) w + 1], l0 = B.lm_off[(size_t) w], L = B.lm_off[(size_t) w + 1] - l0;
+        const size_t N = (size_t) P + L;
+        if (cost) cost[w] = 0.0;
+        if (reassemble[w]) {
+            std::vector<int32_t> ii, jj, ll, col_lm((size_t) B.n_lm, -1);
+            std::vector<double> r, J;
+            for (int l = 0; l < L; l++) col_lm[(size_t) (l0 + l)] = P + l;
+            for (int f = f0; f < f1; f++) {
+                if (active && !active[f]) continue;
+                ii.push_back(B.ii[(size_t) f]), jj.push_back(B.jj[(size_t) f]), ll.push_back(B.ll[(size_t) f]);
+                r.insert(r.end(), B.r.begin() + 2 * (size_t) f, B.r.begin() + 2 * (size_t) f + 2);
+                J.insert(J.end(), B.J.begin() + 46 * (size_t) f, B.J.begin() + 46 * (size_t) f + 46);
+            }
+            B.wH[(size_t) w].assign(N * N, 0.0);
+            B.wb[(size_t) w].assign(N, 0.0);
+            B.winv[(size_t) w].assign((size_t) L, 0.0);
+            orc_reproj_accumulate_normal((int) ii.size(), r.data(), J.data(), ii.data(), jj.data(), ll.data(), col_pose, col_ext[w], col_lm.data(),
+                                         col_td[w], (int) N, B.wH[(size_t) w].data(), B.wb[(size_t) w].data());
+            if (cost) cost[w] = orc_reproj_cost(f1 - f0, &B.r[2 * (size_t) f0], active ? active + f0 : nullptr, B.huber);
+        }
+        B.wdamp[(size_t) w] = damp[w];
+        orc_schur_reduce(P, L, B.wH[(size_t) w].data(), B.wb[(size_t) w].data(), damp[w], min_diag, max_diag, S + (size_t) w * P * P, s + (size_t) w * P,
+                         diag_cc ? diag_cc + (size_t) w * P : nullptr, B.winv[(size_t) w].data());
+    }
+    return ICG_OK;
+}
+
+int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
+    shim_backend &B = g_backend[ctx];
+    if (B.W <= 0 || B.wP != P) return ICG_ERR_INVALID;
+    for (int w = 0; w < B.W; w++) {
+        const int l0 = B.lm_off[(size_t) w], L = B.lm_off[(size_t) w + 1] - l0;
+        orc_schur_backsub(P, L, B.wH[(size_t) w].data(), B.wb[(size_t) w].data(), B.winv[(size_t) w].data(), B.wdamp[(size_t) w], B.min_diag, B.max_diag,
+                          delta_c + (size_t) w * P, delta_l + l0, lm_terms ? lm_terms + 2 * (size_t) w : nullptr);
+    }
+    return ICG_OK;
+}
+
+int icg_reproj_cost_windows(icg_ctx *ctx, const uint8_t *active, double *cost) {
+    shim_backend &B = g_backend[ctx];
+    if (B.W <= 0) return ICG_ERR_INVALID;
+    for (int w = 0; w < B.W; w++) {
+        const int f0 = B.fac_off[(size_t) w], f1 = B.fac_off[(size_t) w + 1];
+        cost[w] = orc_reproj_cost(f1 - f0, &B.r[2 * (size_t) f0], active ? active + f0 : nullptr, B.huber);
+    }
     return ICG_OK;
 }
 

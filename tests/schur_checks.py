@@ -89,3 +89,97 @@ def check_schur(ctx, oracle, tol=1e-9):
         ctx.reproj_eval_resident(w2["poses"], w2["ext"], w2["invdepth"], w2["td"], want_jac=False, huber=huber, fetch=False)
         _, _, cost2 = full_system(oracle, w2, col_pose, col_ext, col_td, P, huber, active)
         assert abs(ctx.reproj_cost(active) - cost2) < tol * max(1.0, cost2)
+
+
+def check_schur_windows(make_ctx, tol=1e-9):
+    """the many-windows-per-launch entry points against per-window calls of the single-window entry points on the same library
+    (those are checked against numpy above): different window sizes, per-window extrinsic / td, constant blocks, a factor mask, a
+    second call that re-damps some windows and re-assembles the others at a new linearization point"""
+    rng = np.random.RandomState(7)
+    specs = [(40, 5), (90, 8), (60, 6), (25, 4), (75, 7)]
+    wins = []
+    for k, (n_lm, n_kf) in enumerate(specs):
+        w = rd.make_window(n_lm, n_kf, seed=20 + k, pixel_noise=2.0)
+        w["invdepth"] = w["invdepth"] * (1 + rng.normal(0, 0.2, n_lm))
+        w["ext"] = rd.pose_plus(w["ext"], rng.normal(0, [0.01] * 3 + [0.005] * 3))
+        w["td"] = 0.003 + 0.001 * k
+        wins.append(w)
+    W = len(wins)
+    pose_off = np.concatenate([[0], np.cumsum([w["poses"].shape[0] for w in wins])])
+    lm_off = np.concatenate([[0], np.cumsum([len(w["invdepth"]) for w in wins])]).astype(np.int32)
+    fac_off = np.concatenate([[0], np.cumsum([w["obs_soa"].shape[1] for w in wins])]).astype(np.int32)
+    obs = np.concatenate([w["obs_soa"] for w in wins], axis=1)
+    ii = np.concatenate([w["idx_i"] + pose_off[k] for k, w in enumerate(wins)]).astype(np.int32)
+    jj = np.concatenate([w["idx_j"] + pose_off[k] for k, w in enumerate(wins)]).astype(np.int32)
+    ll = np.concatenate([w["idx_lm"] + lm_off[k] for k, w in enumerate(wins)]).astype(np.int32)
+    poses = np.concatenate([w["poses"] for w in wins])
+    ext = np.stack([w["ext"] for w in wins])
+    inv = np.concatenate([w["invdepth"] for w in wins])
+    td = np.array([w["td"] for w in wins])
+    n = obs.shape[1]
+    # columns: window k keeps pose 0 constant when k is odd, ext constant when k % 3 == 0, td constant when k % 2 == 0
+    col_pose, col_ext, col_td, Pw = np.full(len(poses), -1, np.int32), np.full(W, -1, np.int32), np.full(W, -1, np.int32), []
+    for k, w in enumerate(wins):
+        c = 0
+        for p in range(w["poses"].shape[0]):
+            if p == 0 and k % 2 == 1:
+                continue
+            col_pose[pose_off[k] + p] = c
+            c += 6
+        if k % 3 != 0:
+            col_ext[k] = c
+            c += 6
+        if k % 2 != 0:
+            col_td[k] = c
+            c += 1
+        Pw.append(c)
+    P = max(Pw) + 2
+    active = (rng.uniform(0, 1, n) > 0.15).astype(np.uint8)
+    huber = 1.0
+    damp1 = np.array([1e-4, 0.0, 1e-3, 1e-4, 1e-2])
+
+    def single(k, poses_k, ext_k, inv_k, td_k, damp, reassemble_ctx=None):
+        ctx = reassemble_ctx or make_ctx()
+        w = wins[k]
+        if reassemble_ctx is None:
+            ctx.reproj_set_factors(w["obs_soa"], w["idx_i"], w["idx_j"], w["idx_lm"])
+        ctx.reproj_eval_resident(poses_k, ext_k, inv_k, td_k, huber=huber, fetch=False)
+        cp = col_pose[pose_off[k]:pose_off[k + 1]]
+        S, s, dg, cost = ctx.reproj_schur(P, cp, col_ext[k], col_td[k], active=active[fac_off[k]:fac_off[k + 1]], damp=damp)
+        return ctx, S, s, dg, cost
+
+    ctxb = make_ctx()
+    ctxb.reproj_set_factors(obs, ii, jj, ll)
+    ctxb.reproj_set_windows(fac_off, lm_off)
+    ctxb.reproj_eval_windows(poses, ext, inv, td, huber=huber)
+    S, s, dg, cost = ctxb.reproj_schur_windows(P, col_pose, col_ext, col_td, active=active, damp=damp1)
+    dc = rng.normal(0, 1e-3, (W, P))
+    dl, terms = ctxb.reproj_backsub_windows(P, dc, len(inv))
+    singles = []
+    for k in range(W):
+        c1, S1, s1, dg1, cost1 = single(k, wins[k]["poses"], wins[k]["ext"], wins[k]["invdepth"], wins[k]["td"], damp1[k])
+        sc = max(1.0, np.abs(S1).max())
+        assert np.abs(S[k] - S1).max() < tol * sc and np.abs(s[k] - s1).max() < tol * max(1.0, np.abs(s1).max()), k
+        assert np.abs(dg[k] - dg1).max() < tol * sc and abs(cost[k] - cost1) < tol * max(1.0, cost1), k
+        dl1, t1 = c1.reproj_backsub(P, dc[k], len(wins[k]["invdepth"]))
+        assert np.abs(dl[lm_off[k]:lm_off[k + 1]] - dl1).max() < tol * max(1e-12, np.abs(dl1).max()), k
+        assert np.abs(terms[k] - t1).max() < tol * max(1.0, np.abs(t1).max()), k
+        singles.append(c1)
+    # second round: windows 0 and 3 only get a new damping (rejected step), the others are re-linearized at a moved point
+    re = np.array([0, 1, 1, 0, 1], np.uint8)
+    damp2 = damp1 * np.array([4.0, 1.0, 0.5, 8.0, 1.0]) + np.array([0, 1e-5, 0, 0, 0])
+    inv2 = inv * (1 + 0.01 * rng.normal(0, 1, len(inv)))
+    ctxb.reproj_eval_windows(poses, ext, inv2, td, huber=huber)
+    costs_now = ctxb.reproj_cost_windows(active)
+    S2, s2, dg2, cost2 = ctxb.reproj_schur_windows(P, col_pose, col_ext, col_td, active=active, reassemble=re, damp=damp2)
+    for k in range(W):
+        cp = col_pose[pose_off[k]:pose_off[k + 1]]
+        if re[k]:
+            _, S1, s1, dg1, cost1 = single(k, wins[k]["poses"], wins[k]["ext"], inv2[lm_off[k]:lm_off[k + 1]], wins[k]["td"], damp2[k], singles[k])
+            assert abs(cost2[k] - cost1) < tol * max(1.0, cost1) and abs(costs_now[k] - cost1) < tol * max(1.0, cost1), k
+        else:
+            S1, s1, dg1, _ = singles[k].reproj_schur(P, cp, col_ext[k], col_td[k], active=active[fac_off[k]:fac_off[k + 1]], reassemble=False, damp=damp2[k])
+        sc = max(1.0, np.abs(S1).max())
+        assert np.abs(S2[k] - S1).max() < tol * sc and np.abs(s2[k] - s1).max() < tol * max(1.0, np.abs(s1).max()), (k, re[k])
+    for c in singles + [ctxb]:
+        c.close()

@@ -66,3 +66,8 @@ def test_map_to_optimizer_to_map_on_tracked_windows_on_gpu():
     import harness as H
     import refine_checks as rc
     rc.check_refinement(H.HOST_LIB)
+
+
+def test_schur_windows_entry_points_on_gpu():
+    import icgvins
+    sc.check_schur_windows(lambda: icgvins.Context(640, 480, n_slots=1, max_batch=1, max_points=64))

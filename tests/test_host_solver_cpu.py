@@ -66,3 +66,9 @@ def test_map_to_optimizer_to_map_on_tracked_windows(host_lib):
     WindowCulling on the maps the tracker built from noisy INS priors"""
     import refine_checks as rc
     rc.check_refinement(host_lib)
+
+
+def test_schur_windows_entry_points_on_oracle_shim(host_lib):
+    import icgvins
+    lib = icgvins.load_library(host_lib)
+    sc.check_schur_windows(lambda: icgvins.Context(640, 480, n_slots=1, max_batch=1, max_points=64, lib=lib))
