@@ -430,6 +430,11 @@ def main():
                                "note": "one host thread + device context + HIP stream per solver (poll waits), as the stream groups of the front-end; "
                                        "bounded by the HIP runtime's launch/copy rate (~100 small operations per window), not by the kernels: "
                                        "batching many windows per launch is the round-2 item"}
+        nbat = 128  # windows of 128 streams advancing through their LM steps together (WindowSolverBatch)
+        su.host_solve_batch(hl, [Pz] * 8)
+        _, bms = su.host_solve_batch(hl, [Pz] * nbat)
+        solve["batched"] = {"windows_per_batch": nbat, "value": round(nbat / (bms * 1e-3), 1), "unit": "windows/s", "batch_ms": round(bms, 2),
+                            "note": "WindowSolverBatch: one evaluation / assembly+elimination / back-substitution launch per LM step for all windows"}
         if not args.no_cpu_baseline:
             from stream_utils import ensure_oracle_host
             ol = C.CDLL(ensure_oracle_host())

@@ -1216,3 +1216,14 @@ extern "C" int icg_reproj_cost_windows(icg_ctx *ctx, const uint8_t *active, doub
     ICG_HIP(ctx, hipGetLastError());
     return c.finish();
 }
+
+// the resident residuals of the last evaluation (n x 2), e.g. for the per-factor chi-square test after icg_reproj_eval_windows
+extern "C" int icg_reproj_fetch_residuals(icg_ctx *ctx, double *out_r) {
+    if (!ctx || !out_r) return ICG_ERR_INVALID;
+    if (!ctx->rJ_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident residuals");
+    const int n = ctx->n_factors_resident;
+    if (n == 0) return ICG_OK;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    ICG_HIP(ctx, hipMemcpyAsync(out_r, ctx->d_rJ, sizeof(double) * 2 * (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+    return icg_stream_wait(ctx);
+}

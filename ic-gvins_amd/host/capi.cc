@@ -200,6 +200,7 @@ int icgh_batch_features(icgh_batch *b, int stream, int max, uint64_t *ids, float
 #include "factors.h"
 #include "misc_hip.h"
 #include "solver_hip.h"
+#include "solver_batch_hip.h"
 #include "culling_hip.h"
 #include "window_visual.h"
 
@@ -862,6 +863,71 @@ int icgh_ins_redo(int n_streams, const double *cfg8, const double *updated23, in
                 ins_put_imu(w[(size_t) s][k].first, imu + 8 * ((size_t) win_offsets[s] + k));
                 ins_put_state(w[(size_t) s][k].second, states + 23 * ((size_t) win_offsets[s] + k));
             }
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
+// icgh_backend_solve for W windows at once on WindowSolverBatch (lock-step LM, one launch per phase for all windows).  Arrays are
+// concatenated window-major: window w owns factors [fac_off[w], fac_off[w+1]) (obs_soa is 15 x n_total, idx_* LOCAL to the window),
+// poses [pose_off[w], ..), inverse depths [lm_off[w], ..); ext is W x 7, td has W entries.  summary8 is W x 8 as in icgh_backend_solve.
+// Returns the wall time of the two solves + culling in ms through *solve_ms.
+int icgh_backend_solve_batch(int W, const int32_t *fac_off, const int32_t *pose_off, const int32_t *lm_off, const double *obs_soa, const int32_t *idx_i,
+                             const int32_t *idx_j, const int32_t *idx_lm, double *poses, double *ext, double *invdepth, double *td,
+                             const double *prior_poses, double prior_weight, double huber, int ext_constant, int td_constant, int iters1, int iters2,
+                             double chi2, double *summary8, double *solve_ms, char *err, int errlen) {
+    try {
+        const int n = fac_off[W];
+        vector<std::unique_ptr<ReprojectionFactor>> factors;
+        WindowSolverBatch solver(0, huber);
+        for (int w = 0; w < W; w++) {
+            const int ww = solver.addWindow();
+            double *P = poses + 7 * (size_t) pose_off[w], *E = ext + 7 * (size_t) w, *D = invdepth + lm_off[w], *TD = td + w;
+            const int K = pose_off[w + 1] - pose_off[w], L = lm_off[w + 1] - lm_off[w];
+            for (int k = 0; k < K; k++) solver.addParameterBlock(ww, P + 7 * (size_t) k, 7, true);
+            solver.addParameterBlock(ww, E, 7, true);
+            for (int l = 0; l < L; l++) solver.addParameterBlock(ww, D + l, 1);
+            solver.addParameterBlock(ww, TD, 1);
+            if (ext_constant) solver.setParameterBlockConstant(ww, E);
+            if (td_constant) solver.setParameterBlockConstant(ww, TD);
+            for (int f = fac_off[w]; f < fac_off[w + 1]; f++) {
+                auto o = [&](int c) { return obs_soa[(size_t) c * n + f]; };
+                factors.emplace_back(new ReprojectionFactor(Vector3d(o(0), o(1), o(2)), Vector3d(o(3), o(4), o(5)), Vector3d(o(6), o(7), o(8)),
+                                                            Vector3d(o(9), o(10), o(11)), o(12), o(13), o(14)));
+                solver.addReprojectionFactor(ww, factors.back().get(), P + 7 * (size_t) idx_i[f], P + 7 * (size_t) idx_j[f], E, D + idx_lm[f], TD);
+            }
+            for (int k = 0; k < K; k++)
+                solver.addResidualBlock(ww, std::make_shared<PosePriorFactor>(prior_poses + 7 * ((size_t) pose_off[w] + k), prior_weight), nullptr,
+                                        {P + 7 * (size_t) k});
+        }
+        auto t0 = std::chrono::steady_clock::now();
+        WindowSolverBatch::Options opt;
+        vector<WindowSolverBatch::Summary> s1, s2;
+        opt.max_num_iterations = iters1;
+        if (!solver.solve(opt, &s1)) {
+            set_err(err, errlen, solver.error().c_str());
+            return -2;
+        }
+        vector<int> removed((size_t) W, 0);
+        if (chi2 > 0) {
+            removed                = solver.removeReprojectionFactorsByChi2(chi2);
+            opt.max_num_iterations = iters2;
+            if (!solver.solve(opt, &s2)) {
+                set_err(err, errlen, solver.error().c_str());
+                return -4;
+            }
+        }
+        if (solve_ms) *solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        for (int w = 0; w < W; w++) {
+            double *o = summary8 + 8 * (size_t) w;
+            o[0] = s1[(size_t) w].initial_cost, o[1] = s1[(size_t) w].final_cost, o[2] = s1[(size_t) w].final_cost;
+            o[3] = s1[(size_t) w].num_successful_steps, o[4] = s1[(size_t) w].num_unsuccessful_steps, o[5] = o[6] = o[7] = 0;
+            if (chi2 > 0)
+                o[2] = s2[(size_t) w].final_cost, o[5] = s2[(size_t) w].num_successful_steps, o[6] = s2[(size_t) w].num_unsuccessful_steps,
+                o[7] = removed[(size_t) w];
         }
         return 0;
     } catch (const std::exception &e) {

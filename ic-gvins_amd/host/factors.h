@@ -47,6 +47,7 @@ public:
     ReprojectionFactor(Vector3d pts0, Vector3d pts1, Vector3d vel0, Vector3d vel1, double td0, double td1, double std);
     bool Evaluate(const double *const *parameters, double *residuals, double **jacobians) const override;
     const ReprojectionBatch *batch() const { return batch_; }
+    const double *observation() const { return obs_; } // the 15 constants in the order of icg_reproj_set_factors
 
 private:
     friend class ReprojectionBatch;

@@ -1,0 +1,391 @@
+// WindowSolverBatch: W Levenberg-Marquardt problems in lock-step on one device context.  See solver_batch_hip.h.
+#include "solver_batch_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+#include "../../include/icgvins_hip.h"
+
+namespace icg {
+
+using solver_detail::choleskySolve;
+using solver_detail::posePlus;
+
+WindowSolverBatch::WindowSolverBatch(int device, double huber_delta) : huber_(huber_delta) {
+    icg_ctx_config cfg{};
+    cfg.device = device, cfg.width = 64, cfg.height = 64, cfg.n_slots = 1, cfg.max_batch = 1, cfg.max_points = 64;
+    if (icg_ctx_create(&cfg, &ctx_) != ICG_OK) throw std::runtime_error(std::string("WindowSolverBatch: ") + icg_last_error(nullptr));
+}
+
+WindowSolverBatch::~WindowSolverBatch() { icg_ctx_destroy(ctx_); }
+
+int WindowSolverBatch::addWindow() {
+    windows_.emplace_back();
+    finalized_ = false;
+    return (int) windows_.size() - 1;
+}
+
+void WindowSolverBatch::addParameterBlock(int w, double *values, int size, bool pose_manifold) {
+    Window &W = windows_.at((size_t) w);
+    if (W.block_of.count(values)) return;
+    if (pose_manifold && size != 7) throw std::runtime_error("WindowSolverBatch: the pose manifold needs a block of size 7");
+    W.block_of[values] = (int) W.blocks.size();
+    W.blocks.push_back({values, size, pose_manifold ? 6 : size, pose_manifold, false, -1, false});
+}
+
+void WindowSolverBatch::setParameterBlockConstant(int w, double *values) {
+    Window &W = windows_.at((size_t) w);
+    auto it   = W.block_of.find(values);
+    if (it == W.block_of.end()) throw std::runtime_error("WindowSolverBatch: unknown parameter block");
+    W.blocks[(size_t) it->second].constant = true;
+}
+
+int WindowSolverBatch::addResidualBlock(int w, std::shared_ptr<ceres::CostFunction> cost, std::shared_ptr<ceres::LossFunction> loss,
+                                        const std::vector<double *> &blocks) {
+    Window &W         = windows_.at((size_t) w);
+    const auto &sizes = cost->parameter_block_sizes();
+    if (sizes.size() != blocks.size()) throw std::runtime_error("WindowSolverBatch: block count does not match the cost function");
+    for (size_t k = 0; k < blocks.size(); k++) {
+        auto it = W.block_of.find(blocks[k]);
+        if (it == W.block_of.end()) throw std::runtime_error("WindowSolverBatch: residual block uses an unknown parameter block");
+        if (W.blocks[(size_t) it->second].size != sizes[k]) throw std::runtime_error("WindowSolverBatch: parameter block size mismatch");
+    }
+    W.residuals.push_back({std::move(cost), std::move(loss), blocks, false});
+    return (int) W.residuals.size() - 1;
+}
+
+void WindowSolverBatch::addReprojectionFactor(int w, const ReprojectionFactor *factor, double *pose_i, double *pose_j, double *extrinsic, double *invdepth,
+                                              double *td) {
+    Window &W = windows_.at((size_t) w);
+    if ((W.ext && W.ext != extrinsic) || (W.td && W.td != td)) throw std::runtime_error("WindowSolverBatch: one extrinsic / td block per window");
+    W.ext = extrinsic, W.td = td;
+    VisualFactor f;
+    memcpy(f.obs, factor->observation(), sizeof f.obs);
+    f.pose_i = pose_i, f.pose_j = pose_j, f.invdepth = invdepth;
+    for (double *p : {pose_i, pose_j})
+        if (!W.pose_index.count(p)) {
+            W.pose_index[p] = (int) W.poses.size();
+            W.poses.push_back(p);
+        }
+    if (!W.lm_index.count(invdepth)) {
+        W.lm_index[invdepth] = (int) W.landmarks.size();
+        W.landmarks.push_back(invdepth);
+    }
+    W.visual.push_back(f);
+    finalized_ = false;
+}
+
+// uploads the factors of all windows (window-major) and the partition
+bool WindowSolverBatch::finalize() {
+    n_factors_ = n_poses_ = n_lm_ = 0;
+    std::vector<int32_t> fac_off{0}, lm_off{0};
+    for (Window &W : windows_) {
+        W.fac_begin = n_factors_, W.pose_begin = n_poses_, W.lm_begin = n_lm_;
+        n_factors_ += (int) W.visual.size(), n_poses_ += (int) W.poses.size(), n_lm_ += (int) W.landmarks.size();
+        fac_off.push_back(n_factors_), lm_off.push_back(n_lm_);
+    }
+    if (n_factors_ == 0) {
+        error_ = "no reprojection factors";
+        return false;
+    }
+    std::vector<double> obs((size_t) 15 * n_factors_);
+    std::vector<int32_t> ii((size_t) n_factors_), jj((size_t) n_factors_), ll((size_t) n_factors_);
+    for (const Window &W : windows_)
+        for (size_t k = 0; k < W.visual.size(); k++) {
+            const size_t f = (size_t) W.fac_begin + k;
+            for (int c = 0; c < 15; c++) obs[(size_t) c * n_factors_ + f] = W.visual[k].obs[c];
+            ii[f] = W.pose_begin + W.pose_index.at(W.visual[k].pose_i);
+            jj[f] = W.pose_begin + W.pose_index.at(W.visual[k].pose_j);
+            ll[f] = W.lm_begin + W.lm_index.at(W.visual[k].invdepth);
+        }
+    if (icg_reproj_set_factors(ctx_, n_factors_, obs.data(), ii.data(), jj.data(), ll.data()) != ICG_OK ||
+        icg_reproj_set_windows(ctx_, (int) windows_.size(), fac_off.data(), lm_off.data()) != ICG_OK) {
+        error_ = icg_last_error(ctx_);
+        return false;
+    }
+    active_.assign((size_t) n_factors_, 1);
+    finalized_ = true;
+    return true;
+}
+
+bool WindowSolverBatch::layout() {
+    P_ = 0;
+    col_pose_.assign((size_t) n_poses_, -1);
+    col_ext_.assign(windows_.size(), -1);
+    col_td_.assign(windows_.size(), -1);
+    for (size_t w = 0; w < windows_.size(); w++) {
+        Window &W = windows_[w];
+        for (Block &b : W.blocks) b.landmark = false, b.column = -1;
+        for (double *p : W.landmarks) {
+            auto it = W.block_of.find(p);
+            if (it == W.block_of.end() || W.blocks[(size_t) it->second].constant) {
+                error_ = "an inverse-depth block of a reprojection factor was not added to its window (or is constant)";
+                return false;
+            }
+            W.blocks[(size_t) it->second].landmark = true;
+        }
+        for (const Residual &R : W.residuals)
+            if (!R.removed)
+                for (double *p : R.blocks)
+                    if (W.blocks[(size_t) W.block_of.at(p)].landmark) {
+                        error_ = "host factors on an eliminated inverse-depth block are not supported";
+                        return false;
+                    }
+        W.P = 0;
+        for (Block &b : W.blocks)
+            if (!b.constant && !b.landmark) {
+                b.column = W.P;
+                W.P += b.local;
+            }
+        auto col = [&](const double *p) {
+            auto it = W.block_of.find(p);
+            if (it == W.block_of.end()) throw std::runtime_error("WindowSolverBatch: a block of a reprojection factor was not added to its window");
+            return W.blocks[(size_t) it->second].column;
+        };
+        for (size_t k = 0; k < W.poses.size(); k++) col_pose_[(size_t) W.pose_begin + k] = col(W.poses[k]);
+        if (W.ext) col_ext_[w] = col(W.ext);
+        if (W.td) col_td_[w] = col(W.td);
+        P_ = std::max(P_, W.P);
+    }
+    return P_ > 0;
+}
+
+void WindowSolverBatch::gather(std::vector<double> &poses, std::vector<double> &ext, std::vector<double> &inv, std::vector<double> &td) const {
+    poses.resize(7 * (size_t) n_poses_), ext.assign(7 * windows_.size(), 0.0), inv.resize((size_t) n_lm_), td.assign(windows_.size(), 0.0);
+    for (size_t w = 0; w < windows_.size(); w++) {
+        const Window &W = windows_[w];
+        for (size_t k = 0; k < W.poses.size(); k++) memcpy(&poses[7 * ((size_t) W.pose_begin + k)], W.poses[k], sizeof(double) * 7);
+        for (size_t k = 0; k < W.landmarks.size(); k++) inv[(size_t) W.lm_begin + k] = *W.landmarks[k];
+        if (W.ext) memcpy(&ext[7 * w], W.ext, sizeof(double) * 7);
+        if (W.td) td[w] = *W.td;
+    }
+}
+
+bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries) {
+    if (!finalized_ && !finalize()) return false;
+    if (!layout()) {
+        if (error_.empty()) error_ = "nothing to optimize";
+        return false;
+    }
+    const size_t NW = windows_.size();
+    const int P     = P_;
+    struct State {
+        double radius, dec, cost, new_cost, model;
+        bool done, relinearize, redamp, stepped;
+        int iters;
+        std::vector<double> S, s, diag, delta_c, dd;
+    };
+    std::vector<State> st(NW);
+    std::vector<Summary> sum(NW);
+    for (size_t w = 0; w < NW; w++) {
+        st[w] = State{o.initial_trust_region_radius, 2.0, 0, 0, 0, false, true, false, false, 0, {}, {}, {}, {}, {}};
+        sum[w].termination = "max_num_iterations";
+    }
+    std::vector<double> poses, ext, inv, td, S((size_t) NW * P * P), s((size_t) NW * P), diag((size_t) NW * P), cost(NW), delta_c((size_t) NW * P),
+        delta_l((size_t) n_lm_), terms(2 * NW), damp(NW);
+    std::vector<uint8_t> reassemble(NW);
+    auto fail = [&](const char *what) {
+        error_ = std::string(what) + ": " + icg_last_error(ctx_);
+        return false;
+    };
+    bool first = true;
+    for (;;) {
+        // ---- (re)linearize / re-damp --------------------------------------------------------------------------------------------
+        bool any_lin = false, any_sys = false;
+        for (size_t w = 0; w < NW; w++) {
+            reassemble[w] = (!st[w].done && st[w].relinearize) ? 1 : 0;
+            damp[w]       = 1.0 / st[w].radius;
+            any_lin |= reassemble[w] != 0;
+            any_sys |= !st[w].done && (st[w].relinearize || st[w].redamp);
+        }
+        if (any_lin) {
+            gather(poses, ext, inv, td);
+            if (icg_reproj_eval_windows(ctx_, n_poses_, poses.data(), ext.data(), n_lm_, inv.data(), td.data(), 1, huber_) != ICG_OK)
+                return fail("icg_reproj_eval_windows");
+        }
+        if (any_sys) {
+            if (icg_reproj_schur_windows(ctx_, P, col_pose_.data(), col_ext_.data(), col_td_.data(), active_.data(), reassemble.data(), damp.data(),
+                                         o.min_lm_diagonal, o.max_lm_diagonal, S.data(), s.data(), diag.data(), cost.data()) != ICG_OK)
+                return fail("icg_reproj_schur_windows");
+            for (size_t w = 0; w < NW; w++) {
+                if (st[w].done || !(st[w].relinearize || st[w].redamp)) continue;
+                Window &W = windows_[w];
+                if (st[w].relinearize) {
+                    W.host_S.assign((size_t) P * P, 0.0), W.host_s.assign((size_t) P, 0.0), W.host_diag.assign((size_t) P, 0.0);
+                    double hc = 0;
+                    if (!solver_detail::hostFactors(W.blocks, W.block_of, W.residuals, P, W.host_S.data(), W.host_s.data(), W.host_diag.data(), &hc)) {
+                        error_ = "a host cost function failed to evaluate";
+                        return false;
+                    }
+                    if (first || st[w].stepped) {
+                        // the cost at the linearization point: on the first pass it initialises the window, afterwards it equals the
+                        // accepted trial cost and is kept (bit-identical bookkeeping with WindowSolver)
+                        if (first) st[w].cost = cost[w] + hc, sum[w].initial_cost = st[w].cost;
+                    }
+                }
+                st[w].S.assign(S.begin() + (long) (w * P * P), S.begin() + (long) ((w + 1) * P * P));
+                st[w].s.assign(s.begin() + (long) (w * P), s.begin() + (long) ((w + 1) * P));
+                st[w].diag.assign(diag.begin() + (long) (w * P), diag.begin() + (long) ((w + 1) * P));
+                for (size_t k = 0; k < st[w].S.size(); k++) st[w].S[k] += W.host_S[k];
+                for (int k = 0; k < P; k++) st[w].s[(size_t) k] += W.host_s[(size_t) k], st[w].diag[(size_t) k] += W.host_diag[(size_t) k];
+                st[w].relinearize = st[w].redamp = false;
+            }
+        }
+        first = false;
+        // ---- every open window: iteration budget, gradient test, reduced solve ----------------------------------------------------
+        bool any_step = false;
+        std::fill(delta_c.begin(), delta_c.end(), 0.0);
+        for (size_t w = 0; w < NW; w++) {
+            State &T = st[w];
+            T.stepped = false;
+            if (T.done) continue;
+            if (T.iters >= o.max_num_iterations) {
+                T.done = true;
+                continue;
+            }
+            T.iters++;
+            double gmax = 0;
+            for (double v : T.s) gmax = std::max(gmax, std::fabs(v));
+            if (gmax < o.gradient_tolerance) {
+                sum[w].termination = "gradient_tolerance";
+                T.done             = true;
+                continue;
+            }
+            std::vector<double> A(T.S);
+            T.delta_c = T.s;
+            T.dd.assign((size_t) P, 0.0);
+            const int Pw = windows_[w].P; // columns beyond Pw are empty (zero rows): solve the leading block only
+            for (int k = 0; k < Pw; k++) {
+                T.dd[(size_t) k] = std::min(std::max(T.diag[(size_t) k], o.min_lm_diagonal), o.max_lm_diagonal) / T.radius;
+                A[(size_t) k * P + k] += T.dd[(size_t) k];
+            }
+            std::vector<double> Ab((size_t) Pw * Pw), bb(T.s.begin(), T.s.begin() + Pw);
+            for (int i = 0; i < Pw; i++)
+                for (int j = 0; j < Pw; j++) Ab[(size_t) i * Pw + j] = A[(size_t) i * P + j];
+            if (!choleskySolve(Pw, Ab, bb)) {
+                T.radius /= T.dec, T.dec *= 2.0;
+                sum[w].num_unsuccessful_steps++;
+                T.redamp = true;
+                if (T.radius < o.min_trust_region_radius) sum[w].termination = "min_trust_region_radius", T.done = true;
+                continue;
+            }
+            std::fill(T.delta_c.begin(), T.delta_c.end(), 0.0);
+            std::copy(bb.begin(), bb.end(), T.delta_c.begin());
+            std::copy(T.delta_c.begin(), T.delta_c.end(), delta_c.begin() + (long) (w * P));
+            T.stepped = true;
+            any_step  = true;
+        }
+        bool all_done = true;
+        for (size_t w = 0; w < NW; w++) all_done &= st[w].done;
+        if (all_done) break;
+        if (!any_step) continue; // only re-damping this round
+        // ---- landmark back-substitution for all windows, model decrease, trial points ---------------------------------------------
+        if (n_lm_ > 0 && icg_reproj_backsub_windows(ctx_, P, delta_c.data(), delta_l.data(), terms.data()) != ICG_OK) return fail("icg_reproj_backsub_windows");
+        bool any_trial = false;
+        for (size_t w = 0; w < NW; w++) {
+            State &T = st[w];
+            if (!T.stepped) continue;
+            Window &W = windows_[w];
+            double t0 = terms[2 * w], t1 = terms[2 * w + 1];
+            for (int k = 0; k < P; k++) t0 += T.delta_c[(size_t) k] * T.s[(size_t) k], t1 += T.dd[(size_t) k] * T.delta_c[(size_t) k] * T.delta_c[(size_t) k];
+            T.model = 0.5 * (t0 + t1);
+            if (!(T.model > 0.0)) {
+                T.radius /= T.dec, T.dec *= 2.0;
+                sum[w].num_unsuccessful_steps++;
+                T.redamp = true, T.stepped = false;
+                if (T.radius < o.min_trust_region_radius) sum[w].termination = "min_trust_region_radius", T.done = true;
+                continue;
+            }
+            double dn = 0, xn = 0;
+            for (double v : T.delta_c) dn += v * v;
+            for (size_t k = 0; k < W.landmarks.size(); k++) dn += delta_l[(size_t) W.lm_begin + k] * delta_l[(size_t) W.lm_begin + k];
+            for (const Block &b : W.blocks)
+                if (!b.constant)
+                    for (int k = 0; k < b.size; k++) xn += b.values[k] * b.values[k];
+            if (std::sqrt(dn) <= o.parameter_tolerance * (std::sqrt(xn) + o.parameter_tolerance)) {
+                sum[w].termination = "parameter_tolerance";
+                T.done = true, T.stepped = false;
+                continue;
+            }
+            W.saved.resize(W.blocks.size());
+            for (size_t k = 0; k < W.blocks.size(); k++) W.saved[k].assign(W.blocks[k].values, W.blocks[k].values + W.blocks[k].size);
+            for (Block &b : W.blocks) {
+                if (b.column < 0) continue;
+                const double *d = &T.delta_c[(size_t) b.column];
+                if (b.pose)
+                    posePlus(b.values, d);
+                else
+                    for (int k = 0; k < b.size; k++) b.values[k] += d[k];
+            }
+            for (size_t k = 0; k < W.landmarks.size(); k++) *W.landmarks[k] += delta_l[(size_t) W.lm_begin + k];
+            any_trial = true;
+        }
+        if (!any_trial) continue;
+        gather(poses, ext, inv, td);
+        if (icg_reproj_eval_windows(ctx_, n_poses_, poses.data(), ext.data(), n_lm_, inv.data(), td.data(), 0, huber_) != ICG_OK)
+            return fail("icg_reproj_eval_windows");
+        if (icg_reproj_cost_windows(ctx_, active_.data(), cost.data()) != ICG_OK) return fail("icg_reproj_cost_windows");
+        for (size_t w = 0; w < NW; w++) {
+            State &T = st[w];
+            if (!T.stepped) continue;
+            Window &W   = windows_[w];
+            double hc   = 0;
+            if (!solver_detail::hostFactors(W.blocks, W.block_of, W.residuals, P, nullptr, nullptr, nullptr, &hc)) {
+                error_ = "a host cost function failed to evaluate";
+                return false;
+            }
+            T.new_cost       = cost[w] + hc;
+            const double rho = (T.cost - T.new_cost) / T.model;
+            if (rho > o.min_relative_decrease) {
+                const double change = T.cost - T.new_cost;
+                T.cost              = T.new_cost;
+                sum[w].num_successful_steps++;
+                T.radius = std::min(o.max_trust_region_radius, T.radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)));
+                T.dec    = 2.0;
+                if (std::fabs(change) < o.function_tolerance * T.cost) {
+                    sum[w].termination = "function_tolerance";
+                    T.done             = true;
+                } else {
+                    T.relinearize = true;
+                }
+            } else {
+                for (size_t k = 0; k < W.blocks.size(); k++) memcpy(W.blocks[k].values, W.saved[k].data(), sizeof(double) * (size_t) W.blocks[k].size);
+                T.radius /= T.dec, T.dec *= 2.0;
+                sum[w].num_unsuccessful_steps++;
+                T.redamp = true;
+                if (T.radius < o.min_trust_region_radius) sum[w].termination = "min_trust_region_radius", T.done = true;
+            }
+        }
+    }
+    for (size_t w = 0; w < NW; w++) sum[w].final_cost = st[w].cost;
+    if (summaries) *summaries = sum;
+    return true;
+}
+
+std::vector<int> WindowSolverBatch::removeReprojectionFactorsByChi2(double chi2) {
+    std::vector<int> removed(windows_.size(), 0);
+    if (!finalized_ && !finalize()) return removed;
+    std::vector<double> poses, ext, inv, td, r(2 * (size_t) n_factors_);
+    gather(poses, ext, inv, td);
+    // raw residuals, no loss: problem.EvaluateResidualBlock(id, false, &cost, ...) with cost = 0.5 |r|^2 (ic_gvins.cc:1278-1284)
+    if (icg_reproj_eval_windows(ctx_, n_poses_, poses.data(), ext.data(), n_lm_, inv.data(), td.data(), 0, 0.0) != ICG_OK ||
+        icg_reproj_fetch_residuals(ctx_, r.data()) != ICG_OK) {
+        error_ = icg_last_error(ctx_);
+        return removed;
+    }
+    for (size_t w = 0; w < windows_.size(); w++)
+        for (size_t k = 0; k < windows_[w].visual.size(); k++) {
+            const size_t f = (size_t) windows_[w].fac_begin + k;
+            if (!active_[f]) continue;
+            const double cost = 0.5 * (r[2 * f] * r[2 * f] + r[2 * f + 1] * r[2 * f + 1]);
+            if (cost * 2.0 > chi2) {
+                active_[f] = 0;
+                removed[w]++;
+            }
+        }
+    return removed;
+}
+
+} // namespace icg

@@ -33,50 +33,8 @@ struct PhaseScope {
 };
 enum { PH_EVAL_JAC = 0, PH_SCHUR, PH_HOST_FACTORS, PH_CHOLESKY, PH_BACKSUB, PH_EVAL_TRIAL, PH_COST, PH_CHI2 };
 
-// in-place Cholesky solve of the symmetric positive definite n x n system A x = b (row-major, lower triangle used)
-bool choleskySolve(int n, std::vector<double> &A, std::vector<double> &b) {
-    for (int j = 0; j < n; j++) {
-        double d = A[(size_t) j * n + j];
-        for (int k = 0; k < j; k++) d -= A[(size_t) j * n + k] * A[(size_t) j * n + k];
-        if (!(d > 0.0) || !std::isfinite(d)) return false;
-        d                     = std::sqrt(d);
-        A[(size_t) j * n + j] = d;
-        for (int i = j + 1; i < n; i++) {
-            double v = A[(size_t) i * n + j];
-            for (int k = 0; k < j; k++) v -= A[(size_t) i * n + k] * A[(size_t) j * n + k];
-            A[(size_t) i * n + j] = v / d;
-        }
-    }
-    for (int i = 0; i < n; i++) {
-        double v = b[(size_t) i];
-        for (int k = 0; k < i; k++) v -= A[(size_t) i * n + k] * b[(size_t) k];
-        b[(size_t) i] = v / A[(size_t) i * n + i];
-    }
-    for (int i = n - 1; i >= 0; i--) {
-        double v = b[(size_t) i];
-        for (int k = i + 1; k < n; k++) v -= A[(size_t) k * n + i] * b[(size_t) k];
-        b[(size_t) i] = v / A[(size_t) i * n + i];
-    }
-    return true;
-}
-
-// PoseParameterization::Plus (factors/pose_parameterization.h:34-50): p += dp, q = (q * rotvec2quaternion(dtheta)).normalized()
-void posePlus(double *x, const double *delta) {
-    for (int k = 0; k < 3; k++) x[k] += delta[k];
-    const double rx = delta[3], ry = delta[4], rz = delta[5];
-    const double angle = std::sqrt(rx * rx + ry * ry + rz * rz);
-    double ax = rx, ay = ry, az = rz;
-    if (angle > 0) ax /= angle, ay /= angle, az /= angle;
-    const double sh = std::sin(0.5 * angle), ch = std::cos(0.5 * angle);
-    const double bx = sh * ax, by = sh * ay, bz = sh * az, bw = ch;
-    const double qx = x[3], qy = x[4], qz = x[5], qw = x[6];
-    double nx = qw * bx + qx * bw + qy * bz - qz * by;
-    double ny = qw * by + qy * bw + qz * bx - qx * bz;
-    double nz = qw * bz + qz * bw + qx * by - qy * bx;
-    double nw = qw * bw - qx * bx - qy * by - qz * bz;
-    const double nn = std::sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
-    x[3] = nx / nn, x[4] = ny / nn, x[5] = nz / nn, x[6] = nw / nn;
-}
+using solver_detail::choleskySolve;
+using solver_detail::posePlus;
 } // namespace
 
 std::string WindowSolver::Summary::BriefReport() const {
@@ -119,18 +77,7 @@ WindowSolver::ResidualBlockId WindowSolver::addResidualBlock(std::shared_ptr<cer
 void WindowSolver::removeResidualBlock(ResidualBlockId id) { residuals_.at((size_t) id).removed = true; }
 
 bool WindowSolver::evaluateResidualBlock(ResidualBlockId id, bool apply_loss_function, double *cost) const {
-    const Residual &R = residuals_.at((size_t) id);
-    std::vector<double> r((size_t) R.cost->num_residuals());
-    if (!R.cost->Evaluate(R.blocks.data(), r.data(), nullptr)) return false;
-    double s = 0;
-    for (double v : r) s += v * v;
-    if (apply_loss_function && R.loss) {
-        double rho[3];
-        R.loss->Evaluate(s, rho);
-        s = rho[0];
-    }
-    *cost = 0.5 * s;
-    return true;
+    return solver_detail::residualCost(residuals_.at((size_t) id), apply_loss_function, cost);
 }
 
 int WindowSolver::numActiveReprojectionFactors() const {
@@ -185,59 +132,6 @@ bool WindowSolver::layout() {
     return P_ > 0;
 }
 
-// host factors: S += J^T J, s -= J^T r (robust-corrected), diag, cost += 0.5 rho(|r|^2)
-bool WindowSolver::hostFactors(std::vector<double> *S, std::vector<double> *s, std::vector<double> *diag, double *cost) const {
-    for (const Residual &R : residuals_) {
-        if (R.removed) continue;
-        if (!S) { // cost only
-            double c;
-            if (!evaluateResidualBlock((ResidualBlockId) (&R - residuals_.data()), true, &c)) return false;
-            *cost += c;
-            continue;
-        }
-        ResidualBlockInfo info(R.cost, nullptr, R.blocks, {});
-        if (!info.Evaluate()) return false;
-        // cost from the raw residual, then the Ceres corrector (residual_block_info.h:59-87) through the shared implementation
-        double sq = 0;
-        for (double v : info.residuals()) sq += v * v;
-        if (R.loss) {
-            double rho[3];
-            R.loss->Evaluate(sq, rho);
-            *cost += 0.5 * rho[0];
-            ResidualBlockInfo corrected(R.cost, R.loss, R.blocks, {});
-            if (!corrected.Evaluate()) return false;
-            info = corrected;
-        } else {
-            *cost += 0.5 * sq;
-        }
-        const int nr = R.cost->num_residuals();
-        const auto &sizes = R.cost->parameter_block_sizes();
-        for (size_t a = 0; a < R.blocks.size(); a++) {
-            const Block &A = blocks_[(size_t) block_of_.at(R.blocks[a])];
-            if (A.column < 0) continue;
-            const std::vector<double> &Ja = info.jacobians()[a];
-            for (int x = 0; x < A.local; x++) {
-                double g = 0;
-                for (int k = 0; k < nr; k++) g += Ja[(size_t) k * sizes[a] + x] * info.residuals()[(size_t) k];
-                (*s)[(size_t) (A.column + x)] -= g;
-            }
-            for (size_t c = 0; c < R.blocks.size(); c++) {
-                const Block &B = blocks_[(size_t) block_of_.at(R.blocks[c])];
-                if (B.column < 0) continue;
-                const std::vector<double> &Jc = info.jacobians()[c];
-                for (int x = 0; x < A.local; x++)
-                    for (int y = 0; y < B.local; y++) {
-                        double v = 0;
-                        for (int k = 0; k < nr; k++) v += Ja[(size_t) k * sizes[a] + x] * Jc[(size_t) k * sizes[c] + y];
-                        (*S)[(size_t) (A.column + x) * P_ + B.column + y] += v;
-                        if (a == c && x == y) (*diag)[(size_t) (A.column + x)] += v;
-                    }
-            }
-        }
-    }
-    return true;
-}
-
 bool WindowSolver::linearize(double damp, bool reassemble, const Options &o, std::vector<double> &S, std::vector<double> &s,
                              std::vector<double> &diag, double *cost) {
     S.assign((size_t) P_ * P_, 0.0);
@@ -267,7 +161,7 @@ bool WindowSolver::linearize(double damp, bool reassemble, const Options &o, std
         host_diag_.assign((size_t) P_, 0.0);
         double hc = 0;
         PhaseScope ps(PH_HOST_FACTORS);
-        if (!hostFactors(&host_S_, &host_s_, &host_diag_, &hc)) {
+        if (!solver_detail::hostFactors(blocks_, block_of_, residuals_, P_, host_S_.data(), host_s_.data(), host_diag_.data(), &hc)) {
             error_ = "a host cost function failed to evaluate";
             return false;
         }
@@ -297,7 +191,7 @@ bool WindowSolver::evaluateCost(double *cost) {
         }
         c += vc;
     }
-    if (!hostFactors(nullptr, nullptr, nullptr, &c)) {
+    if (!solver_detail::hostFactors(blocks_, block_of_, residuals_, P_, nullptr, nullptr, nullptr, &c)) {
         error_ = "a host cost function failed to evaluate";
         return false;
     }

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "factors.h"
+#include "solver_detail.h"
 
 namespace icg {
 
@@ -65,24 +66,12 @@ public:
     const std::string &error() const { return error_; }
 
 private:
-    struct Block {
-        double *values;
-        int size, local;
-        bool pose, constant;
-        int column; // in the reduced (camera) system, -1 for constants and for the eliminated inverse-depth blocks
-        bool landmark;
-    };
-    struct Residual {
-        std::shared_ptr<ceres::CostFunction> cost;
-        std::shared_ptr<ceres::LossFunction> loss;
-        std::vector<double *> blocks;
-        bool removed;
-    };
+    typedef solver_detail::Block Block;
+    typedef solver_detail::Residual Residual;
     bool layout();
     bool linearize(double damp, bool reassemble, const Options &o, std::vector<double> &S, std::vector<double> &s, std::vector<double> &diag,
                    double *cost);
     bool evaluateCost(double *cost);
-    bool hostFactors(std::vector<double> *S, std::vector<double> *s, std::vector<double> *diag, double *cost) const;
     void applyStep(const std::vector<double> &delta_c, const std::vector<double> &delta_l);
     void backup();
     void restore();

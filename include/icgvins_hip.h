@@ -213,6 +213,8 @@ int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const
                              double *diag_cc, double *cost);
 int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms);
 int icg_reproj_cost_windows(icg_ctx *ctx, const uint8_t *active, double *cost);
+/* the resident residuals of the last evaluation (n x 2 doubles): per-factor tests (chi-square culling) after a resident evaluation */
+int icg_reproj_fetch_residuals(icg_ctx *ctx, double *out_r);
 
 /* ---- P1: preintegration inner loop (preintegration/preintegration_base.cc:39-70, preintegration_earth.cc:205-303,
  * preintegration_normal.cc:183-232), batched over independent intervals.

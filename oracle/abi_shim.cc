@@ -433,6 +433,12 @@ int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, doubl
     return ICG_OK;
 }
 
+int icg_reproj_fetch_residuals(icg_ctx *ctx, double *out_r) {
+    shim_backend &B = g_backend[ctx];
+    memcpy(out_r, B.r.data(), sizeof(double) * B.r.size());
+    return ICG_OK;
+}
+
 int icg_reproj_cost_windows(icg_ctx *ctx, const uint8_t *active, double *cost) {
     shim_backend &B = g_backend[ctx];
     if (B.W <= 0) return ICG_ERR_INVALID;

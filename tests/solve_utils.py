@@ -46,6 +46,33 @@ def host_solve(lib, P, prior_weight=30.0, huber=1.0, ext_const=False, td_const=F
     return dict(poses=poses, ext=ext, invdepth=inv, td=float(td[0]), summary=summ[:8], active=active, solve_ms=float(summ[8]), setup_ms=float(summ[9]))
 
 
+def host_solve_batch(lib, problems, prior_weight=30.0, huber=1.0, ext_const=False, td_const=False, iters1=6, iters2=18, chi2=5.991):
+    """all problems in ONE WindowSolverBatch (lock-step LM); -> list of result dicts like host_solve, and the solve wall time in ms"""
+    W = len(problems)
+    fac_off = np.concatenate([[0], np.cumsum([P["obs"].shape[1] for P in problems])]).astype(np.int32)
+    pose_off = np.concatenate([[0], np.cumsum([P["start"]["poses"].shape[0] for P in problems])]).astype(np.int32)
+    lm_off = np.concatenate([[0], np.cumsum([len(P["start"]["invdepth"]) for P in problems])]).astype(np.int32)
+    obs = np.ascontiguousarray(np.concatenate([P["obs"] for P in problems], axis=1))
+    ii = np.ascontiguousarray(np.concatenate([P["ii"] for P in problems]), np.int32)
+    jj = np.ascontiguousarray(np.concatenate([P["jj"] for P in problems]), np.int32)
+    ll = np.ascontiguousarray(np.concatenate([P["ll"] for P in problems]), np.int32)
+    poses = np.ascontiguousarray(np.concatenate([P["start"]["poses"] for P in problems]))
+    ext = np.ascontiguousarray(np.stack([P["start"]["ext"] for P in problems]))
+    inv = np.ascontiguousarray(np.concatenate([P["start"]["invdepth"] for P in problems]))
+    td = np.array([P["start"]["td"] for P in problems], np.float64)
+    prior = np.ascontiguousarray(np.concatenate([P["prior"] for P in problems]))
+    summ, ms = np.zeros((W, 8)), C.c_double(0)
+    err = C.create_string_buffer(512)
+    rc = lib.icgh_backend_solve_batch(W, _p(fac_off), _p(pose_off), _p(lm_off), _p(obs), _p(ii), _p(jj), _p(ll), _p(poses), _p(ext), _p(inv), _p(td),
+                                      _p(prior), C.c_double(prior_weight), C.c_double(huber), int(ext_const), int(td_const), int(iters1), int(iters2),
+                                      C.c_double(chi2), _p(summ), C.byref(ms), err, 512)
+    assert rc == 0, (rc, err.value)
+    out = []
+    for w in range(W):
+        out.append(dict(poses=poses[pose_off[w]:pose_off[w + 1]], ext=ext[w], invdepth=inv[lm_off[w]:lm_off[w + 1]], td=float(td[w]), summary=summ[w]))
+    return out, ms.value
+
+
 def host_solve_throughput(lib, P, threads, repeat, prior_weight=30.0, huber=1.0, iters1=6, iters2=18, chi2=5.991):
     """-> windows per second with `threads` solvers in flight (each its own device context), problem construction excluded"""
     s = P["start"]

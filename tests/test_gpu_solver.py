@@ -71,3 +71,16 @@ def test_map_to_optimizer_to_map_on_tracked_windows_on_gpu():
 def test_schur_windows_entry_points_on_gpu():
     import icgvins
     sc.check_schur_windows(lambda: icgvins.Context(640, 480, n_slots=1, max_batch=1, max_points=64))
+
+
+def test_window_solver_batch_equals_single_solvers_on_gpu():
+    import harness as H
+    from test_host_solver_cpu import _batch_problems
+    lib = C.CDLL(H.HOST_LIB)
+    probs = _batch_problems()
+    res, _ = su.host_solve_batch(lib, probs)
+    for k, P in enumerate(probs):
+        h = su.host_solve(lib, P)
+        assert np.array_equal(res[k]["summary"][3:], h["summary"][3:]), (k, res[k]["summary"], h["summary"])
+        for key in ("poses", "ext", "invdepth"):
+            assert np.abs(res[k][key] - h[key]).max() < 1e-7, (k, key)

@@ -72,3 +72,26 @@ def test_schur_windows_entry_points_on_oracle_shim(host_lib):
     import icgvins
     lib = icgvins.load_library(host_lib)
     sc.check_schur_windows(lambda: icgvins.Context(640, 480, n_slots=1, max_batch=1, max_points=64, lib=lib))
+
+
+def _batch_problems():
+    return [su.make_problem(60, 6, seed=0, n_outliers=8), su.make_problem(40, 5, seed=1, n_outliers=0), su.make_problem(80, 7, seed=2, n_outliers=5),
+            su.make_problem(30, 4, seed=3, n_outliers=3, perturb=0.2), su.make_problem(60, 6, seed=5, n_outliers=4, perturb=2.5)]
+
+
+def test_window_solver_batch_equals_single_solvers(host_lib):
+    """five windows of different size and difficulty (one with rejected steps, one that stops early) optimized in lock-step by
+    WindowSolverBatch: per window the same accepted / rejected steps, the same chi-square removals and the same optimum as a
+    WindowSolver of its own"""
+    lib = C.CDLL(host_lib)
+    probs = _batch_problems()
+    res, _ = su.host_solve_batch(lib, probs)
+    kinds = set()
+    for k, P in enumerate(probs):
+        h = su.host_solve(lib, P)
+        assert np.array_equal(res[k]["summary"][3:], h["summary"][3:]), (k, res[k]["summary"], h["summary"])
+        assert np.abs(res[k]["summary"][:3] - h["summary"][:3]).max() < 1e-8 * max(1.0, h["summary"][0])
+        for key in ("poses", "ext", "invdepth"):
+            assert np.abs(res[k][key] - h[key]).max() < 1e-8, (k, key)
+        kinds.add((h["summary"][4] + h["summary"][6] > 0, h["summary"][5] < 3))
+    assert (True, False) in kinds or (True, True) in kinds  # at least one window had a rejected step
