@@ -903,6 +903,10 @@ int icgh_backend_solve_batch(int W, const int32_t *fac_off, const int32_t *pose_
                 solver.addResidualBlock(ww, std::make_shared<PosePriorFactor>(prior_poses + 7 * ((size_t) pose_off[w] + k), prior_weight), nullptr,
                                         {P + 7 * (size_t) k});
         }
+        if (!solver.prepare()) {
+            set_err(err, errlen, solver.error().c_str());
+            return -5;
+        }
         auto t0 = std::chrono::steady_clock::now();
         WindowSolverBatch::Options opt;
         vector<WindowSolverBatch::Summary> s1, s2;

@@ -4,7 +4,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
+#include <thread>
 
 #include "../../include/icgvins_hip.h"
 
@@ -13,7 +18,31 @@ namespace icg {
 using solver_detail::choleskySolve;
 using solver_detail::posePlus;
 
-WindowSolverBatch::WindowSolverBatch(int device, double huber_delta) : huber_(huber_delta) {
+namespace {
+// fn(w) for w in [0, n) on up to `threads` threads (windows are independent; exceptions are not expected from the per-window phases)
+template <typename F> void parallelFor(size_t n, int threads, F &&fn) {
+    if (threads <= 1 || n < 2) {
+        for (size_t w = 0; w < n; w++) fn(w);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            size_t w = next.fetch_add(1);
+            if (w >= n) break;
+            fn(w);
+        }
+    };
+    std::vector<std::thread> th;
+    const int nt = (int) std::min<size_t>((size_t) threads, n);
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
+}
+} // namespace
+
+WindowSolverBatch::WindowSolverBatch(int device, double huber_delta, int host_threads) : huber_(huber_delta) {
+    host_threads_ = host_threads > 0 ? host_threads : (int) std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     icg_ctx_config cfg{};
     cfg.device = device, cfg.width = 64, cfg.height = 64, cfg.n_slots = 1, cfg.max_batch = 1, cfg.max_points = 64;
     if (icg_ctx_create(&cfg, &ctx_) != ICG_OK) throw std::runtime_error(std::string("WindowSolverBatch: ") + icg_last_error(nullptr));
@@ -110,6 +139,8 @@ bool WindowSolverBatch::finalize() {
     return true;
 }
 
+bool WindowSolverBatch::prepare() { return finalized_ || finalize(); }
+
 bool WindowSolverBatch::layout() {
     P_ = 0;
     col_pose_.assign((size_t) n_poses_, -1);
@@ -163,7 +194,22 @@ void WindowSolverBatch::gather(std::vector<double> &poses, std::vector<double> &
     }
 }
 
+namespace {
+struct BatchClock { // ICG_SOLVER_DEBUG=1: wall time per phase of the lock-step loop
+    bool on = getenv("ICG_SOLVER_DEBUG") != nullptr;
+    double ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::chrono::steady_clock::time_point t;
+    void start() {
+        if (on) t = std::chrono::steady_clock::now();
+    }
+    void stop(int k) {
+        if (on) ms[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+    }
+};
+} // namespace
+
 bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries) {
+    BatchClock clk;
     if (!finalized_ && !finalize()) return false;
     if (!layout()) {
         if (error_.empty()) error_ = "nothing to optimize";
@@ -201,29 +247,33 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
             any_sys |= !st[w].done && (st[w].relinearize || st[w].redamp);
         }
         if (any_lin) {
+            clk.start();
             gather(poses, ext, inv, td);
             if (icg_reproj_eval_windows(ctx_, n_poses_, poses.data(), ext.data(), n_lm_, inv.data(), td.data(), 1, huber_) != ICG_OK)
                 return fail("icg_reproj_eval_windows");
+            clk.stop(0);
         }
         if (any_sys) {
+            clk.start();
             if (icg_reproj_schur_windows(ctx_, P, col_pose_.data(), col_ext_.data(), col_td_.data(), active_.data(), reassemble.data(), damp.data(),
                                          o.min_lm_diagonal, o.max_lm_diagonal, S.data(), s.data(), diag.data(), cost.data()) != ICG_OK)
                 return fail("icg_reproj_schur_windows");
-            for (size_t w = 0; w < NW; w++) {
-                if (st[w].done || !(st[w].relinearize || st[w].redamp)) continue;
+            clk.stop(1);
+            clk.start();
+            std::atomic<int> host_failed{0};
+            parallelFor(NW, host_threads_, [&](size_t w) {
+                if (st[w].done || !(st[w].relinearize || st[w].redamp)) return;
                 Window &W = windows_[w];
                 if (st[w].relinearize) {
                     W.host_S.assign((size_t) P * P, 0.0), W.host_s.assign((size_t) P, 0.0), W.host_diag.assign((size_t) P, 0.0);
                     double hc = 0;
                     if (!solver_detail::hostFactors(W.blocks, W.block_of, W.residuals, P, W.host_S.data(), W.host_s.data(), W.host_diag.data(), &hc)) {
-                        error_ = "a host cost function failed to evaluate";
-                        return false;
+                        host_failed++;
+                        return;
                     }
-                    if (first || st[w].stepped) {
-                        // the cost at the linearization point: on the first pass it initialises the window, afterwards it equals the
-                        // accepted trial cost and is kept (bit-identical bookkeeping with WindowSolver)
-                        if (first) st[w].cost = cost[w] + hc, sum[w].initial_cost = st[w].cost;
-                    }
+                    // the cost at the linearization point initialises the window on the first pass; afterwards it equals the accepted
+                    // trial cost and is kept (the same bookkeeping as WindowSolver)
+                    if (first) st[w].cost = cost[w] + hc, sum[w].initial_cost = st[w].cost;
                 }
                 st[w].S.assign(S.begin() + (long) (w * P * P), S.begin() + (long) ((w + 1) * P * P));
                 st[w].s.assign(s.begin() + (long) (w * P), s.begin() + (long) ((w + 1) * P));
@@ -231,19 +281,24 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
                 for (size_t k = 0; k < st[w].S.size(); k++) st[w].S[k] += W.host_S[k];
                 for (int k = 0; k < P; k++) st[w].s[(size_t) k] += W.host_s[(size_t) k], st[w].diag[(size_t) k] += W.host_diag[(size_t) k];
                 st[w].relinearize = st[w].redamp = false;
+            });
+            if (host_failed.load()) {
+                error_ = "a host cost function failed to evaluate";
+                return false;
             }
+            clk.stop(2);
         }
         first = false;
         // ---- every open window: iteration budget, gradient test, reduced solve ----------------------------------------------------
-        bool any_step = false;
+        clk.start();
         std::fill(delta_c.begin(), delta_c.end(), 0.0);
-        for (size_t w = 0; w < NW; w++) {
+        parallelFor(NW, host_threads_, [&](size_t w) {
             State &T = st[w];
             T.stepped = false;
-            if (T.done) continue;
+            if (T.done) return;
             if (T.iters >= o.max_num_iterations) {
                 T.done = true;
-                continue;
+                return;
             }
             T.iters++;
             double gmax = 0;
@@ -251,42 +306,44 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
             if (gmax < o.gradient_tolerance) {
                 sum[w].termination = "gradient_tolerance";
                 T.done             = true;
-                continue;
+                return;
             }
-            std::vector<double> A(T.S);
-            T.delta_c = T.s;
             T.dd.assign((size_t) P, 0.0);
             const int Pw = windows_[w].P; // columns beyond Pw are empty (zero rows): solve the leading block only
-            for (int k = 0; k < Pw; k++) {
-                T.dd[(size_t) k] = std::min(std::max(T.diag[(size_t) k], o.min_lm_diagonal), o.max_lm_diagonal) / T.radius;
-                A[(size_t) k * P + k] += T.dd[(size_t) k];
-            }
             std::vector<double> Ab((size_t) Pw * Pw), bb(T.s.begin(), T.s.begin() + Pw);
             for (int i = 0; i < Pw; i++)
-                for (int j = 0; j < Pw; j++) Ab[(size_t) i * Pw + j] = A[(size_t) i * P + j];
+                for (int j = 0; j < Pw; j++) Ab[(size_t) i * Pw + j] = T.S[(size_t) i * P + j];
+            for (int k = 0; k < Pw; k++) {
+                T.dd[(size_t) k] = std::min(std::max(T.diag[(size_t) k], o.min_lm_diagonal), o.max_lm_diagonal) / T.radius;
+                Ab[(size_t) k * Pw + k] += T.dd[(size_t) k];
+            }
             if (!choleskySolve(Pw, Ab, bb)) {
                 T.radius /= T.dec, T.dec *= 2.0;
                 sum[w].num_unsuccessful_steps++;
                 T.redamp = true;
                 if (T.radius < o.min_trust_region_radius) sum[w].termination = "min_trust_region_radius", T.done = true;
-                continue;
+                return;
             }
-            std::fill(T.delta_c.begin(), T.delta_c.end(), 0.0);
+            T.delta_c.assign((size_t) P, 0.0);
             std::copy(bb.begin(), bb.end(), T.delta_c.begin());
             std::copy(T.delta_c.begin(), T.delta_c.end(), delta_c.begin() + (long) (w * P));
             T.stepped = true;
-            any_step  = true;
-        }
+        });
+        bool any_step = false;
+        for (size_t w = 0; w < NW; w++) any_step |= st[w].stepped;
+        clk.stop(3);
         bool all_done = true;
         for (size_t w = 0; w < NW; w++) all_done &= st[w].done;
         if (all_done) break;
         if (!any_step) continue; // only re-damping this round
         // ---- landmark back-substitution for all windows, model decrease, trial points ---------------------------------------------
+        clk.start();
         if (n_lm_ > 0 && icg_reproj_backsub_windows(ctx_, P, delta_c.data(), delta_l.data(), terms.data()) != ICG_OK) return fail("icg_reproj_backsub_windows");
-        bool any_trial = false;
-        for (size_t w = 0; w < NW; w++) {
+        clk.stop(4);
+        clk.start();
+        parallelFor(NW, host_threads_, [&](size_t w) {
             State &T = st[w];
-            if (!T.stepped) continue;
+            if (!T.stepped) return;
             Window &W = windows_[w];
             double t0 = terms[2 * w], t1 = terms[2 * w + 1];
             for (int k = 0; k < P; k++) t0 += T.delta_c[(size_t) k] * T.s[(size_t) k], t1 += T.dd[(size_t) k] * T.delta_c[(size_t) k] * T.delta_c[(size_t) k];
@@ -296,7 +353,7 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
                 sum[w].num_unsuccessful_steps++;
                 T.redamp = true, T.stepped = false;
                 if (T.radius < o.min_trust_region_radius) sum[w].termination = "min_trust_region_radius", T.done = true;
-                continue;
+                return;
             }
             double dn = 0, xn = 0;
             for (double v : T.delta_c) dn += v * v;
@@ -307,7 +364,7 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
             if (std::sqrt(dn) <= o.parameter_tolerance * (std::sqrt(xn) + o.parameter_tolerance)) {
                 sum[w].termination = "parameter_tolerance";
                 T.done = true, T.stepped = false;
-                continue;
+                return;
             }
             W.saved.resize(W.blocks.size());
             for (size_t k = 0; k < W.blocks.size(); k++) W.saved[k].assign(W.blocks[k].values, W.blocks[k].values + W.blocks[k].size);
@@ -320,21 +377,27 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
                     for (int k = 0; k < b.size; k++) b.values[k] += d[k];
             }
             for (size_t k = 0; k < W.landmarks.size(); k++) *W.landmarks[k] += delta_l[(size_t) W.lm_begin + k];
-            any_trial = true;
-        }
+        });
+        bool any_trial = false;
+        for (size_t w = 0; w < NW; w++) any_trial |= st[w].stepped;
+        clk.stop(5);
         if (!any_trial) continue;
+        clk.start();
         gather(poses, ext, inv, td);
         if (icg_reproj_eval_windows(ctx_, n_poses_, poses.data(), ext.data(), n_lm_, inv.data(), td.data(), 0, huber_) != ICG_OK)
             return fail("icg_reproj_eval_windows");
         if (icg_reproj_cost_windows(ctx_, active_.data(), cost.data()) != ICG_OK) return fail("icg_reproj_cost_windows");
-        for (size_t w = 0; w < NW; w++) {
+        clk.stop(6);
+        clk.start();
+        std::atomic<int> trial_failed{0};
+        parallelFor(NW, host_threads_, [&](size_t w) {
             State &T = st[w];
-            if (!T.stepped) continue;
-            Window &W   = windows_[w];
-            double hc   = 0;
+            if (!T.stepped) return;
+            Window &W = windows_[w];
+            double hc = 0;
             if (!solver_detail::hostFactors(W.blocks, W.block_of, W.residuals, P, nullptr, nullptr, nullptr, &hc)) {
-                error_ = "a host cost function failed to evaluate";
-                return false;
+                trial_failed++;
+                return;
             }
             T.new_cost       = cost[w] + hc;
             const double rho = (T.cost - T.new_cost) / T.model;
@@ -357,8 +420,17 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
                 T.redamp = true;
                 if (T.radius < o.min_trust_region_radius) sum[w].termination = "min_trust_region_radius", T.done = true;
             }
+        });
+        if (trial_failed.load()) {
+            error_ = "a host cost function failed to evaluate";
+            return false;
         }
+        clk.stop(7);
     }
+    if (clk.on)
+        fprintf(stderr, "[WindowSolverBatch] %zu windows: eval+jac %.2f, schur %.2f, host linearize %.2f, reduced solves %.2f, backsub %.2f, model+apply %.2f, "
+                        "trial eval+cost %.2f, trial host %.2f ms\n",
+                NW, clk.ms[0], clk.ms[1], clk.ms[2], clk.ms[3], clk.ms[4], clk.ms[5], clk.ms[6], clk.ms[7]);
     for (size_t w = 0; w < NW; w++) sum[w].final_cost = st[w].cost;
     if (summaries) *summaries = sum;
     return true;

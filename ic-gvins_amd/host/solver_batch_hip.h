@@ -21,7 +21,8 @@ public:
     typedef WindowSolver::Options Options;
     typedef WindowSolver::Summary Summary;
 
-    explicit WindowSolverBatch(int device = 0, double huber_delta = 1.0);
+    // host_threads: the per-window host phases (host factors, reduced solves, cost bookkeeping) are spread over this many threads
+    explicit WindowSolverBatch(int device = 0, double huber_delta = 1.0, int host_threads = 0 /* 0 = hardware concurrency, at most 16 */);
     ~WindowSolverBatch();
     WindowSolverBatch(const WindowSolverBatch &) = delete;
     WindowSolverBatch &operator=(const WindowSolverBatch &) = delete;
@@ -35,6 +36,8 @@ public:
     // read from `factor`); all factors of a window share its extrinsic and td blocks
     void addReprojectionFactor(int w, const ReprojectionFactor *factor, double *pose_i, double *pose_j, double *extrinsic, double *invdepth, double *td);
 
+    // uploads the factor set and the window partition (done by the first solve() otherwise): problem setup, not part of a solve
+    bool prepare();
     bool solve(const Options &options, std::vector<Summary> *summaries);
     // removeReprojectionFactorsByChi2 (ic_gvins.cc:1269-1297) for every window; returns the number removed per window
     std::vector<int> removeReprojectionFactorsByChi2(double chi2);
@@ -66,6 +69,7 @@ private:
 
     icg_ctx *ctx_{nullptr};
     double huber_;
+    int host_threads_;
     std::vector<Window> windows_;
     std::vector<uint8_t> active_;
     std::vector<int32_t> col_pose_, col_ext_, col_td_;
