@@ -572,21 +572,33 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
         memcpy(pbc.R.m, pose_b_c12, sizeof(double) * 9);
         memcpy(pbc.t.v, pose_b_c12 + 9, sizeof(double) * 3);
         icg_ctx *ctx = b->tb->group(0).device()->ctx();
+        const bool lockstep = getenv("ICG_REFINE_PER_STREAM") == nullptr; // default: all streams' windows in ONE WindowSolverBatch
+        vector<std::unique_ptr<VisualWindow>> wins;
+        vector<vector<vector<double>>> priors((size_t) n);
+        vector<int> slot((size_t) n, -1);
+        WindowSolverBatch batch(0, 1.0);
         for (int s = 0; s < n; s++) {
             auto &S = b->tb->stream(s);
             double *o = out7 + 7 * (size_t) s;
             for (int k = 0; k < 7; k++) o[k] = 0;
-            VisualWindow win(S.camera, S.map, pbc, td, reprojection_error_std);
+            wins.emplace_back(new VisualWindow(S.camera, S.map, pbc, td, reprojection_error_std));
+            VisualWindow &win = *wins.back();
             win.build();
             o[0] = win.numKeyFrames(), o[1] = win.numFactors();
-            if (win.numKeyFrames() >= 2 && win.numFactors() > 0) {
+            if (win.numKeyFrames() < 2 || win.numFactors() == 0) continue;
+            priors[(size_t) s].resize((size_t) win.numKeyFrames());
+            for (int k = 0; k < win.numKeyFrames(); k++) priors[(size_t) s][(size_t) k].assign(win.pose(k), win.pose(k) + 7);
+            if (lockstep) {
+                slot[(size_t) s] = batch.addWindow();
+                win.addTo(batch, slot[(size_t) s]);
+                for (int k = 0; k < win.numKeyFrames(); k++)
+                    batch.addResidualBlock(slot[(size_t) s], std::make_shared<PosePriorFactor>(priors[(size_t) s][(size_t) k].data(), prior_weight), nullptr,
+                                           {win.pose(k)});
+            } else {
                 WindowSolver solver(win.batch(), 1.0);
                 win.addTo(solver);
-                vector<vector<double>> prior((size_t) win.numKeyFrames());
-                for (int k = 0; k < win.numKeyFrames(); k++) {
-                    prior[(size_t) k].assign(win.pose(k), win.pose(k) + 7);
-                    solver.addResidualBlock(std::make_shared<PosePriorFactor>(prior[(size_t) k].data(), prior_weight), nullptr, {win.pose(k)});
-                }
+                for (int k = 0; k < win.numKeyFrames(); k++)
+                    solver.addResidualBlock(std::make_shared<PosePriorFactor>(priors[(size_t) s][(size_t) k].data(), prior_weight), nullptr, {win.pose(k)});
                 WindowSolver::Options opt;
                 WindowSolver::Summary s1, s2;
                 opt.max_num_iterations = iters1;
@@ -604,25 +616,60 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
                     }
                     o[3] = s2.final_cost;
                 }
-                win.updateParametersFromOptimizer();
-                vector<WindowCulling::Stream> one = {{S.map, &win.invdepthlist()}};
-                vector<CullingResult> R;
-                std::string e;
-                if (!WindowCulling::gvinsOutlierCulling(ctx, one, reprojection_error_std, R, &e)) {
-                    set_err(err, errlen, e.c_str());
-                    return -4;
-                }
-                o[5] = R[0].outlier_mappoints, o[6] = R[0].outlier_features;
             }
-            if (kf_out)
-                for (int k = 0; k < std::min(max_kf, win.numKeyFrames()); k++) {
+        }
+        if (lockstep && batch.numWindows() > 0) {
+            WindowSolverBatch::Options opt;
+            vector<WindowSolverBatch::Summary> s1, s2;
+            opt.max_num_iterations = iters1;
+            if (!batch.solve(opt, &s1)) {
+                set_err(err, errlen, batch.error().c_str());
+                return -2;
+            }
+            vector<int> removed((size_t) batch.numWindows(), 0);
+            if (chi2 > 0) {
+                removed                = batch.removeReprojectionFactorsByChi2(chi2);
+                opt.max_num_iterations = iters2;
+                if (!batch.solve(opt, &s2)) {
+                    set_err(err, errlen, batch.error().c_str());
+                    return -3;
+                }
+            }
+            for (int s = 0; s < n; s++) {
+                if (slot[(size_t) s] < 0) continue;
+                double *o = out7 + 7 * (size_t) s;
+                const size_t w = (size_t) slot[(size_t) s];
+                o[2] = s1[w].initial_cost, o[3] = chi2 > 0 ? s2[w].final_cost : s1[w].final_cost, o[4] = removed[w];
+            }
+        }
+        // write-back and culling (all streams' observations in one launch)
+        vector<WindowCulling::Stream> cull;
+        vector<int> cull_stream;
+        for (int s = 0; s < n; s++) {
+            if (wins[(size_t) s]->numKeyFrames() < 2 || wins[(size_t) s]->numFactors() == 0) continue;
+            wins[(size_t) s]->updateParametersFromOptimizer();
+            cull.push_back({b->tb->stream(s).map, &wins[(size_t) s]->invdepthlist()});
+            cull_stream.push_back(s);
+        }
+        vector<CullingResult> R;
+        std::string e;
+        if (!cull.empty() && !WindowCulling::gvinsOutlierCulling(ctx, cull, reprojection_error_std, R, &e)) {
+            set_err(err, errlen, e.c_str());
+            return -4;
+        }
+        for (size_t k = 0; k < cull_stream.size(); k++) {
+            double *o = out7 + 7 * (size_t) cull_stream[k];
+            o[5] = R[k].outlier_mappoints, o[6] = R[k].outlier_features;
+        }
+        if (kf_out)
+            for (int s = 0; s < n; s++)
+                for (int k = 0; k < std::min(max_kf, wins[(size_t) s]->numKeyFrames()); k++) {
                     double *r = kf_out + 14 * ((size_t) s * max_kf + k);
-                    r[0] = win.frame(k)->stamp(), r[1] = (double) win.frame(k)->id();
-                    Pose p = win.frame(k)->pose();
+                    r[0] = wins[(size_t) s]->frame(k)->stamp(), r[1] = (double) wins[(size_t) s]->frame(k)->id();
+                    Pose p = wins[(size_t) s]->frame(k)->pose();
                     memcpy(r + 2, p.R.m, sizeof(double) * 9);
                     memcpy(r + 11, p.t.v, sizeof(double) * 3);
                 }
-        }
         return 0;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());

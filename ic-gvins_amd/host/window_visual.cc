@@ -64,7 +64,7 @@ VisualWindow::VisualWindow(Camera::Ptr camera, Map::Ptr map, const Pose &pose_b_
       std_(reprojection_error_std / camera_->focalLength()) /* optimize_reprojection_error_std_, ic_gvins.cc:141 */ {}
 
 void VisualWindow::build() {
-    frames_.clear(), index_of_.clear(), poses_.clear(), invdepthlist_.clear(), factors_.clear();
+    frames_.clear(), index_of_.clear(), poses_.clear(), invdepthlist_.clear(), factors_.clear(), factor_blocks_.clear();
     batch_.reset(new ReprojectionBatch(0));
     for (ulong id : map_->orderedKeyFrames()) { // statedatalist_ is time ordered like the keyframe ids
         auto frame = map_->keyframes().at(id);
@@ -120,6 +120,7 @@ void VisualWindow::build() {
             factors_.emplace_back(new ReprojectionFactor(ref_frame_pc, obs_frame_pc, ref_feature->velocityInPixel(), obs_feature->velocityInPixel(),
                                                          ref_frame->timeDelay(), obs_frame->timeDelay(), std_));
             batch_->add(factors_.back().get(), pose(ri->second), pose(oi->second), extrinsic_, invdepth, &extrinsic_[7]);
+            factor_blocks_.push_back({pose(ri->second), pose(oi->second), invdepth});
         }
     }
     batch_->finalize();
@@ -132,6 +133,18 @@ void VisualWindow::addTo(WindowSolver &solver, bool estimate_extrinsic, bool est
     solver.addParameterBlock(&extrinsic_[7], 1);
     if (!estimate_extrinsic) solver.setParameterBlockConstant(extrinsic_);
     if (!estimate_td) solver.setParameterBlockConstant(&extrinsic_[7]);
+}
+
+void VisualWindow::addTo(WindowSolverBatch &solver, int w, bool estimate_extrinsic, bool estimate_td) {
+    for (int k = 0; k < numKeyFrames(); k++) solver.addParameterBlock(w, pose(k), 7, true);
+    for (auto &kv : invdepthlist_) solver.addParameterBlock(w, &kv.second, 1);
+    solver.addParameterBlock(w, extrinsic_, 7, true);
+    solver.addParameterBlock(w, &extrinsic_[7], 1);
+    if (!estimate_extrinsic) solver.setParameterBlockConstant(w, extrinsic_);
+    if (!estimate_td) solver.setParameterBlockConstant(w, &extrinsic_[7]);
+    for (size_t f = 0; f < factors_.size(); f++)
+        solver.addReprojectionFactor(w, factors_[f].get(), factor_blocks_[f].pose_i, factor_blocks_[f].pose_j, extrinsic_, factor_blocks_[f].invdepth,
+                                     &extrinsic_[7]);
 }
 
 void VisualWindow::updateParametersFromOptimizer() { // :1347-1391

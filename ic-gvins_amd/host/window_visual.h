@@ -14,6 +14,7 @@
 
 #include "factors.h"
 #include "model.h"
+#include "solver_batch_hip.h"
 #include "solver_hip.h"
 
 namespace icg {
@@ -26,6 +27,8 @@ public:
     void build();
     // parameter blocks + reprojection batch into a solver; extrinsic and td constant unless asked otherwise (:1748-1759)
     void addTo(WindowSolver &solver, bool estimate_extrinsic = false, bool estimate_td = false);
+    // the same into window w of a WindowSolverBatch (many streams per launch): blocks and reprojection factors
+    void addTo(WindowSolverBatch &solver, int w, bool estimate_extrinsic = false, bool estimate_td = false);
     ReprojectionBatch *batch() { return batch_.get(); }
     // write the optimized states back into the map (:1347-1391)
     void updateParametersFromOptimizer();
@@ -52,6 +55,10 @@ private:
     double extrinsic_[8];
     std::unordered_map<ulong, double> invdepthlist_;
     std::vector<std::unique_ptr<ReprojectionFactor>> factors_;
+    struct FactorBlocks {
+        double *pose_i, *pose_j, *invdepth;
+    };
+    std::vector<FactorBlocks> factor_blocks_; // the blocks each factor was registered with (for WindowSolverBatch)
     std::unique_ptr<ReprojectionBatch> batch_;
 };
 
