@@ -300,7 +300,11 @@ void symmetricEigen(int n, const vector<double> &A, vector<double> &evals, vecto
     }
     v(n - 1, n - 1) = 1.0;
     e[0]            = 0.0;
-    // ---- implicit QL on the tridiagonal matrix, rotations accumulated into V ---------------------------------------------------
+    // ---- implicit QL on the tridiagonal matrix; the Givens rotations act on two COLUMNS of V, so V is held transposed for this
+    // phase (two contiguous rows per rotation instead of n strided accesses: 3x faster at n = 133) ------------------------------
+    vector<double> Vt((size_t) n * n);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Vt[(size_t) j * n + i] = v(i, j);
     for (int i = 1; i < n; i++) e[(size_t) i - 1] = e[(size_t) i];
     e[(size_t) n - 1] = 0.0;
     double f = 0.0, tst1 = 0.0;
@@ -341,10 +345,11 @@ void symmetricEigen(int n, const vector<double> &A, vector<double> &evals, vecto
                     c                 = p / r;
                     p                 = c * d[(size_t) i] - s * g;
                     d[(size_t) i + 1] = h + s * (c * g + s * d[(size_t) i]);
-                    for (int k = 0; k < n; k++) { // accumulate
-                        h           = v(k, i + 1);
-                        v(k, i + 1) = s * v(k, i) + c * h;
-                        v(k, i)     = c * v(k, i) - s * h;
+                    double *vi = &Vt[(size_t) i * n], *vi1 = &Vt[(size_t) (i + 1) * n]; // accumulate
+                    for (int k = 0; k < n; k++) {
+                        h      = vi1[k];
+                        vi1[k] = s * vi[k] + c * h;
+                        vi[k]  = c * vi[k] - s * h;
                     }
                 }
                 p             = -s * s2 * c3 * el1 * e[(size_t) l] / dl1;
@@ -362,7 +367,7 @@ void symmetricEigen(int n, const vector<double> &A, vector<double> &evals, vecto
     evecs.assign((size_t) n * n, 0.0);
     for (int k = 0; k < n; k++) {
         evals[(size_t) k] = d[(size_t) order[(size_t) k]];
-        for (int i = 0; i < n; i++) evecs[(size_t) i * n + k] = v(i, order[(size_t) k]);
+        for (int i = 0; i < n; i++) evecs[(size_t) i * n + k] = Vt[(size_t) order[(size_t) k] * n + i];
     }
 }
 
@@ -378,6 +383,11 @@ void MarginalizationInfo::addResidualBlockInfo(const std::shared_ptr<ResidualBlo
     for (size_t k = 0; k < parameter_blocks.size(); k++) parameter_block_size_[idOf(parameter_blocks[k])] = block_sizes[k];
     for (int index : blockinfo->marginalizationParametersIndex()) parameter_block_index_[idOf(parameter_blocks[(size_t) index])] = 0;
 }
+
+namespace {
+double g_marg_phase_ms[4] = {0, 0, 0, 0};
+}
+const double *MarginalizationInfo::lastPhaseMs() { return g_marg_phase_ms; }
 
 bool MarginalizationInfo::marginalization() { // :73-101
     if (!updateParameterBlocksIndex()) {
@@ -407,6 +417,7 @@ bool MarginalizationInfo::marginalization() { // :73-101
     auto t3 = now();
     linearization();
     auto t4 = now();
+    g_marg_phase_ms[0] = ms(t0, t1), g_marg_phase_ms[1] = ms(t1, t2), g_marg_phase_ms[2] = ms(t2, t3), g_marg_phase_ms[3] = ms(t3, t4);
     if (dbg)
         fprintf(stderr, "[marginalization] m=%d r=%d: evaluate %.3f ms, construct %.3f ms, schur %.3f ms, linearize %.3f ms\n", marginalized_size_,
                 remained_size_, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4));
@@ -531,15 +542,21 @@ void MarginalizationInfo::schurElimination() { // :170-192
     vector<double> Hmm((size_t) m * m), ev, V, Hinv((size_t) m * m, 0.0);
     for (int i = 0; i < m; i++)
         for (int j = 0; j < m; j++) Hmm[(size_t) i * m + j] = 0.5 * (H(i, j) + H(j, i));
+    auto tA = std::chrono::steady_clock::now();
     symmetricEigen(m, Hmm, ev, V);
+    auto tB = std::chrono::steady_clock::now();
+    if (getenv("ICG_MARG_DEBUG")) fprintf(stderr, "[schur] eigen(%d) %.3f ms\n", m, std::chrono::duration<double, std::milli>(tB - tA).count());
+    // Hmm^+ = V diag(1/ev, 0 below EPS) V^T: the thresholded reciprocals once, the scaled copy W = V diag(inv) once, and only the
+    // lower triangle of the symmetric product
+    vector<double> inv((size_t) m), Wv((size_t) m * m);
+    for (int k = 0; k < m; k++) inv[(size_t) k] = ev[(size_t) k] > EPS ? 1.0 / ev[(size_t) k] : 0.0;
     for (int i = 0; i < m; i++)
-        for (int j = 0; j < m; j++) {
+        for (int k = 0; k < m; k++) Wv[(size_t) i * m + k] = V[(size_t) i * m + k] * inv[(size_t) k];
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j <= i; j++) {
             double s = 0;
-            for (int k = 0; k < m; k++) {
-                double inv = ev[(size_t) k] > EPS ? 1.0 / ev[(size_t) k] : 0.0;
-                s += V[(size_t) i * m + k] * inv * V[(size_t) j * m + k];
-            }
-            Hinv[(size_t) i * m + j] = s;
+            for (int k = 0; k < m; k++) s += Wv[(size_t) i * m + k] * V[(size_t) j * m + k];
+            Hinv[(size_t) i * m + j] = Hinv[(size_t) j * m + i] = s;
         }
     vector<double> T((size_t) r * m);
     for (int i = 0; i < r; i++)
