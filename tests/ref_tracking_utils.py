@@ -59,6 +59,9 @@ SCENARIOS = {  # name -> (w, h, n_frames, max_features, stream, check_hist)
     "c4_1920x1080_500": (1920, 1080, 10, 500, 5, False),
     # three-channel input: the BGR->gray conversion in front of everything else (tracking.cc:135-137, F1)
     "c1_bgr": (640, 480, 14, 100, 6, False),
+    # long runs: many keyframe decisions, window roll-over several times, rare branches (edge features, quota corner cases)
+    "c1_long_160": (640, 480, 160, 100, 7, False),
+    "c2_long_60": (1280, 720, 60, 300, 8, True),
 }
 BGR_SCENARIOS = ("c1_bgr",)
 

@@ -35,7 +35,7 @@ def test_multi_stream_batch_on_gpu_equals_oracle():
         assert stats_o[s]["digest"] == stats_g[s]["digest"], s
 
 
-@pytest.mark.parametrize("scenario", ["c1_640x480_100", "c2_1280x720_300", "c1_histgate", "c1_lost_and_reinit", "c1_lost_histgate", "c1_slow_second_new", "c4_1920x1080_500", "c1_bgr"])
+@pytest.mark.parametrize("scenario", ["c1_640x480_100", "c2_1280x720_300", "c1_histgate", "c1_lost_and_reinit", "c1_lost_histgate", "c1_slow_second_new", "c4_1920x1080_500", "c1_bgr", "c1_long_160", "c2_long_60"])
 def test_gpu_host_layer_matches_reference_tracker_golden(scenario):
     """icg::Tracking on the HIP kernels vs what the REFERENCE's own tracking.cc produced on the oracle primitives
     (tests/golden/tracking_ref_*.npz): track states, map-point ids, key-point float bits, window bookkeeping per frame."""

@@ -51,7 +51,7 @@ def test_batch_equals_individual_streams():
     assert stats_b[0]["digest"] != stats_b[1]["digest"]
 
 
-@pytest.mark.parametrize("scenario", ["c1_640x480_100", "c2_1280x720_300", "c1_histgate", "c1_lost_and_reinit", "c1_lost_histgate", "c1_slow_second_new", "c4_1920x1080_500", "c1_bgr"])
+@pytest.mark.parametrize("scenario", ["c1_640x480_100", "c2_1280x720_300", "c1_histgate", "c1_lost_and_reinit", "c1_lost_histgate", "c1_slow_second_new", "c4_1920x1080_500", "c1_bgr", "c1_long_160", "c2_long_60"])
 def test_host_layer_matches_reference_tracker_golden(scenario):
     """The product's host layer (icg::Tracking on the oracle primitives) reproduces, frame by frame and bit for bit, what the
     REFERENCE's own tracking.cc produced on the same primitives (tests/golden/tracking_ref_*.npz, generator
