@@ -7,6 +7,10 @@
 // doubles of each factor transposed through LDS (row stride 49 to spread banks) so a 64-factor wave writes its
 // r[64x2] and J[64x46] slabs as contiguous 16-B-per-lane stores.
 // Algorithmic bytes per factor with Jacobians: 120 (obs) + 12 (indices) + 384 (out) = 516 B.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "dev_math.h"
 #include "icg_internal.h"
 
@@ -1057,6 +1061,9 @@ extern "C" int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_
                                         const uint8_t *active, const uint8_t *reassemble, const double *damp, double min_diag, double max_diag,
                                         double *S, double *s, double *diag_cc, double *cost) {
     if (!ctx || P <= 0 || !col_pose || !col_ext || !col_td || !reassemble || !damp || !S || !s) return ICG_ERR_INVALID;
+    const bool tdbg = getenv("ICG_ABI_DEBUG") != nullptr;
+    auto tnow       = [] { return std::chrono::steady_clock::now(); };
+    auto t_begin    = tnow();
     const int W = ctx->n_windows, n = ctx->n_factors_resident;
     if (W <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition: call icg_reproj_set_windows first");
     bool any_new = false;
@@ -1136,6 +1143,7 @@ extern "C" int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_
     const uint8_t *d_act  = active ? c.in(active, (size_t) n) : nullptr;
     std::vector<double> zeros((size_t) W, 0.0);
     double *d_cost = c.inout(zeros.data(), any_new ? cost : (double *) nullptr, (size_t) W);
+    auto t_prep = tnow();
     if ((rc = c.seal())) return rc;
     double *d_S  = c.out(S, (size_t) W * P * P);
     double *d_s  = c.out(s, (size_t) W * P);
@@ -1159,7 +1167,17 @@ extern "C" int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_
         }
     }
     ICG_HIP(ctx, hipGetLastError());
+    auto t_launch = tnow();
+    if (tdbg) {
+        (void) hipStreamSynchronize(ctx->stream);
+    }
+    auto t_kernels = tnow();
     if ((rc = c.finish())) return rc;
+    if (tdbg) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[icg_reproj_schur_windows] W=%d: host prep %.3f, h2d+launch %.3f, kernels %.3f, d2h+copy-out %.3f ms\n", W, ms(t_begin, t_prep),
+                ms(t_prep, t_launch), ms(t_launch, t_kernels), ms(t_kernels, tnow()));
+    }
     ctx->wsys_P = P, ctx->wsys_valid = 1;
     ctx->sys_min_diag = min_diag, ctx->sys_max_diag = max_diag;
     return ICG_OK;
