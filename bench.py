@@ -513,6 +513,7 @@ def main():
 
     # ---- CPU baseline of the front-end: same host layer on the CPU restatement (kind "port") ---------------------------
     cpu_baseline = None
+    cpu_baseline_allcores = None
     if rank == 0 and not args.no_cpu_baseline:
         from stream_utils import ensure_oracle_host
         lib = ensure_oracle_host()
@@ -533,6 +534,28 @@ def main():
                         "sample": f"1 stream x {ntime} steady-state frames {w}x{h}/{nfeat} feats after {nwarm} warm-up frames, "
                                   f"oracle-backed host layer, single thread ({ncpu} host cores available)"}
         sbc.close()
+
+        # (b) all usable host cores: the same oracle-backed host layer with one independent stream per core, every
+        # stream on its own executor thread (stream-level parallelism, the decomposition the GPU path itself is filled with)
+        T = int(max(1, min(32, usable_host_cores())))
+        if T > 1:
+            sbm = H.StreamBatch(lib, T, w, h, cam, max_features=nfeat, window=10, groups=T)
+            nwarm, ntime = 30, 30
+
+            def cpu_run(k0, n):
+                ptrs = [[host0[H.pingpong(k0 + i, args.ring)].ctypes.data] * T for i in range(n)]
+                st = [[1000.0 + (k0 + i) / 20.0] * T for i in range(n)]
+                ps = np.stack([np.repeat(poses[0][H.pingpong(k0 + i, args.ring)][None], T, 0) for i in range(n)])
+                sbm.run(ptrs, w, st, ps)
+
+            cpu_run(0, nwarm)
+            t1 = time.perf_counter()
+            cpu_run(nwarm, ntime)
+            dt = time.perf_counter() - t1
+            cpu_baseline_allcores = {"value": round(T * ntime / dt, 3), "unit": "frames/s", "cores": T, "kind": "port",
+                                     "sample": f"{T} independent streams x {ntime} steady-state frames {w}x{h}/{nfeat} feats, oracle-backed host "
+                                               f"layer, one stream group (thread) per usable host core"}
+            sbm.close()
 
     # the REFERENCE's own tracker sources (oracle/_ref/libref_tracking.so: tracking/*.cc compiled unmodified on interface shims, its
     # OpenCV calls forwarded to the oracle primitives) on the same frames: includes the reference's call pattern (the LK pyramids
@@ -592,6 +615,7 @@ def main():
                        "input_residency": "pinned host frames, uploaded per frame (PCIe-inclusive diagnostic)" if args.host_frames else "raw frames in HBM", "sharding": "independent streams per GPU, no data-path collective"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "cpu_baseline_allcores": cpu_baseline_allcores,
             "cpu_baseline_reference_tracker": cpu_reference,
             "speedup_vs_cpu_baseline": (round(fps / cpu_baseline["value"], 2) if cpu_baseline else None),
             "reproj": reproj,
