@@ -1,0 +1,117 @@
+// C entry points of the replay harness and of the small navigation factors (ctypes plumbing for tests / tools; see replay.h, gvins_hip.h,
+// nav_factors.h, earth.h).
+#include <cstring>
+#include <stdexcept>
+
+#include "replay.h"
+
+using namespace icg;
+
+static void set_err(char *err, int errlen, const char *msg) {
+    if (err && errlen > 0) {
+        strncpy(err, msg, (size_t) errlen - 1);
+        err[errlen - 1] = 0;
+    }
+}
+
+extern "C" {
+
+// summary16: imu, gnss, gnss dropped, frames, frames tracked, keyframes, optimizations, marginalizations, INS launches, lost,
+// reprojection factors, chi2-removed factors, final state, wall seconds, data seconds, time nodes (unused = 0)
+int icgh_replay_run(const char *configfile, const char *outputpath, const char *imufile, const char *gnssfile, const char *imagelist, int imu_is_rate,
+                    double start_time, double end_time, double *summary16, char *err, int errlen) {
+    try {
+        ReplayOptions o;
+        o.configfile = configfile ? configfile : "";
+        o.outputpath = outputpath ? outputpath : "";
+        o.imufile    = imufile ? imufile : "";
+        o.gnssfile   = gnssfile ? gnssfile : "";
+        o.imagelist  = imagelist ? imagelist : "";
+        o.imu_is_rate = imu_is_rate != 0;
+        o.start_time = start_time, o.end_time = end_time;
+        ReplaySummary s;
+        std::string e;
+        if (!Replay::run(o, s, &e)) {
+            set_err(err, errlen, e.c_str());
+            return -2;
+        }
+        const double v[16] = {(double) s.imu, (double) s.gnss, (double) s.gnss_dropped, (double) s.frames, (double) s.counters.frames_tracked,
+                              (double) s.counters.keyframes, (double) s.counters.optimizations, (double) s.counters.marginalizations,
+                              (double) s.counters.ins_launches, (double) s.counters.lost, (double) s.counters.reprojection_factors,
+                              (double) s.counters.chi2_removed, (double) s.final_state, s.wall_seconds, s.data_seconds, 0.0};
+        if (summary16) memcpy(summary16, v, sizeof v);
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
+// ---- the small factors and helpers, for the golden comparison with the reference's headers -------------------------------------
+// kind: 0 GnssFactor (aux: blh3, std3, lever3; x: pose7)   1 ImuErrorFactor (x: mix9)   2 ImuPosePriorFactor (aux: pose7, std6; x: pose7)
+//       3 ImuMixPriorFactor (aux: mix9, std9; x: mix9).  J row-major num_residuals x block size.
+int icgh_nav_factor(int kind, const double *aux, const double *x, double *residuals, double *jacobian) {
+    const double *params[1] = {x};
+    double *J[1]            = {jacobian};
+    try {
+        if (kind == 0) {
+            GNSS g;
+            g.blh = Vector3d(aux[0], aux[1], aux[2]);
+            g.std = Vector3d(aux[3], aux[4], aux[5]);
+            return GnssFactor(g, Vector3d(aux[6], aux[7], aux[8])).Evaluate(params, residuals, jacobian ? J : nullptr) ? 0 : 1;
+        } else if (kind == 1) {
+            return ImuErrorFactor().Evaluate(params, residuals, jacobian ? J : nullptr) ? 0 : 1;
+        } else if (kind == 2) {
+            return ImuPosePriorFactor(aux, aux + 7).Evaluate(params, residuals, jacobian ? J : nullptr) ? 0 : 1;
+        } else if (kind == 3) {
+            return ImuMixPriorFactor(aux, aux + 9).Evaluate(params, residuals, jacobian ? J : nullptr) ? 0 : 1;
+        }
+    } catch (const std::exception &) {
+    }
+    return -1;
+}
+
+// what: 0 gravity(blh) -> out[0]   1 global2local(origin=a, global=b) -> out3   2 local2global(origin=a, local=b) -> out3
+//       3 iewn(origin=a, local=b) -> out3   4 euler2quaternion(a) -> out4 (x y z w)   5 matrix2euler(quaternion2matrix(q = a[0..3] xyzw)) -> out3
+//       6 unix2gps(a[0]) -> out[0] = week, out[1] = second of week
+int icgh_nav_helper(int what, const double *a, const double *b, double *out) {
+    Vector3d A(a[0], a[1], a[2]), B = b ? Vector3d(b[0], b[1], b[2]) : Vector3d();
+    Vector3d r;
+    switch (what) {
+    case 0: out[0] = Earth::gravity(A); return 0;
+    case 1: r = Earth::global2local(A, B); break;
+    case 2: r = Earth::local2global(A, B); break;
+    case 3: r = Earth::iewn(A, B); break;
+    case 4: {
+        Quaterniond q = Rotation::euler2quaternion(A);
+        out[0] = q.x, out[1] = q.y, out[2] = q.z, out[3] = q.w;
+        return 0;
+    }
+    case 5: r = Rotation::matrix2euler(Rotation::quaternion2matrix(Quaterniond{a[0], a[1], a[2], a[3]})); break;
+    case 6: {
+        int week;
+        double sow;
+        GpsTime::unix2gps(a[0], week, sow);
+        out[0] = week, out[1] = sow;
+        return 0;
+    }
+    default: return -1;
+    }
+    out[0] = r[0], out[1] = r[1], out[2] = r[2];
+    return 0;
+}
+
+// MISC::detectZeroVelocity on n rows of (dtheta3, dvel3); average6 out; returns 1 / 0
+int icgh_detect_zero_velocity(int n, const double *rows6, double imudatarate, double *average6) {
+    std::vector<IMU> buf((size_t) n);
+    for (int k = 0; k < n; k++) {
+        buf[(size_t) k].dtheta = Vector3d(rows6[6 * k], rows6[6 * k + 1], rows6[6 * k + 2]);
+        buf[(size_t) k].dvel   = Vector3d(rows6[6 * k + 3], rows6[6 * k + 4], rows6[6 * k + 5]);
+    }
+    std::vector<double> avg;
+    bool z = GVINS::detectZeroVelocity(buf, imudatarate, avg);
+    for (int k = 0; k < 6; k++) average6[k] = avg[(size_t) k];
+    return z ? 1 : 0;
+}
+
+} // extern "C"

@@ -1,0 +1,200 @@
+// GVINS — the estimator that calls the hot path from both sides ("replay harness", i.e. the caller the
+// reference's ROS shell feeds): IMU / GNSS / image ingestion, GNSS-aided initialization, INS mechanization window, INS-aided
+// tracking, sliding-window optimization (GNSS + IMU preintegration + reprojection + marginalization prior), chi-square culling,
+// marginalization, result files.  Mirrors the reference's `GVINS` class (ic_gvins.h:44-270, ic_gvins.cc) with the same public
+// surface: GVINS(configfile, outputpath, drawer), addNewImu / addNewGnss / addNewFrame, setFinished, isRunning, gvinsState.
+//
+// What is different, deliberately:
+//   * The reference runs three free-running threads (fusion / tracking / optimization) that hand work over with try_lock and
+//     condition variables, so its output depends on thread timing.  Here the same three loop bodies (runFusion :237-393,
+//     runTracking :479-552, runOptimization :395-477) are executed as ONE deterministic event loop inside addNewImu(): after
+//     every IMU epoch the tracker consumes every frame the INS has passed, then a signalled optimization runs to completion.
+//     That is the schedule the reference follows when tracker and optimizer finish within one IMU period; results are reproducible.
+//   * All floating-point work goes through the device paths of this library: tracking (icg::Tracking), INS mechanization of the
+//     pending epochs as one series launch per event (MISC::insMechanizationBatch, lazily: the state machine only looks at IMU
+//     *times*), pose prior (MISC::getCameraPoseFromInsWindowBatch), preintegration (Preintegration::integrateBatch: all dirty
+//     intervals per launch), window solve with device-side landmark elimination (WindowSolver replaces Ceres LM + DENSE_SCHUR),
+//     culling / statistics (WindowCulling), marginalization assembly (MarginalizationInfo::setReprojectionBatch).  No CPU fallback.
+//   * Function-local statics of the reference (initial attitude / gyro bias of gvinsInitialization :606-608, iteration split of
+//     gvinsOptimization :1131-1132) are members, so several estimators can live in one process (one per camera stream).
+// Parity: the solver is unpinned (Ceres is an absent dependency); the small factors and Earth / attitude helpers are
+// pinned against the reference's headers (tests/golden/nav_ref_golden.npz); behaviour is checked end to end on a synthetic
+// GNSS + IMU + camera sequence with known truth (tests/gvins_checks.py).
+#pragma once
+#include <deque>
+#include <memory>
+#include <queue>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "culling_hip.h"
+#include "factors.h"
+#include "misc_hip.h"
+#include "nav_factors.h"
+#include "solver_hip.h"
+#include "tracking.h"
+
+namespace icg {
+
+struct IntegrationStateData { // preintegration/integration_state.h:54-60
+    double time{0};
+    double pose[7]{0, 0, 0, 0, 0, 0, 1};
+    double mix[18]{0};
+};
+
+class GVINS {
+public:
+    enum GVINSState { // ic_gvins.h:47-55
+        GVINS_ERROR                 = -1,
+        GVINS_INITIALIZING          = 0,
+        GVINS_INITIALIZING_INS      = 1,
+        GVINS_INITIALIZING_VIO      = 2,
+        GVINS_TRACKING_INITIALIZING = 3,
+        GVINS_TRACKING_NORMAL       = 4,
+        GVINS_TRACKING_LOST         = 5,
+    };
+    typedef std::shared_ptr<GVINS> Ptr;
+
+    GVINS() = delete;
+    explicit GVINS(const std::string &configfile, const std::string &outputpath, Drawer::Ptr drawer = nullptr, int device = 0);
+    ~GVINS();
+
+    bool addNewImu(const IMU &imu);
+    bool addNewGnss(const GNSS &gnss);
+    bool addNewFrame(const Frame::Ptr &frame);
+    void setFinished();
+    bool isRunning() const { return !isfinished_; }
+    GVINSState gvinsState() const { return gvinsstate_; }
+
+    // ---- read-only views for the replay harness and the tests ----
+    struct Counters {
+        long imu{0}, gnss{0}, frames_tracked{0}, keyframes{0}, optimizations{0}, marginalizations{0}, ins_launches{0}, lost{0};
+        long reprojection_factors{0}, chi2_removed{0};
+    };
+    const Counters &counters() const { return counters_; }
+    const std::string &error() const { return error_; }
+    size_t numTimeNodes() const { return timelist_.size(); }
+    const Map::Ptr &map() const { return map_; }
+    Pose extrinsic() const { return pose_b_c_; }
+    double timeDelay() const { return td_b_c_; }
+    // latest mechanized INS state (flushes pending epochs)
+    bool latestState(IntegrationState &state);
+
+    static IntegrationStateData stateToData(const IntegrationState &state);
+    static IntegrationState stateFromData(const IntegrationStateData &data);
+    // MISC::detectZeroVelocity (misc.cc:363-415)
+    static bool detectZeroVelocity(const std::vector<IMU> &imu_buffer, double imudatarate, std::vector<double> &average);
+
+private:
+    // ---- the three loop bodies of the reference, run from addNewImu / addNewFrame ----
+    void fusionStep(const IMU &imu);
+    void processTracking();
+    void runOptimizationOnce();
+
+    void flushIns();
+    void parametersStatistic();
+    bool gvinsInitialization();
+    bool gvinsInitializationOptimization();
+    void addNewTimeNode(double time);
+    void addNewGnssTimeNode();
+    bool insertNewGnssTimeNode();
+    void addNewKeyFrameTimeNode();
+    bool removeUnusedTimeNode();
+    void constructPrior(bool is_zero_velocity);
+
+    void addStateParameters(WindowSolver &problem);
+    void addReprojectionParameters();
+    void registerReprojectionBlocks(WindowSolver &problem);
+    void addImuFactors(WindowSolver &problem);
+    std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> addGnssFactors(WindowSolver &problem, bool isusekernel);
+    int addReprojectionFactors();
+    void doReintegration();
+    void updateParametersFromOptimizer();
+    int getStateDataIndex(double time);
+    bool gvinsOptimization();
+    bool gvinsMarginalization();
+    bool gvinsOutlierCulling();
+    bool gvinsRemoveAllSecondNewFrame();
+    void gnssOutlierCullingByChi2(WindowSolver &problem, std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> &residual_block);
+
+    std::shared_ptr<Preintegration> createPreintegration(const IMU &imu0, const IntegrationState &state);
+    void integrate(const std::vector<Preintegration *> &list);
+    void fail(const std::string &what);
+
+private:
+    const double NORMAL_GRAVITY                = 9.80;  // ic_gvins.h:120-141
+    const size_t MAXIMUM_INS_NUMBER            = 1000;
+    const double MINMUM_ALIGN_VELOCITY         = 0.5;
+    const double MINMUM_SYNC_INTERVAL          = 0.025;
+    const double MAXIMUM_PREINTEGRATION_LENGTH = 10.0;
+    const double GYROSCOPE_BIAS_PRIOR_STD      = 7200 * D2R / 3600;
+    const double ACCELEROMETER_BIAS_PRIOR_STD  = 20000 * 1.0e-5;
+
+    std::deque<std::shared_ptr<Preintegration>> preintegrationlist_;
+    std::deque<IntegrationStateData> statedatalist_;
+    std::deque<GNSS> gnsslist_;
+    std::deque<double> timelist_;
+    std::unordered_map<ulong, double> invdepthlist_;
+    double extrinsic_[8]{0};
+    std::vector<double> unused_time_nodes_;
+
+    std::shared_ptr<MarginalizationInfo> last_marginalization_info_;
+    std::vector<double *> last_marginalization_parameter_blocks_;
+
+    bool is_use_prior_{false};
+    double mix_prior_[18], mix_prior_std_[18], pose_prior_[7], pose_prior_std_[6];
+
+    Tracking::Ptr tracking_;
+    Map::Ptr map_;
+    Camera::Ptr camera_;
+    Drawer::Ptr drawer_;
+
+    bool isoptimized_{false}, isfinished_{false}, isgnssready_{false}, isframeready_{false}, isgnssobs_{false}, isvisualobs_{false};
+    bool optimization_signalled_{false};
+
+    std::queue<Frame::Ptr> keyframes_;
+    GNSS gnss_, last_gnss_, last_last_gnss_;
+    std::queue<Frame::Ptr> frame_buffer_;
+    IMU imu_pre_, imu_cur_;
+    InsWindow ins_window_;
+    size_t ins_pending_{0}; // trailing entries of ins_window_ whose state has not been mechanized yet
+
+    std::shared_ptr<IntegrationParameters> integration_parameters_;
+    Preintegration::Variant preintegration_options_{Preintegration::NORMAL};
+    IntegrationConfiguration integration_config_;
+    double imudatarate_{200}, imudatadt_{0.005};
+    size_t reserved_ins_num_{2};
+    Vector3d antlever_;
+    int initlength_{1};
+    Pose pose_b_c_;
+    double td_b_c_{0};
+    bool is_use_visualization_{false};
+    bool optimize_estimate_extrinsic_{false}, optimize_estimate_td_{false};
+    double optimize_reprojection_error_std_{0};
+    int optimize_num_iterations_{20};
+    size_t optimize_windows_size_{10};
+    double reprojection_error_std_{1.5};
+    int first_num_iterations_{5}, second_num_iterations_{15};
+
+    // gvinsInitialization's function-local statics (ic_gvins.cc:606-608)
+    Vector3d init_bg_, init_att_;
+    bool is_has_zero_velocity_{false};
+
+    int iterations_[2]{0, 0};
+    double timecosts_[3]{0, 0, 0};
+    int outliers_[2]{0, 0};
+
+    FileSaver::Ptr navfilesaver_, imuerrfilesaver_, ptsfilesaver_, statfilesaver_, extfilesaver_, trajfilesaver_;
+    GVINSState gvinsstate_{GVINS_ERROR};
+
+    // device side
+    icg_ctx *ctx_{nullptr}; // INS / preintegration / culling launches of this estimator
+    std::unique_ptr<ReprojectionBatch> visual_batch_, marg_batch_;
+    std::vector<std::unique_ptr<ReprojectionFactor>> visual_factors_;
+    std::vector<double *> visual_invdepth_blocks_; // inverse depths with at least one factor, first-seen order
+    Counters counters_;
+    std::string error_;
+};
+
+} // namespace icg

@@ -1,0 +1,214 @@
+// Replay harness: files -> IMU / GNSS / Frame events -> icg::GVINS.  See replay.h.
+#include "replay.h"
+
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "yaml_lite.h"
+
+namespace icg {
+
+namespace {
+bool setErr(std::string *err, const std::string &what) {
+    if (err) *err = what;
+    return false;
+}
+std::string dirOf(const std::string &path) {
+    size_t slash = path.find_last_of('/');
+    return slash == std::string::npos ? std::string(".") : path.substr(0, slash);
+}
+bool readRows(const std::string &path, size_t min_columns, std::vector<std::vector<double>> &rows, std::string *err) {
+    std::ifstream f(path);
+    if (!f) return setErr(err, "cannot open " + path);
+    std::string line;
+    while (std::getline(f, line)) {
+        for (char &c : line)
+            if (c == ',') c = ' ';
+        size_t a = line.find_first_not_of(" \t\r");
+        if (a == std::string::npos || line[a] == '#') continue;
+        std::istringstream ss(line);
+        std::vector<double> row;
+        double v;
+        while (ss >> v) row.push_back(v);
+        if (row.size() < min_columns) return setErr(err, path + ": a line has fewer than " + std::to_string(min_columns) + " columns");
+        rows.push_back(std::move(row));
+    }
+    return true;
+}
+} // namespace
+
+double Replay::toGpsSecondOfWeek(double stamp) {
+    if (stamp < 1.0e9) return stamp;
+    int week;
+    double sow;
+    GpsTime::unix2gps(stamp, week, sow);
+    return sow;
+}
+
+bool Replay::readImuText(const std::string &path, bool is_rate, std::vector<IMU> &out, std::string *err) {
+    std::vector<std::vector<double>> rows;
+    if (!readRows(path, 7, rows, err)) return false;
+    out.clear();
+    IMU imu_pre;
+    imu_pre.time = 0;
+    for (const auto &r : rows) { // imuCallback (fusion_ros.cc:123-162)
+        IMU imu;
+        imu.time  = toGpsSecondOfWeek(r[0]);
+        imu.dt    = imu.time - imu_pre.time;
+        double s  = is_rate ? imu.dt : 1.0;
+        imu.dtheta = Vector3d(r[1] * s, r[2] * s, r[3] * s);
+        imu.dvel   = Vector3d(r[4] * s, r[5] * s, r[6] * s);
+        imu.odovel = 0;
+        bool ready = imu_pre.time != 0; // the first message only initialises dt (:146-148)
+        imu_pre    = imu;
+        if (ready) out.push_back(imu);
+    }
+    return true;
+}
+
+bool Replay::readGnssText(const std::string &path, std::vector<GNSS> &out, std::string *err) {
+    std::vector<std::vector<double>> rows;
+    if (!readRows(path, 7, rows, err)) return false;
+    out.clear();
+    for (const auto &r : rows) { // gnssCallback (fusion_ros.cc:164-199)
+        GNSS g;
+        g.time       = toGpsSecondOfWeek(r[0]);
+        g.blh        = Vector3d(r[1] * D2R, r[2] * D2R, r[3]);
+        g.std        = Vector3d(r[4], r[5], r[6]);
+        g.isyawvalid = false;
+        out.push_back(g);
+    }
+    return true;
+}
+
+bool Replay::readImageList(const std::string &path, std::vector<ImageEntry> &out, std::string *err) {
+    std::ifstream f(path);
+    if (!f) return setErr(err, "cannot open " + path);
+    const std::string dir = dirOf(path);
+    std::string line;
+    out.clear();
+    while (std::getline(f, line)) {
+        for (char &c : line)
+            if (c == ',') c = ' ';
+        std::istringstream ss(line);
+        double t;
+        std::string name;
+        if (!(ss >> t >> name)) continue;
+        out.push_back({toGpsSecondOfWeek(t), name.front() == '/' ? name : dir + "/" + name});
+    }
+    return true;
+}
+
+bool Replay::loadPnm(const std::string &path, Mat &image, std::string *err) {
+    FILE *fp = fopen(path.c_str(), "rb");
+    if (!fp) return setErr(err, "cannot open " + path);
+    auto token = [&](std::string &tok) { // header tokens, '#' comments skipped
+        tok.clear();
+        int c;
+        while ((c = fgetc(fp)) != EOF) {
+            if (c == '#') {
+                while ((c = fgetc(fp)) != EOF && c != '\n') {
+                }
+                continue;
+            }
+            if (c == ' ' || c == '\t' || c == '\n' || c == '\r') {
+                if (!tok.empty()) return true;
+                continue;
+            }
+            tok.push_back((char) c);
+        }
+        return !tok.empty();
+    };
+    std::string magic, sw, sh, smax;
+    bool ok = token(magic) && token(sw) && token(sh) && token(smax);
+    int w = ok ? atoi(sw.c_str()) : 0, h = ok ? atoi(sh.c_str()) : 0, maxv = ok ? atoi(smax.c_str()) : 0;
+    int chans = magic == "P5" ? 1 : (magic == "P6" ? 3 : 0);
+    if (!ok || chans == 0 || w <= 0 || h <= 0 || maxv != 255) {
+        fclose(fp);
+        return setErr(err, path + ": not an 8-bit binary PGM/PPM");
+    }
+    image     = Mat(h, w, chans);
+    size_t n  = (size_t) w * h * chans;
+    size_t rd = fread(image.data, 1, n, fp);
+    fclose(fp);
+    if (rd != n) return setErr(err, path + ": truncated pixel data");
+    if (chans == 3) // PPM stores RGB, the reference's colour input is BGR8 (fusion_ros.cc:209-211, tracking.cc:109-111)
+        for (size_t k = 0; k < n; k += 3) std::swap(image.data[k], image.data[k + 2]);
+    return true;
+}
+
+bool Replay::run(const ReplayOptions &options, ReplaySummary &summary, std::string *err) {
+    YamlLite config;
+    if (!YamlLite::load(options.configfile, config, err)) return false;
+    std::string outputpath = options.outputpath.empty() ? (config.has("outputpath") ? config.str("outputpath") : std::string()) : options.outputpath;
+    if (outputpath.empty()) return setErr(err, "no output path");
+    struct stat st;
+    if (stat(outputpath.c_str(), &st) != 0) mkdir(outputpath.c_str(), 0755); // fusion_ros.cc:76-83
+    if (stat(outputpath.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return setErr(err, "Failed to open outputpath " + outputpath);
+    summary.outputpath = outputpath;
+    const bool isusegnssoutage = config.has("isusegnssoutage") && config.boolean("isusegnssoutage");
+    const double gnssoutagetime = config.has("gnssoutagetime") ? config.real("gnssoutagetime") : 0.0;
+    const double gnssthreshold  = config.has("gnssthreshold") ? config.real("gnssthreshold") : 1.0e9;
+
+    std::vector<IMU> imus;
+    std::vector<GNSS> gnss;
+    std::vector<ImageEntry> images;
+    if (!readImuText(options.imufile, options.imu_is_rate, imus, err)) return false;
+    if (!options.gnssfile.empty() && !readGnssText(options.gnssfile, gnss, err)) return false;
+    if (!options.imagelist.empty() && !readImageList(options.imagelist, images, err)) return false;
+
+    GVINS gvins(options.configfile, outputpath, nullptr);
+    if (!gvins.isRunning()) return setErr(err, "GVINS failed to start: " + gvins.error());
+
+    auto in_range = [&](double t) { return (options.start_time == 0 || t >= options.start_time) && (options.end_time == 0 || t <= options.end_time); };
+    auto t0       = std::chrono::steady_clock::now();
+    size_t ii = 0, gi = 0, fi = 0;
+    double first = 0, last = 0;
+    try {
+        while (ii < imus.size() || gi < gnss.size() || fi < images.size()) {
+            const double ti = ii < imus.size() ? imus[ii].time : 1e300, tg = gi < gnss.size() ? gnss[gi].time : 1e300,
+                         tf = fi < images.size() ? images[fi].time : 1e300;
+            if (ti <= tg && ti <= tf) {
+                const IMU &imu = imus[ii++];
+                if (!in_range(imu.time)) continue;
+                if (first == 0) first = imu.time;
+                last = imu.time;
+                gvins.addNewImu(imu);
+                summary.imu++;
+            } else if (tg <= tf) {
+                const GNSS &g = gnss[gi++];
+                if (!in_range(g.time)) continue;
+                bool bad = (g.std[0] == 0) || (g.std[1] == 0) || (g.std[2] == 0) ||
+                           !((g.std[0] < gnssthreshold) && (g.std[1] < gnssthreshold) && (g.std[2] < gnssthreshold));
+                if (bad || (isusegnssoutage && (g.time >= gnssoutagetime))) {
+                    summary.gnss_dropped++;
+                    continue;
+                }
+                gvins.addNewGnss(g);
+                summary.gnss++;
+            } else {
+                const ImageEntry &e = images[fi++];
+                if (!in_range(e.time)) continue;
+                Mat image;
+                if (!loadPnm(e.path, image, err)) return false;
+                gvins.addNewFrame(Frame::createFrame(e.time, image));
+                summary.frames++;
+            }
+        }
+        gvins.setFinished();
+    } catch (const std::exception &e) {
+        return setErr(err, e.what());
+    }
+    summary.wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    summary.data_seconds = last - first;
+    summary.counters     = gvins.counters();
+    summary.final_state  = (int) gvins.gvinsState();
+    return true;
+}
+
+} // namespace icg
