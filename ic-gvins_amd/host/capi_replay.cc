@@ -115,3 +115,19 @@ int icgh_detect_zero_velocity(int n, const double *rows6, double imudatarate, do
 }
 
 } // extern "C"
+
+extern "C" {
+// Replay::loadPnm: dims3 = rows, cols, channels; the pixels (BGR order for colour) are copied when `out` holds at least rows*cols*channels bytes
+int icgh_replay_load_pnm(const char *path, int32_t *dims3, uint8_t *out, int out_len, char *err, int errlen) {
+    Mat image;
+    std::string e;
+    if (!Replay::loadPnm(path ? path : "", image, &e)) {
+        set_err(err, errlen, e.c_str());
+        return -2;
+    }
+    dims3[0] = image.rows, dims3[1] = image.cols, dims3[2] = image.chans;
+    const size_t n = (size_t) image.rows * image.cols * image.chans;
+    if (out && (size_t) out_len >= n) memcpy(out, image.data, n);
+    return 0;
+}
+}

@@ -11,6 +11,7 @@
 #include <stdexcept>
 
 #include "yaml_lite.h"
+#include <fenv.h>
 
 namespace icg {
 
@@ -111,6 +112,7 @@ void GVINS::fail(const std::string &what) {
 GVINS::GVINS(const std::string &configfile, const std::string &outputpath, Drawer::Ptr drawer, int device) { // ic_gvins.cc:46-167
     gvinsstate_ = GVINS_ERROR;
     isfinished_ = true;
+    if (getenv("ICG_GVINS_FPE")) feenableexcept(FE_INVALID | FE_DIVBYZERO); // diagnostics: trap where a NaN is born
     YamlLite config;
     std::string err;
     if (!YamlLite::load(configfile, config, &err)) {
@@ -179,7 +181,15 @@ GVINS::GVINS(const std::string &configfile, const std::string &outputpath, Drawe
 
         map_      = std::make_shared<Map>(optimize_windows_size_);
         drawer_   = drawer ? std::move(drawer) : std::make_shared<Drawer>();
-        tracking_ = std::make_shared<Tracking>(camera_, map_, drawer_, configfile, outputpath);
+        // one id space per estimator: the reference's process-wide id factories (frame.cc:38-54, mappoint.cc:47) make the first frame's
+        // map key (keyframe id 0 before Frame::setKeyFrame) coincide with the id it is given later only for the FIRST estimator of a process
+        ids_ = std::make_shared<IdSpace>();
+        TrackingConfig tracking_config;
+        std::string terr;
+        if (!TrackingConfig::fromYamlFile(configfile, tracking_config, &terr)) throw std::runtime_error(terr);
+        auto tracking_device = std::make_shared<DeviceContext>(device, camera_->width(), camera_->height(), 1, tracking_config.track_max_features);
+        tracking_device->setCamera(*camera_);
+        tracking_ = std::make_shared<Tracking>(camera_, map_, drawer_, tracking_config, outputpath, tracking_device, ids_);
 
         icg_ctx_config cfg{};
         cfg.device = device, cfg.width = 64, cfg.height = 64, cfg.n_slots = 1, cfg.max_batch = 1, cfg.max_points = 64;
@@ -200,9 +210,9 @@ GVINS::GVINS(const std::string &configfile, const std::string &outputpath, Drawe
 }
 
 GVINS::~GVINS() {
-    visual_factors_.clear();
-    visual_batch_.reset();
+    visual_batch_.reset(); // the batch un-registers itself from its factors: before they go
     marg_batch_.reset();
+    visual_factors_.clear();
     tracking_.reset();
     if (ctx_) icg_ctx_destroy(ctx_);
 }
@@ -999,7 +1009,13 @@ bool GVINS::gvinsMarginalization() { // ic_gvins.cc:1412-1678
         Vector3d ref_frame_pc = camera_->pixel2cam(mappoint->referenceKeypoint());
         int ref_frame_index   = getStateDataIndex(ref_frame->stamp());
         if (ref_frame_index < 0) continue;
-        double *invdepth  = &invdepthlist_[mappoint->id()];
+        auto idit = invdepthlist_.find(mappoint->id());
+        if (idit == invdepthlist_.end() || idit->second == 0) {
+            GLOG("marginalization: mappoint %lu (type %d, depth %.3f, used %d, observed %d) has no inverse depth in the window", mappoint->id(), (int) mappoint->mapPointType(),
+                 mappoint->depth(), mappoint->usedTimes(), mappoint->observedTimes());
+            continue;
+        }
+        double *invdepth  = &idit->second;
         auto ref_features = ref_frame->features();
         auto rf           = ref_features.find(mappoint->id());
         if (rf == ref_features.end()) continue;

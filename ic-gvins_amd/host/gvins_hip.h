@@ -76,6 +76,8 @@ public:
     const std::string &error() const { return error_; }
     size_t numTimeNodes() const { return timelist_.size(); }
     const Map::Ptr &map() const { return map_; }
+    // the id space of this estimator's frames / keyframes / landmarks: Frame::createFrame(stamp, image, gvins.ids())
+    const std::shared_ptr<IdSpace> &ids() const { return ids_; }
     Pose extrinsic() const { return pose_b_c_; }
     double timeDelay() const { return td_b_c_; }
     // latest mechanized INS state (flushes pending epochs)
@@ -146,6 +148,7 @@ private:
     double mix_prior_[18], mix_prior_std_[18], pose_prior_[7], pose_prior_std_[6];
 
     Tracking::Ptr tracking_;
+    std::shared_ptr<IdSpace> ids_;
     Map::Ptr map_;
     Camera::Ptr camera_;
     Drawer::Ptr drawer_;

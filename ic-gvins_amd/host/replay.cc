@@ -196,7 +196,7 @@ bool Replay::run(const ReplayOptions &options, ReplaySummary &summary, std::stri
                 if (!in_range(e.time)) continue;
                 Mat image;
                 if (!loadPnm(e.path, image, err)) return false;
-                gvins.addNewFrame(Frame::createFrame(e.time, image));
+                gvins.addNewFrame(Frame::createFrame(e.time, image, gvins.ids()));
                 summary.frames++;
             }
         }

@@ -1,0 +1,56 @@
+"""SURVEY.md §8 row f2 on the CPU: the replay harness (IMU / GNSS text, PGM image list, gvins.yaml) driving icg::GVINS — the estimator
+that calls the hot path from both sides — on the oracle-backed host layer, over a synthetic GNSS + IMU + camera sequence with known
+truth (gvins_data.py).  Parity status: the window solver is unpinned (Ceres is absent); the anchors are the truth of the sequence, the
+reference's file formats and determinism.  The small factors / Earth helpers the estimator adds are pinned in test_oracle_vs_reference.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gvins_checks as gc
+
+
+@pytest.fixture(scope="module")
+def host_lib():
+    from stream_utils import ensure_oracle_host
+    return ensure_oracle_host()
+
+
+def test_replay_gnss_imu_camera_sequence(host_lib, tmp_path):
+    gc.check_replay(host_lib, tmp_path)
+
+
+def test_replay_online_calibration_and_earth_rotation(host_lib, tmp_path):
+    gc.check_replay_calibration(host_lib, tmp_path)
+
+
+def test_replay_time_window_and_gnss_outage(host_lib, tmp_path):
+    gc.check_replay_window(host_lib, tmp_path)
+
+
+def test_replay_input_errors(host_lib, tmp_path):
+    lib = C.CDLL(host_lib)
+    err = C.create_string_buffer(512)
+    summ = np.zeros(16)
+    p = lambda s: str(s).encode()
+    # missing configuration / IMU file: an error string, no crash
+    rc = lib.icgh_replay_run(p(tmp_path / "none.yaml"), p(tmp_path), p(tmp_path / "imu.txt"), None, None, 0, C.c_double(0), C.c_double(0),
+                             summ.ctypes.data_as(C.c_void_p), err, 512)
+    assert rc != 0 and b"cannot open" in err.value
+    # a configuration value that is not a number is refused (yaml-cpp would throw BadConversion), it is not read as 0
+    cfg = tmp_path / "bad.yaml"
+    cfg.write_text("outputpath: \"%s\"\ninitlength: 1\nimudatarate: fast\n" % tmp_path)
+    (tmp_path / "imu.txt").write_text("100000.0 0 0 0 0 0 0\n100000.005 0 0 0 0 0 -0.049\n")
+    rc = lib.icgh_replay_run(p(cfg), None, p(tmp_path / "imu.txt"), None, None, 0, C.c_double(0), C.c_double(0), summ.ctypes.data_as(C.c_void_p), err, 512)
+    assert rc != 0 and b"not a number" in err.value, err.value
+    # a truncated image is reported with its path
+    img = tmp_path / "x.pgm"
+    img.write_bytes(b"P5\n8 8\n255\n" + bytes(10))
+    lib.icgh_replay_load_pnm.restype = C.c_int
+    dims = np.zeros(3, np.int32)
+    rc = lib.icgh_replay_load_pnm(p(img), dims.ctypes.data_as(C.c_void_p), None, 0, err, 512)
+    assert rc != 0 and b"truncated" in err.value
+    img.write_bytes(b"P6\n# comment\n2 1\n255\n" + bytes([1, 2, 3, 4, 5, 6]))
+    out = np.zeros(6, np.uint8)
+    rc = lib.icgh_replay_load_pnm(p(img), dims.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), 6, err, 512)
+    assert rc == 0 and list(dims) == [1, 2, 3] and list(out) == [3, 2, 1, 6, 5, 4]  # RGB -> BGR8, as the reference's colour input
