@@ -1,0 +1,62 @@
+// icg_replay — command-line front of the replay harness (ic-gvins_amd/host/replay.h): what `roslaunch ic_gvins ic_gvins.launch
+// configfile:=...` + `rosbag play` do for the reference (README.md:100-109, ROS/fusion_ros.cc), with files in place of a ROS bag.
+//   icg_replay --config gvins.yaml --imu imu.txt [--gnss gnss.txt] [--images cam0/images.txt] [--output DIR] [--imu-rate] [--start T] [--end T]
+// Results (gvins.nav, trajectory.csv, tracking.txt, statistics.txt, extrinsic.txt, mappoint.txt, IMU_ERR.txt, a copy of the configuration)
+// go to --output or to the configuration's `outputpath`.  Needs an MI355X: the library behind it has no CPU fallback.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "../host/replay.h"
+
+static void usage() {
+    fprintf(stderr, "usage: icg_replay --config gvins.yaml --imu imu.txt [--gnss gnss.txt] [--images images.txt] [--output DIR] [--imu-rate]\n"
+                    "                  [--start GPS_SECOND] [--end GPS_SECOND]\n"
+                    "  imu.txt     t dtheta_x dtheta_y dtheta_z dvel_x dvel_y dvel_z   (increments; with --imu-rate: angular rate / specific force)\n"
+                    "  gnss.txt    t lat[deg] lon[deg] h[m] std_n std_e std_d\n"
+                    "  images.txt  t filename   (binary PGM / PPM next to the list)\n");
+}
+
+int main(int argc, char **argv) {
+    icg::ReplayOptions o;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto value    = [&](std::string &dst) {
+            if (i + 1 >= argc) {
+                usage();
+                exit(2);
+            }
+            dst = argv[++i];
+        };
+        std::string num;
+        if (a == "--config") value(o.configfile);
+        else if (a == "--imu") value(o.imufile);
+        else if (a == "--gnss") value(o.gnssfile);
+        else if (a == "--images") value(o.imagelist);
+        else if (a == "--output") value(o.outputpath);
+        else if (a == "--imu-rate") o.imu_is_rate = true;
+        else if (a == "--start") value(num), o.start_time = atof(num.c_str());
+        else if (a == "--end") value(num), o.end_time = atof(num.c_str());
+        else {
+            usage();
+            return 2;
+        }
+    }
+    if (o.configfile.empty() || o.imufile.empty()) {
+        usage();
+        return 2;
+    }
+    icg::ReplaySummary s;
+    std::string err;
+    if (!icg::Replay::run(o, s, &err)) {
+        fprintf(stderr, "icg_replay: %s\n", err.c_str());
+        return 1;
+    }
+    printf("replayed %.2f s of data in %.2f s (x%.1f real time): %ld IMU, %ld GNSS (%ld dropped), %ld images; %ld frames tracked, %ld keyframes, %ld window "
+           "solves, %ld marginalizations, %ld tracking losses; final state %d; results in %s\n",
+           s.data_seconds, s.wall_seconds, s.wall_seconds > 0 ? s.data_seconds / s.wall_seconds : 0.0, s.imu, s.gnss, s.gnss_dropped, s.frames,
+           s.counters.frames_tracked, s.counters.keyframes, s.counters.optimizations, s.counters.marginalizations, s.counters.lost, s.final_state,
+           s.outputpath.c_str());
+    return 0;
+}
