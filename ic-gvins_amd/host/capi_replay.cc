@@ -131,3 +131,44 @@ int icgh_replay_load_pnm(const char *path, int32_t *dims3, uint8_t *out, int out
     return 0;
 }
 }
+
+extern "C" {
+// n independent replays of the same input files side by side (one estimator + host thread each), results under outputs[k].
+// summaries: n x 16 as icgh_replay_run; *batch_wall_seconds = the whole batch.
+int icgh_replay_run_many(int n, const char *configfile, const char *const *outputs, const char *imufile, const char *gnssfile, const char *imagelist,
+                         int imu_is_rate, int wait_poll_us, double *summaries, double *batch_wall_seconds, char *err, int errlen) {
+    try {
+        std::vector<ReplayOptions> opts((size_t) n);
+        for (int k = 0; k < n; k++) {
+            ReplayOptions &o = opts[(size_t) k];
+            o.configfile = configfile ? configfile : "";
+            o.outputpath = outputs[k];
+            o.imufile    = imufile ? imufile : "";
+            o.gnssfile   = gnssfile ? gnssfile : "";
+            o.imagelist  = imagelist ? imagelist : "";
+            o.imu_is_rate  = imu_is_rate != 0;
+            o.wait_poll_us = wait_poll_us;
+        }
+        std::vector<ReplaySummary> S;
+        std::string e;
+        double wall = 0;
+        if (!Replay::runMany(opts, S, &wall, &e)) {
+            set_err(err, errlen, e.c_str());
+            return -2;
+        }
+        for (int k = 0; k < n; k++) {
+            const ReplaySummary &s = S[(size_t) k];
+            const double v[16] = {(double) s.imu, (double) s.gnss, (double) s.gnss_dropped, (double) s.frames, (double) s.counters.frames_tracked,
+                                  (double) s.counters.keyframes, (double) s.counters.optimizations, (double) s.counters.marginalizations,
+                                  (double) s.counters.ins_launches, (double) s.counters.lost, (double) s.counters.reprojection_factors,
+                                  (double) s.counters.chi2_removed, (double) s.final_state, s.wall_seconds, s.data_seconds, 0.0};
+            memcpy(summaries + 16 * (size_t) k, v, sizeof v);
+        }
+        if (batch_wall_seconds) *batch_wall_seconds = wall;
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+}

@@ -190,6 +190,7 @@ GVINS::GVINS(const std::string &configfile, const std::string &outputpath, Drawe
         auto tracking_device = std::make_shared<DeviceContext>(device, camera_->width(), camera_->height(), 1, tracking_config.track_max_features);
         tracking_device->setCamera(*camera_);
         tracking_ = std::make_shared<Tracking>(camera_, map_, drawer_, tracking_config, outputpath, tracking_device, ids_);
+        tracking_device_ = tracking_device;
 
         icg_ctx_config cfg{};
         cfg.device = device, cfg.width = 64, cfg.height = 64, cfg.n_slots = 1, cfg.max_batch = 1, cfg.max_points = 64;
@@ -215,6 +216,13 @@ GVINS::~GVINS() {
     visual_factors_.clear();
     tracking_.reset();
     if (ctx_) icg_ctx_destroy(ctx_);
+}
+
+void GVINS::setWaitMode(int icg_wait_mode, int sleep_us) {
+    if (tracking_device_) (void) icg_ctx_set_wait_mode(tracking_device_->ctx(), icg_wait_mode, sleep_us);
+    if (ctx_) (void) icg_ctx_set_wait_mode(ctx_, icg_wait_mode, sleep_us);
+    if (visual_batch_) visual_batch_->setWaitMode(icg_wait_mode, sleep_us);
+    if (marg_batch_) marg_batch_->setWaitMode(icg_wait_mode, sleep_us);
 }
 
 void GVINS::setFinished() { // ic_gvins.cc:554-582
@@ -297,7 +305,7 @@ void GVINS::flushIns() {
     counters_.ins_launches++;
     for (size_t k = 0; k < ins_pending_; k++) {
         ins_window_[first + k].second = traj[0][k];
-        MISC::writeNavResult(integration_config_, traj[0][k], navfilesaver_, imuerrfilesaver_, trajfilesaver_);
+        MISC::writeNavResult(integration_config_, traj[0][k], navfilesaver_, imuerrfilesaver_, trajfilesaver_, &nav_counter_);
     }
     ins_pending_ = 0;
 }
@@ -374,7 +382,7 @@ void GVINS::fusionStep(const IMU &imu) { // one pass of the IMU BUFFER loop of r
         }
     }
     if (output_now && !skip_output && gvinsstate_ > GVINS_INITIALIZING)
-        MISC::writeNavResult(integration_config_, ins_window_.back().second, navfilesaver_, imuerrfilesaver_, trajfilesaver_);
+        MISC::writeNavResult(integration_config_, ins_window_.back().second, navfilesaver_, imuerrfilesaver_, trajfilesaver_, &nav_counter_);
 
     // the other two loops of the reference, run to completion before the next IMU epoch
     processTracking();

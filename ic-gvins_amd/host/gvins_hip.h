@@ -64,6 +64,9 @@ public:
     bool addNewGnss(const GNSS &gnss);
     bool addNewFrame(const Frame::Ptr &frame);
     void setFinished();
+    // completion waits of this estimator's device contexts (tracker, INS / preintegration / culling, the two reprojection batches):
+    // ICG_WAIT_SPIN (default: lowest latency for one estimator) or ICG_WAIT_POLL + sleep (many estimators on few host cores)
+    void setWaitMode(int icg_wait_mode, int sleep_us);
     bool isRunning() const { return !isfinished_; }
     GVINSState gvinsState() const { return gvinsstate_; }
 
@@ -148,6 +151,8 @@ private:
     double mix_prior_[18], mix_prior_std_[18], pose_prior_[7], pose_prior_std_[6];
 
     Tracking::Ptr tracking_;
+    DeviceContext::Ptr tracking_device_;
+    int nav_counter_{0}; // MISC::writeNavResult's every-10th-call counter, per estimator
     std::shared_ptr<IdSpace> ids_;
     Map::Ptr map_;
     Camera::Ptr camera_;

@@ -4,6 +4,7 @@
 #include <cmath>
 
 #include "../../include/icgvins_hip.h"
+#include "earth.h"
 
 namespace icg {
 
@@ -60,82 +61,22 @@ void FileSaver::flush() {
     if (fp_) fflush(fp_);
 }
 
-namespace {
-// common/earth.h:36-39, 66-150, 194-208 and common/rotation.h:44-66 — only what writeNavResult needs
-const double WGS84_RA = 6378137.0000000000, WGS84_E1 = 0.0066943799901413156, R2D = 180.0 / M_PI;
-double earthRN(double lat) {
-    double sinlat = std::sin(lat);
-    return WGS84_RA / std::sqrt(1.0 - WGS84_E1 * sinlat * sinlat);
-}
-Matrix3d earthCne(const Vector3d &blh) {
-    double sinlat = std::sin(blh[0]), sinlon = std::sin(blh[1]), coslat = std::cos(blh[0]), coslon = std::cos(blh[1]);
-    Matrix3d d;
-    d(0, 0) = -sinlat * coslon, d(0, 1) = -sinlon, d(0, 2) = -coslat * coslon;
-    d(1, 0) = -sinlat * sinlon, d(1, 1) = coslon, d(1, 2) = -coslat * sinlon;
-    d(2, 0) = coslat, d(2, 1) = 0, d(2, 2) = -sinlat;
-    return d;
-}
-Vector3d earthBlh2ecef(const Vector3d &blh) {
-    double coslat = std::cos(blh[0]), sinlat = std::sin(blh[0]), coslon = std::cos(blh[1]), sinlon = std::sin(blh[1]);
-    double rn = earthRN(blh[0]), rnh = rn + blh[2];
-    return {rnh * coslat * coslon, rnh * coslat * sinlon, (rnh - rn * WGS84_E1) * sinlat};
-}
-Vector3d earthEcef2blh(const Vector3d &ecef) {
-    double p = std::sqrt(ecef[0] * ecef[0] + ecef[1] * ecef[1]);
-    double rn, lat, lon, h = 0, h2;
-    lat = std::atan(ecef[2] / (p * (1.0 - WGS84_E1)));
-    lon = 2.0 * std::atan2(ecef[1], ecef[0] + p);
-    do {
-        h2  = h;
-        rn  = earthRN(lat);
-        h   = p / std::cos(lat) - rn;
-        lat = std::atan(ecef[2] / (p * (1.0 - WGS84_E1 * rn / (rn + h))));
-    } while (std::fabs(h - h2) > 1.0e-4);
-    return {lat, lon, h};
-}
-Vector3d matrix2euler(const Matrix3d &dcm) {
-    Vector3d e;
-    e[1] = std::atan(-dcm(2, 0) / std::sqrt(dcm(2, 1) * dcm(2, 1) + dcm(2, 2) * dcm(2, 2)));
-    if (dcm(2, 0) <= -0.999) {
-        e[0] = std::atan2(dcm(2, 1), dcm(2, 2));
-        e[2] = std::atan2((dcm(1, 2) - dcm(0, 1)), (dcm(0, 2) + dcm(1, 1)));
-    } else if (dcm(2, 0) >= 0.999) {
-        e[0] = std::atan2(dcm(2, 1), dcm(2, 2));
-        e[2] = M_PI + std::atan2((dcm(1, 2) + dcm(0, 1)), (dcm(0, 2) - dcm(1, 1)));
-    } else {
-        e[0] = std::atan2(dcm(2, 1), dcm(2, 2));
-        e[2] = std::atan2(dcm(1, 0), dcm(0, 0));
-    }
-    if (e[2] < 0) e[2] = M_PI * 2 + e[2];
-    return e;
-}
-Matrix3d quatToMatrix(const Quaterniond &q) { // Eigen toRotationMatrix from raw coefficients
-    double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
-    double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y,
-           tzz = tz * q.z;
-    Matrix3d r;
-    r(0, 0) = 1 - (tyy + tzz), r(0, 1) = txy - twz, r(0, 2) = txz + twy;
-    r(1, 0) = txy + twz, r(1, 1) = 1 - (txx + tzz), r(1, 2) = tyz - twx;
-    r(2, 0) = txz - twy, r(2, 1) = tyz + twx, r(2, 2) = 1 - (txx + tyy);
-    return r;
-}
-} // namespace
-
 void MISC::writeNavResult(const IntegrationConfiguration &config, const IntegrationState &state, const FileSaver::Ptr &navfile,
-                          const FileSaver::Ptr &errfile, const FileSaver::Ptr &trajfile) { // misc.cc:417-499
-    static int counts = 0;
+                          const FileSaver::Ptr &errfile, const FileSaver::Ptr &trajfile, int *counter) { // misc.cc:417-499
+    static int process_counts = 0;
+    int &counts               = counter ? *counter : process_counts;
     if (counts++ % 10) return;
     std::vector<double> result;
     const double time = state.time;
     // Earth::local2global(config.origin, Pose{R, p})
-    Vector3d ecef0 = earthBlh2ecef(config.origin);
-    Matrix3d cn0e  = earthCne(config.origin);
+    Vector3d ecef0 = Earth::blh2ecef(config.origin);
+    Matrix3d cn0e  = Earth::cne(config.origin);
     Vector3d ecef1 = ecef0 + cn0e * state.p;
-    Vector3d pos   = earthEcef2blh(ecef1);
-    Matrix3d cn1e  = earthCne(pos);
-    Matrix3d Rg    = (cn1e.transpose() * cn0e) * quatToMatrix(state.q);
+    Vector3d pos   = Earth::ecef2blh(ecef1);
+    Matrix3d cn1e  = Earth::cne(pos);
+    Matrix3d Rg    = (cn1e.transpose() * cn0e) * Rotation::quaternion2matrix(state.q);
     pos[0] *= R2D, pos[1] *= R2D;
-    Vector3d att = matrix2euler(Rg) * R2D;
+    Vector3d att = Rotation::matrix2euler(Rg) * R2D;
     Vector3d bg  = (state.bg * R2D) * 3600;
     Vector3d ba  = state.ba * 1e5;
     result = {0, time, pos[0], pos[1], pos[2], state.v[0], state.v[1], state.v[2], att[0], att[1], att[2]};

@@ -54,8 +54,10 @@ public:
     // misc.cc:417-499: every 10th call (process-wide counter, as in the reference) appends one line to the navigation file
     // (0, time, lat/lon [deg], h, v, roll/pitch/heading [deg]), the IMU error file (time, bg [deg/h], ba [mGal], (sg, sa [ppm],) sodo)
     // and the trajectory file (time, p, q xyzw).  Host only: three text lines per 10 IMU epochs.
+    // `counter`: the every-10th-call counter; null = the process-wide one of the reference (a function-local static there), a pointer =
+    // the caller's own (one per estimator when several run in one process)
     static void writeNavResult(const IntegrationConfiguration &config, const IntegrationState &state, const FileSaver::Ptr &navfile,
-                               const FileSaver::Ptr &errfile, const FileSaver::Ptr &trajfile);
+                               const FileSaver::Ptr &errfile, const FileSaver::Ptr &trajfile, int *counter = nullptr);
 
     // ---- device, batched over streams ----
     // insMechanization (misc.cc:151-206) over series[s] (series[s][0] = imu_pre of the first step) starting from *states[s],

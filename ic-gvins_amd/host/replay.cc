@@ -8,6 +8,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <thread>
 
 #include "yaml_lite.h"
 
@@ -164,6 +165,7 @@ bool Replay::run(const ReplayOptions &options, ReplaySummary &summary, std::stri
 
     GVINS gvins(options.configfile, outputpath, nullptr);
     if (!gvins.isRunning()) return setErr(err, "GVINS failed to start: " + gvins.error());
+    if (options.wait_poll_us > 0) gvins.setWaitMode(ICG_WAIT_POLL, options.wait_poll_us);
 
     auto in_range = [&](double t) { return (options.start_time == 0 || t >= options.start_time) && (options.end_time == 0 || t <= options.end_time); };
     auto t0       = std::chrono::steady_clock::now();
@@ -208,6 +210,21 @@ bool Replay::run(const ReplayOptions &options, ReplaySummary &summary, std::stri
     summary.data_seconds = last - first;
     summary.counters     = gvins.counters();
     summary.final_state  = (int) gvins.gvinsState();
+    return true;
+}
+
+bool Replay::runMany(const std::vector<ReplayOptions> &options, std::vector<ReplaySummary> &summaries, double *wall_seconds, std::string *err) {
+    const size_t n = options.size();
+    summaries.assign(n, ReplaySummary());
+    std::vector<std::string> errors(n);
+    std::vector<char> ok(n, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> threads;
+    for (size_t k = 0; k < n; k++) threads.emplace_back([&, k]() { ok[k] = run(options[k], summaries[k], &errors[k]) ? 1 : 0; });
+    for (auto &t : threads) t.join();
+    if (wall_seconds) *wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t k = 0; k < n; k++)
+        if (!ok[k]) return setErr(err, "replay " + std::to_string(k) + ": " + errors[k]);
     return true;
 }
 

@@ -22,6 +22,7 @@ struct ReplayOptions {
     std::string imufile, gnssfile, imagelist;
     bool imu_is_rate{false};
     double start_time{0}, end_time{0};      // 0 = unbounded (after conversion to GPS seconds of week)
+    int wait_poll_us{0};                    // > 0: the estimator's contexts poll + sleep instead of spinning (many replays per host)
 };
 
 struct ReplaySummary {
@@ -45,6 +46,10 @@ public:
     static double toGpsSecondOfWeek(double stamp);
     // the whole run; false + err on I/O or estimator failure
     static bool run(const ReplayOptions &options, ReplaySummary &summary, std::string *err = nullptr);
+    // independent replays side by side, one host thread and one estimator (own device contexts, own id space) each: the camera streams of
+    // one GPU.  Per-stream results do not depend on what runs next to them.  wall_seconds (optional) = the whole batch.
+    static bool runMany(const std::vector<ReplayOptions> &options, std::vector<ReplaySummary> &summaries, double *wall_seconds = nullptr,
+                        std::string *err = nullptr);
 };
 
 } // namespace icg

@@ -138,3 +138,42 @@ def check_replay_window(lib_path, tmp_root):
     late = E[E[:, 0] > 6.0]
     assert late[:, 1].max() < 0.5, late[:, 1].max()  # two seconds without GNSS: visual-inertial drift stays small
     return S, E
+
+
+def run_replay_many(lib, files, outputs, wait_poll_us=0):
+    n = len(outputs)
+    for o in outputs:
+        os.makedirs(o, exist_ok=True)
+    arr = (C.c_char_p * n)(*[o.encode() for o in outputs])
+    summ = np.zeros((n, 16))
+    wall = C.c_double(0)
+    err = C.create_string_buffer(1024)
+    rc = lib.icgh_replay_run_many(n, files["config"].encode(), arr, files["imu"].encode(), files["gnss"].encode(), files["images"].encode(), 0,
+                                  int(wait_poll_us), summ.ctypes.data_as(C.c_void_p), C.byref(wall), err, 1024)
+    assert rc == 0, (rc, err.value.decode())
+    return [dict(zip(SUMMARY_KEYS, row)) for row in summ], wall.value
+
+
+def check_replay_concurrent(lib_path, tmp_root, n=3, bitwise=True, wait_poll_us=0):
+    """n estimators side by side in one process (one host thread, own device contexts and id space each): every stream's result files equal
+    those of the same replay run alone — the streams of one GPU do not see each other"""
+    lib = C.CDLL(lib_path)
+    seq = gd.Sequence(lib)
+    files = seq.write(str(tmp_root))
+    S = run_replay(lib, files)
+    alone = open(os.path.join(files["out"], "trajectory.csv"), "rb").read()
+    alone_rows = np.loadtxt(os.path.join(files["out"], "trajectory.csv"))
+    alone_track = open(os.path.join(files["out"], "tracking.txt")).read().split("\n")
+    outs = [os.path.join(str(tmp_root), "stream%d" % k) for k in range(n)]
+    SS, wall = run_replay_many(lib, files, outs, wait_poll_us)
+    for k, o in enumerate(outs):
+        assert all(SS[k][key] == S[key] for key in ("imu", "gnss", "frames", "frames_tracked", "keyframes", "optimizations", "marginalizations", "lost", "final_state"))
+        if bitwise:
+            assert open(os.path.join(o, "trajectory.csv"), "rb").read() == alone, k
+        else:
+            rows = np.loadtxt(os.path.join(o, "trajectory.csv"))
+            assert rows.shape == alone_rows.shape and np.abs(rows - alone_rows).max() < 1e-5, k
+        # tracking.txt: all columns but the last (wall-clock time per frame) are identical text (bit-exact front-end on both backends)
+        track = open(os.path.join(o, "tracking.txt")).read().split("\n")
+        assert [" ".join(t.split()[:6]) for t in track] == [" ".join(t.split()[:6]) for t in alone_track], k
+    return SS, wall

@@ -28,6 +28,10 @@ def test_replay_time_window_and_gnss_outage(host_lib, tmp_path):
     gc.check_replay_window(host_lib, tmp_path)
 
 
+def test_replay_concurrent_estimators_are_independent(host_lib, tmp_path):
+    gc.check_replay_concurrent(host_lib, tmp_path, n=3)
+
+
 def test_replay_input_errors(host_lib, tmp_path):
     lib = C.CDLL(host_lib)
     err = C.create_string_buffer(512)
