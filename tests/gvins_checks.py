@@ -173,7 +173,13 @@ def check_replay_concurrent(lib_path, tmp_root, n=3, bitwise=True, wait_poll_us=
         else:
             rows = np.loadtxt(os.path.join(o, "trajectory.csv"))
             assert rows.shape == alone_rows.shape and np.abs(rows - alone_rows).max() < 1e-5, k
-        # tracking.txt: all columns but the last (wall-clock time per frame) are identical text (bit-exact front-end on both backends)
+        # tracking.txt: all columns but the last (wall-clock time per frame) are identical text on the CPU backend; on the device the
+        # parallax / relative-motion columns inherit the rounding of the optimized poses, stamps and feature counts stay identical
         track = open(os.path.join(o, "tracking.txt")).read().split("\n")
-        assert [" ".join(t.split()[:6]) for t in track] == [" ".join(t.split()[:6]) for t in alone_track], k
+        if bitwise:
+            assert [" ".join(t.split()[:6]) for t in track] == [" ".join(t.split()[:6]) for t in alone_track], k
+        else:
+            a = np.array([[float(v) for v in t.split()[:6]] for t in alone_track if t.strip()])
+            b = np.array([[float(v) for v in t.split()[:6]] for t in track if t.strip()])
+            assert a.shape == b.shape and np.array_equal(a[:, [0, 1, 5]], b[:, [0, 1, 5]]) and np.abs(a - b).max() < 1e-3, k
     return SS, wall
