@@ -183,3 +183,73 @@ def check_replay_concurrent(lib_path, tmp_root, n=3, bitwise=True, wait_poll_us=
             b = np.array([[float(v) for v in t.split()[:6]] for t in track if t.strip()])
             assert a.shape == b.shape and np.array_equal(a[:, [0, 1, 5]], b[:, [0, 1, 5]]) and np.abs(a - b).max() < 1e-3, k
     return SS, wall
+
+
+def check_replay_tracking_loss(lib_path, tmp_root):
+    """half a second of black images in the middle of the drive: the tracker reports TRACK_LOST, the lost frame and the empty first frames
+    that follow become keyframes (ic_gvins.cc:540-549) and are dropped again as empty keyframes (:1397-1398), the tracker re-initializes
+    on the first textured frames, and the estimator — carried by INS + GNSS meanwhile — stays at the truth"""
+    lib = C.CDLL(lib_path)
+    seq = gd.Sequence(lib)
+    files = seq.write(str(tmp_root))
+    names = [line.split()[1] for line in open(files["images"])]
+    for name in names[40:50]:
+        with open(os.path.join(str(tmp_root), "cam0", name), "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (seq.w, seq.h) + bytes(seq.w * seq.h))
+    S = run_replay(lib, files)
+    assert S["lost"] == 1 and S["final_state"] == STATE_TRACKING_NORMAL
+    assert S["keyframes"] > 30 and S["marginalizations"] >= 10
+    E, _ = trajectory_errors(seq, files)
+    late = E[E[:, 0] > 4.0]
+    assert late[:, 1].max() < 0.10 and late[:, 2].max() < 0.30, (late[:, 1].max(), late[:, 2].max())
+    track = np.loadtxt(os.path.join(files["out"], "tracking.txt"))
+    assert 10 <= len(track) < S["keyframes"]  # a row per keyframe decision of a frame in TRACK_TRACKING (tracking.cc:297-315), none while lost
+    return S, E
+
+
+def check_replay_input_formats(lib_path, tmp_root):
+    """the other input flavours of the replay give the same run: IMU as angular rate / specific force (the fields of sensor_msgs/Imu, multiplied
+    by dt as imuCallback does), Unix time stamps (converted with GpsTime::unix2gps), colour images (PPM -> BGR8 -> gray on the device)"""
+    lib = C.CDLL(lib_path)
+    seq = gd.Sequence(lib)
+    files = seq.write(str(tmp_root))
+    S = run_replay(lib, files)
+    base = np.loadtxt(os.path.join(files["out"], "trajectory.csv"))
+    root = str(tmp_root)
+    week = 2200
+    to_unix = lambda sow: sow + week * 604800 + 315964800 - 18
+    imu = np.loadtxt(files["imu"])
+    dt = np.diff(np.concatenate([[imu[0, 0] - 0.005], imu[:, 0]]))
+    with open(os.path.join(root, "imu_rate_unix.txt"), "w") as f:
+        for r, d in zip(imu, dt):
+            f.write("%.9f %.15e %.15e %.15e %.15e %.15e %.15e\n" % ((to_unix(r[0]),) + tuple(r[1:] / d)))
+    gn = np.loadtxt(files["gnss"])
+    with open(os.path.join(root, "gnss_unix.txt"), "w") as f:
+        for r in gn:
+            f.write("%.9f %.12f %.12f %.6f %.3f %.3f %.3f\n" % ((to_unix(r[0]),) + tuple(r[1:])))
+    os.makedirs(os.path.join(root, "cam1"), exist_ok=True)
+    with open(os.path.join(root, "cam1", "images.txt"), "w") as f:
+        for line in open(files["images"]):
+            t, name = line.split()
+            raw = open(os.path.join(root, "cam0", name), "rb").read()
+            pix = np.frombuffer(raw[-seq.w * seq.h:], np.uint8)
+            out = name.replace(".pgm", ".ppm")
+            with open(os.path.join(root, "cam1", out), "wb") as g:
+                g.write(b"P6\n%d %d\n255\n" % (seq.w, seq.h))
+                g.write(np.repeat(pix, 3).tobytes())  # R = G = B: the BGR -> gray conversion returns the same image
+            f.write("%.9f %s\n" % (to_unix(float(t)), out))
+    files2 = dict(files, imu=os.path.join(root, "imu_rate_unix.txt"), gnss=os.path.join(root, "gnss_unix.txt"), images=os.path.join(root, "cam1", "images.txt"))
+    summ = np.zeros(16)
+    err = C.create_string_buffer(1024)
+    rc = lib.icgh_replay_run(files2["config"].encode(), None, files2["imu"].encode(), files2["gnss"].encode(), files2["images"].encode(), 1, C.c_double(0),
+                             C.c_double(0), summ.ctypes.data_as(C.c_void_p), err, 1024)
+    assert rc == 0, err.value
+    S2 = dict(zip(SUMMARY_KEYS, summ))
+    # the first IMU line only initialises dt in both flavours; the rate file was derived with a 5 ms first interval
+    for k in ("gnss", "frames", "frames_tracked", "keyframes", "marginalizations", "lost", "final_state"):
+        assert S[k] == S2[k], (k, S[k], S2[k])
+    other = np.loadtxt(os.path.join(files["out"], "trajectory.csv"))
+    assert other.shape == base.shape
+    assert np.abs(other[:, 0] - base[:, 0]).max() < 1e-5  # Unix stamps near 1.6e9 resolve 2.4e-7 s
+    assert np.abs(other[:, 1:4] - base[:, 1:4]).max() < 2e-3 and np.abs(other[:, 4:8] - base[:, 4:8]).max() < 1e-4
+    return S2

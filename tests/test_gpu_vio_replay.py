@@ -29,6 +29,10 @@ def test_replay_concurrent_estimators_on_gpu(tmp_path):
     gc.check_replay_concurrent(H.HOST_LIB, tmp_path, n=4, bitwise=False, wait_poll_us=50)
 
 
+def test_replay_tracking_loss_and_reinitialization_on_gpu(tmp_path):
+    gc.check_replay_tracking_loss(H.HOST_LIB, tmp_path)
+
+
 def test_replay_gpu_agrees_with_oracle_backend(tmp_path):
     """the same files through the HIP-backed and the oracle-backed host layer: the front-end is bit-exact, the FP64 paths agree to rounding,
     so keyframe / landmark bookkeeping is identical and the trajectories agree to well below the estimator's accuracy"""

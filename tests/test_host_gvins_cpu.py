@@ -32,6 +32,14 @@ def test_replay_concurrent_estimators_are_independent(host_lib, tmp_path):
     gc.check_replay_concurrent(host_lib, tmp_path, n=3)
 
 
+def test_replay_tracking_loss_and_reinitialization(host_lib, tmp_path):
+    gc.check_replay_tracking_loss(host_lib, tmp_path)
+
+
+def test_replay_input_formats(host_lib, tmp_path):
+    gc.check_replay_input_formats(host_lib, tmp_path)
+
+
 def test_replay_input_errors(host_lib, tmp_path):
     lib = C.CDLL(host_lib)
     err = C.create_string_buffer(512)
