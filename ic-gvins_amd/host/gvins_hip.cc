@@ -523,7 +523,8 @@ bool GVINS::gvinsInitializationOptimization() { // ic_gvins.cc:694-722 (Ceres SP
     WindowSolver::Summary summary;
     if (!problem.solve(options, &summary)) fail("GNSS/INS initialization solve: " + problem.error());
     GLOG("%s", summary.BriefReport().c_str());
-    return summary.termination == "CONVERGENCE";
+    // ceres::CONVERGENCE: one of the three tolerances was met (only logged by the caller, ic_gvins.cc:420-424)
+    return summary.termination == "function_tolerance" || summary.termination == "gradient_tolerance" || summary.termination == "parameter_tolerance";
 }
 
 // ---- time nodes ------------------------------------------------------------------------------------------------------------

@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <numeric> // real Ceres / Eigen headers pull these in; ic_gvins.{h,cc} rely on it
+#include <queue>
 #include <vector>
 
 #include <Eigen/Geometry> // real Ceres headers pull Eigen in; residual_block_info.h relies on that
@@ -55,3 +57,4 @@ private:
     const double a_, b_;
 };
 } // namespace ceres
+#include "problem_shim.h"

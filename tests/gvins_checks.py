@@ -253,3 +253,43 @@ def check_replay_input_formats(lib_path, tmp_root):
     assert np.abs(other[:, 0] - base[:, 0]).max() < 1e-5  # Unix stamps near 1.6e9 resolve 2.4e-7 s
     assert np.abs(other[:, 1:4] - base[:, 1:4]).max() < 2e-3 and np.abs(other[:, 4:8] - base[:, 4:8]).max() < 1e-4
     return S2
+
+
+def check_against_reference_estimator(lib_path, tmp_root, golden_path):
+    """icg::GVINS against the REFERENCE's own estimator on the same input files (tests/golden/gvins_ref_golden.npz: ic_gvins.cc compiled
+    unmodified on interface shims, one run of its three threads).  The reference's output depends on thread timing and its solver there is a
+    restated LM, so the comparison is: identical discrete structure (navigation-line stamps, keyframe stamps and spacing, tracked-frame
+    stamps), the GNSS/INS phase before the first image to 0.1 mm, the first window's reprojection statistics to 1e-6 px, and the whole
+    trajectory within 5 cm / 0.1 deg — the level at which two runs of the reference itself differ (3 cm between pacings)."""
+    import zlib
+    lib = C.CDLL(lib_path)
+    seq = gd.Sequence(lib)
+    files = seq.write(str(tmp_root))
+    g = np.load(golden_path)
+    root = os.path.dirname(files["images"])
+    names = [line.split()[1] for line in open(files["images"])]
+    crc = [zlib.crc32(open(files["imu"], "rb").read()), zlib.crc32(open(files["gnss"], "rb").read())]
+    crc += [zlib.crc32(open(os.path.join(root, n), "rb").read()) for n in (names[0], names[len(names) // 2], names[-1])]
+    assert list(g["checksums"]) == crc, "the synthetic sequence is not byte-identical to the one the golden was made from"
+    S = run_replay(lib, files)
+    assert S["final_state"] == int(g["final_state"]) == STATE_TRACKING_NORMAL
+    load = lambda name: np.loadtxt(os.path.join(files["out"], name))
+    traj, nav, stat, track, mpts = load("trajectory.csv"), load("gvins.nav"), load("statistics.txt"), load("tracking.txt"), load("mappoint.txt")
+    rt, rn, rs, rk, rm = g["trajectory"], g["nav"], g["statistics"], g["tracking"], g["mappoints"]
+    # structure
+    assert traj.shape == rt.shape and np.abs(traj[:, 0] - rt[:, 0]).max() < 1e-6
+    assert stat.shape == rs.shape and np.abs(stat[:, 0] - rs[:, 0]).max() < 1e-6  # every keyframe at the same frame
+    assert np.abs(stat[:, 1:3] - rs[:, 1:3]).max() < 1e-6                          # spacing and frame-id differences
+    assert track.shape == rk.shape and np.abs(track[:, 0] - rk[:, 0]).max() < 1e-6
+    assert np.array_equal(stat[:10, 3], rs[:10, 3]) and np.abs(stat[:, 3] - rs[:, 3]).max() <= 10   # feature counts of the keyframes
+    assert abs(len(mpts) - len(rm)) <= 15
+    # numbers
+    pre = traj[:, 0] < gd.T0 + 3.5  # GNSS/INS only: no image has been processed yet
+    assert np.abs(traj[pre, 1:] - rt[pre, 1:]).max() < 1e-4, np.abs(traj[pre, 1:] - rt[pre, 1:]).max()
+    assert np.abs(stat[0, 4:8] - rs[0, 4:8]).max() < 1e-6 and np.abs(stat[:, 4:8] - rs[:, 4:8]).max() < 0.25  # reprojection min / max / mean / rms [px]
+    assert np.array_equal(stat[:, 8], rs[:, 8])  # successful steps of the first solve (the 5-iteration cap)
+    dpos = np.linalg.norm(traj[:, 1:4] - rt[:, 1:4], axis=1)
+    dq = np.abs(traj[:, 4:8] - rt[:, 4:8]).max(axis=1)
+    assert dpos.max() < 0.05 and dq.max() < 1e-3, (dpos.max(), dq.max())
+    assert np.abs(nav[:, 2:4] - rn[:, 2:4]).max() < 1e-6 and np.abs(nav[:, 8:11] - rn[:, 8:11]).max() < 0.12  # lat/lon [deg], attitude [deg]
+    return dict(max_position_difference=float(dpos.max()), median_position_difference=float(np.median(dpos)), max_quaternion_difference=float(dq.max()))

@@ -33,6 +33,11 @@ def test_replay_tracking_loss_and_reinitialization_on_gpu(tmp_path):
     gc.check_replay_tracking_loss(H.HOST_LIB, tmp_path)
 
 
+def test_estimator_on_gpu_against_reference_estimator_golden(tmp_path):
+    import ref_gvins_utils as ru
+    gc.check_against_reference_estimator(H.HOST_LIB, tmp_path, ru.GOLDEN)
+
+
 def test_replay_gpu_agrees_with_oracle_backend(tmp_path):
     """the same files through the HIP-backed and the oracle-backed host layer: the front-end is bit-exact, the FP64 paths agree to rounding,
     so keyframe / landmark bookkeeping is identical and the trajectories agree to well below the estimator's accuracy"""

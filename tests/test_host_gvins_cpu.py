@@ -40,6 +40,13 @@ def test_replay_input_formats(host_lib, tmp_path):
     gc.check_replay_input_formats(host_lib, tmp_path)
 
 
+def test_estimator_against_reference_estimator_golden(host_lib, tmp_path):
+    """the reference's own ic_gvins.cc (oracle/_ref/libref_gvins.so, golden made by tests/golden/make_gvins_golden.py) on the same files"""
+    import ref_gvins_utils as ru
+    r = gc.check_against_reference_estimator(host_lib, tmp_path, ru.GOLDEN)
+    assert r["median_position_difference"] < 0.01
+
+
 def test_replay_input_errors(host_lib, tmp_path):
     lib = C.CDLL(host_lib)
     err = C.create_string_buffer(512)
