@@ -11,7 +11,6 @@
 #include <stdexcept>
 
 #include "yaml_lite.h"
-#include <fenv.h>
 
 namespace icg {
 
@@ -112,7 +111,6 @@ void GVINS::fail(const std::string &what) {
 GVINS::GVINS(const std::string &configfile, const std::string &outputpath, Drawer::Ptr drawer, int device) { // ic_gvins.cc:46-167
     gvinsstate_ = GVINS_ERROR;
     isfinished_ = true;
-    if (getenv("ICG_GVINS_FPE")) feenableexcept(FE_INVALID | FE_DIVBYZERO); // diagnostics: trap where a NaN is born
     YamlLite config;
     std::string err;
     if (!YamlLite::load(configfile, config, &err)) {
@@ -174,7 +172,6 @@ GVINS::GVINS(const std::string &configfile, const std::string &outputpath, Drawe
         optimize_num_iterations_     = (int) config.integer("optimize_num_iterations");
         optimize_windows_size_       = (size_t) config.integer("optimize_windows_size");
         optimize_reprojection_error_std_ = reprojection_error_std_ / camera_->focalLength();
-        if (getenv("ICG_GVINS_VISUAL_STD_SCALE")) optimize_reprojection_error_std_ *= atof(getenv("ICG_GVINS_VISUAL_STD_SCALE")); // diagnostics
         is_use_visualization_            = config.boolean("is_use_visualization");
         first_num_iterations_            = optimize_num_iterations_ / 4; // :1131-1132
         second_num_iterations_           = optimize_num_iterations_ - first_num_iterations_;
@@ -407,10 +404,6 @@ void GVINS::processTracking() { // body of runTracking (ic_gvins.cc:493-550)
         std::string err;
         if (!MISC::getCameraPoseFromInsWindowBatch(ctx_, {&ins_window_}, pose_b_c_, {frame->stamp()}, poses, found, &err)) fail("pose prior: " + err);
         frame->setPose(poses[0]);
-        if (debugOn())
-            fprintf(stderr, "[gvins-prior] %.4f %.6f %.6f %.6f %.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f\n", frame->stamp(), poses[0].t[0], poses[0].t[1], poses[0].t[2],
-                    poses[0].R(0, 0), poses[0].R(0, 1), poses[0].R(0, 2), poses[0].R(1, 0), poses[0].R(1, 1), poses[0].R(1, 2), poses[0].R(2, 0), poses[0].R(2, 1),
-                    poses[0].R(2, 2));
         TrackState trackstate = tracking_->track(frame);
         counters_.frames_tracked++;
         if (trackstate == TRACK_LOST) counters_.lost++;
@@ -767,9 +760,6 @@ int GVINS::addReprojectionFactors() { // ic_gvins.cc:1763-1837 (the Huber kernel
             if ((obs_frame_index < 0) || (ref_frame_index == obs_frame_index)) continue;
             visual_factors_.emplace_back(new ReprojectionFactor(ref_frame_pc, obs_frame_pc, ref_feature->velocityInPixel(), obs_feature->velocityInPixel(),
                                                                 ref_frame->timeDelay(), obs_frame->timeDelay(), optimize_reprojection_error_std_));
-            if (debugOn() && getenv("ICG_GVINS_DUMP_FACTORS"))
-                fprintf(stderr, "[gvins-factor] %ld %.4f %.4f %.9f %.9f %.9f %.9f %.9f %lu\n", counters_.optimizations, ref_frame->stamp(), obs_frame->stamp(),
-                        ref_frame_pc[0], ref_frame_pc[1], obs_frame_pc[0], obs_frame_pc[1], *invdepth, mappoint->id());
             if (!seen[invdepth]) {
                 seen[invdepth] = true;
                 visual_invdepth_blocks_.push_back(invdepth);
