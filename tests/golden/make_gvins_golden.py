@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/gvins_ref_golden.npz: the result files of the REFERENCE's own estimator (GVINS of ic_gvins.cc, compiled unmodified into
+"""Generates tests/golden/gvins_ref_*golden.npz (three scenarios: the plain sequence; Earth rotation + time-delay estimation; half a second of
+black images = tracking loss and re-initialization): the result files of the REFERENCE's own estimator (GVINS of ic_gvins.cc, compiled unmodified into
 oracle/_ref/libref_gvins.so — see oracle/ref_build/ref_gvins.cc for what the interface shims replace) on the synthetic GNSS + IMU + camera
 sequence of tests/gvins_data.py, played into its three threads three times slower than real time.  The reference's output depends on thread
 timing; this is one run of it.  Build container only:
@@ -30,15 +31,53 @@ def input_checksums(files):
     return np.array(out, np.int64)
 
 
-if __name__ == "__main__":
+def blank_images(files, root, seq, first=40, last=50):
+    names = [line.split()[1] for line in open(files["images"])]
+    for name in names[first:last]:
+        with open(os.path.join(root, "cam0", name), "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (seq.w, seq.h) + bytes(seq.w * seq.h))
+
+
+SCENARIOS = {  # name -> (golden file, Sequence.write keyword arguments, blank a stretch of images)
+    "default": ("gvins_ref_golden.npz", {}, False),
+    "earth_td": ("gvins_ref_earth_td_golden.npz", dict(estimate_td=True, with_earth=True), False),
+    "loss": ("gvins_ref_loss_golden.npz", {}, True),
+}
+
+def one_run(name, root):
+    """one run of the reference estimator on scenario `name` with its files under `root` (executed in a child process: the reference's threads
+    signal each other without predicates, so a run can stall for good — the parent kills it after a time limit and tries again)"""
+    golden, kwargs, blank = SCENARIOS[name]
     lib = C.CDLL(ensure_oracle_host())  # only its scene renderer is used here
     seq = gd.Sequence(lib)
-    root = tempfile.mkdtemp(prefix="gvins_golden_")
-    files = seq.write(root)
+    files = seq.write(root, **kwargs)
+    if blank:
+        blank_images(files, root, seq)
     out = os.path.join(root, "ref_out")
     state = ru.run_reference(files, out, seq.w, seq.h, slowdown=3.0)
-    assert state == 4, state
-    load = lambda name: np.loadtxt(os.path.join(out, name))
-    np.savez_compressed(ru.GOLDEN, final_state=state, trajectory=load("trajectory.csv"), nav=load("gvins.nav"), statistics=load("statistics.txt"),
-                        tracking=load("tracking.txt"), mappoints=load("mappoint.txt"), checksums=input_checksums(files))
-    print("trajectory rows", len(load("trajectory.csv")), "statistics rows", len(load("statistics.txt")), "mappoints", len(load("mappoint.txt")))
+    load = lambda f: np.loadtxt(os.path.join(out, f))
+    if not (state == 4 and len(load("statistics.txt")) >= 25 and len(load("trajectory.csv")) == 110):
+        print(name, "incomplete: state", state, "statistics rows", len(load("statistics.txt")))
+        return 1
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", golden), final_state=state, trajectory=load("trajectory.csv"), nav=load("gvins.nav"),
+                        statistics=load("statistics.txt"), tracking=load("tracking.txt"), mappoints=load("mappoint.txt"), checksums=input_checksums(files))
+    print(name, "trajectory rows", len(load("trajectory.csv")), "statistics rows", len(load("statistics.txt")), "mappoints", len(load("mappoint.txt")))
+    return 0
+
+
+if __name__ == "__main__":
+    import subprocess
+    if len(sys.argv) == 4 and sys.argv[1] == "--worker":
+        sys.exit(one_run(sys.argv[2], sys.argv[3]))
+    for name in (sys.argv[1:] or list(SCENARIOS)):
+        for attempt in range(5):
+            root = tempfile.mkdtemp(prefix="gvins_golden_")
+            try:
+                rc = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", name, root], timeout=120).returncode
+            except subprocess.TimeoutExpired:
+                rc = -1
+                print(name, "attempt", attempt, "stalled: killed")
+            if rc == 0:
+                break
+        else:
+            raise SystemExit("the reference estimator did not complete scenario " + name)

@@ -255,7 +255,7 @@ def check_replay_input_formats(lib_path, tmp_root):
     return S2
 
 
-def check_against_reference_estimator(lib_path, tmp_root, golden_path):
+def check_against_reference_estimator(lib_path, tmp_root, golden_path, write_kwargs=None, blank=None, n_keyframe_features_exact=10, pos_tol=0.05):
     """icg::GVINS against the REFERENCE's own estimator on the same input files (tests/golden/gvins_ref_golden.npz: ic_gvins.cc compiled
     unmodified on interface shims, one run of its three threads).  The reference's output depends on thread timing and its solver there is a
     restated LM, so the comparison is: identical discrete structure (navigation-line stamps, keyframe stamps and spacing, tracked-frame
@@ -264,7 +264,11 @@ def check_against_reference_estimator(lib_path, tmp_root, golden_path):
     import zlib
     lib = C.CDLL(lib_path)
     seq = gd.Sequence(lib)
-    files = seq.write(str(tmp_root))
+    files = seq.write(str(tmp_root), **(write_kwargs or {}))
+    if blank:  # a stretch of black images: tracking loss and re-initialization
+        for name in [line.split()[1] for line in open(files["images"])][blank[0]:blank[1]]:
+            with open(os.path.join(str(tmp_root), "cam0", name), "wb") as f:
+                f.write(b"P5\n%d %d\n255\n" % (seq.w, seq.h) + bytes(seq.w * seq.h))
     g = np.load(golden_path)
     root = os.path.dirname(files["images"])
     names = [line.split()[1] for line in open(files["images"])]
@@ -278,10 +282,12 @@ def check_against_reference_estimator(lib_path, tmp_root, golden_path):
     rt, rn, rs, rk, rm = g["trajectory"], g["nav"], g["statistics"], g["tracking"], g["mappoints"]
     # structure
     assert traj.shape == rt.shape and np.abs(traj[:, 0] - rt[:, 0]).max() < 1e-6
-    assert stat.shape == rs.shape and np.abs(stat[:, 0] - rs[:, 0]).max() < 1e-6  # every keyframe at the same frame
-    assert np.abs(stat[:, 1:3] - rs[:, 1:3]).max() < 1e-6                          # spacing and frame-id differences
-    assert track.shape == rk.shape and np.abs(track[:, 0] - rk[:, 0]).max() < 1e-6
-    assert np.array_equal(stat[:10, 3], rs[:10, 3]) and np.abs(stat[:, 3] - rs[:, 3]).max() <= 10   # feature counts of the keyframes
+    # frame stamps carry the (possibly estimated, ~1e-5 s) camera time delay: 1 ms separates frames that are 50 ms apart
+    assert stat.shape == rs.shape and np.abs(stat[:, 0] - rs[:, 0]).max() < 1e-3  # every keyframe at the same frame
+    assert np.abs(stat[:, 1] - rs[:, 1]).max() < 1e-3 and np.array_equal(stat[:, 2], rs[:, 2])  # spacing and frame-id differences
+    assert track.shape == rk.shape and np.abs(track[:, 0] - rk[:, 0]).max() < 1e-3
+    k = n_keyframe_features_exact
+    assert np.array_equal(stat[:k, 3], rs[:k, 3]) and np.abs(stat[:, 3] - rs[:, 3]).max() <= 10   # feature counts of the keyframes
     assert abs(len(mpts) - len(rm)) <= 15
     # numbers
     pre = traj[:, 0] < gd.T0 + 3.5  # GNSS/INS only: no image has been processed yet
@@ -290,6 +296,6 @@ def check_against_reference_estimator(lib_path, tmp_root, golden_path):
     assert np.array_equal(stat[:, 8], rs[:, 8])  # successful steps of the first solve (the 5-iteration cap)
     dpos = np.linalg.norm(traj[:, 1:4] - rt[:, 1:4], axis=1)
     dq = np.abs(traj[:, 4:8] - rt[:, 4:8]).max(axis=1)
-    assert dpos.max() < 0.05 and dq.max() < 1e-3, (dpos.max(), dq.max())
+    assert dpos.max() < pos_tol and dq.max() < 1e-3, (dpos.max(), dq.max())
     assert np.abs(nav[:, 2:4] - rn[:, 2:4]).max() < 1e-6 and np.abs(nav[:, 8:11] - rn[:, 8:11]).max() < 0.12  # lat/lon [deg], attitude [deg]
     return dict(max_position_difference=float(dpos.max()), median_position_difference=float(np.median(dpos)), max_quaternion_difference=float(dq.max()))

@@ -11,6 +11,12 @@ import gvins_data as gd
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libref_gvins.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden", "gvins_ref_golden.npz")
+# scenario -> (golden file, gvins_data.Sequence.write keyword arguments, (first, last) index of blacked-out images or None)
+SCENARIOS = {
+    "default": (GOLDEN, {}, None),
+    "earth_td": (os.path.join(ROOT, "tests", "golden", "gvins_ref_earth_td_golden.npz"), dict(estimate_td=True, with_earth=True), None),
+    "loss": (os.path.join(ROOT, "tests", "golden", "gvins_ref_loss_golden.npz"), {}, (40, 50)),
+}
 
 
 def _p(a):

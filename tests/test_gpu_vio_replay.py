@@ -33,9 +33,11 @@ def test_replay_tracking_loss_and_reinitialization_on_gpu(tmp_path):
     gc.check_replay_tracking_loss(H.HOST_LIB, tmp_path)
 
 
-def test_estimator_on_gpu_against_reference_estimator_golden(tmp_path):
+@pytest.mark.parametrize("scenario", ["default", "earth_td", "loss"])
+def test_estimator_on_gpu_against_reference_estimator_golden(tmp_path, scenario):
     import ref_gvins_utils as ru
-    gc.check_against_reference_estimator(H.HOST_LIB, tmp_path, ru.GOLDEN)
+    golden, kwargs, blank = ru.SCENARIOS[scenario]
+    gc.check_against_reference_estimator(H.HOST_LIB, tmp_path, golden, kwargs, blank, pos_tol=0.10 if blank else 0.05)
 
 
 def test_replay_gpu_agrees_with_oracle_backend(tmp_path):

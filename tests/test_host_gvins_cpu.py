@@ -40,10 +40,14 @@ def test_replay_input_formats(host_lib, tmp_path):
     gc.check_replay_input_formats(host_lib, tmp_path)
 
 
-def test_estimator_against_reference_estimator_golden(host_lib, tmp_path):
-    """the reference's own ic_gvins.cc (oracle/_ref/libref_gvins.so, golden made by tests/golden/make_gvins_golden.py) on the same files"""
+@pytest.mark.parametrize("scenario", ["default", "earth_td", "loss"])
+def test_estimator_against_reference_estimator_golden(host_lib, tmp_path, scenario):
+    """the reference's own ic_gvins.cc (oracle/_ref/libref_gvins.so, goldens made by tests/golden/make_gvins_golden.py) on the same files:
+    the plain sequence; Earth rotation (INS + PreintegrationEarth with the reference's effective zero station, hazard H9) with time-delay
+    estimation; half a second of black images (TRACK_LOST, empty keyframes, re-initialization)"""
     import ref_gvins_utils as ru
-    r = gc.check_against_reference_estimator(host_lib, tmp_path, ru.GOLDEN)
+    golden, kwargs, blank = ru.SCENARIOS[scenario]
+    r = gc.check_against_reference_estimator(host_lib, tmp_path, golden, kwargs, blank, pos_tol=0.10 if blank else 0.05)  # the reference's own runs of the loss scenario differ by 4-9 cm
     assert r["median_position_difference"] < 0.01
 
 
