@@ -4,9 +4,9 @@
 //   addReprojectionFactors     ic_gvins.cc:1763-1837   one ReprojectionFactor per (landmark, observing keyframe != reference)
 //   updateParametersFromOptimizer  ic_gvins.cc:1347-1391   keyframe poses, landmark positions / depths written back to the map
 // States are the BODY poses of the keyframes (the reference optimizes IMU poses, frames hold camera poses: MISC::stateToCameraPose
-// and its inverse with the body->camera extrinsic).  Everything else of GVINS (IMU / GNSS factors, marginalization order,
-// initialization state machine) is orchestration and stays out of scope; `addPosePriors` stands in for the factors that anchor the
-// poses in the real window.
+// and its inverse with the body->camera extrinsic).  This class serves the keyframe-only windows of the multi-stream refinement
+// (TrackingBatch + WindowSolverBatch); the complete estimator with IMU / GNSS time nodes, marginalization and the initialization
+// state machine is icg::GVINS (gvins_hip.h), which builds the same factors on its own state list.
 #pragma once
 #include <memory>
 #include <unordered_map>
