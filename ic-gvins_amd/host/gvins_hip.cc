@@ -121,7 +121,7 @@ GVINS::GVINS(const std::string &configfile, const std::string &outputpath, Drawe
     ptsfilesaver_    = FileSaver::create(outputpath + "/mappoint.txt", 3);
     statfilesaver_   = FileSaver::create(outputpath + "/statistics.txt", 3);
     extfilesaver_    = FileSaver::create(outputpath + "/extrinsic.txt", 3);
-    imuerrfilesaver_ = FileSaver::create(outputpath + "/IMU_ERR.txt", 7); // the reference writes this one in binary (IMU_ERR.bin); text here
+    imuerrfilesaver_ = FileSaver::create(outputpath + "/IMU_ERR.bin", 7, FileSaver::BINARY);
     trajfilesaver_   = FileSaver::create(outputpath + "/trajectory.csv", 8);
     if (!navfilesaver_->isOpen() || !ptsfilesaver_->isOpen() || !statfilesaver_->isOpen() || !extfilesaver_->isOpen()) {
         error_ = "Failed to open data file";

@@ -48,12 +48,18 @@ bool fail(icg_ctx *ctx, std::string *err) {
 }
 } // namespace
 
-FileSaver::FileSaver(const std::string &filename, int columns) : columns_(columns) { fp_ = fopen(filename.c_str(), "w"); }
+FileSaver::FileSaver(const std::string &filename, int columns, int filetype) : columns_(columns), filetype_(filetype) {
+    fp_ = fopen(filename.c_str(), filetype == TEXT ? "w" : "wb");
+}
 FileSaver::~FileSaver() {
     if (fp_) fclose(fp_);
 }
 void FileSaver::dump(const std::vector<double> &data) { // filesaver.cc:51-66
     if (!fp_) return;
+    if (filetype_ == BINARY) {
+        fwrite(data.data(), sizeof(double), data.size(), fp_);
+        return;
+    }
     for (double v : data) fprintf(fp_, "%-15.9lf ", v);
     fprintf(fp_, "\n");
 }

@@ -25,20 +25,21 @@ struct IntegrationConfiguration { // preintegration/integration_state.h:91-99
 
 typedef std::deque<std::pair<IMU, IntegrationState>> InsWindow;
 
-// fileio/filesaver.h:35-66, text mode: one "%-15.9lf " per value, newline per dump()
+// fileio/filesaver.h:35-66: text mode = one "%-15.9lf " per value and a newline per dump(); binary mode = the doubles as they are
 class FileSaver {
 public:
     typedef std::shared_ptr<FileSaver> Ptr;
-    FileSaver(const std::string &filename, int columns);
+    enum { TEXT = 0, BINARY = 1 }; // fileio/filebase.h:35-38
+    FileSaver(const std::string &filename, int columns, int filetype = TEXT);
     ~FileSaver();
-    static Ptr create(const std::string &filename, int columns) { return std::make_shared<FileSaver>(filename, columns); }
+    static Ptr create(const std::string &filename, int columns, int filetype = TEXT) { return std::make_shared<FileSaver>(filename, columns, filetype); }
     bool isOpen() const { return fp_ != nullptr; }
     void dump(const std::vector<double> &data);
     void flush();
 
 private:
     FILE *fp_{nullptr};
-    int columns_;
+    int columns_, filetype_;
 };
 
 class MISC {

@@ -1,7 +1,7 @@
 // icg_replay — command-line front of the replay harness (ic-gvins_amd/host/replay.h): what `roslaunch ic_gvins ic_gvins.launch
 // configfile:=...` + `rosbag play` do for the reference (README.md:100-109, ROS/fusion_ros.cc), with files in place of a ROS bag.
 //   icg_replay --config gvins.yaml --imu imu.txt [--gnss gnss.txt] [--images cam0/images.txt] [--output DIR] [--imu-rate] [--start T] [--end T]
-// Results (gvins.nav, trajectory.csv, tracking.txt, statistics.txt, extrinsic.txt, mappoint.txt, IMU_ERR.txt, a copy of the configuration)
+// Results (gvins.nav, trajectory.csv, tracking.txt, statistics.txt, extrinsic.txt, mappoint.txt, IMU_ERR.bin, a copy of the configuration)
 // go to --output or to the configuration's `outputpath`.  Needs an MI355X: the library behind it has no CPU fallback.
 #include <cstdio>
 #include <cstdlib>

@@ -60,7 +60,8 @@ def one_run(name, root):
         print(name, "incomplete: state", state, "statistics rows", len(load("statistics.txt")))
         return 1
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", golden), final_state=state, trajectory=load("trajectory.csv"), nav=load("gvins.nav"),
-                        statistics=load("statistics.txt"), tracking=load("tracking.txt"), mappoints=load("mappoint.txt"), checksums=input_checksums(files))
+                        statistics=load("statistics.txt"), tracking=load("tracking.txt"), mappoints=load("mappoint.txt"), checksums=input_checksums(files),
+                        imu_err=np.fromfile(os.path.join(out, "IMU_ERR.bin"), np.float64).reshape(-1, 8))
     print(name, "trajectory rows", len(load("trajectory.csv")), "statistics rows", len(load("statistics.txt")), "mappoints", len(load("mappoint.txt")))
     return 0
 

@@ -36,7 +36,7 @@ def trajectory_errors(seq, files):
 
 def check_result_files(files, S):
     out = files["out"]
-    cols = {"gvins.nav": 11, "trajectory.csv": 8, "IMU_ERR.txt": 8, "statistics.txt": 15, "tracking.txt": 7, "mappoint.txt": 3}
+    cols = {"gvins.nav": 11, "trajectory.csv": 8, "statistics.txt": 15, "tracking.txt": 7, "mappoint.txt": 3}
     rows = {}
     for name, nc in cols.items():
         path = os.path.join(out, name)
@@ -48,6 +48,10 @@ def check_result_files(files, S):
             assert line.endswith(" \n") and all(len(tok.split(".")[1]) == 9 for tok in line.split()), (name, line)
             break
     assert os.path.exists(os.path.join(out, "gvins.yaml"))
+    # IMU_ERR.bin: raw doubles, 8 per navigation line (time, gyroscope bias [deg/h], accelerometer bias [mGal], odometer scale), misc.cc:452-470
+    imu_err = np.fromfile(os.path.join(out, "IMU_ERR.bin"), np.float64).reshape(-1, 8)
+    assert len(imu_err) == len(rows["gvins.nav"]) and np.array_equal(imu_err[:, 0], rows["gvins.nav"][:, 1]) and np.all(imu_err[:, 7] == 0)
+    assert np.abs(imu_err[-1, 1:4]).max() < 500 and np.abs(imu_err[-1, 4:7]).max() < 5000  # estimates near the simulated 20-40 deg/h, 600-1000 mGal
     nav, traj, stat = rows["gvins.nav"], rows["trajectory.csv"], rows["statistics.txt"]
     # one navigation / trajectory line per 10 IMU epochs after the initialization (misc.cc:419-425)
     assert len(nav) == len(traj) and np.array_equal(nav[:, 1], traj[:, 0])
@@ -282,10 +286,19 @@ def check_against_reference_estimator(lib_path, tmp_root, golden_path, write_kwa
     rt, rn, rs, rk, rm = g["trajectory"], g["nav"], g["statistics"], g["tracking"], g["mappoints"]
     # structure
     assert traj.shape == rt.shape and np.abs(traj[:, 0] - rt[:, 0]).max() < 1e-6
-    # frame stamps carry the (possibly estimated, ~1e-5 s) camera time delay: 1 ms separates frames that are 50 ms apart
-    assert stat.shape == rs.shape and np.abs(stat[:, 0] - rs[:, 0]).max() < 1e-3  # every keyframe at the same frame
+    # frame stamps carry the (possibly estimated, ~1e-5 s) camera time delay: 1 ms separates frames that are 50 ms apart.  The keyframe
+    # decision is a parallax threshold, and in the reference the poses it is computed from depend on when its optimizer thread handed its
+    # result over: one of its runs in a few picks a keyframe one frame later somewhere in the second half and stays shifted from there on.
+    # Required: the same number of keyframes (+-1), identical keyframes over at least the first 20, and the per-keyframe columns on that part.
+    assert abs(len(stat) - len(rs)) <= 1 and abs(len(track) - len(rk)) <= 1
+    n = min(len(stat), len(rs))
+    same = np.abs(stat[:n, 0] - rs[:n, 0]) < 1e-3
+    m = n if same.all() else int(np.argmin(same))
+    assert m >= 20, (m, stat[:n, 0] - rs[:n, 0])
+    stat, rs = stat[:m], rs[:m]
     assert np.abs(stat[:, 1] - rs[:, 1]).max() < 1e-3 and np.array_equal(stat[:, 2], rs[:, 2])  # spacing and frame-id differences
-    assert track.shape == rk.shape and np.abs(track[:, 0] - rk[:, 0]).max() < 1e-3
+    nt = min(len(track), len(rk))
+    assert (np.abs(track[:nt, 0] - rk[:nt, 0]) < 1e-3).sum() >= min(nt, 20)
     k = n_keyframe_features_exact
     assert np.array_equal(stat[:k, 3], rs[:k, 3]) and np.abs(stat[:, 3] - rs[:, 3]).max() <= 10   # feature counts of the keyframes
     assert abs(len(mpts) - len(rm)) <= 15
@@ -298,4 +311,18 @@ def check_against_reference_estimator(lib_path, tmp_root, golden_path, write_kwa
     dq = np.abs(traj[:, 4:8] - rt[:, 4:8]).max(axis=1)
     assert dpos.max() < pos_tol and dq.max() < 1e-3, (dpos.max(), dq.max())
     assert np.abs(nav[:, 2:4] - rn[:, 2:4]).max() < 1e-6 and np.abs(nav[:, 8:11] - rn[:, 8:11]).max() < 0.12  # lat/lon [deg], attitude [deg]
-    return dict(max_position_difference=float(dpos.max()), median_position_difference=float(np.median(dpos)), max_quaternion_difference=float(dq.max()))
+    # IMU_ERR.bin (raw doubles as the reference writes them): the bias estimates follow the reference's
+    ie, re_ = np.fromfile(os.path.join(files["out"], "IMU_ERR.bin"), np.float64).reshape(-1, 8), g["imu_err"]
+    assert ie.shape == re_.shape and np.array_equal(ie[:, 0], re_[:, 0])
+    assert np.abs(ie[pre][:, 1:7] - re_[pre][:, 1:7]).max() < 1e-3
+    # a new estimate reaches the INS a few epochs later in the reference (its optimizer thread hands it over with try_lock), so single lines
+    # around a window solve differ by a whole update: compare each line with the reference's lines at the same and the neighbouring stamps
+    def line_difference(cols):
+        best = np.full(len(ie), np.inf)
+        for shift in (-1, 0, 1):
+            idx = np.clip(np.arange(len(ie)) + shift, 0, len(re_) - 1)
+            best = np.minimum(best, np.abs(ie[:, cols] - re_[idx][:, cols]).max(axis=1))
+        return float(best.max())
+    bias = dict(gyro_deg_per_h=line_difference(slice(1, 4)), acc_mgal=line_difference(slice(4, 7)))
+    assert bias["gyro_deg_per_h"] < 20 and bias["acc_mgal"] < 600, bias  # of estimates that reach 70 deg/h and 1 700 mGal (weakly observable here)
+    return dict(max_position_difference=float(dpos.max()), median_position_difference=float(np.median(dpos)), max_quaternion_difference=float(dq.max()), **bias)
