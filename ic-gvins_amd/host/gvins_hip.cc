@@ -418,22 +418,40 @@ void GVINS::processTracking() { // body of runTracking (ic_gvins.cc:493-550)
 // ---- optimization loop body ------------------------------------------------------------------------------------------------
 void GVINS::runOptimizationOnce() { // body of runOptimization (ic_gvins.cc:404-475)
     if (!(isgnssobs_ || isvisualobs_)) return;
-    TimeCost timecost2;
     if (gvinsstate_ == GVINS_INITIALIZING_INS) {
         bool isinitialized = gvinsInitializationOptimization();
         if (preintegrationlist_.size() >= static_cast<size_t>(initlength_)) {
             gvinsstate_ = GVINS_INITIALIZING_VIO;
             GLOG("GINS initialization %s", isinitialized ? "is finished" : "is not convergence");
         }
+        afterWindowSolve();
     } else if (gvinsstate_ >= GVINS_TRACKING_INITIALIZING) {
         if (map_->isMaximumKeframes()) gvinsstate_ = GVINS_TRACKING_NORMAL;
-        gvinsOptimization();
-        timecost2.restart();
+        if (deferred_window_solves_) { // the caller runs the phases (possibly together with other estimators' windows)
+            window_solve_pending_ = true;
+            return;
+        }
+        solveWindowAlone();
+    } else {
+        afterWindowSolve();
+    }
+}
+
+void GVINS::solveWindowAlone() {
+    gvinsOptimization();
+    afterWindowSolve();
+}
+
+// what follows the solve in runOptimization (:436-471): window maintenance, statistics, the flags the fusion loop looks at
+void GVINS::afterWindowSolve() {
+    if (gvinsstate_ >= GVINS_TRACKING_INITIALIZING) {
+        TimeCost timecost2;
         gvinsRemoveAllSecondNewFrame();
         while (map_->isMaximumKeframes()) gvinsMarginalization();
         timecosts_[2] = timecost2.costInMillisecond();
         parametersStatistic();
     }
+    window_solve_pending_ = false;
     isgnssobs_ = isvisualobs_ = false;
     isoptimized_              = true;
     counters_.optimizations++;
@@ -507,14 +525,15 @@ bool GVINS::gvinsInitialization() { // ic_gvins.cc:584-692
 }
 
 bool GVINS::gvinsInitializationOptimization() { // ic_gvins.cc:694-722 (Ceres SPARSE_NORMAL_CHOLESKY, 50 iterations)
-    WindowSolver problem(nullptr, 0.0);
+    WindowSolver solver(nullptr, 0.0);
+    SingleWindowProblem problem(solver);
     addStateParameters(problem);
     addGnssFactors(problem, true);
     addImuFactors(problem);
     WindowSolver::Options options;
     options.max_num_iterations = 50;
     WindowSolver::Summary summary;
-    if (!problem.solve(options, &summary)) fail("GNSS/INS initialization solve: " + problem.error());
+    if (!solver.solve(options, &summary)) fail("GNSS/INS initialization solve: " + solver.error());
     GLOG("%s", summary.BriefReport().c_str());
     // ceres::CONVERGENCE: one of the three tolerances was met (only logged by the caller, ic_gvins.cc:420-424)
     return summary.termination == "function_tolerance" || summary.termination == "gradient_tolerance" || summary.termination == "parameter_tolerance";
@@ -671,14 +690,14 @@ void GVINS::constructPrior(bool is_zero_velocity) { // ic_gvins.cc:1911-1936
 }
 
 // ---- problem construction -----------------------------------------------------------------------------------------------------
-void GVINS::addStateParameters(WindowSolver &problem) { // ic_gvins.cc:1850-1864
+void GVINS::addStateParameters(WindowProblem &problem) { // ic_gvins.cc:1850-1864
     for (auto &statedata : statedatalist_) {
         problem.addParameterBlock(statedata.pose, 7, true);
         problem.addParameterBlock(statedata.mix, 9);
     }
 }
 
-void GVINS::addImuFactors(WindowSolver &problem) { // ic_gvins.cc:1866-1889
+void GVINS::addImuFactors(WindowProblem &problem) { // ic_gvins.cc:1866-1889
     for (size_t k = 0; k < preintegrationlist_.size(); k++)
         problem.addResidualBlock(std::make_shared<PreintegrationFactor>(preintegrationlist_[k]), nullptr,
                                  {statedatalist_[k].pose, statedatalist_[k].mix, statedatalist_[k + 1].pose, statedatalist_[k + 1].mix});
@@ -689,7 +708,7 @@ void GVINS::addImuFactors(WindowSolver &problem) { // ic_gvins.cc:1866-1889
     }
 }
 
-std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> GVINS::addGnssFactors(WindowSolver &problem, bool isusekernel) { // :1891-1909
+std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> GVINS::addGnssFactors(WindowProblem &problem, bool isusekernel) { // :1891-1909
     std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> residual_block;
     std::shared_ptr<ceres::LossFunction> loss_function;
     if (isusekernel) loss_function = std::make_shared<HuberLossHip>(1.0);
@@ -728,10 +747,11 @@ void GVINS::addReprojectionParameters() { // ic_gvins.cc:1697-1761 (the blocks t
     extrinsic_[7] = td_b_c_;
 }
 
-int GVINS::addReprojectionFactors() { // ic_gvins.cc:1763-1837 (the Huber kernel is the solver's huber_delta)
+int GVINS::addReprojectionFactors() { // ic_gvins.cc:1763-1837 (the Huber kernel is the solver's huber_delta); collected, registered later
     visual_batch_->clear();
     visual_factors_.clear();
     visual_invdepth_blocks_.clear();
+    visual_blocks_.clear();
     std::unordered_map<const double *, bool> seen;
     if (map_->keyframes().empty()) return 0;
     for (const auto &landmark : map_->landmarks()) {
@@ -764,17 +784,15 @@ int GVINS::addReprojectionFactors() { // ic_gvins.cc:1763-1837 (the Huber kernel
                 seen[invdepth] = true;
                 visual_invdepth_blocks_.push_back(invdepth);
             }
-            visual_batch_->add(visual_factors_.back().get(), statedatalist_[(size_t) ref_frame_index].pose, statedatalist_[(size_t) obs_frame_index].pose,
-                               extrinsic_, invdepth, &extrinsic_[7]);
+            visual_blocks_.push_back({statedatalist_[(size_t) ref_frame_index].pose, statedatalist_[(size_t) obs_frame_index].pose, invdepth});
         }
     }
-    if (!visual_factors_.empty()) visual_batch_->finalize();
     return (int) visual_factors_.size();
 }
 
 // the parameter blocks of the visual factors: inverse depths that carry at least one factor (Ceres drops blocks without residuals
 // from the reduced program), the extrinsic and the time delay, constant unless estimated in the normal tracking state (:1747-1760)
-void GVINS::registerReprojectionBlocks(WindowSolver &problem) {
+void GVINS::registerReprojectionBlocks(WindowProblem &problem) {
     for (double *p : visual_invdepth_blocks_) problem.addParameterBlock(p, 1);
     problem.addParameterBlock(extrinsic_, 7, true);
     problem.addParameterBlock(&extrinsic_[7], 1);
@@ -797,53 +815,74 @@ void GVINS::doReintegration() { // ic_gvins.cc:1680-1695: every interval that ne
 }
 
 // ---- the window solve ------------------------------------------------------------------------------------------------------------
-bool GVINS::gvinsOptimization() { // ic_gvins.cc:1130-1239
-    TimeCost timecost;
-    // the reprojection batch has to be complete before the solver is built on it (WindowSolver drives it on the device)
+// ---- the window solve in phases (ic_gvins.cc:1130-1239) --------------------------------------------------------------------------
+int GVINS::beginWindowSolve() { // parameters and factors of the visual part (:1150-1154, 1173)
     addReprojectionParameters();
     const int n_visual = addReprojectionFactors();
     counters_.reprojection_factors += n_visual;
-    WindowSolver problem(n_visual > 0 ? visual_batch_.get() : nullptr, 1.0);
-    addStateParameters(problem);
-    if (n_visual > 0) registerReprojectionBlocks(problem);
+    return n_visual;
+}
 
+void GVINS::populateWindow(WindowProblem &problem, int n_visual) { // :1148-1176
+    addStateParameters(problem);
+    if (n_visual > 0) {
+        registerReprojectionBlocks(problem);
+        for (size_t k = 0; k < visual_factors_.size(); k++)
+            problem.addReprojectionFactor(visual_factors_[k].get(), visual_blocks_[k].pose_i, visual_blocks_[k].pose_j, extrinsic_, visual_blocks_[k].invdepth,
+                                          &extrinsic_[7]);
+    }
     if (last_marginalization_info_ && last_marginalization_info_->isValid())
         problem.addResidualBlock(std::make_shared<MarginalizationFactor>(last_marginalization_info_), nullptr, last_marginalization_parameter_blocks_);
-    auto gnss_residual_block = addGnssFactors(problem, true);
+    gnss_blocks_ = addGnssFactors(problem, true);
     addImuFactors(problem);
     GLOG("Add %zu preintegration, %zu GNSS, %d reprojection", preintegrationlist_.size(), gnsslist_.size(), n_visual);
+}
 
-    WindowSolver::Options options;
-    WindowSolver::Summary summary;
-    { // the first optimization
-        timecost.restart();
-        options.max_num_iterations = first_num_iterations_;
-        if (!problem.solve(options, &summary)) fail("window solve: " + problem.error());
-        GLOG("%s", summary.BriefReport().c_str());
-        iterations_[0] = summary.num_successful_steps;
-        timecosts_[0]  = timecost.costInMillisecond();
-    }
-    { // outlier detection for GNSS and visual (:1192-1208)
-        gnssOutlierCullingByChi2(problem, gnss_residual_block);
-        if (n_visual > 0) counters_.chi2_removed += problem.removeReprojectionFactorsByChi2(5.991);
-        for (auto &block : gnss_residual_block) problem.removeResidualBlock(block.first);
-        addGnssFactors(problem, false);
-    }
-    { // the second optimization
-        options.max_num_iterations = second_num_iterations_;
-        timecost.restart();
-        if (!problem.solve(options, &summary)) fail("window solve: " + problem.error());
-        GLOG("%s", summary.BriefReport().c_str());
-        iterations_[1] = summary.num_successful_steps;
-        timecosts_[1]  = timecost.costInMillisecond();
-        if (!map_->isMaximumKeframes()) doReintegration();
-    }
+void GVINS::betweenWindowSolves(WindowProblem &problem) { // outlier detection for GNSS (:1192-1208; the visual factors are the solver's part)
+    gnssOutlierCullingByChi2(problem, gnss_blocks_);
+    for (auto &block : gnss_blocks_) problem.removeResidualBlock(block.first);
+    addGnssFactors(problem, false);
+}
+
+void GVINS::finishWindowSolve(const WindowSolver::Summary &first, const WindowSolver::Summary &second, double first_ms, double second_ms, int chi2_removed) {
+    GLOG("%s", first.BriefReport().c_str());
+    GLOG("%s", second.BriefReport().c_str());
+    iterations_[0] = first.num_successful_steps, iterations_[1] = second.num_successful_steps;
+    timecosts_[0] = first_ms, timecosts_[1] = second_ms;
+    counters_.chi2_removed += chi2_removed;
+    if (!map_->isMaximumKeframes()) doReintegration(); // :1223-1227
     updateParametersFromOptimizer();
     gvinsOutlierCulling();
+    gnss_blocks_.clear();
+}
+
+bool GVINS::gvinsOptimization() { // the phases on a WindowSolver of this estimator
+    TimeCost timecost;
+    const int n_visual = beginWindowSolve();
+    if (n_visual > 0) { // the reprojection batch has to be complete before the solver is built on it (WindowSolver drives it on the device)
+        for (size_t k = 0; k < visual_factors_.size(); k++)
+            visual_batch_->add(visual_factors_[k].get(), visual_blocks_[k].pose_i, visual_blocks_[k].pose_j, extrinsic_, visual_blocks_[k].invdepth, &extrinsic_[7]);
+        visual_batch_->finalize();
+    }
+    WindowSolver solver(n_visual > 0 ? visual_batch_.get() : nullptr, 1.0);
+    SingleWindowProblem problem(solver);
+    populateWindow(problem, n_visual);
+    WindowSolver::Options options;
+    WindowSolver::Summary first, second;
+    timecost.restart();
+    options.max_num_iterations = first_num_iterations_;
+    if (!solver.solve(options, &first)) fail("window solve: " + solver.error());
+    const double first_ms = timecost.costInMillisecond();
+    betweenWindowSolves(problem);
+    const int removed = n_visual > 0 ? solver.removeReprojectionFactorsByChi2(5.991) : 0;
+    options.max_num_iterations = second_num_iterations_;
+    timecost.restart();
+    if (!solver.solve(options, &second)) fail("window solve: " + solver.error());
+    finishWindowSolve(first, second, first_ms, timecost.costInMillisecond(), removed);
     return true;
 }
 
-void GVINS::gnssOutlierCullingByChi2(WindowSolver &problem, std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> &residual_block) { // :1241-1267
+void GVINS::gnssOutlierCullingByChi2(WindowProblem &problem, std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> &residual_block) { // :1241-1267
     const double chi2_threshold = 7.815;
     for (auto &block : residual_block) {
         double cost = 0;

@@ -32,6 +32,7 @@
 #include "factors.h"
 #include "misc_hip.h"
 #include "nav_factors.h"
+#include "solver_batch_hip.h"
 #include "solver_hip.h"
 #include "tracking.h"
 
@@ -41,6 +42,55 @@ struct IntegrationStateData { // preintegration/integration_state.h:54-60
     double time{0};
     double pose[7]{0, 0, 0, 0, 0, 0, 1};
     double mix[18]{0};
+};
+
+// What the window problem of the estimator is built on: a WindowSolver of its own (one stream), or one window of a WindowSolverBatch
+// shared with the estimators of other camera streams (GvinsLockstep, replay.h).  The surface is ceres::Problem's.
+class WindowProblem {
+public:
+    virtual ~WindowProblem() = default;
+    virtual void addParameterBlock(double *values, int size, bool pose_manifold = false)                                     = 0;
+    virtual void setParameterBlockConstant(double *values)                                                                   = 0;
+    virtual int addResidualBlock(std::shared_ptr<ceres::CostFunction> cost, std::shared_ptr<ceres::LossFunction> loss,
+                                 const std::vector<double *> &blocks)                                                        = 0;
+    virtual void removeResidualBlock(int id)                                                                                 = 0;
+    virtual bool evaluateResidualBlock(int id, bool apply_loss_function, double *cost)                                       = 0;
+    virtual void addReprojectionFactor(const ReprojectionFactor *factor, double *pose_i, double *pose_j, double *extrinsic, double *invdepth,
+                                       double *td)                                                                           = 0;
+};
+class SingleWindowProblem : public WindowProblem { // the visual factors already sit in the ReprojectionBatch the solver was built on
+public:
+    explicit SingleWindowProblem(WindowSolver &solver) : s_(solver) {}
+    void addParameterBlock(double *v, int size, bool pose) override { s_.addParameterBlock(v, size, pose); }
+    void setParameterBlockConstant(double *v) override { s_.setParameterBlockConstant(v); }
+    int addResidualBlock(std::shared_ptr<ceres::CostFunction> c, std::shared_ptr<ceres::LossFunction> l, const std::vector<double *> &b) override {
+        return s_.addResidualBlock(std::move(c), std::move(l), b);
+    }
+    void removeResidualBlock(int id) override { s_.removeResidualBlock(id); }
+    bool evaluateResidualBlock(int id, bool apply, double *cost) override { return s_.evaluateResidualBlock(id, apply, cost); }
+    void addReprojectionFactor(const ReprojectionFactor *, double *, double *, double *, double *, double *) override {}
+
+private:
+    WindowSolver &s_;
+};
+class BatchWindowProblem : public WindowProblem {
+public:
+    BatchWindowProblem(WindowSolverBatch &batch, int window) : b_(batch), w_(window) {}
+    int window() const { return w_; }
+    void addParameterBlock(double *v, int size, bool pose) override { b_.addParameterBlock(w_, v, size, pose); }
+    void setParameterBlockConstant(double *v) override { b_.setParameterBlockConstant(w_, v); }
+    int addResidualBlock(std::shared_ptr<ceres::CostFunction> c, std::shared_ptr<ceres::LossFunction> l, const std::vector<double *> &b) override {
+        return b_.addResidualBlock(w_, std::move(c), std::move(l), b);
+    }
+    void removeResidualBlock(int id) override { b_.removeResidualBlock(w_, id); }
+    bool evaluateResidualBlock(int id, bool apply, double *cost) override { return b_.evaluateResidualBlock(w_, id, apply, cost); }
+    void addReprojectionFactor(const ReprojectionFactor *f, double *pi, double *pj, double *ext, double *inv, double *td) override {
+        b_.addReprojectionFactor(w_, f, pi, pj, ext, inv, td);
+    }
+
+private:
+    WindowSolverBatch &b_;
+    int w_;
 };
 
 class GVINS {
@@ -69,6 +119,22 @@ public:
     void setWaitMode(int icg_wait_mode, int sleep_us);
     bool isRunning() const { return !isfinished_; }
     GVINSState gvinsState() const { return gvinsstate_; }
+
+    // ---- lock-step interface: the window solve of several estimators shared through one WindowSolverBatch (replay.h) ----
+    // With deferred solves on, an optimization that addNewImu signals in the tracking states is not run inside addNewImu; the caller asks
+    // windowSolvePending() after the call and drives the phases: n = beginWindowSolve(); populateWindow(problem, n); [solve 1];
+    // betweenWindowSolves(problem); [chi-square removal of reprojection factors]; [solve 2]; finishWindowSolve(...); afterWindowSolve().
+    // solveWindowAlone() runs the same phases on a WindowSolver of this estimator (what addNewImu does without deferral).
+    void setDeferredWindowSolves(bool on) { deferred_window_solves_ = on; }
+    bool windowSolvePending() const { return window_solve_pending_; }
+    int beginWindowSolve();
+    void populateWindow(WindowProblem &problem, int n_visual);
+    void betweenWindowSolves(WindowProblem &problem);
+    void finishWindowSolve(const WindowSolver::Summary &first, const WindowSolver::Summary &second, double first_ms, double second_ms, int chi2_removed);
+    void afterWindowSolve();
+    void solveWindowAlone();
+    int firstNumIterations() const { return first_num_iterations_; }
+    int secondNumIterations() const { return second_num_iterations_; }
 
     // ---- read-only views for the replay harness and the tests ----
     struct Counters {
@@ -108,11 +174,11 @@ private:
     bool removeUnusedTimeNode();
     void constructPrior(bool is_zero_velocity);
 
-    void addStateParameters(WindowSolver &problem);
+    void addStateParameters(WindowProblem &problem);
     void addReprojectionParameters();
-    void registerReprojectionBlocks(WindowSolver &problem);
-    void addImuFactors(WindowSolver &problem);
-    std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> addGnssFactors(WindowSolver &problem, bool isusekernel);
+    void registerReprojectionBlocks(WindowProblem &problem);
+    void addImuFactors(WindowProblem &problem);
+    std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> addGnssFactors(WindowProblem &problem, bool isusekernel);
     int addReprojectionFactors();
     void doReintegration();
     void updateParametersFromOptimizer();
@@ -121,7 +187,7 @@ private:
     bool gvinsMarginalization();
     bool gvinsOutlierCulling();
     bool gvinsRemoveAllSecondNewFrame();
-    void gnssOutlierCullingByChi2(WindowSolver &problem, std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> &residual_block);
+    void gnssOutlierCullingByChi2(WindowProblem &problem, std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> &residual_block);
 
     std::shared_ptr<Preintegration> createPreintegration(const IMU &imu0, const IntegrationState &state);
     void integrate(const std::vector<Preintegration *> &list);
@@ -201,6 +267,12 @@ private:
     std::unique_ptr<ReprojectionBatch> visual_batch_, marg_batch_;
     std::vector<std::unique_ptr<ReprojectionFactor>> visual_factors_;
     std::vector<double *> visual_invdepth_blocks_; // inverse depths with at least one factor, first-seen order
+    struct VisualBlocks {
+        double *pose_i, *pose_j, *invdepth;
+    };
+    std::vector<VisualBlocks> visual_blocks_; // the blocks of visual_factors_[k]
+    std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> gnss_blocks_; // GNSS residual blocks of the window being solved
+    bool deferred_window_solves_{false}, window_solve_pending_{false};
     Counters counters_;
     std::string error_;
 };

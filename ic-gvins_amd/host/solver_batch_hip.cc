@@ -56,6 +56,21 @@ int WindowSolverBatch::addWindow() {
     return (int) windows_.size() - 1;
 }
 
+void WindowSolverBatch::clear() {
+    windows_.clear();
+    active_.clear();
+    col_pose_.clear(), col_ext_.clear(), col_td_.clear();
+    P_ = n_factors_ = n_poses_ = n_lm_ = 0;
+    finalized_ = false;
+    error_.clear();
+}
+
+void WindowSolverBatch::removeResidualBlock(int w, int id) { windows_.at((size_t) w).residuals.at((size_t) id).removed = true; }
+
+bool WindowSolverBatch::evaluateResidualBlock(int w, int id, bool apply_loss_function, double *cost) const {
+    return solver_detail::residualCost(windows_.at((size_t) w).residuals.at((size_t) id), apply_loss_function, cost);
+}
+
 void WindowSolverBatch::addParameterBlock(int w, double *values, int size, bool pose_manifold) {
     Window &W = windows_.at((size_t) w);
     if (W.block_of.count(values)) return;

@@ -29,9 +29,15 @@ public:
 
     int addWindow();
     int numWindows() const { return (int) windows_.size(); }
+    // drops every window but keeps the device context (a batch object that is re-used for one set of windows after another)
+    void clear();
     void addParameterBlock(int w, double *values, int size, bool pose_manifold = false);
     void setParameterBlockConstant(int w, double *values);
     int addResidualBlock(int w, std::shared_ptr<ceres::CostFunction> cost, std::shared_ptr<ceres::LossFunction> loss, const std::vector<double *> &blocks);
+    void removeResidualBlock(int w, int id);
+    // problem.EvaluateResidualBlock(id, apply_loss_function, &cost, nullptr, nullptr) for a host factor of window w
+    bool evaluateResidualBlock(int w, int id, bool apply_loss_function, double *cost) const;
+    int numReprojectionFactors(int w) const { return (int) windows_.at((size_t) w).visual.size(); }
     // a reprojection factor of window w with the five blocks it would get in AddResidualBlock (only its observation constants are
     // read from `factor`); all factors of a window share its extrinsic and td blocks
     void addReprojectionFactor(int w, const ReprojectionFactor *factor, double *pose_i, double *pose_j, double *extrinsic, double *invdepth, double *td);
