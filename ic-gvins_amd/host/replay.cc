@@ -228,4 +228,148 @@ bool Replay::runMany(const std::vector<ReplayOptions> &options, std::vector<Repl
     return true;
 }
 
+namespace {
+struct LockstepStream {
+    std::unique_ptr<GVINS> gvins;
+    std::vector<IMU> imus;
+    std::vector<GNSS> gnss;
+    std::vector<Replay::ImageEntry> images;
+    size_t ii = 0, gi = 0, fi = 0;
+    bool isusegnssoutage = false;
+    double gnssoutagetime = 0, gnssthreshold = 1e9, first = 0, last = 0;
+    ReplaySummary *summary = nullptr;
+    std::unique_ptr<BatchWindowProblem> problem;
+    int n_visual = 0;
+};
+} // namespace
+
+bool Replay::runLockstep(const std::vector<ReplayOptions> &options, std::vector<ReplaySummary> &summaries, double *wall_seconds, long *shared_solves,
+                         std::string *err) {
+    const size_t n = options.size();
+    summaries.assign(n, ReplaySummary());
+    std::vector<LockstepStream> S(n);
+    for (size_t k = 0; k < n; k++) {
+        const ReplayOptions &o = options[k];
+        YamlLite config;
+        if (!YamlLite::load(o.configfile, config, err)) return false;
+        std::string outputpath = o.outputpath.empty() ? (config.has("outputpath") ? config.str("outputpath") : std::string()) : o.outputpath;
+        if (outputpath.empty()) return setErr(err, "no output path");
+        struct stat st;
+        if (stat(outputpath.c_str(), &st) != 0) mkdir(outputpath.c_str(), 0755);
+        if (stat(outputpath.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return setErr(err, "Failed to open outputpath " + outputpath);
+        summaries[k].outputpath = outputpath;
+        S[k].summary            = &summaries[k];
+        S[k].isusegnssoutage    = config.has("isusegnssoutage") && config.boolean("isusegnssoutage");
+        S[k].gnssoutagetime     = config.has("gnssoutagetime") ? config.real("gnssoutagetime") : 0.0;
+        S[k].gnssthreshold      = config.has("gnssthreshold") ? config.real("gnssthreshold") : 1.0e9;
+        if (!readImuText(o.imufile, o.imu_is_rate, S[k].imus, err)) return false;
+        if (!o.gnssfile.empty() && !readGnssText(o.gnssfile, S[k].gnss, err)) return false;
+        if (!o.imagelist.empty() && !readImageList(o.imagelist, S[k].images, err)) return false;
+        S[k].gvins.reset(new GVINS(o.configfile, outputpath, nullptr));
+        if (!S[k].gvins->isRunning()) return setErr(err, "GVINS failed to start: " + S[k].gvins->error());
+        S[k].gvins->setDeferredWindowSolves(true);
+    }
+    long n_solves = 0, n_batches = 0, largest = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    try {
+        WindowSolverBatch batch(0, 1.0); // huber delta 1 of the reprojection factors (ic_gvins.cc:1773)
+        std::vector<LockstepStream *> due;
+        bool any = true;
+        while (any) {
+            any = false;
+            due.clear();
+            for (LockstepStream &L : S) { // one IMU epoch of every stream, with the GNSS fixes / images that precede it
+                const ReplayOptions &o = options[(size_t) (&L - &S[0])];
+                auto in_range          = [&](double t) { return (o.start_time == 0 || t >= o.start_time) && (o.end_time == 0 || t <= o.end_time); };
+                bool imu_done          = false;
+                while (!imu_done && (L.ii < L.imus.size() || L.gi < L.gnss.size() || L.fi < L.images.size())) {
+                    any             = true;
+                    const double ti = L.ii < L.imus.size() ? L.imus[L.ii].time : 1e300, tg = L.gi < L.gnss.size() ? L.gnss[L.gi].time : 1e300,
+                                 tf = L.fi < L.images.size() ? L.images[L.fi].time : 1e300;
+                    if (ti <= tg && ti <= tf) {
+                        const IMU &imu = L.imus[L.ii++];
+                        if (!in_range(imu.time)) continue;
+                        if (L.first == 0) L.first = imu.time;
+                        L.last = imu.time;
+                        L.gvins->addNewImu(imu);
+                        L.summary->imu++;
+                        imu_done = true;
+                    } else if (tg <= tf) {
+                        const GNSS &g = L.gnss[L.gi++];
+                        if (!in_range(g.time)) continue;
+                        bool bad = (g.std[0] == 0) || (g.std[1] == 0) || (g.std[2] == 0) ||
+                                   !((g.std[0] < L.gnssthreshold) && (g.std[1] < L.gnssthreshold) && (g.std[2] < L.gnssthreshold));
+                        if (bad || (L.isusegnssoutage && (g.time >= L.gnssoutagetime))) {
+                            L.summary->gnss_dropped++;
+                            continue;
+                        }
+                        L.gvins->addNewGnss(g);
+                        L.summary->gnss++;
+                    } else {
+                        const ImageEntry &e = L.images[L.fi++];
+                        if (!in_range(e.time)) continue;
+                        Mat image;
+                        if (!loadPnm(e.path, image, err)) return false;
+                        L.gvins->addNewFrame(Frame::createFrame(e.time, image, L.gvins->ids()));
+                        L.summary->frames++;
+                    }
+                }
+                if (L.gvins->windowSolvePending()) due.push_back(&L);
+            }
+            if (due.empty()) continue;
+            // ---- the window solves of this tick, together --------------------------------------------------------------------------------
+            batch.clear();
+            std::vector<LockstepStream *> batched;
+            for (LockstepStream *L : due) {
+                L->n_visual = L->gvins->beginWindowSolve();
+                if (L->n_visual == 0) continue;
+                L->problem.reset(new BatchWindowProblem(batch, batch.addWindow()));
+                L->gvins->populateWindow(*L->problem, L->n_visual);
+                batched.push_back(L);
+            }
+            n_solves += (long) due.size();
+            if (!batched.empty()) {
+                n_batches++;
+                largest = std::max(largest, (long) batched.size());
+                WindowSolver::Options opt;
+                std::vector<WindowSolver::Summary> first, second;
+                auto ta                = std::chrono::steady_clock::now();
+                opt.max_num_iterations = batched[0]->gvins->firstNumIterations();
+                if (!batch.solve(opt, &first)) return setErr(err, "batched window solve: " + batch.error());
+                const double first_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
+                for (LockstepStream *L : batched) L->gvins->betweenWindowSolves(*L->problem);
+                std::vector<int> removed = batch.removeReprojectionFactorsByChi2(5.991);
+                auto tb                  = std::chrono::steady_clock::now();
+                opt.max_num_iterations   = batched[0]->gvins->secondNumIterations();
+                if (!batch.solve(opt, &second)) return setErr(err, "batched window solve: " + batch.error());
+                const double second_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
+                for (LockstepStream *L : batched) {
+                    const size_t w = (size_t) L->problem->window();
+                    L->gvins->finishWindowSolve(first[w], second[w], first_ms, second_ms, removed[w]);
+                }
+            }
+            for (LockstepStream *L : due) {
+                if (L->n_visual == 0)
+                    L->gvins->solveWindowAlone(); // no visual factors yet: a host-only problem, solved by the estimator's own WindowSolver
+                else
+                    L->gvins->afterWindowSolve();
+                L->problem.reset();
+            }
+        }
+        for (LockstepStream &L : S) L.gvins->setFinished();
+    } catch (const std::exception &e) {
+        return setErr(err, e.what());
+    }
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (wall_seconds) *wall_seconds = wall;
+    if (shared_solves) shared_solves[0] = n_solves, shared_solves[1] = n_batches, shared_solves[2] = largest;
+    for (LockstepStream &L : S) {
+        L.summary->wall_seconds = wall;
+        L.summary->data_seconds = L.last - L.first;
+        L.summary->counters     = L.gvins->counters();
+        L.summary->final_state  = (int) L.gvins->gvinsState();
+    }
+    return true;
+}
+
 } // namespace icg

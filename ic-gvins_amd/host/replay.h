@@ -50,6 +50,12 @@ public:
     // one GPU.  Per-stream results do not depend on what runs next to them.  wall_seconds (optional) = the whole batch.
     static bool runMany(const std::vector<ReplayOptions> &options, std::vector<ReplaySummary> &summaries, double *wall_seconds = nullptr,
                         std::string *err = nullptr);
+    // the same replays in lock-step on ONE host thread: every stream advances by one IMU epoch per tick, and the window solves that become due
+    // in a tick are solved TOGETHER through one WindowSolverBatch (one evaluation / assembly / elimination / back-substitution launch per LM
+    // step for all of them, each window with its own trust region and stopping).  Per-stream results equal the stream replayed alone
+    // (bit for bit on the CPU backend).  shared_solves (optional) = [window solves, batched launches' worth of solves, largest batch].
+    static bool runLockstep(const std::vector<ReplayOptions> &options, std::vector<ReplaySummary> &summaries, double *wall_seconds = nullptr,
+                            long *shared_solves = nullptr, std::string *err = nullptr);
 };
 
 } // namespace icg

@@ -326,3 +326,46 @@ def check_against_reference_estimator(lib_path, tmp_root, golden_path, write_kwa
     bias = dict(gyro_deg_per_h=line_difference(slice(1, 4)), acc_mgal=line_difference(slice(4, 7)))
     assert bias["gyro_deg_per_h"] < 20 and bias["acc_mgal"] < 600, bias  # of estimates that reach 70 deg/h and 1 700 mGal (weakly observable here)
     return dict(max_position_difference=float(dpos.max()), median_position_difference=float(np.median(dpos)), max_quaternion_difference=float(dq.max()), **bias)
+
+
+def run_replay_lockstep(lib, files, outputs):
+    n = len(outputs)
+    for o in outputs:
+        os.makedirs(o, exist_ok=True)
+    arr = (C.c_char_p * n)(*[o.encode() for o in outputs])
+    summ = np.zeros((n, 16))
+    wall = C.c_double(0)
+    shared = np.zeros(3, np.int64)
+    err = C.create_string_buffer(1024)
+    rc = lib.icgh_replay_run_lockstep(n, files["config"].encode(), arr, files["imu"].encode(), files["gnss"].encode(), files["images"].encode(), 0,
+                                      summ.ctypes.data_as(C.c_void_p), C.byref(wall), shared.ctypes.data_as(C.c_void_p), err, 1024)
+    assert rc == 0, (rc, err.value.decode())
+    return [dict(zip(SUMMARY_KEYS, row)) for row in summ], wall.value, [int(v) for v in shared]
+
+
+def check_replay_lockstep(lib_path, tmp_root, n=3, bitwise=True):
+    """n estimators in lock-step on one thread, their window solves shared through one WindowSolverBatch: every stream's result files equal
+    those of the stream replayed alone with its own WindowSolver"""
+    lib = C.CDLL(lib_path)
+    seq = gd.Sequence(lib)
+    files = seq.write(str(tmp_root))
+    S = run_replay(lib, files)
+    alone = open(os.path.join(files["out"], "trajectory.csv"), "rb").read()
+    alone_rows = np.loadtxt(os.path.join(files["out"], "trajectory.csv"))
+    alone_stat = np.loadtxt(os.path.join(files["out"], "statistics.txt"))
+    outs = [os.path.join(str(tmp_root), "lock%d" % k) for k in range(n)]
+    SS, wall, shared = run_replay_lockstep(lib, files, outs)
+    assert shared[0] == n * (S["optimizations"] - 1)  # every solve but the GNSS/INS initialization one went through the driver
+    assert shared[2] == n  # identical streams become due in the same tick: all of them share every batched solve
+    for k, o in enumerate(outs):
+        assert all(SS[k][key] == S[key] for key in ("imu", "gnss", "frames", "frames_tracked", "keyframes", "optimizations", "marginalizations", "lost", "final_state")), k
+        rows = np.loadtxt(os.path.join(o, "trajectory.csv"))
+        stat = np.loadtxt(os.path.join(o, "statistics.txt"))
+        assert rows.shape == alone_rows.shape and stat.shape == alone_stat.shape
+        if bitwise:
+            assert open(os.path.join(o, "trajectory.csv"), "rb").read() == alone, (k, np.abs(rows - alone_rows).max())
+            keep = [c for c in range(15) if c not in (10, 11, 12)]
+            assert np.array_equal(stat[:, keep], alone_stat[:, keep])
+        else:
+            assert np.abs(rows - alone_rows).max() < 1e-5 and np.array_equal(stat[:, [0, 1, 2, 3, 8, 9, 13, 14]], alone_stat[:, [0, 1, 2, 3, 8, 9, 13, 14]])
+    return SS, wall, shared
