@@ -174,10 +174,10 @@ int icgh_replay_run_many(int n, const char *configfile, const char *const *outpu
 }
 
 extern "C" {
-// as icgh_replay_run_many, but in lock-step on one thread with the window solves of a tick shared through one WindowSolverBatch.
+// as icgh_replay_run_many, but in `groups` lock-step groups (one thread each) with the window solves of a tick shared through the group's WindowSolverBatch.
 // shared3: window solves, batched solve rounds, largest batch.
 int icgh_replay_run_lockstep(int n, const char *configfile, const char *const *outputs, const char *imufile, const char *gnssfile, const char *imagelist,
-                             int imu_is_rate, double *summaries, double *batch_wall_seconds, int64_t *shared3, char *err, int errlen) {
+                             int imu_is_rate, int groups, double *summaries, double *batch_wall_seconds, int64_t *shared3, char *err, int errlen) {
     try {
         std::vector<ReplayOptions> opts((size_t) n);
         for (int k = 0; k < n; k++) {
@@ -193,7 +193,7 @@ int icgh_replay_run_lockstep(int n, const char *configfile, const char *const *o
         std::string e;
         double wall = 0;
         long shared[3] = {0, 0, 0};
-        if (!Replay::runLockstep(opts, S, &wall, shared, &e)) {
+        if (!Replay::runLockstepGroups(opts, groups, S, &wall, shared, &e)) {
             set_err(err, errlen, e.c_str());
             return -2;
         }

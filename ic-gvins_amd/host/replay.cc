@@ -8,6 +8,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <array>
 #include <thread>
 
 #include "yaml_lite.h"
@@ -244,7 +245,7 @@ struct LockstepStream {
 } // namespace
 
 bool Replay::runLockstep(const std::vector<ReplayOptions> &options, std::vector<ReplaySummary> &summaries, double *wall_seconds, long *shared_solves,
-                         std::string *err) {
+                         std::string *err, int solver_host_threads) {
     const size_t n = options.size();
     summaries.assign(n, ReplaySummary());
     std::vector<LockstepStream> S(n);
@@ -272,7 +273,7 @@ bool Replay::runLockstep(const std::vector<ReplayOptions> &options, std::vector<
     long n_solves = 0, n_batches = 0, largest = 0;
     auto t0 = std::chrono::steady_clock::now();
     try {
-        WindowSolverBatch batch(0, 1.0); // huber delta 1 of the reprojection factors (ic_gvins.cc:1773)
+        WindowSolverBatch batch(0, 1.0, solver_host_threads); // huber delta 1 of the reprojection factors (ic_gvins.cc:1773)
         std::vector<LockstepStream *> due;
         bool any = true;
         while (any) {
@@ -369,6 +370,38 @@ bool Replay::runLockstep(const std::vector<ReplayOptions> &options, std::vector<
         L.summary->counters     = L.gvins->counters();
         L.summary->final_state  = (int) L.gvins->gvinsState();
     }
+    return true;
+}
+
+bool Replay::runLockstepGroups(const std::vector<ReplayOptions> &options, int groups, std::vector<ReplaySummary> &summaries, double *wall_seconds,
+                               long *shared_solves, std::string *err) {
+    const size_t n = options.size();
+    const size_t G = (size_t) std::max(1, std::min(groups, (int) n));
+    if (G == 1) return runLockstep(options, summaries, wall_seconds, shared_solves, err);
+    summaries.assign(n, ReplaySummary());
+    std::vector<std::vector<ReplayOptions>> part(G);
+    std::vector<std::vector<ReplaySummary>> out(G);
+    std::vector<std::string> errors(G);
+    std::vector<char> ok(G, 0);
+    std::vector<std::array<long, 3>> shared(G);
+    std::vector<size_t> begin(G + 1, 0);
+    for (size_t g = 0; g < G; g++) begin[g + 1] = begin[g] + n / G + (g < n % G ? 1 : 0);
+    for (size_t g = 0; g < G; g++) part[g].assign(options.begin() + (long) begin[g], options.begin() + (long) begin[g + 1]);
+    auto t0 = std::chrono::steady_clock::now();
+    const int solver_threads = std::max(1, 16 / (int) G);
+    std::vector<std::thread> threads;
+    for (size_t g = 0; g < G; g++)
+        threads.emplace_back([&, g]() { ok[g] = runLockstep(part[g], out[g], nullptr, shared[g].data(), &errors[g], solver_threads) ? 1 : 0; });
+    for (auto &t : threads) t.join();
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (wall_seconds) *wall_seconds = wall;
+    long total[3] = {0, 0, 0};
+    for (size_t g = 0; g < G; g++) {
+        if (!ok[g]) return setErr(err, "lock-step group " + std::to_string(g) + ": " + errors[g]);
+        for (size_t k = 0; k < out[g].size(); k++) summaries[begin[g] + k] = out[g][k];
+        total[0] += shared[g][0], total[1] += shared[g][1], total[2] = std::max(total[2], shared[g][2]);
+    }
+    if (shared_solves) shared_solves[0] = total[0], shared_solves[1] = total[1], shared_solves[2] = total[2];
     return true;
 }
 

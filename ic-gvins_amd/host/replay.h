@@ -55,7 +55,11 @@ public:
     // step for all of them, each window with its own trust region and stopping).  Per-stream results equal the stream replayed alone
     // (bit for bit on the CPU backend).  shared_solves (optional) = [window solves, batched launches' worth of solves, largest batch].
     static bool runLockstep(const std::vector<ReplayOptions> &options, std::vector<ReplaySummary> &summaries, double *wall_seconds = nullptr,
-                            long *shared_solves = nullptr, std::string *err = nullptr);
+                            long *shared_solves = nullptr, std::string *err = nullptr, int solver_host_threads = 0);
+    // `groups` lock-step groups side by side (one host thread + one WindowSolverBatch each, the streams dealt out in contiguous blocks):
+    // the host work per stream that is not shared (tracking stages, INS, culling, marginalization) spreads over the groups' threads
+    static bool runLockstepGroups(const std::vector<ReplayOptions> &options, int groups, std::vector<ReplaySummary> &summaries, double *wall_seconds = nullptr,
+                                  long *shared_solves = nullptr, std::string *err = nullptr);
 };
 
 } // namespace icg

@@ -328,7 +328,7 @@ def check_against_reference_estimator(lib_path, tmp_root, golden_path, write_kwa
     return dict(max_position_difference=float(dpos.max()), median_position_difference=float(np.median(dpos)), max_quaternion_difference=float(dq.max()), **bias)
 
 
-def run_replay_lockstep(lib, files, outputs):
+def run_replay_lockstep(lib, files, outputs, groups=1):
     n = len(outputs)
     for o in outputs:
         os.makedirs(o, exist_ok=True)
@@ -338,12 +338,12 @@ def run_replay_lockstep(lib, files, outputs):
     shared = np.zeros(3, np.int64)
     err = C.create_string_buffer(1024)
     rc = lib.icgh_replay_run_lockstep(n, files["config"].encode(), arr, files["imu"].encode(), files["gnss"].encode(), files["images"].encode(), 0,
-                                      summ.ctypes.data_as(C.c_void_p), C.byref(wall), shared.ctypes.data_as(C.c_void_p), err, 1024)
+                                      int(groups), summ.ctypes.data_as(C.c_void_p), C.byref(wall), shared.ctypes.data_as(C.c_void_p), err, 1024)
     assert rc == 0, (rc, err.value.decode())
     return [dict(zip(SUMMARY_KEYS, row)) for row in summ], wall.value, [int(v) for v in shared]
 
 
-def check_replay_lockstep(lib_path, tmp_root, n=3, bitwise=True):
+def check_replay_lockstep(lib_path, tmp_root, n=3, bitwise=True, groups=1):
     """n estimators in lock-step on one thread, their window solves shared through one WindowSolverBatch: every stream's result files equal
     those of the stream replayed alone with its own WindowSolver"""
     lib = C.CDLL(lib_path)
@@ -354,9 +354,9 @@ def check_replay_lockstep(lib_path, tmp_root, n=3, bitwise=True):
     alone_rows = np.loadtxt(os.path.join(files["out"], "trajectory.csv"))
     alone_stat = np.loadtxt(os.path.join(files["out"], "statistics.txt"))
     outs = [os.path.join(str(tmp_root), "lock%d" % k) for k in range(n)]
-    SS, wall, shared = run_replay_lockstep(lib, files, outs)
+    SS, wall, shared = run_replay_lockstep(lib, files, outs, groups)
     assert shared[0] == n * (S["optimizations"] - 1)  # every solve but the GNSS/INS initialization one went through the driver
-    assert shared[2] == n  # identical streams become due in the same tick: all of them share every batched solve
+    assert shared[2] == -(-n // groups)  # identical streams become due in the same tick: all streams of a group share every batched solve
     for k, o in enumerate(outs):
         assert all(SS[k][key] == S[key] for key in ("imu", "gnss", "frames", "frames_tracked", "keyframes", "optimizations", "marginalizations", "lost", "final_state")), k
         rows = np.loadtxt(os.path.join(o, "trajectory.csv"))
