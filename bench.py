@@ -543,16 +543,16 @@ def main():
                                     "frames_per_s": round(sum(x["frames_tracked"] for x in SS) / wall_many, 1),
                                     "window_solves_per_s": round(sum(x["optimizations"] for x in SS) / wall_many, 1),
                                     "note": "independent estimators (own device contexts) on one host thread each; per-stream results equal the single-stream run"}
-            # the same streams in lock-step groups of 4 (one host thread per group), the window solves of each tick shared through the group's WindowSolverBatch
+            # the same streams in lock-step groups of 2 (one host thread per group), the window solves of each tick shared through the group's WindowSolverBatch
             outs = [os.path.join(root, "lock%d" % k) for k in range(n_est)]
-            n_groups = max(1, n_est // 4)
+            n_groups = max(1, n_est // 2)
             SL, wall_lock, shared = gvc.run_replay_lockstep(hostlib, files, outs, groups=n_groups)
             replay["lockstep"] = {"estimators": n_est, "groups": n_groups, "value": round(sum(x["data_seconds"] for x in SL) / wall_lock, 2),
                                   "unit": "x real time, summed over the streams; one host thread per lock-step group", "wall_s": round(wall_lock, 3),
                                   "frames_per_s": round(sum(x["frames_tracked"] for x in SL) / wall_lock, 1),
                                   "window_solves_per_s": round(sum(x["optimizations"] for x in SL) / wall_lock, 1),
                                   "window_solves": shared[0], "batched_solve_rounds": shared[1], "largest_batch": shared[2],
-                                  "note": "tracking / INS / culling / marginalization still one launch set per stream and tick; only the LM solves are shared"}
+                                  "note": "only the LM solves are shared; tracking / INS / culling / marginalization stay per stream on the group's one thread, which is why free-running estimators (concurrent) are faster at this size"}
             if not args.no_cpu_baseline:
                 from stream_utils import ensure_oracle_host
                 cpulib = C.CDLL(ensure_oracle_host())
