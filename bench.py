@@ -552,7 +552,7 @@ def main():
                                   "frames_per_s": round(sum(x["frames_tracked"] for x in SL) / wall_lock, 1),
                                   "window_solves_per_s": round(sum(x["optimizations"] for x in SL) / wall_lock, 1),
                                   "window_solves": shared[0], "batched_solve_rounds": shared[1], "largest_batch": shared[2],
-                                  "note": "only the LM solves are shared; tracking / INS / culling / marginalization stay per stream on the group's one thread, which is why free-running estimators (concurrent) are faster at this size"}
+                                  "note": "only the LM solves are shared inside a group; tracking / INS / culling / marginalization stay per stream on the group's one host thread"}
             if not args.no_cpu_baseline:
                 from stream_utils import ensure_oracle_host
                 cpulib = C.CDLL(ensure_oracle_host())
