@@ -16,6 +16,9 @@ SCENARIOS = {
     "default": (GOLDEN, {}, None),
     "earth_td": (os.path.join(ROOT, "tests", "golden", "gvins_ref_earth_td_golden.npz"), dict(estimate_td=True, with_earth=True), None),
     "loss": (os.path.join(ROOT, "tests", "golden", "gvins_ref_loss_golden.npz"), {}, (40, 50)),
+    # a six-keyframe window (more marginalizations per second), extrinsic + time-delay estimation with the Earth-rotation variants on
+    "small_window_calibration": (os.path.join(ROOT, "tests", "golden", "gvins_ref_small_window_golden.npz"),
+                                 dict(optimize_windows_size=6, estimate_extrinsic=True, estimate_td=True, with_earth=True, track_max_features=150), None),
 }
 
 

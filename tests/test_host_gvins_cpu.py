@@ -44,15 +44,16 @@ def test_replay_input_formats(host_lib, tmp_path):
     gc.check_replay_input_formats(host_lib, tmp_path)
 
 
-@pytest.mark.parametrize("scenario", ["default", "earth_td", "loss"])
+@pytest.mark.parametrize("scenario", ["default", "earth_td", "loss", "small_window_calibration"])
 def test_estimator_against_reference_estimator_golden(host_lib, tmp_path, scenario):
     """the reference's own ic_gvins.cc (oracle/_ref/libref_gvins.so, goldens made by tests/golden/make_gvins_golden.py) on the same files:
     the plain sequence; Earth rotation (INS + PreintegrationEarth with the reference's effective zero station, hazard H9) with time-delay
     estimation; half a second of black images (TRACK_LOST, empty keyframes, re-initialization)"""
     import ref_gvins_utils as ru
     golden, kwargs, blank = ru.SCENARIOS[scenario]
-    r = gc.check_against_reference_estimator(host_lib, tmp_path, golden, kwargs, blank, pos_tol=0.10 if blank else 0.05)  # the reference's own runs of the loss scenario differ by 4-9 cm
-    assert r["median_position_difference"] < 0.01
+    r = gc.check_against_reference_estimator(host_lib, tmp_path, golden, kwargs, blank, n_keyframe_features_exact=7 if scenario == "small_window_calibration" else 10,
+                                             pos_tol=0.05 if scenario in ("default", "earth_td") else 0.15)  # the reference's own runs of the other scenarios differ by 4-10 cm
+    assert r["median_position_difference"] < 0.01, r
 
 
 def test_replay_input_errors(host_lib, tmp_path):
