@@ -31,7 +31,7 @@ def test_replay_concurrent_estimators_on_gpu(tmp_path):
 
 def test_replay_lockstep_shared_window_solves_on_gpu(tmp_path):
     """four estimators in lock-step, every window solve of a tick through ONE batched launch sequence (k_reproj_eval, k_reproj_normal_schur_w,
-    k_schur_*_w): each stream equals the stream replayed alone to the rounding of the FP64-atomic assembly, with identical step counts"""
+    k_schur_*_w): each stream equals the stream replayed alone to the rounding of the FP64-atomic assembly"""
     gc.check_replay_lockstep(H.HOST_LIB, tmp_path, n=4, bitwise=False, groups=2)
 
 
