@@ -214,3 +214,42 @@ int icgh_replay_run_lockstep(int n, const char *configfile, const char *const *o
     }
 }
 }
+
+extern "C" {
+// lock-step groups over streams with their OWN input files (configs / imus / gnss / images: n entries each; a NULL gnss / images entry = none)
+int icgh_replay_run_lockstep_files(int n, const char *const *configs, const char *const *outputs, const char *const *imus, const char *const *gnss,
+                                   const char *const *images, int groups, double *summaries, double *batch_wall_seconds, int64_t *shared3, char *err,
+                                   int errlen) {
+    try {
+        std::vector<ReplayOptions> opts((size_t) n);
+        for (int k = 0; k < n; k++) {
+            ReplayOptions &o = opts[(size_t) k];
+            o.configfile = configs[k], o.outputpath = outputs[k], o.imufile = imus[k];
+            o.gnssfile   = gnss && gnss[k] ? gnss[k] : "";
+            o.imagelist  = images && images[k] ? images[k] : "";
+        }
+        std::vector<ReplaySummary> S;
+        std::string e;
+        double wall    = 0;
+        long shared[3] = {0, 0, 0};
+        if (!Replay::runLockstepGroups(opts, groups, S, &wall, shared, &e)) {
+            set_err(err, errlen, e.c_str());
+            return -2;
+        }
+        for (int k = 0; k < n; k++) {
+            const ReplaySummary &s = S[(size_t) k];
+            const double v[16] = {(double) s.imu, (double) s.gnss, (double) s.gnss_dropped, (double) s.frames, (double) s.counters.frames_tracked,
+                                  (double) s.counters.keyframes, (double) s.counters.optimizations, (double) s.counters.marginalizations,
+                                  (double) s.counters.ins_launches, (double) s.counters.lost, (double) s.counters.reprojection_factors,
+                                  (double) s.counters.chi2_removed, (double) s.final_state, s.wall_seconds, s.data_seconds, 0.0};
+            memcpy(summaries + 16 * (size_t) k, v, sizeof v);
+        }
+        if (batch_wall_seconds) *batch_wall_seconds = wall;
+        if (shared3) shared3[0] = shared[0], shared3[1] = shared[1], shared3[2] = shared[2];
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+}

@@ -387,3 +387,44 @@ def check_replay_lockstep(lib_path, tmp_root, n=3, bitwise=True, groups=1):
             # (the step counts of columns 8 / 9 are compared on the CPU backend only: rounding can move a function-tolerance stop by one step)
             assert np.abs(rows - alone_rows).max() < 1e-3 and np.array_equal(stat[:, [0, 1, 2, 3, 13, 14]], alone_stat[:, [0, 1, 2, 3, 13, 14]])
     return SS, wall, shared
+
+
+def check_replay_lockstep_different_streams(lib_path, tmp_root):
+    """three DIFFERENT streams in one lock-step group — the plain sequence, the same drive with half a second of black images (loses track,
+    re-initializes: its keyframes fall on other frames), and a drive with other sensor noise and a later first image — so the window solves of a
+    tick form batches of one, two or three windows of different sizes: every stream still equals its own replay alone, bit for bit"""
+    lib = C.CDLL(lib_path)
+    root = str(tmp_root)
+    sets = []
+    seq = gd.Sequence(lib)
+    sets.append(seq.write(os.path.join(root, "a")))
+    b = seq.write(os.path.join(root, "b"))
+    for name in [line.split()[1] for line in open(b["images"])][40:50]:
+        with open(os.path.join(root, "b", "cam0", name), "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (seq.w, seq.h) + bytes(seq.w * seq.h))
+    sets.append(b)
+    sets.append(gd.Sequence(lib, seed=5, image_start=3.6, duration=7.0).write(os.path.join(root, "c"), track_max_features=120))
+    alone = []
+    for files in sets:
+        S = run_replay(lib, files)
+        alone.append((S, open(os.path.join(files["out"], "trajectory.csv"), "rb").read(), np.loadtxt(os.path.join(files["out"], "statistics.txt"))))
+    n = len(sets)
+    outs = [os.path.join(root, "lock%d" % k) for k in range(n)]
+    for o in outs:
+        os.makedirs(o, exist_ok=True)
+    arr = lambda key: (C.c_char_p * n)(*[f[key].encode() for f in sets])
+    summ, wall, shared, err = np.zeros((n, 16)), C.c_double(0), np.zeros(3, np.int64), C.create_string_buffer(1024)
+    rc = lib.icgh_replay_run_lockstep_files(n, arr("config"), (C.c_char_p * n)(*[o.encode() for o in outs]), arr("imu"), arr("gnss"), arr("images"), 1,
+                                            summ.ctypes.data_as(C.c_void_p), C.byref(wall), shared.ctypes.data_as(C.c_void_p), err, 1024)
+    assert rc == 0, err.value
+    solves = sum(int(a[0]["optimizations"]) - 1 for a in alone)
+    assert shared[0] == solves and shared[1] < solves and 2 <= shared[2] <= n, shared  # some ticks batch several windows, not all of them all
+    keep = [c for c in range(15) if c not in (10, 11, 12)]
+    for k in range(n):
+        S, traj, stat = alone[k]
+        got = dict(zip(SUMMARY_KEYS, summ[k]))
+        assert all(got[key] == S[key] for key in ("imu", "gnss", "frames", "frames_tracked", "keyframes", "optimizations", "marginalizations", "lost", "final_state")), k
+        assert open(os.path.join(outs[k], "trajectory.csv"), "rb").read() == traj, k
+        assert np.array_equal(np.loadtxt(os.path.join(outs[k], "statistics.txt"))[:, keep], stat[:, keep]), k
+    assert alone[1][0]["lost"] == 1 and alone[0][0]["lost"] == 0
+    return [int(v) for v in shared]
