@@ -32,10 +32,6 @@ def test_replay_concurrent_estimators_are_independent(host_lib, tmp_path):
     gc.check_replay_concurrent(host_lib, tmp_path, n=3)
 
 
-def test_replay_lockstep_shared_window_solves(host_lib, tmp_path):
-    gc.check_replay_lockstep(host_lib, tmp_path, n=2)
-
-
 def test_replay_lockstep_with_different_streams(host_lib, tmp_path):
     gc.check_replay_lockstep_different_streams(host_lib, tmp_path)
 
