@@ -50,6 +50,18 @@ bool debugOn() {
     static bool on = getenv("ICG_GVINS_DEBUG") != nullptr;
     return on;
 }
+struct PhaseAccumulator { // ICG_GVINS_DEBUG=1: host wall time per phase of the estimator, printed by setFinished()
+    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+struct PhaseTimer {
+    PhaseAccumulator &acc;
+    int k;
+    std::chrono::steady_clock::time_point t0;
+    PhaseTimer(PhaseAccumulator &a, int k_) : acc(a), k(k_), t0(std::chrono::steady_clock::now()) {}
+    ~PhaseTimer() { acc.ms[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+enum { PH_TRACK = 0, PH_INS, PH_BUILD, PH_SOLVE, PH_FINISH, PH_MARG, PH_STAT, PH_NODES };
+PhaseAccumulator g_phase; // process-wide: meaningful for one estimator at a time (diagnostics)
 #define GLOG(...)                                                                                                                               \
     do {                                                                                                                                        \
         if (debugOn()) {                                                                                                                        \
@@ -229,6 +241,11 @@ void GVINS::setFinished() { // ic_gvins.cc:554-582
     } catch (const std::exception &) {
     }
     isfinished_ = true;
+    if (debugOn()) {
+        static const char *names[8] = {"tracking", "INS launches", "problem build", "window solves", "write-back + culling", "marginalization", "statistics", "time nodes"};
+        for (int k = 0; k < 8; k++) fprintf(stderr, "[gvins-phase] %-22s %9.3f ms\n", names[k], g_phase.ms[k]);
+        g_phase = PhaseAccumulator();
+    }
     for (auto &f : {navfilesaver_, imuerrfilesaver_, ptsfilesaver_, statfilesaver_, extfilesaver_, trajfilesaver_})
         if (f) f->flush();
 }
@@ -290,6 +307,7 @@ bool GVINS::addNewFrame(const Frame::Ptr &frame) { // ic_gvins.cc:222-235
 // after each epoch (runFusion :284-286, :387-389)
 void GVINS::flushIns() {
     if (ins_pending_ == 0) return;
+    PhaseTimer pt(g_phase, PH_INS);
     const size_t n = ins_window_.size(), first = n - ins_pending_;
     if (first == 0) fail("INS window has no mechanized state to start from");
     std::vector<IMU> series;
@@ -404,7 +422,11 @@ void GVINS::processTracking() { // body of runTracking (ic_gvins.cc:493-550)
         std::string err;
         if (!MISC::getCameraPoseFromInsWindowBatch(ctx_, {&ins_window_}, pose_b_c_, {frame->stamp()}, poses, found, &err)) fail("pose prior: " + err);
         frame->setPose(poses[0]);
-        TrackState trackstate = tracking_->track(frame);
+        TrackState trackstate;
+        {
+            PhaseTimer pt(g_phase, PH_TRACK);
+            trackstate = tracking_->track(frame);
+        }
         counters_.frames_tracked++;
         if (trackstate == TRACK_LOST) counters_.lost++;
         GLOG("track %.3f -> state %d, features %zu, new keyframe %d", frame->stamp(), (int) trackstate, frame->numFeatures(), (int) tracking_->isNewKeyFrame());
@@ -649,6 +671,7 @@ void GVINS::addNewGnssTimeNode() { // ic_gvins.cc:890-895
 }
 
 void GVINS::addNewTimeNode(double time) { // ic_gvins.cc:897-928
+    PhaseTimer pt(g_phase, PH_NODES);
     std::vector<IMU> series;
     double start = timelist_.back();
     if (!MISC::getImuSeriesFromTo(ins_window_, start, time, series)) fail("no IMU samples between two time nodes");
@@ -817,6 +840,7 @@ void GVINS::doReintegration() { // ic_gvins.cc:1680-1695: every interval that ne
 // ---- the window solve ------------------------------------------------------------------------------------------------------------
 // ---- the window solve in phases (ic_gvins.cc:1130-1239) --------------------------------------------------------------------------
 int GVINS::beginWindowSolve() { // parameters and factors of the visual part (:1150-1154, 1173)
+    PhaseTimer pt(g_phase, PH_BUILD);
     addReprojectionParameters();
     const int n_visual = addReprojectionFactors();
     counters_.reprojection_factors += n_visual;
@@ -824,6 +848,7 @@ int GVINS::beginWindowSolve() { // parameters and factors of the visual part (:1
 }
 
 void GVINS::populateWindow(WindowProblem &problem, int n_visual) { // :1148-1176
+    PhaseTimer pt(g_phase, PH_BUILD);
     addStateParameters(problem);
     if (n_visual > 0) {
         registerReprojectionBlocks(problem);
@@ -845,6 +870,7 @@ void GVINS::betweenWindowSolves(WindowProblem &problem) { // outlier detection f
 }
 
 void GVINS::finishWindowSolve(const WindowSolver::Summary &first, const WindowSolver::Summary &second, double first_ms, double second_ms, int chi2_removed) {
+    PhaseTimer pt(g_phase, PH_FINISH);
     GLOG("%s", first.BriefReport().c_str());
     GLOG("%s", second.BriefReport().c_str());
     iterations_[0] = first.num_successful_steps, iterations_[1] = second.num_successful_steps;
@@ -871,13 +897,19 @@ bool GVINS::gvinsOptimization() { // the phases on a WindowSolver of this estima
     WindowSolver::Summary first, second;
     timecost.restart();
     options.max_num_iterations = first_num_iterations_;
-    if (!solver.solve(options, &first)) fail("window solve: " + solver.error());
+    {
+        PhaseTimer pt(g_phase, PH_SOLVE);
+        if (!solver.solve(options, &first)) fail("window solve: " + solver.error());
+    }
     const double first_ms = timecost.costInMillisecond();
     betweenWindowSolves(problem);
     const int removed = n_visual > 0 ? solver.removeReprojectionFactorsByChi2(5.991) : 0;
     options.max_num_iterations = second_num_iterations_;
     timecost.restart();
-    if (!solver.solve(options, &second)) fail("window solve: " + solver.error());
+    {
+        PhaseTimer pt(g_phase, PH_SOLVE);
+        if (!solver.solve(options, &second)) fail("window solve: " + solver.error());
+    }
     finishWindowSolve(first, second, first_ms, timecost.costInMillisecond(), removed);
     return true;
 }
@@ -944,6 +976,7 @@ bool GVINS::gvinsOutlierCulling() { // ic_gvins.cc:1035-1128: one device launch 
 }
 
 void GVINS::parametersStatistic() { // ic_gvins.cc:930-1033
+    PhaseTimer pt(g_phase, PH_STAT);
     std::vector<ReprojectionStatistics> stats;
     std::string err;
     if (map_->orderedKeyFrames().size() < 2) return;
@@ -969,6 +1002,7 @@ bool GVINS::gvinsRemoveAllSecondNewFrame() { // ic_gvins.cc:1391-1410
 
 // ---- marginalization -----------------------------------------------------------------------------------------------------------
 bool GVINS::gvinsMarginalization() { // ic_gvins.cc:1412-1678
+    PhaseTimer pt(g_phase, PH_MARG);
     std::vector<ulong> keyframeids = map_->orderedKeyFrames();
     auto latest_keyframe           = map_->latestKeyFrame();
     latest_keyframe->setKeyFrameState(KEYFRAME_NORMAL);
