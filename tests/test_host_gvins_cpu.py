@@ -56,6 +56,30 @@ def test_estimator_against_reference_estimator_golden(host_lib, tmp_path, scenar
     assert r["median_position_difference"] < 0.01, r
 
 
+def test_icg_replay_command_line(host_lib, tmp_path):
+    """the command-line front (tools/icg_replay_main.cc) linked on the oracle-backed host layer: one stream, two streams side by side and two
+    streams as a lock-step group write identical trajectories"""
+    import os
+    import subprocess
+    import gvins_data as gd
+    exe = os.path.join(os.path.dirname(host_lib), "icg_replay_oracle")
+    assert os.path.exists(exe), "make -C oracle builds it"
+    files = gd.Sequence(C.CDLL(host_lib), duration=6.0).write(str(tmp_path))
+    base = [exe, "--config", files["config"], "--imu", files["imu"], "--gnss", files["gnss"], "--images", files["images"]]
+    r = subprocess.run(base + ["--output", str(tmp_path / "one")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "final state 4" in r.stdout, (r.stdout, r.stderr)
+    one = (tmp_path / "one" / "trajectory.csv").read_bytes()
+    r = subprocess.run(base + ["--output", str(tmp_path / "many"), "--streams", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "replayed 2 streams" in r.stdout, (r.stdout, r.stderr)
+    r = subprocess.run(base + ["--output", str(tmp_path / "lock"), "--streams", "2", "--lockstep-groups", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "largest batch 2" in r.stdout, (r.stdout, r.stderr)
+    for d in ("many", "lock"):
+        for k in range(2):
+            assert (tmp_path / d / ("stream%d" % k) / "trajectory.csv").read_bytes() == one, (d, k)
+    r = subprocess.run([exe, "--config", files["config"]], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
 def test_replay_input_errors(host_lib, tmp_path):
     lib = C.CDLL(host_lib)
     err = C.create_string_buffer(512)
