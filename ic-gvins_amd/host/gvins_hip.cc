@@ -50,18 +50,14 @@ bool debugOn() {
     static bool on = getenv("ICG_GVINS_DEBUG") != nullptr;
     return on;
 }
-struct PhaseAccumulator { // ICG_GVINS_DEBUG=1: host wall time per phase of the estimator, printed by setFinished()
-    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-};
-struct PhaseTimer {
-    PhaseAccumulator &acc;
+struct PhaseTimer { // adds the wall time of a scope to one slot of the estimator's phase clock (printed under ICG_GVINS_DEBUG=1)
+    double *acc;
     int k;
     std::chrono::steady_clock::time_point t0;
-    PhaseTimer(PhaseAccumulator &a, int k_) : acc(a), k(k_), t0(std::chrono::steady_clock::now()) {}
-    ~PhaseTimer() { acc.ms[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+    PhaseTimer(double *a, int k_) : acc(a), k(k_), t0(std::chrono::steady_clock::now()) {}
+    ~PhaseTimer() { acc[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 enum { PH_TRACK = 0, PH_INS, PH_BUILD, PH_SOLVE, PH_FINISH, PH_MARG, PH_STAT, PH_NODES };
-PhaseAccumulator g_phase; // process-wide: meaningful for one estimator at a time (diagnostics)
 #define GLOG(...)                                                                                                                               \
     do {                                                                                                                                        \
         if (debugOn()) {                                                                                                                        \
@@ -243,8 +239,7 @@ void GVINS::setFinished() { // ic_gvins.cc:554-582
     isfinished_ = true;
     if (debugOn()) {
         static const char *names[8] = {"tracking", "INS launches", "problem build", "window solves", "write-back + culling", "marginalization", "statistics", "time nodes"};
-        for (int k = 0; k < 8; k++) fprintf(stderr, "[gvins-phase] %-22s %9.3f ms\n", names[k], g_phase.ms[k]);
-        g_phase = PhaseAccumulator();
+        for (int k = 0; k < 8; k++) fprintf(stderr, "[gvins-phase] %-22s %9.3f ms\n", names[k], phase_ms_[k]);
     }
     for (auto &f : {navfilesaver_, imuerrfilesaver_, ptsfilesaver_, statfilesaver_, extfilesaver_, trajfilesaver_})
         if (f) f->flush();
@@ -307,7 +302,7 @@ bool GVINS::addNewFrame(const Frame::Ptr &frame) { // ic_gvins.cc:222-235
 // after each epoch (runFusion :284-286, :387-389)
 void GVINS::flushIns() {
     if (ins_pending_ == 0) return;
-    PhaseTimer pt(g_phase, PH_INS);
+    PhaseTimer pt(phase_ms_, PH_INS);
     const size_t n = ins_window_.size(), first = n - ins_pending_;
     if (first == 0) fail("INS window has no mechanized state to start from");
     std::vector<IMU> series;
@@ -424,7 +419,7 @@ void GVINS::processTracking() { // body of runTracking (ic_gvins.cc:493-550)
         frame->setPose(poses[0]);
         TrackState trackstate;
         {
-            PhaseTimer pt(g_phase, PH_TRACK);
+            PhaseTimer pt(phase_ms_, PH_TRACK);
             trackstate = tracking_->track(frame);
         }
         counters_.frames_tracked++;
@@ -671,7 +666,7 @@ void GVINS::addNewGnssTimeNode() { // ic_gvins.cc:890-895
 }
 
 void GVINS::addNewTimeNode(double time) { // ic_gvins.cc:897-928
-    PhaseTimer pt(g_phase, PH_NODES);
+    PhaseTimer pt(phase_ms_, PH_NODES);
     std::vector<IMU> series;
     double start = timelist_.back();
     if (!MISC::getImuSeriesFromTo(ins_window_, start, time, series)) fail("no IMU samples between two time nodes");
@@ -840,7 +835,7 @@ void GVINS::doReintegration() { // ic_gvins.cc:1680-1695: every interval that ne
 // ---- the window solve ------------------------------------------------------------------------------------------------------------
 // ---- the window solve in phases (ic_gvins.cc:1130-1239) --------------------------------------------------------------------------
 int GVINS::beginWindowSolve() { // parameters and factors of the visual part (:1150-1154, 1173)
-    PhaseTimer pt(g_phase, PH_BUILD);
+    PhaseTimer pt(phase_ms_, PH_BUILD);
     addReprojectionParameters();
     const int n_visual = addReprojectionFactors();
     counters_.reprojection_factors += n_visual;
@@ -848,7 +843,7 @@ int GVINS::beginWindowSolve() { // parameters and factors of the visual part (:1
 }
 
 void GVINS::populateWindow(WindowProblem &problem, int n_visual) { // :1148-1176
-    PhaseTimer pt(g_phase, PH_BUILD);
+    PhaseTimer pt(phase_ms_, PH_BUILD);
     addStateParameters(problem);
     if (n_visual > 0) {
         registerReprojectionBlocks(problem);
@@ -870,7 +865,7 @@ void GVINS::betweenWindowSolves(WindowProblem &problem) { // outlier detection f
 }
 
 void GVINS::finishWindowSolve(const WindowSolver::Summary &first, const WindowSolver::Summary &second, double first_ms, double second_ms, int chi2_removed) {
-    PhaseTimer pt(g_phase, PH_FINISH);
+    PhaseTimer pt(phase_ms_, PH_FINISH);
     GLOG("%s", first.BriefReport().c_str());
     GLOG("%s", second.BriefReport().c_str());
     iterations_[0] = first.num_successful_steps, iterations_[1] = second.num_successful_steps;
@@ -898,7 +893,7 @@ bool GVINS::gvinsOptimization() { // the phases on a WindowSolver of this estima
     timecost.restart();
     options.max_num_iterations = first_num_iterations_;
     {
-        PhaseTimer pt(g_phase, PH_SOLVE);
+        PhaseTimer pt(phase_ms_, PH_SOLVE);
         if (!solver.solve(options, &first)) fail("window solve: " + solver.error());
     }
     const double first_ms = timecost.costInMillisecond();
@@ -907,7 +902,7 @@ bool GVINS::gvinsOptimization() { // the phases on a WindowSolver of this estima
     options.max_num_iterations = second_num_iterations_;
     timecost.restart();
     {
-        PhaseTimer pt(g_phase, PH_SOLVE);
+        PhaseTimer pt(phase_ms_, PH_SOLVE);
         if (!solver.solve(options, &second)) fail("window solve: " + solver.error());
     }
     finishWindowSolve(first, second, first_ms, timecost.costInMillisecond(), removed);
@@ -976,7 +971,7 @@ bool GVINS::gvinsOutlierCulling() { // ic_gvins.cc:1035-1128: one device launch 
 }
 
 void GVINS::parametersStatistic() { // ic_gvins.cc:930-1033
-    PhaseTimer pt(g_phase, PH_STAT);
+    PhaseTimer pt(phase_ms_, PH_STAT);
     std::vector<ReprojectionStatistics> stats;
     std::string err;
     if (map_->orderedKeyFrames().size() < 2) return;
@@ -1002,7 +997,7 @@ bool GVINS::gvinsRemoveAllSecondNewFrame() { // ic_gvins.cc:1391-1410
 
 // ---- marginalization -----------------------------------------------------------------------------------------------------------
 bool GVINS::gvinsMarginalization() { // ic_gvins.cc:1412-1678
-    PhaseTimer pt(g_phase, PH_MARG);
+    PhaseTimer pt(phase_ms_, PH_MARG);
     std::vector<ulong> keyframeids = map_->orderedKeyFrames();
     auto latest_keyframe           = map_->latestKeyFrame();
     latest_keyframe->setKeyFrameState(KEYFRAME_NORMAL);

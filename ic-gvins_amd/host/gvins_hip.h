@@ -274,6 +274,7 @@ private:
     std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> gnss_blocks_; // GNSS residual blocks of the window being solved
     bool deferred_window_solves_{false}, window_solve_pending_{false};
     Counters counters_;
+    double phase_ms_[8]{0, 0, 0, 0, 0, 0, 0, 0}; // host wall time per phase (tracking, INS, build, solves, write-back, marginalization, statistics, nodes)
     std::string error_;
 };
 
