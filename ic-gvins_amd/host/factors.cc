@@ -385,7 +385,7 @@ void MarginalizationInfo::addResidualBlockInfo(const std::shared_ptr<ResidualBlo
 }
 
 namespace {
-double g_marg_phase_ms[4] = {0, 0, 0, 0};
+thread_local double g_marg_phase_ms[4] = {0, 0, 0, 0};
 }
 const double *MarginalizationInfo::lastPhaseMs() { return g_marg_phase_ms; }
 

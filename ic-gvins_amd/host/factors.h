@@ -133,7 +133,7 @@ public:
     // reprojection factors registered in `batch` are evaluated (with their Huber loss) and assembled on the GPU
     void setReprojectionBatch(ReprojectionBatch *batch) { batch_ = batch; }
     bool marginalization();
-    // wall time of the last marginalization() of this process: evaluate, construct, Schur, linearize [ms] (diagnostics / bench)
+    // wall time of the calling thread's last marginalization(): evaluate, construct, Schur, linearize [ms] (diagnostics / bench)
     static const double *lastPhaseMs();
     vector<double *> getParamterBlocks(std::unordered_map<long, double *> &address);
     const vector<double> &linearizedJacobians() const { return linearized_jacobians_; } // remained x remained, row-major
