@@ -95,3 +95,22 @@ def test_window_solver_batch_equals_single_solvers(host_lib):
             assert np.abs(res[k][key] - h[key]).max() < 1e-8, (k, key)
         kinds.add((h["summary"][4] + h["summary"][6] > 0, h["summary"][5] < 3))
     assert (True, False) in kinds or (True, True) in kinds  # at least one window had a rejected step
+
+
+def test_window_solver_matches_reference_factors_with_independent_lm(host_lib):
+    """icg::WindowSolver (landmark elimination + LM of the product, here on the CPU shim) against tests/golden/solve_ref_golden.npz: the same
+    three windows solved with the REFERENCE's own factor code and an independently written LM (oracle/ref_build/shim/ceres/problem_shim.h;
+    generator tests/golden/make_solve_golden.py).  Same costs, the same accepted / rejected step counts in both solves, the same factors
+    removed by the chi-square test, the same optimum."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "solve_ref_golden.npz"))
+    lib = C.CDLL(host_lib)
+    for seed, (nlm, nkf, nout) in enumerate([(60, 6, 4), (300, 10, 10), (120, 8, 0)]):
+        P = su.make_problem(nlm, nkf, seed=seed, n_outliers=nout)
+        H = su.host_solve(lib, P)
+        e = lambda k: g[f"case{seed}_{k}"]
+        assert np.array_equal(H["active"], e("active")) and int((e("active") == 0).sum()) >= nout
+        assert np.array_equal(H["summary"][3:8], e("summary")[3:8])  # step counts of both solves, removed factors
+        assert np.all(np.abs(H["summary"][:3] - e("summary")[:3]) <= 1e-7 * np.abs(e("summary")[:3]))  # initial / intermediate / final cost
+        assert np.abs(H["poses"] - e("poses")).max() < 1e-8 and np.abs(H["ext"] - e("ext")).max() < 1e-6
+        assert np.abs(H["invdepth"] - e("invdepth")).max() < 1e-7 and abs(H["td"] - float(e("td")[0])) < 1e-9
