@@ -107,6 +107,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200,
                     help="timed lock-step frames per stream (default 200: ~1 s timed region; 40 steps gave +-5 %% run-to-run noise)")
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--prime", type=int, default=int(os.environ.get("ICG_BENCH_PRIME", "48")),
+                    help="untimed frames per stream run during SETUP, before the warm-up steps: every stream leaves the start-up phase of "
+                         "the reference's state machine (first frame, initialization, a full 10-keyframe window) and every arena / pool has "
+                         "its steady-state size, whatever --warmup is")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("ICG_BENCH_STREAMS", "0")),
                     help="camera streams per GPU (0 = 8 per stream group)")
     ap.add_argument("--ring", type=int, default=64, help="rendered frames per stream (ping-pong replay)")
@@ -204,11 +208,19 @@ def main():
         return states
 
     k = 0
-    run_prepared(args.warmup, prepare_steps(k, args.warmup))
-    k += args.warmup
+    t_prime = time.time()
+    if args.prime > 0:
+        run_prepared(args.prime, prepare_steps(k, args.prime))
+        k += args.prime
+    t_prime = time.time() - t_prime
+    if args.warmup > 0:
+        run_prepared(args.warmup, prepare_steps(k, args.warmup))
+        k += args.warmup
     prep = prepare_steps(k, args.steps)
     barrier()
     sb.timing(reset=True)
+    sb.step_log(reset=True)
+    t_region0 = sb.now()
     if os.environ.get("ICG_HOST_PROF"):
         _hp = np.zeros(64, np.float64)
         sb.lib.icgh_hostprof(_hp.ctypes.data_as(C.c_void_p), 32, None, 0, 1)
@@ -228,6 +240,20 @@ def main():
             print(f"[hostprof] {_name:16s} {1e6 * _hp[2 * _k] / (B * args.steps):9.2f} us/frame  calls/frame "
                   f"{_hp[2 * _k + 1] / (B * args.steps):.3f}", file=sys.stderr)
     tg = sb.timing_groups().sum(1) * 1e3 / args.steps  # per-group in-step wall time, ms per step
+    # per-step series: step k of the job ends when the slowest group has finished its k-th frame set
+    logs = sb.step_log(reset=True)
+    step_stats = None
+    if logs and all(len(l) == args.steps for l in logs):
+        ends = np.stack([l[:, 0] for l in logs])                      # (groups, steps)
+        job_end = ends.max(0)
+        job_ms = np.diff(np.concatenate([[t_region0], job_end])) * 1e3  # wall time between consecutive job-step completions
+        grp_ms = np.diff(np.concatenate([np.full((len(logs), 1), t_region0), ends], 1), axis=1) * 1e3
+        host_ms = np.stack([l[:, 1] for l in logs]).mean(0) * 1e3
+        step_stats = {"job_step_ms": {"median": round(float(np.median(job_ms)), 4), "p95": round(float(np.percentile(job_ms, 95)), 4),
+                                      "series": [round(float(v), 3) for v in job_ms]},
+                      "group_step_ms": {"median": round(float(np.median(grp_ms)), 4), "p95": round(float(np.percentile(grp_ms, 95)), 4),
+                                        "note": "one group's wall time for one frame of each of its streams; groups run free of each other"},
+                      "host_logic_ms_series": [round(float(v), 3) for v in host_ms]}
     host_breakdown = {k: round(1e3 * v / args.steps, 4) for k, v in sb.timing().items()}
     host_breakdown["cpu_cores_busy"] = round(cpu_cores_used, 2)
     host_breakdown["group_step_ms_min_mean_max"] = [round(float(tg.min()), 3), round(float(tg.mean()), 3), round(float(tg.max()), 3)]
@@ -678,6 +704,8 @@ def main():
             "replay": replay,
             "kernels": kernel_table,
             "host_ms_per_step": host_breakdown,
+            "step_stats": step_stats,
+            "prime": {"frames_per_stream": args.prime, "seconds": round(t_prime, 2)},
             "quality": {"mean_tracked_mappoints_per_frame": round(total_tracked / max(1.0, total_frames), 1),
                         "tracking_state_fraction": round(total_tracking_states / max(1.0, total_frames), 4)},
             "setup_s": round(t_setup, 2),

@@ -184,6 +184,19 @@ class StreamBatch:
             out.append(t.copy())
         return np.stack(out)
 
+    def step_log(self, reset=True, cap=1 << 14):
+        """per group: array (steps, 3) = [steady-clock end time, host-logic s, device-execute s] of every step since the last reset"""
+        out = []
+        for g in range(self.n_groups()):
+            buf = np.zeros((cap, 3), np.float64)
+            n = self.lib.icgh_batch_step_log(C.c_void_p(self.h_), g, buf.ctypes.data_as(C.c_void_p), cap, 1 if reset else 0)
+            out.append(buf[:max(0, n)].copy())
+        return out
+
+    def now(self):
+        self.lib.icgh_now_s.restype = C.c_double
+        return float(self.lib.icgh_now_s())
+
     def features(self, stream, max_n=2048):
         ids = np.zeros(max_n, np.uint64)
         px = np.zeros((max_n, 2), np.float32)

@@ -136,6 +136,24 @@ int icgh_batch_counters(icgh_batch *b, uint64_t *out8, int reset) {
     return 0;
 }
 
+// per-step log of group g since the last reset: out[3k..3k+2] = {steady-clock seconds at the end of the step, host-logic
+// seconds, device-execute seconds}; returns the number of steps written (<= max_steps); reset != 0 clears the log
+int icgh_batch_step_log(icgh_batch *b, int g, double *out, int max_steps, int reset) {
+    if (!b || g < 0 || g >= b->tb->groups()) return -1;
+    auto &log = b->tb->group(g).step_log;
+    int n     = (int) std::min<size_t>(log.size(), (size_t) std::max(0, max_steps));
+    for (int k = 0; k < n && out; k++) {
+        out[3 * k]     = log[(size_t) k].t_end;
+        out[3 * k + 1] = log[(size_t) k].host_logic;
+        out[3 * k + 2] = log[(size_t) k].device_execute;
+    }
+    if (reset) log.clear();
+    return n;
+}
+
+// steady-clock seconds on the clock icgh_batch_step_log reports
+double icgh_now_s(void) { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int icgh_batch_timing_group(icgh_batch *b, int g, double *out5) {
     if (!b || g < 0 || g >= b->tb->groups()) return -1;
     for (int i = 0; i < 5; i++) out5[i] = b->tb->group(g).timing[i];

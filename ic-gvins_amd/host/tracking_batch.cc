@@ -221,6 +221,7 @@ static inline double now_s() {
 void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &states) {
     const int n = (int) streams_.size();
     double t0 = now_s(), t1;
+    const double log_host0 = timing[0], log_dev0 = timing[2];
     states.assign((size_t) n, TRACK_PASSED);
     vector<char> active((size_t) n, 0);
     int cur = 0;
@@ -322,7 +323,9 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
         hostprof::Scope hpk(hostprof::KEEPER);
         s.keeper->onFrame(*s.tracking, frame, st);
     });
-    timing[4] += now_s() - t0;
+    t1 = now_s();
+    timing[4] += t1 - t0;
+    if (step_log.size() < kStepLogCap) step_log.push_back({t1, timing[0] - log_host0, timing[2] - log_dev0});
 }
 
 // ---- StreamGroups -----------------------------------------------------------------------------------------------------

@@ -64,6 +64,13 @@ public:
     // work counters of the batched device calls: [0] LK points, [1] LK calls, [2] detection jobs, [3] detection calls,
     // [4] RANSAC point sets, [5] RANSAC calls, [6] preprocessed frames, [7] triangulated points
     uint64_t counters[8]{0, 0, 0, 0, 0, 0, 0, 0};
+    // per-step log (bounded): {steady-clock time at the end of step(), host-logic seconds, device-execute seconds} of each
+    // call since the last clear — the bench derives per-step median / p95 and the start-up transient from it
+    struct StepLog {
+        double t_end, host_logic, device_execute;
+    };
+    vector<StepLog> step_log;
+    static constexpr size_t kStepLogCap = 1 << 14;
 
 private:
     void gather(int cur, StageBatch &global, vector<std::array<int, 8>> &bases);
