@@ -188,9 +188,24 @@ int icg_arena_reserve(icg_ctx *ctx, size_t bytes) {
 }
 
 size_t icg_arena_alloc(icg_ctx *ctx, size_t bytes) {
-    size_t off     = icg_align_up(ctx->arena_off, 256);
-    ctx->arena_off = off + bytes;
-    return off; // caller guarantees capacity through icg_arena_reserve
+    size_t off = icg_align_up(ctx->arena_off, 256);
+    if (off + bytes > ctx->arena_cap) {
+        // the caller under-counted its reserve(): never hand out memory past the arena.  The allocation is redirected to
+        // offset 0 (in bounds as long as one allocation fits) and the sticky flag fails the call at seal()/finish().
+        ctx->arena_overflow = true;
+        off                 = 0;
+        if (bytes > ctx->arena_cap) abort(); // no in-bounds answer exists
+    } else {
+        ctx->arena_off = off + bytes;
+    }
+    return off;
+}
+
+int icg_arena_overflow_check(icg_ctx *ctx) {
+    if (!ctx->arena_overflow) return 0;
+    ctx->arena_overflow = false;
+    ctx->arena_off      = 0;
+    return icg_fail(ctx, ICG_ERR_NOMEM, "staging arena overflow: the entry point reserved too little");
 }
 
 int icg_arena_h2d(icg_ctx *ctx, size_t begin, size_t end) {

@@ -62,6 +62,7 @@ struct icg_ctx {
     char *h_arena = nullptr;
     char *d_arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
+    bool arena_overflow = false; // an allocation did not fit (sticky until the call's seal()/finish() reports it)
 
     // reprojection back-end resident state
     double *d_obs = nullptr;
@@ -119,6 +120,7 @@ static inline size_t icg_align_up(size_t v, size_t a) { return (v + a - 1) / a *
 size_t icg_arena_alloc(icg_ctx *ctx, size_t bytes);
 template <typename T> static inline T *icg_h(icg_ctx *ctx, size_t off) { return reinterpret_cast<T *>(ctx->h_arena + off); }
 template <typename T> static inline T *icg_d(icg_ctx *ctx, size_t off) { return reinterpret_cast<T *>(ctx->d_arena + off); }
+int icg_arena_overflow_check(icg_ctx *ctx); // ICG_ERR_NOMEM (and the flag cleared) if an allocation since the last check did not fit
 int icg_arena_h2d(icg_ctx *ctx, size_t begin, size_t end);
 int icg_arena_d2h(icg_ctx *ctx, size_t begin, size_t end);
 
@@ -219,7 +221,11 @@ struct icg_call {
         if (user) outs.push_back({(void *) user, (size_t) (reinterpret_cast<char *>(d) - ctx->d_arena), sizeof(T) * n, false});
         return d;
     }
-    int seal() { return mirror_hi > mirror_lo ? icg_arena_h2d(ctx, mirror_lo, mirror_hi) : 0; }
+    int overflowed() { return icg_arena_overflow_check(ctx); }
+    int seal() {
+        if (ctx->arena_overflow) return overflowed();
+        return mirror_hi > mirror_lo ? icg_arena_h2d(ctx, mirror_lo, mirror_hi) : 0;
+    }
     template <typename T> T *out(T *user, size_t n) {
         size_t off = icg_arena_alloc(ctx, sizeof(T) * n);
         if (user) outs.push_back({(void *) user, off, sizeof(T) * n, false});
@@ -232,6 +238,10 @@ struct icg_call {
     }
     int finish() {
         int rc    = 0;
+        if (ctx->arena_overflow) {
+            (void) icg_stream_wait(ctx);
+            return overflowed();
+        }
         size_t lo = (size_t) -1, hi = 0;
         for (auto &o : outs)
             if (!o.zc) {

@@ -513,6 +513,7 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
         int rc         = icg_arena_reserve(ctx, sizeof(unsigned int) * 256 * (size_t) n + 4096);
         if (rc) return rc;
         d_hist = icg_d<unsigned int>(ctx, icg_arena_alloc(ctx, sizeof(unsigned int) * 256 * (size_t) n));
+        if ((rc = icg_arena_overflow_check(ctx))) return rc;
         ICG_HIP(ctx, hipMemsetAsync(d_hist, 0, sizeof(unsigned int) * 256 * (size_t) n, ctx->stream));
     }
 

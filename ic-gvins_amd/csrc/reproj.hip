@@ -276,6 +276,7 @@ extern "C" int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double 
     size_t in_end = ctx->arena_off;
     size_t o_r    = icg_arena_alloc(ctx, rbytes);
     size_t o_J    = want_jac ? icg_arena_alloc(ctx, jbytes) : 0;
+    if ((rc = icg_arena_overflow_check(ctx))) return rc;
     if ((rc = icg_arena_h2d(ctx, o_par, in_end))) return rc;
 
     rpj_args A;

@@ -204,6 +204,10 @@ struct IntegrationState { // preintegration/integration_state.h:35-52 (fields us
 struct IntegrationParameters { // integration_state.h:67-88
     double acc_vrw{0}, gyr_arw{0}, gyr_bias_std{0}, acc_bias_std{0}, corr_time{1}, gravity{9.8};
     Vector3d iewn; // Earth rotation in the local frame, Earth::iewn(station, p) — explicit here (SURVEY.md hazard H9)
+    // when set, every (re)integration derives its own Earth rate from the interval's start position, as
+    // PreintegrationEarth::resetState does (preintegration_earth.cc:319-321); otherwise `iewn` above is used as given
+    bool has_station{false};
+    Vector3d station;
 };
 
 // One IMU interval between two time nodes.  (Re)integration of many intervals is ONE batched device call.
@@ -212,7 +216,8 @@ public:
     enum Variant { NORMAL = 0, EARTH = 1 };
     Preintegration(std::shared_ptr<IntegrationParameters> parameters, const IMU &imu0, const IntegrationState &state, Variant v);
     void addNewImu(const IMU &imu) { imu_buffer_.push_back(imu); dirty_ = true; }
-    void reintegration(const IntegrationState &state) { start_state_ = state; dirty_ = true; }
+    void reintegration(const IntegrationState &state);
+    const Vector3d &earthRate() const { return iewn_; }
     // integrate every dirty interval of the list with a single icg_preint_batch launch
     static bool integrateBatch(icg_ctx *ctx, const vector<Preintegration *> &list, std::string *err = nullptr);
     const IntegrationState &currentState() const { return current_state_; }
@@ -230,6 +235,7 @@ private:
     IntegrationState start_state_, current_state_, delta_state_;
     double delta_time_{0};
     vector<double> jacobian_, covariance_, pn_; // 15x15, 15x15, (n-1)x4
+    Vector3d iewn_; // this interval's Earth rate: P1 (device) and P2 (evaluate) use the same value
     bool dirty_{true};
 };
 

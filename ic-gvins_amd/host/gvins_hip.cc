@@ -454,8 +454,8 @@ void GVINS::runOptimizationOnce() { // body of runOptimization (ic_gvins.cc:404-
     }
 }
 
-void GVINS::solveWindowAlone() {
-    gvinsOptimization();
+void GVINS::solveWindowAlone(int prepared_n_visual) {
+    gvinsOptimization(prepared_n_visual);
     afterWindowSolve();
 }
 
@@ -562,8 +562,10 @@ std::shared_ptr<Preintegration> GVINS::createPreintegration(const IMU &imu0, con
     if (preintegration_options_ == Preintegration::EARTH) {
         // the reference derives the Earth rate from IntegrationParameters::station, which nothing ever assigns (zero-initialised):
         // Earth::iewn(station = 0, p) (preintegration_earth.cc:320, SURVEY.md hazard H9).  Reproduced, per interval.
-        parameters       = std::make_shared<IntegrationParameters>(*integration_parameters_);
-        parameters->iewn = Earth::iewn(Vector3d(0, 0, 0), state.p);
+        // resetState recomputes it from the interval's start position at every reintegration too (:319-321): Preintegration does the same
+        parameters              = std::make_shared<IntegrationParameters>(*integration_parameters_);
+        parameters->has_station = true;
+        parameters->station     = Vector3d(0, 0, 0);
     }
     return std::make_shared<Preintegration>(parameters, imu0, state, preintegration_options_);
 }
@@ -877,9 +879,11 @@ void GVINS::finishWindowSolve(const WindowSolver::Summary &first, const WindowSo
     gnss_blocks_.clear();
 }
 
-bool GVINS::gvinsOptimization() { // the phases on a WindowSolver of this estimator
+bool GVINS::gvinsOptimization(int prepared_n_visual) { // the phases on a WindowSolver of this estimator
     TimeCost timecost;
-    const int n_visual = beginWindowSolve();
+    // a caller that already ran beginWindowSolve() for this window (lock-step replay) hands its factor count over: running it a
+    // second time would count every landmark's addOptimizedTimes() twice and rebuild invdepthlist_
+    const int n_visual = prepared_n_visual >= 0 ? prepared_n_visual : beginWindowSolve();
     if (n_visual > 0) { // the reprojection batch has to be complete before the solver is built on it (WindowSolver drives it on the device)
         for (size_t k = 0; k < visual_factors_.size(); k++)
             visual_batch_->add(visual_factors_[k].get(), visual_blocks_[k].pose_i, visual_blocks_[k].pose_j, extrinsic_, visual_blocks_[k].invdepth, &extrinsic_[7]);
@@ -1067,7 +1071,9 @@ bool GVINS::gvinsMarginalization() { // ic_gvins.cc:1412-1678
     // reprojection factors of the landmarks anchored in the oldest keyframe: evaluated and assembled on the device
     marg_batch_->clear();
     std::vector<std::shared_ptr<ReprojectionFactor>> marg_factors;
-    auto loss_function = std::make_shared<HuberLossHip>(1.0);
+    // ic_gvins.cc:1556 constructs a HuberLoss here but :1600-1606 hands nullptr to every ResidualBlockInfo: the reference's
+    // prior is built from UNCORRECTED reprojection residuals / Jacobians (the device batch therefore runs with delta 0)
+    const std::shared_ptr<ceres::LossFunction> loss_function; // null, as the reference passes
     for (auto const &feature : features) {
         auto mappoint = feature.second->getMapPoint();
         if (feature.second->isOutlier() || !mappoint || mappoint->isOutlier()) continue;

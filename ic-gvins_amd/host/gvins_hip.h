@@ -132,7 +132,7 @@ public:
     void betweenWindowSolves(WindowProblem &problem);
     void finishWindowSolve(const WindowSolver::Summary &first, const WindowSolver::Summary &second, double first_ms, double second_ms, int chi2_removed);
     void afterWindowSolve();
-    void solveWindowAlone();
+    void solveWindowAlone(int prepared_n_visual = -1); // >= 0: beginWindowSolve() already ran for this window and returned this count
     int firstNumIterations() const { return first_num_iterations_; }
     int secondNumIterations() const { return second_num_iterations_; }
 
@@ -183,7 +183,7 @@ private:
     void doReintegration();
     void updateParametersFromOptimizer();
     int getStateDataIndex(double time);
-    bool gvinsOptimization();
+    bool gvinsOptimization(int prepared_n_visual = -1);
     bool gvinsMarginalization();
     bool gvinsOutlierCulling();
     bool gvinsRemoveAllSecondNewFrame();

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "earth.h"
 #include "factors.h"
 
 namespace icg {
@@ -117,6 +118,8 @@ void stateFromArray(const double *a, IntegrationState &s) {
 }
 } // namespace
 
+static void refreshEarthRate(const IntegrationParameters &P, const IntegrationState &state, Vector3d &iewn);
+
 Preintegration::Preintegration(std::shared_ptr<IntegrationParameters> parameters, const IMU &imu0, const IntegrationState &state,
                                Variant v)
     : parameters_(std::move(parameters)), variant_(v), start_state_(state), current_state_(state) {
@@ -126,14 +129,42 @@ Preintegration::Preintegration(std::shared_ptr<IntegrationParameters> parameters
     jacobian_.assign(225, 0.0);
     covariance_.assign(225, 0.0);
     for (int i = 0; i < 15; i++) jacobian_[(size_t) i * 16] = 1.0;
+    refreshEarthRate(*parameters_, state, iewn_);
+}
+
+// preintegration_earth.cc:319-321 (resetState, run by the constructor and by every reintegration)
+static void refreshEarthRate(const IntegrationParameters &P, const IntegrationState &state, Vector3d &iewn) {
+    iewn = P.has_station ? Earth::iewn(P.station, state.p) : P.iewn;
+}
+
+void Preintegration::reintegration(const IntegrationState &state) {
+    start_state_ = state;
+    dirty_       = true;
+    if (variant_ == EARTH) refreshEarthRate(*parameters_, state, iewn_);
 }
 
 bool Preintegration::integrateBatch(icg_ctx *ctx, const vector<Preintegration *> &list, std::string *err) {
-    for (int variant = 0; variant < 2; variant++) {
-        vector<Preintegration *> todo;
-        for (auto *p : list)
-            if (p->dirty_ && (int) p->variant_ == variant) todo.push_back(p);
-        if (todo.empty()) continue;
+    // one launch per (variant, parameter values): icg_preint_batch takes one parameter vector per call, and every interval must be
+    // integrated with ITS OWN Earth rate (the one evaluate() uses).  Intervals of one estimator share their values in practice.
+    auto paramsOf = [](const Preintegration *p, double *out9) {
+        const IntegrationParameters &P = *p->parameters_;
+        const double v[9] = {P.gyr_arw, P.acc_vrw, P.gyr_bias_std, P.acc_bias_std, P.corr_time, P.gravity, p->iewn_[0], p->iewn_[1], p->iewn_[2]};
+        memcpy(out9, v, sizeof v);
+    };
+    vector<Preintegration *> pending;
+    for (auto *p : list)
+        if (p->dirty_) pending.push_back(p);
+    while (!pending.empty()) {
+        double params[9];
+        paramsOf(pending[0], params);
+        const int variant = (int) pending[0]->variant_;
+        vector<Preintegration *> todo, rest;
+        for (auto *p : pending) {
+            double q[9];
+            paramsOf(p, q);
+            ((int) p->variant_ == variant && memcmp(q, params, sizeof q) == 0 ? todo : rest).push_back(p);
+        }
+        pending.swap(rest);
         vector<int32_t> offsets{0};
         vector<double> imu, state0;
         for (auto *p : todo) {
@@ -146,8 +177,6 @@ bool Preintegration::integrateBatch(icg_ctx *ctx, const vector<Preintegration *>
             stateToArray(p->start_state_, a);
             state0.insert(state0.end(), a, a + 16);
         }
-        const IntegrationParameters &P = *todo[0]->parameters_;
-        const double params[9] = {P.gyr_arw, P.acc_vrw, P.gyr_bias_std, P.acc_bias_std, P.corr_time, P.gravity, P.iewn[0], P.iewn[1], P.iewn[2]};
         const size_t n = todo.size();
         vector<double> cur(16 * n), del(16 * n), jac(225 * n), cov(225 * n), dt(n), pn(imu.size() / 2);
         int rc = icg_preint_batch(ctx, variant, (int) n, offsets.data(), imu.data(), state0.data(), params, cur.data(), del.data(),
@@ -227,7 +256,7 @@ bool Preintegration::evaluate(const double *const *parameters, double *residuals
     V3 v0{mix0[0], mix0[1], mix0[2]}, bg0{mix0[3], mix0[4], mix0[5]}, ba0{mix0[6], mix0[7], mix0[8]};
     V3 v1{mix1[0], mix1[1], mix1[2]}, bg1{mix1[3], mix1[4], mix1[5]}, ba1{mix1[6], mix1[7], mix1[8]};
     V3 gravity{0, 0, parameters_->gravity};
-    V3 iewn{parameters_->iewn[0], parameters_->iewn[1], parameters_->iewn[2]};
+    V3 iewn{iewn_[0], iewn_[1], iewn_[2]};
     const IntegrationState &d = delta_state_;
     V3 dp{d.p[0], d.p[1], d.p[2]}, dv{d.v[0], d.v[1], d.v[2]}, dbg0{d.bg[0], d.bg[1], d.bg[2]}, dba0{d.ba[0], d.ba[1], d.ba[2]};
     Q4 dq{d.q.x, d.q.y, d.q.z, d.q.w};

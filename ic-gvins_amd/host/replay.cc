@@ -351,7 +351,7 @@ bool Replay::runLockstep(const std::vector<ReplayOptions> &options, std::vector<
             }
             for (LockstepStream *L : due) {
                 if (L->n_visual == 0)
-                    L->gvins->solveWindowAlone(); // no visual factors yet: a host-only problem, solved by the estimator's own WindowSolver
+                    L->gvins->solveWindowAlone(0); // no visual factors yet: a host-only problem on the estimator's own WindowSolver (the window is already prepared)
                 else
                     L->gvins->afterWindowSolve();
                 L->problem.reset();

@@ -19,7 +19,7 @@ struct PhaseClock {
     int calls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool on = getenv("ICG_SOLVER_DEBUG") != nullptr;
 };
-PhaseClock g_clock;
+thread_local PhaseClock g_clock; // per thread: concurrent estimators (Replay::runMany, lock-step groups) each print their own
 struct PhaseScope {
     int k;
     std::chrono::steady_clock::time_point t0;
