@@ -10,11 +10,11 @@
 //
 // Kernels (HBM/L2-bound stencils, no MFMA shape):
 //   k_mask_discs  one workgroup per existing feature: midpoint-circle span table -> zero spans in the u8 mask
-//   k_min_eig     62x8 response tile per wave, a lane per column, separable exact box sums; per-ROI masked maximum by
-//                 an order-preserving uint atomicMax
-//   k_candidates  threshold + 3x3 NMS + mask, 4 rows per lane -> (key = response bits << 32 | raster index) appended per ROI
-//   k_select      one workgroup per ROI: repeated block-wide arg-max over live candidates + min-distance kill
-//                 (equivalent to sort + greedy grid test, needs no sort and no capacity cap)
+//   k_min_eig_nms 60x16 tile per wave streamed down the image columns: response (separable exact box sums), per-ROI masked
+//                 maximum by an order-preserving uint atomicMax, 3x3 NMS + mask in registers -> every local maximum
+//                 (key = response bits << 32 | raster index) appended per ROI; no response plane in HBM
+//   k_select      one workgroup per ROI: quality threshold 0.01*max, then repeated block-wide arg-max over live candidates +
+//                 min-distance kill (equivalent to sort + greedy grid test, needs no sort and no capacity cap)
 //   k_subpix      one wavefront per corner: 13x13 bilinear patch and the 121 gradient terms in parallel through LDS,
 //                 the five 121-term sums each sequentially in raster order (IEEE order == CPU order), one lane per sum
 #include <cfloat>
@@ -65,125 +65,163 @@ __global__ __launch_bounds__(64) void k_mask_discs(int n_pts, const float2 *pts,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_min_eig: one WAVE per 62 x 8 response tile, one lane per image column (64 lanes = 62 outputs + 2 halo columns), four
-// waves (32 rows) per workgroup.
-//   stage 1  each lane walks DOWN its column: 12 image rows -> the 10 Sobel pairs of its halo column with the running
-//            differences d[r] = p[r][x+1]-p[r][x-1], s[r] = p[r][x-1]+2p[r][x]+p[r][x+1]  (gx = d[r-1]+2d[r]+d[r+1],
-//            gy = s[r+1]-s[r-1]), the 3 float products per entry;  tiles touching the ROI or image border take a
-//            per-entry path with explicit reflect-101
-//   exchange the 3x10 products of a lane go to LDS once; the left/right neighbours' are read back
-//   stage 2  SEPARABLE 3x3 box sums in double: the terms are floats in [s^2, (1020 s)^2] (s = 1/3060, |Sobel| <= 1020), so
-//            every partial sum of nine of them is a multiple of 2^-47 below 1 and exactly representable — the raster-order
-//            double accumulation of the CPU restatement and the separable one are bit-identical
-//   stage 3  min-eigenvalue in float for the lane's 8 pixels, response store, masked per-ROI maximum (order-preserving
-//            uint atomicMax, one per wave)
-// ~1.7 issued instructions per output pixel instead of 6.7 for the one-pixel-per-lane formulation.
-#define EIG_TW 62 // output columns per wave
-#define EIG_TH 8  // output rows per wave
-#define EIG_WAVES 4
+// k_min_eig_nms: Shi-Tomasi response, masked per-ROI maximum AND the 3x3 non-maximum test in ONE pass over the u8 image —
+// the f32 response plane of the two-kernel formulation (4 B/px written by k_min_eig, 4 B/px re-read by k_candidates) is
+// never materialised.  The quality threshold 0.01*max is only known when every tile of the ROI is done, but the local-maximum
+// test does not depend on it ("thresholded value equals the 3x3 maximum of the thresholded map" == v > thresh && v >= every
+// RAW neighbour: a neighbour at or below the threshold is below v, one above it keeps its value), so the kernel appends every
+// unmasked, non-zero local maximum and k_select drops the ones at or below the threshold.
+//
+// One WAVE per 60 x 16 tile of NMS outputs, a lane per image column (64 lanes = 60 outputs + 2 halo columns each side), the
+// wave STREAMS down its columns (22 image rows -> 20 rows of covariance products -> 18 response rows -> 16 NMS rows) with
+// three-row rolling windows in registers; the left/right neighbours' values move through wave-shift DPP, no LDS, no barrier:
+//   image row t      one dword per lane (3 pixels by per-lane byte selects: reflect-101 at true image borders folded in),
+//                    running Sobel differences d = p[x+1]-p[x-1], s = p[x-1]+2p[x]+p[x+1]
+//   product row      gx = d0+2d1+d2, gy = s2-s0, the three float products; horizontal 3-sums in double
+//   response row     vertical 3-sum in double (exact in any order: every term is a float in [s^2,(1020 s)^2], s = 1/3060, so all
+//                    partial sums are multiples of 2^-47 below 1), min-eigenvalue in float, masked maximum (ordered-uint key)
+//   NMS row          centre >= max of the 8 raw neighbours, unmasked, non-zero -> wave-aggregated append
+// Reflect-101 at the ROI edge (the covariance maps are ROI-sized Mats in OpenCV): a lane left/right of the ROI computes the
+// products of the mirrored column (same Sobel, bit-identical), the product row above/below the ROI is the mirrored row of the
+// rolling window.  Coordinates further out belong to partial tiles: clamped, their results never used.
+#define FE_TW 60    // NMS output columns per wave
+#define FE_TH 16    // NMS output rows per wave
+#define FE_WAVES 4  // waves per workgroup, stacked vertically
 
-__device__ __forceinline__ void eig_sobel_slow(const uint8_t *img, int pitch, int w, int h, const det_roi &R, int xcol, int yrow,
-                                               int &gx, int &gy) {
-    // ROI coordinate with reflect-101 at the ROI edge (cov is a fresh ROI-sized Mat in OpenCV); coordinates further out
-    // belong to partial tiles and are clamped (their outputs are never stored)
-    const int x = icg_reflect1(min(max(xcol, -1), R.rw), R.rw), y = icg_reflect1(min(max(yrow, -1), R.rh), R.rh);
-    const int X = R.rx + x, Y = R.ry + y;
-    // Sobel on REAL image pixels (peeks outside the ROI); reflect-101 only at true image borders
-    const int xm = icg_reflect1(X - 1, w), xp = icg_reflect1(X + 1, w);
-    const int ym = icg_reflect1(Y - 1, h), yp = icg_reflect1(Y + 1, h);
-    const uint8_t *r0 = img + (size_t) ym * pitch, *r1 = img + (size_t) Y * pitch, *r2 = img + (size_t) yp * pitch;
-    const int p00 = r0[xm], p01 = r0[X], p02 = r0[xp];
-    const int p10 = r1[xm], p12 = r1[xp];
-    const int p20 = r2[xm], p21 = r2[X], p22 = r2[xp];
-    gx = (p02 - p00) + 2 * (p12 - p10) + (p22 - p20);
-    gy = (p20 - p00) + 2 * (p21 - p01) + (p22 - p02);
+// lane i <- lane i-1 / lane i+1 across the whole wave (wave_shr:1 / wave_shl:1); the edge lanes receive 0 and are halo
+__device__ __forceinline__ float from_left(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float from_right(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130, 0xF, 0xF, true));
 }
 
-__global__ __launch_bounds__(64 * EIG_WAVES) void k_min_eig(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
-                                                            const int32_t *slots, int pitch, int w, int h,
-                                                            const uint8_t *mask, size_t mask_plane, unsigned int gen, float *eig,
-                                                            size_t eig_plane, unsigned int *roi_max, int gx, int gy, int n_blocks,
-                                                            unsigned int m_roi, unsigned int m_gx) {
-    __shared__ float cov[EIG_WAVES][3][EIG_TH + 2][64];
-    // 1-D launch, ROI-major and XCD-chunked: a ROI's blocks (and later its k_candidates blocks) share one XCD's L2
+__global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
+                                                               const int32_t *slots, int pitch, int w, int h, const uint8_t *mask,
+                                                               size_t mask_plane, unsigned int gen, unsigned int *roi_max,
+                                                               unsigned long long *cand, size_t cand_plane, int32_t *cand_cnt,
+                                                               int gx, int gy, int n_blocks, unsigned int m_roi, unsigned int m_gx) {
+    // 1-D launch, ROI-major and XCD-chunked: the tiles of a ROI (and of a frame) share one XCD's L2
     const int bl = icg_xcd_chunked(blockIdx.x, n_blocks);
-    if (bl >= n_blocks) return; // whole workgroup
+    if (bl >= n_blocks) return;
     const int roi = icg_div_by_magic(bl, m_roi), rem = bl - roi * (gx * gy);
     const int by = icg_div_by_magic(rem, m_gx), bx = rem - by * gx;
     const det_roi R = rois[roi];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int tx0 = bx * EIG_TW, ty0 = (by * EIG_WAVES + wv) * EIG_TH;
-    const bool live = tx0 < R.rw && ty0 < R.rh; // wave-uniform; dead waves still join the barrier
+    const int lane = threadIdx.x & 63;
+    const int wv   = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // wave-uniform by construction: keep it in an SGPR
+    const int tx0 = bx * FE_TW, ty0 = (by * FE_WAVES + wv) * FE_TH;
+    if (tx0 >= R.rw || ty0 >= R.rh) return; // wave-uniform; there is no barrier in this kernel
     const uint8_t *img = frames + (size_t) slots[R.job] * slot_bytes;
     const float s      = (float) (1.0 / 3060.0);
-    float cx[EIG_TH + 2], cm[EIG_TH + 2], cy[EIG_TH + 2]; // dx*dx, dx*dy, dy*dy of the lane's halo column
-    if (live) {
-        // the lane's halo column xcol = tx0-1+lane, halo rows ty0-1 .. ty0+8
-        const int xcol = tx0 - 1 + lane;
-        const bool interior = tx0 >= 1 && tx0 + EIG_TW <= R.rw - 1 && ty0 >= 1 && ty0 + EIG_TH <= R.rh - 1 && R.rx + tx0 >= 2 &&
-                              R.rx + tx0 + EIG_TW + 1 <= w - 1 && R.ry + ty0 >= 2 && R.ry + ty0 + EIG_TH + 1 <= h - 1; // wave-uniform
-        int gxv[EIG_TH + 2], gyv[EIG_TH + 2];
-        if (interior) {
-            typedef unsigned int __attribute__((aligned(1))) u32u;
-            const uint8_t *p = img + (size_t) (R.ry + ty0 - 2) * pitch + (R.rx + xcol - 1); // image row of halo row -1, column x-1
-            int d[EIG_TH + 4], sm[EIG_TH + 4];
+
+    // the lane's column: ROI coordinate xcol, mirrored at the ROI edge, then the three image columns with reflect-101 at the true
+    // image border, fetched as byte selects of ONE dword (base <= all three <= base+3)
+    const int xcol = tx0 - 2 + lane;
+    const int X    = R.rx + icg_reflect1(min(max(xcol, -1), R.rw), R.rw);
+    const int ca = icg_reflect1(X - 1, w), cc = icg_reflect1(X + 1, w);
+    const int base = min(max(X - 1, 0), w - 4);
+    const unsigned int sha = 8u * (unsigned int) (ca - base), shb = 8u * (unsigned int) (X - base), shc = 8u * (unsigned int) (cc - base);
+    const bool own_col  = lane >= 2 && lane <= FE_TW + 1 && xcol < R.rw;   // columns whose responses this tile owns
+    const bool nms_col  = own_col && xcol >= 1 && xcol < R.rw - 1;
+    const uint8_t *mroi = mask + (size_t) R.job * mask_plane + (size_t) R.ry * pitch; // wave-uniform; + row*pitch + mx per lane
+    const int mx        = R.rx + xcol;
+    unsigned long long *cbase = cand + (size_t) R.job * cand_plane + R.cand_base;
+
+    // every global load of the tile is issued up front (22 image dwords + 16 mask bytes per lane in flight together): the
+    // streaming loop below then runs from registers
+    typedef unsigned int __attribute__((aligned(1))) u32u;
+    unsigned int pix[FE_TH + 6];
 #pragma unroll
-            for (int r = 0; r < EIG_TH + 4; r++) {
-                const unsigned int v = *reinterpret_cast<const u32u *>(p + (size_t) r * pitch);
-                const int a = v & 0xff, b = (v >> 8) & 0xff, c = (v >> 16) & 0xff;
-                d[r]  = c - a;
-                sm[r] = a + 2 * b + c;
-            }
-#pragma unroll
-            for (int r = 0; r < EIG_TH + 2; r++) {
-                gxv[r] = d[r] + 2 * d[r + 1] + d[r + 2];
-                gyv[r] = sm[r + 2] - sm[r];
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < EIG_TH + 2; r++) eig_sobel_slow(img, pitch, w, h, R, xcol, ty0 - 1 + r, gxv[r], gyv[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < EIG_TH + 2; r++) {
-            const float dx = (float) gxv[r] * s, dy = (float) gyv[r] * s;
-            cx[r] = dx * dx;
-            cm[r] = dx * dy;
-            cy[r] = dy * dy;
-            cov[wv][0][r][lane] = cx[r];
-            cov[wv][1][r][lane] = cm[r];
-            cov[wv][2][r][lane] = cy[r];
-        }
+    for (int t = 0; t < FE_TH + 6; t++) {
+        // image row R.ry + ty0 - 3 + t (rows further than one past the image only feed partial tiles)
+        const int Yr        = icg_reflect1(min(max(R.ry + ty0 - 3 + t, -1), h), h);
+        const uint8_t *rowp = img + (size_t) Yr * pitch; // wave-uniform row base + per-lane 32-bit column offset
+        pix[t]              = *reinterpret_cast<const u32u *>(rowp + base);
     }
-    __syncthreads();
-    if (!live) return;
-    unsigned int key = 0;
-    const int x = tx0 + lane - 1; // output column of this lane (lanes 1..62)
-    if (lane >= 1 && lane <= EIG_TW && x < R.rw) {
-        const int ln = lane - 1, lp = lane + 1;
-        double ha[EIG_TH + 2], hb[EIG_TH + 2], hc[EIG_TH + 2]; // horizontal 3-sums per halo row
+    unsigned int unmasked = 0; // bit k: the owned response of tile row k is not masked
+    {
+        uint8_t mk[FE_TH];
+        const int mxs = own_col ? mx : R.rx;
 #pragma unroll
-        for (int r = 0; r < EIG_TH + 2; r++) {
-            ha[r] = ((double) cov[wv][0][r][ln] + (double) cx[r]) + (double) cov[wv][0][r][lp];
-            hb[r] = ((double) cov[wv][1][r][ln] + (double) cm[r]) + (double) cov[wv][1][r][lp];
-            hc[r] = ((double) cov[wv][2][r][ln] + (double) cy[r]) + (double) cov[wv][2][r][lp];
+        for (int k = 0; k < FE_TH; k++) {
+            const int yc = min(ty0 + k, R.rh - 1);
+            mk[k]        = (mroi + (size_t) yc * pitch)[mxs]; // unconditional (halo lanes read a valid column): no per-load branch
         }
-        const int X = R.rx + x;
-        float *erow         = eig + (size_t) R.job * eig_plane + (size_t) (R.ry + ty0) * w + X;
-        const uint8_t *mrow = mask + (size_t) R.job * mask_plane + (size_t) (R.ry + ty0) * pitch + X;
 #pragma unroll
-        for (int k = 0; k < EIG_TH; k++) {
-            if (ty0 + k < R.rh) {
-                const double sa = (ha[k] + ha[k + 1]) + ha[k + 2], sb = (hb[k] + hb[k + 1]) + hb[k + 2];
-                const double sc = (hc[k] + hc[k + 1]) + hc[k + 2];
-                const float a = (float) sa * 0.5f, b = (float) sb, c = (float) sc * 0.5f;
-                const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-                erow[(size_t) k * w] = e;
-                if (mrow[(size_t) k * pitch] != (uint8_t) gen) {
-                    const unsigned int ke = f32_order_key(e);
+        for (int k = 0; k < FE_TH; k++)
+            if (mk[k] != (uint8_t) gen && ty0 + k < R.rh) unmasked |= 1u << k;
+        if (!own_col) unmasked = 0;
+    }
+    int d0 = 0, d1 = 0, s0 = 0, s1 = 0;                                    // Sobel differences of image rows t-2, t-1
+    double hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0, hC0 = 0, hC1 = 0;           // horizontal 3-sums of product rows r-2, r-1
+    float eC = 0.f, sideC = 0.f, m3T = 0.f, m3C = 0.f;                     // response rows q-1 (centre) and q-2 (top)
+    bool unmC = false;
+    unsigned int key = 0;
+#pragma unroll
+    for (int t = 0; t < FE_TH + 6; t++) {
+        const unsigned int v = pix[t];
+        const int a = (int) ((v >> sha) & 0xffu), b = (int) ((v >> shb) & 0xffu), c = (int) ((v >> shc) & 0xffu);
+        const int dN = c - a, sN = a + 2 * b + c;
+        if (t >= 2) {
+            // product row ty0 - 2 + (t-2)
+            const int gxv = d0 + 2 * d1 + dN, gyv = sN - s0;
+            const float dx = (float) gxv * s, dy = (float) gyv * s;
+            const float cx = dx * dx, cm = dx * dy, cy = dy * dy;
+            double hAn = ((double) from_left(cx) + (double) cx) + (double) from_right(cx);
+            double hBn = ((double) from_left(cm) + (double) cm) + (double) from_right(cm);
+            double hCn = ((double) from_left(cy) + (double) cy) + (double) from_right(cy);
+            if (ty0 - 4 + t == R.rh) { // product row rh := row rh-2 (wave-uniform, at most once per tile: a real branch)
+                asm volatile("");
+                hAn = hA0, hBn = hB0, hCn = hC0;
+            }
+            if (t >= 4) {
+                // response row q = t-4; the window is the product rows above, at and below it = (h?0, h?1, h?n)
+                const int q = t - 4; // ROI row ty0 - 1 + q
+                double tA = hA0, tB = hB0, tC = hC0;
+                if (q == 1 && ty0 == 0) { // product row -1 := row 1 (only the first response row of the first tile row)
+                    asm volatile("");
+                    tA = hAn, tB = hBn, tC = hCn;
+                }
+                const double sa = (tA + hA1) + hAn, sb = (tB + hB1) + hBn, sc = (tC + hC1) + hCn;
+                const float fa = (float) sa * 0.5f, fb = (float) sb, fc = (float) sc * 0.5f;
+                const float e = (fa + fc) - sqrtf((fa - fc) * (fa - fc) + fb * fb);
+                bool unm = false;
+                if (q >= 1 && q <= FE_TH) { // the response rows this tile owns
+                    unm                   = (unmasked >> (q - 1)) & 1u;
+                    const unsigned int ke = unm ? f32_order_key(e) : 0u;
                     key                   = ke > key ? ke : key;
                 }
+                const float el = from_left(e), er = from_right(e);
+                const float side = fmaxf(el, er), m3 = fmaxf(side, e);
+                if (t >= 6) {
+                    // NMS row k = t-6: centre = response row q-1 at ROI row y
+                    const int y = ty0 + (t - 6);
+                    const bool is_cand = (y >= 1 && y < R.rh - 1) && nms_col && unmC && eC != 0.f &&
+                                         eC >= fmaxf(fmaxf(m3T, sideC), m3);
+                    // wave-aggregated append: one atomic per wavefront and row
+                    const unsigned long long m = __ballot(is_cand);
+                    if (m != 0) {
+                        int slot0 = 0;
+                        const int leader = __ffsll((long long) m) - 1;
+                        if (lane == leader) slot0 = atomicAdd(&cand_cnt[roi], __popcll(m));
+                        slot0 = __shfl(slot0, leader, 64);
+                        if (is_cand)
+                            cbase[slot0 + __popcll(m & ((1ull << lane) - 1ull))] =
+                                ((unsigned long long) f32_order_key(eC) << 32) | (unsigned int) (y * R.rw + xcol);
+                    }
+                }
+                m3T   = m3C;
+                m3C   = m3;
+                eC    = e;
+                sideC = side;
+                unmC  = unm;
             }
+            hA0 = hA1, hA1 = hAn;
+            hB0 = hB1, hB1 = hBn;
+            hC0 = hC1, hC1 = hCn;
         }
+        d0 = d1, d1 = dN;
+        s0 = s1, s1 = sN;
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -194,86 +232,11 @@ __global__ __launch_bounds__(64 * EIG_WAVES) void k_min_eig(const det_roi *rois,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// 4 vertically adjacent pixels per lane (one wave = a 64 x 4 strip, one workgroup = 64 x 16): the 6x3 response values a
-// lane needs are loaded once for its 4 pixels and every load is a fully coalesced row segment.  OpenCV's test
-// "thresholded value equals the 3x3 maximum of the thresholded map" is evaluated as
-// v > thresh && v >= every RAW neighbour  (identical: a neighbour at or below the threshold is below v, a neighbour
-// above it keeps its value).
-#define CAND_PY 4
-__global__ __launch_bounds__(256) void k_candidates(const det_roi *rois, int pitch, int w, const uint8_t *mask,
-                                                    size_t mask_plane, unsigned int gen, const float *eig, size_t eig_plane,
-                                                    const unsigned int *roi_max, unsigned long long *cand,
-                                                    size_t cand_plane, int32_t *cand_cnt, int gx, int gy, int n_blocks,
-                                                    unsigned int m_roi, unsigned int m_gx) {
-    const int bl = icg_xcd_chunked(blockIdx.x, n_blocks); // ROI-major, XCD-chunked like k_min_eig
-    if (bl >= n_blocks) return;
-    const int roi = icg_div_by_magic(bl, m_roi), rem = bl - roi * (gx * gy);
-    const int by = icg_div_by_magic(rem, m_gx), bx = rem - by * gx;
-    const det_roi R = rois[roi];
-    const int lane = threadIdx.x & 63;
-    const int x  = bx * 64 + lane;
-    const int y0 = (by * 4 + (threadIdx.x >> 6)) * CAND_PY;
-    if (y0 >= R.rh - 1) return; // wave-uniform
-    const unsigned int mk = roi_max[roi];
-    const double maxVal   = mk ? (double) f32_from_order_key(mk) : 0.0;
-    const float thresh    = (float) (maxVal * 0.01);
-    bool is_cand[CAND_PY];
-    float v[CAND_PY];
-#pragma unroll
-    for (int k = 0; k < CAND_PY; k++) {
-        is_cand[k] = false;
-        v[k]       = 0.f;
-    }
-    if (x >= 1 && x < R.rw - 1) {
-        const float *e = eig + (size_t) R.job * eig_plane + (size_t) R.ry * w + (R.rx + x);
-        float a[CAND_PY + 2][3];
-#pragma unroll
-        for (int j = 0; j < CAND_PY + 2; j++) {
-            // ROI row y0-1+j; rows outside [0, rh) are never a valid centre's neighbour (clamped load, unused)
-            int yj = y0 - 1 + j;
-            yj     = yj < 0 ? 0 : (yj > R.rh - 1 ? R.rh - 1 : yj);
-            const float *row = e + (size_t) yj * w;
-            a[j][0] = row[-1];
-            a[j][1] = row[0];
-            a[j][2] = row[1];
-        }
-        const uint8_t *mcol = mask + (size_t) R.job * mask_plane + (size_t) R.ry * pitch + (R.rx + x);
-#pragma unroll
-        for (int k = 0; k < CAND_PY; k++) {
-            const int y = y0 + k;
-            if (y < 1 || y >= R.rh - 1) continue;
-            const float c = a[k + 1][1];
-            if (!(c > thresh) || c == 0.f) continue; // THRESH_TOZERO leaves 0 below the threshold, and 0 is never a corner
-            float mx = fmaxf(fmaxf(a[k][0], a[k][1]), a[k][2]);
-            mx       = fmaxf(mx, fmaxf(a[k + 1][0], a[k + 1][2]));
-            mx       = fmaxf(mx, fmaxf(fmaxf(a[k + 2][0], a[k + 2][1]), a[k + 2][2]));
-            v[k]       = c;
-            is_cand[k] = (c >= mx) && mcol[(size_t) y * pitch] != (uint8_t) gen;
-        }
-    }
-    // wave-aggregated append: one atomic per wavefront and row instead of one per candidate
-#pragma unroll
-    for (int k = 0; k < CAND_PY; k++) {
-        const unsigned long long m = __ballot(is_cand[k]);
-        if (m == 0) continue;
-        int base = 0;
-        const int leader = __ffsll((long long) m) - 1;
-        if (lane == leader) base = atomicAdd(&cand_cnt[roi], __popcll(m));
-        base = __shfl(base, leader, 64);
-        if (is_cand[k]) {
-            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-            cand[(size_t) R.job * cand_plane + R.cand_base + slot] =
-                ((unsigned long long) f32_order_key(v[k]) << 32) | (unsigned int) ((y0 + k) * R.rw + x);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 #define DET_MAX_PER_BLOCK 64
 
 __global__ __launch_bounds__(256) void k_select(const det_roi *rois, unsigned long long *cand, size_t cand_plane,
-                                                const int32_t *cand_cnt, int min_dist, float2 *corners /*roi x max_pb*/,
-                                                int32_t *corner_cnt, int max_pb) {
+                                                const int32_t *cand_cnt, const unsigned int *roi_max, int min_dist,
+                                                float2 *corners /*roi x max_pb*/, int32_t *corner_cnt, int max_pb) {
     __shared__ unsigned long long wbest[4];
     __shared__ unsigned long long best;
     const det_roi R = rois[blockIdx.x];
@@ -283,6 +246,16 @@ __global__ __launch_bounds__(256) void k_select(const det_roi *rois, unsigned lo
     const double md2 = (double) min_dist * (double) min_dist;
     int quota = R.quota < max_pb ? R.quota : max_pb;
     int acc   = 0;
+    {
+        // quality level (featureselect.cpp: threshold(eig, eig, maxVal*qualityLevel, 0, THRESH_TOZERO)): k_min_eig_nms appended
+        // every unmasked local maximum, the ones that are not above 0.01 * (masked ROI maximum) are dropped here
+        const unsigned int mk = roi_max[blockIdx.x];
+        const double maxVal   = mk ? (double) f32_from_order_key(mk) : 0.0;
+        const float thresh    = (float) (maxVal * 0.01);
+        for (int i = t; i < n; i += 256)
+            if (!(f32_from_order_key((unsigned int) (C[i] >> 32)) > thresh)) C[i] = 0;
+        __syncthreads();
+    }
     while (acc < quota) {
         unsigned long long k = 0;
         for (int i = t; i < n; i += 256) {
@@ -440,9 +413,8 @@ static void circle_halfwidths(int radius, std::vector<int32_t> &hw) {
 }
 
 static int ensure_detect_ws(icg_ctx *ctx) {
-    if (ctx->d_eig) return 0;
+    if (ctx->d_mask) return 0;
     const size_t w = ctx->cfg.width, h = ctx->cfg.height, nb = ctx->cfg.max_batch;
-    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_eig, sizeof(float) * w * h * nb));
     ICG_HIP(ctx, hipMalloc((void **) &ctx->d_mask, (size_t) ctx->lv[0].pitch * h * nb));
     ICG_HIP(ctx, hipMemsetAsync(ctx->d_mask, 0, (size_t) ctx->lv[0].pitch * h * nb, ctx->stream));
     ctx->mask_gen = 0;
@@ -525,7 +497,7 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     float2 *d_corners    = (float2 *) c.out(h_corners.data(), (size_t) n_roi * max_pb * 2);
     int32_t *d_cnt       = c.out(h_cnt.data(), (size_t) n_roi);
 
-    const size_t mask_plane = (size_t) pitch * h, eig_plane = (size_t) w * h, cand_plane = (size_t) w * h;
+    const size_t mask_plane = (size_t) pitch * h, cand_plane = (size_t) w * h;
     // mask generation (see k_mask_discs): a full clear only when the 8-bit tag wraps
     if (++ctx->mask_gen > 255) {
         ICG_HIP(ctx, hipMemsetAsync(ctx->d_mask, 0, mask_plane * ctx->cfg.max_batch, ctx->stream));
@@ -538,22 +510,15 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
                            d_hw, ctx->d_mask, pitch, w, h, mask_plane, gen);
     }
     {
-        icg_prof_scope ps(ctx, "detect_min_eig");
-        const int gx = (grid->block_w + EIG_TW - 1) / EIG_TW, gy = (grid->block_h + EIG_TH * EIG_WAVES - 1) / (EIG_TH * EIG_WAVES);
-        hipLaunchKernelGGL(k_min_eig, dim3(icg_xcd_grid(gx * gy * n_roi)), dim3(64 * EIG_WAVES), 0, ctx->stream, d_rois, ctx->d_frames,
-                           ctx->slot_bytes, d_slots, pitch, w, h, ctx->d_mask, mask_plane, gen, ctx->d_eig, eig_plane, d_rmax, gx, gy,
-                           gx * gy * n_roi, icg_div_magic(gx * gy), icg_div_magic(gx));
-    }
-    {
-        icg_prof_scope ps(ctx, "detect_candidates");
-        const int gx = (grid->block_w + 63) / 64, gy = (grid->block_h + 4 * CAND_PY - 1) / (4 * CAND_PY);
-        hipLaunchKernelGGL(k_candidates, dim3(icg_xcd_grid(gx * gy * n_roi)), dim3(256), 0, ctx->stream, d_rois, pitch, w, ctx->d_mask,
-                           mask_plane, gen, ctx->d_eig, eig_plane, d_rmax, ctx->d_cand, cand_plane, d_ccnt, gx, gy, gx * gy * n_roi,
-                           icg_div_magic(gx * gy), icg_div_magic(gx));
+        icg_prof_scope ps(ctx, "detect_min_eig_nms");
+        const int gx = (grid->block_w + FE_TW - 1) / FE_TW, gy = (grid->block_h + FE_TH * FE_WAVES - 1) / (FE_TH * FE_WAVES);
+        hipLaunchKernelGGL(k_min_eig_nms, dim3(icg_xcd_grid(gx * gy * n_roi)), dim3(64 * FE_WAVES), 0, ctx->stream, d_rois, ctx->d_frames,
+                           ctx->slot_bytes, d_slots, pitch, w, h, ctx->d_mask, mask_plane, gen, d_rmax, ctx->d_cand, cand_plane, d_ccnt,
+                           gx, gy, gx * gy * n_roi, icg_div_magic(gx * gy), icg_div_magic(gx));
     }
     {
         icg_prof_scope ps(ctx, "detect_select");
-        hipLaunchKernelGGL(k_select, dim3(n_roi), dim3(256), 0, ctx->stream, d_rois, ctx->d_cand, cand_plane, d_ccnt,
+        hipLaunchKernelGGL(k_select, dim3(n_roi), dim3(256), 0, ctx->stream, d_rois, ctx->d_cand, cand_plane, d_ccnt, d_rmax,
                            grid->min_dist, d_corners, d_cnt, max_pb);
     }
     {

@@ -68,11 +68,16 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void k_clahe_lut(pre_jobs jobs, clahe_geom g, uint8_t *lut /* n x tiles^2 x 256 */) {
+__global__ __launch_bounds__(64) void k_clahe_lut(pre_jobs jobs, clahe_geom g, uint8_t *lut /* n x tiles^2 x 256 */, int n_items) {
     __shared__ __attribute__((aligned(16))) unsigned int hist[256];
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
-    const int b    = blockIdx.y;
+    // (frame, tile) items frame-major, XCD-chunked: a tile row is 61-byte runs of the same image rows, so neighbouring tiles share
+    // every 128-byte line — with round-robin placement each line was fetched into two or three XCDs' L2s (3.2x the image bytes
+    // from HBM per frame, rocprofv3 FETCH_SIZE); now a frame's tiles sit on one XCD
+    const int item = icg_xcd_chunked(blockIdx.x, n_items);
+    if (item >= n_items) return;
+    const int b    = item / (ICG_CLAHE_TILES * ICG_CLAHE_TILES);
+    const int tile = item - b * (ICG_CLAHE_TILES * ICG_CLAHE_TILES);
     const int ty = tile / ICG_CLAHE_TILES, tx = tile - ty * ICG_CLAHE_TILES;
     const uint8_t *src = jobs.src[b];
     const int stride   = jobs.stride;
@@ -563,7 +568,7 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
         uint8_t *lut = ctx->d_lut + (size_t) base * T * T * 256;
         {
             icg_prof_scope ps(ctx, "clahe_lut");
-            hipLaunchKernelGGL(k_clahe_lut, dim3(T * T, m), dim3(64), 0, ctx->stream, jobs, g, lut);
+            hipLaunchKernelGGL(k_clahe_lut, dim3(icg_xcd_grid(T * T * m)), dim3(64), 0, ctx->stream, jobs, g, lut, T * T * m);
         }
         {
             icg_prof_scope ps(ctx, "clahe_apply");
