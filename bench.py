@@ -84,28 +84,208 @@ def usable_host_cores():
     return float(n)
 
 
-def build_streams(sb, scene, n_streams, n_ring, rank, ctx_dev_upload):
-    """Render n_ring frames per stream and park them in HBM. Returns (device ptr table, host frames of stream 0)."""
-    w, h = scene.w, scene.h
-    dev = []
-    host0 = []
-    for s in range(n_streams):
-        sid = sharding.shard_stream_ids(rank, 0, n_streams)[s]
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def ensure_timing_oracle():
+    """The oracle-backed host layer rebuilt -O3 -march=native -ffp-contract=off ON THIS BOX; only the cpu_baseline legs
+    time it.  Falls back to the -O2 parity build (with a note) if the compiler is missing.  Returns (path, flags string)."""
+    import hashlib
+    import subprocess
+    from stream_utils import ensure_oracle_host
+    tag = hashlib.sha1((cpu_model() + open("/proc/cpuinfo").read().split("flags", 1)[-1][:2000]).encode()).hexdigest()[:12]
+    d = os.path.join(ROOT, "oracle", "_fast", tag)
+    so = os.path.join(d, "libicgvins_host_oracle.so")
+    if not os.path.exists(so):
+        r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "fast", "FASTDIR=_fast/" + tag],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0 or not os.path.exists(so):
+            return ensure_oracle_host(), "-O2 -ffp-contract=off (timing build failed: parity build timed instead)"
+    return so, "-O3 -march=native -ffp-contract=off"
+
+
+def measure_hbm_peak(torch, device, nbytes=1 << 30, reps=10):
+    """Achievable HBM bandwidth of THIS box: device-to-device copy of a 1 GiB buffer (read + write), GB/s."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del src, dst
+    torch.cuda.empty_cache()
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
+def committed_pmc(kernel):
+    """Per-kernel counter means of the newest committed rocprofv3 --pmc summary (profiles/rNN_pmc_summary.json, collected by
+    profiles/collect.sh at the bench configuration).  Returns (entry or None, file name)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))
+    if not files:
+        return None, None
+    return json.load(open(files[-1])).get(kernel), os.path.basename(files[-1])
+
+
+def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, steps, rank, local_rank, host_threads, host_frames,
+                 profile, barrier, ncpu, hostprof=False):
+    """One front-end throughput measurement: B independent synthetic streams in G free-running groups, raw frames resident in HBM,
+    `prime` untimed frames per stream in setup, `warmup` untimed steps, EXACTLY `steps` timed lock-step frames per stream."""
+    cam = H.camera_for(w, h)
+    sb = H.StreamBatch(H.HOST_LIB, B, w, h, cam, max_features=nfeat, window=window, device=local_rank, host_threads=host_threads, groups=G)
+    scene = H.SynthScene(sb.lib, w, h, cam, tex_size=2048, threads=max(1, min(16, ncpu)))
+    ctxh = C.c_void_p(sb.ctx_handle(0))
+    ctx_all = [C.c_void_p(sb.ctx_handle(g)) for g in range(sb.n_groups())]
+    pinned, dev_ptrs = [], []
+
+    def dev_upload(img):
+        if host_frames:
+            t = torch.from_numpy(img).pin_memory()
+            pinned.append(t)
+            return t.data_ptr()
+        p = C.c_void_p()
+        assert hip.icg_dev_alloc(ctxh, C.c_size_t(img.nbytes), C.byref(p)) == 0
+        assert hip.icg_dev_upload(ctxh, p, img.ctypes.data_as(C.c_void_p), C.c_size_t(img.nbytes)) == 0
+        dev_ptrs.append(p)
+        return p.value
+
+    t_setup = time.time()
+    sids = sharding.shard_stream_ids(rank, 0, B)
+    dev, host0 = [], []
+    for s in range(B):
         ptrs = []
-        for k in range(n_ring):
-            img = scene.render(k, stream=sid)
+        for k in range(ring):
+            img = scene.render(k, stream=sids[s])
             if s == 0:
                 host0.append(img)
-            ptrs.append(ctx_dev_upload(img))
+            ptrs.append(dev_upload(img))
         dev.append(ptrs)
-    return dev, host0
+    poses = [[H.pose12(*scene.ins_pose(k, stream=rank * B + s)) for k in range(ring)] for s in range(B)]
+    t_setup = time.time() - t_setup
+
+    def prepare_steps(k0, K):
+        """argument arrays for K lock-step frames (built OUTSIDE the timed region: they are the resident inputs)"""
+        fs = [H.pingpong(k0 + j, ring) for j in range(K)]
+        flat = [dev[s][f] for f in fs for s in range(B)]
+        ptrs = (C.c_void_p * (K * B))(*flat)
+        P = np.ascontiguousarray(np.stack([np.stack([poses[s][f] for s in range(B)]) for f in fs]), np.float64)
+        stamps = np.ascontiguousarray(np.stack([np.full(B, 1000.0 + (k0 + j) / 20.0) for j in range(K)]), np.float64)
+        states = np.zeros((K, B), np.int32)
+        return ptrs, stamps, P, states
+
+    def run_prepared(K, prep):
+        ptrs, stamps, P, states = prep
+        rc = sb.lib.icgh_batch_run(C.c_void_p(sb.h_), K, ptrs, w, 1, 0 if host_frames else 1, stamps.ctypes.data_as(C.c_void_p),
+                                   P.ctypes.data_as(C.c_void_p), states.ctypes.data_as(C.c_void_p), sb._err, 512)
+        if rc != 0:
+            raise RuntimeError("icgh_batch_run failed: " + sb._err.value.decode())
+        return states
+
+    k = 0
+    t_prime = time.time()
+    if prime > 0:
+        run_prepared(prime, prepare_steps(k, prime))
+        k += prime
+    t_prime = time.time() - t_prime
+    if warmup > 0:
+        run_prepared(warmup, prepare_steps(k, warmup))
+        k += warmup
+    prep = prepare_steps(k, steps)
+    barrier()
+    sb.timing(reset=True)
+    sb.step_log(reset=True)
+    t_region0 = sb.now()
+    if hostprof:
+        _hp = np.zeros(64, np.float64)
+        sb.lib.icgh_hostprof(_hp.ctypes.data_as(C.c_void_p), 32, None, 0, 1)
+    tracked_before = sum(sb.stats(s)["tracked_sum"] for s in range(B))
+    c0 = time.process_time()
+    t0 = time.perf_counter()
+    st = run_prepared(steps, prep)  # EXACTLY `steps` lock-step frames for every stream
+    k += steps
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    cpu_cores_used = (time.process_time() - c0) / elapsed  # host cores busy during the timed region (all threads)
+    states_hist = np.bincount(st.ravel(), minlength=5).astype(np.int64)
+    if hostprof and rank == 0:  # diagnostic: host-layer section timers, us per frame, to stderr
+        _nm = C.create_string_buffer(1024)
+        _n = sb.lib.icgh_hostprof(_hp.ctypes.data_as(C.c_void_p), 32, _nm, 1024, 0)
+        for _k, _name in enumerate(_nm.value.decode().split(";")[:_n]):
+            print(f"[hostprof] {_name:16s} {1e6 * _hp[2 * _k] / (B * steps):9.2f} us/frame  calls/frame "
+                  f"{_hp[2 * _k + 1] / (B * steps):.3f}", file=sys.stderr)
+    tg = sb.timing_groups().sum(1) * 1e3 / steps  # per-group in-step wall time, ms per step
+    # per-step series: step k of the job ends when the slowest group has finished its k-th frame set
+    logs = sb.step_log(reset=True)
+    step_stats = None
+    if logs and all(len(l) == steps for l in logs):
+        ends = np.stack([l[:, 0] for l in logs])                        # (groups, steps)
+        job_ms = np.diff(np.concatenate([[t_region0], ends.max(0)])) * 1e3  # wall time between consecutive job-step completions
+        grp_ms = np.diff(np.concatenate([np.full((len(logs), 1), t_region0), ends], 1), axis=1) * 1e3
+        host_ms = np.stack([l[:, 1] for l in logs]).mean(0) * 1e3
+        step_stats = {"job_step_ms": {"median": round(float(np.median(job_ms)), 4), "p95": round(float(np.percentile(job_ms, 95)), 4),
+                                      "series": [round(float(v), 3) for v in job_ms]},
+                      "group_step_ms": {"median": round(float(np.median(grp_ms)), 4), "p95": round(float(np.percentile(grp_ms, 95)), 4),
+                                        "note": "one group's wall time for one frame of each of its streams; groups run free of each other"},
+                      "host_logic_ms_series": [round(float(v), 3) for v in host_ms]}
+    host_breakdown = {kk: round(1e3 * v / steps, 4) for kk, v in sb.timing().items()}
+    host_breakdown["cpu_cores_busy"] = round(cpu_cores_used, 2)
+    host_breakdown["group_step_ms_min_mean_max"] = [round(float(tg.min()), 3), round(float(tg.mean()), 3), round(float(tg.max()), 3)]
+    barrier()
+    stats = [sb.stats(s) for s in range(B)]
+    tracked = sum(s_["tracked_sum"] for s_ in stats) - tracked_before
+
+    # ---- profiled pass (HIP events on the ABI streams) ---------------------------------------------------------------------
+    kernel_table, work = {}, None
+    if profile:
+        for c in ctx_all:
+            hip.icg_prof_enable(c, 1)
+        nprof = min(20, max(8, steps // 2))
+        sb.counters(reset=True)
+        run_prepared(nprof, prepare_steps(k, nprof))  # same free-running groups as the timed region, HIP events on
+        k += nprof
+        torch.cuda.synchronize()
+        work = sb.counters(reset=True)
+        for c in ctx_all:
+            names = C.create_string_buffer(4096)
+            hip.icg_prof_names(c, names, 4096)
+            for name in names.value.decode().split("\n"):
+                if not name:
+                    continue
+                n, ms = C.c_int(), C.c_double()
+                hip.icg_prof_get(c, name.encode(), C.byref(n), C.byref(ms))
+                e = kernel_table.setdefault(name, {"launches": 0, "total_ms": 0.0})
+                e["launches"] += n.value
+                e["total_ms"] += ms.value
+            hip.icg_prof_enable(c, 0)
+        for e in kernel_table.values():
+            e["avg_us"] = round(1e3 * e["total_ms"] / max(1, e["launches"]), 3)
+            e["total_ms"] = round(e["total_ms"], 4)
+    n_groups = sb.n_groups()
+    sb.close()
+    for p in dev_ptrs:
+        hip.icg_dev_free(ctxh, p)
+    return {"elapsed": elapsed, "states_hist": states_hist, "tracked": tracked, "stats": stats, "step_stats": step_stats,
+            "host_breakdown": host_breakdown, "kernel_table": kernel_table, "work": work, "n_groups": n_groups, "setup_s": t_setup,
+            "prime_s": t_prime, "host0": host0, "poses0": poses[0], "cam": cam}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200,
-                    help="timed lock-step frames per stream (default 200: ~1 s timed region; 40 steps gave +-5 %% run-to-run noise)")
+                    help="timed lock-step frames per stream (default 200: ~1 s timed region)")
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--prime", type=int, default=int(os.environ.get("ICG_BENCH_PRIME", "48")),
                     help="untimed frames per stream run during SETUP, before the warm-up steps: every stream leaves the start-up phase of "
@@ -120,9 +300,10 @@ def main():
     ap.add_argument("--host-threads", type=int, default=1, help="host threads inside each group")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("ICG_BENCH_GROUPS", "0")),
                     help="stream groups per GPU (own HIP stream + host thread each); 0 = sized to the host cores this rank "
-                         "may use: 2 per core, at most 32, at least 8")
+                         "may use: 2 per core, at most 32, at least 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-reproj", action="store_true")
+    ap.add_argument("--no-reproj", action="store_true", help="skip the back-end / next-row blocks (reproj, ins, solve, marg, cull, replay, c4)")
+    ap.add_argument("--no-c4", action="store_true", help="skip the timed C4 block (1920x1080 / 500 features / 15-keyframe window)")
     ap.add_argument("--host-frames", action="store_true",
                     help="diagnostic: frames stay in pinned host memory and are uploaded inside the timed region (the PCIe-inclusive "
                          "rate quoted in DESIGN.md; never the contract's value)")
@@ -146,195 +327,80 @@ def main():
     ncpu = os.cpu_count() or 1
     host_threads = max(1, args.host_threads)
     cores_rank = usable_host_cores() / float(world)
-    G = args.groups if args.groups > 0 else int(max(8, min(32, 2 * round(cores_rank))))
+    # one polling host thread per group: 2 groups per usable core of this rank (a group sleeps while its kernels run), never more
+    # threads than that — with 2 cores per rank 8 pollers would only fight each other
+    G = args.groups if args.groups > 0 else int(max(2, min(32, 2 * round(cores_rank))))
     B = args.streams if args.streams > 0 else 8 * G
     G = max(1, min(G, B))
-    cam = H.camera_for(w, h)
-    sb = H.StreamBatch(H.HOST_LIB, B, w, h, cam, max_features=nfeat, window=10, device=local_rank, host_threads=host_threads,
-                       groups=G)
-    scene = H.SynthScene(sb.lib, w, h, cam, tex_size=2048, threads=max(1, min(16, ncpu)))
-
-    # raw frames resident in HBM (uploaded through the ABI's plain device-memory helpers)
     hip = icgvins.load_library()
-    ctxh = C.c_void_p(sb.ctx_handle(0))
-    ctx_all = [C.c_void_p(sb.ctx_handle(g)) for g in range(sb.n_groups())]
-
-    pinned = []  # keeps the pinned host frames of --host-frames alive
-
-    def dev_upload(img):
-        if args.host_frames:
-            t = torch.from_numpy(img).pin_memory()
-            pinned.append(t)
-            return t.data_ptr()
-        p = C.c_void_p()
-        rc = hip.icg_dev_alloc(ctxh, C.c_size_t(img.nbytes), C.byref(p))
-        assert rc == 0
-        rc = hip.icg_dev_upload(ctxh, p, img.ctypes.data_as(C.c_void_p), C.c_size_t(img.nbytes))
-        assert rc == 0
-        return p.value
-
-    t_setup = time.time()
-    dev, host0 = build_streams(sb, scene, B, args.ring, rank, dev_upload)
-    poses = [[H.pose12(*scene.ins_pose(k, stream=rank * B + s)) for k in range(args.ring)] for s in range(B)]
-    t_setup = time.time() - t_setup
-
-    def run_step(k):
-        f = H.pingpong(k, args.ring)
-        ptrs = [dev[s][f] for s in range(B)]
-        P = np.stack([poses[s][f] for s in range(B)])
-        return sb.step(ptrs, w, np.full(B, 1000.0 + k / 20.0), P, on_device=not args.host_frames)
+    hbm_peak_measured = measure_hbm_peak(torch, torch.device("cuda", local_rank)) if rank == 0 else None
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    def prepare_steps(k0, K):
-        """argument arrays for K lock-step frames (built OUTSIDE the timed region: they are the resident inputs)"""
-        fs = [H.pingpong(k0 + j, args.ring) for j in range(K)]
-        flat = [dev[s][f] for f in fs for s in range(B)]
-        ptrs = (C.c_void_p * (K * B))(*flat)
-        P = np.ascontiguousarray(np.stack([np.stack([poses[s][f] for s in range(B)]) for f in fs]), np.float64)
-        stamps = np.ascontiguousarray(np.stack([np.full(B, 1000.0 + (k0 + j) / 20.0) for j in range(K)]), np.float64)
-        states = np.zeros((K, B), np.int32)
-        return ptrs, stamps, P, states
-
-    def run_prepared(K, prep):
-        ptrs, stamps, P, states = prep
-        rc = sb.lib.icgh_batch_run(C.c_void_p(sb.h_), K, ptrs, w, 1, 0 if args.host_frames else 1, stamps.ctypes.data_as(C.c_void_p), P.ctypes.data_as(C.c_void_p),
-                                   states.ctypes.data_as(C.c_void_p), sb._err, 512)
-        if rc != 0:
-            raise RuntimeError("icgh_batch_run failed: " + sb._err.value.decode())
-        return states
-
-    k = 0
-    t_prime = time.time()
-    if args.prime > 0:
-        run_prepared(args.prime, prepare_steps(k, args.prime))
-        k += args.prime
-    t_prime = time.time() - t_prime
-    if args.warmup > 0:
-        run_prepared(args.warmup, prepare_steps(k, args.warmup))
-        k += args.warmup
-    prep = prepare_steps(k, args.steps)
-    barrier()
-    sb.timing(reset=True)
-    sb.step_log(reset=True)
-    t_region0 = sb.now()
-    if os.environ.get("ICG_HOST_PROF"):
-        _hp = np.zeros(64, np.float64)
-        sb.lib.icgh_hostprof(_hp.ctypes.data_as(C.c_void_p), 32, None, 0, 1)
-    tracked_before = sum(sb.stats(s)["tracked_sum"] for s in range(B))
-    c0 = time.process_time()
-    t0 = time.perf_counter()
-    st = run_prepared(args.steps, prep)  # EXACTLY args.steps lock-step frames for every stream
-    k += args.steps
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    cpu_cores_used = (time.process_time() - c0) / elapsed  # host cores busy during the timed region (all threads)
-    states_hist = np.bincount(st.ravel(), minlength=5).astype(np.int64)
-    if os.environ.get("ICG_HOST_PROF") and rank == 0:  # diagnostic: host-layer section timers, us per frame, to stderr
-        _nm = C.create_string_buffer(1024)
-        _n = sb.lib.icgh_hostprof(_hp.ctypes.data_as(C.c_void_p), 32, _nm, 1024, 0)
-        for _k, _name in enumerate(_nm.value.decode().split(";")[:_n]):
-            print(f"[hostprof] {_name:16s} {1e6 * _hp[2 * _k] / (B * args.steps):9.2f} us/frame  calls/frame "
-                  f"{_hp[2 * _k + 1] / (B * args.steps):.3f}", file=sys.stderr)
-    tg = sb.timing_groups().sum(1) * 1e3 / args.steps  # per-group in-step wall time, ms per step
-    # per-step series: step k of the job ends when the slowest group has finished its k-th frame set
-    logs = sb.step_log(reset=True)
-    step_stats = None
-    if logs and all(len(l) == args.steps for l in logs):
-        ends = np.stack([l[:, 0] for l in logs])                      # (groups, steps)
-        job_end = ends.max(0)
-        job_ms = np.diff(np.concatenate([[t_region0], job_end])) * 1e3  # wall time between consecutive job-step completions
-        grp_ms = np.diff(np.concatenate([np.full((len(logs), 1), t_region0), ends], 1), axis=1) * 1e3
-        host_ms = np.stack([l[:, 1] for l in logs]).mean(0) * 1e3
-        step_stats = {"job_step_ms": {"median": round(float(np.median(job_ms)), 4), "p95": round(float(np.percentile(job_ms, 95)), 4),
-                                      "series": [round(float(v), 3) for v in job_ms]},
-                      "group_step_ms": {"median": round(float(np.median(grp_ms)), 4), "p95": round(float(np.percentile(grp_ms, 95)), 4),
-                                        "note": "one group's wall time for one frame of each of its streams; groups run free of each other"},
-                      "host_logic_ms_series": [round(float(v), 3) for v in host_ms]}
-    host_breakdown = {k: round(1e3 * v / args.steps, 4) for k, v in sb.timing().items()}
-    host_breakdown["cpu_cores_busy"] = round(cpu_cores_used, 2)
-    host_breakdown["group_step_ms_min_mean_max"] = [round(float(tg.min()), 3), round(float(tg.mean()), 3), round(float(tg.max()), 3)]
-    barrier()
+    fe = run_frontend(torch, hip, w=w, h=h, nfeat=nfeat, window=10, B=B, G=G, ring=args.ring, prime=args.prime, warmup=args.warmup,
+                      steps=args.steps, rank=rank, local_rank=local_rank, host_threads=host_threads, host_frames=args.host_frames,
+                      profile=(rank == 0 and not args.no_profile_pass), barrier=barrier, ncpu=ncpu,
+                      hostprof=bool(os.environ.get("ICG_HOST_PROF")))
+    elapsed, states_hist, stats = fe["elapsed"], fe["states_hist"], fe["stats"]
+    host0, poses0, cam = fe["host0"], fe["poses0"], fe["cam"]
+    t_setup, t_prime = fe["setup_s"], fe["prime_s"]
+    step_stats, host_breakdown, kernel_table = fe["step_stats"], fe["host_breakdown"], fe["kernel_table"]
 
     # terminal exchange (SURVEY.md §8(e)): max elapsed, summed counters, gathered digests
-    stats = [sb.stats(s) for s in range(B)]
     if os.environ.get("ICG_BENCH_DEBUG") and rank == 0:  # diagnostic: per-stream totals since creation, to stderr
         for si, s_ in enumerate(stats):
             print(f"[stream {si}] frames {s_['frames']} keyframes {s_['keyframes']} tracked/frame "
                   f"{s_['tracked_sum'] / max(1, s_['frames']):.1f} landmarks {s_['landmarks']} last_state {s_['last_state']}",
                   file=sys.stderr)
-    tracked = sum(s["tracked_sum"] for s in stats) - tracked_before
     (total_frames, total_tracked, total_tracking_states), elapsed_max, all_digests = sharding.terminal_exchange(
-        dist, "cuda", [B * args.steps, tracked, states_hist[2]], elapsed, [s["digest"] for s in stats])
+        dist, "cuda", [B * args.steps, fe["tracked"], states_hist[2]], elapsed, [s["digest"] for s in stats])
     fps = total_frames / elapsed_max
 
-    # ---- profiled pass (HIP events on the ABI stream) for the roofline of the dominant kernel -------------------------
+    # ---- roofline of the dominant image kernel (HIP events of the profiled pass) -----------------------------------------------
     roofline = None
-    kernel_table = {}
-    if rank == 0 and not args.no_profile_pass:
-        for c in ctx_all:
-            hip.icg_prof_enable(c, 1)
-        nprof = min(20, max(8, args.steps // 2))
-        sb.counters(reset=True)
-        run_prepared(nprof, prepare_steps(k, nprof))  # same free-running groups as the timed region, HIP events on
-        k += nprof
-        torch.cuda.synchronize()
-        work = sb.counters(reset=True)
-        for c in ctx_all:
-            names = C.create_string_buffer(4096)
-            hip.icg_prof_names(c, names, 4096)
-            for name in names.value.decode().split("\n"):
-                if not name:
-                    continue
-                n, ms = C.c_int(), C.c_double()
-                hip.icg_prof_get(c, name.encode(), C.byref(n), C.byref(ms))
-                e = kernel_table.setdefault(name, {"launches": 0, "total_ms": 0.0})
-                e["launches"] += n.value
-                e["total_ms"] += ms.value
-            hip.icg_prof_enable(c, 0)
-        for e in kernel_table.values():
-            e["avg_us"] = round(1e3 * e["total_ms"] / max(1, e["launches"]), 3)
-            e["total_ms"] = round(e["total_ms"], 4)
-        if kernel_table:
-            # Dominant kernel = largest summed HIP-event time among the kernels that move image data.  (With 32 stream
-            # groups in flight an event pair also spans the wait for the hardware queue, so the <=2-wave RANSAC solver
-            # fm_seven_point shows a long summed time although it issues 0.1% of the instructions — profiles/r01_*.)
-            per_launch_streams = B / float(len(ctx_all))  # each group launches for its own streams
-            modelled = [kk for kk in kernel_table if algorithmic_bytes(kk, w, h, per_launch_streams, 1.0) is not None]
-            dom = max(modelled or list(kernel_table), key=lambda kk: kernel_table[kk]["total_ms"])
-            avg_s = kernel_table[dom]["avg_us"] * 1e-6
-            pts = work["lk_points"] / max(1, work["lk_calls"])  # exact: points handed to icg_lk_track_fb per call
-            ab = algorithmic_bytes(dom, w, h, per_launch_streams, pts)
-            if ab is not None and avg_s > 0:
-                ach = ab / avg_s / 1e9
-                roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-                            "algorithmic_bytes_per_launch": int(ab), "avg_launch_us": kernel_table[dom]["avg_us"],
-                            "units_per_launch": round(pts, 1) if dom == "lk_track_fb" else per_launch_streams,
-                            "launch_concurrency": "launches of %d stream groups overlap on the GPU; avg_launch_us is the "
-                                                  "HIP-event duration of one launch while the others run" % len(ctx_all)}
-                # HBM traffic of the same kernel from the committed rocprofv3 --pmc passes (profiles/collect.sh):
-                # bytes per unit x the units of one launch here
-                pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-                if os.path.exists(pmc_path):
-                    pmc = json.load(open(pmc_path)).get("k_" + dom)
-                    if pmc and "hbm_bytes_per_launch" in pmc and dom == "lk_track_fb":
-                        per_point = pmc["hbm_bytes_per_launch"] / (pmc["grid_threads"] / 64.0)
-                        roofline["traffic"] = int(per_point * pts)
-                        roofline["traffic_source"] = ("profiles/r01_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) per point "
-                                                      "x points per launch (gfx950 correction of MI355X_MICROARCH.md)")
-                if dom == "lk_track_fb":
-                    roofline["note"] = ("LK keeps its working set in LDS/VGPRs by design (8.5 KB of image per point, ~10k VALU "
-                                        "instructions on it): it is instruction-issue bound (rocprofv3 SQ_ACTIVE_INST_ANY ~89% "
-                                        "of SIMD cycles, profiles/r01_lk_pmc.md), not HBM bound")
-            else:
-                roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                            "traffic": None}
-
-    sb.close()
+    if rank == 0 and kernel_table:
+        work = fe["work"]
+        # Dominant kernel = largest summed HIP-event time among the kernels that move image data.  (With 32 stream
+        # groups in flight an event pair also spans the wait for the hardware queue, so the <=2-wave RANSAC solver
+        # fm_seven_point shows a long summed time although it issues 0.1% of the instructions — profiles/.)
+        per_launch_streams = B / float(fe["n_groups"])  # each group launches for its own streams
+        modelled = [kk for kk in kernel_table if algorithmic_bytes(kk, w, h, per_launch_streams, 1.0) is not None]
+        dom = max(modelled or list(kernel_table), key=lambda kk: kernel_table[kk]["total_ms"])
+        avg_s = kernel_table[dom]["avg_us"] * 1e-6
+        pts = work["lk_points"] / max(1, work["lk_calls"])  # exact: points handed to icg_lk_track_fb per call
+        ab = algorithmic_bytes(dom, w, h, per_launch_streams, pts)
+        if ab is not None and avg_s > 0:
+            ach = ab / avg_s / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "peak_measured": round(hbm_peak_measured, 1), "frac_of_measured_peak": round(ach / hbm_peak_measured, 5),
+                        "peak_measured_how": "device-to-device copy of 1 GiB on this box (read + write bytes / HIP-event time)",
+                        "algorithmic_bytes_per_launch": int(ab), "avg_launch_us": kernel_table[dom]["avg_us"],
+                        "units_per_launch": round(pts, 1) if dom == "lk_track_fb" else per_launch_streams,
+                        "launch_concurrency": "launches of %d stream groups overlap on the GPU; avg_launch_us is the "
+                                              "HIP-event duration of one launch while the others run" % fe["n_groups"]}
+            # HBM traffic and issue utilisation of the same kernel from the committed rocprofv3 --pmc passes of THIS configuration
+            # (profiles/collect.sh runs bench.py with the default streams/groups): per unit x the units of one launch here
+            pmc, pmc_file = committed_pmc("k_" + dom)
+            if pmc and "hbm_bytes_per_launch" in pmc and dom == "lk_track_fb":
+                per_point = pmc["hbm_bytes_per_launch"] / (pmc["grid_threads"] / 64.0)
+                roofline["traffic"] = int(per_point * pts)
+                roofline["traffic_source"] = (f"profiles/{pmc_file}: (2*FETCH_SIZE + WRITE_SIZE) per point x points per launch "
+                                              "(gfx950 correction of MI355X_MICROARCH.md)")
+            if pmc and pmc.get("SQ_BUSY_CYCLES") and pmc.get("SQ_ACTIVE_INST_ANY"):
+                # SQ_ACTIVE_INST_ANY counts cycles (x4, per SIMD quad) in which a wave of the SIMD issued; SQ_BUSY_CYCLES the busy cycles
+                roofline["issue_frac"] = round(pmc["SQ_ACTIVE_INST_ANY"] / max(1.0, pmc.get("SQ_WAVE_CYCLES", 0.0) or 1.0), 4) \
+                    if pmc.get("SQ_WAVE_CYCLES") else None
+                roofline["issue_frac_how"] = f"profiles/{pmc_file}: SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of k_{dom} (share of its wave-cycles in which an instruction issued)"
+            if dom == "lk_track_fb":
+                roofline["note"] = ("LK keeps its working set in LDS/VGPRs by design (8.5 KB of image per point, ~10k VALU "
+                                    "instructions on it): it is instruction-issue bound, not HBM bound (profiles/)")
+        else:
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                        "traffic": None}
 
     # ---- back-end: reprojection residual+Jacobian evaluations/s (R1) --------------------------------------------------
     reproj = None
@@ -590,50 +656,108 @@ def main():
             replay = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- CPU baseline of the front-end: same host layer on the CPU restatement (kind "port") ---------------------------
+    # The restatement is scalar C++ (one pixel at a time, exact-integer formulations): it is NOT OpenCV, whose LK / CLAHE / GFTT are
+    # SIMD + parallel_for_ and likely several times faster per core.  Timed on the -O3 -march=native build made on this box.
+    def cpu_frontend(lib_path, cw, ch, cfeat, cwin, frames, pose_rows, n_streams, nwarm, ntime):
+        """n_streams independent copies of one stream on the oracle-backed host layer, one thread (group) per stream"""
+        ring_c = len(frames)
+        sbc = H.StreamBatch(lib_path, n_streams, cw, ch, H.camera_for(cw, ch), max_features=cfeat, window=cwin, groups=n_streams)
+
+        def run(k0, n):
+            ptrs = [[frames[H.pingpong(k0 + i, ring_c)].ctypes.data] * n_streams for i in range(n)]
+            st = [[1000.0 + (k0 + i) / 20.0] * n_streams for i in range(n)]
+            ps = np.stack([np.repeat(pose_rows[H.pingpong(k0 + i, ring_c)][None], n_streams, 0) for i in range(n)])
+            sbc.run(ptrs, cw, st, ps)
+
+        run(0, nwarm)
+        t1 = time.perf_counter()
+        run(nwarm, ntime)
+        dt = time.perf_counter() - t1
+        sbc.close()
+        return n_streams * ntime / dt
+
     cpu_baseline = None
     cpu_baseline_allcores = None
+    c1 = None
+    timing_lib, timing_flags = (None, None)
     if rank == 0 and not args.no_cpu_baseline:
-        from stream_utils import ensure_oracle_host
-        lib = ensure_oracle_host()
-        sbc = H.StreamBatch(lib, 1, w, h, cam, max_features=nfeat, window=10)
+        timing_lib, timing_flags = ensure_timing_oracle()
+        cpu_name = cpu_model()
         nwarm, ntime = 30, 30
-        kk = 0
-        for _ in range(nwarm):
-            f = H.pingpong(kk, args.ring)
-            sbc.step([host0[f].ctypes.data], w, [1000.0 + kk / 20.0], poses[0][f])
-            kk += 1
-        t1 = time.perf_counter()
-        for _ in range(ntime):
-            f = H.pingpong(kk, args.ring)
-            sbc.step([host0[f].ctypes.data], w, [1000.0 + kk / 20.0], poses[0][f])
-            kk += 1
-        dt = time.perf_counter() - t1
-        cpu_baseline = {"value": round(ntime / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+        v = cpu_frontend(timing_lib, w, h, nfeat, 10, host0, poses0, 1, nwarm, ntime)
+        cpu_baseline = {"value": round(v, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                         "sample": f"1 stream x {ntime} steady-state frames {w}x{h}/{nfeat} feats after {nwarm} warm-up frames, "
-                                  f"oracle-backed host layer, single thread ({ncpu} host cores available)"}
-        sbc.close()
-
-        # (b) all usable host cores: the same oracle-backed host layer with one independent stream per core, every
-        # stream on its own executor thread (stream-level parallelism, the decomposition the GPU path itself is filled with)
+                                  f"oracle-backed host layer ({timing_flags}), single thread on {cpu_name} ({ncpu} logical CPUs visible, "
+                                  f"{usable_host_cores():.0f} usable); a scalar restatement of the OpenCV algorithms, not OpenCV itself"}
+        # (b) all usable host cores (SURVEY.md 8(d)): one independent stream per core, every stream on its own executor thread
+        # (stream-level parallelism, the decomposition the GPU path itself is filled with)
         T = int(max(1, min(32, usable_host_cores())))
         if T > 1:
-            sbm = H.StreamBatch(lib, T, w, h, cam, max_features=nfeat, window=10, groups=T)
-            nwarm, ntime = 30, 30
-
-            def cpu_run(k0, n):
-                ptrs = [[host0[H.pingpong(k0 + i, args.ring)].ctypes.data] * T for i in range(n)]
-                st = [[1000.0 + (k0 + i) / 20.0] * T for i in range(n)]
-                ps = np.stack([np.repeat(poses[0][H.pingpong(k0 + i, args.ring)][None], T, 0) for i in range(n)])
-                sbm.run(ptrs, w, st, ps)
-
-            cpu_run(0, nwarm)
-            t1 = time.perf_counter()
-            cpu_run(nwarm, ntime)
-            dt = time.perf_counter() - t1
-            cpu_baseline_allcores = {"value": round(T * ntime / dt, 3), "unit": "frames/s", "cores": T, "kind": "port",
+            v = cpu_frontend(timing_lib, w, h, nfeat, 10, host0, poses0, T, nwarm, ntime)
+            cpu_baseline_allcores = {"value": round(v, 3), "unit": "frames/s", "cores": T, "kind": "port",
                                      "sample": f"{T} independent streams x {ntime} steady-state frames {w}x{h}/{nfeat} feats, oracle-backed host "
-                                               f"layer, one stream group (thread) per usable host core"}
-            sbm.close()
+                                               f"layer ({timing_flags}), one stream group (thread) per usable host core"}
+        # C1 (BASELINE.json configs[0]): the CPU-runnable plumbing case — one 640x480 stream, 100 features, oracle path only, no GPU
+        sc1 = H.SynthScene(C.CDLL(timing_lib), 640, 480, H.camera_for(640, 480), tex_size=2048, threads=max(1, min(16, ncpu)))
+        f1 = [sc1.render(k, stream=0) for k in range(32)]
+        p1 = [H.pose12(*sc1.ins_pose(k, stream=0)) for k in range(32)]
+        v = cpu_frontend(timing_lib, 640, 480, 100, 10, f1, p1, 1, 30, 60)
+        c1 = {"workload": "C1: 640x480 synthetic stream (KAIST-like intrinsics; urban38 is not available offline), 100 features, CPU path only",
+              "value": round(v, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+              "sample": f"1 stream x 60 steady-state frames, oracle-backed host layer ({timing_flags}), single thread"}
+
+    # ---- C4 (BASELINE.json configs[3]): 1920x1080, 500 features, 15-keyframe window + 200 Hz IMU preintegration, 1 MI355X ---------
+    c4 = None
+    if rank == 0 and not args.no_reproj and not args.no_c4:
+        c4 = {"workload": "C4: 1920x1080 synthetic streams, 500 features, 15-keyframe window (7 000 reprojection factors), 15 x 40-sample "
+                          "IMU intervals at 200 Hz, 1 MI355X"}
+        G4 = int(max(2, min(16, 2 * round(cores_rank))))
+        B4 = 4 * G4
+        f4 = run_frontend(torch, hip, w=1920, h=1080, nfeat=500, window=15, B=B4, G=G4, ring=16, prime=64, warmup=10, steps=60,
+                          rank=0, local_rank=local_rank, host_threads=1, host_frames=False, profile=False,
+                          barrier=torch.cuda.synchronize, ncpu=ncpu)
+        fps4 = B4 * 60 / f4["elapsed"]
+        tracked4 = f4["tracked"] / float(B4 * 60)
+        c4["frontend"] = {"value": round(fps4, 1), "unit": "frames/s", "streams": B4, "groups": G4, "timed_steps": 60,
+                          "ms_per_step": round(1e3 * f4["elapsed"] / 60, 3), "host_ms_per_step": f4["host_breakdown"],
+                          "job_step_ms_median_p95": [f4["step_stats"]["job_step_ms"]["median"], f4["step_stats"]["job_step_ms"]["p95"]] if f4["step_stats"] else None,
+                          "mean_tracked_mappoints_per_frame": round(tracked4, 1),
+                          "tracking_state_fraction": round(float(f4["states_hist"][2]) / (B4 * 60), 4),
+                          "algorithmic_GBps": round(fps4 * (6.640625 * 1920 * 1080 + 500 * 8 * 1060) / 1e9, 1)}
+        # 7 000-factor window evaluations (R1 with Jacobians), 64 windows per launch, outputs resident
+        import reproj_data as rd
+        win4 = rd.make_window(500, 15, seed=0)
+        nf4 = win4["obs_soa"].shape[1]
+        reps4 = 64
+        K4, L4 = win4["poses"].shape[0], win4["invdepth"].shape[0]
+        ctx4 = icgvins.Context(640, 480, n_slots=1, max_batch=1, max_points=64, max_factors=nf4 * reps4, device=local_rank)
+        ctx4.reproj_set_factors(np.tile(win4["obs_soa"], (1, reps4)), np.concatenate([win4["idx_i"] + r * K4 for r in range(reps4)]),
+                                np.concatenate([win4["idx_j"] + r * K4 for r in range(reps4)]),
+                                np.concatenate([win4["idx_lm"] + r * L4 for r in range(reps4)]))
+        pR, iR = np.tile(win4["poses"], (reps4, 1)), np.tile(win4["invdepth"], reps4)
+        for _ in range(3):
+            ctx4.reproj_eval_resident(pR, win4["ext"], iR, win4["td"], fetch=False)
+        ctx4.prof_enable(True)
+        for _ in range(20):
+            ctx4.reproj_eval_resident(pR, win4["ext"], iR, win4["td"], fetch=False)
+        n_launch, ms = ctx4.prof()["reproj_eval"]
+        ks = ms * 1e-3 / n_launch
+        c4["reproj"] = {"factors_per_window": int(nf4), "windows_per_launch": reps4, "value": round(nf4 * reps4 / ks, 1), "unit": "evals/s",
+                        "kernel_us": round(ks * 1e6, 2),
+                        "roofline": {"bound": "hbm", "achieved": round(nf4 * reps4 * 516 / ks / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(nf4 * reps4 * 516 / ks / 1e9 / HBM_PEAK_GBS, 5), "bytes_per_eval": 516}}
+        ctx4.close()
+        # 15 intervals x 40 samples of 200 Hz IMU per stream (P1), 256 streams per launch
+        import preint_data as pdz
+        c4["preint"] = pdz.bench_block(icgvins, local_rank, n_streams=256, n_intervals=15, n_samples=40,
+                                       cpu=(None if args.no_cpu_baseline else __import__("oracle_lib").load()))
+        if not args.no_cpu_baseline:
+            sc4 = H.SynthScene(C.CDLL(timing_lib), 1920, 1080, H.camera_for(1920, 1080), tex_size=2048, threads=max(1, min(16, ncpu)))
+            fr4 = [sc4.render(k, stream=0) for k in range(16)]
+            ps4 = [H.pose12(*sc4.ins_pose(k, stream=0)) for k in range(16)]
+            v = cpu_frontend(timing_lib, 1920, 1080, 500, 15, fr4, ps4, 1, 20, 12)
+            c4["frontend"]["cpu_baseline"] = {"value": round(v, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                                              "sample": f"1 stream x 12 frames after 20 warm-up frames, oracle-backed host layer ({timing_flags}), single thread"}
 
     # the REFERENCE's own tracker sources (oracle/_ref/libref_tracking.so: tracking/*.cc compiled unmodified on interface shims, its
     # OpenCV calls forwarded to the oracle primitives) on the same frames: includes the reference's call pattern (the LK pyramids
@@ -657,7 +781,7 @@ def main():
         def ref_step(kk):
             f = H.pingpong(kk, args.ring)
             img = np.ascontiguousarray(host0[f])
-            p12 = np.ascontiguousarray(poses[0][f], np.float64)
+            p12 = np.ascontiguousarray(poses0[f], np.float64)
             rl.ref_tracker_track(T, img.ctypes.data_as(C.c_void_p), w, h, w, 1, C.c_double(1000.0 + kk / 20.0), p12.ctypes.data_as(C.c_void_p))
 
         for _ in range(nwarm):
@@ -702,6 +826,9 @@ def main():
             "cull": cull,
             "marg": marg,
             "replay": replay,
+            "c1": c1,
+            "c4": c4,
+            "hbm_peak_measured_GBps": round(hbm_peak_measured, 1) if hbm_peak_measured else None,
             "kernels": kernel_table,
             "host_ms_per_step": host_breakdown,
             "step_stats": step_stats,

@@ -5,13 +5,14 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
+#include <ctime>
 
 namespace icg {
 namespace hostprof {
 
 enum Section {
     BEGIN_FRAME = 0, ON_PREPROCESS, ON_DETECT_A, ON_LK, ON_RANSAC, ON_TRIANGULATE, ON_DETECT_B, DIGEST, KEEPER,
-    DEV_PREPROCESS, DEV_DETECT, DEV_LK, DEV_RANSAC, DEV_TRIANGULATE, GATHER, SCATTER, X0, X1, X2, X3, X4, X5, X6, X7, N_SECTIONS
+    DEV_PREPROCESS, DEV_DETECT, DEV_LK, DEV_RANSAC, DEV_TRIANGULATE, GATHER, SCATTER, STEP_TOTAL, X1, X2, X3, X4, X5, X6, X7, N_SECTIONS
 };
 
 inline std::atomic<uint64_t> *ns() {
@@ -26,7 +27,18 @@ inline bool enabled() {
     static const bool on = getenv("ICG_HOST_PROF") != nullptr;
     return on;
 }
+// ICG_HOST_PROF=cpu: sections accumulate the calling thread's CPU time (what the host cores are actually spent on: a thread that
+// sleeps in a poll wait or is descheduled does not count) instead of wall time
+inline bool cpu_clock() {
+    static const bool on = getenv("ICG_HOST_PROF") != nullptr && getenv("ICG_HOST_PROF")[0] == 'c';
+    return on;
+}
 inline uint64_t now_ns() {
+    if (cpu_clock()) {
+        struct timespec ts;
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+        return (uint64_t) ts.tv_sec * 1000000000ull + (uint64_t) ts.tv_nsec;
+    }
     return (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 struct Scope {
@@ -43,7 +55,7 @@ struct Scope {
 inline const char *name(int s) {
     static const char *n[N_SECTIONS] = {"begin_frame", "on_preprocess", "on_detect_a", "on_lk", "on_ransac", "on_triangulate",
                                         "on_detect_b", "digest", "keeper", "dev_preprocess", "dev_detect", "dev_lk",
-                                        "dev_ransac", "dev_triangulate", "gather", "scatter", "x0", "x1", "x2", "x3", "x4",
+                                        "dev_ransac", "dev_triangulate", "gather", "scatter", "step_total", "x1", "x2", "x3", "x4",
                                         "x5", "x6", "x7"};
     return n[s];
 }

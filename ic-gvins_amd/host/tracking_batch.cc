@@ -220,6 +220,7 @@ static inline double now_s() {
 
 void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &states) {
     const int n = (int) streams_.size();
+    hostprof::Scope hp_total(hostprof::STEP_TOTAL);
     double t0 = now_s(), t1;
     const double log_host0 = timing[0], log_dev0 = timing[2];
     states.assign((size_t) n, TRACK_PASSED);

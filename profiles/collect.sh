@@ -6,16 +6,23 @@
 # (never --pmc together with a trace domain other than kernel dispatches; one counter group per pass)
 # Copy the summaries produced by profiles/summarize_pmc.py and the *_kernel_stats.csv into profiles/ afterwards.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -o kt -- python $R/bench.py --no-cpu-baseline > $OUT/${TAG}_kt_bench.json 2> $OUT/${TAG}_kt.err
-SHORT="--no-cpu-baseline --no-reproj --steps 6 --warmup 24 --streams 64 --groups 8 --no-profile-pass"
+# the counter passes run the BENCH CONFIGURATION (default streams / groups of this box), shortened: 24 priming + 2 warm-up + 6 timed frames per stream
+SHORT="--no-cpu-baseline --no-reproj --prime 24 --warmup 2 --steps 6 --no-profile-pass"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o p -- python $R/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o p -- python $R/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_write.err
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/${TAG}_pmc_sq -o p -- python $R/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_sq.err
-python $R/profiles/summarize_pmc.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_sq > $OUT/${TAG}_pmc_summary.json
+# k_reproj_eval (the `reproj` block's launch shape) in its own passes
+for CNT in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $CNT --output-format csv -d $OUT/${TAG}_pmc_reproj_$CNT -o p -- python $R/profiles/run_reproj_only.py > /dev/null 2> $OUT/${TAG}_pmc_reproj_$CNT.err
+done
+python $R/profiles/summarize_pmc.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_reproj_FETCH_SIZE $OUT/${TAG}_pmc_reproj_WRITE_SIZE > $OUT/${TAG}_pmc_summary.json
 find $OUT/${TAG}_kt -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
 ls -la $OUT | grep ${TAG}
+# the raw per-dispatch tables are large: keep only the summaries (gpurun merges at most 64 MiB back)
+rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_reproj_FETCH_SIZE $OUT/${TAG}_pmc_reproj_WRITE_SIZE $OUT/${TAG}_kt

@@ -31,3 +31,39 @@ def state(p=(1.0, 2.0, -0.5), rv=(0.02, -0.03, 0.4), v=(3.0, 0.2, -0.1), bg=(1e-
 def split(state16):
     """-> pose[7] (p, qxyzw), mix[9] (v, bg, ba)"""
     return state16[:7].copy(), state16[7:].copy()
+
+
+def bench_block(icgvins, device, n_streams=256, n_intervals=15, n_samples=40, cpu=None):
+    """bench.py's C4 preintegration leg: n_streams x n_intervals intervals of n_samples 200 Hz samples in ONE icg_preint_batch launch
+    (Earth variant, the more expensive one); `cpu` = an oracle_lib.Oracle to time the same interval on one host core."""
+    import time
+    base = [make_interval(n_samples + 1, seed=s) for s in range(n_intervals)]
+    imu = np.concatenate(base * n_streams)
+    off = (np.arange(n_streams * n_intervals + 1) * (n_samples + 1)).astype(np.int32)
+    s0 = np.tile(state(), (n_streams * n_intervals, 1))
+    ctx = icgvins.Context(640, 480, n_slots=1, max_batch=1, max_points=64, device=device)
+    for _ in range(2):
+        ctx.preint_batch(1, off, imu, s0, PARAMS)
+    ctx.prof_enable(True)
+    nrep = 5
+    t1 = time.perf_counter()
+    for _ in range(nrep):
+        ctx.preint_batch(1, off, imu, s0, PARAMS)
+    wall = (time.perf_counter() - t1) / nrep
+    n_launch, ms = ctx.prof()["preint"]
+    ks = ms * 1e-3 / n_launch
+    nsamp = n_streams * n_intervals * n_samples
+    out = {"metric": "preintegration samples/s (P1: PreintegrationEarth::integrationProcess + Jacobian/covariance propagation)",
+           "intervals_per_launch": n_streams * n_intervals, "samples_per_interval": n_samples, "value": round(nsamp / ks, 1), "unit": "samples/s",
+           "kernel_us": round(ks * 1e6, 1), "call_wall_us_incl_transfers": round(wall * 1e6, 1),
+           "bound": "latency: one wave per interval, strictly sequential over its samples (72 B in per sample, 15x15 J and P in LDS)"}
+    ctx.close()
+    if cpu is not None:
+        t1 = time.perf_counter()
+        nloop = 0
+        while time.perf_counter() - t1 < 2.0:
+            cpu.preint_integrate(1, base[nloop % n_intervals], state(), PARAMS)
+            nloop += 1
+        out["cpu_baseline"] = {"value": round(nloop * n_samples / (time.perf_counter() - t1), 1), "unit": "samples/s", "cores": 1, "kind": "port",
+                               "sample": f"{nloop} x one {n_samples}-sample interval, oracle (-O2), 1 thread"}
+    return out
