@@ -303,6 +303,7 @@ def main():
                          "may use: 2 per core, at most 32, at least 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproj", action="store_true", help="skip the back-end / next-row blocks (reproj, ins, solve, marg, cull, replay, c4)")
+    ap.add_argument("--no-replay", action="store_true", help="skip the estimator replay block (16 host threads of estimators; skipped under rocprofv3)")
     ap.add_argument("--no-c4", action="store_true", help="skip the timed C4 block (1920x1080 / 500 features / 15-keyframe window)")
     ap.add_argument("--host-frames", action="store_true",
                     help="diagnostic: frames stay in pinned host memory and are uploaded inside the timed region (the PCIe-inclusive "
@@ -606,7 +607,7 @@ def main():
     # ---- f2: the whole estimator (icg::GVINS through the replay harness) on one synthetic GNSS + IMU + camera sequence ------------------
     # one camera stream, so this is a latency figure (real-time factor), not the chip-filling throughput of `value`
     replay = None
-    if rank == 0 and not args.no_reproj:
+    if rank == 0 and not args.no_reproj and not args.no_replay:
         try:
             import shutil
             import tempfile

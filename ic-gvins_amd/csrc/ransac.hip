@@ -44,10 +44,9 @@ __device__ int dev_solve_cubic_real(const double c[4], double roots[3]) {
         if (disc < 0) return 0;
         double sq = sqrt(disc);
         double q  = -0.5 * (cc + (cc >= 0 ? sq : -sq));
-        double r1 = q / b, r2 = (q != 0) ? d / q : r1;
-        roots[0] = fmin(r1, r2);
-        roots[1] = fmax(r1, r2);
-        return 2;
+        roots[0]  = q / b; // cv::solveCubic's quadratic branch: x0 = q/a1, x1 = a3/q (q the larger-magnitude root of the resolvent)
+        roots[1]  = (q != 0) ? d / q : roots[0];
+        return disc > 0 ? 2 : 1;
     }
     const double p = b / a, q = cc / a, r = d / a;
     const double B = 1.0 + fmax(fabs(p), fmax(fabs(q), fabs(r)));
@@ -89,6 +88,11 @@ __device__ int dev_solve_cubic_real(const double c[4], double roots[3]) {
             j--;
         }
         roots[j + 1] = v;
+    }
+    if (n == 3) { // cv::solveCubic's order of three real roots: (smallest, largest, middle)
+        const double mid = roots[1];
+        roots[1]         = roots[2];
+        roots[2]         = mid;
     }
     return n;
 }
@@ -302,6 +306,37 @@ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) 
     return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int) lrint(num / denom);
 }
 
+// calib3d precomp.hpp haveCollinearPoints(m, 7): the last point of the subset against every pair of the earlier ones
+bool have_collinear_points(const float *pts, const int *idx) {
+    const int i = 6;
+    for (int j = 0; j < i; j++) {
+        double dx1 = pts[2 * idx[j]] - pts[2 * idx[i]];
+        double dy1 = pts[2 * idx[j] + 1] - pts[2 * idx[i] + 1];
+        for (int k = 0; k < j; k++) {
+            double dx2 = pts[2 * idx[k]] - pts[2 * idx[i]];
+            double dy2 = pts[2 * idx[k] + 1] - pts[2 * idx[i] + 1];
+            if (std::fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (std::fabs(dx1) + std::fabs(dy1) + std::fabs(dx2) + std::fabs(dy2)))
+                return true;
+        }
+    }
+    return false;
+}
+
+// RANSACPointSetRegistrator::getSubset (ptsetreg.cpp, OpenCV 4.x) with FMEstimatorCallback::checkSubset (fundam.cpp): a rejected
+// subset has consumed its RNG draws; false after 10000 rejected attempts
+bool get_subset(cv_rng &rng, int n, const float *p1, const float *p2, int idx[7]) {
+    for (int attempt = 0; attempt < 10000; attempt++) {
+        for (int i = 0; i < 7; i++) {
+            int v;
+            for (v = rng.uniform(0, n); std::find(idx, idx + i, v) != idx + i; v = rng.uniform(0, n)) {
+            }
+            idx[i] = v;
+        }
+        if (!have_collinear_points(p1, idx) && !have_collinear_points(p2, idx)) return true;
+    }
+    return false;
+}
+
 struct set_state {
     int begin, n;
     cv_rng rng{(uint64_t) -1};
@@ -358,19 +393,23 @@ extern "C" int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, c
             words += nh * 3 * f.words_per_model;
             for (int h = 0; h < nh; h++) {
                 int idx[7];
-                for (int i = 0; i < 7; i++) { // getSubset (OpenCV 4.x)
-                    int v;
-                    for (v = S.rng.uniform(0, S.n); std::find(idx, idx + i, v) != idx + i; v = S.rng.uniform(0, S.n)) {
-                    }
-                    idx[i] = v;
+                if (!get_subset(S.rng, S.n, pts1 + 2 * (size_t) S.begin, pts2 + 2 * (size_t) S.begin, idx)) {
+                    // ptsetreg.cpp run(): no valid subset -> the iterations end here (nothing found if this was the first one)
+                    S.niters = S.iter + h;
+                    nh       = h;
+                    break;
                 }
                 hyp_set.push_back((int32_t) sets.size());
                 hyp_idx.insert(hyp_idx.end(), idx, idx + 7);
             }
+            f.n_hyp = nh; // (words keeps the planned count: unused tail words are harmless)
             set_of.push_back(s);
             sets.push_back(f);
         }
         const int nh_total = (int) hyp_set.size();
+        std::vector<int32_t> h_good((size_t) nh_total * 3);
+        std::vector<unsigned long long> h_bits((size_t) words);
+        if (nh_total > 0) { // (no hypothesis at all: every active set ran out of valid subsets)
         icg_call c(ctx);
         size_t need = sizeof(fm_set) * sets.size() + sizeof(int32_t) * 8 * (size_t) nh_total + sizeof(float) * 4 * (size_t) total +
                       (size_t) nh_total * (27 * 8 + 4 + 12) + (size_t) words * 8 + 16384;
@@ -382,8 +421,6 @@ extern "C" int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, c
         const float2 *d_p1    = (const float2 *) c.in(pts1, 2 * (size_t) total);
         const float2 *d_p2    = (const float2 *) c.in(pts2, 2 * (size_t) total);
         if ((rc = c.seal())) return rc;
-        std::vector<int32_t> h_good((size_t) nh_total * 3);
-        std::vector<unsigned long long> h_bits((size_t) words);
         double *d_models  = c.out((double *) nullptr, 27 * (size_t) nh_total);
         int32_t *d_nm     = c.out((int32_t *) nullptr, (size_t) nh_total);
         int32_t *d_good   = c.out_zc(h_good.data(), (size_t) nh_total * 3);
@@ -400,6 +437,7 @@ extern "C" int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, c
         }
         ICG_HIP(ctx, hipGetLastError());
         if ((rc = c.finish())) return rc;
+        }
 
         // sequential replay of RANSACPointSetRegistrator::run over the scores (ptsetreg.cpp)
         for (size_t ls = 0; ls < sets.size(); ls++) {

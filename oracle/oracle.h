@@ -69,7 +69,9 @@ int orc_find_fundamental_ransac(int n, const float *pts1, const float *pts2, dou
                                 uint8_t *mask, double *F_out, int *iters_out);
 int orc_seven_point(const double *m1 /*7x2*/, const double *m2 /*7x2*/, double *F /*up to 3 x 9*/);
 int orc_fm_score(const double *F, int n, const float *pts1, const float *pts2, double thresh, uint8_t *mask);
-void orc_ransac_subsets(int n_points, int n_hyp, int32_t *idx_out);
+int orc_ransac_subsets(int n_points, const float *pts1, const float *pts2, int n_hyp, int32_t *idx_out);
+int orc_have_collinear_points(const float *pts, int count);
+int orc_solve_cubic(const double *coeffs4, double *roots3);
 
 // ---- triangulation (orc_triang.cc) -------------------------------------------------------------------
 void orc_triangulate_point(const double *T0 /*3x4 row-major*/, const double *T1, const double *pc0, const double *pc1,

@@ -5,8 +5,15 @@
 // Formulation fixed here (mirrored by the HIP path so that decisions agree bit-for-bit):
 //   * null space of the 7x9 system: one-sided (Hestenes) Jacobi on the 7 columns of A^T + basis completion, using only
 //     + - * / sqrt (OpenCV: JacobiSVD on the same matrix; the two-dimensional null space is basis independent);
-//   * cubic solved WITHOUT libm transcendentals (bisection on a Cauchy bracket + Newton polish + deflation), roots in
-//     ascending order (OpenCV's solveCubic uses acos/cos/cbrt which differ between host and device libm);
+//   * cubic solved WITHOUT libm transcendentals (bisection on a Cauchy bracket + Newton polish + deflation; OpenCV's solveCubic
+//     uses acos/cos/cbrt which differ between host and device libm), roots RETURNED IN cv::solveCubic's ORDER — three real roots:
+//     (smallest, largest, middle) = -2*sqrt(Q)*cos(theta/3 + {0, 2pi/3, 4pi/3}) - a1/3 with theta/3 in [0, pi/3]; the quadratic
+//     fallback: (q/a1, a3/q) with q the larger-magnitude one of (-a2 +- sqrt(disc))/2 — the order decides which of several
+//     equally-scoring models wins the strict `good > maxGood` test of RANSACPointSetRegistrator::run;
+//   * getSubset as in OpenCV 4.x ptsetreg.cpp: seven distinct indices, then FMEstimatorCallback::checkSubset (fundam.cpp) =
+//     !haveCollinearPoints(ms1, 7) && !haveCollinearPoints(ms2, 7) (calib3d precomp.hpp: the LAST point of the subset against
+//     every pair of the earlier ones, |cross| <= FLT_EPSILON * (|dx1|+|dy1|+|dx2|+|dy2|), double arithmetic on the float
+//     coordinates); a rejected subset has consumed its RNG draws and the draw is repeated (at most 10000 attempts);
 //   * scoring in double, compared as float against (float)(thresh^2), exactly as computeError/findInliers;
 //   * the best/niters recurrence is replayed sequentially, so the result equals the sequential algorithm.
 // PARITY UNPINNED (no upstream golden vectors, OpenCV absent offline).
@@ -58,7 +65,8 @@ void hestenes(double *G, int m, int n, double *V, int max_sweeps) {
     }
 }
 
-// Real roots of c0 x^3 + c1 x^2 + c2 x + c3 = 0 without transcendentals; ascending order; returns count (0..3).
+// Real roots of c0 x^3 + c1 x^2 + c2 x + c3 = 0 without transcendentals, in cv::solveCubic's order (see the header); returns
+// count (0..3).
 int solve_cubic_real(const double c[4], double roots[3]) {
     double a = c[0], b = c[1], cc = c[2], d = c[3];
     double scale = std::fmax(std::fmax(std::fabs(a), std::fabs(b)), std::fmax(std::fabs(cc), std::fabs(d)));
@@ -74,11 +82,10 @@ int solve_cubic_real(const double c[4], double roots[3]) {
         double disc = cc * cc - 4 * b * d;
         if (disc < 0) return 0;
         double sq = std::sqrt(disc);
-        double q  = -0.5 * (cc + (cc >= 0 ? sq : -sq));
-        double r1 = q / b, r2 = (q != 0) ? d / q : r1;
-        roots[0] = std::fmin(r1, r2);
-        roots[1] = std::fmax(r1, r2);
-        return 2;
+        double q  = -0.5 * (cc + (cc >= 0 ? sq : -sq)); // the larger-magnitude one of q1 = (-a2+d)/2, q2 = -(a2+d)/2
+        roots[0]  = q / b;                               // mathfuncs.cpp solveCubic: x0 = q/a1, x1 = a3/q
+        roots[1]  = (q != 0) ? d / q : roots[0];
+        return disc > 0 ? 2 : 1;
     }
     double p = b / a, q = cc / a, r = d / a; // x^3 + p x^2 + q x + r
     auto f  = [&](double x) { return ((x + p) * x + q) * x + r; };
@@ -113,6 +120,7 @@ int solve_cubic_real(const double c[4], double roots[3]) {
         roots[n++] = r2;
     }
     std::sort(roots, roots + n);
+    if (n == 3) std::swap(roots[1], roots[2]); // (smallest, largest, middle)
     return n;
 }
 
@@ -197,6 +205,42 @@ struct Rng {
     }
     int uniform(int a, int b) { return a == b ? a : (int) (next() % (unsigned) (b - a) + a); }
 };
+
+// calib3d precomp.hpp haveCollinearPoints(m, count): the last of `count` points against every pair of the earlier ones
+bool have_collinear_points(const float *pts /*count x 2*/, int count) {
+    const int i = count - 1;
+    for (int j = 0; j < i; j++) {
+        double dx1 = pts[2 * j] - pts[2 * i];
+        double dy1 = pts[2 * j + 1] - pts[2 * i + 1];
+        for (int k = 0; k < j; k++) {
+            double dx2 = pts[2 * k] - pts[2 * i];
+            double dy2 = pts[2 * k + 1] - pts[2 * i + 1];
+            if (std::fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (std::fabs(dx1) + std::fabs(dy1) + std::fabs(dx2) + std::fabs(dy2)))
+                return true;
+        }
+    }
+    return false;
+}
+
+// RANSACPointSetRegistrator::getSubset (ptsetreg.cpp, OpenCV 4.x) for modelPoints = 7 with FMEstimatorCallback::checkSubset.
+// pts1 == nullptr: no subset check (the bare index stream).  Returns false after max_attempts rejected subsets.
+bool get_subset(Rng &rng, int n, const float *pts1, const float *pts2, int idx[7], int max_attempts) {
+    for (int attempt = 0; attempt < max_attempts; attempt++) {
+        float a[14], b[14];
+        for (int i = 0; i < 7; i++) {
+            int v;
+            for (v = rng.uniform(0, n); std::find(idx, idx + i, v) != idx + i; v = rng.uniform(0, n)) {
+            }
+            idx[i] = v;
+            if (pts1) {
+                a[2 * i] = pts1[2 * v], a[2 * i + 1] = pts1[2 * v + 1];
+                b[2 * i] = pts2[2 * v], b[2 * i + 1] = pts2[2 * v + 1];
+            }
+        }
+        if (!pts1 || (!have_collinear_points(a, 7) && !have_collinear_points(b, 7))) return true;
+    }
+    return false;
+}
 
 int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
     p  = std::max(p, 0.);
@@ -292,19 +336,19 @@ int orc_fm_score(const double *F, int n, const float *pts1, const float *pts2, d
     return nz;
 }
 
-// the hypothesis index stream of RANSACPointSetRegistrator (getSubset, OpenCV 4.x): idx_out = n_hyp x 7
-void orc_ransac_subsets(int n_points, int n_hyp, int32_t *idx_out) {
+// the hypothesis index stream of RANSACPointSetRegistrator (getSubset, OpenCV 4.x): idx_out = n_hyp x 7.  pts1/pts2 (n_points x 2
+// floats, may be NULL) enable FMEstimatorCallback::checkSubset.  Returns the number of hypotheses produced (< n_hyp if getSubset gave up).
+int orc_ransac_subsets(int n_points, const float *pts1, const float *pts2, int n_hyp, int32_t *idx_out) {
     Rng rng((uint64_t) -1);
-    for (int h = 0; h < n_hyp; h++) {
-        int *idx = idx_out + 7 * h;
-        for (int i = 0; i < 7; i++) {
-            int v;
-            for (v = rng.uniform(0, n_points); std::find(idx, idx + i, v) != idx + i; v = rng.uniform(0, n_points)) {
-            }
-            idx[i] = v;
-        }
-    }
+    for (int h = 0; h < n_hyp; h++)
+        if (!get_subset(rng, n_points, pts1, pts2, idx_out + 7 * h, 10000)) return h;
+    return n_hyp;
 }
+
+// the cubic solver alone (tests pin the root order against cv::solveCubic's closed forms)
+int orc_solve_cubic(const double *coeffs4, double *roots3) { return solve_cubic_real(coeffs4, roots3); }
+
+int orc_have_collinear_points(const float *pts, int count) { return have_collinear_points(pts, count) ? 1 : 0; }
 
 // Full findFundamentalMat(FM_RANSAC). Returns 1 if a model was found. mask: n bytes (all zero on failure).
 int orc_find_fundamental_ransac(int n, const float *pts1, const float *pts2, double thresh, double conf,
@@ -322,11 +366,12 @@ int orc_find_fundamental_ransac(int n, const float *pts1, const float *pts2, dou
     int iter;
     for (iter = 0; iter < niters; iter++) {
         int idx[7];
-        for (int i = 0; i < 7; i++) {
-            int v;
-            for (v = rng.uniform(0, n); std::find(idx, idx + i, v) != idx + i; v = rng.uniform(0, n)) {
+        if (!get_subset(rng, n, pts1, pts2, idx, 10000)) { // ptsetreg.cpp run(): no valid subset -> fail on the first iteration, else stop
+            if (iter == 0) {
+                if (iters_out) *iters_out = 0;
+                return 0;
             }
-            idx[i] = v;
+            break;
         }
         double m1[14], m2[14], F[27];
         for (int i = 0; i < 7; i++) {

@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -o kt -- python $R/bench.py --no-cpu-baseline > $OUT/${TAG}_kt_bench.json 2> $OUT/${TAG}_kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -o kt -- python $R/bench.py --no-cpu-baseline --no-replay > $OUT/${TAG}_kt_bench.json 2> $OUT/${TAG}_kt.err
 # the counter passes run the BENCH CONFIGURATION (default streams / groups of this box), shortened: 24 priming + 2 warm-up + 6 timed frames per stream
 SHORT="--no-cpu-baseline --no-reproj --prime 24 --warmup 2 --steps 6 --no-profile-pass"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o p -- python $R/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_fetch.err

@@ -205,10 +205,22 @@ class Oracle:
         n = self.lib.orc_fm_score(_p(_f64(F)), pts1.shape[0], _p(pts1), _p(pts2), C.c_double(thresh), _p(mask))
         return n, mask
 
-    def ransac_subsets(self, n_points, n_hyp):
+    def ransac_subsets(self, n_points, n_hyp, pts1=None, pts2=None):
+        """hypothesis index stream of getSubset; with pts1/pts2 the FMEstimatorCallback::checkSubset rejection is applied"""
         idx = np.zeros((n_hyp, 7), np.int32)
-        self.lib.orc_ransac_subsets(n_points, n_hyp, _p(idx))
-        return idx
+        a = None if pts1 is None else _f32(pts1)
+        b = None if pts2 is None else _f32(pts2)
+        n = self.lib.orc_ransac_subsets(n_points, _p(a), _p(b), n_hyp, _p(idx))
+        return idx[:n]
+
+    def solve_cubic(self, coeffs4):
+        r = np.zeros(3)
+        n = self.lib.orc_solve_cubic(_p(_f64(coeffs4)), _p(r))
+        return r[:n]
+
+    def have_collinear_points(self, pts):
+        pts = _f32(pts)
+        return bool(self.lib.orc_have_collinear_points(_p(pts), pts.shape[0]))
 
     def fm_ransac(self, pts1, pts2, thresh=1.5, conf=0.99):
         pts1, pts2 = _f32(pts1).reshape(-1, 2), _f32(pts2).reshape(-1, 2)

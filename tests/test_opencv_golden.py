@@ -1,0 +1,87 @@
+"""Oracle (and, on a GPU box, the HIP path) against golden vectors from REAL OpenCV (tests/golden/opencv_golden.npz, produced by
+tests/golden/make_opencv_golden.py on any box that has cv2).  The build image has no OpenCV and no network, so until that file is
+committed every test here SKIPS with that reason — the skip is the visible marker that the OpenCV boundary is still unpinned
+(oracle/README.md "Deviations").  Bounds per primitive (why each is exact or toleranced) are in oracle/README.md."""
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "opencv_golden.npz")
+pytestmark = pytest.mark.skipif(not os.path.exists(GOLDEN),
+                                reason="tests/golden/opencv_golden.npz absent: run tests/golden/make_opencv_golden.py where cv2 is installed "
+                                       "(OpenCV boundary parity UNPINNED until then)")
+
+CONFIGS = ["c1", "c2", "c4"]
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(GOLDEN)
+
+
+def _inputs(tag):
+    import synth
+    w, h = {"c1": (640, 480), "c2": (1280, 720), "c4": (1920, 1080)}[tag]
+    a = synth.texture(w, h, seed=21)
+    return a, synth.shift_image(a, 3.25, -1.75), w, h
+
+
+@pytest.mark.parametrize("tag", CONFIGS)
+def test_clahe_bit_exact(oracle, G, tag):
+    a, b, _, _ = _inputs(tag)
+    assert np.array_equal(oracle.clahe(a), G[f"{tag}_clahe_a"])
+    assert np.array_equal(oracle.clahe(b), G[f"{tag}_clahe_b"])
+
+
+@pytest.mark.parametrize("tag", CONFIGS)
+def test_pyramid_bit_exact(oracle, G, tag):
+    img = G[f"{tag}_clahe_a"]
+    assert np.array_equal(img, G[f"{tag}_pyr0"])
+    for lvl in (1, 2, 3):
+        img = oracle.pyrdown(img)
+        assert np.array_equal(img, G[f"{tag}_pyr{lvl}"]), f"level {lvl}"
+
+
+@pytest.mark.parametrize("tag", CONFIGS)
+def test_lk_status_and_points(oracle, G, tag):
+    """status identical; positions within 2e-3 px: OpenCV accumulates the 441-term window sums in float (SIMD lane order), the
+    oracle in exact integers with one rounding — the two differ by float rounding of sums of ~1e6-magnitude terms"""
+    ca, cb = G[f"{tag}_clahe_a"], G[f"{tag}_clahe_b"]
+    nxt, st, err = oracle.lk_track(ca, cb, G[f"{tag}_lk_prev"], G[f"{tag}_lk_guess"])
+    exp_st = G[f"{tag}_lk_status"].astype(np.uint8)
+    flips = int((st != exp_st).sum())
+    assert flips <= max(1, len(st) // 200), f"{flips} status flips (threshold decisions at minEig / window border)"
+    ok = (st == 1) & (exp_st == 1)
+    assert np.abs(nxt[ok] - G[f"{tag}_lk_next"][ok]).max() < 2e-3
+    assert np.abs(err[ok] - G[f"{tag}_lk_err"][ok]).max() < 1e-3 * max(1.0, float(G[f"{tag}_lk_err"][ok].max()))
+
+
+@pytest.mark.parametrize("tag", CONFIGS)
+def test_undistort_points(oracle, G, tag):
+    import harness as H  # noqa: F401  (camera_for lives in the package harness)
+    w = {"c1": 640, "c2": 1280, "c4": 1920}[tag]
+    h = {"c1": 480, "c2": 720, "c4": 1080}[tag]
+    cam = H.camera_for(w, h)
+    got = oracle.undistort(cam, G[f"{tag}_undist_in"])
+    assert np.array_equal(got.view(np.uint32), G[f"{tag}_undist_out"].view(np.uint32))  # double math, one rounding to float
+
+
+@pytest.mark.parametrize("tag", CONFIGS)
+def test_gridded_detection(oracle, G, tag):
+    """corner SET, ORDER and block assignment identical; sub-pixel coordinates within 1e-3 px (OpenCV's 8u->32f getRectSubPix runs
+    an algebraically equal recurrence)"""
+    cols, rows, bw, bh, quota, min_dist = [int(v) for v in G[f"{tag}_det_grid"]]
+    ca = G[f"{tag}_clahe_a"]
+    pts, blk = oracle.detect(ca, [cols, rows, bw, bh, min_dist, quota], G[f"{tag}_det_exist"], np.full(cols * rows, quota, np.int32),
+                             cols * rows * quota)
+    assert np.array_equal(blk, G[f"{tag}_det_block"])
+    assert np.abs(pts - G[f"{tag}_det_pts"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("tag", CONFIGS)
+def test_fm_ransac_mask(oracle, G, tag):
+    """inlier mask identical: same RNG stream, same subset rejection, same root order, double scoring with float compare"""
+    ok, mask, _, _ = oracle.fm_ransac(G[f"{tag}_fm_p1"], G[f"{tag}_fm_p2"], 1.5, 0.99)
+    assert ok == 1
+    assert np.array_equal(mask, G[f"{tag}_fm_mask"])

@@ -140,6 +140,122 @@ def test_ransac_rng_stream(oracle):
     assert idx[0, 0] == (st & 0xFFFFFFFF) % 300
 
 
+def _cv_solve_cubic(c):
+    """cv::solveCubic (core/src/mathfuncs.cpp, OpenCV 4.x) restated with numpy's libm: the closed forms that define the ORDER"""
+    a0, a1, a2, a3 = [float(v) for v in c]
+    if a0 == 0:
+        if a1 == 0:
+            return [] if a2 == 0 else [-a3 / a2]
+        d = a2 * a2 - 4 * a1 * a3
+        if d < 0:
+            return []
+        d = np.sqrt(d)
+        q1, q2 = (-a2 + d) * 0.5, (a2 + d) * -0.5
+        q = q1 if abs(q1) > abs(q2) else q2
+        return [q / a1, a3 / q] if d > 0 else [q / a1]
+    a1, a2, a3 = a1 / a0, a2 / a0, a3 / a0
+    Q = (a1 * a1 - 3 * a2) / 9.0
+    R = (2 * a1 ** 3 - 9 * a1 * a2 + 27 * a3) / 54.0
+    d = Q ** 3 - R * R
+    if d > 0:
+        theta = np.arccos(R / np.sqrt(Q ** 3))
+        t0, t1, t2 = -2 * np.sqrt(Q), theta / 3.0, a1 / 3.0
+        return [t0 * np.cos(t1) - t2, t0 * np.cos(t1 + 2 * np.pi / 3) - t2, t0 * np.cos(t1 + 4 * np.pi / 3) - t2]
+    d = np.sqrt(-d)
+    e = np.cbrt(d + abs(R))
+    if R > 0:
+        e = -e
+    return [(e + Q / e) - a1 / 3.0]
+
+
+def test_cubic_roots_in_solvecubic_order(oracle):
+    """the transcendental-free solver returns the roots cv::solveCubic returns, IN ITS ORDER (three real roots: smallest, largest,
+    middle; quadratic fallback: q/a1 then a3/q) — the order decides which of equally-scoring 7-point models RANSAC keeps"""
+    rng = np.random.RandomState(5)
+    n3 = n1 = 0
+    for _ in range(400):
+        c = rng.uniform(-3, 3, 4)
+        if abs(c[0]) < 0.05:
+            continue
+        exp = _cv_solve_cubic(c)
+        got = oracle.solve_cubic(c)
+        assert len(got) == len(exp)
+        assert np.allclose(got, exp, rtol=1e-9, atol=1e-9)
+        n3 += len(exp) == 3
+        n1 += len(exp) == 1
+    assert n3 > 50 and n1 > 50
+    # explicit: (x-1)(x-2)(x-5) -> (1, 5, 2)
+    assert np.allclose(oracle.solve_cubic([1, -8, 17, -10]), [1, 5, 2], atol=1e-12)
+    # quadratic fallback (leading coefficient zero): 2x^2 - 3x - 5 -> q = 5 (the larger-magnitude one of 5, -2): (5/2, -5/5)
+    assert np.allclose(oracle.solve_cubic([0, 2, -3, -5]), _cv_solve_cubic([0, 2, -3, -5]), atol=1e-12)
+    assert np.allclose(oracle.solve_cubic([0, 2, -3, -5]), [2.5, -1.0], atol=1e-12)
+
+
+def _have_collinear(pts):
+    """calib3d precomp.hpp haveCollinearPoints(m, count): the LAST point against every pair of the earlier ones"""
+    pts = np.asarray(pts, np.float32).astype(np.float64)
+    i = len(pts) - 1
+    for j in range(i):
+        dx1, dy1 = pts[j] - pts[i]
+        for k in range(j):
+            dx2, dy2 = pts[k] - pts[i]
+            if abs(dx2 * dy1 - dy2 * dx1) <= np.finfo(np.float32).eps * (abs(dx1) + abs(dy1) + abs(dx2) + abs(dy2)):
+                return True
+    return False
+
+
+class _CvRng:
+    def __init__(self):
+        self.state = 0xFFFFFFFFFFFFFFFF
+
+    def uniform(self, a, b):
+        self.state = ((self.state & 0xFFFFFFFF) * 4164903690 + (self.state >> 32)) & 0xFFFFFFFFFFFFFFFF
+        return (self.state & 0xFFFFFFFF) % (b - a) + a
+
+
+def _get_subsets(p1, p2, n_hyp):
+    """RANSACPointSetRegistrator::getSubset (ptsetreg.cpp, 4.x) + FMEstimatorCallback::checkSubset, independent restatement"""
+    rng, n, out = _CvRng(), len(p1), []
+    for _ in range(n_hyp):
+        for _attempt in range(10000):
+            idx = []
+            for i in range(7):
+                v = rng.uniform(0, n)
+                while v in idx:
+                    v = rng.uniform(0, n)
+                idx.append(v)
+            if not _have_collinear(p1[idx]) and not _have_collinear(p2[idx]):
+                break
+        else:
+            return out
+        out.append(idx)
+    return out
+
+
+def test_ransac_check_subset_rejects_collinear_samples(oracle):
+    """FMEstimatorCallback::checkSubset: a sample whose 7th point is collinear with two earlier ones (in either image) is redrawn,
+    and the redraw consumes RNG state — pinned against an independent restatement on lattice points (many collinear triples)"""
+    gx, gy = np.meshgrid(np.arange(6, dtype=np.float32) * 40 + 100, np.arange(5, dtype=np.float32) * 40 + 80)
+    p1 = np.stack([gx.ravel(), gy.ravel()], 1)                         # 30 lattice points
+    p2 = (p1 + np.float32([3.0, -2.0])).astype(np.float32)             # collinearity is preserved in the second image
+    assert oracle.have_collinear_points(p1[[0, 7, 3, 9, 20, 11, 14]])   # (0, 7, 14) lie on the main diagonal; 14 is LAST
+    assert not oracle.have_collinear_points(p1[[0, 7, 14, 9, 20, 11, 3]])  # the same triple not ending in the last point: not tested
+    exp = _get_subsets(p1, p2, 40)
+    got = oracle.ransac_subsets(30, 40, p1, p2)
+    assert np.array_equal(got, np.array(exp, np.int32))
+    free = oracle.ransac_subsets(30, 40)
+    assert not np.array_equal(free, got)                               # rejections happened and shifted the stream
+    # generic (non-lattice) points: nothing is rejected, the stream is the unchecked one
+    rng = np.random.RandomState(1)
+    q1 = rng.uniform(50, 600, (80, 2)).astype(np.float32)
+    q2 = (q1 + rng.normal(0, 5, (80, 2))).astype(np.float32)
+    assert np.array_equal(oracle.ransac_subsets(80, 40, q1, q2), oracle.ransac_subsets(80, 40))
+    # all points on one line: every subset is rejected, findFundamentalMat fails (all-zero mask)
+    line = np.stack([np.arange(20, dtype=np.float32) * 7 + 10, np.arange(20, dtype=np.float32) * 3 + 5], 1)
+    ok, mask, _, iters = oracle.fm_ransac(line, line + np.float32(1.0))
+    assert ok == 0 and mask.sum() == 0 and iters == 0
+
+
 def test_ransac_flags_outliers(oracle):
     p1, p2, truth, _ = two_view(200, seed=2, outlier_frac=0.25, noise=0.2)
     ok, mask, F, iters = oracle.fm_ransac(p1, p2, 1.5, 0.99)
