@@ -710,6 +710,19 @@ extern "C" int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, in
     return ICG_OK;
 }
 
+extern "C" int icg_reproj_landmark_diag(icg_ctx *ctx, double *h_ll) {
+    if (!ctx || !h_ll) return ICG_ERR_INVALID;
+    if (!ctx->sys_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Schur system: call icg_reproj_schur first");
+    const int P = ctx->sys_P, L = ctx->sys_L;
+    if (L == 0) return ICG_OK;
+    const size_t N = (size_t) P + L;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    // the diagonal (P+l, P+l) of the row-major N x N matrix: one 8-byte column with a pitch of (N+1) doubles
+    ICG_HIP(ctx, hipMemcpy2DAsync(h_ll, sizeof(double), ctx->d_sys + (size_t) P * N + P, sizeof(double) * (N + 1), sizeof(double), (size_t) L,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    return icg_stream_wait(ctx);
+}
+
 extern "C" int icg_reproj_backsub(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
     if (!ctx || !delta_c || !delta_l) return ICG_ERR_INVALID;
     if (!ctx->sys_valid || ctx->sys_P != P) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Schur system of size %d: call icg_reproj_schur first", P);

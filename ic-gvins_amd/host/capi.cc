@@ -387,6 +387,8 @@ int icgh_backend_marginalize(int n, const double *obs_soa, const int32_t *idx_i,
 
 // phases of the last MarginalizationInfo::marginalization() of this process: evaluate, construct, Schur, linearize [ms]
 void icgh_backend_marginalization_phases(double *out4) { memcpy(out4, MarginalizationInfo::lastPhaseMs(), sizeof(double) * 4); }
+int icgh_backend_marginalization_structured(void) { return MarginalizationInfo::lastWasStructured() ? 1 : 0; }
+void icgh_backend_marginalization_force_dense(int on) { MarginalizationInfo::forceDense(on != 0); }
 
 // P1 (device batch) + P2 (host evaluate) through the Preintegration / PreintegrationFactor classes.
 // imu: total x 8; offsets: n+1; state0: n x 16; params9 as icg_preint_batch; pose/mix: the evaluation point per interval

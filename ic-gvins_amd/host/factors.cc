@@ -1,6 +1,7 @@
 // Host side of the back-end boundary (see factors.h for the reference lines each class mirrors).
 #include "factors.h"
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -171,6 +172,30 @@ bool ReprojectionBatch::accumulateNormal(const std::unordered_map<const double *
         error_ = icg_last_error(ctx_);
         return false;
     }
+    return true;
+}
+
+bool ReprojectionBatch::accumulateLandmarkEliminated(const std::unordered_map<const double *, int> &camera_column_of, int P, double *H,
+                                                     double *b, double *min_hll) {
+    if (factors_.empty()) return true;
+    auto col = [&](const double *p) {
+        auto it = camera_column_of.find(p);
+        return it == camera_column_of.end() ? -1 : it->second;
+    };
+    vector<int32_t> cp(pose_ptrs_.size());
+    for (size_t k = 0; k < pose_ptrs_.size(); k++) cp[k] = col(pose_ptrs_[k]);
+    vector<double> S((size_t) P * P), s((size_t) P), hll(lm_ptrs_.size());
+    int rc = icg_reproj_schur(ctx_, P, cp.data(), col(ext_), col(td_), nullptr, 1, 0.0, 0.0, 0.0, S.data(), s.data(), nullptr, nullptr);
+    if (rc == ICG_OK) rc = icg_reproj_landmark_diag(ctx_, hll.data());
+    if (rc != ICG_OK) {
+        error_ = icg_last_error(ctx_);
+        return false;
+    }
+    for (size_t k = 0; k < S.size(); k++) H[k] += S[k];
+    for (int k = 0; k < P; k++) b[(size_t) k] += s[(size_t) k];
+    double mn = hll.empty() ? 0.0 : hll[0];
+    for (double v : hll) mn = std::min(mn, v);
+    if (min_hll) *min_hll = mn;
     return true;
 }
 
@@ -386,8 +411,13 @@ void MarginalizationInfo::addResidualBlockInfo(const std::shared_ptr<ResidualBlo
 
 namespace {
 thread_local double g_marg_phase_ms[4] = {0, 0, 0, 0};
+thread_local bool g_marg_structured   = false;
+// process-wide switch (diagnostics / tests): force the reference's dense M2 + M3 even where the structured path applies
+std::atomic<int> g_marg_force_dense{getenv("ICG_MARG_DENSE") != nullptr ? 1 : 0};
 }
 const double *MarginalizationInfo::lastPhaseMs() { return g_marg_phase_ms; }
+bool MarginalizationInfo::lastWasStructured() { return g_marg_structured; }
+void MarginalizationInfo::forceDense(bool on) { g_marg_force_dense.store(on ? 1 : 0); }
 
 bool MarginalizationInfo::marginalization() { // :73-101
     if (!updateParameterBlocksIndex()) {
@@ -407,13 +437,19 @@ bool MarginalizationInfo::marginalization() { // :73-101
         return false;
     }
     auto t1 = now();
-    if (!constructEquation()) {
-        isvalid_ = false;
-        releaseMemory();
-        return false;
+    auto t2 = t1;
+    g_marg_structured = g_marg_force_dense.load() == 0 && constructAndEliminateStructured();
+    if (!g_marg_structured) {
+        if (!constructEquation()) {
+            isvalid_ = false;
+            releaseMemory();
+            return false;
+        }
+        t2 = now();
+        schurElimination();
+    } else {
+        t2 = now(); // (structured path: assembly and elimination are one step, booked under "construct")
     }
-    auto t2 = now();
-    schurElimination();
     auto t3 = now();
     linearization();
     auto t4 = now();
@@ -532,6 +568,123 @@ bool MarginalizationInfo::constructEquation() { // :195-230
         }
     }
     if (any_device && !batch_->accumulateNormal(column_of, local_size_, H0_.data(), b0_.data())) return false;
+    return true;
+}
+
+// The marginalized set of GVINS::gvinsMarginalization (ic_gvins.cc:1425-1610) is {pose, mix of the oldest state} + {the inverse depths
+// anchored in the oldest keyframe}, and an inverse depth is touched by reprojection factors only.  Hmm is then
+//     [ A   B ]   A: the few pose / mix columns (15),  D: DIAGONAL (one 1x1 block per landmark),
+//     [ B^T D ]
+// and the reference's dense pseudo-inverse of Hmm (eigen-decomposition with a 1e-8 floor, :170-181) equals the plain inverse
+// whenever Hmm is safely positive definite.  Then  Hrr - Hrm Hmm^-1 Hmr  can be taken in two exact steps: the landmark block first
+// (reciprocals of h_ll: done on the DEVICE together with the assembly, the resident f1 kernels), the small A-block second (the
+// reference's own eigen / floor procedure on 15 columns instead of 15 + L).  Guard: every h_ll and every eigenvalue of the reduced
+// A-block at least 100 x the reference's floor — otherwise this returns false and the dense path runs.
+bool MarginalizationInfo::constructAndEliminateStructured() {
+    if (!batch_ || batch_->size() == 0) return false;
+    // landmark blocks of the batch: all marginalized, size 1, and touched by batch factors only
+    std::unordered_map<long, char> is_lm;
+    for (double *p : batch_->landmarkBlocks()) {
+        const long id = idOf(p);
+        auto it = parameter_block_index_.find(id);
+        if (it == parameter_block_index_.end() || it->second >= marginalized_size_ || parameter_block_size_[id] != 1) return false;
+        is_lm[id] = 1;
+    }
+    for (const auto &factor : factors_) {
+        const bool on_batch = onBatch(factor, batch_);
+        for (double *p : factor->parameterBlocks()) {
+            const bool lm = is_lm.count(idOf(p)) != 0;
+            if (lm && !on_batch) return false; // a host factor on an inverse depth: Hmm's landmark block is not diagonal
+        }
+        if (!on_batch && dynamic_cast<ReprojectionFactor *>(factor->costFunction().get()) != nullptr) return false;
+    }
+    // compact camera columns: every non-landmark column of the local ordering, order kept (marginalized ones first)
+    const int L = local_size_;
+    vector<int> compact((size_t) L, -1);
+    {
+        vector<char> lm_col((size_t) L, 0);
+        for (const auto &kv : is_lm) lm_col[(size_t) parameter_block_index_[kv.first]] = 1;
+        int c = 0;
+        for (int k = 0; k < L; k++)
+            if (!lm_col[(size_t) k]) compact[(size_t) k] = c++;
+    }
+    const int n_lm = (int) is_lm.size();
+    const int P = L - n_lm, m = marginalized_size_ - n_lm, r = remained_size_;
+    if (m < 0 || P != m + r) return false;
+    vector<double> H((size_t) P * P, 0.0), b((size_t) P, 0.0);
+    std::unordered_map<const double *, int> camera_column_of;
+    for (const auto &factor : factors_) {
+        const auto &blocks = factor->parameterBlocks();
+        if (onBatch(factor, batch_)) {
+            for (double *p : blocks)
+                if (!is_lm.count(idOf(p))) camera_column_of[p] = compact[(size_t) parameter_block_index_[idOf(p)]];
+            continue;
+        }
+        const int nr = (int) factor->residuals().size(); // host factors: J^T J / J^T e straight into the compact system (:195-230)
+        for (size_t i = 0; i < blocks.size(); i++) {
+            const int row0 = compact[(size_t) parameter_block_index_[idOf(blocks[i])]];
+            const int gi   = parameter_block_size_[idOf(blocks[i])];
+            const int rows = localSize(gi);
+            const vector<double> &Ji = factor->jacobians()[i];
+            for (size_t j = i; j < blocks.size(); ++j) {
+                const int col0 = compact[(size_t) parameter_block_index_[idOf(blocks[j])]];
+                const int gj   = parameter_block_size_[idOf(blocks[j])];
+                const int cols = localSize(gj);
+                const vector<double> &Jj = factor->jacobians()[j];
+                for (int x = 0; x < rows; x++)
+                    for (int y = 0; y < cols; y++) {
+                        double sum = 0;
+                        for (int k = 0; k < nr; k++) sum += Ji[(size_t) k * gi + x] * Jj[(size_t) k * gj + y];
+                        H[(size_t) (row0 + x) * P + col0 + y] += sum;
+                        if (i != j) H[(size_t) (col0 + y) * P + row0 + x] = H[(size_t) (row0 + x) * P + col0 + y];
+                    }
+            }
+            for (int x = 0; x < rows; x++) {
+                double sum = 0;
+                for (int k = 0; k < nr; k++) sum += Ji[(size_t) k * gi + x] * factor->residuals()[(size_t) k];
+                b[(size_t) row0 + x] -= sum;
+            }
+        }
+    }
+    double min_hll = 0;
+    if (!batch_->accumulateLandmarkEliminated(camera_column_of, P, H.data(), b.data(), &min_hll)) return false;
+    const double GUARD = 100.0 * EPS;
+    if (!(min_hll > GUARD)) return false;
+    // second step on the m leading columns: the reference's procedure (:170-192) on the reduced system
+    vector<double> Hmm((size_t) m * m), ev, V;
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < m; j++) Hmm[(size_t) i * m + j] = 0.5 * (H[(size_t) i * P + j] + H[(size_t) j * P + i]);
+    symmetricEigen(m, Hmm, ev, V);
+    for (int k = 0; k < m; k++)
+        if (!(ev[(size_t) k] > GUARD)) return false;
+    vector<double> Hinv((size_t) m * m, 0.0), Wv((size_t) m * m);
+    for (int i = 0; i < m; i++)
+        for (int k = 0; k < m; k++) Wv[(size_t) i * m + k] = V[(size_t) i * m + k] / ev[(size_t) k];
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j <= i; j++) {
+            double sum = 0;
+            for (int k = 0; k < m; k++) sum += Wv[(size_t) i * m + k] * V[(size_t) j * m + k];
+            Hinv[(size_t) i * m + j] = Hinv[(size_t) j * m + i] = sum;
+        }
+    vector<double> T((size_t) r * m);
+    for (int i = 0; i < r; i++)
+        for (int j = 0; j < m; j++) {
+            double sum = 0;
+            for (int k = 0; k < m; k++) sum += H[(size_t) (m + i) * P + k] * Hinv[(size_t) k * m + j];
+            T[(size_t) i * m + j] = sum;
+        }
+    Hp_.assign((size_t) r * r, 0.0);
+    bp_.assign((size_t) r, 0.0);
+    for (int i = 0; i < r; i++) {
+        for (int j = 0; j < r; j++) {
+            double sum = 0;
+            for (int k = 0; k < m; k++) sum += T[(size_t) i * m + k] * H[(size_t) k * P + m + j];
+            Hp_[(size_t) i * r + j] = H[(size_t) (m + i) * P + m + j] - sum;
+        }
+        double sum = 0;
+        for (int k = 0; k < m; k++) sum += T[(size_t) i * m + k] * b[(size_t) k];
+        bp_[(size_t) i] = b[(size_t) m + i] - sum;
+    }
     return true;
 }
 

@@ -73,6 +73,12 @@ public:
     bool evaluateCorrected(double huber_delta);
     // H0 += J^T J, b0 -= J^T e of the last evaluation (marginalization_info.h:195-230); columns by parameter address
     bool accumulateNormal(const std::unordered_map<const double *, int> &column_of, int local_size, double *H0, double *b0);
+    // the same normal equations with EVERY inverse-depth block of the batch eliminated on the device (icg_reproj_schur, no damping):
+    // H (P x P, row-major) += Hcc - G^T diag(1/h_ll) G, b += bc - G^T (b_l / h_ll) in the camera columns given by parameter address
+    // (absent = constant block); min_hll = the smallest landmark diagonal (the caller's conditioning guard)
+    bool accumulateLandmarkEliminated(const std::unordered_map<const double *, int> &camera_column_of, int P, double *H, double *b,
+                                      double *min_hll);
+    const vector<double *> &landmarkBlocks() const { return lm_ptrs_; }
     const double *residual(int slot) const { return r_.data() + 2 * (size_t) slot; }
     const double *jacobian(int slot) const { return J_.data() + 46 * (size_t) slot; }
     bool prepared(bool with_jacobians) const { return prepared_ && (!with_jacobians || has_jac_); }
@@ -135,6 +141,8 @@ public:
     bool marginalization();
     // wall time of the calling thread's last marginalization(): evaluate, construct, Schur, linearize [ms] (diagnostics / bench)
     static const double *lastPhaseMs();
+    static bool lastWasStructured(); // the calling thread's last marginalization() took the landmark-eliminated (device) path
+    static void forceDense(bool on);  // process-wide: always take the reference's dense M2 + M3 (diagnostics / tests)
     vector<double *> getParamterBlocks(std::unordered_map<long, double *> &address);
     const vector<double> &linearizedJacobians() const { return linearized_jacobians_; } // remained x remained, row-major
     const vector<double> &linearizedResiduals() const { return linearized_residuals_; }
@@ -152,6 +160,10 @@ private:
     bool preMarginalization();
     bool constructEquation();
     void schurElimination();
+    // M2 + M3 in one step when the marginalized set is {a few pose / mix blocks} + {inverse depths seen only by the device batch}:
+    // the 1x1 landmark blocks are eliminated on the device, the host finishes on the small camera system.  Returns false (nothing
+    // touched) when the structure or the conditioning guard does not hold: the dense path then runs as before.
+    bool constructAndEliminateStructured();
     void linearization();
     void releaseMemory() { factors_.clear(); }
     long idOf(const double *p) { return parameters_ids_[reinterpret_cast<long>(p)]; }

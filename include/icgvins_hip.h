@@ -195,6 +195,10 @@ int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, int32_t col_e
                      double *cost);
 int icg_reproj_backsub(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms);
 int icg_reproj_cost(icg_ctx *ctx, const uint8_t *active, double *cost);
+/* h_ll (n_lm values) of the system left resident by the last icg_reproj_schur: the diagonal of the inverse-depth block BEFORE damping.
+ * M3 (factors/marginalization_info.h:170-192) uses it to decide whether the landmark block may be eliminated by plain reciprocals
+ * (all h_ll well above the reference's 1e-8 eigenvalue floor) or has to go through the dense pseudo-inverse. */
+int icg_reproj_landmark_diag(icg_ctx *ctx, double *h_ll);
 
 /* f1, many windows per launch: the windows of many camera streams advance through their LM steps together, ONE evaluation / assembly /
  * reduction / back-substitution launch per step for all of them (a solver per stream is bounded by the runtime's launch rate).

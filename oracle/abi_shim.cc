@@ -341,6 +341,14 @@ int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, int32_t col_e
     return ICG_OK;
 }
 
+int icg_reproj_landmark_diag(icg_ctx *ctx, double *h_ll) {
+    shim_backend &B = g_backend[ctx];
+    if (B.H.empty()) return ICG_ERR_INVALID;
+    const size_t N = (size_t) B.P + B.n_lm;
+    for (int l = 0; l < B.n_lm; l++) h_ll[l] = B.H[((size_t) B.P + l) * N + B.P + l];
+    return ICG_OK;
+}
+
 int icg_reproj_backsub(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
     shim_backend &B = g_backend[ctx];
     if (B.P != P || B.H.empty()) return ICG_ERR_INVALID;

@@ -235,3 +235,38 @@ def check_marginalization_golden(lib, path):
     assert np.abs(c["bp"] - g["bp"]).max() < 1e-8 * max(1.0, np.abs(g["bp"]).max())
     assert abs(c["cost"] - float(g["cost"])) < 1e-8 * max(1.0, float(g["cost"]))
     assert np.abs(c["grad"] - g["grad"]).max() < 1e-7 * max(1.0, np.abs(g["grad"]).max())
+
+
+def check_marginalization_paths(lib):
+    """M2 + M3: the landmark-eliminated path (device assembly + elimination of the 1x1 inverse-depth blocks, small host finish) against
+    the reference's dense construction + pseudo-inverse (marginalization_info.h:170-230) on the same problems: same Hp, bp, cost at
+    a perturbed point; and the conditioning guard — a landmark with (numerically) no information sends the call down the dense path."""
+    lib.icgh_backend_marginalization_structured.restype = C.c_int
+    for n_lm, n_kf, seed in ((80, 6, 2), (300, 10, 3), (40, 4, 7)):
+        P = md.make_problem(n_lm=n_lm, n_kf=n_kf, seed=seed)
+        lib.icgh_backend_marginalization_force_dense(0)
+        a = backend_marginalize(lib, P)
+        assert lib.icgh_backend_marginalization_structured() == 1
+        lib.icgh_backend_marginalization_force_dense(1)
+        b = backend_marginalize(lib, P)
+        assert lib.icgh_backend_marginalization_structured() == 0
+        lib.icgh_backend_marginalization_force_dense(0)
+        assert a["m"] == b["m"] and a["r"] == b["r"] and np.array_equal(a["ids"], b["ids"]) and np.array_equal(a["index"], b["index"])
+        scale = np.abs(b["Hp"]).max()
+        assert np.abs(a["Hp"] - b["Hp"]).max() < 1e-9 * scale, np.abs(a["Hp"] - b["Hp"]).max() / scale
+        assert np.abs(a["bp"] - b["bp"]).max() < 1e-9 * max(1.0, np.abs(b["bp"]).max())
+        # the prior itself (basis independent): J0^T J0 and J0^T e0
+        assert np.abs(a["J0"].T @ a["J0"] - b["J0"].T @ b["J0"]).max() < 1e-7 * scale
+        assert np.abs(a["J0"].T @ a["e0"] - b["J0"].T @ b["e0"]).max() < 1e-7 * max(1.0, np.abs(b["bp"]).max())
+    # guard: one landmark observed with an enormous standard deviation -> h_ll far below the floor -> dense path, same numbers as forced dense
+    P = md.make_problem(n_lm=60, n_kf=5, seed=4)
+    weak = P["ll"] == P["ll"][0]
+    obs = P["obs"].copy()
+    obs[14, weak] = 1e9  # observation row 14 = std (pixel error / focal length), see icg_reproj_set_factors
+    P2 = dict(P, obs=obs)
+    a = backend_marginalize(lib, P2)
+    assert lib.icgh_backend_marginalization_structured() == 0, "the conditioning guard did not trigger"
+    lib.icgh_backend_marginalization_force_dense(1)
+    b = backend_marginalize(lib, P2)
+    lib.icgh_backend_marginalization_force_dense(0)
+    assert np.array_equal(a["Hp"], b["Hp"]) and np.array_equal(a["bp"], b["bp"])

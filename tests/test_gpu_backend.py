@@ -22,6 +22,10 @@ def test_marginalization_pipeline(oracle):
     bu.check_marginalization(_lib(), oracle)
 
 
+def test_marginalization_structured_path_equals_dense():
+    bu.check_marginalization_paths(_lib())
+
+
 def test_preintegration_factor(oracle):
     bu.check_preintegration(_lib(), oracle)
 
