@@ -620,7 +620,7 @@ def main():
             import gvins_checks as gvc
             import gvins_data as gvd
             root = tempfile.mkdtemp(prefix="bench_replay_")
-            hostlib = C.CDLL(H.HOST_LIB)
+            hostlib = C.CDLL(H.TOOLS_LIB)  # estimator + replay harness: the tools library (links on top of the product libraries)
             seq = gvd.Sequence(hostlib)
             files = seq.write(root)
             gvc.run_replay(hostlib, files)  # first run pays context creation and first-touch costs

@@ -12,6 +12,15 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HOST_LIB = os.path.join(_HERE, "libicgvins_host.so")
+# estimator port + replay harness + scene renderer (ic-gvins_amd/tools/): NOT part of the product libraries; it links on top of them,
+# so a handle on it also resolves the product's icgh_* entry points
+TOOLS_LIB = os.path.join(_HERE, "libicgvins_tools.so")
+
+
+def tools_lib(host_lib_path):
+    """library that carries icgs_* / icgh_replay_* / icgh_nav_* for a given host library: the tools library for the product's
+    host layer, the library itself for the all-in-one oracle-backed checker build"""
+    return TOOLS_LIB if os.path.abspath(host_lib_path) == os.path.abspath(HOST_LIB) else host_lib_path
 
 TRACK_STATES = ["FIRST_FRAME", "INITIALIZING", "TRACKING", "PASSED", "LOST"]
 
@@ -35,6 +44,8 @@ class SynthScene:
     """A slanted textured wall ~20 m in front of a camera that flies past it (x right, y down, z forward)."""
 
     def __init__(self, lib, width, height, cam10, tex_size=2048, seed=7, threads=8):
+        if not hasattr(lib, "icgs_make_texture"):  # a handle on the product's host library: the renderer lives in the tools library
+            lib = C.CDLL(TOOLS_LIB)
         self.lib, self.w, self.h, self.cam = lib, width, height, np.asarray(cam10, np.float64)
         self.tex_size, self.threads = tex_size, threads
         self.tex = np.zeros((tex_size, tex_size), np.uint8)

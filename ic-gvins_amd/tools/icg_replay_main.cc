@@ -14,7 +14,7 @@
 
 #include <sys/stat.h>
 
-#include "../host/replay.h"
+#include "replay.h"
 
 static void usage() {
     fprintf(stderr, "usage: icg_replay --config gvins.yaml --imu imu.txt [--gnss gnss.txt] [--images images.txt] [--output DIR] [--imu-rate]\n"

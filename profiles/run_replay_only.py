@@ -12,7 +12,7 @@ import gvins_checks as gc  # noqa: E402
 import gvins_data as gd  # noqa: E402
 import harness as H  # noqa: E402
 
-lib = C.CDLL(H.HOST_LIB)
+lib = C.CDLL(H.TOOLS_LIB)
 seq = gd.Sequence(lib)
 files = seq.write(tempfile.mkdtemp(prefix="prof_replay_"))
 for _ in range(3):

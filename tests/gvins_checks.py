@@ -6,6 +6,8 @@ import os
 
 import numpy as np
 
+import harness as H
+
 import gvins_data as gd
 import reproj_data as rd
 
@@ -65,7 +67,7 @@ def check_result_files(files, S):
 
 
 def check_replay(lib_path, tmp_root, pos_tol=0.10, att_tol=0.30, bitwise=True):
-    lib = C.CDLL(lib_path)
+    lib = C.CDLL(H.tools_lib(lib_path))
     seq = gd.Sequence(lib)
     files = seq.write(str(tmp_root))
     S = run_replay(lib, files)
@@ -111,7 +113,7 @@ def check_replay_calibration(lib_path, tmp_root):
     The sequence was made with the configured extrinsic and no delay: the time delay stays at zero; the lever arm of the camera is not
     observable on a straight drive, so its estimate wanders and the reference's guard (ic_gvins.cc:1320-1330: more than 1 m / 5 deg away
     from the current value is logged but not taken over) has to keep the states clean.  extrinsic.txt gets one row per window solve."""
-    lib = C.CDLL(lib_path)
+    lib = C.CDLL(H.tools_lib(lib_path))
     seq = gd.Sequence(lib)
     files = seq.write(str(tmp_root), estimate_extrinsic=True, estimate_td=True, with_earth=True)
     S = run_replay(lib, files)
@@ -131,7 +133,7 @@ def check_replay_calibration(lib_path, tmp_root):
 def check_replay_window(lib_path, tmp_root):
     """start/end bounds of the replay and a GNSS outage: fixes after `gnssoutagetime` are dropped (fusion_ros.cc:185-197) and the estimator
     keeps tracking on INS + vision"""
-    lib = C.CDLL(lib_path)
+    lib = C.CDLL(H.tools_lib(lib_path))
     seq = gd.Sequence(lib)
     files = seq.write(str(tmp_root))
     cfg = open(files["config"]).read().replace("isusegnssoutage: false", "isusegnssoutage: true").replace("gnssoutagetime: 0", f"gnssoutagetime: {gd.T0 + 5.0}")
@@ -162,7 +164,7 @@ def run_replay_many(lib, files, outputs, wait_poll_us=0):
 def check_replay_concurrent(lib_path, tmp_root, n=3, bitwise=True, wait_poll_us=0):
     """n estimators side by side in one process (one host thread, own device contexts and id space each): every stream's result files equal
     those of the same replay run alone — the streams of one GPU do not see each other"""
-    lib = C.CDLL(lib_path)
+    lib = C.CDLL(H.tools_lib(lib_path))
     seq = gd.Sequence(lib)
     files = seq.write(str(tmp_root))
     S = run_replay(lib, files)
@@ -194,7 +196,7 @@ def check_replay_tracking_loss(lib_path, tmp_root):
     """half a second of black images in the middle of the drive: the tracker reports TRACK_LOST, the lost frame and the empty first frames
     that follow become keyframes (ic_gvins.cc:540-549) and are dropped again as empty keyframes (:1397-1398), the tracker re-initializes
     on the first textured frames, and the estimator — carried by INS + GNSS meanwhile — stays at the truth"""
-    lib = C.CDLL(lib_path)
+    lib = C.CDLL(H.tools_lib(lib_path))
     seq = gd.Sequence(lib)
     files = seq.write(str(tmp_root))
     names = [line.split()[1] for line in open(files["images"])]
@@ -215,7 +217,7 @@ def check_replay_tracking_loss(lib_path, tmp_root):
 def check_replay_input_formats(lib_path, tmp_root):
     """the other input flavours of the replay give the same run: IMU as angular rate / specific force (the fields of sensor_msgs/Imu, multiplied
     by dt as imuCallback does), Unix time stamps (converted with GpsTime::unix2gps), colour images (PPM -> BGR8 -> gray on the device)"""
-    lib = C.CDLL(lib_path)
+    lib = C.CDLL(H.tools_lib(lib_path))
     seq = gd.Sequence(lib)
     files = seq.write(str(tmp_root))
     S = run_replay(lib, files)
@@ -267,7 +269,7 @@ def check_against_reference_estimator(lib_path, tmp_root, golden_path, write_kwa
     stamps), the GNSS/INS phase before the first image to 0.1 mm, the first window's reprojection statistics to 1e-6 px, and the whole
     trajectory within 5 cm / 0.2 deg — the level at which two runs of the reference itself differ (3 cm between pacings)."""
     import zlib
-    lib = C.CDLL(lib_path)
+    lib = C.CDLL(H.tools_lib(lib_path))
     seq = gd.Sequence(lib)
     files = seq.write(str(tmp_root), **(write_kwargs or {}))
     if blank:  # a stretch of black images: tracking loss and re-initialization
@@ -363,7 +365,7 @@ def run_replay_lockstep(lib, files, outputs, groups=1):
 def check_replay_lockstep(lib_path, tmp_root, n=3, bitwise=True, groups=1):
     """n estimators in lock-step on one thread, their window solves shared through one WindowSolverBatch: every stream's result files equal
     those of the stream replayed alone with its own WindowSolver"""
-    lib = C.CDLL(lib_path)
+    lib = C.CDLL(H.tools_lib(lib_path))
     seq = gd.Sequence(lib)
     files = seq.write(str(tmp_root))
     S = run_replay(lib, files)
@@ -393,7 +395,7 @@ def check_replay_lockstep_different_streams(lib_path, tmp_root):
     """three DIFFERENT streams in one lock-step group — the plain sequence, the same drive with half a second of black images (loses track,
     re-initializes: its keyframes fall on other frames), and a drive with other sensor noise and a later first image — so the window solves of a
     tick form batches of one, two or three windows of different sizes: every stream still equals its own replay alone, bit for bit"""
-    lib = C.CDLL(lib_path)
+    lib = C.CDLL(H.tools_lib(lib_path))
     root = str(tmp_root)
     sets = []
     seq = gd.Sequence(lib)

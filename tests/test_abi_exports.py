@@ -45,5 +45,13 @@ def test_host_library_exports_driver_entry_points():
     import harness
     lib = ctypes.CDLL(harness.HOST_LIB)
     for s in ("icgh_batch_create", "icgh_batch_run", "icgh_batch_step", "icgh_batch_stats", "icgh_batch_features", "icgh_backend_reproj",
-              "icgh_backend_marginalize", "icgh_backend_preint", "icgs_render"):
+              "icgh_backend_marginalize", "icgh_backend_preint"):
         assert hasattr(lib, s), s
+    # the estimator port, the replay harness and the benchmark's renderer are NOT in the product library ...
+    for s in ("icgs_render", "icgh_replay_run", "icgh_nav_factor"):
+        assert not hasattr(lib, s), s
+    # ... they live in the tools library, which links on top of the product libraries
+    tools = ctypes.CDLL(harness.TOOLS_LIB)
+    for s in ("icgs_render", "icgs_make_texture", "icgh_replay_run", "icgh_replay_run_many", "icgh_replay_run_lockstep", "icgh_nav_factor",
+              "icgh_batch_create"):
+        assert hasattr(tools, s), s

@@ -50,7 +50,7 @@ def test_replay_gpu_agrees_with_oracle_backend(tmp_path):
     """the same files through the HIP-backed and the oracle-backed host layer: the front-end is bit-exact, the FP64 paths agree to rounding,
     so keyframe / landmark bookkeeping is identical and the trajectories agree to well below the estimator's accuracy"""
     from stream_utils import ensure_oracle_host
-    gpu, cpu = C.CDLL(H.HOST_LIB), C.CDLL(ensure_oracle_host())
+    gpu, cpu = C.CDLL(H.TOOLS_LIB), C.CDLL(ensure_oracle_host())
     seq = gd.Sequence(gpu)
     files = seq.write(str(tmp_path))
     Sg = gc.run_replay(gpu, files)
