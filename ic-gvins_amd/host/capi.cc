@@ -68,10 +68,7 @@ int icgh_batch_run(icgh_batch *b, int K, const void *const *images, int stride, 
                 if (!images[j]) continue;
                 Mat img = Mat::wrap((uint8_t *) images[j], b->h, b->w, channels, (size_t) stride, on_device != 0);
                 auto f  = Frame::createFrame(stamps[j], img, b->tb->stream(i).ids);
-                Pose p;
-                memcpy(p.R.m, poses12 + 12 * j, sizeof(double) * 9);
-                memcpy(p.t.v, poses12 + 12 * j + 9, sizeof(double) * 3);
-                f->setPose(p);
+                f->setPose(poseFromArray12(poses12 + 12 * j));
                 frames[(size_t) k][(size_t) i] = f;
             }
         vector<vector<TrackState>> st;
@@ -513,8 +510,7 @@ int icgh_batch_landmark_table(icgh_batch *b, int stream, int max_lm, int max_obs
                     if (frame->isKeyFrame()) fl |= 4;
                     if (frame->isKeyFrame() && S.map->isKeyFrameInMap(frame)) fl |= 8;
                     Pose p = frame->pose();
-                    memcpy(obs_pose12 + 12 * (size_t) no, p.R.m, sizeof(double) * 9);
-                    memcpy(obs_pose12 + 12 * (size_t) no + 9, p.t.v, sizeof(double) * 3);
+                    poseToArray12(p, obs_pose12 + 12 * (size_t) no);
                 }
             }
             obs_flags[no] = fl;
@@ -592,8 +588,7 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
     try {
         const int n = b->tb->size();
         Pose pbc;
-        memcpy(pbc.R.m, pose_b_c12, sizeof(double) * 9);
-        memcpy(pbc.t.v, pose_b_c12 + 9, sizeof(double) * 3);
+        pbc = poseFromArray12(pose_b_c12);
         icg_ctx *ctx = b->tb->group(0).device()->ctx();
         const bool lockstep = getenv("ICG_REFINE_PER_STREAM") == nullptr; // default: all streams' windows in ONE WindowSolverBatch
         vector<std::unique_ptr<VisualWindow>> wins;
@@ -690,8 +685,7 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
                     double *r = kf_out + 14 * ((size_t) s * max_kf + k);
                     r[0] = wins[(size_t) s]->frame(k)->stamp(), r[1] = (double) wins[(size_t) s]->frame(k)->id();
                     Pose p = wins[(size_t) s]->frame(k)->pose();
-                    memcpy(r + 2, p.R.m, sizeof(double) * 9);
-                    memcpy(r + 11, p.t.v, sizeof(double) * 3);
+                    poseToArray12(p, r + 2);
                 }
         return 0;
     } catch (const std::exception &e) {

@@ -50,8 +50,9 @@ void flatten(const std::vector<WindowCulling::Stream> &streams, Flat &F) {
                 if (it == pose_of.end()) {
                     it = pose_of.emplace(frame.get(), (int32_t) (F.poses12.size() / 12)).first;
                     const Pose p = frame->pose();
-                    F.poses12.insert(F.poses12.end(), p.R.m, p.R.m + 9);
-                    F.poses12.insert(F.poses12.end(), p.t.v, p.t.v + 3);
+                    double p12[12];
+                    poseToArray12(p, p12);
+                    F.poses12.insert(F.poses12.end(), p12, p12 + 12);
                 }
                 const Point2f pp = feat->keyPoint();
                 F.pose_idx.push_back(it->second);

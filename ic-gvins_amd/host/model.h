@@ -403,14 +403,22 @@ private:
     bool is_window_full_{false};
 };
 
-// ---- Drawer (null object) ------------------------------------------------------------------------------------
+// ---- Drawer (tracking/drawer.h:31-64; here a null object: every hook has an empty default) ----------------------------------------
 class Drawer {
 public:
     typedef std::shared_ptr<Drawer> Ptr;
     virtual ~Drawer() = default;
+    virtual void run() {}
+    virtual void setFinished() {}
+    void setMap(Map::Ptr map) { map_ = std::move(map); }
+    virtual void addNewFixedMappoint(Vector3d) {}
+    virtual void updateMap(const Matrix4d &) {}
     virtual void updateFrame(Frame::Ptr) {}
     virtual void updateTrackedMapPoints(vector<Point2f>, vector<Point2f>, vector<MapPointType>) {}
     virtual void updateTrackedRefPoints(vector<Point2f>, vector<Point2f>) {}
+
+protected:
+    Map::Ptr map_;
 };
 
 } // namespace icg

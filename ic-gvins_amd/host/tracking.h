@@ -18,12 +18,6 @@ namespace icg {
 
 typedef enum TrackState { TRACK_FIRST_FRAME, TRACK_INITIALIZING, TRACK_TRACKING, TRACK_PASSED, TRACK_LOST } TrackState;
 
-struct Matrix4d {
-    double m[16]{};
-    double &operator()(int r, int c) { return m[r * 4 + c]; }
-    double operator()(int r, int c) const { return m[r * 4 + c]; }
-};
-
 // tracker keys of config/gvins.yaml:48-57 (+ is_use_visualization :44)
 struct TrackingConfig {
     bool track_check_histogram{false};

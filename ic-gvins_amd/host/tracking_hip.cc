@@ -235,7 +235,7 @@ bool Tracking::isGoodToTrack(const Point2f &pp, const Pose &pose, const Vector3d
 }
 
 Matrix4d Tracking::pose2Tcw(const Pose &pose) { // :851-859
-    Matrix4d T;
+    Matrix4d T   = Matrix4d::Zero();
     T(3, 3)      = 1;
     Matrix3d Rt  = pose.R.transpose();
     Vector3d t   = Rt * pose.t;
@@ -851,7 +851,11 @@ bool Tracking::queueTriangulation(StageBatch &next) {
     // one Tcw per distinct reference frame + the current frame, appended to the shared pose table
     const int T_cur = (int) (next.tri_Tcw.size() / 12);
     Matrix4d T1     = pose2Tcw(pose1);
-    next.tri_Tcw.insert(next.tri_Tcw.end(), T1.m, T1.m + 12);
+    {
+        double t12[12];
+        toRowMajor3x4(T1, t12);
+        next.tri_Tcw.insert(next.tri_Tcw.end(), t12, t12 + 12);
+    }
     std::unordered_map<Frame *, int> T_of;
 
     for (size_t k = 0; k < pts2d_cur_.size(); k++) {
@@ -881,7 +885,9 @@ bool Tracking::queueTriangulation(StageBatch &next) {
         if (it == T_of.end()) {
             T0 = (int) (next.tri_Tcw.size() / 12);
             Matrix4d T = pose2Tcw(pose0);
-            next.tri_Tcw.insert(next.tri_Tcw.end(), T.m, T.m + 12);
+            double t12[12];
+            toRowMajor3x4(T, t12);
+            next.tri_Tcw.insert(next.tri_Tcw.end(), t12, t12 + 12);
             T_of[frame_ref.get()] = T0;
         } else
             T0 = it->second;
@@ -889,8 +895,8 @@ bool Tracking::queueTriangulation(StageBatch &next) {
         Vector3d pc1 = camera_->pixel2cam(tri_cur_undis_[k]);
         next.tri_T0.push_back(T0);
         next.tri_T1.push_back(T_cur);
-        next.tri_pc0.insert(next.tri_pc0.end(), pc0.v, pc0.v + 3);
-        next.tri_pc1.insert(next.tri_pc1.end(), pc1.v, pc1.v + 3);
+        for (int c = 0; c < 3; c++) next.tri_pc0.push_back(pc0[c]);
+        for (int c = 0; c < 3; c++) next.tri_pc1.push_back(pc1[c]);
         tri_action_[k] = 1;
         tri_point_index_.push_back((int) k);
     }

@@ -1,16 +1,36 @@
-// Host-side value types of the MI355X-native IC-GVINS front-end.
-//
-// The reference's public API speaks Eigen (Vector3d, Matrix3d, Pose) and OpenCV (cv::Point2f, cv::Mat) —
-// reference: ic_gvins/ic_gvins/common/types.h:32-63, tracking/*.h.  Neither library exists in this environment, so
-// the same names are provided here as minimal PODs with the semantics the tracker relies on (column vectors, row-major
-// 3x3 storage, float pixel coordinates).  A maintainer linking against the real libraries converts at the boundary
-// with a memcpy (layouts documented per type).
 #pragma once
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
 #include <vector>
+
+// ---- drop-in mode -------------------------------------------------------------------------------------------------------------
+// Built next to the reference (its include root on the path, Eigen and OpenCV available) the value types below ARE the reference's:
+// Eigen vectors / matrices, cv::Point2f and the reference's own `Pose` (common/types.h:60-63), so that icg::Tracking / Frame /
+// MapPoint / Map / Camera have literally the signatures of tracking/tracking.h:51-61 and the reference's GVINS can hold an
+// icg::Tracking in its `tracking_` member (oracle/ref_build/ref_gvins_icg.cc compiles exactly that and replays the estimator golden).
+// Switched on by ICG_REFERENCE_TYPES (not silently by header presence: the standalone libraries must not change layout because a
+// build machine happens to have Eigen installed).
+#if defined(ICG_REFERENCE_TYPES)
+#if !__has_include(<Eigen/Geometry>) || !__has_include(<opencv2/opencv.hpp>)
+#error "ICG_REFERENCE_TYPES needs Eigen and OpenCV headers on the include path"
+#endif
+#include <Eigen/Geometry>
+#include <opencv2/opencv.hpp>
+
+#include "common/types.h" // the reference's Pose
+
+namespace icg {
+typedef unsigned long ulong;
+using Vector2d = Eigen::Vector2d;
+using Vector3d = Eigen::Vector3d;
+using Matrix3d = Eigen::Matrix3d;
+using Matrix4d = Eigen::Matrix4d;
+using Point2f  = cv::Point2f;
+using ::Pose;
+} // namespace icg
+#else
 
 namespace icg {
 
@@ -80,6 +100,55 @@ struct Point2f {
     Point2f() = default;
     Point2f(float x_, float y_) : x(x_), y(y_) {}
 };
+
+// 4x4, row-major (Tracking::pose2Tcw, tracking/tracking.h:61)
+struct Matrix4d {
+    double m[16]{};
+    double &operator()(int r, int c) { return m[r * 4 + c]; }
+    double operator()(int r, int c) const { return m[r * 4 + c]; }
+    static Matrix4d Zero() { return Matrix4d(); }
+};
+
+} // namespace icg
+#endif // ICG_REFERENCE_TYPES
+
+namespace icg {
+
+// Storage-independent access (the PODs are row-major, Eigen is column-major): always through (row, col)
+inline void toRowMajor(const Matrix3d &R, double *out9) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) out9[i * 3 + j] = R(i, j);
+}
+inline Matrix3d fromRowMajor3(const double *in9) {
+    Matrix3d R;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R(i, j) = in9[i * 3 + j];
+    return R;
+}
+inline void toArray(const Vector3d &v, double *out3) { out3[0] = v[0], out3[1] = v[1], out3[2] = v[2]; }
+inline Vector3d fromArray3(const double *in3) { return Vector3d(in3[0], in3[1], in3[2]); }
+// the upper 3 x 4 block of a 4 x 4 matrix, row-major (what icg_triangulate takes)
+inline void toRowMajor3x4(const Matrix4d &T, double *out12) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++) out12[i * 4 + j] = T(i, j);
+}
+// R | t as the 12 doubles the C entry points exchange
+inline void poseToArray12(const Pose &p, double *out12) {
+    toRowMajor(p.R, out12);
+    toArray(p.t, out12 + 9);
+}
+inline Pose poseFromArray12(const double *in12) {
+    Pose p;
+    p.R = fromRowMajor3(in12);
+    p.t = fromArray3(in12 + 9);
+    return p;
+}
+inline Pose identityPose() {
+    Pose p;
+    p.R = Matrix3d::Identity();
+    p.t = Vector3d(0, 0, 0);
+    return p;
+}
 
 // cv::Mat stand-in for 8-bit images (1 or 3 channels). Data is reference counted like cv::Mat; an image may also
 // live in device memory already (device=true), in which case `data` is a HIP device pointer owned by the caller.

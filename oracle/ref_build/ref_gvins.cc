@@ -24,74 +24,13 @@
 
 #include "ic_gvins.cc"
 
-namespace {
-class ReplayDrawer : public Drawer { // tracking/drawer.h: the RViz drawer of the ROS shell is not part of the estimator
-public:
-    void run() override {}
-    void setFinished() override {}
-    void addNewFixedMappoint(Vector3d) override {}
-    void updateMap(const Eigen::Matrix4d &) override {}
-    void updateFrame(Frame::Ptr) override {}
-    void updateTrackedMapPoints(vector<cv::Point2f>, vector<cv::Point2f>, vector<MapPointType>) override {}
-    void updateTrackedRefPoints(vector<cv::Point2f>, vector<cv::Point2f>) override {}
-};
-} // namespace
-
-extern "C" {
-// imu rows: t, dtheta3, dvel3 (increments; dt from consecutive stamps as imuCallback computes it); gnss rows: t, lat [rad], lon [rad], h, std3;
-// images: n_img gray frames of w x h, row-major, one after the other, with their stamps.  slowdown: wall seconds per data second.
-// Returns the final GVINS state; the result files are in outputpath.
-int ref_gvins_run(const char *configfile, const char *outputpath, int n_imu, const double *imu_rows, int n_gnss, const double *gnss_rows, int n_img,
-                  const double *img_stamps, const uint8_t *images, int w, int h, double slowdown) {
-    Drawer::Ptr drawer = std::make_shared<ReplayDrawer>();
-    auto gvins         = std::make_shared<GVINS>(configfile, outputpath, drawer);
-    if (!gvins->isRunning()) return -100;
-    int ii = 1, gi = 0, fi = 0; // the first IMU message only initialises dt (fusion_ros.cc:146-148)
-    const double t_first = imu_rows[0];
-    auto wall0           = std::chrono::steady_clock::now();
-    auto wait_until      = [&](double t) {
-        auto due = wall0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>((t - t_first) * slowdown));
-        std::this_thread::sleep_until(due);
-    };
-    while (ii < n_imu || gi < n_gnss || fi < n_img) {
-        const double ti = ii < n_imu ? imu_rows[7 * ii] : 1e300, tg = gi < n_gnss ? gnss_rows[7 * gi] : 1e300, tf = fi < n_img ? img_stamps[fi] : 1e300;
-        if (ti <= tg && ti <= tf) {
-            wait_until(ti);
-            const double *r = imu_rows + 7 * (size_t) ii;
-            IMU imu;
-            imu.time   = r[0];
-            imu.dt     = r[0] - imu_rows[7 * (size_t) (ii - 1)];
-            imu.dtheta = Vector3d(r[1], r[2], r[3]);
-            imu.dvel   = Vector3d(r[4], r[5], r[6]);
-            imu.odovel = 0;
-            while (!gvins->addNewImu(imu)) usleep(50); // try_lock failed: the shell retries with the next message (fusion_ros.cc:151-161)
-            ii++;
-        } else if (tg <= tf) {
-            wait_until(tg);
-            const double *r = gnss_rows + 7 * (size_t) gi;
-            GNSS g;
-            g.time       = r[0];
-            g.blh        = Vector3d(r[1], r[2], r[3]);
-            g.std        = Vector3d(r[4], r[5], r[6]);
-            g.isyawvalid = false;
-            g.yaw        = 0;
-            gvins->addNewGnss(g);
-            gi++;
-        } else {
-            wait_until(tf);
-            Mat image(h, w, CV_8UC1);
-            memcpy(image.data, images + (size_t) fi * w * h, (size_t) w * h);
-            auto frame = Frame::createFrame(tf, image);
-            while (!gvins->addNewFrame(frame)) usleep(50);
-            fi++;
-        }
-    }
-    usleep((useconds_t) (300000 * std::max(1.0, slowdown))); // let the last optimization finish
-    int state = (int) gvins->gvinsState();
-    gvins->setFinished();
-    return state;
+static Frame::Ptr ref_make_frame(double stamp, const uint8_t *gray, int w, int h) {
+    Mat image(h, w, CV_8UC1);
+    memcpy(image.data, gray, (size_t) w * h);
+    return Frame::createFrame(stamp, image);
 }
-}
+#define REF_GVINS_RUN_NAME ref_gvins_run
+#include "ref_gvins_driver.inc"
 
 // ---- f1 cross-check: one sliding window of reprojection factors + pose priors through the REFERENCE's own factor code
 // (factors/reprojection_factor.h, factors/pose_parameterization.h, preintegration/imu_pose_prior_factor.h, ceres::HuberLoss) and the shim's

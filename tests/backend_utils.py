@@ -269,4 +269,6 @@ def check_marginalization_paths(lib):
     lib.icgh_backend_marginalization_force_dense(1)
     b = backend_marginalize(lib, P2)
     lib.icgh_backend_marginalization_force_dense(0)
-    assert np.array_equal(a["Hp"], b["Hp"]) and np.array_equal(a["bp"], b["bp"])
+    # (same path twice: equal up to the summation order of the device's FP64 atomics)
+    sc = np.abs(b["Hp"]).max()
+    assert np.abs(a["Hp"] - b["Hp"]).max() <= 1e-12 * sc and np.abs(a["bp"] - b["bp"]).max() <= 1e-12 * max(1.0, np.abs(b["bp"]).max())

@@ -284,6 +284,13 @@ def check_against_reference_estimator(lib_path, tmp_root, golden_path, write_kwa
     assert list(g["checksums"]) == crc, "the synthetic sequence is not byte-identical to the one the golden was made from"
     S = run_replay(lib, files)
     assert S["final_state"] == int(g["final_state"]) == STATE_TRACKING_NORMAL
+    return compare_result_files_with_reference_golden(files["out"], g, n_keyframe_features_exact, pos_tol)
+
+
+def compare_result_files_with_reference_golden(out_dir, g, n_keyframe_features_exact=10, pos_tol=0.05):
+    """the result files of one estimator run (trajectory.csv, gvins.nav, statistics.txt, tracking.txt, mappoint.txt, IMU_ERR.bin, extrinsic.txt
+    under out_dir) against the arrays of a reference-estimator golden; tolerances: see check_against_reference_estimator"""
+    files = {"out": out_dir}
     load = lambda name: np.loadtxt(os.path.join(files["out"], name))
     traj, nav, stat, track, mpts = load("trajectory.csv"), load("gvins.nav"), load("statistics.txt"), load("tracking.txt"), load("mappoint.txt")
     rt, rn, rs, rk, rm = g["trajectory"], g["nav"], g["statistics"], g["tracking"], g["mappoints"]
