@@ -777,6 +777,7 @@ extern "C" int icg_reproj_cost(icg_ctx *ctx, const uint8_t *active, double *cost
 // launch per LM step for all of them.  The resident factor set is partitioned into W windows (factors sorted by window, landmarks
 // contiguous per window, poses indexed globally); every window has its own extrinsic / td, its own reduced system of the common
 // size P and its own damping.  Window w's system lives at d_sys + w_sys_off[w]: H (N_w x N_w, N_w = P + L_w) | b (N_w) | inv (L_w).
+#define LM_SLOTS 64 // landmark slots of one assembly workgroup (256 factors ~ 30 landmarks when the list is landmark-major)
 struct win_desc {
     int32_t fac_begin, fac_end, lm_begin, L;
     int64_t sys_off;
@@ -852,15 +853,70 @@ __global__ __launch_bounds__(NRM_BLOCK) void k_reproj_normal_schur_w(const win_d
             }
         }
     }
+    // Landmark rows (G_l, h_ll, b_l).  A landmark's factors are neighbours in the factor list (the window builder adds them landmark by
+    // landmark) and share its reference pose, the extrinsic and td: those 15 sums (6 reference-pose columns, 6 + 1 shared columns, h_ll,
+    // b_l) are first accumulated in LDS per (landmark, reference pose) slot of this workgroup and flushed with ONE global atomic each —
+    // ~9 factors per landmark made 21 global FP64 atomics per factor the dominant cost of the batched assembly (rocprofv3, round 1).
+    // The observer-pose columns are unique per factor and go straight to memory.  Landmarks outside the workgroup's slot range (an
+    // unsorted factor list) take the direct path: placement only, the sums are the same.
+    double *lrow = bs + V; // LM_SLOTS x 16: [0..5] reference pose, [6..11] ext, [12] td, [13] h_ll, [14] b_l, [15] ci (slot owner check)
+    int *lslot_ci = reinterpret_cast<int *>(lrow + LM_SLOTS * 16);
+    for (int e = t; e < LM_SLOTS * 16; e += NRM_BLOCK) lrow[e] = 0.0;
+    for (int e = t; e < LM_SLOTS; e += NRM_BLOCK) lslot_ci[e] = -2;
+    __shared__ int lm_base;
+    if (t == 0) lm_base = idx_lm[blk_first[blockIdx.x]] - W.lm_begin; // landmark of the workgroup's first factor
+    __syncthreads();
+    const int slot = lm - lm_base;
+    bool in_lds    = false;
     if (on) {
         double *row = H + (size_t) (P + lm) * N;
+        const int ci = cc[0]; // compact column of the reference pose (-1: constant)
+        if (slot >= 0 && slot < LM_SLOTS) { // claim the slot for this (landmark, reference pose); a different owner -> direct path
+            const int prev = atomicCAS(&lslot_ci[slot], -2, ci);
+            in_lds         = prev == -2 || prev == ci;
+        }
+        if (in_lds) {
+            double *L = lrow + slot * 16;
 #pragma unroll
-        for (int x = 0; x < 19; x++)
-            if (cc[x] >= 0) unsafeAtomicAdd(&row[vmap[cc[x]]], jl0 * j0[x] + jl1 * j1[x]);
-        unsafeAtomicAdd(&row[P + lm], jl0 * jl0 + jl1 * jl1);
-        unsafeAtomicAdd(&b[P + lm], -(jl0 * r0 + jl1 * r1));
+            for (int x = 0; x < 6; x++)
+                if (cc[x] >= 0) atomicAdd(&L[x], jl0 * j0[x] + jl1 * j1[x]);
+#pragma unroll
+            for (int x = 12; x < 19; x++)
+                if (cc[x] >= 0) atomicAdd(&L[x - 6], jl0 * j0[x] + jl1 * j1[x]);
+            atomicAdd(&L[13], jl0 * jl0 + jl1 * jl1);
+            atomicAdd(&L[14], -(jl0 * r0 + jl1 * r1));
+#pragma unroll
+            for (int x = 6; x < 12; x++)
+                if (cc[x] >= 0) unsafeAtomicAdd(&row[vmap[cc[x]]], jl0 * j0[x] + jl1 * j1[x]);
+        } else {
+#pragma unroll
+            for (int x = 0; x < 19; x++)
+                if (cc[x] >= 0) unsafeAtomicAdd(&row[vmap[cc[x]]], jl0 * j0[x] + jl1 * j1[x]);
+            unsafeAtomicAdd(&row[P + lm], jl0 * jl0 + jl1 * jl1);
+            unsafeAtomicAdd(&b[P + lm], -(jl0 * r0 + jl1 * r1));
+        }
     }
     __syncthreads();
+    // flush the landmark slots: thread e -> (slot e / 16, value e % 16)
+    for (int e = t; e < LM_SLOTS * 16; e += NRM_BLOCK) {
+        const int sl = e >> 4, k = e & 15, ci = lslot_ci[sl];
+        if (ci == -2 || k == 15) continue;
+        const double v = lrow[e];
+        if (v == 0.0) continue;
+        const int l = lm_base + sl;
+        double *row = H + (size_t) (P + l) * N;
+        if (k < 6) {
+            if (ci >= 0) unsafeAtomicAdd(&row[vmap[ci + k]], v);
+        } else if (k < 12) {
+            unsafeAtomicAdd(&row[vmap[W.vcol_ext + (k - 6)]], v);
+        } else if (k == 12) {
+            unsafeAtomicAdd(&row[vmap[W.vcol_td]], v);
+        } else if (k == 13) {
+            unsafeAtomicAdd(&row[P + l], v);
+        } else {
+            unsafeAtomicAdd(&b[P + l], v);
+        }
+    }
     for (int e = t; e < V * V; e += NRM_BLOCK) {
         const double v = Hs[e];
         if (v != 0.0) unsafeAtomicAdd(&H[(size_t) vmap[e / V] * N + vmap[e % V]], v);
@@ -1126,8 +1182,8 @@ extern "C" int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_
         Vw[(size_t) w] = (int32_t) vmaps[(size_t) w].size();
         Vmax           = std::max(Vmax, (int) Vw[(size_t) w]);
     }
-    const size_t lds = sizeof(double) * ((size_t) Vmax * Vmax + Vmax);
-    if (lds > 60 * 1024) return icg_fail(ctx, ICG_ERR_CAPACITY, "a window has %d free camera columns: more than the LDS tile of the batched assembly holds", Vmax);
+    const size_t lds = sizeof(double) * ((size_t) Vmax * Vmax + Vmax + LM_SLOTS * 16) + sizeof(int) * LM_SLOTS;
+    if (lds > 62 * 1024) return icg_fail(ctx, ICG_ERR_CAPACITY, "a window has %d free camera columns: more than the LDS tile of the batched assembly holds", Vmax);
     std::vector<int32_t> vmap_all((size_t) W * Vmax, 0);
     for (int w = 0; w < W; w++) std::copy(vmaps[(size_t) w].begin(), vmaps[(size_t) w].end(), vmap_all.begin() + (size_t) w * Vmax);
     for (int w = 0; w < W; w++)

@@ -1,0 +1,83 @@
+#include "host_pool.h"
+
+#include <stdexcept>
+
+namespace icg {
+
+// ---- HostPool -----------------------------------------------------------------------------------------------------------
+HostPool::HostPool(int n_threads) {
+    for (int t = 1; t < n_threads; t++) helpers_.emplace_back([this] { helperLoop(); });
+}
+
+HostPool::~HostPool() {
+    {
+        std::lock_guard<std::mutex> lock(m_);
+        stop_ = true;
+        gen_.fetch_add(1, std::memory_order_release);
+    }
+    cv_.notify_all();
+    for (auto &t : helpers_) t.join();
+}
+
+void HostPool::drain() {
+    for (;;) {
+        const int i = next_.fetch_add(1, std::memory_order_relaxed);
+        if (i >= n_) break;
+        try {
+            (*fn_)(i);
+        } catch (const std::exception &ex) {
+            std::lock_guard<std::mutex> lock(m_);
+            if (error_.empty()) error_ = ex.what();
+        }
+    }
+}
+
+void HostPool::helperLoop() {
+    uint64_t seen = 0;
+    for (;;) {
+        int spins = 0;
+        while (gen_.load(std::memory_order_acquire) == seen) {
+            if (++spins < 20000) {
+                __builtin_ia32_pause();
+                continue;
+            }
+            std::unique_lock<std::mutex> lock(m_);
+            sleepers_.fetch_add(1);
+            cv_.wait(lock, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+            sleepers_.fetch_sub(1);
+        }
+        seen = gen_.load(std::memory_order_acquire);
+        if (stop_) return;
+        drain();
+        acks_.fetch_add(1, std::memory_order_release); // this helper no longer touches fn_/n_/next_ of this generation
+    }
+}
+
+// Full barrier per dispatch: returns only after every helper has left drain(), so fn_/n_/next_ are never rewritten
+// under a straggler.
+void HostPool::parallelFor(int n, const std::function<void(int)> &f) {
+    if (n <= 0) return;
+    fn_ = &f;
+    n_  = n;
+    next_.store(0, std::memory_order_relaxed);
+    acks_.store(0, std::memory_order_relaxed);
+    {
+        // the generation bump publishes fn_/n_/next_; taking the mutex orders it against helpers about to sleep
+        std::lock_guard<std::mutex> lock(m_);
+        gen_.fetch_add(1, std::memory_order_release);
+    }
+    if (sleepers_.load() > 0) cv_.notify_all();
+    drain();
+    const int helpers = (int) helpers_.size();
+    while (acks_.load(std::memory_order_acquire) < helpers) __builtin_ia32_pause();
+    if (!error_.empty()) {
+        std::string e;
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            e.swap(error_);
+        }
+        throw std::runtime_error(e);
+    }
+}
+
+} // namespace icg

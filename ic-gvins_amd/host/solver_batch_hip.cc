@@ -18,28 +18,17 @@ namespace icg {
 using solver_detail::choleskySolve;
 using solver_detail::posePlus;
 
-namespace {
-// fn(w) for w in [0, n) on up to `threads` threads (windows are independent; exceptions are not expected from the per-window phases)
-template <typename F> void parallelFor(size_t n, int threads, F &&fn) {
-    if (threads <= 1 || n < 2) {
+// The per-window host phases of an LM step (host factors, reduced solves, trial bookkeeping) take tens of microseconds per window: they
+// run on a persistent pool — spawning threads per phase (four phases per step) cost more than the phases themselves.
+template <typename F> void WindowSolverBatch::forEachWindow(size_t n, F &&fn) {
+    if (host_threads_ <= 1 || n < 4) {
         for (size_t w = 0; w < n; w++) fn(w);
         return;
     }
-    std::atomic<size_t> next{0};
-    auto work = [&]() {
-        for (;;) {
-            size_t w = next.fetch_add(1);
-            if (w >= n) break;
-            fn(w);
-        }
-    };
-    std::vector<std::thread> th;
-    const int nt = (int) std::min<size_t>((size_t) threads, n);
-    for (int t = 1; t < nt; t++) th.emplace_back(work);
-    work();
-    for (auto &x : th) x.join();
+    if (!pool_) pool_.reset(new HostPool(host_threads_));
+    const std::function<void(int)> f = [&](int w) { fn((size_t) w); };
+    pool_->parallelFor((int) n, f);
 }
-} // namespace
 
 WindowSolverBatch::WindowSolverBatch(int device, double huber_delta, int host_threads) : huber_(huber_delta) {
     host_threads_ = host_threads > 0 ? host_threads : (int) std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -276,7 +265,7 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
             clk.stop(1);
             clk.start();
             std::atomic<int> host_failed{0};
-            parallelFor(NW, host_threads_, [&](size_t w) {
+            forEachWindow(NW, [&](size_t w) {
                 if (st[w].done || !(st[w].relinearize || st[w].redamp)) return;
                 Window &W = windows_[w];
                 if (st[w].relinearize) {
@@ -307,7 +296,7 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
         // ---- every open window: iteration budget, gradient test, reduced solve ----------------------------------------------------
         clk.start();
         std::fill(delta_c.begin(), delta_c.end(), 0.0);
-        parallelFor(NW, host_threads_, [&](size_t w) {
+        forEachWindow(NW, [&](size_t w) {
             State &T = st[w];
             T.stepped = false;
             if (T.done) return;
@@ -356,7 +345,7 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
         if (n_lm_ > 0 && icg_reproj_backsub_windows(ctx_, P, delta_c.data(), delta_l.data(), terms.data()) != ICG_OK) return fail("icg_reproj_backsub_windows");
         clk.stop(4);
         clk.start();
-        parallelFor(NW, host_threads_, [&](size_t w) {
+        forEachWindow(NW, [&](size_t w) {
             State &T = st[w];
             if (!T.stepped) return;
             Window &W = windows_[w];
@@ -405,7 +394,7 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
         clk.stop(6);
         clk.start();
         std::atomic<int> trial_failed{0};
-        parallelFor(NW, host_threads_, [&](size_t w) {
+        forEachWindow(NW, [&](size_t w) {
             State &T = st[w];
             if (!T.stepped) return;
             Window &W = windows_[w];

@@ -12,6 +12,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "host_pool.h"
 #include "solver_hip.h"
 
 namespace icg {
@@ -73,9 +74,13 @@ private:
     bool layout();
     void gather(std::vector<double> &poses, std::vector<double> &ext, std::vector<double> &inv, std::vector<double> &td) const;
 
+    // fn(w) for every window on the persistent helper threads (created on first use: a batch of one or two windows never needs them)
+    template <typename F> void forEachWindow(size_t n, F &&fn);
+
     icg_ctx *ctx_{nullptr};
     double huber_;
     int host_threads_;
+    std::unique_ptr<HostPool> pool_;
     std::vector<Window> windows_;
     std::vector<uint8_t> active_;
     std::vector<int32_t> col_pose_, col_ext_, col_td_;

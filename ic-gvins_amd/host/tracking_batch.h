@@ -8,33 +8,10 @@
 #include <functional>
 #include <thread>
 
+#include "host_pool.h"
 #include "tracking.h"
 
 namespace icg {
-
-// Persistent helpers for the per-stream host stages of one group: parallelFor(n, f) runs f(0..n-1) on the caller plus the
-// helper threads (dynamic index claiming).  Helpers spin briefly between dispatches (stages follow each other every
-// ~100 us) and sleep on a condition variable when the group is idle.
-class HostPool {
-public:
-    explicit HostPool(int n_threads);
-    ~HostPool();
-    void parallelFor(int n, const std::function<void(int)> &f);
-    int threads() const { return (int) helpers_.size() + 1; }
-
-private:
-    void helperLoop();
-    void drain();
-    vector<std::thread> helpers_;
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::atomic<uint64_t> gen_{0};
-    std::atomic<int> next_{0}, acks_{0}, sleepers_{0};
-    int n_{0};
-    const std::function<void(int)> *fn_{nullptr};
-    std::atomic<bool> stop_{false};
-    std::string error_;
-};
 
 class TrackingBatch {
 public:
