@@ -91,6 +91,19 @@ private:
 class Frame;
 class MapPoint;
 
+// prefetch of an object created by make_shared (control block in front of it) that is about to be locked / read: its first lines
+// only the reference counts of such an object (it is about to be released, not read)
+inline void prefetchCounts(const void *object) {
+    if (object) __builtin_prefetch(static_cast<const char *>(object) - 16, 1);
+}
+inline void prefetchShared(const void *object) {
+    if (!object) return;
+    const char *p = static_cast<const char *>(object);
+    __builtin_prefetch(p - 16); // use / weak counts
+    __builtin_prefetch(p + 48);
+    __builtin_prefetch(p + 112);
+}
+
 enum FeatureType { FEATURE_NONE = -1, FEATURE_MATCHED = 0, FEATURE_TRIANGULATED = 1, FEATURE_DEPTH_ASSOCIATED = 2 };
 
 class Feature {
@@ -108,7 +121,14 @@ public:
     std::shared_ptr<MapPoint> getMapPoint() { return mappoint_.lock(); }
     const Point2f &keyPoint() { return keypoint_; }
     const Point2f &distortedKeyPoint() { return distorted_keypoint_; }
-    void addMapPoint(const std::shared_ptr<MapPoint> &mappoint) { mappoint_ = mappoint; }
+    void addMapPoint(const std::shared_ptr<MapPoint> &mappoint) {
+        mappoint_      = mappoint;
+        mappoint_hint_ = mappoint.get();
+    }
+    // address of the map point this feature was attached to, for cache prefetching ONLY (never dereferenced: the object may be gone;
+    // ownership questions go through getMapPoint()).  The walks over a frame's features chase feature -> map point -> observation
+    // through cold memory (hundreds of streams per host), which is what the host layer's time goes into.
+    const void *mapPointHint() const { return mappoint_hint_; }
     void setOutlier(bool isoutlier) { isoutlier_ = isoutlier; }
     bool isOutlier() const { return isoutlier_; }
     FeatureType featureType() { return type_; }
@@ -118,6 +138,7 @@ public:
 private:
     std::weak_ptr<Frame> frame_;
     std::weak_ptr<MapPoint> mappoint_;
+    const void *mappoint_hint_{nullptr};
     Point2f keypoint_, distorted_keypoint_;
     Vector3d velocity_{0, 0, 0};
     bool isoutlier_;
@@ -161,14 +182,21 @@ public:
     typedef vector<std::pair<ulong, Feature::Ptr>> FeatureList;
     void featureSnapshot(FeatureList &out) {
         ModelLock lock(frame_mutex_);
-        out.clear();
-        out.reserve(features_.size());
-        for (const auto &kv : features_) out.emplace_back(kv.first, kv.second);
+        // walking the hash table is a dependent pointer chase through cold nodes; the list is rebuilt only after the feature set
+        // changed (once per frame in practice) and copied from contiguous memory afterwards (independent loads: they overlap)
+        if (!snapshot_valid_) {
+            snapshot_.clear();
+            snapshot_.reserve(features_.size());
+            for (const auto &kv : features_) snapshot_.emplace_back(kv.first, kv.second);
+            snapshot_valid_ = true;
+        }
+        out = snapshot_;
     }
     // bucket space for n more features up front (no incremental rehashing while a frame is being filled)
     void reserveFeatures(size_t n) {
         ModelLock lock(frame_mutex_);
-        features_.reserve(features_.size() + n);
+        features_.reserve(features_.size() + n); // (a rehash changes the iteration order: the cached list is rebuilt)
+        snapshot_valid_ = false;
     }
     // visit (map-point id, feature) pairs in place (the lock is held: the visitor must not call back into this frame)
     template <typename F> void forEachFeature(F &&f) {
@@ -177,8 +205,16 @@ public:
     }
     void clearFeatures() {
         ModelLock lock(frame_mutex_);
+        // destroying ~300 features of a frame that left the window ten keyframes ago touches cold memory three levels deep (hash node ->
+        // feature -> its map point's weak count).  Staged prefetch over the contiguous list, then the actual release.
+        if (snapshot_valid_ && snapshot_.size() == features_.size()) {
+            for (const auto &kv : snapshot_) prefetchShared(kv.second.get());
+            for (const auto &kv : snapshot_) prefetchCounts(kv.second->mapPointHint());
+        }
         features_.clear();
         unupdated_mappoints_.clear();
+        snapshot_.clear();
+        snapshot_valid_ = false;
     }
     size_t numFeatures() {
         ModelLock lock(frame_mutex_);
@@ -195,6 +231,7 @@ public:
     void addFeature(ulong mappointid, const Feature::Ptr &feature) {
         ModelLock lock(frame_mutex_);
         features_.insert(std::make_pair(mappointid, feature));
+        snapshot_valid_ = false;
     }
     double stamp() const { return stamp_; }
     void setStamp(double stamp) { stamp_ = stamp; }
@@ -225,6 +262,8 @@ private:
     Mat image_, raw_image_;
     bool iskeyframe_;
     std::unordered_map<ulong, Feature::Ptr> features_;
+    FeatureList snapshot_; // features_ in its iteration order (valid while snapshot_valid_)
+    bool snapshot_valid_{false};
     vector<std::shared_ptr<MapPoint>> unupdated_mappoints_;
     std::shared_ptr<IdSpace> ids_;
     int device_slot_{-1};
@@ -282,7 +321,11 @@ public:
     }
     void removeAllObservations() {
         ModelLock lock(mappoint_mutex_);
+        // releasing a weak_ptr writes the observing feature's control block: one cold line per observation, spread over every frame of
+        // the window.  Request them all first (they overlap), then release.
+        for (const void *h : observation_hints_) prefetchCounts(h);
         observations_.clear();
+        observation_hints_.clear();
     }
     vector<std::weak_ptr<Feature>> observations() {
         ModelLock lock(mappoint_mutex_);
@@ -347,6 +390,7 @@ public:
 
 private:
     vector<std::weak_ptr<Feature>> observations_;
+    vector<const void *> observation_hints_; // address of each observing feature, for prefetching only (never dereferenced)
     SpinLock mappoint_mutex_;
     bool isneedupdate_{false};
     Vector3d pos_, pos_tmp_;

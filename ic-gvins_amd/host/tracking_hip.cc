@@ -215,7 +215,10 @@ Tracking::~Tracking() {
 template <typename T> void Tracking::reduceVector(T &vec, const vector<uint8_t> &status) { // :831-839
     size_t index = 0;
     for (size_t k = 0; k < vec.size(); k++)
-        if (status[k]) vec[index++] = vec[k];
+        if (status[k]) {
+            if (index != k) vec[index] = std::move(vec[k]); // (shared_ptr lists: no reference-count round trip per kept element)
+            index++;
+        }
     vec.resize(index);
 }
 
@@ -265,7 +268,11 @@ int Tracking::parallaxFromReferenceMapPoints(double &parallax) { // :873-905
     int counts = 0;
     frame_ref_->featureSnapshot(feat_snap_);
     const Matrix3d R10 = frame_cur_->pose().R.transpose() * frame_ref_->pose().R; // loop invariant of :890
-    for (auto &feature : feat_snap_) {
+    constexpr size_t AHEAD = 12; // features whose map points are requested from memory before they are locked
+    for (size_t k = 0; k < std::min(AHEAD, feat_snap_.size()); k++) prefetchShared(feat_snap_[k].second->mapPointHint());
+    for (size_t fi = 0; fi < feat_snap_.size(); fi++) {
+        auto &feature = feat_snap_[fi];
+        if (fi + AHEAD < feat_snap_.size()) prefetchShared(feat_snap_[fi + AHEAD].second->mapPointHint());
         auto mappoint = feature.second->getMapPoint();
         if (mappoint) {
             std::shared_ptr<Feature> feat; // !isOutlier() && observations().back().lock() (:880-887)
@@ -661,7 +668,11 @@ void Tracking::queueTrackMappoint(StageBatch &next) {
     frame_pre_->featureSnapshot(feat_snap_);
     Pose pose_cur = frame_cur_->pose();
     pts2d_matched.reserve(feat_snap_.size());
-    for (auto &feature : feat_snap_) {
+    constexpr size_t AHEAD = 12;
+    for (size_t k = 0; k < std::min(AHEAD, feat_snap_.size()); k++) prefetchShared(feat_snap_[k].second->mapPointHint());
+    for (size_t fi = 0; fi < feat_snap_.size(); fi++) {
+        auto &feature = feat_snap_[fi];
+        if (fi + AHEAD < feat_snap_.size()) prefetchShared(feat_snap_[fi + AHEAD].second->mapPointHint());
         auto mappoint = feature.second->getMapPoint();
         Vector3d pos;
         MapPointType type;
@@ -711,23 +722,30 @@ bool Tracking::finishTrackMappoint(StageBatch &done) {
         parallax_map_counts_ = 0;
         return false;
     }
+    {
+    hostprof::Scope hp_feat(hostprof::LK_MAP_FEATURES);
     frame_cur_->clearFeatures(); // :426
     frame_cur_->reserveFeatures(pts2d_matched_undis.size() + 64);
     tracked_mappoint_.clear();
-    tracked_mappoint_.reserve(pts2d_matched_undis.size());
     double dt = frame_cur_->stamp() - frame_pre_->stamp();
     for (size_t k = 0; k < pts2d_matched_undis.size(); k++) {
-        auto mappoint = mappoint_matched_[k];
+        if (k + 8 < mappoint_matched_.size()) prefetchShared(mappoint_matched_[k + 8].get());
+        const MapPoint::Ptr &mappoint = mappoint_matched_[k];
         Vector3d velocity = (camera_->pixel2cam(pts2d_matched_undis[k]) - camera_->pixel2cam(tm_pts2d_map_undis_[k])) / dt;
         auto feature = Feature::createFeature(frame_cur_, Vector2d(velocity.x(), velocity.y()), pts2d_matched_undis[k],
                                               pts2d_matched[k], FEATURE_MATCHED);
         mappoint->addObservation(feature);
         feature->addMapPoint(mappoint);
         frame_cur_->addFeature(mappoint->id(), feature);
-        tracked_mappoint_.push_back(mappoint);
+    }
+    tracked_mappoint_.swap(mappoint_matched_); // every matched map point is a tracked one (:446): the list changes hands, no copies
+    mappoint_matched_.clear();
     }
     if (cfg_.is_use_visualization) drawer_->updateTrackedMapPoints(tm_pts2d_map_, pts2d_matched, tm_type_);
-    parallax_map_counts_ = parallaxFromReferenceMapPoints(parallax_map_); // :450
+    {
+        hostprof::Scope hp_par(hostprof::LK_MAP_PARALLAX);
+        parallax_map_counts_ = parallaxFromReferenceMapPoints(parallax_map_); // :450
+    }
     return true;
 }
 
@@ -756,6 +774,7 @@ void Tracking::queueTrackReference(StageBatch &next) {
 }
 
 bool Tracking::midTrackReference(StageBatch &done, StageBatch &next) {
+    hostprof::Scope hp_ref(hostprof::LK_REF);
     rs_set_ = -1;
     if (lk_ref_n_ == 0) return false;
     const int n = lk_ref_n_;
@@ -968,7 +987,11 @@ TrackState Tracking::track(Frame::Ptr frame) {
 // ---- sliding-window stand-in ---------------------------------------------------------------------------------------
 void WindowKeeper::onFrame(Tracking &tracking, const Frame::Ptr &frame, TrackState st) {
     if (!(tracking.isNewKeyFrame() || st == TRACK_FIRST_FRAME || st == TRACK_LOST)) return; // ic_gvins.cc:542
-    map_->insertKeyFrame(frame);                                                            // ic_gvins.cc:743
+    {
+        hostprof::Scope hp(hostprof::KEEP_INSERT);
+        map_->insertKeyFrame(frame); // ic_gvins.cc:743
+    }
+    hostprof::Scope hp_rm(hostprof::KEEP_REMOVE);
     // gvinsRemoveAllSecondNewFrame (ic_gvins.cc:1391-1410)
     vector<ulong> ids = map_->orderedKeyFrames();
     for (auto id : ids) {
