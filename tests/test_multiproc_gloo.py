@@ -51,3 +51,21 @@ def test_two_rank_sharding_matches_single_process():
     assert counters[0] == world * per_rank * nframes
     assert counters[1] == sum(s["tracked_sum"] for s in stats)
     assert tmax == 1.5  # MAX over ranks
+
+
+def test_host_plan_scales_the_polling_threads_with_the_rank_share():
+    """bench.py's per-rank host plan (sharding.host_plan): group threads follow the rank's share of the usable cores (never 8 pollers on
+    2 cores), and the ranks of a node pin themselves to disjoint CPU slices"""
+    sys.path.insert(0, os.path.join(ROOT, "ic-gvins_amd"))
+    import sharding
+    one = sharding.host_plan(16, 1, 0, cpu_ids=range(256))
+    assert one["groups"] == 32 and one["streams"] == 256 and one["cpu_slice"] is None
+    eight = [sharding.host_plan(16, 8, r, cpu_ids=range(256)) for r in range(8)]
+    assert all(p["groups"] == 4 and p["streams"] == 32 and abs(p["cores_rank"] - 2.0) < 1e-12 for p in eight)
+    slices = [set(p["cpu_slice"]) for p in eight]
+    assert all(len(s_) == 32 for s_ in slices) and len(set().union(*slices)) == 256  # disjoint, covering
+    big = sharding.host_plan(128, 8, 3, cpu_ids=range(128))
+    assert big["groups"] == 32 and big["cpu_slice"] == list(range(48, 64))
+    tiny = sharding.host_plan(4, 8, 0, cpu_ids=range(4))
+    assert tiny["groups"] == 2 and tiny["streams"] == 16 and tiny["cpu_slice"]
+    assert sharding.host_plan(16, 1, 0, groups_override=8, streams_override=64)["groups"] == 8
