@@ -138,7 +138,6 @@ MapPoint::MapPoint(ulong id, const std::shared_ptr<Frame> &ref_frame, Vector3d p
       observed_times_(0), isoutlier_(false), id_(id), mappoint_type_(type) {
     if ((depth_ < NEAREST_DEPTH) || (depth_ > FARTHEST_DEPTH)) depth_ = DEFAULT_DEPTH;
     observations_.reserve(16); // one observation per tracked frame: skip the 1-2-4-8 reallocation ladder
-    observation_hints_.reserve(16);
 }
 
 MapPoint::Ptr MapPoint::createMapPoint(std::shared_ptr<Frame> &ref_frame, Vector3d &pos, Point2f &feature, double depth,
@@ -149,7 +148,6 @@ MapPoint::Ptr MapPoint::createMapPoint(std::shared_ptr<Frame> &ref_frame, Vector
 void MapPoint::addObservation(const Feature::Ptr &feature) {
     ModelLock lock(mappoint_mutex_);
     observations_.push_back(feature);
-    observation_hints_.push_back(feature.get());
     observed_times_++;
 }
 

@@ -321,15 +321,18 @@ public:
     }
     void removeAllObservations() {
         ModelLock lock(mappoint_mutex_);
-        // releasing a weak_ptr writes the observing feature's control block: one cold line per observation, spread over every frame of
-        // the window.  Request them all first (they overlap), then release.
-        for (const void *h : observation_hints_) prefetchCounts(h);
         observations_.clear();
-        observation_hints_.clear();
     }
     vector<std::weak_ptr<Feature>> observations() {
         ModelLock lock(mappoint_mutex_);
         return observations_;
+    }
+    // The slot the next addObservation() will write (the list's storage is its own heap block, cold when a stream is touched again): a
+    // store that misses is drained by the next locked instruction, i.e. it stalls the reference-count traffic that follows it.
+    // Unlocked read of the end pointer, used as a prefetch address only.
+    void prefetchObservationSlot() const {
+        const std::weak_ptr<Feature> *end = observations_.data() + observations_.size();
+        __builtin_prefetch(end, 1);
     }
     // observations().back() without copying the whole list (same result; the list grows with every tracked frame)
     bool lastObservation(std::shared_ptr<Feature> &out) {
@@ -390,7 +393,6 @@ public:
 
 private:
     vector<std::weak_ptr<Feature>> observations_;
-    vector<const void *> observation_hints_; // address of each observing feature, for prefetching only (never dereferenced)
     SpinLock mappoint_mutex_;
     bool isneedupdate_{false};
     Vector3d pos_, pos_tmp_;

@@ -729,7 +729,10 @@ bool Tracking::finishTrackMappoint(StageBatch &done) {
     tracked_mappoint_.clear();
     double dt = frame_cur_->stamp() - frame_pre_->stamp();
     for (size_t k = 0; k < pts2d_matched_undis.size(); k++) {
-        if (k + 8 < mappoint_matched_.size()) prefetchShared(mappoint_matched_[k + 8].get());
+        // two-stage software pipeline over the map points of the list: the object (and its reference counts) 12 ahead, then — once it
+        // has arrived — the slot of its observation list that addObservation() will write, 5 ahead
+        if (k + 12 < mappoint_matched_.size()) prefetchShared(mappoint_matched_[k + 12].get());
+        if (k + 5 < mappoint_matched_.size()) mappoint_matched_[k + 5]->prefetchObservationSlot();
         const MapPoint::Ptr &mappoint = mappoint_matched_[k];
         Vector3d velocity = (camera_->pixel2cam(pts2d_matched_undis[k]) - camera_->pixel2cam(tm_pts2d_map_undis_[k])) / dt;
         auto feature = Feature::createFeature(frame_cur_, Vector2d(velocity.x(), velocity.y()), pts2d_matched_undis[k],
