@@ -218,18 +218,11 @@ void Map::removeKeyFrame(Frame::Ptr &frame, bool isremovemappoint) {
     ModelLock lock(map_mutex_);
     if (isremovemappoint) {
         vector<ulong> mappointid;
-        Frame::FeatureList features;
-        frame->featureSnapshot(features);
-        for (size_t k = 0; k < features.size(); k++) {
-            auto &feature = features[k];
-            if (k + 12 < features.size()) prefetchShared(features[k + 12].second->mapPointHint());
-            auto mappoint = feature.second->getMapPoint();
-            if (mappoint) {
-                auto ref_frame = mappoint->referenceFrame();
-                if (ref_frame != frame) continue;
-                mappointid.push_back(mappoint->id());
-            }
-        }
+        const Frame *self = frame.get();
+        frame->forEachFeaturePipelined([&](ulong, const Feature::Ptr &feature) {
+            auto mappoint = feature->getMapPoint();
+            if (mappoint && mappoint->referenceFrame().get() == self) mappointid.push_back(mappoint->id());
+        });
         for (auto id : mappointid) {
             auto landmark = landmarks_.find(id);
             if (landmark != landmarks_.end()) {

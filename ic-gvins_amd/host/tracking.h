@@ -172,7 +172,6 @@ private:
     // is undistorted once when detected / re-anchored, and a tracked point's undistorted position comes back from the LK
     // kernel (same iteration, bit-identical; ICG_HOST_CHECK=1 re-derives them on the host and compares)
     vector<Point2f> pts2d_ref_undis_, pts2d_new_undis_;
-    Frame::FeatureList feat_snap_; // scratch for Frame::featureSnapshot
     vector<Frame::Ptr> pts2d_ref_frame_;
     vector<Vector2d> velocity_ref_, velocity_cur_;
     vector<MapPoint::Ptr> tracked_mappoint_, mappoint_matched_;

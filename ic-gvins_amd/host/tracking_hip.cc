@@ -266,26 +266,21 @@ double Tracking::keyPointParallax(const Point2f &pp0, const Point2f &pp1, const 
 int Tracking::parallaxFromReferenceMapPoints(double &parallax) { // :873-905
     parallax   = 0;
     int counts = 0;
-    frame_ref_->featureSnapshot(feat_snap_);
     const Matrix3d R10 = frame_cur_->pose().R.transpose() * frame_ref_->pose().R; // loop invariant of :890
-    constexpr size_t AHEAD = 12; // features whose map points are requested from memory before they are locked
-    for (size_t k = 0; k < std::min(AHEAD, feat_snap_.size()); k++) prefetchShared(feat_snap_[k].second->mapPointHint());
-    for (size_t fi = 0; fi < feat_snap_.size(); fi++) {
-        auto &feature = feat_snap_[fi];
-        if (fi + AHEAD < feat_snap_.size()) prefetchShared(feat_snap_[fi + AHEAD].second->mapPointHint());
-        auto mappoint = feature.second->getMapPoint();
+    frame_ref_->forEachFeaturePipelined([&](ulong, const Feature::Ptr &feature) {
+        auto mappoint = feature->getMapPoint();
         if (mappoint) {
             std::shared_ptr<Feature> feat; // !isOutlier() && observations().back().lock() (:880-887)
-            if (!mappoint->lastObservationUnlessOutlier(feat)) continue;
+            if (!mappoint->lastObservationUnlessOutlier(feat)) return;
             if (feat && !feat->isOutlier()) {
                 auto frame = feat->getFrame();
                 if (frame && (frame == frame_cur_)) {
-                    parallax += keyPointParallax(feature.second->keyPoint(), feat->keyPoint(), R10);
+                    parallax += keyPointParallax(feature->keyPoint(), feat->keyPoint(), R10);
                     counts++;
                 }
             }
         }
-    }
+    });
     if (counts != 0) parallax /= counts;
     return counts;
 }
@@ -606,19 +601,17 @@ bool Tracking::queueDetection(Frame::Ptr &frame, bool ismask, StageBatch &next) 
         const long idx = (long) row * block_cols_ + col;
         if (idx >= 0 && idx < (long) block_cnts_) features_cnts[(size_t) idx]++;
     };
-    frame->featureSnapshot(feat_snap_);
-    for (const auto &feature : feat_snap_) count(feature.second->keyPoint().x, feature.second->keyPoint().y);
+    frame->forEachFeaturePipelined([&](ulong, const Feature::Ptr &feature) { count(feature->keyPoint().x, feature->keyPoint().y); });
     for (auto &pts2d : pts2d_new_) count(pts2d.x, pts2d.y);
     det_job_     = (int) next.det_slots.size();
     det_ismask_  = ismask;
     det_frame_   = frame;
     next.det_slots.push_back(frame->deviceSlot());
     if (ismask) { // :610-620
-        if (frame != frame_cur_) frame_cur_->featureSnapshot(feat_snap_);
-        for (const auto &pt : feat_snap_) {
-            next.det_mask_pts.push_back(pt.second->keyPoint().x);
-            next.det_mask_pts.push_back(pt.second->keyPoint().y);
-        }
+        frame_cur_->forEachFeaturePipelined([&](ulong, const Feature::Ptr &pt) {
+            next.det_mask_pts.push_back(pt->keyPoint().x);
+            next.det_mask_pts.push_back(pt->keyPoint().y);
+        });
         for (const auto &pts2d : pts2d_new_) {
             next.det_mask_pts.push_back(pts2d.x);
             next.det_mask_pts.push_back(pts2d.y);
@@ -665,25 +658,20 @@ void Tracking::queueTrackMappoint(StageBatch &next) {
     tm_pts2d_map_undis_.clear();
     tm_type_.clear();
     vector<Point2f> pts2d_matched;
-    frame_pre_->featureSnapshot(feat_snap_);
     Pose pose_cur = frame_cur_->pose();
-    pts2d_matched.reserve(feat_snap_.size());
-    constexpr size_t AHEAD = 12;
-    for (size_t k = 0; k < std::min(AHEAD, feat_snap_.size()); k++) prefetchShared(feat_snap_[k].second->mapPointHint());
-    for (size_t fi = 0; fi < feat_snap_.size(); fi++) {
-        auto &feature = feat_snap_[fi];
-        if (fi + AHEAD < feat_snap_.size()) prefetchShared(feat_snap_[fi + AHEAD].second->mapPointHint());
-        auto mappoint = feature.second->getMapPoint();
+    pts2d_matched.reserve(frame_pre_->numFeatures());
+    frame_pre_->forEachFeaturePipelined([&](ulong, const Feature::Ptr &feature) {
+        auto mappoint = feature->getMapPoint();
         Vector3d pos;
         MapPointType type;
         if (mappoint && mappoint->trackingView(pos, type)) { // !isOutlier(), pos(), mapPointType() in one critical section
-            tm_pts2d_map_undis_.push_back(feature.second->keyPoint());
-            tm_pts2d_map_.push_back(feature.second->distortedKeyPoint());
+            tm_pts2d_map_undis_.push_back(feature->keyPoint());
+            tm_pts2d_map_.push_back(feature->distortedKeyPoint());
             tm_type_.push_back(type);
             pts2d_matched.emplace_back(camera_->world2pixel(pos, pose_cur)); // INS-aided prediction :367
             mappoint_matched_.push_back(std::move(mappoint));
         }
-    }
+    });
     lk_map_begin_ = (int) next.lk_prev_slot.size();
     lk_map_n_     = (int) pts2d_matched.size();
     if (pts2d_matched.empty()) return; // :372-375
