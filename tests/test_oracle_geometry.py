@@ -282,3 +282,84 @@ def test_triangulation_recovers_point(oracle):
         pc1 = c1 / c1[2]
         pw = oracle.triangulate(T0, T1, pc0, pc1)
         assert np.abs(pw - Xw).max() < 1e-8 * max(1, np.abs(Xw).max())
+
+
+def test_undistort_points_vs_numpy_restatement(oracle):
+    """cv::undistortPoints(pts, K, D, noArray(), K) (camera.cc:72-74; SURVEY.md App. B.6) restated independently in numpy float64: exactly 5
+    fixed-point iterations, skew ignored on the input side and applied on the output side, one rounding to float — bit for bit"""
+    import synth
+    for cam in (synth.CAM_1280, synth.CAM_640, [700.0, 705.0, 631.0, 352.0, 0.8, -0.31, 0.12, 1e-3, -7e-4, -0.02]):
+        fx, fy, cx, cy, skew, k1, k2, p1, p2, k3 = [np.float64(v) for v in cam]
+        pts = synth.random_points(300, 1280, 720, 0, seed=41)
+        u, v = pts[:, 0].astype(np.float64), pts[:, 1].astype(np.float64)
+        x0, y0 = (u - cx) / fx, (v - cy) / fy
+        x, y = x0.copy(), y0.copy()
+        for _ in range(5):
+            r2 = x * x + y * y
+            icd = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+            assert np.all(icd > 0)
+            dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+            dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+            x, y = (x0 - dx) * icd, (y0 - dy) * icd
+        exp = np.stack([fx * x + skew * y + cx, fy * y + cy], 1).astype(np.float32)
+        got = oracle.undistort(cam, pts)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+def _corner_subpix_numpy(img, roi, corner, mask11):
+    """cv::cornerSubPix(block, (5,5), (-1,-1), (COUNT+EPS, 20, 0.01)) for ONE corner, written from SURVEY.md App. B.8 (independent of
+    oracle/orc_detect.cc): float bilinear 13x13 patch with replicate border at the ROI edge, double accumulation in raster order"""
+    rx, ry, rw, rh = roi
+    blk = img[ry:ry + rh, rx:rx + rw].astype(np.float32)
+    cT = np.float32(corner)
+    cI = cT.copy()
+    for it in range(20):
+        o = cI - np.float32(6)
+        io = np.floor(o).astype(int)
+        a, b = np.float32(o[0] - io[0]), np.float32(o[1] - io[1])
+        w00, w01 = np.float32((1 - a) * (1 - b)), np.float32(a * (1 - b))
+        w10, w11 = np.float32((1 - a) * b), np.float32(a * b)
+        xs0, xs1 = np.clip(io[0] + np.arange(13), 0, rw - 1), np.clip(io[0] + np.arange(13) + 1, 0, rw - 1)
+        ys0, ys1 = np.clip(io[1] + np.arange(13), 0, rh - 1), np.clip(io[1] + np.arange(13) + 1, 0, rh - 1)
+        p = (blk[np.ix_(ys0, xs0)] * w00 + blk[np.ix_(ys0, xs1)] * w01 + blk[np.ix_(ys1, xs0)] * w10 + blk[np.ix_(ys1, xs1)] * w11).astype(np.float32)
+        sa = sb = sc = b1 = b2 = 0.0
+        for i in range(11):
+            for j in range(11):
+                m = float(mask11[i * 11 + j])
+                tgx = float(p[i + 1, j + 2]) - float(p[i + 1, j])
+                tgy = float(p[i + 2, j + 1]) - float(p[i, j + 1])
+                gxx, gxy, gyy = tgx * tgx * m, tgx * tgy * m, tgy * tgy * m
+                px, py = j - 5, i - 5
+                sa += gxx
+                sb += gxy
+                sc += gyy
+                b1 += gxx * px + gxy * py
+                b2 += gxy * px + gyy * py
+        det = sa * sc - sb * sb
+        if abs(det) <= np.finfo(np.float64).eps ** 2:
+            break
+        scale = 1.0 / det
+        c2 = np.float32([float(cI[0]) + sc * scale * b1 - sb * scale * b2, float(cI[1]) - sb * scale * b1 + sa * scale * b2])
+        err = float(np.float32(np.float32(c2[0] - cI[0]) ** 2 + np.float32(c2[1] - cI[1]) ** 2))
+        cI = c2
+        if cI[0] < 0 or cI[0] >= rw or cI[1] < 0 or cI[1] >= rh:
+            break
+        if not err > 1e-4:
+            break
+    if abs(cI[0] - cT[0]) > 5 or abs(cI[1] - cT[1]) > 5:
+        cI = cT
+    return cI
+
+
+def test_corner_subpix_vs_numpy_restatement(oracle):
+    import synth
+    w, h = 240, 200
+    img = synth.texture(w, h, seed=42)
+    roi = (20, 15, 180, 160)
+    corners = oracle.good_features(img, None, roi, 25, 0.01, 12.0)
+    assert len(corners) >= 15
+    got = oracle.corner_subpix(img, roi, corners)
+    m = oracle.subpix_mask()
+    exp = np.stack([_corner_subpix_numpy(img, roi, c, m) for c in corners])
+    assert np.abs(got - exp).max() < 2e-5  # (numpy rounds the float32 blend term by term; the oracle's expression is the same up to that)
+    assert np.abs(got - corners).max() > 0.05  # the refinement moved the corners
