@@ -127,17 +127,8 @@ __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *ro
     const int mx        = R.rx + xcol;
     unsigned long long *cbase = cand + (size_t) R.job * cand_plane + R.cand_base;
 
-    // every global load of the tile is issued up front (22 image dwords + 16 mask bytes per lane in flight together): the
-    // streaming loop below then runs from registers
-    typedef unsigned int __attribute__((aligned(1))) u32u;
-    unsigned int pix[FE_TH + 6];
-#pragma unroll
-    for (int t = 0; t < FE_TH + 6; t++) {
-        // image row R.ry + ty0 - 3 + t (rows further than one past the image only feed partial tiles)
-        const int Yr        = icg_reflect1(min(max(R.ry + ty0 - 3 + t, -1), h), h);
-        const uint8_t *rowp = img + (size_t) Yr * pitch; // wave-uniform row base + per-lane 32-bit column offset
-        pix[t]              = *reinterpret_cast<const u32u *>(rowp + base);
-    }
+    // the mask first: existing features blank discs of radius min_dist, which cover most of a tracked image — a tile whose owned pixels
+    // are ALL masked can neither raise the ROI maximum nor produce a candidate and leaves before any image byte is read
     unsigned int unmasked = 0; // bit k: the owned response of tile row k is not masked
     {
         uint8_t mk[FE_TH];
@@ -151,6 +142,17 @@ __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *ro
         for (int k = 0; k < FE_TH; k++)
             if (mk[k] != (uint8_t) gen && ty0 + k < R.rh) unmasked |= 1u << k;
         if (!own_col) unmasked = 0;
+    }
+    if (__ballot(unmasked != 0) == 0) return; // wave-uniform
+    // all image loads of the tile are issued up front (22 dwords per lane in flight together): the streaming loop runs from registers
+    typedef unsigned int __attribute__((aligned(1))) u32u;
+    unsigned int pix[FE_TH + 6];
+#pragma unroll
+    for (int t = 0; t < FE_TH + 6; t++) {
+        // image row R.ry + ty0 - 3 + t (rows further than one past the image only feed partial tiles)
+        const int Yr        = icg_reflect1(min(max(R.ry + ty0 - 3 + t, -1), h), h);
+        const uint8_t *rowp = img + (size_t) Yr * pitch; // wave-uniform row base + per-lane 32-bit column offset
+        pix[t]              = *reinterpret_cast<const u32u *>(rowp + base);
     }
     int d0 = 0, d1 = 0, s0 = 0, s1 = 0;                                    // Sobel differences of image rows t-2, t-1
     double hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0, hC0 = 0, hC1 = 0;           // horizontal 3-sums of product rows r-2, r-1

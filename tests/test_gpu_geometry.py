@@ -168,3 +168,45 @@ def test_wait_modes_give_identical_results(oracle):
             assert np.array_equal(out.view(np.uint32), ref_out.view(np.uint32))
     finally:
         c.close()
+
+
+def test_detect_dense_mask_and_fully_masked_blocks(oracle, ctx1280):
+    """a tracked frame: ~250 existing features blank most of the image (k_min_eig_nms leaves tiles whose owned pixels are all masked
+    before reading the image), plus one frame whose mask covers EVERYTHING (no corner, like the oracle)"""
+    w, h = 1280, 720
+    imgs = [synth.texture(w, h, seed=83), synth.texture(w, h, seed=84)]
+    ctx1280.preprocess([0, 1], imgs)
+    grid = grid_for(w, h, 300)
+    nblk = grid[0] * grid[1]
+    dense = synth.random_points(250, w, h, 0, seed=93)
+    gx, gy = np.meshgrid(np.arange(0, w + 40, 40, dtype=np.float32), np.arange(0, h + 40, 40, dtype=np.float32))
+    everything = np.stack([gx.ravel(), gy.ravel()], 1)  # discs of radius 45 on a 40-px lattice cover the plane
+    masks = [dense, everything]
+    quotas = [np.full(nblk, grid[5], np.int32)] * 2
+    mask_off = np.cumsum([0] + [len(m) for m in masks]).astype(np.int32)
+    out, cnt, blk = ctx1280.detect([0, 1], grid, mask_off, np.concatenate(masks), np.concatenate(quotas), 400)
+    for j, img in enumerate(imgs):
+        exp_pts, exp_blk = oracle.detect(oracle.clahe(img), grid, masks[j], quotas[j], 400)
+        assert cnt[j] == len(exp_pts)
+        assert np.array_equal(blk[j, :cnt[j]], exp_blk)
+        assert np.array_equal(out[j, :cnt[j]].view(np.uint32), exp_pts.view(np.uint32))
+    assert 0 < cnt[0] < 200 and cnt[1] == 0
+
+
+def test_fm_ransac_check_subset_on_lattice_points(oracle, ctx1280):
+    """FMEstimatorCallback::checkSubset on the device path: lattice points have many collinear triples, so subsets are rejected and
+    redrawn (the RNG keeps advancing) — the mask must still equal the oracle's; a set on ONE line has no valid subset at all"""
+    gx, gy = np.meshgrid(np.arange(8, dtype=np.float32) * 35 + 90, np.arange(6, dtype=np.float32) * 35 + 70)
+    p1 = np.stack([gx.ravel(), gy.ravel()], 1)
+    rng = np.random.RandomState(3)
+    p2 = (p1 * np.float32(1.01) + np.float32([4.0, -2.5])).astype(np.float32)
+    p2[::7] += rng.uniform(-30, 30, (len(p2[::7]), 2)).astype(np.float32)  # gross outliers
+    line = np.stack([np.arange(24, dtype=np.float32) * 9 + 20, np.arange(24, dtype=np.float32) * 4 + 11], 1)
+    sets = [(p1, p2), (line, (line + np.float32(2.0)).astype(np.float32))]
+    offsets = np.cumsum([0] + [len(s[0]) for s in sets]).astype(np.int32)
+    mask = ctx1280.fm_ransac(offsets, np.concatenate([s[0] for s in sets]), np.concatenate([s[1] for s in sets]))
+    ok, exp, _, _ = oracle.fm_ransac(p1, p2)
+    assert np.array_equal(mask[:len(p1)], exp)
+    assert not np.array_equal(oracle.ransac_subsets(len(p1), 30, p1, p2), oracle.ransac_subsets(len(p1), 30))  # rejections did happen
+    ok2, exp2, _, it2 = oracle.fm_ransac(*sets[1])
+    assert ok2 == 0 and it2 == 0 and np.array_equal(mask[len(p1):], exp2) and mask[len(p1):].sum() == 0
