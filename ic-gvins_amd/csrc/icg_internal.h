@@ -1,5 +1,6 @@
 // Internal definitions shared by the HIP translation units of libicgvins_hip.so (gfx950 only).
 #pragma once
+#include <utility>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -199,6 +200,7 @@ struct icg_call {
         bool zc;
     };
     std::vector<outrec> outs;
+    std::vector<std::pair<size_t, size_t>> zc_regions; // [begin, end) of every zero-copy output: written by kernels through the host mapping
     explicit icg_call(icg_ctx *c) : ctx(c) { ctx->arena_off = 0; }
     int reserve(size_t bytes) { return icg_arena_reserve(ctx, bytes + 8192); }
     template <typename T> T *in(const T *src, size_t n) {
@@ -233,6 +235,7 @@ struct icg_call {
     template <typename T> T *out_zc(T *user, size_t n) {
         size_t off = icg_arena_alloc(ctx, sizeof(T) * n);
         if (user) outs.push_back({(void *) user, off, sizeof(T) * n, true});
+        zc_regions.push_back({off, off + sizeof(T) * n});
         return reinterpret_cast<T *>(ctx->h_arena + off);
     }
     int finish() {
@@ -247,7 +250,16 @@ struct icg_call {
                 if (o.off < lo) lo = o.off;
                 if (o.off + o.bytes > hi) hi = o.off + o.bytes;
             }
-        if (hi > lo) rc = icg_arena_d2h(ctx, lo, hi);
+        // one copy for the span of all mirrored outputs — unless a zero-copy region lies inside that span: the copy would overwrite what
+        // the kernels wrote there through the host mapping with stale device-arena bytes; then every mirrored output is copied on its own
+        bool spans_zc = false;
+        for (auto &z : zc_regions) spans_zc |= z.first < hi && z.second > lo;
+        if (hi > lo && !spans_zc) {
+            rc = icg_arena_d2h(ctx, lo, hi);
+        } else if (hi > lo) {
+            for (auto &o : outs)
+                if (!o.zc && !rc) rc = icg_arena_d2h(ctx, o.off, o.off + o.bytes);
+        }
         if (rc) return rc;
         rc = icg_stream_wait(ctx);
         if (rc) return rc;

@@ -822,11 +822,13 @@ __global__ __launch_bounds__(NRM_BLOCK) void k_reproj_normal_schur_w(const win_d
 #pragma unroll
         for (int x = 0; x < 19; x++) j0[x] = j1[x] = 0.0, cc[x] = -1;
     }
+    // J^T J is symmetric: only the pairs x <= y of a factor's 19 camera columns are accumulated (half the LDS atomics, which bound this
+    // kernel); the flush adds every cell and its mirror cell into both halves of the window's matrix
 #pragma unroll
     for (int x = 0; x < 19; x++) {
         if (cc[x] < 0) continue;
 #pragma unroll
-        for (int y = 0; y < 19; y++) {
+        for (int y = x; y < 19; y++) {
             if (x >= 12 && y >= 12) continue;
             if (cc[y] < 0) continue;
             atomicAdd(&Hs[cc[x] * V + cc[y]], j0[x] * j0[y] + j1[x] * j1[y]);
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(NRM_BLOCK) void k_reproj_normal_schur_w(const win_d
 #pragma unroll
     for (int x = 12; x < 19; x++) {
 #pragma unroll
-        for (int y = 12; y < 20; y++) {
+        for (int y = x; y < 20; y++) {
             double v = (y < 19) ? j0[x] * j0[y] + j1[x] * j1[y] : -(j0[x] * r0 + j1[x] * r1);
             if (!on) v = 0.0;
 #pragma unroll
@@ -918,8 +920,9 @@ __global__ __launch_bounds__(NRM_BLOCK) void k_reproj_normal_schur_w(const win_d
         }
     }
     for (int e = t; e < V * V; e += NRM_BLOCK) {
-        const double v = Hs[e];
-        if (v != 0.0) unsafeAtomicAdd(&H[(size_t) vmap[e / V] * N + vmap[e % V]], v);
+        const int ca = e / V, cb = e - ca * V;
+        const double v = Hs[e] + (ca != cb ? Hs[cb * V + ca] : 0.0); // the cell and its mirror (x <= y accumulation above)
+        if (v != 0.0) unsafeAtomicAdd(&H[(size_t) vmap[ca] * N + vmap[cb]], v);
     }
     for (int e = t; e < V; e += NRM_BLOCK) {
         const double v = bs[e];
@@ -1127,10 +1130,12 @@ static void build_win_desc(icg_ctx *ctx, int P, const int32_t *vcol_ext, const i
     }
 }
 
-extern "C" int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td,
-                                        const uint8_t *active, const uint8_t *reassemble, const double *damp, double min_diag, double max_diag,
-                                        double *S, double *s, double *diag_cc, double *cost) {
-    if (!ctx || P <= 0 || !col_pose || !col_ext || !col_td || !reassemble || !damp || !S || !s) return ICG_ERR_INVALID;
+// S_view != nullptr: the reduced systems are written by the reduction kernel straight into the context's pinned staging memory (zero-copy)
+// and *S_view points there — no device-to-host copy and no 9 MB copy-out per LM step at 256 windows; valid until the next call on ctx
+static int schur_windows_impl(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
+                              const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, double *S, const double **S_view,
+                              double *s, double *diag_cc, double *cost) {
+    if (!ctx || P <= 0 || !col_pose || !col_ext || !col_td || !reassemble || !damp || (!S && !S_view) || !s) return ICG_ERR_INVALID;
     const bool tdbg = getenv("ICG_ABI_DEBUG") != nullptr;
     auto tnow       = [] { return std::chrono::steady_clock::now(); };
     auto t_begin    = tnow();
@@ -1215,9 +1220,15 @@ extern "C" int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_
     double *d_cost = c.inout(zeros.data(), any_new ? cost : (double *) nullptr, (size_t) W);
     auto t_prep = tnow();
     if ((rc = c.seal())) return rc;
-    double *d_S  = c.out(S, (size_t) W * P * P);
+    // (the zero-copy region is allocated LAST: finish() copies ONE device range back that spans all mirrored outputs, and must not run
+    // over memory the kernel wrote through the host mapping)
+    double *d_S  = S_view ? nullptr : c.out(S, (size_t) W * P * P);
     double *d_s  = c.out(s, (size_t) W * P);
     double *d_dg = c.out(diag_cc, (size_t) W * P);
+    if (S_view) {
+        d_S     = c.out_zc((double *) nullptr, (size_t) W * P * P);
+        *S_view = d_S;
+    }
     const double *d_r = ctx->d_rJ, *d_J = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
     if (any_new) {
         icg_prof_scope ps(ctx, "reproj_normal");
@@ -1251,6 +1262,18 @@ extern "C" int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_
     ctx->wsys_P = P, ctx->wsys_valid = 1;
     ctx->sys_min_diag = min_diag, ctx->sys_max_diag = max_diag;
     return ICG_OK;
+}
+
+extern "C" int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td,
+                                        const uint8_t *active, const uint8_t *reassemble, const double *damp, double min_diag, double max_diag,
+                                        double *S, double *s, double *diag_cc, double *cost) {
+    return schur_windows_impl(ctx, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, S, nullptr, s, diag_cc, cost);
+}
+
+extern "C" int icg_reproj_schur_windows_view(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td,
+                                             const uint8_t *active, const uint8_t *reassemble, const double *damp, double min_diag,
+                                             double max_diag, const double **S_view, double *s, double *diag_cc, double *cost) {
+    return schur_windows_impl(ctx, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, nullptr, S_view, s, diag_cc, cost);
 }
 
 extern "C" int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
@@ -1306,6 +1329,33 @@ extern "C" int icg_reproj_cost_windows(icg_ctx *ctx, const uint8_t *active, doub
 }
 
 // the resident residuals of the last evaluation (n x 2), e.g. for the per-factor chi-square test after icg_reproj_eval_windows
+__global__ void k_reproj_chi2(int n, const double *r, double chi2, const uint8_t *active_in, uint8_t *active_out) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const double r0 = r[2 * (size_t) f], r1 = r[2 * (size_t) f + 1];
+    const double cost = 0.5 * (r0 * r0 + r1 * r1); // EvaluateResidualBlock(id, false, &cost, ...) (ic_gvins.cc:1278)
+    active_out[f]     = (active_in[f] && !(cost * 2.0 > chi2)) ? 1 : 0;
+}
+
+extern "C" int icg_reproj_chi2_cull(icg_ctx *ctx, double chi2, uint8_t *active) {
+    if (!ctx || !active) return ICG_ERR_INVALID;
+    if (!ctx->rJ_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident residuals");
+    const int n = ctx->n_factors_resident;
+    if (n == 0) return ICG_OK;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    icg_call c(ctx);
+    int rc = c.reserve(2 * (size_t) n + 4096);
+    if (rc) return rc;
+    const uint8_t *d_in = c.in_zc(active, (size_t) n);
+    uint8_t *d_out      = c.out_zc(active, (size_t) n);
+    {
+        icg_prof_scope ps(ctx, "reproj_chi2");
+        hipLaunchKernelGGL(k_reproj_chi2, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, (const double *) ctx->d_rJ, chi2, d_in, d_out);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}
+
 extern "C" int icg_reproj_fetch_residuals(icg_ctx *ctx, double *out_r) {
     if (!ctx || !out_r) return ICG_ERR_INVALID;
     if (!ctx->rJ_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident residuals");

@@ -32,6 +32,7 @@ template <typename F> void WindowSolverBatch::forEachWindow(size_t n, F &&fn) {
 
 WindowSolverBatch::WindowSolverBatch(int device, double huber_delta, int host_threads) : huber_(huber_delta) {
     host_threads_ = host_threads > 0 ? host_threads : (int) std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("ICG_SOLVER_THREADS")) host_threads_ = std::max(1, atoi(e)); // diagnostics
     icg_ctx_config cfg{};
     cfg.device = device, cfg.width = 64, cfg.height = 64, cfg.n_slots = 1, cfg.max_batch = 1, cfg.max_points = 64;
     if (icg_ctx_create(&cfg, &ctx_) != ICG_OK) throw std::runtime_error(std::string("WindowSolverBatch: ") + icg_last_error(nullptr));
@@ -187,15 +188,16 @@ bool WindowSolverBatch::layout() {
     return P_ > 0;
 }
 
-void WindowSolverBatch::gather(std::vector<double> &poses, std::vector<double> &ext, std::vector<double> &inv, std::vector<double> &td) const {
+void WindowSolverBatch::gather(std::vector<double> &poses, std::vector<double> &ext, std::vector<double> &inv, std::vector<double> &td) {
     poses.resize(7 * (size_t) n_poses_), ext.assign(7 * windows_.size(), 0.0), inv.resize((size_t) n_lm_), td.assign(windows_.size(), 0.0);
-    for (size_t w = 0; w < windows_.size(); w++) {
+    // (scattered reads through the callers' parameter pointers: spread over the pool like the other per-window phases)
+    forEachWindow(windows_.size(), [&](size_t w) {
         const Window &W = windows_[w];
         for (size_t k = 0; k < W.poses.size(); k++) memcpy(&poses[7 * ((size_t) W.pose_begin + k)], W.poses[k], sizeof(double) * 7);
         for (size_t k = 0; k < W.landmarks.size(); k++) inv[(size_t) W.lm_begin + k] = *W.landmarks[k];
         if (W.ext) memcpy(&ext[7 * w], W.ext, sizeof(double) * 7);
         if (W.td) td[w] = *W.td;
-    }
+    });
 }
 
 namespace {
@@ -225,16 +227,18 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
         double radius, dec, cost, new_cost, model;
         bool done, relinearize, redamp, stepped;
         int iters;
-        std::vector<double> S, s, diag, delta_c, dd;
+        std::vector<double> s, diag, delta_c, dd;
     };
     std::vector<State> st(NW);
     std::vector<Summary> sum(NW);
     for (size_t w = 0; w < NW; w++) {
-        st[w] = State{o.initial_trust_region_radius, 2.0, 0, 0, 0, false, true, false, false, 0, {}, {}, {}, {}, {}};
+        st[w] = State{o.initial_trust_region_radius, 2.0, 0, 0, 0, false, true, false, false, 0, {}, {}, {}, {}};
         sum[w].termination = "max_num_iterations";
     }
-    std::vector<double> poses, ext, inv, td, S((size_t) NW * P * P), s((size_t) NW * P), diag((size_t) NW * P), cost(NW), delta_c((size_t) NW * P),
-        delta_l((size_t) n_lm_), terms(2 * NW), damp(NW);
+    std::vector<double> poses, ext, inv, td, s((size_t) NW * P), diag((size_t) NW * P), cost(NW), delta_c((size_t) NW * P), delta_l((size_t) n_lm_),
+        terms(2 * NW), damp(NW);
+    const double *S = nullptr; // W x P x P reduced systems, left in the context's pinned staging memory by the reduction kernel (valid until
+                               // the next call on ctx_: consumed by the reduced solves below, before the back-substitution call)
     std::vector<uint8_t> reassemble(NW);
     auto fail = [&](const char *what) {
         error_ = std::string(what) + ": " + icg_last_error(ctx_);
@@ -259,9 +263,9 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
         }
         if (any_sys) {
             clk.start();
-            if (icg_reproj_schur_windows(ctx_, P, col_pose_.data(), col_ext_.data(), col_td_.data(), active_.data(), reassemble.data(), damp.data(),
-                                         o.min_lm_diagonal, o.max_lm_diagonal, S.data(), s.data(), diag.data(), cost.data()) != ICG_OK)
-                return fail("icg_reproj_schur_windows");
+            if (icg_reproj_schur_windows_view(ctx_, P, col_pose_.data(), col_ext_.data(), col_td_.data(), active_.data(), reassemble.data(), damp.data(),
+                                              o.min_lm_diagonal, o.max_lm_diagonal, &S, s.data(), diag.data(), cost.data()) != ICG_OK)
+                return fail("icg_reproj_schur_windows_view");
             clk.stop(1);
             clk.start();
             std::atomic<int> host_failed{0};
@@ -279,11 +283,13 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
                     // trial cost and is kept (the same bookkeeping as WindowSolver)
                     if (first) st[w].cost = cost[w] + hc, sum[w].initial_cost = st[w].cost;
                 }
-                st[w].S.assign(S.begin() + (long) (w * P * P), S.begin() + (long) ((w + 1) * P * P));
-                st[w].s.assign(s.begin() + (long) (w * P), s.begin() + (long) ((w + 1) * P));
-                st[w].diag.assign(diag.begin() + (long) (w * P), diag.begin() + (long) ((w + 1) * P));
-                for (size_t k = 0; k < st[w].S.size(); k++) st[w].S[k] += W.host_S[k];
-                for (int k = 0; k < P; k++) st[w].s[(size_t) k] += W.host_s[(size_t) k], st[w].diag[(size_t) k] += W.host_diag[(size_t) k];
+                // the window's reduced system is used where it arrived (S, s, diag of the batched call) plus the host factors' part: no
+                // per-window copy of the P x P block (9 MB per step at 256 windows)
+                st[w].s.resize((size_t) P), st[w].diag.resize((size_t) P);
+                for (int k = 0; k < P; k++) {
+                    st[w].s[(size_t) k]    = s[w * P + (size_t) k] + W.host_s[(size_t) k];
+                    st[w].diag[(size_t) k] = diag[w * P + (size_t) k] + W.host_diag[(size_t) k];
+                }
                 st[w].relinearize = st[w].redamp = false;
             });
             if (host_failed.load()) {
@@ -315,8 +321,9 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
             T.dd.assign((size_t) P, 0.0);
             const int Pw = windows_[w].P; // columns beyond Pw are empty (zero rows): solve the leading block only
             std::vector<double> Ab((size_t) Pw * Pw), bb(T.s.begin(), T.s.begin() + Pw);
+            const double *Sw = &S[w * (size_t) P * P], *Hw = windows_[w].host_S.data();
             for (int i = 0; i < Pw; i++)
-                for (int j = 0; j < Pw; j++) Ab[(size_t) i * Pw + j] = T.S[(size_t) i * P + j];
+                for (int j = 0; j < Pw; j++) Ab[(size_t) i * Pw + j] = Sw[(size_t) i * P + j] + Hw[(size_t) i * P + j];
             for (int k = 0; k < Pw; k++) {
                 T.dd[(size_t) k] = std::min(std::max(T.diag[(size_t) k], o.min_lm_diagonal), o.max_lm_diagonal) / T.radius;
                 Ab[(size_t) k * Pw + k] += T.dd[(size_t) k];
@@ -443,23 +450,21 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
 std::vector<int> WindowSolverBatch::removeReprojectionFactorsByChi2(double chi2) {
     std::vector<int> removed(windows_.size(), 0);
     if (!finalized_ && !finalize()) return removed;
-    std::vector<double> poses, ext, inv, td, r(2 * (size_t) n_factors_);
+    std::vector<double> poses, ext, inv, td;
     gather(poses, ext, inv, td);
-    // raw residuals, no loss: problem.EvaluateResidualBlock(id, false, &cost, ...) with cost = 0.5 |r|^2 (ic_gvins.cc:1278-1284)
+    // raw residuals, no loss: problem.EvaluateResidualBlock(id, false, &cost, ...) with cost = 0.5 |r|^2 (ic_gvins.cc:1278-1284); the
+    // test runs where the residuals are, only the flags come back
+    std::vector<uint8_t> before(active_);
     if (icg_reproj_eval_windows(ctx_, n_poses_, poses.data(), ext.data(), n_lm_, inv.data(), td.data(), 0, 0.0) != ICG_OK ||
-        icg_reproj_fetch_residuals(ctx_, r.data()) != ICG_OK) {
+        icg_reproj_chi2_cull(ctx_, chi2, active_.data()) != ICG_OK) {
         error_ = icg_last_error(ctx_);
+        active_.swap(before);
         return removed;
     }
     for (size_t w = 0; w < windows_.size(); w++)
         for (size_t k = 0; k < windows_[w].visual.size(); k++) {
             const size_t f = (size_t) windows_[w].fac_begin + k;
-            if (!active_[f]) continue;
-            const double cost = 0.5 * (r[2 * f] * r[2 * f] + r[2 * f + 1] * r[2 * f + 1]);
-            if (cost * 2.0 > chi2) {
-                active_[f] = 0;
-                removed[w]++;
-            }
+            if (before[f] && !active_[f]) removed[w]++;
         }
     return removed;
 }

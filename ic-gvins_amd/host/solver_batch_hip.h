@@ -72,7 +72,7 @@ private:
     };
     bool finalize();
     bool layout();
-    void gather(std::vector<double> &poses, std::vector<double> &ext, std::vector<double> &inv, std::vector<double> &td) const;
+    void gather(std::vector<double> &poses, std::vector<double> &ext, std::vector<double> &inv, std::vector<double> &td);
 
     // fn(w) for every window on the persistent helper threads (created on first use: a batch of one or two windows never needs them)
     template <typename F> void forEachWindow(size_t n, F &&fn);

@@ -215,10 +215,19 @@ int icg_reproj_eval_windows(icg_ctx *ctx, int n_poses, const double *poses, cons
 int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
                              const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, double *S, double *s,
                              double *diag_cc, double *cost);
+/* the same call with the W x P x P reduced systems left where the reduction kernel writes them (the context's pinned staging memory):
+ * *S_view is valid until the next call on ctx.  Saves the device-to-host copy and the copy-out of 9 MB per LM step at 256 C2 windows. */
+int icg_reproj_schur_windows_view(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
+                                  const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, const double **S_view, double *s,
+                                  double *diag_cc, double *cost);
 int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms);
 int icg_reproj_cost_windows(icg_ctx *ctx, const uint8_t *active, double *cost);
 /* the resident residuals of the last evaluation (n x 2 doubles): per-factor tests (chi-square culling) after a resident evaluation */
 int icg_reproj_fetch_residuals(icg_ctx *ctx, double *out_r);
+/* GVINS::removeReprojectionFactorsByChi2 (ic_gvins.cc:1269-1297) on the resident residuals of a want_jac = 0, huber = 0 evaluation:
+ * factor f stays active iff it was active and NOT  (0.5 |r_f|^2) * 2.0 > chi2  (the reference's test on EvaluateResidualBlock's cost).
+ * active (n bytes) is updated in place; only the flags cross the link instead of 16 bytes of residual per factor. */
+int icg_reproj_chi2_cull(icg_ctx *ctx, double chi2, uint8_t *active);
 
 /* ---- P1: preintegration inner loop (preintegration/preintegration_base.cc:39-70, preintegration_earth.cc:205-303,
  * preintegration_normal.cc:183-232), batched over independent intervals.

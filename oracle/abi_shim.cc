@@ -260,6 +260,7 @@ struct shim_backend {
     int W = 0;
     std::vector<int32_t> fac_off, lm_off;
     std::vector<std::vector<double>> wH, wb, winv;
+    std::vector<double> S_view; // icg_reproj_schur_windows_view: the reduced systems stay here until the next call
     std::vector<double> wdamp;
     int wP = 0;
 };
@@ -430,6 +431,15 @@ int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const
     return ICG_OK;
 }
 
+int icg_reproj_schur_windows_view(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
+                                  const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, const double **S_view, double *s,
+                                  double *diag_cc, double *cost) {
+    shim_backend &B = g_backend[ctx];
+    B.S_view.assign((size_t) std::max(0, B.W) * P * P, 0.0);
+    *S_view = B.S_view.data();
+    return icg_reproj_schur_windows(ctx, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, B.S_view.data(), s, diag_cc, cost);
+}
+
 int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
     shim_backend &B = g_backend[ctx];
     if (B.W <= 0 || B.wP != P) return ICG_ERR_INVALID;
@@ -437,6 +447,16 @@ int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, doubl
         const int l0 = B.lm_off[(size_t) w], L = B.lm_off[(size_t) w + 1] - l0;
         orc_schur_backsub(P, L, B.wH[(size_t) w].data(), B.wb[(size_t) w].data(), B.winv[(size_t) w].data(), B.wdamp[(size_t) w], B.min_diag, B.max_diag,
                           delta_c + (size_t) w * P, delta_l + l0, lm_terms ? lm_terms + 2 * (size_t) w : nullptr);
+    }
+    return ICG_OK;
+}
+
+int icg_reproj_chi2_cull(icg_ctx *ctx, double chi2, uint8_t *active) {
+    shim_backend &B = g_backend[ctx];
+    for (int f = 0; f < B.n; f++) {
+        const double r0 = B.r[2 * (size_t) f], r1 = B.r[2 * (size_t) f + 1];
+        const double cost = 0.5 * (r0 * r0 + r1 * r1);
+        if (cost * 2.0 > chi2) active[f] = 0;
     }
     return ICG_OK;
 }
