@@ -255,9 +255,10 @@ extern "C" int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa
     return ICG_OK;
 }
 
-extern "C" int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm,
-                                        const double *invdepth, double td, int want_jac, double huber_delta,
-                                        double *out_r, double *out_J) {
+// r_view / J_view != nullptr: the results are left in the context's pinned staging memory after the device-to-host copy and the views point
+// there (valid until the next call on ctx) — the per-factor Evaluate() surface reads them in place, no 1 MB copy-out per window
+static int eval_resident_impl(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm, const double *invdepth, double td,
+                              int want_jac, double huber_delta, double *out_r, double *out_J, const double **r_view, const double **J_view) {
     if (!ctx || !poses || !ext || !invdepth || n_poses <= 0 || n_lm <= 0) return ICG_ERR_INVALID;
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
     const int n = ctx->n_factors_resident;
@@ -307,18 +308,33 @@ extern "C" int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double 
     ctx->last_huber   = huber_delta;
     ctx->last_n_poses = n_poses;
     ctx->last_n_lm    = n_lm;
-    if (out_r) {
+    if (out_r || r_view) {
         ICG_HIP(ctx, hipMemcpyAsync(icg_h<double>(ctx, o_r), A.out_r, rbytes, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (out_J && want_jac) {
+    if ((out_J || J_view) && want_jac) {
         ICG_HIP(ctx, hipMemcpyAsync(icg_h<double>(ctx, o_J), A.out_J, jbytes, hipMemcpyDeviceToHost, ctx->stream));
     }
     ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     icg_prof_collect(ctx);
     if (out_r) memcpy(out_r, icg_h<double>(ctx, o_r), rbytes);
     if (out_J && want_jac) memcpy(out_J, icg_h<double>(ctx, o_J), jbytes);
+    if (r_view) *r_view = icg_h<double>(ctx, o_r);
+    if (J_view) *J_view = want_jac ? icg_h<double>(ctx, o_J) : nullptr;
     ctx->arena_off = 0;
     return ICG_OK;
+}
+
+extern "C" int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm,
+                                        const double *invdepth, double td, int want_jac, double huber_delta,
+                                        double *out_r, double *out_J) {
+    return eval_resident_impl(ctx, n_poses, poses, ext, n_lm, invdepth, td, want_jac, huber_delta, out_r, out_J, nullptr, nullptr);
+}
+
+extern "C" int icg_reproj_eval_resident_view(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm,
+                                             const double *invdepth, double td, int want_jac, double huber_delta,
+                                             const double **r_view, const double **J_view) {
+    if (!r_view || !J_view) return ICG_ERR_INVALID;
+    return eval_resident_impl(ctx, n_poses, poses, ext, n_lm, invdepth, td, want_jac, huber_delta, nullptr, nullptr, r_view, J_view);
 }
 
 extern "C" int icg_reproj_eval_batch(icg_ctx *ctx, int n, const double *obs_soa, const int32_t *idx_i,

@@ -126,8 +126,6 @@ void ReprojectionBatch::finalize() {
         for (int c = 0; c < 15; c++) obs[(size_t) c * n + k] = factors_[(size_t) k]->obs_[c];
     if (icg_reproj_set_factors(ctx_, n, obs.data(), idx_i_.data(), idx_j_.data(), idx_lm_.data()) != ICG_OK)
         throw std::runtime_error(std::string("icg_reproj_set_factors: ") + icg_last_error(ctx_));
-    r_.assign((size_t) 2 * n, 0.0);
-    J_.assign((size_t) 46 * n, 0.0);
     finalized_ = true;
     prepared_  = false;
 }
@@ -142,8 +140,11 @@ bool ReprojectionBatch::run(bool want_jac, double huber, bool fetch) {
     vector<double> poses(7 * pose_ptrs_.size()), inv(lm_ptrs_.size());
     for (size_t k = 0; k < pose_ptrs_.size(); k++) memcpy(&poses[7 * k], pose_ptrs_[k], sizeof(double) * 7);
     for (size_t k = 0; k < lm_ptrs_.size(); k++) inv[k] = *lm_ptrs_[k];
-    int rc = icg_reproj_eval_resident(ctx_, (int) pose_ptrs_.size(), poses.data(), ext_, (int) lm_ptrs_.size(), inv.data(), *td_,
-                                      want_jac ? 1 : 0, huber, fetch ? r_.data() : nullptr, (fetch && want_jac) ? J_.data() : nullptr);
+    r_view_ = J_view_ = nullptr;
+    int rc = fetch ? icg_reproj_eval_resident_view(ctx_, (int) pose_ptrs_.size(), poses.data(), ext_, (int) lm_ptrs_.size(), inv.data(), *td_,
+                                                   want_jac ? 1 : 0, huber, &r_view_, &J_view_)
+                   : icg_reproj_eval_resident(ctx_, (int) pose_ptrs_.size(), poses.data(), ext_, (int) lm_ptrs_.size(), inv.data(), *td_,
+                                              want_jac ? 1 : 0, huber, nullptr, nullptr);
     if (rc != ICG_OK) {
         error_ = icg_last_error(ctx_);
         return false;
@@ -155,7 +156,8 @@ bool ReprojectionBatch::run(bool want_jac, double huber, bool fetch) {
 
 void ReprojectionBatch::PrepareForEvaluation(bool evaluate_jacobians, bool /*new_evaluation_point*/) { run(evaluate_jacobians, 0.0); }
 
-bool ReprojectionBatch::evaluateCorrected(double huber_delta) { return run(true, huber_delta); }
+// (the marginalization never reads a factor's slice: the batch is assembled on the device, nothing is fetched)
+bool ReprojectionBatch::evaluateCorrected(double huber_delta) { return run(true, huber_delta, false); }
 
 bool ReprojectionBatch::accumulateNormal(const std::unordered_map<const double *, int> &column_of, int local_size, double *H0,
                                          double *b0) {
@@ -167,6 +169,7 @@ bool ReprojectionBatch::accumulateNormal(const std::unordered_map<const double *
     vector<int32_t> cp(pose_ptrs_.size()), cl(lm_ptrs_.size());
     for (size_t k = 0; k < pose_ptrs_.size(); k++) cp[k] = col(pose_ptrs_[k]);
     for (size_t k = 0; k < lm_ptrs_.size(); k++) cl[k] = col(lm_ptrs_[k]);
+    prepared_ = false; // (any further call on the context invalidates the fetched views)
     int rc = icg_reproj_accumulate_normal(ctx_, local_size, cp.data(), col(ext_), cl.data(), col(td_), H0, b0);
     if (rc != ICG_OK) {
         error_ = icg_last_error(ctx_);
@@ -185,6 +188,7 @@ bool ReprojectionBatch::accumulateLandmarkEliminated(const std::unordered_map<co
     vector<int32_t> cp(pose_ptrs_.size());
     for (size_t k = 0; k < pose_ptrs_.size(); k++) cp[k] = col(pose_ptrs_[k]);
     vector<double> S((size_t) P * P), s((size_t) P), hll(lm_ptrs_.size());
+    prepared_ = false;
     int rc = icg_reproj_schur(ctx_, P, cp.data(), col(ext_), col(td_), nullptr, 1, 0.0, 0.0, 0.0, S.data(), s.data(), nullptr, nullptr);
     if (rc == ICG_OK) rc = icg_reproj_landmark_diag(ctx_, hll.data());
     if (rc != ICG_OK) {

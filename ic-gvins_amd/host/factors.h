@@ -79,8 +79,9 @@ public:
     bool accumulateLandmarkEliminated(const std::unordered_map<const double *, int> &camera_column_of, int P, double *H, double *b,
                                       double *min_hll);
     const vector<double *> &landmarkBlocks() const { return lm_ptrs_; }
-    const double *residual(int slot) const { return r_.data() + 2 * (size_t) slot; }
-    const double *jacobian(int slot) const { return J_.data() + 46 * (size_t) slot; }
+    // slices of the last fetched evaluation, read in place from the context's pinned staging memory (valid while prepared())
+    const double *residual(int slot) const { return r_view_ + 2 * (size_t) slot; }
+    const double *jacobian(int slot) const { return J_view_ + 46 * (size_t) slot; }
     bool prepared(bool with_jacobians) const { return prepared_ && (!with_jacobians || has_jac_); }
     const std::string &error() const { return error_; }
     // completion waits of this batch's context: busy-wait (default, lowest latency for one solver) or poll + sleep (many solvers
@@ -97,7 +98,7 @@ private:
     std::unordered_map<const double *, int> pose_index_, lm_index_;
     vector<int32_t> idx_i_, idx_j_, idx_lm_;
     double *ext_{nullptr}, *td_{nullptr};
-    vector<double> r_, J_;
+    const double *r_view_{nullptr}, *J_view_{nullptr};
     bool finalized_{false}, prepared_{false}, has_jac_{false};
     std::string error_;
 };

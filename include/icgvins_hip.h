@@ -169,6 +169,10 @@ int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa, const int
 int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm,
                              const double *invdepth, double td, int want_jac, double huber_delta, double *out_r,
                              double *out_J);
+/* the same evaluation with r (n x 2) and J (n x 46) left in the context's pinned staging memory: *r_view / *J_view are valid until the
+ * next call on ctx.  ReprojectionBatch (the ceres::EvaluationCallback of boundary B1) hands each factor's Evaluate() its slice of the views. */
+int icg_reproj_eval_resident_view(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm, const double *invdepth,
+                                  double td, int want_jac, double huber_delta, const double **r_view, const double **J_view);
 
 /* ---- M2: MarginalizationInfo::constructEquation (factors/marginalization_info.h:195-230) for the reprojection
  * factors of the last icg_reproj_eval_* call (Jacobians still resident): accumulates H0 += J^T J, b0 -= J^T e into

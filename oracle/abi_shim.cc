@@ -304,6 +304,15 @@ int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double *poses, con
     return ICG_OK;
 }
 
+int icg_reproj_eval_resident_view(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm, const double *invdepth, double td,
+                                  int want_jac, double huber_delta, const double **r_view, const double **J_view) {
+    int rc = icg_reproj_eval_resident(ctx, n_poses, poses, ext, n_lm, invdepth, td, want_jac, huber_delta, nullptr, nullptr);
+    shim_backend &B = g_backend[ctx];
+    *r_view = B.r.data();
+    *J_view = want_jac ? B.J.data() : nullptr;
+    return rc;
+}
+
 int icg_reproj_accumulate_normal(icg_ctx *ctx, int local_size, const int32_t *col_pose, int32_t col_ext, const int32_t *col_lm,
                                  int32_t col_td, double *H0, double *b0) {
     shim_backend &B = g_backend[ctx];

@@ -30,7 +30,7 @@ out = os.path.join({tmp!r}, "icg_out")
 os.makedirs(out, exist_ok=True)
 p = lambda a: a.ctypes.data_as(C.c_void_p)
 state = lib.ref_gvins_icg_run(files["config"].encode(), out.encode(), len(imu), p(imu), len(gn), p(gn), len(stamps), p(stamps), p(imgs), seq.w, seq.h,
-                              C.c_double(3.0))
+                              C.c_double({slowdown}))
 print("STATE", state)
 """
 
@@ -39,11 +39,15 @@ def test_reference_estimator_runs_on_the_product_tracker(tmp_path):
     import gvins_checks as gc
     g = np.load(os.path.join(ROOT, "tests", "golden", "gvins_ref_golden.npz"))
     last = None
-    for attempt in range(3):  # the reference's threads signal each other without predicates: a run can stall, so: time limit + retry
+    # The reference's three threads run against the wall clock: its optimizer has to finish between two frames, or a keyframe / a
+    # marginalization lands one frame later than in the golden run, and its threads signal each other without
+    # predicates, so a run can stall for good.  Hence: time limit, and retries with slower pacing when the machine is loaded.
+    for attempt, slowdown in enumerate((3.0, 5.0, 8.0)):
         tmp = str(tmp_path / f"run{attempt}")
         os.makedirs(tmp)
         try:
-            r = subprocess.run([sys.executable, "-c", WORKER.format(root=ROOT, tmp=tmp, so=ICG_SO)], capture_output=True, text=True, timeout=90)
+            r = subprocess.run([sys.executable, "-c", WORKER.format(root=ROOT, tmp=tmp, so=ICG_SO, slowdown=slowdown)], capture_output=True, text=True,
+                               timeout=60 + 12 * slowdown)
         except subprocess.TimeoutExpired:
             last = "stalled"
             continue
@@ -57,7 +61,11 @@ def test_reference_estimator_runs_on_the_product_tracker(tmp_path):
             continue
         # same comparison (and tolerances) as the product's own estimator against this golden: identical navigation-line / keyframe /
         # tracked-frame structure, GNSS/INS phase to 0.1 mm, first-window statistics to 1e-6 px, trajectory within 5 cm / 2e-3 in quaternion
-        res = gc.compare_result_files_with_reference_golden(out, g)
+        try:
+            res = gc.compare_result_files_with_reference_golden(out, g)
+        except AssertionError as e:  # a run whose threads fell behind: try again with slower pacing
+            last = ("comparison failed at pacing %.0fx" % slowdown, str(e)[:300])
+            continue
         assert res["max_position_difference"] < 0.05
         return
     pytest.fail(f"no complete run of the reference estimator on the product tracker in 3 attempts: {last}")
