@@ -23,8 +23,9 @@ import time
 import numpy as np
 
 # Each stream group owns a HIP stream; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and kernels of
-# streams that share a queue serialise.  16 queues measured best on MI355X for 32 groups.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# streams that share a queue serialise.  Measured on MI355X with 32 groups (round 2, one box, 100-step runs): 8 -> 52 k, 12 -> 59 k,
+# 16 -> 62 k, 18 -> 65 k, 20 -> 64-66 k, 22 -> 66 k, 24 -> 55 k, 32 -> 48 k frames/s: 20 sits on the plateau, away from the cliff.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ic-gvins_amd"))
