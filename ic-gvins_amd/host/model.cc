@@ -142,7 +142,7 @@ MapPoint::MapPoint(ulong id, const std::shared_ptr<Frame> &ref_frame, Vector3d p
 
 MapPoint::Ptr MapPoint::createMapPoint(std::shared_ptr<Frame> &ref_frame, Vector3d &pos, Point2f &feature, double depth,
                                        MapPointType type, const std::shared_ptr<IdSpace> &ids) {
-    return std::make_shared<MapPoint>(ids->mappoint_id++, ref_frame, pos, feature, depth, type);
+    return std::allocate_shared<MapPoint>(PoolAllocator<MapPoint>(), ids->mappoint_id++, ref_frame, pos, feature, depth, type);
 }
 
 void MapPoint::addObservation(const Feature::Ptr &feature) {

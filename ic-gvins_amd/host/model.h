@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/icgvins_hip.h"
+#include "object_pool.h"
 #include "types.h"
 
 namespace icg {
@@ -123,7 +124,7 @@ public:
     }
     static Ptr createFeature(const std::shared_ptr<Frame> &frame, const Vector2d &velocity, const Point2f &keypoint,
                              const Point2f &distorted, FeatureType type) {
-        return std::make_shared<Feature>(frame, velocity, keypoint, distorted, type);
+        return std::allocate_shared<Feature>(PoolAllocator<Feature>(), frame, velocity, keypoint, distorted, type);
     }
     std::shared_ptr<Frame> getFrame() { return frame_.lock(); }
     std::shared_ptr<MapPoint> getMapPoint() { return mappoint_.lock(); }
@@ -181,7 +182,9 @@ public:
         ModelLock lock(frame_mutex_);
         pose_ = pose;
     }
-    std::unordered_map<ulong, Feature::Ptr> features() {
+    // the reference's container (frame.h:80-83: unordered_map<ulong, Feature::Ptr>, same iteration order) with pooled nodes
+    typedef std::unordered_map<ulong, Feature::Ptr, std::hash<ulong>, std::equal_to<ulong>, PoolAllocator<std::pair<const ulong, Feature::Ptr>>> FeatureMap;
+    FeatureMap features() {
         ModelLock lock(frame_mutex_);
         return features_;
     }
@@ -291,7 +294,7 @@ private:
     Pose pose_;
     Mat image_, raw_image_;
     bool iskeyframe_;
-    std::unordered_map<ulong, Feature::Ptr> features_;
+    FeatureMap features_;
     FeatureList snapshot_; // features_ in its iteration order (valid while snapshot_valid_)
     bool snapshot_valid_{false};
     vector<std::shared_ptr<MapPoint>> unupdated_mappoints_;
@@ -443,7 +446,7 @@ class Map {
 public:
     typedef std::shared_ptr<Map> Ptr;
     typedef std::unordered_map<ulong, Frame::Ptr> KeyFrames;
-    typedef std::unordered_map<ulong, MapPoint::Ptr> LandMarks;
+    typedef std::unordered_map<ulong, MapPoint::Ptr, std::hash<ulong>, std::equal_to<ulong>, PoolAllocator<std::pair<const ulong, MapPoint::Ptr>>> LandMarks;
     explicit Map(size_t size) : window_size_(size) {}
     void resetWindowSize(size_t size) { window_size_ = size; }
     size_t windowSize() const { return window_size_; }
