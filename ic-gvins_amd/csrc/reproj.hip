@@ -966,8 +966,12 @@ __global__ void k_schur_inv_w(const win_desc *wd, int P, double *sys, double min
     inv[l] = h > 0.0 ? 1.0 / (h + fmin(fmax(h, min_diag), max_diag) * W.damp) : 0.0;
 }
 
-__global__ __launch_bounds__(SCH_T *SCH_T) void k_schur_reduce_w(const win_desc *wd, int P, const double *sys, double *S, double *s, double *diag) {
+__global__ __launch_bounds__(SCH_T *SCH_T) void k_schur_reduce_w(const win_desc *wd, int P, const double *sys, double *S, double *s, double *diag,
+                                                                int lower_only) {
     __shared__ double gi[SCH_T][SCH_T + 1], gj[SCH_T][SCH_T + 1], w[SCH_T];
+    // the reduced systems are symmetric and the factorization reads rows >= columns only: the tiles strictly above the diagonal are neither
+    // computed nor written when the caller asks for that (40 % of the tiles, and of the bytes that cross PCIe in the zero-copy form, at P = 67)
+    if (lower_only && blockIdx.x > blockIdx.y) return;
     const win_desc W = wd[blockIdx.z];
     const int L = W.L, N = P + L;
     const double *H = sys + W.sys_off, *b = H + (size_t) N * N, *inv = b + N;
@@ -1257,7 +1261,7 @@ static int schur_windows_impl(icg_ctx *ctx, int P, const int32_t *col_pose, cons
         icg_prof_scope ps(ctx, "schur_reduce");
         hipLaunchKernelGGL(k_schur_inv_w, dim3((Lmax + 255) / 256, W), dim3(256), 0, ctx->stream, d_wd, P, ctx->d_sys, min_diag, max_diag);
         hipLaunchKernelGGL(k_schur_reduce_w, dim3((P + SCH_T - 1) / SCH_T, (P + SCH_T - 1) / SCH_T, W), dim3(SCH_T, SCH_T), 0, ctx->stream, d_wd, P,
-                           (const double *) ctx->d_sys, d_S, d_s, d_dg);
+                           (const double *) ctx->d_sys, d_S, d_s, d_dg, S_view ? 1 : 0);
         if (any_new) {
             // cost only of the windows that were re-assembled is meaningful; the others keep their previous value on the host side
             hipLaunchKernelGGL(k_reproj_cost_w, dim3(4, W), dim3(256), 0, ctx->stream, d_wd, d_r, d_act, ctx->last_huber, d_cost);
@@ -1278,6 +1282,26 @@ static int schur_windows_impl(icg_ctx *ctx, int P, const int32_t *col_pose, cons
     ctx->wsys_P = P, ctx->wsys_valid = 1;
     ctx->sys_min_diag = min_diag, ctx->sys_max_diag = max_diag;
     return ICG_OK;
+}
+
+// Problem-setup companion of the batched calls: sizes the resident window systems (W x ((P + L_w)^2 + ...) doubles of device memory) and the
+// staging arena of the largest per-step call for reduced systems of size P, so that the first LM step of a solve does not pay a device
+// allocation and a pinned re-allocation (4 ms at 256 C2 windows).  A hint: the calls themselves still grow what they need.
+extern "C" int icg_reproj_reserve_windows(icg_ctx *ctx, int P) {
+    if (!ctx || P <= 0) return ICG_ERR_INVALID;
+    const int W = ctx->n_windows, n = ctx->n_factors_resident;
+    if (W <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition: call icg_reproj_set_windows first");
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    size_t doubles = 0;
+    for (int w = 0; w < W; w++) {
+        const size_t N = (size_t) P + (size_t) (ctx->w_lm_off[(size_t) w + 1] - ctx->w_lm_off[(size_t) w]);
+        doubles += N * N + N + (N - (size_t) P);
+    }
+    int rc = ensure_sys_capacity(ctx, doubles + 8);
+    if (rc) return rc;
+    icg_call c(ctx);
+    return c.reserve(sizeof(win_desc) * (size_t) W + sizeof(int32_t) * ((size_t) ctx->last_n_poses + (size_t) W * (size_t) P + 2 * ((size_t) n / NRM_BLOCK + (size_t) W) + 16) +
+                     (size_t) n + sizeof(double) * ((size_t) W * ((size_t) P * P + 2 * (size_t) P + 1)) + 8192);
 }
 
 extern "C" int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td,

@@ -144,7 +144,13 @@ bool WindowSolverBatch::finalize() {
     return true;
 }
 
-bool WindowSolverBatch::prepare() { return finalized_ || finalize(); }
+bool WindowSolverBatch::prepare() {
+    if (!finalized_ && !finalize()) return false;
+    // device memory of the window systems and the staging memory of a step, for the layout as it stands now (solve() re-derives the layout)
+    if (layout()) (void) icg_reproj_reserve_windows(ctx_, P_);
+    error_.clear();
+    return true;
+}
 
 bool WindowSolverBatch::layout() {
     P_ = 0;
@@ -322,8 +328,8 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
             const int Pw = windows_[w].P; // columns beyond Pw are empty (zero rows): solve the leading block only
             std::vector<double> Ab((size_t) Pw * Pw), bb(T.s.begin(), T.s.begin() + Pw);
             const double *Sw = &S[w * (size_t) P * P], *Hw = windows_[w].host_S.data();
-            for (int i = 0; i < Pw; i++)
-                for (int j = 0; j < Pw; j++) Ab[(size_t) i * Pw + j] = Sw[(size_t) i * P + j] + Hw[(size_t) i * P + j];
+            for (int i = 0; i < Pw; i++) // lower triangle: what the view holds and what choleskySolve reads
+                for (int j = 0; j <= i; j++) Ab[(size_t) i * Pw + j] = Sw[(size_t) i * P + j] + Hw[(size_t) i * P + j];
             for (int k = 0; k < Pw; k++) {
                 T.dd[(size_t) k] = std::min(std::max(T.diag[(size_t) k], o.min_lm_diagonal), o.max_lm_diagonal) / T.radius;
                 Ab[(size_t) k * Pw + k] += T.dd[(size_t) k];

@@ -220,10 +220,14 @@ int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const
                              const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, double *S, double *s,
                              double *diag_cc, double *cost);
 /* the same call with the W x P x P reduced systems left where the reduction kernel writes them (the context's pinned staging memory):
- * *S_view is valid until the next call on ctx.  Saves the device-to-host copy and the copy-out of 9 MB per LM step at 256 C2 windows. */
+ * *S_view is valid until the next call on ctx.  Saves the device-to-host copy and the copy-out of 9 MB per LM step at 256 C2 windows.
+ * Only the 16 x 16 tiles on and below the diagonal are written (the systems are symmetric; a Cholesky factorization reads rows >= columns):
+ * the elements above those tiles are undefined. */
 int icg_reproj_schur_windows_view(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
                                   const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, const double **S_view, double *s,
                                   double *diag_cc, double *cost);
+/* problem setup: pre-sizes the resident window systems and the staging memory for reduced systems of size P (a hint; optional) */
+int icg_reproj_reserve_windows(icg_ctx *ctx, int P);
 int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms);
 int icg_reproj_cost_windows(icg_ctx *ctx, const uint8_t *active, double *cost);
 /* the resident residuals of the last evaluation (n x 2 doubles): per-factor tests (chi-square culling) after a resident evaluation */

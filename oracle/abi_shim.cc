@@ -449,6 +449,8 @@ int icg_reproj_schur_windows_view(icg_ctx *ctx, int P, const int32_t *col_pose, 
     return icg_reproj_schur_windows(ctx, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, B.S_view.data(), s, diag_cc, cost);
 }
 
+int icg_reproj_reserve_windows(icg_ctx *, int P) { return P > 0 ? ICG_OK : ICG_ERR_INVALID; } // nothing to pre-size on the CPU
+
 int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
     shim_backend &B = g_backend[ctx];
     if (B.W <= 0 || B.wP != P) return ICG_ERR_INVALID;
