@@ -247,7 +247,10 @@ private:
     vector<IMU> imu_buffer_;
     IntegrationState start_state_, current_state_, delta_state_;
     double delta_time_{0};
+    void updateSqrtInformation();
     vector<double> jacobian_, covariance_, pn_; // 15x15, 15x15, (n-1)x4
+    vector<double> sqrt_information_;            // 15x15, of covariance_ (formed when an integration result arrives)
+    bool sqrt_information_ok_{false};
     Vector3d iewn_; // this interval's Earth rate: P1 (device) and P2 (evaluate) use the same value
     bool dirty_{true};
 };

@@ -195,60 +195,70 @@ bool Preintegration::integrateBatch(icg_ctx *ctx, const vector<Preintegration *>
             p->delta_time_ = dt[k];
             const int b = offsets[k], cnt = offsets[k + 1] - offsets[k];
             p->pn_.assign(pn.begin() + 4 * (long) b, pn.begin() + 4 * (long) (b + cnt - 1));
+            p->updateSqrtInformation();
             p->dirty_ = false;
         }
     }
     return true;
 }
 
+// sqrt_information = LLT(cov^-1).matrixL().transpose()  (normal :39-40, earth :39-40).  The reference forms it inside every evaluate();
+// it only depends on the covariance, so it is formed once when an integration result arrives (same arithmetic, same value).
+void Preintegration::updateSqrtInformation() {
+    typedef double M15[15][15];
+    M15 cov, inv, L;
+    memcpy(cov, covariance_.data(), sizeof cov);
+    sqrt_information_ok_ = false;
+    sqrt_information_.assign(225, 0.0);
+    double w[15][30];
+    for (int i = 0; i < 15; i++)
+        for (int j = 0; j < 15; j++) {
+            w[i][j]      = cov[i][j];
+            w[i][15 + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 15; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 15; r++)
+            if (std::fabs(w[r][c]) > std::fabs(w[piv][c])) piv = r;
+        if (w[piv][c] == 0.0) return;
+        if (piv != c)
+            for (int j = 0; j < 30; j++) std::swap(w[c][j], w[piv][j]);
+        double d = w[c][c];
+        for (int j = 0; j < 30; j++) w[c][j] /= d;
+        for (int r = 0; r < 15; r++)
+            if (r != c) {
+                double f = w[r][c];
+                if (f != 0.0)
+                    for (int j = 0; j < 30; j++) w[r][j] -= f * w[c][j];
+            }
+    }
+    for (int i = 0; i < 15; i++)
+        for (int j = 0; j < 15; j++) inv[i][j] = w[i][15 + j];
+    for (int i = 0; i < 15; i++)
+        for (int j = 0; j < i; j++) inv[j][i] = inv[i][j];
+    memset(L, 0, sizeof L);
+    for (int j = 0; j < 15; j++) {
+        double s = inv[j][j];
+        for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+        L[j][j] = std::sqrt(s);
+        for (int i = j + 1; i < 15; i++) {
+            double t = inv[i][j];
+            for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
+            L[i][j] = t / L[j][j];
+        }
+    }
+    for (int i = 0; i < 15; i++)
+        for (int j = 0; j < 15; j++) sqrt_information_[(size_t) i * 15 + j] = L[j][i];
+    sqrt_information_ok_ = true;
+}
+
 bool Preintegration::evaluate(const double *const *parameters, double *residuals, double **jacobians) const {
     if (dirty_) return false; // not integrated for the current buffer/start state: evaluation failed, loudly
+    if (!sqrt_information_ok_) return false; // singular covariance
     typedef double M15[15][15];
-    M15 jac, cov, inv, L, S;
+    M15 jac, S;
     memcpy(jac, jacobian_.data(), sizeof jac);
-    memcpy(cov, covariance_.data(), sizeof cov);
-    // sqrt_information = LLT(cov^-1).matrixL().transpose()  (normal :39-40, earth :39-40)
-    {
-        double w[15][30];
-        for (int i = 0; i < 15; i++)
-            for (int j = 0; j < 15; j++) {
-                w[i][j]      = cov[i][j];
-                w[i][15 + j] = (i == j) ? 1.0 : 0.0;
-            }
-        for (int c = 0; c < 15; c++) {
-            int piv = c;
-            for (int r = c + 1; r < 15; r++)
-                if (std::fabs(w[r][c]) > std::fabs(w[piv][c])) piv = r;
-            if (w[piv][c] == 0.0) return false;
-            if (piv != c)
-                for (int j = 0; j < 30; j++) std::swap(w[c][j], w[piv][j]);
-            double d = w[c][c];
-            for (int j = 0; j < 30; j++) w[c][j] /= d;
-            for (int r = 0; r < 15; r++)
-                if (r != c) {
-                    double f = w[r][c];
-                    if (f != 0.0)
-                        for (int j = 0; j < 30; j++) w[r][j] -= f * w[c][j];
-                }
-        }
-        for (int i = 0; i < 15; i++)
-            for (int j = 0; j < 15; j++) inv[i][j] = w[i][15 + j];
-        for (int i = 0; i < 15; i++)
-            for (int j = 0; j < i; j++) inv[j][i] = inv[i][j];
-        memset(L, 0, sizeof L);
-        for (int j = 0; j < 15; j++) {
-            double s = inv[j][j];
-            for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
-            L[j][j] = std::sqrt(s);
-            for (int i = j + 1; i < 15; i++) {
-                double t = inv[i][j];
-                for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-                L[i][j] = t / L[j][j];
-            }
-        }
-        for (int i = 0; i < 15; i++)
-            for (int j = 0; j < 15; j++) S[i][j] = L[j][i];
-    }
+    memcpy(S, sqrt_information_.data(), sizeof S);
     // constructState (normal :162-180)
     const double *pose0 = parameters[0], *mix0 = parameters[1], *pose1 = parameters[2], *mix1 = parameters[3];
     V3 p0{pose0[0], pose0[1], pose0[2]}, p1{pose1[0], pose1[1], pose1[2]};

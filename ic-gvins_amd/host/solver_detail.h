@@ -25,32 +25,10 @@ struct Residual {
     bool removed;
 };
 
-// in-place Cholesky solve of the symmetric positive definite n x n system A x = b (row-major, lower triangle used)
-inline bool choleskySolve(int n, std::vector<double> &A, std::vector<double> &b) {
-    for (int j = 0; j < n; j++) {
-        double d = A[(size_t) j * n + j];
-        for (int k = 0; k < j; k++) d -= A[(size_t) j * n + k] * A[(size_t) j * n + k];
-        if (!(d > 0.0) || !std::isfinite(d)) return false;
-        d                     = std::sqrt(d);
-        A[(size_t) j * n + j] = d;
-        for (int i = j + 1; i < n; i++) {
-            double v = A[(size_t) i * n + j];
-            for (int k = 0; k < j; k++) v -= A[(size_t) i * n + k] * A[(size_t) j * n + k];
-            A[(size_t) i * n + j] = v / d;
-        }
-    }
-    for (int i = 0; i < n; i++) {
-        double v = b[(size_t) i];
-        for (int k = 0; k < i; k++) v -= A[(size_t) i * n + k] * b[(size_t) k];
-        b[(size_t) i] = v / A[(size_t) i * n + i];
-    }
-    for (int i = n - 1; i >= 0; i--) {
-        double v = b[(size_t) i];
-        for (int k = i + 1; k < n; k++) v -= A[(size_t) k * n + i] * b[(size_t) k];
-        b[(size_t) i] = v / A[(size_t) i * n + i];
-    }
-    return true;
-}
+// in-place Cholesky solve of the symmetric positive definite n x n system A x = b (row-major, lower triangle used); dense_kernels.cc
+bool choleskySolve(int n, std::vector<double> &A, std::vector<double> &b);
+// T (nf x nf, upper triangle) += J^T J, g (nf) += J^T r for a dense row-major J (nr x nf); dense_kernels.cc
+void accumulateJtJ(int nr, int nf, const double *J, const double *r, double *T, double *g);
 
 // PoseParameterization::Plus (factors/pose_parameterization.h:34-50): p += dp, q = (q * rotvec2quaternion(dtheta)).normalized()
 inline void posePlus(double *x, const double *delta) {
@@ -111,28 +89,45 @@ inline bool hostFactors(const std::vector<Block> &blocks, const std::unordered_m
         } else {
             *cost += 0.5 * sq;
         }
+        // J^T J of the factor's free columns: the blocks are gathered into ONE dense row-major Jacobian (nr x n_free) so that the triple
+        // loop runs with the residual index outermost and a contiguous, independent inner index (vectorizable as written); every cell is
+        // the sum over k in ascending order from zero, as in a cell-by-cell inner product, and is then added to S once.
         const int nr      = R.cost->num_residuals();
         const auto &sizes = R.cost->parameter_block_sizes();
+        thread_local std::vector<double> Jd, T;
+        thread_local std::vector<int> cols;
+        cols.clear();
         for (size_t a = 0; a < R.blocks.size(); a++) {
             const Block &A = blocks[(size_t) block_of.at(R.blocks[a])];
             if (A.column < 0) continue;
-            const std::vector<double> &Ja = info.jacobians()[a];
-            for (int x = 0; x < A.local; x++) {
-                double g = 0;
-                for (int k = 0; k < nr; k++) g += Ja[(size_t) k * sizes[a] + x] * info.residuals()[(size_t) k];
-                s[(size_t) (A.column + x)] -= g;
+            for (int x = 0; x < A.local; x++) cols.push_back(A.column + x);
+        }
+        const int nf = (int) cols.size();
+        if (nf == 0) continue;
+        Jd.resize((size_t) nr * nf);
+        {
+            int c0 = 0;
+            for (size_t a = 0; a < R.blocks.size(); a++) {
+                const Block &A = blocks[(size_t) block_of.at(R.blocks[a])];
+                if (A.column < 0) continue;
+                const std::vector<double> &Ja = info.jacobians()[a];
+                for (int k = 0; k < nr; k++)
+                    for (int x = 0; x < A.local; x++) Jd[(size_t) k * nf + c0 + x] = Ja[(size_t) k * sizes[a] + x];
+                c0 += A.local;
             }
-            for (size_t c = 0; c < R.blocks.size(); c++) {
-                const Block &B = blocks[(size_t) block_of.at(R.blocks[c])];
-                if (B.column < 0) continue;
-                const std::vector<double> &Jc = info.jacobians()[c];
-                for (int x = 0; x < A.local; x++)
-                    for (int y = 0; y < B.local; y++) {
-                        double v = 0;
-                        for (int k = 0; k < nr; k++) v += Ja[(size_t) k * sizes[a] + x] * Jc[(size_t) k * sizes[c] + y];
-                        S[(size_t) (A.column + x) * P + B.column + y] += v;
-                        if (a == c && x == y) diag[(size_t) (A.column + x)] += v;
-                    }
+        }
+        const std::vector<double> &res = info.residuals();
+        T.assign((size_t) nf * nf + nf, 0.0);
+        double *g = T.data() + (size_t) nf * nf;
+        accumulateJtJ(nr, nf, Jd.data(), res.data(), T.data(), g);
+        for (int x = 0; x < nf; x++) {
+            s[(size_t) cols[(size_t) x]] -= g[x];
+            diag[(size_t) cols[(size_t) x]] += T[(size_t) x * nf + x];
+            S[(size_t) cols[(size_t) x] * P + cols[(size_t) x]] += T[(size_t) x * nf + x];
+            for (int y = x + 1; y < nf; y++) {
+                const double v = T[(size_t) x * nf + y];
+                S[(size_t) cols[(size_t) x] * P + cols[(size_t) y]] += v;
+                S[(size_t) cols[(size_t) y] * P + cols[(size_t) x]] += v;
             }
         }
     }

@@ -6,6 +6,10 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 
 #include "../../include/icgvins_hip.h"
@@ -33,6 +37,32 @@ struct PhaseScope {
 };
 enum { PH_EVAL_JAC = 0, PH_SCHUR, PH_HOST_FACTORS, PH_CHOLESKY, PH_BACKSUB, PH_EVAL_TRIAL, PH_COST, PH_CHI2 };
 
+// one helper thread per process for WindowSolver::setHostFactorOverlap: whoever holds the lock uses it, anybody else runs the halves in turn
+std::atomic<bool> g_overlap{false};
+struct OverlapPool {
+    std::mutex m;
+    std::unique_ptr<HostPool> pool;
+};
+OverlapPool &overlapPool() {
+    static OverlapPool p;
+    return p;
+}
+// device() and host() both run, side by side when the overlap is on and the helper is free; -> both succeeded
+bool runHalves(bool want_overlap, const std::function<bool()> &device, const std::function<bool()> &host) {
+    if (want_overlap && g_overlap.load(std::memory_order_relaxed)) {
+        OverlapPool &op = overlapPool();
+        std::unique_lock<std::mutex> lock(op.m, std::try_to_lock);
+        if (lock.owns_lock()) {
+            if (!op.pool) op.pool.reset(new HostPool(2));
+            bool ok[2] = {false, false};
+            op.pool->parallelFor(2, [&](int i) { ok[i] = i == 0 ? device() : host(); });
+            return ok[0] && ok[1];
+        }
+    }
+    const bool a = device();
+    return host() && a;
+}
+
 using solver_detail::choleskySolve;
 using solver_detail::posePlus;
 } // namespace
@@ -43,6 +73,8 @@ std::string WindowSolver::Summary::BriefReport() const {
              final_cost, num_successful_steps, num_unsuccessful_steps, termination.c_str());
     return buf;
 }
+
+void WindowSolver::setHostFactorOverlap(bool on) { g_overlap.store(on); }
 
 WindowSolver::WindowSolver(ReprojectionBatch *visual, double huber_delta) : visual_(visual), huber_(huber_delta) {
     if (visual_) active_.assign((size_t) visual_->size(), 1);
@@ -137,64 +169,70 @@ bool WindowSolver::linearize(double damp, bool reassemble, const Options &o, std
     S.assign((size_t) P_ * P_, 0.0);
     s.assign((size_t) P_, 0.0);
     diag.assign((size_t) P_, 0.0);
-    double c = 0;
-    if (visual_ && visual_->size() > 0) {
+    double vc = 0, hc = 0;
+    const bool has_visual = visual_ && visual_->size() > 0;
+    std::string device_error;
+    auto device = [&]() -> bool {
+        if (!has_visual) return true;
         if (reassemble) {
             PhaseScope ps(PH_EVAL_JAC);
             if (!visual_->run(true, huber_, false)) {
-                error_ = visual_->error();
+                device_error = visual_->error();
                 return false;
             }
         }
-        double vc = 0;
         PhaseScope ps(PH_SCHUR);
         if (icg_reproj_schur(visual_->ctx_, P_, col_pose_.data(), col_ext_, col_td_, active_.data(), reassemble ? 1 : 0, damp, o.min_lm_diagonal,
                              o.max_lm_diagonal, S.data(), s.data(), diag.data(), &vc) != ICG_OK) {
-            error_ = icg_last_error(visual_->ctx_);
+            device_error = icg_last_error(visual_->ctx_);
             return false;
         }
-        c += vc;
-    }
-    if (reassemble) {
+        return true;
+    };
+    auto host = [&]() -> bool {
+        if (!reassemble) return true;
         host_S_.assign((size_t) P_ * P_, 0.0);
         host_s_.assign((size_t) P_, 0.0);
         host_diag_.assign((size_t) P_, 0.0);
-        double hc = 0;
         PhaseScope ps(PH_HOST_FACTORS);
-        if (!solver_detail::hostFactors(blocks_, block_of_, residuals_, P_, host_S_.data(), host_s_.data(), host_diag_.data(), &hc)) {
-            error_ = "a host cost function failed to evaluate";
-            return false;
-        }
-        c += hc;
-        if (cost) *cost = c;
+        return solver_detail::hostFactors(blocks_, block_of_, residuals_, P_, host_S_.data(), host_s_.data(), host_diag_.data(), &hc);
+    };
+    if (!runHalves(has_visual && reassemble && !residuals_.empty(), device, host)) {
+        error_ = device_error.empty() ? "a host cost function failed to evaluate" : device_error;
+        return false;
     }
+    if (reassemble && cost) *cost = vc + hc;
     for (size_t k = 0; k < S.size(); k++) S[k] += host_S_[k];
     for (size_t k = 0; k < s.size(); k++) s[k] += host_s_[k], diag[k] += host_diag_[k];
     return true;
 }
 
 bool WindowSolver::evaluateCost(double *cost) {
-    double c = 0;
-    if (visual_ && visual_->size() > 0) {
+    double vc = 0, hc = 0;
+    const bool has_visual = visual_ && visual_->size() > 0;
+    std::string device_error;
+    auto device = [&]() -> bool {
+        if (!has_visual) return true;
         {
             PhaseScope ps(PH_EVAL_TRIAL);
             if (!visual_->run(false, huber_, false)) {
-                error_ = visual_->error();
+                device_error = visual_->error();
                 return false;
             }
         }
-        double vc = 0;
         PhaseScope ps(PH_COST);
         if (icg_reproj_cost(visual_->ctx_, active_.data(), &vc) != ICG_OK) {
-            error_ = icg_last_error(visual_->ctx_);
+            device_error = icg_last_error(visual_->ctx_);
             return false;
         }
-        c += vc;
-    }
-    if (!solver_detail::hostFactors(blocks_, block_of_, residuals_, P_, nullptr, nullptr, nullptr, &c)) {
-        error_ = "a host cost function failed to evaluate";
+        return true;
+    };
+    auto host = [&]() -> bool { return solver_detail::hostFactors(blocks_, block_of_, residuals_, P_, nullptr, nullptr, nullptr, &hc); };
+    if (!runHalves(has_visual && !residuals_.empty(), device, host)) {
+        error_ = device_error.empty() ? "a host cost function failed to evaluate" : device_error;
         return false;
     }
+    const double c = vc + hc;
     *cost = c;
     return true;
 }

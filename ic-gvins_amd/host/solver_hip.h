@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "factors.h"
+#include "host_pool.h"
 #include "solver_detail.h"
 
 namespace icg {
@@ -57,6 +58,10 @@ public:
     bool evaluateResidualBlock(ResidualBlockId id, bool apply_loss_function, double *cost) const;
 
     bool solve(const Options &options, Summary *summary);
+    // Process-wide: evaluate the host factors of a linearization / trial point on ONE helper thread while the calling thread drives the
+    // device calls for the visual factors (the two halves are independent; results are identical).  For a single camera stream, where the
+    // window solve is a latency chain; leave it off when every core already runs an estimator of its own.
+    static void setHostFactorOverlap(bool on);
 
     // removeReprojectionFactorsByChi2 (ic_gvins.cc:1269-1297): raw cost of every active visual factor at the current state,
     // factors with 2 cost > chi2 are deactivated for the following solves; returns how many

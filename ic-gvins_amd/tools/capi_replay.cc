@@ -31,6 +31,11 @@ int icgh_replay_run(const char *configfile, const char *outputpath, const char *
         o.start_time = start_time, o.end_time = end_time;
         ReplaySummary s;
         std::string e;
+        // one camera stream: the window solve is a latency chain, so the host factors of a linearization run beside the device calls
+        struct Overlap {
+            Overlap() { WindowSolver::setHostFactorOverlap(true); }
+            ~Overlap() { WindowSolver::setHostFactorOverlap(false); }
+        } overlap;
         if (!Replay::run(o, s, &e)) {
             set_err(err, errlen, e.c_str());
             return -2;

@@ -1,5 +1,5 @@
-"""The f2 workload alone (one synthetic GNSS + IMU + camera sequence through icg::GVINS on the HIP-backed host layer), for
-`rocprofv3 --kernel-trace --stats -- python profiles/run_replay_only.py`.  ICG_GVINS_DEBUG=1 prints the estimator's log."""
+#!/usr/bin/env python3
+"""Profiling harness: the single-stream estimator replay of bench.py's `replay` block, three repetitions (ICG_GVINS_DEBUG=1 prints the phase split)."""
 import ctypes as C
 import os
 import sys
@@ -8,13 +8,14 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "ic-gvins_amd"))
-import gvins_checks as gc  # noqa: E402
-import gvins_data as gd  # noqa: E402
 import harness as H  # noqa: E402
+import gvins_checks as gvc  # noqa: E402
+import gvins_data as gvd  # noqa: E402
 
-lib = C.CDLL(H.TOOLS_LIB)
-seq = gd.Sequence(lib)
-files = seq.write(tempfile.mkdtemp(prefix="prof_replay_"))
+root = tempfile.mkdtemp(prefix="replay_only_")
+hostlib = C.CDLL(H.TOOLS_LIB)
+seq = gvd.Sequence(hostlib)
+files = seq.write(root)
 for _ in range(3):
-    S = gc.run_replay(lib, files)
-    print({k: S[k] for k in ("data_seconds", "wall_seconds", "frames_tracked", "keyframes", "optimizations", "marginalizations", "ins_launches")})
+    S = gvc.run_replay(hostlib, files)
+    print("x real time %.2f  wall %.3f s" % (S["data_seconds"] / S["wall_seconds"], S["wall_seconds"]), file=sys.stderr)
