@@ -28,13 +28,14 @@ def terminal_exchange(dist, device, counters, elapsed, digests):
 def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, streams_override=0):
     """Host resources of one rank (one rank's polling threads must not assume the whole box):
       cores_rank   the rank's share of the usable host cores
-      groups       stream groups (one host thread + HIP stream each): 2 per core of the share — a group sleeps while its kernels run —
-                   between 2 and 32; never 8 pollers on 2 cores
+      groups       stream groups (one host thread + HIP stream each): 3 per core of the share — a group sleeps while its kernels run, and the
+                   GPU only fills up at ~48 groups in flight (profiles/README.md, round-2 sweep: 32 -> 66 k, 48 -> 72 k, 64 -> 73 k frames/s) —
+                   between 2 and 48; never 8 pollers on 2 cores
       streams      8 camera streams per group
       cpu_slice    the contiguous slice of the allowed CPU ids this rank pins itself to (None for a single rank: nothing to separate)
     """
     cores_rank = float(usable_cores) / float(max(1, world))
-    groups = int(groups_override) if groups_override > 0 else int(max(2, min(32, 2 * round(cores_rank))))
+    groups = int(groups_override) if groups_override > 0 else int(max(2, min(48, 3 * round(cores_rank))))
     streams = int(streams_override) if streams_override > 0 else 8 * groups
     groups = max(1, min(groups, streams))
     cpu_slice = None

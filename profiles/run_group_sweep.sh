@@ -1,0 +1,9 @@
+#!/bin/bash
+# sweep of stream groups x streams per group for the front-end bench (one JSON summary line per configuration)
+IFS=";" read -ra CFGS <<< "${SWEEP:-32 256;40 320;48 384;56 448;64 512}"
+for cfg in "${CFGS[@]}"; do
+  IFS=" " read -r g s <<< "$cfg"; set -- $g $s
+  timeout 200 python bench.py --steps 120 --warmup 30 --groups $1 --streams $2 --no-reproj --no-cpu-baseline --no-profile-pass 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); h=d['host_ms_per_step']; print('groups $1 streams $2:', d['value'], 'fps  cores_busy', h['cpu_cores_busy'], ' device_execute', h['device_execute'], ' host_logic', h['host_logic'], ' group_step', h['group_step_ms_min_mean_max'])"
+done

@@ -59,13 +59,13 @@ def test_host_plan_scales_the_polling_threads_with_the_rank_share():
     sys.path.insert(0, os.path.join(ROOT, "ic-gvins_amd"))
     import sharding
     one = sharding.host_plan(16, 1, 0, cpu_ids=range(256))
-    assert one["groups"] == 32 and one["streams"] == 256 and one["cpu_slice"] is None
+    assert one["groups"] == 48 and one["streams"] == 384 and one["cpu_slice"] is None
     eight = [sharding.host_plan(16, 8, r, cpu_ids=range(256)) for r in range(8)]
-    assert all(p["groups"] == 4 and p["streams"] == 32 and abs(p["cores_rank"] - 2.0) < 1e-12 for p in eight)
+    assert all(p["groups"] == 6 and p["streams"] == 48 and abs(p["cores_rank"] - 2.0) < 1e-12 for p in eight)
     slices = [set(p["cpu_slice"]) for p in eight]
     assert all(len(s_) == 32 for s_ in slices) and len(set().union(*slices)) == 256  # disjoint, covering
     big = sharding.host_plan(128, 8, 3, cpu_ids=range(128))
-    assert big["groups"] == 32 and big["cpu_slice"] == list(range(48, 64))
+    assert big["groups"] == 48 and big["cpu_slice"] == list(range(48, 64))
     tiny = sharding.host_plan(4, 8, 0, cpu_ids=range(4))
     assert tiny["groups"] == 2 and tiny["streams"] == 16 and tiny["cpu_slice"]
     assert sharding.host_plan(16, 1, 0, groups_override=8, streams_override=64)["groups"] == 8
