@@ -723,8 +723,8 @@ def main():
     if rank == 0 and not args.no_reproj and not args.no_c4:
         c4 = {"workload": "C4: 1920x1080 synthetic streams, 500 features, 15-keyframe window (7 000 reprojection factors), 15 x 40-sample "
                           "IMU intervals at 200 Hz, 1 MI355X"}
-        G4 = int(max(2, min(16, 2 * round(cores_rank))))
-        B4 = 4 * G4
+        G4 = int(max(2, min(32, 2 * round(cores_rank))))  # round-2 sweep (profiles/run_c4_sweep.sh): 16 x 4 -> 27.8 k, 32 x 4 -> 32.9 k, 32 x 8 -> 39.4 k
+        B4 = 8 * G4
         f4 = run_frontend(torch, hip, w=1920, h=1080, nfeat=500, window=15, B=B4, G=G4, ring=16, prime=64, warmup=10, steps=60,
                           rank=0, local_rank=local_rank, host_threads=1, host_frames=False, profile=False,
                           barrier=torch.cuda.synchronize, ncpu=ncpu)
