@@ -226,7 +226,8 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
         for _k, _name in enumerate(_nm.value.decode().split(";")[:_n]):
             print(f"[hostprof] {_name:16s} {1e6 * _hp[2 * _k] / (B * steps):9.2f} us/frame  calls/frame "
                   f"{_hp[2 * _k + 1] / (B * steps):.3f}", file=sys.stderr)
-    tg = sb.timing_groups().sum(1) * 1e3 / steps  # per-group in-step wall time, ms per step
+    tg_all = sb.timing_groups()
+    tg = tg_all.sum(1) * 1e3 / steps  # per-group in-step wall time, ms per step
     # per-step series: step k of the job ends when the slowest group has finished its k-th frame set
     logs = sb.step_log(reset=True)
     step_stats = None
@@ -243,6 +244,8 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
     host_breakdown = {kk: round(1e3 * v / steps, 4) for kk, v in sb.timing().items()}
     host_breakdown["cpu_cores_busy"] = round(cpu_cores_used, 2)
     host_breakdown["group_step_ms_min_mean_max"] = [round(float(tg.min()), 3), round(float(tg.mean()), 3), round(float(tg.max()), 3)]
+    host_breakdown["group_step_ms_per_group"] = [round(float(v), 2) for v in tg]
+    host_breakdown["group_device_ms_per_group"] = [round(float(v), 2) for v in tg_all[:, 2] * 1e3 / steps]
     barrier()
     stats = [sb.stats(s) for s in range(B)]
     tracked = sum(s_["tracked_sum"] for s_ in stats) - tracked_before

@@ -237,8 +237,8 @@ __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *ro
 #define DET_MAX_PER_BLOCK 64
 
 __global__ __launch_bounds__(256) void k_select(const det_roi *rois, unsigned long long *cand, size_t cand_plane,
-                                                const int32_t *cand_cnt, const unsigned int *roi_max, int min_dist,
-                                                float2 *corners /*roi x max_pb*/, int32_t *corner_cnt, int max_pb) {
+                                                int32_t *cand_cnt, unsigned int *roi_max, int min_dist,
+                                                float2 *corners /*roi x max_pb*/, int32_t *corner_cnt, int32_t *corner_cnt_host, int max_pb) {
     __shared__ unsigned long long wbest[4];
     __shared__ unsigned long long best;
     const det_roi R = rois[blockIdx.x];
@@ -298,7 +298,14 @@ __global__ __launch_bounds__(256) void k_select(const det_roi *rois, unsigned lo
         }
         __syncthreads();
     }
-    if (t == 0) corner_cnt[blockIdx.x] = acc;
+    if (t == 0) {
+        corner_cnt[blockIdx.x]      = acc; // device copy: read by every k_subpix workgroup of the ROI
+        corner_cnt_host[blockIdx.x] = acc; // the caller's copy, written straight into its pinned staging memory (no D2H launch)
+        // the ROI's accumulators are consumed (every thread read them before the first barrier above): leave them zero for the next call,
+        // which then needs neither a memset nor an upload of zeros
+        roi_max[blockIdx.x]  = 0;
+        cand_cnt[blockIdx.x] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -307,7 +314,7 @@ struct subpix_mask_t {
 };
 
 __global__ __launch_bounds__(64) void k_subpix(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
-                                               const int32_t *slots, int pitch, float2 *corners,
+                                               const int32_t *slots, int pitch, const float2 *corners, float2 *corners_host,
                                                const int32_t *corner_cnt, int max_pb, subpix_mask_t M) {
     __shared__ float patch[13][13];
     __shared__ double terms[121][5];
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(64) void k_subpix(const det_roi *rois, const uint8_
             cIx = cT.x;
             cIy = cT.y;
         }
-        corners[(size_t) roi * max_pb + ci] = make_float2(cIx, cIy);
+        corners_host[(size_t) roi * max_pb + ci] = make_float2(cIx, cIy); // pinned staging memory of the call (zero-copy result)
     }
 }
 
@@ -481,23 +488,40 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
 
     icg_call c(ctx);
     size_t need = sizeof(det_roi) * n_roi + sizeof(int32_t) * (n + hw.size() + n_mask) + sizeof(float) * 2 * n_mask +
-                  (sizeof(float2) * max_pb + 16) * (size_t) n_roi + 8192;
+                  2 * (sizeof(float2) * max_pb + 16) * (size_t) n_roi + 8192;
     if ((rc = c.reserve(need))) return rc;
-    const det_roi *d_rois  = c.in(rois.data(), (size_t) n_roi);
-    const int32_t *d_slots = c.in(slots, (size_t) n);
-    const int32_t *d_hw    = c.in(hw.data(), hw.size());
-    const float2 *d_mpts   = (const float2 *) c.in(mask_pts, 2 * (size_t) n_mask);
-    const int32_t *d_ptjob = c.in(pt_job.data(), (size_t) n_mask);
-    // [roi_max | cand_cnt] start at zero: staged with the inputs (rides on the single H2D copy, no memset launch)
-    std::vector<unsigned int> zeros(2 * (size_t) n_roi, 0u);
-    unsigned int *d_rmax = const_cast<unsigned int *>(c.in(zeros.data(), zeros.size()));
-    int32_t *d_ccnt      = (int32_t *) (d_rmax + n_roi);
+    // Every small array of the call is read or written by the kernels in the call's pinned staging memory (zero-copy over PCIe): one
+    // read per workgroup / one write per corner.  The mirrored form cost an H2D and a D2H copy launch per call, and under load every
+    // launch on a busy hardware queue costs ~75-100 us whatever its size (profiles/r02_queue_view.json).
+    const det_roi *d_rois  = c.in_zc(rois.data(), (size_t) n_roi);
+    const int32_t *d_slots = c.in_zc(slots, (size_t) n);
+    const int32_t *d_hw    = c.in_zc(hw.data(), hw.size());
+    const float2 *d_mpts   = (const float2 *) c.in_zc(mask_pts, 2 * (size_t) n_mask);
+    const int32_t *d_ptjob = c.in_zc(pt_job.data(), (size_t) n_mask);
+    // [roi_max | cand_cnt] per ROI live in the context and are zero between calls (k_select clears the entries it consumed)
+    if (n_roi > ctx->roi_state_cap) {
+        ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_roi_max) (void) hipFree(ctx->d_roi_max);
+        if (ctx->d_cand_cnt) (void) hipFree(ctx->d_cand_cnt);
+        ctx->d_roi_max = nullptr, ctx->d_cand_cnt = nullptr, ctx->roi_state_cap = 0;
+        const int cap = std::max(1024, 2 * n_roi);
+        ICG_HIP(ctx, hipMalloc((void **) &ctx->d_roi_max, sizeof(uint32_t) * (size_t) cap));
+        ICG_HIP(ctx, hipMalloc((void **) &ctx->d_cand_cnt, sizeof(int32_t) * (size_t) cap));
+        ICG_HIP(ctx, hipMemsetAsync(ctx->d_roi_max, 0, sizeof(uint32_t) * (size_t) cap, ctx->stream));
+        ICG_HIP(ctx, hipMemsetAsync(ctx->d_cand_cnt, 0, sizeof(int32_t) * (size_t) cap, ctx->stream));
+        ctx->roi_state_cap = cap;
+    }
+    unsigned int *d_rmax = ctx->d_roi_max;
+    int32_t *d_ccnt      = ctx->d_cand_cnt;
     if ((rc = c.seal())) return rc;
     std::vector<float> h_corners((size_t) n_roi * max_pb * 2);
     std::vector<int32_t> h_cnt((size_t) n_roi);
-    // corners are re-read by k_subpix: keep them in device memory, fetch with the single D2H of finish()
-    float2 *d_corners    = (float2 *) c.out(h_corners.data(), (size_t) n_roi * max_pb * 2);
-    int32_t *d_cnt       = c.out(h_cnt.data(), (size_t) n_roi);
+    // selected corners and their counts are re-read by k_subpix: device scratch; the refined corners and the counts the caller needs
+    // are written by the kernels into the staging memory directly
+    float2 *d_corners  = (float2 *) c.out((float *) nullptr, (size_t) n_roi * max_pb * 2);
+    int32_t *d_cnt     = c.out((int32_t *) nullptr, (size_t) n_roi);
+    float2 *z_corners  = (float2 *) c.out_zc(h_corners.data(), (size_t) n_roi * max_pb * 2);
+    int32_t *z_cnt     = c.out_zc(h_cnt.data(), (size_t) n_roi);
 
     const size_t mask_plane = (size_t) pitch * h, cand_plane = (size_t) w * h;
     // mask generation (see k_mask_discs): a full clear only when the 8-bit tag wraps
@@ -521,7 +545,7 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     {
         icg_prof_scope ps(ctx, "detect_select");
         hipLaunchKernelGGL(k_select, dim3(n_roi), dim3(256), 0, ctx->stream, d_rois, ctx->d_cand, cand_plane, d_ccnt, d_rmax,
-                           grid->min_dist, d_corners, d_cnt, max_pb);
+                           grid->min_dist, d_corners, d_cnt, z_cnt, max_pb);
     }
     {
         subpix_mask_t M;
@@ -535,7 +559,7 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
         }
         icg_prof_scope ps(ctx, "detect_subpix");
         hipLaunchKernelGGL(k_subpix, dim3(n_roi * max_pb), dim3(64), 0, ctx->stream, d_rois, ctx->d_frames, ctx->slot_bytes,
-                           d_slots, pitch, d_corners, d_cnt, max_pb, M);
+                           d_slots, pitch, (const float2 *) d_corners, z_corners, d_cnt, max_pb, M);
     }
     ICG_HIP(ctx, hipGetLastError());
     if ((rc = c.finish())) return rc;

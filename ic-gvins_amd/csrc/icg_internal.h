@@ -56,6 +56,7 @@ struct icg_ctx {
     uint32_t *d_roi_max   = nullptr;
     unsigned long long *d_cand = nullptr;
     int32_t *d_cand_cnt   = nullptr;
+    int roi_state_cap     = 0;       // entries of d_roi_max / d_cand_cnt (zero between calls: k_select clears what it consumed)
     size_t cand_cap_per_roi = 0;
 
     // mirrored staging arena (pinned host <-> device), bump-allocated per call

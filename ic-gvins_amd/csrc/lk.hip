@@ -37,6 +37,9 @@ using namespace icgd;
 #define LK_JS 36   // J tile row stride in bytes (9 dwords: 3 aligned dwords cover any 8-byte run)
 #define LK_JM 5    // J tile margin around the 22x22 support
 #define LK_MAX_ITERS 30
+#ifndef LK_WAVES_PER_EU
+#define LK_WAVES_PER_EU 5 // second __launch_bounds__ argument of k_lk_track_fb: 95 VGPRs, no scratch (6 would spill; 4, 5 and 6 measured equal in the bench)
+#endif
 
 struct lk_smem {
     unsigned int I[LK_IT * LK_IS / 4];
@@ -374,51 +377,65 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
 #pragma unroll
         for (int k = 0; k < 7; k++) JA[k] = JB[k] = 0;
 
-        for (int j = 0; j < LK_MAX_ITERS; j++) {
+        // The Gauss-Newton iterations, as EPOCHS of constant integer window position: the lane's pixel pairs JA/JB are fetched once per epoch
+        // and are loop-invariant inside it (written as one loop with a conditional re-fetch, they were loop-carried through the condition
+        // and the compiler copied all 14 registers twice per iteration: 28 of ~130 VALU instructions).  Same checks in the same order.
+        int j = 0;
+        bool more = true;
+        while (more) {
             const int inx = (int) floorf(nptx), iny = (int) floorf(npty);
             if (inx < -ICG_LK_WIN || inx >= W || iny < -ICG_LK_WIN || iny >= H) {
                 if (level == 0) status = false;
                 break;
             }
-            if (inx != cinx || iny != ciny) {
-                if (!(inx >= jx0 && inx <= jx0 + (LK_JT - 22) && iny >= jy0 && iny <= jy0 + (LK_JT - 22))) {
-                    jx0 = inx - LK_JM;
-                    jy0 = iny - LK_JM;
-                    __syncthreads();
-                    lk_stage_J(S, J, W, H, pitch, jx0, jy0, lane);
-                    __syncthreads();
+            if (!(inx >= jx0 && inx <= jx0 + (LK_JT - 22) && iny >= jy0 && iny <= jy0 + (LK_JT - 22))) {
+                jx0 = inx - LK_JM;
+                jy0 = iny - LK_JM;
+                __syncthreads();
+                lk_stage_J(S, J, W, H, pitch, jx0, jy0, lane);
+                __syncthreads();
+            }
+            lk_fetch_J(S, iny - jy0 + ly, (inx - jx0) + lx0, JA, JB);
+            cinx = inx;
+            ciny = iny;
+            for (;;) {
+                lk_weights(nptx - inx, npty - iny, w00, w01, w10, w11);
+                W0 = pk_lo16(w00, w01);
+                W1 = pk_lo16(w10, w11);
+                int diff[7];
+#pragma unroll
+                for (int k = 0; k < 7; k++) diff[k] = dot2(JB[k], W1, dot2(JA[k], W0, c0[k])) >> 9;
+                int sb1 = 0, sb2 = 0;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const unsigned int dp = m < 3 ? pk_lo16(diff[2 * m], diff[2 * m + 1]) : (unsigned int) diff[6]; // IXP[3].hi == 0
+                    sb1 = dot2(dp, IXP[m], sb1);
+                    sb2 = dot2(dp, IYP[m], sb2);
                 }
-                lk_fetch_J(S, iny - jy0 + ly, (inx - jx0) + lx0, JA, JB);
-                cinx = inx;
-                ciny = iny;
+                const float b1 = wave_sum_i32x8_f32(sb1) * FLT_SCALE, b2 = wave_sum_i32x8_f32(sb2) * FLT_SCALE;
+                const float dx = (float) ((A12 * b2 - A22 * b1) * D);
+                const float dy = (float) ((A12 * b1 - A11 * b2) * D);
+                nptx += dx;
+                npty += dy;
+                nextStore = make_float2(nptx + (float) ICG_LK_HALF, npty + (float) ICG_LK_HALF);
+                if ((double) dx * dx + (double) dy * dy <= eps2) {
+                    more = false;
+                    break;
+                }
+                if (j > 0 && fabs((double) (dx + pdx)) < 0.01 && fabs((double) (dy + pdy)) < 0.01) {
+                    nextStore.x -= dx * 0.5f;
+                    nextStore.y -= dy * 0.5f;
+                    more = false;
+                    break;
+                }
+                pdx = dx;
+                pdy = dy;
+                if (++j >= LK_MAX_ITERS) {
+                    more = false;
+                    break;
+                }
+                if ((int) floorf(nptx) != inx || (int) floorf(npty) != iny) break; // next epoch: bounds test, tile, fetch
             }
-            lk_weights(nptx - inx, npty - iny, w00, w01, w10, w11);
-            W0 = pk_lo16(w00, w01);
-            W1 = pk_lo16(w10, w11);
-            int diff[7];
-#pragma unroll
-            for (int k = 0; k < 7; k++) diff[k] = dot2(JB[k], W1, dot2(JA[k], W0, c0[k])) >> 9;
-            int sb1 = 0, sb2 = 0;
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const unsigned int dp = m < 3 ? pk_lo16(diff[2 * m], diff[2 * m + 1]) : (unsigned int) diff[6]; // IXP[3].hi == 0
-                sb1 = dot2(dp, IXP[m], sb1);
-                sb2 = dot2(dp, IYP[m], sb2);
-            }
-            const float b1 = wave_sum_i32x8_f32(sb1) * FLT_SCALE, b2 = wave_sum_i32x8_f32(sb2) * FLT_SCALE;
-            const float dx = (float) ((A12 * b2 - A22 * b1) * D);
-            const float dy = (float) ((A12 * b1 - A11 * b2) * D);
-            nptx += dx;
-            npty += dy;
-            nextStore = make_float2(nptx + (float) ICG_LK_HALF, npty + (float) ICG_LK_HALF);
-            if ((double) dx * dx + (double) dy * dy <= eps2) break;
-            if (j > 0 && fabs((double) (dx + pdx)) < 0.01 && fabs((double) (dy + pdy)) < 0.01) {
-                nextStore.x -= dx * 0.5f;
-                nextStore.y -= dy * 0.5f;
-                break;
-            }
-            pdx = dx;
-            pdy = dy;
         }
 
         if (status && level == 0) {
@@ -475,7 +492,7 @@ __global__ __launch_bounds__(64) void k_lk_track(icg_pyr_desc P, int n, const in
     }
 }
 
-__global__ __launch_bounds__(64) void k_lk_track_fb(icg_pyr_desc P, int n, const int32_t *prev_slot,
+__global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_desc P, int n, const int32_t *prev_slot,
                                                     const int32_t *next_slot, const float2 *prev_pts,
                                                     const float2 *guess_pts, float2 *out_pts, unsigned char *status,
                                                     int has_cam, icg_camera cam, float2 *out_undist, int img_w, int img_h) {

@@ -6,11 +6,11 @@
 // best/niters replay).  Mapping:
 //   * the hypothesis index stream depends only on cv::RNG's state, not on scores, so it is generated up front on the
 //     host (same LCG as cv::RNG((uint64)-1)) for a chunk of hypotheses;
-//   * k_seven_point: ONE LANE per hypothesis; as cv::SVDecomp does for m < n, the one-sided Jacobi runs on the 7
-//     full-rank columns of A^T (9x7, REGISTER resident, fully unrolled) and the two null vectors come from completing the
-//     orthonormal basis; only + - * / sqrt are used so results match the CPU restatement bit-for-bit;
-//   * k_fm_score: ONE WAVEFRONT per (hypothesis, model): 64 points per step, symmetric epipolar distance in double,
-//     inlier bits by wave ballot, count by popcount;
+//   * k_fm_hypothesis: ONE WAVEFRONT per hypothesis.  Lane 0 solves the seven-point system: as cv::SVDecomp does for m < n, the
+//     one-sided Jacobi runs on the 7 full-rank columns of A^T (9x7, REGISTER resident, fully unrolled) and the two null vectors come
+//     from completing the orthonormal basis; only + - * / sqrt are used so results match the CPU restatement bit-for-bit.  The whole
+//     wave then scores the (up to three) models: 64 points per step, symmetric epipolar distance in double, inlier bits by wave
+//     ballot, count by popcount;
 //   * the host replays the `best / niters` recurrence over the score array in hypothesis order, which makes the result
 //     identical to the sequential algorithm; further chunks are generated only if niters demands them.
 #include <algorithm>
@@ -18,8 +18,6 @@
 #include <cmath>
 
 #include "icg_internal.h"
-
-#define SP_LANES 64
 
 struct fm_set {
     int pt_begin, n_pts; // range in the concatenated point arrays
@@ -97,15 +95,9 @@ __device__ int dev_solve_cubic_real(const double c[4], double roots[3]) {
     return n;
 }
 
-__global__ __launch_bounds__(SP_LANES, 1) void k_seven_point(int n_hyp_total, const fm_set *sets, const int32_t *hyp_set,
-                                                             const int32_t *hyp_idx /*n_hyp x 7 (set-local)*/,
-                                                             const float2 *pts1, const float2 *pts2,
-                                                             double *models /*n_hyp x 3 x 9*/, int32_t *n_models) {
-    const int lane = threadIdx.x;
-    const int hyp  = blockIdx.x * SP_LANES + lane;
-    if (hyp >= n_hyp_total) return;
-    const fm_set S     = sets[hyp_set[hyp]];
-    const int32_t *idx = hyp_idx + 7 * (size_t) hyp;
+// The seven-point solve of ONE hypothesis by the calling lane: up to three fundamental matrices into out27, their number into *n_out.
+__device__ __forceinline__ void seven_point_solve(const fm_set &S, const int32_t *idx /*7, set-local*/, const float2 *pts1, const float2 *pts2,
+                                                  double *out27, int *n_out) {
     // M = A^T (9 x 7) register resident; see oracle/orc_ransac.cc null_space_9x7 for the definition this mirrors.
     double M[9][7];
 #pragma unroll
@@ -224,7 +216,7 @@ __global__ __launch_bounds__(SP_LANES, 1) void k_seven_point(int n_hyp_total, co
            f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
     double roots[3];
     const int n = dev_solve_cubic_real(c, roots);
-    double *out = models + 27 * (size_t) hyp;
+    double *out = out27;
     for (int k = 0; k < n; k++) {
         double lambda = roots[k], mu = 1.;
         double s   = f1[8] * roots[k] + f2[8];
@@ -237,48 +229,65 @@ __global__ __launch_bounds__(SP_LANES, 1) void k_seven_point(int n_hyp_total, co
             Fk[8] = 0.;
         for (int i = 0; i < 8; i++) Fk[i] = f1[i] * lambda + f2[i] * mu;
     }
-    n_models[hyp] = n;
+    *n_out = n;
 }
 
-// grid: (3 models, n_hyp_total); one wave per (hypothesis, model)
-__global__ __launch_bounds__(64) void k_fm_score(const fm_set *sets, const int32_t *hyp_set, const float2 *pts1,
-                                                 const float2 *pts2, const double *models, const int32_t *n_models,
-                                                 float thresh2, int32_t *good /*n_hyp x 3*/,
-                                                 unsigned long long *bits) {
-    const int model = blockIdx.x, hyp = blockIdx.y, lane = threadIdx.x;
-    if (model >= n_models[hyp]) {
-        if (lane == 0) good[hyp * 3 + model] = -1;
-        return;
+// k_fm_hypothesis: ONE WAVE per hypothesis.  Lane 0 solves the seven-point system (a strictly serial FP64 chain: Jacobi sweeps, basis
+// completion, cubic), the models go through LDS, then the whole wave scores each model over the set's points (64 points per step,
+// symmetric epipolar distance in double, inlier bits by wave ballot, count by popcount).  One launch instead of a solve launch, a score
+// launch and an upload: on a hardware queue shared by several stream groups every launch costs ~75-100 us whatever its size
+// (profiles/r02_queue_view.json).  All inputs are read where the host wrote them (pinned staging memory, zero-copy): 14 points by lane 0,
+// and every point of the set once per model, coalesced.
+__global__ __launch_bounds__(64, 1) void k_fm_hypothesis(int n_hyp_total, const fm_set *sets, const int32_t *hyp_set,
+                                                         const int32_t *hyp_idx /*n_hyp x 7 (set-local)*/, const float2 *pts1,
+                                                         const float2 *pts2, float thresh2, int32_t *good /*n_hyp x 3*/,
+                                                         unsigned long long *bits) {
+    __shared__ double Fm[27];
+    __shared__ int n_sh;
+    const int hyp = blockIdx.x, lane = threadIdx.x;
+    if (hyp >= n_hyp_total) return;
+    const fm_set S = sets[hyp_set[hyp]];
+    if (lane == 0) {
+        int n = 0;
+        seven_point_solve(S, hyp_idx + 7 * (size_t) hyp, pts1, pts2, Fm, &n);
+        n_sh = n;
     }
-    const fm_set S  = sets[hyp_set[hyp]];
-    const double *F = models + 27 * (size_t) hyp + 9 * model;
-    const double F0 = F[0], F1 = F[1], F2 = F[2], F3 = F[3], F4 = F[4], F5 = F[5], F6 = F[6], F7 = F[7], F8 = F[8];
-    unsigned long long *w = bits + S.word_begin + ((size_t) (hyp - S.hyp_begin) * 3 + model) * S.words_per_model;
-    int count = 0;
-    for (int base = 0; base < S.n_pts; base += 64) {
-        const int i = base + lane;
-        bool in     = false;
-        if (i < S.n_pts) {
-            const float2 p1 = pts1[S.pt_begin + i], p2 = pts2[S.pt_begin + i];
-            const double x1 = p1.x, y1 = p1.y, x2 = p2.x, y2 = p2.y;
-            double a = F0 * x1 + F1 * y1 + F2;
-            double b = F3 * x1 + F4 * y1 + F5;
-            double c = F6 * x1 + F7 * y1 + F8;
-            double s2 = 1. / (a * a + b * b);
-            double d2 = x2 * a + y2 * b + c;
-            a         = F0 * x2 + F3 * y2 + F6;
-            b         = F1 * x2 + F4 * y2 + F7;
-            c         = F2 * x2 + F5 * y2 + F8;
-            double s1 = 1. / (a * a + b * b);
-            double d1 = x1 * a + y1 * b + c;
-            float e   = (float) fmax(d1 * d1 * s1, d2 * d2 * s2);
-            in        = e <= thresh2;
+    __syncthreads();
+    const int n_models = n_sh;
+    for (int model = 0; model < 3; model++) {
+        if (model >= n_models) {
+            if (lane == 0) good[hyp * 3 + model] = -1;
+            continue;
         }
-        const unsigned long long m = __ballot(in);
-        if (lane == 0) w[base >> 6] = m;
-        count += __popcll(m);
+        const double *F = Fm + 9 * model;
+        const double F0 = F[0], F1 = F[1], F2 = F[2], F3 = F[3], F4 = F[4], F5 = F[5], F6 = F[6], F7 = F[7], F8 = F[8];
+        unsigned long long *w = bits + S.word_begin + ((size_t) (hyp - S.hyp_begin) * 3 + model) * S.words_per_model;
+        int count = 0;
+        for (int base = 0; base < S.n_pts; base += 64) {
+            const int i = base + lane;
+            bool in     = false;
+            if (i < S.n_pts) {
+                const float2 p1 = pts1[S.pt_begin + i], p2 = pts2[S.pt_begin + i];
+                const double x1 = p1.x, y1 = p1.y, x2 = p2.x, y2 = p2.y;
+                double a = F0 * x1 + F1 * y1 + F2;
+                double b = F3 * x1 + F4 * y1 + F5;
+                double c = F6 * x1 + F7 * y1 + F8;
+                double s2 = 1. / (a * a + b * b);
+                double d2 = x2 * a + y2 * b + c;
+                a         = F0 * x2 + F3 * y2 + F6;
+                b         = F1 * x2 + F4 * y2 + F7;
+                c         = F2 * x2 + F5 * y2 + F8;
+                double s1 = 1. / (a * a + b * b);
+                double d1 = x1 * a + y1 * b + c;
+                float e   = (float) fmax(d1 * d1 * s1, d2 * d2 * s2);
+                in        = e <= thresh2;
+            }
+            const unsigned long long m = __ballot(in);
+            if (lane == 0) w[base >> 6] = m;
+            count += __popcll(m);
+        }
+        if (lane == 0) good[hyp * 3 + model] = count;
     }
-    if (lane == 0) good[hyp * 3 + model] = count;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -415,25 +424,19 @@ extern "C" int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, c
                       (size_t) nh_total * (27 * 8 + 4 + 12) + (size_t) words * 8 + 16384;
         int rc = c.reserve(need);
         if (rc) return rc;
-        const fm_set *d_sets  = c.in(sets.data(), sets.size());
-        const int32_t *d_hset = c.in(hyp_set.data(), (size_t) nh_total);
-        const int32_t *d_hidx = c.in(hyp_idx.data(), 7 * (size_t) nh_total);
-        const float2 *d_p1    = (const float2 *) c.in(pts1, 2 * (size_t) total);
-        const float2 *d_p2    = (const float2 *) c.in(pts2, 2 * (size_t) total);
+        // everything the launch reads stays where it is staged (pinned memory, read over PCIe): no upload launch
+        const fm_set *d_sets  = c.in_zc(sets.data(), sets.size());
+        const int32_t *d_hset = c.in_zc(hyp_set.data(), (size_t) nh_total);
+        const int32_t *d_hidx = c.in_zc(hyp_idx.data(), 7 * (size_t) nh_total);
+        const float2 *d_p1    = (const float2 *) c.in_zc(pts1, 2 * (size_t) total);
+        const float2 *d_p2    = (const float2 *) c.in_zc(pts2, 2 * (size_t) total);
         if ((rc = c.seal())) return rc;
-        double *d_models  = c.out((double *) nullptr, 27 * (size_t) nh_total);
-        int32_t *d_nm     = c.out((int32_t *) nullptr, (size_t) nh_total);
         int32_t *d_good   = c.out_zc(h_good.data(), (size_t) nh_total * 3);
         unsigned long long *d_bits = c.out_zc(h_bits.data(), (size_t) words);
         {
-            icg_prof_scope ps(ctx, "fm_seven_point");
-            hipLaunchKernelGGL(k_seven_point, dim3((nh_total + SP_LANES - 1) / SP_LANES), dim3(SP_LANES), 0, ctx->stream,
-                               nh_total, d_sets, d_hset, d_hidx, d_p1, d_p2, d_models, d_nm);
-        }
-        {
-            icg_prof_scope ps(ctx, "fm_score");
-            hipLaunchKernelGGL(k_fm_score, dim3(3, nh_total), dim3(64), 0, ctx->stream, d_sets, d_hset, d_p1, d_p2, d_models,
-                               d_nm, (float) (thresh * thresh), d_good, d_bits);
+            icg_prof_scope ps(ctx, "fm_hypothesis");
+            hipLaunchKernelGGL(k_fm_hypothesis, dim3(nh_total), dim3(64), 0, ctx->stream, nh_total, d_sets, d_hset, d_hidx, d_p1, d_p2,
+                               (float) (thresh * thresh), d_good, d_bits);
         }
         ICG_HIP(ctx, hipGetLastError());
         if ((rc = c.finish())) return rc;

@@ -23,6 +23,9 @@ for CNT in FETCH_SIZE WRITE_SIZE; do
 done
 python $R/profiles/summarize_pmc.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_reproj_FETCH_SIZE $OUT/${TAG}_pmc_reproj_WRITE_SIZE > $OUT/${TAG}_pmc_summary.json
 find $OUT/${TAG}_kt -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
+# queue-level view of the same trace (hardware-queue occupancy, kernels in flight, per-kernel duration under load)
+KT=$(find $OUT/${TAG}_kt -name "*kernel_trace.csv" | head -1)
+[ -n "$KT" ] && python $R/profiles/analyze_trace.py "$KT" > $OUT/${TAG}_queue_view.json
 ls -la $OUT | grep ${TAG}
 # the raw per-dispatch tables are large: keep only the summaries (gpurun merges at most 64 MiB back)
 rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_reproj_FETCH_SIZE $OUT/${TAG}_pmc_reproj_WRITE_SIZE $OUT/${TAG}_kt
