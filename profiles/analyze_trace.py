@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Queue-level view of a rocprofv3 --kernel-trace CSV (…_kernel_trace.csv): how busy every hardware queue is, how many kernels run side by
-side, and how long each kernel takes while the others run.  Restricted to the densest part of the run (the middle half of the k_lk_track_fb
-dispatches = the steady front-end).  usage: analyze_trace.py <kernel_trace.csv>  -> JSON on stdout"""
+side, and how long each kernel takes while the others run.  Restricted to the densest part of the run (the quarter of the k_lk_track_fb
+dispatches that lie closest together = the steady front-end).  usage: analyze_trace.py <kernel_trace.csv>  -> JSON on stdout"""
 import csv
 import json
 import sys
@@ -16,7 +16,10 @@ lk = [r for r in rows if r[2].startswith("k_lk_track_fb")]
 if len(lk) < 40:
     print(json.dumps({"error": "too few k_lk_track_fb dispatches", "n": len(lk)}))
     sys.exit(0)
-t0, t1 = lk[len(lk) // 4][0], lk[3 * len(lk) // 4][0]
+# the densest run of consecutive k_lk_track_fb dispatches (a quarter of them, at most 2500): the steady state of the main front-end block
+N = max(20, min(2500, len(lk) // 4))
+best = min(range(len(lk) - N), key=lambda i: lk[i + N][0] - lk[i][0])
+t0, t1 = lk[best][0], lk[best + N][0]
 win = [r for r in rows if r[0] >= t0 and r[1] <= t1]
 span = float(t1 - t0)
 per_q = defaultdict(list)
