@@ -140,6 +140,25 @@ def committed_pmc(kernel):
     return json.load(open(files[-1])).get(kernel), os.path.basename(files[-1])
 
 
+def frontend_valu(pmc_file, streams_per_launch, fps):
+    """Vector-ALU issue rate of the whole front-end against the chip's: sum over the image kernels of SQ_INSTS_VALU per launch x launches
+    (the committed --pmc summary of the bench configuration), per frame, x the measured frames/s, / (256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles
+    per wave64 instruction, MI355X_MICROARCH.md).  None when the summary is missing or has no LK entry."""
+    try:
+        allp = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+        lk = allp["k_lk_track_fb"]
+        per_step = sum(float(v.get("SQ_INSTS_VALU", 0.0)) * float(v.get("launches", 0.0)) for kk, v in allp.items()
+                       if kk.startswith("k_") and kk != "k_reproj_eval" and isinstance(v, dict)) / float(lk["launches"])
+        per_frame = per_step / float(streams_per_launch)
+        peak = 256 * 4 * 2.4e9 / 2.0
+        return {"wave_instructions_per_frame": int(per_frame), "lk_share": round(float(lk["SQ_INSTS_VALU"]) / per_step, 3),
+                "achieved_per_s": round(per_frame * fps, 1), "peak_per_s": peak, "frac": round(per_frame * fps / peak, 4),
+                "how": f"profiles/{pmc_file}: sum of SQ_INSTS_VALU x launches over the image kernels per frame x frames/s, against 256 CUs x 4 SIMDs x "
+                       "2.4 GHz / 2 cycles per wave64 VALU instruction"}
+    except Exception:
+        return None
+
+
 def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, steps, rank, local_rank, host_threads, host_frames,
                  profile, barrier, ncpu, hostprof=False):
     """One front-end throughput measurement: B independent synthetic streams in G free-running groups, raw frames resident in HBM,
@@ -404,9 +423,13 @@ def main():
                 roofline["issue_frac"] = round(pmc["SQ_ACTIVE_INST_ANY"] / max(1.0, pmc.get("SQ_WAVE_CYCLES", 0.0) or 1.0), 4) \
                     if pmc.get("SQ_WAVE_CYCLES") else None
                 roofline["issue_frac_how"] = f"profiles/{pmc_file}: SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of k_{dom} (share of its wave-cycles in which an instruction issued)"
+            if pmc_file:
+                roofline["valu"] = frontend_valu(pmc_file, per_launch_streams, fps)
             if dom == "lk_track_fb":
-                roofline["note"] = ("LK keeps its working set in LDS/VGPRs by design (8.5 KB of image per point, ~10k VALU "
-                                    "instructions on it): it is instruction-issue bound, not HBM bound (profiles/)")
+                roofline["note"] = ("LK keeps its working set in LDS/VGPRs by design (8.5 KB of image per point, ~9.3k VALU instructions on it): HBM "
+                                    "is the wrong roof, and so is raw VALU issue (`valu.frac`): with 48 stream groups on 20 hardware queues every "
+                                    "launch, however small, takes 110-230 us while ~16 others run (profiles/r02_queue_view.json) — the front-end is "
+                                    "bound by launch latency under load x launches per frame, see DESIGN.md section 4")
         else:
             roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                         "traffic": None}
