@@ -694,6 +694,19 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
     }
 }
 
+// the dense helpers of the window solvers (dense_kernels.cc), for tests: in-place Cholesky solve of A x = b (row-major, lower triangle
+// read; A is overwritten with the factor, b with x; -1 = not positive definite) and T (upper triangle) += J^T J, g += J^T r
+int icgh_dense_cholesky_solve(int n, double *A, double *b) {
+    vector<double> Av(A, A + (size_t) n * n), bv(b, b + n);
+    if (!solver_detail::choleskySolve(n, Av, bv)) return -1;
+    memcpy(A, Av.data(), sizeof(double) * (size_t) n * n);
+    memcpy(b, bv.data(), sizeof(double) * (size_t) n);
+    return 0;
+}
+void icgh_dense_accumulate_jtj(int nr, int nf, const double *J, const double *r, double *T, double *g) {
+    solver_detail::accumulateJtJ(nr, nf, J, r, T, g);
+}
+
 // ---- f1: the window optimization flow of GVINS::gvinsOptimization (ic_gvins.cc:1130-1239) on WindowSolver -----------------
 // Reprojection factors from flat arrays (as icgh_backend_reproj) + one PosePriorFactor per pose (weight prior_weight, target
 // prior_poses: fixes the gauge like the reference's marginalization prior / GNSS factors do).  Two solves with the chi-square
