@@ -323,7 +323,7 @@ def main():
     ap.add_argument("--host-threads", type=int, default=1, help="host threads inside each group")
     ap.add_argument("--groups", type=int, default=int(os.environ.get("ICG_BENCH_GROUPS", "0")),
                     help="stream groups per GPU (own HIP stream + host thread each); 0 = sized to the host cores this rank "
-                         "may use: 2 per core, at most 32, at least 2")
+                         "may use: 3 per core, at most 48, at least 2 (sharding.host_plan)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reproj", action="store_true", help="skip the back-end / next-row blocks (reproj, ins, solve, marg, cull, replay, c4)")
     ap.add_argument("--no-replay", action="store_true", help="skip the estimator replay block (16 host threads of estimators; skipped under rocprofv3)")

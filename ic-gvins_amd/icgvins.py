@@ -359,6 +359,24 @@ class Context:
                  "icg_reproj_schur_windows")
         return S, s, dg, cost
 
+    def reproj_reserve_windows(self, P):
+        self._ck(self.lib.icg_reproj_reserve_windows(self.h, int(P)), "icg_reproj_reserve_windows")
+
+    def reproj_schur_windows_view(self, P, col_pose, col_ext, col_td, active=None, reassemble=None, damp=None, min_diag=1e-6, max_diag=1e32):
+        """icg_reproj_schur_windows_view: the reduced systems are read where the reduction kernel left them (a copy is returned; only the
+        16 x 16 tiles on and below the diagonal are defined)"""
+        W = self._nwin
+        s, dg, cost = np.zeros((W, P)), np.zeros((W, P)), np.zeros(W)
+        act = None if active is None else np.ascontiguousarray(active, np.uint8)
+        re = np.ones(W, np.uint8) if reassemble is None else np.ascontiguousarray(reassemble, np.uint8)
+        dm = np.zeros(W) if damp is None else _f64(damp)
+        view = C.POINTER(C.c_double)()
+        self._ck(self.lib.icg_reproj_schur_windows_view(self.h, int(P), _p(_i32(col_pose)), _p(_i32(col_ext)), _p(_i32(col_td)), _p(act), _p(re), _p(dm),
+                                                         C.c_double(min_diag), C.c_double(max_diag), C.byref(view), _p(s), _p(dg), _p(cost)),
+                 "icg_reproj_schur_windows_view")
+        S = np.ctypeslib.as_array(view, shape=(W, P, P)).copy()
+        return S, s, dg, cost
+
     def reproj_backsub_windows(self, P, delta_c, n_lm):
         out, terms = np.zeros(n_lm), np.zeros((self._nwin, 2))
         self._ck(self.lib.icg_reproj_backsub_windows(self.h, int(P), _p(_f64(delta_c)), _p(out), _p(terms)), "icg_reproj_backsub_windows")
