@@ -337,6 +337,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # a multi-GPU run measures the sharded front-end (value, roofline): the CPU baselines (contract: rank 0 at N=1 only) and the
+        # single-GPU next-row blocks would run on rank 0 alone while the other ranks wait in the final barrier
+        args.no_cpu_baseline = True
+        args.no_reproj = True
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
