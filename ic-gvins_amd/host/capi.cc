@@ -5,6 +5,7 @@
 #include <stdexcept>
 #include <thread>
 #include <atomic>
+#include <mutex>
 
 #include "tracking_batch.h"
 #include "hostprof.h"
@@ -213,6 +214,7 @@ int icgh_batch_features(icgh_batch *b, int stream, int max, uint64_t *ids, float
 
 // ---- back-end test/driver entry points -----------------------------------------------------------------------------------
 #include "factors.h"
+#include "object_pool.h"
 #include "misc_hip.h"
 #include "solver_hip.h"
 #include "solver_batch_hip.h"
@@ -692,6 +694,77 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
         set_err(err, errlen, e.what());
         return -1;
     }
+}
+
+// BlockPool / PoolAllocator (object_pool.h) under cross-thread traffic, for tests: `threads` workers each allocate `iters` blocks of two
+// size classes, stamp them, hand every second one to the next worker through a mailbox (freed on a thread other than the allocating one:
+// the spill / refill path of the per-thread lists) and free the rest themselves; every block is checked for its stamp before it is freed.
+// Returns the number of corrupted blocks (0 = pass), -1 on an internal error.
+int icgh_pool_selftest(int threads, int iters) {
+    struct Small {
+        uint64_t tag, a;
+    };
+    struct Large {
+        uint64_t tag, pad[11];
+    };
+    if (threads < 1 || iters < 1) return -1;
+    std::vector<std::mutex> box_m((size_t) threads);
+    std::vector<std::vector<std::pair<void *, int>>> box((size_t) threads); // (block, size class)
+    std::atomic<int> bad{0}, live{0};
+    auto check_free = [&](void *p, int cls) {
+        if (cls == 0) {
+            Small *s = static_cast<Small *>(p);
+            if (s->tag != (0xabcdef0000000000ull ^ (uint64_t) (uintptr_t) p) || s->a != ~s->tag) bad++;
+            PoolAllocator<Small>().deallocate(s, 1);
+        } else {
+            Large *l = static_cast<Large *>(p);
+            if (l->tag != (0x1234560000000000ull ^ (uint64_t) (uintptr_t) p) || l->pad[10] != ~l->tag) bad++;
+            PoolAllocator<Large>().deallocate(l, 1);
+        }
+        live--;
+    };
+    auto worker = [&](int t) {
+        std::vector<std::pair<void *, int>> mine;
+        for (int i = 0; i < iters; i++) {
+            const int cls = (i + t) & 1;
+            void *p;
+            if (cls == 0) {
+                Small *s = PoolAllocator<Small>().allocate(1);
+                s->tag   = 0xabcdef0000000000ull ^ (uint64_t) (uintptr_t) s;
+                s->a     = ~s->tag;
+                p        = s;
+            } else {
+                Large *l   = PoolAllocator<Large>().allocate(1);
+                l->tag     = 0x1234560000000000ull ^ (uint64_t) (uintptr_t) l;
+                l->pad[10] = ~l->tag;
+                p          = l;
+            }
+            live++;
+            if (i & 1) {
+                std::lock_guard<std::mutex> lock(box_m[(size_t) ((t + 1) % threads)]);
+                box[(size_t) ((t + 1) % threads)].emplace_back(p, cls);
+            } else {
+                mine.emplace_back(p, cls);
+            }
+            if ((i & 63) == 63) { // drain the mailbox and half of the own blocks (LIFO reuse follows)
+                std::vector<std::pair<void *, int>> got;
+                {
+                    std::lock_guard<std::mutex> lock(box_m[(size_t) t]);
+                    got.swap(box[(size_t) t]);
+                }
+                for (auto &g : got) check_free(g.first, g.second);
+                for (size_t k = mine.size() / 2; k < mine.size(); k++) check_free(mine[k].first, mine[k].second);
+                mine.resize(mine.size() / 2);
+            }
+        }
+        for (auto &m : mine) check_free(m.first, m.second);
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(worker, t);
+    for (auto &t : th) t.join();
+    for (int t = 0; t < threads; t++)
+        for (auto &g : box[(size_t) t]) check_free(g.first, g.second);
+    return live.load() == 0 ? bad.load() : -1;
 }
 
 // the dense helpers of the window solvers (dense_kernels.cc), for tests: in-place Cholesky solve of A x = b (row-major, lower triangle

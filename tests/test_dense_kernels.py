@@ -61,3 +61,12 @@ def test_accumulate_jtj_is_the_cell_by_cell_inner_product(nr, nf):
     assert np.array_equal(np.triu(T), np.triu(ref_T))
     assert np.array_equal(np.tril(T, -1), np.tril(T0, -1))  # the lower triangle is not touched
     assert np.array_equal(g, ref_g)
+
+
+def test_block_pool_cross_thread_traffic():
+    """host/object_pool.h: blocks allocated on one thread and freed on another (spill / refill of the per-thread lists), two size classes,
+    LIFO reuse — no block is handed out twice or loses its contents"""
+    lib = C.CDLL(ensure_oracle_host())
+    lib.icgh_pool_selftest.argtypes = [C.c_int, C.c_int]
+    for threads, iters in [(1, 5000), (4, 40000), (7, 30001)]:
+        assert lib.icgh_pool_selftest(threads, iters) == 0, (threads, iters)
