@@ -85,6 +85,7 @@ int main(int argc, char **argv) {
         return 0;
     }
     icg::ReplaySummary s;
+    icg::WindowSolver::setHostFactorOverlap(true); // one stream: the host factors of a linearization run beside the device calls
     if (!icg::Replay::run(o, s, &err)) {
         fprintf(stderr, "icg_replay: %s\n", err.c_str());
         return 1;
