@@ -1,12 +1,14 @@
 #!/bin/bash
 # Race detection for the host layer (not part of pytest: ~10 minutes).  Builds the checker's all-in-one host library (product host layer +
-# tools on the CPU shim of the C ABI) with -fsanitize=thread in a scratch copy and runs, under ThreadSanitizer:
+# tools on the CPU shim of the C ABI) with -fsanitize=$SAN in a scratch copy and runs, under ThreadSanitizer:
 #   1. block_pool.cc        BlockPool / PoolAllocator: allocate on one thread, free on another
 #   2. frontend_groups.cc   StreamGroups: 6 streams in 3 groups x 2 host threads, 30 frames each (worker threads, HostPool, pooled objects)
 #   3. icg_replay_oracle    one estimator with the host-factor helper thread (WindowSolver::setHostFactorOverlap)
 #   4. icg_replay_oracle --streams 3 --lockstep-groups 1   WindowSolverBatch with its persistent pool
 # Expected: 0 "WARNING: ThreadSanitizer" in every log (round 2: all four clean).
+# SAN=address,undefined tests/tsan/run.sh /tmp/icg_asan runs the same four under AddressSanitizer + UBSan (round 2: 2. and 3. clean).
 set -eu
+SAN=${SAN:-thread}
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 W=${1:-/tmp/icg_tsan}
 rm -rf $W && mkdir -p $W/src
@@ -14,12 +16,12 @@ python3 $ROOT/tests/tsan/make_inputs.py $W > $W/inputs.txt
 read CFG IMU GNSS IMG < $W/inputs.txt
 cp -r $ROOT/include $ROOT/ic-gvins_amd $ROOT/oracle $W/src/
 find $W/src -name "*.o" -delete; rm -f $W/src/oracle/*.so $W/src/oracle/icg_replay_oracle
-make -s -C $W/src/oracle -j8 CXXFLAGS="-O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-psabi -pthread -fsanitize=thread" liboracle.so libicgvins_host_oracle.so icg_replay_oracle
-export TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0"
-g++ -std=c++17 -O1 -g -fsanitize=thread -pthread $ROOT/tests/tsan/block_pool.cc -o $W/block_pool && $W/block_pool > $W/1_block_pool.log 2>&1
-g++ -std=c++17 -O1 -g -fsanitize=thread -pthread $ROOT/tests/tsan/frontend_groups.cc -o $W/frontend_groups -L$W/src/oracle -licgvins_host_oracle -loracle -Wl,-rpath,$W/src/oracle
+make -s -C $W/src/oracle -j8 CXXFLAGS="-O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-psabi -pthread -fsanitize=$SAN" liboracle.so libicgvins_host_oracle.so icg_replay_oracle
+export TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" ASAN_OPTIONS="detect_leaks=0"
+g++ -std=c++17 -O1 -g -fsanitize=$SAN -pthread $ROOT/tests/tsan/block_pool.cc -o $W/block_pool && $W/block_pool > $W/1_block_pool.log 2>&1
+g++ -std=c++17 -O1 -g -fsanitize=$SAN -pthread $ROOT/tests/tsan/frontend_groups.cc -o $W/frontend_groups -L$W/src/oracle -licgvins_host_oracle -loracle -Wl,-rpath,$W/src/oracle
 $W/frontend_groups > $W/2_frontend_groups.log 2>&1
 (cd $W/src/oracle && LD_LIBRARY_PATH=. ./icg_replay_oracle --config $CFG --imu $IMU --gnss $GNSS --images $IMG --output $W/out1 > $W/3_replay_single.log 2>&1)
 mkdir -p $W/out3
 (cd $W/src/oracle && LD_LIBRARY_PATH=. ./icg_replay_oracle --config $CFG --imu $IMU --gnss $GNSS --images $IMG --output $W/out3 --streams 3 --lockstep-groups 1 > $W/4_replay_lockstep.log 2>&1)
-for f in $W/[1-4]_*.log; do echo "$(basename $f): $(grep -c 'WARNING: ThreadSanitizer' $f || true) warnings; $(tail -1 $f | cut -c1-140)"; done
+for f in $W/[1-4]_*.log; do echo "$(basename $f): $(grep -c 'WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error' $f || true) reports; $(tail -1 $f | cut -c1-140)"; done
