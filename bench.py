@@ -429,7 +429,7 @@ def main():
                     if pmc.get("SQ_WAVE_CYCLES") else None
                 roofline["issue_frac_how"] = f"profiles/{pmc_file}: SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of k_{dom} (share of its wave-cycles in which an instruction issued)"
             if pmc_file:
-                roofline["valu"] = frontend_valu(pmc_file, per_launch_streams, fps)
+                roofline["valu"] = frontend_valu(pmc_file, per_launch_streams, fps / max(1, world))  # per GPU: the peak is one chip's
             if dom == "lk_track_fb":
                 roofline["note"] = ("LK keeps its working set in LDS/VGPRs by design (8.5 KB of image per point, ~9.3k VALU instructions on it): HBM "
                                     "is the wrong roof, and so is raw VALU issue (`valu.frac`): with 48 stream groups on 20 hardware queues every "
