@@ -99,10 +99,15 @@ class StreamBatch:
     """ctypes driver of icgh_batch (host/capi.cc): N independent streams tracked in lock-step on one device."""
 
     def __init__(self, lib_path, n_streams, width, height, cam10, max_features=300, window=10, min_parallax=20.0,
-                 max_interval=0.5, check_hist=False, reproj_std=1.5, device=0, host_threads=1, groups=1):
+                 max_interval=0.5, check_hist=False, reproj_std=1.5, device=0, host_threads=1, groups=1, engine=None):
+        """engine: None (ICG_TRACK_ENGINE or the default, the track table), "table" or "object" (the reference-shaped object graph:
+        needed by the entry points that work on the tracker's icg::Map — culling, window refinement, landmark tables)."""
         if not os.path.exists(lib_path):
             raise RuntimeError(f"{lib_path} not found (build first; there is no fallback)")
         self.lib = C.CDLL(lib_path)
+        old_engine = os.environ.get("ICG_TRACK_ENGINE")
+        if engine is not None:
+            os.environ["ICG_TRACK_ENGINE"] = engine
         self.lib.icgh_batch_create.restype = C.c_void_p
         self.lib.icgh_batch_ctx.restype = C.c_void_p
         self.lib.icgh_batch_ctx.argtypes = [C.c_void_p, C.c_int]
@@ -113,9 +118,29 @@ class StreamBatch:
         self.h_ = self.lib.icgh_batch_create(device, n_streams, cam.ctypes.data_as(C.c_void_p), width, height, max_features,
                                              C.c_double(min_parallax), C.c_double(max_interval), 1 if check_hist else 0,
                                              C.c_double(reproj_std), window, host_threads, groups, err, 512)
+        if engine is not None:
+            if old_engine is None:
+                del os.environ["ICG_TRACK_ENGINE"]
+            else:
+                os.environ["ICG_TRACK_ENGINE"] = old_engine
         if not self.h_:
             raise RuntimeError("icgh_batch_create failed: " + err.value.decode())
         self._err = err
+
+    def engine(self):
+        return ["table", "object"][self.lib.icgh_batch_engine(C.c_void_p(self.h_))]
+
+    def dump(self, stream, kind=0):
+        """canonical text of a stream's tracker + map state: kind 0 the engine's state, 1 the map part (table engine), 2 the map part
+        computed from the materialized object graph (table engine's B2 view)"""
+        self.lib.icgh_batch_dump.restype = C.c_long
+        self.lib.icgh_batch_dump.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_long]
+        n = self.lib.icgh_batch_dump(C.c_void_p(self.h_), stream, kind, None, C.c_long(0))
+        if n < 0:
+            raise RuntimeError(f"icgh_batch_dump failed: {n}")
+        buf = C.create_string_buffer(n + 1)
+        self.lib.icgh_batch_dump(C.c_void_p(self.h_), stream, kind, buf, C.c_long(n + 1))
+        return buf.value.decode()
 
     def close(self):
         if getattr(self, "h_", None):

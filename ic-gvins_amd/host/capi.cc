@@ -62,15 +62,16 @@ int icgh_batch_run(icgh_batch *b, int K, const void *const *images, int stride, 
     try {
         const int n = b->tb->size();
         auto t0     = std::chrono::steady_clock::now();
-        vector<vector<Frame::Ptr>> frames((size_t) K, vector<Frame::Ptr>((size_t) n));
+        vector<vector<FrameInput>> frames((size_t) K, vector<FrameInput>((size_t) n));
         for (int k = 0; k < K; k++)
             for (int i = 0; i < n; i++) {
                 const size_t j = (size_t) k * n + i;
                 if (!images[j]) continue;
-                Mat img = Mat::wrap((uint8_t *) images[j], b->h, b->w, channels, (size_t) stride, on_device != 0);
-                auto f  = Frame::createFrame(stamps[j], img, b->tb->stream(i).ids);
-                f->setPose(poseFromArray12(poses12 + 12 * j));
-                frames[(size_t) k][(size_t) i] = f;
+                FrameInput &f = frames[(size_t) k][(size_t) i];
+                f.valid       = true;
+                f.stamp       = stamps[j];
+                f.image       = Mat::wrap((uint8_t *) images[j], b->h, b->w, channels, (size_t) stride, on_device != 0);
+                f.pose        = poseFromArray12(poses12 + 12 * j);
             }
         vector<vector<TrackState>> st;
         auto t1 = std::chrono::steady_clock::now();
@@ -105,8 +106,8 @@ int icgh_batch_stats(icgh_batch *b, int stream, uint64_t *out8) {
     out8[2] = s.tracked_sum;
     out8[3] = s.digest;
     out8[4] = s.ids->mappoint_id;
-    out8[5] = s.map->keyframes().size();
-    out8[6] = s.map->landmarks().size();
+    out8[5] = s.windowKeyFrames();
+    out8[6] = s.landmarks();
     out8[7] = (uint64_t) s.last_state;
     return 0;
 }
@@ -179,8 +180,8 @@ int icgh_hostprof(double *out, int max_sections, char *names, int names_len, int
 // the tracker's un-triangulated candidate points in list order: cur[2k..] (pts2d_new_), ref[2k..] (pts2d_ref_)
 int icgh_batch_candidates(icgh_batch *b, int stream, int max, float *cur, float *ref) {
     if (!b || stream < 0 || stream >= b->tb->size()) return -1;
-    const auto &pn = b->tb->stream(stream).tracking->trackedRefPoints();
-    const auto &pr = b->tb->stream(stream).tracking->referencePoints();
+    const auto &pn = b->tb->stream(stream).trackedRefPoints();
+    const auto &pr = b->tb->stream(stream).referencePoints();
     int n = (int) std::min(pn.size(), pr.size());
     if (n > max) n = max;
     for (int k = 0; k < n; k++) {
@@ -193,21 +194,68 @@ int icgh_batch_candidates(icgh_batch *b, int stream, int max, float *cur, float 
 // features of the stream's current frame, sorted by map-point id: ids[k], px[2k..2k+1] (distorted keypoint)
 int icgh_batch_features(icgh_batch *b, int stream, int max, uint64_t *ids, float *px) {
     if (!b || stream < 0 || stream >= b->tb->size()) return -1;
-    auto frame = b->tb->stream(stream).tracking->currentFrame();
-    if (!frame) return 0;
-    auto feats = frame->features();
-    vector<ulong> v;
-    for (auto &kv : feats) v.push_back(kv.first);
-    std::sort(v.begin(), v.end());
+    vector<std::pair<ulong, Point2f>> v;
+    b->tb->stream(stream).currentFeatures(v);
+    std::sort(v.begin(), v.end(), [](const auto &a, const auto &c) { return a.first < c.first; });
     int n = 0;
-    for (ulong id : v) {
+    for (const auto &kv : v) {
         if (n >= max) break;
-        ids[n]        = id;
-        px[2 * n]     = feats[id]->distortedKeyPoint().x;
-        px[2 * n + 1] = feats[id]->distortedKeyPoint().y;
+        ids[n]        = kv.first;
+        px[2 * n]     = kv.second.x;
+        px[2 * n + 1] = kv.second.y;
         n++;
     }
     return n;
+}
+
+// 0 = track table (default), 1 = object graph (ICG_TRACK_ENGINE=object)
+int icgh_batch_engine(icgh_batch *b) { return b ? (int) b->tb->group(0).engine() : -1; }
+
+// canonical text dump of a stream's tracker + map state (engine-vs-engine tests): kind 0 = the engine's state, 1 = the map part of the
+// table engine's state, 2 = the same text computed from the table engine's materialized object graph (B2 view).  Returns the length
+// of the text (the buffer receives at most len-1 characters), -1 on bad arguments.
+long icgh_batch_dump(icgh_batch *b, int stream, int kind, char *out, long len) {
+    if (!b || stream < 0 || stream >= b->tb->size()) return -1;
+    try {
+        const std::string s = b->tb->stream(stream).dump(kind);
+        if (out && len > 0) {
+            const size_t n = std::min((size_t) len - 1, s.size());
+            memcpy(out, s.data(), n);
+            out[n] = 0;
+        }
+        return (long) s.size();
+    } catch (const std::exception &) {
+        return -2;
+    }
+}
+
+// HashOrder (track_table.h) against a real std::unordered_map<ulong, int>: n random distinct keys inserted one by one, the iteration
+// orders compared after every `check_every` insertions.  Returns 0 when they always agree, k > 0 = first disagreement after k insertions.
+int icgh_hashorder_selftest(uint64_t seed, int n, int check_every, int dense_ids) {
+    std::unordered_map<ulong, int> ref;
+    HashOrder h;
+    h.clear();
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
+    ulong next_id = seed % 1000;
+    for (int k = 0; k < n; k++) {
+        x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+        ulong key = dense_ids ? (next_id += 1 + (x % 3)) : (ulong) (x % 1000003);
+        if (ref.count(key)) {
+            if (h.insert(key)) return k + 1; // duplicates must be refused
+            continue;
+        }
+        ref.emplace(key, (int) h.size());
+        if (!h.insert(key)) return k + 1;
+        if ((k + 1) % check_every == 0 || k + 1 == n) {
+            int r = h.head();
+            for (const auto &kv : ref) {
+                if (r < 0 || r != kv.second) return k + 1;
+                r = h.next(r);
+            }
+            if (r >= 0) return k + 1;
+        }
+    }
+    return 0;
 }
 
 } // extern "C"
@@ -481,6 +529,7 @@ int icgh_batch_landmark_table(icgh_batch *b, int stream, int max_lm, int max_obs
                               float *obs_pix) {
     if (!b || stream < 0 || stream >= b->tb->size()) return -1;
     auto &S = b->tb->stream(stream);
+    if (!S.map) return -4; // needs the object engine (ICG_TRACK_ENGINE=object)
     vector<ulong> ids;
     for (auto &kv : S.map->landmarks()) ids.push_back(kv.first);
     std::sort(ids.begin(), ids.end());
@@ -527,6 +576,7 @@ int icgh_batch_landmark_table(icgh_batch *b, int stream, int max_lm, int max_obs
 int icgh_batch_set_landmark_pos(icgh_batch *b, int stream, int n, const uint64_t *ids, const double *pos3) {
     if (!b || stream < 0 || stream >= b->tb->size()) return -1;
     auto &S = b->tb->stream(stream);
+    if (!S.map) return -4; // needs the object engine (ICG_TRACK_ENGINE=object)
     for (int k = 0; k < n; k++) {
         auto it = S.map->landmarks().find(ids[k]);
         if (it == S.map->landmarks().end()) return -2;
@@ -542,6 +592,7 @@ int icgh_batch_culling(icgh_batch *b, int mode, const int32_t *list_off, const u
                        double *stats5, char *err, int errlen) {
     try {
         const int n = b->tb->size();
+        if (!b->tb->stream(0).map) throw std::runtime_error("culling over the tracker's map needs the object engine (ICG_TRACK_ENGINE=object)");
         vector<std::unordered_map<ulong, double>> lists((size_t) n);
         vector<WindowCulling::Stream> streams;
         for (int s = 0; s < n; s++) {
@@ -589,6 +640,7 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
                               int iters2, double chi2, double *out7, int max_kf, double *kf_out, char *err, int errlen) {
     try {
         const int n = b->tb->size();
+        if (!b->tb->stream(0).map) throw std::runtime_error("window refinement on the tracker's map needs the object engine (ICG_TRACK_ENGINE=object)");
         Pose pbc;
         pbc = poseFromArray12(pose_b_c12);
         icg_ctx *ctx = b->tb->group(0).device()->ctx();

@@ -168,6 +168,13 @@ public:
         iskeyframe_     = false;
         keyframe_state_ = KEYFRAME_NONE;
     }
+    // materialization hook (TableTracker::materialize): keyframe flag / id / state as recorded, no id is drawn from the id space
+    void restoreKeyFrame(bool iskeyframe, ulong keyframe_id, int state) {
+        ModelLock lock(frame_mutex_);
+        iskeyframe_     = iskeyframe;
+        keyframe_id_    = keyframe_id;
+        keyframe_state_ = state;
+    }
     Mat &image() { return image_; }
     // frame.cc:34 deep-copies every incoming image into raw_image_ for the drawer.  Here the copy (0.9 MB per C2 frame on the
     // ingest thread) is made only when someone asked for it — Tracking does when is_use_visualization is set; otherwise
@@ -352,6 +359,14 @@ public:
         ModelLock lock(mappoint_mutex_);
         return optimized_times_;
     }
+    // materialization hook (TableTracker::materialize): the counters as recorded (addObservation counted the live observations only)
+    void restoreCounters(int used, int observed, int optimized, bool outlier) {
+        ModelLock lock(mappoint_mutex_);
+        used_times_      = used;
+        observed_times_  = observed;
+        optimized_times_ = optimized;
+        isoutlier_       = outlier;
+    }
     void removeAllObservations() {
         ModelLock lock(mappoint_mutex_);
         // releasing a weak_ptr is a locked decrement of the observing feature's control block: one cold line per observation, spread
@@ -474,6 +489,17 @@ public:
     bool isWindowNormal() {
         ModelLock lock(map_mutex_);
         return keyframes_.size() == window_size_;
+    }
+    // materialization hook (TableTracker::materialize): keyframes under their keys and landmarks (inserted in the order given)
+    void restore(const vector<std::pair<ulong, Frame::Ptr>> &keyframes, const vector<MapPoint::Ptr> &landmarks, const Frame::Ptr &latest,
+                 bool is_window_full) {
+        ModelLock lock(map_mutex_);
+        keyframes_.clear();
+        landmarks_.clear();
+        for (const auto &k : keyframes) keyframes_[k.first] = k.second;
+        for (const auto &m : landmarks) landmarks_[m->id()] = m;
+        latest_keyframe_ = latest;
+        is_window_full_  = is_window_full;
     }
 
 private:

@@ -1,0 +1,288 @@
+// Table engine of the front-end: the reference's per-frame algorithm (ic_gvins/ic_gvins/tracking/tracking.cc:144-245, :351-455,
+// :457-574, :576-688, :690-798, :263-307) on an arena-resident structure-of-arrays track table instead of the shared_ptr / weak_ptr /
+// unordered_map object graph of tracking/{frame,feature,mappoint,map}.h.
+//
+// Why: with hundreds of camera streams per host the object graph costs ~140 us of host CPU per frame (pointer chasing through cold
+// memory, ~10 locked reference-count operations per feature), which bounds both the one-GPU rate and the GPUs one host can feed.
+// Here a frame is a handful of contiguous arrays (map-point handle, undistorted / distorted pixel, normalized-plane velocity per
+// feature row), a map point is a row of a per-stream pool, an observation is a (frame, row) pair, and the window bookkeeping of
+// GVINS (ic_gvins.cc:724-747, 1391-1410, 440-448) — `WindowKeeper` for the object engine — works on frame handles.
+//
+// The result is the same, bit for bit: ids, states, key-point bits, candidate lists, the tracking.txt rows.  In particular the
+// features of a frame are visited in the order std::unordered_map<ulong, Feature::Ptr> (frame.h:134) would yield them (HashOrder
+// emulates libstdc++'s bucket list), because the parallax averages (tracking.cc:873-905) are floating-point sums in that order.
+// The B2 surface survives as a view: materialize() builds the reference-shaped icg::Map / Frame / Feature / MapPoint objects of a
+// stream on demand (tests compare them with what icg::Tracking built on the same frames).
+#pragma once
+#include <cstdio>
+#include <string>
+
+#include "tracking.h"
+
+namespace icg {
+
+// Iteration order of a libstdc++ std::unordered_map<ulong, T> with unique keys that has only ever been inserted into (the only use
+// a Frame makes of features_): singly linked node list + per-bucket "node before the bucket's first node" (bits/hashtable.h
+// _M_insert_bucket_begin, _M_rehash_aux(unique keys)), identity hash, bucket = key % bucket_count, bucket counts taken from a real
+// std::unordered_map of this standard library (growthTable()).  Nodes are row indices 0..n-1 inserted in that order.
+class HashOrder {
+public:
+    void clear() {
+        next_.clear();
+        key_.clear();
+        head_ = -1;
+        // (std::unordered_map::clear() keeps its buckets; a Frame's map is only ever cleared while empty, so this is a fresh table)
+        bucket_.assign(1, kEmpty);
+    }
+    void reserveRows(size_t n) {
+        next_.reserve(n);
+        key_.reserve(n);
+    }
+    size_t size() const { return next_.size(); }
+    // appends row index size() with this key; returns false (and adds nothing) if the key is already present
+    bool insert(ulong key);
+    int head() const { return head_; }
+    int next(int i) const { return next_[(size_t) i]; }
+    bool contains(ulong key) const;
+    // bucket count after k insertions into a fresh std::unordered_map<ulong, char> of this libstdc++
+    static size_t bucketsAfter(size_t k);
+
+private:
+    static constexpr int kEmpty = -1, kBeforeBegin = -2;
+    void rehash(size_t n);
+    int nextOf(int prev) const { return prev == kBeforeBegin ? head_ : next_[(size_t) prev]; }
+    void setNext(int prev, int i) {
+        if (prev == kBeforeBegin)
+            head_ = i;
+        else
+            next_[(size_t) prev] = i;
+    }
+    vector<int> next_, bucket_{kEmpty};
+    vector<ulong> key_;
+    int head_{-1};
+};
+
+class TableTracker {
+public:
+    typedef std::shared_ptr<TableTracker> Ptr;
+    struct Input {
+        double stamp{0};
+        Mat image;
+        Pose pose;
+    };
+
+    TableTracker(Camera::Ptr camera, size_t window_size, const TrackingConfig &config, const std::string &outputpath,
+                 DeviceContext::Ptr device, std::shared_ptr<IdSpace> ids);
+    ~TableTracker();
+
+    // ---- staged interface (same stages as icg::Tracking) ----
+    void beginFrame(const Input &in, StageBatch &next);
+    void advance(int stage, StageBatch &done, StageBatch &next);
+    bool frameDone() const { return done_; }
+    TrackState result() const { return result_; }
+    bool isNewKeyFrame() const { return isnewkeyframe_; }
+    // sliding-window side effects of GVINS on the map after a frame (WindowKeeper::onFrame) + release of dead frames
+    void endFrame();
+
+    const icg_detect_grid &grid() const { return grid_; }
+    int maxFeaturesPerJob() const { return grid_.max_per_block * block_cnts_; }
+    size_t numTrackedRefPoints() const { return pts2d_new_.size(); }
+    const vector<Point2f> &trackedRefPoints() const { return pts2d_new_; }
+    const vector<Point2f> &referencePoints() const { return pts2d_ref_; }
+
+    // ---- results of the current frame ----
+    ulong currentFrameId() const;
+    ulong lastInputFrameId() const { return last_input_fid_; } // id of the frame handed to the last beginFrame (also when it was skipped)
+    size_t numCurrentFeatures() const;
+    // visits (map-point id, distorted key point) of the current frame's features, container order
+    template <typename F> void forEachCurrentFeature(F &&f) const {
+        if (cur_ < 0) return;
+        const Frame_ &fr = frames_[(size_t) cur_];
+        for (int r = fr.order.head(); r >= 0; r = fr.order.next(r)) f(fr.id[(size_t) r], fr.kpd[(size_t) r]);
+    }
+    size_t windowKeyFrames() const { return map_kf_.size(); }
+    size_t landmarks() const { return n_landmarks_; }
+
+    // ---- B2 view: the reference-shaped object graph of this stream, built on demand ----
+    // keyframes of the window (+ the tracker's current / previous / reference frames when they are not keyframes) with their features,
+    // the landmarks with position / reference frame / depth / counters / observation lists.  `extra` receives the non-keyframe frames.
+    Map::Ptr materialize(vector<Frame::Ptr> *extra = nullptr) const;
+    // canonical text dump of the state (sorted by ids; floats as bit patterns), for engine-vs-engine tests
+    std::string dump() const;
+    // the same dump computed from an object graph (icg::Tracking + Map)
+    static std::string dumpObjects(Tracking &tracking, Map &map);
+    std::string dumpMap() const;          // the map part of dump()
+    std::string dumpMaterialized() const; // the same text computed from materialize(): must equal dumpMap()
+
+private:
+    struct Frame_ {
+        bool alive{false};
+        uint32_t gen{0};
+        ulong fid{0}, kf_id{0};
+        double stamp{0};
+        Pose pose;
+        bool is_kf{false};
+        int kf_state{KEYFRAME_NORMAL}; // frame.h default
+        int slot{-1};
+        Mat image;
+        // feature rows (insertion order); `order` is the container order of the reference's features_
+        vector<ulong> id;        // map-point id (the container key)
+        vector<uint32_t> mp, mpgen; // map-point handle
+        vector<Point2f> kp, kpd; // undistorted / distorted key point
+        vector<Vector2d> vel;
+        vector<int8_t> type;
+        HashOrder order;
+        vector<uint32_t> unupdated, unupdated_gen; // map points created with this frame as the current one (frame.h unupdated_mappoints_)
+        size_t rows() const { return id.size(); }
+        void clearRows();
+    };
+    struct LastObs {
+        int32_t frame{-1};
+        uint32_t gen{0};
+        int32_t row{-1};
+    };
+    struct MapPoints { // per-stream pool, structure of arrays; handle = (index, gen)
+        vector<uint32_t> gen;
+        vector<uint8_t> live, outlier, in_map;
+        vector<ulong> id, born_fid;
+        vector<Vector3d> pos;
+        vector<int32_t> ref_frame;
+        vector<uint32_t> ref_gen;
+        vector<Point2f> ref_kp;
+        vector<double> depth;
+        vector<int8_t> type;
+        vector<int32_t> used, observed, optimized;
+        vector<LastObs> last;
+        vector<uint32_t> free_list;
+        uint32_t alloc();
+        void release(uint32_t i) {
+            live[i] = 0;
+            gen[i]++;
+            free_list.push_back(i);
+        }
+        bool valid(uint32_t i, uint32_t g) const { return live[i] && gen[i] == g; }
+    };
+
+    // frames
+    int allocFrame();
+    void freeFrame(int h);
+    void sweepFrames();
+    void setKeyFrame(int h, int state);
+    int addRow(int h, ulong id, uint32_t mp, const Point2f &kp, const Point2f &kpd, const Vector2d &vel, FeatureType type);
+    vector<ulong> observationFrames(uint32_t mp, const vector<int> &alive_by_fid) const;
+    bool frameValid(int h, uint32_t g) const { return h >= 0 && frames_[(size_t) h].alive && frames_[(size_t) h].gen == g; }
+
+    // map (tracking/map.cc) on handles
+    void mapInsertKeyFrame(int h);
+    void mapRemoveKeyFrame(int h, bool isremovemappoint);
+    bool mapIsWindowFull() const { return is_window_full_; }
+    bool mapIsWindowNormal() const { return map_kf_.size() == window_size_; }
+    bool mapIsKeyFrameInMap(int h) const;
+    int mapFind(ulong kf_id) const;
+
+    // stage bodies (tracking_hip.cc has the object-graph twins)
+    void onPreprocessDone(StageBatch &done, StageBatch &next);
+    void onDetectADone(StageBatch &done, StageBatch &next);
+    void onLKDone(StageBatch &done, StageBatch &next);
+    void onRansacDone(StageBatch &done, StageBatch &next);
+    void onTriangulateDone(StageBatch &done, StageBatch &next);
+    void onDetectBDone(StageBatch &done);
+    void finish(TrackState st);
+    bool queueDetection(int frame, bool ismask, StageBatch &next);
+    void integrateDetection(StageBatch &done);
+    void queueTrackMappoint(StageBatch &next);
+    bool finishTrackMappoint(StageBatch &done);
+    void queueTrackReference(StageBatch &next);
+    bool midTrackReference(StageBatch &done, StageBatch &next);
+    bool finishTrackReference(StageBatch &done);
+    bool queueTriangulation(StageBatch &next);
+    void finishTriangulation(StageBatch &done);
+    void makeNewFrameQueue(int state, StageBatch &next);
+    keyFrameState checkKeyFrameSate();
+    void writeLoggingMessage();
+    bool doResetTracking();
+    double relativeTranslation() const;
+    double relativeRotation() const;
+    int parallaxFromReferenceKeyPoints(const vector<Point2f> &ref, const vector<Point2f> &cur, double &parallax);
+    int parallaxFromReferenceMapPoints(double &parallax);
+    double keyPointParallax(const Point2f &pp0, const Point2f &pp1, const Matrix3d &R10) const;
+    bool isGoodToTrack(const Point2f &pp, const Pose &pose, const Vector3d &pw, double scale, double depth_scale) const;
+    bool isOnBorder(const Point2f &pts) const;
+    void checkCarriedUndistortion(const char *where);
+    void assignSlot(int h);
+    void releaseUnusedSlots();
+    template <typename T> static void reduceVector(T &vec, const vector<uint8_t> &status);
+
+    const double TRACK_BLOCK_SIZE   = 200.0; // tracking.h:112
+    const double TRACK_MIN_PARALLAX = 10.0;  // tracking.h:114
+    const double TRACK_MIN_INTERVAl = 0.08;  // tracking.h:115
+
+    Camera::Ptr camera_;
+    DeviceContext::Ptr device_;
+    std::shared_ptr<IdSpace> ids_;
+    TrackingConfig cfg_;
+
+    vector<Frame_> frames_;
+    vector<int> free_frames_;
+    MapPoints mps_;
+    int cur_{-1}, ref_{-1}, pre_{-1}, last_keyframe_{-1}, pending_{-1};
+
+    // map
+    size_t window_size_;
+    struct MapKf {
+        ulong key;
+        int frame;
+    };
+    vector<MapKf> map_kf_; // unordered in the reference; every use sorts or searches by key
+    int latest_keyframe_{-1};
+    bool is_window_full_{false};
+    size_t n_landmarks_{0};
+
+    // candidates (tracking.h:129-136)
+    vector<Point2f> pts2d_cur_, pts2d_new_, pts2d_ref_, pts2d_ref_undis_, pts2d_new_undis_;
+    vector<int> pts2d_ref_frame_;
+    vector<Vector2d> velocity_ref_, velocity_cur_;
+    struct MpRef {
+        uint32_t i, g;
+    };
+    vector<MpRef> tracked_mappoint_, mappoint_matched_;
+
+    int block_cols_, block_rows_, block_cnts_, block_w_, block_h_, track_max_block_features_;
+    icg_detect_grid grid_{};
+    double parallax_map_{0}, parallax_ref_{0};
+    int parallax_map_counts_{0}, parallax_ref_counts_{0};
+    bool isnewkeyframe_{false}, isinitializing_{true};
+    double histogram_{0};
+    int passed_cnt_{0};
+    int track_min_pixel_distance_;
+    double track_max_interval_;
+    FILE *logfile_{nullptr};
+    std::chrono::steady_clock::time_point t_start_;
+    vector<double> logging_data_;
+
+    // per-frame staged state
+    bool done_{true};
+    TrackState result_{TRACK_PASSED};
+    int pending_slot_{-1};
+    vector<int> owned_slots_;
+    enum Mode { M_NONE, M_FIRST, M_INIT, M_TRACK } mode_{M_NONE};
+    int det_job_{-1};
+    bool det_ismask_{true};
+    int det_frame_{-1};
+    int lk_map_begin_{0}, lk_map_n_{0}, lk_ref_begin_{0}, lk_ref_n_{0};
+    vector<Point2f> tm_pts2d_map_, tm_pts2d_map_undis_, tm_pred_;
+    bool ref_tracked_{false};
+    int rs_set_{-1};
+    vector<Point2f> tr_new_undis_, tr_cur_undis_;
+    keyFrameState kf_state_{KEYFRAME_NONE};
+    bool tri_queued_{false};
+    int tri_begin_{0};
+    vector<int> tri_point_index_;
+    vector<uint8_t> tri_status_, status_;
+    vector<Point2f> tri_ref_undis_, tri_cur_undis_, scratch_a_, scratch_b_;
+    int lost_reset_{0};
+    ulong last_input_fid_{0};
+    vector<uint8_t> mark_;
+};
+
+} // namespace icg

@@ -108,6 +108,16 @@ public:
     const vector<Point2f> &referencePoints() const { return pts2d_ref_; }
     const Frame::Ptr &currentFrame() const { return frame_cur_; }
     const Frame::Ptr &referenceFrame() const { return frame_ref_; }
+    // tracker state for engine-vs-engine tests (TableTracker::dumpObjects)
+    const Frame::Ptr &previousFrame() const { return frame_pre_; }
+    const Frame::Ptr &lastKeyFrame() const { return last_keyframe_; }
+    const vector<Frame::Ptr> &referencePointFrames() const { return pts2d_ref_frame_; }
+    const vector<Vector2d> &referenceVelocities() const { return velocity_ref_; }
+    bool initializing() const { return isinitializing_; }
+    double parallaxMap() const { return parallax_map_; }
+    double parallaxRef() const { return parallax_ref_; }
+    int parallaxMapCounts() const { return parallax_map_counts_; }
+    int parallaxRefCounts() const { return parallax_ref_counts_; }
 
 public:
     static constexpr double ASSOCIATE_MAXIUM_DISTANCE      = 1.0;

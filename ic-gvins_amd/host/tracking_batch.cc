@@ -12,14 +12,18 @@
 namespace icg {
 
 TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &intrinsic, const vector<double> &distortion,
-                             const vector<int> &size, const TrackingConfig &cfg, int window_size, int host_threads)
+                             const vector<int> &size, const TrackingConfig &cfg, int window_size, int host_threads, int engine)
     : host_threads_(host_threads < 1 ? 1 : host_threads) {
+    if (engine < 0) { // ICG_TRACK_ENGINE=object|table; the drawer hooks only exist in the object engine
+        const char *e = getenv("ICG_TRACK_ENGINE");
+        engine        = (e && e[0] == 'o') || cfg.is_use_visualization ? ENGINE_OBJECT : ENGINE_TABLE;
+    }
+    engine_ = engine == ENGINE_OBJECT ? ENGINE_OBJECT : ENGINE_TABLE;
     device_ = std::make_shared<DeviceContext>(device, size[0], size[1], n_streams, cfg.track_max_features);
     streams_.resize((size_t) n_streams);
     for (int i = 0; i < n_streams; i++) {
         Stream &s  = streams_[(size_t) i];
         s.camera   = Camera::createCamera(intrinsic, distortion, size);
-        s.map      = std::make_shared<Map>((size_t) window_size);
         s.ids      = std::make_shared<IdSpace>();
         // tracking.txt (tracking.cc:309-315) per stream under $ICG_TRACKING_LOG_DIR/stream<i>/ when that is set
         std::string outputpath;
@@ -28,13 +32,32 @@ TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &in
             if (mkdir(outputpath.c_str(), 0755) != 0 && errno != EEXIST)
                 throw std::runtime_error("TrackingBatch: cannot create " + outputpath);
         }
-        s.tracking = std::make_shared<Tracking>(s.camera, s.map, nullptr, cfg, outputpath, device_, s.ids);
-        s.keeper   = std::make_shared<WindowKeeper>(s.map);
+        if (engine_ == ENGINE_TABLE) {
+            s.table = std::make_shared<TableTracker>(s.camera, (size_t) window_size, cfg, outputpath, device_, s.ids);
+        } else {
+            s.map      = std::make_shared<Map>((size_t) window_size);
+            s.tracking = std::make_shared<Tracking>(s.camera, s.map, nullptr, cfg, outputpath, device_, s.ids);
+            s.keeper   = std::make_shared<WindowKeeper>(s.map);
+        }
     }
     if (host_threads_ > 1 && n_streams > 1) pool_.reset(new HostPool(std::min(host_threads_, n_streams)));
     device_->setCamera(*streams_[0].camera);
-    grid_        = streams_[0].tracking->grid();
-    max_per_job_ = streams_[0].tracking->maxFeaturesPerJob();
+    grid_        = engine_ == ENGINE_TABLE ? streams_[0].table->grid() : streams_[0].tracking->grid();
+    max_per_job_ = engine_ == ENGINE_TABLE ? streams_[0].table->maxFeaturesPerJob() : streams_[0].tracking->maxFeaturesPerJob();
+}
+
+void TrackingBatch::Stream::currentFeatures(vector<std::pair<ulong, Point2f>> &out) const {
+    out.clear();
+    if (table) {
+        table->forEachCurrentFeature([&](ulong id, const Point2f &kp) { out.emplace_back(id, kp); });
+    } else if (auto f = tracking->currentFrame()) {
+        f->forEachFeature([&](ulong id, Feature &ft) { out.emplace_back(id, ft.distortedKeyPoint()); });
+    }
+}
+
+std::string TrackingBatch::Stream::dump(int kind) const {
+    if (table) return kind == 0 ? table->dump() : kind == 1 ? table->dumpMap() : table->dumpMaterialized();
+    return kind == 0 ? TableTracker::dumpObjects(*tracking, *map) : std::string();
 }
 
 template <typename F> void TrackingBatch::forEachStream(F &&f) {
@@ -138,11 +161,22 @@ static inline void fnv(uint64_t &h, const void *p, size_t n) {
     }
 }
 
+// per-feature hash of (map-point id, key-point bits): two rounds of a 64-bit finalizer (the digest visits ~300 features per frame
+// of every stream; byte-wise FNV over the 16 bytes was 5 us of host time per frame)
+static inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
 static inline double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &states) {
+void TrackingBatch::step(const FrameInput *frames, vector<TrackState> &states) {
     const int n = (int) streams_.size();
     hostprof::Scope hp_total(hostprof::STEP_TOTAL);
     double t0 = now_s(), t1;
@@ -154,17 +188,26 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
         Stream &s = streams_[(size_t) i];
         s.box[0].clear();
         s.box[1].clear();
-        if (frames[(size_t) i]) {
+        const FrameInput &in = frames[(size_t) i];
+        if (in.valid) {
             active[(size_t) i] = 1;
             hostprof::Scope hp(hostprof::BEGIN_FRAME);
-            s.tracking->beginFrame(frames[(size_t) i], s.box[0]);
+            if (s.table) {
+                TableTracker::Input ti;
+                ti.stamp = in.stamp, ti.image = in.image, ti.pose = in.pose;
+                s.table->beginFrame(ti, s.box[0]);
+            } else {
+                s.frame = Frame::createFrame(in.stamp, in.image, s.ids);
+                s.frame->setPose(in.pose);
+                s.tracking->beginFrame(s.frame, s.box[0]);
+            }
         }
     });
     t1 = now_s();
     timing[0] += t1 - t0;
     t0 = t1;
-    StageBatch global;
-    vector<std::array<int, 8>> bases;
+    StageBatch &global = global_;
+    vector<std::array<int, 8>> &bases = bases_;
     for (int stage = 1; stage < Tracking::N_STAGES; stage++) {
         gather(cur, global, bases);
         t1 = now_s();
@@ -197,13 +240,16 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
         forEachStream([&](int i) {
             Stream &s = streams_[(size_t) i];
             s.box[nxt].clear();
-            if (active[(size_t) i] && !s.tracking->frameDone()) {
+            if (active[(size_t) i] && !s.frameDone()) {
                 hostprof::Scope hp(stage);
-                s.tracking->advance(stage, s.box[cur], s.box[nxt]);
+                if (s.table)
+                    s.table->advance(stage, s.box[cur], s.box[nxt]);
+                else
+                    s.tracking->advance(stage, s.box[cur], s.box[nxt]);
             }
         });
         for (int i = 0; i < n; i++)
-            if (active[(size_t) i] && !streams_[(size_t) i].tracking->frameDone()) any = true;
+            if (active[(size_t) i] && !streams_[(size_t) i].frameDone()) any = true;
         cur = nxt;
         t1  = now_s();
         timing[0] += t1 - t0;
@@ -212,41 +258,48 @@ void TrackingBatch::step(const vector<Frame::Ptr> &frames, vector<TrackState> &s
     }
     forEachStream([&](int i) {
         if (!active[(size_t) i]) return;
-        Stream &s  = streams_[(size_t) i];
-        TrackState st = s.tracking->result();
+        Stream &s     = streams_[(size_t) i];
+        TrackState st = s.result();
         states[(size_t) i] = st;
         s.last_state       = st;
         s.frames++;
-        if (s.tracking->isNewKeyFrame() || st == TRACK_FIRST_FRAME || st == TRACK_LOST) s.keyframes++;
-        // digest of everything index-like this frame produced: state, frame id, (map-point id, pixel bits) per feature
-        // in id order, and the surviving un-triangulated reference points
-        auto frame = frames[(size_t) i];
+        if (s.isNewKeyFrame() || st == TRACK_FIRST_FRAME || st == TRACK_LOST) s.keyframes++;
+        // digest of everything index-like this frame produced: state, frame id, (map-point id, pixel bits) per feature and the
+        // number of surviving un-triangulated reference points
         {
-        hostprof::Scope hpd(hostprof::DIGEST);
-        int sti    = (int) st;
-        fnv(s.digest, &sti, sizeof sti);
-        ulong fid = frame->id();
-        fnv(s.digest, &fid, sizeof fid);
-        if (st != TRACK_PASSED) {
-            // order-independent combination of per-feature hashes (the container order is not part of the result)
-            uint64_t acc = 0, cnt = 0;
-            frame->forEachFeature([&](ulong id, Feature &f) {
-                uint64_t hf = 1469598103934665603ull;
-                const Point2f &kp = f.distortedKeyPoint();
-                fnv(hf, &id, sizeof id);
-                fnv(hf, &kp, sizeof kp);
-                acc += hf * 0x9E3779B97F4A7C15ull + (hf >> 29);
-                cnt++;
-            });
-            fnv(s.digest, &acc, sizeof acc);
-            fnv(s.digest, &cnt, sizeof cnt);
-            s.tracked_sum += cnt;
-            uint64_t nref = s.tracking->numTrackedRefPoints();
-            fnv(s.digest, &nref, sizeof nref);
-        }
+            hostprof::Scope hpd(hostprof::DIGEST);
+            int sti = (int) st;
+            fnv(s.digest, &sti, sizeof sti);
+            ulong fid = s.table ? s.table->lastInputFrameId() : s.frame->id();
+            fnv(s.digest, &fid, sizeof fid);
+            if (st != TRACK_PASSED) {
+                // order-independent combination of per-feature hashes (the container order is not part of the result)
+                uint64_t acc = 0, cnt = 0;
+                auto one = [&](ulong id, const Point2f &kp) {
+                    uint64_t bits;
+                    memcpy(&bits, &kp, sizeof bits);
+                    const uint64_t hf = mix64(mix64((uint64_t) id) ^ bits);
+                    acc += hf;
+                    cnt++;
+                };
+                if (s.table)
+                    s.table->forEachCurrentFeature(one);
+                else
+                    s.frame->forEachFeature([&](ulong id, Feature &f) { one(id, f.distortedKeyPoint()); });
+                fnv(s.digest, &acc, sizeof acc);
+                fnv(s.digest, &cnt, sizeof cnt);
+                s.tracked_sum += cnt;
+                uint64_t nref = s.trackedRefPoints().size();
+                fnv(s.digest, &nref, sizeof nref);
+            }
         }
         hostprof::Scope hpk(hostprof::KEEPER);
-        s.keeper->onFrame(*s.tracking, frame, st);
+        if (s.table) {
+            s.table->endFrame();
+        } else {
+            s.keeper->onFrame(*s.tracking, s.frame, st);
+            s.frame.reset();
+        }
     });
     t1 = now_s();
     timing[4] += t1 - t0;
@@ -306,14 +359,10 @@ void StreamGroups::workerLoop(int g) {
         std::string err;
         const double tw0 = now_s();
         try {
+            vector<TrackState> st;
             for (size_t k = 0; k < frames_->size(); k++) {
-                vector<Frame::Ptr> fr((*frames_)[k].begin() + b, (*frames_)[k].begin() + e);
-                vector<TrackState> st;
-                groups_[(size_t) g]->step(fr, st);
-                for (int i = b; i < e; i++) {
-                    (*states_)[k][(size_t) i] = st[(size_t) (i - b)];
-                    (*frames_)[k][(size_t) i].reset(); // drop the caller's reference here, on this worker
-                }
+                groups_[(size_t) g]->step((*frames_)[k].data() + b, st);
+                for (int i = b; i < e; i++) (*states_)[k][(size_t) i] = st[(size_t) (i - b)];
             }
         } catch (const std::exception &ex) {
             err = ex.what();
@@ -331,20 +380,17 @@ void StreamGroups::workerLoop(int g) {
     }
 }
 
-void StreamGroups::step(const vector<Frame::Ptr> &frames, vector<TrackState> &states) {
-    vector<vector<Frame::Ptr>> f1(1, frames);
+void StreamGroups::step(const vector<FrameInput> &frames, vector<TrackState> &states) {
+    vector<vector<FrameInput>> f1(1, frames);
     vector<vector<TrackState>> s1;
     stepMany(f1, s1);
     states = s1[0];
 }
 
-void StreamGroups::stepMany(vector<vector<Frame::Ptr>> &frames, vector<vector<TrackState>> &states) {
+void StreamGroups::stepMany(const vector<vector<FrameInput>> &frames, vector<vector<TrackState>> &states) {
     states.assign(frames.size(), vector<TrackState>((size_t) n_streams_, TRACK_PASSED));
     if (workers_.empty()) {
-        for (size_t k = 0; k < frames.size(); k++) {
-            groups_[0]->step(frames[k], states[k]);
-            for (auto &f : frames[k]) f.reset();
-        }
+        for (size_t k = 0; k < frames.size(); k++) groups_[0]->step(frames[k].data(), states[k]);
         return;
     }
     {

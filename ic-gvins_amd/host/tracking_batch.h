@@ -10,28 +10,55 @@
 
 #include "host_pool.h"
 #include "tracking.h"
+#include "track_table.h"
 
 namespace icg {
 
+// One incoming frame of one stream: what FusionROS::imageCallback + GVINS::runTracking hand to Tracking::track (ROS/fusion_ros.cc:201-234,
+// ic_gvins.cc:531): stamp, image (host or device memory, not copied) and the INS pose prior.  valid == false idles the stream that step.
+struct FrameInput {
+    bool valid{false};
+    double stamp{0};
+    Mat image;
+    Pose pose;
+};
+
 class TrackingBatch {
 public:
+    // Two engines run the same per-frame algorithm behind the same stages: the track table (track_table.h; default, the throughput
+    // path) and the reference-shaped object graph (icg::Tracking + Map + WindowKeeper; ICG_TRACK_ENGINE=object).  Per-stream results are
+    // identical (tests/test_host_engines_cpu.py).
+    enum Engine { ENGINE_TABLE = 0, ENGINE_OBJECT = 1 };
     struct Stream {
         Camera::Ptr camera;
-        Map::Ptr map;
+        std::shared_ptr<IdSpace> ids;
+        TableTracker::Ptr table; // ENGINE_TABLE
+        Map::Ptr map;            // ENGINE_OBJECT
         Tracking::Ptr tracking;
         std::shared_ptr<WindowKeeper> keeper;
-        std::shared_ptr<IdSpace> ids;
+        Frame::Ptr frame; // the object engine's frame of the current step
         StageBatch box[2];
+        bool frameDone() const { return table ? table->frameDone() : tracking->frameDone(); }
+        TrackState result() const { return table ? table->result() : tracking->result(); }
+        bool isNewKeyFrame() const { return table ? table->isNewKeyFrame() : tracking->isNewKeyFrame(); }
+        const vector<Point2f> &trackedRefPoints() const { return table ? table->trackedRefPoints() : tracking->trackedRefPoints(); }
+        const vector<Point2f> &referencePoints() const { return table ? table->referencePoints() : tracking->referencePoints(); }
+        size_t windowKeyFrames() const { return table ? table->windowKeyFrames() : map->keyframes().size(); }
+        size_t landmarks() const { return table ? table->landmarks() : map->landmarks().size(); }
+        // (map-point id, distorted key point) of the features of the stream's current frame, unordered
+        void currentFeatures(vector<std::pair<ulong, Point2f>> &out) const;
+        std::string dump(int kind) const; // 0: engine state (canonical text), 1: table map part, 2: the same from materialize()
         // statistics / digest
         uint64_t frames{0}, keyframes{0}, tracked_sum{0}, digest{1469598103934665603ull};
         TrackState last_state{TRACK_PASSED};
     };
 
     TrackingBatch(int device, int n_streams, const vector<double> &intrinsic, const vector<double> &distortion,
-                  const vector<int> &size, const TrackingConfig &cfg, int window_size, int host_threads = 1);
+                  const vector<int> &size, const TrackingConfig &cfg, int window_size, int host_threads = 1, int engine = -1);
 
-    // one frame per stream (frames[i] may be null to idle a stream); returns per-stream states
-    void step(const vector<Frame::Ptr> &frames, vector<TrackState> &states);
+    // one frame per stream (frames[i].valid == false idles a stream); returns per-stream states
+    void step(const FrameInput *frames, vector<TrackState> &states);
+    Engine engine() const { return engine_; }
     Stream &stream(int i) { return streams_[(size_t) i]; }
     int size() const { return (int) streams_.size(); }
     DeviceContext::Ptr device() { return device_; }
@@ -56,6 +83,9 @@ private:
 
     DeviceContext::Ptr device_;
     vector<Stream> streams_;
+    Engine engine_{ENGINE_TABLE};
+    StageBatch global_; // the concatenated work lists of a stage (kept: their capacity is the steady-state size)
+    vector<std::array<int, 8>> bases_;
     int host_threads_;
     std::unique_ptr<HostPool> pool_;
     icg_detect_grid grid_{};
@@ -71,11 +101,10 @@ public:
     StreamGroups(int device, int n_streams, int n_groups, const vector<double> &intrinsic, const vector<double> &distortion,
                  const vector<int> &size, const TrackingConfig &cfg, int window_size, int host_threads_per_group);
     ~StreamGroups();
-    void step(const vector<Frame::Ptr> &frames, vector<TrackState> &states);
+    void step(const vector<FrameInput> &frames, vector<TrackState> &states);
     // K consecutive steps without a cross-group barrier in between: every group walks through its own K frames at its
     // own pace (streams are independent, so the per-stream results equal K calls of step()).
-    // (each group releases its reference to a frame as soon as the frame has been processed)
-    void stepMany(vector<vector<Frame::Ptr>> &frames, vector<vector<TrackState>> &states);
+    void stepMany(const vector<vector<FrameInput>> &frames, vector<vector<TrackState>> &states);
     int size() const { return n_streams_; }
     int groups() const { return (int) groups_.size(); }
     TrackingBatch &group(int g) { return *groups_[(size_t) g]; }
@@ -94,7 +123,7 @@ private:
     uint64_t generation_{0};
     int pending_{0};
     bool stop_{false};
-    vector<vector<Frame::Ptr>> *frames_{nullptr};
+    const vector<vector<FrameInput>> *frames_{nullptr};
     vector<vector<TrackState>> *states_{nullptr};
     std::string error_;
 };

@@ -712,8 +712,8 @@ bool Tracking::finishTrackMappoint(StageBatch &done) {
     }
     {
     hostprof::Scope hp_feat(hostprof::LK_MAP_FEATURES);
-    frame_cur_->clearFeatures(); // :426
-    frame_cur_->reserveFeatures(pts2d_matched_undis.size() + 64);
+    frame_cur_->clearFeatures(); // :426 (no bucket reservation: the container must grow exactly as the reference's does, its iteration
+                                 // order is the summation order of the parallax average, :873-905)
     tracked_mappoint_.clear();
     double dt = frame_cur_->stamp() - frame_pre_->stamp();
     for (size_t k = 0; k < pts2d_matched_undis.size(); k++) {

@@ -11,7 +11,7 @@ def check_window_culling(lib_path, oracle, n_streams=3, n_frames=16):
     import harness as H
     w, h = 640, 480
     cam = H.camera_for(w, h)
-    sb = H.StreamBatch(lib_path, n_streams, w, h, cam, max_features=100, window=10)
+    sb = H.StreamBatch(lib_path, n_streams, w, h, cam, max_features=100, window=10, engine="object")  # works on the tracker's icg::Map
     scene = H.SynthScene(sb.lib, w, h, cam, tex_size=1024, threads=4)
     for k in range(n_frames):
         frames = [scene.render(k, stream=s) for s in range(n_streams)]

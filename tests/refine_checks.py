@@ -28,7 +28,7 @@ def check_refinement(lib_path, n_streams=3, n_frames=30):
     import harness as H
     w, h = 640, 480
     cam = H.camera_for(w, h)
-    sb = H.StreamBatch(lib_path, n_streams, w, h, cam, max_features=100, window=10)
+    sb = H.StreamBatch(lib_path, n_streams, w, h, cam, max_features=100, window=10, engine="object")  # works on the tracker's icg::Map
     scene = H.SynthScene(sb.lib, w, h, cam, tex_size=1024, threads=4)
     t0 = 100.0
     for k in range(n_frames):

@@ -1,0 +1,89 @@
+"""The two engines of TrackingBatch — the track table (track_table.h, the throughput path) and the reference-shaped object graph
+(icg::Tracking + Map + WindowKeeper) — must hold the SAME state after every frame: tracker state, candidate lists, window, every live
+frame's features in container order (ids, key-point bits, velocities), every landmark with position, reference frame, counters and
+observation list.  Checked on the canonical text dumps (floats as bit patterns), oracle-backed (CPU).  Also: the table engine's B2 view
+(materialize(): real icg::Map / Frame / Feature / MapPoint objects built from the table) dumps to the same text as the table itself, and
+HashOrder reproduces std::unordered_map's iteration order."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import harness as H
+from stream_utils import ensure_oracle_host
+
+
+def _drive(engine, w, h, nfeat, n_frames, frames, poses, blank=(), check_hist=False, window=10, dump_every=1):
+    cam = H.camera_for(w, h)
+    sb = H.StreamBatch(ensure_oracle_host(), 1, w, h, cam, max_features=nfeat, window=window, engine=engine, check_hist=check_hist)
+    assert sb.engine() == engine
+    dumps, states = [], []
+    for k in range(n_frames):
+        img = frames[k]
+        st = sb.step([img.ctypes.data], w, [100.0 + k / 20.0], poses[k])
+        states.append(int(st[0]))
+        if k % dump_every == 0 or k == n_frames - 1:
+            dumps.append((k, sb.dump(0, 0), sb.dump(0, 1) if engine == "table" else None, sb.dump(0, 2) if engine == "table" else None))
+    stats = sb.stats(0)
+    sb.close()
+    return states, dumps, stats
+
+
+def _scene(w, h, n_frames, stream, blank=(), blank_value=90, slow_after=None):
+    cam = H.camera_for(w, h)
+    lib = C.CDLL(ensure_oracle_host())
+    scene = H.SynthScene(lib, w, h, cam, tex_size=1024, threads=4)
+    warp = (lambda k: float(k)) if slow_after is None else (lambda k: float(k) if k < slow_after[0] else slow_after[0] + (k - slow_after[0]) * slow_after[1])
+    frames = [scene.render(warp(k), stream=stream) for k in range(n_frames)]
+    for k in blank:
+        frames[k] = np.full_like(frames[k], blank_value)
+    poses = []
+    for k in range(n_frames):
+        R, t = scene.pose(warp(k), stream=stream)
+        rng = np.random.RandomState(9000 + k)
+        poses.append(H.pose12(R @ H._rot_yp(*rng.normal(0, np.deg2rad(0.1), 2)), t + rng.normal(0, 0.02, 3)))
+    return frames, poses
+
+
+CASES = {
+    # name: (w, h, features, frames, stream, blank frames, histogram gate, slow phase)
+    "c1_window_rolls": (640, 480, 100, 70, 11, (), False, None),
+    "c1_lost_and_reinit": (640, 480, 100, 34, 12, (14, 15, 16), False, None),
+    "c1_lost_histgate": (640, 480, 100, 34, 13, (14, 15, 16), True, None),
+    "c1_slow_second_new": (640, 480, 100, 40, 14, (), False, (8, 0.02)),
+    "c2": (1280, 720, 300, 16, 15, (), False, None),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_table_engine_state_equals_object_engine(name):
+    w, h, nfeat, n, stream, blank, hist, slow = CASES[name]
+    frames, poses = _scene(w, h, n, stream, blank=blank, blank_value=235 if hist else 90, slow_after=slow)
+    st_t, d_t, stats_t = _drive("table", w, h, nfeat, n, frames, poses, check_hist=hist)
+    st_o, d_o, stats_o = _drive("object", w, h, nfeat, n, frames, poses, check_hist=hist)
+    assert st_t == st_o
+    assert stats_t == stats_o
+    for (k, full_t, map_t, mat_t), (_, full_o, _, _) in zip(d_t, d_o):
+        if full_t != full_o:
+            lt, lo = full_t.splitlines(), full_o.splitlines()
+            first = next((i for i in range(min(len(lt), len(lo))) if lt[i] != lo[i]), min(len(lt), len(lo)))
+            raise AssertionError(f"{name}: engines differ after frame {k}, dump line {first}:\n table : {lt[first] if first < len(lt) else '<end>'}\n"
+                                 f" object: {lo[first] if first < len(lo) else '<end>'}")
+        # B2 view: the materialized object graph says the same as the table
+        if map_t != mat_t:
+            lt, lo = map_t.splitlines(), mat_t.splitlines()
+            first = next((i for i in range(min(len(lt), len(lo))) if lt[i] != lo[i]), min(len(lt), len(lo)))
+            raise AssertionError(f"{name}: materialized view differs after frame {k}, line {first}:\n table       : {lt[first] if first < len(lt) else '<end>'}\n"
+                                 f" materialized: {lo[first] if first < len(lo) else '<end>'}")
+    assert 2 in st_t  # TRACK_TRACKING reached
+    if blank:
+        assert 4 in st_t  # TRACK_LOST exercised
+    assert stats_t["mappoints_created"] > 40
+
+
+def test_hash_order_equals_std_unordered_map():
+    lib = C.CDLL(ensure_oracle_host())
+    lib.icgh_hashorder_selftest.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int]
+    for seed in range(24):
+        for dense in (0, 1):
+            assert lib.icgh_hashorder_selftest(seed, 900, 1 if seed < 4 else 41, dense) == 0, (seed, dense)
