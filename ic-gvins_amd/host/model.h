@@ -68,13 +68,47 @@ public:
     }
     void undistortPoints(vector<Point2f> &pts) const;
     void distortPoints(vector<Point2f> &pts) const;
-    void distortPoint(Point2f &pp) const;
-    Point2f distortCameraPoint(const Vector3d &pc) const;
-    Vector2d reprojectionError(const Pose &pose, const Vector3d &pw, const Point2f &pp) const;
-    static Vector3d world2cam(const Vector3d &world, const Pose &pose);
-    static Vector3d cam2world(const Vector3d &cam, const Pose &pose);
-    Vector3d pixel2cam(const Point2f &pixel) const;
-    Point2f cam2pixel(const Vector3d &cam) const;
+    // The per-point maps are defined here (inline): the front-end evaluates them a few thousand times per frame.
+    void distortPoint(Point2f &pp) const { // camera.cc:91-102
+        Vector3d pc = pixel2cam(pp);
+        double x    = pc.x();
+        double y    = pc.y();
+        double r2   = x * x + y * y;
+        double rr   = (1 + k1_ * r2 + k2_ * r2 * r2 + k3_ * r2 * r2 * r2);
+        pc[0]       = x * rr + 2 * p1_ * x * y + p2_ * (r2 + 2 * x * x);
+        pc[1]       = y * rr + p1_ * (r2 + 2 * y * y) + 2 * p2_ * x * y;
+        pp          = cam2pixel(pc);
+    }
+    Point2f distortCameraPoint(const Vector3d &pc) const { // camera.cc:104-117
+        double x  = pc.x() / pc.z();
+        double y  = pc.y() / pc.z();
+        double r2 = x * x + y * y;
+        double rr = (1 + k1_ * r2 + k2_ * r2 * r2 + k3_ * r2 * r2 * r2);
+        Vector3d pc1;
+        pc1[0] = static_cast<float>(x * rr + 2 * p1_ * x * y + p2_ * (r2 + 2 * x * x));
+        pc1[1] = static_cast<float>(y * rr + p1_ * (r2 + 2 * y * y) + 2 * p2_ * x * y);
+        pc1[2] = 1.0;
+        return cam2pixel(pc1);
+    }
+    Vector2d reprojectionError(const Pose &pose, const Vector3d &pw, const Point2f &pp) const { // camera.cc:153-157
+        Point2f ppp = world2pixel(pw, pose);
+        return {ppp.x - pp.x, ppp.y - pp.y};
+    }
+    static Vector3d world2cam(const Vector3d &world, const Pose &pose) { // camera.cc:145-147: pose.R^T * (world - pose.t)
+        Vector3d d        = world - pose.t;
+        const Matrix3d &R = pose.R;
+        return {R(0, 0) * d[0] + R(1, 0) * d[1] + R(2, 0) * d[2], R(0, 1) * d[0] + R(1, 1) * d[1] + R(2, 1) * d[2],
+                R(0, 2) * d[0] + R(1, 2) * d[1] + R(2, 2) * d[2]};
+    }
+    static Vector3d cam2world(const Vector3d &cam, const Pose &pose) { return pose.R * cam + pose.t; }
+    Vector3d pixel2cam(const Point2f &pixel) const { // camera.cc:123-127
+        double y = (pixel.y - cy_) / fy_;
+        double x = (pixel.x - cx_ - skew_ * y) / fx_;
+        return {x, y, 1.0};
+    }
+    Point2f cam2pixel(const Vector3d &cam) const { // camera.cc:129-131
+        return Point2f((float) ((fx_ * cam[0] + skew_ * cam[1]) / cam[2] + cx_), (float) (fy_ * cam[1] / cam[2] + cy_));
+    }
     Vector3d pixel2world(const Point2f &pixel, const Pose &pose) const { return cam2world(pixel2cam(pixel), pose); }
     Point2f world2pixel(const Vector3d &world, const Pose &pose) const { return cam2pixel(world2cam(world, pose)); }
     int width() const { return width_; }

@@ -33,6 +33,11 @@ size_t HashOrder::bucketsAfter(size_t k) {
     return table[k];
 }
 
+// key % n; the ids of this code base are small counters: a 32-bit division when the key fits
+static inline size_t bucketOf(ulong key, size_t n) {
+    return (key >> 32) == 0 ? (size_t) ((uint32_t) key % (uint32_t) n) : (size_t) (key % n);
+}
+
 void HashOrder::rehash(size_t n) { // bits/hashtable.h _M_rehash_aux(__n, true_type)
     vector<int> nb(n, kEmpty);
     int p = head_;
@@ -40,7 +45,7 @@ void HashOrder::rehash(size_t n) { // bits/hashtable.h _M_rehash_aux(__n, true_t
     size_t bbegin_bkt = 0;
     while (p >= 0) {
         const int nx   = next_[(size_t) p];
-        const size_t b = (size_t) (key_[(size_t) p] % n);
+        const size_t b = bucketOf(key_[(size_t) p], n);
         if (nb[b] == kEmpty) {
             next_[(size_t) p] = head_;
             head_             = p;
@@ -62,19 +67,19 @@ void HashOrder::rehash(size_t n) { // bits/hashtable.h _M_rehash_aux(__n, true_t
 
 bool HashOrder::contains(ulong key) const {
     const size_t n = bucket_.size();
-    const int prev = bucket_[(size_t) (key % n)];
+    const size_t b = bucketOf(key, n);
+    const int prev = bucket_[b];
     if (prev == kEmpty) return false;
-    for (int p = nextOf(prev); p >= 0 && key_[(size_t) p] % n == key % n; p = next_[(size_t) p])
+    for (int p = nextOf(prev); p >= 0 && bucketOf(key_[(size_t) p], n) == b; p = next_[(size_t) p])
         if (key_[(size_t) p] == key) return true;
     return false;
 }
 
-bool HashOrder::insert(ulong key) { // _M_insert_unique_node + _M_insert_bucket_begin
-    if (contains(key)) return false;
+void HashOrder::insertUnique(ulong key) { // _M_insert_unique_node + _M_insert_bucket_begin
     const size_t want = bucketsAfter(next_.size() + 1);
     if (want != bucket_.size()) rehash(want);
     const int i    = (int) next_.size();
-    const size_t n = bucket_.size(), b = (size_t) (key % n);
+    const size_t n = bucket_.size(), b = bucketOf(key, n);
     key_.push_back(key);
     next_.push_back(-1);
     if (bucket_[b] != kEmpty) {
@@ -84,21 +89,14 @@ bool HashOrder::insert(ulong key) { // _M_insert_unique_node + _M_insert_bucket_
     } else {
         next_[(size_t) i] = head_;
         head_             = i;
-        if (next_[(size_t) i] >= 0) bucket_[(size_t) (key_[(size_t) next_[(size_t) i]] % n)] = i;
+        if (next_[(size_t) i] >= 0) bucket_[bucketOf(key_[(size_t) next_[(size_t) i]], n)] = i;
         bucket_[b] = kBeforeBegin;
     }
-    return true;
 }
 
 // ---- pools -------------------------------------------------------------------------------------------------------------------
 void TableTracker::Frame_::clearRows() {
-    id.clear();
-    mp.clear();
-    mpgen.clear();
-    kp.clear();
-    kpd.clear();
-    vel.clear();
-    type.clear();
+    row.clear();
     order.clear();
     unupdated.clear();
     unupdated_gen.clear();
@@ -110,26 +108,15 @@ uint32_t TableTracker::MapPoints::alloc() {
         i = free_list.back();
         free_list.pop_back();
     } else {
-        i = (uint32_t) gen.size();
-        gen.push_back(0);
-        live.push_back(0);
-        outlier.push_back(0);
-        in_map.push_back(0);
-        id.push_back(0);
-        born_fid.push_back(0);
-        pos.emplace_back();
-        ref_frame.push_back(-1);
-        ref_gen.push_back(0);
-        ref_kp.emplace_back();
-        depth.push_back(0);
-        type.push_back(0);
-        used.push_back(0);
-        observed.push_back(0);
-        optimized.push_back(0);
-        last.emplace_back();
+        i = (uint32_t) hot.size();
+        hot.emplace_back();
+        cold.emplace_back();
     }
-    live[i] = 1, outlier[i] = 0, in_map[i] = 0, used[i] = 0, observed[i] = 0, optimized[i] = 0;
-    last[i] = LastObs();
+    const uint32_t g = hot[i].gen;
+    hot[i]           = MapPointHot();
+    hot[i].gen       = g;
+    hot[i].live      = 1;
+    cold[i]          = MapPointCold();
     return i;
 }
 
@@ -158,7 +145,7 @@ void TableTracker::freeFrame(int h) {
     // a map point lives as long as the map or a frame's unupdated list holds it; this frame's list goes away with it
     for (size_t k = 0; k < f.unupdated.size(); k++) {
         const uint32_t i = f.unupdated[k];
-        if (mps_.valid(i, f.unupdated_gen[k]) && !mps_.in_map[i]) mps_.release(i);
+        if (mps_.valid(i, f.unupdated_gen[k]) && !mps_.hot[i].in_map) mps_.release(i);
     }
     f.alive = false;
     f.gen++;
@@ -189,17 +176,15 @@ void TableTracker::setKeyFrame(int h, int state) { // frame.cc:42-54
     }
 }
 
-int TableTracker::addRow(int h, ulong id, uint32_t mp, const Point2f &kp, const Point2f &kpd, const Vector2d &vel, FeatureType type) {
+int TableTracker::addRow(int h, ulong id, uint32_t mp, const Point2f &kp, const Point2f &kpd, const Vector2d &vel, FeatureType type,
+                         double pcx, double pcy, bool unique_key) {
     Frame_ &f = frames_[(size_t) h];
-    if (!f.order.insert(id)) return -1; // std::unordered_map::insert of an existing key adds nothing (frame.h:71-74)
-    f.id.push_back(id);
-    f.mp.push_back(mp);
-    f.mpgen.push_back(mps_.gen[mp]);
-    f.kp.push_back(kp);
-    f.kpd.push_back(kpd);
-    f.vel.push_back(vel);
-    f.type.push_back((int8_t) type);
-    return (int) f.id.size() - 1;
+    if (unique_key)
+        f.order.insertUnique(id);
+    else if (!f.order.insert(id))
+        return -1; // std::unordered_map::insert of an existing key adds nothing (frame.h:71-74)
+    f.row.push_back(Row{id, mp, mps_.hot[mp].gen, kp, kpd, vel, pcx, pcy, (int8_t) type});
+    return (int) f.row.size() - 1;
 }
 
 // ---- map (tracking/map.cc) -----------------------------------------------------------------------------------------------------
@@ -222,8 +207,8 @@ void TableTracker::mapInsertKeyFrame(int h) { // map.cc:27-61
     for (size_t k = 0; k < f.unupdated.size(); k++) {
         const uint32_t i = f.unupdated[k];
         if (!mps_.valid(i, f.unupdated_gen[k])) continue;
-        if (!mps_.in_map[i]) {
-            mps_.in_map[i] = 1;
+        if (!mps_.hot[i].in_map) {
+            mps_.hot[i].in_map = 1;
             n_landmarks_++;
         }
     }
@@ -233,13 +218,13 @@ void TableTracker::mapInsertKeyFrame(int h) { // map.cc:27-61
 void TableTracker::mapRemoveKeyFrame(int h, bool isremovemappoint) { // map.cc:89-127
     Frame_ &f = frames_[(size_t) h];
     if (isremovemappoint) {
-        for (size_t r = 0; r < f.rows(); r++) {
-            const uint32_t i = f.mp[r];
-            if (!mps_.valid(i, f.mpgen[r])) continue;
-            if (mps_.ref_frame[i] == h && mps_.ref_gen[i] == f.gen && mps_.in_map[i]) {
+        for (const Row &r : f.row) {
+            const uint32_t i = r.mp;
+            if (!mps_.valid(i, r.mpgen)) continue;
+            if (mps_.cold[i].ref_frame == h && mps_.cold[i].ref_gen == f.gen && mps_.hot[i].in_map) {
                 // removeAllObservations + setOutlier + landmarks_.erase: nothing can reach it any more
-                mps_.in_map[i]  = 0;
-                mps_.outlier[i] = 1;
+                mps_.hot[i].in_map  = 0;
+                mps_.hot[i].outlier = 1;
                 n_landmarks_--;
                 mps_.release(i);
             }
@@ -247,7 +232,7 @@ void TableTracker::mapRemoveKeyFrame(int h, bool isremovemappoint) { // map.cc:8
         // Frame::clearFeatures (frame.h:46-51): features and the unupdated list
         for (size_t k = 0; k < f.unupdated.size(); k++) {
             const uint32_t i = f.unupdated[k];
-            if (mps_.valid(i, f.unupdated_gen[k]) && !mps_.in_map[i]) mps_.release(i);
+            if (mps_.valid(i, f.unupdated_gen[k]) && !mps_.hot[i].in_map) mps_.release(i);
         }
         f.clearRows();
     }
@@ -359,12 +344,17 @@ int TableTracker::parallaxFromReferenceMapPoints(double &parallax) { // :873-905
     const Frame_ &fc   = frames_[(size_t) cur_];
     const Frame_ &fr   = frames_[(size_t) ref_];
     const Matrix3d R10 = fc.pose.R.transpose() * fr.pose.R;
-    for (int r = fr.order.head(); r >= 0; r = fr.order.next(r)) {
-        const uint32_t i = fr.mp[(size_t) r];
-        if (!mps_.valid(i, fr.mpgen[(size_t) r]) || mps_.outlier[i]) continue; // getMapPoint() && !isOutlier()
-        const LastObs &lo = mps_.last[i];                                     // observations().back().lock()
-        if (lo.frame != cur_ || lo.gen != fc.gen) continue;                   // feat && feat->getFrame() == frame_cur_
-        parallax += keyPointParallax(fr.kp[(size_t) r], fc.kp[(size_t) lo.row], R10);
+    const double focal = camera_->focalLength();
+    for (int q = fr.order.head(); q >= 0; q = fr.order.next(q)) {
+        const Row &r0    = fr.row[(size_t) q];
+        const uint32_t i = r0.mp;
+        if (!mps_.valid(i, r0.mpgen) || mps_.hot[i].outlier) continue; // getMapPoint() && !isOutlier()
+        const LastObs &lo = mps_.hot[i].last;                           // observations().back().lock()
+        if (lo.frame != cur_ || lo.gen != fc.gen) continue;             // feat && feat->getFrame() == frame_cur_
+        const Row &r1 = fc.row[(size_t) lo.row];
+        // keyPointParallax (:861-871) on the rows' stored pixel2cam values
+        const double x = R10(0, 0) * r0.pcx + R10(0, 1) * r0.pcy + R10(0, 2) * 1.0, y = R10(1, 0) * r0.pcx + R10(1, 1) * r0.pcy + R10(1, 2) * 1.0;
+        parallax += Vector2d(x - r1.pcx, y - r1.pcy).norm() * focal;
         counts++;
     }
     if (counts != 0) parallax /= counts;
@@ -451,7 +441,7 @@ keyFrameState TableTracker::checkKeyFrameSate() { // :263-307
     if (keyframe_state != KEYFRAME_NONE) {
         last_keyframe_ = cur_;
         for (const auto &m : tracked_mappoint_)
-            if (mps_.valid(m.i, m.g)) mps_.used[m.i]++;
+            if (mps_.valid(m.i, m.g)) mps_.hot[m.i].used++;
         logging_data_.clear();
         logging_data_.push_back(frames_[(size_t) cur_].stamp);
         logging_data_.push_back(dt);
@@ -673,7 +663,7 @@ bool TableTracker::queueDetection(int frame, bool ismask, StageBatch &next) {
         const long idx = (long) row * block_cols_ + col;
         if (idx >= 0 && idx < (long) block_cnts_) features_cnts[idx]++;
     };
-    for (size_t r = 0; r < f.rows(); r++) count(f.kp[r].x, f.kp[r].y);
+    for (const Row &r : f.row) count(r.kp.x, r.kp.y);
     for (auto &pts2d : pts2d_new_) count(pts2d.x, pts2d.y);
     det_job_    = (int) next.det_slots.size();
     det_ismask_ = ismask;
@@ -684,8 +674,8 @@ bool TableTracker::queueDetection(int frame, bool ismask, StageBatch &next) {
         const size_t at  = next.det_mask_pts.size();
         next.det_mask_pts.resize(at + 2 * (fc.rows() + pts2d_new_.size()));
         float *p = next.det_mask_pts.data() + at;
-        memcpy(p, fc.kp.data(), fc.rows() * sizeof(Point2f));
-        memcpy(p + 2 * fc.rows(), pts2d_new_.data(), pts2d_new_.size() * sizeof(Point2f));
+        for (const Row &r : fc.row) *p++ = r.kp.x, *p++ = r.kp.y;
+        memcpy(p, pts2d_new_.data(), pts2d_new_.size() * sizeof(Point2f));
     }
     next.det_mask_off.push_back((int32_t) (next.det_mask_pts.size() / 2));
     for (int k = 0; k < block_cnts_; k++) next.det_quota.push_back(track_max_block_features_ - features_cnts[k]); // :629
@@ -724,22 +714,25 @@ void TableTracker::integrateDetection(StageBatch &done) { // :659-685
 void TableTracker::queueTrackMappoint(StageBatch &next) {
     mappoint_matched_.clear();
     tm_pts2d_map_.clear();
-    tm_pts2d_map_undis_.clear();
+    tm_pc_.clear();
     tm_pred_.clear();
     const Frame_ &fp    = frames_[(size_t) pre_];
     const Pose pose_cur = frames_[(size_t) cur_].pose;
-    for (int r = fp.order.head(); r >= 0; r = fp.order.next(r)) {
-        const uint32_t i = fp.mp[(size_t) r];
-        if (!mps_.valid(i, fp.mpgen[(size_t) r]) || mps_.outlier[i]) continue; // mappoint && !mappoint->isOutlier() (:360)
-        tm_pts2d_map_undis_.push_back(fp.kp[(size_t) r]);
-        tm_pts2d_map_.push_back(fp.kpd[(size_t) r]);
-        tm_pred_.emplace_back(camera_->world2pixel(mps_.pos[i], pose_cur)); // INS-aided prediction :367
-        mappoint_matched_.push_back({i, fp.mpgen[(size_t) r]});
+    for (int q = fp.order.head(); q >= 0; q = fp.order.next(q)) {
+        const Row &r     = fp.row[(size_t) q];
+        const uint32_t i = r.mp;
+        if (!mps_.valid(i, r.mpgen) || mps_.hot[i].outlier) continue; // mappoint && !mappoint->isOutlier() (:360)
+        tm_pc_.push_back(r.pcx); // pixel2cam of the previous undistorted key point (:434 needs it for the velocity)
+        tm_pc_.push_back(r.pcy);
+        tm_pts2d_map_.push_back(r.kpd);
+        Point2f pp = camera_->world2pixel(mps_.hot[i].pos, pose_cur); // INS-aided prediction :367
+        camera_->distortPoint(pp);                                    // :378
+        tm_pred_.push_back(pp);
+        mappoint_matched_.push_back({i, r.mpgen});
     }
     lk_map_begin_ = (int) next.lk_prev_slot.size();
     lk_map_n_     = (int) tm_pred_.size();
     if (tm_pred_.empty()) return; // :372-375
-    camera_->distortPoints(tm_pred_); // :378
     const size_t at = next.lk_prev_slot.size();
     next.lk_prev_slot.resize(at + (size_t) lk_map_n_, fp.slot);
     next.lk_next_slot.resize(at + (size_t) lk_map_n_, frames_[(size_t) cur_].slot);
@@ -767,16 +760,19 @@ bool TableTracker::finishTrackMappoint(StageBatch &done) {
         hostprof::Scope hp_feat(hostprof::LK_MAP_FEATURES);
         Frame_ &fc = frames_[(size_t) cur_];
         fc.clearRows(); // :426 (a fresh frame: nothing to clear)
+        fc.row.reserve((size_t) kept + 64);
+        fc.order.reserveRows((size_t) kept + 64);
         tracked_mappoint_.clear();
         const double dt = fc.stamp - frames_[(size_t) pre_].stamp;
         for (int k = 0; k < n; k++) { // reduceVector (:404-408) and the feature loop (:430-444) in one pass
             if (!status[k]) continue;
             const MpRef m     = mappoint_matched_[(size_t) k];
-            Vector3d velocity = (camera_->pixel2cam(undis[k]) - camera_->pixel2cam(tm_pts2d_map_undis_[(size_t) k])) / dt;
-            const int row     = addRow(cur_, mps_.id[m.i], m.i, undis[k], out[k], Vector2d(velocity.x(), velocity.y()), FEATURE_MATCHED);
-            mps_.observed[m.i]++; // addObservation (mappoint.cc:58-62); the feature exists (and is the last observation) even if the key was taken
-            if (row >= 0) mps_.last[m.i] = LastObs{cur_, fc.gen, row};
-            else mps_.last[m.i] = LastObs{-1, 0, -1}; // observation of a feature that died at once: expired
+            const Vector3d pc = camera_->pixel2cam(undis[k]);
+            // (pixel2cam(cur) - pixel2cam(pre)) / dt (:434); the ids of the previous frame's rows are distinct keys
+            const Vector2d velocity((pc[0] - tm_pc_[2 * (size_t) k]) / dt, (pc[1] - tm_pc_[2 * (size_t) k + 1]) / dt);
+            const int row = addRow(cur_, mps_.hot[m.i].id, m.i, undis[k], out[k], velocity, FEATURE_MATCHED, pc[0], pc[1], true);
+            mps_.hot[m.i].observed++; // addObservation (mappoint.cc:58-62)
+            mps_.hot[m.i].last = LastObs{cur_, fc.gen, row};
             tracked_mappoint_.push_back(m);
         }
     }
@@ -962,24 +958,26 @@ void TableTracker::finishTriangulation(StageBatch &done) {
         double depth = pc.z();
         // MapPoint::createMapPoint (mappoint.cc:25-49)
         const uint32_t i = mps_.alloc();
-        mps_.id[i]        = ids_->mappoint_id++;
-        mps_.born_fid[i]  = frames_[(size_t) cur_].fid;
-        mps_.pos[i]       = pw;
-        mps_.ref_frame[i] = frame_ref;
-        mps_.ref_gen[i]   = frames_[(size_t) frame_ref].gen;
-        mps_.ref_kp[i]    = tri_ref_undis_[k];
-        mps_.depth[i]     = ((depth < MapPoint::NEAREST_DEPTH) || (depth > MapPoint::FARTHEST_DEPTH)) ? MapPoint::DEFAULT_DEPTH : depth;
-        mps_.type[i]      = (int8_t) MAPPOINT_TRIANGULATED;
-        addRow(cur_, mps_.id[i], i, tri_cur_undis_[k], pts2d_cur_[k], velocity_cur_[k], FEATURE_TRIANGULATED); // :769-774
-        mps_.observed[i]++;
-        mps_.used[i]++;
-        const int row = addRow(frame_ref, mps_.id[i], i, tri_ref_undis_[k], pts2d_ref_[k], velocity_ref_[k], FEATURE_TRIANGULATED); // :776-781
-        mps_.observed[i]++;
-        mps_.used[i]++;
-        mps_.last[i] = LastObs{frame_ref, frames_[(size_t) frame_ref].gen, row};
+        mps_.hot[i].id        = ids_->mappoint_id++;
+        mps_.cold[i].born_fid  = frames_[(size_t) cur_].fid;
+        mps_.hot[i].pos       = pw;
+        mps_.cold[i].ref_frame = frame_ref;
+        mps_.cold[i].ref_gen   = frames_[(size_t) frame_ref].gen;
+        mps_.cold[i].ref_kp    = tri_ref_undis_[k];
+        mps_.cold[i].depth     = ((depth < MapPoint::NEAREST_DEPTH) || (depth > MapPoint::FARTHEST_DEPTH)) ? MapPoint::DEFAULT_DEPTH : depth;
+        mps_.hot[i].type      = (int8_t) MAPPOINT_TRIANGULATED;
+        const Vector3d pcc = camera_->pixel2cam(tri_cur_undis_[k]), pcr = camera_->pixel2cam(tri_ref_undis_[k]);
+        addRow(cur_, mps_.hot[i].id, i, tri_cur_undis_[k], pts2d_cur_[k], velocity_cur_[k], FEATURE_TRIANGULATED, pcc[0], pcc[1], true); // :769-774
+        mps_.hot[i].observed++;
+        mps_.hot[i].used++;
+        const int row = addRow(frame_ref, mps_.hot[i].id, i, tri_ref_undis_[k], pts2d_ref_[k], velocity_ref_[k], FEATURE_TRIANGULATED, pcr[0], pcr[1],
+                               true); // :776-781 (a freshly drawn id is in no frame yet)
+        mps_.hot[i].observed++;
+        mps_.hot[i].used++;
+        mps_.hot[i].last = LastObs{frame_ref, frames_[(size_t) frame_ref].gen, row};
         Frame_ &fc   = frames_[(size_t) cur_];
         fc.unupdated.push_back(i); // :784
-        fc.unupdated_gen.push_back(mps_.gen[i]);
+        fc.unupdated_gen.push_back(mps_.hot[i].gen);
     }
     reduceVector(pts2d_ref_, tri_status_); // :788-793
     reduceVector(pts2d_ref_frame_, tri_status_);
@@ -1044,21 +1042,21 @@ std::string TableTracker::dump() const {
         d.pose(f.pose);
         d.f("\n");
         for (int r = f.order.head(); r >= 0; r = f.order.next(r)) {
-            const size_t q = (size_t) r;
-            const bool mp  = mps_.valid(f.mp[q], f.mpgen[q]) && !mps_.outlier[f.mp[q]];
-            d.f("R id=%lu kp=%08x,%08x kpd=%08x,%08x vel=%016llx,%016llx type=%d mp=%d\n", f.id[q], Dump::fb(f.kp[q].x), Dump::fb(f.kp[q].y),
-                Dump::fb(f.kpd[q].x), Dump::fb(f.kpd[q].y), Dump::db(f.vel[q][0]), Dump::db(f.vel[q][1]), (int) f.type[q], (int) mp);
+            const Row &q  = f.row[(size_t) r];
+            const bool mp = mps_.valid(q.mp, q.mpgen) && !mps_.hot[q.mp].outlier;
+            d.f("R id=%lu kp=%08x,%08x kpd=%08x,%08x vel=%016llx,%016llx type=%d mp=%d\n", q.id, Dump::fb(q.kp.x), Dump::fb(q.kp.y), Dump::fb(q.kpd.x),
+                Dump::fb(q.kpd.y), Dump::db(q.vel[0]), Dump::db(q.vel[1]), (int) q.type, (int) mp);
         }
     }
     vector<uint32_t> lms;
-    for (uint32_t i = 0; i < mps_.gen.size(); i++)
-        if (mps_.live[i] && mps_.in_map[i]) lms.push_back(i);
-    std::sort(lms.begin(), lms.end(), [&](uint32_t a, uint32_t b) { return mps_.id[a] < mps_.id[b]; });
+    for (uint32_t i = 0; i < mps_.size(); i++)
+        if (mps_.hot[i].live && mps_.hot[i].in_map) lms.push_back(i);
+    std::sort(lms.begin(), lms.end(), [&](uint32_t a, uint32_t b) { return mps_.hot[a].id < mps_.hot[b].id; });
     for (uint32_t i : lms) {
-        const long ref = frameValid(mps_.ref_frame[i], mps_.ref_gen[i]) ? (long) frames_[(size_t) mps_.ref_frame[i]].fid : -1L;
-        d.f("L id=%lu pos=%016llx,%016llx,%016llx depth=%016llx ref=%ld refkp=%08x,%08x type=%d used=%d observed=%d optimized=%d outlier=%d obs=", mps_.id[i],
-            Dump::db(mps_.pos[i][0]), Dump::db(mps_.pos[i][1]), Dump::db(mps_.pos[i][2]), Dump::db(mps_.depth[i]), ref, Dump::fb(mps_.ref_kp[i].x),
-            Dump::fb(mps_.ref_kp[i].y), (int) mps_.type[i], mps_.used[i], mps_.observed[i], mps_.optimized[i], (int) mps_.outlier[i]);
+        const long ref = frameValid(mps_.cold[i].ref_frame, mps_.cold[i].ref_gen) ? (long) frames_[(size_t) mps_.cold[i].ref_frame].fid : -1L;
+        d.f("L id=%lu pos=%016llx,%016llx,%016llx depth=%016llx ref=%ld refkp=%08x,%08x type=%d used=%d observed=%d optimized=%d outlier=%d obs=", mps_.hot[i].id,
+            Dump::db(mps_.hot[i].pos[0]), Dump::db(mps_.hot[i].pos[1]), Dump::db(mps_.hot[i].pos[2]), Dump::db(mps_.cold[i].depth), ref, Dump::fb(mps_.cold[i].ref_kp.x),
+            Dump::fb(mps_.cold[i].ref_kp.y), (int) mps_.hot[i].type, mps_.hot[i].used, mps_.hot[i].observed, mps_.cold[i].optimized, (int) mps_.hot[i].outlier);
         for (ulong o : observationFrames(i, alive)) d.f("%lu,", o);
         d.f("\n");
     }
@@ -1069,18 +1067,18 @@ std::string TableTracker::dump() const {
 // was current when the point was triangulated, then its reference frame (tracking.cc:769-781), then every later frame that tracked it.
 vector<ulong> TableTracker::observationFrames(uint32_t i, const vector<int> &alive_by_fid) const {
     vector<ulong> out;
-    const ulong born = mps_.born_fid[i];
+    const ulong born = mps_.cold[i].born_fid;
     auto has = [&](int h) {
         const Frame_ &f = frames_[(size_t) h];
-        if (!f.order.contains(mps_.id[i])) return false;
-        for (size_t r = 0; r < f.rows(); r++)
-            if (f.id[r] == mps_.id[i]) return f.mp[r] == i && f.mpgen[r] == mps_.gen[i];
+        if (!f.order.contains(mps_.hot[i].id)) return false;
+        for (const Row &r : f.row)
+            if (r.id == mps_.hot[i].id) return r.mp == i && r.mpgen == mps_.hot[i].gen;
         return false;
     };
     for (int h : alive_by_fid)
         if (frames_[(size_t) h].fid == born && has(h)) out.push_back(born);
-    if (frameValid(mps_.ref_frame[i], mps_.ref_gen[i]) && frames_[(size_t) mps_.ref_frame[i]].fid != born && has(mps_.ref_frame[i]))
-        out.push_back(frames_[(size_t) mps_.ref_frame[i]].fid);
+    if (frameValid(mps_.cold[i].ref_frame, mps_.cold[i].ref_gen) && frames_[(size_t) mps_.cold[i].ref_frame].fid != born && has(mps_.cold[i].ref_frame))
+        out.push_back(frames_[(size_t) mps_.cold[i].ref_frame].fid);
     for (int h : alive_by_fid)
         if (frames_[(size_t) h].fid > born && has(h)) out.push_back(frames_[(size_t) h].fid);
     return out;
@@ -1182,17 +1180,17 @@ Map::Ptr TableTracker::materialize(vector<Frame::Ptr> *extra) const {
         obj[(size_t) h] = fr;
         feat[(size_t) h].resize(f.rows());
         for (size_t r = 0; r < f.rows(); r++) // insertion order: the container of the object reproduces the iteration order
-            feat[(size_t) h][r] = Feature::createFeature(fr, f.vel[r], f.kp[r], f.kpd[r], (FeatureType) f.type[r]);
+            feat[(size_t) h][r] = Feature::createFeature(fr, f.row[r].vel, f.row[r].kp, f.row[r].kpd, (FeatureType) f.row[r].type);
     }
-    vector<MapPoint::Ptr> mpo(mps_.gen.size());
+    vector<MapPoint::Ptr> mpo(mps_.size());
     vector<uint32_t> lms;
-    for (uint32_t i = 0; i < mps_.gen.size(); i++)
-        if (mps_.live[i]) lms.push_back(i);
-    std::sort(lms.begin(), lms.end(), [&](uint32_t a, uint32_t b) { return mps_.id[a] < mps_.id[b]; });
+    for (uint32_t i = 0; i < mps_.size(); i++)
+        if (mps_.hot[i].live) lms.push_back(i);
+    std::sort(lms.begin(), lms.end(), [&](uint32_t a, uint32_t b) { return mps_.hot[a].id < mps_.hot[b].id; });
     for (uint32_t i : lms) {
-        Frame::Ptr rf = frameValid(mps_.ref_frame[i], mps_.ref_gen[i]) ? obj[(size_t) mps_.ref_frame[i]] : nullptr;
-        auto m        = std::allocate_shared<MapPoint>(PoolAllocator<MapPoint>(), mps_.id[i], rf, mps_.pos[i], mps_.ref_kp[i], mps_.depth[i],
-                                                (MapPointType) mps_.type[i]);
+        Frame::Ptr rf = frameValid(mps_.cold[i].ref_frame, mps_.cold[i].ref_gen) ? obj[(size_t) mps_.cold[i].ref_frame] : nullptr;
+        auto m        = std::allocate_shared<MapPoint>(PoolAllocator<MapPoint>(), mps_.hot[i].id, rf, mps_.hot[i].pos, mps_.cold[i].ref_kp, mps_.cold[i].depth,
+                                                (MapPointType) mps_.hot[i].type);
         mpo[i] = m;
         // observations in list order
         for (ulong ofid : observationFrames(i, alive))
@@ -1200,15 +1198,15 @@ Map::Ptr TableTracker::materialize(vector<Frame::Ptr> *extra) const {
                 if (frames_[(size_t) h].fid == ofid) {
                     const Frame_ &f = frames_[(size_t) h];
                     for (size_t r = 0; r < f.rows(); r++)
-                        if (f.id[r] == mps_.id[i]) m->addObservation(feat[(size_t) h][r]);
+                        if (f.row[r].id == mps_.hot[i].id) m->addObservation(feat[(size_t) h][r]);
                 }
-        m->restoreCounters(mps_.used[i], mps_.observed[i], mps_.optimized[i], mps_.outlier[i] != 0);
+        m->restoreCounters(mps_.hot[i].used, mps_.hot[i].observed, mps_.cold[i].optimized, mps_.hot[i].outlier != 0);
     }
     for (int h : alive) {
         const Frame_ &f = frames_[(size_t) h];
         for (size_t r = 0; r < f.rows(); r++) {
-            if (mps_.valid(f.mp[r], f.mpgen[r])) feat[(size_t) h][r]->addMapPoint(mpo[f.mp[r]]);
-            obj[(size_t) h]->addFeature(f.id[r], feat[(size_t) h][r]);
+            if (mps_.valid(f.row[r].mp, f.row[r].mpgen)) feat[(size_t) h][r]->addMapPoint(mpo[f.row[r].mp]);
+            obj[(size_t) h]->addFeature(f.row[r].id, feat[(size_t) h][r]);
         }
         for (size_t k = 0; k < f.unupdated.size(); k++)
             if (mps_.valid(f.unupdated[k], f.unupdated_gen[k])) obj[(size_t) h]->addNewUnupdatedMappoint(mpo[f.unupdated[k]]);
@@ -1217,7 +1215,7 @@ Map::Ptr TableTracker::materialize(vector<Frame::Ptr> *extra) const {
     for (const auto &k : map_kf_) kfs.emplace_back(k.key, obj[(size_t) k.frame]);
     vector<MapPoint::Ptr> in_map;
     for (uint32_t i : lms)
-        if (mps_.in_map[i]) in_map.push_back(mpo[i]);
+        if (mps_.hot[i].in_map) in_map.push_back(mpo[i]);
     map->restore(kfs, in_map, latest_keyframe_ >= 0 ? obj[(size_t) latest_keyframe_] : nullptr, is_window_full_);
     if (extra)
         for (int h : alive) extra->push_back(obj[(size_t) h]);

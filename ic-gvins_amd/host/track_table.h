@@ -40,7 +40,9 @@ public:
     }
     size_t size() const { return next_.size(); }
     // appends row index size() with this key; returns false (and adds nothing) if the key is already present
-    bool insert(ulong key);
+    bool insert(ulong key) { return contains(key) ? false : (insertUnique(key), true); }
+    // the same for a key the caller knows to be absent (ids of one frame's rows carried to the next frame, freshly drawn ids)
+    void insertUnique(ulong key);
     int head() const { return head_; }
     int next(int i) const { return next_[(size_t) i]; }
     bool contains(ulong key) const;
@@ -94,11 +96,11 @@ public:
     ulong currentFrameId() const;
     ulong lastInputFrameId() const { return last_input_fid_; } // id of the frame handed to the last beginFrame (also when it was skipped)
     size_t numCurrentFeatures() const;
-    // visits (map-point id, distorted key point) of the current frame's features, container order
+    // visits (map-point id, distorted key point) of the current frame's features
     template <typename F> void forEachCurrentFeature(F &&f) const {
         if (cur_ < 0) return;
         const Frame_ &fr = frames_[(size_t) cur_];
-        for (int r = fr.order.head(); r >= 0; r = fr.order.next(r)) f(fr.id[(size_t) r], fr.kpd[(size_t) r]);
+        for (const Row &r : fr.row) f(r.id, r.kpd); // (any order: the digest does not depend on it)
     }
     size_t windowKeyFrames() const { return map_kf_.size(); }
     size_t landmarks() const { return n_landmarks_; }
@@ -115,6 +117,14 @@ public:
     std::string dumpMaterialized() const; // the same text computed from materialize(): must equal dumpMap()
 
 private:
+    struct Row {           // one Feature (feature.h:41-118) of a frame
+        ulong id;          // map-point id (the key of the reference's features_ container)
+        uint32_t mp, mpgen; // map-point handle
+        Point2f kp, kpd;   // undistorted / distorted key point
+        Vector2d vel;      // velocity on the normalized plane
+        double pcx, pcy;   // Camera::pixel2cam(kp), kept: the next frame's velocity and every parallax need it again
+        int8_t type;
+    };
     struct Frame_ {
         bool alive{false};
         uint32_t gen{0};
@@ -126,14 +136,10 @@ private:
         int slot{-1};
         Mat image;
         // feature rows (insertion order); `order` is the container order of the reference's features_
-        vector<ulong> id;        // map-point id (the container key)
-        vector<uint32_t> mp, mpgen; // map-point handle
-        vector<Point2f> kp, kpd; // undistorted / distorted key point
-        vector<Vector2d> vel;
-        vector<int8_t> type;
+        vector<Row> row;
         HashOrder order;
         vector<uint32_t> unupdated, unupdated_gen; // map points created with this frame as the current one (frame.h unupdated_mappoints_)
-        size_t rows() const { return id.size(); }
+        size_t rows() const { return row.size(); }
         void clearRows();
     };
     struct LastObs {
@@ -141,26 +147,35 @@ private:
         uint32_t gen{0};
         int32_t row{-1};
     };
-    struct MapPoints { // per-stream pool, structure of arrays; handle = (index, gen)
-        vector<uint32_t> gen;
-        vector<uint8_t> live, outlier, in_map;
-        vector<ulong> id, born_fid;
-        vector<Vector3d> pos;
-        vector<int32_t> ref_frame;
-        vector<uint32_t> ref_gen;
-        vector<Point2f> ref_kp;
-        vector<double> depth;
-        vector<int8_t> type;
-        vector<int32_t> used, observed, optimized;
-        vector<LastObs> last;
+    struct MapPointHot { // what the per-feature loops touch: one cache line per map point
+        uint32_t gen{0};
+        uint8_t live{0}, outlier{0}, in_map{0};
+        int8_t type{0};
+        ulong id{0};
+        Vector3d pos;
+        int32_t observed{0}, used{0};
+        LastObs last;
+    };
+    struct MapPointCold {
+        ulong born_fid{0};
+        int32_t ref_frame{-1};
+        uint32_t ref_gen{0};
+        Point2f ref_kp;
+        double depth{0};
+        int32_t optimized{0};
+    };
+    struct MapPoints { // per-stream pool; handle = (index, gen)
+        vector<MapPointHot> hot;
+        vector<MapPointCold> cold;
         vector<uint32_t> free_list;
         uint32_t alloc();
         void release(uint32_t i) {
-            live[i] = 0;
-            gen[i]++;
+            hot[i].live = 0;
+            hot[i].gen++;
             free_list.push_back(i);
         }
-        bool valid(uint32_t i, uint32_t g) const { return live[i] && gen[i] == g; }
+        bool valid(uint32_t i, uint32_t g) const { return hot[i].live && hot[i].gen == g; }
+        size_t size() const { return hot.size(); }
     };
 
     // frames
@@ -168,7 +183,8 @@ private:
     void freeFrame(int h);
     void sweepFrames();
     void setKeyFrame(int h, int state);
-    int addRow(int h, ulong id, uint32_t mp, const Point2f &kp, const Point2f &kpd, const Vector2d &vel, FeatureType type);
+    int addRow(int h, ulong id, uint32_t mp, const Point2f &kp, const Point2f &kpd, const Vector2d &vel, FeatureType type, double pcx,
+               double pcy, bool unique_key);
     vector<ulong> observationFrames(uint32_t mp, const vector<int> &alive_by_fid) const;
     bool frameValid(int h, uint32_t g) const { return h >= 0 && frames_[(size_t) h].alive && frames_[(size_t) h].gen == g; }
 
@@ -270,7 +286,8 @@ private:
     bool det_ismask_{true};
     int det_frame_{-1};
     int lk_map_begin_{0}, lk_map_n_{0}, lk_ref_begin_{0}, lk_ref_n_{0};
-    vector<Point2f> tm_pts2d_map_, tm_pts2d_map_undis_, tm_pred_;
+    vector<Point2f> tm_pts2d_map_, tm_pred_;
+    vector<double> tm_pc_;
     bool ref_tracked_{false};
     int rs_set_{-1};
     vector<Point2f> tr_new_undis_, tr_cur_undis_;
