@@ -6,11 +6,10 @@
 // best/niters replay).  Mapping:
 //   * the hypothesis index stream depends only on cv::RNG's state, not on scores, so it is generated up front on the
 //     host (same LCG as cv::RNG((uint64)-1)) for a chunk of hypotheses;
-//   * k_fm_hypothesis: ONE WAVEFRONT per hypothesis.  Lane 0 solves the seven-point system: as cv::SVDecomp does for m < n, the
-//     one-sided Jacobi runs on the 7 full-rank columns of A^T (9x7, REGISTER resident, fully unrolled) and the two null vectors come
-//     from completing the orthonormal basis; only + - * / sqrt are used so results match the CPU restatement bit-for-bit.  The whole
-//     wave then scores the (up to three) models: 64 points per step, symmetric epipolar distance in double, inlier bits by wave
-//     ballot, count by popcount;
+//   * k_fm_hypothesis: 32 hypotheses per workgroup.  Solve: a LANE per hypothesis — as cv::SVDecomp does for m < n, the one-sided
+//     Jacobi runs on the 7 full-rank columns of A^T (9x7, REGISTER resident, fully unrolled) and the two null vectors come from
+//     completing the orthonormal basis; only + - * / sqrt are used so results match the CPU restatement bit-for-bit.  Score: a WAVE
+//     per model — 64 points per step, symmetric epipolar distance in double, inlier bits by wave ballot, count by popcount;
 //   * the host replays the `best / niters` recurrence over the score array in hypothesis order, which makes the result
 //     identical to the sequential algorithm; further chunks are generated only if niters demands them.
 #include <algorithm>
@@ -232,34 +231,38 @@ __device__ __forceinline__ void seven_point_solve(const fm_set &S, const int32_t
     *n_out = n;
 }
 
-// k_fm_hypothesis: ONE WAVE per hypothesis.  Lane 0 solves the seven-point system (a strictly serial FP64 chain: Jacobi sweeps, basis
-// completion, cubic), the models go through LDS, then the whole wave scores each model over the set's points (64 points per step,
-// symmetric epipolar distance in double, inlier bits by wave ballot, count by popcount).  One launch instead of a solve launch, a score
-// launch and an upload: on a hardware queue shared by several stream groups every launch costs ~75-100 us whatever its size
-// (profiles/r02_queue_view.json).  All inputs are read where the host wrote them (pinned staging memory, zero-copy): 14 points by lane 0,
-// and every point of the set once per model, coalesced.
-__global__ __launch_bounds__(64, 1) void k_fm_hypothesis(int n_hyp_total, const fm_set *sets, const int32_t *hyp_set,
-                                                         const int32_t *hyp_idx /*n_hyp x 7 (set-local)*/, const float2 *pts1,
-                                                         const float2 *pts2, float thresh2, int32_t *good /*n_hyp x 3*/,
-                                                         unsigned long long *bits) {
-    __shared__ double Fm[27];
-    __shared__ int n_sh;
-    const int hyp = blockIdx.x, lane = threadIdx.x;
-    if (hyp >= n_hyp_total) return;
-    const fm_set S = sets[hyp_set[hyp]];
-    if (lane == 0) {
-        int n = 0;
-        seven_point_solve(S, hyp_idx + 7 * (size_t) hyp, pts1, pts2, Fm, &n);
-        n_sh = n;
+// k_fm_hypothesis: a workgroup of four waves takes FM_HPW hypotheses.  Solve phase: LANE PER HYPOTHESIS in wave 0 — the seven-point
+// solve is a strictly serial FP64 chain per hypothesis (Jacobi sweeps, basis completion, cubic) whose rotations cannot be spread over
+// lanes without changing its rounding, but different hypotheses are independent, so 32 of them advance in the lanes of one wave at the
+// cost of one (round 2: one wave per hypothesis with 63 idle lanes, 23 % of the queue time for < 10 % of the work).  The models pass
+// through LDS; scoring phase: WAVE PER MODEL — the four waves take the (hypothesis, model) pairs in turn, 64 points per step, symmetric
+// epipolar distance in double, inlier bits by wave ballot, count by popcount.  Still one launch per RANSAC round, every input read
+// where the host staged it (pinned memory, zero-copy).  Per hypothesis the arithmetic is the one of round 2: bit-identical masks.
+#define FM_HPW 32
+__global__ __launch_bounds__(256, 1) void k_fm_hypothesis(int n_hyp_total, const fm_set *sets, const int32_t *hyp_set,
+                                                          const int32_t *hyp_idx /*n_hyp x 7 (set-local)*/, const float2 *pts1,
+                                                          const float2 *pts2, float thresh2, int32_t *good /*n_hyp x 3*/,
+                                                          unsigned long long *bits) {
+    __shared__ double Fm[FM_HPW][27];
+    __shared__ int n_sh[FM_HPW];
+    const int hyp0 = blockIdx.x * FM_HPW, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int n_here = min(FM_HPW, n_hyp_total - hyp0);
+    if (n_here <= 0) return;
+    if (wave == 0 && lane < n_here) {
+        const int hyp = hyp0 + lane;
+        int n         = 0;
+        seven_point_solve(sets[hyp_set[hyp]], hyp_idx + 7 * (size_t) hyp, pts1, pts2, Fm[lane], &n);
+        n_sh[lane] = n;
     }
     __syncthreads();
-    const int n_models = n_sh;
-    for (int model = 0; model < 3; model++) {
-        if (model >= n_models) {
+    for (int pair = wave; pair < 3 * n_here; pair += 4) {
+        const int hl = pair / 3, model = pair - 3 * hl, hyp = hyp0 + hl;
+        if (model >= n_sh[hl]) {
             if (lane == 0) good[hyp * 3 + model] = -1;
             continue;
         }
-        const double *F = Fm + 9 * model;
+        const fm_set S  = sets[hyp_set[hyp]];
+        const double *F = Fm[hl] + 9 * model;
         const double F0 = F[0], F1 = F[1], F2 = F[2], F3 = F[3], F4 = F[4], F5 = F[5], F6 = F[6], F7 = F[7], F8 = F[8];
         unsigned long long *w = bits + S.word_begin + ((size_t) (hyp - S.hyp_begin) * 3 + model) * S.words_per_model;
         int count = 0;
@@ -435,7 +438,7 @@ extern "C" int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, c
         unsigned long long *d_bits = c.out_zc(h_bits.data(), (size_t) words);
         {
             icg_prof_scope ps(ctx, "fm_hypothesis");
-            hipLaunchKernelGGL(k_fm_hypothesis, dim3(nh_total), dim3(64), 0, ctx->stream, nh_total, d_sets, d_hset, d_hidx, d_p1, d_p2,
+            hipLaunchKernelGGL(k_fm_hypothesis, dim3((nh_total + FM_HPW - 1) / FM_HPW), dim3(256), 0, ctx->stream, nh_total, d_sets, d_hset, d_hidx, d_p1, d_p2,
                                (float) (thresh * thresh), d_good, d_bits);
         }
         ICG_HIP(ctx, hipGetLastError());

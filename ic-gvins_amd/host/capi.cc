@@ -208,6 +208,29 @@ int icgh_batch_features(icgh_batch *b, int stream, int max, uint64_t *ids, float
     return n;
 }
 
+// Kernel-only ceiling: icgh_batch_record(b, 1); <one icgh_batch_run step>; icgh_batch_record(b, 0); then icgh_batch_replay(b, reps) issues the
+// recorded device calls of every group again — one group after the other, nothing else on the GPU, no tracker logic — so that the HIP-event
+// times of icg_prof_* are the EXCLUSIVE device times of the step's kernels.  Returns the number of recorded stage batches (all groups).
+int icgh_batch_record(icgh_batch *b, int on) {
+    if (!b) return -1;
+    for (int g = 0; g < b->tb->groups(); g++) b->tb->group(g).record(on != 0);
+    return 0;
+}
+int icgh_batch_replay(icgh_batch *b, int reps, char *err, int errlen) {
+    if (!b) return -1;
+    try {
+        int n = 0;
+        for (int g = 0; g < b->tb->groups(); g++) {
+            b->tb->group(g).replay(reps);
+            n += (int) b->tb->group(g).device()->recorded();
+        }
+        return n;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -2;
+    }
+}
+
 // 0 = track table (default), 1 = object graph (ICG_TRACK_ENGINE=object)
 int icgh_batch_engine(icgh_batch *b) { return b ? (int) b->tb->group(0).engine() : -1; }
 

@@ -70,8 +70,27 @@ public:
     void execute(StageBatch &b, const icg_detect_grid &grid, int max_per_job);
     int allocSlot();
     void freeSlot(int s);
+    // Kernel-only replay (profiles/r03_kernel_ceiling.json): while recording, every execute() keeps a copy of its work lists; replay()
+    // issues the recorded calls again, back to back, with no tracker logic in between — under icg_prof_enable that yields the exclusive
+    // device time of every kernel of a step.  Valid until the next frame is tracked (the frame slots still hold the recorded images).
+    void record(bool on) {
+        recording_ = on;
+        if (on) recorded_.clear();
+    }
+    size_t recorded() const { return recorded_.size(); }
+    void replay(const icg_detect_grid &grid, int max_per_job) {
+        for (auto &b : recorded_) {
+            StageBatch copy = b;
+            const bool was  = recording_;
+            recording_      = false;
+            execute(copy, grid, max_per_job);
+            recording_ = was;
+        }
+    }
 
 private:
+    bool recording_{false};
+    vector<StageBatch> recorded_;
     icg_ctx *ctx_{nullptr};
     vector<int> free_slots_;
     std::mutex slot_mutex_;

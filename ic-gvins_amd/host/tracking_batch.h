@@ -59,6 +59,11 @@ public:
     // one frame per stream (frames[i].valid == false idles a stream); returns per-stream states
     void step(const FrameInput *frames, vector<TrackState> &states);
     Engine engine() const { return engine_; }
+    // kernel-only replay of the device calls of the steps run while recording (DeviceContext::record / replay)
+    void record(bool on) { device_->record(on); }
+    void replay(int reps) {
+        for (int r = 0; r < reps; r++) device_->replay(grid_, max_per_job_);
+    }
     Stream &stream(int i) { return streams_[(size_t) i]; }
     int size() const { return (int) streams_.size(); }
     DeviceContext::Ptr device() { return device_; }

@@ -115,6 +115,7 @@ void DeviceContext::freeSlot(int s) {
 }
 
 void DeviceContext::execute(StageBatch &b, const icg_detect_grid &grid, int max_per_job) {
+    if (recording_) recorded_.push_back(b);
     if (!b.pre_slots.empty()) {
         hostprof::Scope hp(hostprof::DEV_PREPROCESS);
         int n = (int) b.pre_slots.size();

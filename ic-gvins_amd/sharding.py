@@ -25,18 +25,22 @@ def terminal_exchange(dist, device, counters, elapsed, digests):
     return [float(x) for x in c.cpu()], float(t.cpu()[0]), [int(x) for g in gathered for x in g.cpu()]
 
 
+STREAMS_PER_GPU = 384  # fixed work per GPU whatever the world size: "scaling": "weak" means exactly this
+
+
 def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, streams_override=0):
-    """Host resources of one rank (VERDICT r1: one rank's polling threads must not assume the whole box):
+    """Host resources of one rank (one rank's polling threads must not assume the whole box):
       cores_rank   the rank's share of the usable host cores
-      groups       stream groups (one host thread + HIP stream each): 3 per core of the share — a group sleeps while its kernels run, and the
-                   GPU only fills up at ~48 groups in flight (profiles/README.md, round-2 sweep: 32 -> 66 k, 48 -> 72 k, 64 -> 73 k frames/s) —
-                   between 2 and 48; never 8 pollers on 2 cores
-      streams      8 camera streams per group
+      streams      384 camera streams per GPU, the same for every world size (weak scaling: per-GPU work is fixed)
+      groups       stream groups (one host thread + HIP stream each).  With the track-table engine a frame costs the host ~20 us of logic, so
+                   a group can carry 32-64 streams; round-3 sweep on one MI355X (profiles/r03_group_sweep.txt): 48 x 8 -> 78 k, 24 x 16 -> 92 k,
+                   16 x 24 -> 98.6 k, 12 x 32 -> 99.9 k, 8 x 48 -> 100.7 k frames/s with 3.3-3.9 host cores busy.  3 groups per core of the
+                   share, between 4 and 12.
       cpu_slice    the contiguous slice of the allowed CPU ids this rank pins itself to (None for a single rank: nothing to separate)
     """
     cores_rank = float(usable_cores) / float(max(1, world))
-    groups = int(groups_override) if groups_override > 0 else int(max(2, min(48, 3 * round(cores_rank))))
-    streams = int(streams_override) if streams_override > 0 else 8 * groups
+    groups = int(groups_override) if groups_override > 0 else int(max(4, min(12, 3 * round(cores_rank))))
+    streams = int(streams_override) if streams_override > 0 else STREAMS_PER_GPU
     groups = max(1, min(groups, streams))
     cpu_slice = None
     if world > 1 and cpu_ids:

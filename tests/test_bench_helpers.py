@@ -35,3 +35,27 @@ def test_frontend_valu_fraction():
     per_step = sum(e.get("SQ_INSTS_VALU", 0.0) * e.get("launches", 0.0) for k, e in allp.items() if k.startswith("k_") and k != "k_reproj_eval")
     assert abs(v["wave_instructions_per_frame"] - per_step / lk["launches"] / 8.0) < 1.0
     assert b.frontend_valu("no_such_summary.json", 8.0, 1.0) is None
+
+
+def test_contract_line_is_compact_and_keeps_every_quoted_number():
+    """The driver keeps the last 8 KB of bench.py's output: the contract line must hold the headline with its parity witness, roofline
+    (incl. the exclusive-time ceiling), CPU baseline and the summary of every block, whatever the length of the per-group series."""
+    b = _bench()
+    committed = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("r02_bench_driver_command"))
+    full = json.load(open(os.path.join(ROOT, "profiles", committed[-1])))  # a real (round-2) full record: ~15 KB
+    full["parity"] = {"ok": True, "streams": [0, 383], "frames_per_stream": 73, "digest_gpu": ["0" * 16] * 2, "digest_oracle": ["0" * 16] * 2,
+                      "checker": "x" * 120, "seconds": 3.2}
+    full["roofline"].update({"exclusive_us": 61.0, "frac_exclusive": 0.04, "ceiling_frames_per_s": 120000.0, "exclusive_us_per_frame_all_kernels": 8.3,
+                             "value_over_ceiling": 0.8, "achieved_exclusive": 330.0})
+    full["host_ms_per_step"]["group_step_ms_per_group"] = [4.321] * 512
+    full["step_stats"]["job_step_ms"]["series"] = [5.123] * 2000
+    line = json.dumps(b.compact_line(full, os.path.join(ROOT, "gpurun_out", "bench_details.json")))
+    assert len(line) < 7000, len(line)
+    c = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "parity", "roofline", "cpu_baseline"):
+        assert key in c, key
+    assert c["parity"]["ok"] is True and c["roofline"]["ceiling_frames_per_s"] == 120000.0 and c["roofline"]["frac"] == full["roofline"]["frac"]
+    assert c["solve"]["batched"]["value"] == full["solve"]["batched"]["value"]
+    assert c["reproj"]["value"] == full["reproj"]["value"] and c["c4"]["frontend"]["value"] == full["c4"]["frontend"]["value"]
+    assert c["pcie_inclusive"]["value"] == full["pcie_inclusive"]["value"] and c["details"] == "gpurun_out/bench_details.json"
