@@ -231,6 +231,18 @@ int icgh_batch_replay(icgh_batch *b, int reps, char *err, int errlen) {
     }
 }
 
+// the same recorded calls issued by ALL groups at once from their own threads (the concurrency of a real run, no tracker logic)
+int icgh_batch_replay_concurrent(icgh_batch *b, int reps, char *err, int errlen) {
+    if (!b) return -1;
+    try {
+        b->tb->replayAll(reps);
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -2;
+    }
+}
+
 // 0 = track table (default), 1 = object graph (ICG_TRACK_ENGINE=object)
 int icgh_batch_engine(icgh_batch *b) { return b ? (int) b->tb->group(0).engine() : -1; }
 

@@ -78,11 +78,13 @@ public:
         if (on) recorded_.clear();
     }
     size_t recorded() const { return recorded_.size(); }
-    void replay(const icg_detect_grid &grid, int max_per_job) {
-        for (auto &b : recorded_) {
-            StageBatch copy = b;
-            const bool was  = recording_;
-            recording_      = false;
+    // `first`: index of the recorded call to start with (the calls of a step only depend on the frame slots, not on each other, so a replay
+    // may start anywhere: concurrent replays of several contexts are staggered that way, as free-running groups are)
+    void replay(const icg_detect_grid &grid, int max_per_job, size_t first = 0) {
+        for (size_t k = 0; k < recorded_.size(); k++) {
+            StageBatch copy = recorded_[(first + k) % recorded_.size()];
+            const bool was = recording_;
+            recording_     = false;
             execute(copy, grid, max_per_job);
             recording_ = was;
         }

@@ -360,14 +360,15 @@ void StreamGroups::workerLoop(int g) {
         const double tw0 = now_s();
         try {
             vector<TrackState> st;
-            for (size_t k = 0; k < frames_->size(); k++) {
+            if (replay_reps_ > 0) groups_[(size_t) g]->replay(replay_reps_, (size_t) g); // staggered: group g starts at its g-th recorded call
+            for (size_t k = 0; replay_reps_ == 0 && k < frames_->size(); k++) {
                 groups_[(size_t) g]->step((*frames_)[k].data() + b, st);
                 for (int i = b; i < e; i++) (*states_)[k][(size_t) i] = st[(size_t) (i - b)];
             }
         } catch (const std::exception &ex) {
             err = ex.what();
         }
-        if (getenv("ICG_DEBUG_TIMING") && frames_->size() > 1) {
+        if (getenv("ICG_DEBUG_TIMING") && replay_reps_ == 0 && frames_->size() > 1) {
             const double *t = groups_[(size_t) g]->timing;
             fprintf(stderr, "[group %d] worker wall %.2f ms, in-step accumulated %.2f ms\n", g, 1e3 * (now_s() - tw0),
                     1e3 * (t[0] + t[1] + t[2] + t[3] + t[4]));
@@ -385,6 +386,26 @@ void StreamGroups::step(const vector<FrameInput> &frames, vector<TrackState> &st
     vector<vector<TrackState>> s1;
     stepMany(f1, s1);
     states = s1[0];
+}
+
+void StreamGroups::replayAll(int reps) {
+    if (reps <= 0) return;
+    if (workers_.empty()) {
+        groups_[0]->replay(reps);
+        return;
+    }
+    {
+        std::unique_lock<std::mutex> lock(m_);
+        replay_reps_ = reps;
+        pending_     = (int) groups_.size();
+        error_.clear();
+        generation_++;
+    }
+    cv_go_.notify_all();
+    std::unique_lock<std::mutex> lock(m_);
+    cv_done_.wait(lock, [&] { return pending_ == 0; });
+    replay_reps_ = 0;
+    if (!error_.empty()) throw std::runtime_error(error_);
 }
 
 void StreamGroups::stepMany(const vector<vector<FrameInput>> &frames, vector<vector<TrackState>> &states) {

@@ -61,8 +61,8 @@ public:
     Engine engine() const { return engine_; }
     // kernel-only replay of the device calls of the steps run while recording (DeviceContext::record / replay)
     void record(bool on) { device_->record(on); }
-    void replay(int reps) {
-        for (int r = 0; r < reps; r++) device_->replay(grid_, max_per_job_);
+    void replay(int reps, size_t first = 0) {
+        for (int r = 0; r < reps; r++) device_->replay(grid_, max_per_job_, first);
     }
     Stream &stream(int i) { return streams_[(size_t) i]; }
     int size() const { return (int) streams_.size(); }
@@ -110,6 +110,9 @@ public:
     // K consecutive steps without a cross-group barrier in between: every group walks through its own K frames at its
     // own pace (streams are independent, so the per-stream results equal K calls of step()).
     void stepMany(const vector<vector<FrameInput>> &frames, vector<vector<TrackState>> &states);
+    // device-only run: every group's thread issues its recorded device calls (TrackingBatch::record) `reps` times, all groups at once, no
+    // tracker logic — the rate the kernels and the launch structure allow under the same concurrency as a real run
+    void replayAll(int reps);
     int size() const { return n_streams_; }
     int groups() const { return (int) groups_.size(); }
     TrackingBatch &group(int g) { return *groups_[(size_t) g]; }
@@ -128,6 +131,7 @@ private:
     uint64_t generation_{0};
     int pending_{0};
     bool stop_{false};
+    int replay_reps_{0}; // > 0: the pending job is a device-only replay
     const vector<vector<FrameInput>> *frames_{nullptr};
     vector<vector<TrackState>> *states_{nullptr};
     std::string error_;
