@@ -121,6 +121,11 @@ void ReprojectionBatch::add(ReprojectionFactor *factor, double *pose_i, double *
 
 void ReprojectionBatch::finalize() {
     const int n = (int) factors_.size();
+    if (n == 0) { // a window without visual factors (the reference solves those too: GNSS / IMU only)
+        finalized_ = true;
+        prepared_  = false;
+        return;
+    }
     vector<double> obs((size_t) 15 * n);
     for (int k = 0; k < n; k++)
         for (int c = 0; c < 15; c++) obs[(size_t) c * n + k] = factors_[(size_t) k]->obs_[c];

@@ -53,8 +53,15 @@ public:
             rho[2] = 0.0;
         }
     }
+    double delta() const { return a_; }
 private:
     const double a_, b_;
+};
+// ceres/evaluation_callback.h (Ceres >= 2.0): called once per evaluation point before the residual blocks are evaluated
+class EvaluationCallback {
+public:
+    virtual ~EvaluationCallback() = default;
+    virtual void PrepareForEvaluation(bool evaluate_jacobians, bool new_evaluation_point) = 0;
 };
 } // namespace ceres
 #include "problem_shim.h"

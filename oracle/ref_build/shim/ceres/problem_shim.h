@@ -43,9 +43,11 @@ class Problem {
 public:
     struct Options {
         bool enable_fast_removal = false;
+        EvaluationCallback *evaluation_callback = nullptr; // problem.h: not owned
     };
     Problem() = default;
-    explicit Problem(const Options &) {}
+    explicit Problem(const Options &o) : options_(o) {}
+    EvaluationCallback *evaluation_callback() const { return options_.evaluation_callback; }
     Problem(const Problem &)            = delete;
     Problem &operator=(const Problem &) = delete;
     ~Problem() {
@@ -85,7 +87,14 @@ public:
         return AddResidualBlock(cost, loss, std::vector<double *>{x0, xs...});
     }
     void RemoveResidualBlock(ResidualBlockId id) { id->removed = true; }
+    // problem.h: "if an EvaluationCallback is associated with the problem, its PrepareForEvaluation method is called every time this method
+    // is called, with new_point = true"
     bool EvaluateResidualBlock(ResidualBlockId id, bool apply_loss_function, double *cost, double *residuals, double **jacobians) const {
+        if (options_.evaluation_callback) options_.evaluation_callback->PrepareForEvaluation(jacobians != nullptr, true);
+        return EvaluateResidualBlockAssumingParametersUnchanged(id, apply_loss_function, cost, residuals, jacobians);
+    }
+    bool EvaluateResidualBlockAssumingParametersUnchanged(ResidualBlockId id, bool apply_loss_function, double *cost, double *residuals,
+                                                          double **jacobians) const {
         std::vector<double> r((size_t) id->cost->num_residuals());
         if (!id->cost->Evaluate(id->blocks.data(), r.data(), jacobians)) return false;
         double sq = 0;
@@ -102,6 +111,7 @@ public:
 
 private:
     friend class Solver;
+    Options options_;
     struct Block {
         int size;
         LocalParameterization *parameterization;
@@ -186,10 +196,11 @@ private:
     }
     static bool evaluateCost(Problem &p, double *cost) {
         double c = 0;
+        if (p.evaluation_callback()) p.evaluation_callback()->PrepareForEvaluation(false, true); // once per evaluation point
         for (auto *R : p.residuals_) {
             if (R->removed) continue;
             double rc;
-            if (!p.EvaluateResidualBlock(R, true, &rc, nullptr, nullptr)) return false;
+            if (!p.EvaluateResidualBlockAssumingParametersUnchanged(R, true, &rc, nullptr, nullptr)) return false;
             c += rc;
         }
         *cost = c;
@@ -199,6 +210,7 @@ private:
         const int P = S.P, L = S.L;
         S.Hcc.assign((size_t) P * P, 0.0), S.G.assign((size_t) L * P, 0.0), S.hll.assign((size_t) L, 0.0), S.bc.assign((size_t) P, 0.0), S.bl.assign((size_t) L, 0.0);
         S.cost = 0;
+        if (p.evaluation_callback()) p.evaluation_callback()->PrepareForEvaluation(true, true); // once per evaluation point
         for (auto *R : p.residuals_) {
             if (R->removed) continue;
             const int nr      = R->cost->num_residuals();

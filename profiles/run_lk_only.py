@@ -33,4 +33,6 @@ for _ in range(reps):
     out, st = c.lk_track_fb(prev, prev + 1, pts, guess)
 dt = (time.time() - t0) / reps
 n, ms = c.prof()["lk_track_fb"]
+import hashlib
+print("output sha1", hashlib.sha1(out.tobytes() + st.tobytes()).hexdigest()[:16], "ICG_LK_PAIR", os.environ.get("ICG_LK_PAIR", "default"))
 print(f"S={S} N={N}: {S*N} points, kernel {ms/n*1e3:.1f} us/launch ({S*N/(ms/n*1e-3)/1e6:.2f} Mpoints/s), call {dt*1e6:.0f} us, kept {st.mean():.3f}")
