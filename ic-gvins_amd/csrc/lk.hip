@@ -1011,8 +1011,10 @@ extern "C" int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, co
     int32_t *d_keep     = keep_idx ? c.out_zc(keep_idx, (size_t) n) : nullptr;
     int32_t *d_nkeep    = keep_idx ? c.out_zc(n_keep, 1) : nullptr;
     {
-        // ICG_LK_PAIR=0: one feature per wave (round 2's mapping, kept for A/B measurements); default: two features per wave
-        static const bool pair = !(getenv("ICG_LK_PAIR") && getenv("ICG_LK_PAIR")[0] == '0');
+        // ICG_LK_PAIR=1: two features per wave (k_lk_track_fb2).  Measured on MI355X (profiles/r03_lk_pair.md): 28 % fewer instructions per
+        // Gauss-Newton iteration and 16 % fewer per level set-up, but a wave runs max() of its two features' iteration counts and keeps only
+        // 3 waves per SIMD: SQ_INSTS_VALU -7 %, kernel time +2 % isolated, bench unchanged — so one feature per wave stays the default.
+        static const bool pair = getenv("ICG_LK_PAIR") && getenv("ICG_LK_PAIR")[0] == '1';
         icg_prof_scope ps(ctx, "lk_track_fb");
         if (pair)
             hipLaunchKernelGGL(k_lk_track_fb2, dim3(icg_xcd_grid((n + 1) / 2)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns,
