@@ -130,6 +130,35 @@ def measure_hbm_peak(torch, device, nbytes=1 << 30, reps=10):
     return 2.0 * nbytes / (ms * 1e-3) / 1e9
 
 
+def csrc_sha1():
+    """sha1 over the names and contents of the kernel sources (what profiles/summarize_pmc.py stores in the counter summary's _meta)"""
+    import hashlib
+    h = hashlib.sha1()
+    src = os.path.join(ROOT, "ic-gvins_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_provenance(pmc_file, streams_per_launch):
+    """The committed counter summary only describes THIS build if it was collected on these kernel sources at this launch shape.
+    Returns None when it does, else the reason it is stale (the roofline block then omits traffic / issue_frac / valu)."""
+    try:
+        meta = json.load(open(os.path.join(ROOT, "profiles", pmc_file))).get("_meta")
+    except Exception:
+        return "unreadable"
+    if not meta:
+        return "no provenance record (_meta) in " + pmc_file
+    if meta.get("csrc_sha1") != csrc_sha1():
+        return "kernel sources changed since " + pmc_file + " was collected"
+    spl = meta.get("streams_per_launch")
+    if spl is not None and abs(float(spl) - float(streams_per_launch)) > 0.5:
+        return f"collected at {spl} streams per launch, this run has {streams_per_launch:g}"
+    return None
+
+
 def committed_pmc(kernel):
     """Per-kernel counter means of the newest committed rocprofv3 --pmc summary (profiles/rNN_pmc_summary.json, collected by
     profiles/collect.sh at the bench configuration).  Returns (entry or None, file name)."""
@@ -383,7 +412,7 @@ def compact_line(full, details_path):
     c["roofline"] = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "peak_measured", "frac_of_measured_peak",
                               "algorithmic_bytes_per_launch", "avg_launch_us", "units_per_launch", "exclusive_us", "achieved_exclusive",
                               "frac_exclusive", "exclusive_us_per_frame_all_kernels", "serialized_frames_per_s", "ceiling_frames_per_s", "value_over_ceiling",
-                              "issue_frac"))
+                              "issue_frac", "pmc_stale"))
     if r and r.get("valu"):
         c["roofline"]["valu"] = _pick(r["valu"], ("wave_instructions_per_frame", "lk_share", "frac"))
     for k in ("cpu_baseline", "cpu_baseline_allcores", "cpu_baseline_reference_tracker"):
@@ -470,7 +499,7 @@ def main():
                          "its steady-state size, whatever --warmup is")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("ICG_BENCH_STREAMS", "0")),
                     help="camera streams per GPU (0 = 8 per stream group)")
-    ap.add_argument("--ring", type=int, default=64, help="rendered frames per stream (ping-pong replay)")
+    ap.add_argument("--ring", type=int, default=32, help="rendered frames per stream (ping-pong replay)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--features", type=int, default=300)
@@ -582,6 +611,10 @@ def main():
             # HBM traffic and issue utilisation of the same kernel from the committed rocprofv3 --pmc passes of THIS configuration
             # (profiles/collect.sh runs bench.py with the default streams/groups): per unit x the units of one launch here
             pmc, pmc_file = committed_pmc("k_" + dom)
+            stale = pmc_provenance(pmc_file, per_launch_streams) if pmc_file else "no committed counter summary"
+            if stale:
+                roofline["pmc_stale"] = stale  # counters of another build / launch shape are not quoted next to this measurement
+                pmc, pmc_file = None, None
             if pmc and "hbm_bytes_per_launch" in pmc and dom == "lk_track_fb":
                 per_point = pmc["hbm_bytes_per_launch"] / (pmc["grid_threads"] / 64.0)
                 roofline["traffic"] = int(per_point * pts)
@@ -930,8 +963,8 @@ def main():
     if rank == 0 and not args.no_reproj and not args.no_c4:
         c4 = {"workload": "C4: 1920x1080 synthetic streams, 500 features, 15-keyframe window (7 000 reprojection factors), 15 x 40-sample "
                           "IMU intervals at 200 Hz, 1 MI355X"}
-        G4 = int(max(2, min(32, 2 * round(cores_rank))))  # round-2 sweep (profiles/run_c4_sweep.sh): 16 x 4 -> 27.8 k, 32 x 4 -> 32.9 k, 32 x 8 -> 39.4 k
-        B4 = 8 * G4
+        G4 = int(max(4, min(12, 3 * round(cores_rank))))  # table engine: few large groups (round 2, object engine: 32 x 8 -> 39.4 k)
+        B4 = 32 * G4
         f4 = run_frontend(torch, hip, w=1920, h=1080, nfeat=500, window=15, B=B4, G=G4, ring=16, prime=64, warmup=10, steps=60,
                           rank=0, local_rank=local_rank, host_threads=1, host_frames=False, profile=False,
                           barrier=torch.cuda.synchronize, ncpu=ncpu)
@@ -983,8 +1016,8 @@ def main():
     pcie = None
     if rank == 0 and not args.no_reproj and not args.host_frames:
         # (32 groups: with every frame crossing the link, more groups in flight only add contention — 48 x 8: 35.1 k, 32 x 8: 40.7 k)
-        Gh = min(G, 32)
-        Bh = B if Gh == G else 8 * Gh
+        Gh = min(G, 12)
+        Bh = 32 * Gh  # (384 streams: 8 ring frames each = 2.8 GB of pinned host memory)
         fh = run_frontend(torch, hip, w=w, h=h, nfeat=nfeat, window=10, B=Bh, G=Gh, ring=8, prime=args.prime, warmup=5, steps=40, rank=0,
                           local_rank=local_rank, host_threads=host_threads, host_frames=True, profile=False, barrier=torch.cuda.synchronize,
                           ncpu=ncpu)

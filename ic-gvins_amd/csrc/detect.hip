@@ -530,6 +530,7 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
         ctx->mask_gen = 1;
     }
     const unsigned int gen = (unsigned int) ctx->mask_gen;
+    ICG_LAUNCH_GUARD(c);
     if (n_mask > 0) {
         icg_prof_scope ps(ctx, "detect_mask");
         hipLaunchKernelGGL(k_mask_discs, dim3(n_mask), dim3(64), 0, ctx->stream, n_mask, d_mpts, d_ptjob, grid->min_dist,

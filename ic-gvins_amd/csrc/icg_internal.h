@@ -192,6 +192,12 @@ static inline int icg_stream_wait(icg_ctx *ctx) {
 //   in()/out()       mirrored: ONE H2D copy at seal(), ONE D2H copy at finish() — for data many workgroups re-read
 //   in_zc()/out_zc() zero-copy: kernels read/write the pinned host memory over PCIe — for data touched once per
 //                    lane/wave (point lists, status bytes); saves the copy API calls, which dominate at small batches
+#define ICG_LAUNCH_GUARD(call)                \
+    do {                                      \
+        const int rc_guard_ = (call).outputs_done(); \
+        if (rc_guard_) return rc_guard_;      \
+    } while (0)
+
 struct icg_call {
     icg_ctx *ctx;
     size_t mirror_lo = (size_t) -1, mirror_hi = 0;
@@ -224,6 +230,9 @@ struct icg_call {
         return d;
     }
     int overflowed() { return icg_arena_overflow_check(ctx); }
+    // after the last in()/out()/out_zc() and BEFORE the first launch: an allocation that did not fit was redirected to offset 0, i.e. it
+    // aliases the inputs staged there — no kernel may run on that (ICG_LAUNCH_GUARD returns ICG_ERR_NOMEM instead)
+    int outputs_done() { return ctx->arena_overflow ? overflowed() : 0; }
     int seal() {
         if (ctx->arena_overflow) return overflowed();
         return mirror_hi > mirror_lo ? icg_arena_h2d(ctx, mirror_lo, mirror_hi) : 0;

@@ -141,6 +141,7 @@ extern "C" int icg_ins_mechanize_batch(icg_ctx *ctx, int n_streams, const int32_
     double *d_st         = c.inout(states23, states23, 23 * (size_t) n_streams); // read and written in place
     if ((rc = c.seal())) return rc;
     double *d_traj = traj23 ? c.out(traj23, 23 * (size_t) total) : nullptr;
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "ins_mechanize");
         hipLaunchKernelGGL(k_ins_mechanize, dim3((n_streams + 63) / 64), dim3(64), 0, ctx->stream, n_streams, d_off, d_imu, d_cfg, d_st,
@@ -164,6 +165,7 @@ extern "C" int icg_ins_camera_pose_batch(icg_ctx *ctx, int n, const double *brac
     const double *d_pbc = c.in_zc(pose_b_c12, 12);
     const double *d_t   = c.in_zc(times, (size_t) n);
     double *d_o         = c.out_zc(pose12_out, 12 * (size_t) n);
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "ins_camera_pose");
         hipLaunchKernelGGL(k_ins_camera_pose, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, n, d_b, d_i, d_pbc, d_t, d_o);

@@ -975,6 +975,7 @@ extern "C" int icg_lk_track(icg_ctx *ctx, int n, const int32_t *prev_slot, const
     memcpy(d_np, next_pts, sizeof(float) * 2 * (size_t) n);
     unsigned char *d_st = c.out_zc(status, (size_t) n);
     float *d_err        = err ? c.out_zc(err, (size_t) n) : nullptr;
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "lk_track");
         hipLaunchKernelGGL(k_lk_track, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp, d_np,
@@ -1010,6 +1011,7 @@ extern "C" int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, co
     float2 *d_und       = out_undist ? (float2 *) c.out_zc(out_undist, 2 * (size_t) n) : nullptr;
     int32_t *d_keep     = keep_idx ? c.out_zc(keep_idx, (size_t) n) : nullptr;
     int32_t *d_nkeep    = keep_idx ? c.out_zc(n_keep, 1) : nullptr;
+    ICG_LAUNCH_GUARD(c);
     {
         // ICG_LK_PAIR=1: two features per wave (k_lk_track_fb2).  Measured on MI355X (profiles/r03_lk_pair.md): 28 % fewer instructions per
         // Gauss-Newton iteration and 16 % fewer per level set-up, but a wave runs max() of its two features' iteration counts and keeps only

@@ -84,6 +84,7 @@ extern "C" int icg_undistort_points(icg_ctx *ctx, int n, float *pts) {
     if ((rc = c.seal())) return rc;
     float2 *d_out = (float2 *) c.out(pts, 2 * (size_t) n);
     ICG_HIP(ctx, hipMemcpyAsync(d_out, d_in, sizeof(float2) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "undistort_points");
         hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_out);
@@ -103,6 +104,7 @@ extern "C" int icg_distort_points(icg_ctx *ctx, int n, float *pts) {
     if ((rc = c.seal())) return rc;
     float2 *d_out = (float2 *) c.out(pts, 2 * (size_t) n);
     ICG_HIP(ctx, hipMemcpyAsync(d_out, d_in, sizeof(float2) * n, hipMemcpyDeviceToDevice, ctx->stream));
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "distort_points");
         hipLaunchKernelGGL(k_distort, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_out);
@@ -126,6 +128,7 @@ extern "C" int icg_predict_mappoints(icg_ctx *ctx, int n, const double *pw, cons
     const double *d_po  = c.in(poses12, 12 * (size_t) n_poses);
     if ((rc = c.seal())) return rc;
     float2 *d_out = (float2 *) c.out(pts_out, 2 * (size_t) n);
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "predict_mappoints");
         hipLaunchKernelGGL(k_predict_mappoints, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_pw, d_pi,
@@ -150,6 +153,7 @@ extern "C" int icg_predict_rotation(icg_ctx *ctx, int n, const float *pts_in, co
     const double *d_r   = c.in(rots9, 9 * (size_t) n_rots);
     if ((rc = c.seal())) return rc;
     float2 *d_out = (float2 *) c.out(pts_out, 2 * (size_t) n);
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "predict_rotation");
         hipLaunchKernelGGL(k_predict_rotation, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_in, d_ri, d_r,
@@ -182,6 +186,7 @@ extern "C" int icg_reproj_error_batch(icg_ctx *ctx, int n, const int32_t *pose_i
     if ((rc = c.seal())) return rc;
     double *d_e  = c.out_zc(err_out, (size_t) n);
     uint8_t *d_g = c.out_zc(good_out, (size_t) n);
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "reproj_error");
         hipLaunchKernelGGL(k_reproj_error, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_pi, d_li, d_po, d_pw, d_px, max_error,

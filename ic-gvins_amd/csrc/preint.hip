@@ -271,6 +271,7 @@ extern "C" int icg_preint_batch(icg_ctx *ctx, int variant, int n_intervals, cons
     double *d_cov = c.out_zc(cov, 225 * (size_t) n_intervals);
     double *d_dt  = c.out_zc(delta_time, (size_t) n_intervals);
     double *d_pn  = pn ? c.out_zc(pn, 4 * (size_t) total) : nullptr;
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "preint");
         hipLaunchKernelGGL(k_preint, dim3(n_intervals), dim3(64), 0, ctx->stream, variant, d_off, d_imu, d_s0, d_par, d_cur, d_del,

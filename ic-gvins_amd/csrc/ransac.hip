@@ -436,6 +436,7 @@ extern "C" int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, c
         if ((rc = c.seal())) return rc;
         int32_t *d_good   = c.out_zc(h_good.data(), (size_t) nh_total * 3);
         unsigned long long *d_bits = c.out_zc(h_bits.data(), (size_t) words);
+        ICG_LAUNCH_GUARD(c);
         {
             icg_prof_scope ps(ctx, "fm_hypothesis");
             hipLaunchKernelGGL(k_fm_hypothesis, dim3((nh_total + FM_HPW - 1) / FM_HPW), dim3(256), 0, ctx->stream, nh_total, d_sets, d_hset, d_hidx, d_p1, d_p2,
@@ -572,6 +573,7 @@ extern "C" int icg_triangulate(icg_ctx *ctx, int n, const int32_t *T0_idx, const
     const double *d_p0  = c.in_zc(pc0, 3 * (size_t) n);
     const double *d_p1  = c.in_zc(pc1, 3 * (size_t) n);
     double *d_pw = c.out_zc(pw, 3 * (size_t) n);
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "triangulate");
         hipLaunchKernelGGL(k_triangulate, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, n, d_i0, d_i1, d_T, d_p0, d_p1, d_pw);

@@ -434,6 +434,7 @@ extern "C" int icg_reproj_accumulate_normal(icg_ctx *ctx, int local_size, const 
     double *d_b = c.out(hb.data(), L);
     ICG_HIP(ctx, hipMemsetAsync(d_H, 0, sizeof(double) * L * L, ctx->stream));
     ICG_HIP(ctx, hipMemsetAsync(d_b, 0, sizeof(double) * L, ctx->stream));
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "reproj_normal");
         hipLaunchKernelGGL(k_reproj_normal, dim3((n + NRM_BLOCK - 1) / NRM_BLOCK), dim3(NRM_BLOCK), 0, ctx->stream, n,
@@ -693,6 +694,7 @@ extern "C" int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, in
     double *d_dg = c.out(diag_cc, (size_t) P); // user pointer may be null: still a valid device scratch
     double *d_co = c.out(cost, 1);
     const double *d_r = ctx->d_rJ, *d_J = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
+    ICG_LAUNCH_GUARD(c);
     if (reassemble) {
         ICG_HIP(ctx, hipMemsetAsync(d_H, 0, sizeof(double) * (N * N + N + (size_t) L + 1), ctx->stream));
         icg_prof_scope ps(ctx, "reproj_normal");
@@ -754,6 +756,7 @@ extern "C" int icg_reproj_backsub(icg_ctx *ctx, int P, const double *delta_c, do
     double *d_tm = c.inout(zeros, lm_terms, 2); // device accumulators, pre-zeroed
     if ((rc = c.seal())) return rc;
     double *d_dl = c.out(delta_l, (size_t) L);
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "schur_backsub");
         hipLaunchKernelGGL(k_schur_backsub, dim3(L), dim3(64), 0, ctx->stream, P, L, (int) N, d_H, d_b, d_inv, d_dc, d_dl, d_tm, ctx->sys_damp,
@@ -777,6 +780,7 @@ extern "C" int icg_reproj_cost(icg_ctx *ctx, const uint8_t *active, double *cost
     const double zero = 0.0;
     double *d_acc = c.inout(&zero, cost, 1); // device accumulator, pre-zeroed
     if ((rc = c.seal())) return rc;
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "reproj_cost");
         hipLaunchKernelGGL(k_reproj_cost, dim3(std::min(64, (n + 255) / 256)), dim3(256), 0, ctx->stream, n, (const double *) ctx->d_rJ, d_act,
@@ -1119,6 +1123,7 @@ extern "C" int icg_reproj_eval_windows(icg_ctx *ctx, int n_poses, const double *
     A.out_r       = ctx->d_rJ;
     A.out_J       = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
     if ((rc = c.seal())) return rc;
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "reproj_eval");
         hipLaunchKernelGGL(k_reproj_eval, dim3((n + RPJ_TILE - 1) / RPJ_TILE), dim3(RPJ_TILE), 0, ctx->stream, A);
@@ -1250,6 +1255,7 @@ static int schur_windows_impl(icg_ctx *ctx, int P, const int32_t *col_pose, cons
         *S_view = d_S;
     }
     const double *d_r = ctx->d_rJ, *d_J = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
+    ICG_LAUNCH_GUARD(c);
     if (any_new) {
         icg_prof_scope ps(ctx, "reproj_normal");
         hipLaunchKernelGGL(k_sys_clear_w, dim3(32, W), dim3(256), 0, ctx->stream, d_wd, P, ctx->d_sys);
@@ -1333,6 +1339,7 @@ extern "C" int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *del
     double *d_tm = c.inout(zeros.data(), lm_terms, 2 * (size_t) W);
     if ((rc = c.seal())) return rc;
     double *d_dl = c.out(delta_l, (size_t) n_lm);
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "schur_backsub");
         hipLaunchKernelGGL(k_schur_backsub_w, dim3(n_lm), dim3(64), 0, ctx->stream, d_wd, (const int32_t *) ctx->d_lmwin, P, (const double *) ctx->d_sys, d_dc,
@@ -1360,6 +1367,7 @@ extern "C" int icg_reproj_cost_windows(icg_ctx *ctx, const uint8_t *active, doub
     std::vector<double> zeros((size_t) W, 0.0);
     double *d_cost = c.inout(zeros.data(), cost, (size_t) W);
     if ((rc = c.seal())) return rc;
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "reproj_cost");
         hipLaunchKernelGGL(k_reproj_cost_w, dim3(4, W), dim3(256), 0, ctx->stream, d_wd, (const double *) ctx->d_rJ, d_act, ctx->last_huber, d_cost);
@@ -1388,6 +1396,7 @@ extern "C" int icg_reproj_chi2_cull(icg_ctx *ctx, double chi2, uint8_t *active) 
     if (rc) return rc;
     const uint8_t *d_in = c.in_zc(active, (size_t) n);
     uint8_t *d_out      = c.out_zc(active, (size_t) n);
+    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "reproj_chi2");
         hipLaunchKernelGGL(k_reproj_chi2, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, (const double *) ctx->d_rJ, chi2, d_in, d_out);

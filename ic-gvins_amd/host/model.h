@@ -239,18 +239,19 @@ public:
         refreshSnapshotLocked();
         out = snapshot_;
     }
-    // Visits (map-point id, feature) in container order WITHOUT copying the shared_ptrs (a copy is a locked increment of each feature's
-    // control block: ~300 serialized cache misses on a frame that was last touched several frames ago), software-pipelined: the feature
-    // object 16 ahead and the map point (object + reference counts) of the feature 8 ahead are requested while feature k is visited.
-    // The frame lock is held: the visitor must not call back into this frame.
+    // Visits (map-point id, feature) in container order, software-pipelined: the feature object 16 ahead and the map point (object +
+    // reference counts) of the feature 8 ahead are requested while feature k is visited.
+    // The visitor runs on a copy of the list, WITHOUT the frame lock: visitors take map-point locks, grow vectors and drop
+    // shared_ptrs (possibly destroying map points / frames), none of which may happen under a non-recursive spin lock that the estimator
+    // and drawer threads also take (round-2 review).  The throughput path no longer walks object graphs at all (track_table.h).
     template <typename F> void forEachFeaturePipelined(F &&f) {
-        ModelLock lock(frame_mutex_);
-        refreshSnapshotLocked();
-        const size_t n = snapshot_.size();
+        FeatureList view;
+        featureSnapshot(view);
+        const size_t n = view.size();
         for (size_t k = 0; k < n; k++) {
-            if (k + 16 < n) prefetchShared(snapshot_[k + 16].second.get());
-            if (k + 8 < n) prefetchShared(snapshot_[k + 8].second->mapPointHint());
-            f(snapshot_[k].first, snapshot_[k].second);
+            if (k + 16 < n) prefetchShared(view[k + 16].second.get());
+            if (k + 8 < n) prefetchShared(view[k + 8].second->mapPointHint());
+            f(view[k].first, view[k].second);
         }
     }
     // bucket space for n more features up front (no incremental rehashing while a frame is being filled)
@@ -415,7 +416,8 @@ public:
     // The slot the next addObservation() will write (the list's storage is its own heap block, cold when a stream is touched again): a
     // store that misses is drained by the next locked instruction, i.e. it stalls the reference-count traffic that follows it.
     // Unlocked read of the end pointer, used as a prefetch address only.
-    void prefetchObservationSlot() const {
+    void prefetchObservationSlot() {
+        ModelLock lock(mappoint_mutex_); // (the end pointer is written under this lock: no unlocked read, not even for a prefetch address)
         const std::weak_ptr<Feature> *end = observations_.data() + observations_.size();
         __builtin_prefetch(end, 1);
     }

@@ -16,9 +16,14 @@
 
 namespace icg {
 
-template <size_t BlockBytes> class BlockPool {
+template <size_t BlockBytes, size_t Align = 16> class BlockPool {
 public:
     static void *allocate() {
+        if (!tls_alive()) { // (see deallocate) no per-thread list any more: straight from the heap, block-sized and aligned
+            void *q = nullptr;
+            if (posix_memalign(&q, Align < sizeof(void *) ? sizeof(void *) : Align, kBlock) != 0) throw std::bad_alloc();
+            return q;
+        }
         Local &L = local();
         if (!L.head) refill(L);
         Node *n = L.head;
@@ -27,6 +32,13 @@ public:
         return n;
     }
     static void deallocate(void *p) {
+        if (!tls_alive()) { // this thread's free list is already destroyed (static-lifetime objects freed during thread / process exit)
+            std::lock_guard<std::mutex> lock(shared().m);
+            Node *n       = static_cast<Node *>(p);
+            n->next       = shared().head;
+            shared().head = n;
+            return;
+        }
         Local &L = local();
         Node *n  = static_cast<Node *>(p);
         n->next  = L.head;
@@ -41,7 +53,9 @@ private:
     struct Local {
         Node *head{nullptr};
         size_t count{0};
-        ~Local() { // thread exit: hand the blocks back to the shared list
+        Local() { tls_alive() = true; }
+        ~Local() { // thread exit: hand the blocks back to the shared list; later frees on this thread go there directly
+            tls_alive() = false;
             if (!head) return;
             std::lock_guard<std::mutex> lock(shared().m);
             while (head) {
@@ -56,9 +70,16 @@ private:
         std::mutex m;
         Node *head{nullptr};
     };
-    static constexpr size_t kBlock    = (BlockBytes + 15) / 16 * 16;
+    static_assert(Align >= 16 && (Align & (Align - 1)) == 0 && Align <= 4096, "block alignment must be a power of two >= 16");
+    static constexpr size_t kBlock    = (BlockBytes + Align - 1) / Align * Align;
     static constexpr size_t kSlab     = 64 * 1024;
     static constexpr size_t kLocalMax = 8192;
+    // trivially destructible flag next to the list: true while this thread's Local exists (or has not been created yet: local()
+    // creates it on first use), false once its destructor ran
+    static bool &tls_alive() {
+        static thread_local bool alive = true;
+        return alive;
+    }
     static Local &local() {
         static thread_local Local L;
         return L;
@@ -81,8 +102,9 @@ private:
             L.count += taken;
             if (taken) return;
         }
-        char *slab = static_cast<char *>(std::malloc(kSlab));
-        if (!slab) throw std::bad_alloc();
+        void *raw = nullptr; // slabs are aligned to the block alignment (malloc only guarantees 16: an AVX Eigen member needs 32)
+        if (posix_memalign(&raw, Align, kSlab) != 0 || !raw) throw std::bad_alloc();
+        char *slab = static_cast<char *>(raw);
         const size_t n = kSlab / kBlock;
         for (size_t k = n; k-- > 0;) { // ascending addresses come off the list first: a burst of allocations walks memory forwards
             Node *b = reinterpret_cast<Node *>(slab + k * kBlock);
@@ -106,15 +128,17 @@ private:
 // std::allocator-compatible front for single-object allocations (allocate_shared, node-based containers); anything else goes to the heap
 template <typename T> struct PoolAllocator {
     typedef T value_type;
+    // blocks carry the alignment of the type (ICG_REFERENCE_TYPES: fixed-size vectorizable Eigen members may ask for 32 bytes)
+    typedef BlockPool<sizeof(T), (alignof(T) > 16 ? alignof(T) : 16)> Pool;
     PoolAllocator() = default;
     template <typename U> PoolAllocator(const PoolAllocator<U> &) {}
     T *allocate(size_t n) {
-        if (n == 1) return static_cast<T *>(BlockPool<sizeof(T)>::allocate());
+        if (n == 1) return static_cast<T *>(Pool::allocate());
         return static_cast<T *>(::operator new(n * sizeof(T)));
     }
     void deallocate(T *p, size_t n) {
         if (n == 1)
-            BlockPool<sizeof(T)>::deallocate(p);
+            Pool::deallocate(p);
         else
             ::operator delete(p);
     }

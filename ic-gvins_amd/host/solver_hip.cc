@@ -12,6 +12,9 @@
 #include <mutex>
 #include <stdexcept>
 
+#include <condition_variable>
+#include <thread>
+
 #include "../../include/icgvins_hip.h"
 
 namespace icg {
@@ -37,26 +40,85 @@ struct PhaseScope {
 };
 enum { PH_EVAL_JAC = 0, PH_SCHUR, PH_HOST_FACTORS, PH_CHOLESKY, PH_BACKSUB, PH_EVAL_TRIAL, PH_COST, PH_CHI2 };
 
-// one helper thread per process for WindowSolver::setHostFactorOverlap: whoever holds the lock uses it, anybody else runs the halves in turn
+// One helper thread per process for WindowSolver::setHostFactorOverlap: whoever holds the lock hands it the HOST half (the host factors of a
+// linearization) and drives the device half itself — the calling thread is the one that talks to the device, always — anybody else runs the
+// halves in turn.  The helper's phase clock (thread_local) is merged into the caller's after the join, so ICG_SOLVER_DEBUG books every phase.
 std::atomic<bool> g_overlap{false};
-struct OverlapPool {
-    std::mutex m;
-    std::unique_ptr<HostPool> pool;
+class OverlapHelper {
+public:
+    std::mutex owner; // try_lock'ed by the solver that wants the helper
+    ~OverlapHelper() {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (thread_.joinable()) thread_.join();
+    }
+    void submit(const std::function<bool()> *job) {
+        if (!thread_.joinable()) thread_ = std::thread(&OverlapHelper::loop, this);
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            job_  = job;
+            done_ = false;
+        }
+        cv_.notify_all();
+    }
+    bool wait(PhaseClock &into) {
+        std::unique_lock<std::mutex> lock(m_);
+        cv_.wait(lock, [&] { return done_; });
+        for (int k = 0; k < 8; k++) into.ms[k] += clock_.ms[k], into.calls[k] += clock_.calls[k];
+        return ok_;
+    }
+
+private:
+    void loop() {
+        for (;;) {
+            const std::function<bool()> *job;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                cv_.wait(lock, [&] { return stop_ || job_ != nullptr; });
+                if (stop_) return;
+                job  = job_;
+                job_ = nullptr;
+            }
+            g_clock = PhaseClock();
+            bool ok = false;
+            try {
+                ok = (*job)();
+            } catch (...) {
+                ok = false;
+            }
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                ok_    = ok;
+                clock_ = g_clock;
+                done_  = true;
+            }
+            cv_.notify_all();
+        }
+    }
+    std::thread thread_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    const std::function<bool()> *job_{nullptr};
+    bool done_{true}, ok_{false}, stop_{false};
+    PhaseClock clock_;
 };
-OverlapPool &overlapPool() {
-    static OverlapPool p;
-    return p;
+OverlapHelper &overlapHelper() {
+    static OverlapHelper h;
+    return h;
 }
 // device() and host() both run, side by side when the overlap is on and the helper is free; -> both succeeded
 bool runHalves(bool want_overlap, const std::function<bool()> &device, const std::function<bool()> &host) {
     if (want_overlap && g_overlap.load(std::memory_order_relaxed)) {
-        OverlapPool &op = overlapPool();
-        std::unique_lock<std::mutex> lock(op.m, std::try_to_lock);
+        OverlapHelper &h = overlapHelper();
+        std::unique_lock<std::mutex> lock(h.owner, std::try_to_lock);
         if (lock.owns_lock()) {
-            if (!op.pool) op.pool.reset(new HostPool(2));
-            bool ok[2] = {false, false};
-            op.pool->parallelFor(2, [&](int i) { ok[i] = i == 0 ? device() : host(); });
-            return ok[0] && ok[1];
+            h.submit(&host);
+            const bool a = device(); // on the calling thread
+            const bool b = h.wait(g_clock);
+            return a && b;
         }
     }
     const bool a = device();

@@ -25,17 +25,18 @@ def terminal_exchange(dist, device, counters, elapsed, digests):
     return [float(x) for x in c.cpu()], float(t.cpu()[0]), [int(x) for g in gathered for x in g.cpu()]
 
 
-STREAMS_PER_GPU = 384  # fixed work per GPU whatever the world size: "scaling": "weak" means exactly this
+STREAMS_PER_GPU = 768  # fixed work per GPU whatever the world size: "scaling": "weak" means exactly this
 
 
 def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, streams_override=0):
     """Host resources of one rank (one rank's polling threads must not assume the whole box):
       cores_rank   the rank's share of the usable host cores
-      streams      384 camera streams per GPU, the same for every world size (weak scaling: per-GPU work is fixed)
+      streams      768 camera streams per GPU, the same for every world size (weak scaling: per-GPU work is fixed)
       groups       stream groups (one host thread + HIP stream each).  With the track-table engine a frame costs the host ~20 us of logic, so
                    a group can carry 32-64 streams; round-3 sweep on one MI355X (profiles/r03_group_sweep.txt): 48 x 8 -> 78 k, 24 x 16 -> 92 k,
-                   16 x 24 -> 98.6 k, 12 x 32 -> 99.9 k, 8 x 48 -> 100.7 k frames/s with 3.3-3.9 host cores busy.  3 groups per core of the
-                   share, between 4 and 12.
+                   16 x 24 -> 98.6 k, 12 x 32 -> 99.9 k, 8 x 48 -> 100.7 k frames/s with 3.3-3.9 host cores busy; larger launches have shorter
+                   tails: 12 x 64 -> 111.0 k, 16 x 64 -> 111.7 k, 8 x 96 -> 105.5 k (4.2 cores busy).  3 groups per core of the share, between
+                   4 and 12.
       cpu_slice    the contiguous slice of the allowed CPU ids this rank pins itself to (None for a single rank: nothing to separate)
     """
     cores_rank = float(usable_cores) / float(max(1, world))

@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -o kt -- python $R/bench.py --no-cpu-baseline --no-replay > $OUT/${TAG}_kt_bench.json 2> $OUT/${TAG}_kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_kt -o kt -- python $R/bench.py --no-cpu-baseline --no-replay --details $OUT/${TAG}_kt_bench_details.json > $OUT/${TAG}_kt_bench.json 2> $OUT/${TAG}_kt.err
 # the counter passes run the BENCH CONFIGURATION (default streams / groups of this box), shortened: 24 priming + 2 warm-up + 6 timed frames per stream
 SHORT="--no-cpu-baseline --no-reproj --prime 24 --warmup 2 --steps 6 --no-profile-pass"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o p -- python $R/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_fetch.err
@@ -21,6 +21,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCL
 for CNT in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CNT --output-format csv -d $OUT/${TAG}_pmc_reproj_$CNT -o p -- python $R/profiles/run_reproj_only.py > /dev/null 2> $OUT/${TAG}_pmc_reproj_$CNT.err
 done
+export ICG_PMC_STREAMS_PER_LAUNCH=$(python -c "import json; c=json.load(open('$OUT/${TAG}_kt_bench.json'))['config']; print(c['streams_per_gpu'] / c['groups_per_gpu'])")
 python $R/profiles/summarize_pmc.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_reproj_FETCH_SIZE $OUT/${TAG}_pmc_reproj_WRITE_SIZE > $OUT/${TAG}_pmc_summary.json
 find $OUT/${TAG}_kt -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
 # queue-level view of the same trace (hardware-queue occupancy, kernels in flight, per-kernel duration under load)

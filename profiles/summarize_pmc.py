@@ -32,6 +32,22 @@ def main(dirs):
         if "FETCH_SIZE" in e or "WRITE_SIZE" in e:
             e["hbm_bytes_per_launch"] = 2.0 * 1024.0 * e.get("FETCH_SIZE", 0.0) + 1024.0 * e.get("WRITE_SIZE", 0.0)
         out[k] = e
+    # provenance (bench.py checks it before it quotes these counters next to a fresh measurement): a hash of the kernel sources the
+    # counters were collected on and the launch shape of the bench configuration (streams per launch)
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha1()
+    src = os.path.join(root, "ic-gvins_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    lk = out.get("k_lk_track_fb")
+    pre = out.get("k_pyramid3")
+    out["_meta"] = {"csrc_sha1": h.hexdigest(), "streams_per_launch": os.environ.get("ICG_PMC_STREAMS_PER_LAUNCH"),
+                    "lk_points_per_launch": (lk["grid_threads"] / 64.0) if lk else None,
+                    "note": "csrc_sha1 = sha1 over the names and contents of ic-gvins_amd/csrc/*.{hip,h} at collection time"}
     json.dump(out, sys.stdout, indent=1)
 
 

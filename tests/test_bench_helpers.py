@@ -59,3 +59,23 @@ def test_contract_line_is_compact_and_keeps_every_quoted_number():
     assert c["solve"]["batched"]["value"] == full["solve"]["batched"]["value"]
     assert c["reproj"]["value"] == full["reproj"]["value"] and c["c4"]["frontend"]["value"] == full["c4"]["frontend"]["value"]
     assert c["pcie_inclusive"]["value"] == full["pcie_inclusive"]["value"] and c["details"] == "gpurun_out/bench_details.json"
+
+
+def test_stale_counter_summaries_are_not_quoted(tmp_path, monkeypatch):
+    """roofline.traffic / issue_frac / valu come from a committed rocprofv3 --pmc summary; they may only be quoted when that
+    summary was collected on the kernel sources and launch shape of this build (profiles/summarize_pmc.py writes the provenance)."""
+    b = _bench()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    src = tmp_path / "ic-gvins_amd" / "csrc"
+    src.mkdir(parents=True)
+    (src / "a.hip").write_text("kernel v1")
+    sha = b.csrc_sha1()
+    (prof / "r09_pmc_summary.json").write_text(json.dumps({"k_lk_track_fb": {}, "_meta": {"csrc_sha1": sha, "streams_per_launch": "32.0"}}))
+    assert b.pmc_provenance("r09_pmc_summary.json", 32.0) is None
+    assert "streams per launch" in b.pmc_provenance("r09_pmc_summary.json", 8.0)
+    (src / "a.hip").write_text("kernel v2")
+    assert "changed" in b.pmc_provenance("r09_pmc_summary.json", 32.0)
+    (prof / "r08_pmc_summary.json").write_text(json.dumps({"k_lk_track_fb": {}}))
+    assert "no provenance" in b.pmc_provenance("r08_pmc_summary.json", 32.0)
