@@ -84,6 +84,19 @@ def main():
                                                 maxLevel=3, criteria=crit, flags=cv2.OPTFLOW_USE_INITIAL_FLOW)
         out[f"{tag}_lk_prev"], out[f"{tag}_lk_guess"] = pts, guess
         out[f"{tag}_lk_next"], out[f"{tag}_lk_status"], out[f"{tag}_lk_err"] = nxt.reshape(-1, 2), st.ravel(), err.ravel()
+        # intermediates (diagnosis only: a mismatch of the final positions is localised in one pass): the position every point has after
+        # the coarse levels, obtained by stopping the pyramid early — calcOpticalFlowPyrLK(maxLevel = L) on the level-(3-L) images with the
+        # guess scaled accordingly is what the full call does internally for its first L+1 levels
+        for top in (3, 2, 1):  # track only levels 3..top on the images of level `top`
+            sc = 1.0 / (1 << top)
+            pa, pb = pyr[top], cv2.buildOpticalFlowPyramid(cb, (21, 21), 3, withDerivatives=False)[1][top]
+            n_t, s_t, _ = cv2.calcOpticalFlowPyrLK(np.ascontiguousarray(pa), np.ascontiguousarray(pb), (pts * sc).reshape(-1, 1, 2).astype(np.float32),
+                                                   (guess * sc).reshape(-1, 1, 2).astype(np.float32), winSize=(21, 21), maxLevel=3 - top,
+                                                   criteria=crit, flags=cv2.OPTFLOW_USE_INITIAL_FLOW)
+            out[f"{tag}_lk_partial_top{top}"] = n_t.reshape(-1, 2)
+            out[f"{tag}_lk_partial_top{top}_status"] = s_t.ravel()
+        out[f"{tag}_scharr_x"] = cv2.Scharr(ca, cv2.CV_16S, 1, 0)  # the derivative planes LK samples (lkpyramid.cpp calcSharrDeriv)
+        out[f"{tag}_scharr_y"] = cv2.Scharr(ca, cv2.CV_16S, 0, 1)
         K, D = camera_for(w, h)
         und = cv2.undistortPoints(pts.reshape(-1, 1, 2), K, D, None, K).reshape(-1, 2)
         out[f"{tag}_undist_in"], out[f"{tag}_undist_out"] = pts, und.astype(np.float32)
@@ -93,7 +106,10 @@ def main():
         mask = np.full((h, w), 255, np.uint8)
         for p in exist:
             cv2.circle(mask, (int(round(float(p[0]))), int(round(float(p[1])))), min_dist, 0, cv2.FILLED)
-        det, det_blk = [], []
+        det, det_blk, det_raw = [], [], []
+        out[f"{tag}_mineig"] = cv2.cornerMinEigenVal(ca, 3, ksize=3)  # whole image; the per-block maps differ only at the ROI borders
+        out[f"{tag}_sobel_x"] = cv2.Sobel(ca, cv2.CV_32F, 1, 0, ksize=3)
+        out[f"{tag}_sobel_y"] = cv2.Sobel(ca, cv2.CV_32F, 0, 1, ksize=3)
         for k in range(cols * rows):
             c, r = k % cols, k // cols
             x0, y0, rw, rh = c * bw, r * bh, bw, bh
@@ -103,6 +119,10 @@ def main():
             corners = cv2.goodFeaturesToTrack(blk, quota, 0.01, min_dist, mask=blk_mask)
             if corners is None or len(corners) == 0:
                 continue
+            for q in corners.reshape(-1, 2):
+                det_raw.append([q[0] + x0, q[1] + y0])  # integer corners before cornerSubPix
+            if k == 0:
+                out[f"{tag}_mineig_block0"] = cv2.cornerMinEigenVal(np.ascontiguousarray(blk), 3, ksize=3)  # what GFTT sees for block 0
             corners = cv2.cornerSubPix(blk, corners, (5, 5), (-1, -1), (cv2.TERM_CRITERIA_COUNT + cv2.TERM_CRITERIA_EPS, 20, 0.01))
             for q in corners.reshape(-1, 2):
                 det.append([q[0] + x0, q[1] + y0])
@@ -111,6 +131,7 @@ def main():
         out[f"{tag}_det_mask"] = mask
         out[f"{tag}_det_pts"] = np.array(det, np.float32).reshape(-1, 2)
         out[f"{tag}_det_block"] = np.array(det_blk, np.int32)
+        out[f"{tag}_det_raw"] = np.array(det_raw, np.float32).reshape(-1, 2)
         out[f"{tag}_det_grid"] = np.array([cols, rows, bw, bh, quota, min_dist], np.int32)
         p1, p2 = two_view_points(max(40, nfeat // 2), 24, w, h)
         F, m = cv2.findFundamentalMat(p1, p2, cv2.FM_RANSAC, 1.5, 0.99)

@@ -15,6 +15,24 @@ pytestmark = pytest.mark.skipif(not os.path.exists(GOLDEN),
 CONFIGS = ["c1", "c2", "c4"]
 
 
+def test_manifest(G):
+    """the file is complete and comes from a supported OpenCV (tests/golden/README.md lists keys, dtypes and shapes)"""
+    major, minor = [int(v) for v in str(G["opencv_version"]).split(".")[:2]]
+    assert (major, minor) >= (4, 5) and major < 5, str(G["opencv_version"])
+    sizes = {"c1": (640, 480, 100), "c2": (1280, 720, 300), "c4": (1920, 1080, 500)}
+    for tag, (w, h, n) in sizes.items():
+        for key, dtype, shape in ((f"{tag}_clahe_a", np.uint8, (h, w)), (f"{tag}_clahe_b", np.uint8, (h, w)), (f"{tag}_pyr3", np.uint8, None),
+                                  (f"{tag}_lk_prev", np.float32, (n, 2)), (f"{tag}_lk_next", np.float32, (n, 2)), (f"{tag}_lk_status", None, (n,)),
+                                  (f"{tag}_lk_err", np.float32, (n,)), (f"{tag}_undist_out", np.float32, (n, 2)), (f"{tag}_det_grid", np.int32, (6,)),
+                                  (f"{tag}_det_mask", np.uint8, (h, w)), (f"{tag}_det_pts", np.float32, None), (f"{tag}_det_block", np.int32, None),
+                                  (f"{tag}_fm_p1", np.float32, None), (f"{tag}_fm_mask", np.uint8, None), (f"{tag}_fm_F", np.float64, (3, 3))):
+            assert key in G.files, key
+            if dtype is not None:
+                assert G[key].dtype == dtype, (key, G[key].dtype)
+            if shape is not None:
+                assert G[key].shape == shape, (key, G[key].shape)
+
+
 @pytest.fixture(scope="module")
 def G():
     return np.load(GOLDEN)
