@@ -385,11 +385,19 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
                           "workgroups, so a real run overlaps them. (b) all groups at once from their own threads: ceiling_frames_per_s, the rate "
                           "the kernels and the launch structure allow at the concurrency of the timed run; value / ceiling = share of that rate "
                           "the whole path (with the tracker logic on the host) reaches"}
+    # template set-up reuse in the LK calls (icg_lk_track_fb_reuse): points tracked / points whose hint passed the entry point's checks
+    lk_reuse = [0, 0]
+    for c in ctx_all:
+        o2 = (C.c_uint64 * 2)()
+        if hip.icg_lk_reuse_stats(c, o2) == 0:
+            lk_reuse[0] += int(o2[0])
+            lk_reuse[1] += int(o2[1])
     n_groups = sb.n_groups()
     sb.close()
     for p in dev_ptrs:
         hip.icg_dev_free(ctxh, p)
-    return {"ceiling": ceiling, "witness": {s: {"frames": host_keep[s], "poses": poses[s], "digest": stats[s]["digest"], "stream_id": sids[s]} for s in witness},
+    return {"lk_reuse": {"points": lk_reuse[0], "hinted": lk_reuse[1], "fraction": round(lk_reuse[1] / max(1, lk_reuse[0]), 4)},
+            "ceiling": ceiling, "witness": {s: {"frames": host_keep[s], "poses": poses[s], "digest": stats[s]["digest"], "stream_id": sids[s]} for s in witness},
             "frames_per_stream_at_digest": prime + warmup + steps, "ring": ring,
             "elapsed": elapsed, "states_hist": states_hist, "tracked": tracked, "stats": stats, "step_stats": step_stats,
             "host_breakdown": host_breakdown, "kernel_table": kernel_table, "work": work, "n_groups": n_groups, "setup_s": t_setup,
@@ -1103,6 +1111,7 @@ def main():
             "pcie_inclusive": pcie,
             "hbm_peak_measured_GBps": round(hbm_peak_measured, 1) if hbm_peak_measured else None,
             "kernel_ceiling": ceiling,
+            "lk_setup_reuse": fe.get("lk_reuse"),
             "kernels": kernel_table,
             "host_ms_per_step": host_breakdown,
             "step_stats": step_stats,

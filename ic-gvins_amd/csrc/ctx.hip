@@ -147,6 +147,8 @@ extern "C" void icg_ctx_destroy(icg_ctx *ctx) {
                    ctx->d_fwin,   ctx->d_lmwin};
     for (void *p : dev)
         if (p) (void) hipFree(p);
+    for (int b = 0; b < 2; b++)
+        if (ctx->d_lkc[b]) (void) hipFree(ctx->d_lkc[b]);
     if (ctx->h_arena) (void) hipHostFree(ctx->h_arena);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -176,6 +178,8 @@ int icg_arena_reserve(icg_ctx *ctx, size_t bytes) {
     if (ctx->arena_off != 0) return icg_fail(ctx, ICG_ERR_NOMEM, "arena grow requested mid-call");
     size_t cap = icg_align_up(bytes + bytes / 2, 1 << 16);
     ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < 2; b++)
+        if (ctx->d_lkc[b]) (void) hipFree(ctx->d_lkc[b]);
     if (ctx->h_arena) (void) hipHostFree(ctx->h_arena);
     if (ctx->d_arena) (void) hipFree(ctx->d_arena);
     ctx->h_arena = nullptr;

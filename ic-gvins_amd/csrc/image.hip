@@ -488,6 +488,8 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
     for (int k = 0; k < n; k++)
         if (slots[k] < 0 || slots[k] >= ctx->cfg.n_slots || !images[k]) return icg_fail(ctx, ICG_ERR_INVALID, "bad slot/image %d", k);
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (ctx->slot_gen.size() != (size_t) ctx->cfg.n_slots) ctx->slot_gen.assign((size_t) ctx->cfg.n_slots, 0);
+    for (int k = 0; k < n; k++) ctx->slot_gen[(size_t) slots[k]]++; // the slot holds a new image: set-ups cached for the old one are void
 
     // CLAHE geometry
     const int T = ICG_CLAHE_TILES;

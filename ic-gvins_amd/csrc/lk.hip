@@ -37,6 +37,7 @@ using namespace icgd;
 #define LK_JS 36   // J tile row stride in bytes (9 dwords: 3 aligned dwords cover any 8-byte run)
 #define LK_JM 5    // J tile margin around the 22x22 support
 #define LK_MAX_ITERS 30
+#define ICG_MAX_LK_LEVELS_CACHED 4
 #ifndef LK_WAVES_PER_EU
 #define LK_WAVES_PER_EU 5 // second __launch_bounds__ argument of k_lk_track_fb: 95 VGPRs, no scratch (6 would spill; 4, 5 and 6 measured equal in the bench)
 #endif
@@ -211,9 +212,26 @@ __device__ __forceinline__ void lk_fetch_J(const lk_smem &S, int row0, int o, un
     }
 }
 
+// ---- template set-up cache (round 3) ---------------------------------------------------------------------------------------------------
+// 44 % of the instructions of a track are the per-level SET-UP of the template: staging the 24x24 neighbourhood, the Scharr stencil, the
+// bilinear I / Ix / Iy samples of the lane's run, three exact reductions and the minimum-eigenvalue test.  That set-up depends only on
+// (image, point).  The BACKWARD pass of frame k (template = image k at the forward result) and the FORWARD pass of frame k+1 (template =
+// image k at the feature's position, which IS that forward result, bit for bit) compute the same set-up: the backward pass stores it —
+// per level 15 dwords per lane (c0[7], IXP[4], IYP[4]), the three window sums and the outcome of the eigenvalue test — and the next
+// call's forward pass loads it instead of recomputing (icg_lk_track_fb_reuse: the caller says which point of the previous call a point
+// continues; the entry point checks slot and slot generation, the kernel checks the point's bit pattern and the block's completeness,
+// so a wrong hint is a miss, never a wrong value).  Block: 32 header dwords + 4 levels x 15 x 64 dwords = 15 488 bytes per point.
+#define LKC_HDR 32
+#define LKC_LEVEL (15 * 64)
+#define LKC_DWORDS (LKC_HDR + ICG_MAX_LK_LEVELS_CACHED * LKC_LEVEL)
+#define LKC_ST_MINEIG 2u // the level ended at the minimum-eigenvalue / determinant test
+#define LKC_ST_DATA 3u   // A11, A12, A22 and the lane data are valid
+
 // One calcOpticalFlowPyrLK point, executed cooperatively by a full wave. Returns status.
+// rd: set-up block to take the template set-up from (its header has been validated by the caller), or null;  wr: block to store it to, or null
 __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI, const unsigned char *slotJ,
-                              float2 prevPt, float2 &nextIO, lk_smem &S, int lane, float *err_out) {
+                              float2 prevPt, float2 &nextIO, lk_smem &S, int lane, float *err_out, const unsigned int *rd = nullptr,
+                              unsigned int *wr = nullptr) {
     const float FLT_SCALE = 1.f / (1 << 20);
     const double eps2     = 0.01 * 0.01;
     bool status           = true;
@@ -248,6 +266,7 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                 status = false;
                 errv   = 0.f;
             }
+            if (wr != nullptr && level < ICG_MAX_LK_LEVELS_CACHED && lane == 0) wr[4 + 4 * level] = 0; // nothing to reuse (the reader skips the level by the same test)
             continue;
         }
         int w00, w01, w10, w11;
@@ -257,19 +276,24 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
         // ---- stage the 24x24 neighbourhood of the previous image AND the 32x32 tile of the next image around the
         //      level's starting estimate in one go (both address sets are known here) ----
         int jx0 = -1000000, jy0 = -1000000;
+        const bool cached = rd != nullptr && level < ICG_MAX_LK_LEVELS_CACHED; // wave-uniform
+        unsigned int cst  = 0;                                                  // outcome stored for this level by the pass that wrote rd
+        if (cached) cst = rd[4 + 4 * level];
+        const bool use_cache = cached && (cst == LKC_ST_MINEIG || cst == LKC_ST_DATA);
         {
             const int inx0 = (int) floorf(nptx - (float) ICG_LK_HALF), iny0 = (int) floorf(npty - (float) ICG_LK_HALF);
             const bool jok = !(inx0 < -ICG_LK_WIN || inx0 >= W || iny0 < -ICG_LK_WIN || iny0 >= H); // else iteration 0 bails out
-            unsigned int vi[3], vj[4] = {0, 0, 0, 0};
-            lk_load_I(vi, I, W, H, pitch, ipx, ipy, lane);
-            if (jok) {
+            unsigned int vi[3] = {0, 0, 0}, vj[4] = {0, 0, 0, 0};
+            const bool need_j  = jok && !(use_cache && cst == LKC_ST_MINEIG);
+            if (!use_cache) lk_load_I(vi, I, W, H, pitch, ipx, ipy, lane); // (a cached template needs no pixels of the previous image)
+            if (need_j) {
                 jx0 = inx0 - LK_JM;
                 jy0 = iny0 - LK_JM;
                 lk_load_J(vj, J, W, H, pitch, jx0, jy0, lane);
             }
             __syncthreads(); // previous level's LDS readers are done
-            lk_store_I(S, vi, lane);
-            if (jok) lk_store_J(S, vj, lane);
+            if (!use_cache) lk_store_I(S, vi, lane);
+            if (need_j) lk_store_J(S, vj, lane);
             __syncthreads();
         }
 
@@ -279,8 +303,26 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
         // IXP/IYP: the derivative samples as packed i16 pairs (k, k+1), k = 0,2,4,6 (upper half of the last pair is 0)
         int c0[7];
         unsigned int IXP[4], IYP[4];
-        int sA11, sA12, sA22;
-        {
+        int sA11 = 0, sA12 = 0, sA22 = 0;
+        float A11, A12, A22;
+        if (use_cache) {
+            if (cst == LKC_ST_MINEIG) { // the same template failed the eigenvalue / determinant test when it was set up
+                if (level == 0) status = false;
+                continue;
+            }
+            // (streamed once: non-temporal, so that the blocks do not push the pyramid tiles out of the XCD's L2)
+            const unsigned int *blk = rd + LKC_HDR + level * LKC_LEVEL + lane;
+#pragma unroll
+            for (int k = 0; k < 7; k++) c0[k] = (int) __builtin_nontemporal_load(blk + k * 64);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                IXP[m] = __builtin_nontemporal_load(blk + (7 + m) * 64);
+                IYP[m] = __builtin_nontemporal_load(blk + (11 + m) * 64);
+            }
+            A11 = __uint_as_float(rd[4 + 4 * level + 1]);
+            A12 = __uint_as_float(rd[4 + 4 * level + 2]);
+            A22 = __uint_as_float(rd[4 + 4 * level + 3]);
+        } else {
             const int idx = lx0 >> 2, sh = lx0 & 3;
             unsigned int Pp[4][5]; // pixel pairs (col 2m, 2m+1) of tile rows ly..ly+3, cols lx0..lx0+9
 #pragma unroll
@@ -359,12 +401,31 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
             sA11 = dot2(IXP[3], IXP[3], dot2(IXP[2], IXP[2], dot2(IXP[1], IXP[1], dot2(IXP[0], IXP[0], 0))));
             sA12 = dot2(IXP[3], IYP[3], dot2(IXP[2], IYP[2], dot2(IXP[1], IYP[1], dot2(IXP[0], IYP[0], 0))));
             sA22 = dot2(IYP[3], IYP[3], dot2(IYP[2], IYP[2], dot2(IYP[1], IYP[1], dot2(IYP[0], IYP[0], 0))));
+            A11 = wave_sum_i32x16_f32(sA11) * FLT_SCALE, A12 = wave_sum_i32x16_f32(sA12) * FLT_SCALE;
+            A22 = wave_sum_i32x16_f32(sA22) * FLT_SCALE;
         }
-        const float A11 = wave_sum_i32x16_f32(sA11) * FLT_SCALE, A12 = wave_sum_i32x16_f32(sA12) * FLT_SCALE;
-        const float A22 = wave_sum_i32x16_f32(sA22) * FLT_SCALE;
         float D            = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float) (2 * ICG_LK_WIN * ICG_LK_WIN);
-        if (minEig < 1e-4f || D < FLT_EPSILON) {
+        const bool weak    = minEig < 1e-4f || D < FLT_EPSILON;
+        if (wr != nullptr && level < ICG_MAX_LK_LEVELS_CACHED) { // this pass's template is the next call's forward template
+            if (!weak) {
+                unsigned int *blk = wr + LKC_HDR + level * LKC_LEVEL + lane;
+#pragma unroll
+                for (int k = 0; k < 7; k++) __builtin_nontemporal_store((unsigned int) c0[k], blk + k * 64);
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    __builtin_nontemporal_store(IXP[m], blk + (7 + m) * 64);
+                    __builtin_nontemporal_store(IYP[m], blk + (11 + m) * 64);
+                }
+            }
+            if (lane == 0) {
+                wr[4 + 4 * level]     = weak ? LKC_ST_MINEIG : LKC_ST_DATA;
+                wr[4 + 4 * level + 1] = __float_as_uint(A11);
+                wr[4 + 4 * level + 2] = __float_as_uint(A12);
+                wr[4 + 4 * level + 3] = __float_as_uint(A22);
+            }
+        }
+        if (weak) {
             if (level == 0) status = false;
             continue;
         }
@@ -827,7 +888,8 @@ __global__ __launch_bounds__(64) void k_lk_track(icg_pyr_desc P, int n, const in
 __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_desc P, int n, const int32_t *prev_slot,
                                                     const int32_t *next_slot, const float2 *prev_pts,
                                                     const float2 *guess_pts, float2 *out_pts, unsigned char *status,
-                                                    int has_cam, icg_camera cam, float2 *out_undist, int img_w, int img_h) {
+                                                    int has_cam, icg_camera cam, float2 *out_undist, int img_w, int img_h,
+                                                    const int32_t *reuse_idx, const unsigned int *cache_rd, unsigned int *cache_wr) {
     __shared__ lk_smem S;
     const int i = icg_xcd_chunked(blockIdx.x, n);
     if (i >= n) return;
@@ -838,6 +900,21 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_des
     float2 fwd      = guess_pts[i];
     float2 bwd      = p0;
     bool st_f = false, st_b = false;
+    // template set-up cache (see LKC_*): the block this point's backward pass fills for the next call, and the block of the point it
+    // continues — usable only if it was completed and was set up at exactly this point (the entry point already matched slot + generation)
+    unsigned int *wr       = nullptr;
+    const unsigned int *rd = nullptr;
+    if (cache_wr) {
+        wr = cache_wr + (size_t) i * LKC_DWORDS;
+        if (lane == 0) wr[2] = 0; // not complete (yet)
+    }
+    if (cache_rd && reuse_idx) {
+        const int j = reuse_idx[i];
+        if (j >= 0) {
+            const unsigned int *b = cache_rd + (size_t) j * LKC_DWORDS;
+            if (b[2] == 1u && b[0] == __float_as_uint(p0.x) && b[1] == __float_as_uint(p0.y)) rd = b;
+        }
+    }
     // forward then backward through ONE copy of the tracker body (16 KB of code instead of 32 KB in the shared I-cache)
     for (int dir = 0; dir < 2; dir++) {
         if (dir) {
@@ -849,10 +926,15 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_des
         const unsigned char *a = dir ? sN : sP, *b = dir ? sP : sN;
         const float2 from      = dir ? fwd : p0;
         float2 io              = dir ? bwd : fwd;
-        const bool st          = lk_track_wave(P, a, b, from, io, S, lane, nullptr);
+        const bool st          = lk_track_wave(P, a, b, from, io, S, lane, nullptr, dir ? nullptr : rd, dir ? wr : nullptr);
         if (dir) {
             bwd  = io;
             st_b = st;
+            if (wr && lane == 0) { // the backward template = next image at the forward result: what the next frame tracks FROM
+                wr[0] = __float_as_uint(fwd.x);
+                wr[1] = __float_as_uint(fwd.y);
+                wr[2] = 1u;
+            }
         } else {
             fwd  = io;
             st_f = st;
@@ -1023,12 +1105,90 @@ extern "C" int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, co
                                d_pp, d_gs, d_out, d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height);
         else
             hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp,
-                               d_gs, d_out, d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height);
+                               d_gs, d_out, d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height,
+                               (const int32_t *) nullptr, (const unsigned int *) nullptr, (unsigned int *) nullptr);
     }
     if (keep_idx) {
         icg_prof_scope ps(ctx, "keep_indices");
         hipLaunchKernelGGL(k_keep_indices, dim3(1), dim3(1024), 0, ctx->stream, n, d_st, d_keep, d_nkeep);
     }
     ICG_HIP(ctx, hipGetLastError());
+    ctx->lkc_last_n = 0; // a call without the set-up cache breaks the chain of icg_lk_track_fb_reuse calls
     return c.finish();
+}
+
+extern "C" int icg_lk_track_fb_reuse(icg_ctx *ctx, int n, const int32_t *prev_slot, const int32_t *next_slot, const float *prev_pts,
+                                     const float *guess_pts, const int32_t *prev_index, float *out_pts, uint8_t *status, float *out_undist) {
+    if (!ctx || n < 0) return ICG_ERR_INVALID;
+    if (n == 0) return ICG_OK;
+    if (!prev_slot || !next_slot || !prev_pts || !guess_pts || !out_pts || !status) return ICG_ERR_INVALID;
+    if (out_undist && !ctx->has_cam) return icg_fail(ctx, ICG_ERR_INVALID, "out_undist requested but camera not set");
+    if (n > ctx->cfg.max_points) return icg_fail(ctx, ICG_ERR_CAPACITY, "%d points > max_points %d", n, ctx->cfg.max_points);
+    int rc = check_slots(ctx, n, prev_slot, next_slot);
+    if (rc) return rc;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (ctx->n_levels > ICG_MAX_LK_LEVELS_CACHED) return icg_fail(ctx, ICG_ERR_INVALID, "set-up cache holds %d levels", ICG_MAX_LK_LEVELS_CACHED);
+    // two blocks per point slot of the context, alternating per call: this call reads what the previous call wrote
+    if ((size_t) n > ctx->lkc_cap) {
+        ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t cap = std::min<size_t>((size_t) ctx->cfg.max_points, std::max<size_t>(1024, (size_t) n + (size_t) n / 2));
+        for (int b = 0; b < 2; b++) {
+            if (ctx->d_lkc[b]) (void) hipFree(ctx->d_lkc[b]);
+            ctx->d_lkc[b] = nullptr;
+            ICG_HIP(ctx, hipMalloc((void **) &ctx->d_lkc[b], cap * LKC_DWORDS * sizeof(unsigned int)));
+            ctx->lkc_slot[b].assign(cap, -1);
+            ctx->lkc_gen[b].assign(cap, 0);
+        }
+        ctx->lkc_cap    = cap;
+        ctx->lkc_last_n = 0; // (the blocks are gone)
+    }
+    const int rdb = ctx->lkc_cur, wrb = rdb ^ 1;
+    icg_call c(ctx);
+    if ((rc = c.reserve((size_t) n * 112))) return rc;
+    const int32_t *d_ps = c.in_zc(prev_slot, (size_t) n);
+    const int32_t *d_ns = c.in_zc(next_slot, (size_t) n);
+    const float2 *d_pp  = (const float2 *) c.in_zc(prev_pts, 2 * (size_t) n);
+    const float2 *d_gs  = (const float2 *) c.in_zc(guess_pts, 2 * (size_t) n);
+    // the hint of point i is honoured when the block it names was written for the image this point is tracked FROM: same slot, and the
+    // slot has not been preprocessed again since (the kernel then compares the point's bit pattern and the block's completeness flag)
+    std::vector<int32_t> ri((size_t) n);
+    int hinted = 0;
+    if (ctx->slot_gen.size() != (size_t) ctx->cfg.n_slots) ctx->slot_gen.assign((size_t) ctx->cfg.n_slots, 0);
+    for (int i = 0; i < n; i++) {
+        int j = prev_index ? prev_index[i] : -1;
+        if (j < 0 || j >= ctx->lkc_last_n || ctx->lkc_slot[rdb][(size_t) j] != prev_slot[i] ||
+            ctx->lkc_gen[rdb][(size_t) j] != ctx->slot_gen[(size_t) prev_slot[i]])
+            j = -1;
+        hinted += j >= 0;
+        ri[(size_t) i] = j;
+    }
+    const int32_t *h_ri = c.in_zc(ri.data(), (size_t) n);
+    float2 *d_out       = (float2 *) c.out_zc(out_pts, 2 * (size_t) n);
+    unsigned char *d_st = c.out_zc(status, (size_t) n);
+    float2 *d_und       = out_undist ? (float2 *) c.out_zc(out_undist, 2 * (size_t) n) : nullptr;
+    ICG_LAUNCH_GUARD(c);
+    {
+        icg_prof_scope ps(ctx, "lk_track_fb");
+        hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp, d_gs,
+                           d_out, d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height, h_ri,
+                           (const unsigned int *) (hinted ? ctx->d_lkc[rdb] : nullptr), ctx->d_lkc[wrb]);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    // what the blocks just written belong to (the NEXT image of every point, at its generation)
+    for (int i = 0; i < n; i++) {
+        ctx->lkc_slot[wrb][(size_t) i] = next_slot[i];
+        ctx->lkc_gen[wrb][(size_t) i]  = ctx->slot_gen[(size_t) next_slot[i]];
+    }
+    ctx->lkc_cur         = wrb;
+    ctx->lkc_last_n      = n;
+    ctx->lkc_hits_hinted += (uint64_t) hinted;
+    ctx->lkc_points      += (uint64_t) n;
+    return c.finish();
+}
+
+extern "C" int icg_lk_reuse_stats(icg_ctx *ctx, uint64_t *out2) {
+    if (!ctx || !out2) return ICG_ERR_INVALID;
+    out2[0] = ctx->lkc_points;
+    out2[1] = ctx->lkc_hits_hinted;
+    return ICG_OK;
 }

@@ -177,13 +177,13 @@ void TableTracker::setKeyFrame(int h, int state) { // frame.cc:42-54
 }
 
 int TableTracker::addRow(int h, ulong id, uint32_t mp, const Point2f &kp, const Point2f &kpd, const Vector2d &vel, FeatureType type,
-                         double pcx, double pcy, bool unique_key) {
+                         double pcx, double pcy, bool unique_key, int32_t lk_idx) {
     Frame_ &f = frames_[(size_t) h];
     if (unique_key)
         f.order.insertUnique(id);
     else if (!f.order.insert(id))
         return -1; // std::unordered_map::insert of an existing key adds nothing (frame.h:71-74)
-    f.row.push_back(Row{id, mp, mps_.hot[mp].gen, kp, kpd, vel, pcx, pcy, (int8_t) type});
+    f.row.push_back(Row{id, mp, mps_.hot[mp].gen, kp, kpd, vel, pcx, pcy, lk_idx, (int8_t) type});
     return (int) f.row.size() - 1;
 }
 
@@ -412,6 +412,7 @@ bool TableTracker::doResetTracking() { // :317-329
         pts2d_new_undis_.clear();
         pts2d_ref_frame_.clear();
         velocity_ref_.clear();
+        cand_lk_idx_.clear();
         return true;
     }
     return false;
@@ -690,6 +691,7 @@ void TableTracker::integrateDetection(StageBatch &done) { // :659-685
         pts2d_new_undis_.clear();
         pts2d_ref_frame_.clear();
         velocity_ref_.clear();
+        cand_lk_idx_.clear();
     }
     const int max_per_job = maxFeaturesPerJob();
     const int n           = done.det_count[(size_t) det_job_];
@@ -706,6 +708,7 @@ void TableTracker::integrateDetection(StageBatch &done) { // :659-685
         pts2d_ref_frame_.push_back(det_frame_);
         velocity_ref_.emplace_back(0, 0);
     }
+    cand_lk_idx_.resize(pts2d_new_.size(), -1); // (a list that lost its alignment is padded / cut: hints are hints)
     det_job_   = -1;
     det_frame_ = -1;
 }
@@ -716,6 +719,7 @@ void TableTracker::queueTrackMappoint(StageBatch &next) {
     tm_pts2d_map_.clear();
     tm_pc_.clear();
     tm_pred_.clear();
+    tm_hint_.clear();
     const Frame_ &fp    = frames_[(size_t) pre_];
     const Pose pose_cur = frames_[(size_t) cur_].pose;
     for (int q = fp.order.head(); q >= 0; q = fp.order.next(q)) {
@@ -729,6 +733,7 @@ void TableTracker::queueTrackMappoint(StageBatch &next) {
         camera_->distortPoint(pp);                                    // :378
         tm_pred_.push_back(pp);
         mappoint_matched_.push_back({i, r.mpgen});
+        tm_hint_.push_back(r.lk_idx);
     }
     lk_map_begin_ = (int) next.lk_prev_slot.size();
     lk_map_n_     = (int) tm_pred_.size();
@@ -740,6 +745,9 @@ void TableTracker::queueTrackMappoint(StageBatch &next) {
     next.lk_guess.resize(2 * (at + (size_t) lk_map_n_));
     memcpy(next.lk_prev.data() + 2 * at, tm_pts2d_map_.data(), (size_t) lk_map_n_ * sizeof(Point2f));
     memcpy(next.lk_guess.data() + 2 * at, tm_pred_.data(), (size_t) lk_map_n_ * sizeof(Point2f));
+    // the distorted key point of a row IS the forward result of the LK point that produced it: its template can be reused
+    next.lk_prev_index.resize(at, -1);
+    next.lk_prev_index.insert(next.lk_prev_index.end(), tm_hint_.begin(), tm_hint_.end());
 }
 
 bool TableTracker::finishTrackMappoint(StageBatch &done) {
@@ -770,7 +778,8 @@ bool TableTracker::finishTrackMappoint(StageBatch &done) {
             const Vector3d pc = camera_->pixel2cam(undis[k]);
             // (pixel2cam(cur) - pixel2cam(pre)) / dt (:434); the ids of the previous frame's rows are distinct keys
             const Vector2d velocity((pc[0] - tm_pc_[2 * (size_t) k]) / dt, (pc[1] - tm_pc_[2 * (size_t) k + 1]) / dt);
-            const int row = addRow(cur_, mps_.hot[m.i].id, m.i, undis[k], out[k], velocity, FEATURE_MATCHED, pc[0], pc[1], true);
+            const int row = addRow(cur_, mps_.hot[m.i].id, m.i, undis[k], out[k], velocity, FEATURE_MATCHED, pc[0], pc[1], true,
+                                   done.lk_base + lk_map_begin_ + k);
             mps_.hot[m.i].observed++; // addObservation (mappoint.cc:58-62)
             mps_.hot[m.i].last = LastObs{cur_, fc.gen, row};
             tracked_mappoint_.push_back(m);
@@ -805,6 +814,11 @@ void TableTracker::queueTrackReference(StageBatch &next) {
     next.lk_guess.resize(2 * (at + (size_t) lk_ref_n_));
     memcpy(next.lk_prev.data() + 2 * at, pts2d_new_.data(), (size_t) lk_ref_n_ * sizeof(Point2f));
     memcpy(next.lk_guess.data() + 2 * at, pts2d_cur_.data(), (size_t) lk_ref_n_ * sizeof(Point2f));
+    next.lk_prev_index.resize(at, -1);
+    if (cand_lk_idx_.size() == pts2d_new_.size())
+        next.lk_prev_index.insert(next.lk_prev_index.end(), cand_lk_idx_.begin(), cand_lk_idx_.end());
+    else
+        next.lk_prev_index.resize(at + (size_t) lk_ref_n_, -1);
 }
 
 bool TableTracker::midTrackReference(StageBatch &done, StageBatch &next) {
@@ -816,6 +830,9 @@ bool TableTracker::midTrackReference(StageBatch &done, StageBatch &next) {
     scratch_a_.resize((size_t) n);
     memcpy((void *) pts2d_cur_.data(), done.lk_out.data() + 2 * (size_t) lk_ref_begin_, (size_t) n * sizeof(Point2f));
     memcpy((void *) scratch_a_.data(), done.lk_undist.data() + 2 * (size_t) lk_ref_begin_, (size_t) n * sizeof(Point2f));
+    cand_lk_idx_.resize((size_t) n);
+    for (int k = 0; k < n; k++) cand_lk_idx_[(size_t) k] = done.lk_base + lk_ref_begin_ + k; // pts2d_cur_[k] is this call's forward result k
+    reduceVector(cand_lk_idx_, status_);
     reduceVector(pts2d_ref_, status_); // :507-511
     reduceVector(pts2d_cur_, status_);
     reduceVector(pts2d_new_, status_);
@@ -863,6 +880,7 @@ bool TableTracker::finishTrackReference(StageBatch &done) {
         reduceVector(velocity_ref_, status_);
         reduceVector(pts2d_ref_undis_, status_);
         reduceVector(tr_cur_undis_, status_);
+        reduceVector(cand_lk_idx_, status_);
         rs_set_ = -1;
     }
     if (pts2d_cur_.empty()) return false; // :557-561
@@ -967,7 +985,8 @@ void TableTracker::finishTriangulation(StageBatch &done) {
         mps_.cold[i].depth     = ((depth < MapPoint::NEAREST_DEPTH) || (depth > MapPoint::FARTHEST_DEPTH)) ? MapPoint::DEFAULT_DEPTH : depth;
         mps_.hot[i].type      = (int8_t) MAPPOINT_TRIANGULATED;
         const Vector3d pcc = camera_->pixel2cam(tri_cur_undis_[k]), pcr = camera_->pixel2cam(tri_ref_undis_[k]);
-        addRow(cur_, mps_.hot[i].id, i, tri_cur_undis_[k], pts2d_cur_[k], velocity_cur_[k], FEATURE_TRIANGULATED, pcc[0], pcc[1], true); // :769-774
+        addRow(cur_, mps_.hot[i].id, i, tri_cur_undis_[k], pts2d_cur_[k], velocity_cur_[k], FEATURE_TRIANGULATED, pcc[0], pcc[1], true,
+               k < cand_lk_idx_.size() ? cand_lk_idx_[k] : -1); // :769-774
         mps_.hot[i].observed++;
         mps_.hot[i].used++;
         const int row = addRow(frame_ref, mps_.hot[i].id, i, tri_ref_undis_[k], pts2d_ref_[k], velocity_ref_[k], FEATURE_TRIANGULATED, pcr[0], pcr[1],
@@ -985,6 +1004,7 @@ void TableTracker::finishTriangulation(StageBatch &done) {
     reduceVector(velocity_ref_, tri_status_);
     reduceVector(pts2d_ref_undis_, tri_status_);
     reduceVector(tr_cur_undis_, tri_status_);
+    if (cand_lk_idx_.size() == tri_status_.size()) reduceVector(cand_lk_idx_, tri_status_);
     pts2d_new_       = pts2d_cur_;
     pts2d_new_undis_ = tr_cur_undis_;
 }

@@ -123,6 +123,7 @@ private:
         Point2f kp, kpd;   // undistorted / distorted key point
         Vector2d vel;      // velocity on the normalized plane
         double pcx, pcy;   // Camera::pixel2cam(kp), kept: the next frame's velocity and every parallax need it again
+        int32_t lk_idx;    // index of the LK point that produced this key point in the group's LK call of that frame (-1: not from LK)
         int8_t type;
     };
     struct Frame_ {
@@ -184,7 +185,7 @@ private:
     void sweepFrames();
     void setKeyFrame(int h, int state);
     int addRow(int h, ulong id, uint32_t mp, const Point2f &kp, const Point2f &kpd, const Vector2d &vel, FeatureType type, double pcx,
-               double pcy, bool unique_key);
+               double pcy, bool unique_key, int32_t lk_idx = -1);
     vector<ulong> observationFrames(uint32_t mp, const vector<int> &alive_by_fid) const;
     bool frameValid(int h, uint32_t g) const { return h >= 0 && frames_[(size_t) h].alive && frames_[(size_t) h].gen == g; }
 
@@ -257,6 +258,7 @@ private:
     // candidates (tracking.h:129-136)
     vector<Point2f> pts2d_cur_, pts2d_new_, pts2d_ref_, pts2d_ref_undis_, pts2d_new_undis_;
     vector<int> pts2d_ref_frame_;
+    vector<int32_t> cand_lk_idx_; // per candidate: index of the LK point that produced pts2d_new_[k] in the group's last LK call (-1: detected)
     vector<Vector2d> velocity_ref_, velocity_cur_;
     struct MpRef {
         uint32_t i, g;
@@ -288,6 +290,7 @@ private:
     int lk_map_begin_{0}, lk_map_n_{0}, lk_ref_begin_{0}, lk_ref_n_{0};
     vector<Point2f> tm_pts2d_map_, tm_pred_;
     vector<double> tm_pc_;
+    vector<int32_t> tm_hint_;
     bool ref_tracked_{false};
     int rs_set_{-1};
     vector<Point2f> tr_new_undis_, tr_cur_undis_;

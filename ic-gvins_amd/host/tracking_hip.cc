@@ -64,6 +64,7 @@ void StageBatch::clear() {
     lk_out.clear();
     lk_undist.clear();
     lk_status.clear();
+    lk_prev_index.clear();
     rs_off.assign(1, 0);
     rs_p1.clear();
     rs_p2.clear();
@@ -141,10 +142,17 @@ void DeviceContext::execute(StageBatch &b, const icg_detect_grid &grid, int max_
         b.lk_out.assign((size_t) n * 2, 0.f);
         b.lk_undist.assign((size_t) n * 2, 0.f);
         b.lk_status.assign((size_t) n, 0);
-        abi_check(ctx_,
-                  icg_lk_track_fb(ctx_, n, b.lk_prev_slot.data(), b.lk_next_slot.data(), b.lk_prev.data(), b.lk_guess.data(),
-                                  b.lk_out.data(), b.lk_status.data(), b.lk_undist.data(), nullptr, nullptr),
-                  "icg_lk_track_fb");
+        static const bool reuse = !(getenv("ICG_LK_REUSE") && getenv("ICG_LK_REUSE")[0] == '0'); // ICG_LK_REUSE=0: A/B measurements
+        if (reuse && (int) b.lk_prev_index.size() == n)
+            abi_check(ctx_,
+                      icg_lk_track_fb_reuse(ctx_, n, b.lk_prev_slot.data(), b.lk_next_slot.data(), b.lk_prev.data(), b.lk_guess.data(),
+                                            b.lk_prev_index.data(), b.lk_out.data(), b.lk_status.data(), b.lk_undist.data()),
+                      "icg_lk_track_fb_reuse");
+        else
+            abi_check(ctx_,
+                      icg_lk_track_fb(ctx_, n, b.lk_prev_slot.data(), b.lk_next_slot.data(), b.lk_prev.data(), b.lk_guess.data(),
+                                      b.lk_out.data(), b.lk_status.data(), b.lk_undist.data(), nullptr, nullptr),
+                      "icg_lk_track_fb");
     }
     if (b.rs_off.size() > 1) {
         hostprof::Scope hp(hostprof::DEV_RANSAC);
