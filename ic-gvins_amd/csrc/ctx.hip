@@ -149,6 +149,9 @@ extern "C" void icg_ctx_destroy(icg_ctx *ctx) {
         if (p) (void) hipFree(p);
     for (int b = 0; b < 2; b++)
         if (ctx->d_lkc[b]) (void) hipFree(ctx->d_lkc[b]);
+    if (ctx->d_redS) (void) hipFree(ctx->d_redS);
+    if (ctx->d_hostS) (void) hipFree(ctx->d_hostS);
+
     if (ctx->h_arena) (void) hipHostFree(ctx->h_arena);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -180,6 +183,9 @@ int icg_arena_reserve(icg_ctx *ctx, size_t bytes) {
     ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int b = 0; b < 2; b++)
         if (ctx->d_lkc[b]) (void) hipFree(ctx->d_lkc[b]);
+    if (ctx->d_redS) (void) hipFree(ctx->d_redS);
+    if (ctx->d_hostS) (void) hipFree(ctx->d_hostS);
+
     if (ctx->h_arena) (void) hipHostFree(ctx->h_arena);
     if (ctx->d_arena) (void) hipFree(ctx->d_arena);
     ctx->h_arena = nullptr;

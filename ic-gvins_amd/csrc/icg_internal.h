@@ -89,6 +89,12 @@ struct icg_ctx {
     int32_t *d_lmwin = nullptr;               // window of every landmark
     int lmwin_cap = 0, wsys_P = 0, wsys_valid = 0;
     std::vector<double> w_damp;               // damping that went into each window's inv
+    // f1, reduced systems solved on the device (icg_reproj_schur_windows_resident / _set_host_part_windows / _solve_backsub_windows):
+    double *d_redS = nullptr;  // W x P x P, lower tiles written by k_schur_reduce_w
+    size_t redS_cap = 0;       // doubles
+    double *d_hostS = nullptr; // W x P(P+1)/2: packed lower triangle of every window's host-factor contribution (zero until set)
+    size_t hostS_cap = 0;
+    int hostS_P = 0, hostS_W = 0;
 
 
     // LK template set-up cache (lk.hip, icg_lk_track_fb_reuse): two buffers of one block per point, alternating per call, and what

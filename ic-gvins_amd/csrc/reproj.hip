@@ -1157,10 +1157,11 @@ static void build_win_desc(icg_ctx *ctx, int P, const int32_t *vcol_ext, const i
 
 // S_view != nullptr: the reduced systems are written by the reduction kernel straight into the context's pinned staging memory (zero-copy)
 // and *S_view points there — no device-to-host copy and no 9 MB copy-out per LM step at 256 windows; valid until the next call on ctx
+// S and S_view both null: the reduced systems stay on the device (ctx->d_redS)
 static int schur_windows_impl(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
                               const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, double *S, const double **S_view,
                               double *s, double *diag_cc, double *cost) {
-    if (!ctx || P <= 0 || !col_pose || !col_ext || !col_td || !reassemble || !damp || (!S && !S_view) || !s) return ICG_ERR_INVALID;
+    if (!ctx || P <= 0 || !col_pose || !col_ext || !col_td || !reassemble || !damp || !s) return ICG_ERR_INVALID;
     const bool tdbg = getenv("ICG_ABI_DEBUG") != nullptr;
     auto tnow       = [] { return std::chrono::steady_clock::now(); };
     auto t_begin    = tnow();
@@ -1247,12 +1248,23 @@ static int schur_windows_impl(icg_ctx *ctx, int P, const int32_t *col_pose, cons
     if ((rc = c.seal())) return rc;
     // (the zero-copy region is allocated LAST: finish() copies ONE device range back that spans all mirrored outputs, and must not run
     // over memory the kernel wrote through the host mapping)
-    double *d_S  = S_view ? nullptr : c.out(S, (size_t) W * P * P);
+    const bool resident = !S && !S_view; // the reduced systems stay on the device (solved there: icg_reproj_solve_backsub_windows)
+    double *d_S  = (S_view || resident) ? nullptr : c.out(S, (size_t) W * P * P);
     double *d_s  = c.out(s, (size_t) W * P);
     double *d_dg = c.out(diag_cc, (size_t) W * P);
     if (S_view) {
         d_S     = c.out_zc((double *) nullptr, (size_t) W * P * P);
         *S_view = d_S;
+    }
+    if (resident) {
+        if ((size_t) W * P * P > ctx->redS_cap) {
+            ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_redS) (void) hipFree(ctx->d_redS);
+            ctx->d_redS = nullptr, ctx->redS_cap = 0;
+            ICG_HIP(ctx, hipMalloc((void **) &ctx->d_redS, sizeof(double) * (size_t) W * P * P));
+            ctx->redS_cap = (size_t) W * P * P;
+        }
+        d_S = ctx->d_redS;
     }
     const double *d_r = ctx->d_rJ, *d_J = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
     ICG_LAUNCH_GUARD(c);
@@ -1267,7 +1279,7 @@ static int schur_windows_impl(icg_ctx *ctx, int P, const int32_t *col_pose, cons
         icg_prof_scope ps(ctx, "schur_reduce");
         hipLaunchKernelGGL(k_schur_inv_w, dim3((Lmax + 255) / 256, W), dim3(256), 0, ctx->stream, d_wd, P, ctx->d_sys, min_diag, max_diag);
         hipLaunchKernelGGL(k_schur_reduce_w, dim3((P + SCH_T - 1) / SCH_T, (P + SCH_T - 1) / SCH_T, W), dim3(SCH_T, SCH_T), 0, ctx->stream, d_wd, P,
-                           (const double *) ctx->d_sys, d_S, d_s, d_dg, S_view ? 1 : 0);
+                           (const double *) ctx->d_sys, d_S, d_s, d_dg, (S_view || resident) ? 1 : 0);
         if (any_new) {
             // cost only of the windows that were re-assembled is meaningful; the others keep their previous value on the host side
             hipLaunchKernelGGL(k_reproj_cost_w, dim3(4, W), dim3(256), 0, ctx->stream, d_wd, d_r, d_act, ctx->last_huber, d_cost);
@@ -1313,13 +1325,183 @@ extern "C" int icg_reproj_reserve_windows(icg_ctx *ctx, int P) {
 extern "C" int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td,
                                         const uint8_t *active, const uint8_t *reassemble, const double *damp, double min_diag, double max_diag,
                                         double *S, double *s, double *diag_cc, double *cost) {
+    if (!S) return ICG_ERR_INVALID;
     return schur_windows_impl(ctx, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, S, nullptr, s, diag_cc, cost);
 }
 
 extern "C" int icg_reproj_schur_windows_view(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td,
                                              const uint8_t *active, const uint8_t *reassemble, const double *damp, double min_diag,
                                              double max_diag, const double **S_view, double *s, double *diag_cc, double *cost) {
+    if (!S_view) return ICG_ERR_INVALID;
     return schur_windows_impl(ctx, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, nullptr, S_view, s, diag_cc, cost);
+}
+
+extern "C" int icg_reproj_schur_windows_resident(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td,
+                                                 const uint8_t *active, const uint8_t *reassemble, const double *damp, double min_diag,
+                                                 double max_diag, double *s, double *diag_cc, double *cost) {
+    return schur_windows_impl(ctx, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, nullptr, nullptr, s, diag_cc, cost);
+}
+
+// ---- reduced systems solved on the device -------------------------------------------------------------------------------------------
+// packed lower triangle: row i of a P x P symmetric matrix occupies entries i(i+1)/2 .. i(i+1)/2 + i
+__global__ __launch_bounds__(256) void k_hostS_scatter(int tri, const int32_t *win_idx, const double *packed, double *hostS) {
+    const double *src = packed + (size_t) blockIdx.x * tri;
+    double *dst       = hostS + (size_t) win_idx[blockIdx.x] * tri;
+    for (int k = threadIdx.x; k < tri; k += 256) dst[k] = src[k];
+}
+
+// One workgroup per window: A = lower(S_w + hostS_w) + diag(dd_w) in LDS, right-looking Cholesky (the whole trailing update of a column
+// step spread over the 256 threads), forward substitution by wave 0 (a wave reduction per row), backward substitution as a column
+// sweep.  ok[w] = 0 when a pivot is not positive / finite (dense_kernels.cc choleskySolve returns false there: the caller re-damps).
+// Columns >= Pw[w] of a window are empty (zero rows): only the leading Pw x Pw block is factored, the rest of delta_c is zero.
+__global__ __launch_bounds__(256) void k_chol_solve_w(int P, const int32_t *Pw, const uint8_t *stepped, const double *S, const double *hostS,
+                                                      const double *rhs, const double *dd, double *delta_c, uint8_t *ok) {
+    extern __shared__ double sh[];
+    const int w = blockIdx.x, t = threadIdx.x, n = Pw[w];
+    double *A = sh;          // n x n, row stride n (lower triangle used)
+    double *b = sh + P * P;  // n
+    __shared__ int failed;
+    double *dcw = delta_c + (size_t) w * P;
+    for (int k = t; k < P; k += 256) dcw[k] = 0.0;
+    if (!stepped[w] || n <= 0) {
+        if (t == 0) ok[w] = 0;
+        return;
+    }
+    const double *Sw = S + (size_t) w * P * P, *Hw = hostS + (size_t) w * ((size_t) P * (P + 1) / 2);
+    for (int e = t; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        if (j <= i) A[i * n + j] = Sw[(size_t) i * P + j] + Hw[(size_t) i * (i + 1) / 2 + j] + (i == j ? dd[(size_t) w * P + i] : 0.0);
+    }
+    for (int k = t; k < n; k += 256) b[k] = rhs[(size_t) w * P + k];
+    if (t == 0) failed = 0;
+    __syncthreads();
+    for (int k = 0; k < n; k++) {
+        const double d = A[k * n + k];
+        if (!(d > 0.0) || !isfinite(d)) {
+            if (t == 0) failed = 1;
+            break; // uniform: every thread reads the same pivot
+        }
+        const double piv = sqrt(d);
+        __syncthreads(); // everybody has read the pivot before it is overwritten
+        for (int i = k + t; i < n; i += 256) A[i * n + k] = (i == k) ? piv : A[i * n + k] / piv;
+        __syncthreads();
+        // trailing update of the lower triangle: A[i][j] -= L[i][k] * L[j][k], k < j <= i < n
+        const int m = n - k - 1;
+        for (int e = t; e < m * m; e += 256) {
+            const int a = e / m, c = e - a * m;
+            if (c <= a) A[(k + 1 + a) * n + (k + 1 + c)] -= A[(k + 1 + a) * n + k] * A[(k + 1 + c) * n + k];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (failed) {
+        if (t == 0) ok[w] = 0;
+        return;
+    }
+    if (t < 64) { // wave 0: L y = b, then L^T x = y
+        for (int r = 0; r < n; r++) {
+            double acc = 0.0;
+            for (int k = t; k < r; k += 64) acc += A[r * n + k] * b[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (t == 0) b[r] = (b[r] - acc) / A[r * n + r];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int r = n - 1; r >= 0; r--) {
+            const double x = b[r] / A[r * n + r];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (t == 0) b[r] = x;
+            for (int k = t; k < r; k += 64) b[k] -= A[r * n + k] * x;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int k = t; k < n; k += 64) dcw[k] = b[k];
+        if (t == 0) ok[w] = 1;
+    }
+}
+
+// packed[k]: the lower triangle (P(P+1)/2 doubles, row by row) of the host factors' contribution to the reduced system of window
+// win_idx[k]; stays on the device until replaced (a re-damped step re-uses it)
+extern "C" int icg_reproj_set_host_part_windows(icg_ctx *ctx, int P, int n_upd, const int32_t *win_idx, const double *packed) {
+    if (!ctx || P <= 0 || n_upd < 0 || (n_upd > 0 && (!win_idx || !packed))) return ICG_ERR_INVALID;
+    const int W = ctx->n_windows;
+    if (W <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition: call icg_reproj_set_windows first");
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t tri = (size_t) P * (P + 1) / 2;
+    if (ctx->hostS_P != P || ctx->hostS_W != W || (size_t) W * tri > ctx->hostS_cap) {
+        ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if ((size_t) W * tri > ctx->hostS_cap) {
+            if (ctx->d_hostS) (void) hipFree(ctx->d_hostS);
+            ctx->d_hostS = nullptr, ctx->hostS_cap = 0;
+            ICG_HIP(ctx, hipMalloc((void **) &ctx->d_hostS, sizeof(double) * (size_t) W * tri));
+            ctx->hostS_cap = (size_t) W * tri;
+        }
+        ICG_HIP(ctx, hipMemsetAsync(ctx->d_hostS, 0, sizeof(double) * (size_t) W * tri, ctx->stream));
+        ctx->hostS_P = P, ctx->hostS_W = W;
+    }
+    if (n_upd == 0) return ICG_OK;
+    for (int k = 0; k < n_upd; k++)
+        if (win_idx[k] < 0 || win_idx[k] >= W) return icg_fail(ctx, ICG_ERR_INVALID, "window index out of range");
+    icg_call c(ctx);
+    int rc = c.reserve(sizeof(int32_t) * (size_t) n_upd + sizeof(double) * (size_t) n_upd * tri + 4096);
+    if (rc) return rc;
+    const int32_t *d_wi = c.in(win_idx, (size_t) n_upd);
+    const double *d_pk  = c.in(packed, (size_t) n_upd * tri);
+    if ((rc = c.seal())) return rc;
+    ICG_LAUNCH_GUARD(c);
+    {
+        icg_prof_scope ps(ctx, "schur_host_part");
+        hipLaunchKernelGGL(k_hostS_scatter, dim3(n_upd), dim3(256), 0, ctx->stream, (int) tri, d_wi, d_pk, ctx->d_hostS);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}
+
+// For every window with stepped[w] != 0: (S_w + hostS_w + diag(dd_w)) delta_c_w = rhs_w on the leading Pw[w] columns (batched Cholesky in
+// LDS, P <= 88), then the landmark back-substitution of icg_reproj_backsub_windows with those steps, in one call: per LM step only rhs, dd
+// go up and delta_c, ok, delta_l and the two model-decrease sums come back; the P x P systems never leave the device.
+extern "C" int icg_reproj_solve_backsub_windows(icg_ctx *ctx, int P, const int32_t *Pw, const uint8_t *stepped, const double *rhs,
+                                                const double *dd, double *delta_c, uint8_t *ok, double *delta_l, double *lm_terms) {
+    if (!ctx || P <= 0 || !Pw || !stepped || !rhs || !dd || !delta_c || !ok) return ICG_ERR_INVALID;
+    if (!ctx->wsys_valid || ctx->wsys_P != P || !ctx->d_redS)
+        return icg_fail(ctx, ICG_ERR_INVALID, "no resident reduced systems of size %d: call icg_reproj_schur_windows_resident first", P);
+    const int W = ctx->n_windows, n_lm = ctx->w_lm_off[(size_t) W];
+    const size_t lds = sizeof(double) * ((size_t) P * P + (size_t) P);
+    if (lds > 63 * 1024) return icg_fail(ctx, ICG_ERR_CAPACITY, "reduced system of %d columns does not fit the LDS tile of the batched Cholesky (<= 88)", P);
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    int rc = icg_reproj_set_host_part_windows(ctx, P, 0, nullptr, nullptr); // (allocates a zero host part if none was ever set)
+    if (rc) return rc;
+    std::vector<win_desc> wd;
+    build_win_desc(ctx, P, nullptr, nullptr, nullptr, nullptr, nullptr, wd);
+    icg_call c(ctx);
+    rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(int32_t) * (size_t) W + 2 * (size_t) W + sizeof(double) * (3 * (size_t) W * P + (size_t) n_lm + 2 * (size_t) W) + 8192);
+    if (rc) return rc;
+    const win_desc *d_wd = c.in(wd.data(), (size_t) W);
+    const int32_t *d_pw  = c.in(Pw, (size_t) W);
+    const uint8_t *d_st  = c.in(stepped, (size_t) W);
+    const double *d_rhs  = c.in(rhs, (size_t) W * P);
+    const double *d_dd   = c.in(dd, (size_t) W * P);
+    std::vector<double> zeros(2 * (size_t) W, 0.0);
+    double *d_tm = c.inout(zeros.data(), lm_terms, 2 * (size_t) W);
+    if ((rc = c.seal())) return rc;
+    double *d_dl   = n_lm > 0 && delta_l ? c.out(delta_l, (size_t) n_lm) : nullptr;
+    double *d_dco  = c.out(delta_c, (size_t) W * P);
+    uint8_t *d_ok  = c.out(ok, (size_t) W);
+    ICG_LAUNCH_GUARD(c);
+    {
+        icg_prof_scope ps(ctx, "schur_cholesky");
+        hipLaunchKernelGGL(k_chol_solve_w, dim3(W), dim3(256), lds, ctx->stream, P, d_pw, d_st, (const double *) ctx->d_redS, (const double *) ctx->d_hostS,
+                           d_rhs, d_dd, d_dco, d_ok);
+    }
+    if (d_dl) {
+        icg_prof_scope ps(ctx, "schur_backsub");
+        hipLaunchKernelGGL(k_schur_backsub_w, dim3(n_lm), dim3(64), 0, ctx->stream, d_wd, (const int32_t *) ctx->d_lmwin, P, (const double *) ctx->d_sys,
+                           (const double *) d_dco, d_dl, d_tm, ctx->sys_min_diag, ctx->sys_max_diag);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
 }
 
 extern "C" int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {

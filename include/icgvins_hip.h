@@ -239,6 +239,20 @@ int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const
 int icg_reproj_schur_windows_view(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
                                   const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, const double **S_view, double *s,
                                   double *diag_cc, double *cost);
+/* The reduced camera systems of icg_reproj_schur_windows solved ON THE DEVICE (what Ceres' DENSE_SCHUR does per LM iteration on the host:
+ * ic_gvins.cc:1143-1146, 1183, 1217): icg_reproj_schur_windows_resident leaves the W lower-triangular P x P systems in device memory (s,
+ * diag_cc and cost come back as before); icg_reproj_set_host_part_windows uploads, for the listed windows, the packed lower triangle
+ * (P(P+1)/2 doubles, row by row) of what the HOST-evaluated factors (preintegration, marginalization prior, priors) add to the system — it
+ * stays until replaced, a re-damped step re-uses it; icg_reproj_solve_backsub_windows factors (S_w + host_w + diag(dd_w)) by a batched
+ * Cholesky (one workgroup per window, LDS, P <= 88) for every window with stepped[w] != 0, solves for delta_c (leading Pw[w] columns,
+ * rhs = the window's full gradient), sets ok[w] = 0 where a pivot is not positive (the caller re-damps, as it does when its own
+ * factorization fails), and runs the landmark back-substitution of icg_reproj_backsub_windows with those steps in the same call. */
+int icg_reproj_schur_windows_resident(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td,
+                                      const uint8_t *active, const uint8_t *reassemble, const double *damp, double min_diag, double max_diag,
+                                      double *s, double *diag_cc, double *cost);
+int icg_reproj_set_host_part_windows(icg_ctx *ctx, int P, int n_upd, const int32_t *win_idx, const double *packed);
+int icg_reproj_solve_backsub_windows(icg_ctx *ctx, int P, const int32_t *Pw, const uint8_t *stepped, const double *rhs, const double *dd,
+                                     double *delta_c, uint8_t *ok, double *delta_l, double *lm_terms);
 /* problem setup: pre-sizes the resident window systems and the staging memory for reduced systems of size P (a hint; optional) */
 int icg_reproj_reserve_windows(icg_ctx *ctx, int P);
 int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms);

@@ -5,6 +5,7 @@
 // Used by tests/ for end-to-end parity (HIP-backed vs oracle-backed streams must produce identical track ids,
 // states and digests) and by bench.py's cpu_baseline leg (kind "port").  It is never linked into, loaded by or
 // shipped with the product libraries (libicgvins_hip.so / libicgvins_host.so).
+#include <cmath>
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -271,6 +272,8 @@ struct shim_backend {
     std::vector<int32_t> fac_off, lm_off;
     std::vector<std::vector<double>> wH, wb, winv;
     std::vector<double> S_view; // icg_reproj_schur_windows_view: the reduced systems stay here until the next call
+    std::vector<double> redS, hostS; // icg_reproj_schur_windows_resident / _set_host_part_windows: resident systems, packed host parts
+    int hostS_P = 0;
     std::vector<double> wdamp;
     int wP = 0;
 };
@@ -460,6 +463,76 @@ int icg_reproj_schur_windows_view(icg_ctx *ctx, int P, const int32_t *col_pose, 
 }
 
 int icg_reproj_reserve_windows(icg_ctx *, int P) { return P > 0 ? ICG_OK : ICG_ERR_INVALID; } // nothing to pre-size on the CPU
+
+// CPU statement of the device-side reduced solve (same interface: the checker build of the host layer drives the same code path)
+int icg_reproj_schur_windows_resident(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
+                                      const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, double *s, double *diag_cc,
+                                      double *cost) {
+    shim_backend &B = g_backend[ctx];
+    B.redS.assign((size_t) std::max(0, B.W) * P * P, 0.0);
+    return icg_reproj_schur_windows(ctx, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, B.redS.data(), s, diag_cc, cost);
+}
+
+int icg_reproj_set_host_part_windows(icg_ctx *ctx, int P, int n_upd, const int32_t *win_idx, const double *packed) {
+    shim_backend &B = g_backend[ctx];
+    if (B.W <= 0 || P <= 0) return ICG_ERR_INVALID;
+    const size_t tri = (size_t) P * (P + 1) / 2;
+    if (B.hostS_P != P || B.hostS.size() != (size_t) B.W * tri) B.hostS.assign((size_t) B.W * tri, 0.0), B.hostS_P = P;
+    for (int k = 0; k < n_upd; k++) {
+        if (win_idx[k] < 0 || win_idx[k] >= B.W) return ICG_ERR_INVALID;
+        memcpy(&B.hostS[(size_t) win_idx[k] * tri], packed + (size_t) k * tri, sizeof(double) * tri);
+    }
+    return ICG_OK;
+}
+
+int icg_reproj_solve_backsub_windows(icg_ctx *ctx, int P, const int32_t *Pw, const uint8_t *stepped, const double *rhs, const double *dd,
+                                     double *delta_c, uint8_t *ok, double *delta_l, double *lm_terms) {
+    shim_backend &B = g_backend[ctx];
+    if (B.W <= 0 || B.wP != P || B.redS.size() != (size_t) B.W * P * P) return ICG_ERR_INVALID;
+    int rc = icg_reproj_set_host_part_windows(ctx, P, 0, nullptr, nullptr);
+    if (rc) return rc;
+    const size_t tri = (size_t) P * (P + 1) / 2;
+    for (int w = 0; w < B.W; w++) {
+        double *dc = delta_c + (size_t) w * P;
+        std::fill(dc, dc + P, 0.0);
+        ok[w]       = 0;
+        const int n = Pw[w];
+        if (!stepped[w] || n <= 0) continue;
+        std::vector<double> A((size_t) n * n, 0.0), b(rhs + (size_t) w * P, rhs + (size_t) w * P + n);
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j <= i; j++)
+                A[(size_t) i * n + j] = B.redS[(size_t) w * P * P + (size_t) i * P + j] + B.hostS[(size_t) w * tri + (size_t) i * (i + 1) / 2 + j] +
+                                        (i == j ? dd[(size_t) w * P + i] : 0.0);
+        bool good = true; // right-looking Cholesky, the order of the device kernel
+        for (int k = 0; k < n && good; k++) {
+            const double d = A[(size_t) k * n + k];
+            if (!(d > 0.0) || !std::isfinite(d)) {
+                good = false;
+                break;
+            }
+            const double piv = std::sqrt(d);
+            A[(size_t) k * n + k] = piv;
+            for (int i = k + 1; i < n; i++) A[(size_t) i * n + k] /= piv;
+            for (int i = k + 1; i < n; i++)
+                for (int j = k + 1; j <= i; j++) A[(size_t) i * n + j] -= A[(size_t) i * n + k] * A[(size_t) j * n + k];
+        }
+        if (!good) continue;
+        for (int r = 0; r < n; r++) {
+            double acc = 0.0;
+            for (int k = 0; k < r; k++) acc += A[(size_t) r * n + k] * b[(size_t) k];
+            b[(size_t) r] = (b[(size_t) r] - acc) / A[(size_t) r * n + r];
+        }
+        for (int r = n - 1; r >= 0; r--) {
+            const double x = b[(size_t) r] / A[(size_t) r * n + r];
+            b[(size_t) r]  = x;
+            for (int k = 0; k < r; k++) b[(size_t) k] -= A[(size_t) r * n + k] * x;
+        }
+        std::copy(b.begin(), b.end(), dc);
+        ok[w] = 1;
+    }
+    if (delta_l) return icg_reproj_backsub_windows(ctx, P, delta_c, delta_l, lm_terms);
+    return ICG_OK;
+}
 
 int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
     shim_backend &B = g_backend[ctx];

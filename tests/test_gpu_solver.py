@@ -84,3 +84,19 @@ def test_window_solver_batch_equals_single_solvers_on_gpu():
         assert np.array_equal(res[k]["summary"][3:], h["summary"][3:]), (k, res[k]["summary"], h["summary"])
         for key in ("poses", "ext", "invdepth"):
             assert np.abs(res[k][key] - h[key]).max() < 1e-7, (k, key)
+
+
+def test_window_solver_batch_device_side_reduced_solve_on_gpu(monkeypatch):
+    """the batched Cholesky of k_chol_solve_w (ICG_SOLVER_DEVICE_CHOLESKY=1) against the default path (host factorization): same accepted /
+    rejected steps and removals, optima within 1e-7"""
+    import harness as H
+    from test_host_solver_cpu import _batch_problems
+    lib = C.CDLL(H.HOST_LIB)
+    probs = _batch_problems()
+    ref, _ = su.host_solve_batch(lib, probs)
+    monkeypatch.setenv("ICG_SOLVER_DEVICE_CHOLESKY", "1")
+    dev, _ = su.host_solve_batch(lib, probs)
+    for k in range(len(probs)):
+        assert np.array_equal(dev[k]["summary"][3:], ref[k]["summary"][3:]), (k, dev[k]["summary"], ref[k]["summary"])
+        for key in ("poses", "ext", "invdepth"):
+            assert np.abs(dev[k][key] - ref[k][key]).max() < 1e-7, (k, key)

@@ -97,6 +97,22 @@ def test_window_solver_batch_equals_single_solvers(host_lib):
     assert (True, False) in kinds or (True, True) in kinds  # at least one window had a rejected step
 
 
+def test_window_solver_batch_device_side_reduced_solve(host_lib, monkeypatch):
+    """ICG_SOLVER_DEVICE_CHOLESKY=1 (icg_reproj_schur_windows_resident / _set_host_part_windows / _solve_backsub_windows: the reduced systems
+    stay behind the ABI, the host factors' part goes up as packed lower triangles, a batched Cholesky solves them): the same step sequences,
+    removals and optima as the default path (reduced systems factored by the host)"""
+    lib = C.CDLL(host_lib)
+    probs = _batch_problems()
+    ref, _ = su.host_solve_batch(lib, probs)
+    monkeypatch.setenv("ICG_SOLVER_DEVICE_CHOLESKY", "1")
+    dev, _ = su.host_solve_batch(lib, probs)
+    for k in range(len(probs)):
+        assert np.array_equal(dev[k]["summary"][3:], ref[k]["summary"][3:]), (k, dev[k]["summary"], ref[k]["summary"])
+        assert np.abs(dev[k]["summary"][:3] - ref[k]["summary"][:3]).max() < 1e-8 * max(1.0, ref[k]["summary"][0])
+        for key in ("poses", "ext", "invdepth"):
+            assert np.abs(dev[k][key] - ref[k][key]).max() < 1e-8, (k, key)
+
+
 def test_window_solver_matches_reference_factors_with_independent_lm(host_lib):
     """icg::WindowSolver (landmark elimination + LM of the product, here on the CPU shim) against tests/golden/solve_ref_golden.npz: the same
     three windows solved with the REFERENCE's own factor code and an independently written LM (oracle/ref_build/shim/ceres/problem_shim.h;
