@@ -144,7 +144,7 @@ void DeviceContext::execute(StageBatch &b, const icg_detect_grid &grid, int max_
         b.lk_status.assign((size_t) n, 0);
         // ICG_LK_REUSE=1: icg_lk_track_fb_reuse with the track table's hints.  Off by default: the template set-up cache cuts the isolated LK
         // launch by 15.7 % but the frame rate does not move (the front-end is bound by the latencies of its small launches, DESIGN.md
-        // section 4), while the set-up blocks double the HBM traffic per frame (10.3 -> 19.8 MB): profiles/r03_lk_setup_reuse.md
+        // section 4), while the set-up blocks double the HBM traffic per frame (11.0 -> 19.8 MB): profiles/r03_lk_setup_reuse.md
         static const bool reuse = getenv("ICG_LK_REUSE") && getenv("ICG_LK_REUSE")[0] == '1';
         if (reuse && (int) b.lk_prev_index.size() == n)
             abi_check(ctx_,
