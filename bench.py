@@ -257,14 +257,16 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
     if warmup > 0:
         run_prepared(warmup, prep_warm)
         k += warmup
-    barrier()
+    # bookkeeping that needs the streams at rest is done BEFORE the barrier: between the barrier and t0 the GPU must not sit idle for
+    # milliseconds (768 ctypes calls, log resets) — the first timed steps then run on a device that has clocked down
     sb.timing(reset=True)
     sb.step_log(reset=True)
-    t_region0 = sb.now()
     if hostprof:
         _hp = np.zeros(64, np.float64)
         sb.lib.icgh_hostprof(_hp.ctypes.data_as(C.c_void_p), 32, None, 0, 1)
     tracked_before = sum(sb.stats(s)["tracked_sum"] for s in range(B))
+    barrier()
+    t_region0 = sb.now()
     c0 = time.process_time()
     t0 = time.perf_counter()
     st = run_prepared(steps, prep)  # EXACTLY `steps` lock-step frames for every stream
