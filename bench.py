@@ -550,6 +550,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     w, h, nfeat = args.width, args.height, args.features
+    if world > 1:
+        # every rank renders its own streams on its share of the host cores: half the ring keeps the set-up of an 8-rank run on a 16-core
+        # box at about two minutes (the replay ping-pongs over the ring, so its length does not change what a step computes)
+        args.ring = min(args.ring, 16)
     ncpu = os.cpu_count() or 1
     host_threads = max(1, args.host_threads)
     # host resources of this rank: its share of the usable cores sizes the number of polling group threads, and with several ranks on
