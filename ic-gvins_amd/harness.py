@@ -100,8 +100,9 @@ class StreamBatch:
 
     def __init__(self, lib_path, n_streams, width, height, cam10, max_features=300, window=10, min_parallax=20.0,
                  max_interval=0.5, check_hist=False, reproj_std=1.5, device=0, host_threads=1, groups=1, engine=None):
-        """engine: None (ICG_TRACK_ENGINE or the default, the track table), "table" or "object" (the reference-shaped object graph:
-        needed by the entry points that work on the tracker's icg::Map — culling, window refinement, landmark tables)."""
+        """engine: None (ICG_TRACK_ENGINE or the default, the track table), "table" or "object" (the reference-shaped object graph
+        throughout; on the table engine the entry points that work on the tracker's icg::Map — culling, window refinement, landmark
+        tables — get an object view of the table and write their results back)."""
         if not os.path.exists(lib_path):
             raise RuntimeError(f"{lib_path} not found (build first; there is no fallback)")
         self.lib = C.CDLL(lib_path)

@@ -563,15 +563,15 @@ int icgh_batch_landmark_table(icgh_batch *b, int stream, int max_lm, int max_obs
                               uint64_t *lm_ref_frame, int32_t *lm_obs_off, uint64_t *obs_frame, int32_t *obs_flags, double *obs_pose12,
                               float *obs_pix) {
     if (!b || stream < 0 || stream >= b->tb->size()) return -1;
-    auto &S = b->tb->stream(stream);
-    if (!S.map) return -4; // needs the object engine (ICG_TRACK_ENGINE=object)
+    auto &S       = b->tb->stream(stream);
+    Map::Ptr Smap = S.objectMap(); // (track-table engine: a view of the table as reference-shaped objects; read-only use here)
     vector<ulong> ids;
-    for (auto &kv : S.map->landmarks()) ids.push_back(kv.first);
+    for (auto &kv : Smap->landmarks()) ids.push_back(kv.first);
     std::sort(ids.begin(), ids.end());
     if ((int) ids.size() > max_lm) return -2;
     int no = 0;
     for (size_t k = 0; k < ids.size(); k++) {
-        auto mp      = S.map->landmarks().at(ids[k]);
+        auto mp      = Smap->landmarks().at(ids[k]);
         lm_id[k]     = ids[k];
         Vector3d pos = mp->pos();
         for (int c = 0; c < 3; c++) lm_pos[3 * k + c] = pos[c];
@@ -594,7 +594,7 @@ int icgh_batch_landmark_table(icgh_batch *b, int stream, int max_lm, int max_obs
                 if (frame) {
                     obs_frame[no] = frame->id();
                     if (frame->isKeyFrame()) fl |= 4;
-                    if (frame->isKeyFrame() && S.map->isKeyFrameInMap(frame)) fl |= 8;
+                    if (frame->isKeyFrame() && Smap->isKeyFrameInMap(frame)) fl |= 8;
                     Pose p = frame->pose();
                     poseToArray12(p, obs_pose12 + 12 * (size_t) no);
                 }
@@ -610,14 +610,18 @@ int icgh_batch_landmark_table(icgh_batch *b, int stream, int max_lm, int max_obs
 // moves landmarks (by id) to new positions: stands in for the optimizer's write-back (ic_gvins.cc:1299-1357) in the tests
 int icgh_batch_set_landmark_pos(icgh_batch *b, int stream, int n, const uint64_t *ids, const double *pos3) {
     if (!b || stream < 0 || stream >= b->tb->size()) return -1;
-    auto &S = b->tb->stream(stream);
-    if (!S.map) return -4; // needs the object engine (ICG_TRACK_ENGINE=object)
-    for (int k = 0; k < n; k++) {
-        auto it = S.map->landmarks().find(ids[k]);
-        if (it == S.map->landmarks().end()) return -2;
-        it->second->setPos(Vector3d(pos3[3 * k], pos3[3 * k + 1], pos3[3 * k + 2]));
+    auto &S       = b->tb->stream(stream);
+    Map::Ptr Smap = S.objectMap();
+    int rc        = 0;
+    for (int k = 0; k < n && rc == 0; k++) {
+        auto it = Smap->landmarks().find(ids[k]);
+        if (it == Smap->landmarks().end())
+            rc = -2;
+        else
+            it->second->setPos(Vector3d(pos3[3 * k], pos3[3 * k + 1], pos3[3 * k + 2]));
     }
-    return 0;
+    S.commitMap(); // (track-table engine: the new positions go into the table)
+    return rc;
 }
 
 // WindowCulling over ALL streams of the batch with one device launch.  in_list: per stream the landmark ids that "took part in
@@ -627,12 +631,11 @@ int icgh_batch_culling(icgh_batch *b, int mode, const int32_t *list_off, const u
                        double *stats5, char *err, int errlen) {
     try {
         const int n = b->tb->size();
-        if (!b->tb->stream(0).map) throw std::runtime_error("culling over the tracker's map needs the object engine (ICG_TRACK_ENGINE=object)");
         vector<std::unordered_map<ulong, double>> lists((size_t) n);
         vector<WindowCulling::Stream> streams;
         for (int s = 0; s < n; s++) {
             for (int k = list_off[s]; k < list_off[s + 1]; k++) lists[(size_t) s][in_list[k]] = 0.0;
-            streams.push_back({b->tb->stream(s).map, &lists[(size_t) s]});
+            streams.push_back({b->tb->stream(s).objectMap(), &lists[(size_t) s]});
         }
         icg_ctx *ctx = b->tb->group(0).device()->ctx();
         std::string e;
@@ -659,6 +662,7 @@ int icgh_batch_culling(icgh_batch *b, int mode, const int32_t *list_off, const u
                 memcpy(stats5 + 5 * s, v, sizeof v);
             }
         }
+        for (int s = 0; s < n; s++) b->tb->stream(s).commitMap(); // (track-table engine: flags, counters and removals go into the table)
         return 0;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());
@@ -675,7 +679,6 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
                               int iters2, double chi2, double *out7, int max_kf, double *kf_out, char *err, int errlen) {
     try {
         const int n = b->tb->size();
-        if (!b->tb->stream(0).map) throw std::runtime_error("window refinement on the tracker's map needs the object engine (ICG_TRACK_ENGINE=object)");
         Pose pbc;
         pbc = poseFromArray12(pose_b_c12);
         icg_ctx *ctx = b->tb->group(0).device()->ctx();
@@ -688,7 +691,7 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
             auto &S = b->tb->stream(s);
             double *o = out7 + 7 * (size_t) s;
             for (int k = 0; k < 7; k++) o[k] = 0;
-            wins.emplace_back(new VisualWindow(S.camera, S.map, pbc, td, reprojection_error_std));
+            wins.emplace_back(new VisualWindow(S.camera, S.objectMap(), pbc, td, reprojection_error_std));
             VisualWindow &win = *wins.back();
             win.build();
             o[0] = win.numKeyFrames(), o[1] = win.numFactors();
@@ -755,7 +758,7 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
         for (int s = 0; s < n; s++) {
             if (wins[(size_t) s]->numKeyFrames() < 2 || wins[(size_t) s]->numFactors() == 0) continue;
             wins[(size_t) s]->updateParametersFromOptimizer();
-            cull.push_back({b->tb->stream(s).map, &wins[(size_t) s]->invdepthlist()});
+            cull.push_back({b->tb->stream(s).objectMap(), &wins[(size_t) s]->invdepthlist()});
             cull_stream.push_back(s);
         }
         vector<CullingResult> R;
@@ -776,6 +779,7 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
                     Pose p = wins[(size_t) s]->frame(k)->pose();
                     poseToArray12(p, r + 2);
                 }
+        for (int s = 0; s < n; s++) b->tb->stream(s).commitMap(); // (track-table engine: the write-back and the culling go into the table)
         return 0;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());

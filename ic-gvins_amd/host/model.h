@@ -526,14 +526,18 @@ public:
         ModelLock lock(map_mutex_);
         return keyframes_.size() == window_size_;
     }
-    // materialization hook (TableTracker::materialize): keyframes under their keys and landmarks (inserted in the order given)
-    void restore(const vector<std::pair<ulong, Frame::Ptr>> &keyframes, const vector<MapPoint::Ptr> &landmarks, const Frame::Ptr &latest,
-                 bool is_window_full) {
+    // materialization hook (TableTracker::view): keyframes under their keys, and the landmarks so that landmarks_ ITERATES in the order
+    // given with `buckets` buckets.  libstdc++ puts a new node at the front of its bucket, or at the front of the whole list when the
+    // bucket is empty, and keeps the nodes of one bucket adjacent; inserting back to front into a table that does not rehash on the way
+    // therefore rebuilds any order an insert / erase history left behind.
+    void restore(const vector<std::pair<ulong, Frame::Ptr>> &keyframes, const vector<MapPoint::Ptr> &landmarks, size_t buckets,
+                 const Frame::Ptr &latest, bool is_window_full) {
         ModelLock lock(map_mutex_);
         keyframes_.clear();
-        landmarks_.clear();
+        landmarks_ = LandMarks();
         for (const auto &k : keyframes) keyframes_[k.first] = k.second;
-        for (const auto &m : landmarks) landmarks_[m->id()] = m;
+        if (buckets > 1) landmarks_.rehash(buckets);
+        for (size_t k = landmarks.size(); k-- > 0;) landmarks_.insert(std::make_pair(landmarks[k]->id(), landmarks[k]));
         latest_keyframe_ = latest;
         is_window_full_  = is_window_full;
     }

@@ -183,7 +183,7 @@ int TableTracker::addRow(int h, ulong id, uint32_t mp, const Point2f &kp, const 
         f.order.insertUnique(id);
     else if (!f.order.insert(id))
         return -1; // std::unordered_map::insert of an existing key adds nothing (frame.h:71-74)
-    f.row.push_back(Row{id, mp, mps_.hot[mp].gen, kp, kpd, vel, pcx, pcy, lk_idx, (int8_t) type});
+    f.row.push_back(Row{id, mp, mps_.hot[mp].gen, kp, kpd, vel, pcx, pcy, lk_idx, (int8_t) type, 0});
     return (int) f.row.size() - 1;
 }
 
@@ -209,6 +209,7 @@ void TableTracker::mapInsertKeyFrame(int h) { // map.cc:27-61
         if (!mps_.valid(i, f.unupdated_gen[k])) continue;
         if (!mps_.hot[i].in_map) {
             mps_.hot[i].in_map = 1;
+            map_lm_.insert(std::make_pair(mps_.hot[i].id, i)); // map.cc:56-61
             n_landmarks_++;
         }
     }
@@ -225,6 +226,7 @@ void TableTracker::mapRemoveKeyFrame(int h, bool isremovemappoint) { // map.cc:8
                 // removeAllObservations + setOutlier + landmarks_.erase: nothing can reach it any more
                 mps_.hot[i].in_map  = 0;
                 mps_.hot[i].outlier = 1;
+                map_lm_.erase(mps_.hot[i].id);
                 n_landmarks_--;
                 mps_.release(i);
             }
@@ -352,6 +354,7 @@ int TableTracker::parallaxFromReferenceMapPoints(double &parallax) { // :873-905
         const LastObs &lo = mps_.hot[i].last;                           // observations().back().lock()
         if (lo.frame != cur_ || lo.gen != fc.gen) continue;             // feat && feat->getFrame() == frame_cur_
         const Row &r1 = fc.row[(size_t) lo.row];
+        if (r1.outlier) continue; // feat && !feat->isOutlier() (:884)
         // keyPointParallax (:861-871) on the rows' stored pixel2cam values
         const double x = R10(0, 0) * r0.pcx + R10(0, 1) * r0.pcy + R10(0, 2) * 1.0, y = R10(1, 0) * r0.pcx + R10(1, 1) * r0.pcy + R10(1, 2) * 1.0;
         parallax += Vector2d(x - r1.pcx, y - r1.pcy).norm() * focal;
@@ -1080,6 +1083,9 @@ std::string TableTracker::dump() const {
         for (ulong o : observationFrames(i, alive)) d.f("%lu,", o);
         d.f("\n");
     }
+    d.f("O buckets=%zu order=", map_lm_.bucket_count());
+    for (const auto &kv : map_lm_) d.f("%lu,", kv.first);
+    d.f("\n");
     return d.s;
 }
 
@@ -1152,6 +1158,9 @@ static void dumpMapObjects(Dump &d, Map &map, const vector<Frame::Ptr> &roots) {
         }
         d.f("\n");
     }
+    d.f("O buckets=%zu order=", map.landmarks().bucket_count());
+    for (const auto &kv : map.landmarks()) d.f("%lu,", kv.first);
+    d.f("\n");
 }
 
 std::string TableTracker::dumpObjects(Tracking &t, Map &map) {
@@ -1183,26 +1192,36 @@ std::string TableTracker::dumpMap() const {
     return all.substr(all.find("M window="));
 }
 
-Map::Ptr TableTracker::materialize(vector<Frame::Ptr> *extra) const {
+std::shared_ptr<TableTracker::ObjectView> TableTracker::view() const {
+    auto V   = std::make_shared<ObjectView>();
     auto map = std::make_shared<Map>(window_size_);
+    V->map   = map;
     vector<int> alive;
     for (size_t h = 0; h < frames_.size(); h++)
         if (frames_[h].alive && (int) h != pending_) alive.push_back((int) h);
     std::sort(alive.begin(), alive.end(), [&](int a, int b) { return frames_[(size_t) a].fid < frames_[(size_t) b].fid; });
-    vector<Frame::Ptr> obj(frames_.size());
-    vector<vector<Feature::Ptr>> feat(frames_.size());
+    vector<Frame::Ptr> &obj             = V->frame;
+    vector<vector<Feature::Ptr>> &feat = V->feat;
+    obj.assign(frames_.size(), nullptr);
+    feat.assign(frames_.size(), {});
+    V->frame_gen.assign(frames_.size(), 0);
     for (int h : alive) {
         const Frame_ &f = frames_[(size_t) h];
         auto fr         = std::make_shared<Frame>(f.fid, f.stamp, f.image, ids_);
         fr->setPose(f.pose);
         fr->restoreKeyFrame(f.is_kf, f.kf_id, f.kf_state);
         fr->setDeviceSlot(f.slot);
-        obj[(size_t) h] = fr;
+        obj[(size_t) h]          = fr;
+        V->frame_gen[(size_t) h] = f.gen;
         feat[(size_t) h].resize(f.rows());
-        for (size_t r = 0; r < f.rows(); r++) // insertion order: the container of the object reproduces the iteration order
+        for (size_t r = 0; r < f.rows(); r++) { // insertion order: the container of the object reproduces the iteration order
             feat[(size_t) h][r] = Feature::createFeature(fr, f.row[r].vel, f.row[r].kp, f.row[r].kpd, (FeatureType) f.row[r].type);
+            feat[(size_t) h][r]->setOutlier(f.row[r].outlier != 0);
+        }
     }
-    vector<MapPoint::Ptr> mpo(mps_.size());
+    vector<MapPoint::Ptr> &mpo = V->mappoint;
+    mpo.assign(mps_.size(), nullptr);
+    V->mp_gen.assign(mps_.size(), 0);
     vector<uint32_t> lms;
     for (uint32_t i = 0; i < mps_.size(); i++)
         if (mps_.hot[i].live) lms.push_back(i);
@@ -1211,7 +1230,8 @@ Map::Ptr TableTracker::materialize(vector<Frame::Ptr> *extra) const {
         Frame::Ptr rf = frameValid(mps_.cold[i].ref_frame, mps_.cold[i].ref_gen) ? obj[(size_t) mps_.cold[i].ref_frame] : nullptr;
         auto m        = std::allocate_shared<MapPoint>(PoolAllocator<MapPoint>(), mps_.hot[i].id, rf, mps_.hot[i].pos, mps_.cold[i].ref_kp, mps_.cold[i].depth,
                                                 (MapPointType) mps_.hot[i].type);
-        mpo[i] = m;
+        mpo[i]       = m;
+        V->mp_gen[i] = mps_.hot[i].gen;
         // observations in list order
         for (ulong ofid : observationFrames(i, alive))
             for (int h : alive)
@@ -1233,13 +1253,47 @@ Map::Ptr TableTracker::materialize(vector<Frame::Ptr> *extra) const {
     }
     vector<std::pair<ulong, Frame::Ptr>> kfs;
     for (const auto &k : map_kf_) kfs.emplace_back(k.key, obj[(size_t) k.frame]);
-    vector<MapPoint::Ptr> in_map;
-    for (uint32_t i : lms)
-        if (mps_.hot[i].in_map) in_map.push_back(mpo[i]);
-    map->restore(kfs, in_map, latest_keyframe_ >= 0 ? obj[(size_t) latest_keyframe_] : nullptr, is_window_full_);
+    vector<MapPoint::Ptr> in_map; // in Map::landmarks_' iteration order
+    for (const auto &kv : map_lm_) in_map.push_back(mpo[kv.second]);
+    map->restore(kfs, in_map, map_lm_.bucket_count(), latest_keyframe_ >= 0 ? obj[(size_t) latest_keyframe_] : nullptr, is_window_full_);
+    return V;
+}
+
+Map::Ptr TableTracker::materialize(vector<Frame::Ptr> *extra) const {
+    auto V = view();
     if (extra)
-        for (int h : alive) extra->push_back(obj[(size_t) h]);
-    return map;
+        for (const auto &f : V->frame)
+            if (f) extra->push_back(f);
+    if (extra) std::sort(extra->begin(), extra->end(), [](const Frame::Ptr &a, const Frame::Ptr &b) { return a->id() < b->id(); });
+    return V->map;
+}
+
+// Takes over what was done to the objects of a view since it was built (see ObjectView).  Frames and map points that have gone in the
+// table meanwhile (generation mismatch) are skipped; nothing else may have changed the table in between (no frame was tracked).
+void TableTracker::absorb(const ObjectView &V) {
+    for (size_t h = 0; h < V.frame.size() && h < frames_.size(); h++) {
+        if (!V.frame[h] || !frames_[h].alive || frames_[h].gen != V.frame_gen[h]) continue;
+        Frame_ &f = frames_[h];
+        f.pose    = V.frame[h]->pose(); // updateParametersFromOptimizer (ic_gvins.cc:1347-1357)
+        for (size_t r = 0; r < f.rows() && r < V.feat[h].size(); r++) f.row[r].outlier = V.feat[h][r]->isOutlier() ? 1 : 0; // :1078-1091
+    }
+    for (uint32_t i = 0; i < V.mappoint.size() && i < mps_.size(); i++) {
+        const MapPoint::Ptr &m = V.mappoint[i];
+        if (!m || !mps_.hot[i].live || mps_.hot[i].gen != V.mp_gen[i]) continue;
+        mps_.hot[i].pos        = m->pos();
+        mps_.cold[i].depth     = m->depth();
+        mps_.hot[i].used       = m->usedTimes();
+        mps_.cold[i].optimized = m->optimizedTimes();
+        mps_.hot[i].outlier    = m->isOutlier() ? 1 : 0;
+        if (mps_.hot[i].in_map && V.map->landmarks().find(m->id()) == V.map->landmarks().end()) {
+            // Map::removeMappoint (map.cc:129-137): outlier, observations dropped, erased from the landmarks — nothing reaches it any more
+            mps_.hot[i].in_map  = 0;
+            mps_.hot[i].outlier = 1;
+            map_lm_.erase(mps_.hot[i].id);
+            n_landmarks_--;
+            mps_.release(i);
+        }
+    }
 }
 
 } // namespace icg

@@ -16,6 +16,7 @@
 #pragma once
 #include <cstdio>
 #include <string>
+#include <unordered_map>
 
 #include "tracking.h"
 
@@ -105,7 +106,19 @@ public:
     size_t windowKeyFrames() const { return map_kf_.size(); }
     size_t landmarks() const { return n_landmarks_; }
 
-    // ---- B2 view: the reference-shaped object graph of this stream, built on demand ----
+    // ---- B2 view: the reference-shaped object graph of this stream, built on demand, and the way back ----
+    // What code written against the reference's types does to a map between two frames — the optimizer's write-back (keyframe poses,
+    // landmark positions and depths: ic_gvins.cc:1347-1391), outlier culling (feature / map-point outlier flags, used-times, removal of
+    // landmarks: ic_gvins.cc:1035-1128) — is done on the objects of a view and taken over by absorb().
+    struct ObjectView {
+        Map::Ptr map;
+        vector<Frame::Ptr> frame;          // by frame handle (null: not alive at the time)
+        vector<vector<Feature::Ptr>> feat; // by frame handle, row
+        vector<MapPoint::Ptr> mappoint;    // by map-point pool index (null: not live at the time)
+        vector<uint32_t> frame_gen, mp_gen;
+    };
+    std::shared_ptr<ObjectView> view() const;
+    void absorb(const ObjectView &v);
     // keyframes of the window (+ the tracker's current / previous / reference frames when they are not keyframes) with their features,
     // the landmarks with position / reference frame / depth / counters / observation lists.  `extra` receives the non-keyframe frames.
     Map::Ptr materialize(vector<Frame::Ptr> *extra = nullptr) const;
@@ -125,6 +138,7 @@ private:
         double pcx, pcy;   // Camera::pixel2cam(kp), kept: the next frame's velocity and every parallax need it again
         int32_t lk_idx;    // index of the LK point that produced this key point in the group's LK call of that frame (-1: not from LK)
         int8_t type;
+        uint8_t outlier;   // Feature::isOutlier (set by the optimizer's culling, read by the parallax of tracking.cc:873-905)
     };
     struct Frame_ {
         bool alive{false};
@@ -254,6 +268,11 @@ private:
     int latest_keyframe_{-1};
     bool is_window_full_{false};
     size_t n_landmarks_{0};
+    // Map::landmarks_ by operation history: the same container type (key, hasher, bucket policy) fed the same insert / erase sequence
+    // iterates in the same order, which is the order VisualWindow walks the landmarks in (window_visual.cc) — and so the order of the
+    // optimizer's residual blocks and of every floating-point sum over them.  Value: the map point's pool index.
+    typedef std::unordered_map<ulong, uint32_t, std::hash<ulong>, std::equal_to<ulong>, PoolAllocator<std::pair<const ulong, uint32_t>>> LandmarkOrder;
+    LandmarkOrder map_lm_;
 
     // candidates (tracking.h:129-136)
     vector<Point2f> pts2d_cur_, pts2d_new_, pts2d_ref_, pts2d_ref_undis_, pts2d_new_undis_;

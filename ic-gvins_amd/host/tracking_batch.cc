@@ -55,6 +55,17 @@ void TrackingBatch::Stream::currentFeatures(vector<std::pair<ulong, Point2f>> &o
     }
 }
 
+Map::Ptr TrackingBatch::Stream::objectMap() {
+    if (!table) return map;
+    if (!view_) view_ = table->view();
+    return view_->map;
+}
+
+void TrackingBatch::Stream::commitMap() {
+    if (table && view_) table->absorb(*view_);
+    view_.reset();
+}
+
 std::string TrackingBatch::Stream::dump(int kind) const {
     if (table) return kind == 0 ? table->dump() : kind == 1 ? table->dumpMap() : table->dumpMaterialized();
     return kind == 0 ? TableTracker::dumpObjects(*tracking, *map) : std::string();
@@ -201,6 +212,7 @@ void TrackingBatch::step(const FrameInput *frames, vector<TrackState> &states) {
         if (in.valid) {
             active[(size_t) i] = 1;
             hostprof::Scope hp(hostprof::BEGIN_FRAME);
+            s.view_.reset(); // (an object view of the table is a snapshot between two frames)
             if (s.table) {
                 TableTracker::Input ti;
                 ti.stamp = in.stamp, ti.image = in.image, ti.pose = in.pose;

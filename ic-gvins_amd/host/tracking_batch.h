@@ -48,6 +48,12 @@ public:
         // (map-point id, distorted key point) of the features of the stream's current frame, unordered
         void currentFeatures(vector<std::pair<ulong, Point2f>> &out) const;
         std::string dump(int kind) const; // 0: engine state (canonical text), 1: table map part, 2: the same from materialize()
+        // The stream's map as reference-shaped objects: the object engine's own map, or a view of the track table (built on first use
+        // and kept until commitMap()).  Code that writes to it (optimizer write-back, culling) calls commitMap() when it is done: the
+        // table engine takes the changes over (TableTracker::absorb) and drops the view; a no-op for the object engine.
+        Map::Ptr objectMap();
+        void commitMap();
+        std::shared_ptr<TableTracker::ObjectView> view_;
         // statistics / digest
         uint64_t frames{0}, keyframes{0}, tracked_sum{0}, digest{1469598103934665603ull};
         TrackState last_state{TRACK_PASSED};

@@ -4,14 +4,14 @@ import numpy as np
 import cull_utils as cu
 
 
-def check_window_culling(lib_path, oracle, n_streams=3, n_frames=16):
+def check_window_culling(lib_path, oracle, n_streams=3, n_frames=16, engine="table"):
     """tracks a few synthetic streams, moves some landmarks (as an optimizer write-back would), then runs
     reprojectionStatistics and gvinsOutlierCulling for all streams in one call each and compares counters, the removed landmark
     set and the features flagged as outliers with the Python restatement working on the raw landmark-graph dump"""
     import harness as H
     w, h = 640, 480
     cam = H.camera_for(w, h)
-    sb = H.StreamBatch(lib_path, n_streams, w, h, cam, max_features=100, window=10, engine="object")  # works on the tracker's icg::Map
+    sb = H.StreamBatch(lib_path, n_streams, w, h, cam, max_features=100, window=10, engine=engine)  # icg::Map itself, or a view of the track table
     scene = H.SynthScene(sb.lib, w, h, cam, tex_size=1024, threads=4)
     for k in range(n_frames):
         frames = [scene.render(k, stream=s) for s in range(n_streams)]
@@ -57,5 +57,12 @@ def check_window_culling(lib_path, oracle, n_streams=3, n_frames=16):
                                if int(T["id"][k]) in pos_of)
         assert n_flagged_after - n_flagged_before == sum(1 for (lid, j) in flagged if lid in pos_of), s
     assert total[0] > 5 and total[1] > 0 and total[2] > 0 and total[3] > 0 and total[4] > 0, total  # every branch was exercised
+    # the tracker goes on with the culled map; the state it ends in is returned for engine-vs-engine comparisons
+    for k in range(n_frames, n_frames + 4):
+        frames = [scene.render(k, stream=s) for s in range(n_streams)]
+        poses = np.stack([H.pose12(*scene.ins_pose(k, stream=s)) for s in range(n_streams)])
+        sb.step([f.ctypes.data for f in frames], w, np.full(n_streams, 100.0 + k / 20.0), poses)
+    final = [sb.dump(s, 0) for s in range(n_streams)]
     sb.close()
+    return [list(o) for o in out], [list(x) for x in stats], final
     return total

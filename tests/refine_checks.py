@@ -20,7 +20,7 @@ def refine(sb, pose_b_c12, prior_weight=50.0, std=1.5, iters1=6, iters2=18, chi2
     return out7, kf
 
 
-def check_refinement(lib_path, n_streams=3, n_frames=30):
+def check_refinement(lib_path, n_streams=3, n_frames=30, engine="table"):
     """tracks synthetic streams whose INS priors carry N(0.02 m, 0.1 deg) noise, then optimizes every stream's sliding window
     (reprojection factors from the map + pose priors at the INS poses) and writes the result back: the keyframe poses must move
     TOWARDS the true camera poses (the visual factors average the independent prior noise down), the cost must drop, and the
@@ -28,7 +28,7 @@ def check_refinement(lib_path, n_streams=3, n_frames=30):
     import harness as H
     w, h = 640, 480
     cam = H.camera_for(w, h)
-    sb = H.StreamBatch(lib_path, n_streams, w, h, cam, max_features=100, window=10, engine="object")  # works on the tracker's icg::Map
+    sb = H.StreamBatch(lib_path, n_streams, w, h, cam, max_features=100, window=10, engine=engine)  # icg::Map itself, or a view of the track table
     scene = H.SynthScene(sb.lib, w, h, cam, tex_size=1024, threads=4)
     t0 = 100.0
     for k in range(n_frames):
@@ -62,5 +62,6 @@ def check_refinement(lib_path, n_streams=3, n_frames=30):
         poses = np.stack([H.pose12(*scene.ins_pose(k, stream=s)) for s in range(n_streams)])
         st = sb.step([f.ctypes.data for f in frames], w, np.full(n_streams, t0 + k / 20.0), poses)
         assert all(int(x) == 2 for x in st), st
+    final = [sb.dump(s, 0) for s in range(n_streams)]
     sb.close()
-    return results, out7
+    return results, out7, final

@@ -87,3 +87,35 @@ def test_hash_order_equals_std_unordered_map():
     for seed in range(24):
         for dense in (0, 1):
             assert lib.icgh_hashorder_selftest(seed, 900, 1 if seed < 4 else 41, dense) == 0, (seed, dense)
+
+
+def _first_difference(a, b):
+    la, lb = a.splitlines(), b.splitlines()
+    i = next((i for i in range(min(len(la), len(lb))) if la[i] != lb[i]), min(len(la), len(lb)))
+    return i, la[i] if i < len(la) else "<end>", lb[i] if i < len(lb) else "<end>"
+
+
+def test_culling_through_the_object_view_equals_the_object_engine(oracle):
+    """icgh_batch_culling on the table engine works on a lazily built object view (TableTracker::view) and writes the result back
+    (absorb): outputs, per-observation flags (checked inside against the python restatement) and the tracker state four frames
+    later are the object engine's, bit for bit"""
+    import cull_checks as cc
+    lib = ensure_oracle_host()
+    a = cc.check_window_culling(lib, oracle, engine="object")
+    b = cc.check_window_culling(lib, oracle, engine="table")
+    assert a[0] == b[0] and a[1] == b[1]
+    for s, (x, y) in enumerate(zip(a[2], b[2])):
+        assert x == y, (s, _first_difference(x, y))
+
+
+def test_refinement_through_the_object_view_equals_the_object_engine():
+    """same for icgh_batch_refine_windows (VisualWindow gather -> WindowSolver -> write-back -> WindowCulling): keyframe poses,
+    landmark positions, outlier flags and removals land in the track table exactly as they land in icg::Map"""
+    import refine_checks as rc
+    lib = ensure_oracle_host()
+    ra, oa, fa = rc.check_refinement(lib, engine="object")
+    rb, ob, fb = rc.check_refinement(lib, engine="table")
+    assert np.array_equal(oa, ob), (oa, ob)
+    assert ra == rb
+    for s, (x, y) in enumerate(zip(fa, fb)):
+        assert x == y, (s, _first_difference(x, y))
