@@ -65,4 +65,3 @@ def check_window_culling(lib_path, oracle, n_streams=3, n_frames=16, engine="tab
     final = [sb.dump(s, 0) for s in range(n_streams)]
     sb.close()
     return [list(o) for o in out], [list(x) for x in stats], final
-    return total
