@@ -12,7 +12,7 @@ namespace hostprof {
 
 enum Section {
     BEGIN_FRAME = 0, ON_PREPROCESS, ON_DETECT_A, ON_LK, ON_RANSAC, ON_TRIANGULATE, ON_DETECT_B, DIGEST, KEEPER,
-    DEV_PREPROCESS, DEV_DETECT, DEV_LK, DEV_RANSAC, DEV_TRIANGULATE, GATHER, SCATTER, STEP_TOTAL, LK_MAP_FEATURES, LK_MAP_PARALLAX, LK_REF, KEEP_INSERT, KEEP_REMOVE, X5, X6, X7, N_SECTIONS
+    DEV_PREPROCESS, DEV_DETECT, DEV_LK, DEV_RANSAC, DEV_TRIANGULATE, GATHER, SCATTER, STEP_TOTAL, LK_MAP_FEATURES, LK_MAP_PARALLAX, LK_REF, KEEP_INSERT, KEEP_REMOVE, DET_INTEGRATE, QUEUE_MAP, QUEUE_REF, N_SECTIONS
 };
 
 inline std::atomic<uint64_t> *ns() {
@@ -56,7 +56,7 @@ inline const char *name(int s) {
     static const char *n[N_SECTIONS] = {"begin_frame", "on_preprocess", "on_detect_a", "on_lk", "on_ransac", "on_triangulate",
                                         "on_detect_b", "digest", "keeper", "dev_preprocess", "dev_detect", "dev_lk",
                                         "dev_ransac", "dev_triangulate", "gather", "scatter", "step_total", "lk_map_features", "lk_map_parallax", "lk_ref", "keep_insert", "keep_remove",
-                                        "x5", "x6", "x7"};
+                                        "det_integrate", "queue_map", "queue_ref"};
     return n[s];
 }
 

@@ -33,19 +33,25 @@ size_t HashOrder::bucketsAfter(size_t k) {
     return table[k];
 }
 
-// key % n; the ids of this code base are small counters: a 32-bit division when the key fits
-static inline size_t bucketOf(ulong key, size_t n) {
-    return (key >> 32) == 0 ? (size_t) ((uint32_t) key % (uint32_t) n) : (size_t) (key % n);
+// key % n without a division for keys below 2^32 (the ids of this code base are small counters): Lemire's fastmod, exact for every
+// 32-bit key and divisor; M = floor((2^64 - 1) / n) + 1 is computed once per bucket count
+static inline uint64_t modMagic(size_t n) { return UINT64_C(0xFFFFFFFFFFFFFFFF) / (uint64_t) n + 1; }
+static inline size_t bucketOf(ulong key, size_t n, uint64_t M) {
+    if ((key >> 32) != 0 || (n >> 32) != 0) return (size_t) (key % n);
+    const uint64_t low = M * (uint64_t) (uint32_t) key;
+    return (size_t) (((__uint128_t) low * (uint64_t) n) >> 64);
 }
 
 void HashOrder::rehash(size_t n) { // bits/hashtable.h _M_rehash_aux(__n, true_type)
-    vector<int> nb(n, kEmpty);
+    vector<int> &nb = scratch_;
+    nb.assign(n, kEmpty);
+    const uint64_t M = modMagic(n);
     int p = head_;
     head_ = -1;
     size_t bbegin_bkt = 0;
     while (p >= 0) {
         const int nx   = next_[(size_t) p];
-        const size_t b = bucketOf(key_[(size_t) p], n);
+        const size_t b = bucketOf(key_[(size_t) p], n, M);
         if (nb[b] == kEmpty) {
             next_[(size_t) p] = head_;
             head_             = p;
@@ -63,14 +69,15 @@ void HashOrder::rehash(size_t n) { // bits/hashtable.h _M_rehash_aux(__n, true_t
         p = nx;
     }
     bucket_.swap(nb);
+    magic_ = M;
 }
 
 bool HashOrder::contains(ulong key) const {
     const size_t n = bucket_.size();
-    const size_t b = bucketOf(key, n);
+    const size_t b = bucketOf(key, n, magic_);
     const int prev = bucket_[b];
     if (prev == kEmpty) return false;
-    for (int p = nextOf(prev); p >= 0 && bucketOf(key_[(size_t) p], n) == b; p = next_[(size_t) p])
+    for (int p = nextOf(prev); p >= 0 && bucketOf(key_[(size_t) p], n, magic_) == b; p = next_[(size_t) p])
         if (key_[(size_t) p] == key) return true;
     return false;
 }
@@ -79,7 +86,7 @@ void HashOrder::insertUnique(ulong key) { // _M_insert_unique_node + _M_insert_b
     const size_t want = bucketsAfter(next_.size() + 1);
     if (want != bucket_.size()) rehash(want);
     const int i    = (int) next_.size();
-    const size_t n = bucket_.size(), b = bucketOf(key, n);
+    const size_t n = bucket_.size(), b = bucketOf(key, n, magic_);
     key_.push_back(key);
     next_.push_back(-1);
     if (bucket_[b] != kEmpty) {
@@ -89,7 +96,7 @@ void HashOrder::insertUnique(ulong key) { // _M_insert_unique_node + _M_insert_b
     } else {
         next_[(size_t) i] = head_;
         head_             = i;
-        if (next_[(size_t) i] >= 0) bucket_[bucketOf(key_[(size_t) next_[(size_t) i]], n)] = i;
+        if (next_[(size_t) i] >= 0) bucket_[bucketOf(key_[(size_t) next_[(size_t) i]], n, magic_)] = i;
         bucket_[b] = kBeforeBegin;
     }
 }
@@ -340,6 +347,20 @@ double TableTracker::keyPointParallax(const Point2f &pp0, const Point2f &pp1, co
     return Vector2d(pc01[0] - pc1[0], pc01[1] - pc1[1]).norm() * camera_->focalLength();
 }
 
+// order_idx_ := the rows of f in container order; requests the rows and the map-point records of the first few (see queueTrackMappoint)
+size_t TableTracker::listContainerOrder(const Frame_ &f) {
+    order_idx_.clear();
+    for (int q = f.order.head(); q >= 0; q = f.order.next(q)) {
+        order_idx_.push_back(q);
+        const char *line = reinterpret_cast<const char *>(&f.row[(size_t) q]);
+        __builtin_prefetch(line);
+        __builtin_prefetch(line + sizeof(Row) - 1);
+    }
+    const size_t nq = order_idx_.size();
+    for (size_t k = 0; k < std::min(kAhead, nq); k++) __builtin_prefetch(&mps_.hot[f.row[(size_t) order_idx_[k]].mp]);
+    return nq;
+}
+
 int TableTracker::parallaxFromReferenceMapPoints(double &parallax) { // :873-905
     parallax   = 0;
     int counts = 0;
@@ -347,8 +368,10 @@ int TableTracker::parallaxFromReferenceMapPoints(double &parallax) { // :873-905
     const Frame_ &fr   = frames_[(size_t) ref_];
     const Matrix3d R10 = fc.pose.R.transpose() * fr.pose.R;
     const double focal = camera_->focalLength();
-    for (int q = fr.order.head(); q >= 0; q = fr.order.next(q)) {
-        const Row &r0    = fr.row[(size_t) q];
+    const size_t nq = listContainerOrder(fr);
+    for (size_t k = 0; k < nq; k++) {
+        if (k + kAhead < nq) __builtin_prefetch(&mps_.hot[fr.row[(size_t) order_idx_[k + kAhead]].mp]);
+        const Row &r0    = fr.row[(size_t) order_idx_[k]];
         const uint32_t i = r0.mp;
         if (!mps_.valid(i, r0.mpgen) || mps_.hot[i].outlier) continue; // getMapPoint() && !isOutlier()
         const LastObs &lo = mps_.hot[i].last;                           // observations().back().lock()
@@ -564,14 +587,21 @@ void TableTracker::onPreprocessDone(StageBatch &done, StageBatch &next) {
 }
 
 void TableTracker::onDetectADone(StageBatch &done, StageBatch &next) {
-    if (det_job_ >= 0) integrateDetection(done);
+    if (det_job_ >= 0) {
+        hostprof::Scope hp(hostprof::DET_INTEGRATE);
+        integrateDetection(done);
+    }
     if (mode_ == M_FIRST) {
         releaseUnusedSlots();
         finish(TRACK_FIRST_FRAME);
         return;
     }
-    if (mode_ == M_TRACK) queueTrackMappoint(next); // :206
-    queueTrackReference(next);                      // :173 / :209
+    if (mode_ == M_TRACK) { // :206
+        hostprof::Scope hp(hostprof::QUEUE_MAP);
+        queueTrackMappoint(next);
+    }
+    hostprof::Scope hp(hostprof::QUEUE_REF);
+    queueTrackReference(next); // :173 / :209
 }
 
 void TableTracker::onLKDone(StageBatch &done, StageBatch &next) {
@@ -725,8 +755,13 @@ void TableTracker::queueTrackMappoint(StageBatch &next) {
     tm_hint_.clear();
     const Frame_ &fp    = frames_[(size_t) pre_];
     const Pose pose_cur = frames_[(size_t) cur_].pose;
-    for (int q = fp.order.head(); q >= 0; q = fp.order.next(q)) {
-        const Row &r     = fp.row[(size_t) q];
+    // The rows are visited in container order (random within the row array) and every row names a map point somewhere in the pool: with
+    // hundreds of streams per GPU both are cold by the time a stream's turn comes round again.  Pass 1 lists the rows in container order
+    // and requests them; pass 2 requests the map-point record a few rows ahead of the one it works on.
+    const size_t nq = listContainerOrder(fp);
+    for (size_t k = 0; k < nq; k++) {
+        if (k + kAhead < nq) __builtin_prefetch(&mps_.hot[fp.row[(size_t) order_idx_[k + kAhead]].mp]);
+        const Row &r     = fp.row[(size_t) order_idx_[k]];
         const uint32_t i = r.mp;
         if (!mps_.valid(i, r.mpgen) || mps_.hot[i].outlier) continue; // mappoint && !mappoint->isOutlier() (:360)
         tm_pc_.push_back(r.pcx); // pixel2cam of the previous undistorted key point (:434 needs it for the velocity)
@@ -776,6 +811,7 @@ bool TableTracker::finishTrackMappoint(StageBatch &done) {
         tracked_mappoint_.clear();
         const double dt = fc.stamp - frames_[(size_t) pre_].stamp;
         for (int k = 0; k < n; k++) { // reduceVector (:404-408) and the feature loop (:430-444) in one pass
+            if (k + 8 < n) __builtin_prefetch(&mps_.hot[mappoint_matched_[(size_t) k + 8].i], 1);
             if (!status[k]) continue;
             const MpRef m     = mappoint_matched_[(size_t) k];
             const Vector3d pc = camera_->pixel2cam(undis[k]);

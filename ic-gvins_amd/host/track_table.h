@@ -34,6 +34,7 @@ public:
         head_ = -1;
         // (std::unordered_map::clear() keeps its buckets; a Frame's map is only ever cleared while empty, so this is a fresh table)
         bucket_.assign(1, kEmpty);
+        magic_ = 0; // (M for one bucket is 2^64: wraps to 0, and the fastmod of any key is 0 — the right bucket)
     }
     void reserveRows(size_t n) {
         next_.reserve(n);
@@ -60,7 +61,8 @@ private:
         else
             next_[(size_t) prev] = i;
     }
-    vector<int> next_, bucket_{kEmpty};
+    vector<int> next_, bucket_{kEmpty}, scratch_;
+    uint64_t magic_{0};
     vector<ulong> key_;
     int head_{-1};
 };
@@ -201,6 +203,7 @@ private:
     int addRow(int h, ulong id, uint32_t mp, const Point2f &kp, const Point2f &kpd, const Vector2d &vel, FeatureType type, double pcx,
                double pcy, bool unique_key, int32_t lk_idx = -1);
     vector<ulong> observationFrames(uint32_t mp, const vector<int> &alive_by_fid) const;
+    size_t listContainerOrder(const Frame_ &f);
     bool frameValid(int h, uint32_t g) const { return h >= 0 && frames_[(size_t) h].alive && frames_[(size_t) h].gen == g; }
 
     // map (tracking/map.cc) on handles
@@ -310,6 +313,8 @@ private:
     vector<Point2f> tm_pts2d_map_, tm_pred_;
     vector<double> tm_pc_;
     vector<int32_t> tm_hint_;
+    vector<int> order_idx_; // rows of a frame in container order (scratch)
+    static constexpr size_t kAhead = 8; // prefetch distance of the per-row loops, in rows
     bool ref_tracked_{false};
     int rs_set_{-1};
     vector<Point2f> tr_new_undis_, tr_cur_undis_;
