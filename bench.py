@@ -246,6 +246,16 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
             raise RuntimeError("icgh_batch_run failed: " + sb._err.value.decode())
         return states
 
+    # diagnostic (profiles/r03_cpu_quota.md): ICG_BENCH_TIMED_CPUS=N confines EVERY thread of the process (group threads, HIP runtime
+    # threads) to the first N allowed CPUs from here on — priming, warm-up and the timed region run on N cores, only the set-up
+    # (rendering, uploads) used them all.  What one rank of an 8-rank run on a 16-core box has is N = 2.
+    if os.environ.get("ICG_BENCH_TIMED_CPUS"):
+        cpus = sorted(os.sched_getaffinity(0))[:max(1, int(os.environ["ICG_BENCH_TIMED_CPUS"]))]
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), cpus)
+            except OSError:
+                pass
     k = 0
     t_prime = time.time()
     if prime > 0:
