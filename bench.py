@@ -972,7 +972,9 @@ def main():
             v = cpu_frontend(timing_lib, w, h, nfeat, 10, host0, poses0, T, nwarm, ntime)
             cpu_baseline_allcores = {"value": round(v, 3), "unit": "frames/s", "cores": T, "kind": "port",
                                      "sample": f"{T} independent streams x {ntime} steady-state frames {w}x{h}/{nfeat} feats, oracle-backed host "
-                                               f"layer ({timing_flags}), one stream group (thread) per usable host core"}
+                                               f"layer ({timing_flags}), one stream group (thread) per usable host core; stream-level parallelism is the "
+                                               "CPU-friendly decomposition (the reference parallelises INSIDE one stream: LK over points, detection "
+                                               "over blocks tracking.cc:656, 4 Ceres threads ic_gvins.cc:1146)"}
         # C1 (BASELINE.json configs[0]): the CPU-runnable plumbing case — one 640x480 stream, 100 features, oracle path only, no GPU
         sc1 = H.SynthScene(C.CDLL(timing_lib), 640, 480, H.camera_for(640, 480), tex_size=2048, threads=max(1, min(16, ncpu)))
         f1 = [sc1.render(k, stream=0) for k in range(32)]
