@@ -52,15 +52,18 @@ CASES = {
     "c1_lost_histgate": (640, 480, 100, 34, 13, (14, 15, 16), True, None),
     "c1_slow_second_new": (640, 480, 100, 40, 14, (), False, (8, 0.02)),
     "c2": (1280, 720, 300, 16, 15, (), False, None),
+    "c4_window15": (1920, 1080, 500, 44, 16, (), False, None),  # BASELINE.json configs[3]: 15-keyframe window
 }
+WINDOW = {"c4_window15": 15}
 
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_table_engine_state_equals_object_engine(name):
     w, h, nfeat, n, stream, blank, hist, slow = CASES[name]
     frames, poses = _scene(w, h, n, stream, blank=blank, blank_value=235 if hist else 90, slow_after=slow)
-    st_t, d_t, stats_t = _drive("table", w, h, nfeat, n, frames, poses, check_hist=hist)
-    st_o, d_o, stats_o = _drive("object", w, h, nfeat, n, frames, poses, check_hist=hist)
+    win = WINDOW.get(name, 10)
+    st_t, d_t, stats_t = _drive("table", w, h, nfeat, n, frames, poses, check_hist=hist, window=win)
+    st_o, d_o, stats_o = _drive("object", w, h, nfeat, n, frames, poses, check_hist=hist, window=win)
     assert st_t == st_o
     assert stats_t == stats_o
     for (k, full_t, map_t, mat_t), (_, full_o, _, _) in zip(d_t, d_o):
