@@ -435,7 +435,7 @@ def compact_line(full, details_path):
                               "issue_frac", "pmc_stale"))
     if r and r.get("valu"):
         c["roofline"]["valu"] = _pick(r["valu"], ("wave_instructions_per_frame", "lk_share", "frac"))
-    for k in ("cpu_baseline", "cpu_baseline_allcores", "cpu_baseline_reference_tracker"):
+    for k in ("cpu_baseline", "cpu_baseline_allcores", "cpu_baseline_reference_decomposition", "cpu_baseline_reference_tracker"):
         c[k] = _pick(full.get(k), ("value", "unit", "cores", "kind", "sample"))
         if c[k] and len(c[k].get("sample", "")) > 150:
             c[k]["sample"] = c[k]["sample"][:147] + "..."
@@ -954,6 +954,7 @@ def main():
 
     cpu_baseline = None
     cpu_baseline_allcores = None
+    cpu_baseline_refdecomp = None
     c1 = None
     timing_lib, timing_flags = (None, None)
     if rank == 0 and not args.no_cpu_baseline:
@@ -975,6 +976,18 @@ def main():
                                                f"layer ({timing_flags}), one stream group (thread) per usable host core; stream-level parallelism is the "
                                                "CPU-friendly decomposition (the reference parallelises INSIDE one stream: LK over points, detection "
                                                "over blocks tracking.cc:656, 4 Ceres threads ic_gvins.cc:1146)"}
+        # (c) one stream, the reference's OWN decomposition: the points of an LK call in parallel (OpenCV's parallel_for_
+        # in calcOpticalFlowPyrLK) and the detection blocks in parallel (tbb::parallel_for, tracking.cc:656) on T threads; results identical
+        if T > 1:
+            os.environ["ICG_ORACLE_INNER_THREADS"] = str(T)
+            try:
+                v = cpu_frontend(timing_lib, w, h, nfeat, 10, host0, poses0, 1, nwarm, ntime)
+            finally:
+                os.environ.pop("ICG_ORACLE_INNER_THREADS", None)
+            cpu_baseline_refdecomp = {"value": round(v, 3), "unit": "frames/s", "cores": T, "kind": "port",
+                                      "sample": f"1 stream x {ntime} steady-state frames {w}x{h}/{nfeat} feats, oracle-backed host layer "
+                                                f"({timing_flags}); the reference's decomposition inside the stream: LK points and detection "
+                                                f"blocks over {T} threads (preprocessing and tracker logic serial)"}
         # C1 (BASELINE.json configs[0]): the CPU-runnable plumbing case — one 640x480 stream, 100 features, oracle path only, no GPU
         sc1 = H.SynthScene(C.CDLL(timing_lib), 640, 480, H.camera_for(640, 480), tex_size=2048, threads=max(1, min(16, ncpu)))
         f1 = [sc1.render(k, stream=0) for k in range(32)]
@@ -1116,6 +1129,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "cpu_baseline_allcores": cpu_baseline_allcores,
+            "cpu_baseline_reference_decomposition": cpu_baseline_refdecomp,
             "cpu_baseline_reference_tracker": cpu_reference,
             "speedup_vs_cpu_baseline": (round(fps / cpu_baseline["value"], 2) if cpu_baseline else None),
             "reproj": reproj,

@@ -10,6 +10,7 @@
 //     (OpenCV's 8u->32f getRectSubPix uses an algebraically equal recurrence; differences are ~1e-5 px);
 //     the 11x11 Gaussian mask is passed in by the caller (expf is libm-specific).
 // PARITY UNPINNED (no upstream golden vectors, OpenCV absent offline).
+#include "orc_parallel.h"
 #include "oracle.h"
 #include <algorithm>
 #include <cfloat>
@@ -269,26 +270,35 @@ int orc_detect(const uint8_t *img, int w, int h, int stride, const int *grid6, i
     std::vector<uint8_t> mask((size_t) w * h, 255);
     for (int i = 0; i < n_mask; i++)
         orc_draw_filled_circle(mask.data(), w, h, w, cv_round_f(mask_pts[2 * i]), cv_round_f(mask_pts[2 * i + 1]), md, 0);
-    int total = 0;
     const int nb = bc * br;
-    std::vector<float> corners;
-    for (int k = 0; k < nb; k++) {
-        int q = quota[k];
-        if (q <= 0) continue;
-        int cols = k % bc, rows = k / bc;
-        int col_sta = cols * bw, col_end = col_sta + bw, row_sta = rows * bh, row_end = row_sta + bh;
-        if (k != nb - 1) {
-            col_end -= 5;
-            row_end -= 5;
+    // every block's corners in its own list (the reference's tbb::parallel_for over blocks, tracking.cc:656), appended in block order
+    std::vector<std::vector<float>> found((size_t) nb);
+    std::vector<int> origin_x((size_t) nb, 0), origin_y((size_t) nb, 0);
+    orc_parallel_chunks(nb, [&](int k0, int k1) {
+        for (int k = k0; k < k1; k++) {
+            int q = quota[k];
+            if (q <= 0) continue;
+            int cols = k % bc, rows = k / bc;
+            int col_sta = cols * bw, col_end = col_sta + bw, row_sta = rows * bh, row_end = row_sta + bh;
+            if (k != nb - 1) {
+                col_end -= 5;
+                row_end -= 5;
+            }
+            int rw = col_end - col_sta, rh = row_end - row_sta;
+            std::vector<float> corners((size_t) 2 * q, 0.f);
+            int n = orc_good_features(img, w, h, stride, mask.data(), w, col_sta, row_sta, rw, rh, q, 0.01, (double) md, corners.data());
+            if (n > 0) orc_corner_subpix(img, w, h, stride, col_sta, row_sta, rw, rh, n, corners.data());
+            corners.resize((size_t) 2 * std::max(0, n));
+            found[(size_t) k].swap(corners);
+            origin_x[(size_t) k] = col_sta, origin_y[(size_t) k] = row_sta;
         }
-        int rw = col_end - col_sta, rh = row_end - row_sta;
-        corners.assign((size_t) 2 * q, 0.f);
-        int n = orc_good_features(img, w, h, stride, mask.data(), w, col_sta, row_sta, rw, rh, q, 0.01, (double) md,
-                                  corners.data());
-        if (n > 0) orc_corner_subpix(img, w, h, stride, col_sta, row_sta, rw, rh, n, corners.data());
-        for (int i = 0; i < n && total < max_out; i++) {
-            out_pts[2 * total]     = (float) col_sta + corners[2 * i];
-            out_pts[2 * total + 1] = (float) row_sta + corners[2 * i + 1];
+    });
+    int total = 0;
+    for (int k = 0; k < nb; k++) {
+        const std::vector<float> &corners = found[(size_t) k];
+        for (size_t i = 0; 2 * i < corners.size() && total < max_out; i++) {
+            out_pts[2 * total]     = (float) origin_x[(size_t) k] + corners[2 * i];
+            out_pts[2 * total + 1] = (float) origin_y[(size_t) k] + corners[2 * i + 1];
             if (out_block) out_block[total] = k;
             total++;
         }

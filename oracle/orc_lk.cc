@@ -5,6 +5,7 @@
 // Algorithm: OpenCV modules/video/src/lkpyramid.cpp (LKTrackerInvoker) as defined in SURVEY.md Appendix B.5;
 // window sums are accumulated as exact int64 and converted once (the survey's bit-stable formulation).
 // PARITY UNPINNED (no upstream golden vectors, OpenCV absent offline).
+#include "orc_parallel.h"
 #include "oracle.h"
 #include <cfloat>
 #include <cmath>
@@ -225,11 +226,13 @@ void orc_lk_track(const uint8_t *prev, const uint8_t *next, int w, int h, int st
     Pyr P, N;
     build_pyr(prev, w, h, stride, 3, WIN, true, P);
     build_pyr(next, w, h, stride, 3, WIN, false, N);
-    for (int i = 0; i < n; i++) {
-        float e = 0;
-        lk_point(P, N, prev_pts[2 * i], prev_pts[2 * i + 1], &next_pts[2 * i], &next_pts[2 * i + 1], &status[i], &e);
-        if (err) err[i] = e;
-    }
+    orc_parallel_chunks(n, [&](int i0, int i1) { // (points are independent: OpenCV's own parallel_for_ over them)
+        for (int i = i0; i < i1; i++) {
+            float e = 0;
+            lk_point(P, N, prev_pts[2 * i], prev_pts[2 * i + 1], &next_pts[2 * i], &next_pts[2 * i + 1], &status[i], &e);
+            if (err) err[i] = e;
+        }
+    });
 }
 
 // Forward + backward + cull exactly as tracking.cc:385-403 (or :487-506):

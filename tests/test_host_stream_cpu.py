@@ -58,3 +58,33 @@ def test_host_layer_matches_reference_tracker_golden(scenario):
     tests/golden/make_tracking_golden.py): track states, map-point ids, key-point floats, window bookkeeping."""
     import ref_tracking_utils as rt
     rt.compare_scenario(ensure_oracle_host(), scenario)
+
+
+def test_oracle_inner_threads_give_identical_results():
+    """ICG_ORACLE_INNER_THREADS (bench.py's cpu_baseline_reference_decomposition leg: LK points and detection blocks in parallel inside one
+    stream, the reference's own CPU decomposition) changes the schedule only: same tracker state, same digest"""
+    import os
+
+    import numpy as np
+
+    import harness as H
+    from stream_utils import ensure_oracle_host
+    w, h = 640, 480
+    cam = H.camera_for(w, h)
+
+    def run(threads):
+        if threads > 1:
+            os.environ["ICG_ORACLE_INNER_THREADS"] = str(threads)
+        try:
+            sb = H.StreamBatch(ensure_oracle_host(), 1, w, h, cam, max_features=100, window=10)
+            scene = H.SynthScene(sb.lib, w, h, cam, tex_size=1024, threads=4)
+            for k in range(14):
+                img = scene.render(k, stream=21)
+                sb.step([img.ctypes.data], w, [100.0 + k / 20.0], np.stack([H.pose12(*scene.ins_pose(k, stream=21))]))
+            out = (sb.dump(0, 0), sb.stats(0)["digest"])
+            sb.close()
+            return out
+        finally:
+            os.environ.pop("ICG_ORACLE_INNER_THREADS", None)
+
+    assert run(1) == run(5)
