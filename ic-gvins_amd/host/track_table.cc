@@ -1255,6 +1255,13 @@ std::shared_ptr<TableTracker::ObjectView> TableTracker::view() const {
             feat[(size_t) h][r]->setOutlier(f.row[r].outlier != 0);
         }
     }
+    // (frame handle, row) of every row that holds a live map point, per map point, frames in id order
+    vector<vector<std::pair<int, int>>> seen(mps_.size());
+    for (int h : alive) {
+        const Frame_ &f = frames_[(size_t) h];
+        for (size_t r = 0; r < f.rows(); r++)
+            if (mps_.valid(f.row[r].mp, f.row[r].mpgen) && f.row[r].id == mps_.hot[f.row[r].mp].id) seen[f.row[r].mp].emplace_back(h, (int) r);
+    }
     vector<MapPoint::Ptr> &mpo = V->mappoint;
     mpo.assign(mps_.size(), nullptr);
     V->mp_gen.assign(mps_.size(), 0);
@@ -1268,14 +1275,17 @@ std::shared_ptr<TableTracker::ObjectView> TableTracker::view() const {
                                                 (MapPointType) mps_.hot[i].type);
         mpo[i]       = m;
         V->mp_gen[i] = mps_.hot[i].gen;
-        // observations in list order
-        for (ulong ofid : observationFrames(i, alive))
-            for (int h : alive)
-                if (frames_[(size_t) h].fid == ofid) {
-                    const Frame_ &f = frames_[(size_t) h];
-                    for (size_t r = 0; r < f.rows(); r++)
-                        if (f.row[r].id == mps_.hot[i].id) m->addObservation(feat[(size_t) h][r]);
-                }
+        // observations in list order (see observationFrames): the frame that was current at the triangulation, the reference frame, then
+        // every later frame — from the (frame, row) pairs collected in one pass over the rows above
+        const ulong born = mps_.cold[i].born_fid;
+        const auto &at   = seen[i];
+        for (const auto &o : at)
+            if (frames_[(size_t) o.first].fid == born) m->addObservation(feat[(size_t) o.first][(size_t) o.second]);
+        if (rf && frames_[(size_t) mps_.cold[i].ref_frame].fid != born)
+            for (const auto &o : at)
+                if (o.first == mps_.cold[i].ref_frame) m->addObservation(feat[(size_t) o.first][(size_t) o.second]);
+        for (const auto &o : at)
+            if (frames_[(size_t) o.first].fid > born) m->addObservation(feat[(size_t) o.first][(size_t) o.second]);
         m->restoreCounters(mps_.hot[i].used, mps_.hot[i].observed, mps_.cold[i].optimized, mps_.hot[i].outlier != 0);
     }
     for (int h : alive) {
