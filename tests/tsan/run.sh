@@ -6,7 +6,7 @@
 #   3. icg_replay_oracle    one estimator with the host-factor helper thread (WindowSolver::setHostFactorOverlap)
 #   4. icg_replay_oracle --streams 3 --lockstep-groups 1   WindowSolverBatch with its persistent pool
 # Expected: 0 "WARNING: ThreadSanitizer" in every log (round 2: all four clean).
-# SAN=address,undefined tests/tsan/run.sh /tmp/icg_asan runs the same four under AddressSanitizer + UBSan (round 2: 2. and 3. clean).
+# SAN=address,undefined tests/tsan/run.sh /tmp/icg_asan runs the same four under AddressSanitizer + UBSan, plus 5. below (round 3: all clean).
 set -eu
 SAN=${SAN:-thread}
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
@@ -24,4 +24,18 @@ $W/frontend_groups > $W/2_frontend_groups.log 2>&1
 (cd $W/src/oracle && LD_LIBRARY_PATH=. ./icg_replay_oracle --config $CFG --imu $IMU --gnss $GNSS --images $IMG --output $W/out1 > $W/3_replay_single.log 2>&1)
 mkdir -p $W/out3
 (cd $W/src/oracle && LD_LIBRARY_PATH=. ./icg_replay_oracle --config $CFG --imu $IMU --gnss $GNSS --images $IMG --output $W/out3 --streams 3 --lockstep-groups 1 > $W/4_replay_lockstep.log 2>&1)
-for f in $W/[1-4]_*.log; do echo "$(basename $f): $(grep -c 'WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error' $f || true) reports; $(tail -1 $f | cut -c1-140)"; done
+# 5. (address/undefined only) the lazily built object view of the track table and its write-back — culling and window refinement through
+#    the C entry points on both engines — driven from python with the sanitizer runtime preloaded
+case "$SAN" in *address*)
+  LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) PYTHONPATH=$ROOT/ic-gvins_amd:$ROOT:$ROOT/tests python3 - > $W/5_object_view.log 2>&1 <<PY
+import oracle_lib, cull_checks as cc, refine_checks as rc
+LIB = "$W/src/oracle/libicgvins_host_oracle.so"
+oracle = oracle_lib.load()
+for eng in ("table", "object"):
+    cc.check_window_culling(LIB, oracle, engine=eng)
+    rc.check_refinement(LIB, n_frames=24, engine=eng)
+print("done")
+PY
+  ;;
+esac
+for f in $W/[1-5]_*.log; do echo "$(basename $f): $(grep -c 'WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error' $f || true) reports; $(tail -1 $f | cut -c1-140)"; done
