@@ -80,6 +80,7 @@ void icgs_render(const uint8_t *tex, int tsize, double texels_per_m, const float
                  const double *plane4, const double *e1, const double *e2, uint8_t *out, int stride, int threads) {
     const double *R = pose12, *t = pose12 + 9;
     const double nt = plane4[0] * t[0] + plane4[1] * t[1] + plane4[2] * t[2];
+    const bool pow2 = tsize > 0 && (tsize & (tsize - 1)) == 0;
     auto rows = [&](int y0, int y1) {
         for (int v = y0; v < y1; v++)
             for (int u = 0; u < w; u++) {
@@ -96,11 +97,12 @@ void icgs_render(const uint8_t *tex, int tsize, double texels_per_m, const float
                         double fa = std::floor(a), fb = std::floor(b);
                         double wa = a - fa, wb = b - fb;
                         long ia = (long) fa, ib = (long) fb;
-                        auto T = [&](long i, long j) {
-                            long ii = ((i % tsize) + tsize) % tsize, jj = ((j % tsize) + tsize) % tsize;
-                            return (double) tex[(size_t) jj * tsize + ii];
-                        };
-                        double s = (T(ia, ib) * (1 - wa) + T(ia + 1, ib) * wa) * (1 - wb) + (T(ia, ib + 1) * (1 - wa) + T(ia + 1, ib + 1) * wa) * wb;
+                        // wrap-around texel indices: two wraps per pixel instead of sixteen divisions (a mask when the size is a power of
+                        // two); the same texels and the same arithmetic as T(i, j) = tex[wrap(j)][wrap(i)] at (ia, ib) .. (ia+1, ib+1)
+                        const long i0 = pow2 ? (ia & (tsize - 1)) : ((ia % tsize) + tsize) % tsize, i1 = i0 + 1 == tsize ? 0 : i0 + 1;
+                        const long j0 = pow2 ? (ib & (tsize - 1)) : ((ib % tsize) + tsize) % tsize, j1 = j0 + 1 == tsize ? 0 : j0 + 1;
+                        const uint8_t *r0 = tex + (size_t) j0 * tsize, *r1 = tex + (size_t) j1 * tsize;
+                        double s = ((double) r0[i0] * (1 - wa) + (double) r0[i1] * wa) * (1 - wb) + ((double) r1[i0] * (1 - wa) + (double) r1[i1] * wa) * wb;
                         val = (uint8_t) (s + 0.5);
                     }
                 }
