@@ -94,9 +94,12 @@ void icgs_render(const uint8_t *tex, int tsize, double texels_per_m, const float
                         double px = t[0] + lam * rx, py = t[1] + lam * ry, pz = t[2] + lam * rz;
                         double a = (px * e1[0] + py * e1[1] + pz * e1[2]) * texels_per_m;
                         double b = (px * e2[0] + py * e2[1] + pz * e2[2]) * texels_per_m;
-                        double fa = std::floor(a), fb = std::floor(b);
+                        // floor without the libm call (|a|, |b| are texel coordinates, far below 2^53: the conversions are exact)
+                        long ia = (long) a, ib = (long) b;
+                        if ((double) ia > a) ia--;
+                        if ((double) ib > b) ib--;
+                        double fa = (double) ia, fb = (double) ib;
                         double wa = a - fa, wb = b - fb;
-                        long ia = (long) fa, ib = (long) fb;
                         // wrap-around texel indices: two wraps per pixel instead of sixteen divisions (a mask when the size is a power of
                         // two); the same texels and the same arithmetic as T(i, j) = tex[wrap(j)][wrap(i)] at (ia, ib) .. (ia+1, ib+1)
                         const long i0 = pow2 ? (ia & (tsize - 1)) : ((ia % tsize) + tsize) % tsize, i1 = i0 + 1 == tsize ? 0 : i0 + 1;
