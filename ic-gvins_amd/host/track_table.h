@@ -142,6 +142,7 @@ private:
         int8_t type;
         uint8_t outlier;   // Feature::isOutlier (set by the optimizer's culling, read by the parallax of tracking.cc:873-905)
     };
+    static_assert(sizeof(Row) == 72, "a feature row is 72 bytes (DESIGN.md section 1)");
     struct Frame_ {
         bool alive{false};
         uint32_t gen{0};
@@ -173,6 +174,7 @@ private:
         int32_t observed{0}, used{0};
         LastObs last;
     };
+    static_assert(sizeof(MapPointHot) == 64, "the hot record of a map point is one cache line");
     struct MapPointCold {
         ulong born_fid{0};
         int32_t ref_frame{-1};
