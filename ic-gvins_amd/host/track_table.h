@@ -165,7 +165,7 @@ private:
         uint32_t gen{0};
         int32_t row{-1};
     };
-    struct MapPointHot { // what the per-feature loops touch: one cache line per map point
+    struct alignas(64) MapPointHot { // what the per-feature loops touch: one cache line per map point (aligned: a record never straddles two)
         uint32_t gen{0};
         uint8_t live{0}, outlier{0}, in_map{0};
         int8_t type{0};
