@@ -35,12 +35,12 @@ def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, 
       groups       stream groups (one host thread + HIP stream each).  With the track-table engine a frame costs the host ~20 us of logic, so
                    a group can carry 32-64 streams; round-3 sweep on one MI355X (profiles/r03_group_sweep.txt): 48 x 8 -> 78 k, 24 x 16 -> 92 k,
                    16 x 24 -> 98.6 k, 12 x 32 -> 99.9 k, 8 x 48 -> 100.7 k frames/s with 3.3-3.9 host cores busy; larger launches have shorter
-                   tails: 12 x 64 -> 111.0 k, 16 x 64 -> 111.7 k, 8 x 96 -> 105.5 k (4.2 cores busy).  3 groups per core of the share, between
-                   4 and 12.
+                   tails: 12 x 64 -> 111.0 k, 16 x 64 -> 111.7 k, 8 x 96 -> 105.5 k (4.2 cores busy).  4 groups per core of the share, between
+                   4 and 12 (every thread confined to 2 CPUs, profiles/r03_cpu_quota.md: 8 x 96 -> 44.4 k, 6 x 128 -> 42.1 k frames/s).
       cpu_slice    the contiguous slice of the allowed CPU ids this rank pins itself to (None for a single rank: nothing to separate)
     """
     cores_rank = float(usable_cores) / float(max(1, world))
-    groups = int(groups_override) if groups_override > 0 else int(max(4, min(12, 3 * round(cores_rank))))
+    groups = int(groups_override) if groups_override > 0 else int(max(4, min(12, 4 * round(cores_rank))))
     streams = int(streams_override) if streams_override > 0 else STREAMS_PER_GPU
     groups = max(1, min(groups, streams))
     cpu_slice = None

@@ -62,7 +62,7 @@ def test_host_plan_scales_the_polling_threads_with_the_rank_share():
     assert one["groups"] == 12 and one["streams"] == 768 and one["cpu_slice"] is None
     eight = [sharding.host_plan(16, 8, r, cpu_ids=range(256)) for r in range(8)]
     # weak scaling: the streams of a GPU do not shrink with the world size; only the number of polling threads follows the rank's cores
-    assert all(p["groups"] == 6 and p["streams"] == 768 and abs(p["cores_rank"] - 2.0) < 1e-12 for p in eight)
+    assert all(p["groups"] == 8 and p["streams"] == 768 and abs(p["cores_rank"] - 2.0) < 1e-12 for p in eight)
     slices = [set(p["cpu_slice"]) for p in eight]
     assert all(len(s_) == 32 for s_ in slices) and len(set().union(*slices)) == 256  # disjoint, covering
     big = sharding.host_plan(128, 8, 3, cpu_ids=range(128))
