@@ -181,11 +181,8 @@ int icg_arena_reserve(icg_ctx *ctx, size_t bytes) {
     if (ctx->arena_off != 0) return icg_fail(ctx, ICG_ERR_NOMEM, "arena grow requested mid-call");
     size_t cap = icg_align_up(bytes + bytes / 2, 1 << 16);
     ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int b = 0; b < 2; b++)
-        if (ctx->d_lkc[b]) (void) hipFree(ctx->d_lkc[b]);
-    if (ctx->d_redS) (void) hipFree(ctx->d_redS);
-    if (ctx->d_hostS) (void) hipFree(ctx->d_hostS);
-
+    // only the staging arena pair is replaced here: the LK set-up cache (d_lkc), the resident reduced systems (d_redS) and the
+    // packed host parts (d_hostS) are independent allocations that live until icg_ctx_destroy
     if (ctx->h_arena) (void) hipHostFree(ctx->h_arena);
     if (ctx->d_arena) (void) hipFree(ctx->d_arena);
     ctx->h_arena = nullptr;

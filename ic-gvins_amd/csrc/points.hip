@@ -83,8 +83,8 @@ extern "C" int icg_undistort_points(icg_ctx *ctx, int n, float *pts) {
     float2 *d_in = (float2 *) c.in(pts, 2 * (size_t) n);
     if ((rc = c.seal())) return rc;
     float2 *d_out = (float2 *) c.out(pts, 2 * (size_t) n);
+    ICG_LAUNCH_GUARD(c); // before the device copy: on overflow d_out aliases the staged inputs
     ICG_HIP(ctx, hipMemcpyAsync(d_out, d_in, sizeof(float2) * n, hipMemcpyDeviceToDevice, ctx->stream));
-    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "undistort_points");
         hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_out);
@@ -103,8 +103,8 @@ extern "C" int icg_distort_points(icg_ctx *ctx, int n, float *pts) {
     float2 *d_in = (float2 *) c.in(pts, 2 * (size_t) n);
     if ((rc = c.seal())) return rc;
     float2 *d_out = (float2 *) c.out(pts, 2 * (size_t) n);
+    ICG_LAUNCH_GUARD(c); // before the device copy: on overflow d_out aliases the staged inputs
     ICG_HIP(ctx, hipMemcpyAsync(d_out, d_in, sizeof(float2) * n, hipMemcpyDeviceToDevice, ctx->stream));
-    ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "distort_points");
         hipLaunchKernelGGL(k_distort, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->cam, n, d_out);

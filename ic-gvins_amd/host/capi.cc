@@ -267,30 +267,7 @@ long icgh_batch_dump(icgh_batch *b, int stream, int kind, char *out, long len) {
 // HashOrder (track_table.h) against a real std::unordered_map<ulong, int>: n random distinct keys inserted one by one, the iteration
 // orders compared after every `check_every` insertions.  Returns 0 when they always agree, k > 0 = first disagreement after k insertions.
 int icgh_hashorder_selftest(uint64_t seed, int n, int check_every, int dense_ids) {
-    std::unordered_map<ulong, int> ref;
-    HashOrder h;
-    h.clear();
-    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1;
-    ulong next_id = seed % 1000;
-    for (int k = 0; k < n; k++) {
-        x ^= x << 13, x ^= x >> 7, x ^= x << 17;
-        ulong key = dense_ids ? (next_id += 1 + (x % 3)) : (ulong) (x % 1000003);
-        if (ref.count(key)) {
-            if (h.insert(key)) return k + 1; // duplicates must be refused
-            continue;
-        }
-        ref.emplace(key, (int) h.size());
-        if (!h.insert(key)) return k + 1;
-        if ((k + 1) % check_every == 0 || k + 1 == n) {
-            int r = h.head();
-            for (const auto &kv : ref) {
-                if (r < 0 || r != kv.second) return k + 1;
-                r = h.next(r);
-            }
-            if (r >= 0) return k + 1;
-        }
-    }
-    return 0;
+    return HashOrder::selfTest(seed, n, check_every, dense_ids != 0);
 }
 
 } // extern "C"
@@ -624,6 +601,25 @@ int icgh_batch_set_landmark_pos(icgh_batch *b, int stream, int n, const uint64_t
     return rc;
 }
 
+namespace {
+// Views of the streams' maps (TrackingBatch::Stream::objectMap) that an entry point mutates: committed to the track tables only when the
+// entry point ran to its end (commit()); on an exception or an early error return every view is dropped unabsorbed, so the tables keep the
+// state they had and no later objectMap() sees a half-modified view.
+struct MapViewsGuard {
+    explicit MapViewsGuard(icgh_batch *batch) : b(batch) {}
+    ~MapViewsGuard() {
+        if (done) return;
+        for (int s = 0; s < b->tb->size(); s++) b->tb->stream(s).discardMap();
+    }
+    void commit() {
+        for (int s = 0; s < b->tb->size(); s++) b->tb->stream(s).commitMap();
+        done = true;
+    }
+    icgh_batch *b;
+    bool done{false};
+};
+} // namespace
+
 // WindowCulling over ALL streams of the batch with one device launch.  in_list: per stream the landmark ids that "took part in
 // the optimization" (invdepthlist_), concatenated, list_off[n_streams+1].  mode 0: gvinsOutlierCulling -> out5[s*5..] =
 // outlier mappoints, outlier features, num1, num2, num3;  mode 1: reprojectionStatistics -> stats5[s*5..] = min, max, avg, rms, count
@@ -631,6 +627,7 @@ int icgh_batch_culling(icgh_batch *b, int mode, const int32_t *list_off, const u
                        double *stats5, char *err, int errlen) {
     try {
         const int n = b->tb->size();
+        MapViewsGuard views(b);
         vector<std::unordered_map<ulong, double>> lists((size_t) n);
         vector<WindowCulling::Stream> streams;
         for (int s = 0; s < n; s++) {
@@ -662,7 +659,7 @@ int icgh_batch_culling(icgh_batch *b, int mode, const int32_t *list_off, const u
                 memcpy(stats5 + 5 * s, v, sizeof v);
             }
         }
-        for (int s = 0; s < n; s++) b->tb->stream(s).commitMap(); // (track-table engine: flags, counters and removals go into the table)
+        views.commit(); // (track-table engine: flags, counters and removals go into the table)
         return 0;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());
@@ -679,6 +676,7 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
                               int iters2, double chi2, double *out7, int max_kf, double *kf_out, char *err, int errlen) {
     try {
         const int n = b->tb->size();
+        MapViewsGuard views(b);
         Pose pbc;
         pbc = poseFromArray12(pose_b_c12);
         icg_ctx *ctx = b->tb->group(0).device()->ctx();
@@ -779,7 +777,7 @@ int icgh_batch_refine_windows(icgh_batch *b, const double *pose_b_c12, double td
                     Pose p = wins[(size_t) s]->frame(k)->pose();
                     poseToArray12(p, r + 2);
                 }
-        for (int s = 0; s < n; s++) b->tb->stream(s).commitMap(); // (track-table engine: the write-back and the culling go into the table)
+        views.commit(); // (track-table engine: the write-back and the culling go into the table)
         return 0;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());

@@ -116,7 +116,13 @@ bool runHalves(bool want_overlap, const std::function<bool()> &device, const std
         std::unique_lock<std::mutex> lock(h.owner, std::try_to_lock);
         if (lock.owns_lock()) {
             h.submit(&host);
-            const bool a = device(); // on the calling thread
+            bool a = false;
+            try {
+                a = device(); // on the calling thread
+            } catch (...) {
+                (void) h.wait(g_clock); // the helper still runs `host`, which lives in the caller's frame: join before unwinding
+                throw;
+            }
             const bool b = h.wait(g_clock);
             return a && b;
         }

@@ -8,13 +8,59 @@
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
+#include <string>
 #include <unordered_map>
 
 #include "hostprof.h"
 
+#if !defined(__GLIBCXX__)
+#error "HashOrder reproduces libstdc++'s std::unordered_map node order (bits/hashtable.h); build the table engine with libstdc++"
+#endif
+
 namespace icg {
 
 // ---- HashOrder -------------------------------------------------------------------------------------------------------------
+int HashOrder::selfTest(uint64_t seed, int n, int check_every, bool dense_ids) {
+    std::unordered_map<ulong, int> ref;
+    HashOrder h;
+    h.clear();
+    uint64_t x    = seed * 0x9E3779B97F4A7C15ull + 1;
+    ulong next_id = seed % 1000;
+    for (int k = 0; k < n; k++) {
+        x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+        ulong key = dense_ids ? (next_id += 1 + (x % 3)) : (ulong) (x % 1000003);
+        if (ref.count(key)) {
+            if (h.insert(key)) return k + 1; // duplicates must be refused
+            continue;
+        }
+        ref.emplace(key, (int) h.size());
+        if (!h.insert(key)) return k + 1;
+        if ((k + 1) % check_every == 0 || k + 1 == n) {
+            int r = h.head();
+            for (const auto &kv : ref) {
+                if (r < 0 || r != kv.second) return k + 1;
+                r = h.next(r);
+            }
+            if (r >= 0) return k + 1;
+        }
+    }
+    return 0;
+}
+
+void HashOrder::verifyOnce() {
+    static std::once_flag once;
+    static int bad = 0;
+    std::call_once(once, [] {
+        // a frame holds a few hundred features: 1500 insertions cross six rehashes; dense ids as the id factories hand them out, and
+        // scattered ones (~0.2 ms altogether)
+        bad = selfTest(1, 1500, 50, true);
+        if (!bad) bad = selfTest(2, 1500, 50, false);
+    });
+    if (bad)
+        throw std::runtime_error("HashOrder: this standard library's std::unordered_map iterates differently from the emulation (first "
+                                 "difference after " + std::to_string(bad) + " insertions); use ICG_TRACK_ENGINE=object");
+}
+
 size_t HashOrder::bucketsAfter(size_t k) {
     static const vector<uint32_t> table = [] {
         // ask the standard library itself: bucket_count() after every insertion into a fresh map (insert-only history, which is

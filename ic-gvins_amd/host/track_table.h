@@ -50,6 +50,12 @@ public:
     bool contains(ulong key) const;
     // bucket count after k insertions into a fresh std::unordered_map<ulong, char> of this libstdc++
     static size_t bucketsAfter(size_t k);
+    // n pseudo-random distinct keys inserted one by one into a HashOrder and into a real std::unordered_map<ulong, int>, the iteration
+    // orders compared after every `check_every` insertions: 0 when they always agree, k > 0 = first disagreement after k insertions
+    static int selfTest(uint64_t seed, int n, int check_every, bool dense_ids);
+    // run once per process before the table engine is used: throws when this standard library's container does not iterate the way
+    // HashOrder assumes (the parallax sums and landmark order of the engine would silently leave the reference's order)
+    static void verifyOnce();
 
 private:
     static constexpr int kEmpty = -1, kBeforeBegin = -2;

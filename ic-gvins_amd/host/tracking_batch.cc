@@ -19,6 +19,7 @@ TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &in
         engine        = (e && e[0] == 'o') || cfg.is_use_visualization ? ENGINE_OBJECT : ENGINE_TABLE;
     }
     engine_ = engine == ENGINE_OBJECT ? ENGINE_OBJECT : ENGINE_TABLE;
+    if (engine_ == ENGINE_TABLE) HashOrder::verifyOnce(); // fails loudly if the container order cannot be reproduced here
     device_ = std::make_shared<DeviceContext>(device, size[0], size[1], n_streams, cfg.track_max_features);
     streams_.resize((size_t) n_streams);
     for (int i = 0; i < n_streams; i++) {

@@ -51,8 +51,10 @@ public:
         // The stream's map as reference-shaped objects: the object engine's own map, or a view of the track table (built on first use
         // and kept until commitMap()).  Code that writes to it (optimizer write-back, culling) calls commitMap() when it is done: the
         // table engine takes the changes over (TableTracker::absorb) and drops the view; a no-op for the object engine.
+        // discardMap() drops the view WITHOUT taking anything over (error paths: a half-modified view must not be seen again).
         Map::Ptr objectMap();
         void commitMap();
+        void discardMap() { view_.reset(); }
         std::shared_ptr<TableTracker::ObjectView> view_;
         // statistics / digest
         uint64_t frames{0}, keyframes{0}, tracked_sum{0}, digest{1469598103934665603ull};

@@ -211,3 +211,49 @@ def test_lk_reuse_of_the_backward_template_is_bit_exact(oracle, ctx1280):
         if hints == "regenerated":
             assert h1 == h0, "hints into a re-preprocessed slot were honoured"
         p0, h0 = p1, h1
+
+
+def test_lk_reuse_survives_a_growing_staging_arena(oracle):
+    """icg_arena_reserve used to free the set-up cache (and the resident solver buffers) when the staging arena grew, without
+    resetting their bookkeeping — the next icg_lk_track_fb_reuse then ran on freed memory.  Here the arena of a small context is forced to grow
+    between two chained reuse calls (a long INS series needs more staging than the context was created with); the second call must still
+    return the oracle's bit patterns, with its hints honoured (the cache blocks survived)."""
+    import icgvins
+    w, h = 640, 480
+    c = icgvins.Context(w, h, n_slots=4, max_batch=2, max_points=512, max_factors=16)
+    c.set_camera(synth.CAM_640)
+    try:
+        A = synth.texture(w, h, seed=70)
+        B = synth.shift_image(A, 1.7, -2.1)
+        Cc = synth.shift_image(B, -1.2, 1.6)
+        c.preprocess([0, 1], [A, B])
+        c.preprocess([2], [Cc])
+        b_img, c_img = oracle.clahe(B), oracle.clahe(Cc)
+        pts = synth.random_points(200, w, h, 12, seed=71)
+        n = len(pts)
+        s0, s1, s2 = np.zeros(n, np.int32), np.ones(n, np.int32), np.full(n, 2, np.int32)
+        out1, st1 = c.lk_track_fb_reuse(s0, s1, pts, pts + np.float32([1.5, -2.0]))
+        # ~6 MB of staging for one call: several times the arena of this context (512 points, 16 factors -> ~1.6 MB)
+        n_streams, n_samples = 64, 400
+        offsets = np.arange(n_streams + 1, dtype=np.int32) * n_samples
+        imu = np.zeros((n_streams * n_samples, 8))
+        imu[:, 0] = np.tile(np.arange(1, n_samples + 1) * 0.005, n_streams)
+        imu[:, 1] = 0.005
+        states = np.zeros((n_streams, 23))
+        states[:, 9] = 1.0  # a valid state layout is not needed for this test beyond finite numbers
+        try:
+            c.ins_mechanize_batch(offsets, imu, np.zeros(8), states, want_traj=True)
+        except RuntimeError:
+            pass  # (whatever the INS entry point thinks of these numbers, the arena has grown by then)
+        guess2 = out1 + np.float32([-1.0, 1.5])
+        exp_pts, exp_st = oracle.lk_track_fb(b_img, c_img, out1, guess2)
+        idx = np.arange(n, dtype=np.int32)
+        idx[st1 == 0] = -1
+        p0, h0 = c.lk_reuse_stats()
+        got_pts, got_st = c.lk_track_fb_reuse(s1, s2, out1, guess2, prev_index=idx)
+        p1, h1 = c.lk_reuse_stats()
+        assert np.array_equal(got_st, exp_st)
+        assert np.array_equal(got_pts.view(np.uint32), exp_pts.view(np.uint32))
+        assert h1 - h0 == int((st1 != 0).sum())
+    finally:
+        c.close()
