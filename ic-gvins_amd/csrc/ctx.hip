@@ -142,7 +142,7 @@ extern "C" void icg_ctx_destroy(icg_ctx *ctx) {
     for (auto e : ctx->ev_pool) (void) hipEventDestroy(e);
     if (ctx->ev_wait) (void) hipEventDestroy(ctx->ev_wait);
     void *dev[] = {ctx->d_frames, ctx->d_raw,     ctx->d_bgr,  ctx->d_lut,      ctx->d_histmean,
-                   ctx->d_mask,   ctx->d_roi_max, ctx->d_cand, ctx->d_cand_cnt, ctx->d_arena,    ctx->d_obs,
+                   ctx->d_roi_max, ctx->d_cand, ctx->d_cand_cnt, ctx->d_arena,    ctx->d_obs,
                    ctx->d_fidx,   ctx->d_rJ,      ctx->d_params,   ctx->d_sys,
                    ctx->d_fwin,   ctx->d_lmwin};
     for (void *p : dev)

@@ -9,14 +9,14 @@
 // selection; sub-pixel refinement with sequential double accumulation (bit-identical to the CPU restatement).
 //
 // Kernels (HBM/L2-bound stencils, no MFMA shape):
-//   k_mask_discs  one workgroup per existing feature: midpoint-circle span table -> zero spans in the u8 mask
-//   k_min_eig_nms 60x16 tile per wave streamed down the image columns: response (separable exact box sums), per-ROI masked
-//                 maximum by an order-preserving uint atomicMax, 3x3 NMS + mask in registers -> every local maximum
-//                 (key = response bits << 32 | raster index) appended per ROI; no response plane in HBM
-//   k_select      one workgroup per ROI: quality threshold 0.01*max, then repeated block-wide arg-max over live candidates +
-//                 min-distance kill (equivalent to sort + greedy grid test, needs no sort and no capacity cap)
-//   k_subpix      one wavefront per corner: 13x13 bilinear patch and the 121 gradient terms in parallel through LDS,
-//                 the five 121-term sums each sequentially in raster order (IEEE order == CPU order), one lane per sum
+//   k_min_eig_nms 60x16 tile per wave streamed down the image columns: the mask of the tile from the DISC LIST (no mask plane: the
+//                 existing features whose discs reach the tile are found by the wave itself), response (separable exact box
+//                 sums), per-ROI masked maximum by an order-preserving uint atomicMax, 3x3 NMS + mask in registers -> every local
+//                 maximum (key = response bits << 32 | raster index) appended per ROI; no response plane in HBM
+//   k_select_subpix  one workgroup of 16 waves per ROI: quality threshold 0.01*max, repeated block-wide arg-max over live candidates
+//                 + min-distance kill (equivalent to sort + greedy grid test, needs no sort and no capacity cap), then a wave per
+//                 picked corner: 13x13 bilinear patch and the 121 gradient terms in parallel through LDS, the five 121-term sums
+//                 each sequentially in raster order (IEEE order == CPU order), one lane per sum
 #include <cfloat>
 
 #include "icg_internal.h"
@@ -35,35 +35,15 @@ __device__ __forceinline__ float f32_from_order_key(unsigned int k) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// The mask plane is GENERATION-TAGGED: a pixel is masked in this call iff mask[p] == gen (gen cycles 1..255 per context;
-// the plane is cleared only when gen wraps).  This removes the 0.9 MB-per-frame memset launch of the 255/0 formulation.
-// One 64-lane workgroup per existing feature; each lane fills whole rows of the midpoint-circle span table with
-// dword stores (head/tail bytes) instead of testing every pixel of the bounding square.
-__global__ __launch_bounds__(64) void k_mask_discs(int n_pts, const float2 *pts, const int32_t *pt_job, int radius,
-                                                   const int32_t *halfw /*radius+1*/, uint8_t *mask, int pitch, int w,
-                                                   int h, size_t plane, unsigned int gen) {
-    const int i = blockIdx.x;
-    if (i >= n_pts) return;
-    const float2 p = pts[i];
-    const int cx = (int) rintf(p.x), cy = (int) rintf(p.y);
-    uint8_t *m   = mask + (size_t) pt_job[i] * plane;
-    const unsigned int g4 = gen * 0x01010101u;
-    for (int r = threadIdx.x; r <= 2 * radius; r += 64) {
-        const int dy = r - radius, y = cy + dy;
-        if (y < 0 || y >= h) continue;
-        const int hw = halfw[dy < 0 ? -dy : dy];
-        if (hw < 0) continue;
-        int x0 = cx - hw, x1 = cx + hw; // inclusive span
-        if (x0 < 0) x0 = 0;
-        if (x1 > w - 1) x1 = w - 1;
-        uint8_t *row = m + (size_t) y * pitch;
-        int x = x0;
-        for (; x <= x1 && (x & 3); x++) row[x] = (uint8_t) gen;
-        for (; x + 3 <= x1; x += 4) *reinterpret_cast<unsigned int *>(row + x) = g4; // pitch % 128 == 0: aligned
-        for (; x <= x1; x++) row[x] = (uint8_t) gen;
-    }
-}
-
+// The mask (tracking.cc:609-620: a 255-plane with a filled cv::circle of radius track_min_pixel_distance_ zeroed at every existing feature)
+// is never materialised.  Rounds 1-3 wrote it as a byte plane (k_mask_discs: 0.9 MB per frame written in spans and read back by the
+// detector, 1.4-1.6 us per frame of pure HBM time and a launch); now every wave of k_min_eig_nms tests its 60 x 16 tile against the
+// discs directly.  A pixel (x, y) is masked iff some feature centre (cx, cy) = (rint(px), rint(py)) has |x - cx| <= halfw[|y - cy|],
+// halfw = the span table of OpenCV's midpoint circle (drawing.cpp Circle(), circle_halfwidths below).  That table is non-increasing in
+// |dy| (checked on the host when it is built), so per COLUMN distance a = |x - cx| the masked rows are the interval |y - cy| <= vh[a] with
+// vh[a] = max{dy : halfw[dy] >= a}: one LDS lookup and a 16-bit interval mask per (lane, disc) instead of 16 span tests.  The wave finds
+// the discs that reach its tile itself: the job's ~300 centres in chunks of 64 (a lane each, bounding-box test, ballot), then a
+// wave-uniform loop over the hits with the centre moved to SGPRs by readlane.
 // ---------------------------------------------------------------------------------------------------------
 // k_min_eig_nms: Shi-Tomasi response, masked per-ROI maximum AND the 3x3 non-maximum test in ONE pass over the u8 image —
 // the f32 response plane of the two-kernel formulation (4 B/px written by k_min_eig, 4 B/px re-read by k_candidates) is
@@ -87,6 +67,7 @@ __global__ __launch_bounds__(64) void k_mask_discs(int n_pts, const float2 *pts,
 #define FE_TW 60    // NMS output columns per wave
 #define FE_TH 16    // NMS output rows per wave
 #define FE_WAVES 4  // waves per workgroup, stacked vertically
+#define FE_MAX_RADIUS 1022 // largest disc radius the LDS span table holds (min_dist; 45 at C2)
 
 // lane i <- lane i-1 / lane i+1 across the whole wave (wave_shr:1 / wave_shl:1); the edge lanes receive 0 and are halo
 __device__ __forceinline__ float from_left(float v) {
@@ -97,20 +78,25 @@ __device__ __forceinline__ float from_right(float v) {
 }
 
 __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
-                                                               const int32_t *slots, int pitch, int w, int h, const uint8_t *mask,
-                                                               size_t mask_plane, unsigned int gen, unsigned int *roi_max,
+                                                               const int32_t *slots, int pitch, int w, int h, const float2 *mask_pts,
+                                                               const int32_t *mask_off, int radius, const int32_t *vspan /*radius+2*/,
+                                                               unsigned int *roi_max,
                                                                unsigned long long *cand, size_t cand_plane, int32_t *cand_cnt,
                                                                int gx, int gy, int n_blocks, unsigned int m_roi, unsigned int m_gx) {
     // 1-D launch, ROI-major and XCD-chunked: the tiles of a ROI (and of a frame) share one XCD's L2
     const int bl = icg_xcd_chunked(blockIdx.x, n_blocks);
     if (bl >= n_blocks) return;
+    // vh[a], a = 0..radius, and vh[radius+1] = -1 for every column further away; staged before the first wave may leave (the only barrier)
+    __shared__ int vh[FE_MAX_RADIUS + 2];
+    for (int a = threadIdx.x; a < radius + 2; a += 64 * FE_WAVES) vh[a] = vspan[a];
+    __syncthreads();
     const int roi = icg_div_by_magic(bl, m_roi), rem = bl - roi * (gx * gy);
     const int by = icg_div_by_magic(rem, m_gx), bx = rem - by * gx;
     const det_roi R = rois[roi];
     const int lane = threadIdx.x & 63;
     const int wv   = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // wave-uniform by construction: keep it in an SGPR
     const int tx0 = bx * FE_TW, ty0 = (by * FE_WAVES + wv) * FE_TH;
-    if (tx0 >= R.rw || ty0 >= R.rh) return; // wave-uniform; there is no barrier in this kernel
+    if (tx0 >= R.rw || ty0 >= R.rh) return; // wave-uniform; there is no barrier below this line
     const uint8_t *img = frames + (size_t) slots[R.job] * slot_bytes;
     const float s      = (float) (1.0 / 3060.0);
 
@@ -123,24 +109,40 @@ __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *ro
     const unsigned int sha = 8u * (unsigned int) (ca - base), shb = 8u * (unsigned int) (X - base), shc = 8u * (unsigned int) (cc - base);
     const bool own_col  = lane >= 2 && lane <= FE_TW + 1 && xcol < R.rw;   // columns whose responses this tile owns
     const bool nms_col  = own_col && xcol >= 1 && xcol < R.rw - 1;
-    const uint8_t *mroi = mask + (size_t) R.job * mask_plane + (size_t) R.ry * pitch; // wave-uniform; + row*pitch + mx per lane
-    const int mx        = R.rx + xcol;
+    const int mx        = R.rx + xcol; // image column of the lane
     unsigned long long *cbase = cand + (size_t) R.job * cand_plane + R.cand_base;
 
     // the mask first: existing features blank discs of radius min_dist, which cover most of a tracked image — a tile whose owned pixels
     // are ALL masked can neither raise the ROI maximum nor produce a candidate and leaves before any image byte is read
     unsigned int unmasked = 0; // bit k: the owned response of tile row k is not masked
     {
-        uint8_t mk[FE_TH];
-        const int mxs = own_col ? mx : R.rx;
-#pragma unroll
-        for (int k = 0; k < FE_TH; k++) {
-            const int yc = min(ty0 + k, R.rh - 1);
-            mk[k]        = (mroi + (size_t) yc * pitch)[mxs]; // unconditional (halo lanes read a valid column): no per-load branch
+        const int ytop = R.ry + ty0;                          // image row of tile row 0
+        const int xl = R.rx + tx0, xr = xl + FE_TW - 1;        // image columns of the owned lanes
+        const int p0 = mask_off[R.job], p1 = mask_off[R.job + 1];
+        unsigned int masked = 0;
+        for (int pb = p0; pb < p1; pb += 64) {
+            const int i = pb + lane;
+            int cx = 0, cy = 0;
+            bool hit = false;
+            if (i < p1) {
+                const float2 p = mask_pts[i];
+                cx  = (int) rintf(p.x); // cvRound of the key point (tracking.cc:613, 618)
+                cy  = (int) rintf(p.y);
+                hit = cx + radius >= xl && cx - radius <= xr && cy + radius >= ytop && cy - radius <= ytop + FE_TH - 1;
+            }
+            unsigned long long m = __ballot(hit);
+            while (m) { // wave-uniform
+                const int l = __ffsll((long long) m) - 1;
+                m &= m - 1;
+                const int ccx = __builtin_amdgcn_readlane(cx, l), ccy = __builtin_amdgcn_readlane(cy, l);
+                const int adx = abs(mx - ccx);
+                const int v   = vh[min(adx, radius + 1)]; // rows |y - ccy| <= v of this column are inside the disc (-1: none)
+                const int lo = max(ccy - v - ytop, 0), hi = min(ccy + v - ytop, FE_TH - 1);
+                if (v >= 0 && lo <= hi) masked |= ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+            }
         }
-#pragma unroll
-        for (int k = 0; k < FE_TH; k++)
-            if (mk[k] != (uint8_t) gen && ty0 + k < R.rh) unmasked |= 1u << k;
+        const int rows  = min(R.rh - ty0, FE_TH); // tile rows inside the ROI (>= 1 here)
+        unmasked        = ~masked & ((1u << rows) - 1u);
         if (!own_col) unmasked = 0;
     }
     if (__ballot(unmasked != 0) == 0) return; // wave-uniform
@@ -235,97 +237,30 @@ __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *ro
 
 // ---------------------------------------------------------------------------------------------------------
 #define DET_MAX_PER_BLOCK 64
+#define SEL_WAVES 16 // waves per ROI workgroup: selection on all of them, then one corner per wave
 
-__global__ __launch_bounds__(256) void k_select(const det_roi *rois, unsigned long long *cand, size_t cand_plane,
-                                                int32_t *cand_cnt, unsigned int *roi_max, int min_dist,
-                                                float2 *corners /*roi x max_pb*/, int32_t *corner_cnt, int32_t *corner_cnt_host, int max_pb) {
-    __shared__ unsigned long long wbest[4];
-    __shared__ unsigned long long best;
-    const det_roi R = rois[blockIdx.x];
-    unsigned long long *C = cand + (size_t) R.job * cand_plane + R.cand_base;
-    const int n = cand_cnt[blockIdx.x];
-    const int t = threadIdx.x;
-    const double md2 = (double) min_dist * (double) min_dist;
-    int quota = R.quota < max_pb ? R.quota : max_pb;
-    int acc   = 0;
-    {
-        // quality level (featureselect.cpp: threshold(eig, eig, maxVal*qualityLevel, 0, THRESH_TOZERO)): k_min_eig_nms appended
-        // every unmasked local maximum, the ones that are not above 0.01 * (masked ROI maximum) are dropped here
-        const unsigned int mk = roi_max[blockIdx.x];
-        const double maxVal   = mk ? (double) f32_from_order_key(mk) : 0.0;
-        const float thresh    = (float) (maxVal * 0.01);
-        for (int i = t; i < n; i += 256)
-            if (!(f32_from_order_key((unsigned int) (C[i] >> 32)) > thresh)) C[i] = 0;
-        __syncthreads();
-    }
-    while (acc < quota) {
-        unsigned long long k = 0;
-        for (int i = t; i < n; i += 256) {
-            unsigned long long c = C[i];
-            k                    = c > k ? c : k;
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            unsigned long long o = __shfl_xor(k, m, 64);
-            k                    = o > k ? o : k;
-        }
-        if ((t & 63) == 0) wbest[t >> 6] = k;
-        __syncthreads();
-        if (t == 0) {
-            unsigned long long b = wbest[0];
-            for (int i = 1; i < 4; i++) b = wbest[i] > b ? wbest[i] : b;
-            best = b;
-        }
-        __syncthreads();
-        const unsigned long long b = best;
-        if (b == 0) break; // no live candidate left
-        const int idx = (int) (b & 0xffffffffu);
-        const int by = idx / R.rw, bx = idx - by * R.rw;
-        if (t == 0) corners[(size_t) blockIdx.x * max_pb + acc] = make_float2((float) bx, (float) by);
-        acc++;
-        if (min_dist >= 1) {
-            for (int i = t; i < n; i += 256) {
-                unsigned long long c = C[i];
-                if (!c) continue;
-                int ci = (int) (c & 0xffffffffu);
-                int cy = ci / R.rw, cx = ci - cy * R.rw;
-                float dx = (float) (cx - bx), dy = (float) (cy - by);
-                if (c == b || (double) (dx * dx + dy * dy) < md2) C[i] = 0;
-            }
-        } else {
-            for (int i = t; i < n; i += 256)
-                if (C[i] == b) C[i] = 0;
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-        corner_cnt[blockIdx.x]      = acc; // device copy: read by every k_subpix workgroup of the ROI
-        corner_cnt_host[blockIdx.x] = acc; // the caller's copy, written straight into its pinned staging memory (no D2H launch)
-        // the ROI's accumulators are consumed (every thread read them before the first barrier above): leave them zero for the next call,
-        // which then needs neither a memset nor an upload of zeros
-        roi_max[blockIdx.x]  = 0;
-        cand_cnt[blockIdx.x] = 0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 struct subpix_mask_t {
     float m[121];
 };
 
-__global__ __launch_bounds__(64) void k_subpix(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
-                                               const int32_t *slots, int pitch, const float2 *corners, float2 *corners_host,
-                                               const int32_t *corner_cnt, int max_pb, subpix_mask_t M) {
-    __shared__ float patch[13][13];
-    __shared__ double terms[121][5];
-    __shared__ float cur[2];
-    __shared__ int stop;
-    const int roi = blockIdx.x / max_pb, ci = blockIdx.x - roi * max_pb;
-    if (ci >= corner_cnt[roi]) return;
-    const det_roi R    = rois[roi];
-    const uint8_t *img = frames + (size_t) slots[R.job] * slot_bytes;
-    const int lane     = threadIdx.x;
-    const float2 cT    = corners[(size_t) roi * max_pb + ci];
+struct subpix_smem { // per wave
+    double terms[121][5];
+    float patch[13][13];
+    float cur[2];
+    int stop;
+};
+
+// LDS ordering inside ONE wave: the LDS queue is in order, the compiler must not reorder across the point
+#define DET_WAVE_SYNC()                                         \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  \
+        __builtin_amdgcn_wave_barrier();                        \
+    } while (0)
+
+// cv::cornerSubPix (App. B.8) of ONE corner on one wave: 13x13 bilinear patch and the 121 gradient terms in parallel through the wave's
+// LDS block, the five 121-term sums each sequentially in raster order (IEEE order == CPU order), one lane per sum.
+__device__ __forceinline__ float2 subpix_corner(subpix_smem &S, const det_roi &R, const uint8_t *img, int pitch, const float2 cT, int lane,
+                                                const subpix_mask_t &M) {
     float cIx = cT.x, cIy = cT.y;
     int iter = 0;
     while (true) {
@@ -340,66 +275,150 @@ __global__ __launch_bounds__(64) void k_subpix(const det_roi *rois, const uint8_
             const uint8_t *p0 = img + (size_t) (R.ry + y0) * pitch + R.rx;
             const uint8_t *p1 = img + (size_t) (R.ry + y1) * pitch + R.rx;
             float s00 = p0[x0], s01 = p0[x1], s10 = p1[x0], s11 = p1[x1];
-            patch[r][c] = s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11;
+            S.patch[r][c] = s00 * w00 + s01 * w01 + s10 * w10 + s11 * w11;
         }
-        __syncthreads();
+        DET_WAVE_SYNC();
         for (int i = lane; i < 121; i += 64) {
             int r = i / 11, c = i - r * 11;
             double m   = M.m[i];
-            double tgx = patch[r + 1][c + 2] - patch[r + 1][c];
-            double tgy = patch[r + 2][c + 1] - patch[r][c + 1];
+            double tgx = S.patch[r + 1][c + 2] - S.patch[r + 1][c];
+            double tgy = S.patch[r + 2][c + 1] - S.patch[r][c + 1];
             double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
             double px = c - 5, py = r - 5;
-            terms[i][0] = gxx;
-            terms[i][1] = gxy;
-            terms[i][2] = gyy;
-            terms[i][3] = gxx * px + gxy * py;
-            terms[i][4] = gxy * px + gyy * py;
+            S.terms[i][0] = gxx;
+            S.terms[i][1] = gxy;
+            S.terms[i][2] = gyy;
+            S.terms[i][3] = gxx * px + gxy * py;
+            S.terms[i][4] = gxy * px + gyy * py;
         }
-        __syncthreads();
+        DET_WAVE_SYNC();
         // the five 121-term sums keep the CPU's sequential raster order, but run side by side on lanes 0..4
         double acc = 0;
         if (lane < 5) {
 #pragma unroll 11
-            for (int i = 0; i < 121; i++) acc += terms[i][lane];
+            for (int i = 0; i < 121; i++) acc += S.terms[i][lane];
         }
         const double a = __shfl(acc, 0, 64), b = __shfl(acc, 1, 64), c = __shfl(acc, 2, 64);
         const double bb1 = __shfl(acc, 3, 64), bb2 = __shfl(acc, 4, 64);
-        if (lane == 0) {
-            int st     = 0;
-            double det = a * c - b * b;
-            if (fabs(det) <= DBL_EPSILON * DBL_EPSILON) {
-                st = 1; // break before updating
-            } else {
-                double scale = 1.0 / det;
-                float c2x    = (float) (cIx + c * scale * bb1 - b * scale * bb2);
-                float c2y    = (float) (cIy - b * scale * bb1 + a * scale * bb2);
-                double err   = (double) ((c2x - cIx) * (c2x - cIx) + (c2y - cIy) * (c2y - cIy));
-                cur[0]       = c2x;
-                cur[1]       = c2y;
-                if (c2x < 0 || c2x >= R.rw || c2y < 0 || c2y >= R.rh)
-                    st = 2;
-                else if (!(iter + 1 < 20 && err > 0.01 * 0.01))
-                    st = 2;
-            }
-            stop = st;
+        // every lane evaluates the (wave-uniform) update: no LDS round trip for the decision
+        int st     = 0;
+        float c2x = cIx, c2y = cIy;
+        double det = a * c - b * b;
+        if (fabs(det) <= DBL_EPSILON * DBL_EPSILON) {
+            st = 1; // break before updating
+        } else {
+            double scale = 1.0 / det;
+            c2x          = (float) (cIx + c * scale * bb1 - b * scale * bb2);
+            c2y          = (float) (cIy - b * scale * bb1 + a * scale * bb2);
+            double err   = (double) ((c2x - cIx) * (c2x - cIx) + (c2y - cIy) * (c2y - cIy));
+            if (c2x < 0 || c2x >= R.rw || c2y < 0 || c2y >= R.rh)
+                st = 2;
+            else if (!(iter + 1 < 20 && err > 0.01 * 0.01))
+                st = 2;
         }
-        __syncthreads();
-        const int st = stop;
         if (st != 1) {
-            cIx = cur[0];
-            cIy = cur[1];
+            cIx = c2x;
+            cIy = c2y;
         }
         ++iter;
-        __syncthreads();
+        DET_WAVE_SYNC(); // the next iteration overwrites patch / terms
         if (st) break;
     }
-    if (lane == 0) {
-        if (fabsf(cIx - cT.x) > 5 || fabsf(cIy - cT.y) > 5) {
-            cIx = cT.x;
-            cIy = cT.y;
+    if (fabsf(cIx - cT.x) > 5 || fabsf(cIy - cT.y) > 5) {
+        cIx = cT.x;
+        cIy = cT.y;
+    }
+    return make_float2(cIx, cIy);
+}
+
+// One workgroup of SEL_WAVES waves per ROI (round 4: k_select + k_subpix in one launch).
+//   phase 1  quality threshold 0.01 * (masked ROI maximum), then repeated block-wide arg-max over the live candidates + min-distance
+//            kill (equivalent to featureselect.cpp's sort + greedy grid test; needs no sort and no capacity cap); the picks go to LDS
+//   phase 2  wave k refines picks k, k + SEL_WAVES, ... (cornerSubPix) and writes them straight into the call's pinned staging memory
+__global__ __launch_bounds__(64 * SEL_WAVES) void k_select_subpix(const det_roi *rois, unsigned long long *cand, size_t cand_plane,
+                                                                  int32_t *cand_cnt, unsigned int *roi_max, int min_dist,
+                                                                  const uint8_t *frames, size_t slot_bytes, const int32_t *slots, int pitch,
+                                                                  float2 *corners_host /*roi x max_pb*/, int32_t *corner_cnt_host, int max_pb,
+                                                                  subpix_mask_t M) {
+    __shared__ unsigned long long wbest[SEL_WAVES];
+    __shared__ unsigned long long best;
+    __shared__ float2 picked[DET_MAX_PER_BLOCK];
+    __shared__ subpix_smem SP[SEL_WAVES];
+    constexpr int NT = 64 * SEL_WAVES;
+    const det_roi R = rois[blockIdx.x];
+    unsigned long long *C = cand + (size_t) R.job * cand_plane + R.cand_base;
+    const int n = cand_cnt[blockIdx.x];
+    const int t = threadIdx.x;
+    const double md2 = (double) min_dist * (double) min_dist;
+    int quota = R.quota < max_pb ? R.quota : max_pb;
+    int acc   = 0;
+    {
+        // quality level (featureselect.cpp: threshold(eig, eig, maxVal*qualityLevel, 0, THRESH_TOZERO)): k_min_eig_nms appended
+        // every unmasked local maximum, the ones that are not above 0.01 * (masked ROI maximum) are dropped here
+        const unsigned int mk = roi_max[blockIdx.x];
+        const double maxVal   = mk ? (double) f32_from_order_key(mk) : 0.0;
+        const float thresh    = (float) (maxVal * 0.01);
+        for (int i = t; i < n; i += NT)
+            if (!(f32_from_order_key((unsigned int) (C[i] >> 32)) > thresh)) C[i] = 0;
+        __syncthreads();
+    }
+    while (acc < quota) {
+        unsigned long long k = 0;
+        for (int i = t; i < n; i += NT) {
+            unsigned long long c = C[i];
+            k                    = c > k ? c : k;
         }
-        corners_host[(size_t) roi * max_pb + ci] = make_float2(cIx, cIy); // pinned staging memory of the call (zero-copy result)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            unsigned long long o = __shfl_xor(k, m, 64);
+            k                    = o > k ? o : k;
+        }
+        if ((t & 63) == 0) wbest[t >> 6] = k;
+        __syncthreads();
+        if (t < 64) {
+            unsigned long long b = t < SEL_WAVES ? wbest[t] : 0ull;
+#pragma unroll
+            for (int m = SEL_WAVES / 2; m >= 1; m >>= 1) {
+                unsigned long long o = __shfl_xor(b, m, 64);
+                b                    = o > b ? o : b;
+            }
+            if (t == 0) best = b;
+        }
+        __syncthreads();
+        const unsigned long long b = best;
+        if (b == 0) break; // no live candidate left
+        const int idx = (int) (b & 0xffffffffu);
+        const int by = idx / R.rw, bx = idx - by * R.rw;
+        if (t == 0) picked[acc] = make_float2((float) bx, (float) by);
+        acc++;
+        if (min_dist >= 1) {
+            for (int i = t; i < n; i += NT) {
+                unsigned long long c = C[i];
+                if (!c) continue;
+                int ci = (int) (c & 0xffffffffu);
+                int cy = ci / R.rw, cx = ci - cy * R.rw;
+                float dx = (float) (cx - bx), dy = (float) (cy - by);
+                if (c == b || (double) (dx * dx + dy * dy) < md2) C[i] = 0;
+            }
+        } else {
+            for (int i = t; i < n; i += NT)
+                if (C[i] == b) C[i] = 0;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        corner_cnt_host[blockIdx.x] = acc; // the caller's copy, written straight into its pinned staging memory (no D2H launch)
+        // the ROI's accumulators are consumed (every thread read them before the first barrier above): leave them zero for the next call,
+        // which then needs neither a memset nor an upload of zeros
+        roi_max[blockIdx.x]  = 0;
+        cand_cnt[blockIdx.x] = 0;
+    }
+    __syncthreads(); // picked[] complete (also after the break: every thread leaves the loop in the same round)
+    const int wv = t >> 6, lane = t & 63;
+    const uint8_t *img = frames + (size_t) slots[R.job] * slot_bytes;
+    for (int ci = wv; ci < acc; ci += SEL_WAVES) {
+        const float2 r = subpix_corner(SP[wv], R, img, pitch, picked[ci], lane, M);
+        if (lane == 0) corners_host[(size_t) blockIdx.x * max_pb + ci] = r; // pinned staging memory of the call (zero-copy result)
     }
 }
 
@@ -421,12 +440,23 @@ static void circle_halfwidths(int radius, std::vector<int32_t> &hw) {
     }
 }
 
+// vh[a] = max{dy : halfw[dy] >= a} for a = 0..radius, vh[radius+1] = -1: the rows of a disc column (see the note on the mask above).
+// Returns false if the span table is not non-increasing (then the interval form would not describe the disc; cannot happen for a circle)
+static bool circle_row_spans(const std::vector<int32_t> &hw, std::vector<int32_t> &vh) {
+    const int radius = (int) hw.size() - 1;
+    vh.assign((size_t) radius + 2, -1);
+    for (int a = 0; a <= radius; a++)
+        for (int dy = 0; dy <= radius; dy++)
+            if (hw[(size_t) dy] >= a) vh[(size_t) a] = dy;
+    for (int a = 0; a <= radius; a++)
+        for (int dy = 0; dy <= radius; dy++)
+            if ((hw[(size_t) dy] >= a) != (dy <= vh[(size_t) a])) return false;
+    return true;
+}
+
 static int ensure_detect_ws(icg_ctx *ctx) {
-    if (ctx->d_mask) return 0;
+    if (ctx->d_cand) return 0;
     const size_t w = ctx->cfg.width, h = ctx->cfg.height, nb = ctx->cfg.max_batch;
-    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_mask, (size_t) ctx->lv[0].pitch * h * nb));
-    ICG_HIP(ctx, hipMemsetAsync(ctx->d_mask, 0, (size_t) ctx->lv[0].pitch * h * nb, ctx->stream));
-    ctx->mask_gen = 0;
     ICG_HIP(ctx, hipMalloc((void **) &ctx->d_cand, sizeof(unsigned long long) * w * h * nb));
     return 0;
 }
@@ -442,7 +472,7 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     const int nblk = grid->block_cols * grid->block_rows;
     if (nblk <= 0 || grid->block_w <= 6 || grid->block_h <= 6 || grid->block_cols * grid->block_w > w ||
         grid->block_rows * grid->block_h > h || grid->min_dist < 0 || grid->max_per_block <= 0 ||
-        grid->max_per_block > DET_MAX_PER_BLOCK)
+        grid->max_per_block > DET_MAX_PER_BLOCK || grid->min_dist > FE_MAX_RADIUS)
         return icg_fail(ctx, ICG_ERR_INVALID, "bad detection grid");
     for (int k = 0; k < n; k++)
         if (slots[k] < 0 || slots[k] >= ctx->cfg.n_slots) return icg_fail(ctx, ICG_ERR_INVALID, "bad slot");
@@ -480,14 +510,14 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     if (n_roi == 0) return ICG_OK;
     const int max_pb = grid->max_per_block;
 
-    std::vector<int32_t> hw;
+    std::vector<int32_t> hw, vh;
     circle_halfwidths(grid->min_dist, hw);
-    std::vector<int32_t> pt_job((size_t) n_mask);
+    if (!circle_row_spans(hw, vh)) return icg_fail(ctx, ICG_ERR_INVALID, "circle span table of radius %d is not monotone", grid->min_dist);
     for (int b = 0; b < n; b++)
-        for (int i = mask_off[b]; i < mask_off[b + 1]; i++) pt_job[i] = b;
+        if (mask_off[b] < 0 || mask_off[b] > mask_off[b + 1]) return icg_fail(ctx, ICG_ERR_INVALID, "mask_off is not non-decreasing");
 
     icg_call c(ctx);
-    size_t need = sizeof(det_roi) * n_roi + sizeof(int32_t) * (n + hw.size() + n_mask) + sizeof(float) * 2 * n_mask +
+    size_t need = sizeof(det_roi) * n_roi + sizeof(int32_t) * (2 * (size_t) n + 1 + vh.size()) + sizeof(float) * 2 * n_mask +
                   2 * (sizeof(float2) * max_pb + 16) * (size_t) n_roi + 8192;
     if ((rc = c.reserve(need))) return rc;
     // Every small array of the call is read or written by the kernels in the call's pinned staging memory (zero-copy over PCIe): one
@@ -495,9 +525,10 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     // launch on a busy hardware queue costs ~75-100 us whatever its size (profiles/r02_queue_view.json).
     const det_roi *d_rois  = c.in_zc(rois.data(), (size_t) n_roi);
     const int32_t *d_slots = c.in_zc(slots, (size_t) n);
-    const int32_t *d_hw    = c.in_zc(hw.data(), hw.size());
-    const float2 *d_mpts   = (const float2 *) c.in_zc(mask_pts, 2 * (size_t) n_mask);
-    const int32_t *d_ptjob = c.in_zc(pt_job.data(), (size_t) n_mask);
+    // the disc centres are read by every wave of the job's ROIs (48 per ROI): device copy, not zero-copy
+    const int32_t *d_vh    = c.in(vh.data(), vh.size());
+    const float2 *d_mpts   = (const float2 *) c.in(mask_pts, 2 * (size_t) n_mask);
+    const int32_t *d_moff  = c.in(mask_off, (size_t) n + 1);
     // [roi_max | cand_cnt] per ROI live in the context and are zero between calls (k_select clears the entries it consumed)
     if (n_roi > ctx->roi_state_cap) {
         ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -516,37 +547,18 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     if ((rc = c.seal())) return rc;
     std::vector<float> h_corners((size_t) n_roi * max_pb * 2);
     std::vector<int32_t> h_cnt((size_t) n_roi);
-    // selected corners and their counts are re-read by k_subpix: device scratch; the refined corners and the counts the caller needs
-    // are written by the kernels into the staging memory directly
-    float2 *d_corners  = (float2 *) c.out((float *) nullptr, (size_t) n_roi * max_pb * 2);
-    int32_t *d_cnt     = c.out((int32_t *) nullptr, (size_t) n_roi);
+    // the refined corners and the counts are written by the kernel into the staging memory directly
     float2 *z_corners  = (float2 *) c.out_zc(h_corners.data(), (size_t) n_roi * max_pb * 2);
     int32_t *z_cnt     = c.out_zc(h_cnt.data(), (size_t) n_roi);
 
-    const size_t mask_plane = (size_t) pitch * h, cand_plane = (size_t) w * h;
-    // mask generation (see k_mask_discs): a full clear only when the 8-bit tag wraps
-    if (++ctx->mask_gen > 255) {
-        ICG_HIP(ctx, hipMemsetAsync(ctx->d_mask, 0, mask_plane * ctx->cfg.max_batch, ctx->stream));
-        ctx->mask_gen = 1;
-    }
-    const unsigned int gen = (unsigned int) ctx->mask_gen;
+    const size_t cand_plane = (size_t) w * h;
     ICG_LAUNCH_GUARD(c);
-    if (n_mask > 0) {
-        icg_prof_scope ps(ctx, "detect_mask");
-        hipLaunchKernelGGL(k_mask_discs, dim3(n_mask), dim3(64), 0, ctx->stream, n_mask, d_mpts, d_ptjob, grid->min_dist,
-                           d_hw, ctx->d_mask, pitch, w, h, mask_plane, gen);
-    }
     {
         icg_prof_scope ps(ctx, "detect_min_eig_nms");
         const int gx = (grid->block_w + FE_TW - 1) / FE_TW, gy = (grid->block_h + FE_TH * FE_WAVES - 1) / (FE_TH * FE_WAVES);
         hipLaunchKernelGGL(k_min_eig_nms, dim3(icg_xcd_grid(gx * gy * n_roi)), dim3(64 * FE_WAVES), 0, ctx->stream, d_rois, ctx->d_frames,
-                           ctx->slot_bytes, d_slots, pitch, w, h, ctx->d_mask, mask_plane, gen, d_rmax, ctx->d_cand, cand_plane, d_ccnt,
+                           ctx->slot_bytes, d_slots, pitch, w, h, d_mpts, d_moff, grid->min_dist, d_vh, d_rmax, ctx->d_cand, cand_plane, d_ccnt,
                            gx, gy, gx * gy * n_roi, icg_div_magic(gx * gy), icg_div_magic(gx));
-    }
-    {
-        icg_prof_scope ps(ctx, "detect_select");
-        hipLaunchKernelGGL(k_select, dim3(n_roi), dim3(256), 0, ctx->stream, d_rois, ctx->d_cand, cand_plane, d_ccnt, d_rmax,
-                           grid->min_dist, d_corners, d_cnt, z_cnt, max_pb);
     }
     {
         subpix_mask_t M;
@@ -558,9 +570,9 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
                 M.m[i * 11 + j] = (float) (vy * std::exp(-x * x));
             }
         }
-        icg_prof_scope ps(ctx, "detect_subpix");
-        hipLaunchKernelGGL(k_subpix, dim3(n_roi * max_pb), dim3(64), 0, ctx->stream, d_rois, ctx->d_frames, ctx->slot_bytes,
-                           d_slots, pitch, (const float2 *) d_corners, z_corners, d_cnt, max_pb, M);
+        icg_prof_scope ps(ctx, "detect_select_subpix");
+        hipLaunchKernelGGL(k_select_subpix, dim3(n_roi), dim3(64 * SEL_WAVES), 0, ctx->stream, d_rois, ctx->d_cand, cand_plane, d_ccnt, d_rmax,
+                           grid->min_dist, ctx->d_frames, ctx->slot_bytes, d_slots, pitch, z_corners, z_cnt, max_pb, M);
     }
     ICG_HIP(ctx, hipGetLastError());
     if ((rc = c.finish())) return rc;

@@ -51,8 +51,6 @@ struct icg_ctx {
     double *d_histmean = nullptr; // max_batch
 
     // detection workspace (lazily allocated)
-    uint8_t *d_mask       = nullptr; // max_batch x pitch0 x h, generation-tagged (masked iff == mask_gen)
-    int mask_gen          = 0;
     uint32_t *d_roi_max   = nullptr;
     unsigned long long *d_cand = nullptr;
     int32_t *d_cand_cnt   = nullptr;

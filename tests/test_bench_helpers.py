@@ -81,3 +81,40 @@ def test_stale_counter_summaries_are_not_quoted(tmp_path, monkeypatch):
     assert "changed" in b.pmc_provenance("r09_pmc_summary.json", 32.0)
     (prof / "r08_pmc_summary.json").write_text(json.dumps({"k_lk_track_fb": {}}))
     assert "no provenance" in b.pmc_provenance("r08_pmc_summary.json", 32.0)
+
+
+def test_whole_path_fraction_and_event_rates():
+    """roofline.frac_whole_path = SURVEY 8(d)'s bytes per frame x frames/s of one GPU / peak (8.66 MB x 97.5 k / 8 TB/s
+    = 0.106 for round 3's driver line); event rates per frame from the work counters."""
+    b = _bench()
+    assert abs(b.frame_bytes(1280, 720, 300) - 8.664e6) < 1e3            # C2
+    assert abs(b.frame_bytes(640, 480, 100) - 2.888e6) < 1e3             # C1
+    assert abs(b.frame_bytes(1920, 1080, 500) - 18.01e6) < 1e4           # C4
+    assert abs(b.whole_path_fraction(1280, 720, 300, 97549.8, 8000.0) - 0.1056) < 5e-4
+    r = b.event_rates({"lk_points": 58000, "lk_calls": 4, "detect_jobs": 150, "detect_calls": 4, "ransac_sets": 180, "ransac_calls": 9,
+                       "frames": 200, "tri_points": 700}, keyframes=90, mappoints=640, frames=200)
+    assert r == {"keyframes_per_frame": 0.45, "detections_per_frame": 0.75, "ransac_sets_per_frame": 0.9, "triangulated_points_per_frame": 3.5,
+                 "mappoints_created_per_frame": 3.2, "lk_points_per_frame": 290.0}
+
+
+def test_contract_line_carries_the_round4_honesty_fields():
+    """frac on the exclusive duration with the under-load figure beside it, frac_whole_path, the forward-only control with both runs' event
+    rates, and pcie_inclusive as a named configuration variant — all in the compact line, which still fits the driver's 8 KB tail."""
+    b = _bench()
+    committed = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("r02_bench_driver_command"))
+    full = json.load(open(os.path.join(ROOT, "profiles", committed[-1])))
+    full["parity"] = {"ok": True}
+    rates = {"keyframes_per_frame": 0.5, "detections_per_frame": 1.0, "ransac_sets_per_frame": 1.0, "triangulated_points_per_frame": 20.0,
+             "mappoints_created_per_frame": 18.0, "lk_points_per_frame": 290.0}
+    full["roofline"].update({"achieved": 437.6, "frac": 0.0547, "achieved_exclusive": 437.6, "frac_exclusive": 0.0547, "achieved_under_load": 141.6,
+                             "frac_under_load": 0.0177, "frac_whole_path": 0.1071, "bytes_per_frame_algorithmic": 8664000, "exclusive_us": 373.7})
+    full["rates"] = rates
+    full["forward_control"] = {"value": 30000.0, "unit": "frames/s", "streams": 96, "groups": 12, "timed_steps": 40, "frames_per_stream": 84,
+                               "rates": rates, "rates_pingpong_headline": rates, "tracking_state_fraction": 1.0, "note": "x" * 300}
+    full["pcie_inclusive"].update({"config": {"workload": "C2", "streams_per_gpu": 384, "groups_per_gpu": 12, "input_residency": "pinned host"},
+                                   "frac_whole_path": 0.055})
+    c = b.compact_line(full, None)
+    assert len(json.dumps(c)) < 8000
+    assert c["roofline"]["frac"] == 0.0547 and c["roofline"]["frac_under_load"] == 0.0177 and c["roofline"]["frac_whole_path"] == 0.1071
+    assert c["forward_control"]["rates"] == rates and c["rates"] == rates and "note" not in c["forward_control"]
+    assert c["pcie_inclusive"]["config"]["input_residency"] == "pinned host"

@@ -122,27 +122,41 @@ def test_triangulate_matches_oracle(oracle, ctx1280):
     assert np.median(np.abs(got - X)) < 0.5  # ~1 px of noise at 6-40 m depth
 
 
-def test_detect_mask_generation_wraps(oracle):
-    """The detection mask is generation-tagged (8-bit tag, cleared only when it wraps): results must stay identical to
-    the CPU restatement across the wrap, with a different mask every call."""
+def test_detect_disc_list_mask(oracle):
+    """The detection mask is never written as a plane (round 4): every wave of k_min_eig_nms tests its tile against the list of disc
+    centres.  Results must equal the CPU restatement (which draws cv::circle into a byte mask) for masks that change every call: centres
+    on half-pixel ties (cvRound: ties to even), outside the image, on the image border, clustered inside one tile, more than 64 centres
+    (several ballot chunks), and two jobs with different lists in one call (mask_off)."""
     import icgvins
     w, h = 640, 480
-    c = icgvins.Context(w, h, n_slots=1, max_batch=1, max_points=256)
+    c = icgvins.Context(w, h, n_slots=2, max_batch=2, max_points=256)
     try:
-        img = synth.texture(w, h, seed=83)
-        c.preprocess([0], [img])
-        clahe = oracle.clahe(img)
+        img0, img1 = synth.texture(w, h, seed=83), synth.texture(w, h, seed=183)
+        c.preprocess([0, 1], [img0, img1])
+        clahe = [oracle.clahe(img0), oracle.clahe(img1)]
         grid = grid_for(w, h, 100)
         q = np.full(6, grid[5], np.int32)
         rng = np.random.RandomState(5)
-        for call in range(262):  # crosses generation 255 -> 1
-            m = rng.uniform([20, 20], [w - 20, h - 20], (3 + call % 5, 2)).astype(np.float32)
-            out, cnt, blk = c.detect([0], grid, [0, len(m)], m, q, 200)
-            if call in (0, 1, 2, 100) or call >= 252:
-                exp_pts, exp_blk = oracle.detect(clahe, grid, m, q, 200)
-                assert cnt[0] == len(exp_pts), call
-                assert np.array_equal(blk[0, :cnt[0]], exp_blk), call
-                assert np.array_equal(out[0, :cnt[0]].view(np.uint32), exp_pts.view(np.uint32)), call
+
+        def one_mask(kind):
+            if kind == 0:
+                return rng.uniform([20, 20], [w - 20, h - 20], (3 + rng.randint(5), 2))
+            if kind == 1:  # ties and borders
+                return np.array([[100.5, 50.5], [101.5, 51.5], [0.0, 0.0], [w - 1, h - 1], [w - 0.5, 200.5], [320.5, 0.49]])
+            if kind == 2:  # outside the image, reaching in (and not)
+                return np.array([[-30.0, 100.0], [w + 25.0, 300.0], [200.0, -39.0], [250.0, h + 38.9], [-500.0, -500.0], [w + 41.0, 20.0]])
+            if kind == 3:  # a cluster inside one 60 x 16 tile + scattered
+                return np.concatenate([rng.uniform([300, 200], [330, 210], (12, 2)), rng.uniform([0, 0], [w, h], (10, 2))])
+            return rng.uniform([-10, -10], [w + 10, h + 10], (150, 2))  # three ballot chunks
+
+        for call in range(15):
+            m0, m1 = one_mask(call % 5).astype(np.float32), one_mask((call + 2) % 5).astype(np.float32)
+            out, cnt, blk = c.detect([0, 1], grid, [0, len(m0), len(m0) + len(m1)], np.concatenate([m0, m1]), np.concatenate([q, q]), 200)
+            for job, m in ((0, m0), (1, m1)):
+                exp_pts, exp_blk = oracle.detect(clahe[job], grid, m, q, 200)
+                assert cnt[job] == len(exp_pts), (call, job)
+                assert np.array_equal(blk[job, :cnt[job]], exp_blk), (call, job)
+                assert np.array_equal(out[job, :cnt[job]].view(np.uint32), exp_pts.view(np.uint32)), (call, job)
     finally:
         c.close()
 

@@ -70,3 +70,46 @@ def test_host_plan_scales_the_polling_threads_with_the_rank_share():
     tiny = sharding.host_plan(4, 8, 0, cpu_ids=range(4))
     assert tiny["groups"] == 4 and tiny["streams"] == 768 and tiny["cpu_slice"]
     assert sharding.host_plan(16, 1, 0, groups_override=8, streams_override=64)["groups"] == 8
+
+
+def _run_bench_selftest(world, streams, port, details):
+    """bench.py's own main() as the driver launches it (python -m torch.distributed.run ... bench.py --gpus N ...), in its CPU plumbing
+    self-test mode (ICG_BENCH_SELFTEST_ORACLE=1: gloo + the oracle-backed checker build of the host layer; value is null by construction)"""
+    import json
+    import subprocess
+    env = dict(os.environ, ICG_BENCH_SELFTEST_ORACLE="1", MASTER_ADDR="127.0.0.1")
+    tiny = ["--steps", "3", "--warmup", "1", "--width", "320", "--height", "240", "--features", "60", "--streams", str(streams),
+            "--groups", "2", "--ring", "6", "--prime", "4", "--details", details]
+    bench = os.path.join(ROOT, "bench.py")
+    if world == 1:
+        cmd = [sys.executable, bench, "--gpus", "1"] + tiny
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), bench, "--gpus", str(world)] + tiny
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE json line
+    return json.loads(lines[0])
+
+
+def test_bench_main_runs_two_ranks_as_the_driver_launches_it(tmp_path):
+    """the N>1 path of bench.py ITSELF — env ranks, per-rank CPU slice, ring sizing, priming, warm-up, the barrier-bracketed
+    timed region, MAX over ranks, the terminal exchange (all-reduce of counters, all-gather of digests) and the contract line — executed as
+    written with two gloo ranks, and checked for placement invariance against the same main() as ONE rank owning all four streams."""
+    from stream_utils import ensure_oracle_host
+    ensure_oracle_host()
+    port = 29900 + (os.getpid() % 90)
+    two = _run_bench_selftest(2, 2, port, str(tmp_path / "two.json"))
+    one = _run_bench_selftest(1, 4, port + 1, str(tmp_path / "one.json"))
+    for line, n in ((two, 2), (one, 1)):
+        assert line["value"] is None and "selftest" in line  # never a measurement
+        assert line["n_gpus"] == n and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+        assert line["selftest"]["frames"] == 4 * 3                       # all ranks' frames of the timed region, summed
+        assert line["quality"]["tracking_state_fraction"] == 1.0
+        assert line["ms_per_step"] > 0 and line["selftest"]["elapsed_max_s"] > 0
+    assert two["config"]["streams_per_gpu"] == 2 and two["config"]["frames_per_step"] == 4 and "pinned" in two["config"]["cpu_slice_per_rank"]
+    # rank order of the gathered digests = global stream order: the same four streams, wherever they ran
+    # (the gathered digests travel as int64: 63 bits)
+    assert two["selftest"]["digests"] == [d & 0x7fffffffffffffff for d in one["selftest"]["digests"]]
+    assert two["selftest"]["tracked_mappoints"] == one["selftest"]["tracked_mappoints"]

@@ -103,3 +103,19 @@ def test_fm_ransac_mask(oracle, G, tag):
     ok, mask, _, _ = oracle.fm_ransac(G[f"{tag}_fm_p1"], G[f"{tag}_fm_p2"], 1.5, 0.99)
     assert ok == 1
     assert np.array_equal(mask, G[f"{tag}_fm_mask"])
+
+
+@pytest.mark.gpu
+def test_hip_path_against_real_opencv_on_the_gpu_box(G):
+    """Selected by `-m gpu`, so the GPU summary carries the marker too: while the golden is absent this SKIPS (visible as `1 skipped` with the
+    reason above) — on the GPU lease there is no cv2, no wheel in /opt/wheelhouse, no pip index, no apt source and no network either
+    (profiles/r04_opencv_probe.txt, one gpurun call of round 4).  With the golden present: the HIP preprocessing against OpenCV's CLAHE."""
+    import icgvins
+    a, b, w, h = _inputs("c2")
+    c = icgvins.Context(w, h, n_slots=2, max_batch=2, max_points=512)
+    try:
+        c.preprocess([0, 1], [a, b])
+        assert np.array_equal(c.download(0, 0), G["c2_clahe_a"])
+        assert np.array_equal(c.download(1, 0), G["c2_clahe_b"])
+    finally:
+        c.close()
