@@ -1,0 +1,1358 @@
+// Tracker core: the front-end state machine of ONE camera stream (tracking/tracking.cc:144-245 and everything it calls between the
+// device primitives) as plain functions over a fixed-layout POD state, compiled TWICE from this one source:
+//   * by hipcc for gfx950 (csrc/tracker.hip): the stage kernels of the device-resident tracker — the stream's rows, map points, candidate
+//     lists and window live in HBM, a wave per stream runs the stage body between two device primitives, the primitives (preprocess, LK,
+//     RANSAC, triangulation, detection) read their work lists where the stage body left them; the host neither builds lists nor waits
+//     between stages (round 4);
+//   * by g++ (host/track_core_engine.cc): the same bodies behind the staged interface of TrackingBatch, on the oracle-backed checker build
+//     and on the product's host layer — the CPU-side twin that pins the core against the track table (host/track_table.cc), which is
+//     itself pinned bit for bit against the reference's own tracking.cc (tests/golden/tracking_ref_*.npz).
+// The state is the track table's, member for member (track_table.h): 72-byte feature rows in insertion order with the reference
+// container's iteration order (HashOrder: libstdc++'s unordered_map node list and rehash policy), 64-byte map-point records with
+// generation handles, observations as (frame, row), the window as (key, frame) pairs, frames freed by mark-and-sweep over the roots the
+// reference's shared_ptrs form.  Capacities are compile-time (a stream is one flat block: upload / download / snapshot are memcpy);
+// exceeding one sets Stream::overflow and the executor fails loudly.
+//
+// Every function cites the reference lines it follows; the floating-point expressions are written out operation by operation (both
+// compilers run with -ffp-contract=off), so the two builds and the track table produce the same bits.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TC_FN __host__ __device__ inline
+#else
+#include <math.h>
+#define TC_FN inline
+#endif
+
+namespace tc {
+
+typedef unsigned long long u64;
+
+// ---- capacities ------------------------------------------------------------------------------------------------------------------
+constexpr int MAX_ROWS    = 640;   // features of one frame (C4: 500 + the detector's rounding slack), candidates, points of one LK call
+constexpr int MAX_BUCKETS = 1109;  // libstdc++ bucket count after MAX_ROWS insertions (13, 29, 59, 127, 257, 541, 1109)
+constexpr int MAX_FRAMES  = 28;    // live frames: window (<= 16 keyframes + 1) + cur / pre / ref / pending + candidates' reference frames
+constexpr int MAX_MPS     = 8192;  // map-point pool (live landmarks of the window + the not yet inserted ones)
+constexpr int MAX_WINDOW  = 18;    // keyframes in the map (window size + 1, rounded up)
+constexpr int MAX_BLOCKS  = 64;    // detection grid blocks (C4: 50)
+constexpr int MAX_TCW     = 12;    // distinct camera matrices of one triangulation call (current + reference frames of the candidates)
+constexpr int LOG_CAP     = 4096;  // landmark insert / erase log between two host drains
+constexpr int MAX_SLOTS   = 4;     // frame slots a stream owns on the device (pre / cur / ref / incoming)
+
+enum { TRACK_FIRST_FRAME = 0, TRACK_INITIALIZING = 1, TRACK_TRACKING = 2, TRACK_PASSED = 3, TRACK_LOST = 4 }; // tracking.h:38-44
+enum { KEYFRAME_NONE = 0, KEYFRAME_REMOVE_SECOND_NEW = 1, KEYFRAME_NORMAL = 2, KEYFRAME_REMOVE_OLDEST = 3 }; // frame.h:36-41
+enum { FEATURE_MATCHED = 0, FEATURE_TRIANGULATED = 1 };
+enum { MAPPOINT_TRIANGULATED = 0 }; // mappoint.h:36-42
+enum { M_NONE = 0, M_FIRST = 1, M_INIT = 2, M_TRACK = 3 };
+enum { OVF_ROWS = 1, OVF_FRAMES = 2, OVF_MPS = 4, OVF_TCW = 8, OVF_LOG = 16, OVF_WINDOW = 32, OVF_SLOTS = 64, OVF_INTERNAL = 128 };
+
+// ---- records (layouts shared with track_table.h: static_asserts there and here) -----------------------------------------------------
+struct P2f {
+    float x, y;
+};
+struct Row { // one Feature (feature.h:41-118)
+    u64 id;
+    uint32_t mp, mpgen;
+    P2f kp, kpd;
+    double vel[2];
+    double pcx, pcy;
+    int32_t lk_idx;
+    int8_t type;
+    uint8_t outlier;
+    uint8_t pad_[2];
+};
+static_assert(sizeof(Row) == 72, "feature row");
+struct LastObs {
+    int32_t frame;
+    uint32_t gen;
+    int32_t row;
+};
+struct alignas(64) MpHot {
+    uint32_t gen;
+    uint8_t live, outlier, in_map;
+    int8_t type;
+    u64 id;
+    double pos[3];
+    int32_t observed, used;
+    LastObs last;
+};
+static_assert(sizeof(MpHot) == 64, "hot map-point record");
+struct MpCold {
+    u64 born_fid;
+    int32_t ref_frame;
+    uint32_t ref_gen;
+    P2f ref_kp;
+    double depth;
+    int32_t optimized;
+    int32_t pad_;
+};
+static_assert(sizeof(MpCold) == 40, "cold map-point record");
+struct MpRef {
+    uint32_t i, g;
+};
+struct Pose {
+    double R[9]; // row-major
+    double t[3];
+};
+
+struct Frame {
+    int32_t alive;
+    uint32_t gen;
+    u64 fid, kf_id;
+    double stamp;
+    Pose pose;
+    int32_t is_kf, kf_state, slot;
+    u64 image; // address of the frame's raw image as the caller handed it in (host or device memory); only the B2 view needs it
+    // rows in insertion order + the container order of the reference's features_ (HashOrder)
+    int32_t n_rows, head, n_buckets, n_unupd;
+    u64 magic;
+    Row row[MAX_ROWS];
+    int32_t next[MAX_ROWS];
+    int32_t bucket[MAX_BUCKETS];
+    uint32_t unupd[MAX_ROWS], unupd_gen[MAX_ROWS]; // frame.h unupdated_mappoints_
+};
+
+struct LmLog { // Map::landmarks_ operation history since the last drain: the host replays it into its container (track_table.h map_lm_)
+    u64 id;
+    uint32_t mp;
+    int32_t op; // 1 insert, 0 erase
+};
+
+// ---- configuration (constant per batch) ----------------------------------------------------------------------------------------------
+struct Cam {
+    double fx, fy, cx, cy, skew, k1, k2, p1, p2, k3;
+    int32_t width, height;
+};
+struct Cfg {
+    Cam cam;
+    int32_t track_max_features, check_histogram, window_size, pad0_;
+    double track_min_parallax, reprojection_error_std, track_max_interval /* x 0.95 (tracking.cc:57) */;
+    int32_t block_cols, block_rows, block_cnts, block_w, block_h, max_block_features, min_pixel_distance, max_per_job;
+    u64 stream_id_base; // unused by the algorithm (per-stream id spaces start at 0); kept for the executor
+};
+
+// ---- per-stream I/O with the device primitives (the executor points these at the stream's segment of the group arenas) -----------------
+struct Io {
+    // F1 preprocess
+    int32_t *pre_slot;     // [1] slot the incoming frame is preprocessed into (-1: no frame this step)
+    const double *pre_hist; // [1] mean brightness of the raw frame (histogram gate), valid when Cfg::check_histogram
+    // F2/F3/F4 LK forward-backward + undistortion
+    int32_t *lk_count;      // [1]
+    int32_t *lk_prev_slot, *lk_next_slot; // [MAX_ROWS]
+    P2f *lk_prev, *lk_guess;              // [MAX_ROWS]
+    const P2f *lk_out, *lk_undist;        // [MAX_ROWS]
+    const uint8_t *lk_status;             // [MAX_ROWS]
+    int32_t lk_base;                      // index of this stream's first point in the group's LK call (set-up reuse hints)
+    // F6 RANSAC (one set per stream)
+    int32_t *rs_count; // [1] 0: no set
+    P2f *rs_p1, *rs_p2;
+    const uint8_t *rs_mask;
+    // F8 triangulation
+    int32_t *tri_count, *tri_n_tcw;
+    int32_t *tri_T0, *tri_T1; // [MAX_ROWS] indices into this stream's tri_Tcw table
+    double *tri_Tcw;          // [MAX_TCW][12]
+    double *tri_pc0, *tri_pc1; // [MAX_ROWS][3]
+    const double *tri_pw;      // [MAX_ROWS][3]
+    // F7 detection (one job per stream)
+    int32_t *det_slot;     // [1] -1: no job
+    int32_t *det_quota;    // [block_cnts]
+    int32_t *det_mask_count;
+    P2f *det_mask_pts;     // [MAX_ROWS]
+    const int32_t *det_count;
+    const P2f *det_out;    // [max_per_job]
+};
+
+// ---- the stream --------------------------------------------------------------------------------------------------------------------
+struct Stream {
+    // id factories (frame.cc:37-53, mappoint.cc:45-49): one id space per stream
+    u64 frame_id, keyframe_id, mappoint_id;
+    // tracker roles (handles into frame[]; -1 = none)
+    int32_t cur, ref, pre, last_keyframe, pending, latest_keyframe, det_frame;
+    int32_t overflow;
+    // frame pool
+    int32_t n_frames, n_free_frames;
+    int32_t free_frames[MAX_FRAMES];
+    // map (tracking/map.cc)
+    int32_t n_map_kf, is_window_full, n_landmarks, pad1_;
+    u64 map_kf_key[MAX_WINDOW];
+    int32_t map_kf_frame[MAX_WINDOW];
+    // tracker scalars (tracking.h:117-160)
+    double parallax_map, parallax_ref, histogram;
+    int32_t parallax_map_counts, parallax_ref_counts, isnewkeyframe, isinitializing, passed_cnt;
+    // per-frame staged state
+    int32_t done, result, pending_slot, mode, det_job, det_ismask, lk_map_begin, lk_map_n, lk_ref_begin, lk_ref_n, ref_tracked, rs_set, kf_state,
+        tri_queued, lost_reset, tri_begin;
+    u64 last_input_fid;
+    int32_t n_owned, owned_slots[MAX_SLOTS + 1], n_free_slots, free_slots[MAX_SLOTS];
+    // candidate lists (tracking.h:129-136) and their carried twins; every list keeps its own length, as the vectors of the table do
+    int32_t n_cur, n_new, n_ref, n_ref_undis, n_new_undis, n_ref_frame, n_cand_lk, n_vel_ref, n_vel_cur, n_tracked, n_matched, n_tr_new_undis,
+        n_tr_cur_undis, n_tri_status, n_tri_index, n_tri_ref_undis, n_tri_cur_undis;
+    P2f pts2d_cur[MAX_ROWS], pts2d_new[MAX_ROWS], pts2d_ref[MAX_ROWS], pts2d_ref_undis[MAX_ROWS], pts2d_new_undis[MAX_ROWS];
+    int32_t pts2d_ref_frame[MAX_ROWS], cand_lk_idx[MAX_ROWS];
+    double velocity_ref[MAX_ROWS][2], velocity_cur[MAX_ROWS][2];
+    MpRef tracked_mappoint[MAX_ROWS], mappoint_matched[MAX_ROWS];
+    double tm_pc[MAX_ROWS][2];
+    P2f tr_new_undis[MAX_ROWS], tr_cur_undis[MAX_ROWS], tri_ref_undis[MAX_ROWS], tri_cur_undis[MAX_ROWS], scratch_a[MAX_ROWS];
+    int32_t tri_point_index[MAX_ROWS];
+    uint8_t tri_status[MAX_ROWS], status[MAX_ROWS];
+    int32_t order_idx[MAX_ROWS];
+    int32_t scratch_bucket[MAX_BUCKETS];
+    // statistics / digest (TrackingBatch::Stream)
+    u64 frames, keyframes, tracked_sum, digest;
+    int32_t last_state, pad2_;
+    // landmark container history
+    int32_t n_log, log_dropped;
+    LmLog log[LOG_CAP];
+    // pools
+    int32_t n_mps, n_free_mps;
+    uint32_t free_mps[MAX_MPS];
+    MpHot hot[MAX_MPS];
+    MpCold cold[MAX_MPS];
+    Frame frame[MAX_FRAMES];
+};
+
+// ---- small math, written out (types.h / model.h twins) ---------------------------------------------------------------------------------
+TC_FN double tc_sqrt(double v) { return sqrt(v); }
+TC_FN double tc_fabs(double v) { return fabs(v); }
+
+TC_FN void mat_mul_t(const double *A, const double *B, double *out) { // A^T * B (Matrix3d::transpose() then operator*)
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) out[i * 3 + j] = A[0 * 3 + i] * B[0 * 3 + j] + A[1 * 3 + i] * B[1 * 3 + j] + A[2 * 3 + i] * B[2 * 3 + j];
+}
+TC_FN void world2cam(const double *pw, const Pose &pose, double *pc) { // camera.cc:145-147: pose.R^T * (world - pose.t)
+    const double d0 = pw[0] - pose.t[0], d1 = pw[1] - pose.t[1], d2 = pw[2] - pose.t[2];
+    const double *R = pose.R;
+    pc[0] = R[0] * d0 + R[3] * d1 + R[6] * d2;
+    pc[1] = R[1] * d0 + R[4] * d1 + R[7] * d2;
+    pc[2] = R[2] * d0 + R[5] * d1 + R[8] * d2;
+}
+TC_FN void pixel2cam(const Cam &c, const P2f &p, double &x, double &y) { // camera.cc:123-127
+    y = (p.y - c.cy) / c.fy;
+    x = (p.x - c.cx - c.skew * y) / c.fx;
+}
+TC_FN P2f cam2pixel(const Cam &c, double X, double Y, double Z) { // camera.cc:129-131
+    P2f r;
+    r.x = (float) ((c.fx * X + c.skew * Y) / Z + c.cx);
+    r.y = (float) (c.fy * Y / Z + c.cy);
+    return r;
+}
+TC_FN P2f world2pixel(const Cam &c, const double *pw, const Pose &pose) {
+    double pc[3];
+    world2cam(pw, pose, pc);
+    return cam2pixel(c, pc[0], pc[1], pc[2]);
+}
+TC_FN void distortPoint(const Cam &c, P2f &pp) { // camera.cc:91-102
+    double x, y;
+    pixel2cam(c, pp, x, y);
+    const double r2 = x * x + y * y;
+    const double rr = (1 + c.k1 * r2 + c.k2 * r2 * r2 + c.k3 * r2 * r2 * r2);
+    const double xd = x * rr + 2 * c.p1 * x * y + c.p2 * (r2 + 2 * x * x);
+    const double yd = y * rr + c.p1 * (r2 + 2 * y * y) + 2 * c.p2 * x * y;
+    pp              = cam2pixel(c, xd, yd, 1.0);
+}
+TC_FN P2f distortCameraPoint(const Cam &c, double X, double Y, double Z) { // camera.cc:104-117
+    const double x = X / Z, y = Y / Z;
+    const double r2 = x * x + y * y;
+    const double rr = (1 + c.k1 * r2 + c.k2 * r2 * r2 + c.k3 * r2 * r2 * r2);
+    const double a  = (double) (float) (x * rr + 2 * c.p1 * x * y + c.p2 * (r2 + 2 * x * x));
+    const double b  = (double) (float) (y * rr + c.p1 * (r2 + 2 * y * y) + 2 * c.p2 * x * y);
+    return cam2pixel(c, a, b, 1.0);
+}
+// cv::undistortPoints(pts, pts, K, D, noArray, K) for one point (model.cc Camera::undistortPoints, csrc/dev_camera.h)
+TC_FN P2f undistortPoint(const Cam &c, const P2f &p) {
+    const double ifx = 1. / c.fx, ify = 1. / c.fy;
+    double x = p.x, y = p.y;
+    const double u = x, v = y;
+    x               = (x - c.cx) * ifx;
+    y               = (y - c.cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2     = x * x + y * y;
+        const double icdist = 1. / (1 + ((c.k3 * r2 + c.k2) * r2 + c.k1) * r2);
+        if (icdist < 0) {
+            x = (u - c.cx) * ifx;
+            y = (v - c.cy) * ify;
+            break;
+        }
+        const double deltaX = 2 * c.p1 * x * y + c.p2 * (r2 + 2 * x * x);
+        const double deltaY = c.p1 * (r2 + 2 * y * y) + 2 * c.p2 * x * y;
+        x                   = (x0 - deltaX) * icdist;
+        y                   = (y0 - deltaY) * icdist;
+    }
+    P2f r;
+    r.x = (float) (c.fx * x + c.skew * y + c.cx);
+    r.y = (float) (c.fy * y + c.cy);
+    return r;
+}
+TC_FN double focalLength(const Cam &c) { return (c.fx + c.fy) * 0.5; }
+
+// ---- HashOrder (track_table.cc: bits/hashtable.h _M_insert_unique_node / _M_insert_bucket_begin / _M_rehash_aux) ---------------------
+constexpr int H_EMPTY = -1, H_BEFORE_BEGIN = -2;
+
+TC_FN u64 mulhi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64) (((unsigned __int128) a * b) >> 64);
+#endif
+}
+TC_FN u64 modMagic(u64 n) { return 0xFFFFFFFFFFFFFFFFull / n + 1; }
+TC_FN int bucketOf(u64 key, int n, u64 M) {
+    if ((key >> 32) != 0) return (int) (key % (u64) n);
+    const u64 low = M * (u64) (uint32_t) key;
+    return (int) mulhi64(low, (u64) n);
+}
+TC_FN void order_clear(Frame &f) {
+    f.n_rows    = 0;
+    f.head      = -1;
+    f.n_buckets = 1;
+    f.bucket[0] = H_EMPTY;
+    f.magic     = 0; // (M for one bucket is 2^64: wraps to 0, and the fastmod of any key is 0 — the right bucket)
+}
+TC_FN int order_next_of(const Frame &f, int prev) { return prev == H_BEFORE_BEGIN ? f.head : f.next[prev]; }
+TC_FN void order_set_next(Frame &f, int prev, int i) {
+    if (prev == H_BEFORE_BEGIN)
+        f.head = i;
+    else
+        f.next[prev] = i;
+}
+TC_FN bool order_contains(const Frame &f, u64 key) {
+    const int n = f.n_buckets, b = bucketOf(key, n, f.magic);
+    const int prev = f.bucket[b];
+    if (prev == H_EMPTY) return false;
+    for (int p = order_next_of(f, prev); p >= 0 && bucketOf(f.row[p].id, n, f.magic) == b; p = f.next[p])
+        if (f.row[p].id == key) return true;
+    return false;
+}
+TC_FN void order_rehash(Frame &f, int n, int32_t *scratch) {
+    for (int b = 0; b < n; b++) scratch[b] = H_EMPTY;
+    const u64 M = modMagic((u64) n);
+    int p = f.head;
+    f.head = -1;
+    int bbegin_bkt = 0;
+    while (p >= 0) {
+        const int nx = f.next[p];
+        const int b  = bucketOf(f.row[p].id, n, M);
+        if (scratch[b] == H_EMPTY) {
+            f.next[p]  = f.head;
+            f.head     = p;
+            scratch[b] = H_BEFORE_BEGIN;
+            if (f.next[p] >= 0) scratch[bbegin_bkt] = p;
+            bbegin_bkt = b;
+        } else {
+            const int prev = scratch[b];
+            f.next[p]      = order_next_of(f, prev);
+            order_set_next(f, prev, p);
+        }
+        p = nx;
+    }
+    for (int b = 0; b < n; b++) f.bucket[b] = scratch[b];
+    f.n_buckets = n;
+    f.magic     = modMagic((u64) n);
+}
+// row index n_rows (the caller has filled f.row[n_rows].id) enters the container order; buckets_after[k] = bucket count of a fresh
+// std::unordered_map<ulong, char> after k insertions (HashOrder::bucketsAfter)
+TC_FN void order_insert_unique(Frame &f, const uint32_t *buckets_after, int32_t *scratch) {
+    const int i    = f.n_rows;
+    const int want = (int) buckets_after[i + 1];
+    if (want != f.n_buckets) order_rehash(f, want, scratch);
+    const int n = f.n_buckets, b = bucketOf(f.row[i].id, n, f.magic);
+    f.next[i]   = -1;
+    if (f.bucket[b] != H_EMPTY) {
+        const int prev = f.bucket[b];
+        f.next[i]      = order_next_of(f, prev);
+        order_set_next(f, prev, i);
+    } else {
+        f.next[i] = f.head;
+        f.head    = i;
+        if (f.next[i] >= 0) f.bucket[bucketOf(f.row[f.next[i]].id, n, f.magic)] = i;
+        f.bucket[b] = H_BEFORE_BEGIN;
+    }
+    f.n_rows = i + 1;
+}
+
+// ---- pools (track_table.cc) ----------------------------------------------------------------------------------------------------------
+TC_FN bool mp_valid(const Stream &S, uint32_t i, uint32_t g) { return S.hot[i].live && S.hot[i].gen == g; }
+TC_FN void mp_release(Stream &S, uint32_t i) {
+    S.hot[i].live = 0;
+    S.hot[i].gen++;
+    S.free_mps[S.n_free_mps++] = i;
+}
+TC_FN uint32_t mp_alloc(Stream &S) {
+    uint32_t i;
+    if (S.n_free_mps > 0) {
+        i = S.free_mps[--S.n_free_mps];
+    } else if (S.n_mps < MAX_MPS) {
+        i = (uint32_t) S.n_mps++;
+        S.hot[i].gen = 0;
+    } else {
+        S.overflow |= OVF_MPS;
+        i = MAX_MPS - 1; // (in bounds; the executor fails the step)
+    }
+    const uint32_t g = S.hot[i].gen;
+    MpHot h;
+    memset(&h, 0, sizeof h);
+    h.gen  = g;
+    h.live = 1;
+    h.last.frame = -1;
+    h.last.row   = -1;
+    S.hot[i] = h;
+    MpCold c;
+    memset(&c, 0, sizeof c);
+    c.ref_frame = -1;
+    S.cold[i]   = c;
+    return i;
+}
+TC_FN void frame_clear_rows(Frame &f) {
+    order_clear(f);
+    f.n_unupd = 0;
+}
+TC_FN int frame_alloc(Stream &S) {
+    int h;
+    if (S.n_free_frames > 0) {
+        h = S.free_frames[--S.n_free_frames];
+    } else if (S.n_frames < MAX_FRAMES) {
+        h = S.n_frames++;
+        S.frame[h].gen = 0;
+    } else {
+        S.overflow |= OVF_FRAMES;
+        h = MAX_FRAMES - 1;
+    }
+    Frame &f   = S.frame[h];
+    f.alive    = 1;
+    f.fid      = 0;
+    f.kf_id    = 0;
+    f.is_kf    = 0;
+    f.kf_state = KEYFRAME_NORMAL;
+    f.slot     = -1;
+    f.image    = 0;
+    frame_clear_rows(f);
+    return h;
+}
+TC_FN void frame_free(Stream &S, int h) {
+    Frame &f = S.frame[h];
+    // a map point lives as long as the map or a frame's unupdated list holds it; this frame's list goes away with it
+    for (int k = 0; k < f.n_unupd; k++) {
+        const uint32_t i = f.unupd[k];
+        if (mp_valid(S, i, f.unupd_gen[k]) && !S.hot[i].in_map) mp_release(S, i);
+    }
+    f.alive = 0;
+    f.gen++;
+    f.image = 0;
+    frame_clear_rows(f);
+    S.free_frames[S.n_free_frames++] = h;
+}
+// A Frame of the reference dies with its last shared_ptr: the tracker's roles, the candidates' reference frames, the map.
+TC_FN void sweep_frames(Stream &S) {
+    uint32_t mark = 0; // MAX_FRAMES <= 32
+    if (S.cur >= 0) mark |= 1u << S.cur;
+    if (S.pre >= 0) mark |= 1u << S.pre;
+    if (S.ref >= 0) mark |= 1u << S.ref;
+    if (S.last_keyframe >= 0) mark |= 1u << S.last_keyframe;
+    if (S.pending >= 0) mark |= 1u << S.pending;
+    if (S.latest_keyframe >= 0) mark |= 1u << S.latest_keyframe;
+    if (S.det_frame >= 0) mark |= 1u << S.det_frame;
+    for (int k = 0; k < S.n_map_kf; k++) mark |= 1u << S.map_kf_frame[k];
+    for (int k = 0; k < S.n_ref_frame; k++) mark |= 1u << S.pts2d_ref_frame[k];
+    for (int h = 0; h < S.n_frames; h++)
+        if (S.frame[h].alive && !((mark >> h) & 1u)) frame_free(S, h);
+}
+static_assert(MAX_FRAMES <= 32, "sweep_frames marks frames in one 32-bit word");
+
+TC_FN void set_keyframe(Stream &S, int h, int state) { // frame.cc:42-54
+    Frame &f = S.frame[h];
+    if (!f.is_kf) {
+        f.is_kf    = 1;
+        f.kf_id    = S.keyframe_id++;
+        f.kf_state = state;
+    }
+}
+// appends a row to frame h (the key is known to be absent: ids of the previous frame's rows, freshly drawn ids); returns its index
+TC_FN int add_row(Stream &S, int h, u64 id, uint32_t mp, const P2f &kp, const P2f &kpd, double vx, double vy, int type, double pcx, double pcy,
+                  int32_t lk_idx, const uint32_t *buckets_after) {
+    Frame &f = S.frame[h];
+    if (f.n_rows >= MAX_ROWS) {
+        S.overflow |= OVF_ROWS;
+        return MAX_ROWS - 1;
+    }
+    Row r;
+    r.id      = id;
+    r.mp      = mp;
+    r.mpgen   = S.hot[mp].gen;
+    r.kp      = kp;
+    r.kpd     = kpd;
+    r.vel[0]  = vx;
+    r.vel[1]  = vy;
+    r.pcx     = pcx;
+    r.pcy     = pcy;
+    r.lk_idx  = lk_idx;
+    r.type    = (int8_t) type;
+    r.outlier = 0;
+    r.pad_[0] = r.pad_[1] = 0;
+    const int i = f.n_rows;
+    f.row[i]    = r;
+    order_insert_unique(f, buckets_after, S.scratch_bucket);
+    return i;
+}
+TC_FN void log_landmark(Stream &S, u64 id, uint32_t mp, int op) {
+    if (S.n_log >= LOG_CAP) {
+        S.overflow |= OVF_LOG;
+        S.log_dropped++;
+        return;
+    }
+    LmLog e;
+    e.id = id, e.mp = mp, e.op = op;
+    S.log[S.n_log++] = e;
+}
+
+// ---- map (tracking/map.cc) on handles -----------------------------------------------------------------------------------------------
+TC_FN int map_find(const Stream &S, u64 key) {
+    for (int k = 0; k < S.n_map_kf; k++)
+        if (S.map_kf_key[k] == key) return k;
+    return -1;
+}
+TC_FN bool map_is_keyframe_in_map(const Stream &S, int h) { return map_find(S, S.frame[h].kf_id) >= 0; }
+TC_FN void map_insert_keyframe(Stream &S, const Cfg &C, int h) { // map.cc:27-61
+    S.latest_keyframe = h;
+    Frame &f          = S.frame[h];
+    const int at      = map_find(S, f.kf_id);
+    if (at < 0) {
+        if (S.n_map_kf >= MAX_WINDOW) {
+            S.overflow |= OVF_WINDOW;
+        } else {
+            S.map_kf_key[S.n_map_kf]   = f.kf_id;
+            S.map_kf_frame[S.n_map_kf] = h;
+            S.n_map_kf++;
+        }
+    } else {
+        S.map_kf_frame[at] = h;
+    }
+    for (int k = 0; k < f.n_unupd; k++) {
+        const uint32_t i = f.unupd[k];
+        if (!mp_valid(S, i, f.unupd_gen[k])) continue;
+        if (!S.hot[i].in_map) {
+            S.hot[i].in_map = 1;
+            log_landmark(S, S.hot[i].id, i, 1); // map.cc:56-61
+            S.n_landmarks++;
+        }
+    }
+    if (S.n_map_kf > C.window_size) S.is_window_full = 1;
+}
+TC_FN void map_remove_keyframe(Stream &S, int h, bool isremovemappoint) { // map.cc:89-127
+    Frame &f = S.frame[h];
+    if (isremovemappoint) {
+        for (int q = 0; q < f.n_rows; q++) {
+            const Row &r     = f.row[q];
+            const uint32_t i = r.mp;
+            if (!mp_valid(S, i, r.mpgen)) continue;
+            if (S.cold[i].ref_frame == h && S.cold[i].ref_gen == f.gen && S.hot[i].in_map) {
+                S.hot[i].in_map  = 0;
+                S.hot[i].outlier = 1;
+                log_landmark(S, S.hot[i].id, i, 0);
+                S.n_landmarks--;
+                mp_release(S, i);
+            }
+        }
+        for (int k = 0; k < f.n_unupd; k++) { // Frame::clearFeatures (frame.h:46-51)
+            const uint32_t i = f.unupd[k];
+            if (mp_valid(S, i, f.unupd_gen[k]) && !S.hot[i].in_map) mp_release(S, i);
+        }
+        frame_clear_rows(f);
+    }
+    const int at = map_find(S, f.kf_id);
+    if (at >= 0) { // vector::erase: the later entries move down
+        for (int k = at; k + 1 < S.n_map_kf; k++) {
+            S.map_kf_key[k]   = S.map_kf_key[k + 1];
+            S.map_kf_frame[k] = S.map_kf_frame[k + 1];
+        }
+        S.n_map_kf--;
+    }
+}
+
+// ---- device slots (per-stream pool of MAX_SLOTS) --------------------------------------------------------------------------------------
+TC_FN int slot_alloc(Stream &S) {
+    if (S.n_free_slots <= 0) {
+        S.overflow |= OVF_SLOTS;
+        return S.free_slots[0];
+    }
+    return S.free_slots[--S.n_free_slots];
+}
+TC_FN void slot_free(Stream &S, int s) { S.free_slots[S.n_free_slots++] = s; }
+TC_FN void assign_slot(Stream &S, int h) {
+    S.frame[h].slot               = S.pending_slot;
+    S.owned_slots[S.n_owned++]    = S.pending_slot;
+    S.pending_slot                = -1;
+}
+TC_FN void release_unused_slots(Stream &S) {
+    int keep = 0;
+    for (int k = 0; k < S.n_owned; k++) {
+        const int s = S.owned_slots[k];
+        const bool used = (S.cur >= 0 && S.frame[S.cur].slot == s) || (S.pre >= 0 && S.frame[S.pre].slot == s) || (S.ref >= 0 && S.frame[S.ref].slot == s);
+        if (used)
+            S.owned_slots[keep++] = s;
+        else
+            slot_free(S, s);
+    }
+    S.n_owned = keep;
+}
+
+// ---- helpers (tracking.cc:813-871) ------------------------------------------------------------------------------------------------------
+template <typename T> TC_FN int reduce_vector(T *vec, int n, const uint8_t *status) { // :831-839
+    int index = 0;
+    for (int k = 0; k < n; k++)
+        if (status[k]) {
+            if (index != k) vec[index] = vec[k];
+            index++;
+        }
+    return index;
+}
+TC_FN int reduce_vector2(double (*vec)[2], int n, const uint8_t *status) {
+    int index = 0;
+    for (int k = 0; k < n; k++)
+        if (status[k]) {
+            if (index != k) vec[index][0] = vec[k][0], vec[index][1] = vec[k][1];
+            index++;
+        }
+    return index;
+}
+TC_FN bool is_good_to_track(const Cfg &C, const P2f &pp, const Pose &pose, const double *pw, double scale, double depth_scale) { // :813-829
+    double pc[3];
+    world2cam(pw, pose, pc);
+    if (!((pc[2] > 1.0 /*NEAREST_DEPTH*/) && (pc[2] < 200.0 /*FARTHEST_DEPTH*/ * depth_scale))) return false; // :247-249
+    const P2f ppp   = cam2pixel(C.cam, pc[0], pc[1], pc[2]);
+    const double ex = ppp.x - pp.x, ey = ppp.y - pp.y; // Vector2d of float differences (camera.cc:153-157)
+    if (tc_sqrt(ex * ex + ey * ey) > C.reprojection_error_std * scale) return false;
+    return true;
+}
+TC_FN double keypoint_parallax(const Cfg &C, const P2f &pp0, const P2f &pp1, const double *R10) { // :861-871
+    double x0, y0, x1, y1;
+    pixel2cam(C.cam, pp0, x0, y0);
+    pixel2cam(C.cam, pp1, x1, y1);
+    const double a = R10[0] * x0 + R10[1] * y0 + R10[2] * 1.0, b = R10[3] * x0 + R10[4] * y0 + R10[5] * 1.0;
+    const double dx = a - x1, dy = b - y1;
+    return tc_sqrt(dx * dx + dy * dy) * focalLength(C.cam);
+}
+// order_idx := the rows of f in container order
+TC_FN int list_container_order(Stream &S, const Frame &f) {
+    int n = 0;
+    for (int q = f.head; q >= 0; q = f.next[q]) S.order_idx[n++] = q;
+    return n;
+}
+TC_FN int parallax_from_reference_mappoints(Stream &S, const Cfg &C, double &parallax) { // :873-905
+    parallax   = 0;
+    int counts = 0;
+    const Frame &fc = S.frame[S.cur];
+    const Frame &fr = S.frame[S.ref];
+    double R10[9];
+    mat_mul_t(fc.pose.R, fr.pose.R, R10);
+    const double focal = focalLength(C.cam);
+    const int nq       = list_container_order(S, fr);
+    for (int k = 0; k < nq; k++) {
+        const Row &r0    = fr.row[S.order_idx[k]];
+        const uint32_t i = r0.mp;
+        if (!mp_valid(S, i, r0.mpgen) || S.hot[i].outlier) continue;
+        const LastObs lo = S.hot[i].last;
+        if (lo.frame != S.cur || lo.gen != fc.gen) continue;
+        const Row &r1 = fc.row[lo.row];
+        if (r1.outlier) continue;
+        const double x = R10[0] * r0.pcx + R10[1] * r0.pcy + R10[2] * 1.0, y = R10[3] * r0.pcx + R10[4] * r0.pcy + R10[5] * 1.0;
+        const double dx = x - r1.pcx, dy = y - r1.pcy;
+        parallax += tc_sqrt(dx * dx + dy * dy) * focal;
+        counts++;
+    }
+    if (counts != 0) parallax /= counts;
+    return counts;
+}
+TC_FN int parallax_from_reference_keypoints(Stream &S, const Cfg &C, const P2f *ref, const P2f *cur, double &parallax) { // :907-922
+    parallax   = 0;
+    int counts = 0;
+    double R10[9];
+    mat_mul_t(S.frame[S.cur].pose.R, S.frame[S.ref].pose.R, R10);
+    for (int k = 0; k < S.n_ref_frame; k++) {
+        if (S.pts2d_ref_frame[k] == S.ref) {
+            parallax += keypoint_parallax(C, ref[k], cur[k], R10);
+            counts++;
+        }
+    }
+    if (counts != 0) parallax /= counts;
+    return counts;
+}
+TC_FN void clear_candidates(Stream &S) {
+    S.n_new = S.n_ref = S.n_ref_undis = S.n_new_undis = S.n_ref_frame = S.n_vel_ref = S.n_cand_lk = 0;
+}
+TC_FN bool do_reset_tracking(Stream &S) { // :317-329
+    if (!S.frame[S.cur].n_rows) {
+        S.isinitializing = 1;
+        S.ref            = S.cur;
+        clear_candidates(S);
+        return true;
+    }
+    return false;
+}
+TC_FN int check_keyframe_state(Stream &S, const Cfg &C) { // :263-307
+    int keyframe_state = KEYFRAME_NONE;
+    const double dt    = S.frame[S.cur].stamp - S.frame[S.last_keyframe].stamp;
+    if (dt < 0.08 /*TRACK_MIN_INTERVAl*/) return keyframe_state;
+    const double parallax = (S.parallax_map * S.parallax_map_counts + S.parallax_ref * S.parallax_ref_counts) /
+                            (S.parallax_map_counts + S.parallax_ref_counts);
+    if (parallax > C.track_min_parallax) {
+        keyframe_state = S.is_window_full ? KEYFRAME_REMOVE_OLDEST : KEYFRAME_NORMAL;
+    } else if (dt > C.track_max_interval) {
+        keyframe_state = KEYFRAME_REMOVE_SECOND_NEW;
+    }
+    if (keyframe_state != KEYFRAME_NONE) {
+        S.last_keyframe = S.cur;
+        for (int k = 0; k < S.n_tracked; k++) {
+            const MpRef m = S.tracked_mappoint[k];
+            if (mp_valid(S, m.i, m.g)) S.hot[m.i].used++;
+        }
+    }
+    return keyframe_state;
+}
+
+TC_FN void finish(Stream &S, int st) {
+    S.result = st;
+    S.done   = 1;
+}
+
+// ---- featuresDetection (:576-688) ------------------------------------------------------------------------------------------------------
+TC_FN bool queue_detection(Stream &S, const Cfg &C, Io &io, int frame, bool ismask) {
+    S.det_job        = -1;
+    const Frame &f   = S.frame[frame];
+    const int num_features = f.n_rows + S.n_ref; // :579
+    if (num_features > (C.track_max_features - 5)) return false; // :580
+    int features_cnts[MAX_BLOCKS];
+    for (int k = 0; k < C.block_cnts; k++) features_cnts[k] = 0;
+    for (int q = 0; q < f.n_rows + S.n_new; q++) {
+        const P2f p  = q < f.n_rows ? f.row[q].kp : S.pts2d_new[q - f.n_rows];
+        const int col = (int) (p.x / (float) C.block_w); // :598
+        const int row = (int) (p.y / (float) C.block_h);
+        // hazard H5 (unclamped column of an undistorted key point), reproduced as in tracking_hip.cc
+        const long idx = (long) row * C.block_cols + col;
+        if (idx >= 0 && idx < (long) C.block_cnts) features_cnts[idx]++;
+    }
+    S.det_job     = 0;
+    S.det_ismask  = ismask ? 1 : 0;
+    S.det_frame   = frame;
+    *io.det_slot  = f.slot;
+    int nm        = 0;
+    if (ismask) { // :610-620 (a union of discs: the order of the points is immaterial)
+        const Frame &fc = S.frame[S.cur];
+        for (int q = 0; q < fc.n_rows; q++) io.det_mask_pts[nm++] = fc.row[q].kp;
+        for (int q = 0; q < S.n_new && nm < MAX_ROWS; q++) io.det_mask_pts[nm++] = S.pts2d_new[q];
+    }
+    *io.det_mask_count = nm;
+    for (int k = 0; k < C.block_cnts; k++) io.det_quota[k] = C.max_block_features - features_cnts[k]; // :629
+    return true;
+}
+TC_FN void integrate_detection(Stream &S, const Cfg &C, const Io &io) { // :659-685
+    if (!S.det_ismask) clear_candidates(S);
+    const int n = *io.det_count;
+    for (int i = 0; i < n; i++) {
+        if (S.n_ref >= MAX_ROWS || S.n_new >= MAX_ROWS) {
+            S.overflow |= OVF_ROWS;
+            break;
+        }
+        const P2f p = io.det_out[i];
+        const P2f u = undistortPoint(C.cam, p); // the one undistortion a detected corner ever needs
+        S.pts2d_ref[S.n_ref++]             = p;
+        S.pts2d_new[S.n_new++]             = p;
+        S.pts2d_ref_undis[S.n_ref_undis++] = u;
+        S.pts2d_new_undis[S.n_new_undis++] = u;
+        S.pts2d_ref_frame[S.n_ref_frame++] = S.det_frame;
+        S.velocity_ref[S.n_vel_ref][0] = 0, S.velocity_ref[S.n_vel_ref][1] = 0;
+        S.n_vel_ref++;
+    }
+    // cand_lk_idx_.resize(pts2d_new_.size(), -1): a list that lost its alignment is padded / cut (hints are hints)
+    for (int k = S.n_cand_lk; k < S.n_new; k++) S.cand_lk_idx[k] = -1;
+    S.n_cand_lk = S.n_new;
+    S.det_job   = -1;
+    S.det_frame = -1;
+}
+
+// ---- trackMappoint (:351-455) ------------------------------------------------------------------------------------------------------------
+TC_FN void queue_track_mappoint(Stream &S, const Cfg &C, Io &io) {
+    S.n_matched     = 0;
+    const Frame &fp = S.frame[S.pre];
+    const Pose pose_cur = S.frame[S.cur].pose;
+    const int nq    = list_container_order(S, fp);
+    int n           = 0;
+    for (int k = 0; k < nq; k++) {
+        const Row &r     = fp.row[S.order_idx[k]];
+        const uint32_t i = r.mp;
+        if (!mp_valid(S, i, r.mpgen) || S.hot[i].outlier) continue; // mappoint && !mappoint->isOutlier() (:360)
+        S.tm_pc[n][0] = r.pcx, S.tm_pc[n][1] = r.pcy;
+        P2f pp        = world2pixel(C.cam, S.hot[i].pos, pose_cur); // INS-aided prediction :367
+        distortPoint(C.cam, pp);                                    // :378
+        io.lk_prev_slot[n] = fp.slot;
+        io.lk_next_slot[n] = S.frame[S.cur].slot;
+        io.lk_prev[n]      = r.kpd;
+        io.lk_guess[n]     = pp;
+        MpRef m;
+        m.i = i, m.g = r.mpgen;
+        S.mappoint_matched[n] = m;
+        n++;
+    }
+    S.n_matched    = n;
+    S.lk_map_begin = 0;
+    S.lk_map_n     = n;
+    *io.lk_count   = n;
+}
+TC_FN bool finish_track_mappoint(Stream &S, const Cfg &C, const Io &io, const uint32_t *buckets_after) {
+    if (S.lk_map_n == 0) return false;
+    const int n           = S.lk_map_n;
+    const uint8_t *status = io.lk_status + S.lk_map_begin;
+    const P2f *out        = io.lk_out + S.lk_map_begin;
+    const P2f *undis      = io.lk_undist + S.lk_map_begin;
+    int kept = 0;
+    for (int k = 0; k < n; k++) kept += status[k] ? 1 : 0;
+    if (kept == 0) { // :410-419
+        S.parallax_map        = 0;
+        S.parallax_map_counts = 0;
+        return false;
+    }
+    Frame &fc = S.frame[S.cur];
+    frame_clear_rows(fc); // :426
+    S.n_tracked     = 0;
+    const double dt = fc.stamp - S.frame[S.pre].stamp;
+    for (int k = 0; k < n; k++) { // reduceVector (:404-408) and the feature loop (:430-444) in one pass
+        if (!status[k]) continue;
+        const MpRef m = S.mappoint_matched[k];
+        double pcx, pcy;
+        pixel2cam(C.cam, undis[k], pcx, pcy);
+        const double vx = (pcx - S.tm_pc[k][0]) / dt, vy = (pcy - S.tm_pc[k][1]) / dt; // :434
+        const int row = add_row(S, S.cur, S.hot[m.i].id, m.i, undis[k], out[k], vx, vy, FEATURE_MATCHED, pcx, pcy, io.lk_base + S.lk_map_begin + k,
+                                buckets_after);
+        S.hot[m.i].observed++; // addObservation (mappoint.cc:58-62)
+        LastObs lo;
+        lo.frame = S.cur, lo.gen = fc.gen, lo.row = row;
+        S.hot[m.i].last                 = lo;
+        S.tracked_mappoint[S.n_tracked++] = m;
+    }
+    S.parallax_map_counts = parallax_from_reference_mappoints(S, C, S.parallax_map); // :450
+    return true;
+}
+
+// ---- trackReferenceFrame (:457-574) ----------------------------------------------------------------------------------------------------
+TC_FN void queue_track_reference(Stream &S, const Cfg &C, Io &io) {
+    S.lk_ref_begin = *io.lk_count;
+    S.lk_ref_n     = 0;
+    if (S.n_ref == 0) return; // :459-462
+    const Frame &fc = S.frame[S.cur], &fp = S.frame[S.pre];
+    double r_cur_pre[9];
+    mat_mul_t(fc.pose.R, fp.pose.R, r_cur_pre); // :465
+    const int at = S.lk_ref_begin;
+    if (at + S.n_new > MAX_ROWS) {
+        S.overflow |= OVF_ROWS;
+        return;
+    }
+    S.n_cur = 0;
+    for (int k = 0; k < S.n_new_undis; k++) { // :469 (carried), :472-479
+        double x, y;
+        pixel2cam(C.cam, S.pts2d_new_undis[k], x, y);
+        const double X = r_cur_pre[0] * x + r_cur_pre[1] * y + r_cur_pre[2] * 1.0, Y = r_cur_pre[3] * x + r_cur_pre[4] * y + r_cur_pre[5] * 1.0,
+                     Z = r_cur_pre[6] * x + r_cur_pre[7] * y + r_cur_pre[8] * 1.0;
+        S.pts2d_cur[S.n_cur++] = distortCameraPoint(C.cam, X, Y, Z);
+    }
+    S.lk_ref_n = S.n_new;
+    for (int k = 0; k < S.lk_ref_n; k++) {
+        io.lk_prev_slot[at + k] = fp.slot;
+        io.lk_next_slot[at + k] = fc.slot;
+        io.lk_prev[at + k]      = S.pts2d_new[k];
+        io.lk_guess[at + k]     = S.pts2d_cur[k];
+    }
+    *io.lk_count = at + S.lk_ref_n;
+}
+TC_FN bool mid_track_reference(Stream &S, const Cfg &C, Io &io) {
+    S.rs_set      = -1;
+    *io.rs_count  = 0;
+    if (S.lk_ref_n == 0) return false;
+    const int n = S.lk_ref_n;
+    for (int k = 0; k < n; k++) {
+        S.status[k]       = io.lk_status[S.lk_ref_begin + k];
+        S.pts2d_cur[k]    = io.lk_out[S.lk_ref_begin + k];
+        S.scratch_a[k]    = io.lk_undist[S.lk_ref_begin + k];
+        S.cand_lk_idx[k]  = io.lk_base + S.lk_ref_begin + k;
+    }
+    S.n_cur = n;
+    // reduceVector (:507-511): every list by the LK status
+    S.n_cand_lk      = reduce_vector(S.cand_lk_idx, n, S.status);
+    S.n_ref          = reduce_vector(S.pts2d_ref, S.n_ref, S.status);
+    S.n_cur          = reduce_vector(S.pts2d_cur, S.n_cur, S.status);
+    S.n_new          = reduce_vector(S.pts2d_new, S.n_new, S.status);
+    S.n_ref_frame    = reduce_vector(S.pts2d_ref_frame, S.n_ref_frame, S.status);
+    S.n_vel_ref      = reduce_vector2(S.velocity_ref, S.n_vel_ref, S.status);
+    const int n_a    = reduce_vector(S.scratch_a, n, S.status);
+    S.n_ref_undis    = reduce_vector(S.pts2d_ref_undis, S.n_ref_undis, S.status);
+    S.n_new_undis    = reduce_vector(S.pts2d_new_undis, S.n_new_undis, S.status);
+    if (S.n_ref == 0) return false; // :513-517 (tr_cur_undis_ keeps what it held, as in the table)
+    for (int k = 0; k < n_a; k++) S.tr_cur_undis[k] = S.scratch_a[k];
+    S.n_tr_cur_undis = n_a;
+    for (int k = 0; k < S.n_new_undis; k++) S.tr_new_undis[k] = S.pts2d_new_undis[k]; // :520-524 (carried)
+    S.n_tr_new_undis = S.n_new_undis;
+
+    S.n_vel_cur = 0; // :527-539
+    const Frame &fc   = S.frame[S.cur];
+    const u64 ref_fid = S.frame[S.ref].fid;
+    const double dt   = fc.stamp - S.frame[S.pre].stamp;
+    for (int k = 0; k < S.n_tr_cur_undis; k++) {
+        double x1, y1, x0, y0;
+        pixel2cam(C.cam, S.tr_cur_undis[k], x1, y1);
+        pixel2cam(C.cam, S.tr_new_undis[k], x0, y0);
+        const double vx = (x1 - x0) / dt, vy = (y1 - y0) / dt;
+        S.velocity_cur[k][0] = vx, S.velocity_cur[k][1] = vy;
+        if (S.frame[S.pts2d_ref_frame[k]].fid > ref_fid) S.velocity_ref[k][0] = vx, S.velocity_ref[k][1] = vy;
+    }
+    S.n_vel_cur           = S.n_tr_cur_undis;
+    S.parallax_ref_counts = parallax_from_reference_keypoints(S, C, S.pts2d_ref_undis, S.tr_cur_undis, S.parallax_ref); // :542-544
+
+    if (S.n_cur >= 15) { // :547-548
+        S.rs_set = 0;
+        const int m = S.n_tr_new_undis;
+        for (int k = 0; k < m; k++) {
+            io.rs_p1[k] = S.tr_new_undis[k];
+            io.rs_p2[k] = S.tr_cur_undis[k];
+        }
+        *io.rs_count = m;
+    }
+    return true;
+}
+TC_FN bool finish_track_reference(Stream &S, const Io &io) {
+    if (S.rs_set >= 0) { // :550-554
+        const uint8_t *mask = io.rs_mask;
+        const int m         = S.n_tr_new_undis; // (the set's size)
+        for (int k = 0; k < m; k++) S.status[k] = mask[k];
+        S.n_ref          = reduce_vector(S.pts2d_ref, S.n_ref, S.status);
+        S.n_cur          = reduce_vector(S.pts2d_cur, S.n_cur, S.status);
+        S.n_ref_frame    = reduce_vector(S.pts2d_ref_frame, S.n_ref_frame, S.status);
+        S.n_vel_cur      = reduce_vector2(S.velocity_cur, S.n_vel_cur, S.status);
+        S.n_vel_ref      = reduce_vector2(S.velocity_ref, S.n_vel_ref, S.status);
+        S.n_ref_undis    = reduce_vector(S.pts2d_ref_undis, S.n_ref_undis, S.status);
+        S.n_tr_cur_undis = reduce_vector(S.tr_cur_undis, S.n_tr_cur_undis, S.status);
+        S.n_cand_lk      = reduce_vector(S.cand_lk_idx, S.n_cand_lk, S.status);
+        S.rs_set         = -1;
+    }
+    if (S.n_cur == 0) return false; // :557-561
+    for (int k = 0; k < S.n_cur; k++) S.pts2d_new[k] = S.pts2d_cur[k]; // :569
+    S.n_new = S.n_cur;
+    for (int k = 0; k < S.n_tr_cur_undis; k++) S.pts2d_new_undis[k] = S.tr_cur_undis[k];
+    S.n_new_undis = S.n_tr_cur_undis;
+    return S.n_new != 0;
+}
+
+// ---- triangulation (:690-798) ----------------------------------------------------------------------------------------------------------
+TC_FN void pose2Tcw12(const Pose &pose, double *t12) { // :851-859, upper 3 x 4 block row-major
+    const double *R = pose.R;
+    // Rt = R^T; t = Rt * pose.t
+    const double t0 = R[0] * pose.t[0] + R[3] * pose.t[1] + R[6] * pose.t[2];
+    const double t1 = R[1] * pose.t[0] + R[4] * pose.t[1] + R[7] * pose.t[2];
+    const double t2 = R[2] * pose.t[0] + R[5] * pose.t[1] + R[8] * pose.t[2];
+    t12[0] = R[0], t12[1] = R[3], t12[2] = R[6], t12[3] = -t0;
+    t12[4] = R[1], t12[5] = R[4], t12[6] = R[7], t12[7] = -t1;
+    t12[8] = R[2], t12[9] = R[5], t12[10] = R[8], t12[11] = -t2;
+}
+TC_FN bool queue_triangulation(Stream &S, const Cfg &C, Io &io) {
+    S.tri_queued   = 0;
+    *io.tri_count  = 0;
+    *io.tri_n_tcw  = 0;
+    if (S.n_cur == 0) return false; // :692-694
+    S.tri_queued     = 1;
+    const Pose pose1 = S.frame[S.cur].pose;
+    if (S.n_tr_cur_undis != S.n_cur) { // no reference tracking ran this frame: derive them
+        for (int k = 0; k < S.n_cur; k++) S.tr_cur_undis[k] = undistortPoint(C.cam, S.pts2d_cur[k]);
+        S.n_tr_cur_undis = S.n_cur;
+    }
+    if (S.n_ref_undis != S.n_ref) {
+        for (int k = 0; k < S.n_ref; k++) S.pts2d_ref_undis[k] = undistortPoint(C.cam, S.pts2d_ref[k]);
+        S.n_ref_undis = S.n_ref;
+    }
+    for (int k = 0; k < S.n_ref_undis; k++) S.tri_ref_undis[k] = S.pts2d_ref_undis[k]; // :712-713 (carried)
+    S.n_tri_ref_undis = S.n_ref_undis;
+    for (int k = 0; k < S.n_tr_cur_undis; k++) S.tri_cur_undis[k] = S.tr_cur_undis[k];
+    S.n_tri_cur_undis = S.n_tr_cur_undis;
+    for (int k = 0; k < S.n_cur; k++) S.tri_status[k] = 0;
+    S.n_tri_status = S.n_cur;
+    S.n_tri_index  = 0;
+    S.tri_begin    = 0;
+
+    int n_tcw = 0, n_tri = 0;
+    const int T_cur = n_tcw;
+    pose2Tcw12(pose1, io.tri_Tcw + 12 * n_tcw);
+    n_tcw++;
+    int T_frame[8], T_index[8], n_T = 0; // distinct reference frames of the candidates (a handful)
+    const u64 ref_fid = S.frame[S.ref].fid;
+    for (int k = 0; k < S.n_cur; k++) {
+        const int frame_ref = S.pts2d_ref_frame[k];
+        const Frame &fr     = S.frame[frame_ref];
+        if (fr.fid > ref_fid) { // :723-730 feature added after the reference keyframe: re-anchor
+            S.pts2d_ref_frame[k] = S.cur;
+            S.pts2d_ref[k]       = S.pts2d_cur[k];
+            S.pts2d_ref_undis[k] = S.tri_cur_undis[k];
+            S.tri_status[k]      = 1;
+            continue;
+        }
+        if (S.n_map_kf == C.window_size && !map_is_keyframe_in_map(S, frame_ref)) { // :733-737
+            S.tri_status[k] = 0;
+            continue;
+        }
+        double R10[9];
+        mat_mul_t(pose1.R, fr.pose.R, R10); // (pose1.R^T * pose0.R)
+        const double parallax = keypoint_parallax(C, S.tri_ref_undis[k], S.tri_cur_undis[k], R10); // :741
+        if (parallax < 10.0 /*TRACK_MIN_PARALLAX*/) {
+            S.tri_status[k] = 1;
+            continue;
+        }
+        int T0 = -1;
+        for (int q = 0; q < n_T; q++)
+            if (T_frame[q] == frame_ref) T0 = T_index[q];
+        if (T0 < 0) {
+            if (n_tcw >= MAX_TCW) {
+                S.overflow |= OVF_TCW;
+                T0 = 0;
+            } else {
+                T0 = n_tcw;
+                pose2Tcw12(fr.pose, io.tri_Tcw + 12 * n_tcw);
+                n_tcw++;
+            }
+            if (n_T < 8) T_frame[n_T] = frame_ref, T_index[n_T] = T0, n_T++;
+        }
+        double x0, y0, x1, y1;
+        pixel2cam(C.cam, S.tri_ref_undis[k], x0, y0); // :750-751
+        pixel2cam(C.cam, S.tri_cur_undis[k], x1, y1);
+        io.tri_T0[n_tri] = T0;
+        io.tri_T1[n_tri] = T_cur;
+        io.tri_pc0[3 * n_tri] = x0, io.tri_pc0[3 * n_tri + 1] = y0, io.tri_pc0[3 * n_tri + 2] = 1.0;
+        io.tri_pc1[3 * n_tri] = x1, io.tri_pc1[3 * n_tri + 1] = y1, io.tri_pc1[3 * n_tri + 2] = 1.0;
+        S.tri_point_index[S.n_tri_index++] = k;
+        n_tri++;
+    }
+    *io.tri_count = n_tri;
+    *io.tri_n_tcw = n_tcw;
+    return true;
+}
+TC_FN void finish_triangulation(Stream &S, const Cfg &C, const Io &io, const uint32_t *buckets_after) {
+    S.tri_queued     = 0;
+    const Pose pose1 = S.frame[S.cur].pose;
+    for (int q = 0; q < S.n_tri_index; q++) {
+        const int k     = S.tri_point_index[q];
+        const double *p = io.tri_pw + 3 * (S.tri_begin + q);
+        const double pw[3]  = {p[0], p[1], p[2]};
+        const int frame_ref = S.pts2d_ref_frame[k];
+        const Pose pose0    = S.frame[frame_ref].pose;
+        const P2f pp0 = S.tri_ref_undis[k], pp1 = S.tri_cur_undis[k];
+        S.tri_status[k] = 0; // :757 / :761: rejected or consumed, the candidate leaves the list either way
+        if (!is_good_to_track(C, pp0, pose0, pw, 1.0, 3.0) || !is_good_to_track(C, pp1, pose1, pw, 1.0, 3.0)) continue; // :756-760
+        double pc[3];
+        world2cam(pw, pose0, pc);
+        const double depth = pc[2];
+        // MapPoint::createMapPoint (mappoint.cc:25-49)
+        const uint32_t i   = mp_alloc(S);
+        S.hot[i].id        = S.mappoint_id++;
+        S.cold[i].born_fid = S.frame[S.cur].fid;
+        S.hot[i].pos[0] = pw[0], S.hot[i].pos[1] = pw[1], S.hot[i].pos[2] = pw[2];
+        S.cold[i].ref_frame = frame_ref;
+        S.cold[i].ref_gen   = S.frame[frame_ref].gen;
+        S.cold[i].ref_kp    = S.tri_ref_undis[k];
+        S.cold[i].depth     = ((depth < 1.0) || (depth > 200.0)) ? 10.0 /*DEFAULT_DEPTH*/ : depth;
+        S.hot[i].type       = (int8_t) MAPPOINT_TRIANGULATED;
+        double pccx, pccy, pcrx, pcry;
+        pixel2cam(C.cam, S.tri_cur_undis[k], pccx, pccy);
+        pixel2cam(C.cam, S.tri_ref_undis[k], pcrx, pcry);
+        add_row(S, S.cur, S.hot[i].id, i, S.tri_cur_undis[k], S.pts2d_cur[k], S.velocity_cur[k][0], S.velocity_cur[k][1], FEATURE_TRIANGULATED, pccx, pccy,
+                k < S.n_cand_lk ? S.cand_lk_idx[k] : -1, buckets_after); // :769-774
+        S.hot[i].observed++;
+        S.hot[i].used++;
+        const int row = add_row(S, frame_ref, S.hot[i].id, i, S.tri_ref_undis[k], S.pts2d_ref[k], S.velocity_ref[k][0], S.velocity_ref[k][1],
+                                FEATURE_TRIANGULATED, pcrx, pcry, -1, buckets_after); // :776-781
+        S.hot[i].observed++;
+        S.hot[i].used++;
+        LastObs lo;
+        lo.frame = frame_ref, lo.gen = S.frame[frame_ref].gen, lo.row = row;
+        S.hot[i].last = lo;
+        Frame &fc     = S.frame[S.cur];
+        if (fc.n_unupd < MAX_ROWS) {
+            fc.unupd[fc.n_unupd]     = i; // :784
+            fc.unupd_gen[fc.n_unupd] = S.hot[i].gen;
+            fc.n_unupd++;
+        } else {
+            S.overflow |= OVF_ROWS;
+        }
+    }
+    const int nst = S.n_tri_status;
+    S.n_ref       = reduce_vector(S.pts2d_ref, S.n_ref, S.tri_status); // :788-793
+    S.n_ref_frame = reduce_vector(S.pts2d_ref_frame, S.n_ref_frame, S.tri_status);
+    S.n_cur       = reduce_vector(S.pts2d_cur, S.n_cur, S.tri_status);
+    S.n_vel_ref   = reduce_vector2(S.velocity_ref, S.n_vel_ref, S.tri_status);
+    S.n_ref_undis = reduce_vector(S.pts2d_ref_undis, S.n_ref_undis, S.tri_status);
+    S.n_tr_cur_undis = reduce_vector(S.tr_cur_undis, S.n_tr_cur_undis, S.tri_status);
+    if (S.n_cand_lk == nst) S.n_cand_lk = reduce_vector(S.cand_lk_idx, S.n_cand_lk, S.tri_status);
+    for (int k = 0; k < S.n_cur; k++) S.pts2d_new[k] = S.pts2d_cur[k];
+    S.n_new = S.n_cur;
+    for (int k = 0; k < S.n_tr_cur_undis; k++) S.pts2d_new_undis[k] = S.tr_cur_undis[k];
+    S.n_new_undis = S.n_tr_cur_undis;
+}
+
+TC_FN void make_new_frame_queue(Stream &S, const Cfg &C, Io &io, int state) { // :251-261
+    set_keyframe(S, S.cur, state);
+    S.isnewkeyframe = 1;
+    if ((state == KEYFRAME_NORMAL) || (state == KEYFRAME_REMOVE_OLDEST)) {
+        S.ref = S.cur;
+        queue_detection(S, C, io, S.ref, true);
+    }
+}
+
+// ---- the stages (TableTracker::beginFrame / advance; the device primitive that runs after each stage is named) --------------------------
+// stage 0 -> preprocess
+TC_FN void stage_begin_frame(Stream &S, Io &io, double stamp, const Pose &pose, u64 image) {
+    S.done          = 0;
+    S.result        = TRACK_PASSED;
+    S.isnewkeyframe = 0; // :108
+    S.mode          = M_NONE;
+    S.det_job       = -1;
+    S.rs_set        = -1;
+    S.tri_queued    = 0;
+    S.lk_map_n = S.lk_ref_n = 0;
+    S.ref_tracked   = 0;
+    S.pending       = frame_alloc(S);
+    Frame &f        = S.frame[S.pending];
+    f.fid           = S.frame_id++; // frame.cc:37-40
+    S.last_input_fid = f.fid;
+    f.stamp         = stamp;
+    f.pose          = pose;
+    f.image         = image;
+    S.pending_slot  = slot_alloc(S);
+    *io.pre_slot    = S.pending_slot;
+    // nothing else is queued yet
+    *io.det_slot       = -1;
+    *io.det_mask_count = 0;
+    *io.lk_count       = 0;
+    *io.rs_count       = 0;
+    *io.tri_count      = 0;
+    *io.tri_n_tcw      = 0;
+}
+// stage 1 (after preprocess) -> detection A
+TC_FN void stage_on_preprocess(Stream &S, const Cfg &C, Io &io) {
+    if (S.done) return;
+    if (C.check_histogram) { // :115-133
+        const double hist = *io.pre_hist;
+        if (S.histogram != 0) {
+            const double rate = tc_fabs((hist - S.histogram) / S.histogram);
+            if (rate > 0.1) {
+                S.passed_cnt++;
+                if (S.passed_cnt > 1) S.histogram = 0;
+                slot_free(S, S.pending_slot);
+                S.pending_slot = -1;
+                frame_free(S, S.pending);
+                S.pending = -1;
+                finish(S, TRACK_PASSED);
+                return;
+            }
+        }
+        S.histogram = hist;
+    }
+    S.det_job = -1;
+    S.pre     = S.cur; // :135
+    S.cur     = S.pending;
+    S.pending = -1;
+    assign_slot(S, S.cur);
+    release_unused_slots(S);
+    if (S.isinitializing) {
+        if (S.ref < 0) { // :158-166
+            do_reset_tracking(S);
+            S.ref  = S.cur;
+            S.mode = M_FIRST;
+            queue_detection(S, C, io, S.ref, false);
+            return;
+        }
+        S.mode = M_INIT;
+        if (S.n_ref == 0) queue_detection(S, C, io, S.ref, false); // :168-170
+    } else {
+        S.mode = M_TRACK;
+    }
+}
+// stage 2 (after detection A) -> LK
+TC_FN void stage_on_detect_a(Stream &S, const Cfg &C, Io &io) {
+    if (S.done) return;
+    if (S.det_job >= 0) integrate_detection(S, C, io);
+    *io.det_slot = -1;
+    if (S.mode == M_FIRST) {
+        release_unused_slots(S);
+        finish(S, TRACK_FIRST_FRAME);
+        return;
+    }
+    *io.lk_count = 0;
+    if (S.mode == M_TRACK) queue_track_mappoint(S, C, io); // :206
+    queue_track_reference(S, C, io);                        // :173 / :209
+}
+// stage 3 (after LK) -> RANSAC
+TC_FN void stage_on_lk(Stream &S, const Cfg &C, Io &io, const uint32_t *buckets_after) {
+    if (S.done) return;
+    if (S.mode == M_TRACK) finish_track_mappoint(S, C, io, buckets_after);
+    S.ref_tracked = mid_track_reference(S, C, io) ? 1 : 0;
+    *io.lk_count  = 0;
+}
+// stage 4 (after RANSAC) -> triangulation
+TC_FN void stage_on_ransac(Stream &S, const Cfg &C, Io &io) {
+    if (S.done) return;
+    if (S.ref_tracked) finish_track_reference(S, io);
+    *io.rs_count = 0;
+    if (S.mode == M_INIT) {
+        if (S.parallax_ref < C.track_min_parallax) { // :175-178
+            finish(S, TRACK_INITIALIZING);
+            return;
+        }
+        queue_triangulation(S, C, io); // :182
+        return;
+    }
+    S.kf_state = check_keyframe_state(S, C); // :212
+    if ((S.kf_state == KEYFRAME_NORMAL) || (S.kf_state == KEYFRAME_REMOVE_OLDEST)) queue_triangulation(S, C, io); // :215-217
+}
+// stage 5 (after triangulation) -> detection B
+TC_FN void stage_on_triangulate(Stream &S, const Cfg &C, Io &io, const uint32_t *buckets_after) {
+    if (S.done) return;
+    if (S.tri_queued) finish_triangulation(S, C, io, buckets_after);
+    *io.tri_count = 0;
+    if (S.mode == M_INIT) {
+        if (do_reset_tracking(S)) { // :184-190
+            S.lost_reset = 1;
+            make_new_frame_queue(S, C, io, KEYFRAME_NORMAL);
+            return;
+        }
+        S.lost_reset = 0;
+        set_keyframe(S, S.ref, KEYFRAME_NORMAL);         // :193
+        make_new_frame_queue(S, C, io, KEYFRAME_NORMAL); // :196
+        S.last_keyframe  = S.cur;
+        S.isinitializing = 0;
+        return;
+    }
+    S.lost_reset = 0;
+    if (!S.frame[S.cur].n_rows) { // :224
+        do_reset_tracking(S);
+        S.lost_reset = 2;
+        make_new_frame_queue(S, C, io, KEYFRAME_NORMAL); // :225
+        return;
+    }
+    if ((S.kf_state == KEYFRAME_NORMAL) || (S.kf_state == KEYFRAME_REMOVE_OLDEST)) {
+        make_new_frame_queue(S, C, io, S.kf_state); // :230-232
+    } else {
+        queue_detection(S, C, io, S.cur, true); // :220
+        if (S.kf_state != KEYFRAME_NONE) make_new_frame_queue(S, C, io, S.kf_state); // REMOVE_SECOND_NEW: flags only
+    }
+}
+// stage 6 (after detection B): the frame is done
+TC_FN void stage_on_detect_b(Stream &S, const Cfg &C, Io &io) {
+    if (S.done) return;
+    if (S.det_job >= 0) integrate_detection(S, C, io);
+    *io.det_slot = -1;
+    release_unused_slots(S);
+    if (S.mode == M_INIT) {
+        finish(S, S.lost_reset == 1 ? TRACK_FIRST_FRAME : TRACK_TRACKING);
+        return;
+    }
+    if (S.lost_reset == 2) {
+        finish(S, TRACK_LOST);
+        return;
+    }
+    finish(S, TRACK_TRACKING);
+}
+
+// ---- after the frame: statistics, digest, sliding-window stand-in (TrackingBatch::step, TableTracker::endFrame) ---------------------------
+TC_FN void fnv(u64 &h, const void *p, int n) {
+    const unsigned char *c = (const unsigned char *) p;
+    for (int i = 0; i < n; i++) {
+        h ^= c[i];
+        h *= 1099511628211ull;
+    }
+}
+TC_FN u64 mix64(u64 x) {
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+TC_FN void stage_end_frame(Stream &S, const Cfg &C) {
+    const int st = S.result;
+    S.last_state = st;
+    S.frames++;
+    if (S.isnewkeyframe || st == TRACK_FIRST_FRAME || st == TRACK_LOST) S.keyframes++;
+    {
+        int32_t sti = st;
+        fnv(S.digest, &sti, sizeof sti);
+        u64 fid = S.last_input_fid;
+        fnv(S.digest, &fid, sizeof fid);
+        if (st != TRACK_PASSED) {
+            u64 acc = 0, cnt = 0;
+            if (S.cur >= 0) {
+                const Frame &fr = S.frame[S.cur];
+                for (int q = 0; q < fr.n_rows; q++) {
+                    u64 bits;
+                    memcpy(&bits, &fr.row[q].kpd, sizeof bits);
+                    acc += mix64(mix64(fr.row[q].id) ^ bits);
+                    cnt++;
+                }
+            }
+            fnv(S.digest, &acc, sizeof acc);
+            fnv(S.digest, &cnt, sizeof cnt);
+            S.tracked_sum += cnt;
+            u64 nref = (u64) S.n_new;
+            fnv(S.digest, &nref, sizeof nref);
+        }
+    }
+    // WindowKeeper::onFrame (ic_gvins.cc:542, 743, 1391-1410, 445-448, 1675)
+    const int frame = S.cur;
+    if (st != TRACK_PASSED && frame >= 0 && (S.isnewkeyframe || st == TRACK_FIRST_FRAME || st == TRACK_LOST)) {
+        map_insert_keyframe(S, C, frame);
+        u64 ids[MAX_WINDOW];
+        int n = S.n_map_kf;
+        for (int k = 0; k < n; k++) ids[k] = S.map_kf_key[k];
+        for (int a = 1; a < n; a++) { // insertion sort (<= 17 keys)
+            const u64 v = ids[a];
+            int b       = a - 1;
+            while (b >= 0 && ids[b] > v) ids[b + 1] = ids[b], b--;
+            ids[b + 1] = v;
+        }
+        for (int q = 0; q < n; q++) {
+            const u64 id = ids[q];
+            const int at = map_find(S, id);
+            if (at < 0) continue;
+            const int h = S.map_kf_frame[at];
+            Frame &f    = S.frame[h];
+            if ((f.kf_state == KEYFRAME_REMOVE_SECOND_NEW) || ((f.n_rows == 0) && (id != ids[n - 1]))) {
+                f.is_kf    = 0; // resetKeyFrame (frame.h:58-63); the keyframe id stays
+                f.kf_state = KEYFRAME_NONE;
+                map_remove_keyframe(S, h, false);
+            }
+        }
+        while (S.n_map_kf > C.window_size) {
+            int oldest = 0;
+            for (int k = 1; k < S.n_map_kf; k++)
+                if (S.map_kf_key[k] < S.map_kf_key[oldest]) oldest = k;
+            map_remove_keyframe(S, S.map_kf_frame[oldest], true);
+        }
+    }
+    sweep_frames(S);
+}
+
+// ---- a fresh stream --------------------------------------------------------------------------------------------------------------------
+TC_FN void stream_init(Stream &S, int first_slot) {
+    // (the caller zero-fills the block first: memset / hipMemset)
+    S.cur = S.ref = S.pre = S.last_keyframe = S.pending = S.latest_keyframe = S.det_frame = -1;
+    S.isinitializing = 1;
+    S.done           = 1;
+    S.result         = TRACK_PASSED;
+    S.pending_slot   = -1;
+    S.det_job        = -1;
+    S.rs_set         = -1;
+    S.kf_state       = KEYFRAME_NONE;
+    S.last_state     = TRACK_PASSED;
+    S.digest         = 1469598103934665603ull;
+    S.n_free_slots   = MAX_SLOTS;
+    for (int k = 0; k < MAX_SLOTS; k++) S.free_slots[k] = first_slot + MAX_SLOTS - 1 - k; // popped in ascending order
+}
+
+} // namespace tc

@@ -297,6 +297,13 @@ void TableTracker::mapRemoveKeyFrame(int h, bool isremovemappoint) { // map.cc:8
 
 // Sliding-window stand-in (WindowKeeper::onFrame; ic_gvins.cc:542, 743, 1391-1410, 445-448, 1675)
 void TableTracker::endFrame() {
+    if (core_) { // statistics, digest, window keeper and sweep are the core's (tc::stage_end_frame)
+        tc::stage_end_frame(*core_, core_cfg_);
+        core_dirty_ = true;
+        if (core_->overflow) throw std::runtime_error("tracker core: capacity exceeded (overflow flags " + std::to_string(core_->overflow) + ")");
+        if (core_->n_log > tc::LOG_CAP / 2) importCore(); // (drains the landmark history into map_lm_)
+        return;
+    }
     const TrackState st = result_;
     const int frame     = cur_;
     if (st != TRACK_PASSED && frame >= 0 && (isnewkeyframe_ || st == TRACK_FIRST_FRAME || st == TRACK_LOST)) {
@@ -357,12 +364,19 @@ TableTracker::TableTracker(Camera::Ptr camera, size_t window_size, const Trackin
 
 TableTracker::~TableTracker() {
     if (logfile_) fclose(logfile_);
+    for (int s : core_slots_) device_->freeSlot(s);
     for (int s : owned_slots_) device_->freeSlot(s);
     if (pending_slot_ >= 0) device_->freeSlot(pending_slot_);
 }
 
-ulong TableTracker::currentFrameId() const { return cur_ >= 0 ? frames_[(size_t) cur_].fid : 0; }
-size_t TableTracker::numCurrentFeatures() const { return cur_ >= 0 ? frames_[(size_t) cur_].rows() : 0; }
+ulong TableTracker::currentFrameId() const {
+    if (core_) return core_->cur >= 0 ? (ulong) core_->frame[core_->cur].fid : 0;
+    return cur_ >= 0 ? frames_[(size_t) cur_].fid : 0;
+}
+size_t TableTracker::numCurrentFeatures() const {
+    if (core_) return core_->cur >= 0 ? (size_t) core_->frame[core_->cur].n_rows : 0;
+    return cur_ >= 0 ? frames_[(size_t) cur_].rows() : 0;
+}
 
 // ---- helpers -------------------------------------------------------------------------------------------------------------------
 template <typename T> void TableTracker::reduceVector(T &vec, const vector<uint8_t> &status) { // :831-839
@@ -547,6 +561,7 @@ void TableTracker::releaseUnusedSlots() {
 
 // ---- stage 0: preprocessing (tracking.cc:107-142) -------------------------------------------------------------------------------
 void TableTracker::beginFrame(const Input &in, StageBatch &next) {
+    if (core_) return coreBeginFrame(in, next);
     t_start_       = std::chrono::steady_clock::now();
     done_          = false;
     result_        = TRACK_PASSED;
@@ -575,6 +590,7 @@ void TableTracker::beginFrame(const Input &in, StageBatch &next) {
 }
 
 void TableTracker::advance(int stage, StageBatch &done, StageBatch &next) {
+    if (core_) return coreAdvance(stage, done, next);
     if (done_) return;
     switch (stage) {
     case 1: onPreprocessDone(done, next); break;
@@ -1126,6 +1142,7 @@ struct Dump {
 } // namespace
 
 std::string TableTracker::dump() const {
+    syncTable();
     Dump d;
     auto fid = [&](int h) { return h >= 0 ? (long) frames_[(size_t) h].fid : -1L; };
     d.f("T init=%d cur=%ld pre=%ld ref=%ld lastkf=%ld pmap=%016llx/%d pref=%016llx/%d ncand=%zu\n", (int) isinitializing_, fid(cur_), fid(pre_),
@@ -1275,6 +1292,7 @@ std::string TableTracker::dumpMap() const {
 }
 
 std::shared_ptr<TableTracker::ObjectView> TableTracker::view() const {
+    syncTable();
     auto V   = std::make_shared<ObjectView>();
     auto map = std::make_shared<Map>(window_size_);
     V->map   = map;
@@ -1363,6 +1381,13 @@ Map::Ptr TableTracker::materialize(vector<Frame::Ptr> *extra) const {
 // Takes over what was done to the objects of a view since it was built (see ObjectView).  Frames and map points that have gone in the
 // table meanwhile (generation mismatch) are skipped; nothing else may have changed the table in between (no frame was tracked).
 void TableTracker::absorb(const ObjectView &V) {
+    syncTable();
+    struct WriteBack { // core mode: the block follows the table image
+        TableTracker *t;
+        ~WriteBack() {
+            if (t->core_) t->exportCore();
+        }
+    } write_back{this};
     for (size_t h = 0; h < V.frame.size() && h < frames_.size(); h++) {
         if (!V.frame[h] || !frames_[h].alive || frames_[h].gen != V.frame_gen[h]) continue;
         Frame_ &f = frames_[h];

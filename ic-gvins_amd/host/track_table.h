@@ -19,6 +19,7 @@
 #include <unordered_map>
 
 #include "tracking.h"
+#include "track_core.h"
 
 namespace icg {
 
@@ -56,6 +57,19 @@ public:
     // run once per process before the table engine is used: throws when this standard library's container does not iterate the way
     // HashOrder assumes (the parallax sums and landmark order of the engine would silently leave the reference's order)
     static void verifyOnce();
+    // the container order as flat arrays (the tracker core's representation, track_core.h): read access, and the way back
+    int bucketCount() const { return (int) bucket_.size(); }
+    const int *bucketData() const { return bucket_.data(); }
+    const int *nextData() const { return next_.data(); }
+    uint64_t magic() const { return magic_; }
+    void restore(const int *next, const uint64_t *keys, size_t stride_keys_bytes, int n, const int *bucket, int n_buckets, int head, uint64_t magic) {
+        next_.assign(next, next + n);
+        key_.resize((size_t) n);
+        for (int i = 0; i < n; i++) key_[(size_t) i] = *reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(keys) + (size_t) i * stride_keys_bytes);
+        bucket_.assign(bucket, bucket + n_buckets);
+        head_  = head;
+        magic_ = magic;
+    }
 
 private:
     static constexpr int kEmpty = -1, kBeforeBegin = -2;
@@ -89,30 +103,49 @@ public:
     // ---- staged interface (same stages as icg::Tracking) ----
     void beginFrame(const Input &in, StageBatch &next);
     void advance(int stage, StageBatch &done, StageBatch &next);
-    bool frameDone() const { return done_; }
-    TrackState result() const { return result_; }
-    bool isNewKeyFrame() const { return isnewkeyframe_; }
+    bool frameDone() const { return core_ ? core_->done != 0 : done_; }
+    TrackState result() const { return core_ ? (TrackState) core_->result : result_; }
+    bool isNewKeyFrame() const { return core_ ? core_->isnewkeyframe != 0 : isnewkeyframe_; }
+
+    // ---- core mode (round 4): the stream's state lives in a tc::Stream block (track_core.h) and the stage bodies are the tracker core's —
+    // the code the device-resident tracker runs inside its stage kernels, compiled for the host.  The table members above are then a
+    // lazily refreshed IMAGE of the block (syncTable(): importCore when the block has changed), so that every accessor, the object view,
+    // absorb() and the canonical dumps work unchanged; absorb() writes the image back (exportCore).  ICG_TRACK_ENGINE=core selects it for
+    // the host executor; the device executor (tracking_device.h) keeps the blocks in HBM and hands a downloaded copy to attachCore().
+    void enableCore();
+    bool coreMode() const { return core_ != nullptr; }
+    tc::Stream *core() { return core_.get(); }
+    const tc::Cfg &coreCfg() const { return core_cfg_; }
+    void markCoreChanged() { core_dirty_ = true; }
+    void syncTable() const {
+        if (core_ && core_dirty_) const_cast<TableTracker *>(this)->importCore();
+    }
+    void importCore(); // tc::Stream -> table members
+    void exportCore(); // table members -> tc::Stream
+    static tc::Cfg makeCoreCfg(const Camera &camera, const TrackingConfig &cfg, size_t window_size);
+    static const uint32_t *bucketsAfterTable(); // HashOrder::bucketsAfter(k) for k = 0..tc::MAX_ROWS + 1
     // sliding-window side effects of GVINS on the map after a frame (WindowKeeper::onFrame) + release of dead frames
     void endFrame();
 
     const icg_detect_grid &grid() const { return grid_; }
     int maxFeaturesPerJob() const { return grid_.max_per_block * block_cnts_; }
-    size_t numTrackedRefPoints() const { return pts2d_new_.size(); }
-    const vector<Point2f> &trackedRefPoints() const { return pts2d_new_; }
-    const vector<Point2f> &referencePoints() const { return pts2d_ref_; }
+    size_t numTrackedRefPoints() const { return core_ ? (size_t) core_->n_new : pts2d_new_.size(); }
+    const vector<Point2f> &trackedRefPoints() const { return syncTable(), pts2d_new_; }
+    const vector<Point2f> &referencePoints() const { return syncTable(), pts2d_ref_; }
 
     // ---- results of the current frame ----
     ulong currentFrameId() const;
-    ulong lastInputFrameId() const { return last_input_fid_; } // id of the frame handed to the last beginFrame (also when it was skipped)
+    ulong lastInputFrameId() const { return core_ ? (ulong) core_->last_input_fid : last_input_fid_; } // id of the frame handed to the last beginFrame (also when it was skipped)
     size_t numCurrentFeatures() const;
     // visits (map-point id, distorted key point) of the current frame's features
     template <typename F> void forEachCurrentFeature(F &&f) const {
+        syncTable();
         if (cur_ < 0) return;
         const Frame_ &fr = frames_[(size_t) cur_];
         for (const Row &r : fr.row) f(r.id, r.kpd); // (any order: the digest does not depend on it)
     }
-    size_t windowKeyFrames() const { return map_kf_.size(); }
-    size_t landmarks() const { return n_landmarks_; }
+    size_t windowKeyFrames() const { return core_ ? (size_t) core_->n_map_kf : map_kf_.size(); }
+    size_t landmarks() const { return core_ ? (size_t) core_->n_landmarks : n_landmarks_; }
 
     // ---- B2 view: the reference-shaped object graph of this stream, built on demand, and the way back ----
     // What code written against the reference's types does to a map between two frames — the optimizer's write-back (keyframe poses,
@@ -335,6 +368,32 @@ private:
     int lost_reset_{0};
     ulong last_input_fid_{0};
     vector<uint8_t> mark_;
+
+    // core mode
+    struct CoreFree {
+        void operator()(tc::Stream *p) const { free(p); }
+    };
+    std::unique_ptr<tc::Stream, CoreFree> core_;
+    tc::Cfg core_cfg_{};
+    bool core_dirty_{false};
+    bool core_changed_{false};          // exportCore() ran: a device-resident copy of the block is stale (tracking_device.h uploads it)
+    bool core_device_resident_{false};  // the authoritative block lives in HBM; core_ is a downloaded copy
+    int core_log_applied_{0};      // entries of core_->log already replayed into map_lm_
+    vector<int> core_slots_;       // the device slots reserved for this stream (core slot pool)
+    Mat core_image_format_;        // rows / cols / channels / step / device flag of the stream's frames (the block keeps addresses only)
+    struct CoreArena {             // this stream's segment of the primitives' work lists (track_core.h Io)
+        int32_t pre_slot{-1}, lk_count{0}, rs_count{0}, tri_count{0}, tri_n_tcw{0}, det_slot{-1}, det_mask_count{0}, det_count{0};
+        double pre_hist{0};
+        vector<int32_t> lk_prev_slot, lk_next_slot, tri_T0, tri_T1, det_quota;
+        vector<tc::P2f> lk_prev, lk_guess, lk_out, lk_undist, rs_p1, rs_p2, det_mask_pts, det_out;
+        vector<uint8_t> lk_status, rs_mask;
+        vector<double> tri_Tcw, tri_pc0, tri_pc1, tri_pw;
+    } arena_;
+    int core_pre_job_{-1}, core_det_job_{-1};
+    tc::Io coreIo(int lk_base);
+    void coreBeginFrame(const Input &in, StageBatch &next);
+    void coreAdvance(int stage, StageBatch &done, StageBatch &next);
+    void coreQueueOutputs(StageBatch &next, bool pre, bool det, bool lk, bool rs, bool tri);
 };
 
 } // namespace icg

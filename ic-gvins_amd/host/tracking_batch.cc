@@ -14,12 +14,15 @@ namespace icg {
 TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &intrinsic, const vector<double> &distortion,
                              const vector<int> &size, const TrackingConfig &cfg, int window_size, int host_threads, int engine)
     : host_threads_(host_threads < 1 ? 1 : host_threads) {
-    if (engine < 0) { // ICG_TRACK_ENGINE=object|table; the drawer hooks only exist in the object engine
+    if (engine < 0) { // ICG_TRACK_ENGINE=object|table|core; the drawer hooks only exist in the object engine
         const char *e = getenv("ICG_TRACK_ENGINE");
-        engine        = (e && e[0] == 'o') || cfg.is_use_visualization ? ENGINE_OBJECT : ENGINE_TABLE;
+        engine        = (e && e[0] == 'o') || cfg.is_use_visualization ? ENGINE_OBJECT : (e && e[0] == 'c') ? ENGINE_CORE : ENGINE_TABLE;
     }
-    engine_ = engine == ENGINE_OBJECT ? ENGINE_OBJECT : ENGINE_TABLE;
-    if (engine_ == ENGINE_TABLE) HashOrder::verifyOnce(); // fails loudly if the container order cannot be reproduced here
+    // ENGINE_CORE: the track table's interface on the tracker core (track_core.h) — the stage bodies of the device-resident tracker, here
+    // compiled for the host and run between the same batched device calls as the table engine
+    const bool core = engine == ENGINE_CORE;
+    engine_ = engine == ENGINE_OBJECT ? ENGINE_OBJECT : (core ? ENGINE_CORE : ENGINE_TABLE);
+    if (engine_ != ENGINE_OBJECT) HashOrder::verifyOnce(); // fails loudly if the container order cannot be reproduced here
     device_ = std::make_shared<DeviceContext>(device, size[0], size[1], n_streams, cfg.track_max_features);
     streams_.resize((size_t) n_streams);
     for (int i = 0; i < n_streams; i++) {
@@ -33,8 +36,9 @@ TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &in
             if (mkdir(outputpath.c_str(), 0755) != 0 && errno != EEXIST)
                 throw std::runtime_error("TrackingBatch: cannot create " + outputpath);
         }
-        if (engine_ == ENGINE_TABLE) {
+        if (engine_ != ENGINE_OBJECT) {
             s.table = std::make_shared<TableTracker>(s.camera, (size_t) window_size, cfg, outputpath, device_, s.ids);
+            if (core) s.table->enableCore();
         } else {
             s.map      = std::make_shared<Map>((size_t) window_size);
             s.tracking = std::make_shared<Tracking>(s.camera, s.map, nullptr, cfg, outputpath, device_, s.ids);
@@ -43,8 +47,8 @@ TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &in
     }
     if (host_threads_ > 1 && n_streams > 1) pool_.reset(new HostPool(std::min(host_threads_, n_streams)));
     device_->setCamera(*streams_[0].camera);
-    grid_        = engine_ == ENGINE_TABLE ? streams_[0].table->grid() : streams_[0].tracking->grid();
-    max_per_job_ = engine_ == ENGINE_TABLE ? streams_[0].table->maxFeaturesPerJob() : streams_[0].tracking->maxFeaturesPerJob();
+    grid_        = engine_ != ENGINE_OBJECT ? streams_[0].table->grid() : streams_[0].tracking->grid();
+    max_per_job_ = engine_ != ENGINE_OBJECT ? streams_[0].table->maxFeaturesPerJob() : streams_[0].tracking->maxFeaturesPerJob();
 }
 
 void TrackingBatch::Stream::currentFeatures(vector<std::pair<ulong, Point2f>> &out) const {
@@ -283,6 +287,14 @@ void TrackingBatch::step(const FrameInput *frames, vector<TrackState> &states) {
         Stream &s     = streams_[(size_t) i];
         TrackState st = s.result();
         states[(size_t) i] = st;
+        if (s.table && s.table->coreMode()) { // statistics, digest and the window keeper are part of the core's end-of-frame stage
+            hostprof::Scope hpk(hostprof::KEEPER);
+            s.table->endFrame();
+            const tc::Stream &C = *s.table->core();
+            s.last_state = st, s.frames = C.frames, s.keyframes = C.keyframes, s.tracked_sum = C.tracked_sum, s.digest = C.digest;
+            s.ids->frame_id = C.frame_id, s.ids->keyframe_id = C.keyframe_id, s.ids->mappoint_id = C.mappoint_id;
+            return;
+        }
         s.last_state       = st;
         s.frames++;
         if (s.isNewKeyFrame() || st == TRACK_FIRST_FRAME || st == TRACK_LOST) s.keyframes++;

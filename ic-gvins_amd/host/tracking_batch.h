@@ -28,7 +28,7 @@ public:
     // Two engines run the same per-frame algorithm behind the same stages: the track table (track_table.h; default, the throughput
     // path) and the reference-shaped object graph (icg::Tracking + Map + WindowKeeper; ICG_TRACK_ENGINE=object).  Per-stream results are
     // identical (tests/test_host_engines_cpu.py).
-    enum Engine { ENGINE_TABLE = 0, ENGINE_OBJECT = 1 };
+    enum Engine { ENGINE_TABLE = 0, ENGINE_OBJECT = 1, ENGINE_CORE = 2 /* the table interface on track_core.h */ };
     struct Stream {
         Camera::Ptr camera;
         std::shared_ptr<IdSpace> ids;

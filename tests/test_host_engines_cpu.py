@@ -122,3 +122,24 @@ def test_refinement_through_the_object_view_equals_the_object_engine():
     assert ra == rb
     for s, (x, y) in enumerate(zip(fa, fb)):
         assert x == y, (s, _first_difference(x, y))
+
+
+# ---- the tracker core (track_core.h): the stage bodies of the device-resident tracker, compiled for the host ------------------------------
+@pytest.mark.parametrize("name", list(CASES))
+def test_core_engine_state_equals_table_engine(name):
+    """ICG_TRACK_ENGINE=core runs the SAME source the stage kernels of the device-resident tracker are compiled from (tracker core: flat
+    per-stream block, fixed capacities) between the same batched device calls.  After every frame its state — imported back into the table
+    members — must dump to the table engine's text: tracker scalars, candidate lists, window, every live frame's rows in container order,
+    every landmark with counters and observation list, and Map::landmarks_' iteration order (replayed from the core's operation log).  The
+    digest / statistics the core computes in its end-of-frame stage must equal the executor's."""
+    w, h, nfeat, n, stream, blank, hist, slow = CASES[name]
+    frames, poses = _scene(w, h, n, stream, blank=blank, blank_value=235 if hist else 90, slow_after=slow)
+    win = WINDOW.get(name, 10)
+    st_t, d_t, stats_t = _drive("table", w, h, nfeat, n, frames, poses, check_hist=hist, window=win)
+    st_c, d_c, stats_c = _drive("core", w, h, nfeat, n, frames, poses, check_hist=hist, window=win)
+    assert st_t == st_c
+    for (k, full_t, _, _), (_, full_c, _, _) in zip(d_t, d_c):
+        if full_t != full_c:
+            i, a, b = _first_difference(full_t, full_c)
+            raise AssertionError(f"{name}: core differs from the table after frame {k}, dump line {i}:\n table: {a}\n core : {b}")
+    assert stats_t == stats_c
