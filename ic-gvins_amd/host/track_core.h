@@ -186,6 +186,10 @@ struct Stream {
     int32_t done, result, pending_slot, mode, det_job, det_ismask, lk_map_begin, lk_map_n, lk_ref_begin, lk_ref_n, ref_tracked, rs_set, kf_state,
         tri_queued, lost_reset, tri_begin;
     u64 last_input_fid;
+    // the tracking.txt line of a keyframe decision (tracking.cc:289-296, 309-315): stamp, dt, parallax, relative translation, relative
+    // rotation [deg]; written out by the host executor when a log file is configured (log_valid: set at the decision, cleared per frame)
+    double log_data[5];
+    int32_t log_valid, pad3_;
     int32_t n_owned, owned_slots[MAX_SLOTS + 1], n_free_slots, free_slots[MAX_SLOTS];
     // candidate lists (tracking.h:129-136) and their carried twins; every list keeps its own length, as the vectors of the table do
     int32_t n_cur, n_new, n_ref, n_ref_undis, n_new_undis, n_ref_frame, n_cand_lk, n_vel_ref, n_vel_cur, n_tracked, n_matched, n_tr_new_undis,
@@ -709,6 +713,15 @@ TC_FN int check_keyframe_state(Stream &S, const Cfg &C) { // :263-307
             const MpRef m = S.tracked_mappoint[k];
             if (mp_valid(S, m.i, m.g)) S.hot[m.i].used++;
         }
+        const Pose &pc = S.frame[S.cur].pose, &pr = S.frame[S.ref].pose;
+        const double dx = pc.t[0] - pr.t[0], dy = pc.t[1] - pr.t[1], dz = pc.t[2] - pr.t[2];
+        double R[9];
+        mat_mul_t(pc.R, pr.R, R);
+        const double pitch = atan(-R[6] / tc_sqrt(R[7] * R[7] + R[8] * R[8])); // :335-341
+        S.log_data[0] = S.frame[S.cur].stamp, S.log_data[1] = dt, S.log_data[2] = parallax;
+        S.log_data[3] = tc_sqrt(dx * dx + dy * dy + dz * dz); // :331-333
+        S.log_data[4] = tc_fabs(pitch * (180.0 / 3.14159265358979323846));
+        S.log_valid   = 1;
     }
     return keyframe_state;
 }
@@ -1110,6 +1123,7 @@ TC_FN void stage_begin_frame(Stream &S, Io &io, double stamp, const Pose &pose, 
     S.done          = 0;
     S.result        = TRACK_PASSED;
     S.isnewkeyframe = 0; // :108
+    S.log_valid     = 0;
     S.mode          = M_NONE;
     S.det_job       = -1;
     S.rs_set        = -1;

@@ -298,6 +298,15 @@ void TableTracker::mapRemoveKeyFrame(int h, bool isremovemappoint) { // map.cc:8
 // Sliding-window stand-in (WindowKeeper::onFrame; ic_gvins.cc:542, 743, 1391-1410, 445-448, 1675)
 void TableTracker::endFrame() {
     if (core_) { // statistics, digest, window keeper and sweep are the core's (tc::stage_end_frame)
+        // tracking.txt (:236-238, 309-315): the decision's numbers were kept by the core; the line is written when the frame ends as TRACKING
+        if (logfile_ && core_->log_valid && core_->result == tc::TRACK_TRACKING && core_->mode == tc::M_TRACK && core_->lost_reset != 2) {
+            logging_data_.assign(core_->log_data, core_->log_data + 5);
+            logging_data_.push_back(static_cast<double>(core_->frame[core_->cur].n_rows));
+            logging_data_.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start_).count());
+            for (double v : logging_data_) fprintf(logfile_, "%-15.9lf ", v);
+            fprintf(logfile_, "\n");
+            fflush(logfile_);
+        }
         tc::stage_end_frame(*core_, core_cfg_);
         core_dirty_ = true;
         if (core_->overflow) throw std::runtime_error("tracker core: capacity exceeded (overflow flags " + std::to_string(core_->overflow) + ")");

@@ -53,7 +53,6 @@ tc::Cfg TableTracker::makeCoreCfg(const Camera &camera, const TrackingConfig &cf
 void TableTracker::enableCore() {
     if (core_) return;
     HashOrder::verifyOnce();
-    if (logfile_) throw std::runtime_error("TableTracker: tracking.txt logging needs the table engine (the core keeps no log lines)");
     core_cfg_ = makeCoreCfg(*camera_, cfg_, window_size_);
     (void) bucketsAfterTable();
     tc::Stream *S = static_cast<tc::Stream *>(calloc(1, sizeof(tc::Stream)));
@@ -130,6 +129,7 @@ void TableTracker::coreQueueOutputs(StageBatch &next, bool pre, bool det, bool l
 }
 
 void TableTracker::coreBeginFrame(const Input &in, StageBatch &next) {
+    t_start_  = std::chrono::steady_clock::now();
     tc::Io io = coreIo(0);
     tc::Pose pose;
     poseToArray12(in.pose, pose.R); // R row-major then t: the 12 doubles of tc::Pose

@@ -143,3 +143,22 @@ def test_core_engine_state_equals_table_engine(name):
             i, a, b = _first_difference(full_t, full_c)
             raise AssertionError(f"{name}: core differs from the table after frame {k}, dump line {i}:\n table: {a}\n core : {b}")
     assert stats_t == stats_c
+
+
+def test_map_writers_on_the_core_engine_equal_the_object_engine(oracle):
+    """culling and window refinement on the core engine: the object view is built from the block's imported image, absorb() writes the image
+    back into the block (exportCore), and the tracker continues on it — outputs and the states four frames later equal the object engine's"""
+    import cull_checks as cc
+    import refine_checks as rc
+    lib = ensure_oracle_host()
+    a = cc.check_window_culling(lib, oracle, engine="object")
+    b = cc.check_window_culling(lib, oracle, engine="core")
+    assert a[0] == b[0] and a[1] == b[1]
+    for s, (x, y) in enumerate(zip(a[2], b[2])):
+        assert x == y, (s, _first_difference(x, y))
+    ra, oa, fa = rc.check_refinement(lib, engine="object")
+    rb, ob, fb = rc.check_refinement(lib, engine="core")
+    assert np.array_equal(oa, ob), (oa, ob)
+    assert ra == rb
+    for s, (x, y) in enumerate(zip(fa, fb)):
+        assert x == y, (s, _first_difference(x, y))
