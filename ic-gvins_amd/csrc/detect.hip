@@ -21,9 +21,6 @@
 
 #include "icg_internal.h"
 
-struct det_roi {
-    int job, block, rx, ry, rw, rh, quota, cand_base; // cand_base: offset into the job's candidate plane
-};
 
 __device__ __forceinline__ unsigned int f32_order_key(float f) {
     unsigned int b = __float_as_uint(f);
@@ -79,7 +76,8 @@ __device__ __forceinline__ float from_right(float v) {
 
 __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
                                                                const int32_t *slots, int pitch, int w, int h, const float2 *mask_pts,
-                                                               const int32_t *mask_off, int radius, const int32_t *vspan /*radius+2*/,
+                                                               const int32_t *mask_begin, const int32_t *mask_cnt /* per job */, int radius,
+                                                               const int32_t *vspan /*radius+2*/,
                                                                unsigned int *roi_max,
                                                                unsigned long long *cand, size_t cand_plane, int32_t *cand_cnt,
                                                                int gx, int gy, int n_blocks, unsigned int m_roi, unsigned int m_gx) {
@@ -93,6 +91,7 @@ __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *ro
     const int roi = icg_div_by_magic(bl, m_roi), rem = bl - roi * (gx * gy);
     const int by = icg_div_by_magic(rem, m_gx), bx = rem - by * gx;
     const det_roi R = rois[roi];
+    if (R.quota <= 0) return; // inactive entry of a dense (job, block) table (device-resident tracker); workgroup-uniform
     const int lane = threadIdx.x & 63;
     const int wv   = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // wave-uniform by construction: keep it in an SGPR
     const int tx0 = bx * FE_TW, ty0 = (by * FE_WAVES + wv) * FE_TH;
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *ro
     {
         const int ytop = R.ry + ty0;                          // image row of tile row 0
         const int xl = R.rx + tx0, xr = xl + FE_TW - 1;        // image columns of the owned lanes
-        const int p0 = mask_off[R.job], p1 = mask_off[R.job + 1];
+        const int p0 = mask_begin[R.job], p1 = p0 + mask_cnt[R.job];
         unsigned int masked = 0;
         for (int pb = p0; pb < p1; pb += 64) {
             const int i = pb + lane;
@@ -346,6 +345,10 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void k_select_subpix(const det_roi 
     __shared__ subpix_smem SP[SEL_WAVES];
     constexpr int NT = 64 * SEL_WAVES;
     const det_roi R = rois[blockIdx.x];
+    if (R.quota <= 0) { // inactive entry of a dense (job, block) table: no corner (its accumulators were never touched)
+        if (threadIdx.x == 0) corner_cnt_host[blockIdx.x] = 0;
+        return;
+    }
     unsigned long long *C = cand + (size_t) R.job * cand_plane + R.cand_base;
     const int n = cand_cnt[blockIdx.x];
     const int t = threadIdx.x;
@@ -454,6 +457,34 @@ static bool circle_row_spans(const std::vector<int32_t> &hw, std::vector<int32_t
     return true;
 }
 
+static int ensure_roi_state(icg_ctx *ctx, int n_roi) {
+    if (n_roi <= ctx->roi_state_cap) return 0;
+    ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_roi_max) (void) hipFree(ctx->d_roi_max);
+    if (ctx->d_cand_cnt) (void) hipFree(ctx->d_cand_cnt);
+    ctx->d_roi_max = nullptr, ctx->d_cand_cnt = nullptr, ctx->roi_state_cap = 0;
+    const int cap = std::max(1024, 2 * n_roi);
+    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_roi_max, sizeof(uint32_t) * (size_t) cap));
+    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_cand_cnt, sizeof(int32_t) * (size_t) cap));
+    ICG_HIP(ctx, hipMemsetAsync(ctx->d_roi_max, 0, sizeof(uint32_t) * (size_t) cap, ctx->stream));
+    ICG_HIP(ctx, hipMemsetAsync(ctx->d_cand_cnt, 0, sizeof(int32_t) * (size_t) cap, ctx->stream));
+    ctx->roi_state_cap = cap;
+    return 0;
+}
+
+static subpix_mask_t subpix_window() {
+    subpix_mask_t M;
+    for (int i = 0; i < 11; i++) {
+        float y  = (float) (i - 5) / 5;
+        float vy = std::exp(-y * y);
+        for (int j = 0; j < 11; j++) {
+            float x         = (float) (j - 5) / 5;
+            M.m[i * 11 + j] = (float) (vy * std::exp(-x * x));
+        }
+    }
+    return M;
+}
+
 static int ensure_detect_ws(icg_ctx *ctx) {
     if (ctx->d_cand) return 0;
     const size_t w = ctx->cfg.width, h = ctx->cfg.height, nb = ctx->cfg.max_batch;
@@ -528,20 +559,12 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     // the disc centres are read by every wave of the job's ROIs (48 per ROI): device copy, not zero-copy
     const int32_t *d_vh    = c.in(vh.data(), vh.size());
     const float2 *d_mpts   = (const float2 *) c.in(mask_pts, 2 * (size_t) n_mask);
-    const int32_t *d_moff  = c.in(mask_off, (size_t) n + 1);
+    std::vector<int32_t> mcnt((size_t) n);
+    for (int b = 0; b < n; b++) mcnt[(size_t) b] = mask_off[b + 1] - mask_off[b];
+    const int32_t *d_moff  = c.in(mask_off, (size_t) n);
+    const int32_t *d_mcnt  = c.in(mcnt.data(), (size_t) n);
     // [roi_max | cand_cnt] per ROI live in the context and are zero between calls (k_select clears the entries it consumed)
-    if (n_roi > ctx->roi_state_cap) {
-        ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_roi_max) (void) hipFree(ctx->d_roi_max);
-        if (ctx->d_cand_cnt) (void) hipFree(ctx->d_cand_cnt);
-        ctx->d_roi_max = nullptr, ctx->d_cand_cnt = nullptr, ctx->roi_state_cap = 0;
-        const int cap = std::max(1024, 2 * n_roi);
-        ICG_HIP(ctx, hipMalloc((void **) &ctx->d_roi_max, sizeof(uint32_t) * (size_t) cap));
-        ICG_HIP(ctx, hipMalloc((void **) &ctx->d_cand_cnt, sizeof(int32_t) * (size_t) cap));
-        ICG_HIP(ctx, hipMemsetAsync(ctx->d_roi_max, 0, sizeof(uint32_t) * (size_t) cap, ctx->stream));
-        ICG_HIP(ctx, hipMemsetAsync(ctx->d_cand_cnt, 0, sizeof(int32_t) * (size_t) cap, ctx->stream));
-        ctx->roi_state_cap = cap;
-    }
+    if ((rc = ensure_roi_state(ctx, n_roi))) return rc;
     unsigned int *d_rmax = ctx->d_roi_max;
     int32_t *d_ccnt      = ctx->d_cand_cnt;
     if ((rc = c.seal())) return rc;
@@ -557,19 +580,11 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
         icg_prof_scope ps(ctx, "detect_min_eig_nms");
         const int gx = (grid->block_w + FE_TW - 1) / FE_TW, gy = (grid->block_h + FE_TH * FE_WAVES - 1) / (FE_TH * FE_WAVES);
         hipLaunchKernelGGL(k_min_eig_nms, dim3(icg_xcd_grid(gx * gy * n_roi)), dim3(64 * FE_WAVES), 0, ctx->stream, d_rois, ctx->d_frames,
-                           ctx->slot_bytes, d_slots, pitch, w, h, d_mpts, d_moff, grid->min_dist, d_vh, d_rmax, ctx->d_cand, cand_plane, d_ccnt,
+                           ctx->slot_bytes, d_slots, pitch, w, h, d_mpts, d_moff, d_mcnt, grid->min_dist, d_vh, d_rmax, ctx->d_cand, cand_plane, d_ccnt,
                            gx, gy, gx * gy * n_roi, icg_div_magic(gx * gy), icg_div_magic(gx));
     }
     {
-        subpix_mask_t M;
-        for (int i = 0; i < 11; i++) {
-            float y  = (float) (i - 5) / 5;
-            float vy = std::exp(-y * y);
-            for (int j = 0; j < 11; j++) {
-                float x         = (float) (j - 5) / 5;
-                M.m[i * 11 + j] = (float) (vy * std::exp(-x * x));
-            }
-        }
+        const subpix_mask_t M = subpix_window();
         icg_prof_scope ps(ctx, "detect_select_subpix");
         hipLaunchKernelGGL(k_select_subpix, dim3(n_roi), dim3(64 * SEL_WAVES), 0, ctx->stream, d_rois, ctx->d_cand, cand_plane, d_ccnt, d_rmax,
                            grid->min_dist, ctx->d_frames, ctx->slot_bytes, d_slots, pitch, z_corners, z_cnt, max_pb, M);
@@ -591,5 +606,43 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
             cnt++;
         }
     }
+    return ICG_OK;
+}
+
+// ---- device-resident tracker (tracker.hip) ----------------------------------------------------------------------------------------------
+// The work of a detection call as the stage kernels leave it in device memory: a DENSE table of n_jobs x n_blocks ROI descriptors
+// (quota <= 0: inactive), the frame slot of every job, the disc centres of every job as (begin, count) into one point array; the corners
+// and their counts stay in device memory (the next stage kernel assembles them in block order).  Asynchronous on the context's stream.
+int icg_detect_circle_rows(int radius, std::vector<int32_t> &vh) {
+    std::vector<int32_t> hw;
+    circle_halfwidths(radius, hw);
+    return circle_row_spans(hw, vh) ? 0 : -1;
+}
+
+int icg_detect_launch_ind(icg_ctx *ctx, int n_jobs, const icg_detect_grid *grid, const void *d_rois, const int32_t *d_slots, const float2 *d_mask_pts,
+                          const int32_t *d_mask_begin, const int32_t *d_mask_cnt, const int32_t *d_vh, float2 *d_corners, int32_t *d_corner_cnt) {
+    const int w = ctx->cfg.width, h = ctx->cfg.height, pitch = ctx->lv[0].pitch;
+    const int nblk = grid->block_cols * grid->block_rows, n_roi = n_jobs * nblk;
+    if (n_jobs > ctx->cfg.max_batch) return icg_fail(ctx, ICG_ERR_CAPACITY, "detect batch %d > max_batch %d", n_jobs, ctx->cfg.max_batch);
+    if (grid->max_per_block > DET_MAX_PER_BLOCK || grid->min_dist > FE_MAX_RADIUS) return icg_fail(ctx, ICG_ERR_INVALID, "bad detection grid");
+    int rc = ensure_detect_ws(ctx);
+    if (rc) return rc;
+    if ((rc = ensure_roi_state(ctx, n_roi))) return rc;
+    const size_t cand_plane = (size_t) w * h;
+    {
+        icg_prof_scope ps(ctx, "detect_min_eig_nms");
+        const int gx = (grid->block_w + FE_TW - 1) / FE_TW, gy = (grid->block_h + FE_TH * FE_WAVES - 1) / (FE_TH * FE_WAVES);
+        hipLaunchKernelGGL(k_min_eig_nms, dim3(icg_xcd_grid(gx * gy * n_roi)), dim3(64 * FE_WAVES), 0, ctx->stream, (const det_roi *) d_rois, ctx->d_frames,
+                           ctx->slot_bytes, d_slots, pitch, w, h, d_mask_pts, d_mask_begin, d_mask_cnt, grid->min_dist, d_vh, ctx->d_roi_max, ctx->d_cand,
+                           cand_plane, ctx->d_cand_cnt, gx, gy, gx * gy * n_roi, icg_div_magic(gx * gy), icg_div_magic(gx));
+    }
+    {
+        const subpix_mask_t M = subpix_window();
+        icg_prof_scope ps(ctx, "detect_select_subpix");
+        hipLaunchKernelGGL(k_select_subpix, dim3(n_roi), dim3(64 * SEL_WAVES), 0, ctx->stream, (const det_roi *) d_rois, ctx->d_cand, cand_plane,
+                           ctx->d_cand_cnt, ctx->d_roi_max, grid->min_dist, ctx->d_frames, ctx->slot_bytes, d_slots, pitch, d_corners, d_corner_cnt,
+                           grid->max_per_block, M);
+    }
+    ICG_HIP(ctx, hipGetLastError());
     return ICG_OK;
 }

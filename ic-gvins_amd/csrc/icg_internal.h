@@ -292,3 +292,21 @@ struct icg_call {
         return 0;
     }
 };
+
+// ---- device-resident tracker (tracker.hip): segmented / indirect launches of the primitives ----------------------------------------------
+// Everything below is asynchronous on the context's stream and takes DEVICE pointers: the stage kernels of the tracker leave the work
+// lists (and their lengths) in device memory, so no host round trip sizes a grid or builds a list between two stages.
+struct det_roi {
+    int job, block, rx, ry, rw, rh, quota, cand_base; // cand_base: offset into the job's candidate plane; quota <= 0: inactive entry
+};
+int icg_preprocess_launch_ind(icg_ctx *ctx, int n, const int32_t *d_slot_ind, const uint8_t *const *images, int stride, int channels, int src_on_device,
+                              double *d_hist_mean);
+int icg_lk_launch_segments(icg_ctx *ctx, int n_seg, int seg_cap, const int32_t *d_count, const int32_t *d_prev_slot, const int32_t *d_next_slot,
+                           const float2 *d_prev, const float2 *d_guess, float2 *d_out, uint8_t *d_status, float2 *d_undist);
+int icg_fm_ransac_launch_sets(icg_ctx *ctx, int n_sets, int seg_cap, const int32_t *d_count, const float2 *d_p1, const float2 *d_p2, double thresh,
+                              double conf, uint8_t *d_mask);
+int icg_triangulate_launch_segments(icg_ctx *ctx, int n_seg, int seg_cap, const int32_t *d_count, const int32_t *d_T0, const int32_t *d_T1, int tcw_cap,
+                                    const double *d_Tcw, const double *d_pc0, const double *d_pc1, double *d_pw);
+int icg_detect_circle_rows(int radius, std::vector<int32_t> &vh); // vh[a] = rows of a disc column at distance a (detect.hip); -1 on failure
+int icg_detect_launch_ind(icg_ctx *ctx, int n_jobs, const icg_detect_grid *grid, const void *d_rois, const int32_t *d_slots, const float2 *d_mask_pts,
+                          const int32_t *d_mask_begin, const int32_t *d_mask_cnt, const int32_t *d_vh, float2 *d_corners, int32_t *d_corner_cnt);

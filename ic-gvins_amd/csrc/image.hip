@@ -21,10 +21,14 @@
 // per-launch job list passed BY VALUE in the kernel arguments (no staging copy, no host sync needed)
 #define PRE_MAX_JOBS 64
 struct pre_jobs {
-    const uint8_t *src[PRE_MAX_JOBS]; // gray source image per job (device memory)
+    const uint8_t *src[PRE_MAX_JOBS]; // gray source image per job (device memory); nullptr: the job is idle this launch
     int32_t slot[PRE_MAX_JOBS];       // destination frame slot per job
     int stride;                       // source row stride in bytes
+    // device-resident tracker (tracker.hip): the slot of job b is slot_ind[b], written by the stage kernel that ran before this launch
+    // (the stream's own slot pool lives on the device); < 0 = no frame for that stream in this step
+    const int32_t *slot_ind;
 };
+__device__ __forceinline__ int pre_job_slot(const pre_jobs &j, int b) { return j.slot_ind ? j.slot_ind[b] : j.slot[b]; }
 
 // ---------------------------------------------------------------------------------------------------------
 __global__ void k_bgr2gray(const uint8_t *bgr, int w, int h, int sstride, size_t sbatch, uint8_t *gray, int gstride,
@@ -45,7 +49,7 @@ __global__ void k_hist256(pre_jobs jobs, int w, int h, unsigned int *hist /*n x 
     __syncthreads();
     const uint8_t *src = jobs.src[b];
     const int stride   = jobs.stride;
-    int total          = w * h;
+    int total          = src ? w * h : 0; // (idle job: the barriers below are still reached by every thread)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         int y = i / w, x = i - y * w;
         atomicAdd(&sh[src[(size_t) y * stride + x]], 1u);
@@ -80,6 +84,7 @@ __global__ __launch_bounds__(64) void k_clahe_lut(pre_jobs jobs, clahe_geom g, u
     const int tile = item - b * (ICG_CLAHE_TILES * ICG_CLAHE_TILES);
     const int ty = tile / ICG_CLAHE_TILES, tx = tile - ty * ICG_CLAHE_TILES;
     const uint8_t *src = jobs.src[b];
+    if (!src) return; // idle job (workgroup-uniform)
     const int stride   = jobs.stride;
     reinterpret_cast<uint4 *>(hist)[lane] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -197,6 +202,8 @@ __global__ __launch_bounds__(256) void k_clahe_apply(pre_jobs jobs, clahe_geom g
     const int b     = blockIdx.z;
     const int t     = threadIdx.x;
     const int T     = ICG_CLAHE_TILES;
+    const int dslot = pre_job_slot(jobs, b);
+    if (!jobs.src[b] || dslot < 0) return; // idle job (workgroup-uniform, before the first barrier)
 
     int ty1 = strip - 1, ty2 = strip;
     if (ty1 < 0) ty1 = 0;
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256) void k_clahe_apply(pre_jobs jobs, clahe_geom g
     if (y_hi > g.h) y_hi = g.h;
     const uint8_t *src = jobs.src[b];
     const int stride   = jobs.stride;
-    uint8_t *dst       = frames + (size_t) jobs.slot[b] * slot_bytes;
+    uint8_t *dst       = frames + (size_t) dslot * slot_bytes;
     const f32x2 XA01 = {xa[0], xa[1]}, XA23 = {xa[2], xa[3]}, XB01 = {xa1[0], xa1[1]}, XB23 = {xa1[2], xa1[3]};
     for (int y = y_lo + wave; y < y_hi; y += 4) {
         const float tyf = y * g.inv_th - 0.5f;
@@ -296,7 +303,9 @@ __global__ __launch_bounds__(256) void k_pyrdown(uint8_t *frames, size_t slot_by
     __shared__ uint8_t in[PD_IH][PD_IW + 1];
     __shared__ int tmp[PD_IH][PD_TW];
     const int b      = blockIdx.z;
-    uint8_t *slot    = frames + (size_t) jobs.slot[b] * slot_bytes;
+    const int dslot  = pre_job_slot(jobs, b);
+    if (dslot < 0) return; // idle job (workgroup-uniform)
+    uint8_t *slot    = frames + (size_t) dslot * slot_bytes;
     const uint8_t *s = slot + src_off;
     uint8_t *d       = slot + dst_off;
     const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH; // output tile origin
@@ -438,7 +447,9 @@ __global__ __launch_bounds__(256) void k_pyramid3(icg_pyr_desc P, pre_jobs jobs,
     if (b >= n_tiles) return;
     const int job = icg_div_by_magic(b, m_tile), rem = b - job * (gx * gy);
     const int by = icg_div_by_magic(rem, m_gx), bx = rem - by * gx;
-    uint8_t *slot = P.base + (size_t) jobs.slot[job] * P.slot_bytes;
+    const int dslot = pre_job_slot(jobs, job);
+    if (dslot < 0) return; // idle job (workgroup-uniform, before the first barrier)
+    uint8_t *slot = P.base + (size_t) dslot * P.slot_bytes;
     const int X3 = bx * 16, Y3 = by * 8;
 
     {
@@ -477,19 +488,37 @@ __global__ __launch_bounds__(256) void k_pyramid3(icg_pyr_desc P, pre_jobs jobs,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, const uint8_t *const *images,
-                                     int stride, int channels, int src_on_device, double *hist_mean) {
-    if (!ctx || n < 0 || (n > 0 && (!slots || !images))) return ICG_ERR_INVALID;
+// tracking.cc:98-102 on the device (segmented preprocess only): float histogram, (float)k product in float, /256.0 and accumulation in
+// double, sequentially — a lane per job
+__global__ void k_hist_mean(int n, const unsigned int *hist, int w, int h, double *mean) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double acc = 0;
+    for (int i = 0; i < 256; i++) {
+        const float hf = (float) hist[(size_t) k * 256 + i];
+        acc += hf * (float) i / 256.0;
+    }
+    mean[k] = acc / ((double) w * h);
+}
+
+// slots: host array (the ABI entry point) — or nullptr with d_slot_ind: the slot of job k is read by the kernels from device memory and
+// images[k] == nullptr marks a job that is idle in this launch (device-resident tracker).  hist_mean: host output (synchronous) or
+// d_hist_mean: device output (asynchronous).
+static int preprocess_impl(icg_ctx *ctx, int n, const int32_t *slots, const int32_t *d_slot_ind, const uint8_t *const *images, int stride, int channels,
+                           int src_on_device, double *hist_mean, double *d_hist_mean) {
+    if (!ctx || n < 0 || (n > 0 && ((!slots && !d_slot_ind) || !images))) return ICG_ERR_INVALID;
     if (n == 0) return ICG_OK;
     if (n > ctx->cfg.max_batch) return icg_fail(ctx, ICG_ERR_CAPACITY, "preprocess batch %d > max_batch %d", n, ctx->cfg.max_batch);
     if (channels != 1 && channels != 3) return icg_fail(ctx, ICG_ERR_INVALID, "channels must be 1 or 3");
     const int w = ctx->cfg.width, h = ctx->cfg.height;
     if (stride < w * channels) return icg_fail(ctx, ICG_ERR_INVALID, "stride too small");
-    for (int k = 0; k < n; k++)
+    for (int k = 0; k < n && slots; k++)
         if (slots[k] < 0 || slots[k] >= ctx->cfg.n_slots || !images[k]) return icg_fail(ctx, ICG_ERR_INVALID, "bad slot/image %d", k);
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
     if (ctx->slot_gen.size() != (size_t) ctx->cfg.n_slots) ctx->slot_gen.assign((size_t) ctx->cfg.n_slots, 0);
-    for (int k = 0; k < n; k++) ctx->slot_gen[(size_t) slots[k]]++; // the slot holds a new image: set-ups cached for the old one are void
+    for (int k = 0; k < n && slots; k++) ctx->slot_gen[(size_t) slots[k]]++; // the slot holds a new image: set-ups cached for the old one are void
+    if (!slots) ctx->lkc_last_n = 0; // (which slots were rewritten is only known on the device: no set-up survives)
+    const bool want_hist = hist_mean || d_hist_mean;
 
     // CLAHE geometry
     const int T = ICG_CLAHE_TILES;
@@ -515,7 +544,7 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
     const size_t raw_batch = (size_t) ctx->raw_pitch * h;
     hipMemcpyKind kind     = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     unsigned int *d_hist   = nullptr;
-    if (hist_mean) {
+    if (want_hist) {
         ctx->arena_off = 0;
         int rc         = icg_arena_reserve(ctx, sizeof(unsigned int) * 256 * (size_t) n + 4096);
         if (rc) return rc;
@@ -528,17 +557,19 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
         const int m = std::min(PRE_MAX_JOBS, n - base);
         pre_jobs jobs;
         memset(&jobs, 0, sizeof jobs);
-        for (int k = 0; k < m; k++) jobs.slot[k] = slots[base + k];
+        for (int k = 0; k < m && slots; k++) jobs.slot[k] = slots[base + k];
+        jobs.slot_ind = d_slot_ind ? d_slot_ind + base : nullptr;
         if (channels == 3) {
             if (!ctx->d_bgr) ICG_HIP(ctx, hipMalloc((void **) &ctx->d_bgr, (size_t) w * 3 * h * ctx->cfg.max_batch));
             for (int k = 0; k < m; k++)
-                ICG_HIP(ctx, hipMemcpy2DAsync(ctx->d_bgr + (size_t) (base + k) * w * 3 * h, (size_t) w * 3, images[base + k], stride,
-                                              (size_t) w * 3, h, kind, ctx->stream));
+                if (images[base + k])
+                    ICG_HIP(ctx, hipMemcpy2DAsync(ctx->d_bgr + (size_t) (base + k) * w * 3 * h, (size_t) w * 3, images[base + k], stride,
+                                                  (size_t) w * 3, h, kind, ctx->stream));
             icg_prof_scope ps(ctx, "bgr2gray");
             hipLaunchKernelGGL(k_bgr2gray, dim3((w + 255) / 256, h, m), dim3(256), 0, ctx->stream,
                                ctx->d_bgr + (size_t) base * w * 3 * h, w, h, w * 3, (size_t) w * 3 * h,
                                ctx->d_raw + (size_t) base * raw_batch, ctx->raw_pitch, raw_batch);
-            for (int k = 0; k < m; k++) jobs.src[k] = ctx->d_raw + (size_t) (base + k) * raw_batch;
+            for (int k = 0; k < m; k++) jobs.src[k] = images[base + k] ? ctx->d_raw + (size_t) (base + k) * raw_batch : nullptr;
             jobs.stride = ctx->raw_pitch;
         } else {
             // device-resident gray frames are consumed in place when uchar4 loads are aligned; otherwise (and for host
@@ -554,6 +585,10 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
                 const bool linear = stride == w && ctx->raw_pitch == w;
                 for (int k = 0; k < m; k++) {
                     uint8_t *dst = ctx->d_raw + (size_t) (base + k) * raw_batch;
+                    if (!images[base + k]) {
+                        jobs.src[k] = nullptr;
+                        continue;
+                    }
                     if (linear)
                         ICG_HIP(ctx, hipMemcpyAsync(dst, images[base + k], (size_t) w * h, kind, ctx->stream));
                     else
@@ -563,7 +598,7 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
                 jobs.stride = ctx->raw_pitch;
             }
         }
-        if (hist_mean) {
+        if (want_hist) {
             icg_prof_scope ps(ctx, "hist256");
             hipLaunchKernelGGL(k_hist256, dim3(64, m), dim3(256), 0, ctx->stream, jobs, w, h, d_hist + (size_t) base * 256);
         }
@@ -592,7 +627,9 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
             }
         }
     }
+    if (d_hist_mean) hipLaunchKernelGGL(k_hist_mean, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, n, d_hist, w, h, d_hist_mean);
     ICG_HIP(ctx, hipGetLastError());
+    if (d_hist_mean) ctx->arena_off = 0;
     if (!hist_mean) return ICG_OK; // asynchronous: later calls on this context are stream-ordered behind these kernels
 
     std::vector<unsigned int> hc((size_t) n * 256);
@@ -610,6 +647,19 @@ extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, 
     }
     ctx->arena_off = 0;
     return ICG_OK;
+}
+
+extern "C" int icg_frames_preprocess(icg_ctx *ctx, int n, const int32_t *slots, const uint8_t *const *images, int stride, int channels,
+                                     int src_on_device, double *hist_mean) {
+    if (n > 0 && !slots) return ICG_ERR_INVALID;
+    return preprocess_impl(ctx, n, slots, nullptr, images, stride, channels, src_on_device, hist_mean, nullptr);
+}
+
+// device-resident tracker: slots read from device memory (d_slot_ind[k] < 0 or images[k] == nullptr: stream k idles), brightness mean
+// (histogram gate) left in device memory; asynchronous on the context's stream
+int icg_preprocess_launch_ind(icg_ctx *ctx, int n, const int32_t *d_slot_ind, const uint8_t *const *images, int stride, int channels,
+                              int src_on_device, double *d_hist_mean) {
+    return preprocess_impl(ctx, n, nullptr, d_slot_ind, images, stride, channels, src_on_device, nullptr, d_hist_mean);
 }
 
 extern "C" int icg_frame_download(icg_ctx *ctx, int slot, int level, uint8_t *dst, int dst_stride) {

@@ -889,10 +889,17 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_des
                                                     const int32_t *next_slot, const float2 *prev_pts,
                                                     const float2 *guess_pts, float2 *out_pts, unsigned char *status,
                                                     int has_cam, icg_camera cam, float2 *out_undist, int img_w, int img_h,
-                                                    const int32_t *reuse_idx, const unsigned int *cache_rd, unsigned int *cache_wr) {
+                                                    const int32_t *reuse_idx, const unsigned int *cache_rd, unsigned int *cache_wr,
+                                                    int seg_cap, const int32_t *seg_count) {
     __shared__ lk_smem S;
     const int i = icg_xcd_chunked(blockIdx.x, n);
     if (i >= n) return;
+    // segmented call (device-resident tracker, tracker.hip): the points of stream s are entries [s * seg_cap, s * seg_cap + seg_count[s])
+    // of every array; the stage kernel that ran before this launch left the count in device memory — no host round trip sizes the grid
+    if (seg_count) {
+        const int s = i / seg_cap;
+        if (i - s * seg_cap >= seg_count[s]) return; // wave-uniform
+    }
     const int lane = threadIdx.x;
     const unsigned char *sP = P.base + (size_t) prev_slot[i] * P.slot_bytes;
     const unsigned char *sN = P.base + (size_t) next_slot[i] * P.slot_bytes;
@@ -1106,7 +1113,7 @@ extern "C" int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, co
         else
             hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp,
                                d_gs, d_out, d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height,
-                               (const int32_t *) nullptr, (const unsigned int *) nullptr, (unsigned int *) nullptr);
+                               (const int32_t *) nullptr, (const unsigned int *) nullptr, (unsigned int *) nullptr, 0, (const int32_t *) nullptr);
     }
     if (keep_idx) {
         icg_prof_scope ps(ctx, "keep_indices");
@@ -1171,7 +1178,7 @@ extern "C" int icg_lk_track_fb_reuse(icg_ctx *ctx, int n, const int32_t *prev_sl
         icg_prof_scope ps(ctx, "lk_track_fb");
         hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp, d_gs,
                            d_out, d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height, h_ri,
-                           (const unsigned int *) (hinted ? ctx->d_lkc[rdb] : nullptr), ctx->d_lkc[wrb]);
+                           (const unsigned int *) (hinted ? ctx->d_lkc[rdb] : nullptr), ctx->d_lkc[wrb], 0, (const int32_t *) nullptr);
     }
     ICG_HIP(ctx, hipGetLastError());
     // what the blocks just written belong to (the NEXT image of every point, at its generation)
@@ -1190,5 +1197,20 @@ extern "C" int icg_lk_reuse_stats(icg_ctx *ctx, uint64_t *out2) {
     if (!ctx || !out2) return ICG_ERR_INVALID;
     out2[0] = ctx->lkc_points;
     out2[1] = ctx->lkc_hits_hinted;
+    return ICG_OK;
+}
+
+// Segmented launch for the device-resident tracker (tracker.hip): every array is device memory laid out as n_seg segments of seg_cap
+// entries, d_count[s] of them valid; asynchronous on the context's stream (the tracker's next stage kernel is stream-ordered behind it).
+int icg_lk_launch_segments(icg_ctx *ctx, int n_seg, int seg_cap, const int32_t *d_count, const int32_t *d_prev_slot, const int32_t *d_next_slot,
+                           const float2 *d_prev, const float2 *d_guess, float2 *d_out, uint8_t *d_status, float2 *d_undist) {
+    if (!ctx->has_cam) return icg_fail(ctx, ICG_ERR_INVALID, "camera not set");
+    const int n = n_seg * seg_cap;
+    icg_prof_scope ps(ctx, "lk_track_fb");
+    hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_prev_slot, d_next_slot, d_prev,
+                       d_guess, d_out, d_status, 1, ctx->cam, d_undist, ctx->cfg.width, ctx->cfg.height, (const int32_t *) nullptr,
+                       (const unsigned int *) nullptr, (unsigned int *) nullptr, seg_cap, d_count);
+    ICG_HIP(ctx, hipGetLastError());
+    ctx->lkc_last_n = 0;
     return ICG_OK;
 }

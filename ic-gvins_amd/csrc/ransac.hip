@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <map>
+#include <mutex>
 
 #include "icg_internal.h"
 
@@ -478,11 +480,8 @@ extern "C" int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, c
 
 // ---------------------------------------------------------------------------------------------------------
 // F8: 4x4 DLT, smallest right singular vector by one-sided Jacobi (registers), one lane per point.
-__global__ void k_triangulate(int n, const int32_t *T0_idx, const int32_t *T1_idx, const double *Tcw12, const double *pc0,
-                              const double *pc1, double *pw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double *T0 = Tcw12 + 12 * (size_t) T0_idx[i], *T1 = Tcw12 + 12 * (size_t) T1_idx[i];
+// one point: T0 / T1 its two 3x4 camera matrices, pc0 / pc1 / pw entry i of the arrays
+__device__ __forceinline__ void triangulate_point(int i, const double *T0, const double *T1, const double *pc0, const double *pc1, double *pw) {
     double D[4][4], V[4][4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -554,6 +553,25 @@ __global__ void k_triangulate(int n, const int32_t *T0_idx, const int32_t *T1_id
     pw[3 * i + 2] = v2 / v3;
 }
 
+__global__ void k_triangulate(int n, const int32_t *T0_idx, const int32_t *T1_idx, const double *Tcw12, const double *pc0,
+                              const double *pc1, double *pw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    triangulate_point(i, Tcw12 + 12 * (size_t) T0_idx[i], Tcw12 + 12 * (size_t) T1_idx[i], pc0, pc1, pw);
+}
+
+// segmented form (device-resident tracker): stream s owns entries [s * seg_cap, s * seg_cap + count[s]) of the point arrays and the
+// camera matrices [s * tcw_cap, ...) — its T0 / T1 indices are local to that table
+__global__ void k_triangulate_seg(int n_seg, int seg_cap, const int32_t *count, const int32_t *T0_idx, const int32_t *T1_idx, int tcw_cap,
+                                  const double *Tcw12, const double *pc0, const double *pc1, double *pw) {
+    const int s = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg || k >= count[s]) return;
+    const int i      = s * seg_cap + k;
+    const double *T  = Tcw12 + 12 * (size_t) s * tcw_cap;
+    triangulate_point(i, T + 12 * (size_t) T0_idx[i], T + 12 * (size_t) T1_idx[i], pc0, pc1, pw);
+}
+
 extern "C" int icg_triangulate(icg_ctx *ctx, int n, const int32_t *T0_idx, const int32_t *T1_idx, int n_T,
                                const double *Tcw12, const double *pc0, const double *pc1, double *pw) {
     if (!ctx || n < 0) return ICG_ERR_INVALID;
@@ -580,4 +598,216 @@ extern "C" int icg_triangulate(icg_ctx *ctx, int n, const int32_t *T0_idx, const
     }
     ICG_HIP(ctx, hipGetLastError());
     return c.finish();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Device-resident tracker (tracker.hip): cv::findFundamentalMat(FM_RANSAC) of one point set per stream, the WHOLE run in one launch — the
+// host loop of icg_fm_ransac (subset draws, one launch per round, sequential replay of the best / niters recurrence) moves into the
+// workgroup that owns the set:
+//   round:  thread 0 draws up to FM_HPW subsets from the set's cv::RNG (getSubset + checkSubset, RNG-consuming redraws) -> LDS
+//           wave 0, a lane per hypothesis: seven-point solve (the serial FP64 chain of k_fm_hypothesis) -> models in LDS
+//           four waves, a wave per (hypothesis, model): inlier bits by ballot + count -> LDS
+//           thread 0 replays the hypotheses in order: best mask, max_good, niters = RANSACUpdateNumIters(...)
+// Any chunking of the hypothesis stream gives the sequential algorithm's result (scores do not depend on one another; hypotheses past
+// the updated niters are discarded) — the argument of icg_fm_ransac.  RANSACUpdateNumIters needs log and pow: their values for every
+// (set size, inlier count) come from a table the HOST computed with the same libm calls the host path makes (fm_denom_table), so the
+// iteration counts are the host path's bit for bit; the comparisons, the division and lrint run on the device in IEEE double.
+__device__ __forceinline__ unsigned dev_rng_next(unsigned long long &state) {
+    state = (unsigned long long) (unsigned) state * 4164903690U + (unsigned) (state >> 32);
+    return (unsigned) state;
+}
+__device__ bool dev_have_collinear(const float2 *pts, const int *idx) { // calib3d precomp.hpp haveCollinearPoints(m, 7)
+    const int i = 6;
+    for (int j = 0; j < i; j++) {
+        const double dx1 = pts[idx[j]].x - pts[idx[i]].x;
+        const double dy1 = pts[idx[j]].y - pts[idx[i]].y;
+        for (int k = 0; k < j; k++) {
+            const double dx2 = pts[idx[k]].x - pts[idx[i]].x;
+            const double dy2 = pts[idx[k]].y - pts[idx[i]].y;
+            if (fabs(dx2 * dy1 - dy2 * dx1) <= (double) FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
+        }
+    }
+    return false;
+}
+__device__ bool dev_get_subset(unsigned long long &rng, int n, const float2 *p1, const float2 *p2, int idx[7]) {
+    for (int attempt = 0; attempt < 10000; attempt++) {
+        for (int i = 0; i < 7; i++) {
+            int v;
+            for (;;) {
+                v = (int) (dev_rng_next(rng) % (unsigned) n); // RNG::uniform(0, n), n > 0
+                bool dup = false;
+                for (int q = 0; q < i; q++) dup |= idx[q] == v;
+                if (!dup) break;
+            }
+            idx[i] = v;
+        }
+        if (!dev_have_collinear(p1, idx) && !dev_have_collinear(p2, idx)) return true;
+    }
+    return false;
+}
+
+#define FMS_MAX_WORDS 16 // 64-bit inlier words per model: sets of up to 1024 points
+
+__global__ __launch_bounds__(256, 1) void k_fm_ransac_sets(int n_sets, int seg_cap, const int32_t *count, const float2 *pts1, const float2 *pts2,
+                                                           float thresh2, double log_num, const double *denom_tab, int tab_n, uint8_t *mask) {
+    __shared__ double Fm[FM_HPW][27];
+    __shared__ int n_sh[FM_HPW];
+    __shared__ int idx_sh[FM_HPW][7];
+    __shared__ int good_sh[FM_HPW * 3];
+    __shared__ unsigned long long bits_sh[FM_HPW * 3][FMS_MAX_WORDS];
+    __shared__ unsigned long long best_sh[FMS_MAX_WORDS];
+    __shared__ int nh_sh, iter_sh, niters_sh, max_good_sh;
+    const int s = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    if (s >= n_sets) return;
+    const int n = count[s];
+    if (n <= 0) return; // no set for this stream in this step
+    const float2 *p1 = pts1 + (size_t) s * seg_cap, *p2 = pts2 + (size_t) s * seg_cap;
+    uint8_t *m       = mask + (size_t) s * seg_cap;
+    if (n < 15 || n > tab_n || n > 64 * FMS_MAX_WORDS) { // the reference only calls findFundamentalMat with >= 15 points: leave untouched
+        for (int i = t; i < n; i += 256) m[i] = 1;
+        return;
+    }
+    const int words = (n + 63) >> 6;
+    fm_set S;
+    S.pt_begin = 0, S.n_pts = n, S.hyp_begin = 0, S.n_hyp = 0, S.word_begin = 0, S.words_per_model = words;
+    unsigned long long rng = 0xffffffffffffffffull; // cv::RNG((uint64) -1): the fixed seed of every findFundamentalMat call
+    if (t == 0) iter_sh = 0, niters_sh = 1000, max_good_sh = 0;
+    if (t < FMS_MAX_WORDS) best_sh[t] = 0;
+    __syncthreads();
+    for (;;) {
+        if (t == 0) {
+            int nh = min(FM_HPW, niters_sh - iter_sh);
+            for (int h = 0; h < nh; h++) {
+                if (!dev_get_subset(rng, n, p1, p2, idx_sh[h])) {
+                    // ptsetreg.cpp run(): no valid subset -> the iterations end here (nothing found if this was the first one)
+                    niters_sh = iter_sh + h;
+                    nh        = h;
+                    break;
+                }
+            }
+            nh_sh = nh;
+        }
+        __syncthreads();
+        const int nh = nh_sh;
+        if (nh <= 0) break;
+        if (wave == 0 && lane < nh) {
+            int nm = 0;
+            seven_point_solve(S, idx_sh[lane], p1, p2, Fm[lane], &nm);
+            n_sh[lane] = nm;
+        }
+        __syncthreads();
+        for (int pair = wave; pair < 3 * nh; pair += 4) {
+            const int hl = pair / 3, model = pair - 3 * hl;
+            if (model >= n_sh[hl]) {
+                if (lane == 0) good_sh[pair] = -1;
+                continue;
+            }
+            const double *F = Fm[hl] + 9 * model;
+            const double F0 = F[0], F1 = F[1], F2 = F[2], F3 = F[3], F4 = F[4], F5 = F[5], F6 = F[6], F7 = F[7], F8 = F[8];
+            int cnt = 0;
+            for (int base = 0; base < n; base += 64) {
+                const int i = base + lane;
+                bool in     = false;
+                if (i < n) {
+                    const float2 a0 = p1[i], b0 = p2[i];
+                    const double x1 = a0.x, y1 = a0.y, x2 = b0.x, y2 = b0.y;
+                    double a = F0 * x1 + F1 * y1 + F2;
+                    double b = F3 * x1 + F4 * y1 + F5;
+                    double c = F6 * x1 + F7 * y1 + F8;
+                    double s2 = 1. / (a * a + b * b);
+                    double d2 = x2 * a + y2 * b + c;
+                    a         = F0 * x2 + F3 * y2 + F6;
+                    b         = F1 * x2 + F4 * y2 + F7;
+                    c         = F2 * x2 + F5 * y2 + F8;
+                    double s1 = 1. / (a * a + b * b);
+                    double d1 = x1 * a + y1 * b + c;
+                    float e   = (float) fmax(d1 * d1 * s1, d2 * d2 * s2);
+                    in        = e <= thresh2;
+                }
+                const unsigned long long mm = __ballot(in);
+                if (lane == 0) bits_sh[pair][base >> 6] = mm;
+                cnt += __popcll(mm);
+            }
+            if (lane == 0) good_sh[pair] = cnt;
+        }
+        __syncthreads();
+        if (t == 0) { // sequential replay of RANSACPointSetRegistrator::run over the scores (ptsetreg.cpp)
+            int iter = iter_sh, niters = niters_sh, max_good = max_good_sh;
+            for (int h = 0; h < nh && iter < niters; h++, iter++) {
+                for (int mdl = 0; mdl < 3; mdl++) {
+                    const int good = good_sh[h * 3 + mdl];
+                    if (good < 0) break;
+                    if (good > max(max_good, 7 - 1)) {
+                        for (int w = 0; w < words; w++) best_sh[w] = bits_sh[h * 3 + mdl][w];
+                        max_good = good;
+                        // RANSACUpdateNumIters(conf, (n - good) / n, 7, niters) with log(1 - (1 - ep)^7) from the host's table
+                        const double denom = denom_tab[(size_t) n * (tab_n + 1) + good];
+                        if (denom != denom) { // (NaN marks 1 - (1 - ep)^7 < DBL_MIN: "return 0")
+                            niters = 0;
+                        } else {
+                            niters = (denom >= 0 || -log_num >= niters * (-denom)) ? niters : (int) lrint(log_num / denom);
+                        }
+                    }
+                }
+            }
+            iter_sh = iter, niters_sh = niters, max_good_sh = max_good;
+        }
+        __syncthreads();
+        if (iter_sh >= niters_sh) break;
+    }
+    __syncthreads();
+    const bool found = max_good_sh > 0;
+    for (int i = t; i < n; i += 256) m[i] = found ? (uint8_t) ((best_sh[i >> 6] >> (i & 63)) & 1ull) : (uint8_t) 0;
+}
+
+// log(1 - (1 - ep)^7) for ep = (n - good) / n, n = 0..tab_n, good = 0..n, with the libm calls of ransac_update_num_iters (NaN where that
+// function returns 0 before taking the logarithm): one table per process and device, shared by every tracker
+static int fm_denom_table(icg_ctx *ctx, int tab_n, const double **d_tab) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, double *> tabs;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(ctx->cfg.device, tab_n);
+    auto it  = tabs.find(key);
+    if (it == tabs.end()) {
+        std::vector<double> h((size_t) (tab_n + 1) * (tab_n + 1), 0.0);
+        for (int n = 1; n <= tab_n; n++)
+            for (int good = 0; good <= n; good++) {
+                double ep = (double) (n - good) / n;
+                ep        = std::min(std::max(ep, 0.), 1.);
+                double denom = 1. - std::pow(1. - ep, 7);
+                h[(size_t) n * (tab_n + 1) + good] = denom < DBL_MIN ? std::nan("") : std::log(denom);
+            }
+        double *d = nullptr;
+        ICG_HIP(ctx, hipMalloc((void **) &d, h.size() * sizeof(double)));
+        ICG_HIP(ctx, hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+        it = tabs.emplace(key, d).first;
+    }
+    *d_tab = it->second;
+    return 0;
+}
+
+int icg_fm_ransac_launch_sets(icg_ctx *ctx, int n_sets, int seg_cap, const int32_t *d_count, const float2 *d_p1, const float2 *d_p2, double thresh,
+                              double conf, uint8_t *d_mask) {
+    if (thresh <= 0) thresh = 3;
+    if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
+    const int tab_n    = std::min(seg_cap, 64 * FMS_MAX_WORDS);
+    const double *d_tab = nullptr;
+    int rc = fm_denom_table(ctx, tab_n, &d_tab);
+    if (rc) return rc;
+    double p         = std::min(std::max(conf, 0.), 1.);
+    const double num = std::log(std::max(1. - p, DBL_MIN)); // the numerator of RANSACUpdateNumIters
+    icg_prof_scope ps(ctx, "fm_ransac_sets");
+    hipLaunchKernelGGL(k_fm_ransac_sets, dim3(n_sets), dim3(256), 0, ctx->stream, n_sets, seg_cap, d_count, d_p1, d_p2, (float) (thresh * thresh), num, d_tab,
+                       tab_n, d_mask);
+    ICG_HIP(ctx, hipGetLastError());
+    return ICG_OK;
+}
+
+int icg_triangulate_launch_segments(icg_ctx *ctx, int n_seg, int seg_cap, const int32_t *d_count, const int32_t *d_T0, const int32_t *d_T1, int tcw_cap,
+                                    const double *d_Tcw, const double *d_pc0, const double *d_pc1, double *d_pw) {
+    icg_prof_scope ps(ctx, "triangulate");
+    hipLaunchKernelGGL(k_triangulate_seg, dim3((seg_cap + 63) / 64, n_seg), dim3(64), 0, ctx->stream, n_seg, seg_cap, d_count, d_T0, d_T1, tcw_cap, d_Tcw,
+                       d_pc0, d_pc1, d_pw);
+    ICG_HIP(ctx, hipGetLastError());
+    return ICG_OK;
 }

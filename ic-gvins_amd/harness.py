@@ -129,7 +129,7 @@ class StreamBatch:
         self._err = err
 
     def engine(self):
-        return ["table", "object", "core"][self.lib.icgh_batch_engine(C.c_void_p(self.h_))]
+        return ["table", "object", "core", "device"][self.lib.icgh_batch_engine(C.c_void_p(self.h_))]
 
     def dump(self, stream, kind=0):
         """canonical text of a stream's tracker + map state: kind 0 the engine's state, 1 the map part (table engine), 2 the map part

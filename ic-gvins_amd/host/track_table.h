@@ -112,8 +112,25 @@ public:
     // lazily refreshed IMAGE of the block (syncTable(): importCore when the block has changed), so that every accessor, the object view,
     // absorb() and the canonical dumps work unchanged; absorb() writes the image back (exportCore).  ICG_TRACK_ENGINE=core selects it for
     // the host executor; the device executor (tracking_device.h) keeps the blocks in HBM and hands a downloaded copy to attachCore().
-    void enableCore();
+    void enableCore(bool device_resident = false);
     bool coreMode() const { return core_ != nullptr; }
+    bool coreDeviceResident() const { return core_device_resident_; }
+    // device-resident block: exportCore() ran since the last call (the executor uploads the block then) / the executor restarted the
+    // device's landmark history after this copy replayed it
+    bool takeCoreChanged() {
+        const bool c  = core_changed_;
+        core_changed_ = false;
+        return c;
+    }
+    void coreLogRestarted() {
+        core_->n_log      = 0;
+        core_log_applied_ = 0;
+    }
+    void setCoreImageFormat(const Mat &m) {
+        core_image_format_      = m;
+        core_image_format_.data = nullptr;
+        core_image_format_.storage.reset();
+    }
     tc::Stream *core() { return core_.get(); }
     const tc::Cfg &coreCfg() const { return core_cfg_; }
     void markCoreChanged() { core_dirty_ = true; }

@@ -50,8 +50,9 @@ tc::Cfg TableTracker::makeCoreCfg(const Camera &camera, const TrackingConfig &cf
     return C;
 }
 
-void TableTracker::enableCore() {
+void TableTracker::enableCore(bool device_resident) {
     if (core_) return;
+    core_device_resident_ = device_resident;
     HashOrder::verifyOnce();
     core_cfg_ = makeCoreCfg(*camera_, cfg_, window_size_);
     (void) bucketsAfterTable();
@@ -59,10 +60,12 @@ void TableTracker::enableCore() {
     if (!S) throw std::bad_alloc();
     core_.reset(S);
     tc::stream_init(*S, 0);
-    // the stream's own slot pool: MAX_SLOTS slots of the context, reserved for its lifetime
-    for (int k = 0; k < tc::MAX_SLOTS; k++) core_slots_.push_back(device_->allocSlot());
-    for (int k = 0; k < tc::MAX_SLOTS; k++) S->free_slots[k] = core_slots_[(size_t) (tc::MAX_SLOTS - 1 - k)];
-    S->n_free_slots = tc::MAX_SLOTS;
+    if (!device_resident) {
+        // the stream's own slot pool: MAX_SLOTS slots of the context, reserved for its lifetime
+        for (int k = 0; k < tc::MAX_SLOTS; k++) core_slots_.push_back(device_->allocSlot());
+        for (int k = 0; k < tc::MAX_SLOTS; k++) S->free_slots[k] = core_slots_[(size_t) (tc::MAX_SLOTS - 1 - k)];
+        S->n_free_slots = tc::MAX_SLOTS;
+    }
     arena_.lk_prev_slot.resize(tc::MAX_ROWS), arena_.lk_next_slot.resize(tc::MAX_ROWS);
     arena_.lk_prev.resize(tc::MAX_ROWS), arena_.lk_guess.resize(tc::MAX_ROWS), arena_.lk_out.resize(tc::MAX_ROWS), arena_.lk_undist.resize(tc::MAX_ROWS);
     arena_.lk_status.resize(tc::MAX_ROWS), arena_.rs_mask.resize(tc::MAX_ROWS);

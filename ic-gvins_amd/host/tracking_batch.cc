@@ -16,12 +16,12 @@ TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &in
     : host_threads_(host_threads < 1 ? 1 : host_threads) {
     if (engine < 0) { // ICG_TRACK_ENGINE=object|table|core; the drawer hooks only exist in the object engine
         const char *e = getenv("ICG_TRACK_ENGINE");
-        engine        = (e && e[0] == 'o') || cfg.is_use_visualization ? ENGINE_OBJECT : (e && e[0] == 'c') ? ENGINE_CORE : ENGINE_TABLE;
+        engine        = (e && e[0] == 'o') || cfg.is_use_visualization ? ENGINE_OBJECT : (e && e[0] == 'c') ? ENGINE_CORE : (e && e[0] == 'd') ? ENGINE_DEVICE : ENGINE_TABLE;
     }
     // ENGINE_CORE: the track table's interface on the tracker core (track_core.h) — the stage bodies of the device-resident tracker, here
     // compiled for the host and run between the same batched device calls as the table engine
     const bool core = engine == ENGINE_CORE;
-    engine_ = engine == ENGINE_OBJECT ? ENGINE_OBJECT : (core ? ENGINE_CORE : ENGINE_TABLE);
+    engine_ = engine == ENGINE_OBJECT ? ENGINE_OBJECT : (core ? ENGINE_CORE : engine == ENGINE_DEVICE ? ENGINE_DEVICE : ENGINE_TABLE);
     if (engine_ != ENGINE_OBJECT) HashOrder::verifyOnce(); // fails loudly if the container order cannot be reproduced here
     device_ = std::make_shared<DeviceContext>(device, size[0], size[1], n_streams, cfg.track_max_features);
     streams_.resize((size_t) n_streams);
@@ -47,11 +47,95 @@ TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &in
     }
     if (host_threads_ > 1 && n_streams > 1) pool_.reset(new HostPool(std::min(host_threads_, n_streams)));
     device_->setCamera(*streams_[0].camera);
+    if (engine_ == ENGINE_DEVICE) {
+        if (getenv("ICG_TRACKING_LOG_DIR")) throw std::runtime_error("TrackingBatch: tracking.txt logging needs a host engine (ICG_TRACK_ENGINE=table|core)");
+        const tc::Cfg C = TableTracker::makeCoreCfg(*streams_[0].camera, cfg, (size_t) window_size);
+        icg_tracker_config tcfg;
+        static_assert(sizeof(tcfg) == sizeof(C), "icg_tracker_config mirrors tc::Cfg");
+        memcpy(&tcfg, &C, sizeof tcfg);
+        const int rc = icg_tracker_create(device_->ctx(), n_streams, &tcfg, TableTracker::bucketsAfterTable(), tc::MAX_ROWS + 2, &tracker_);
+        if (rc != ICG_OK) throw std::runtime_error(std::string("icg_tracker_create failed: ") + icg_last_error(device_->ctx()));
+        for (int i = 0; i < n_streams; i++) {
+            streams_[(size_t) i].tracker       = tracker_;
+            streams_[(size_t) i].tracker_index = i;
+        }
+    }
     grid_        = engine_ != ENGINE_OBJECT ? streams_[0].table->grid() : streams_[0].tracking->grid();
     max_per_job_ = engine_ != ENGINE_OBJECT ? streams_[0].table->maxFeaturesPerJob() : streams_[0].tracking->maxFeaturesPerJob();
 }
 
+TrackingBatch::~TrackingBatch() {
+    if (tracker_) icg_tracker_destroy(tracker_);
+}
+
+void TrackingBatch::Stream::syncDevice() const {
+    if (!tracker || !device_stale) return;
+    if (!table->coreMode()) table->enableCore(true); // the host copy of the block (2.7 MB) exists only for streams somebody looked at
+    const int rc = icg_tracker_download(tracker, tracker_index, table->core());
+    if (rc != ICG_OK) throw std::runtime_error("icg_tracker_download failed");
+    table->markCoreChanged();
+    device_stale = false;
+}
+
+// ---- ENGINE_DEVICE: one chain of launches per step, one wait (csrc/tracker.hip) ---------------------------------------------------------
+void TrackingBatch::stepDevice(const FrameInput *frames, vector<TrackState> &states) {
+    const int n = (int) streams_.size();
+    hostprof::Scope hp_total(hostprof::STEP_TOTAL);
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    states.assign((size_t) n, TRACK_PASSED);
+    dev_images_.assign((size_t) n, nullptr);
+    dev_stamps_.assign((size_t) n, 0.0);
+    dev_poses_.resize(12 * (size_t) n);
+    dev_results_.resize((size_t) n);
+    int stride = 0, channels = 1, on_device = 0;
+    bool any = false;
+    for (int i = 0; i < n; i++) {
+        const FrameInput &in = frames[(size_t) i];
+        Stream &s            = streams_[(size_t) i];
+        s.view_.reset(); // (an object view is a snapshot between two frames)
+        if (!in.valid) continue;
+        if (any && ((int) in.image.step != stride || in.image.channels() != channels || (in.image.device ? 1 : 0) != on_device))
+            throw std::runtime_error("TrackingBatch (device engine): the frames of one step must share stride, channels and residency");
+        any = true, stride = (int) in.image.step, channels = in.image.channels(), on_device = in.image.device ? 1 : 0;
+        dev_images_[(size_t) i] = in.image.data;
+        dev_stamps_[(size_t) i] = in.stamp;
+        poseToArray12(in.pose, dev_poses_.data() + 12 * (size_t) i);
+        s.table->setCoreImageFormat(in.image);
+    }
+    if (any) {
+        hostprof::Scope hp(hostprof::DEV_LK);
+        const int rc = icg_tracker_step(tracker_, dev_images_.data(), stride, channels, on_device, dev_stamps_.data(), dev_poses_.data(), dev_results_.data());
+        if (rc != ICG_OK) throw std::runtime_error(std::string("icg_tracker_step failed: ") + icg_last_error(device_->ctx()));
+    }
+    const double t1 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    timing[2] += t1 - t0;
+    uint64_t lk = 0, det = 0, rs = 0, tri = 0, pre = 0;
+    for (int i = 0; any && i < n; i++) {
+        Stream &s                   = streams_[(size_t) i];
+        const icg_tracker_result &r = dev_results_[(size_t) i];
+        if (!r.active) continue;
+        s.last         = r;
+        s.device_stale = true;
+        states[(size_t) i] = (TrackState) r.state;
+        s.last_state = (TrackState) r.state, s.frames = r.frames, s.keyframes = r.keyframes, s.tracked_sum = r.tracked_sum, s.digest = r.digest;
+        s.ids->frame_id = r.frame_id, s.ids->keyframe_id = r.keyframe_id, s.ids->mappoint_id = r.mappoint_id;
+        lk += (uint64_t) r.lk_points, det += (uint64_t) r.detect_jobs, rs += (uint64_t) r.ransac_sets, tri += (uint64_t) r.tri_points, pre++;
+        if (r.n_log > tc::LOG_CAP / 2) { // the landmark-container history is replayed by the host copy before the block's log wraps
+            s.syncDevice();
+            s.table->syncTable();
+            if (icg_tracker_reset_log(tracker_, i) != ICG_OK) throw std::runtime_error("icg_tracker_reset_log failed");
+            s.table->coreLogRestarted();
+        }
+    }
+    counters[0] += lk, counters[1] += lk ? 1 : 0, counters[2] += det, counters[3] += det ? 1 : 0, counters[4] += rs, counters[5] += rs ? 1 : 0;
+    counters[6] += pre, counters[7] += tri;
+    const double t2 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    timing[4] += t2 - t1;
+    if (step_log.size() < kStepLogCap) step_log.push_back({t2, t2 - t1, t1 - t0});
+}
+
 void TrackingBatch::Stream::currentFeatures(vector<std::pair<ulong, Point2f>> &out) const {
+    syncDevice();
     out.clear();
     if (table) {
         table->forEachCurrentFeature([&](ulong id, const Point2f &kp) { out.emplace_back(id, kp); });
@@ -62,6 +146,7 @@ void TrackingBatch::Stream::currentFeatures(vector<std::pair<ulong, Point2f>> &o
 
 Map::Ptr TrackingBatch::Stream::objectMap() {
     if (!table) return map;
+    syncDevice();
     if (!view_) view_ = table->view();
     return view_->map;
 }
@@ -69,9 +154,14 @@ Map::Ptr TrackingBatch::Stream::objectMap() {
 void TrackingBatch::Stream::commitMap() {
     if (table && view_) table->absorb(*view_);
     view_.reset();
+    if (tracker && table->coreMode() && table->takeCoreChanged()) { // the write-back goes into the device's block
+        if (icg_tracker_upload(tracker, tracker_index, table->core()) != ICG_OK) throw std::runtime_error("icg_tracker_upload failed");
+        table->coreLogRestarted(); // (exportCore emptied the history: map_lm_ is current)
+    }
 }
 
 std::string TrackingBatch::Stream::dump(int kind) const {
+    syncDevice();
     if (table) return kind == 0 ? table->dump() : kind == 1 ? table->dumpMap() : table->dumpMaterialized();
     return kind == 0 ? TableTracker::dumpObjects(*tracking, *map) : std::string();
 }
@@ -202,6 +292,7 @@ static inline double now_s() {
 }
 
 void TrackingBatch::step(const FrameInput *frames, vector<TrackState> &states) {
+    if (engine_ == ENGINE_DEVICE) return stepDevice(frames, states);
     const int n = (int) streams_.size();
     hostprof::Scope hp_total(hostprof::STEP_TOTAL);
     double t0 = now_s(), t1;

@@ -28,7 +28,9 @@ public:
     // Two engines run the same per-frame algorithm behind the same stages: the track table (track_table.h; default, the throughput
     // path) and the reference-shaped object graph (icg::Tracking + Map + WindowKeeper; ICG_TRACK_ENGINE=object).  Per-stream results are
     // identical (tests/test_host_engines_cpu.py).
-    enum Engine { ENGINE_TABLE = 0, ENGINE_OBJECT = 1, ENGINE_CORE = 2 /* the table interface on track_core.h */ };
+    // ENGINE_DEVICE (round 4, ICG_TRACK_ENGINE=device): the device-resident tracker (icg_tracker_*, csrc/tracker.hip) — the streams' state lives in
+    // HBM, a step is one chain of launches and one wait, the host reads a stream's block only when an accessor below asks for it.
+    enum Engine { ENGINE_TABLE = 0, ENGINE_OBJECT = 1, ENGINE_CORE = 2 /* the table interface on track_core.h */, ENGINE_DEVICE = 3 };
     struct Stream {
         Camera::Ptr camera;
         std::shared_ptr<IdSpace> ids;
@@ -41,10 +43,17 @@ public:
         bool frameDone() const { return table ? table->frameDone() : tracking->frameDone(); }
         TrackState result() const { return table ? table->result() : tracking->result(); }
         bool isNewKeyFrame() const { return table ? table->isNewKeyFrame() : tracking->isNewKeyFrame(); }
-        const vector<Point2f> &trackedRefPoints() const { return table ? table->trackedRefPoints() : tracking->trackedRefPoints(); }
-        const vector<Point2f> &referencePoints() const { return table ? table->referencePoints() : tracking->referencePoints(); }
-        size_t windowKeyFrames() const { return table ? table->windowKeyFrames() : map->keyframes().size(); }
-        size_t landmarks() const { return table ? table->landmarks() : map->landmarks().size(); }
+        const vector<Point2f> &trackedRefPoints() const { return syncDevice(), table ? table->trackedRefPoints() : tracking->trackedRefPoints(); }
+        const vector<Point2f> &referencePoints() const { return syncDevice(), table ? table->referencePoints() : tracking->referencePoints(); }
+        size_t windowKeyFrames() const { return tracker ? (size_t) last.window_keyframes : table ? table->windowKeyFrames() : map->keyframes().size(); }
+        size_t landmarks() const { return tracker ? (size_t) last.landmarks : table ? table->landmarks() : map->landmarks().size(); }
+        // ENGINE_DEVICE: the group's tracker, this stream's index in it, the results of its last step, and whether the table's copy of the
+        // block (TableTracker core mode, device-resident) is older than the device's
+        icg_tracker *tracker{nullptr};
+        int tracker_index{0};
+        icg_tracker_result last{};
+        mutable bool device_stale{false};
+        void syncDevice() const; // downloads the block if the device's is newer (no-op for the host engines)
         // (map-point id, distorted key point) of the features of the stream's current frame, unordered
         void currentFeatures(vector<std::pair<ulong, Point2f>> &out) const;
         std::string dump(int kind) const; // 0: engine state (canonical text), 1: table map part, 2: the same from materialize()
@@ -63,6 +72,7 @@ public:
 
     TrackingBatch(int device, int n_streams, const vector<double> &intrinsic, const vector<double> &distortion,
                   const vector<int> &size, const TrackingConfig &cfg, int window_size, int host_threads = 1, int engine = -1);
+    ~TrackingBatch();
 
     // one frame per stream (frames[i].valid == false idles a stream); returns per-stream states
     void step(const FrameInput *frames, vector<TrackState> &states);
@@ -90,6 +100,11 @@ public:
     static constexpr size_t kStepLogCap = 1 << 14;
 
 private:
+    void stepDevice(const FrameInput *frames, vector<TrackState> &states);
+    icg_tracker *tracker_{nullptr};
+    vector<const uint8_t *> dev_images_;
+    vector<double> dev_stamps_, dev_poses_;
+    vector<icg_tracker_result> dev_results_;
     void gather(int cur, StageBatch &global, vector<std::array<int, 8>> &bases);
     void scatter(int cur, const StageBatch &global, const vector<std::array<int, 8>> &bases);
     template <typename F> void forEachStream(F &&f);

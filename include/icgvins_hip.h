@@ -308,6 +308,57 @@ int icg_ins_mechanize_batch(icg_ctx *ctx, int n_streams, const int32_t *offsets,
 int icg_ins_camera_pose_batch(icg_ctx *ctx, int n, const double *brackets16, const int32_t *interp, const double *pose_b_c12,
                               const double *times, double *pose12_out);
 
+/* ---- device-resident tracker of a stream group (round 4) ---------------------------------------------------------------------
+ * Replaces, for n independent camera streams at once, everything Tracking::track (tracking/tracking.cc:144-245) does BETWEEN its image
+ * primitives: the state machine (first frame / initializing / tracking / lost), trackMappoint (:351-455), trackReferenceFrame (:457-574),
+ * reduceVector (:831-845), the parallax sums and keyframe decision (:263-307, 873-922), triangulation bookkeeping (:690-798), the detection
+ * lists (:576-688), and — as the throughput harness does for GVINS — the sliding-window side effects on the map (map.cc:27-127).  The
+ * per-stream state (frames with their feature rows in the reference container's iteration order, map points, candidate lists, window) is
+ * one flat block per stream in HBM; a step is ONE chain of launches on the context's stream — stage kernel, primitive, stage kernel, ... —
+ * with the work lists of every primitive left in device memory by the stage kernel before it, and ONE wait at the end.  The host never
+ * builds a list, never sizes a grid from results and never reads the tracker's state unless it asks for a block.
+ *
+ * The stage bodies are the functions of ic-gvins_amd/host/track_core.h, compiled for gfx950; the same source compiled for the host is the
+ * CPU twin the parity tests pin against the track table and the reference's own tracker.  icg_tracker_config mirrors tc::Cfg of that file
+ * (static_assert in csrc/tracker.hip); a block is sizeof(tc::Stream) bytes = icg_tracker_block_bytes(). */
+typedef struct icg_tracker icg_tracker;
+typedef struct icg_tracker_config {
+    double fx, fy, cx, cy, skew, k1, k2, p1, p2, k3; /* camera (icg_camera) */
+    int32_t width, height;
+    int32_t track_max_features, check_histogram, window_size, pad0;
+    double track_min_parallax, reprojection_error_std, track_max_interval; /* track_max_interval already x 0.95 (tracking.cc:57) */
+    int32_t block_cols, block_rows, block_cnts, block_w, block_h, max_block_features, min_pixel_distance, max_per_job; /* tracking.cc:66-85 */
+    uint64_t stream_id_base;
+} icg_tracker_config;
+typedef struct icg_tracker_result { /* per stream, after a step */
+    int32_t active;          /* the stream had a frame in this step */
+    int32_t state;           /* TrackState of the frame (tracking.h:38-44) */
+    int32_t is_new_keyframe; /* Tracking::isNewKeyFrame() */
+    int32_t overflow;        /* != 0: a capacity of the block was exceeded (the step fails) */
+    int32_t n_features, n_candidates, window_keyframes, landmarks;
+    uint64_t frames, keyframes, tracked_sum, digest; /* running statistics / digest of everything index-like the stream produced */
+    uint64_t frame_id, keyframe_id, mappoint_id, last_input_fid; /* id factories (frame.cc:37-53, mappoint.cc:45-49) */
+    int32_t need_detect_a;   /* the stream's next frame starts with a detection (first frame / initialization without candidates) */
+    int32_t n_log;           /* landmark-container operations logged in the block since the last drain */
+    int32_t lk_points, detect_jobs, ransac_sets, tri_points; /* work this frame handed to the primitives */
+} icg_tracker_result;
+
+/* buckets_after[k], k = 0..n_buckets_after-1: bucket count of a fresh std::unordered_map<ulong, T> after k insertions on the host's standard
+ * library (the reference container whose iteration order the feature rows keep); n_buckets_after must cover the row capacity + 2. */
+int icg_tracker_create(icg_ctx *ctx, int n_streams, const icg_tracker_config *cfg, const uint32_t *buckets_after, int n_buckets_after,
+                       icg_tracker **out);
+void icg_tracker_destroy(icg_tracker *t);
+size_t icg_tracker_block_bytes(void);
+/* One frame per stream: images[k] (stride / channels as icg_frames_preprocess; NULL = stream k idles this step), its stamp and INS pose
+ * prior (R row-major 9, t 3).  Returns after the whole chain has run; results[k] is filled for every stream. */
+int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, int stride, int channels, int images_on_device, const double *stamps,
+                     const double *poses12, icg_tracker_result *results);
+/* the block of one stream, to / from host memory (B2 view, dumps, optimizer write-back); both wait for the context's stream */
+int icg_tracker_download(icg_tracker *t, int stream, void *block);
+int icg_tracker_upload(icg_tracker *t, int stream, const void *block);
+/* the landmark-container history of a stream has been replayed by the host: restart it (n_log = 0) */
+int icg_tracker_reset_log(icg_tracker *t, int stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -616,3 +616,183 @@ int icg_ins_camera_pose_batch(icg_ctx *, int n, const double *brackets16, const 
 }
 
 } // extern "C"
+
+// ---- icg_tracker_* on the CPU (TEST INFRASTRUCTURE, like the rest of this file) -------------------------------------------------------------
+// The device-resident tracker's ABI with host memory as "device memory": the blocks are heap memory, a step runs the SAME stage bodies
+// (ic-gvins_amd/host/track_core.h, here compiled by g++) between the shim's primitives, stream after stream.  With it the host executor of
+// the device engine (TrackingBatch::stepDevice: download / import / view / absorb / upload, log drains, statistics) runs in the CPU suite,
+// and the GPU tests have a checker that speaks the same ABI.
+#include "../ic-gvins_amd/host/track_core.h"
+
+static_assert(sizeof(icg_tracker_config) == sizeof(tc::Cfg), "icg_tracker_config mirrors tc::Cfg");
+
+struct icg_tracker {
+    icg_ctx *ctx;
+    int n;
+    tc::Cfg cfg;
+    icg_detect_grid grid;
+    std::vector<uint32_t> buckets;
+    std::vector<tc::Stream *> streams;
+    struct Arena {
+        int32_t pre_slot = -1, lk_count = 0, rs_count = 0, tri_count = 0, tri_n_tcw = 0, det_slot = -1, det_mask_count = 0, det_count = 0;
+        double pre_hist = 0;
+        std::vector<int32_t> lk_prev_slot, lk_next_slot, tri_T0, tri_T1, det_quota;
+        std::vector<tc::P2f> lk_prev, lk_guess, lk_out, lk_undist, rs_p1, rs_p2, det_mask_pts, det_out;
+        std::vector<uint8_t> lk_status, rs_mask;
+        std::vector<double> tri_Tcw, tri_pc0, tri_pc1, tri_pw;
+    };
+    std::vector<Arena> arena;
+};
+
+static tc::Io shim_io(icg_tracker::Arena &a, int lk_base) {
+    tc::Io io;
+    memset(&io, 0, sizeof io);
+    io.pre_slot = &a.pre_slot, io.pre_hist = &a.pre_hist;
+    io.lk_count = &a.lk_count, io.lk_prev_slot = a.lk_prev_slot.data(), io.lk_next_slot = a.lk_next_slot.data();
+    io.lk_prev = a.lk_prev.data(), io.lk_guess = a.lk_guess.data(), io.lk_out = a.lk_out.data(), io.lk_undist = a.lk_undist.data();
+    io.lk_status = a.lk_status.data(), io.lk_base = lk_base;
+    io.rs_count = &a.rs_count, io.rs_p1 = a.rs_p1.data(), io.rs_p2 = a.rs_p2.data(), io.rs_mask = a.rs_mask.data();
+    io.tri_count = &a.tri_count, io.tri_n_tcw = &a.tri_n_tcw, io.tri_T0 = a.tri_T0.data(), io.tri_T1 = a.tri_T1.data();
+    io.tri_Tcw = a.tri_Tcw.data(), io.tri_pc0 = a.tri_pc0.data(), io.tri_pc1 = a.tri_pc1.data(), io.tri_pw = a.tri_pw.data();
+    io.det_slot = &a.det_slot, io.det_quota = a.det_quota.data(), io.det_mask_count = &a.det_mask_count;
+    io.det_mask_pts = a.det_mask_pts.data(), io.det_count = &a.det_count, io.det_out = a.det_out.data();
+    return io;
+}
+
+extern "C" {
+
+size_t icg_tracker_block_bytes(void) { return sizeof(tc::Stream); }
+
+void icg_tracker_destroy(icg_tracker *t) {
+    if (!t) return;
+    for (tc::Stream *s : t->streams) free(s);
+    delete t;
+}
+
+int icg_tracker_create(icg_ctx *ctx, int n_streams, const icg_tracker_config *cfg, const uint32_t *buckets_after, int n_buckets_after, icg_tracker **out) {
+    if (!ctx || !cfg || !buckets_after || !out || n_streams <= 0 || n_buckets_after < tc::MAX_ROWS + 2) return ICG_ERR_INVALID;
+    if (ctx->cfg.n_slots < tc::MAX_SLOTS * n_streams || cfg->block_cnts > tc::MAX_BLOCKS || cfg->max_per_job + 64 > tc::MAX_ROWS) return ICG_ERR_CAPACITY;
+    icg_tracker *t = new icg_tracker;
+    t->ctx = ctx, t->n = n_streams;
+    memcpy(&t->cfg, cfg, sizeof(tc::Cfg));
+    t->grid.block_cols = cfg->block_cols, t->grid.block_rows = cfg->block_rows, t->grid.block_w = cfg->block_w, t->grid.block_h = cfg->block_h;
+    t->grid.min_dist = cfg->min_pixel_distance, t->grid.max_per_block = cfg->max_block_features;
+    t->buckets.assign(buckets_after, buckets_after + n_buckets_after);
+    t->arena.resize((size_t) n_streams);
+    for (int s = 0; s < n_streams; s++) {
+        tc::Stream *S = static_cast<tc::Stream *>(calloc(1, sizeof(tc::Stream)));
+        if (!S) {
+            icg_tracker_destroy(t);
+            return ICG_ERR_NOMEM;
+        }
+        tc::stream_init(*S, s * tc::MAX_SLOTS);
+        t->streams.push_back(S);
+        auto &a = t->arena[(size_t) s];
+        const size_t R = tc::MAX_ROWS;
+        a.lk_prev_slot.resize(R), a.lk_next_slot.resize(R), a.lk_prev.resize(R), a.lk_guess.resize(R), a.lk_out.resize(R), a.lk_undist.resize(R);
+        a.lk_status.resize(R), a.rs_mask.resize(R), a.rs_p1.resize(R), a.rs_p2.resize(R), a.tri_T0.resize(R), a.tri_T1.resize(R);
+        a.tri_Tcw.resize(12 * tc::MAX_TCW), a.tri_pc0.resize(3 * R), a.tri_pc1.resize(3 * R), a.tri_pw.resize(3 * R);
+        a.det_quota.resize(tc::MAX_BLOCKS), a.det_mask_pts.resize(R), a.det_out.resize(R);
+    }
+    *out = t;
+    return ICG_OK;
+}
+
+int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, int stride, int channels, int images_on_device, const double *stamps,
+                     const double *poses12, icg_tracker_result *results) {
+    if (!t || !images || !stamps || !poses12 || !results) return ICG_ERR_INVALID;
+    icg_ctx *ctx     = t->ctx;
+    const tc::Cfg &C = t->cfg;
+    int overflow     = 0;
+    for (int s = 0; s < t->n; s++) {
+        tc::Stream &S = *t->streams[(size_t) s];
+        auto &a       = t->arena[(size_t) s];
+        icg_tracker_result &r = results[s];
+        memset(&r, 0, sizeof r);
+        int work[4] = {0, 0, 0, 0};
+        if (images[s]) {
+            tc::Io io = shim_io(a, s * tc::MAX_ROWS);
+            tc::Pose pose;
+            memcpy(pose.R, poses12 + 12 * (size_t) s, sizeof(double) * 12);
+            tc::stage_begin_frame(S, io, stamps[s], pose, (tc::u64) (uintptr_t) images[s]);
+            int rc = icg_frames_preprocess(ctx, 1, &a.pre_slot, &images[s], stride, channels, images_on_device, C.check_histogram ? &a.pre_hist : nullptr);
+            if (rc) return rc;
+            auto detect = [&]() -> int {
+                a.det_count = 0;
+                if (a.det_slot < 0) return ICG_OK;
+                const int32_t moff[2] = {0, a.det_mask_count};
+                std::vector<float> out((size_t) C.max_per_job * 2);
+                int32_t cnt = 0;
+                int rcd = icg_detect(ctx, 1, &a.det_slot, &t->grid, moff, reinterpret_cast<const float *>(a.det_mask_pts.data()), a.det_quota.data(),
+                                     C.max_per_job, out.data(), &cnt, nullptr);
+                if (rcd) return rcd;
+                a.det_count = cnt;
+                memcpy(a.det_out.data(), out.data(), sizeof(float) * 2 * (size_t) cnt);
+                work[1]++;
+                return ICG_OK;
+            };
+            tc::stage_on_preprocess(S, C, io);
+            if ((rc = detect())) return rc;
+            tc::stage_on_detect_a(S, C, io);
+            work[0] = a.lk_count;
+            if (a.lk_count > 0) {
+                rc = icg_lk_track_fb(ctx, a.lk_count, a.lk_prev_slot.data(), a.lk_next_slot.data(), reinterpret_cast<const float *>(a.lk_prev.data()),
+                                     reinterpret_cast<const float *>(a.lk_guess.data()), reinterpret_cast<float *>(a.lk_out.data()), a.lk_status.data(),
+                                     reinterpret_cast<float *>(a.lk_undist.data()), nullptr, nullptr);
+                if (rc) return rc;
+            }
+            tc::stage_on_lk(S, C, io, t->buckets.data());
+            if (a.rs_count > 0) {
+                work[2]               = 1;
+                const int32_t off[2] = {0, a.rs_count};
+                for (int k = 0; k < a.rs_count; k++) a.rs_mask[(size_t) k] = 1;
+                rc = icg_fm_ransac(ctx, 1, off, reinterpret_cast<const float *>(a.rs_p1.data()), reinterpret_cast<const float *>(a.rs_p2.data()),
+                                   C.reprojection_error_std, 0.99, a.rs_mask.data());
+                if (rc) return rc;
+            }
+            tc::stage_on_ransac(S, C, io);
+            work[3] = a.tri_count;
+            if (a.tri_count > 0) {
+                rc = icg_triangulate(ctx, a.tri_count, a.tri_T0.data(), a.tri_T1.data(), a.tri_n_tcw, a.tri_Tcw.data(), a.tri_pc0.data(), a.tri_pc1.data(),
+                                     a.tri_pw.data());
+                if (rc) return rc;
+            }
+            tc::stage_on_triangulate(S, C, io, t->buckets.data());
+            if ((rc = detect())) return rc;
+            tc::stage_on_detect_b(S, C, io);
+            tc::stage_end_frame(S, C);
+            r.active = 1;
+        }
+        r.state = S.result, r.is_new_keyframe = S.isnewkeyframe, r.overflow = S.overflow;
+        r.n_features = S.cur >= 0 ? S.frame[S.cur].n_rows : 0, r.n_candidates = S.n_new, r.window_keyframes = S.n_map_kf, r.landmarks = S.n_landmarks;
+        r.frames = S.frames, r.keyframes = S.keyframes, r.tracked_sum = S.tracked_sum, r.digest = S.digest;
+        r.frame_id = S.frame_id, r.keyframe_id = S.keyframe_id, r.mappoint_id = S.mappoint_id, r.last_input_fid = S.last_input_fid;
+        r.need_detect_a = (S.isinitializing && (S.ref < 0 || S.n_ref == 0)) ? 1 : 0;
+        r.n_log = S.n_log;
+        r.lk_points = work[0], r.detect_jobs = work[1], r.ransac_sets = work[2], r.tri_points = work[3];
+        overflow |= S.overflow;
+    }
+    if (overflow) {
+        ctx->err = "tracker block capacity exceeded";
+        return ICG_ERR_CAPACITY;
+    }
+    return ICG_OK;
+}
+
+int icg_tracker_download(icg_tracker *t, int stream, void *block) {
+    if (!t || !block || stream < 0 || stream >= t->n) return ICG_ERR_INVALID;
+    memcpy(block, t->streams[(size_t) stream], sizeof(tc::Stream));
+    return ICG_OK;
+}
+int icg_tracker_upload(icg_tracker *t, int stream, const void *block) {
+    if (!t || !block || stream < 0 || stream >= t->n) return ICG_ERR_INVALID;
+    memcpy(t->streams[(size_t) stream], block, sizeof(tc::Stream));
+    return ICG_OK;
+}
+int icg_tracker_reset_log(icg_tracker *t, int stream) {
+    if (!t || stream < 0 || stream >= t->n) return ICG_ERR_INVALID;
+    t->streams[(size_t) stream]->n_log = 0;
+    return ICG_OK;
+}
+
+} // extern "C"

@@ -162,3 +162,41 @@ def test_map_writers_on_the_core_engine_equal_the_object_engine(oracle):
     assert ra == rb
     for s, (x, y) in enumerate(zip(fa, fb)):
         assert x == y, (s, _first_difference(x, y))
+
+
+# ---- the device engine's HOST side, on the CPU backend of the tracker ABI (oracle/abi_shim.cc) ----------------------------------------------
+@pytest.mark.parametrize("name", ["c1_window_rolls", "c1_lost_histgate", "c2"])
+def test_device_engine_host_side_equals_table_engine(name):
+    """ICG_TRACK_ENGINE=device: TrackingBatch::stepDevice drives icg_tracker_* — here the shim's CPU backend, the same stage bodies between the
+    oracle's primitives — and everything the host keeps for it: results -> statistics / digest, block download -> import -> dump on demand,
+    the landmark-history cursor across downloads.  Same text as the table engine after every frame."""
+    w, h, nfeat, n, stream, blank, hist, slow = CASES[name]
+    frames, poses = _scene(w, h, n, stream, blank=blank, blank_value=235 if hist else 90, slow_after=slow)
+    st_t, d_t, stats_t = _drive("table", w, h, nfeat, n, frames, poses, check_hist=hist)
+    st_d, d_d, stats_d = _drive("device", w, h, nfeat, n, frames, poses, check_hist=hist, dump_every=3)
+    assert st_t == st_d
+    by_frame = {k: full for k, full, _, _ in d_t}
+    for k, full_d, _, _ in d_d:
+        if by_frame[k] != full_d:
+            i, a, b = _first_difference(by_frame[k], full_d)
+            raise AssertionError(f"{name}: device engine differs from the table after frame {k}, dump line {i}:\n table : {a}\n device: {b}")
+    assert stats_t == stats_d
+
+
+def test_map_writers_on_the_device_engine_equal_the_object_engine(oracle):
+    """culling and window refinement with the blocks behind the tracker ABI: download -> view -> absorb -> export -> upload, then the tracker
+    continues on the uploaded block"""
+    import cull_checks as cc
+    import refine_checks as rc
+    lib = ensure_oracle_host()
+    a = cc.check_window_culling(lib, oracle, engine="object")
+    b = cc.check_window_culling(lib, oracle, engine="device")
+    assert a[0] == b[0] and a[1] == b[1]
+    for s, (x, y) in enumerate(zip(a[2], b[2])):
+        assert x == y, (s, _first_difference(x, y))
+    ra, oa, fa = rc.check_refinement(lib, engine="object")
+    rb, ob, fb = rc.check_refinement(lib, engine="device")
+    assert np.array_equal(oa, ob), (oa, ob)
+    assert ra == rb
+    for s, (x, y) in enumerate(zip(fa, fb)):
+        assert x == y, (s, _first_difference(x, y))
