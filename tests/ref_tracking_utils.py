@@ -167,19 +167,19 @@ def load(path):
                 und=[g["und"][off[k]:off[k + 1]] for k in range(n)], stats=g["stats"], log=g["log"])
 
 
-def compare_scenario(lib_path, name, ref=None):
+def compare_scenario(lib_path, name, ref=None, engine=None):
     w, h, n, mf, stream, hist = SCENARIOS[name]
     old = CONFIG["check_hist"]
     CONFIG["check_hist"] = hist
     _current_scenario[0] = name
     try:
-        compare_with_host(lib_path, ref if ref is not None else load(golden_path(name)), w, h, n, mf, stream)
+        compare_with_host(lib_path, ref if ref is not None else load(golden_path(name)), w, h, n, mf, stream, engine=engine)
     finally:
         CONFIG["check_hist"] = old
         _current_scenario[0] = None
 
 
-def compare_with_host(lib_path, ref, w, h, n_frames, max_features, stream=0):
+def compare_with_host(lib_path, ref, w, h, n_frames, max_features, stream=0, engine=None):
     """Runs the product's host layer (lib_path: GPU-backed or oracle-backed) on the same frames and asserts frame-by-frame
     equality with the reference run: track state, map-point ids of the frame's features, distorted key-point float bits, the
     un-triangulated candidate lists (current and reference pixels, list order), and the window bookkeeping (keyframe count,
@@ -187,12 +187,14 @@ def compare_with_host(lib_path, ref, w, h, n_frames, max_features, stream=0):
     import harness as H
     cam = H.camera_for(w, h)
     logdir = tempfile.mkdtemp(prefix="icgtrk_")
-    os.environ["ICG_TRACKING_LOG_DIR"] = logdir
+    with_log = engine != "device"  # (the device-resident tracker keeps no tracking.txt: its host never sees the decision's numbers)
+    if with_log:
+        os.environ["ICG_TRACKING_LOG_DIR"] = logdir
     try:
         sb = H.StreamBatch(lib_path, 1, w, h, cam, max_features=max_features, window=CONFIG["window"], min_parallax=CONFIG["min_parallax"],
-                           max_interval=CONFIG["max_interval"], check_hist=CONFIG["check_hist"], reproj_std=CONFIG["reproj_std"])
+                           max_interval=CONFIG["max_interval"], check_hist=CONFIG["check_hist"], reproj_std=CONFIG["reproj_std"], engine=engine)
     finally:
-        del os.environ["ICG_TRACKING_LOG_DIR"]
+        os.environ.pop("ICG_TRACKING_LOG_DIR", None)
     _, frames, poses, stamps = scene_and_frames(sb.lib, w, h, n_frames, stream)
     for k in range(n_frames):
         ch = 3 if frames[k].ndim == 3 else 1
@@ -209,6 +211,8 @@ def compare_with_host(lib_path, ref, w, h, n_frames, max_features, stream=0):
         assert cand.shape == ref["cand"][k].shape, (k, cand.shape, ref["cand"][k].shape)
         assert np.array_equal(cand.view(np.uint32), ref["cand"][k].view(np.uint32)), k
     sb.close()
+    if not with_log:
+        return
     # tracking.txt: same rows, same text in the six deterministic columns
     log = read_tracking_log(os.path.join(logdir, "stream0", "tracking.txt"))
     assert len(log) == len(ref["log"]), (len(log), len(ref["log"]))
