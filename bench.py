@@ -373,7 +373,7 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
     # ---- kernel-only ceiling: the device calls of ONE step of every group, recorded and issued again with no tracker logic, one group
     # after the other (nothing else on the GPU): HIP-event times = exclusive device time per kernel ----------------------------------
     ceiling = None
-    if profile:
+    if profile and os.environ.get("ICG_TRACK_ENGINE") != "device":  # (the device engine has no host-side call list to record: a step is one chain)
         frames_total = k  # frames per stream so far
         sb.lib.icgh_batch_record(C.c_void_p(sb.h_), 1)
         run_prepared(1, prepare_steps(k, 1))
@@ -571,10 +571,14 @@ def main():
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event pass (used under rocprofv3 --pmc)")
     ap.add_argument("--no-parity", action="store_true", help="diagnostic sweeps only: skip the parity witness (the line then carries parity: null "
                                                               "and says so; the driver's command never uses this)")
+    ap.add_argument("--engine", default=os.environ.get("ICG_TRACK_ENGINE", "table"), choices=["table", "object", "core", "device"],
+                    help="tracker engine of the host executor: device = the device-resident tracker (state in HBM, one launch chain + one wait per "
+                         "step); table = the host track table between batched device calls (rounds 1-3)")
     ap.add_argument("--details", default=os.environ.get("ICG_BENCH_DETAILS", ""),
                     help="file for the long per-group / per-step series and notes (default gpurun_out/bench_details.json); the contract line stays compact")
     args = ap.parse_args()
 
+    os.environ["ICG_TRACK_ENGINE"] = args.engine
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1209,7 +1213,8 @@ def main():
                        "usable_host_cores_per_rank": round(cores_rank, 1),
                        "cpu_slice_per_rank": (f"{len(plan['cpu_slice'])} CPUs pinned" if plan["cpu_slice"] else "not pinned (single rank)"),
                        "input_residency": "pinned host frames, uploaded per frame (PCIe-inclusive diagnostic)" if args.host_frames else "raw frames in HBM", "sharding": "independent streams per GPU, no data-path collective",
-                       "engine": "track table (host/track_table.h)" if not os.environ.get("ICG_TRACK_ENGINE", "").startswith("o") else "object graph"},
+                       "engine": {"table": "track table (host/track_table.h)", "object": "object graph", "core": "tracker core on the host (host/track_core.h)",
+                                  "device": "device-resident tracker (csrc/tracker.hip: state in HBM, one launch chain + one wait per step)"}[args.engine]},
             "parity": parity if not args.no_parity else {"ok": None, "skipped": "--no-parity (diagnostic run)"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

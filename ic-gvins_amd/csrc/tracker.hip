@@ -20,10 +20,11 @@
 // (stage 1 -> detection -> stage 2 replaces stage 12 in the rare steps in which a stream starts with a detection: first frame,
 // initialization without candidates — the host knows from the previous step's results.)  The host issues the launches and waits ONCE.
 //
-// Parallelism: streams are independent — a wave per stream, all streams of the group in one launch.  Inside a stream the bodies are the
-// reference's sequential bookkeeping (linked-list walks in container order, hash-table insertions, order-dependent float sums), run by
-// lane 0; they are latency-bound pointer work that occupies one wave slot per stream while the chip-filling kernels of the OTHER groups
-// run beside them.
+// Parallelism: streams are independent — a wave per stream, all streams of the group in one launch.  Inside a stream the data-parallel loops
+// (prediction of every map point, feature rows, velocities, parallax terms, the compactions of reduceVector, detection lists, the digest)
+// are split over the 64 lanes with ballot / rank so that list order is kept; what is sequential by nature — the walk of the reference
+// container's node list, the hash-table insertions that give a new frame its iteration order, the order-dependent float sums — runs
+// through LDS (tc::Scratch) and is executed redundantly by all lanes in lockstep (track_core.h "execution model").
 #include <algorithm>
 #include <mutex>
 
@@ -129,9 +130,7 @@ __device__ void assemble_corners(const TrkArena &A, const tc::Cfg &C, int s) {
     A.det_count[s] = cnt;
 }
 
-__global__ __launch_bounds__(64) void k_trk_begin(int n, tc::Stream *streams, TrkArena A, const TrkInput *in) {
-    const int s = blockIdx.x;
-    if (s >= n || threadIdx.x != 0) return;
+__device__ void begin_frame(int s, tc::Stream *streams, const TrkArena &A, const TrkInput *in) {
     const TrkInput I = in[s];
     A.active[s]      = I.valid;
     A.work[4 * s] = A.work[4 * s + 1] = A.work[4 * s + 2] = A.work[4 * s + 3] = 0;
@@ -151,12 +150,20 @@ __global__ __launch_bounds__(64) void k_trk_begin(int n, tc::Stream *streams, Tr
     tc::stage_begin_frame(streams[s], io, I.stamp, pose, I.image);
 }
 
-// stage: 1, 2, 12 (1 then 2 in one launch: no stream queued a detection), 3, 4, 5, 6 (+ end of frame + results)
+// stage: 0 (new frame), 1, 2, 12 (1 then 2 in one launch: no stream queued a detection), 120 (0 then 12: additionally no histogram gate, so
+// nothing of the preprocessing is needed before the prediction), 3, 4, 5, 6 (+ end of frame + results)
 __global__ __launch_bounds__(64) void k_trk_stage(int stage, int n, tc::Stream *streams, TrkArena A, tc::Cfg C, const uint32_t *buckets_after,
-                                                  icg_tracker_result *results) {
+                                                  icg_tracker_result *results, const TrkInput *in) {
+    __shared__ tc::Scratch X;
     const int s = blockIdx.x;
-    if (s >= n || threadIdx.x != 0) return;
+    if (s >= n) return; // all 64 lanes run the stage body (track_core.h "execution model"): redundantly where it is sequential
     tc::Stream &S = streams[s];
+    if (stage == 0 || stage == 120) {
+        begin_frame(s, streams, A, in);
+        tc::sync();
+        if (stage == 0) return;
+        stage = 12;
+    }
     const bool active = A.active[s] != 0;
     tc::Io io = io_of(A, C, s);
     if (active) {
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(64) void k_trk_stage(int stage, int n, tc::Stream *
             break;
         case 2:
             assemble_corners(A, C, s);
-            tc::stage_on_detect_a(S, C, io);
+            tc::stage_on_detect_a(S, C, io, X);
             A.work[4 * s] = A.lk_count[s];
             break;
         case 12:
@@ -179,11 +186,11 @@ __global__ __launch_bounds__(64) void k_trk_stage(int stage, int n, tc::Stream *
                 S.det_job     = -1;
             }
             A.det_count[s] = 0;
-            tc::stage_on_detect_a(S, C, io);
+            tc::stage_on_detect_a(S, C, io, X);
             A.work[4 * s] = A.lk_count[s];
             break;
         case 3:
-            tc::stage_on_lk(S, C, io, buckets_after);
+            tc::stage_on_lk(S, C, io, buckets_after, X);
             A.work[4 * s + 2] = A.rs_count[s] > 0 ? 1 : 0;
             break;
         case 4:
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(64) void k_trk_stage(int stage, int n, tc::Stream *
             A.work[4 * s + 3] = A.tri_count[s];
             break;
         case 5:
-            tc::stage_on_triangulate(S, C, io, buckets_after);
+            tc::stage_on_triangulate(S, C, io, buckets_after, X);
             build_rois(A, C, s);
             A.work[4 * s + 1] += A.det_slot[s] >= 0 ? 1 : 0;
             break;
@@ -205,6 +212,7 @@ __global__ __launch_bounds__(64) void k_trk_stage(int stage, int n, tc::Stream *
     } else if (stage == 1 || stage == 5) {
         build_rois(A, C, s); // (an idle stream's table entries must read "inactive")
     }
+    tc::sync();
     if (stage == 6) {
         icg_tracker_result r;
         r.active          = active ? 1 : 0;
@@ -246,6 +254,7 @@ struct icg_tracker {
     TrkInput *h_in             = nullptr; // pinned, GPU-addressable
     icg_tracker_result *h_res  = nullptr; // pinned, written by k_trk_stage 6
     bool need_detect_a         = true;    // some stream starts its next frame with a detection
+    hipEvent_t ev_done         = nullptr; // blocking-sync event of the step's single wait (nullptr: the context's wait mode)
 };
 
 extern "C" size_t icg_tracker_block_bytes(void) { return sizeof(tc::Stream); }
@@ -262,6 +271,7 @@ extern "C" void icg_tracker_destroy(icg_tracker *t) {
     if (t->d_arena) (void) hipFree(t->d_arena);
     if (t->h_in) (void) hipHostFree(t->h_in);
     if (t->h_res) (void) hipHostFree(t->h_res);
+    if (t->ev_done) (void) hipEventDestroy(t->ev_done);
     delete t;
 }
 
@@ -333,6 +343,11 @@ extern "C" int icg_tracker_create(icg_ctx *ctx, int n_streams, const icg_tracker
     if (icg_hip_check(ctx, hipHostMalloc((void **) &t->h_in, sizeof(TrkInput) * n, hipHostMallocDefault), "hipHostMalloc inputs")) return fail(ICG_ERR_NOMEM);
     if (icg_hip_check(ctx, hipHostMalloc((void **) &t->h_res, sizeof(icg_tracker_result) * n, hipHostMallocDefault), "hipHostMalloc results"))
         return fail(ICG_ERR_NOMEM);
+    {
+        const char *wm = getenv("ICG_TRACKER_WAIT");
+        if (!wm || wm[0] == 'b')
+            if (icg_hip_check(ctx, hipEventCreateWithFlags(&t->ev_done, hipEventBlockingSync | hipEventDisableTiming), "hipEventCreate")) return fail(ICG_ERR_HIP);
+    }
     memset(t->h_in, 0, sizeof(TrkInput) * n);
     memset(t->h_res, 0, sizeof(icg_tracker_result) * n);
     hipLaunchKernelGGL(k_trk_init, dim3((n_streams + 63) / 64), dim3(64), 0, ctx->stream, n_streams, t->d_streams);
@@ -345,7 +360,8 @@ extern "C" int icg_tracker_create(icg_ctx *ctx, int n_streams, const icg_tracker
 static int launch_stage(icg_tracker *t, int stage, const char *name) {
     icg_ctx *ctx = t->ctx;
     icg_prof_scope ps(ctx, name);
-    hipLaunchKernelGGL(k_trk_stage, dim3(t->n), dim3(64), 0, ctx->stream, stage, t->n, t->d_streams, t->A, t->cfg, (const uint32_t *) t->d_buckets, t->h_res);
+    hipLaunchKernelGGL(k_trk_stage, dim3(t->n), dim3(64), 0, ctx->stream, stage, t->n, t->d_streams, t->A, t->cfg, (const uint32_t *) t->d_buckets, t->h_res,
+                       (const TrkInput *) t->h_in);
     ICG_HIP(ctx, hipGetLastError());
     return ICG_OK;
 }
@@ -365,11 +381,10 @@ extern "C" int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, in
     }
     int rc;
     const TrkArena &A = t->A;
-    {
-        icg_prof_scope ps(ctx, "trk_begin");
-        hipLaunchKernelGGL(k_trk_begin, dim3(n), dim3(64), 0, ctx->stream, n, t->d_streams, t->A, (const TrkInput *) t->h_in);
-        ICG_HIP(ctx, hipGetLastError());
-    }
+    // without a detection at the start of the frame and without the histogram gate, the prediction needs nothing of the preprocessing:
+    // new frame + state machine + prediction in ONE launch, the preprocessing behind it
+    const bool fused_begin = !t->need_detect_a && !t->cfg.check_histogram;
+    if ((rc = launch_stage(t, fused_begin ? 120 : 0, fused_begin ? "trk_stage_predict" : "trk_begin"))) return rc;
     if ((rc = icg_preprocess_launch_ind(ctx, n, A.pre_slot, images, stride, channels, images_on_device, t->cfg.check_histogram ? A.pre_hist : nullptr))) return rc;
     auto detect = [&]() {
         return icg_detect_launch_ind(ctx, n, &t->grid, A.rois, A.det_slot, A.det_mask_pts, A.det_mask_begin, A.det_mask_count, t->d_vh, A.corners, A.corner_cnt);
@@ -378,7 +393,7 @@ extern "C" int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, in
         if ((rc = launch_stage(t, 1, "trk_stage_pre"))) return rc;
         if ((rc = detect())) return rc;
         if ((rc = launch_stage(t, 2, "trk_stage_predict"))) return rc;
-    } else {
+    } else if (!fused_begin) {
         if ((rc = launch_stage(t, 12, "trk_stage_predict"))) return rc;
     }
     if ((rc = icg_lk_launch_segments(ctx, n, tc::MAX_ROWS, A.lk_count, A.lk_prev_slot, A.lk_next_slot, A.lk_prev, A.lk_guess, A.lk_out, A.lk_status, A.lk_undist)))
@@ -391,7 +406,14 @@ extern "C" int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, in
     if ((rc = launch_stage(t, 5, "trk_stage_tri"))) return rc;
     if ((rc = detect())) return rc;
     if ((rc = launch_stage(t, 6, "trk_stage_end"))) return rc;
-    if ((rc = icg_stream_wait(ctx))) return rc;
+    // ONE wait per step.  Default: block on an interrupt-driven event (the group's thread sleeps for the ~10 ms the chain takes instead of
+    // polling the stream every 100 us); ICG_TRACKER_WAIT=poll|spin selects the context's wait mode instead
+    if (t->ev_done) {
+        ICG_HIP(ctx, hipEventRecord(t->ev_done, ctx->stream));
+        ICG_HIP(ctx, hipEventSynchronize(t->ev_done));
+    } else if ((rc = icg_stream_wait(ctx))) {
+        return rc;
+    }
     icg_prof_collect(ctx);
     bool need = false;
     int overflow = 0;

@@ -31,6 +31,36 @@ namespace tc {
 
 typedef unsigned long long u64;
 
+// ---- execution model --------------------------------------------------------------------------------------------------------------------
+// On the device a stage body is executed by ALL 64 lanes of the stream's wave.  Sequential bookkeeping is simply executed redundantly: the
+// lanes run in lockstep, read the same addresses, compute the same values and store the same values — no guard is needed and none is
+// written.  Data-parallel loops split their iterations over the lanes with the primitives below (chunks of NL items in order, ballot +
+// rank for order-preserving appends), followed by sync() before any lane reads what another lane wrote.  The host build is the same source
+// with NL == 1 (lane 0, ballot = the predicate, rank 0): every parallel loop degenerates to the plain sequential loop.
+#if defined(__HIP_DEVICE_COMPILE__)
+constexpr int NL = 64;
+TC_FN int lane() { return (int) (threadIdx.x & 63); }
+TC_FN u64 ballot(bool p) { return __ballot(p); }
+TC_FN int popc(u64 m) { return __popcll(m); }
+TC_FN u64 lanes_below() { return (1ull << lane()) - 1ull; }
+TC_FN void sync() { // stores of every lane visible to every lane of the wave (same CU: ordering only, no cache maintenance)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+TC_FN u64 wave_sum(u64 v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+#else
+constexpr int NL = 1;
+TC_FN int lane() { return 0; }
+TC_FN u64 ballot(bool p) { return p ? 1ull : 0ull; }
+TC_FN int popc(u64 m) { return (int) __builtin_popcountll(m); }
+TC_FN u64 lanes_below() { return 0ull; }
+TC_FN void sync() {}
+TC_FN u64 wave_sum(u64 v) { return v; }
+#endif
+
 // ---- capacities ------------------------------------------------------------------------------------------------------------------
 constexpr int MAX_ROWS    = 640;   // features of one frame (C4: 500 + the detector's rounding slack), candidates, points of one LK call
 constexpr int MAX_BUCKETS = 1109;  // libstdc++ bucket count after MAX_ROWS insertions (13, 29, 59, 127, 257, 541, 1109)
@@ -41,6 +71,15 @@ constexpr int MAX_BLOCKS  = 64;    // detection grid blocks (C4: 50)
 constexpr int MAX_TCW     = 12;    // distinct camera matrices of one triangulation call (current + reference frames of the candidates)
 constexpr int LOG_CAP     = 4096;  // landmark insert / erase log between two host drains
 constexpr int MAX_SLOTS   = 4;     // frame slots a stream owns on the device (pre / cur / ref / incoming)
+
+// per-wave scratch (LDS on the device, a heap block on the host): the linked lists and hash buckets of the frame a stage is working on,
+// so that the sequential walks / insertions chase pointers through LDS instead of HBM
+struct Scratch {
+    int32_t next[MAX_ROWS];
+    int32_t bucket[MAX_BUCKETS];
+    int32_t tmp_bucket[MAX_BUCKETS];
+    u64 key[MAX_ROWS];
+};
 
 enum { TRACK_FIRST_FRAME = 0, TRACK_INITIALIZING = 1, TRACK_TRACKING = 2, TRACK_PASSED = 3, TRACK_LOST = 4 }; // tracking.h:38-44
 enum { KEYFRAME_NONE = 0, KEYFRAME_REMOVE_SECOND_NEW = 1, KEYFRAME_NORMAL = 2, KEYFRAME_REMOVE_OLDEST = 3 }; // frame.h:36-41
@@ -204,6 +243,9 @@ struct Stream {
     uint8_t tri_status[MAX_ROWS], status[MAX_ROWS];
     int32_t order_idx[MAX_ROWS];
     int32_t scratch_bucket[MAX_BUCKETS];
+    double tri_tmp[MAX_ROWS][4]; // normalized points of the candidates a triangulation takes (reference view x, y; current view x, y)
+    double par_term[MAX_ROWS]; // terms of a parallax average in the order they are summed (computed in parallel, summed sequentially)
+    uint8_t par_ok[MAX_ROWS];
     // statistics / digest (TrackingBatch::Stream)
     u64 frames, keyframes, tracked_sum, digest;
     int32_t last_state, pad2_;
@@ -501,6 +543,33 @@ TC_FN int add_row(Stream &S, int h, u64 id, uint32_t mp, const P2f &kp, const P2
     order_insert_unique(f, buckets_after, S.scratch_bucket);
     return i;
 }
+// the row data only (the caller enters the new rows into the container order afterwards: order_extend)
+TC_FN int append_row(Stream &S, int h, u64 id, uint32_t mp, const P2f &kp, const P2f &kpd, double vx, double vy, int type, double pcx, double pcy,
+                     int32_t lk_idx) {
+    Frame &f = S.frame[h];
+    if (f.n_rows >= MAX_ROWS) {
+        S.overflow |= OVF_ROWS;
+        return MAX_ROWS - 1;
+    }
+    Row r;
+    r.id      = id;
+    r.mp      = mp;
+    r.mpgen   = S.hot[mp].gen;
+    r.kp      = kp;
+    r.kpd     = kpd;
+    r.vel[0]  = vx;
+    r.vel[1]  = vy;
+    r.pcx     = pcx;
+    r.pcy     = pcy;
+    r.lk_idx  = lk_idx;
+    r.type    = (int8_t) type;
+    r.outlier = 0;
+    r.pad_[0] = r.pad_[1] = 0;
+    const int i = f.n_rows;
+    f.row[i]    = r;
+    f.n_rows    = i + 1;
+    return i;
+}
 TC_FN void log_landmark(Stream &S, u64 id, uint32_t mp, int op) {
     if (S.n_log >= LOG_CAP) {
         S.overflow |= OVF_LOG;
@@ -548,17 +617,31 @@ TC_FN void map_insert_keyframe(Stream &S, const Cfg &C, int h) { // map.cc:27-61
 TC_FN void map_remove_keyframe(Stream &S, int h, bool isremovemappoint) { // map.cc:89-127
     Frame &f = S.frame[h];
     if (isremovemappoint) {
-        for (int q = 0; q < f.n_rows; q++) {
-            const Row &r     = f.row[q];
-            const uint32_t i = r.mp;
-            if (!mp_valid(S, i, r.mpgen)) continue;
-            if (S.cold[i].ref_frame == h && S.cold[i].ref_gen == f.gen && S.hot[i].in_map) {
-                S.hot[i].in_map  = 0;
-                S.hot[i].outlier = 1;
-                log_landmark(S, S.hot[i].id, i, 0);
-                S.n_landmarks--;
-                mp_release(S, i);
+        // the landmarks this keyframe is the reference frame of leave the map: found in parallel (a chunk of rows per step, appended in row
+        // order), released one by one in that order
+        int n_rm = 0;
+        for (int base = 0; base < f.n_rows; base += NL) {
+            const int q = base + lane();
+            bool rm     = false;
+            uint32_t i  = 0;
+            if (q < f.n_rows) {
+                const Row &r = f.row[q];
+                i            = r.mp;
+                rm           = mp_valid(S, i, r.mpgen) && S.cold[i].ref_frame == h && S.cold[i].ref_gen == f.gen && S.hot[i].in_map;
             }
+            const u64 m = ballot(rm);
+            if (rm) S.order_idx[n_rm + popc(m & lanes_below())] = (int32_t) i;
+            n_rm += popc(m);
+        }
+        sync();
+        for (int q = 0; q < n_rm; q++) {
+            const uint32_t i = (uint32_t) S.order_idx[q];
+            if (!S.hot[i].live || !S.hot[i].in_map) continue; // (a map point held by two rows of the frame cannot exist; kept as a guard)
+            S.hot[i].in_map  = 0;
+            S.hot[i].outlier = 1;
+            log_landmark(S, S.hot[i].id, i, 0);
+            S.n_landmarks--;
+            mp_release(S, i);
         }
         for (int k = 0; k < f.n_unupd; k++) { // Frame::clearFeatures (frame.h:46-51)
             const uint32_t i = f.unupd[k];
@@ -604,23 +687,28 @@ TC_FN void release_unused_slots(Stream &S) {
 }
 
 // ---- helpers (tracking.cc:813-871) ------------------------------------------------------------------------------------------------------
-template <typename T> TC_FN int reduce_vector(T *vec, int n, const uint8_t *status) { // :831-839
+// reduceVector (:831-839): stable in-place compaction; chunks of NL items in order — a chunk's writes land at or below its own first index,
+// later chunks read above it, and inside a chunk every store waits for the loads (its data comes from one)
+template <typename T> TC_FN int reduce_vector(T *vec, int n, const uint8_t *status) {
     int index = 0;
-    for (int k = 0; k < n; k++)
-        if (status[k]) {
-            if (index != k) vec[index] = vec[k];
-            index++;
-        }
+    for (int base = 0; base < n; base += NL) {
+        const int k     = base + lane();
+        const bool keep = k < n && status[k];
+        T v             = vec[keep ? k : 0];
+        const u64 m     = ballot(keep);
+        if (keep) vec[index + popc(m & lanes_below())] = v;
+        index += popc(m);
+    }
+    sync();
     return index;
 }
-TC_FN int reduce_vector2(double (*vec)[2], int n, const uint8_t *status) {
-    int index = 0;
-    for (int k = 0; k < n; k++)
-        if (status[k]) {
-            if (index != k) vec[index][0] = vec[k][0], vec[index][1] = vec[k][1];
-            index++;
-        }
-    return index;
+struct D2 {
+    double a, b;
+};
+TC_FN int reduce_vector2(double (*vec)[2], int n, const uint8_t *status) { return reduce_vector(reinterpret_cast<D2 *>(vec), n, status); }
+template <typename T> TC_FN void copy_n(T *dst, const T *src, int n) {
+    for (int k = lane(); k < n; k += NL) dst[k] = src[k];
+    sync();
 }
 TC_FN bool is_good_to_track(const Cfg &C, const P2f &pp, const Pose &pose, const double *pw, double scale, double depth_scale) { // :813-829
     double pc[3];
@@ -639,50 +727,142 @@ TC_FN double keypoint_parallax(const Cfg &C, const P2f &pp0, const P2f &pp1, con
     const double dx = a - x1, dy = b - y1;
     return tc_sqrt(dx * dx + dy * dy) * focalLength(C.cam);
 }
-// order_idx := the rows of f in container order
-TC_FN int list_container_order(Stream &S, const Frame &f) {
+// order_idx := the rows of f in container order.  The list is copied into the wave's scratch first (parallel), so the walk — a chain of
+// dependent reads by nature — runs through LDS
+TC_FN int list_container_order(Stream &S, const Frame &f, Scratch &X) {
+    copy_n(X.next, f.next, f.n_rows);
     int n = 0;
-    for (int q = f.head; q >= 0; q = f.next[q]) S.order_idx[n++] = q;
+    for (int q = f.head; q >= 0; q = X.next[q]) S.order_idx[n++] = q;
+    sync();
     return n;
 }
-TC_FN int parallax_from_reference_mappoints(Stream &S, const Cfg &C, double &parallax) { // :873-905
+// Rows [n_old, f.n_rows) of frame f have just been written (f.n_rows already counts them; the container order covers the first n_old): they
+// enter the container order one by one, in row order (bits/hashtable.h _M_insert_unique_node / _M_insert_bucket_begin / _M_rehash_aux, as
+// order_insert_unique / order_rehash above) — keys, node list and buckets in the wave's scratch, written back when done
+TC_FN void order_extend(Frame &f, int n_old, const uint32_t *buckets_after, Scratch &X) {
+    const int n = f.n_rows;
+    if (n <= n_old) return;
+    int head = n_old ? f.head : -1, nb = n_old ? f.n_buckets : 1;
+    u64 M    = n_old ? f.magic : 0;
+    for (int k = lane(); k < n; k += NL) X.key[k] = f.row[k].id;
+    for (int k = lane(); k < n_old; k += NL) X.next[k] = f.next[k];
+    for (int b = lane(); b < nb; b += NL) X.bucket[b] = n_old ? f.bucket[b] : H_EMPTY;
+    sync();
+    for (int i = n_old; i < n; i++) {
+        const int want = (int) buckets_after[i + 1];
+        if (want != nb) { // _M_rehash_aux over the i nodes inserted so far
+            for (int b = lane(); b < want; b += NL) X.tmp_bucket[b] = H_EMPTY;
+            sync();
+            const u64 M2 = modMagic((u64) want);
+            int p = head;
+            head  = -1;
+            int bbegin_bkt = 0;
+            while (p >= 0) {
+                const int nx = X.next[p];
+                const int b  = bucketOf(X.key[p], want, M2);
+                if (X.tmp_bucket[b] == H_EMPTY) {
+                    X.next[p]       = head;
+                    head            = p;
+                    X.tmp_bucket[b] = H_BEFORE_BEGIN;
+                    if (X.next[p] >= 0) X.tmp_bucket[bbegin_bkt] = p;
+                    bbegin_bkt = b;
+                } else {
+                    const int prev = X.tmp_bucket[b];
+                    if (prev == H_BEFORE_BEGIN) {
+                        X.next[p] = head;
+                        head      = p;
+                    } else {
+                        X.next[p]    = X.next[prev];
+                        X.next[prev] = p;
+                    }
+                }
+                p = nx;
+            }
+            sync();
+            for (int b = lane(); b < want; b += NL) X.bucket[b] = X.tmp_bucket[b];
+            sync();
+            nb = want;
+            M  = M2;
+        }
+        const int b = bucketOf(X.key[i], nb, M);
+        if (X.bucket[b] != H_EMPTY) {
+            const int prev = X.bucket[b];
+            if (prev == H_BEFORE_BEGIN) {
+                X.next[i] = head;
+                head      = i;
+            } else {
+                X.next[i]    = X.next[prev];
+                X.next[prev] = i;
+            }
+        } else {
+            X.next[i] = head;
+            head      = i;
+            if (X.next[i] >= 0) X.bucket[bucketOf(X.key[X.next[i]], nb, M)] = i;
+            X.bucket[b] = H_BEFORE_BEGIN;
+        }
+    }
+    sync();
+    for (int k = lane(); k < n; k += NL) f.next[k] = X.next[k];
+    for (int b = lane(); b < nb; b += NL) f.bucket[b] = X.bucket[b];
+    f.head      = head;
+    f.n_buckets = nb;
+    f.magic     = M;
+    sync();
+}
+// the sum of a parallax average: terms in the order the reference adds them (par_term / par_ok, filled in parallel), added one by one
+TC_FN int sum_parallax_terms(const Stream &S, int n, double &parallax) {
     parallax   = 0;
     int counts = 0;
+    for (int k = 0; k < n; k++)
+        if (S.par_ok[k]) {
+            parallax += S.par_term[k];
+            counts++;
+        }
+    if (counts != 0) parallax /= counts;
+    return counts;
+}
+TC_FN int parallax_from_reference_mappoints(Stream &S, const Cfg &C, double &parallax, Scratch &X) { // :873-905
     const Frame &fc = S.frame[S.cur];
     const Frame &fr = S.frame[S.ref];
     double R10[9];
     mat_mul_t(fc.pose.R, fr.pose.R, R10);
     const double focal = focalLength(C.cam);
-    const int nq       = list_container_order(S, fr);
-    for (int k = 0; k < nq; k++) {
+    const int nq       = list_container_order(S, fr, X);
+    for (int k = lane(); k < nq; k += NL) {
         const Row &r0    = fr.row[S.order_idx[k]];
         const uint32_t i = r0.mp;
-        if (!mp_valid(S, i, r0.mpgen) || S.hot[i].outlier) continue;
-        const LastObs lo = S.hot[i].last;
-        if (lo.frame != S.cur || lo.gen != fc.gen) continue;
-        const Row &r1 = fc.row[lo.row];
-        if (r1.outlier) continue;
-        const double x = R10[0] * r0.pcx + R10[1] * r0.pcy + R10[2] * 1.0, y = R10[3] * r0.pcx + R10[4] * r0.pcy + R10[5] * 1.0;
-        const double dx = x - r1.pcx, dy = y - r1.pcy;
-        parallax += tc_sqrt(dx * dx + dy * dy) * focal;
-        counts++;
+        bool ok          = mp_valid(S, i, r0.mpgen) && !S.hot[i].outlier; // getMapPoint() && !isOutlier()
+        double term      = 0;
+        if (ok) {
+            const LastObs lo = S.hot[i].last;                       // observations().back().lock()
+            ok               = lo.frame == S.cur && lo.gen == fc.gen; // feat && feat->getFrame() == frame_cur_
+            if (ok) {
+                const Row &r1 = fc.row[lo.row];
+                ok            = !r1.outlier; // :884
+                if (ok) {
+                    const double x = R10[0] * r0.pcx + R10[1] * r0.pcy + R10[2] * 1.0, y = R10[3] * r0.pcx + R10[4] * r0.pcy + R10[5] * 1.0;
+                    const double dx = x - r1.pcx, dy = y - r1.pcy;
+                    term            = tc_sqrt(dx * dx + dy * dy) * focal;
+                }
+            }
+        }
+        S.par_ok[k]   = ok ? 1 : 0;
+        S.par_term[k] = term;
     }
-    if (counts != 0) parallax /= counts;
-    return counts;
+    sync();
+    return sum_parallax_terms(S, nq, parallax);
 }
 TC_FN int parallax_from_reference_keypoints(Stream &S, const Cfg &C, const P2f *ref, const P2f *cur, double &parallax) { // :907-922
-    parallax   = 0;
-    int counts = 0;
     double R10[9];
     mat_mul_t(S.frame[S.cur].pose.R, S.frame[S.ref].pose.R, R10);
-    for (int k = 0; k < S.n_ref_frame; k++) {
-        if (S.pts2d_ref_frame[k] == S.ref) {
-            parallax += keypoint_parallax(C, ref[k], cur[k], R10);
-            counts++;
-        }
+    const int n = S.n_ref_frame;
+    for (int k = lane(); k < n; k += NL) {
+        const bool ok = S.pts2d_ref_frame[k] == S.ref;
+        S.par_ok[k]   = ok ? 1 : 0;
+        S.par_term[k] = ok ? keypoint_parallax(C, ref[k], cur[k], R10) : 0.0;
     }
-    if (counts != 0) parallax /= counts;
-    return counts;
+    sync();
+    return sum_parallax_terms(S, n, parallax);
 }
 TC_FN void clear_candidates(Stream &S) {
     S.n_new = S.n_ref = S.n_ref_undis = S.n_new_undis = S.n_ref_frame = S.n_vel_ref = S.n_cand_lk = 0;
@@ -709,10 +889,11 @@ TC_FN int check_keyframe_state(Stream &S, const Cfg &C) { // :263-307
     }
     if (keyframe_state != KEYFRAME_NONE) {
         S.last_keyframe = S.cur;
-        for (int k = 0; k < S.n_tracked; k++) {
+        for (int k = lane(); k < S.n_tracked; k += NL) { // (the tracked map points are distinct: independent increments)
             const MpRef m = S.tracked_mappoint[k];
             if (mp_valid(S, m.i, m.g)) S.hot[m.i].used++;
         }
+        sync();
         const Pose &pc = S.frame[S.cur].pose, &pr = S.frame[S.ref].pose;
         const double dx = pc.t[0] - pr.t[0], dy = pc.t[1] - pr.t[1], dz = pc.t[2] - pr.t[2];
         double R[9];
@@ -739,13 +920,18 @@ TC_FN bool queue_detection(Stream &S, const Cfg &C, Io &io, int frame, bool isma
     if (num_features > (C.track_max_features - 5)) return false; // :580
     int features_cnts[MAX_BLOCKS];
     for (int k = 0; k < C.block_cnts; k++) features_cnts[k] = 0;
-    for (int q = 0; q < f.n_rows + S.n_new; q++) {
-        const P2f p  = q < f.n_rows ? f.row[q].kp : S.pts2d_new[q - f.n_rows];
-        const int col = (int) (p.x / (float) C.block_w); // :598
-        const int row = (int) (p.y / (float) C.block_h);
-        // hazard H5 (unclamped column of an undistorted key point), reproduced as in tracking_hip.cc
-        const long idx = (long) row * C.block_cols + col;
-        if (idx >= 0 && idx < (long) C.block_cnts) features_cnts[idx]++;
+    const int total = f.n_rows + S.n_new;
+    for (int base = 0; base < total; base += NL) { // a chunk of points per step, a ballot per block
+        const int q = base + lane();
+        long idx    = -1;
+        if (q < total) {
+            const P2f p   = q < f.n_rows ? f.row[q].kp : S.pts2d_new[q - f.n_rows];
+            const int col = (int) (p.x / (float) C.block_w); // :598
+            const int row = (int) (p.y / (float) C.block_h);
+            // hazard H5 (unclamped column of an undistorted key point), reproduced as in tracking_hip.cc
+            idx = (long) row * C.block_cols + col;
+        }
+        for (int b = 0; b < C.block_cnts; b++) features_cnts[b] += popc(ballot(idx == (long) b));
     }
     S.det_job     = 0;
     S.det_ismask  = ismask ? 1 : 0;
@@ -754,74 +940,95 @@ TC_FN bool queue_detection(Stream &S, const Cfg &C, Io &io, int frame, bool isma
     int nm        = 0;
     if (ismask) { // :610-620 (a union of discs: the order of the points is immaterial)
         const Frame &fc = S.frame[S.cur];
-        for (int q = 0; q < fc.n_rows; q++) io.det_mask_pts[nm++] = fc.row[q].kp;
-        for (int q = 0; q < S.n_new && nm < MAX_ROWS; q++) io.det_mask_pts[nm++] = S.pts2d_new[q];
+        nm              = fc.n_rows + S.n_new;
+        if (nm > MAX_ROWS) nm = MAX_ROWS;
+        for (int q = lane(); q < nm; q += NL) io.det_mask_pts[q] = q < fc.n_rows ? fc.row[q].kp : S.pts2d_new[q - fc.n_rows];
     }
     *io.det_mask_count = nm;
-    for (int k = 0; k < C.block_cnts; k++) io.det_quota[k] = C.max_block_features - features_cnts[k]; // :629
+    for (int k = lane(); k < C.block_cnts; k += NL) io.det_quota[k] = C.max_block_features - features_cnts[k]; // :629
+    sync();
     return true;
 }
 TC_FN void integrate_detection(Stream &S, const Cfg &C, const Io &io) { // :659-685
     if (!S.det_ismask) clear_candidates(S);
-    const int n = *io.det_count;
-    for (int i = 0; i < n; i++) {
-        if (S.n_ref >= MAX_ROWS || S.n_new >= MAX_ROWS) {
-            S.overflow |= OVF_ROWS;
-            break;
-        }
+    int n = *io.det_count;
+    if (S.n_ref + n > MAX_ROWS || S.n_new + n > MAX_ROWS) {
+        S.overflow |= OVF_ROWS;
+        n = 0;
+    }
+    const int r0 = S.n_ref, n0 = S.n_new, ru0 = S.n_ref_undis, nu0 = S.n_new_undis, f0 = S.n_ref_frame, v0 = S.n_vel_ref;
+    for (int i = lane(); i < n; i += NL) {
         const P2f p = io.det_out[i];
         const P2f u = undistortPoint(C.cam, p); // the one undistortion a detected corner ever needs
-        S.pts2d_ref[S.n_ref++]             = p;
-        S.pts2d_new[S.n_new++]             = p;
-        S.pts2d_ref_undis[S.n_ref_undis++] = u;
-        S.pts2d_new_undis[S.n_new_undis++] = u;
-        S.pts2d_ref_frame[S.n_ref_frame++] = S.det_frame;
-        S.velocity_ref[S.n_vel_ref][0] = 0, S.velocity_ref[S.n_vel_ref][1] = 0;
-        S.n_vel_ref++;
+        S.pts2d_ref[r0 + i]        = p;
+        S.pts2d_new[n0 + i]        = p;
+        S.pts2d_ref_undis[ru0 + i] = u;
+        S.pts2d_new_undis[nu0 + i] = u;
+        S.pts2d_ref_frame[f0 + i]  = S.det_frame;
+        S.velocity_ref[v0 + i][0] = 0, S.velocity_ref[v0 + i][1] = 0;
     }
+    S.n_ref = r0 + n, S.n_new = n0 + n, S.n_ref_undis = ru0 + n, S.n_new_undis = nu0 + n, S.n_ref_frame = f0 + n, S.n_vel_ref = v0 + n;
     // cand_lk_idx_.resize(pts2d_new_.size(), -1): a list that lost its alignment is padded / cut (hints are hints)
-    for (int k = S.n_cand_lk; k < S.n_new; k++) S.cand_lk_idx[k] = -1;
+    for (int k = S.n_cand_lk + lane(); k < S.n_new; k += NL) S.cand_lk_idx[k] = -1;
     S.n_cand_lk = S.n_new;
     S.det_job   = -1;
     S.det_frame = -1;
+    sync();
 }
 
 // ---- trackMappoint (:351-455) ------------------------------------------------------------------------------------------------------------
-TC_FN void queue_track_mappoint(Stream &S, const Cfg &C, Io &io) {
+TC_FN void queue_track_mappoint(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     S.n_matched     = 0;
     const Frame &fp = S.frame[S.pre];
     const Pose pose_cur = S.frame[S.cur].pose;
-    const int nq    = list_container_order(S, fp);
+    const int cur_slot  = S.frame[S.cur].slot;
+    const int nq    = list_container_order(S, fp, X);
     int n           = 0;
-    for (int k = 0; k < nq; k++) {
-        const Row &r     = fp.row[S.order_idx[k]];
-        const uint32_t i = r.mp;
-        if (!mp_valid(S, i, r.mpgen) || S.hot[i].outlier) continue; // mappoint && !mappoint->isOutlier() (:360)
-        S.tm_pc[n][0] = r.pcx, S.tm_pc[n][1] = r.pcy;
-        P2f pp        = world2pixel(C.cam, S.hot[i].pos, pose_cur); // INS-aided prediction :367
-        distortPoint(C.cam, pp);                                    // :378
-        io.lk_prev_slot[n] = fp.slot;
-        io.lk_next_slot[n] = S.frame[S.cur].slot;
-        io.lk_prev[n]      = r.kpd;
-        io.lk_guess[n]     = pp;
-        MpRef m;
-        m.i = i, m.g = r.mpgen;
-        S.mappoint_matched[n] = m;
-        n++;
+    for (int base = 0; base < nq; base += NL) { // rows in container order, a chunk per step; the valid ones are appended in that order
+        const int k = base + lane();
+        bool valid  = false;
+        Row r;
+        if (k < nq) {
+            r     = fp.row[S.order_idx[k]];
+            valid = mp_valid(S, r.mp, r.mpgen) && !S.hot[r.mp].outlier; // mappoint && !mappoint->isOutlier() (:360)
+        }
+        P2f pp;
+        pp.x = pp.y = 0;
+        if (valid) {
+            pp = world2pixel(C.cam, S.hot[r.mp].pos, pose_cur); // INS-aided prediction :367
+            distortPoint(C.cam, pp);                            // :378
+        }
+        const u64 m   = ballot(valid);
+        const int pos = n + popc(m & lanes_below());
+        if (valid) {
+            S.tm_pc[pos][0] = r.pcx, S.tm_pc[pos][1] = r.pcy;
+            io.lk_prev_slot[pos] = fp.slot;
+            io.lk_next_slot[pos] = cur_slot;
+            io.lk_prev[pos]      = r.kpd;
+            io.lk_guess[pos]     = pp;
+            MpRef mr;
+            mr.i = r.mp, mr.g = r.mpgen;
+            S.mappoint_matched[pos] = mr;
+        }
+        n += popc(m);
     }
     S.n_matched    = n;
     S.lk_map_begin = 0;
     S.lk_map_n     = n;
     *io.lk_count   = n;
+    sync();
 }
-TC_FN bool finish_track_mappoint(Stream &S, const Cfg &C, const Io &io, const uint32_t *buckets_after) {
+TC_FN bool finish_track_mappoint(Stream &S, const Cfg &C, const Io &io, const uint32_t *buckets_after, Scratch &X) {
     if (S.lk_map_n == 0) return false;
     const int n           = S.lk_map_n;
     const uint8_t *status = io.lk_status + S.lk_map_begin;
     const P2f *out        = io.lk_out + S.lk_map_begin;
     const P2f *undis      = io.lk_undist + S.lk_map_begin;
     int kept = 0;
-    for (int k = 0; k < n; k++) kept += status[k] ? 1 : 0;
+    for (int base = 0; base < n; base += NL) {
+        const int k = base + lane();
+        kept += popc(ballot(k < n && status[k]));
+    }
     if (kept == 0) { // :410-419
         S.parallax_map        = 0;
         S.parallax_map_counts = 0;
@@ -829,23 +1036,50 @@ TC_FN bool finish_track_mappoint(Stream &S, const Cfg &C, const Io &io, const ui
     }
     Frame &fc = S.frame[S.cur];
     frame_clear_rows(fc); // :426
-    S.n_tracked     = 0;
-    const double dt = fc.stamp - S.frame[S.pre].stamp;
-    for (int k = 0; k < n; k++) { // reduceVector (:404-408) and the feature loop (:430-444) in one pass
-        if (!status[k]) continue;
-        const MpRef m = S.mappoint_matched[k];
-        double pcx, pcy;
-        pixel2cam(C.cam, undis[k], pcx, pcy);
-        const double vx = (pcx - S.tm_pc[k][0]) / dt, vy = (pcy - S.tm_pc[k][1]) / dt; // :434
-        const int row = add_row(S, S.cur, S.hot[m.i].id, m.i, undis[k], out[k], vx, vy, FEATURE_MATCHED, pcx, pcy, io.lk_base + S.lk_map_begin + k,
-                                buckets_after);
-        S.hot[m.i].observed++; // addObservation (mappoint.cc:58-62)
-        LastObs lo;
-        lo.frame = S.cur, lo.gen = fc.gen, lo.row = row;
-        S.hot[m.i].last                 = lo;
-        S.tracked_mappoint[S.n_tracked++] = m;
+    if (kept > MAX_ROWS) { // (cannot happen: n <= MAX_ROWS)
+        S.overflow |= OVF_ROWS;
+        return false;
     }
-    S.parallax_map_counts = parallax_from_reference_mappoints(S, C, S.parallax_map); // :450
+    const double dt     = fc.stamp - S.frame[S.pre].stamp;
+    const uint32_t cgen = fc.gen;
+    int r0 = 0;
+    for (int base = 0; base < n; base += NL) { // reduceVector (:404-408) and the feature loop (:430-444): the rows of the kept points, in order
+        const int k     = base + lane();
+        const bool keep = k < n && status[k];
+        const u64 mm    = ballot(keep);
+        if (keep) {
+            const int row = r0 + popc(mm & lanes_below());
+            const MpRef m = S.mappoint_matched[k];
+            double pcx, pcy;
+            pixel2cam(C.cam, undis[k], pcx, pcy);
+            Row r;
+            r.id      = S.hot[m.i].id;
+            r.mp      = m.i;
+            r.mpgen   = S.hot[m.i].gen;
+            r.kp      = undis[k];
+            r.kpd     = out[k];
+            r.vel[0]  = (pcx - S.tm_pc[k][0]) / dt; // (pixel2cam(cur) - pixel2cam(pre)) / dt (:434)
+            r.vel[1]  = (pcy - S.tm_pc[k][1]) / dt;
+            r.pcx     = pcx;
+            r.pcy     = pcy;
+            r.lk_idx  = io.lk_base + S.lk_map_begin + k;
+            r.type    = (int8_t) FEATURE_MATCHED;
+            r.outlier = 0;
+            r.pad_[0] = r.pad_[1] = 0;
+            fc.row[row] = r;
+            S.hot[m.i].observed++; // addObservation (mappoint.cc:58-62); the matched map points are distinct
+            LastObs lo;
+            lo.frame = S.cur, lo.gen = cgen, lo.row = row;
+            S.hot[m.i].last          = lo;
+            S.tracked_mappoint[row] = m;
+        }
+        r0 += popc(mm);
+    }
+    S.n_tracked = kept;
+    fc.n_rows   = kept;
+    sync();
+    order_extend(fc, 0, buckets_after, X); // the ids of the previous frame's rows are distinct keys
+    S.parallax_map_counts = parallax_from_reference_mappoints(S, C, S.parallax_map, X); // :450
     return true;
 }
 
@@ -862,35 +1096,40 @@ TC_FN void queue_track_reference(Stream &S, const Cfg &C, Io &io) {
         S.overflow |= OVF_ROWS;
         return;
     }
-    S.n_cur = 0;
-    for (int k = 0; k < S.n_new_undis; k++) { // :469 (carried), :472-479
+    const int nu = S.n_new_undis;
+    for (int k = lane(); k < nu; k += NL) { // :469 (carried), :472-479
         double x, y;
         pixel2cam(C.cam, S.pts2d_new_undis[k], x, y);
         const double X = r_cur_pre[0] * x + r_cur_pre[1] * y + r_cur_pre[2] * 1.0, Y = r_cur_pre[3] * x + r_cur_pre[4] * y + r_cur_pre[5] * 1.0,
                      Z = r_cur_pre[6] * x + r_cur_pre[7] * y + r_cur_pre[8] * 1.0;
-        S.pts2d_cur[S.n_cur++] = distortCameraPoint(C.cam, X, Y, Z);
+        S.pts2d_cur[k] = distortCameraPoint(C.cam, X, Y, Z);
     }
+    S.n_cur = nu;
+    sync();
     S.lk_ref_n = S.n_new;
-    for (int k = 0; k < S.lk_ref_n; k++) {
-        io.lk_prev_slot[at + k] = fp.slot;
-        io.lk_next_slot[at + k] = fc.slot;
+    const int pslot = fp.slot, cslot = fc.slot;
+    for (int k = lane(); k < S.lk_ref_n; k += NL) {
+        io.lk_prev_slot[at + k] = pslot;
+        io.lk_next_slot[at + k] = cslot;
         io.lk_prev[at + k]      = S.pts2d_new[k];
         io.lk_guess[at + k]     = S.pts2d_cur[k];
     }
     *io.lk_count = at + S.lk_ref_n;
+    sync();
 }
 TC_FN bool mid_track_reference(Stream &S, const Cfg &C, Io &io) {
     S.rs_set      = -1;
     *io.rs_count  = 0;
     if (S.lk_ref_n == 0) return false;
     const int n = S.lk_ref_n;
-    for (int k = 0; k < n; k++) {
-        S.status[k]       = io.lk_status[S.lk_ref_begin + k];
-        S.pts2d_cur[k]    = io.lk_out[S.lk_ref_begin + k];
-        S.scratch_a[k]    = io.lk_undist[S.lk_ref_begin + k];
-        S.cand_lk_idx[k]  = io.lk_base + S.lk_ref_begin + k;
+    for (int k = lane(); k < n; k += NL) {
+        S.status[k]      = io.lk_status[S.lk_ref_begin + k];
+        S.pts2d_cur[k]   = io.lk_out[S.lk_ref_begin + k];
+        S.scratch_a[k]   = io.lk_undist[S.lk_ref_begin + k];
+        S.cand_lk_idx[k] = io.lk_base + S.lk_ref_begin + k;
     }
     S.n_cur = n;
+    sync();
     // reduceVector (:507-511): every list by the LK status
     S.n_cand_lk      = reduce_vector(S.cand_lk_idx, n, S.status);
     S.n_ref          = reduce_vector(S.pts2d_ref, S.n_ref, S.status);
@@ -902,16 +1141,16 @@ TC_FN bool mid_track_reference(Stream &S, const Cfg &C, Io &io) {
     S.n_ref_undis    = reduce_vector(S.pts2d_ref_undis, S.n_ref_undis, S.status);
     S.n_new_undis    = reduce_vector(S.pts2d_new_undis, S.n_new_undis, S.status);
     if (S.n_ref == 0) return false; // :513-517 (tr_cur_undis_ keeps what it held, as in the table)
-    for (int k = 0; k < n_a; k++) S.tr_cur_undis[k] = S.scratch_a[k];
+    copy_n(S.tr_cur_undis, S.scratch_a, n_a);
     S.n_tr_cur_undis = n_a;
-    for (int k = 0; k < S.n_new_undis; k++) S.tr_new_undis[k] = S.pts2d_new_undis[k]; // :520-524 (carried)
+    copy_n(S.tr_new_undis, S.pts2d_new_undis, S.n_new_undis); // :520-524 (carried)
     S.n_tr_new_undis = S.n_new_undis;
 
-    S.n_vel_cur = 0; // :527-539
+    // :527-539
     const Frame &fc   = S.frame[S.cur];
     const u64 ref_fid = S.frame[S.ref].fid;
     const double dt   = fc.stamp - S.frame[S.pre].stamp;
-    for (int k = 0; k < S.n_tr_cur_undis; k++) {
+    for (int k = lane(); k < S.n_tr_cur_undis; k += NL) {
         double x1, y1, x0, y0;
         pixel2cam(C.cam, S.tr_cur_undis[k], x1, y1);
         pixel2cam(C.cam, S.tr_new_undis[k], x0, y0);
@@ -919,17 +1158,19 @@ TC_FN bool mid_track_reference(Stream &S, const Cfg &C, Io &io) {
         S.velocity_cur[k][0] = vx, S.velocity_cur[k][1] = vy;
         if (S.frame[S.pts2d_ref_frame[k]].fid > ref_fid) S.velocity_ref[k][0] = vx, S.velocity_ref[k][1] = vy;
     }
-    S.n_vel_cur           = S.n_tr_cur_undis;
+    S.n_vel_cur = S.n_tr_cur_undis;
+    sync();
     S.parallax_ref_counts = parallax_from_reference_keypoints(S, C, S.pts2d_ref_undis, S.tr_cur_undis, S.parallax_ref); // :542-544
 
     if (S.n_cur >= 15) { // :547-548
         S.rs_set = 0;
         const int m = S.n_tr_new_undis;
-        for (int k = 0; k < m; k++) {
+        for (int k = lane(); k < m; k += NL) {
             io.rs_p1[k] = S.tr_new_undis[k];
             io.rs_p2[k] = S.tr_cur_undis[k];
         }
         *io.rs_count = m;
+        sync();
     }
     return true;
 }
@@ -937,7 +1178,8 @@ TC_FN bool finish_track_reference(Stream &S, const Io &io) {
     if (S.rs_set >= 0) { // :550-554
         const uint8_t *mask = io.rs_mask;
         const int m         = S.n_tr_new_undis; // (the set's size)
-        for (int k = 0; k < m; k++) S.status[k] = mask[k];
+        for (int k = lane(); k < m; k += NL) S.status[k] = mask[k];
+        sync();
         S.n_ref          = reduce_vector(S.pts2d_ref, S.n_ref, S.status);
         S.n_cur          = reduce_vector(S.pts2d_cur, S.n_cur, S.status);
         S.n_ref_frame    = reduce_vector(S.pts2d_ref_frame, S.n_ref_frame, S.status);
@@ -949,9 +1191,9 @@ TC_FN bool finish_track_reference(Stream &S, const Io &io) {
         S.rs_set         = -1;
     }
     if (S.n_cur == 0) return false; // :557-561
-    for (int k = 0; k < S.n_cur; k++) S.pts2d_new[k] = S.pts2d_cur[k]; // :569
+    copy_n(S.pts2d_new, S.pts2d_cur, S.n_cur); // :569
     S.n_new = S.n_cur;
-    for (int k = 0; k < S.n_tr_cur_undis; k++) S.pts2d_new_undis[k] = S.tr_cur_undis[k];
+    copy_n(S.pts2d_new_undis, S.tr_cur_undis, S.n_tr_cur_undis);
     S.n_new_undis = S.n_tr_cur_undis;
     return S.n_new != 0;
 }
@@ -975,19 +1217,22 @@ TC_FN bool queue_triangulation(Stream &S, const Cfg &C, Io &io) {
     S.tri_queued     = 1;
     const Pose pose1 = S.frame[S.cur].pose;
     if (S.n_tr_cur_undis != S.n_cur) { // no reference tracking ran this frame: derive them
-        for (int k = 0; k < S.n_cur; k++) S.tr_cur_undis[k] = undistortPoint(C.cam, S.pts2d_cur[k]);
+        for (int k = lane(); k < S.n_cur; k += NL) S.tr_cur_undis[k] = undistortPoint(C.cam, S.pts2d_cur[k]);
         S.n_tr_cur_undis = S.n_cur;
+        sync();
     }
     if (S.n_ref_undis != S.n_ref) {
-        for (int k = 0; k < S.n_ref; k++) S.pts2d_ref_undis[k] = undistortPoint(C.cam, S.pts2d_ref[k]);
+        for (int k = lane(); k < S.n_ref; k += NL) S.pts2d_ref_undis[k] = undistortPoint(C.cam, S.pts2d_ref[k]);
         S.n_ref_undis = S.n_ref;
+        sync();
     }
-    for (int k = 0; k < S.n_ref_undis; k++) S.tri_ref_undis[k] = S.pts2d_ref_undis[k]; // :712-713 (carried)
+    copy_n(S.tri_ref_undis, S.pts2d_ref_undis, S.n_ref_undis); // :712-713 (carried)
     S.n_tri_ref_undis = S.n_ref_undis;
-    for (int k = 0; k < S.n_tr_cur_undis; k++) S.tri_cur_undis[k] = S.tr_cur_undis[k];
+    copy_n(S.tri_cur_undis, S.tr_cur_undis, S.n_tr_cur_undis);
     S.n_tri_cur_undis = S.n_tr_cur_undis;
-    for (int k = 0; k < S.n_cur; k++) S.tri_status[k] = 0;
+    for (int k = lane(); k < S.n_cur; k += NL) S.tri_status[k] = 0;
     S.n_tri_status = S.n_cur;
+    sync();
     S.n_tri_index  = 0;
     S.tri_begin    = 0;
 
@@ -995,29 +1240,43 @@ TC_FN bool queue_triangulation(Stream &S, const Cfg &C, Io &io) {
     const int T_cur = n_tcw;
     pose2Tcw12(pose1, io.tri_Tcw + 12 * n_tcw);
     n_tcw++;
-    int T_frame[8], T_index[8], n_T = 0; // distinct reference frames of the candidates (a handful)
+    // pass 1 (parallel): what happens to candidate k — 0 re-anchored (:723-730), 1 dropped (:733-737), 2 kept for later (:741-746),
+    // 3 triangulated — and, for 3, its two normalized points
     const u64 ref_fid = S.frame[S.ref].fid;
-    for (int k = 0; k < S.n_cur; k++) {
+    for (int k = lane(); k < S.n_cur; k += NL) {
         const int frame_ref = S.pts2d_ref_frame[k];
         const Frame &fr     = S.frame[frame_ref];
-        if (fr.fid > ref_fid) { // :723-730 feature added after the reference keyframe: re-anchor
+        int kind;
+        if (fr.fid > ref_fid) { // feature added after the reference keyframe: re-anchor
             S.pts2d_ref_frame[k] = S.cur;
             S.pts2d_ref[k]       = S.pts2d_cur[k];
             S.pts2d_ref_undis[k] = S.tri_cur_undis[k];
             S.tri_status[k]      = 1;
-            continue;
-        }
-        if (S.n_map_kf == C.window_size && !map_is_keyframe_in_map(S, frame_ref)) { // :733-737
+            kind                 = 0;
+        } else if (S.n_map_kf == C.window_size && !map_is_keyframe_in_map(S, frame_ref)) {
             S.tri_status[k] = 0;
-            continue;
+            kind            = 1;
+        } else {
+            double R10[9];
+            mat_mul_t(pose1.R, fr.pose.R, R10); // (pose1.R^T * pose0.R)
+            const double parallax = keypoint_parallax(C, S.tri_ref_undis[k], S.tri_cur_undis[k], R10); // :741
+            if (parallax < 10.0 /*TRACK_MIN_PARALLAX*/) {
+                S.tri_status[k] = 1;
+                kind            = 2;
+            } else {
+                kind = 3;
+                pixel2cam(C.cam, S.tri_ref_undis[k], S.tri_tmp[k][0], S.tri_tmp[k][1]); // :750-751
+                pixel2cam(C.cam, S.tri_cur_undis[k], S.tri_tmp[k][2], S.tri_tmp[k][3]);
+            }
         }
-        double R10[9];
-        mat_mul_t(pose1.R, fr.pose.R, R10); // (pose1.R^T * pose0.R)
-        const double parallax = keypoint_parallax(C, S.tri_ref_undis[k], S.tri_cur_undis[k], R10); // :741
-        if (parallax < 10.0 /*TRACK_MIN_PARALLAX*/) {
-            S.tri_status[k] = 1;
-            continue;
-        }
+        S.par_ok[k] = (uint8_t) kind;
+    }
+    sync();
+    // pass 2 (in list order): camera matrices of the distinct reference frames, the triangulation list
+    int T_frame[8], T_index[8], n_T = 0;
+    for (int k = 0; k < S.n_cur; k++) {
+        if (S.par_ok[k] != 3) continue;
+        const int frame_ref = S.pts2d_ref_frame[k];
         int T0 = -1;
         for (int q = 0; q < n_T; q++)
             if (T_frame[q] == frame_ref) T0 = T_index[q];
@@ -1027,18 +1286,15 @@ TC_FN bool queue_triangulation(Stream &S, const Cfg &C, Io &io) {
                 T0 = 0;
             } else {
                 T0 = n_tcw;
-                pose2Tcw12(fr.pose, io.tri_Tcw + 12 * n_tcw);
+                pose2Tcw12(S.frame[frame_ref].pose, io.tri_Tcw + 12 * n_tcw);
                 n_tcw++;
             }
             if (n_T < 8) T_frame[n_T] = frame_ref, T_index[n_T] = T0, n_T++;
         }
-        double x0, y0, x1, y1;
-        pixel2cam(C.cam, S.tri_ref_undis[k], x0, y0); // :750-751
-        pixel2cam(C.cam, S.tri_cur_undis[k], x1, y1);
         io.tri_T0[n_tri] = T0;
         io.tri_T1[n_tri] = T_cur;
-        io.tri_pc0[3 * n_tri] = x0, io.tri_pc0[3 * n_tri + 1] = y0, io.tri_pc0[3 * n_tri + 2] = 1.0;
-        io.tri_pc1[3 * n_tri] = x1, io.tri_pc1[3 * n_tri + 1] = y1, io.tri_pc1[3 * n_tri + 2] = 1.0;
+        io.tri_pc0[3 * n_tri] = S.tri_tmp[k][0], io.tri_pc0[3 * n_tri + 1] = S.tri_tmp[k][1], io.tri_pc0[3 * n_tri + 2] = 1.0;
+        io.tri_pc1[3 * n_tri] = S.tri_tmp[k][2], io.tri_pc1[3 * n_tri + 1] = S.tri_tmp[k][3], io.tri_pc1[3 * n_tri + 2] = 1.0;
         S.tri_point_index[S.n_tri_index++] = k;
         n_tri++;
     }
@@ -1046,9 +1302,13 @@ TC_FN bool queue_triangulation(Stream &S, const Cfg &C, Io &io) {
     *io.tri_n_tcw = n_tcw;
     return true;
 }
-TC_FN void finish_triangulation(Stream &S, const Cfg &C, const Io &io, const uint32_t *buckets_after) {
+TC_FN void finish_triangulation(Stream &S, const Cfg &C, const Io &io, const uint32_t *buckets_after, Scratch &X) {
     S.tri_queued     = 0;
     const Pose pose1 = S.frame[S.cur].pose;
+    // the new rows are written first; the frames that received some (the current one and the candidates' reference frames) then take them
+    // into their container order in one pass each, in row order — the order the reference's insertions happen in per container
+    int touched[10], touched_old[10], n_touched = 0;
+    touched[0] = S.cur, touched_old[0] = S.frame[S.cur].n_rows, n_touched = 1;
     for (int q = 0; q < S.n_tri_index; q++) {
         const int k     = S.tri_point_index[q];
         const double *p = io.tri_pw + 3 * (S.tri_begin + q);
@@ -1074,12 +1334,22 @@ TC_FN void finish_triangulation(Stream &S, const Cfg &C, const Io &io, const uin
         double pccx, pccy, pcrx, pcry;
         pixel2cam(C.cam, S.tri_cur_undis[k], pccx, pccy);
         pixel2cam(C.cam, S.tri_ref_undis[k], pcrx, pcry);
-        add_row(S, S.cur, S.hot[i].id, i, S.tri_cur_undis[k], S.pts2d_cur[k], S.velocity_cur[k][0], S.velocity_cur[k][1], FEATURE_TRIANGULATED, pccx, pccy,
-                k < S.n_cand_lk ? S.cand_lk_idx[k] : -1, buckets_after); // :769-774
+        int tq = -1;
+        for (int u = 0; u < n_touched; u++)
+            if (touched[u] == frame_ref) tq = u;
+        if (tq < 0) {
+            if (n_touched < 10) {
+                touched[n_touched] = frame_ref, touched_old[n_touched] = S.frame[frame_ref].n_rows, n_touched++;
+            } else {
+                S.overflow |= OVF_TCW; // (more distinct reference frames than a window holds)
+            }
+        }
+        append_row(S, S.cur, S.hot[i].id, i, S.tri_cur_undis[k], S.pts2d_cur[k], S.velocity_cur[k][0], S.velocity_cur[k][1], FEATURE_TRIANGULATED, pccx, pccy,
+                   k < S.n_cand_lk ? S.cand_lk_idx[k] : -1); // :769-774
         S.hot[i].observed++;
         S.hot[i].used++;
-        const int row = add_row(S, frame_ref, S.hot[i].id, i, S.tri_ref_undis[k], S.pts2d_ref[k], S.velocity_ref[k][0], S.velocity_ref[k][1],
-                                FEATURE_TRIANGULATED, pcrx, pcry, -1, buckets_after); // :776-781
+        const int row = append_row(S, frame_ref, S.hot[i].id, i, S.tri_ref_undis[k], S.pts2d_ref[k], S.velocity_ref[k][0], S.velocity_ref[k][1],
+                                   FEATURE_TRIANGULATED, pcrx, pcry, -1); // :776-781 (a freshly drawn id is in no frame yet)
         S.hot[i].observed++;
         S.hot[i].used++;
         LastObs lo;
@@ -1094,6 +1364,8 @@ TC_FN void finish_triangulation(Stream &S, const Cfg &C, const Io &io, const uin
             S.overflow |= OVF_ROWS;
         }
     }
+    sync();
+    for (int u = 0; u < n_touched; u++) order_extend(S.frame[touched[u]], touched_old[u], buckets_after, X);
     const int nst = S.n_tri_status;
     S.n_ref       = reduce_vector(S.pts2d_ref, S.n_ref, S.tri_status); // :788-793
     S.n_ref_frame = reduce_vector(S.pts2d_ref_frame, S.n_ref_frame, S.tri_status);
@@ -1102,9 +1374,9 @@ TC_FN void finish_triangulation(Stream &S, const Cfg &C, const Io &io, const uin
     S.n_ref_undis = reduce_vector(S.pts2d_ref_undis, S.n_ref_undis, S.tri_status);
     S.n_tr_cur_undis = reduce_vector(S.tr_cur_undis, S.n_tr_cur_undis, S.tri_status);
     if (S.n_cand_lk == nst) S.n_cand_lk = reduce_vector(S.cand_lk_idx, S.n_cand_lk, S.tri_status);
-    for (int k = 0; k < S.n_cur; k++) S.pts2d_new[k] = S.pts2d_cur[k];
+    copy_n(S.pts2d_new, S.pts2d_cur, S.n_cur);
     S.n_new = S.n_cur;
-    for (int k = 0; k < S.n_tr_cur_undis; k++) S.pts2d_new_undis[k] = S.tr_cur_undis[k];
+    copy_n(S.pts2d_new_undis, S.tr_cur_undis, S.n_tr_cur_undis);
     S.n_new_undis = S.n_tr_cur_undis;
 }
 
@@ -1188,7 +1460,7 @@ TC_FN void stage_on_preprocess(Stream &S, const Cfg &C, Io &io) {
     }
 }
 // stage 2 (after detection A) -> LK
-TC_FN void stage_on_detect_a(Stream &S, const Cfg &C, Io &io) {
+TC_FN void stage_on_detect_a(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     if (S.done) return;
     if (S.det_job >= 0) integrate_detection(S, C, io);
     *io.det_slot = -1;
@@ -1198,13 +1470,13 @@ TC_FN void stage_on_detect_a(Stream &S, const Cfg &C, Io &io) {
         return;
     }
     *io.lk_count = 0;
-    if (S.mode == M_TRACK) queue_track_mappoint(S, C, io); // :206
+    if (S.mode == M_TRACK) queue_track_mappoint(S, C, io, X); // :206
     queue_track_reference(S, C, io);                        // :173 / :209
 }
 // stage 3 (after LK) -> RANSAC
-TC_FN void stage_on_lk(Stream &S, const Cfg &C, Io &io, const uint32_t *buckets_after) {
+TC_FN void stage_on_lk(Stream &S, const Cfg &C, Io &io, const uint32_t *buckets_after, Scratch &X) {
     if (S.done) return;
-    if (S.mode == M_TRACK) finish_track_mappoint(S, C, io, buckets_after);
+    if (S.mode == M_TRACK) finish_track_mappoint(S, C, io, buckets_after, X);
     S.ref_tracked = mid_track_reference(S, C, io) ? 1 : 0;
     *io.lk_count  = 0;
 }
@@ -1225,9 +1497,9 @@ TC_FN void stage_on_ransac(Stream &S, const Cfg &C, Io &io) {
     if ((S.kf_state == KEYFRAME_NORMAL) || (S.kf_state == KEYFRAME_REMOVE_OLDEST)) queue_triangulation(S, C, io); // :215-217
 }
 // stage 5 (after triangulation) -> detection B
-TC_FN void stage_on_triangulate(Stream &S, const Cfg &C, Io &io, const uint32_t *buckets_after) {
+TC_FN void stage_on_triangulate(Stream &S, const Cfg &C, Io &io, const uint32_t *buckets_after, Scratch &X) {
     if (S.done) return;
-    if (S.tri_queued) finish_triangulation(S, C, io, buckets_after);
+    if (S.tri_queued) finish_triangulation(S, C, io, buckets_after, X);
     *io.tri_count = 0;
     if (S.mode == M_INIT) {
         if (do_reset_tracking(S)) { // :184-190
@@ -1301,14 +1573,15 @@ TC_FN void stage_end_frame(Stream &S, const Cfg &C) {
         fnv(S.digest, &fid, sizeof fid);
         if (st != TRACK_PASSED) {
             u64 acc = 0, cnt = 0;
-            if (S.cur >= 0) {
+            if (S.cur >= 0) { // order-independent combination of per-feature hashes: a partial sum per lane
                 const Frame &fr = S.frame[S.cur];
-                for (int q = 0; q < fr.n_rows; q++) {
+                for (int q = lane(); q < fr.n_rows; q += NL) {
                     u64 bits;
                     memcpy(&bits, &fr.row[q].kpd, sizeof bits);
                     acc += mix64(mix64(fr.row[q].id) ^ bits);
-                    cnt++;
                 }
+                acc = wave_sum(acc);
+                cnt = (u64) fr.n_rows;
             }
             fnv(S.digest, &acc, sizeof acc);
             fnv(S.digest, &cnt, sizeof cnt);

@@ -392,6 +392,7 @@ private:
     };
     std::unique_ptr<tc::Stream, CoreFree> core_;
     tc::Cfg core_cfg_{};
+    std::unique_ptr<tc::Scratch> core_scratch_;
     bool core_dirty_{false};
     bool core_changed_{false};          // exportCore() ran: a device-resident copy of the block is stale (tracking_device.h uploads it)
     bool core_device_resident_{false};  // the authoritative block lives in HBM; core_ is a downloaded copy

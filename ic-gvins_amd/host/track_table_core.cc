@@ -73,6 +73,7 @@ void TableTracker::enableCore(bool device_resident) {
     arena_.tri_T0.resize(tc::MAX_ROWS), arena_.tri_T1.resize(tc::MAX_ROWS);
     arena_.tri_Tcw.resize(12 * tc::MAX_TCW), arena_.tri_pc0.resize(3 * tc::MAX_ROWS), arena_.tri_pc1.resize(3 * tc::MAX_ROWS), arena_.tri_pw.resize(3 * tc::MAX_ROWS);
     arena_.det_quota.resize(tc::MAX_BLOCKS), arena_.det_mask_pts.resize(tc::MAX_ROWS), arena_.det_out.resize(tc::MAX_ROWS);
+    core_scratch_.reset(new tc::Scratch);
     core_dirty_       = true;
     core_log_applied_ = 0;
 }
@@ -171,7 +172,7 @@ void TableTracker::coreAdvance(int stage, StageBatch &done, StageBatch &next) {
         break;
     case 2:
         take_detection();
-        tc::stage_on_detect_a(S, core_cfg_, io);
+        tc::stage_on_detect_a(S, core_cfg_, io, *core_scratch_);
         coreQueueOutputs(next, false, false, true, false, false);
         break;
     case 3: {
@@ -181,7 +182,7 @@ void TableTracker::coreAdvance(int stage, StageBatch &done, StageBatch &next) {
             memcpy(arena_.lk_out.data(), done.lk_out.data(), n * sizeof(tc::P2f));
             memcpy(arena_.lk_undist.data(), done.lk_undist.data(), n * sizeof(tc::P2f));
         }
-        tc::stage_on_lk(S, core_cfg_, io, ba);
+        tc::stage_on_lk(S, core_cfg_, io, ba, *core_scratch_);
         coreQueueOutputs(next, false, false, false, true, false);
         break;
     }
@@ -192,7 +193,7 @@ void TableTracker::coreAdvance(int stage, StageBatch &done, StageBatch &next) {
         break;
     case 5:
         if (!done.tri_pw.empty()) memcpy(arena_.tri_pw.data(), done.tri_pw.data(), done.tri_pw.size() * sizeof(double));
-        tc::stage_on_triangulate(S, core_cfg_, io, ba);
+        tc::stage_on_triangulate(S, core_cfg_, io, ba, *core_scratch_);
         coreQueueOutputs(next, false, true, false, false, false);
         break;
     case 6:

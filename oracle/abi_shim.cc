@@ -642,6 +642,7 @@ struct icg_tracker {
         std::vector<double> tri_Tcw, tri_pc0, tri_pc1, tri_pw;
     };
     std::vector<Arena> arena;
+    tc::Scratch scratch;
 };
 
 static tc::Io shim_io(icg_tracker::Arena &a, int lk_base) {
@@ -733,7 +734,7 @@ int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, int stride, i
             };
             tc::stage_on_preprocess(S, C, io);
             if ((rc = detect())) return rc;
-            tc::stage_on_detect_a(S, C, io);
+            tc::stage_on_detect_a(S, C, io, t->scratch);
             work[0] = a.lk_count;
             if (a.lk_count > 0) {
                 rc = icg_lk_track_fb(ctx, a.lk_count, a.lk_prev_slot.data(), a.lk_next_slot.data(), reinterpret_cast<const float *>(a.lk_prev.data()),
@@ -741,7 +742,7 @@ int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, int stride, i
                                      reinterpret_cast<float *>(a.lk_undist.data()), nullptr, nullptr);
                 if (rc) return rc;
             }
-            tc::stage_on_lk(S, C, io, t->buckets.data());
+            tc::stage_on_lk(S, C, io, t->buckets.data(), t->scratch);
             if (a.rs_count > 0) {
                 work[2]               = 1;
                 const int32_t off[2] = {0, a.rs_count};
@@ -757,7 +758,7 @@ int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, int stride, i
                                      a.tri_pw.data());
                 if (rc) return rc;
             }
-            tc::stage_on_triangulate(S, C, io, t->buckets.data());
+            tc::stage_on_triangulate(S, C, io, t->buckets.data(), t->scratch);
             if ((rc = detect())) return rc;
             tc::stage_on_detect_b(S, C, io);
             tc::stage_end_frame(S, C);
