@@ -13,10 +13,10 @@
 //                 existing features whose discs reach the tile are found by the wave itself), response (separable exact box
 //                 sums), per-ROI masked maximum by an order-preserving uint atomicMax, 3x3 NMS + mask in registers -> every local
 //                 maximum (key = response bits << 32 | raster index) appended per ROI; no response plane in HBM
-//   k_select_subpix  one workgroup of 16 waves per ROI: quality threshold 0.01*max, repeated block-wide arg-max over live candidates
-//                 + min-distance kill (equivalent to sort + greedy grid test, needs no sort and no capacity cap), then a wave per
-//                 picked corner: 13x13 bilinear patch and the 121 gradient terms in parallel through LDS, the five 121-term sums
-//                 each sequentially in raster order (IEEE order == CPU order), one lane per sum
+//   k_select      one workgroup per ROI: quality threshold 0.01*max, then repeated block-wide arg-max over live candidates +
+//                 min-distance kill (equivalent to sort + greedy grid test, needs no sort and no capacity cap)
+//   k_subpix      one wavefront per corner: 13x13 bilinear patch and the 121 gradient terms in parallel through LDS,
+//                 the five 121-term sums each sequentially in raster order (IEEE order == CPU order), one lane per sum
 #include <cfloat>
 
 #include "icg_internal.h"
@@ -236,7 +236,6 @@ __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *ro
 
 // ---------------------------------------------------------------------------------------------------------
 #define DET_MAX_PER_BLOCK 64
-#define SEL_WAVES 16 // waves per ROI workgroup: selection on all of them, then one corner per wave
 
 struct subpix_mask_t {
     float m[121];
@@ -330,28 +329,23 @@ __device__ __forceinline__ float2 subpix_corner(subpix_smem &S, const det_roi &R
     return make_float2(cIx, cIy);
 }
 
-// One workgroup of SEL_WAVES waves per ROI (round 4: k_select + k_subpix in one launch).
-//   phase 1  quality threshold 0.01 * (masked ROI maximum), then repeated block-wide arg-max over the live candidates + min-distance
-//            kill (equivalent to featureselect.cpp's sort + greedy grid test; needs no sort and no capacity cap); the picks go to LDS
-//   phase 2  wave k refines picks k, k + SEL_WAVES, ... (cornerSubPix) and writes them straight into the call's pinned staging memory
-__global__ __launch_bounds__(64 * SEL_WAVES) void k_select_subpix(const det_roi *rois, unsigned long long *cand, size_t cand_plane,
-                                                                  int32_t *cand_cnt, unsigned int *roi_max, int min_dist,
-                                                                  const uint8_t *frames, size_t slot_bytes, const int32_t *slots, int pitch,
-                                                                  float2 *corners_host /*roi x max_pb*/, int32_t *corner_cnt_host, int max_pb,
-                                                                  subpix_mask_t M) {
-    __shared__ unsigned long long wbest[SEL_WAVES];
+// k_select: one workgroup per ROI — quality threshold 0.01 * (masked ROI maximum), then repeated block-wide arg-max over the live candidates
+// + min-distance kill (equivalent to featureselect.cpp's sort + greedy grid test; needs no sort and no capacity cap).
+// k_subpix: one wave per picked corner (cornerSubPix).  (Round 4 fused the two into one 16-wave workgroup per ROI: 138 us alone on the GPU
+// against 41 + 85 us for the pair, and 949 us against 240 + 263 us with twelve groups' kernels in flight — a 1024-thread workgroup with
+// 89 KB of LDS waits for a whole CU; reverted to the pair.)
+__global__ __launch_bounds__(256) void k_select(const det_roi *rois, unsigned long long *cand, size_t cand_plane, int32_t *cand_cnt, unsigned int *roi_max,
+                                                int min_dist, float2 *picks /*roi x max_pb*/, int32_t *pick_cnt, int32_t *cnt_out, int max_pb) {
+    __shared__ unsigned long long wbest[4];
     __shared__ unsigned long long best;
-    __shared__ float2 picked[DET_MAX_PER_BLOCK];
-    __shared__ subpix_smem SP[SEL_WAVES];
-    constexpr int NT = 64 * SEL_WAVES;
     const det_roi R = rois[blockIdx.x];
+    const int t     = threadIdx.x;
     if (R.quota <= 0) { // inactive entry of a dense (job, block) table: no corner (its accumulators were never touched)
-        if (threadIdx.x == 0) corner_cnt_host[blockIdx.x] = 0;
+        if (t == 0) pick_cnt[blockIdx.x] = 0, cnt_out[blockIdx.x] = 0;
         return;
     }
     unsigned long long *C = cand + (size_t) R.job * cand_plane + R.cand_base;
     const int n = cand_cnt[blockIdx.x];
-    const int t = threadIdx.x;
     const double md2 = (double) min_dist * (double) min_dist;
     int quota = R.quota < max_pb ? R.quota : max_pb;
     int acc   = 0;
@@ -361,13 +355,13 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void k_select_subpix(const det_roi 
         const unsigned int mk = roi_max[blockIdx.x];
         const double maxVal   = mk ? (double) f32_from_order_key(mk) : 0.0;
         const float thresh    = (float) (maxVal * 0.01);
-        for (int i = t; i < n; i += NT)
+        for (int i = t; i < n; i += 256)
             if (!(f32_from_order_key((unsigned int) (C[i] >> 32)) > thresh)) C[i] = 0;
         __syncthreads();
     }
     while (acc < quota) {
         unsigned long long k = 0;
-        for (int i = t; i < n; i += NT) {
+        for (int i = t; i < n; i += 256) {
             unsigned long long c = C[i];
             k                    = c > k ? c : k;
         }
@@ -378,24 +372,20 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void k_select_subpix(const det_roi 
         }
         if ((t & 63) == 0) wbest[t >> 6] = k;
         __syncthreads();
-        if (t < 64) {
-            unsigned long long b = t < SEL_WAVES ? wbest[t] : 0ull;
-#pragma unroll
-            for (int m = SEL_WAVES / 2; m >= 1; m >>= 1) {
-                unsigned long long o = __shfl_xor(b, m, 64);
-                b                    = o > b ? o : b;
-            }
-            if (t == 0) best = b;
+        if (t == 0) {
+            unsigned long long b = wbest[0];
+            for (int i = 1; i < 4; i++) b = wbest[i] > b ? wbest[i] : b;
+            best = b;
         }
         __syncthreads();
         const unsigned long long b = best;
         if (b == 0) break; // no live candidate left
         const int idx = (int) (b & 0xffffffffu);
         const int by = idx / R.rw, bx = idx - by * R.rw;
-        if (t == 0) picked[acc] = make_float2((float) bx, (float) by);
+        if (t == 0) picks[(size_t) blockIdx.x * max_pb + acc] = make_float2((float) bx, (float) by);
         acc++;
         if (min_dist >= 1) {
-            for (int i = t; i < n; i += NT) {
+            for (int i = t; i < n; i += 256) {
                 unsigned long long c = C[i];
                 if (!c) continue;
                 int ci = (int) (c & 0xffffffffu);
@@ -404,25 +394,30 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void k_select_subpix(const det_roi 
                 if (c == b || (double) (dx * dx + dy * dy) < md2) C[i] = 0;
             }
         } else {
-            for (int i = t; i < n; i += NT)
+            for (int i = t; i < n; i += 256)
                 if (C[i] == b) C[i] = 0;
         }
         __syncthreads();
     }
     if (t == 0) {
-        corner_cnt_host[blockIdx.x] = acc; // the caller's copy, written straight into its pinned staging memory (no D2H launch)
+        pick_cnt[blockIdx.x] = acc; // device copy: read by every k_subpix workgroup of the ROI
+        cnt_out[blockIdx.x]  = acc; // the caller's copy (pinned staging memory of the call, or the tracker's arena)
         // the ROI's accumulators are consumed (every thread read them before the first barrier above): leave them zero for the next call,
         // which then needs neither a memset nor an upload of zeros
         roi_max[blockIdx.x]  = 0;
         cand_cnt[blockIdx.x] = 0;
     }
-    __syncthreads(); // picked[] complete (also after the break: every thread leaves the loop in the same round)
-    const int wv = t >> 6, lane = t & 63;
+}
+
+__global__ __launch_bounds__(64) void k_subpix(const det_roi *rois, const uint8_t *frames, size_t slot_bytes, const int32_t *slots, int pitch,
+                                               const float2 *picks, float2 *corners_out, const int32_t *pick_cnt, int max_pb, subpix_mask_t M) {
+    __shared__ subpix_smem SP;
+    const int roi = blockIdx.x / max_pb, ci = blockIdx.x - roi * max_pb;
+    if (ci >= pick_cnt[roi]) return;
+    const det_roi R    = rois[roi];
     const uint8_t *img = frames + (size_t) slots[R.job] * slot_bytes;
-    for (int ci = wv; ci < acc; ci += SEL_WAVES) {
-        const float2 r = subpix_corner(SP[wv], R, img, pitch, picked[ci], lane, M);
-        if (lane == 0) corners_host[(size_t) blockIdx.x * max_pb + ci] = r; // pinned staging memory of the call (zero-copy result)
-    }
+    const float2 r     = subpix_corner(SP, R, img, pitch, picks[(size_t) roi * max_pb + ci], (int) threadIdx.x, M);
+    if (threadIdx.x == 0) corners_out[(size_t) roi * max_pb + ci] = r;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------
@@ -570,7 +565,10 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     if ((rc = c.seal())) return rc;
     std::vector<float> h_corners((size_t) n_roi * max_pb * 2);
     std::vector<int32_t> h_cnt((size_t) n_roi);
-    // the refined corners and the counts are written by the kernel into the staging memory directly
+    // the picks and their counts are re-read by k_subpix: device scratch; the refined corners and the counts the caller needs are written
+    // by the kernels into the staging memory directly
+    float2 *d_picks = (float2 *) c.out((float *) nullptr, (size_t) n_roi * max_pb * 2);
+    int32_t *d_pcnt = c.out((int32_t *) nullptr, (size_t) n_roi);
     float2 *z_corners  = (float2 *) c.out_zc(h_corners.data(), (size_t) n_roi * max_pb * 2);
     int32_t *z_cnt     = c.out_zc(h_cnt.data(), (size_t) n_roi);
 
@@ -584,10 +582,15 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
                            gx, gy, gx * gy * n_roi, icg_div_magic(gx * gy), icg_div_magic(gx));
     }
     {
+        icg_prof_scope ps(ctx, "detect_select");
+        hipLaunchKernelGGL(k_select, dim3(n_roi), dim3(256), 0, ctx->stream, d_rois, ctx->d_cand, cand_plane, d_ccnt, d_rmax, grid->min_dist, d_picks, d_pcnt,
+                           z_cnt, max_pb);
+    }
+    {
         const subpix_mask_t M = subpix_window();
-        icg_prof_scope ps(ctx, "detect_select_subpix");
-        hipLaunchKernelGGL(k_select_subpix, dim3(n_roi), dim3(64 * SEL_WAVES), 0, ctx->stream, d_rois, ctx->d_cand, cand_plane, d_ccnt, d_rmax,
-                           grid->min_dist, ctx->d_frames, ctx->slot_bytes, d_slots, pitch, z_corners, z_cnt, max_pb, M);
+        icg_prof_scope ps(ctx, "detect_subpix");
+        hipLaunchKernelGGL(k_subpix, dim3(n_roi * max_pb), dim3(64), 0, ctx->stream, d_rois, ctx->d_frames, ctx->slot_bytes, d_slots, pitch,
+                           (const float2 *) d_picks, z_corners, (const int32_t *) d_pcnt, max_pb, M);
     }
     ICG_HIP(ctx, hipGetLastError());
     if ((rc = c.finish())) return rc;
@@ -620,7 +623,8 @@ int icg_detect_circle_rows(int radius, std::vector<int32_t> &vh) {
 }
 
 int icg_detect_launch_ind(icg_ctx *ctx, int n_jobs, const icg_detect_grid *grid, const void *d_rois, const int32_t *d_slots, const float2 *d_mask_pts,
-                          const int32_t *d_mask_begin, const int32_t *d_mask_cnt, const int32_t *d_vh, float2 *d_corners, int32_t *d_corner_cnt) {
+                          const int32_t *d_mask_begin, const int32_t *d_mask_cnt, const int32_t *d_vh, float2 *d_picks, int32_t *d_pick_cnt,
+                          float2 *d_corners, int32_t *d_corner_cnt) {
     const int w = ctx->cfg.width, h = ctx->cfg.height, pitch = ctx->lv[0].pitch;
     const int nblk = grid->block_cols * grid->block_rows, n_roi = n_jobs * nblk;
     if (n_jobs > ctx->cfg.max_batch) return icg_fail(ctx, ICG_ERR_CAPACITY, "detect batch %d > max_batch %d", n_jobs, ctx->cfg.max_batch);
@@ -637,11 +641,15 @@ int icg_detect_launch_ind(icg_ctx *ctx, int n_jobs, const icg_detect_grid *grid,
                            cand_plane, ctx->d_cand_cnt, gx, gy, gx * gy * n_roi, icg_div_magic(gx * gy), icg_div_magic(gx));
     }
     {
+        icg_prof_scope ps(ctx, "detect_select");
+        hipLaunchKernelGGL(k_select, dim3(n_roi), dim3(256), 0, ctx->stream, (const det_roi *) d_rois, ctx->d_cand, cand_plane, ctx->d_cand_cnt, ctx->d_roi_max,
+                           grid->min_dist, d_picks, d_pick_cnt, d_corner_cnt, grid->max_per_block);
+    }
+    {
         const subpix_mask_t M = subpix_window();
-        icg_prof_scope ps(ctx, "detect_select_subpix");
-        hipLaunchKernelGGL(k_select_subpix, dim3(n_roi), dim3(64 * SEL_WAVES), 0, ctx->stream, (const det_roi *) d_rois, ctx->d_cand, cand_plane,
-                           ctx->d_cand_cnt, ctx->d_roi_max, grid->min_dist, ctx->d_frames, ctx->slot_bytes, d_slots, pitch, d_corners, d_corner_cnt,
-                           grid->max_per_block, M);
+        icg_prof_scope ps(ctx, "detect_subpix");
+        hipLaunchKernelGGL(k_subpix, dim3(n_roi * grid->max_per_block), dim3(64), 0, ctx->stream, (const det_roi *) d_rois, ctx->d_frames, ctx->slot_bytes,
+                           d_slots, pitch, (const float2 *) d_picks, d_corners, (const int32_t *) d_pick_cnt, grid->max_per_block, M);
     }
     ICG_HIP(ctx, hipGetLastError());
     return ICG_OK;

@@ -309,4 +309,5 @@ int icg_triangulate_launch_segments(icg_ctx *ctx, int n_seg, int seg_cap, const 
                                     const double *d_Tcw, const double *d_pc0, const double *d_pc1, double *d_pw);
 int icg_detect_circle_rows(int radius, std::vector<int32_t> &vh); // vh[a] = rows of a disc column at distance a (detect.hip); -1 on failure
 int icg_detect_launch_ind(icg_ctx *ctx, int n_jobs, const icg_detect_grid *grid, const void *d_rois, const int32_t *d_slots, const float2 *d_mask_pts,
-                          const int32_t *d_mask_begin, const int32_t *d_mask_cnt, const int32_t *d_vh, float2 *d_corners, int32_t *d_corner_cnt);
+                          const int32_t *d_mask_begin, const int32_t *d_mask_cnt, const int32_t *d_vh, float2 *d_picks, int32_t *d_pick_cnt,
+                          float2 *d_corners, int32_t *d_corner_cnt);

@@ -26,6 +26,8 @@
 // container's node list, the hash-table insertions that give a new frame its iteration order, the order-dependent float sums — runs
 // through LDS (tc::Scratch) and is executed redundantly by all lanes in lockstep (track_core.h "execution model").
 #include <algorithm>
+#include <chrono>
+#include <ctime>
 #include <mutex>
 
 #include "icg_internal.h"
@@ -63,6 +65,8 @@ struct TrkArena {
     det_roi *rois;        // [n x block_cnts]
     float2 *corners;      // [n x block_cnts x max_block_features]
     int32_t *corner_cnt;  // [n x block_cnts]
+    float2 *picks;        // [n x block_cnts x max_block_features] integer corners between k_select and k_subpix
+    int32_t *pick_cnt;    // [n x block_cnts]
 };
 
 __device__ __forceinline__ tc::Io io_of(const TrkArena &A, const tc::Cfg &C, int s) {
@@ -254,7 +258,9 @@ struct icg_tracker {
     TrkInput *h_in             = nullptr; // pinned, GPU-addressable
     icg_tracker_result *h_res  = nullptr; // pinned, written by k_trk_stage 6
     bool need_detect_a         = true;    // some stream starts its next frame with a detection
-    hipEvent_t ev_done         = nullptr; // blocking-sync event of the step's single wait (nullptr: the context's wait mode)
+    hipEvent_t ev_done         = nullptr; // wait_mode 2
+    int wait_mode              = 0;       // 0 adaptive (sleep + query), 1 the context's wait mode, 2 blocking event; ICG_TRACKER_WAIT=adaptive|ctx|block
+    double step_us_ema         = 0;       // running estimate of a step's issue-to-completion time
 };
 
 extern "C" size_t icg_tracker_block_bytes(void) { return sizeof(tc::Stream); }
@@ -336,7 +342,7 @@ extern "C" int icg_tracker_create(icg_ctx *ctx, int n_streams, const icg_tracker
     want(&A.det_slot, n), want(&A.det_quota, n * tc::MAX_BLOCKS), want(&A.det_mask_begin, n), want(&A.det_mask_count, n), want(&A.det_count, n);
     want(&A.det_mask_pts, n * R), want(&A.det_out, n * R);
     want(&A.work, 4 * n);
-    want(&A.rois, n * nblk), want(&A.corners, n * nblk * mpb), want(&A.corner_cnt, n * nblk);
+    want(&A.rois, n * nblk), want(&A.corners, n * nblk * mpb), want(&A.corner_cnt, n * nblk), want(&A.picks, n * nblk * mpb), want(&A.pick_cnt, n * nblk);
     if (icg_hip_check(ctx, hipMalloc((void **) &t->d_arena, off), "hipMalloc tracker arenas")) return fail(ICG_ERR_NOMEM);
     if (icg_hip_check(ctx, hipMemsetAsync(t->d_arena, 0, off, ctx->stream), "memset arenas")) return fail(ICG_ERR_HIP);
     for (auto &pc : pieces) *pc.p = t->d_arena + pc.at;
@@ -345,7 +351,8 @@ extern "C" int icg_tracker_create(icg_ctx *ctx, int n_streams, const icg_tracker
         return fail(ICG_ERR_NOMEM);
     {
         const char *wm = getenv("ICG_TRACKER_WAIT");
-        if (!wm || wm[0] == 'b')
+        t->wait_mode   = !wm ? 0 : wm[0] == 'b' ? 2 : wm[0] == 'c' ? 1 : 0;
+        if (t->wait_mode == 2)
             if (icg_hip_check(ctx, hipEventCreateWithFlags(&t->ev_done, hipEventBlockingSync | hipEventDisableTiming), "hipEventCreate")) return fail(ICG_ERR_HIP);
     }
     memset(t->h_in, 0, sizeof(TrkInput) * n);
@@ -387,7 +394,7 @@ extern "C" int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, in
     if ((rc = launch_stage(t, fused_begin ? 120 : 0, fused_begin ? "trk_stage_predict" : "trk_begin"))) return rc;
     if ((rc = icg_preprocess_launch_ind(ctx, n, A.pre_slot, images, stride, channels, images_on_device, t->cfg.check_histogram ? A.pre_hist : nullptr))) return rc;
     auto detect = [&]() {
-        return icg_detect_launch_ind(ctx, n, &t->grid, A.rois, A.det_slot, A.det_mask_pts, A.det_mask_begin, A.det_mask_count, t->d_vh, A.corners, A.corner_cnt);
+        return icg_detect_launch_ind(ctx, n, &t->grid, A.rois, A.det_slot, A.det_mask_pts, A.det_mask_begin, A.det_mask_count, t->d_vh, A.picks, A.pick_cnt, A.corners, A.corner_cnt);
     };
     if (t->need_detect_a) {
         if ((rc = launch_stage(t, 1, "trk_stage_pre"))) return rc;
@@ -408,11 +415,30 @@ extern "C" int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, in
     if ((rc = launch_stage(t, 6, "trk_stage_end"))) return rc;
     // ONE wait per step.  Default: block on an interrupt-driven event (the group's thread sleeps for the ~10 ms the chain takes instead of
     // polling the stream every 100 us); ICG_TRACKER_WAIT=poll|spin selects the context's wait mode instead
-    if (t->ev_done) {
+    if (t->wait_mode == 2) { // "block": an event with hipEventBlockingSync (measured on ROCm 7.2: the runtime still spins — 9.5 cores busy with 12 groups)
         ICG_HIP(ctx, hipEventRecord(t->ev_done, ctx->stream));
         ICG_HIP(ctx, hipEventSynchronize(t->ev_done));
-    } else if ((rc = icg_stream_wait(ctx))) {
-        return rc;
+    } else if (t->wait_mode == 1) { // the context's wait mode (spin, or query + sleep every poll interval)
+        if ((rc = icg_stream_wait(ctx))) return rc;
+    } else {
+        // default, "adaptive": the chain of a step takes milliseconds and about as long as the last one did — sleep through most of it
+        // (85 % of the running estimate), then query the stream every 100 us.  A group's thread wakes ~10 times per step instead of ~100.
+        const auto t_issue = std::chrono::steady_clock::now();
+        if (t->step_us_ema > 400.0) {
+            struct timespec ts;
+            const long ns = (long) (850.0 * t->step_us_ema);
+            ts.tv_sec = ns / 1000000000L, ts.tv_nsec = ns % 1000000000L;
+            nanosleep(&ts, nullptr);
+        }
+        for (;;) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return icg_hip_check(ctx, q, "hipStreamQuery");
+            struct timespec ts = {0, 100000L};
+            nanosleep(&ts, nullptr);
+        }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_issue).count();
+        t->step_us_ema  = t->step_us_ema > 0 ? 0.8 * t->step_us_ema + 0.2 * us : us;
     }
     icg_prof_collect(ctx);
     bool need = false;
