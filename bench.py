@@ -571,14 +571,14 @@ def main():
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the HIP-event pass (used under rocprofv3 --pmc)")
     ap.add_argument("--no-parity", action="store_true", help="diagnostic sweeps only: skip the parity witness (the line then carries parity: null "
                                                               "and says so; the driver's command never uses this)")
-    ap.add_argument("--engine", default=os.environ.get("ICG_TRACK_ENGINE", "table"), choices=["table", "object", "core", "device"],
+    ap.add_argument("--engine", default=os.environ.get("ICG_TRACK_ENGINE", "auto"), choices=["auto", "table", "object", "core", "device"],
                     help="tracker engine of the host executor: device = the device-resident tracker (state in HBM, one launch chain + one wait per "
-                         "step); table = the host track table between batched device calls (rounds 1-3)")
+                         "step); table = the host track table between batched device calls (rounds 1-3); auto (default) = by the rank's share of "
+                         "the host cores (sharding.host_plan: table with >= 4 cores per GPU, device below)")
     ap.add_argument("--details", default=os.environ.get("ICG_BENCH_DETAILS", ""),
                     help="file for the long per-group / per-step series and notes (default gpurun_out/bench_details.json); the contract line stays compact")
     args = ap.parse_args()
 
-    os.environ["ICG_TRACK_ENGINE"] = args.engine
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -619,8 +619,10 @@ def main():
     # host resources of this rank: its share of the usable cores sizes the number of polling group threads, and with several ranks on
     # the node every rank pins itself to its own contiguous slice of the allowed CPUs (ranks do not migrate over each other's caches)
     plan = sharding.host_plan(usable_host_cores(), world, local_rank, cpu_ids=(os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None),
-                              groups_override=args.groups, streams_override=args.streams)
+                              groups_override=args.groups, streams_override=args.streams, engine_override=(None if args.engine == "auto" else args.engine))
     cores_rank, G, B = plan["cores_rank"], plan["groups"], plan["streams"]
+    args.engine = plan["engine"]
+    os.environ["ICG_TRACK_ENGINE"] = args.engine
     if plan["cpu_slice"] and not os.environ.get("ICG_BENCH_NO_PIN"):
         try:
             os.sched_setaffinity(0, plan["cpu_slice"])

@@ -811,3 +811,44 @@ int icg_triangulate_launch_segments(icg_ctx *ctx, int n_seg, int seg_cap, const 
     ICG_HIP(ctx, hipGetLastError());
     return ICG_OK;
 }
+
+// The same result as icg_fm_ransac with ONE launch and ONE wait (no host round per RANSAC chunk): the whole run of every set inside the
+// workgroup that owns it (k_fm_ransac_sets).  Sets of more than 64 * FMS_MAX_WORDS points fall back to icg_fm_ransac.
+extern "C" int icg_fm_ransac_device(icg_ctx *ctx, int n_sets, const int32_t *offsets, const float *pts1, const float *pts2, double thresh, double conf,
+                                    uint8_t *mask) {
+    if (!ctx || n_sets < 0) return ICG_ERR_INVALID;
+    if (n_sets == 0) return ICG_OK;
+    if (!offsets || !pts1 || !pts2 || !mask) return ICG_ERR_INVALID;
+    int seg_cap = 1;
+    for (int s = 0; s < n_sets; s++) {
+        const int n = offsets[s + 1] - offsets[s];
+        if (n < 0) return ICG_ERR_INVALID;
+        seg_cap = std::max(seg_cap, n);
+    }
+    if (seg_cap > 64 * FMS_MAX_WORDS) return icg_fm_ransac(ctx, n_sets, offsets, pts1, pts2, thresh, conf, mask);
+    seg_cap = (seg_cap + 63) & ~63;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t cells = (size_t) n_sets * seg_cap;
+    std::vector<float> a(2 * cells, 0.f), b(2 * cells, 0.f);
+    std::vector<int32_t> cnt((size_t) n_sets);
+    for (int s = 0; s < n_sets; s++) {
+        const int n = offsets[s + 1] - offsets[s];
+        cnt[(size_t) s] = n;
+        memcpy(a.data() + 2 * (size_t) s * seg_cap, pts1 + 2 * (size_t) offsets[s], sizeof(float) * 2 * (size_t) n);
+        memcpy(b.data() + 2 * (size_t) s * seg_cap, pts2 + 2 * (size_t) offsets[s], sizeof(float) * 2 * (size_t) n);
+    }
+    std::vector<uint8_t> m(cells, 0);
+    icg_call c(ctx);
+    int rc = c.reserve(cells * (16 + 1) + sizeof(int32_t) * (size_t) n_sets + 4096);
+    if (rc) return rc;
+    const float2 *d_p1 = (const float2 *) c.in(a.data(), 2 * cells);
+    const float2 *d_p2 = (const float2 *) c.in(b.data(), 2 * cells);
+    const int32_t *d_n = c.in(cnt.data(), (size_t) n_sets);
+    if ((rc = c.seal())) return rc;
+    uint8_t *d_m = c.out(m.data(), cells);
+    ICG_LAUNCH_GUARD(c);
+    if ((rc = icg_fm_ransac_launch_sets(ctx, n_sets, seg_cap, d_n, d_p1, d_p2, thresh, conf, d_m))) return rc;
+    if ((rc = c.finish())) return rc;
+    for (int s = 0; s < n_sets; s++) memcpy(mask + offsets[s], m.data() + (size_t) s * seg_cap, (size_t) cnt[(size_t) s]);
+    return ICG_OK;
+}

@@ -156,10 +156,16 @@ __device__ void begin_frame(int s, tc::Stream *streams, const TrkArena &A, const
 
 // stage: 0 (new frame), 1, 2, 12 (1 then 2 in one launch: no stream queued a detection), 120 (0 then 12: additionally no histogram gate, so
 // nothing of the preprocessing is needed before the prediction), 3, 4, 5, 6 (+ end of frame + results)
-__global__ __launch_bounds__(64) void k_trk_stage(int stage, int n, tc::Stream *streams, TrkArena A, tc::Cfg C, const uint32_t *buckets_after,
-                                                  icg_tracker_result *results, const TrkInput *in) {
-    __shared__ tc::Scratch X;
-    const int s = blockIdx.x;
+// TRK_WAVES streams per workgroup (a wave each, no workgroup barrier).  Measured (profiles/r04_device_tracker.md): 8 per workgroup — tried to
+// keep the ~115 KB of stage code off most CUs' instruction caches — is SLOWER than one (12 x 64: 74.3 k vs 84.8 k frames/s; 2 confined CPUs
+// 63.9 k vs 72.9 k): the stage bodies are latency chains, and eight of them sharing one CU's LDS and memory pipeline lengthen every chain.
+#define TRK_WAVES 1
+__global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, tc::Stream *streams, TrkArena A, tc::Cfg C, const uint32_t *buckets_after,
+                                                              icg_tracker_result *results, const TrkInput *in) {
+    __shared__ tc::Scratch XS[TRK_WAVES];
+    const int wave = (int) (threadIdx.x >> 6);
+    tc::Scratch &X = XS[wave];
+    const int s = blockIdx.x * TRK_WAVES + wave;
     if (s >= n) return; // all 64 lanes run the stage body (track_core.h "execution model"): redundantly where it is sequential
     tc::Stream &S = streams[s];
     if (stage == 0 || stage == 120) {
@@ -367,7 +373,7 @@ extern "C" int icg_tracker_create(icg_ctx *ctx, int n_streams, const icg_tracker
 static int launch_stage(icg_tracker *t, int stage, const char *name) {
     icg_ctx *ctx = t->ctx;
     icg_prof_scope ps(ctx, name);
-    hipLaunchKernelGGL(k_trk_stage, dim3(t->n), dim3(64), 0, ctx->stream, stage, t->n, t->d_streams, t->A, t->cfg, (const uint32_t *) t->d_buckets, t->h_res,
+    hipLaunchKernelGGL(k_trk_stage, dim3((t->n + TRK_WAVES - 1) / TRK_WAVES), dim3(64 * TRK_WAVES), 0, ctx->stream, stage, t->n, t->d_streams, t->A, t->cfg, (const uint32_t *) t->d_buckets, t->h_res,
                        (const TrkInput *) t->h_in);
     ICG_HIP(ctx, hipGetLastError());
     return ICG_OK;

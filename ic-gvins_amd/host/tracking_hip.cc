@@ -161,8 +161,15 @@ void DeviceContext::execute(StageBatch &b, const icg_detect_grid &grid, int max_
         hostprof::Scope hp(hostprof::DEV_RANSAC);
         int n = (int) b.rs_off.size() - 1;
         b.rs_mask.assign((size_t) b.rs_off.back(), 1);
-        abi_check(ctx_, icg_fm_ransac(ctx_, n, b.rs_off.data(), b.rs_p1.data(), b.rs_p2.data(), b.rs_thresh, b.rs_conf, b.rs_mask.data()),
-                  "icg_fm_ransac");
+        // ICG_RANSAC_DEVICE_LOOP=1: the one-launch form (every set's whole run inside its workgroup, the kernel of the device-resident
+        // tracker) instead of one launch + one wait per RANSAC chunk; identical masks (tests/test_gpu_geometry.py)
+        static const bool device_loop = getenv("ICG_RANSAC_DEVICE_LOOP") && getenv("ICG_RANSAC_DEVICE_LOOP")[0] == '1';
+        if (device_loop)
+            abi_check(ctx_, icg_fm_ransac_device(ctx_, n, b.rs_off.data(), b.rs_p1.data(), b.rs_p2.data(), b.rs_thresh, b.rs_conf, b.rs_mask.data()),
+                      "icg_fm_ransac_device");
+        else
+            abi_check(ctx_, icg_fm_ransac(ctx_, n, b.rs_off.data(), b.rs_p1.data(), b.rs_p2.data(), b.rs_thresh, b.rs_conf, b.rs_mask.data()),
+                      "icg_fm_ransac");
     }
     if (!b.tri_T0.empty()) {
         hostprof::Scope hp(hostprof::DEV_TRIANGULATE);

@@ -16,7 +16,7 @@ EXPORTS = [
     "icg_version", "icg_pyramid_levels", "icg_prof_enable", "icg_prof_get", "icg_prof_names", "icg_dev_alloc",
     "icg_dev_free", "icg_dev_upload", "icg_dev_download", "icg_frames_preprocess", "icg_frame_download",
     "icg_lk_track", "icg_lk_track_fb", "icg_lk_track_fb_reuse", "icg_lk_reuse_stats", "icg_undistort_points", "icg_distort_points", "icg_predict_mappoints",
-    "icg_predict_rotation", "icg_fm_ransac", "icg_detect", "icg_triangulate", "icg_reproj_eval_batch",
+    "icg_predict_rotation", "icg_fm_ransac", "icg_fm_ransac_device", "icg_detect", "icg_triangulate", "icg_reproj_eval_batch",
     "icg_reproj_set_factors", "icg_reproj_eval_resident", "icg_reproj_accumulate_normal", "icg_preint_batch",
     "icg_ins_mechanize_batch", "icg_ins_camera_pose_batch", "icg_reproj_schur", "icg_reproj_backsub", "icg_reproj_cost", "icg_reproj_landmark_diag",
     "icg_reproj_error_batch", "icg_reproj_set_windows", "icg_reproj_eval_windows", "icg_reproj_schur_windows",
@@ -254,6 +254,16 @@ class Context:
         mask = np.ones(pts1.shape[0], np.uint8)
         self._ck(self.lib.icg_fm_ransac(self.h, len(offsets) - 1, _p(offsets), _p(pts1), _p(pts2), C.c_double(thresh),
                                          C.c_double(conf), _p(mask)), "icg_fm_ransac")
+        return mask
+
+    def fm_ransac_device(self, offsets, pts1, pts2, thresh=1.5, conf=0.99):
+        """icg_fm_ransac_device: the whole RANSAC run of every set in one launch (the kernel the device-resident tracker uses)"""
+        offsets = _i32(offsets)
+        pts1 = _f32(pts1).reshape(-1, 2)
+        pts2 = _f32(pts2).reshape(-1, 2)
+        mask = np.ones(pts1.shape[0], np.uint8)
+        self._ck(self.lib.icg_fm_ransac_device(self.h, len(offsets) - 1, _p(offsets), _p(pts1), _p(pts2), C.c_double(thresh),
+                                                C.c_double(conf), _p(mask)), "icg_fm_ransac_device")
         return mask
 
     # ---- F7

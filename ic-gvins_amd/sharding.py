@@ -28,7 +28,7 @@ def terminal_exchange(dist, device, counters, elapsed, digests):
 STREAMS_PER_GPU = 768  # fixed work per GPU whatever the world size: "scaling": "weak" means exactly this
 
 
-def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, streams_override=0):
+def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, streams_override=0, engine_override=None):
     """Host resources of one rank (one rank's polling threads must not assume the whole box):
       cores_rank   the rank's share of the usable host cores
       streams      768 camera streams per GPU, the same for every world size (weak scaling: per-GPU work is fixed)
@@ -40,7 +40,16 @@ def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, 
       cpu_slice    the contiguous slice of the allowed CPU ids this rank pins itself to (None for a single rank: nothing to separate)
     """
     cores_rank = float(usable_cores) / float(max(1, world))
-    groups = int(groups_override) if groups_override > 0 else int(max(4, min(12, 4 * round(cores_rank))))
+    # engine (round 4): with >= 4 host cores per GPU the track table on the host (host logic of one group overlaps the other groups' kernels for
+    # free: 100-110 k frames/s per GPU, 4.4 cores busy); with fewer, the device-resident tracker (state in HBM, one launch chain + one wait
+    # per step: 85 k frames/s per GPU with 1.3 cores busy, 76 k with every thread confined to 2 CPUs where the table engine reaches 43 k) —
+    # profiles/r04_cpu_quota.md.  Same results either way (tests/test_gpu_device_tracker.py).
+    engine = engine_override or ("table" if cores_rank >= 4.0 else "device")
+    if engine == "device":
+        # wide launches: the stage kernels cost the same whatever the number of streams (a wave per stream)
+        groups = int(groups_override) if groups_override > 0 else 4  # 4 x 192: 72.9 k on 2 confined CPUs (8 x 96: 71.6 k, 12 x 64: 69.1 k, 6 x 128: 64.0 k)
+    else:
+        groups = int(groups_override) if groups_override > 0 else int(max(4, min(12, 4 * round(cores_rank))))
     streams = int(streams_override) if streams_override > 0 else STREAMS_PER_GPU
     groups = max(1, min(groups, streams))
     cpu_slice = None
@@ -48,4 +57,4 @@ def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, 
         ids = sorted(cpu_ids)
         per = max(1, len(ids) // world)
         cpu_slice = ids[local_rank * per:(local_rank + 1) * per] or ids
-    return {"cores_rank": cores_rank, "groups": groups, "streams": streams, "cpu_slice": cpu_slice}
+    return {"cores_rank": cores_rank, "groups": groups, "streams": streams, "cpu_slice": cpu_slice, "engine": engine}

@@ -141,6 +141,11 @@ int icg_predict_rotation(icg_ctx *ctx, int n, const float *pts_in, const int32_t
  * points are left untouched (mask = 1), as the reference skips them.  mask: 0/1 per point. */
 int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, const float *pts1, const float *pts2,
                   double thresh, double conf, uint8_t *mask);
+/* the same masks from ONE launch: every set's whole RANSAC run — subset draws from the set's cv::RNG, seven-point solves, scoring, the
+ * best / niters recurrence of RANSACPointSetRegistrator::run — inside the workgroup that owns the set (csrc/ransac.hip k_fm_ransac_sets);
+ * the device-resident tracker runs the same kernel on its segments.  Sets of more than 1024 points go through icg_fm_ransac. */
+int icg_fm_ransac_device(icg_ctx *ctx, int n_sets, const int32_t *offsets, const float *pts1, const float *pts2, double thresh,
+                         double conf, uint8_t *mask);
 
 /* ---- F7: Tracking::featuresDetection (tracking.cc:576-688) ----------------------------------------------
  * Gridded cv::goodFeaturesToTrack(quality 0.01, minDistance, mask) + cv::cornerSubPix((5,5),(-1,-1),(20,0.01))

@@ -220,6 +220,11 @@ int icg_fm_ransac(icg_ctx *ctx, int n_sets, const int32_t *offsets, const float 
     return ICG_OK;
 }
 
+int icg_fm_ransac_device(icg_ctx *ctx, int n_sets, const int32_t *offsets, const float *pts1, const float *pts2, double thresh, double conf,
+                         uint8_t *mask) {
+    return icg_fm_ransac(ctx, n_sets, offsets, pts1, pts2, thresh, conf, mask);
+}
+
 int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_detect_grid *grid, const int32_t *mask_off,
                const float *mask_pts, const int32_t *quota, int max_per_job, float *out_pts, int32_t *out_count,
                int32_t *out_block) {

@@ -107,6 +107,36 @@ def test_fm_ransac_degenerate_all_identical(oracle, ctx1280):
     assert np.array_equal(mask, exp)
 
 
+def test_fm_ransac_device_loop_equals_host_loop_and_oracle(oracle, ctx1280):
+    """icg_fm_ransac_device (k_fm_ransac_sets: subset draws from cv::RNG, seven-point solves, scoring and the best / niters recurrence of a
+    whole RANSAC run inside one workgroup — the kernel the device-resident tracker launches on its segments) against the host-looped entry
+    point and the oracle: identical inlier masks for clean and contaminated sets, many rounds (60 % outliers: niters stays in the hundreds),
+    sets below 15 points (left untouched), the degenerate all-identical set and a collinear lattice (checkSubset's RNG-consuming redraws);
+    the iteration counts come from log / pow values tabulated by the host's libm (fm_denom_table)."""
+    sets = []
+    for seed, n, frac in ((11, 200, 0.25), (12, 60, 0.4), (13, 15, 0.0), (14, 10, 0.0), (15, 300, 0.6), (16, 120, 0.1), (17, 640, 0.5), (18, 33, 0.7),
+                          (19, 64, 0.0), (20, 65, 0.3)):
+        p1, p2, _, _ = two_view(n, seed=seed, outlier_frac=frac, noise=0.3)
+        sets.append((p1, p2))
+    same = np.tile(np.array([[100.0, 200.0]], np.float32), (20, 1))
+    sets.append((same, same))
+    gx, gy = np.meshgrid(np.arange(6, dtype=np.float32) * 40 + 50, np.arange(5, dtype=np.float32) * 40 + 60)
+    lat = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
+    sets.append((lat, lat + np.float32([3.0, -2.0])))
+    offsets = np.cumsum([0] + [len(s[0]) for s in sets]).astype(np.int32)
+    a, b = np.concatenate([s[0] for s in sets]), np.concatenate([s[1] for s in sets])
+    dev = ctx1280.fm_ransac_device(offsets, a, b)
+    host = ctx1280.fm_ransac(offsets, a, b)
+    assert np.array_equal(dev, host)
+    for k, (p1, p2) in enumerate(sets):
+        got = dev[offsets[k]:offsets[k + 1]]
+        if len(p1) < 15:
+            assert np.all(got == 1)
+            continue
+        ok, exp, _, iters = oracle.fm_ransac(p1, p2)
+        assert np.array_equal(got, exp), (k, iters, got.sum(), exp.sum())
+
+
 def test_triangulate_matches_oracle(oracle, ctx1280):
     _, _, _, (K, R, t, X) = two_view(300, seed=7)
     T0 = np.hstack([np.eye(3), np.zeros((3, 1))])

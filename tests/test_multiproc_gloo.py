@@ -62,24 +62,27 @@ def test_host_plan_scales_the_polling_threads_with_the_rank_share():
     assert one["groups"] == 12 and one["streams"] == 768 and one["cpu_slice"] is None
     eight = [sharding.host_plan(16, 8, r, cpu_ids=range(256)) for r in range(8)]
     # weak scaling: the streams of a GPU do not shrink with the world size; only the number of polling threads follows the rank's cores
-    assert all(p["groups"] == 8 and p["streams"] == 768 and abs(p["cores_rank"] - 2.0) < 1e-12 for p in eight)
+    # (2 cores per GPU: the device-resident tracker — the host only issues a launch chain per step — in six wide groups)
+    assert all(p["groups"] == 4 and p["engine"] == "device" and p["streams"] == 768 and abs(p["cores_rank"] - 2.0) < 1e-12 for p in eight)
+    assert one["engine"] == "table"
     slices = [set(p["cpu_slice"]) for p in eight]
     assert all(len(s_) == 32 for s_ in slices) and len(set().union(*slices)) == 256  # disjoint, covering
     big = sharding.host_plan(128, 8, 3, cpu_ids=range(128))
-    assert big["groups"] == 12 and big["streams"] == 768 and big["cpu_slice"] == list(range(48, 64))
+    assert big["groups"] == 12 and big["engine"] == "table" and big["streams"] == 768 and big["cpu_slice"] == list(range(48, 64))
     tiny = sharding.host_plan(4, 8, 0, cpu_ids=range(4))
-    assert tiny["groups"] == 4 and tiny["streams"] == 768 and tiny["cpu_slice"]
+    assert tiny["groups"] == 4 and tiny["engine"] == "device" and tiny["streams"] == 768 and tiny["cpu_slice"]
+    assert sharding.host_plan(16, 8, 0, engine_override="table")["groups"] == 8
     assert sharding.host_plan(16, 1, 0, groups_override=8, streams_override=64)["groups"] == 8
 
 
-def _run_bench_selftest(world, streams, port, details):
+def _run_bench_selftest(world, streams, port, details, engine="table"):
     """bench.py's own main() as the driver launches it (python -m torch.distributed.run ... bench.py --gpus N ...), in its CPU plumbing
     self-test mode (ICG_BENCH_SELFTEST_ORACLE=1: gloo + the oracle-backed checker build of the host layer; value is null by construction)"""
     import json
     import subprocess
     env = dict(os.environ, ICG_BENCH_SELFTEST_ORACLE="1", MASTER_ADDR="127.0.0.1")
     tiny = ["--steps", "3", "--warmup", "1", "--width", "320", "--height", "240", "--features", "60", "--streams", str(streams),
-            "--groups", "2", "--ring", "6", "--prime", "4", "--details", details]
+            "--groups", "2", "--ring", "6", "--prime", "4", "--details", details, "--engine", engine]
     bench = os.path.join(ROOT, "bench.py")
     if world == 1:
         cmd = [sys.executable, bench, "--gpus", "1"] + tiny
@@ -100,8 +103,11 @@ def test_bench_main_runs_two_ranks_as_the_driver_launches_it(tmp_path):
     from stream_utils import ensure_oracle_host
     ensure_oracle_host()
     port = 29900 + (os.getpid() % 90)
-    two = _run_bench_selftest(2, 2, port, str(tmp_path / "two.json"))
-    one = _run_bench_selftest(1, 4, port + 1, str(tmp_path / "one.json"))
+    # the two ranks on the device engine (the tracker ABI, here on the shim's CPU backend: what an 8-rank run on a 16-CPU box selects), the
+    # single rank on the track table: same four streams, same digests — placement AND engine invariance through bench.main itself
+    two = _run_bench_selftest(2, 2, port, str(tmp_path / "two.json"), engine="device")
+    one = _run_bench_selftest(1, 4, port + 1, str(tmp_path / "one.json"), engine="table")
+    assert "device-resident" in two["config"]["engine"] and "track table" in one["config"]["engine"]
     for line, n in ((two, 2), (one, 1)):
         assert line["value"] is None and "selftest" in line  # never a measurement
         assert line["n_gpus"] == n and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
