@@ -486,3 +486,21 @@ extern "C" int icg_tracker_reset_log(icg_tracker *t, int stream) {
     ICG_HIP(ctx, hipGetLastError());
     return ICG_OK;
 }
+
+extern "C" int icg_tracker_fetch_logs(icg_tracker *t, int n_req, const int32_t *streams, const int32_t *counts, void *out, int entry_stride) {
+    if (!t || n_req < 0 || (n_req > 0 && (!streams || !counts || !out)) || entry_stride < 0) return ICG_ERR_INVALID;
+    if (n_req == 0) return ICG_OK;
+    icg_ctx *ctx = t->ctx;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    for (int k = 0; k < n_req; k++) {
+        const int s = streams[k], n = counts[k];
+        if (s < 0 || s >= t->n || n < 0 || n > tc::LOG_CAP || n > entry_stride) return icg_fail(ctx, ICG_ERR_INVALID, "icg_tracker_fetch_logs: bad request %d", k);
+        if (n > 0)
+            ICG_HIP(ctx, hipMemcpyAsync((char *) out + sizeof(tc::LmLog) * (size_t) k * entry_stride, (const char *) (t->d_streams + s) + offsetof(tc::Stream, log),
+                                        sizeof(tc::LmLog) * (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+        hipLaunchKernelGGL(k_trk_reset_log, dim3(1), dim3(1), 0, ctx->stream, t->d_streams + s);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ICG_OK;
+}

@@ -69,7 +69,7 @@ constexpr int MAX_MPS     = 8192;  // map-point pool (live landmarks of the wind
 constexpr int MAX_WINDOW  = 18;    // keyframes in the map (window size + 1, rounded up)
 constexpr int MAX_BLOCKS  = 64;    // detection grid blocks (C4: 50)
 constexpr int MAX_TCW     = 12;    // distinct camera matrices of one triangulation call (current + reference frames of the candidates)
-constexpr int LOG_CAP     = 4096;  // landmark insert / erase log between two host drains
+constexpr int LOG_CAP     = 8192;  // landmark insert / erase log between two host drains
 constexpr int MAX_SLOTS   = 4;     // frame slots a stream owns on the device (pre / cur / ref / incoming)
 
 // per-wave scratch (LDS on the device, a heap block on the host): the linked lists and hash buckets of the frame a stage is working on,

@@ -122,6 +122,18 @@ public:
         core_changed_ = false;
         return c;
     }
+    // entries [0, n) of the device's landmark history, fetched without the block (icg_tracker_fetch_logs): replayed into map_lm_ from where
+    // this copy had got to; the device's history restarts at 0
+    void coreApplyFetchedLog(const tc::LmLog *log, int n) {
+        for (int k = core_log_applied_; k < n; k++) {
+            if (log[k].op)
+                map_lm_.insert(std::make_pair((ulong) log[k].id, log[k].mp));
+            else
+                map_lm_.erase((ulong) log[k].id);
+        }
+        core_log_applied_ = 0;
+        if (core_) core_->n_log = 0;
+    }
     void coreLogRestarted() {
         core_->n_log      = 0;
         core_log_applied_ = 0;

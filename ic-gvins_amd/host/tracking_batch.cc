@@ -120,12 +120,22 @@ void TrackingBatch::stepDevice(const FrameInput *frames, vector<TrackState> &sta
         s.last_state = (TrackState) r.state, s.frames = r.frames, s.keyframes = r.keyframes, s.tracked_sum = r.tracked_sum, s.digest = r.digest;
         s.ids->frame_id = r.frame_id, s.ids->keyframe_id = r.keyframe_id, s.ids->mappoint_id = r.mappoint_id;
         lk += (uint64_t) r.lk_points, det += (uint64_t) r.detect_jobs, rs += (uint64_t) r.ransac_sets, tri += (uint64_t) r.tri_points, pre++;
-        if (r.n_log > tc::LOG_CAP / 2) { // the landmark-container history is replayed by the host copy before the block's log wraps
-            s.syncDevice();
-            s.table->syncTable();
-            if (icg_tracker_reset_log(tracker_, i) != ICG_OK) throw std::runtime_error("icg_tracker_reset_log failed");
-            s.table->coreLogRestarted();
+        // (ICG_TRACKER_LOG_DRAIN: drain threshold in operations, for tests; default half the block's capacity)
+        static const int drain_at = getenv("ICG_TRACKER_LOG_DRAIN") ? std::max(1, atoi(getenv("ICG_TRACKER_LOG_DRAIN"))) : tc::LOG_CAP / 2;
+        if (r.n_log > drain_at) dev_drain_.push_back(i), dev_drain_n_.push_back(r.n_log);
+    }
+    if (!dev_drain_.empty()) {
+        // the landmark-container histories that are half full are fetched (the log only, 16 bytes per operation — not the 2.7 MB block) and
+        // replayed into the streams' Map::landmarks_ twins before they can wrap; one wait for all of them
+        dev_log_.resize((size_t) tc::LOG_CAP * dev_drain_.size());
+        if (icg_tracker_fetch_logs(tracker_, (int) dev_drain_.size(), dev_drain_.data(), dev_drain_n_.data(), dev_log_.data(), tc::LOG_CAP) != ICG_OK)
+            throw std::runtime_error(std::string("icg_tracker_fetch_logs failed: ") + icg_last_error(device_->ctx()));
+        for (size_t k = 0; k < dev_drain_.size(); k++) {
+            Stream &s = streams_[(size_t) dev_drain_[k]];
+            s.table->coreApplyFetchedLog(dev_log_.data() + (size_t) tc::LOG_CAP * k, dev_drain_n_[k]);
+            s.last.n_log = 0;
         }
+        dev_drain_.clear(), dev_drain_n_.clear();
     }
     counters[0] += lk, counters[1] += lk ? 1 : 0, counters[2] += det, counters[3] += det ? 1 : 0, counters[4] += rs, counters[5] += rs ? 1 : 0;
     counters[6] += pre, counters[7] += tri;

@@ -105,6 +105,8 @@ private:
     vector<const uint8_t *> dev_images_;
     vector<double> dev_stamps_, dev_poses_;
     vector<icg_tracker_result> dev_results_;
+    vector<int32_t> dev_drain_, dev_drain_n_;
+    vector<tc::LmLog> dev_log_;
     void gather(int cur, StageBatch &global, vector<std::array<int, 8>> &bases);
     void scatter(int cur, const StageBatch &global, const vector<std::array<int, 8>> &bases);
     template <typename F> void forEachStream(F &&f);

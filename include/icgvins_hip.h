@@ -363,6 +363,10 @@ int icg_tracker_download(icg_tracker *t, int stream, void *block);
 int icg_tracker_upload(icg_tracker *t, int stream, const void *block);
 /* the landmark-container history of a stream has been replayed by the host: restart it (n_log = 0) */
 int icg_tracker_reset_log(icg_tracker *t, int stream);
+/* The same without the block: the first counts[k] entries (16 bytes each: id u64, map-point index u32, op i32 — 1 insert, 0 erase) of the
+ * history of streams[k] are copied to out + k * entry_stride entries and the history restarts; one wait for all n_req streams.  counts[k]
+ * is the n_log the stream's last result reported. */
+int icg_tracker_fetch_logs(icg_tracker *t, int n_req, const int32_t *streams, const int32_t *counts, void *out, int entry_stride);
 
 #ifdef __cplusplus
 }

@@ -795,6 +795,16 @@ int icg_tracker_upload(icg_tracker *t, int stream, const void *block) {
     memcpy(t->streams[(size_t) stream], block, sizeof(tc::Stream));
     return ICG_OK;
 }
+int icg_tracker_fetch_logs(icg_tracker *t, int n_req, const int32_t *streams, const int32_t *counts, void *out, int entry_stride) {
+    if (!t || n_req < 0) return ICG_ERR_INVALID;
+    for (int k = 0; k < n_req; k++) {
+        tc::Stream &S = *t->streams[(size_t) streams[k]];
+        if (counts[k] != S.n_log || counts[k] > entry_stride) return ICG_ERR_INVALID;
+        memcpy((char *) out + sizeof(tc::LmLog) * (size_t) k * entry_stride, S.log, sizeof(tc::LmLog) * (size_t) counts[k]);
+        S.n_log = 0;
+    }
+    return ICG_OK;
+}
 int icg_tracker_reset_log(icg_tracker *t, int stream) {
     if (!t || stream < 0 || stream >= t->n) return ICG_ERR_INVALID;
     t->streams[(size_t) stream]->n_log = 0;

@@ -200,3 +200,18 @@ def test_map_writers_on_the_device_engine_equal_the_object_engine(oracle):
     assert ra == rb
     for s, (x, y) in enumerate(zip(fa, fb)):
         assert x == y, (s, _first_difference(x, y))
+
+
+def test_device_engine_landmark_history_drains(monkeypatch):
+    """the landmark-container history of a block is fetched (log only) and replayed into the host's Map::landmarks_ twin whenever it passes
+    the drain threshold — here every ~30 operations instead of every 4096: the iteration order in the dumps (line "O buckets=... order=...")
+    must still be the table engine's after every frame, with downloads of the block interleaved at other frames"""
+    monkeypatch.setenv("ICG_TRACKER_LOG_DRAIN", "30")
+    w, h, nfeat, n, stream, blank, hist, slow = CASES["c1_window_rolls"]
+    frames, poses = _scene(w, h, n, stream)
+    st_t, d_t, stats_t = _drive("table", w, h, nfeat, n, frames, poses)
+    st_d, d_d, stats_d = _drive("device", w, h, nfeat, n, frames, poses, dump_every=7)
+    assert st_t == st_d and stats_t == stats_d
+    by_frame = {k: full for k, full, _, _ in d_t}
+    for k, full_d, _, _ in d_d:
+        assert by_frame[k] == full_d, (k, _first_difference(by_frame[k], full_d))
