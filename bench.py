@@ -426,6 +426,41 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
                           "workgroups, so a real run overlaps them. (b) all groups at once from their own threads: ceiling_frames_per_s, the rate "
                           "the kernels and the launch structure allow at the concurrency of the timed run; value / ceiling = share of that rate "
                           "the whole path (with the tracker logic on the host) reaches"}
+    if profile and os.environ.get("ICG_TRACK_ENGINE") == "device":
+        # device engine: a step is one launch chain per group, so the exclusive time of every kernel is measured directly — a few steps in which
+        # only group 0's streams receive frames (the other groups issue nothing): HIP events on group 0's stream, nothing else on the GPU
+        B0 = B // sb.n_groups() + (1 if B % sb.n_groups() else 0)  # streams of group 0 (StreamGroups gives the first groups the remainder)
+        reps = 4
+        fs = [(k + j) if forward else H.pingpong(k + j, ring) for j in range(reps)]
+        flat = [(dev[s][f] if s < B0 else None) for f in fs for s in range(B)]
+        ptrs = (C.c_void_p * (reps * B))(*flat)
+        P = np.ascontiguousarray(np.stack([np.stack([poses[s][f] for s in range(B)]) for f in fs]), np.float64)
+        stamps = np.ascontiguousarray(np.stack([np.full(B, 1000.0 + (k + j) / 20.0) for j in range(reps)]), np.float64)
+        hip.icg_prof_enable(ctx_all[0], 0)
+        run_prepared(1, ((C.c_void_p * B)(*flat[:B]), stamps[:1].copy(), P[:1].copy(), np.zeros((1, B), np.int32)))  # untimed pass
+        hip.icg_prof_enable(ctx_all[0], 1)
+        run_prepared(reps - 1, ((C.c_void_p * ((reps - 1) * B))(*flat[B:]), stamps[1:].copy(), P[1:].copy(), np.zeros((reps - 1, B), np.int32)))
+        dev_sync()
+        k += reps
+        excl = {}
+        names = C.create_string_buffer(4096)
+        hip.icg_prof_names(ctx_all[0], names, 4096)
+        for name in names.value.decode().split("\n"):
+            if not name:
+                continue
+            n_, ms_ = C.c_int(), C.c_double()
+            hip.icg_prof_get(ctx_all[0], name.encode(), C.byref(n_), C.byref(ms_))
+            excl[name] = [n_.value, ms_.value]
+        hip.icg_prof_enable(ctx_all[0], 0)
+        frames_alone = B0 * (reps - 1)
+        per_kernel = {kk: {"launches_per_step": round(v[0] / float(reps - 1), 3), "exclusive_us_per_launch": round(1e3 * v[1] / max(1, v[0]), 2),
+                           "exclusive_us_per_frame": round(1e3 * v[1] / frames_alone, 4)} for kk, v in sorted(excl.items(), key=lambda t: -t[1][1]) if v[0]}
+        sum_us = sum(v["exclusive_us_per_frame"] for v in per_kernel.values())
+        ceiling = {"streams_per_launch": B0, "groups_replayed": 1, "replays": reps - 1, "exclusive_us_per_frame": round(sum_us, 3),
+                   "serialized_frames_per_s": round(1e6 / sum_us, 1) if sum_us > 0 else None, "ceiling_frames_per_s": None, "kernels": per_kernel,
+                   "how": "device engine: steps in which only ONE group's streams receive frames, HIP events around every kernel of its launch chain "
+                          "(stage kernels of the tracker included): exclusive device time per kernel, nothing else on the GPU.  There is no separate "
+                          "device-only ceiling: the timed run itself has no tracker logic on the host"}
     # template set-up reuse in the LK calls (icg_lk_track_fb_reuse): points tracked / points whose hint passed the entry point's checks
     lk_reuse = [0, 0]
     for c in ctx_all:
@@ -573,8 +608,7 @@ def main():
                                                               "and says so; the driver's command never uses this)")
     ap.add_argument("--engine", default=os.environ.get("ICG_TRACK_ENGINE", "auto"), choices=["auto", "table", "object", "core", "device"],
                     help="tracker engine of the host executor: device = the device-resident tracker (state in HBM, one launch chain + one wait per "
-                         "step); table = the host track table between batched device calls (rounds 1-3); auto (default) = by the rank's share of "
-                         "the host cores (sharding.host_plan: table with >= 4 cores per GPU, device below)")
+                         "step); table = the host track table between batched device calls (rounds 1-3); auto (default) = sharding.host_plan's choice (device)")
     ap.add_argument("--details", default=os.environ.get("ICG_BENCH_DETAILS", ""),
                     help="file for the long per-group / per-step series and notes (default gpurun_out/bench_details.json); the contract line stays compact")
     args = ap.parse_args()
@@ -728,7 +762,7 @@ def main():
         roofline["exclusive_us_per_frame_all_kernels"] = ceiling["exclusive_us_per_frame"]
         roofline["serialized_frames_per_s"] = ceiling["serialized_frames_per_s"]
         roofline["ceiling_frames_per_s"] = ceiling["ceiling_frames_per_s"]
-        roofline["value_over_ceiling"] = round(fps / max(1, world) / ceiling["ceiling_frames_per_s"], 4) if ceiling["ceiling_frames_per_s"] else None
+        roofline["value_over_ceiling"] = round(fps / max(1, world) / ceiling["ceiling_frames_per_s"], 4) if ceiling.get("ceiling_frames_per_s") else None
         # `achieved` / `frac` are quoted on the kernel's OWN duration (the launch alone on the GPU, HIP events of the
         # kernel-only replay — what a rocprofv3 kernel trace of an unloaded launch shows); the HIP-event duration of the same launch while
         # the other stream groups' kernels share the chip stays next to it as *_under_load
@@ -1072,8 +1106,8 @@ def main():
     if rank == 0 and not args.no_reproj and not args.no_c4:
         c4 = {"workload": "C4: 1920x1080 synthetic streams, 500 features, 15-keyframe window (7 000 reprojection factors), 15 x 40-sample "
                           "IMU intervals at 200 Hz, 1 MI355X"}
-        G4 = int(max(4, min(12, 3 * round(cores_rank))))  # table engine: few large groups (round 2, object engine: 32 x 8 -> 39.4 k)
-        B4 = 32 * G4
+        G4 = G if args.engine == "device" else int(max(4, min(12, 3 * round(cores_rank))))  # (table engine: few large groups)
+        B4 = 384
         f4 = run_frontend(torch, hip, w=1920, h=1080, nfeat=500, window=15, B=B4, G=G4, ring=16, prime=64, warmup=10, steps=60,
                           rank=0, local_rank=local_rank, host_threads=1, host_frames=False, profile=False,
                           barrier=torch.cuda.synchronize, ncpu=ncpu)
@@ -1126,7 +1160,7 @@ def main():
     if rank == 0 and not args.no_reproj and not args.host_frames:
         # (32 groups: with every frame crossing the link, more groups in flight only add contention — 48 x 8: 35.1 k, 32 x 8: 40.7 k)
         Gh = min(G, 12)
-        Bh = 32 * Gh  # (384 streams: 8 ring frames each = 2.8 GB of pinned host memory)
+        Bh = 384  # (8 ring frames each = 2.8 GB of pinned host memory)
         fh = run_frontend(torch, hip, w=w, h=h, nfeat=nfeat, window=10, B=Bh, G=Gh, ring=8, prime=args.prime, warmup=5, steps=40, rank=0,
                           local_rank=local_rank, host_threads=host_threads, host_frames=True, profile=False, barrier=torch.cuda.synchronize,
                           ncpu=ncpu)
@@ -1145,7 +1179,7 @@ def main():
     forward = None
     if rank == 0 and not args.no_reproj and not args.host_frames:
         Gf = min(G, 12)
-        Bf = 8 * Gf
+        Bf = 96
         f_prime, f_warm, f_steps = min(args.prime, 40), 4, 40
         ff = run_frontend(torch, hip, w=w, h=h, nfeat=nfeat, window=10, B=Bf, G=Gf, ring=f_prime + f_warm + f_steps, prime=f_prime, warmup=f_warm,
                           steps=f_steps, rank=0, local_rank=local_rank, host_threads=host_threads, host_frames=False, profile=False,

@@ -40,14 +40,15 @@ def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, 
       cpu_slice    the contiguous slice of the allowed CPU ids this rank pins itself to (None for a single rank: nothing to separate)
     """
     cores_rank = float(usable_cores) / float(max(1, world))
-    # engine (round 4): with >= 4 host cores per GPU the track table on the host (host logic of one group overlaps the other groups' kernels for
-    # free: 100-110 k frames/s per GPU, 4.4 cores busy); with fewer, the device-resident tracker (state in HBM, one launch chain + one wait
-    # per step: 85 k frames/s per GPU with 1.3 cores busy, 76 k with every thread confined to 2 CPUs where the table engine reaches 43 k) —
-    # profiles/r04_cpu_quota.md.  Same results either way (tests/test_gpu_device_tracker.py).
-    engine = engine_override or ("table" if cores_rank >= 4.0 else "device")
+    # engine (round 4): the device-resident tracker (csrc/tracker.hip: the streams' state in HBM, one launch chain + one wait per step) whatever
+    # the rank's share of the host: 107-112 k frames/s per GPU with 0.4-0.8 host cores busy, 106.7 k with every thread of the process confined
+    # to 2 CPUs — where the track table on the host (rounds 1-3; engine_override="table") needs 4.5 cores for 105-118 k and reaches 41-43 k on 2
+    # (profiles/r04_cpu_quota.md).  Same results either way (tests/test_gpu_device_tracker.py, tests/test_host_engines_cpu.py).
+    engine = engine_override or "device"
     if engine == "device":
-        # wide launches: the stage kernels cost the same whatever the number of streams (a wave per stream)
-        groups = int(groups_override) if groups_override > 0 else 4  # 4 x 192: 72.9 k on 2 confined CPUs (8 x 96: 71.6 k, 12 x 64: 69.1 k, 6 x 128: 64.0 k)
+        # wide launches: the stage kernels cost the same whatever the number of streams (a wave per stream).  4 x 192 -> 106.9 k, 12 x 64 ->
+        # 108.8 k, 8 x 192 (1536 streams) -> 111.8 k; 2 confined CPUs: 4 x 192 -> 106.7 k, 8 x 96 -> 106.1 k
+        groups = int(groups_override) if groups_override > 0 else 4
     else:
         groups = int(groups_override) if groups_override > 0 else int(max(4, min(12, 4 * round(cores_rank))))
     streams = int(streams_override) if streams_override > 0 else STREAMS_PER_GPU
