@@ -281,25 +281,29 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
                 os.sched_setaffinity(int(tid), cpus)
             except OSError:
                 pass
+    # Every argument array of the run (priming, warm-up, timed steps) is built BEFORE the first frame is tracked, and the bookkeeping between
+    # warm-up and t0 is one C call: from the first priming step to t0 the GPU works without a gap of more than a fraction of a millisecond.
+    # (Measured, round 4: with ~40 ms of python between priming / warm-up / timed region the 20 timed steps of the driver's command ran at 7.5 ms
+    # per step against 6.9 ms in 60-200-step runs — the device had clocked down and 5 warm-up steps = 35 ms do not bring it back.)
     k = 0
+    prep_prime = prepare_steps(k, prime) if prime > 0 else None
+    prep_warm = prepare_steps(k + prime, warmup) if warmup > 0 else None
+    prep = prepare_steps(k + prime + warmup, steps)
+    if hostprof:
+        _hp = np.zeros(64, np.float64)
     t_prime = time.time()
     if prime > 0:
-        run_prepared(prime, prepare_steps(k, prime))
+        run_prepared(prime, prep_prime)
         k += prime
     t_prime = time.time() - t_prime
-    prep_warm = prepare_steps(k, warmup) if warmup > 0 else None
-    prep = prepare_steps(k + warmup, steps)  # built BEFORE the warm-up: the GPU does not idle (and clock down) between warm-up and t0
     if warmup > 0:
         run_prepared(warmup, prep_warm)
         k += warmup
-    # bookkeeping that needs the streams at rest is done BEFORE the barrier: between the barrier and t0 the GPU must not sit idle for
-    # milliseconds (768 ctypes calls, log resets) — the first timed steps then run on a device that has clocked down
     sb.timing(reset=True)
     sb.step_log(reset=True)
     if hostprof:
-        _hp = np.zeros(64, np.float64)
         sb.lib.icgh_hostprof(_hp.ctypes.data_as(C.c_void_p), 32, None, 0, 1)
-    stats_before = [sb.stats(s) for s in range(B)]
+    stats_before = sb.stats_all()
     tracked_before = sum(s_["tracked_sum"] for s_ in stats_before)
     sb.counters(reset=True)
     barrier()
@@ -339,7 +343,7 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
     host_breakdown["group_step_ms_per_group"] = [round(float(v), 2) for v in tg]
     host_breakdown["group_device_ms_per_group"] = [round(float(v), 2) for v in tg_all[:, 2] * 1e3 / steps]
     barrier()
-    stats = [sb.stats(s) for s in range(B)]
+    stats = sb.stats_all()
     tracked = sum(s_["tracked_sum"] for s_ in stats) - tracked_before
     rates = event_rates(sb.counters(reset=True), sum(a["keyframes"] - b["keyframes"] for a, b in zip(stats, stats_before)),
                         sum(a["mappoints_created"] - b["mappoints_created"] for a, b in zip(stats, stats_before)), B * steps)
@@ -582,10 +586,13 @@ def main():
     ap.add_argument("--steps", type=int, default=200,
                     help="timed lock-step frames per stream (default 200: ~1 s timed region)")
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--prime", type=int, default=int(os.environ.get("ICG_BENCH_PRIME", "48")),
+    ap.add_argument("--prime", type=int, default=int(os.environ.get("ICG_BENCH_PRIME", "200")),
                     help="untimed frames per stream run during SETUP, before the warm-up steps: every stream leaves the start-up phase of "
-                         "the reference's state machine (first frame, initialization, a full 10-keyframe window) and every arena / pool has "
-                         "its steady-state size, whatever --warmup is")
+                         "the reference's state machine (first frame, initialization, a full 10-keyframe window), every arena / pool has "
+                         "its steady-state size, and the DEVICE has reached its steady state whatever --warmup is: after the seconds of "
+                         "rendering during set-up an MI355X needs > 1 s of sustained load before a step takes its steady 6.6-6.9 ms (round 4, "
+                         "profiles/r04_device_tracker.md: 20 timed steps after 48 / 120 / 200 priming frames = 97.5 / 97.0 / 108.1 k frames/s, "
+                         "on either engine); the 5 warm-up steps of the driver's command are 35 ms")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("ICG_BENCH_STREAMS", "0")),
                     help="camera streams per GPU (0 = 8 per stream group)")
     ap.add_argument("--ring", type=int, default=32, help="rendered frames per stream (ping-pong replay)")

@@ -194,6 +194,14 @@ class StreamBatch:
         keys = ["frames", "keyframes", "tracked_sum", "digest", "mappoints_created", "window_keyframes", "landmarks", "last_state"]
         return dict(zip(keys, [int(v) for v in out]))
 
+    def stats_all(self):
+        """stats() of every stream in one call"""
+        out = np.zeros((self.n, 8), np.uint64)
+        if not hasattr(self.lib, "icgh_batch_stats_all") or self.lib.icgh_batch_stats_all(C.c_void_p(self.h_), out.ctypes.data_as(C.c_void_p)) != 0:
+            return [self.stats(s) for s in range(self.n)]
+        keys = ["frames", "keyframes", "tracked_sum", "digest", "mappoints_created", "window_keyframes", "landmarks", "last_state"]
+        return [dict(zip(keys, [int(v) for v in row])) for row in out]
+
     def candidates(self, stream, cap=4096):
         """un-triangulated candidate points of the tracker (current and reference pixel), list order"""
         cur, ref = np.zeros((cap, 2), np.float32), np.zeros((cap, 2), np.float32)

@@ -112,6 +112,15 @@ int icgh_batch_stats(icgh_batch *b, int stream, uint64_t *out8) {
     return 0;
 }
 
+// the same for every stream in one call (n x 8): the bench reads the statistics of hundreds of streams between its warm-up and its timed
+// region, where every millisecond the GPU idles costs clock state
+int icgh_batch_stats_all(icgh_batch *b, uint64_t *out8n) {
+    if (!b || !out8n) return -1;
+    for (int i = 0; i < b->tb->size(); i++)
+        if (icgh_batch_stats(b, i, out8n + 8 * (size_t) i) != 0) return -1;
+    return 0;
+}
+
 int icgh_batch_timing(icgh_batch *b, double *out5, int reset) {
     if (!b) return -1;
     for (int i = 0; i < 5; i++) out5[i] = 0;

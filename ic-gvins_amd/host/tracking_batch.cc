@@ -142,6 +142,7 @@ void TrackingBatch::stepDevice(const FrameInput *frames, vector<TrackState> &sta
     const double t2 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     timing[4] += t2 - t1;
     if (step_log.size() < kStepLogCap) step_log.push_back({t2, t2 - t1, t1 - t0});
+    if (any) last_step_s_ = t2 - t0;
 }
 
 void TrackingBatch::Stream::currentFeatures(vector<std::pair<ulong, Point2f>> &out) const {
@@ -462,6 +463,7 @@ StreamGroups::StreamGroups(int device, int n_streams, int n_groups, const vector
         begin += cnt;
     }
     group_begin_.push_back(begin);
+    stagger_ = !(getenv("ICG_GROUP_STAGGER") && getenv("ICG_GROUP_STAGGER")[0] == '0');
     if (n_groups > 1) {
         // many contexts share the host cores: waits must not spin (a spinning wait burns the core another group needs).
         // 100 us between stream queries: measured on MI355X with 32 groups / 16 usable cores, 20 us and 100 us give the same
@@ -496,6 +498,14 @@ void StreamGroups::workerLoop(int g) {
         try {
             vector<TrackState> st;
             if (replay_reps_ > 0) groups_[(size_t) g]->replay(replay_reps_, (size_t) g); // staggered: group g starts at its g-th recorded call
+            // Device engine, several steps in one call: the groups leave the call's start line one G-th of a step apart.  Their launch chains
+            // are identical, so groups that start together stay in phase for ~20 steps — all in their stage kernels (the chip idles), then
+            // all in LK (the chip is contended): 7.7 ms per step instead of 6.9 until they drift apart.  (ICG_GROUP_STAGGER=0 turns it off.)
+            if (replay_reps_ == 0 && frames_->size() > 1 && groups_[(size_t) g]->engine() == TrackingBatch::ENGINE_DEVICE && stagger_) {
+                const double T = groups_[(size_t) g]->lastStepSeconds();
+                const double d = T > 0 && T < 0.1 ? T * g / (double) groups_.size() : 0.0;
+                if (d > 0) std::this_thread::sleep_for(std::chrono::duration<double>(d));
+            }
             for (size_t k = 0; replay_reps_ == 0 && k < frames_->size(); k++) {
                 groups_[(size_t) g]->step((*frames_)[k].data() + b, st);
                 for (int i = b; i < e; i++) (*states_)[k][(size_t) i] = st[(size_t) (i - b)];

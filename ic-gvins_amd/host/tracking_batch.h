@@ -77,6 +77,7 @@ public:
     // one frame per stream (frames[i].valid == false idles a stream); returns per-stream states
     void step(const FrameInput *frames, vector<TrackState> &states);
     Engine engine() const { return engine_; }
+    double lastStepSeconds() const { return last_step_s_; }
     // kernel-only replay of the device calls of the steps run while recording (DeviceContext::record / replay)
     void record(bool on) { device_->record(on); }
     void replay(int reps, size_t first = 0) {
@@ -102,6 +103,7 @@ public:
 private:
     void stepDevice(const FrameInput *frames, vector<TrackState> &states);
     icg_tracker *tracker_{nullptr};
+    double last_step_s_{0};
     vector<const uint8_t *> dev_images_;
     vector<double> dev_stamps_, dev_poses_;
     vector<icg_tracker_result> dev_results_;
@@ -156,6 +158,7 @@ private:
     uint64_t generation_{0};
     int pending_{0};
     bool stop_{false};
+    bool stagger_{true};
     int replay_reps_{0}; // > 0: the pending job is a device-only replay
     const vector<vector<FrameInput>> *frames_{nullptr};
     vector<vector<TrackState>> *states_{nullptr};
