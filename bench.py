@@ -176,14 +176,22 @@ def pmc_provenance(pmc_file, streams_per_launch):
     return None
 
 
-def committed_pmc(kernel):
-    """Per-kernel counter means of the newest committed rocprofv3 --pmc summary (profiles/rNN_pmc_summary.json, collected by
-    profiles/collect.sh at the bench configuration).  Returns (entry or None, file name)."""
+def committed_pmc(kernel, streams_per_launch=None):
+    """Per-kernel counter means of a committed rocprofv3 --pmc summary (profiles/rNN_pmc_summary*.json, collected by profiles/collect.sh at
+    a bench configuration): the newest one whose provenance fits this build and launch shape (the round's summaries exist per engine: the
+    track table launches 64 streams at a time, the device-resident tracker 192), else the newest.  Returns (entry or None, file name)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary*.json")))
     if not files:
         return None, None
-    return json.load(open(files[-1])).get(kernel), os.path.basename(files[-1])
+    pick = files[-1]
+    if streams_per_launch is not None:
+        newest_round = os.path.basename(files[-1])[:3]
+        for f in reversed([f for f in files if os.path.basename(f).startswith(newest_round)]):
+            if pmc_provenance(os.path.basename(f), streams_per_launch) is None:
+                pick = f
+                break
+    return json.load(open(pick)).get(kernel), os.path.basename(pick)
 
 
 def frontend_valu(pmc_file, streams_per_launch, fps):
@@ -615,7 +623,8 @@ def main():
                                                               "and says so; the driver's command never uses this)")
     ap.add_argument("--engine", default=os.environ.get("ICG_TRACK_ENGINE", "auto"), choices=["auto", "table", "object", "core", "device"],
                     help="tracker engine of the host executor: device = the device-resident tracker (state in HBM, one launch chain + one wait per "
-                         "step); table = the host track table between batched device calls (rounds 1-3); auto (default) = sharding.host_plan's choice (device)")
+                         "step); table = the host track table between batched device calls (rounds 1-3); auto (default) = sharding.host_plan's choice: the table where the rank has >= 6 host cores, "
+                         "the device tracker below")
     ap.add_argument("--details", default=os.environ.get("ICG_BENCH_DETAILS", ""),
                     help="file for the long per-group / per-step series and notes (default gpurun_out/bench_details.json); the contract line stays compact")
     args = ap.parse_args()
@@ -733,13 +742,15 @@ def main():
                                               "HIP-event duration of one launch while the others run" % fe["n_groups"]}
             # HBM traffic and issue utilisation of the same kernel from the committed rocprofv3 --pmc passes of THIS configuration
             # (profiles/collect.sh runs bench.py with the default streams/groups): per unit x the units of one launch here
-            pmc, pmc_file = committed_pmc("k_" + dom)
+            pmc, pmc_file = committed_pmc("k_" + dom, per_launch_streams)
             stale = pmc_provenance(pmc_file, per_launch_streams) if pmc_file else "no committed counter summary"
             if stale:
                 roofline["pmc_stale"] = stale  # counters of another build / launch shape are not quoted next to this measurement
                 pmc, pmc_file = None, None
             if pmc and "hbm_bytes_per_launch" in pmc and dom == "lk_track_fb":
-                per_point = pmc["hbm_bytes_per_launch"] / (pmc["grid_threads"] / 64.0)
+                meta = (json.load(open(os.path.join(ROOT, "profiles", pmc_file))).get("_meta") or {})
+                # (segmented launches size the grid by capacity: the summary names the points actually tracked per launch)
+                per_point = pmc["hbm_bytes_per_launch"] / (meta.get("lk_active_points_per_launch") or (pmc["grid_threads"] / 64.0))
                 roofline["traffic"] = int(per_point * pts)
                 roofline["traffic_source"] = (f"profiles/{pmc_file}: (2*FETCH_SIZE + WRITE_SIZE) per point x points per launch "
                                               "(gfx950 correction of MI355X_MICROARCH.md)")

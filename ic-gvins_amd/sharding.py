@@ -40,11 +40,13 @@ def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, 
       cpu_slice    the contiguous slice of the allowed CPU ids this rank pins itself to (None for a single rank: nothing to separate)
     """
     cores_rank = float(usable_cores) / float(max(1, world))
-    # engine (round 4): the device-resident tracker (csrc/tracker.hip: the streams' state in HBM, one launch chain + one wait per step) whatever
-    # the rank's share of the host: 107-112 k frames/s per GPU with 0.4-0.8 host cores busy, 106.7 k with every thread of the process confined
-    # to 2 CPUs — where the track table on the host (rounds 1-3; engine_override="table") needs 4.5 cores for 105-118 k and reaches 41-43 k on 2
-    # (profiles/r04_cpu_quota.md).  Same results either way (tests/test_gpu_device_tracker.py, tests/test_host_engines_cpu.py).
-    engine = engine_override or "device"
+    # engine (round 4).  The device-resident tracker (csrc/tracker.hip: the streams' state in HBM, one launch chain + one wait per step) needs
+    # 0.3-0.5 host cores per GPU: 111 k frames/s at the driver's command, 110 k with every thread of the process confined to 2 CPUs, 106 k on ONE.
+    # The track table on the host (rounds 1-3) overlaps its host logic with the other groups' kernels for free and is 7 % faster on a GPU that
+    # has the cores for it (119.6 k with 5.2 cores busy) — and collapses to 44 k on 2 CPUs (profiles/r04_cpu_quota.md).  So: the table where
+    # a rank has >= 6 cores, the device tracker below.  Same results either way, state for state (tests/test_gpu_device_tracker.py,
+    # tests/test_host_engines_cpu.py; the 2-rank bench self-test runs one rank count on each engine and compares the digests).
+    engine = engine_override or ("table" if cores_rank >= 6.0 else "device")
     if engine == "device":
         # wide launches: the stage kernels cost the same whatever the number of streams (a wave per stream).  4 x 192 -> 106.9 k, 12 x 64 ->
         # 108.8 k, 8 x 192 (1536 streams) -> 111.8 k; 2 confined CPUs: 4 x 192 -> 106.7 k, 8 x 96 -> 106.1 k

@@ -10,7 +10,7 @@ from collections import defaultdict
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0], r.get("Queue_Id", "0")))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], r.get("Queue_Id", "0")))
 rows.sort()
 lk = [r for r in rows if r[2].startswith("k_lk_track_fb")]
 if len(lk) < 40:

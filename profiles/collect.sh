@@ -22,6 +22,7 @@ for CNT in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CNT --output-format csv -d $OUT/${TAG}_pmc_reproj_$CNT -o p -- python $R/profiles/run_reproj_only.py > /dev/null 2> $OUT/${TAG}_pmc_reproj_$CNT.err
 done
 export ICG_PMC_STREAMS_PER_LAUNCH=$(python -c "import json; c=json.load(open('$OUT/${TAG}_kt_bench.json'))['config']; print(c['streams_per_gpu'] / c['groups_per_gpu'])")
+export ICG_PMC_LK_ACTIVE_POINTS=$(python -c "import json; print(json.load(open('$OUT/${TAG}_kt_bench_details.json'))['roofline']['units_per_launch'])")
 python $R/profiles/summarize_pmc.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_reproj_FETCH_SIZE $OUT/${TAG}_pmc_reproj_WRITE_SIZE > $OUT/${TAG}_pmc_summary.json
 find $OUT/${TAG}_kt -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
 # queue-level view of the same trace (hardware-queue occupancy, kernels in flight, per-kernel duration under load)

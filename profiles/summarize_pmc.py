@@ -18,7 +18,7 @@ def main(dirs):
     for d in dirs:
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                k = r["Kernel_Name"].split("(")[0]
+                k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
                 acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 cnt[k][r["Counter_Name"]] += 1
                 grid[k].append(int(r["Grid_Size"]))
@@ -47,6 +47,9 @@ def main(dirs):
     pre = out.get("k_pyramid3")
     out["_meta"] = {"csrc_sha1": h.hexdigest(), "streams_per_launch": os.environ.get("ICG_PMC_STREAMS_PER_LAUNCH"),
                     "lk_points_per_launch": (lk["grid_threads"] / 64.0) if lk else None,
+                    # segmented launches (device-resident tracker) size the grid by capacity: the points actually tracked per launch, from the
+                    # bench line of the same configuration (roofline.units_per_launch)
+                    "lk_active_points_per_launch": float(os.environ["ICG_PMC_LK_ACTIVE_POINTS"]) if os.environ.get("ICG_PMC_LK_ACTIVE_POINTS") else None,
                     "note": "csrc_sha1 = sha1 over the names and contents of ic-gvins_amd/csrc/*.{hip,h} at collection time"}
     json.dump(out, sys.stdout, indent=1)
 

@@ -22,7 +22,8 @@ def test_committed_pmc_summary_feeds_the_roofline_block():
         assert key in entry, key
     # traffic per point as the bench forms it: near the algorithmic 8 480 B (the XCD-chunked mapping keeps re-reads out: 31.7 KB before
     # it).  0.98x with 8 groups x 64 streams (round 2), 1.16x with 12 x 64 (round 3: the other groups' kernels evict pyramid lines)
-    per_point = entry["hbm_bytes_per_launch"] / (entry["grid_threads"] / 64.0)
+    meta = json.load(open(os.path.join(ROOT, "profiles", name))).get("_meta") or {}
+    per_point = entry["hbm_bytes_per_launch"] / (meta.get("lk_active_points_per_launch") or entry["grid_threads"] / 64.0)
     assert 0.9 * 8480 < per_point < 1.25 * 8480
 
 
