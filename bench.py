@@ -726,7 +726,13 @@ def main():
         # fm_seven_point shows a long summed time although it issues 0.1% of the instructions — profiles/.)
         per_launch_streams = B / float(fe["n_groups"])  # each group launches for its own streams
         modelled = [kk for kk in kernel_table if algorithmic_bytes(kk, w, h, per_launch_streams, 1.0) is not None]
-        dom = max(modelled or list(kernel_table), key=lambda kk: kernel_table[kk]["total_ms"])
+        # by exclusive time (the kernel alone on the GPU) when the exclusive pass ran: under load a kernel's HIP-event time is mostly the wait
+        # for wave slots other kernels hold (round 4: k_min_eig_nms 1.39 ms per launch under load against 0.29 alone, k_lk_track_fb 1.17 / 1.07)
+        excl_tab = (fe.get("ceiling") or {}).get("kernels") or {}
+        if excl_tab and any(kk in excl_tab for kk in modelled):
+            dom = max([kk for kk in modelled if kk in excl_tab], key=lambda kk: excl_tab[kk]["exclusive_us_per_frame"])
+        else:
+            dom = max(modelled or list(kernel_table), key=lambda kk: kernel_table[kk]["total_ms"])
         avg_s = kernel_table[dom]["avg_us"] * 1e-6
         pts = work["lk_points"] / max(1, work["lk_calls"])  # exact: points handed to icg_lk_track_fb per call
         ab = algorithmic_bytes(dom, w, h, per_launch_streams, pts)
