@@ -279,6 +279,61 @@ int icgh_hashorder_selftest(uint64_t seed, int n, int check_every, int dense_ids
     return HashOrder::selfTest(seed, n, check_every, dense_ids != 0);
 }
 
+// The tracker core's container order (tc::order_extend, track_core.h: node list + buckets in scratch memory, batched insertion of the rows
+// [n_old, n_rows) — what the stage kernels run) against a real std::unordered_map<ulong, int>: `n_first` rows entered at once into an empty
+// frame, then `rounds` times `n_more` further rows appended to the existing order (every extension starts from the stored head / buckets and
+// crosses rehashes).  Returns 0 when the iteration orders agree after every step, else the step (1-based) of the first disagreement.
+int icgh_core_order_selftest(uint64_t seed, int n_first, int n_more, int rounds) {
+    if (n_first < 0 || n_more < 0 || rounds < 0 || n_first + (long) n_more * rounds > tc::MAX_ROWS) return -1;
+    std::unique_ptr<tc::Frame> f(new tc::Frame);
+    std::unique_ptr<tc::Scratch> X(new tc::Scratch);
+    memset(f.get(), 0, sizeof(tc::Frame));
+    tc::order_clear(*f);
+    std::unordered_map<ulong, int> ref;
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 7;
+    ulong id   = seed % 977;
+    const uint32_t *ba = TableTracker::bucketsAfterTable();
+    auto append = [&](int count) {
+        for (int k = 0; k < count; k++) {
+            x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+            id += 1 + (x % 5) * ((seed & 1) ? 1 : 131); // dense ids as the id factories hand them out, or scattered ones
+            f->row[f->n_rows].id = id;
+            ref.emplace(id, f->n_rows);
+            f->n_rows++;
+        }
+    };
+    auto same = [&]() {
+        int r = f->head;
+        for (const auto &kv : ref) {
+            if (r < 0 || r != kv.second) return false;
+            r = f->next[r];
+        }
+        return r < 0 && (size_t) f->n_buckets == ref.bucket_count();
+    };
+    int old = 0;
+    append(n_first);
+    tc::order_extend(*f, old, ba, *X);
+    if (!same()) return 1;
+    for (int r = 0; r < rounds; r++) {
+        old = f->n_rows;
+        append(n_more);
+        tc::order_extend(*f, old, ba, *X);
+        if (!same()) return 2 + r;
+    }
+    // and the one-by-one form (order_insert_unique: the path of rows added outside a batch) gives the same list
+    std::unique_ptr<tc::Frame> g(new tc::Frame);
+    memset(g.get(), 0, sizeof(tc::Frame));
+    tc::order_clear(*g);
+    vector<int32_t> scratch((size_t) tc::MAX_BUCKETS);
+    for (int k = 0; k < f->n_rows; k++) {
+        g->row[k].id = f->row[k].id;
+        tc::order_insert_unique(*g, ba, scratch.data());
+    }
+    int a = f->head, b = g->head;
+    while (a >= 0 && b >= 0 && a == b) a = f->next[a], b = g->next[b];
+    return (a < 0 && b < 0) ? 0 : 1000;
+}
+
 } // extern "C"
 
 // ---- back-end test/driver entry points -----------------------------------------------------------------------------------

@@ -17,7 +17,12 @@ def _bench():
 def test_committed_pmc_summary_feeds_the_roofline_block():
     b = _bench()
     entry, name = b.committed_pmc("k_lk_track_fb")
-    assert name and name.endswith("_pmc_summary.json") and entry
+    assert name and "_pmc_summary" in name and name.endswith(".json") and entry
+    # the round's summaries exist per engine (launch shape): the one that fits the run is picked
+    for spl, want in ((64.0, "r04_pmc_summary.json"), (192.0, "r04_pmc_summary_device.json")):
+        e2, n2 = b.committed_pmc("k_lk_track_fb", spl)
+        if b.pmc_provenance(want, spl) is None:  # (only while the kernel sources are the ones the counters were collected on)
+            assert n2 == want and e2
     for key in ("hbm_bytes_per_launch", "grid_threads", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "launches"):
         assert key in entry, key
     # traffic per point as the bench forms it: near the algorithmic 8 480 B (the XCD-chunked mapping keeps re-reads out: 31.7 KB before

@@ -215,3 +215,13 @@ def test_device_engine_landmark_history_drains(monkeypatch):
     by_frame = {k: full for k, full, _, _ in d_t}
     for k, full_d, _, _ in d_d:
         assert by_frame[k] == full_d, (k, _first_difference(by_frame[k], full_d))
+
+
+def test_core_container_order_equals_std_unordered_map():
+    """tc::order_extend — the batched, scratch-resident insertion the stage kernels run (fresh frames: all rows at once; triangulation: a few
+    rows appended to an existing order) — against a real std::unordered_map, across every rehash threshold up to the row capacity"""
+    lib = C.CDLL(ensure_oracle_host())
+    lib.icgh_core_order_selftest.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int]
+    for seed in range(12):
+        for n_first, n_more, rounds in ((0, 1, 60), (240, 17, 20), (1, 0, 0), (13, 1, 30), (300, 50, 6), (639, 1, 1), (58, 1, 4), (127, 130, 3)):
+            assert lib.icgh_core_order_selftest(seed, n_first, n_more, rounds) == 0, (seed, n_first, n_more, rounds)
