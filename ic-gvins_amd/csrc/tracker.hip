@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, 
             A.work[4 * s + 2] = A.rs_count[s] > 0 ? 1 : 0;
             break;
         case 4:
-            tc::stage_on_ransac(S, C, io);
+            tc::stage_on_ransac(S, C, io, X);
             A.work[4 * s + 3] = A.tri_count[s];
             break;
         case 5:

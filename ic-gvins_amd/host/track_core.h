@@ -809,13 +809,24 @@ TC_FN void order_extend(Frame &f, int n_old, const uint32_t *buckets_after, Scra
     f.magic     = M;
     sync();
 }
-// the sum of a parallax average: terms in the order the reference adds them (par_term / par_ok, filled in parallel), added one by one
-TC_FN int sum_parallax_terms(const Stream &S, int n, double &parallax) {
+// the sum of a parallax average: terms in the order the reference adds them, added one by one.  The terms (X.key as doubles) and their
+// validity (X.next) were filled in parallel into the wave's scratch: the sequential pass reads LDS, not HBM
+TC_FN double key_as_double(u64 v) {
+    double d;
+    memcpy(&d, &v, sizeof d);
+    return d;
+}
+TC_FN u64 double_as_key(double d) {
+    u64 v;
+    memcpy(&v, &d, sizeof v);
+    return v;
+}
+TC_FN int sum_parallax_terms(const Scratch &X, int n, double &parallax) {
     parallax   = 0;
     int counts = 0;
     for (int k = 0; k < n; k++)
-        if (S.par_ok[k]) {
-            parallax += S.par_term[k];
+        if (X.next[k]) {
+            parallax += key_as_double(X.key[k]);
             counts++;
         }
     if (counts != 0) parallax /= counts;
@@ -846,23 +857,23 @@ TC_FN int parallax_from_reference_mappoints(Stream &S, const Cfg &C, double &par
                 }
             }
         }
-        S.par_ok[k]   = ok ? 1 : 0;
-        S.par_term[k] = term;
+        X.next[k] = ok ? 1 : 0; // (the copy of the node list in X.next has been consumed by list_container_order)
+        X.key[k]  = double_as_key(term);
     }
     sync();
-    return sum_parallax_terms(S, nq, parallax);
+    return sum_parallax_terms(X, nq, parallax);
 }
-TC_FN int parallax_from_reference_keypoints(Stream &S, const Cfg &C, const P2f *ref, const P2f *cur, double &parallax) { // :907-922
+TC_FN int parallax_from_reference_keypoints(Stream &S, const Cfg &C, const P2f *ref, const P2f *cur, double &parallax, Scratch &X) { // :907-922
     double R10[9];
     mat_mul_t(S.frame[S.cur].pose.R, S.frame[S.ref].pose.R, R10);
     const int n = S.n_ref_frame;
     for (int k = lane(); k < n; k += NL) {
         const bool ok = S.pts2d_ref_frame[k] == S.ref;
-        S.par_ok[k]   = ok ? 1 : 0;
-        S.par_term[k] = ok ? keypoint_parallax(C, ref[k], cur[k], R10) : 0.0;
+        X.next[k]     = ok ? 1 : 0;
+        X.key[k]      = double_as_key(ok ? keypoint_parallax(C, ref[k], cur[k], R10) : 0.0);
     }
     sync();
-    return sum_parallax_terms(S, n, parallax);
+    return sum_parallax_terms(X, n, parallax);
 }
 TC_FN void clear_candidates(Stream &S) {
     S.n_new = S.n_ref = S.n_ref_undis = S.n_new_undis = S.n_ref_frame = S.n_vel_ref = S.n_cand_lk = 0;
@@ -1117,7 +1128,7 @@ TC_FN void queue_track_reference(Stream &S, const Cfg &C, Io &io) {
     *io.lk_count = at + S.lk_ref_n;
     sync();
 }
-TC_FN bool mid_track_reference(Stream &S, const Cfg &C, Io &io) {
+TC_FN bool mid_track_reference(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     S.rs_set      = -1;
     *io.rs_count  = 0;
     if (S.lk_ref_n == 0) return false;
@@ -1160,7 +1171,7 @@ TC_FN bool mid_track_reference(Stream &S, const Cfg &C, Io &io) {
     }
     S.n_vel_cur = S.n_tr_cur_undis;
     sync();
-    S.parallax_ref_counts = parallax_from_reference_keypoints(S, C, S.pts2d_ref_undis, S.tr_cur_undis, S.parallax_ref); // :542-544
+    S.parallax_ref_counts = parallax_from_reference_keypoints(S, C, S.pts2d_ref_undis, S.tr_cur_undis, S.parallax_ref, X); // :542-544
 
     if (S.n_cur >= 15) { // :547-548
         S.rs_set = 0;
@@ -1209,7 +1220,7 @@ TC_FN void pose2Tcw12(const Pose &pose, double *t12) { // :851-859, upper 3 x 4 
     t12[4] = R[1], t12[5] = R[4], t12[6] = R[7], t12[7] = -t1;
     t12[8] = R[2], t12[9] = R[5], t12[10] = R[8], t12[11] = -t2;
 }
-TC_FN bool queue_triangulation(Stream &S, const Cfg &C, Io &io) {
+TC_FN bool queue_triangulation(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     S.tri_queued   = 0;
     *io.tri_count  = 0;
     *io.tri_n_tcw  = 0;
@@ -1269,13 +1280,13 @@ TC_FN bool queue_triangulation(Stream &S, const Cfg &C, Io &io) {
                 pixel2cam(C.cam, S.tri_cur_undis[k], S.tri_tmp[k][2], S.tri_tmp[k][3]);
             }
         }
-        S.par_ok[k] = (uint8_t) kind;
+        X.next[k] = kind;
     }
     sync();
     // pass 2 (in list order): camera matrices of the distinct reference frames, the triangulation list
     int T_frame[8], T_index[8], n_T = 0;
     for (int k = 0; k < S.n_cur; k++) {
-        if (S.par_ok[k] != 3) continue;
+        if (X.next[k] != 3) continue;
         const int frame_ref = S.pts2d_ref_frame[k];
         int T0 = -1;
         for (int q = 0; q < n_T; q++)
@@ -1305,64 +1316,129 @@ TC_FN bool queue_triangulation(Stream &S, const Cfg &C, Io &io) {
 TC_FN void finish_triangulation(Stream &S, const Cfg &C, const Io &io, const uint32_t *buckets_after, Scratch &X) {
     S.tri_queued     = 0;
     const Pose pose1 = S.frame[S.cur].pose;
-    // the new rows are written first; the frames that received some (the current one and the candidates' reference frames) then take them
-    // into their container order in one pass each, in row order — the order the reference's insertions happen in per container
-    int touched[10], touched_old[10], n_touched = 0;
-    touched[0] = S.cur, touched_old[0] = S.frame[S.cur].n_rows, n_touched = 1;
-    for (int q = 0; q < S.n_tri_index; q++) {
+    const int n      = S.n_tri_index;
+    // pass 1 (parallel): the gates of :756-760 for every triangulated point -> accepted or not, its depth in the reference view, its
+    // reference frame (scratch: X.next / X.key / X.bucket); either way the candidate leaves the list (:757 / :761)
+    for (int q = lane(); q < n; q += NL) {
         const int k     = S.tri_point_index[q];
         const double *p = io.tri_pw + 3 * (S.tri_begin + q);
         const double pw[3]  = {p[0], p[1], p[2]};
         const int frame_ref = S.pts2d_ref_frame[k];
         const Pose pose0    = S.frame[frame_ref].pose;
-        const P2f pp0 = S.tri_ref_undis[k], pp1 = S.tri_cur_undis[k];
-        S.tri_status[k] = 0; // :757 / :761: rejected or consumed, the candidate leaves the list either way
-        if (!is_good_to_track(C, pp0, pose0, pw, 1.0, 3.0) || !is_good_to_track(C, pp1, pose1, pw, 1.0, 3.0)) continue; // :756-760
+        S.tri_status[k]     = 0;
+        const bool good = is_good_to_track(C, S.tri_ref_undis[k], pose0, pw, 1.0, 3.0) && is_good_to_track(C, S.tri_cur_undis[k], pose1, pw, 1.0, 3.0);
         double pc[3];
         world2cam(pw, pose0, pc);
-        const double depth = pc[2];
-        // MapPoint::createMapPoint (mappoint.cc:25-49)
-        const uint32_t i   = mp_alloc(S);
-        S.hot[i].id        = S.mappoint_id++;
-        S.cold[i].born_fid = S.frame[S.cur].fid;
-        S.hot[i].pos[0] = pw[0], S.hot[i].pos[1] = pw[1], S.hot[i].pos[2] = pw[2];
-        S.cold[i].ref_frame = frame_ref;
-        S.cold[i].ref_gen   = S.frame[frame_ref].gen;
-        S.cold[i].ref_kp    = S.tri_ref_undis[k];
-        S.cold[i].depth     = ((depth < 1.0) || (depth > 200.0)) ? 10.0 /*DEFAULT_DEPTH*/ : depth;
-        S.hot[i].type       = (int8_t) MAPPOINT_TRIANGULATED;
-        double pccx, pccy, pcrx, pcry;
-        pixel2cam(C.cam, S.tri_cur_undis[k], pccx, pccy);
-        pixel2cam(C.cam, S.tri_ref_undis[k], pcrx, pcry);
+        X.next[q]   = good ? 1 : 0;
+        X.key[q]    = double_as_key(pc[2]);
+        X.bucket[q] = frame_ref;
+    }
+    sync();
+    // the frames that receive rows: the current one and the distinct reference frames of the accepted points, in order of first appearance
+    int touched[10], touched_old[10], touched_cnt[10], n_touched = 0;
+    touched[0] = S.cur, touched_old[0] = S.frame[S.cur].n_rows, touched_cnt[0] = 0, n_touched = 1;
+    for (int q = 0; q < n; q++) {
+        if (!X.next[q]) continue;
+        const int fr = X.bucket[q];
         int tq = -1;
         for (int u = 0; u < n_touched; u++)
-            if (touched[u] == frame_ref) tq = u;
+            if (touched[u] == fr) tq = u;
         if (tq < 0) {
             if (n_touched < 10) {
-                touched[n_touched] = frame_ref, touched_old[n_touched] = S.frame[frame_ref].n_rows, n_touched++;
+                touched[n_touched] = fr, touched_old[n_touched] = S.frame[fr].n_rows, touched_cnt[n_touched] = 0, n_touched++;
             } else {
                 S.overflow |= OVF_TCW; // (more distinct reference frames than a window holds)
+                X.next[q] = 0;
             }
         }
-        append_row(S, S.cur, S.hot[i].id, i, S.tri_cur_undis[k], S.pts2d_cur[k], S.velocity_cur[k][0], S.velocity_cur[k][1], FEATURE_TRIANGULATED, pccx, pccy,
-                   k < S.n_cand_lk ? S.cand_lk_idx[k] : -1); // :769-774
-        S.hot[i].observed++;
-        S.hot[i].used++;
-        const int row = append_row(S, frame_ref, S.hot[i].id, i, S.tri_ref_undis[k], S.pts2d_ref[k], S.velocity_ref[k][0], S.velocity_ref[k][1],
-                                   FEATURE_TRIANGULATED, pcrx, pcry, -1); // :776-781 (a freshly drawn id is in no frame yet)
-        S.hot[i].observed++;
-        S.hot[i].used++;
-        LastObs lo;
-        lo.frame = frame_ref, lo.gen = S.frame[frame_ref].gen, lo.row = row;
-        S.hot[i].last = lo;
-        Frame &fc     = S.frame[S.cur];
-        if (fc.n_unupd < MAX_ROWS) {
-            fc.unupd[fc.n_unupd]     = i; // :784
-            fc.unupd_gen[fc.n_unupd] = S.hot[i].gen;
-            fc.n_unupd++;
-        } else {
-            S.overflow |= OVF_ROWS;
+    }
+    // pass 2 (parallel, a chunk of points per step): MapPoint::createMapPoint (mappoint.cc:25-49) and the two features (:769-784).  What the
+    // one-by-one loop of the reference hands out in sequence is a function of the point's rank among the accepted ones: the r-th accepted
+    // point takes the r-th map-point index the pool would pop (free list from the back, then fresh indices), id mappoint_id + r, row
+    // n_rows + r of the current frame, and — ranked among the accepted points of ITS reference frame — the next row there
+    const int n_free0 = S.n_free_mps, n_mps0 = S.n_mps, cur_rows0 = touched_old[0];
+    const u64 id0     = S.mappoint_id;
+    const u64 cur_fid = S.frame[S.cur].fid;
+    const int unupd0  = S.frame[S.cur].n_unupd;
+    int acc_before    = 0;
+    for (int base = 0; base < n; base += NL) {
+        const int q    = base + lane();
+        const bool acc = q < n && X.next[q] != 0;
+        const int fr   = acc ? X.bucket[q] : -1;
+        const u64 m    = ballot(acc);
+        const int r    = acc_before + popc(m & lanes_below());
+        int tq = 0, rr = 0;
+        for (int u = 1; u < n_touched; u++) { // (a triangulated point's reference frame is never the current frame: :723-730 re-anchors instead)
+            const bool mine = acc && fr == touched[u];
+            const u64 mu    = ballot(mine);
+            if (mine) tq = u, rr = touched_cnt[u] + popc(mu & lanes_below());
+            touched_cnt[u] += popc(mu);
         }
+        if (acc) {
+            const int k = S.tri_point_index[q];
+            uint32_t i;
+            if (r < n_free0) {
+                i = S.free_mps[n_free0 - 1 - r];
+            } else if (n_mps0 + (r - n_free0) < MAX_MPS) {
+                i            = (uint32_t) (n_mps0 + (r - n_free0));
+                S.hot[i].gen = 0;
+            } else {
+                S.overflow |= OVF_MPS;
+                i = MAX_MPS - 1;
+            }
+            const int row_cur = cur_rows0 + r, row_ref = touched_old[tq] + rr;
+            if (fr == S.cur || row_cur >= MAX_ROWS || row_ref >= MAX_ROWS || unupd0 + r >= MAX_ROWS) {
+                S.overflow |= (fr == S.cur) ? OVF_INTERNAL : OVF_ROWS;
+            } else {
+                const double depth = key_as_double(X.key[q]);
+                const double *p    = io.tri_pw + 3 * (S.tri_begin + q);
+                MpHot h;
+                memset(&h, 0, sizeof h);
+                h.gen  = S.hot[i].gen;
+                h.live = 1;
+                h.type = (int8_t) MAPPOINT_TRIANGULATED;
+                h.id   = id0 + (u64) r;
+                h.pos[0] = p[0], h.pos[1] = p[1], h.pos[2] = p[2];
+                h.observed = 2, h.used = 2; // addObservation + increaseUsedTimes for both features (:773-774, :780-781)
+                h.last.frame = fr, h.last.gen = S.frame[fr].gen, h.last.row = row_ref;
+                S.hot[i] = h;
+                MpCold c;
+                memset(&c, 0, sizeof c);
+                c.born_fid  = cur_fid;
+                c.ref_frame = fr;
+                c.ref_gen   = S.frame[fr].gen;
+                c.ref_kp    = S.tri_ref_undis[k];
+                c.depth     = ((depth < 1.0) || (depth > 200.0)) ? 10.0 /*DEFAULT_DEPTH*/ : depth;
+                S.cold[i]   = c;
+                double pccx, pccy, pcrx, pcry;
+                pixel2cam(C.cam, S.tri_cur_undis[k], pccx, pccy);
+                pixel2cam(C.cam, S.tri_ref_undis[k], pcrx, pcry);
+                Row a;
+                a.id = h.id, a.mp = i, a.mpgen = h.gen, a.kp = S.tri_cur_undis[k], a.kpd = S.pts2d_cur[k];
+                a.vel[0] = S.velocity_cur[k][0], a.vel[1] = S.velocity_cur[k][1], a.pcx = pccx, a.pcy = pccy;
+                a.lk_idx = k < S.n_cand_lk ? S.cand_lk_idx[k] : -1, a.type = (int8_t) FEATURE_TRIANGULATED, a.outlier = 0, a.pad_[0] = a.pad_[1] = 0;
+                S.frame[S.cur].row[row_cur] = a; // :769-774
+                Row b;
+                b.id = h.id, b.mp = i, b.mpgen = h.gen, b.kp = S.tri_ref_undis[k], b.kpd = S.pts2d_ref[k];
+                b.vel[0] = S.velocity_ref[k][0], b.vel[1] = S.velocity_ref[k][1], b.pcx = pcrx, b.pcy = pcry;
+                b.lk_idx = -1, b.type = (int8_t) FEATURE_TRIANGULATED, b.outlier = 0, b.pad_[0] = b.pad_[1] = 0;
+                S.frame[fr].row[row_ref] = b; // :776-781 (a freshly drawn id is in no frame yet)
+                S.frame[S.cur].unupd[unupd0 + r]     = i; // :784
+                S.frame[S.cur].unupd_gen[unupd0 + r] = h.gen;
+            }
+        }
+        acc_before += popc(m);
+    }
+    sync();
+    if (!S.overflow) {
+        const int total = acc_before;
+        const int from_free = total < n_free0 ? total : n_free0;
+        S.n_free_mps = n_free0 - from_free;
+        S.n_mps      = n_mps0 + (total - from_free);
+        S.mappoint_id = id0 + (u64) total;
+        S.frame[S.cur].n_rows  = cur_rows0 + total;
+        S.frame[S.cur].n_unupd = unupd0 + total;
+        for (int u = 1; u < n_touched; u++) S.frame[touched[u]].n_rows = touched_old[u] + touched_cnt[u];
     }
     sync();
     for (int u = 0; u < n_touched; u++) order_extend(S.frame[touched[u]], touched_old[u], buckets_after, X);
@@ -1477,11 +1553,11 @@ TC_FN void stage_on_detect_a(Stream &S, const Cfg &C, Io &io, Scratch &X) {
 TC_FN void stage_on_lk(Stream &S, const Cfg &C, Io &io, const uint32_t *buckets_after, Scratch &X) {
     if (S.done) return;
     if (S.mode == M_TRACK) finish_track_mappoint(S, C, io, buckets_after, X);
-    S.ref_tracked = mid_track_reference(S, C, io) ? 1 : 0;
+    S.ref_tracked = mid_track_reference(S, C, io, X) ? 1 : 0;
     *io.lk_count  = 0;
 }
 // stage 4 (after RANSAC) -> triangulation
-TC_FN void stage_on_ransac(Stream &S, const Cfg &C, Io &io) {
+TC_FN void stage_on_ransac(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     if (S.done) return;
     if (S.ref_tracked) finish_track_reference(S, io);
     *io.rs_count = 0;
@@ -1490,11 +1566,11 @@ TC_FN void stage_on_ransac(Stream &S, const Cfg &C, Io &io) {
             finish(S, TRACK_INITIALIZING);
             return;
         }
-        queue_triangulation(S, C, io); // :182
+        queue_triangulation(S, C, io, X); // :182
         return;
     }
     S.kf_state = check_keyframe_state(S, C); // :212
-    if ((S.kf_state == KEYFRAME_NORMAL) || (S.kf_state == KEYFRAME_REMOVE_OLDEST)) queue_triangulation(S, C, io); // :215-217
+    if ((S.kf_state == KEYFRAME_NORMAL) || (S.kf_state == KEYFRAME_REMOVE_OLDEST)) queue_triangulation(S, C, io, X); // :215-217
 }
 // stage 5 (after triangulation) -> detection B
 TC_FN void stage_on_triangulate(Stream &S, const Cfg &C, Io &io, const uint32_t *buckets_after, Scratch &X) {

@@ -188,7 +188,7 @@ void TableTracker::coreAdvance(int stage, StageBatch &done, StageBatch &next) {
     }
     case 4:
         if (done.rs_off.size() > 1 && S.rs_set >= 0) memcpy(arena_.rs_mask.data(), done.rs_mask.data() + done.rs_off[0], (size_t) (done.rs_off[1] - done.rs_off[0]));
-        tc::stage_on_ransac(S, core_cfg_, io);
+        tc::stage_on_ransac(S, core_cfg_, io, *core_scratch_);
         coreQueueOutputs(next, false, false, false, false, true);
         break;
     case 5:

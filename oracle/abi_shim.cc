@@ -756,7 +756,7 @@ int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, int stride, i
                                    C.reprojection_error_std, 0.99, a.rs_mask.data());
                 if (rc) return rc;
             }
-            tc::stage_on_ransac(S, C, io);
+            tc::stage_on_ransac(S, C, io, t->scratch);
             work[3] = a.tri_count;
             if (a.tri_count > 0) {
                 rc = icg_triangulate(ctx, a.tri_count, a.tri_T0.data(), a.tri_T1.data(), a.tri_n_tcw, a.tri_Tcw.data(), a.tri_pc0.data(), a.tri_pc1.data(),
