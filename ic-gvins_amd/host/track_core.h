@@ -79,6 +79,7 @@ struct Scratch {
     int32_t bucket[MAX_BUCKETS];
     int32_t tmp_bucket[MAX_BUCKETS];
     u64 key[MAX_ROWS];
+    uint32_t want[MAX_ROWS + 2]; // bucket counts after k insertions for the rows an order_extend pass enters (a copy of buckets_after)
 };
 
 enum { TRACK_FIRST_FRAME = 0, TRACK_INITIALIZING = 1, TRACK_TRACKING = 2, TRACK_PASSED = 3, TRACK_LOST = 4 }; // tracking.h:38-44
@@ -603,15 +604,38 @@ TC_FN void map_insert_keyframe(Stream &S, const Cfg &C, int h) { // map.cc:27-61
     } else {
         S.map_kf_frame[at] = h;
     }
-    for (int k = 0; k < f.n_unupd; k++) {
-        const uint32_t i = f.unupd[k];
-        if (!mp_valid(S, i, f.unupd_gen[k])) continue;
-        if (!S.hot[i].in_map) {
-            S.hot[i].in_map = 1;
-            log_landmark(S, S.hot[i].id, i, 1); // map.cc:56-61
-            S.n_landmarks++;
+    // the frame's new map points enter the map (map.cc:56-61), in list order: a chunk per step, the history entries by rank
+    int n_in = 0;
+    const int log0 = S.n_log;
+    for (int base = 0; base < f.n_unupd; base += NL) {
+        const int k = base + lane();
+        bool in     = false;
+        uint32_t i  = 0;
+        if (k < f.n_unupd) {
+            i  = f.unupd[k];
+            in = mp_valid(S, i, f.unupd_gen[k]) && !S.hot[i].in_map;
         }
+        const u64 m = ballot(in);
+        if (in) {
+            S.hot[i].in_map = 1;
+            const int at    = log0 + n_in + popc(m & lanes_below());
+            if (at < LOG_CAP) {
+                LmLog e;
+                e.id = S.hot[i].id, e.mp = i, e.op = 1;
+                S.log[at] = e;
+            }
+        }
+        n_in += popc(m);
     }
+    if (log0 + n_in > LOG_CAP) {
+        S.overflow |= OVF_LOG;
+        S.log_dropped += log0 + n_in - LOG_CAP;
+        S.n_log = LOG_CAP;
+    } else {
+        S.n_log = log0 + n_in;
+    }
+    S.n_landmarks += n_in;
+    sync();
     if (S.n_map_kf > C.window_size) S.is_window_full = 1;
 }
 TC_FN void map_remove_keyframe(Stream &S, int h, bool isremovemappoint) { // map.cc:89-127
@@ -747,9 +771,10 @@ TC_FN void order_extend(Frame &f, int n_old, const uint32_t *buckets_after, Scra
     for (int k = lane(); k < n; k += NL) X.key[k] = f.row[k].id;
     for (int k = lane(); k < n_old; k += NL) X.next[k] = f.next[k];
     for (int b = lane(); b < nb; b += NL) X.bucket[b] = n_old ? f.bucket[b] : H_EMPTY;
+    for (int k = n_old + 1 + lane(); k <= n; k += NL) X.want[k] = buckets_after[k]; // (one HBM load per insertion otherwise: ~1 us each)
     sync();
     for (int i = n_old; i < n; i++) {
-        const int want = (int) buckets_after[i + 1];
+        const int want = (int) X.want[i + 1];
         if (want != nb) { // _M_rehash_aux over the i nodes inserted so far
             for (int b = lane(); b < want; b += NL) X.tmp_bucket[b] = H_EMPTY;
             sync();
