@@ -41,9 +41,9 @@ def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, 
     """
     cores_rank = float(usable_cores) / float(max(1, world))
     # engine (round 4).  The device-resident tracker (csrc/tracker.hip: the streams' state in HBM, one launch chain + one wait per step) needs
-    # 0.3-0.5 host cores per GPU: 111 k frames/s at the driver's command, 110 k with every thread of the process confined to 2 CPUs, 106 k on ONE.
-    # The track table on the host (rounds 1-3) overlaps its host logic with the other groups' kernels for free and is 7 % faster on a GPU that
-    # has the cores for it (119.6 k with 5.2 cores busy) — and collapses to 44 k on 2 CPUs (profiles/r04_cpu_quota.md).  So: the table where
+    # 0.3-0.5 host cores per GPU: 116 k frames/s at the driver's command, 108 k with every thread of the process confined to 2 CPUs, 116 k on ONE.
+    # The track table on the host (rounds 1-3) overlaps its host logic with the other groups' kernels for free and is 3-5 % faster on a GPU that
+    # has the cores for it (119-122 k with 4.3-4.6 cores busy) — and collapses to 44 k on 2 CPUs (profiles/r04_cpu_quota.md).  So: the table where
     # a rank has >= 6 cores, the device tracker below.  Same results either way, state for state (tests/test_gpu_device_tracker.py,
     # tests/test_host_engines_cpu.py; the 2-rank bench self-test runs one rank count on each engine and compares the digests).
     engine = engine_override or ("table" if cores_rank >= 6.0 else "device")
