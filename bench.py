@@ -538,6 +538,8 @@ def compact_line(full, details_path):
             c["c4"]["frontend"]["cpu_baseline"] = _pick(c4["frontend"]["cpu_baseline"], ("value", "unit", "cores", "kind"))
     c["c1"] = _pick(full.get("c1"), ("value", "unit", "cores", "kind"))
     c["pcie_inclusive"] = _pick(full.get("pcie_inclusive"), ("value", "unit", "config", "host_to_device_GBps", "frac_whole_path"))
+    c["engine_twin"] = _pick(full.get("engine_twin"), ("engine", "value", "unit", "streams", "groups", "cpu_cores_busy", "digests_equal_to_headline_run",
+                                                       "digests_compared", "ok", "error"))
     c["rates"] = full.get("rates")
     c["forward_control"] = _pick(full.get("forward_control"), ("value", "unit", "streams", "groups", "frames_per_stream", "rates", "tracking_state_fraction"))
     for k in ("marg", "ins", "cull"):
@@ -625,6 +627,9 @@ def main():
                     help="tracker engine of the host executor: device = the device-resident tracker (state in HBM, one launch chain + one wait per "
                          "step); table = the host track table between batched device calls (rounds 1-3); auto (default) = sharding.host_plan's choice: the table where the rank has >= 6 host cores, "
                          "the device tracker below")
+    ap.add_argument("--no-engine-twin", action="store_true",
+                    help="skip the engine_twin block (the same run on the OTHER tracker engine — device-resident tracker vs track table — with every "
+                         "stream's digest compared between the two)")
     ap.add_argument("--details", default=os.environ.get("ICG_BENCH_DETAILS", ""),
                     help="file for the long per-group / per-step series and notes (default gpurun_out/bench_details.json); the contract line stays compact")
     args = ap.parse_args()
@@ -1197,6 +1202,29 @@ def main():
                 "note": "named variant of the headline configuration with input_residency = pinned host: frames in pinned host memory, uploaded per "
                         "frame inside the timed region (what a live camera deployment — B3's host-pointer contract — sees); never `value`"}
 
+    # ---- the same run on the OTHER engine: the device-resident tracker where the headline ran on the track table (and vice versa).  Same streams,
+    # same frames, same number of steps — so every stream's digest must be the headline run's, and the block carries the twin's rate and host load.
+    engine_twin = None
+    if rank == 0 and world == 1 and not args.no_engine_twin and (selftest or not args.host_frames) and args.engine in ("table", "device"):
+        other = "device" if args.engine == "table" else "table"
+        try:
+            tplan = sharding.host_plan(usable_host_cores(), 1, 0, streams_override=B, engine_override=other)
+            os.environ["ICG_TRACK_ENGINE"] = other
+            ft = run_frontend(torch, hip, w=w, h=h, nfeat=nfeat, window=10, B=B, G=tplan["groups"], ring=args.ring, prime=args.prime, warmup=args.warmup,
+                              steps=args.steps, rank=0, local_rank=local_rank, host_threads=host_threads, host_frames=bool(selftest), profile=False,
+                              barrier=dev_sync, ncpu=ncpu, host_lib=selftest_lib, dev_sync=dev_sync)
+            same = [a["digest"] == b["digest"] for a, b in zip(stats, ft["stats"])]
+            engine_twin = {"engine": other, "value": None if selftest else round(B * args.steps / ft["elapsed"], 1), "unit": "frames/s", "streams": B,
+                           "groups": tplan["groups"], "timed_steps": args.steps, "cpu_cores_busy": ft["cpu_cores_busy"],
+                           "digests_equal_to_headline_run": int(sum(same)), "digests_compared": len(same), "ok": bool(all(same)),
+                           "note": "the same streams, frames and step counts on the other tracker engine (device-resident tracker: state in HBM, one "
+                                   "launch chain + one wait per step; track table: host logic between batched device calls); results must be "
+                                   "identical stream by stream"}
+        except Exception as e:  # (never takes the line down)
+            engine_twin = {"engine": other, "ok": False, "error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            os.environ["ICG_TRACK_ENGINE"] = args.engine
+
     # ---- forward-only control: the ping-pong ring reverses the motion every ring-1 frames; here fewer streams fly past
     # the wall in ONE direction for the whole run (ring = prime + warm-up + timed frames), and the per-frame event rates of both runs stand
     # side by side: keyframes, detections, RANSAC sets, triangulated points, created map points, LK points
@@ -1292,6 +1320,7 @@ def main():
             "c4": c4,
             "pcie_inclusive": pcie,
             "forward_control": forward,
+            "engine_twin": engine_twin,
             "rates": fe["rates"],
             "hbm_peak_measured_GBps": round(hbm_peak_measured, 1) if hbm_peak_measured else None,
             "kernel_ceiling": ceiling,

@@ -116,6 +116,9 @@ def test_bench_main_runs_two_ranks_as_the_driver_launches_it(tmp_path):
         assert line["selftest"]["frames"] == 4 * 3                       # all ranks' frames of the timed region, summed
         assert line["quality"]["tracking_state_fraction"] == 1.0
         assert line["ms_per_step"] > 0 and line["selftest"]["elapsed_max_s"] > 0
+    # the single-rank run carries the engine twin: the same four streams on the other engine (device tracker on the shim's CPU backend), digest by digest
+    assert one["engine_twin"]["engine"] == "device" and one["engine_twin"]["ok"] is True and one["engine_twin"]["digests_compared"] == 4
+    assert two.get("engine_twin") is None  # (N > 1 measures the sharded front-end only)
     assert two["config"]["streams_per_gpu"] == 2 and two["config"]["frames_per_step"] == 4 and "pinned" in two["config"]["cpu_slice_per_rank"]
     # rank order of the gathered digests = global stream order: the same four streams, wherever they ran
     # (the gathered digests travel as int64: 63 bits)

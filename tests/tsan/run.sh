@@ -36,6 +36,30 @@ for eng in ("table", "object"):
     rc.check_refinement(LIB, n_frames=24, engine=eng)
 print("done")
 PY
+  # 6. (round 4) the tracker core — fixed-capacity blocks, the source of the device-resident tracker's stage kernels — as the host engine
+  #    ("core") and behind the tracker ABI's CPU backend ("device": download / import / view / absorb / export / upload, history drains with
+  #    a low threshold): culling, refinement and a 70-frame stream whose window rolls over, under AddressSanitizer + UBSan
+  ICG_TRACKER_LOG_DRAIN=30 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) PYTHONPATH=$ROOT/ic-gvins_amd:$ROOT:$ROOT/tests python3 - > $W/6_tracker_core.log 2>&1 <<PY
+import oracle_lib, cull_checks as cc, refine_checks as rc
+import ctypes as C, numpy as np, harness as H
+LIB = "$W/src/oracle/libicgvins_host_oracle.so"
+oracle = oracle_lib.load()
+for eng in ("core", "device"):
+    cc.check_window_culling(LIB, oracle, engine=eng)
+    rc.check_refinement(LIB, n_frames=24, engine=eng)
+    w, h = 640, 480
+    cam = H.camera_for(w, h)
+    sb = H.StreamBatch(LIB, 2, w, h, cam, max_features=100, engine=eng)
+    scene = H.SynthScene(sb.lib, w, h, cam, tex_size=1024, threads=2)
+    for k in range(70):
+        frames = [scene.render(k, stream=50 + s) if not (30 <= k < 33) else np.full((h, w), 90, np.uint8) for s in range(2)]
+        poses = np.stack([H.pose12(*scene.ins_pose(k, stream=50 + s)) for s in range(2)])
+        sb.step([f.ctypes.data for f in frames], w, np.full(2, 100.0 + k / 20.0), poses)
+        if k % 9 == 0:
+            sb.dump(0, 0), sb.features(1)
+    sb.close()
+print("done")
+PY
   ;;
 esac
-for f in $W/[1-5]_*.log; do echo "$(basename $f): $(grep -c 'WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error' $f || true) reports; $(tail -1 $f | cut -c1-140)"; done
+for f in $W/[1-6]_*.log; do echo "$(basename $f): $(grep -c 'WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error' $f || true) reports; $(tail -1 $f | cut -c1-140)"; done
