@@ -159,9 +159,26 @@ def csrc_sha1():
     return h.hexdigest()
 
 
-def pmc_provenance(pmc_file, streams_per_launch):
+def kernel_source_files(kernels):
+    """The csrc files the named kernels are compiled from: the .hip file that defines each (`void <kernel>(`), every header of csrc, and the
+    context (ctx.hip: arena and launch plumbing of every call).  A kernel that no file defines maps to '?' (never matches a record)."""
+    src = os.path.join(ROOT, "ic-gvins_amd", "csrc")
+    names = sorted(n for n in os.listdir(src) if n.endswith((".hip", ".h")))
+    files = set(n for n in names if n.endswith(".h") or n == "ctx.hip")
+    text = {n: open(os.path.join(src, n), errors="replace").read() for n in names if n.endswith(".hip")}
+    for k in kernels:
+        hit = [n for n, t in text.items() if ("void " + k + "(") in t]
+        files.update(hit if hit else ["?" + k])
+    return sorted(files)
+
+
+def pmc_provenance(pmc_file, streams_per_launch, kernels=None):
     """The committed counter summary only describes THIS build if it was collected on these kernel sources at this launch shape.
-    Returns None when it does, else the reason it is stale (the roofline block then omits traffic / issue_frac / valu)."""
+    Returns None when it does, else the reason it is stale (the roofline block then omits traffic / issue_frac / valu).
+    kernels: the kernels whose counters are about to be quoted — with a per-file record (_meta.csrc_files) only the files those kernels
+    are compiled from have to be unchanged (a new back-end entry point in reproj.hip does not age the LK counters); without the record,
+    or without `kernels`, every file of csrc has to be."""
+    import hashlib
     try:
         meta = json.load(open(os.path.join(ROOT, "profiles", pmc_file))).get("_meta")
     except Exception:
@@ -169,7 +186,15 @@ def pmc_provenance(pmc_file, streams_per_launch):
     if not meta:
         return "no provenance record (_meta) in " + pmc_file
     if meta.get("csrc_sha1") != csrc_sha1():
-        return "kernel sources changed since " + pmc_file + " was collected"
+        per = meta.get("csrc_files")
+        if not per or not kernels:
+            return "kernel sources changed since " + pmc_file + " was collected"
+        src = os.path.join(ROOT, "ic-gvins_amd", "csrc")
+        for name in kernel_source_files(kernels):
+            path = os.path.join(src, name)
+            now = hashlib.sha1(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
+            if now is None or per.get(name) != now:
+                return f"kernel sources changed since {pmc_file} was collected ({name})"
     spl = meta.get("streams_per_launch")
     if spl is not None and abs(float(spl) - float(streams_per_launch)) > 0.5:
         return f"collected at {spl} streams per launch, this run has {streams_per_launch:g}"
@@ -188,7 +213,7 @@ def committed_pmc(kernel, streams_per_launch=None):
     if streams_per_launch is not None:
         newest_round = os.path.basename(files[-1])[:3]
         for f in reversed([f for f in files if os.path.basename(f).startswith(newest_round)]):
-            if pmc_provenance(os.path.basename(f), streams_per_launch) is None:
+            if pmc_provenance(os.path.basename(f), streams_per_launch, [kernel]) is None:
                 pick = f
                 break
     return json.load(open(pick)).get(kernel), os.path.basename(pick)
@@ -511,7 +536,7 @@ def compact_line(full, details_path):
                               "algorithmic_bytes_per_launch", "avg_launch_us", "units_per_launch", "exclusive_us", "achieved_exclusive",
                               "frac_exclusive", "achieved_under_load", "frac_under_load", "frac_whole_path", "bytes_per_frame_algorithmic",
                               "exclusive_us_per_frame_all_kernels", "serialized_frames_per_s", "ceiling_frames_per_s", "value_over_ceiling",
-                              "issue_frac", "pmc_stale"))
+                              "issue_frac", "pmc_stale", "valu_stale"))
     if r and r.get("valu"):
         c["roofline"]["valu"] = _pick(r["valu"], ("wave_instructions_per_frame", "lk_share", "frac"))
     for k in ("cpu_baseline", "cpu_baseline_allcores", "cpu_baseline_reference_decomposition", "cpu_baseline_reference_tracker"):
@@ -546,6 +571,8 @@ def compact_line(full, details_path):
         c[k] = _pick(full.get(k), ("value", "unit", "kernel_us"))
         if c[k] and (full[k].get("cpu_baseline")):
             c[k]["cpu_baseline"] = _pick(full[k]["cpu_baseline"], ("value", "unit", "cores", "kind"))
+        if c[k] and full[k].get("batched"):
+            c[k]["batched"] = _pick(full[k]["batched"], ("windows_per_batch", "value", "unit", "speedup", "max_rel_diff_Hp_vs_one_by_one", "error"))
     rpl = full.get("replay")
     if rpl:
         c["replay"] = _pick(rpl, ("value", "unit", "error"))
@@ -754,7 +781,7 @@ def main():
             # HBM traffic and issue utilisation of the same kernel from the committed rocprofv3 --pmc passes of THIS configuration
             # (profiles/collect.sh runs bench.py with the default streams/groups): per unit x the units of one launch here
             pmc, pmc_file = committed_pmc("k_" + dom, per_launch_streams)
-            stale = pmc_provenance(pmc_file, per_launch_streams) if pmc_file else "no committed counter summary"
+            stale = pmc_provenance(pmc_file, per_launch_streams, ["k_" + dom]) if pmc_file else "no committed counter summary"
             if stale:
                 roofline["pmc_stale"] = stale  # counters of another build / launch shape are not quoted next to this measurement
                 pmc, pmc_file = None, None
@@ -771,7 +798,14 @@ def main():
                     if pmc.get("SQ_WAVE_CYCLES") else None
                 roofline["issue_frac_how"] = f"profiles/{pmc_file}: SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of k_{dom} (share of its wave-cycles in which an instruction issued)"
             if pmc_file:
-                roofline["valu"] = frontend_valu(pmc_file, per_launch_streams, fps / max(1, world))  # per GPU: the peak is one chip's
+                # (the sum runs over every image kernel of the summary: all of their sources have to be the collected ones)
+                image_kernels = [k for k, v in json.load(open(os.path.join(ROOT, "profiles", pmc_file))).items()
+                                 if k.startswith("k_") and k != "k_reproj_eval" and isinstance(v, dict)]
+                valu_stale = pmc_provenance(pmc_file, per_launch_streams, image_kernels)
+                if valu_stale:
+                    roofline["valu_stale"] = valu_stale
+                else:
+                    roofline["valu"] = frontend_valu(pmc_file, per_launch_streams, fps / max(1, world))  # per GPU: the peak is one chip's
             if dom == "lk_track_fb":
                 roofline["note"] = ("LK keeps its working set in LDS/VGPRs by design (8.5 KB of image per point, ~9.3k VALU instructions on it): HBM "
                                     "is the wrong roof, and so is raw VALU issue (`valu.frac`): with 48 stream groups on 20 hardware queues every "
@@ -971,6 +1005,27 @@ def main():
             pc = marg_phases(C.CDLL(ensure_oracle_host()))
             marg["cpu_baseline"] = {"value": round(float(pc.sum()), 3), "unit": "ms per marginalization", "cores": 1, "kind": "port",
                                     "sample": "the same host layer on the oracle shim; evaluate+construct " + str(round(float(pc[0] + pc[1]), 3)) + " ms"}
+
+        # the marginalizations of many streams in one pass (MarginalizationBatch, host/marg_batch.h): one evaluation launch, one assembly +
+        # elimination launch sequence and one read-back for all windows; the per-window host phases on the pool
+        try:
+            nmb = 256
+            bu.backend_marginalize_batch(hl, Pm, 8, 0)  # (contexts, pool, code paged in)
+            one = bu.backend_marginalize_batch(hl, Pm, nmb, 1)
+            bat = min((bu.backend_marginalize_batch(hl, Pm, nmb, 0) for _ in range(3)), key=lambda d: d["seconds"])
+            scale = np.abs(one["Hp"]).max(axis=(1, 2))
+            marg["batched"] = {"windows_per_batch": nmb, "value": round(nmb / bat["seconds"], 1), "unit": "windows/s",
+                               "batch_ms": round(bat["seconds"] * 1e3, 2),
+                               "one_by_one": {"value": round(nmb / one["seconds"], 1), "unit": "windows/s",
+                                              "what": "MarginalizationInfo::marginalization() window after window on one ReprojectionBatch (one host thread)"},
+                               "speedup": round(one["seconds"] / bat["seconds"], 2),
+                               "windows_structured_dense": [bat["structured"], bat["dense"]],
+                               "max_rel_diff_Hp_vs_one_by_one": float((np.abs(bat["Hp"] - one["Hp"]).max(axis=(1, 2)) / scale).max()),
+                               "note": "MarginalizationBatch: jittered copies of the C2 window; per batch one icg_reproj_eval_windows, one "
+                                       "icg_reproj_schur_windows and one icg_reproj_landmark_diag_windows; M1 bookkeeping, host factors, the "
+                                       "pose/mix-block M3 and the eigen linearization per window on the host pool"}
+        except Exception as e:  # (a next-row block: it must not take the line down)
+            marg["batched"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- f3: per-observation reprojection error + isGoodToTrack gate of the culling / statistics pass ---------------------------
     cull = None

@@ -1504,6 +1504,41 @@ extern "C" int icg_reproj_solve_backsub_windows(icg_ctx *ctx, int P, const int32
     return c.finish();
 }
 
+// h_ll of every landmark (global landmark order of the partition) from the window systems left resident by the last
+// icg_reproj_schur_windows*: the diagonal (P + l, P + l) of each window's N x N block
+__global__ void k_lm_diag_w(const win_desc *wd, int P, const double *sys, double *h_ll) {
+    const win_desc W = wd[blockIdx.y];
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= W.L) return;
+    const size_t N = (size_t) P + W.L;
+    h_ll[W.lm_begin + l] = sys[W.sys_off + (size_t) (P + l) * N + P + l];
+}
+
+extern "C" int icg_reproj_landmark_diag_windows(icg_ctx *ctx, double *h_ll) {
+    if (!ctx || !h_ll) return ICG_ERR_INVALID;
+    if (!ctx->wsys_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident window systems: call icg_reproj_schur_windows first");
+    const int W = ctx->n_windows, P = ctx->wsys_P, n_lm = ctx->w_lm_off[(size_t) W];
+    if (n_lm == 0) return ICG_OK;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    std::vector<win_desc> wd;
+    build_win_desc(ctx, P, nullptr, nullptr, nullptr, nullptr, nullptr, wd);
+    int Lmax = 1;
+    for (int w = 0; w < W; w++) Lmax = std::max(Lmax, (int) wd[(size_t) w].L);
+    icg_call c(ctx);
+    int rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(double) * (size_t) n_lm + 4096);
+    if (rc) return rc;
+    const win_desc *d_wd = c.in(wd.data(), (size_t) W);
+    if ((rc = c.seal())) return rc;
+    double *d_out = c.out(h_ll, (size_t) n_lm);
+    ICG_LAUNCH_GUARD(c);
+    {
+        icg_prof_scope ps(ctx, "schur_reduce");
+        hipLaunchKernelGGL(k_lm_diag_w, dim3((Lmax + 255) / 256, W), dim3(256), 0, ctx->stream, d_wd, P, (const double *) ctx->d_sys, d_out);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}
+
 extern "C" int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
     if (!ctx || !delta_c || !delta_l) return ICG_ERR_INVALID;
     if (!ctx->wsys_valid || ctx->wsys_P != P) return icg_fail(ctx, ICG_ERR_INVALID, "no resident window systems of size %d: call icg_reproj_schur_windows first", P);

@@ -342,6 +342,7 @@ int icgh_core_order_selftest(uint64_t seed, int n_first, int n_more, int rounds)
 #include "misc_hip.h"
 #include "solver_hip.h"
 #include "solver_batch_hip.h"
+#include "marg_batch.h"
 #include "culling_hip.h"
 #include "window_visual.h"
 
@@ -374,6 +375,20 @@ public:
 
 private:
     double x0_[7], w_;
+};
+// a host factor on a one-dimensional block (an inverse depth): residual = w (x - x0).  On a landmark it breaks the structure the
+// landmark-eliminated marginalization relies on (tests: that window then takes the dense M2 + M3)
+class ScalarPriorFactor : public ceres::SizedCostFunction<1, 1> {
+public:
+    ScalarPriorFactor(double x0, double weight) : x0_(x0), w_(weight) {}
+    bool Evaluate(const double *const *parameters, double *residuals, double **jacobians) const override {
+        residuals[0] = w_ * (parameters[0][0] - x0_);
+        if (jacobians && jacobians[0]) jacobians[0][0] = w_;
+        return true;
+    }
+
+private:
+    double x0_, w_;
 };
 } // namespace
 
@@ -500,6 +515,130 @@ int icgh_backend_marginalize(int n, const double *obs_soa, const int32_t *idx_i,
                 off += (size_t) rem_size[b];
             }
             if (!factor.Evaluate(params.data(), marg_res, nullptr)) return -3;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        set_err(err, errlen, e.what());
+        return -1;
+    }
+}
+
+// The marginalizations of n_windows streams (M1-M4 of each: the window of icgh_backend_marginalize, window w > 0 with its poses and inverse
+// depths moved by a deterministic jitter of relative size `jitter`), mode 0: one MarginalizationBatch (marg_batch.h: the windows share
+// their device launches), mode 1: one MarginalizationInfo::marginalization() after the other on a ReprojectionBatch (what a stream on its
+// own does).  dense_window >= 0: that window gets a host factor on one of its inverse depths, which takes it off the landmark-eliminated
+// path in both modes.  Outputs per window (r = sizes[1], equal for all windows): Hp (r x r), bp, J0 (r x r), e0; counts = windows on the
+// structured / dense path (mode 0), seconds = wall time of the marginalizations alone (problem construction excluded).
+int icgh_backend_marginalize_batch(int mode, int n_windows, int dense_window, double jitter, int n, const double *obs_soa, const int32_t *idx_i,
+                                   const int32_t *idx_j, const int32_t *idx_lm, int n_poses, const double *poses, const double *ext, int n_lm,
+                                   const double *invdepth, double td, double huber_delta, double prior_weight, int host_threads, int32_t *sizes,
+                                   double *Hp, double *bp, double *J0, double *e0, int32_t *counts, double *seconds, char *err, int errlen) {
+    try {
+        struct Win {
+            vector<double> P, E, D;
+            double TD;
+            std::unordered_map<long, long> ids;
+            std::shared_ptr<MarginalizationInfo> info;
+            vector<std::shared_ptr<ReprojectionFactor>> factors;
+            vector<double> pose0_prior;
+        };
+        vector<std::unique_ptr<Win>> wins;
+        uint64_t lcg = 0x9E3779B97F4A7C15ull;
+        auto rnd     = [&] { // uniform in [-1, 1)
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            return (double) ((lcg >> 11) & ((1ull << 53) - 1)) / (double) (1ull << 52) - 1.0;
+        };
+        auto loss = huber_delta > 0 ? std::make_shared<HuberLossHip>(huber_delta) : nullptr;
+        for (int w = 0; w < n_windows; w++) {
+            std::unique_ptr<Win> W(new Win);
+            W->P.assign(poses, poses + 7 * (size_t) n_poses), W->E.assign(ext, ext + 7), W->D.assign(invdepth, invdepth + n_lm), W->TD = td;
+            if (w > 0) {
+                for (int k = 0; k < n_poses; k++)
+                    for (int c = 0; c < 3; c++) W->P[7 * (size_t) k + c] += jitter * rnd();
+                for (int l = 0; l < n_lm; l++) W->D[(size_t) l] *= 1.0 + jitter * rnd();
+            }
+            for (int k = 0; k < n_poses; k++) W->ids[reinterpret_cast<long>(&W->P[7 * (size_t) k])] = k;
+            for (int l = 0; l < n_lm; l++) W->ids[reinterpret_cast<long>(&W->D[(size_t) l])] = 100000 + l;
+            W->ids[reinterpret_cast<long>(W->E.data())] = 900000;
+            W->ids[reinterpret_cast<long>(&W->TD)]       = 900001;
+            W->info = std::make_shared<MarginalizationInfo>();
+            W->info->updateParamtersIds(W->ids);
+            for (int k = 0; k < n; k++) {
+                auto o = [&](int c) { return obs_soa[(size_t) c * n + k]; };
+                W->factors.push_back(std::make_shared<ReprojectionFactor>(Vector3d(o(0), o(1), o(2)), Vector3d(o(3), o(4), o(5)), Vector3d(o(6), o(7), o(8)),
+                                                                          Vector3d(o(9), o(10), o(11)), o(12), o(13), o(14)));
+                double *pi = &W->P[7 * (size_t) idx_i[k]], *pj = &W->P[7 * (size_t) idx_j[k]], *lm = &W->D[(size_t) idx_lm[k]];
+                W->info->addResidualBlockInfo(
+                    std::make_shared<ResidualBlockInfo>(W->factors.back(), loss, vector<double *>{pi, pj, W->E.data(), lm, &W->TD}, vector<int>{0, 3}));
+            }
+            W->pose0_prior.assign(W->P.begin(), W->P.begin() + 7);
+            W->pose0_prior[0] += 0.01;
+            W->info->addResidualBlockInfo(std::make_shared<ResidualBlockInfo>(std::make_shared<PosePriorFactor>(W->pose0_prior.data(), prior_weight),
+                                                                              nullptr, vector<double *>{&W->P[0]}, vector<int>{0}));
+            if (w == dense_window && n > 0) {
+                double *lm = &W->D[(size_t) idx_lm[0]];
+                W->info->addResidualBlockInfo(std::make_shared<ResidualBlockInfo>(std::make_shared<ScalarPriorFactor>(*lm * 1.01, 0.5 * prior_weight),
+                                                                                  nullptr, vector<double *>{lm}, vector<int>{0}));
+            }
+            wins.push_back(std::move(W));
+        }
+        vector<char> ok((size_t) n_windows, 0);
+        counts[0] = counts[1] = 0;
+        auto add_factors = [&](Win &W, const std::function<void(const ReprojectionFactor *, double *, double *, double *, double *, double *)> &add) {
+            for (int k = 0; k < n; k++)
+                add(W.factors[(size_t) k].get(), &W.P[7 * (size_t) idx_i[k]], &W.P[7 * (size_t) idx_j[k]], W.E.data(), &W.D[(size_t) idx_lm[k]], &W.TD);
+        };
+        std::string what;
+        std::chrono::steady_clock::time_point t0, t1;
+        if (mode == 0) {
+            MarginalizationBatch mb(0, huber_delta, host_threads);
+            for (auto &W : wins) {
+                const int w = mb.addWindow(W->info);
+                add_factors(*W, [&](const ReprojectionFactor *f, double *pi, double *pj, double *e, double *lm, double *t) { mb.addReprojectionFactor(w, f, pi, pj, e, lm, t); });
+            }
+            t0 = std::chrono::steady_clock::now();
+            const bool good = mb.marginalize(&ok);
+            t1 = std::chrono::steady_clock::now();
+            if (!good) what = mb.error();
+            counts[0] = mb.structuredWindows(), counts[1] = mb.denseWindows();
+        } else {
+            ReprojectionBatch batch(0);
+            double total = 0;
+            for (size_t w = 0; w < wins.size(); w++) {
+                Win &W = *wins[w];
+                batch.clear();
+                add_factors(W, [&](const ReprojectionFactor *f, double *pi, double *pj, double *e, double *lm, double *t) {
+                    batch.add(const_cast<ReprojectionFactor *>(f), pi, pj, e, lm, t);
+                });
+                W.info->setReprojectionBatch(&batch);
+                auto a = std::chrono::steady_clock::now();
+                batch.finalize();
+                ok[w] = W.info->marginalization() ? 1 : 0;
+                total += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+                if (!ok[w]) what = batch.error();
+                counts[MarginalizationInfo::lastWasStructured() ? 0 : 1] += ok[w] ? 1 : 0;
+            }
+            t0 = std::chrono::steady_clock::time_point();
+            t1 = t0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(total));
+        }
+        *seconds = std::chrono::duration<double>(t1 - t0).count();
+        for (int w = 0; w < n_windows; w++)
+            if (!ok[(size_t) w]) {
+                set_err(err, errlen, ("marginalization of window " + std::to_string(w) + " failed: " + what).c_str());
+                return -2;
+            }
+        const size_t r = (size_t) wins[0]->info->remainedSize();
+        sizes[0] = wins[0]->info->marginalizedSize(), sizes[1] = (int32_t) r;
+        for (int w = 0; w < n_windows; w++) {
+            const MarginalizationInfo &I = *wins[(size_t) w]->info;
+            if ((size_t) I.remainedSize() != r) {
+                set_err(err, errlen, "windows of different remained size");
+                return -3;
+            }
+            memcpy(Hp + (size_t) w * r * r, I.Hp().data(), sizeof(double) * r * r);
+            memcpy(bp + (size_t) w * r, I.bp().data(), sizeof(double) * r);
+            memcpy(J0 + (size_t) w * r * r, I.linearizedJacobians().data(), sizeof(double) * r * r);
+            memcpy(e0 + (size_t) w * r, I.linearizedResiduals().data(), sizeof(double) * r);
         }
         return 0;
     } catch (const std::exception &e) {

@@ -427,6 +427,7 @@ std::atomic<int> g_marg_force_dense{getenv("ICG_MARG_DENSE") != nullptr ? 1 : 0}
 const double *MarginalizationInfo::lastPhaseMs() { return g_marg_phase_ms; }
 bool MarginalizationInfo::lastWasStructured() { return g_marg_structured; }
 void MarginalizationInfo::forceDense(bool on) { g_marg_force_dense.store(on ? 1 : 0); }
+bool MarginalizationInfo::denseForced() { return g_marg_force_dense.load() != 0; }
 
 bool MarginalizationInfo::marginalization() { // :73-101
     if (!updateParameterBlocksIndex()) {
@@ -504,10 +505,10 @@ bool MarginalizationInfo::updateParameterBlocksIndex() { // :232-253
     return marginalized_size_ > 0;
 }
 
-static bool onBatch(const std::shared_ptr<ResidualBlockInfo> &f, ReprojectionBatch *batch) {
+static bool onBatch(const std::shared_ptr<ResidualBlockInfo> &f, DeviceFactorSet *batch) {
     if (!batch) return false;
     auto *rf = dynamic_cast<ReprojectionFactor *>(f->costFunction().get());
-    if (rf == nullptr || rf->batch() != batch) return false;
+    if (rf == nullptr || !batch->owns(rf)) return false;
     return f->lossFunction() == nullptr || dynamic_cast<HuberLossHip *>(f->lossFunction().get()) != nullptr;
 }
 
@@ -590,6 +591,14 @@ bool MarginalizationInfo::constructEquation() { // :195-230
 // reference's own eigen / floor procedure on 15 columns instead of 15 + L).  Guard: every h_ll and every eigenvalue of the reduced
 // A-block at least 100 x the reference's floor — otherwise this returns false and the dense path runs.
 bool MarginalizationInfo::constructAndEliminateStructured() {
+    StructuredPlan plan;
+    if (!planStructured(plan)) return false;
+    double min_hll = 0;
+    if (!batch_->accumulateLandmarkEliminated(plan.camera_column_of, plan.P, plan.H.data(), plan.b.data(), &min_hll)) return false;
+    return finishStructured(plan, min_hll);
+}
+
+bool MarginalizationInfo::planStructured(StructuredPlan &plan) {
     if (!batch_ || batch_->size() == 0) return false;
     // landmark blocks of the batch: all marginalized, size 1, and touched by batch factors only
     std::unordered_map<long, char> is_lm;
@@ -620,8 +629,11 @@ bool MarginalizationInfo::constructAndEliminateStructured() {
     const int n_lm = (int) is_lm.size();
     const int P = L - n_lm, m = marginalized_size_ - n_lm, r = remained_size_;
     if (m < 0 || P != m + r) return false;
-    vector<double> H((size_t) P * P, 0.0), b((size_t) P, 0.0);
-    std::unordered_map<const double *, int> camera_column_of;
+    plan.P = P, plan.m = m, plan.r = r;
+    plan.H.assign((size_t) P * P, 0.0), plan.b.assign((size_t) P, 0.0);
+    plan.camera_column_of.clear();
+    vector<double> &H = plan.H, &b = plan.b;
+    std::unordered_map<const double *, int> &camera_column_of = plan.camera_column_of;
     for (const auto &factor : factors_) {
         const auto &blocks = factor->parameterBlocks();
         if (onBatch(factor, batch_)) {
@@ -655,8 +667,12 @@ bool MarginalizationInfo::constructAndEliminateStructured() {
             }
         }
     }
-    double min_hll = 0;
-    if (!batch_->accumulateLandmarkEliminated(camera_column_of, P, H.data(), b.data(), &min_hll)) return false;
+    return true;
+}
+
+bool MarginalizationInfo::finishStructured(StructuredPlan &plan, double min_hll) {
+    const int P = plan.P, m = plan.m, r = plan.r;
+    const vector<double> &H = plan.H, &b = plan.b;
     const double GUARD = 100.0 * EPS;
     if (!(min_hll > GUARD)) return false;
     // second step on the m leading columns: the reference's procedure (:170-192) on the reduced system

@@ -56,9 +56,25 @@ private:
     int slot_{-1};
 };
 
+// What MarginalizationInfo needs from the device side of ONE window: its reprojection factors, evaluated (with the robust correction)
+// and assembled there.  ReprojectionBatch implements it for a window with a context of its own, MarginalizationBatch (marg_batch.h) for a
+// window that shares its launches with the windows of many other streams.
+class DeviceFactorSet {
+public:
+    virtual ~DeviceFactorSet() = default;
+    virtual bool owns(const ReprojectionFactor *factor) const = 0;
+    virtual int size() const = 0;
+    virtual const vector<double *> &landmarkBlocks() const = 0;
+    virtual bool evaluateCorrected(double huber_delta) = 0;
+    virtual bool accumulateNormal(const std::unordered_map<const double *, int> &column_of, int local_size, double *H0, double *b0) = 0;
+    virtual bool accumulateLandmarkEliminated(const std::unordered_map<const double *, int> &camera_column_of, int P, double *H, double *b,
+                                              double *min_hll) = 0;
+    virtual const std::string &error() const = 0;
+};
+
 // Owns one icg_ctx.  Usage with Ceres: options.evaluation_callback = &batch; problem.AddResidualBlock(factor, loss, blocks)
 // and batch.add(factor, blocks) for every reprojection factor; call finalize() once before solving.
-class ReprojectionBatch : public ceres::EvaluationCallback {
+class ReprojectionBatch : public ceres::EvaluationCallback, public DeviceFactorSet {
 public:
     explicit ReprojectionBatch(int device = 0);
     ~ReprojectionBatch() override;
@@ -66,24 +82,25 @@ public:
     void add(ReprojectionFactor *factor, double *pose_i, double *pose_j, double *extrinsic, double *invdepth, double *td);
     void finalize();
     void clear();
-    int size() const { return (int) factors_.size(); }
+    int size() const override { return (int) factors_.size(); }
+    bool owns(const ReprojectionFactor *factor) const override { return factor != nullptr && factor->batch() == this; }
     // ceres::EvaluationCallback: gathers the CURRENT values of the user parameter arrays and launches one batch
     void PrepareForEvaluation(bool evaluate_jacobians, bool new_evaluation_point) override;
     // marginalization support: evaluate with the robust correction applied on device (residual_block_info.h:59-87)
-    bool evaluateCorrected(double huber_delta);
+    bool evaluateCorrected(double huber_delta) override;
     // H0 += J^T J, b0 -= J^T e of the last evaluation (marginalization_info.h:195-230); columns by parameter address
-    bool accumulateNormal(const std::unordered_map<const double *, int> &column_of, int local_size, double *H0, double *b0);
+    bool accumulateNormal(const std::unordered_map<const double *, int> &column_of, int local_size, double *H0, double *b0) override;
     // the same normal equations with EVERY inverse-depth block of the batch eliminated on the device (icg_reproj_schur, no damping):
     // H (P x P, row-major) += Hcc - G^T diag(1/h_ll) G, b += bc - G^T (b_l / h_ll) in the camera columns given by parameter address
     // (absent = constant block); min_hll = the smallest landmark diagonal (the caller's conditioning guard)
     bool accumulateLandmarkEliminated(const std::unordered_map<const double *, int> &camera_column_of, int P, double *H, double *b,
-                                      double *min_hll);
-    const vector<double *> &landmarkBlocks() const { return lm_ptrs_; }
+                                      double *min_hll) override;
+    const vector<double *> &landmarkBlocks() const override { return lm_ptrs_; }
     // slices of the last fetched evaluation, read in place from the context's pinned staging memory (valid while prepared())
     const double *residual(int slot) const { return r_view_ + 2 * (size_t) slot; }
     const double *jacobian(int slot) const { return J_view_ + 46 * (size_t) slot; }
     bool prepared(bool with_jacobians) const { return prepared_ && (!with_jacobians || has_jac_); }
-    const std::string &error() const { return error_; }
+    const std::string &error() const override { return error_; }
     // completion waits of this batch's context: busy-wait (default, lowest latency for one solver) or poll + sleep (many solvers
     // in flight on few host cores: see icg_ctx_set_wait_mode)
     void setWaitMode(int icg_wait_mode, int sleep_us);
@@ -139,11 +156,13 @@ public:
     void updateParamtersIds(const std::unordered_map<long, long> &parameters_ids) { parameters_ids_ = parameters_ids; }
     // reprojection factors registered in `batch` are evaluated (with their Huber loss) and assembled on the GPU
     void setReprojectionBatch(ReprojectionBatch *batch) { batch_ = batch; }
+    void setDeviceFactors(DeviceFactorSet *set) { batch_ = set; }
     bool marginalization();
     // wall time of the calling thread's last marginalization(): evaluate, construct, Schur, linearize [ms] (diagnostics / bench)
     static const double *lastPhaseMs();
     static bool lastWasStructured(); // the calling thread's last marginalization() took the landmark-eliminated (device) path
     static void forceDense(bool on);  // process-wide: always take the reference's dense M2 + M3 (diagnostics / tests)
+    static bool denseForced();
     vector<double *> getParamterBlocks(std::unordered_map<long, double *> &address);
     const vector<double> &linearizedJacobians() const { return linearized_jacobians_; } // remained x remained, row-major
     const vector<double> &linearizedResiduals() const { return linearized_residuals_; }
@@ -165,6 +184,17 @@ private:
     // the 1x1 landmark blocks are eliminated on the device, the host finishes on the small camera system.  Returns false (nothing
     // touched) when the structure or the conditioning guard does not hold: the dense path then runs as before.
     bool constructAndEliminateStructured();
+    // the two host halves of it, either side of the device step (MarginalizationBatch runs that step for many windows in one launch):
+    // planStructured checks the structure, lays out the compact camera system and adds the host factors; finishStructured takes the
+    // system with the landmark-eliminated device part added and runs the conditioning guard and the small M3
+    struct StructuredPlan {
+        int P{0}, m{0}, r{0};
+        vector<double> H, b;
+        std::unordered_map<const double *, int> camera_column_of;
+    };
+    bool planStructured(StructuredPlan &plan);
+    bool finishStructured(StructuredPlan &plan, double min_hll);
+    friend class MarginalizationBatch;
     void linearization();
     void releaseMemory() { factors_.clear(); }
     long idOf(const double *p) { return parameters_ids_[reinterpret_cast<long>(p)]; }
@@ -181,7 +211,7 @@ private:
     const double EPS = 1e-8;
     vector<double> linearized_jacobians_, linearized_residuals_;
     bool isvalid_{true};
-    ReprojectionBatch *batch_{nullptr};
+    DeviceFactorSet *batch_{nullptr};
 };
 
 class MarginalizationFactor : public ceres::CostFunction {

@@ -161,7 +161,8 @@ void TableTracker::coreAdvance(int stage, StageBatch &done, StageBatch &next) {
         if (core_det_job_ < 0) return;
         const int max_per_job = maxFeaturesPerJob();
         arena_.det_count      = done.det_count[(size_t) core_det_job_];
-        memcpy(arena_.det_out.data(), done.det_out.data() + (size_t) core_det_job_ * max_per_job * 2, sizeof(tc::P2f) * (size_t) arena_.det_count);
+        if (arena_.det_count > 0)
+            memcpy(arena_.det_out.data(), done.det_out.data() + (size_t) core_det_job_ * max_per_job * 2, sizeof(tc::P2f) * (size_t) arena_.det_count);
         core_det_job_ = -1;
     };
     switch (stage) {
@@ -301,9 +302,9 @@ void TableTracker::exportCore() {
         if ((int) f.rows() > tc::MAX_ROWS) throw std::runtime_error("tracker core: frame larger than MAX_ROWS");
         c.n_rows = (int) f.rows();
         if (c.n_rows) memcpy((void *) c.row, f.row.data(), sizeof(Row) * (size_t) c.n_rows);
-        memcpy(c.next, f.order.nextData(), sizeof(int) * (size_t) c.n_rows);
+        if (c.n_rows) memcpy(c.next, f.order.nextData(), sizeof(int) * (size_t) c.n_rows);
         c.n_buckets = f.order.bucketCount();
-        memcpy(c.bucket, f.order.bucketData(), sizeof(int) * (size_t) c.n_buckets);
+        if (c.n_buckets) memcpy(c.bucket, f.order.bucketData(), sizeof(int) * (size_t) c.n_buckets);
         c.head = f.order.head(), c.magic = f.order.magic();
         c.n_unupd = (int) f.unupdated.size();
         for (int k = 0; k < c.n_unupd; k++) c.unupd[k] = f.unupdated[(size_t) k], c.unupd_gen[k] = f.unupdated_gen[(size_t) k];

@@ -262,6 +262,10 @@ int icg_reproj_solve_backsub_windows(icg_ctx *ctx, int P, const int32_t *Pw, con
 int icg_reproj_reserve_windows(icg_ctx *ctx, int P);
 int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms);
 int icg_reproj_cost_windows(icg_ctx *ctx, const uint8_t *active, double *cost);
+/* h_ll of every landmark of the partition (n_lm values, global landmark order) from the window systems left resident by the last
+ * icg_reproj_schur_windows*: icg_reproj_landmark_diag for many windows — the conditioning guard of the batched M3
+ * (factors/marginalization_info.h:170-192 for the marginalizations of many streams, host/marg_batch.h). */
+int icg_reproj_landmark_diag_windows(icg_ctx *ctx, double *h_ll);
 /* the resident residuals of the last evaluation (n x 2 doubles): per-factor tests (chi-square culling) after a resident evaluation */
 int icg_reproj_fetch_residuals(icg_ctx *ctx, double *out_r);
 /* GVINS::removeReprojectionFactorsByChi2 (ic_gvins.cc:1269-1297) on the resident residuals of a want_jac = 0, huber = 0 evaluation:

@@ -550,6 +550,17 @@ int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, doubl
     return ICG_OK;
 }
 
+int icg_reproj_landmark_diag_windows(icg_ctx *ctx, double *h_ll) {
+    shim_backend &B = g_backend[ctx];
+    if (B.W <= 0 || B.wP <= 0 || !h_ll) return ICG_ERR_INVALID;
+    for (int w = 0; w < B.W; w++) {
+        const int l0 = B.lm_off[(size_t) w], L = B.lm_off[(size_t) w + 1] - l0;
+        const size_t N = (size_t) B.wP + L;
+        for (int l = 0; l < L; l++) h_ll[l0 + l] = B.wH[(size_t) w][((size_t) B.wP + l) * N + B.wP + l];
+    }
+    return ICG_OK;
+}
+
 int icg_reproj_chi2_cull(icg_ctx *ctx, double chi2, uint8_t *active) {
     shim_backend &B = g_backend[ctx];
     for (int f = 0; f < B.n; f++) {

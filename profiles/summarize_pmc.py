@@ -38,19 +38,23 @@ def main(dirs):
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha1()
+    per_file = {}
     src = os.path.join(root, "ic-gvins_amd", "csrc")
     for name in sorted(os.listdir(src)):
         if name.endswith((".hip", ".h")):
+            data = open(os.path.join(src, name), "rb").read()
             h.update(name.encode())
-            h.update(open(os.path.join(src, name), "rb").read())
+            h.update(data)
+            per_file[name] = hashlib.sha1(data).hexdigest()
     lk = out.get("k_lk_track_fb")
     pre = out.get("k_pyramid3")
-    out["_meta"] = {"csrc_sha1": h.hexdigest(), "streams_per_launch": os.environ.get("ICG_PMC_STREAMS_PER_LAUNCH"),
+    out["_meta"] = {"csrc_sha1": h.hexdigest(), "csrc_files": per_file, "streams_per_launch": os.environ.get("ICG_PMC_STREAMS_PER_LAUNCH"),
                     "lk_points_per_launch": (lk["grid_threads"] / 64.0) if lk else None,
                     # segmented launches (device-resident tracker) size the grid by capacity: the points actually tracked per launch, from the
                     # bench line of the same configuration (roofline.units_per_launch)
                     "lk_active_points_per_launch": float(os.environ["ICG_PMC_LK_ACTIVE_POINTS"]) if os.environ.get("ICG_PMC_LK_ACTIVE_POINTS") else None,
-                    "note": "csrc_sha1 = sha1 over the names and contents of ic-gvins_amd/csrc/*.{hip,h} at collection time"}
+                    "note": "csrc_sha1 = sha1 over the names and contents of ic-gvins_amd/csrc/*.{hip,h} at collection time; csrc_files = the sha1 of each "
+                            "of them (bench.py accepts the summary for a kernel while the files that kernel is compiled from are unchanged)"}
     json.dump(out, sys.stdout, indent=1)
 
 

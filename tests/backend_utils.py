@@ -237,6 +237,76 @@ def check_marginalization_golden(lib, path):
     assert np.abs(c["grad"] - g["grad"]).max() < 1e-7 * max(1.0, np.abs(g["grad"]).max())
 
 
+def backend_marginalize_batch(lib, P, n_windows, mode, dense_window=-1, jitter=1e-3, huber=1.0, prior_weight=100.0, host_threads=0):
+    """icgh_backend_marginalize_batch (capi.cc): the marginalizations of n_windows jittered copies of problem P, mode 0 = one
+    MarginalizationBatch, mode 1 = one MarginalizationInfo::marginalization() after the other."""
+    w = P["w"]
+    obs = _f64(P["obs"])
+    n = obs.shape[1]
+    poses, inv = _f64(w["poses"]), _f64(w["invdepth"])
+    K, L = poses.shape[0], inv.shape[0]
+    cap = 6 * K + L + 7
+    sizes, counts, seconds = np.zeros(2, np.int32), np.zeros(2, np.int32), np.zeros(1)
+    Hp, bp, J0, e0 = (np.zeros(n_windows * cap * cap), np.zeros(n_windows * cap), np.zeros(n_windows * cap * cap), np.zeros(n_windows * cap))
+    err = C.create_string_buffer(512)
+    rc = lib.icgh_backend_marginalize_batch(mode, n_windows, dense_window, C.c_double(jitter), n, _p(obs), _p(_i32(P["ii"])), _p(_i32(P["jj"])),
+                                            _p(_i32(P["ll"])), K, _p(poses), _p(_f64(w["ext"])), L, _p(inv), C.c_double(w["td"]),
+                                            C.c_double(huber), C.c_double(prior_weight), host_threads, _p(sizes), _p(Hp), _p(bp), _p(J0), _p(e0),
+                                            _p(counts), _p(seconds), err, 512)
+    assert rc == 0, (rc, err.value)
+    r = int(sizes[1])
+    W = n_windows
+    return dict(m=int(sizes[0]), r=r, Hp=Hp[:W * r * r].reshape(W, r, r), bp=bp[:W * r].reshape(W, r), J0=J0[:W * r * r].reshape(W, r, r),
+                e0=e0[:W * r].reshape(W, r), structured=int(counts[0]), dense=int(counts[1]), seconds=float(seconds[0]))
+
+
+def check_marginalization_batch(lib):
+    """M2 + M3 for the windows of many streams in one pass (host/marg_batch.h): every window's Schur complement and
+    linearization equal what MarginalizationInfo::marginalization() gives the same window on its own (marginalization_info.h:73-101) —
+    all windows on the landmark-eliminated path; one window with a host factor on an inverse depth (dense M2 + M3 for that window only);
+    the process-wide dense switch; window 0 (no jitter) equals the single-window entry point the reference-code golden is checked on."""
+    for (n_lm, n_kf, seed), W in (((80, 6, 2), 5), ((300, 10, 3), 12), ((40, 4, 7), 1)):
+        P = md.make_problem(n_lm=n_lm, n_kf=n_kf, seed=seed)
+        for dense_window in (-1, min(2, W - 1)):
+            a = backend_marginalize_batch(lib, P, W, 0, dense_window)
+            b = backend_marginalize_batch(lib, P, W, 1, dense_window)
+            assert a["m"] == b["m"] and a["r"] == b["r"]
+            assert (a["structured"], a["dense"]) == (b["structured"], b["dense"]) == ((W, 0) if dense_window < 0 else (W - 1, 1))
+            for k in range(W):
+                scale = np.abs(b["Hp"][k]).max()
+                assert np.abs(a["Hp"][k] - b["Hp"][k]).max() < 1e-9 * scale, (k, np.abs(a["Hp"][k] - b["Hp"][k]).max() / scale)
+                assert np.abs(a["bp"][k] - b["bp"][k]).max() < 1e-9 * max(1.0, np.abs(b["bp"][k]).max())
+                # the prior itself (the eigenbasis of a linearization is free in degenerate subspaces): J0^T J0 and J0^T e0
+                assert np.abs(a["J0"][k].T @ a["J0"][k] - b["J0"][k].T @ b["J0"][k]).max() < 1e-7 * scale
+                assert np.abs(a["J0"][k].T @ a["e0"][k] - b["J0"][k].T @ b["e0"][k]).max() < 1e-7 * max(1.0, np.abs(b["bp"][k]).max())
+            if W > 1:  # the windows are different problems (the jitter moved them)
+                assert np.abs(a["Hp"][1] - a["Hp"][0]).max() > 1e-6 * np.abs(a["Hp"][0]).max()
+            if dense_window != 0:  # (window 0 as the single-window entry point builds it: no extra host factor)
+                single = backend_marginalize(lib, P)
+                assert single["r"] == a["r"]
+                assert np.abs(a["Hp"][0] - single["Hp"]).max() < 1e-9 * np.abs(single["Hp"]).max()
+                assert np.abs(a["bp"][0] - single["bp"]).max() < 1e-9 * max(1.0, np.abs(single["bp"]).max())
+    P = md.make_problem(n_lm=80, n_kf=6, seed=2)
+    lib.icgh_backend_marginalization_force_dense(1)
+    try:
+        a = backend_marginalize_batch(lib, P, 4, 0)
+        b = backend_marginalize_batch(lib, P, 4, 1)
+    finally:
+        lib.icgh_backend_marginalization_force_dense(0)
+    assert (a["structured"], a["dense"]) == (0, 4) == (b["structured"], b["dense"])
+    c = backend_marginalize_batch(lib, P, 4, 0)
+    for k in range(4):
+        scale = np.abs(b["Hp"][k]).max()
+        assert np.abs(a["Hp"][k] - b["Hp"][k]).max() < 1e-9 * scale
+        assert np.abs(a["Hp"][k] - c["Hp"][k]).max() < 1e-9 * scale  # dense == landmark-eliminated, as for a window on its own
+        assert np.abs(a["bp"][k] - c["bp"][k]).max() < 1e-9 * max(1.0, np.abs(c["bp"][k]).max())
+    # host threads: the per-window phases spread over the pool give the same numbers as one thread
+    d = backend_marginalize_batch(lib, P, 9, 0, host_threads=1)
+    e = backend_marginalize_batch(lib, P, 9, 0, host_threads=4)
+    # (bit-equal on the CPU backend; the device assembles with floating-point atomics, whose order differs from launch to launch)
+    assert np.abs(d["Hp"] - e["Hp"]).max() < 1e-9 * np.abs(d["Hp"]).max() and np.abs(d["bp"] - e["bp"]).max() < 1e-9 * max(1.0, np.abs(d["bp"]).max())
+
+
 def check_marginalization_paths(lib):
     """M2 + M3: the landmark-eliminated path (device assembly + elimination of the 1x1 inverse-depth blocks, small host finish) against
     the reference's dense construction + pseudo-inverse (marginalization_info.h:170-230) on the same problems: same Hp, bp, cost at

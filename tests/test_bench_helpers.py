@@ -87,6 +87,23 @@ def test_stale_counter_summaries_are_not_quoted(tmp_path, monkeypatch):
     assert "changed" in b.pmc_provenance("r09_pmc_summary.json", 32.0)
     (prof / "r08_pmc_summary.json").write_text(json.dumps({"k_lk_track_fb": {}}))
     assert "no provenance" in b.pmc_provenance("r08_pmc_summary.json", 32.0)
+    # per-file record: only the files the quoted kernels are compiled from have to be the collected ones
+    import hashlib
+    (src / "a.hip").write_text("__global__ void k_a(int) {} v1")
+    (src / "b.hip").write_text("__global__ void k_b(int) {} v1")
+    (src / "common.h").write_text("// v1")
+    (src / "ctx.hip").write_text("// ctx v1")
+    per = {n: hashlib.sha1((src / n).read_bytes()).hexdigest() for n in ("a.hip", "b.hip", "common.h", "ctx.hip")}
+    (prof / "r10_pmc_summary.json").write_text(json.dumps({"k_a": {}, "_meta": {"csrc_sha1": b.csrc_sha1(), "csrc_files": per, "streams_per_launch": "32.0"}}))
+    assert b.kernel_source_files(["k_a"]) == ["a.hip", "common.h", "ctx.hip"]
+    assert b.pmc_provenance("r10_pmc_summary.json", 32.0, ["k_a"]) is None
+    (src / "b.hip").write_text("__global__ void k_b(int) {} v2")  # another kernel's file
+    assert b.pmc_provenance("r10_pmc_summary.json", 32.0, ["k_a"]) is None
+    assert "changed" in b.pmc_provenance("r10_pmc_summary.json", 32.0, ["k_a", "k_b"])
+    assert "changed" in b.pmc_provenance("r10_pmc_summary.json", 32.0)  # (no kernel named: every file counts)
+    assert "changed" in b.pmc_provenance("r10_pmc_summary.json", 32.0, ["k_missing"])
+    (src / "common.h").write_text("// v2")  # a shared header ages every kernel
+    assert "common.h" in b.pmc_provenance("r10_pmc_summary.json", 32.0, ["k_a"])
 
 
 def test_whole_path_fraction_and_event_rates():
