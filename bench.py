@@ -1011,8 +1011,8 @@ def main():
         try:
             nmb = 256
             bu.backend_marginalize_batch(hl, Pm, 8, 0)  # (contexts, pool, code paged in)
-            one = bu.backend_marginalize_batch(hl, Pm, nmb, 1)
-            bat = min((bu.backend_marginalize_batch(hl, Pm, nmb, 0) for _ in range(3)), key=lambda d: d["seconds"])
+            one = bu.backend_marginalize_batch(hl, Pm, nmb, 1, reps=2)
+            bat = bu.backend_marginalize_batch(hl, Pm, nmb, 0, reps=3)
             scale = np.abs(one["Hp"]).max(axis=(1, 2))
             marg["batched"] = {"windows_per_batch": nmb, "value": round(nmb / bat["seconds"], 1), "unit": "windows/s",
                                "batch_ms": round(bat["seconds"] * 1e3, 2),

@@ -527,12 +527,15 @@ int icgh_backend_marginalize(int n, const double *obs_soa, const int32_t *idx_i,
 // depths moved by a deterministic jitter of relative size `jitter`), mode 0: one MarginalizationBatch (marg_batch.h: the windows share
 // their device launches), mode 1: one MarginalizationInfo::marginalization() after the other on a ReprojectionBatch (what a stream on its
 // own does).  dense_window >= 0: that window gets a host factor on one of its inverse depths, which takes it off the landmark-eliminated
-// path in both modes.  Outputs per window (r = sizes[1], equal for all windows): Hp (r x r), bp, J0 (r x r), e0; counts = windows on the
-// structured / dense path (mode 0), seconds = wall time of the marginalizations alone (problem construction excluded).
-int icgh_backend_marginalize_batch(int mode, int n_windows, int dense_window, double jitter, int n, const double *obs_soa, const int32_t *idx_i,
-                                   const int32_t *idx_j, const int32_t *idx_lm, int n_poses, const double *poses, const double *ext, int n_lm,
-                                   const double *invdepth, double td, double huber_delta, double prior_weight, int host_threads, int32_t *sizes,
-                                   double *Hp, double *bp, double *J0, double *e0, int32_t *counts, double *seconds, char *err, int errlen) {
+// path in both modes.  The whole set is marginalized `reps` times on the SAME batch object (as a group of streams does keyframe after
+// keyframe: the problems are rebuilt each time, outside the clock).  Outputs per window of the last repetition (r = sizes[1], equal for
+// all windows): Hp (r x r), bp, J0 (r x r), e0; counts = windows on the structured / dense path, seconds = wall time of the
+// marginalizations alone in the fastest repetition (problem construction excluded).
+int icgh_backend_marginalize_batch(int mode, int n_windows, int dense_window, double jitter, int reps, int n, const double *obs_soa,
+                                   const int32_t *idx_i, const int32_t *idx_j, const int32_t *idx_lm, int n_poses, const double *poses,
+                                   const double *ext, int n_lm, const double *invdepth, double td, double huber_delta, double prior_weight,
+                                   int host_threads, int32_t *sizes, double *Hp, double *bp, double *J0, double *e0, int32_t *counts,
+                                   double *seconds, char *err, int errlen) {
     try {
         struct Win {
             vector<double> P, E, D;
@@ -542,91 +545,99 @@ int icgh_backend_marginalize_batch(int mode, int n_windows, int dense_window, do
             vector<std::shared_ptr<ReprojectionFactor>> factors;
             vector<double> pose0_prior;
         };
-        vector<std::unique_ptr<Win>> wins;
-        uint64_t lcg = 0x9E3779B97F4A7C15ull;
-        auto rnd     = [&] { // uniform in [-1, 1)
-            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
-            return (double) ((lcg >> 11) & ((1ull << 53) - 1)) / (double) (1ull << 52) - 1.0;
-        };
         auto loss = huber_delta > 0 ? std::make_shared<HuberLossHip>(huber_delta) : nullptr;
-        for (int w = 0; w < n_windows; w++) {
-            std::unique_ptr<Win> W(new Win);
-            W->P.assign(poses, poses + 7 * (size_t) n_poses), W->E.assign(ext, ext + 7), W->D.assign(invdepth, invdepth + n_lm), W->TD = td;
-            if (w > 0) {
-                for (int k = 0; k < n_poses; k++)
-                    for (int c = 0; c < 3; c++) W->P[7 * (size_t) k + c] += jitter * rnd();
-                for (int l = 0; l < n_lm; l++) W->D[(size_t) l] *= 1.0 + jitter * rnd();
+        auto build = [&](vector<std::unique_ptr<Win>> &wins) {
+            wins.clear();
+            uint64_t lcg = 0x9E3779B97F4A7C15ull;
+            auto rnd     = [&] { // uniform in [-1, 1)
+                lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                return (double) ((lcg >> 11) & ((1ull << 53) - 1)) / (double) (1ull << 52) - 1.0;
+            };
+            for (int w = 0; w < n_windows; w++) {
+                std::unique_ptr<Win> W(new Win);
+                W->P.assign(poses, poses + 7 * (size_t) n_poses), W->E.assign(ext, ext + 7), W->D.assign(invdepth, invdepth + n_lm), W->TD = td;
+                if (w > 0) {
+                    for (int k = 0; k < n_poses; k++)
+                        for (int c = 0; c < 3; c++) W->P[7 * (size_t) k + c] += jitter * rnd();
+                    for (int l = 0; l < n_lm; l++) W->D[(size_t) l] *= 1.0 + jitter * rnd();
+                }
+                for (int k = 0; k < n_poses; k++) W->ids[reinterpret_cast<long>(&W->P[7 * (size_t) k])] = k;
+                for (int l = 0; l < n_lm; l++) W->ids[reinterpret_cast<long>(&W->D[(size_t) l])] = 100000 + l;
+                W->ids[reinterpret_cast<long>(W->E.data())] = 900000;
+                W->ids[reinterpret_cast<long>(&W->TD)]       = 900001;
+                W->info = std::make_shared<MarginalizationInfo>();
+                W->info->updateParamtersIds(W->ids);
+                for (int k = 0; k < n; k++) {
+                    auto o = [&](int c) { return obs_soa[(size_t) c * n + k]; };
+                    W->factors.push_back(std::make_shared<ReprojectionFactor>(Vector3d(o(0), o(1), o(2)), Vector3d(o(3), o(4), o(5)),
+                                                                              Vector3d(o(6), o(7), o(8)), Vector3d(o(9), o(10), o(11)), o(12), o(13), o(14)));
+                    double *pi = &W->P[7 * (size_t) idx_i[k]], *pj = &W->P[7 * (size_t) idx_j[k]], *lm = &W->D[(size_t) idx_lm[k]];
+                    W->info->addResidualBlockInfo(
+                        std::make_shared<ResidualBlockInfo>(W->factors.back(), loss, vector<double *>{pi, pj, W->E.data(), lm, &W->TD}, vector<int>{0, 3}));
+                }
+                W->pose0_prior.assign(W->P.begin(), W->P.begin() + 7);
+                W->pose0_prior[0] += 0.01;
+                W->info->addResidualBlockInfo(std::make_shared<ResidualBlockInfo>(std::make_shared<PosePriorFactor>(W->pose0_prior.data(), prior_weight),
+                                                                                  nullptr, vector<double *>{&W->P[0]}, vector<int>{0}));
+                if (w == dense_window && n > 0) {
+                    double *lm = &W->D[(size_t) idx_lm[0]];
+                    W->info->addResidualBlockInfo(std::make_shared<ResidualBlockInfo>(std::make_shared<ScalarPriorFactor>(*lm * 1.01, 0.5 * prior_weight),
+                                                                                      nullptr, vector<double *>{lm}, vector<int>{0}));
+                }
+                wins.push_back(std::move(W));
             }
-            for (int k = 0; k < n_poses; k++) W->ids[reinterpret_cast<long>(&W->P[7 * (size_t) k])] = k;
-            for (int l = 0; l < n_lm; l++) W->ids[reinterpret_cast<long>(&W->D[(size_t) l])] = 100000 + l;
-            W->ids[reinterpret_cast<long>(W->E.data())] = 900000;
-            W->ids[reinterpret_cast<long>(&W->TD)]       = 900001;
-            W->info = std::make_shared<MarginalizationInfo>();
-            W->info->updateParamtersIds(W->ids);
-            for (int k = 0; k < n; k++) {
-                auto o = [&](int c) { return obs_soa[(size_t) c * n + k]; };
-                W->factors.push_back(std::make_shared<ReprojectionFactor>(Vector3d(o(0), o(1), o(2)), Vector3d(o(3), o(4), o(5)), Vector3d(o(6), o(7), o(8)),
-                                                                          Vector3d(o(9), o(10), o(11)), o(12), o(13), o(14)));
-                double *pi = &W->P[7 * (size_t) idx_i[k]], *pj = &W->P[7 * (size_t) idx_j[k]], *lm = &W->D[(size_t) idx_lm[k]];
-                W->info->addResidualBlockInfo(
-                    std::make_shared<ResidualBlockInfo>(W->factors.back(), loss, vector<double *>{pi, pj, W->E.data(), lm, &W->TD}, vector<int>{0, 3}));
-            }
-            W->pose0_prior.assign(W->P.begin(), W->P.begin() + 7);
-            W->pose0_prior[0] += 0.01;
-            W->info->addResidualBlockInfo(std::make_shared<ResidualBlockInfo>(std::make_shared<PosePriorFactor>(W->pose0_prior.data(), prior_weight),
-                                                                              nullptr, vector<double *>{&W->P[0]}, vector<int>{0}));
-            if (w == dense_window && n > 0) {
-                double *lm = &W->D[(size_t) idx_lm[0]];
-                W->info->addResidualBlockInfo(std::make_shared<ResidualBlockInfo>(std::make_shared<ScalarPriorFactor>(*lm * 1.01, 0.5 * prior_weight),
-                                                                                  nullptr, vector<double *>{lm}, vector<int>{0}));
-            }
-            wins.push_back(std::move(W));
-        }
-        vector<char> ok((size_t) n_windows, 0);
-        counts[0] = counts[1] = 0;
-        auto add_factors = [&](Win &W, const std::function<void(const ReprojectionFactor *, double *, double *, double *, double *, double *)> &add) {
-            for (int k = 0; k < n; k++)
-                add(W.factors[(size_t) k].get(), &W.P[7 * (size_t) idx_i[k]], &W.P[7 * (size_t) idx_j[k]], W.E.data(), &W.D[(size_t) idx_lm[k]], &W.TD);
         };
+        vector<std::unique_ptr<Win>> wins;
+        vector<char> ok((size_t) n_windows, 0);
         std::string what;
-        std::chrono::steady_clock::time_point t0, t1;
-        if (mode == 0) {
-            MarginalizationBatch mb(0, huber_delta, host_threads);
-            for (auto &W : wins) {
-                const int w = mb.addWindow(W->info);
-                add_factors(*W, [&](const ReprojectionFactor *f, double *pi, double *pj, double *e, double *lm, double *t) { mb.addReprojectionFactor(w, f, pi, pj, e, lm, t); });
+        double best = -1.0;
+        std::unique_ptr<MarginalizationBatch> mb;
+        std::unique_ptr<ReprojectionBatch> batch;
+        if (mode == 0)
+            mb.reset(new MarginalizationBatch(0, huber_delta, host_threads));
+        else
+            batch.reset(new ReprojectionBatch(0));
+        for (int rep = 0; rep < std::max(1, reps); rep++) {
+            if (mb) mb->clear(); // (before the infos of the last repetition go)
+            if (batch) batch->clear();
+            build(wins);
+            counts[0] = counts[1] = 0;
+            double took = 0;
+            if (mode == 0) {
+                for (auto &W : wins) {
+                    const int w = mb->addWindow(W->info);
+                    for (int k = 0; k < n; k++)
+                        mb->addReprojectionFactor(w, W->factors[(size_t) k].get(), &W->P[7 * (size_t) idx_i[k]], &W->P[7 * (size_t) idx_j[k]], W->E.data(),
+                                                  &W->D[(size_t) idx_lm[k]], &W->TD);
+                }
+                auto t0         = std::chrono::steady_clock::now();
+                const bool good = mb->marginalize(&ok);
+                took            = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (!good) what = mb->error();
+                counts[0] = mb->structuredWindows(), counts[1] = mb->denseWindows();
+            } else {
+                for (size_t w = 0; w < wins.size(); w++) {
+                    Win &W = *wins[w];
+                    batch->clear();
+                    for (int k = 0; k < n; k++)
+                        batch->add(W.factors[(size_t) k].get(), &W.P[7 * (size_t) idx_i[k]], &W.P[7 * (size_t) idx_j[k]], W.E.data(), &W.D[(size_t) idx_lm[k]], &W.TD);
+                    W.info->setReprojectionBatch(batch.get());
+                    auto a = std::chrono::steady_clock::now();
+                    batch->finalize();
+                    ok[w] = W.info->marginalization() ? 1 : 0;
+                    took += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+                    if (!ok[w]) what = batch->error();
+                    counts[MarginalizationInfo::lastWasStructured() ? 0 : 1] += ok[w] ? 1 : 0;
+                }
             }
-            t0 = std::chrono::steady_clock::now();
-            const bool good = mb.marginalize(&ok);
-            t1 = std::chrono::steady_clock::now();
-            if (!good) what = mb.error();
-            counts[0] = mb.structuredWindows(), counts[1] = mb.denseWindows();
-        } else {
-            ReprojectionBatch batch(0);
-            double total = 0;
-            for (size_t w = 0; w < wins.size(); w++) {
-                Win &W = *wins[w];
-                batch.clear();
-                add_factors(W, [&](const ReprojectionFactor *f, double *pi, double *pj, double *e, double *lm, double *t) {
-                    batch.add(const_cast<ReprojectionFactor *>(f), pi, pj, e, lm, t);
-                });
-                W.info->setReprojectionBatch(&batch);
-                auto a = std::chrono::steady_clock::now();
-                batch.finalize();
-                ok[w] = W.info->marginalization() ? 1 : 0;
-                total += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
-                if (!ok[w]) what = batch.error();
-                counts[MarginalizationInfo::lastWasStructured() ? 0 : 1] += ok[w] ? 1 : 0;
-            }
-            t0 = std::chrono::steady_clock::time_point();
-            t1 = t0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(total));
+            for (int w = 0; w < n_windows; w++)
+                if (!ok[(size_t) w]) {
+                    set_err(err, errlen, ("marginalization of window " + std::to_string(w) + " failed: " + what).c_str());
+                    return -2;
+                }
+            if (best < 0 || took < best) best = took;
         }
-        *seconds = std::chrono::duration<double>(t1 - t0).count();
-        for (int w = 0; w < n_windows; w++)
-            if (!ok[(size_t) w]) {
-                set_err(err, errlen, ("marginalization of window " + std::to_string(w) + " failed: " + what).c_str());
-                return -2;
-            }
+        *seconds = best;
         const size_t r = (size_t) wins[0]->info->remainedSize();
         sizes[0] = wins[0]->info->marginalizedSize(), sizes[1] = (int32_t) r;
         for (int w = 0; w < n_windows; w++) {
@@ -640,6 +651,8 @@ int icgh_backend_marginalize_batch(int mode, int n_windows, int dense_window, do
             memcpy(J0 + (size_t) w * r * r, I.linearizedJacobians().data(), sizeof(double) * r * r);
             memcpy(e0 + (size_t) w * r, I.linearizedResiduals().data(), sizeof(double) * r);
         }
+        if (mb) mb->clear(); // (the infos die with `wins` before the batch does)
+        if (batch) batch->clear();
         return 0;
     } catch (const std::exception &e) {
         set_err(err, errlen, e.what());

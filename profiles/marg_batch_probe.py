@@ -18,8 +18,8 @@ Pm = md.make_problem(n_lm=300, n_kf=10, seed=2)
 out = {"factors_per_window": int(Pm["obs"].shape[1])}
 bu.backend_marginalize_batch(hl, Pm, 8, 0)
 for nmb in (16, 64, 256):
-    one = bu.backend_marginalize_batch(hl, Pm, nmb, 1)
-    bat = min((bu.backend_marginalize_batch(hl, Pm, nmb, 0) for _ in range(3)), key=lambda d: d["seconds"])
+    one = bu.backend_marginalize_batch(hl, Pm, nmb, 1, reps=2)
+    bat = bu.backend_marginalize_batch(hl, Pm, nmb, 0, reps=3)
     scale = np.abs(one["Hp"]).max(axis=(1, 2))
     out[str(nmb)] = {"batch_ms": round(bat["seconds"] * 1e3, 3), "one_by_one_ms": round(one["seconds"] * 1e3, 3),
                      "windows_per_s": round(nmb / bat["seconds"], 1), "windows_per_s_one_by_one": round(nmb / one["seconds"], 1),
