@@ -1008,23 +1008,26 @@ def main():
 
         # the marginalizations of many streams in one pass (MarginalizationBatch, host/marg_batch.h): one evaluation launch, one assembly +
         # elimination launch sequence and one read-back for all windows; the per-window host phases on the pool
+        # (a child process: the block is outside the headline path and must not be able to take the line down)
         try:
+            import subprocess
             nmb = 256
-            bu.backend_marginalize_batch(hl, Pm, 8, 0)  # (contexts, pool, code paged in)
-            one = bu.backend_marginalize_batch(hl, Pm, nmb, 1, reps=2)
-            bat = bu.backend_marginalize_batch(hl, Pm, nmb, 0, reps=3)
-            scale = np.abs(one["Hp"]).max(axis=(1, 2))
-            marg["batched"] = {"windows_per_batch": nmb, "value": round(nmb / bat["seconds"], 1), "unit": "windows/s",
-                               "batch_ms": round(bat["seconds"] * 1e3, 2),
-                               "one_by_one": {"value": round(nmb / one["seconds"], 1), "unit": "windows/s",
+            pr = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "marg_batch_probe.py"), "--windows", str(nmb)],
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
+            if pr.returncode != 0:
+                raise RuntimeError(f"marg_batch_probe.py exited with {pr.returncode}: {pr.stderr[-200:]}")
+            mbp = json.loads(pr.stdout.strip().splitlines()[-1])[str(nmb)]
+            marg["batched"] = {"windows_per_batch": nmb, "value": mbp["windows_per_s"], "unit": "windows/s", "batch_ms": mbp["batch_ms"],
+                               "one_by_one": {"value": mbp["windows_per_s_one_by_one"], "unit": "windows/s",
                                               "what": "MarginalizationInfo::marginalization() window after window on one ReprojectionBatch (one host thread)"},
-                               "speedup": round(one["seconds"] / bat["seconds"], 2),
-                               "windows_structured_dense": [bat["structured"], bat["dense"]],
-                               "max_rel_diff_Hp_vs_one_by_one": float((np.abs(bat["Hp"] - one["Hp"]).max(axis=(1, 2)) / scale).max()),
-                               "note": "MarginalizationBatch: jittered copies of the C2 window; per batch one icg_reproj_eval_windows, one "
-                                       "icg_reproj_schur_windows and one icg_reproj_landmark_diag_windows; M1 bookkeeping, host factors, the "
-                                       "pose/mix-block M3 and the eigen linearization per window on the host pool"}
-        except Exception as e:  # (a next-row block: it must not take the line down)
+                               "speedup": round(mbp["one_by_one_ms"] / mbp["batch_ms"], 2),
+                               "windows_structured_dense": mbp["structured_dense"],
+                               "max_rel_diff_Hp_vs_one_by_one": mbp["max_rel_diff_Hp"],
+                               "note": "MarginalizationBatch: jittered copies of the C2 window, the fastest of 3 passes on one batch object; per pass one "
+                                       "icg_reproj_eval_windows, one icg_reproj_schur_windows and one icg_reproj_landmark_diag_windows; M1 bookkeeping, "
+                                       "host factors, the pose/mix-block M3 and the eigen linearization per window on the host pool "
+                                       "(profiles/marg_batch_probe.py in a child process)"}
+        except Exception as e:
             marg["batched"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- f3: per-observation reprojection error + isGoodToTrack gate of the culling / statistics pass ---------------------------

@@ -419,8 +419,8 @@ extern "C" int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, in
     if ((rc = launch_stage(t, 5, "trk_stage_tri"))) return rc;
     if ((rc = detect())) return rc;
     if ((rc = launch_stage(t, 6, "trk_stage_end"))) return rc;
-    // ONE wait per step.  Default: block on an interrupt-driven event (the group's thread sleeps for the ~10 ms the chain takes instead of
-    // polling the stream every 100 us); ICG_TRACKER_WAIT=poll|spin selects the context's wait mode instead
+    // ONE wait per step.  Default ("adaptive", below): sleep through most of the chain, then poll the stream.  ICG_TRACKER_WAIT=ctx selects
+    // the context's wait mode (spin, or query + sleep every poll interval), ICG_TRACKER_WAIT=block an event with hipEventBlockingSync
     if (t->wait_mode == 2) { // "block": an event with hipEventBlockingSync (measured on ROCm 7.2: the runtime still spins — 9.5 cores busy with 12 groups)
         ICG_HIP(ctx, hipEventRecord(t->ev_done, ctx->stream));
         ICG_HIP(ctx, hipEventSynchronize(t->ev_done));

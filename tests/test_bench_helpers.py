@@ -141,3 +141,21 @@ def test_contract_line_carries_the_round4_honesty_fields():
     assert c["roofline"]["frac"] == 0.0547 and c["roofline"]["frac_under_load"] == 0.0177 and c["roofline"]["frac_whole_path"] == 0.1071
     assert c["forward_control"]["rates"] == rates and c["rates"] == rates and "note" not in c["forward_control"]
     assert c["pcie_inclusive"]["config"]["input_residency"] == "pinned host"
+
+
+def test_marg_batch_probe_child_process_schema():
+    """bench.py's marg.batched block runs profiles/marg_batch_probe.py as a child process and reads these keys from its last line
+    (here on the oracle-backed host layer: the CPU backend of the *_windows ABI)."""
+    import os
+    import subprocess
+    import sys
+    from stream_utils import ensure_oracle_host
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ICG_PROBE_HOST_LIB=ensure_oracle_host())
+    pr = subprocess.run([sys.executable, os.path.join(root, "profiles", "marg_batch_probe.py"), "--windows", "4"], stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert pr.returncode == 0, pr.stderr[-500:]
+    d = json.loads(pr.stdout.strip().splitlines()[-1])["4"]
+    for k in ("windows_per_s", "batch_ms", "windows_per_s_one_by_one", "one_by_one_ms", "structured_dense", "max_rel_diff_Hp"):
+        assert k in d
+    assert d["structured_dense"] == [4, 0] and d["max_rel_diff_Hp"] < 1e-9

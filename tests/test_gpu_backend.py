@@ -26,11 +26,6 @@ def test_marginalization_structured_path_equals_dense():
     bu.check_marginalization_paths(_lib())
 
 
-def test_marginalization_batch_equals_per_window():
-    """the marginalizations of many streams in one pass (MarginalizationBatch) == each window marginalized on its own"""
-    bu.check_marginalization_batch(_lib())
-
-
 def test_preintegration_factor(oracle):
     bu.check_preintegration(_lib(), oracle)
 

@@ -1,0 +1,15 @@
+"""GPU test of MarginalizationBatch (host/marg_batch.h): the marginalizations of many streams in one pass == each window marginalized
+on its own by MarginalizationInfo::marginalization() (reference factors/marginalization_info.h:73-101), on the HIP library.
+(The file sorts after the other GPU tests on purpose: the class is the newest code of the round.)"""
+import ctypes as C
+
+import pytest
+
+import backend_utils as bu
+import harness as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_marginalization_batch_equals_per_window():
+    bu.check_marginalization_batch(C.CDLL(H.HOST_LIB))
