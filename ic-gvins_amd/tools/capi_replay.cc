@@ -221,6 +221,13 @@ int icgh_replay_run_lockstep(int n, const char *configfile, const char *const *o
 }
 
 extern "C" {
+// batches / windows that went through a MarginalizationBatch in the lock-step runs since the last call (ICG_LOCKSTEP_MARG_BATCH=1)
+void icgh_replay_lockstep_marg_counts(int64_t *out2) {
+    long v[2];
+    icg::Replay::takeLockstepMarginalizationCounts(v);
+    out2[0] = v[0], out2[1] = v[1];
+}
+
 // lock-step groups over streams with their OWN input files (configs / imus / gnss / images: n entries each; a NULL gnss / images entry = none)
 int icgh_replay_run_lockstep_files(int n, const char *const *configs, const char *const *outputs, const char *const *imus, const char *const *gnss,
                                    const char *const *images, int groups, double *summaries, double *batch_wall_seconds, int64_t *shared3, char *err,

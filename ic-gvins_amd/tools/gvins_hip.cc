@@ -461,11 +461,21 @@ void GVINS::solveWindowAlone(int prepared_n_visual) {
 
 // what follows the solve in runOptimization (:436-471): window maintenance, statistics, the flags the fusion loop looks at
 void GVINS::afterWindowSolve() {
+    afterWindowSolveBegin();
+    while (marginalizationDue()) gvinsMarginalization();
+    afterWindowSolveEnd();
+}
+
+void GVINS::afterWindowSolveBegin() {
+    after_solve_t0_ = std::chrono::steady_clock::now();
+    if (gvinsstate_ >= GVINS_TRACKING_INITIALIZING) gvinsRemoveAllSecondNewFrame();
+}
+
+bool GVINS::marginalizationDue() const { return gvinsstate_ >= GVINS_TRACKING_INITIALIZING && map_->isMaximumKeframes(); }
+
+void GVINS::afterWindowSolveEnd() {
     if (gvinsstate_ >= GVINS_TRACKING_INITIALIZING) {
-        TimeCost timecost2;
-        gvinsRemoveAllSecondNewFrame();
-        while (map_->isMaximumKeframes()) gvinsMarginalization();
-        timecosts_[2] = timecost2.costInMillisecond();
+        timecosts_[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - after_solve_t0_).count();
         parametersStatistic();
     }
     window_solve_pending_ = false;
@@ -1001,6 +1011,28 @@ bool GVINS::gvinsRemoveAllSecondNewFrame() { // ic_gvins.cc:1391-1410
 
 // ---- marginalization -----------------------------------------------------------------------------------------------------------
 bool GVINS::gvinsMarginalization() { // ic_gvins.cc:1412-1678
+    MarginalizationJob job;
+    marg_batch_->clear();
+    beginMarginalization(job, [this](ReprojectionFactor *f, double *pi, double *pj, double *ext, double *invdepth, double *td) {
+        marg_batch_->add(f, pi, pj, ext, invdepth, td);
+    });
+    bool valid;
+    {
+        PhaseTimer pt(phase_ms_, PH_MARG);
+        if (marg_batch_->size() > 0) {
+            marg_batch_->finalize();
+            job.info->setReprojectionBatch(marg_batch_.get());
+        }
+        valid = job.info->marginalization();
+        job.info->setReprojectionBatch(nullptr);
+        marg_batch_->clear();
+    }
+    finishMarginalization(job, valid);
+    return true;
+}
+
+// the factors of the marginalization (:1412-1610): the MarginalizationInfo with every host factor, the reprojection factors handed to `sink`
+void GVINS::beginMarginalization(MarginalizationJob &job, const MarginalizationSink &sink) {
     PhaseTimer pt(phase_ms_, PH_MARG);
     std::vector<ulong> keyframeids = map_->orderedKeyFrames();
     auto latest_keyframe           = map_->latestKeyFrame();
@@ -1069,8 +1101,7 @@ bool GVINS::gvinsMarginalization() { // ic_gvins.cc:1412-1678
     }
 
     // reprojection factors of the landmarks anchored in the oldest keyframe: evaluated and assembled on the device
-    marg_batch_->clear();
-    std::vector<std::shared_ptr<ReprojectionFactor>> marg_factors;
+    std::vector<std::shared_ptr<ReprojectionFactor>> &marg_factors = job.factors;
     // ic_gvins.cc:1556 constructs a HuberLoss here but :1600-1606 hands nullptr to every ResidualBlockInfo: the reference's
     // prior is built from UNCORRECTED reprojection residuals / Jacobians (the device batch therefore runs with delta 0)
     const std::shared_ptr<ceres::LossFunction> loss_function; // null, as the reference passes
@@ -1105,18 +1136,31 @@ bool GVINS::gvinsMarginalization() { // ic_gvins.cc:1412-1678
                                                                ref_frame->timeDelay(), obs_frame->timeDelay(), optimize_reprojection_error_std_);
             marg_factors.push_back(factor);
             double *pi = statedatalist_[(size_t) ref_frame_index].pose, *pj = statedatalist_[(size_t) obs_frame_index].pose;
-            marg_batch_->add(factor.get(), pi, pj, extrinsic_, invdepth, &extrinsic_[7]);
+            sink(factor.get(), pi, pj, extrinsic_, invdepth, &extrinsic_[7]);
             marginalization_info->addResidualBlockInfo(std::make_shared<ResidualBlockInfo>(
                 factor, loss_function, std::vector<double *>{pi, pj, extrinsic_, invdepth, &extrinsic_[7]}, std::vector<int>{0, 3}));
         }
     }
-    if (marg_batch_->size() > 0) {
-        marg_batch_->finalize();
-        marginalization_info->setReprojectionBatch(marg_batch_.get());
-    }
-    if (!marginalization_info->marginalization()) GLOG("marginalization produced no valid prior");
-    marginalization_info->setReprojectionBatch(nullptr);
-    marg_batch_->clear();
+    job.device_factors = (int) marg_factors.size();
+    job.info           = std::move(marginalization_info);
+    job.parameters_ids = std::move(parameters_ids);
+    job.num_marg       = num_marg;
+    job.last_time      = last_time;
+    job.frame          = frame;
+}
+
+// what follows MarginalizationInfo::marginalization() (:1612-1678): the prior's retained blocks, the window bookkeeping, the keyframe leaves the map
+void GVINS::finishMarginalization(MarginalizationJob &job, bool valid) {
+    PhaseTimer pt(phase_ms_, PH_MARG);
+    if (!valid) GLOG("marginalization produced no valid prior");
+    std::shared_ptr<MarginalizationInfo> marginalization_info = std::move(job.info);
+    std::unordered_map<long, long> &parameters_ids            = job.parameters_ids;
+    const size_t num_marg                                     = job.num_marg;
+    const double last_time                                    = job.last_time;
+    auto frame                                                = job.frame;
+    auto features                                             = frame->features();
+    auto key                                                  = [](const double *p) { return reinterpret_cast<long>(p); };
+    job.factors.clear();
     counters_.marginalizations++;
 
     std::unordered_map<long, double *> address;
@@ -1148,7 +1192,6 @@ bool GVINS::gvinsMarginalization() { // ic_gvins.cc:1412-1678
         ptsfilesaver_->dump({pw.x(), pw.y(), pw.z()});
     }
     map_->removeKeyFrame(frame, true);
-    return true;
 }
 
 } // namespace icg

@@ -21,7 +21,9 @@
 // pinned against the reference's headers (tests/golden/nav_ref_golden.npz); behaviour is checked end to end on a synthetic
 // GNSS + IMU + camera sequence with known truth (tests/gvins_checks.py).
 #pragma once
+#include <chrono>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <queue>
 #include <string>
@@ -132,6 +134,25 @@ public:
     void betweenWindowSolves(WindowProblem &problem);
     void finishWindowSolve(const WindowSolver::Summary &first, const WindowSolver::Summary &second, double first_ms, double second_ms, int chi2_removed);
     void afterWindowSolve();
+    // afterWindowSolve() in phases, for a caller that marginalizes the windows of several estimators together (MarginalizationBatch,
+    // host/marg_batch.h): afterWindowSolveBegin(); while (marginalizationDue()) { beginMarginalization(job, sink); [job.info marginalized: by
+    // the caller's batch when job.device_factors > 0, else job.info->marginalization()]; finishMarginalization(job); } afterWindowSolveEnd().
+    struct MarginalizationJob {
+        std::shared_ptr<MarginalizationInfo> info;
+        std::vector<std::shared_ptr<ReprojectionFactor>> factors; // the reprojection factors handed to the sink (kept alive until finish)
+        int device_factors{0};
+        std::unordered_map<long, long> parameters_ids;
+        size_t num_marg{0};
+        double last_time{0};
+        std::shared_ptr<Frame> frame;
+    };
+    // (factor, pose_ref, pose_obs, extrinsic, inverse depth, td): ReprojectionBatch::add / MarginalizationBatch::addReprojectionFactor
+    typedef std::function<void(ReprojectionFactor *, double *, double *, double *, double *, double *)> MarginalizationSink;
+    void afterWindowSolveBegin();
+    bool marginalizationDue() const;
+    void beginMarginalization(MarginalizationJob &job, const MarginalizationSink &sink);
+    void finishMarginalization(MarginalizationJob &job, bool valid);
+    void afterWindowSolveEnd();
     void solveWindowAlone(int prepared_n_visual = -1); // >= 0: beginWindowSolve() already ran for this window and returned this count
     int firstNumIterations() const { return first_num_iterations_; }
     int secondNumIterations() const { return second_num_iterations_; }
@@ -273,6 +294,7 @@ private:
     std::vector<VisualBlocks> visual_blocks_; // the blocks of visual_factors_[k]
     std::vector<std::pair<WindowSolver::ResidualBlockId, GNSS *>> gnss_blocks_; // GNSS residual blocks of the window being solved
     bool deferred_window_solves_{false}, window_solve_pending_{false};
+    std::chrono::steady_clock::time_point after_solve_t0_; // afterWindowSolveBegin() .. End(): column 13 of statistics.txt (timecosts_[2])
     Counters counters_;
     double phase_ms_[8]{0, 0, 0, 0, 0, 0, 0, 0}; // host wall time per phase (tracking, INS, build, solves, write-back, marginalization, statistics, nodes)
     std::string error_;

@@ -9,8 +9,10 @@
 #include <fstream>
 #include <sstream>
 #include <array>
+#include <atomic>
 #include <thread>
 
+#include "marg_batch.h"
 #include "yaml_lite.h"
 
 namespace icg {
@@ -230,6 +232,8 @@ bool Replay::runMany(const std::vector<ReplayOptions> &options, std::vector<Repl
 }
 
 namespace {
+// marginalizations that went through a MarginalizationBatch since the last Replay::takeLockstepMarginalizationCounts() (all groups)
+std::atomic<long> g_lockstep_marg_batches{0}, g_lockstep_marg_windows{0};
 struct LockstepStream {
     std::unique_ptr<GVINS> gvins;
     std::vector<IMU> imus;
@@ -243,6 +247,11 @@ struct LockstepStream {
     int n_visual = 0;
 };
 } // namespace
+
+void Replay::takeLockstepMarginalizationCounts(long out[2]) {
+    out[0] = g_lockstep_marg_batches.exchange(0);
+    out[1] = g_lockstep_marg_windows.exchange(0);
+}
 
 bool Replay::runLockstep(const std::vector<ReplayOptions> &options, std::vector<ReplaySummary> &summaries, double *wall_seconds, long *shared_solves,
                          std::string *err, int solver_host_threads) {
@@ -270,10 +279,16 @@ bool Replay::runLockstep(const std::vector<ReplayOptions> &options, std::vector<
         if (!S[k].gvins->isRunning()) return setErr(err, "GVINS failed to start: " + S[k].gvins->error());
         S[k].gvins->setDeferredWindowSolves(true);
     }
-    long n_solves = 0, n_batches = 0, largest = 0;
+    long n_solves = 0, n_batches = 0, largest = 0, n_marg_batches = 0, n_marg_windows = 0;
     auto t0 = std::chrono::steady_clock::now();
     try {
         WindowSolverBatch batch(0, 1.0, solver_host_threads); // huber delta 1 of the reprojection factors (ic_gvins.cc:1773)
+        // ICG_LOCKSTEP_MARG_BATCH=1: the marginalizations of a tick share their device launches too (MarginalizationBatch, host/marg_batch.h;
+        // Huber delta 0: the reference builds the prior from uncorrected reprojection factors, ic_gvins.cc:1600-1606).  Opt-in until the
+        // class has been through a replay on the device (round 4 ended before that could be run).
+        std::unique_ptr<MarginalizationBatch> marg_batch;
+        if (const char *e = getenv("ICG_LOCKSTEP_MARG_BATCH"))
+            if (atoi(e) > 0) marg_batch.reset(new MarginalizationBatch(0, 0.0, solver_host_threads));
         std::vector<LockstepStream *> due;
         bool any = true;
         while (any) {
@@ -349,12 +364,52 @@ bool Replay::runLockstep(const std::vector<ReplayOptions> &options, std::vector<
                     L->gvins->finishWindowSolve(first[w], second[w], first_ms, second_ms, removed[w]);
                 }
             }
+            std::vector<LockstepStream *> solved;
             for (LockstepStream *L : due) {
                 if (L->n_visual == 0)
                     L->gvins->solveWindowAlone(0); // no visual factors yet: a host-only problem on the estimator's own WindowSolver (the window is already prepared)
+                else if (marg_batch)
+                    solved.push_back(L);
                 else
                     L->gvins->afterWindowSolve();
                 L->problem.reset();
+            }
+            if (!solved.empty()) {
+                // ---- window maintenance of this tick; the marginalizations (one per estimator that is over its keyframe count), together -------
+                for (LockstepStream *L : solved) L->gvins->afterWindowSolveBegin();
+                for (;;) {
+                    std::vector<LockstepStream *> marg;
+                    for (LockstepStream *L : solved)
+                        if (L->gvins->marginalizationDue()) marg.push_back(L);
+                    if (marg.empty()) break;
+                    marg_batch->clear();
+                    std::vector<GVINS::MarginalizationJob> jobs(marg.size());
+                    std::vector<int> window(marg.size(), -1);
+                    std::vector<std::array<double *, 6>> fac; // (one estimator's factors are collected first: only a job WITH device factors gets a window)
+                    for (size_t k = 0; k < marg.size(); k++) {
+                        fac.clear();
+                        std::vector<ReprojectionFactor *> ptr;
+                        marg[k]->gvins->beginMarginalization(jobs[k], [&](ReprojectionFactor *f, double *pi, double *pj, double *ext, double *inv, double *td) {
+                            ptr.push_back(f);
+                            fac.push_back({pi, pj, ext, inv, td, nullptr});
+                        });
+                        if (ptr.empty()) continue;
+                        window[k] = marg_batch->addWindow(jobs[k].info);
+                        for (size_t i = 0; i < ptr.size(); i++) marg_batch->addReprojectionFactor(window[k], ptr[i], fac[i][0], fac[i][1], fac[i][2], fac[i][3], fac[i][4]);
+                    }
+                    std::vector<char> ok;
+                    if (marg_batch->numWindows() > 0) {
+                        if (!marg_batch->marginalize(&ok)) return setErr(err, "batched marginalization: " + marg_batch->error());
+                        n_marg_batches++;
+                        n_marg_windows += marg_batch->numWindows();
+                    }
+                    for (size_t k = 0; k < marg.size(); k++) {
+                        const bool valid = window[k] >= 0 ? ok[(size_t) window[k]] != 0 : jobs[k].info->marginalization(); // (host factors only: on its own)
+                        marg[k]->gvins->finishMarginalization(jobs[k], valid);
+                    }
+                    marg_batch->clear();
+                }
+                for (LockstepStream *L : solved) L->gvins->afterWindowSolveEnd();
             }
         }
         for (LockstepStream &L : S) L.gvins->setFinished();
@@ -364,6 +419,7 @@ bool Replay::runLockstep(const std::vector<ReplayOptions> &options, std::vector<
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (wall_seconds) *wall_seconds = wall;
     if (shared_solves) shared_solves[0] = n_solves, shared_solves[1] = n_batches, shared_solves[2] = largest;
+    g_lockstep_marg_batches.fetch_add(n_marg_batches), g_lockstep_marg_windows.fetch_add(n_marg_windows);
     for (LockstepStream &L : S) {
         L.summary->wall_seconds = wall;
         L.summary->data_seconds = L.last - L.first;

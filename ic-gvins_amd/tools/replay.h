@@ -58,6 +58,8 @@ public:
                             long *shared_solves = nullptr, std::string *err = nullptr, int solver_host_threads = 0);
     // `groups` lock-step groups side by side (one host thread + one WindowSolverBatch each, the streams dealt out in contiguous blocks):
     // the host work per stream that is not shared (tracking stages, INS, culling, marginalization) spreads over the groups' threads
+    // batches / windows that went through a MarginalizationBatch in lock-step runs since the last call (ICG_LOCKSTEP_MARG_BATCH=1)
+    static void takeLockstepMarginalizationCounts(long out[2]);
     static bool runLockstepGroups(const std::vector<ReplayOptions> &options, int groups, std::vector<ReplaySummary> &summaries, double *wall_seconds = nullptr,
                                   long *shared_solves = nullptr, std::string *err = nullptr);
 };

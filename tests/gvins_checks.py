@@ -437,3 +437,36 @@ def check_replay_lockstep_different_streams(lib_path, tmp_root):
         assert np.array_equal(np.loadtxt(os.path.join(outs[k], "statistics.txt"))[:, keep], stat[:, keep]), k
     assert alone[1][0]["lost"] == 1 and alone[0][0]["lost"] == 0
     return [int(v) for v in shared]
+
+
+def lockstep_marg_counts(lib):
+    """(batches, windows) that went through a MarginalizationBatch in the lock-step runs since the last call"""
+    out = np.zeros(2, np.int64)
+    lib.icgh_replay_lockstep_marg_counts(out.ctypes.data_as(C.c_void_p))
+    return int(out[0]), int(out[1])
+
+
+def check_replay_lockstep_shared_marginalizations(lib_path, tmp_root, bitwise=True):
+    """ICG_LOCKSTEP_MARG_BATCH=1: the marginalizations of a tick go through ONE MarginalizationBatch (host/marg_batch.h) as the window solves
+    go through one WindowSolverBatch — identical streams (every batch holds all windows) and three different streams (batches of one, two
+    or three windows; a stream that loses track and re-initializes): every stream still equals its own replay alone."""
+    lib = C.CDLL(H.tools_lib(lib_path))
+    old = os.environ.get("ICG_LOCKSTEP_MARG_BATCH")
+    os.environ["ICG_LOCKSTEP_MARG_BATCH"] = "1"
+    try:
+        lockstep_marg_counts(lib)
+        SS, _, _ = check_replay_lockstep(lib_path, os.path.join(str(tmp_root), "same"), n=3, bitwise=bitwise, groups=1)
+        batches, windows = lockstep_marg_counts(lib)
+        n_marg = int(SS[0]["marginalizations"])
+        # (a marginalization without reprojection factors — the oldest keyframe anchors no landmark — stays with its estimator)
+        assert n_marg > 0 and windows == 3 * batches and n_marg - 4 <= batches <= n_marg, (batches, windows, n_marg)
+        if bitwise:
+            check_replay_lockstep_different_streams(lib_path, os.path.join(str(tmp_root), "diff"))
+            batches, windows = lockstep_marg_counts(lib)
+            assert windows > batches > 0, (batches, windows)  # some ticks marginalize several windows together, not all of them all
+    finally:
+        if old is None:
+            os.environ.pop("ICG_LOCKSTEP_MARG_BATCH", None)
+        else:
+            os.environ["ICG_LOCKSTEP_MARG_BATCH"] = old
+    return batches, windows

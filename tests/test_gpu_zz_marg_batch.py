@@ -6,6 +6,7 @@ import ctypes as C
 import pytest
 
 import backend_utils as bu
+import gvins_checks as gc
 import harness as H
 
 pytestmark = pytest.mark.gpu
@@ -13,3 +14,9 @@ pytestmark = pytest.mark.gpu
 
 def test_marginalization_batch_equals_per_window():
     bu.check_marginalization_batch(C.CDLL(H.HOST_LIB))
+
+
+def test_replay_lockstep_shared_marginalizations_on_gpu(tmp_path):
+    """three estimators in lock-step with ICG_LOCKSTEP_MARG_BATCH=1: every marginalization of a tick through one batched launch sequence;
+    each stream equals the stream replayed alone to the rounding of the FP64-atomic assembly"""
+    gc.check_replay_lockstep_shared_marginalizations(H.HOST_LIB, tmp_path, bitwise=False)

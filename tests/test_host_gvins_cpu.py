@@ -36,6 +36,10 @@ def test_replay_lockstep_with_different_streams(host_lib, tmp_path):
     gc.check_replay_lockstep_different_streams(host_lib, tmp_path)
 
 
+def test_replay_lockstep_shared_marginalizations(host_lib, tmp_path):
+    gc.check_replay_lockstep_shared_marginalizations(host_lib, tmp_path)
+
+
 def test_replay_tracking_loss_and_reinitialization(host_lib, tmp_path):
     gc.check_replay_tracking_loss(host_lib, tmp_path)
 

@@ -24,3 +24,18 @@ np.stack([np.stack([H.pose12(*scene.ins_pose(k, stream=s)) for k in range(ring)]
 np.asarray(cam, np.float64).tofile(os.path.join(out, "fe_cam.bin"))
 files = gvd.Sequence(lib).write(os.path.join(out, "seq"))
 print(files["config"], files["imu"], files["gnss"], files["images"])
+# 7. marg_batch.cc: one marginalization problem (the window of the back-end tests), flat binary: header of 4 int32 (factors, poses, landmarks, 0),
+#    obs (15 x n, SoA), idx_i, idx_j, idx_lm (int32 each), poses (7 per pose), extrinsic (7), inverse depths, td
+import marg_data as md  # noqa: E402
+Pm = md.make_problem(n_lm=80, n_kf=6, seed=2)
+wm = Pm["w"]
+with open(os.path.join(out, "marg_problem.bin"), "wb") as f:
+    n = Pm["obs"].shape[1]
+    np.asarray([n, wm["poses"].shape[0], wm["invdepth"].shape[0], 0], np.int32).tofile(f)
+    np.ascontiguousarray(Pm["obs"], np.float64).tofile(f)
+    for k in ("ii", "jj", "ll"):
+        np.ascontiguousarray(Pm[k], np.int32).tofile(f)
+    np.ascontiguousarray(wm["poses"], np.float64).tofile(f)
+    np.ascontiguousarray(wm["ext"], np.float64).tofile(f)
+    np.ascontiguousarray(wm["invdepth"], np.float64).tofile(f)
+    np.asarray([wm["td"]], np.float64).tofile(f)

@@ -5,6 +5,8 @@
 #   2. frontend_groups.cc   StreamGroups: 6 streams in 3 groups x 2 host threads, 30 frames each (worker threads, HostPool, pooled objects)
 #   3. icg_replay_oracle    one estimator with the host-factor helper thread (WindowSolver::setHostFactorOverlap)
 #   4. icg_replay_oracle --streams 3 --lockstep-groups 1   WindowSolverBatch with its persistent pool
+#   7. marg_batch.cc        MarginalizationBatch: 12 windows x 3 passes, per-window phases on 4 pool threads (round 4)
+#   8. icg_replay_oracle --streams 3 --lockstep-groups 1 with ICG_LOCKSTEP_MARG_BATCH=1: the marginalizations of a tick in one batch (round 4)
 # Expected: 0 "WARNING: ThreadSanitizer" in every log (round 2: all four clean).
 # SAN=address,undefined tests/tsan/run.sh /tmp/icg_asan runs the same four under AddressSanitizer + UBSan, plus 5. below (round 3: all clean).
 set -eu
@@ -24,6 +26,12 @@ $W/frontend_groups > $W/2_frontend_groups.log 2>&1
 (cd $W/src/oracle && LD_LIBRARY_PATH=. ./icg_replay_oracle --config $CFG --imu $IMU --gnss $GNSS --images $IMG --output $W/out1 > $W/3_replay_single.log 2>&1)
 mkdir -p $W/out3
 (cd $W/src/oracle && LD_LIBRARY_PATH=. ./icg_replay_oracle --config $CFG --imu $IMU --gnss $GNSS --images $IMG --output $W/out3 --streams 3 --lockstep-groups 1 > $W/4_replay_lockstep.log 2>&1)
+# 8. (round 4) the lock-step replay with the marginalizations of a tick shared through one MarginalizationBatch
+mkdir -p $W/out8
+(cd $W/src/oracle && ICG_LOCKSTEP_MARG_BATCH=1 LD_LIBRARY_PATH=. ./icg_replay_oracle --config $CFG --imu $IMU --gnss $GNSS --images $IMG --output $W/out8 --streams 3 --lockstep-groups 1 > $W/8_replay_lockstep_marg.log 2>&1)
+# 7. (round 4) MarginalizationBatch: 12 windows (one on the dense path) x 3 passes on one batch object, per-window phases on 4 pool threads
+g++ -std=c++17 -O1 -g -fsanitize=$SAN -pthread $ROOT/tests/tsan/marg_batch.cc -o $W/marg_batch -L$W/src/oracle -licgvins_host_oracle -loracle -Wl,-rpath,$W/src/oracle
+$W/marg_batch $W/marg_problem.bin > $W/7_marg_batch.log 2>&1
 # 5. (address/undefined only) the lazily built object view of the track table and its write-back — culling and window refinement through
 #    the C entry points on both engines — driven from python with the sanitizer runtime preloaded
 case "$SAN" in *address*)
@@ -62,4 +70,4 @@ print("done")
 PY
   ;;
 esac
-for f in $W/[1-6]_*.log; do echo "$(basename $f): $(grep -c 'WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error' $f || true) reports; $(tail -1 $f | cut -c1-140)"; done
+for f in $W/[1-8]_*.log; do echo "$(basename $f): $(grep -c 'WARNING: ThreadSanitizer\|ERROR: AddressSanitizer\|runtime error' $f || true) reports; $(tail -1 $f | cut -c1-140)"; done
