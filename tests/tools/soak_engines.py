@@ -5,9 +5,12 @@ write-back -> WindowCulling), outlier culling with random optimisation lists, an
 table engine those work on TableTracker::view() and are absorbed back; after every frame and every operation the canonical state dumps
 (floats as bit patterns, landmark iteration order included) and the operations' outputs must be equal.  Oracle-backed (CPU).
 
-    python tests/tools/soak_engines.py <seed> <n_scenarios>
+    python tests/tools/soak_engines.py <seed> <n_scenarios> [engine_a,engine_b]
 
-Round 3: seeds 1 (24 scenarios) and 2 (24): no divergence."""
+The engine pair defaults to table,object; round 4 adds table,core (the tracker core compiled for the host) and table,device (the
+device-resident tracker's host side on the CPU backend of icg_tracker_*: every map-writing operation goes through download / view / absorb /
+upload; ICG_TRACKER_LOG_DRAIN=30 makes the landmark-history drains frequent).
+Round 3: seeds 1 (24 scenarios) and 2 (24): no divergence.  Round 4: see DESIGN.md section 2."""
 import ctypes as C
 import os
 import sys
@@ -30,7 +33,8 @@ def first_difference(a, b):
     return i, la[i] if i < len(la) else "<end>", lb[i] if i < len(lb) else "<end>"
 
 
-def scenario(lib, rng, tag):
+def scenario(lib, rng, tag, engines=("table", "object")):
+    A, B = engines
     w, h = (640, 480) if rng.rand() < 0.85 else (1280, 720)
     n = int(rng.randint(30, 90)) if w == 640 else int(rng.randint(20, 32))
     mf = int(rng.choice([60, 100, 150]))
@@ -38,8 +42,8 @@ def scenario(lib, rng, tag):
     stream = int(rng.randint(10, 10000))
     blank = int(rng.randint(10, max(11, n - 8))) if rng.rand() < 0.3 else -1
     cam = H.camera_for(w, h)
-    sbs = {e: H.StreamBatch(lib, 1, w, h, cam, max_features=mf, window=window, engine=e) for e in ("table", "object")}
-    scene = H.SynthScene(sbs["table"].lib, w, h, cam, tex_size=1024, threads=4)
+    sbs = {e: H.StreamBatch(lib, 1, w, h, cam, max_features=mf, window=window, engine=e) for e in engines}
+    scene = H.SynthScene(sbs[A].lib, w, h, cam, tex_size=1024, threads=4)
     ops = []
     for k in range(n):
         img = scene.render(k, stream=stream)
@@ -48,7 +52,7 @@ def scenario(lib, rng, tag):
         R, t = scene.ins_pose(k, stream=stream)
         pose = np.stack([H.pose12(R, t)])
         states = {e: int(sb.step([img.ctypes.data], w, [100.0 + k / 20.0], pose)[0]) for e, sb in sbs.items()}
-        assert states["table"] == states["object"], (tag, k, states)
+        assert states[A] == states[B], (tag, k, states)
         op = None
         if k >= 10 and rng.rand() < 0.25:
             op = rng.choice(["refine", "cull", "move", "stats"])
@@ -81,8 +85,8 @@ def scenario(lib, rng, tag):
                 outs[e] = (ids.tobytes(), newpos.tobytes())
         if op:
             ops.append(op)
-            assert outs["table"] == outs["object"], (tag, k, op)
-        a, b = sbs["table"].dump(0, 0), sbs["object"].dump(0, 0)
+            assert outs[A] == outs[B], (tag, k, op)
+        a, b = sbs[A].dump(0, 0), sbs[B].dump(0, 0)
         assert a == b, (tag, k, op, first_difference(a, b))
     for sb in sbs.values():
         sb.close()
@@ -91,13 +95,14 @@ def scenario(lib, rng, tag):
 
 if __name__ == "__main__":
     seed, count = int(sys.argv[1]), int(sys.argv[2])
+    engines = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("table", "object")
     rng = np.random.RandomState(seed)
     lib = ensure_oracle_host()
     fails = 0
     for it in range(count):
         tag = f"soak_{seed}_{it}"
         try:
-            params, ops = scenario(lib, rng, tag)
+            params, ops = scenario(lib, rng, tag, engines)
             print("ok  ", tag, *params, "ops:", ",".join(ops) or "-", flush=True)
         except AssertionError as e:
             fails += 1
