@@ -238,6 +238,31 @@ def frontend_valu(pmc_file, streams_per_launch, fps):
         return None
 
 
+def measure_marg_batched(nmb, timeout=180):
+    """marg.batched: `nmb` jittered copies of the C2 window marginalized by one MarginalizationBatch (host/marg_batch.h) against
+    MarginalizationInfo::marginalization() window after window, measured by profiles/marg_batch_probe.py in a CHILD process — the block is
+    outside the headline path and must not be able to take the bench line down.  Returns the block (or {"error": ...})."""
+    import subprocess
+    try:
+        pr = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "marg_batch_probe.py"), "--windows", str(nmb)],
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        if pr.returncode != 0:
+            raise RuntimeError(f"marg_batch_probe.py exited with {pr.returncode}: {pr.stderr[-200:]}")
+        mbp = json.loads(pr.stdout.strip().splitlines()[-1])[str(nmb)]
+        return {"windows_per_batch": nmb, "value": mbp["windows_per_s"], "unit": "windows/s", "batch_ms": mbp["batch_ms"],
+                "one_by_one": {"value": mbp["windows_per_s_one_by_one"], "unit": "windows/s",
+                               "what": "MarginalizationInfo::marginalization() window after window on one ReprojectionBatch (one host thread)"},
+                "speedup": round(mbp["one_by_one_ms"] / mbp["batch_ms"], 2),
+                "windows_structured_dense": mbp["structured_dense"],
+                "max_rel_diff_Hp_vs_one_by_one": mbp["max_rel_diff_Hp"],
+                "note": "MarginalizationBatch: jittered copies of the C2 window, the fastest of 3 passes on one batch object; per pass one "
+                        "icg_reproj_eval_windows, one icg_reproj_schur_windows and one icg_reproj_landmark_diag_windows; M1 bookkeeping, "
+                        "host factors, the pose/mix-block M3 and the eigen linearization per window on the host pool "
+                        "(profiles/marg_batch_probe.py in a child process)"}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, steps, rank, local_rank, host_threads, host_frames,
                  profile, barrier, ncpu, hostprof=False, forward=False, host_lib=None, dev_sync=None):
     """One front-end throughput measurement: B independent synthetic streams in G free-running groups, raw frames resident in HBM,
@@ -1008,27 +1033,7 @@ def main():
 
         # the marginalizations of many streams in one pass (MarginalizationBatch, host/marg_batch.h): one evaluation launch, one assembly +
         # elimination launch sequence and one read-back for all windows; the per-window host phases on the pool
-        # (a child process: the block is outside the headline path and must not be able to take the line down)
-        try:
-            import subprocess
-            nmb = 256
-            pr = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "marg_batch_probe.py"), "--windows", str(nmb)],
-                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
-            if pr.returncode != 0:
-                raise RuntimeError(f"marg_batch_probe.py exited with {pr.returncode}: {pr.stderr[-200:]}")
-            mbp = json.loads(pr.stdout.strip().splitlines()[-1])[str(nmb)]
-            marg["batched"] = {"windows_per_batch": nmb, "value": mbp["windows_per_s"], "unit": "windows/s", "batch_ms": mbp["batch_ms"],
-                               "one_by_one": {"value": mbp["windows_per_s_one_by_one"], "unit": "windows/s",
-                                              "what": "MarginalizationInfo::marginalization() window after window on one ReprojectionBatch (one host thread)"},
-                               "speedup": round(mbp["one_by_one_ms"] / mbp["batch_ms"], 2),
-                               "windows_structured_dense": mbp["structured_dense"],
-                               "max_rel_diff_Hp_vs_one_by_one": mbp["max_rel_diff_Hp"],
-                               "note": "MarginalizationBatch: jittered copies of the C2 window, the fastest of 3 passes on one batch object; per pass one "
-                                       "icg_reproj_eval_windows, one icg_reproj_schur_windows and one icg_reproj_landmark_diag_windows; M1 bookkeeping, "
-                                       "host factors, the pose/mix-block M3 and the eigen linearization per window on the host pool "
-                                       "(profiles/marg_batch_probe.py in a child process)"}
-        except Exception as e:
-            marg["batched"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        marg["batched"] = measure_marg_batched(256)
 
     # ---- f3: per-observation reprojection error + isGoodToTrack gate of the culling / statistics pass ---------------------------
     cull = None

@@ -159,3 +159,18 @@ def test_marg_batch_probe_child_process_schema():
     for k in ("windows_per_s", "batch_ms", "windows_per_s_one_by_one", "one_by_one_ms", "structured_dense", "max_rel_diff_Hp"):
         assert k in d
     assert d["structured_dense"] == [4, 0] and d["max_rel_diff_Hp"] < 1e-9
+    # the bench's own wrapper around the child process (and what it does with a child that fails)
+    b = _bench()
+    os.environ["ICG_PROBE_HOST_LIB"] = env["ICG_PROBE_HOST_LIB"]
+    try:
+        blk = b.measure_marg_batched(4)
+        assert blk.get("error") is None and blk["windows_per_batch"] == 4 and blk["value"] > 0 and blk["windows_structured_dense"] == [4, 0]
+        committed = sorted(f for f in os.listdir(os.path.join(root, "profiles")) if f.startswith("r02_bench_driver_command"))
+        full = json.load(open(os.path.join(root, "profiles", committed[-1])))  # a real full record
+        full["parity"] = {"ok": True}
+        full["marg"] = dict(full.get("marg") or {"value": 1.0, "unit": "ms per marginalization"}, batched=blk)
+        assert b.compact_line(full, "details.json")["marg"]["batched"]["windows_per_batch"] == 4
+        os.environ["ICG_PROBE_HOST_LIB"] = "/nonexistent/lib.so"
+        assert "error" in b.measure_marg_batched(4)
+    finally:
+        os.environ.pop("ICG_PROBE_HOST_LIB", None)
