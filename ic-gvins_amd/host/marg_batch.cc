@@ -239,6 +239,18 @@ bool MarginalizationBatch::marginalize(std::vector<char> *ok) {
     auto t2 = now();
 
     // ---- 3: assembly + landmark elimination of every planned window, one launch sequence; the landmark diagonals --------------------------
+    // (the batched assembly holds a window's camera block in LDS — csrc/reproj.hip, schur_windows_impl: V^2 + V + 1 024 doubles within 62 KB —
+    // i.e. at most 82 free camera columns: 12 poses + extrinsic + td.  The oldest keyframe of a 15-keyframe window can be seen from more; such a
+    // window takes the dense path on its own, whose one-window assembly has no such limit)
+    const int max_camera_columns = 82;
+    for (size_t w = 0; w < NW; w++) {
+        if (!st[w].planned) continue;
+        const Slice &W = *windows_[w];
+        int V          = 0;
+        for (double *p : W.poses) V += st[w].plan.camera_column_of.count(p) ? 6 : 0;
+        V += (W.ext && st[w].plan.camera_column_of.count(W.ext) ? 6 : 0) + (W.td && st[w].plan.camera_column_of.count(W.td) ? 1 : 0);
+        if (V > max_camera_columns) st[w].planned = false;
+    }
     int P = 0;
     for (size_t w = 0; w < NW; w++)
         if (st[w].planned) P = std::max(P, st[w].plan.P);
