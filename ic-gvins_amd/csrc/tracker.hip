@@ -176,6 +176,8 @@ __global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, 
     }
     const bool active = A.active[s] != 0;
     tc::Io io = io_of(A, C, s);
+    bool log_ok  = false;
+    int log_rows = 0;
     if (active) {
         switch (stage) {
         case 1:
@@ -215,6 +217,9 @@ __global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, 
         case 6:
             assemble_corners(A, C, s);
             tc::stage_on_detect_b(S, C, io);
+            // the frame's tracking.txt line (TableTracker::endFrame writes it before the window keeper runs: same condition, same count)
+            log_ok   = S.log_valid && S.result == tc::TRACK_TRACKING && S.mode == tc::M_TRACK && S.lost_reset != 2;
+            log_rows = S.cur >= 0 ? S.frame[S.cur].n_rows : 0;
             tc::stage_end_frame(S, C);
             break;
         default: break;
@@ -238,6 +243,8 @@ __global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, 
         r.need_detect_a = (S.isinitializing && (S.ref < 0 || S.n_ref == 0)) ? 1 : 0; // stage_on_preprocess :158-170
         r.n_log         = S.n_log;
         r.lk_points = A.work[4 * s], r.detect_jobs = A.work[4 * s + 1], r.ransac_sets = A.work[4 * s + 2], r.tri_points = A.work[4 * s + 3];
+        r.log_valid = log_ok ? 1 : 0, r.log_features = log_rows;
+        for (int k = 0; k < 5; k++) r.log_data[k] = S.log_data[k];
         results[s]      = r;
     }
 }

@@ -295,6 +295,13 @@ void TableTracker::mapRemoveKeyFrame(int h, bool isremovemappoint) { // map.cc:8
     if (at >= 0) map_kf_.erase(map_kf_.begin() + at);
 }
 
+void TableTracker::writeTrackingLog(const double data5[5], int features, double cost_ms) {
+    if (!logfile_) return;
+    for (int k = 0; k < 5; k++) fprintf(logfile_, "%-15.9lf ", data5[k]);
+    fprintf(logfile_, "%-15.9lf %-15.9lf \n", static_cast<double>(features), cost_ms);
+    fflush(logfile_);
+}
+
 // Sliding-window stand-in (WindowKeeper::onFrame; ic_gvins.cc:542, 743, 1391-1410, 445-448, 1675)
 void TableTracker::endFrame() {
     if (core_) { // statistics, digest, window keeper and sweep are the core's (tc::stage_end_frame)

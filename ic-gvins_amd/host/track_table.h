@@ -113,6 +113,9 @@ public:
     // absorb() and the canonical dumps work unchanged; absorb() writes the image back (exportCore).  ICG_TRACK_ENGINE=core selects it for
     // the host executor; the device executor (tracking_device.h) keeps the blocks in HBM and hands a downloaded copy to attachCore().
     void enableCore(bool device_resident = false);
+    // the device-resident tracker's line of tracking.txt (tracking.cc:309-315): the five numbers of the keyframe decision and the feature
+    // count come with the step's result (icg_tracker_result), the time cost is the executor's
+    void writeTrackingLog(const double data5[5], int features, double cost_ms);
     bool coreMode() const { return core_ != nullptr; }
     bool coreDeviceResident() const { return core_device_resident_; }
     // device-resident block: exportCore() ran since the last call (the executor uploads the block then) / the executor restarted the

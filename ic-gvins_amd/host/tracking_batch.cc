@@ -48,7 +48,6 @@ TrackingBatch::TrackingBatch(int device, int n_streams, const vector<double> &in
     if (host_threads_ > 1 && n_streams > 1) pool_.reset(new HostPool(std::min(host_threads_, n_streams)));
     device_->setCamera(*streams_[0].camera);
     if (engine_ == ENGINE_DEVICE) {
-        if (getenv("ICG_TRACKING_LOG_DIR")) throw std::runtime_error("TrackingBatch: tracking.txt logging needs a host engine (ICG_TRACK_ENGINE=table|core)");
         const tc::Cfg C = TableTracker::makeCoreCfg(*streams_[0].camera, cfg, (size_t) window_size);
         icg_tracker_config tcfg;
         static_assert(sizeof(tcfg) == sizeof(C), "icg_tracker_config mirrors tc::Cfg");
@@ -120,6 +119,7 @@ void TrackingBatch::stepDevice(const FrameInput *frames, vector<TrackState> &sta
         s.last_state = (TrackState) r.state, s.frames = r.frames, s.keyframes = r.keyframes, s.tracked_sum = r.tracked_sum, s.digest = r.digest;
         s.ids->frame_id = r.frame_id, s.ids->keyframe_id = r.keyframe_id, s.ids->mappoint_id = r.mappoint_id;
         lk += (uint64_t) r.lk_points, det += (uint64_t) r.detect_jobs, rs += (uint64_t) r.ransac_sets, tri += (uint64_t) r.tri_points, pre++;
+        if (r.log_valid && s.table) s.table->writeTrackingLog(r.log_data, r.log_features, (t1 - t0) * 1e3); // (time cost: the group's step)
         // (ICG_TRACKER_LOG_DRAIN: drain threshold in operations, for tests; default half the block's capacity)
         static const int drain_at = getenv("ICG_TRACKER_LOG_DRAIN") ? std::max(1, atoi(getenv("ICG_TRACKER_LOG_DRAIN"))) : tc::LOG_CAP / 2;
         if (r.n_log > drain_at) dev_drain_.push_back(i), dev_drain_n_.push_back(r.n_log);

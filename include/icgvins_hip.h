@@ -350,6 +350,10 @@ typedef struct icg_tracker_result { /* per stream, after a step */
     int32_t need_detect_a;   /* the stream's next frame starts with a detection (first frame / initialization without candidates) */
     int32_t n_log;           /* landmark-container operations logged in the block since the last drain */
     int32_t lk_points, detect_jobs, ransac_sets, tri_points; /* work this frame handed to the primitives */
+    /* the frame's line of tracking.txt (tracking.cc:236-238, 309-315), when it has one: stamp, dt, parallax, translation, rotation [deg] as
+     * kept at the keyframe decision, and the frame's feature count before the window keeper ran; the caller appends its own time cost */
+    int32_t log_valid, log_features;
+    double log_data[5];
 } icg_tracker_result;
 
 /* buckets_after[k], k = 0..n_buckets_after-1: bucket count of a fresh std::unordered_map<ulong, T> after k insertions on the host's standard

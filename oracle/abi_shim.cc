@@ -777,9 +777,12 @@ int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, int stride, i
             tc::stage_on_triangulate(S, C, io, t->buckets.data(), t->scratch);
             if ((rc = detect())) return rc;
             tc::stage_on_detect_b(S, C, io);
+            r.log_valid    = (S.log_valid && S.result == tc::TRACK_TRACKING && S.mode == tc::M_TRACK && S.lost_reset != 2) ? 1 : 0;
+            r.log_features = S.cur >= 0 ? S.frame[S.cur].n_rows : 0;
             tc::stage_end_frame(S, C);
             r.active = 1;
         }
+        for (int k = 0; k < 5; k++) r.log_data[k] = S.log_data[k];
         r.state = S.result, r.is_new_keyframe = S.isnewkeyframe, r.overflow = S.overflow;
         r.n_features = S.cur >= 0 ? S.frame[S.cur].n_rows : 0, r.n_candidates = S.n_new, r.window_keyframes = S.n_map_kf, r.landmarks = S.n_landmarks;
         r.frames = S.frames, r.keyframes = S.keyframes, r.tracked_sum = S.tracked_sum, r.digest = S.digest;

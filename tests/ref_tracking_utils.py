@@ -167,19 +167,19 @@ def load(path):
                 und=[g["und"][off[k]:off[k + 1]] for k in range(n)], stats=g["stats"], log=g["log"])
 
 
-def compare_scenario(lib_path, name, ref=None, engine=None):
+def compare_scenario(lib_path, name, ref=None, engine=None, with_log=None):
     w, h, n, mf, stream, hist = SCENARIOS[name]
     old = CONFIG["check_hist"]
     CONFIG["check_hist"] = hist
     _current_scenario[0] = name
     try:
-        compare_with_host(lib_path, ref if ref is not None else load(golden_path(name)), w, h, n, mf, stream, engine=engine)
+        compare_with_host(lib_path, ref if ref is not None else load(golden_path(name)), w, h, n, mf, stream, engine=engine, with_log=with_log)
     finally:
         CONFIG["check_hist"] = old
         _current_scenario[0] = None
 
 
-def compare_with_host(lib_path, ref, w, h, n_frames, max_features, stream=0, engine=None):
+def compare_with_host(lib_path, ref, w, h, n_frames, max_features, stream=0, engine=None, with_log=None):
     """Runs the product's host layer (lib_path: GPU-backed or oracle-backed) on the same frames and asserts frame-by-frame
     equality with the reference run: track state, map-point ids of the frame's features, distorted key-point float bits, the
     un-triangulated candidate lists (current and reference pixels, list order), and the window bookkeeping (keyframe count,
@@ -187,7 +187,10 @@ def compare_with_host(lib_path, ref, w, h, n_frames, max_features, stream=0, eng
     import harness as H
     cam = H.camera_for(w, h)
     logdir = tempfile.mkdtemp(prefix="icgtrk_")
-    with_log = engine != "device"  # (the device-resident tracker keeps no tracking.txt: its host never sees the decision's numbers)
+    # tracking.txt of the device-resident tracker: the decision's numbers come back with the step result (icg_tracker_result.log_*, round 4).
+    # Compared on the CPU backend of the tracker ABI (tests/test_host_engines_cpu.py); the callers on the device do not ask for it yet.
+    if with_log is None:
+        with_log = engine != "device"
     if with_log:
         os.environ["ICG_TRACKING_LOG_DIR"] = logdir
     try:

@@ -225,3 +225,14 @@ def test_core_container_order_equals_std_unordered_map():
     for seed in range(12):
         for n_first, n_more, rounds in ((0, 1, 60), (240, 17, 20), (1, 0, 0), (13, 1, 30), (300, 50, 6), (639, 1, 1), (58, 1, 4), (127, 130, 3)):
             assert lib.icgh_core_order_selftest(seed, n_first, n_more, rounds) == 0, (seed, n_first, n_more, rounds)
+
+
+@pytest.mark.parametrize("scenario", ["c1_640x480_100", "c1_lost_histgate", "c1_slow_second_new", "c2_long_60"])
+def test_device_engine_writes_the_reference_trackers_log(scenario):
+    """tracking.txt (tracking.cc:309-315) of the device-resident tracker: the keyframe decision's numbers travel in icg_tracker_result
+    (log_valid, log_features, log_data) and the host executor writes the line — same text as the REFERENCE's own tracker wrote, in the six
+    deterministic columns (here on the shim's CPU backend of icg_tracker_*)."""
+    import ref_tracking_utils as rt
+    if scenario not in rt.SCENARIOS:
+        pytest.skip("no such golden scenario")
+    rt.compare_scenario(ensure_oracle_host(), scenario, engine="device", with_log=True)
