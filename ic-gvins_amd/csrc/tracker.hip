@@ -218,6 +218,7 @@ __global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, 
             assemble_corners(A, C, s);
             tc::stage_on_detect_b(S, C, io);
             // the frame's tracking.txt line (TableTracker::endFrame writes it before the window keeper runs: same condition, same count)
+            tc::sync();
             log_ok   = S.log_valid && S.result == tc::TRACK_TRACKING && S.mode == tc::M_TRACK && S.lost_reset != 2;
             log_rows = S.cur >= 0 ? S.frame[S.cur].n_rows : 0;
             tc::stage_end_frame(S, C);
