@@ -21,6 +21,10 @@ class WindowSolverBatch {
 public:
     typedef WindowSolver::Options Options;
     typedef WindowSolver::Summary Summary;
+    // The batched assembly holds a window's free camera columns (6 per free pose, 6 extrinsic, 1 td) as an LDS tile: V^2 + V + 1 024 doubles
+    // within 62 KB (csrc/reproj.hip, schur_windows_impl) — at most 82 columns, i.e. 12 free poses with the calibration blocks.  A window
+    // that can exceed it (a 15-keyframe window) is the caller's to solve on a WindowSolver of its own, whose assembly has no such limit.
+    static constexpr int kMaxCameraColumns = 82;
 
     // host_threads: the per-window host phases (host factors, reduced solves, cost bookkeeping) are spread over this many threads
     explicit WindowSolverBatch(int device = 0, double huber_delta = 1.0, int host_threads = 0 /* 0 = hardware concurrency, at most 16 */);

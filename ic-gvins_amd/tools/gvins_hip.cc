@@ -846,6 +846,8 @@ void GVINS::doReintegration() { // ic_gvins.cc:1680-1695: every interval that ne
 
 // ---- the window solve ------------------------------------------------------------------------------------------------------------
 // ---- the window solve in phases (ic_gvins.cc:1130-1239) --------------------------------------------------------------------------
+int GVINS::windowCameraColumnsBound() const { return 6 * (int) map_->keyframes().size() + 7; }
+
 int GVINS::beginWindowSolve() { // parameters and factors of the visual part (:1150-1154, 1173)
     PhaseTimer pt(phase_ms_, PH_BUILD);
     addReprojectionParameters();

@@ -130,6 +130,8 @@ public:
     void setDeferredWindowSolves(bool on) { deferred_window_solves_ = on; }
     bool windowSolvePending() const { return window_solve_pending_; }
     int beginWindowSolve();
+    // upper bound of the free camera columns of this estimator's window in a batched solve: 6 per keyframe in the map, extrinsic 6, td 1
+    int windowCameraColumnsBound() const;
     void populateWindow(WindowProblem &problem, int n_visual);
     void betweenWindowSolves(WindowProblem &problem);
     void finishWindowSolve(const WindowSolver::Summary &first, const WindowSolver::Summary &second, double first_ms, double second_ms, int chi2_removed);

@@ -245,6 +245,7 @@ struct LockstepStream {
     ReplaySummary *summary = nullptr;
     std::unique_ptr<BatchWindowProblem> problem;
     int n_visual = 0;
+    bool alone   = false;
 };
 } // namespace
 
@@ -338,7 +339,8 @@ bool Replay::runLockstep(const std::vector<ReplayOptions> &options, std::vector<
             std::vector<LockstepStream *> batched;
             for (LockstepStream *L : due) {
                 L->n_visual = L->gvins->beginWindowSolve();
-                if (L->n_visual == 0) continue;
+                L->alone    = L->n_visual == 0 || L->gvins->windowCameraColumnsBound() > WindowSolverBatch::kMaxCameraColumns;
+                if (L->alone) continue; // (no visual factors yet, or a window too wide for the batched assembly's LDS tile: 15 keyframes)
                 L->problem.reset(new BatchWindowProblem(batch, batch.addWindow()));
                 L->gvins->populateWindow(*L->problem, L->n_visual);
                 batched.push_back(L);
@@ -366,8 +368,8 @@ bool Replay::runLockstep(const std::vector<ReplayOptions> &options, std::vector<
             }
             std::vector<LockstepStream *> solved;
             for (LockstepStream *L : due) {
-                if (L->n_visual == 0)
-                    L->gvins->solveWindowAlone(0); // no visual factors yet: a host-only problem on the estimator's own WindowSolver (the window is already prepared)
+                if (L->alone)
+                    L->gvins->solveWindowAlone(L->n_visual); // on the estimator's own WindowSolver (the window is already prepared)
                 else if (marg_batch)
                     solved.push_back(L);
                 else
