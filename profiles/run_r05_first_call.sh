@@ -3,7 +3,8 @@
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash profiles/run_r05_first_call.sh'
 # 1. the whole GPU suite (tests/test_gpu_zz_marg_batch.py last: MarginalizationBatch in its final form, the lock-step replay with shared
 #    marginalizations)
-# 2. tracking.txt of the device-resident tracker against the reference tracker's goldens ON THE DEVICE (round 4 compared it on the CPU backend)
+# 2. (now inside the suite: tests/test_gpu_device_tracker.py::test_device_tracker_writes_the_reference_tracking_txt, and the 15-keyframe
+#    lock-step replay in tests/test_gpu_zz_marg_batch.py)
 # 3. MarginalizationBatch throughput (steady state: one batch object, three passes) at 16 / 64 / 256 windows, with the phase split
 # 4. lock-step replay of 8 estimators in one group with and without ICG_LOCKSTEP_MARG_BATCH=1
 # 5. the driver's command (engine_twin and marg.batched in the line)
@@ -12,14 +13,7 @@ O=$R/gpurun_out/r5first
 mkdir -p $O
 cd $R
 export PYTHONPATH=$R/tests:$R/ic-gvins_amd:$R
-timeout 300 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/gputests.txt; cat $O/gputests.txt
-timeout 200 python - > $O/device_log.txt 2>&1 <<'PY'
-import ref_tracking_utils as rt, harness as H
-for name in ("c1_640x480_100", "c1_lost_histgate", "c1_slow_second_new", "c2_long_60", "c4_1920x1080_500"):
-    rt.compare_scenario(H.HOST_LIB, name, engine="device", with_log=True)
-    print("ok", name, flush=True)
-PY
-tail -6 $O/device_log.txt
+timeout 420 python -m pytest tests -m gpu -q --durations=12 2>&1 | tail -24 > $O/gputests.txt; cat $O/gputests.txt
 ICG_MARG_DEBUG=1 timeout 120 python profiles/marg_batch_probe.py $O/marg_batch_probe.json > $O/marg_batch_probe.out 2> $O/marg_batch_probe.err
 cat $O/marg_batch_probe.json; grep "batch\]" $O/marg_batch_probe.err | tail -3
 timeout 300 python - > $O/lockstep_marg.txt 2>&1 <<'PY'

@@ -472,7 +472,7 @@ def check_replay_lockstep_shared_marginalizations(lib_path, tmp_root, bitwise=Tr
     return batches, windows
 
 
-def check_replay_lockstep_wide_windows(lib_path, tmp_root, n=2):
+def check_replay_lockstep_wide_windows(lib_path, tmp_root, n=2, bitwise=True):
     """15-keyframe windows (BASELINE configs[3]): once a window has more free camera columns than the batched assembly's LDS tile holds
     (WindowSolverBatch::kMaxCameraColumns = 82: 13 keyframes with the calibration blocks), the lock-step driver solves it on the estimator's
     own WindowSolver — on the device the batched call would refuse it.  Every stream still equals its own replay alone, bit for bit, and
@@ -482,6 +482,7 @@ def check_replay_lockstep_wide_windows(lib_path, tmp_root, n=2):
     files = seq.write(str(tmp_root), optimize_windows_size=15)
     S = run_replay(lib, files)
     alone = open(os.path.join(files["out"], "trajectory.csv"), "rb").read()
+    alone_rows = np.loadtxt(os.path.join(files["out"], "trajectory.csv"))
     outs = [os.path.join(str(tmp_root), "lock%d" % k) for k in range(n)]
     SS, _, shared = run_replay_lockstep(lib, files, outs, 1)
     assert shared[0] == n * (S["optimizations"] - 1)
@@ -489,5 +490,9 @@ def check_replay_lockstep_wide_windows(lib_path, tmp_root, n=2):
     assert 0 < shared[1] and batched_windows_upper < shared[0], shared  # the early (narrow) windows are batched, the wide ones are not
     for k, o in enumerate(outs):
         assert all(SS[k][key] == S[key] for key in ("frames_tracked", "keyframes", "optimizations", "marginalizations", "lost", "final_state")), k
-        assert open(os.path.join(o, "trajectory.csv"), "rb").read() == alone, k
+        if bitwise:
+            assert open(os.path.join(o, "trajectory.csv"), "rb").read() == alone, k
+        else:  # (on the device the FP64-atomic assembly reorders sums from launch to launch)
+            rows = np.loadtxt(os.path.join(o, "trajectory.csv"))
+            assert rows.shape == alone_rows.shape and np.abs(rows - alone_rows).max() < 1e-3, k
     return shared

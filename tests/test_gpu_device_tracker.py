@@ -20,6 +20,14 @@ def test_device_tracker_matches_reference_tracker_golden(scenario):
     rt.compare_scenario(H.HOST_LIB, scenario, engine="device")
 
 
+@pytest.mark.parametrize("scenario", ["c1_640x480_100", "c1_lost_histgate", "c1_slow_second_new", "c2_long_60", "c4_1920x1080_500"])
+def test_device_tracker_writes_the_reference_tracking_txt(scenario):
+    """tracking.txt (reference tracking/tracking.cc:297-315): the keyframe decision's numbers travel in icg_tracker_result.log_* from the
+    stage kernel on the MI355X, the executor writes the line — the reference tracker's own text in the deterministic columns"""
+    import ref_tracking_utils as rt
+    rt.compare_scenario(H.HOST_LIB, scenario, engine="device", with_log=True)
+
+
 def _drive(lib, engine, w, h, nfeat, frames, poses, n_streams, dump_at, groups=1):
     cam = H.camera_for(w, h)
     sb = H.StreamBatch(lib, n_streams, w, h, cam, max_features=nfeat, engine=engine, groups=groups)

@@ -20,3 +20,9 @@ def test_replay_lockstep_shared_marginalizations_on_gpu(tmp_path):
     """three estimators in lock-step with ICG_LOCKSTEP_MARG_BATCH=1: every marginalization of a tick through one batched launch sequence;
     each stream equals the stream replayed alone to the rounding of the FP64-atomic assembly"""
     gc.check_replay_lockstep_shared_marginalizations(H.HOST_LIB, tmp_path, bitwise=False)
+
+
+def test_replay_lockstep_wide_windows_on_gpu(tmp_path):
+    """15-keyframe windows (BASELINE configs[3]) through icgh_replay_run_lockstep on the device: every stream equals its own replay alone to
+    the rounding of the FP64-atomic assembly, whichever path (batched or the estimator's own solver) takes the wide windows"""
+    gc.check_replay_lockstep_wide_windows(H.HOST_LIB, tmp_path, bitwise=False)
