@@ -753,9 +753,11 @@ __global__ __launch_bounds__(256, 1) void k_fm_ransac_sets(int n_sets, int seg_c
             iter_sh = iter, niters_sh = niters, max_good_sh = max_good;
         }
         __syncthreads();
-        if (iter_sh >= niters_sh) break;
+        // (the stop test is read into a register by every thread BEFORE thread 0 may write niters_sh at the top of the next round)
+        const bool stop = iter_sh >= niters_sh;
+        __syncthreads();
+        if (stop) break;
     }
-    __syncthreads();
     const bool found = max_good_sh > 0;
     for (int i = t; i < n; i += 256) m[i] = found ? (uint8_t) ((best_sh[i >> 6] >> (i & 63)) & 1ull) : (uint8_t) 0;
 }

@@ -7,6 +7,7 @@
 // doubles of each factor transposed through LDS (row stride 49 to spread banks) so a 64-factor wave writes its
 // r[64x2] and J[64x46] slabs as contiguous 16-B-per-lane stores.
 // Algorithmic bytes per factor with Jacobians: 120 (obs) + 12 (indices) + 384 (out) = 516 B.
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -354,6 +355,20 @@ extern "C" int icg_reproj_eval_batch(icg_ctx *ctx, int n, const double *obs_soa,
 // Summation order is not fixed -> results equal the sequential sum to ~1e-15 relative (tolerance-tested, not bit-tested).
 #define NRM_BLOCK 256
 
+// gfx950 has 160 KiB of LDS per CU and one workgroup may own all of it (MI355X_MICROARCH.md, "LDS"); a launch with more dynamic LDS than the
+// 64 KiB default needs the function attribute.  The camera-block tiles of the assembly kernels and the batched Cholesky are sized by the
+// window (97 free columns for the 15-keyframe windows of BASELINE configs[3] = 76 KB), so their launches go through this.
+static constexpr size_t RPJ_LDS_LIMIT = 160 * 1024 - 256; // (- the kernels' few static words)
+template <typename K> static int rpj_allow_lds(icg_ctx *ctx, K kernel, size_t bytes, int slot) {
+    static std::atomic<size_t> granted[4][16];
+    if (bytes <= 48 * 1024) return 0;
+    const int dev = ctx->cfg.device & 15;
+    if (granted[slot][dev].load(std::memory_order_relaxed) >= bytes) return 0;
+    ICG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) RPJ_LDS_LIMIT));
+    granted[slot][dev].store(RPJ_LDS_LIMIT, std::memory_order_relaxed);
+    return 0;
+}
+
 __global__ __launch_bounds__(NRM_BLOCK) void k_reproj_normal(int n, const double *r, const double *J, const int32_t *idx_i,
                                                              const int32_t *idx_j, const int32_t *idx_lm,
                                                              const int32_t *col_pose, int col_ext, const int32_t *col_lm,
@@ -699,11 +714,12 @@ extern "C" int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, in
         ICG_HIP(ctx, hipMemsetAsync(d_H, 0, sizeof(double) * (N * N + N + (size_t) L + 1), ctx->stream));
         icg_prof_scope ps(ctx, "reproj_normal");
         const size_t lds = sizeof(double) * ((size_t) V * V + V);
-        if (lds <= 60 * 1024) {
+        if (lds <= RPJ_LDS_LIMIT) {
+            if ((rc = rpj_allow_lds(ctx, k_reproj_normal_schur, lds, 0))) return rc;
             hipLaunchKernelGGL(k_reproj_normal_schur, dim3((n + NRM_BLOCK - 1) / NRM_BLOCK), dim3(NRM_BLOCK), lds, ctx->stream, n, d_r, d_J,
                                (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n), (const int32_t *) (ctx->d_fidx + 2 * (size_t) n),
                                d_vp, vcol_ext, vcol_td, d_vm, V, P, (int) N, d_H, d_b, d_act);
-        } else { // windows with more than ~14 free poses: the camera block does not fit the default LDS budget
+        } else { // more than 142 free camera columns (23 free poses): the camera block does not fit a CU's LDS
             hipLaunchKernelGGL(k_reproj_normal, dim3((n + NRM_BLOCK - 1) / NRM_BLOCK), dim3(NRM_BLOCK), 0, ctx->stream, n, d_r, d_J,
                                (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n), (const int32_t *) (ctx->d_fidx + 2 * (size_t) n),
                                d_cp, (int) col_ext, (const int32_t *) nullptr, (int) col_td, (int) N, d_H, d_b, d_act, P);
@@ -1214,7 +1230,9 @@ static int schur_windows_impl(icg_ctx *ctx, int P, const int32_t *col_pose, cons
         Vmax           = std::max(Vmax, (int) Vw[(size_t) w]);
     }
     const size_t lds = sizeof(double) * ((size_t) Vmax * Vmax + Vmax + LM_SLOTS * 16) + sizeof(int) * LM_SLOTS;
-    if (lds > 62 * 1024) return icg_fail(ctx, ICG_ERR_CAPACITY, "a window has %d free camera columns: more than the LDS tile of the batched assembly holds", Vmax);
+    if (lds > RPJ_LDS_LIMIT)
+        return icg_fail(ctx, ICG_ERR_CAPACITY, "a window has %d free camera columns: more than the LDS tile of the batched assembly holds (138)", Vmax);
+    if ((rc = rpj_allow_lds(ctx, k_reproj_normal_schur_w, lds, 1))) return rc;
     std::vector<int32_t> vmap_all((size_t) W * Vmax, 0);
     for (int w = 0; w < W; w++) std::copy(vmaps[(size_t) w].begin(), vmaps[(size_t) w].end(), vmap_all.begin() + (size_t) w * Vmax);
     for (int w = 0; w < W; w++)
@@ -1460,7 +1478,7 @@ extern "C" int icg_reproj_set_host_part_windows(icg_ctx *ctx, int P, int n_upd, 
 }
 
 // For every window with stepped[w] != 0: (S_w + hostS_w + diag(dd_w)) delta_c_w = rhs_w on the leading Pw[w] columns (batched Cholesky in
-// LDS, P <= 88), then the landmark back-substitution of icg_reproj_backsub_windows with those steps, in one call: per LM step only rhs, dd
+// LDS, P <= 142), then the landmark back-substitution of icg_reproj_backsub_windows with those steps, in one call: per LM step only rhs, dd
 // go up and delta_c, ok, delta_l and the two model-decrease sums come back; the P x P systems never leave the device.
 extern "C" int icg_reproj_solve_backsub_windows(icg_ctx *ctx, int P, const int32_t *Pw, const uint8_t *stepped, const double *rhs,
                                                 const double *dd, double *delta_c, uint8_t *ok, double *delta_l, double *lm_terms) {
@@ -1469,8 +1487,9 @@ extern "C" int icg_reproj_solve_backsub_windows(icg_ctx *ctx, int P, const int32
         return icg_fail(ctx, ICG_ERR_INVALID, "no resident reduced systems of size %d: call icg_reproj_schur_windows_resident first", P);
     const int W = ctx->n_windows, n_lm = ctx->w_lm_off[(size_t) W];
     const size_t lds = sizeof(double) * ((size_t) P * P + (size_t) P);
-    if (lds > 63 * 1024) return icg_fail(ctx, ICG_ERR_CAPACITY, "reduced system of %d columns does not fit the LDS tile of the batched Cholesky (<= 88)", P);
+    if (lds > RPJ_LDS_LIMIT) return icg_fail(ctx, ICG_ERR_CAPACITY, "reduced system of %d columns does not fit the LDS tile of the batched Cholesky (<= 142)", P);
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (int rca = rpj_allow_lds(ctx, k_chol_solve_w, lds, 2)) return rca;
     int rc = icg_reproj_set_host_part_windows(ctx, P, 0, nullptr, nullptr); // (allocates a zero host part if none was ever set)
     if (rc) return rc;
     std::vector<win_desc> wd;

@@ -613,7 +613,11 @@ int icgh_backend_marginalize_batch(int mode, int n_windows, int dense_window, do
                 auto t0         = std::chrono::steady_clock::now();
                 const bool good = mb->marginalize(&ok);
                 took            = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                if (!good) what = mb->error();
+                if (!good) {
+                    set_err(err, errlen, ("batched marginalization failed: " + mb->error()).c_str());
+                    return -2;
+                }
+                what = mb->windowError();
                 counts[0] = mb->structuredWindows(), counts[1] = mb->denseWindows();
             } else {
                 for (size_t w = 0; w < wins.size(); w++) {

@@ -1,5 +1,6 @@
 // MarginalizationBatch: see marg_batch.h.  Reference: factors/marginalization_info.h:73-101 (marginalization), :153-273 (the steps).
 #include "marg_batch.h"
+#include "solver_batch_hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -187,6 +188,7 @@ bool MarginalizationBatch::marginalize(std::vector<char> *ok) {
     n_structured_ = n_dense_ = 0;
     phase_ms_[0] = phase_ms_[1] = phase_ms_[2] = phase_ms_[3] = 0;
     error_.clear();
+    window_error_.clear();
     if (NW == 0) return true;
     if (!laid_out_ && !layout()) return false;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -239,10 +241,10 @@ bool MarginalizationBatch::marginalize(std::vector<char> *ok) {
     auto t2 = now();
 
     // ---- 3: assembly + landmark elimination of every planned window, one launch sequence; the landmark diagonals --------------------------
-    // (the batched assembly holds a window's camera block in LDS — csrc/reproj.hip, schur_windows_impl: V^2 + V + 1 024 doubles within 62 KB —
-    // i.e. at most 82 free camera columns: 12 poses + extrinsic + td.  The oldest keyframe of a 15-keyframe window can be seen from more; such a
-    // window takes the dense path on its own, whose one-window assembly has no such limit)
-    const int max_camera_columns = 82;
+    // (the batched assembly holds a window's camera block in LDS — csrc/reproj.hip, schur_windows_impl: V^2 + V + 1 024 doubles within the
+    // 160 KiB of a gfx950 CU — i.e. at most 138 free camera columns: 21 poses + extrinsic + td, so the 15-keyframe windows of BASELINE
+    // configs[3] (97 columns) are batched; a wider window takes the dense path on its own, whose one-window assembly has no such limit)
+    const int max_camera_columns = WindowSolverBatch::kMaxCameraColumns;
     for (size_t w = 0; w < NW; w++) {
         if (!st[w].planned) continue;
         const Slice &W = *windows_[w];
@@ -316,13 +318,16 @@ bool MarginalizationBatch::marginalize(std::vector<char> *ok) {
         windows_[w]->evaluated = false;
         if (good[w]) (structured[w] ? n_structured_ : n_dense_)++;
         if (ok) (*ok)[w] = good[w];
-        if (!good[w] && st[w].alive && error_.empty() && !windows_[w]->err.empty()) error_ = windows_[w]->err;
+        // (a window that failed on its own — its dense path left a message — is reported through ok[w] and windowError() only: the other
+        // windows' priors are good, as they are when every stream marginalizes alone and one of them logs "no valid prior")
+        if (!good[w] && st[w].alive && window_error_.empty() && !windows_[w]->err.empty())
+            window_error_ = "window " + std::to_string(w) + ": " + windows_[w]->err;
     }
     phase_ms_[0] = ms(t0, t1), phase_ms_[1] = ms(t1, t2), phase_ms_[2] = ms(t2, t3), phase_ms_[3] = ms(t3, t4);
     if (getenv("ICG_MARG_DEBUG"))
         fprintf(stderr, "[marginalization batch] %zu windows (%d structured, %d dense): evaluate %.3f ms, bookkeeping + host factors %.3f ms, assemble + eliminate %.3f ms, M3 + linearize %.3f ms\n",
                 NW, n_structured_, n_dense_, phase_ms_[0], phase_ms_[1], phase_ms_[2], phase_ms_[3]);
-    return error_.empty();
+    return true; // (false above: a launch all windows share failed)
 }
 
 } // namespace icg

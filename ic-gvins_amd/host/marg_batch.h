@@ -49,7 +49,8 @@ public:
     void clear();
 
     // marginalization() of every window.  ok[w] = what the window's own call would have returned (false: info->isValid() is false, as
-    // there); the return value is false only when a device call failed (error()).
+    // there); the return value is false only when a device call all windows share failed (error()).  A window that failed by itself
+    // (its dense fallback could not run) has ok[w] == 0 and its message in windowError(); the other windows are unaffected.
     bool marginalize(std::vector<char> *ok);
 
     // diagnostics of the last marginalize(): windows that took the landmark-eliminated device path / the dense path; wall time of the
@@ -58,6 +59,7 @@ public:
     int denseWindows() const { return n_dense_; }
     const double *lastPhaseMs() const { return phase_ms_; }
     const std::string &error() const { return error_; }
+    const std::string &windowError() const { return window_error_; } // first per-window failure of the last marginalize()
 
 private:
     // one window's view of the batch: what MarginalizationInfo asks of its device factors
@@ -97,7 +99,7 @@ private:
     int n_factors_{0}, n_poses_{0}, n_lm_{0};
     int n_structured_{0}, n_dense_{0};
     double phase_ms_[4]{0, 0, 0, 0};
-    std::string error_;
+    std::string error_, window_error_;
 };
 
 } // namespace icg

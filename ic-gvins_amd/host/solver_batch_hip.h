@@ -22,9 +22,10 @@ public:
     typedef WindowSolver::Options Options;
     typedef WindowSolver::Summary Summary;
     // The batched assembly holds a window's free camera columns (6 per free pose, 6 extrinsic, 1 td) as an LDS tile: V^2 + V + 1 024 doubles
-    // within 62 KB (csrc/reproj.hip, schur_windows_impl) — at most 82 columns, i.e. 12 free poses with the calibration blocks.  A window
-    // that can exceed it (a 15-keyframe window) is the caller's to solve on a WindowSolver of its own, whose assembly has no such limit.
-    static constexpr int kMaxCameraColumns = 82;
+    // within the 160 KiB of a gfx950 CU (csrc/reproj.hip, schur_windows_impl / RPJ_LDS_LIMIT) — at most 138 columns, i.e. 21 free poses with
+    // the calibration blocks (rounds 2-4 sized the tile for 64 KiB: 82 columns, which kept the 15-keyframe windows of BASELINE configs[3]
+    // out).  A window that can exceed it is the caller's to solve on a WindowSolver of its own, whose assembly falls back to global atomics.
+    static constexpr int kMaxCameraColumns = 138;
 
     // host_threads: the per-window host phases (host factors, reduced solves, cost bookkeeping) are spread over this many threads
     explicit WindowSolverBatch(int device = 0, double huber_delta = 1.0, int host_threads = 0 /* 0 = hardware concurrency, at most 16 */);

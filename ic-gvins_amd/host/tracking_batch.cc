@@ -168,6 +168,9 @@ void TrackingBatch::Stream::commitMap() {
     if (tracker && table->coreMode() && table->takeCoreChanged()) { // the write-back goes into the device's block
         if (icg_tracker_upload(tracker, tracker_index, table->core()) != ICG_OK) throw std::runtime_error("icg_tracker_upload failed");
         table->coreLogRestarted(); // (exportCore emptied the history: map_lm_ is current)
+        // culling removes landmarks, refinement removes keyframes: the counts of the last step's results follow the uploaded block
+        last.landmarks        = (int32_t) table->landmarks();
+        last.window_keyframes = (int32_t) table->windowKeyFrames();
     }
 }
 

@@ -40,9 +40,10 @@ public:
         std::shared_ptr<WindowKeeper> keeper;
         Frame::Ptr frame; // the object engine's frame of the current step
         StageBatch box[2];
-        bool frameDone() const { return table ? table->frameDone() : tracking->frameDone(); }
-        TrackState result() const { return table ? table->result() : tracking->result(); }
-        bool isNewKeyFrame() const { return table ? table->isNewKeyFrame() : tracking->isNewKeyFrame(); }
+        // (ENGINE_DEVICE: the step's results are the stream's state — the table's copy of the block may be absent or older)
+        bool frameDone() const { return tracker ? true : table ? table->frameDone() : tracking->frameDone(); }
+        TrackState result() const { return tracker ? (TrackState) last.state : table ? table->result() : tracking->result(); }
+        bool isNewKeyFrame() const { return tracker ? last.is_new_keyframe != 0 : table ? table->isNewKeyFrame() : tracking->isNewKeyFrame(); }
         const vector<Point2f> &trackedRefPoints() const { return syncDevice(), table ? table->trackedRefPoints() : tracking->trackedRefPoints(); }
         const vector<Point2f> &referencePoints() const { return syncDevice(), table ? table->referencePoints() : tracking->referencePoints(); }
         size_t windowKeyFrames() const { return tracker ? (size_t) last.window_keyframes : table ? table->windowKeyFrames() : map->keyframes().size(); }

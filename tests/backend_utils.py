@@ -304,12 +304,12 @@ def check_marginalization_batch(lib):
     # a batch object re-used for the next set of windows (clear() keeps the device context and its buffers)
     f = backend_marginalize_batch(lib, P, 4, 0, reps=3)
     assert np.abs(f["Hp"] - c["Hp"]).max() < 1e-9 * np.abs(c["Hp"]).max() and (f["structured"], f["dense"]) == (4, 0)
-    # a window whose camera block exceeds the LDS tile of the batched assembly (15 keyframes: 15 x 6 + 7 = 97 > 82 columns) takes the dense path
-    # inside the batch; the same window alone takes the landmark-eliminated path (its one-window assembly has no such limit): same prior
+    # 15-keyframe windows (BASELINE configs[3]: 15 x 6 + 7 = 97 free camera columns = a 76 KB LDS tile; rounds 2-4 capped the tile at 64 KB /
+    # 82 columns and sent such windows down the dense path) are batched on gfx950's 160 KiB of LDS: same prior as each window alone
     P15 = md.make_problem(n_lm=120, n_kf=15, seed=9)
     g = backend_marginalize_batch(lib, P15, 3, 0)
     h = backend_marginalize_batch(lib, P15, 3, 1)
-    assert (g["structured"], g["dense"]) == (0, 3) and (h["structured"], h["dense"]) == (3, 0)
+    assert (g["structured"], g["dense"]) == (3, 0) and (h["structured"], h["dense"]) == (3, 0)
     for k in range(3):
         scale = np.abs(h["Hp"][k]).max()
         assert np.abs(g["Hp"][k] - h["Hp"][k]).max() < 1e-9 * scale and np.abs(g["bp"][k] - h["bp"][k]).max() < 1e-9 * max(1.0, np.abs(h["bp"][k]).max())

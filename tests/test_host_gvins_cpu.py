@@ -40,7 +40,7 @@ def test_replay_lockstep_shared_marginalizations(host_lib, tmp_path):
     gc.check_replay_lockstep_shared_marginalizations(host_lib, tmp_path)
 
 
-def test_replay_lockstep_solves_wide_windows_alone(host_lib, tmp_path):
+def test_replay_lockstep_batches_wide_windows(host_lib, tmp_path):
     gc.check_replay_lockstep_wide_windows(host_lib, tmp_path)
 
 
