@@ -290,11 +290,15 @@ __device__ __forceinline__ float2 subpix_corner(subpix_smem &S, const det_roi &R
             S.terms[i][4] = gxy * px + gyy * py;
         }
         DET_WAVE_SYNC();
-        // the five 121-term sums keep the CPU's sequential raster order, but run side by side on lanes 0..4
+        // the five 121-term sums keep the CPU's sequential raster order and run side by side: sum q on every lane with lane % 5 == q.
+        // (Round 5: ALL lanes add, lanes 5..63 as copies of lanes 0..4 — an FP64 add issued with 16 or fewer active lanes takes ~5x as long on
+        // gfx950 as one issued with more, profiles/ubench/valu_cost_r05.txt: under `if (lane < 5)` this chain was 121 x 8.9 ns per iteration;
+        // the LDS reads of the copies are broadcasts of the same five addresses.)
         double acc = 0;
-        if (lane < 5) {
+        {
+            const int q = lane % 5;
 #pragma unroll 11
-            for (int i = 0; i < 121; i++) acc += S.terms[i][lane];
+            for (int i = 0; i < 121; i++) acc += S.terms[i][q];
         }
         const double a = __shfl(acc, 0, 64), b = __shfl(acc, 1, 64), c = __shfl(acc, 2, 64);
         const double bb1 = __shfl(acc, 3, 64), bb2 = __shfl(acc, 4, 64);

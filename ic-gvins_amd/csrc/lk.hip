@@ -60,13 +60,19 @@ __device__ __forceinline__ int dpp_add_mirror(int v) { return v + __builtin_amdg
 // half, which both survive the remaining cross-row stages (row_mirror / row_bcast15 / row_bcast31, one fused
 // v_add_u32_dpp each) without overflow; lane 63 holds both totals, hi*65536 + lo is formed exactly in double and one
 // v_cvt_f32_f64 rounds once (RNE) like i64->f32.  No scalar carry chains, no 64-bit DPP moves.
+// (round 5) the totals are combined in f32, not f64: |hi| < 2^24 and lo < 2^24 convert exactly, hi * 65536 is exact, and the one rounding of
+// the fused multiply-add is RNE of the exact integer hi * 65536 + lo — what i64 -> f32 gives.  Two conversions + one v_fma on the lane that
+// holds the totals, ONE v_readlane of the result (was: two readlanes, two v_cvt_f64_i32, v_ldexp_f64, v_add_f64, v_cvt_f32_f64).
+__device__ __forceinline__ float lk_combine_f32(int hi, int lo) { return __builtin_fmaf((float) hi, 65536.f, (float) lo); }
+__device__ __forceinline__ float lk_readlane_f32(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 __device__ __forceinline__ float wave_sum_tail_f32(int hi, int lo) {
     hi += __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false); // row_bcast15: rows 1,3 += lane 15 of rows 0,2
     lo += __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);
     hi += __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false); // row_bcast31: rows 2,3 += lane 31
     lo += __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);
-    const int th = __builtin_amdgcn_readlane(hi, 63), tl = __builtin_amdgcn_readlane(lo, 63);
-    return (float) ((double) th * 65536.0 + (double) tl);
+    return lk_readlane_f32(lk_combine_f32(hi, lo), 63);
 }
 // |per-lane partial| <= 2^28: sums of 8 lanes fit in int32
 __device__ __forceinline__ float wave_sum_i32x8_f32(int v) {
@@ -87,7 +93,59 @@ __device__ __forceinline__ float wave_sum_i32x16_f32(int v) {
     return wave_sum_tail_f32(v >> 16, v & 0xffff);
 }
 
+// TWO exact wave-wide sums from ONE reduction tree (round 5).  v_permlane32_swap (gfx950) exchanges the upper half of the first register with
+// the lower half of the second: one add later lanes 0..31 hold the 2-lane sums of v1 and lanes 32..63 those of v2, and every further DPP
+// stage works on both values at once; lane 31 ends with the total of v1, lane 63 with the total of v2.
+typedef unsigned int lk_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int lk_fold32(int v1, int v2) {
+    const lk_u2 r = __builtin_amdgcn_permlane32_swap((unsigned int) v1, (unsigned int) v2, false, false);
+    return (int) (r.x + r.y);
+}
+__device__ __forceinline__ void wave_sum2_finish_f32(int hi, int lo, float &f1, float &f2) {
+    hi += __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false); // row_bcast15: lanes 31 / 63 = totals of lanes 0..31 / 32..63
+    lo += __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);
+    const float t = lk_combine_f32(hi, lo);
+    f1 = lk_readlane_f32(t, 31);
+    f2 = lk_readlane_f32(t, 63);
+}
+// |per-lane partial| <= 2^28: sums of 8 lanes fit in int32
+__device__ __forceinline__ void wave_sum2_i32x8_f32(int v1, int v2, float &f1, float &f2) {
+    int v = lk_fold32(v1, v2);
+    v     = dpp_add_xor1(v);
+    v     = dpp_add_xor2(v);
+    int hi = v >> 16, lo = v & 0xffff;
+    hi     = dpp_add_half_mirror(hi);
+    lo     = dpp_add_half_mirror(lo);
+    hi     = dpp_add_mirror(hi);
+    lo     = dpp_add_mirror(lo);
+    wave_sum2_finish_f32(hi, lo, f1, f2);
+}
+// |per-lane partial| <= 2^27: sums of 16 lanes fit in int32
+__device__ __forceinline__ void wave_sum2_i32x16_f32(int v1, int v2, float &f1, float &f2) {
+    int v = lk_fold32(v1, v2);
+    v     = dpp_add_xor1(v);
+    v     = dpp_add_xor2(v);
+    v     = dpp_add_half_mirror(v);
+    int hi = v >> 16, lo = v & 0xffff;
+    hi     = dpp_add_mirror(hi);
+    lo     = dpp_add_mirror(lo);
+    wave_sum2_finish_f32(hi, lo, f1, f2);
+}
+
 __device__ __forceinline__ int lk_descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
+
+// The Q14 weights as the packed pairs the blends consume, W0 = (w00, w01), W1 = (w10, w11) (round 5).  rint() by the magic constant: for
+// 0 <= x < 2^22 the low 16 bits of bits(x + 1.5 * 2^23) are rint(x) (the addition rounds to nearest even on an integer grid and the
+// constant is even) — one full-rate v_add_f32 instead of v_rndne_f32 + v_cvt_i32_f32; w11 = 2^14 - w00 - w01 - w10 is formed on the biased
+// bit patterns modulo 2^16 (the three biases 0x4B400000 have zero low halves) and v_perm picks the low halves.  Same weights, bit for bit.
+__device__ __forceinline__ void lk_weights_pk(float a, float b, unsigned int &W0, unsigned int &W1) {
+    const float A = a * (float) (1 << 14), A1 = (float) (1 << 14) - A, b1 = 1.f - b;
+    const unsigned int r00 = __float_as_uint(A1 * b1 + 12582912.f), r01 = __float_as_uint(A * b1 + 12582912.f);
+    const unsigned int r10 = __float_as_uint(A1 * b + 12582912.f);
+    const unsigned int r11 = 0x4000u - (r00 + r01 + r10);
+    W0 = __builtin_amdgcn_perm(r01, r00, 0x05040100u);
+    W1 = __builtin_amdgcn_perm(r11, r10, 0x05040100u);
+}
 
 __device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01, int &w10, int &w11) {
     // rint((1-a)(1-b) 2^14) etc.; the power-of-two scale commutes with every rounding, so it is applied to a once:
@@ -187,6 +245,13 @@ __device__ __forceinline__ unsigned int pk_mul(unsigned int a, unsigned short k)
 __device__ __forceinline__ int dot2(unsigned int a, unsigned int b, int c) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
 }
+// the same with a SEPARATE accumulator register (VOP3P v_dot2_i32_i16).  The builtin is selected as v_dot2c, whose accumulator is tied to the
+// destination: an accumulator that must survive (c0[k] in every iteration, the rounding constants of the set-up) costs a v_mov per use.
+__device__ __forceinline__ int dot2_keep(unsigned int a, unsigned int b, int c) {
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 // (lo16(a), lo16(b)) as one packed register
 __device__ __forceinline__ unsigned int pk_lo16(int a, int b) {
     return __builtin_amdgcn_perm((unsigned int) b, (unsigned int) a, 0x05040100u);
@@ -241,6 +306,10 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
     const bool active     = lane < 63;
     const int ly          = active ? lane / 3 : 0;
     const int lx0         = active ? (lane - ly * 3) * 7 : 0;
+    const unsigned int am = active ? ~0u : 0u; // lane 63 owns no pixels: its derivative weights are zeroed (Ix = Iy = 0 -> no contribution to any sum)
+    // rounding constants of the set-up's blends, kept in registers for dot2_keep (opaque to the optimizer: not re-materialised per use)
+    int rnd13 = 1 << 13, rnd8 = 1 << 8;
+    asm volatile("" : "+v"(rnd13), "+v"(rnd8));
 
     for (int level = maxLevel; level >= 0; --level) {
         const int W = P.w[level], H = P.h[level], pitch = P.pitch[level];
@@ -269,9 +338,8 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
             if (wr != nullptr && level < ICG_MAX_LK_LEVELS_CACHED && lane == 0) wr[4 + 4 * level] = 0; // nothing to reuse (the reader skips the level by the same test)
             continue;
         }
-        int w00, w01, w10, w11;
-        lk_weights(prevx - ipx, prevy - ipy, w00, w01, w10, w11);
-        unsigned int W0 = pk_lo16(w00, w01), W1 = pk_lo16(w10, w11);
+        unsigned int W0, W1;
+        lk_weights_pk(prevx - ipx, prevy - ipy, W0, W1);
 
         // ---- stage the 24x24 neighbourhood of the previous image AND the 32x32 tile of the next image around the
         //      level's starting estimate in one go (both address sets are known here) ----
@@ -340,14 +408,6 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
             // derivative at support position (c = lx0+j, r = ly+rr): 3x3 neighbourhood = tile rows rr..rr+2, cols j..j+2.
             // The derivative plane is ZERO outside the image: X = ipx+lx0+j in [0,W), Y = ipy+ly+rr in [0,H).
             const bool all_in = ipx >= 0 && ipx + 22 <= W && ipy >= 0 && ipy + 22 <= H; // wave-uniform fast path
-            unsigned int CM[4] = {~0u, ~0u, ~0u, ~0u};
-            if (!all_in) {
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const int X0 = ipx + lx0 + 2 * m, X1 = X0 + 1;
-                    CM[m] = ((X0 >= 0 && X0 < W) ? 0x0000ffffu : 0u) | ((X1 >= 0 && X1 < W) ? 0xffff0000u : 0u);
-                }
-            }
             unsigned int DX[2][4], DY[2][4];
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
@@ -357,22 +417,30 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                     T0[m] = pk_add(pk_mul(pk_add(Pp[rr][m], Pp[rr + 2][m]), 3), pk_mul(Pp[rr + 1][m], 10)); // 3*(p0+p2) + 10*p1
                     T1[m] = pk_sub(Pp[rr + 2][m], Pp[rr][m]);                                                // p2 - p0
                 }
-                unsigned int RM = ~0u;
-                if (!all_in) {
-                    const int Y = ipy + ly + rr;
-                    RM          = (Y >= 0 && Y < H) ? ~0u : 0u;
-                }
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     DX[rr][m] = pk_sub(T0[m + 1], T0[m]);                                                       // t0[j+2] - t0[j]
                     DY[rr][m] = pk_add(pk_mul(pk_add(T1[m], T1[m + 1]), 3), pk_mul(pk_shift(T1[m], T1[m + 1]), 10)); // 3*(t1[j]+t1[j+2]) + 10*t1[j+1]
-                    if (!all_in) {
-                        DX[rr][m] &= CM[m] & RM;
-                        DY[rr][m] &= CM[m] & RM;
+                }
+            }
+            if (!all_in) { // windows that reach over the image border: a real (wave-uniform) branch — written as masks on the common path the
+                           // compiler turned it into 46 v_cndmask + 16 v_and per level for every window (round 5: the asm statement keeps it a branch)
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const int Y           = ipy + ly + rr;
+                    const unsigned int RM = (Y >= 0 && Y < H) ? ~0u : 0u;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        const int X0 = ipx + lx0 + 2 * m, X1 = X0 + 1;
+                        const unsigned int CM = ((X0 >= 0 && X0 < W) ? 0x0000ffffu : 0u) | ((X1 >= 0 && X1 < W) ? 0xffff0000u : 0u);
+                        DX[rr][m] &= CM & RM;
+                        DY[rr][m] &= CM & RM;
                     }
                 }
             }
             int ix[7], iy[7];
+            const unsigned int W0d = W0 & am, W1d = W1 & am; // (lane 63: (0 + 2^13) >> 14 = 0)
 #pragma unroll
             for (int k = 0; k < 7; k++) {
                 const int m = k >> 1;
@@ -384,14 +452,10 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                 const int m1 = (k + 1) >> 1;
                 const unsigned int i1 = ((k + 1) & 1) ? pk_shift(Pp[1][m1], Pp[1][m1 + 1]) : Pp[1][m1];
                 const unsigned int i2 = ((k + 1) & 1) ? pk_shift(Pp[2][m1], Pp[2][m1 + 1]) : Pp[2][m1];
-                ix[k]        = dot2(dx1, W1, dot2(dx0, W0, 1 << 13)) >> 14;
-                iy[k]        = dot2(dy1, W1, dot2(dy0, W0, 1 << 13)) >> 14;
-                const int iv = dot2(i2, W1, dot2(i1, W0, 1 << 8)) >> 9;
+                ix[k]        = dot2(dx1, W1d, dot2_keep(dx0, W0d, rnd13)) >> 14;
+                iy[k]        = dot2(dy1, W1d, dot2_keep(dy0, W0d, rnd13)) >> 14;
+                const int iv = dot2(i2, W1, dot2_keep(i1, W0, rnd8)) >> 9;
                 c0[k]        = 256 - 512 * iv;
-                if (!active) {
-                    ix[k] = 0;
-                    iy[k] = 0;
-                }
             }
 #pragma unroll
             for (int m = 0; m < 4; m++) {
@@ -401,7 +465,8 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
             sA11 = dot2(IXP[3], IXP[3], dot2(IXP[2], IXP[2], dot2(IXP[1], IXP[1], dot2(IXP[0], IXP[0], 0))));
             sA12 = dot2(IXP[3], IYP[3], dot2(IXP[2], IYP[2], dot2(IXP[1], IYP[1], dot2(IXP[0], IYP[0], 0))));
             sA22 = dot2(IYP[3], IYP[3], dot2(IYP[2], IYP[2], dot2(IYP[1], IYP[1], dot2(IYP[0], IYP[0], 0))));
-            A11 = wave_sum_i32x16_f32(sA11) * FLT_SCALE, A12 = wave_sum_i32x16_f32(sA12) * FLT_SCALE;
+            wave_sum2_i32x16_f32(sA11, sA12, A11, A12);
+            A11 *= FLT_SCALE, A12 *= FLT_SCALE;
             A22 = wave_sum_i32x16_f32(sA22) * FLT_SCALE;
         }
         float D            = A11 * A22 - A12 * A12;
@@ -430,6 +495,10 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
             continue;
         }
         D = 1.f / D;
+        // the 2^-20 of the window sums folded into the inverse determinant (round 5): b1, b2 stay unscaled integers-as-floats, and scaling by a
+        // power of two commutes with every rounding of (A12 b2 - A22 b1) D (no intermediate leaves the normal range: |b| >= 1 or 0,
+        // A = n 2^-20, 2^-28 <= D <= 2^23) — the step is the same float, bit for bit, two multiplications per iteration cheaper
+        const float Ds = D * FLT_SCALE;
         nptx -= (float) ICG_LK_HALF;
         npty -= (float) ICG_LK_HALF;
         float pdx = 0.f, pdy = 0.f;
@@ -441,10 +510,17 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
         // The Gauss-Newton iterations, as EPOCHS of constant integer window position: the lane's pixel pairs JA/JB are fetched once per epoch
         // and are loop-invariant inside it (written as one loop with a conditional re-fetch, they were loop-carried through the condition
         // and the compiler copied all 14 registers twice per iteration: 28 of ~130 VALU instructions).  Same checks in the same order.
+        // Round 5 (instruction diet by the measured issue costs, profiles/ubench: conversions, roundings, compares, DPP, dot2, FP64 and
+        // everything VOP3 cost twice a plain add / mul): the fractional position a = npt - floor(npt) is carried from
+        // the epoch test of the previous iteration (the window stays in the epoch iff 0 <= a < 1 on both axes: one subtraction and one
+        // unsigned compare per axis instead of floor, convert, compare and convert back), the weights come packed from lk_weights_pk,
+        // c0[k] is read in place (dot2_keep), b1 and b2 come out of ONE reduction tree, the oscillation test compares in f32
+        // (|s| < 0.01 in double  <=>  |s| <= 0.01f for a float s: 0.01f < 0.01 < nextafter(0.01f)).
         int j = 0;
         bool more = true;
         while (more) {
-            const int inx = (int) floorf(nptx), iny = (int) floorf(npty);
+            const float fx = floorf(nptx), fy = floorf(npty);
+            const int inx = (int) fx, iny = (int) fy;
             if (inx < -ICG_LK_WIN || inx >= W || iny < -ICG_LK_WIN || iny >= H) {
                 if (level == 0) status = false;
                 break;
@@ -459,13 +535,12 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
             lk_fetch_J(S, iny - jy0 + ly, (inx - jx0) + lx0, JA, JB);
             cinx = inx;
             ciny = iny;
+            float ax = nptx - fx, ay = npty - fy; // == nptx - (float) inx
             for (;;) {
-                lk_weights(nptx - inx, npty - iny, w00, w01, w10, w11);
-                W0 = pk_lo16(w00, w01);
-                W1 = pk_lo16(w10, w11);
+                lk_weights_pk(ax, ay, W0, W1);
                 int diff[7];
 #pragma unroll
-                for (int k = 0; k < 7; k++) diff[k] = dot2(JB[k], W1, dot2(JA[k], W0, c0[k])) >> 9;
+                for (int k = 0; k < 7; k++) diff[k] = dot2(JB[k], W1, dot2_keep(JA[k], W0, c0[k])) >> 9;
                 int sb1 = 0, sb2 = 0;
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
@@ -473,17 +548,19 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                     sb1 = dot2(dp, IXP[m], sb1);
                     sb2 = dot2(dp, IYP[m], sb2);
                 }
-                const float b1 = wave_sum_i32x8_f32(sb1) * FLT_SCALE, b2 = wave_sum_i32x8_f32(sb2) * FLT_SCALE;
-                const float dx = (float) ((A12 * b2 - A22 * b1) * D);
-                const float dy = (float) ((A12 * b1 - A11 * b2) * D);
+                float b1, b2;
+                wave_sum2_i32x8_f32(sb1, sb2, b1, b2);
+                const float dx = (float) ((A12 * b2 - A22 * b1) * Ds);
+                const float dy = (float) ((A12 * b1 - A11 * b2) * Ds);
                 nptx += dx;
                 npty += dy;
                 nextStore = make_float2(nptx + (float) ICG_LK_HALF, npty + (float) ICG_LK_HALF);
-                if ((double) dx * dx + (double) dy * dy <= eps2) {
+                // dx^2 is exact in double, so the fused form rounds the same sum once, as the two-step form does
+                if (__builtin_fma((double) dx, (double) dx, (double) dy * (double) dy) <= eps2) {
                     more = false;
                     break;
                 }
-                if (j > 0 && fabs((double) (dx + pdx)) < 0.01 && fabs((double) (dy + pdy)) < 0.01) {
+                if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
                     nextStore.x -= dx * 0.5f;
                     nextStore.y -= dy * 0.5f;
                     more = false;
@@ -495,7 +572,11 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                     more = false;
                     break;
                 }
-                if ((int) floorf(nptx) != inx || (int) floorf(npty) != iny) break; // next epoch: bounds test, tile, fetch
+                ax = nptx - fx;
+                ay = npty - fy;
+                // floor(npt) unchanged on both axes <=> 0 <= a < 1 <=> bits(a) < bits(1.0f) as unsigned (a negative a has the sign bit set);
+                // when a rounding makes a == 1.0f for a position still inside the pixel, the next epoch finds the same pixels again
+                if (!(__float_as_uint(ax) < 0x3f800000u && __float_as_uint(ay) < 0x3f800000u)) break; // next epoch: bounds test, tile, fetch
             }
         }
 
@@ -518,16 +599,14 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                     }
                     lk_fetch_J(S, iny - jy0 + ly, (inx - jx0) + lx0, JA, JB);
                 }
-                lk_weights(ex - inx, ey - iny, w00, w01, w10, w11);
-                W0 = pk_lo16(w00, w01);
-                W1 = pk_lo16(w10, w11);
+                lk_weights_pk(ex - inx, ey - iny, W0, W1);
                 int se = 0;
 #pragma unroll
                 for (int k = 0; k < 7; k++) {
-                    int diff = dot2(JB[k], W1, dot2(JA[k], W0, c0[k])) >> 9;
-                    if (!active) diff = 0;
+                    const int diff = dot2(JB[k], W1, dot2_keep(JA[k], W0, c0[k])) >> 9;
                     se += diff < 0 ? -diff : diff;
                 }
+                se &= (int) am; // lane 63 owns no pixels
                 errv = wave_sum_i32x16_f32(se) * 1.f / (float) (32 * ICG_LK_WIN * ICG_LK_WIN);
             }
         }
@@ -947,15 +1026,24 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_des
             st_f = st;
         }
     }
-    if (lane == 0) {
-        // isOnBorder (tracking.cc:847-849) and ptsDistance (tracking.cc:841-845)
+    {
+        // isOnBorder (tracking.cc:847-849) and ptsDistance (tracking.cc:841-845), then undistortPoints of the result.
+        // EVERY lane computes these (uniform) values and lane 0 stores them: conversions, FP64 and every other half-rate VALU instruction
+        // take ~5x longer when 16 lanes or fewer are active (measured on the MI355X, profiles/ubench/valu_cost_r05.txt: 1.7 -> 8.9 ns per
+        // wave-instruction) — under `if (lane == 0)` these ~320 instructions were 13 % of the kernel's time (round 5).
         const bool border = (double) fwd.x < 5.0 || (double) fwd.y < 5.0 || ((double) fwd.x > (img_w - 5.0)) ||
                             ((double) fwd.y > (img_h - 5.0));
         const double ddx = (double) (bwd.x - p0.x), ddy = (double) (bwd.y - p0.y);
         const double dist = sqrt(ddx * ddx + ddy * ddy);
-        out_pts[i]        = fwd;
-        status[i]         = (st_f && st_b && !border && dist < 0.5) ? 1 : 0;
-        if (out_undist) out_undist[i] = has_cam ? cam_undistort(cam, fwd) : fwd;
+        unsigned int st = (st_f && st_b && !border && dist < 0.5) ? 1u : 0u;
+        float2 und      = fwd;
+        if (out_undist && has_cam) und = cam_undistort(cam, fwd); // wave-uniform
+        asm volatile("" : "+v"(st), "+v"(und.x), "+v"(und.y));   // (keeps the compiler from sinking the computation into the one-lane branch)
+        if (lane == 0) {
+            out_pts[i] = fwd;
+            status[i]  = (unsigned char) st;
+            if (out_undist) out_undist[i] = und;
+        }
     }
 }
 

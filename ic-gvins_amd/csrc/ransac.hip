@@ -604,7 +604,8 @@ extern "C" int icg_triangulate(icg_ctx *ctx, int n, const int32_t *T0_idx, const
 // Device-resident tracker (tracker.hip): cv::findFundamentalMat(FM_RANSAC) of one point set per stream, the WHOLE run in one launch — the
 // host loop of icg_fm_ransac (subset draws, one launch per round, sequential replay of the best / niters recurrence) moves into the
 // workgroup that owns the set:
-//   round:  thread 0 draws up to FM_HPW subsets from the set's cv::RNG (getSubset + checkSubset, RNG-consuming redraws) -> LDS
+//   round:  wave 0 draws up to FM_HPW subsets from the set's cv::RNG (getSubset + checkSubset with a collinearity test per lane,
+//           RNG-consuming redraws) -> LDS
 //           wave 0, a lane per hypothesis: seven-point solve (the serial FP64 chain of k_fm_hypothesis) -> models in LDS
 //           four waves, a wave per (hypothesis, model): inlier bits by ballot + count -> LDS
 //           thread 0 replays the hypotheses in order: best mask, max_good, niters = RANSACUpdateNumIters(...)
@@ -616,21 +617,20 @@ __device__ __forceinline__ unsigned dev_rng_next(unsigned long long &state) {
     state = (unsigned long long) (unsigned) state * 4164903690U + (unsigned) (state >> 32);
     return (unsigned) state;
 }
-__device__ bool dev_have_collinear(const float2 *pts, const int *idx) { // calib3d precomp.hpp haveCollinearPoints(m, 7)
-    const int i = 6;
-    for (int j = 0; j < i; j++) {
-        const double dx1 = pts[idx[j]].x - pts[idx[i]].x;
-        const double dy1 = pts[idx[j]].y - pts[idx[i]].y;
-        for (int k = 0; k < j; k++) {
-            const double dx2 = pts[idx[k]].x - pts[idx[i]].x;
-            const double dy2 = pts[idx[k]].y - pts[idx[i]].y;
-            if (fabs(dx2 * dy1 - dy2 * dx1) <= (double) FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
-        }
-    }
-    return false;
-}
-__device__ bool dev_get_subset(unsigned long long &rng, int n, const float2 *p1, const float2 *p2, int idx[7]) {
+// getSubset + checkSubset of ONE hypothesis by a whole wave (round 5).  The draws (cv::RNG, duplicate rejection) are uniform integer work that
+// every lane repeats; checkSubset's collinearity test — the last point against the 15 pairs of the other six, in both point sets: 30
+// independent FP64 tests of calib3d's haveCollinearPoints(m, 7), an OR — runs a test per lane (lanes 30..63 repeat tests of lanes 0..29: every lane stays active, because FP64
+// and the other half-rate VALU instructions take ~5x as long on gfx950 when 16 or fewer lanes are active — under `if (t == 0)` the
+// up-to-32 subsets of a round cost more than the seven-point solves and the scoring together; profiles/ubench/valu_cost_r05.txt).
+// idx_lds: the hypothesis' seven indices in LDS (written here, read by the solve).  Same subsets, same RNG consumption as dev_get_subset's
+// sequential form (k_fm_hypothesis' host twin draws on the host).
+__device__ bool dev_get_subset_wave(unsigned long long &rng, int n, const float2 *p1, const float2 *p2, int *idx_lds, int lane) {
+    const int pr = lane % 15;
+    const int j  = pr < 1 ? 1 : pr < 3 ? 2 : pr < 6 ? 3 : pr < 10 ? 4 : 5; // pairs (j, k), k < j < 6, in the order of haveCollinearPoints
+    const int k  = pr - j * (j - 1) / 2;
+    const float2 *pts = ((lane / 15) & 1) ? p2 : p1;
     for (int attempt = 0; attempt < 10000; attempt++) {
+        int idx[7];
         for (int i = 0; i < 7; i++) {
             int v;
             for (;;) {
@@ -641,7 +641,19 @@ __device__ bool dev_get_subset(unsigned long long &rng, int n, const float2 *p1,
             }
             idx[i] = v;
         }
-        if (!dev_have_collinear(p1, idx) && !dev_have_collinear(p2, idx)) return true;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // (the previous attempt's readers are done: one wave, LDS queue in order)
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 7; q++) idx_lds[q] = idx[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const float2 a = pts[idx_lds[6]], b = pts[idx_lds[j]], c = pts[idx_lds[k]];
+        const double dx1 = b.x - a.x, dy1 = b.y - a.y; // (float differences widened, as the CPU form: pts[..].x - pts[..].x in float, then double)
+        const double dx2 = c.x - a.x, dy2 = c.y - a.y;
+        const bool bad   = fabs(dx2 * dy1 - dy2 * dx1) <= (double) FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2));
+        if (__ballot(bad) == 0ull) return true;
     }
     return false;
 }
@@ -675,17 +687,18 @@ __global__ __launch_bounds__(256, 1) void k_fm_ransac_sets(int n_sets, int seg_c
     if (t < FMS_MAX_WORDS) best_sh[t] = 0;
     __syncthreads();
     for (;;) {
-        if (t == 0) {
-            int nh = min(FM_HPW, niters_sh - iter_sh);
+        if (wave == 0) { // all 64 lanes: see dev_get_subset_wave
+            const int it0 = iter_sh;
+            int nh        = min(FM_HPW, niters_sh - it0);
             for (int h = 0; h < nh; h++) {
-                if (!dev_get_subset(rng, n, p1, p2, idx_sh[h])) {
+                if (!dev_get_subset_wave(rng, n, p1, p2, idx_sh[h], lane)) {
                     // ptsetreg.cpp run(): no valid subset -> the iterations end here (nothing found if this was the first one)
-                    niters_sh = iter_sh + h;
-                    nh        = h;
+                    if (lane == 0) niters_sh = it0 + h;
+                    nh = h;
                     break;
                 }
             }
-            nh_sh = nh;
+            if (lane == 0) nh_sh = nh;
         }
         __syncthreads();
         const int nh = nh_sh;
