@@ -56,7 +56,7 @@ def algorithmic_bytes(kernel, w, h, n_streams, pts_per_launch):
         "lk_track_fb": lk_bytes_per_point() * pts_per_launch,
         "detect_min_eig_nms": px * n_streams,             # the image (round 4: the mask is a disc list, no plane)
     }
-    if kernel == "pyrdown":
+    if kernel in ("pyrdown", "pyrdown_rows"):
         # three launches per step; average bytes per launch
         tot = sum(pyr[l][0] * pyr[l][1] + pyr[l + 1][0] * pyr[l + 1][1] for l in range(3))
         return tot * n_streams / 3.0

@@ -334,6 +334,109 @@ __global__ __launch_bounds__(256) void k_pyrdown(uint8_t *frames, size_t slot_by
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// One pyrDown step as a ROW STREAM (round 5; replaces k_pyramid3 on the default path).  The front-end as a whole is bound by VALU issue
+// (~88 % of the issue slots of the co-resident kernel mix are taken), so what a streaming kernel costs the frame rate is
+// its instruction count, not its HBM fraction — and the tile kernel below spends 24 VALU + 16 SALU instructions per level-0 pixel
+// (rocprofv3, profiles/r04_pmc_summary.json): 1.74x / 1.6x halo recomputation per level, per-item index arithmetic, three LDS round trips.
+// Here a wave owns 128 output columns (a lane: output columns 2l, 2l+1 <- the 12 source bytes x-4 .. x+7, ONE global_load_dwordx3 per source
+// row) and a band of output rows, and streams down the band with the horizontal [1 4 6 4 1] sums of the last five source rows in registers
+// (packed u16 pairs, as below): per output row two new source rows (2 x (1 align + 3 v_dot4 + 1 and + 1 pack)), one SWAR vertical sum
+// (9 instructions for both columns) and one 2-byte store.  No LDS, no barrier, vertical halo 3 source rows per band, horizontal halo none
+// (the neighbours' bytes come with the lane's own 12-byte load).  ~5 issue units per source pixel and level instead of ~40.
+// Borders: BORDER_REFLECT_101 of the level's own image — rows by a scalar reflect of the row index; columns by per-lane byte selectors
+// computed once (v_perm picks the reflected partner out of the same 12-byte window: every partner a valid output needs lies inside it),
+// only in the waves that touch the left or right image edge (wave-uniform branch).  Exact integers; results identical to k_pyramid3 /
+// k_pyrdown (tests/test_gpu_frontend.py: all levels at 4 sizes incl. 333 x 257 and 1278 x 1022).
+#define PR_STRIP_OUT 128 // output columns per wave
+struct pr_sel {
+    unsigned int a, b, t, v; // selectors of (V-2 V-1 V0 V1), (V0 V1 V2 V3), the (E1, E0) candidate of V4, and V4 out of (E2, candidate)
+};
+typedef unsigned int pr_u3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ pr_u3 pr_load(const uint8_t *row, unsigned int wx) { // source bytes wx .. wx + 11 of a row (row: wave-uniform)
+    typedef pr_u3 __attribute__((aligned(4))) u3a;
+    return *reinterpret_cast<const u3a *>(row + wx);
+}
+template <bool EDGE> __device__ __forceinline__ unsigned int pr_hsum(const pr_u3 E, const pr_sel &S) {
+    unsigned int A, B, V4;
+    if (EDGE) {
+        A  = __builtin_amdgcn_perm(E.y, E.x, S.a);
+        B  = __builtin_amdgcn_perm(E.y, E.x, S.b);
+        V4 = __builtin_amdgcn_perm(E.z, __builtin_amdgcn_perm(E.y, E.x, S.t), S.v);
+    } else {
+        A  = __builtin_amdgcn_alignbyte(E.y, E.x, 2);
+        B  = E.y;
+        V4 = E.z & 0xffu;
+    }
+    const unsigned int h0 = __builtin_amdgcn_udot4(B, 0x00010000u, __builtin_amdgcn_udot4(A, 0x04060401u, 0u, false), false); // + V2
+    const unsigned int h1 = __builtin_amdgcn_udot4(B, 0x04060401u, V4, false);
+    return h0 | (h1 << 16);
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void pr_band(const uint8_t *src, int sh, int spitch, uint8_t *dst, int dpitch, int i0, int i1, unsigned int wx,
+                                        const pr_sel &S, unsigned int dcol, bool store) {
+    // (|overshoot| <= 4 rows, sh >= 6; the row offset is forced onto the scalar unit: address = scalar row pointer + the lane's 32-bit wx)
+    auto srow = [&](int r) { return src + (unsigned int) __builtin_amdgcn_readfirstlane(icg_reflect1(r, sh) * spitch); };
+    unsigned int hA = pr_hsum<EDGE>(pr_load(srow(2 * i0 - 2), wx), S), hB = pr_hsum<EDGE>(pr_load(srow(2 * i0 - 1), wx), S);
+    unsigned int hC = pr_hsum<EDGE>(pr_load(srow(2 * i0), wx), S);
+    // the two source rows of an output row are loaded one iteration ahead (one memory round trip per band, not per output row)
+    pr_u3 R1 = pr_load(srow(2 * i0 + 1), wx), R2 = pr_load(srow(2 * i0 + 2), wx);
+    for (int i = i0; i < i1; i++) {
+        const pr_u3 N1 = pr_load(srow(2 * i + 3), wx), N2 = pr_load(srow(2 * i + 4), wx); // (past the band: reflected, valid rows; unused)
+        const unsigned int hD = pr_hsum<EDGE>(R1, S), hE = pr_hsum<EDGE>(R2, S);
+        // (v + 128) >> 8 of v = hA + 4 hB + 6 hC + 4 hD + hE on both packed fields (<= 65408: no carry between them)
+        unsigned int v = hA + hE;
+        v              = ((hB + hD) << 2) + v;
+        v += (hC << 2) + (hC + hC);
+        v += 0x00800080u;
+        if (store) *reinterpret_cast<unsigned short *>(dst + (size_t) i * dpitch + dcol) = (unsigned short) __builtin_amdgcn_perm(v, v, 0x0c0c0301u);
+        hA = hC, hB = hD, hC = hE;
+        R1 = N1, R2 = N2;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_pyrdown_rows(uint8_t *frames, size_t slot_bytes, pre_jobs jobs, unsigned int src_off, int sw, int sh,
+                                                     int spitch, unsigned int dst_off, int dw, int dh, int dpitch, int n_strips, int n_bands,
+                                                     int band_rows, int n_tasks) {
+    const int task = icg_xcd_chunked(blockIdx.x, n_tasks);
+    if (task >= n_tasks) return;
+    const int per_job = n_strips * n_bands;
+    const int job = task / per_job, rem = task - job * per_job; // (wave-uniform: scalar unit)
+    const int band = rem / n_strips, strip = rem - band * n_strips;
+    const int dslot = __builtin_amdgcn_readfirstlane(pre_job_slot(jobs, job)); // (wave-uniform: row pointers stay on the scalar unit)
+    if (dslot < 0) return; // idle job
+    uint8_t *slot = frames + (size_t) dslot * slot_bytes;
+    const int lane = threadIdx.x;
+    const int oj   = strip * PR_STRIP_OUT + 2 * lane; // the lane's output columns oj, oj + 1
+    // lanes right of the image repeat the last lane that has a valid output (their loads stay inside the row, nothing is stored)
+    const int x  = min(2 * oj, (sw - 1) & ~3);        // first source column of the lane's pair
+    const int wx = max(x - 4, 0);                     // window: source bytes wx .. wx + 11 (<= 8 bytes past the row end: inside the slot)
+    const bool edge = strip == 0 || 2 * (strip + 1) * PR_STRIP_OUT + 4 > sw; // wave-uniform: some lane needs a reflected column
+    pr_sel S;
+    S.a = S.b = S.t = S.v = 0;
+    if (edge) {
+        int ix[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) ix[k] = min(max(icg_reflect101(x - 2 + k, sw) - wx, 0), 11); // window index of V[k-2]
+        // (V-2 .. V3 of a lane with a valid output lie in bytes 0..7; V4 only feeds the second output: when that one is valid its
+        // reflected partner is byte 8 or one of bytes 0..7 — image.hip comment above)
+        S.a = (unsigned int) (ix[0] & 7) | ((unsigned int) (ix[1] & 7) << 8) | ((unsigned int) (ix[2] & 7) << 16) | ((unsigned int) (ix[3] & 7) << 24);
+        S.b = (unsigned int) (ix[2] & 7) | ((unsigned int) (ix[3] & 7) << 8) | ((unsigned int) (ix[4] & 7) << 16) | ((unsigned int) (ix[5] & 7) << 24);
+        S.t = 0x0c0c0c00u | (unsigned int) (ix[6] & 7);
+        S.v = ix[6] >= 8 ? (0x0c0c0c04u + (unsigned int) (ix[6] - 8)) : 0x0c0c0c00u;
+    }
+    const int i0 = band * band_rows, i1 = min(i0 + band_rows, dh);
+    if (i0 >= i1) return;
+    const uint8_t *src = slot + src_off;
+    uint8_t *dst       = slot + dst_off;
+    const bool store   = oj < dw; // (oj + 1 == dw: the second byte lands in the row padding)
+    if (edge)
+        pr_band<true>(src, sh, spitch, dst, dpitch, i0, i1, (unsigned int) wx, S, (unsigned int) oj, store);
+    else
+        pr_band<false>(src, sh, spitch, dst, dpitch, i0, i1, (unsigned int) wx, S, (unsigned int) oj, store);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Fused 3-step pyramid (the common 4-level case): one workgroup owns a 16x8 tile of level 3 and everything below it
 // (32x16 of level 2, 64x32 of level 1); the 164x85 level-0 neighbourhood is staged once as dwords and the three
 // pyrDown steps run LDS -> LDS, so level 0 is read ~1.7x (mostly L2 hits) instead of the per-level kernels' three
@@ -612,7 +715,23 @@ static int preprocess_impl(icg_ctx *ctx, int n, const int32_t *slots, const int3
             hipLaunchKernelGGL(k_clahe_apply, dim3(T + 1, (w + CLAHE_CHUNK - 1) / CLAHE_CHUNK, m), dim3(256), 0, ctx->stream, jobs,
                                g, lut, ctx->d_frames, ctx->slot_bytes, ctx->lv[0].pitch);
         }
-        if (ctx->n_levels == 4) {
+        static const bool tile_pyramid = getenv("ICG_PYRAMID_TILES") && getenv("ICG_PYRAMID_TILES")[0] == '1'; // A/B switch: the round-1..4 tile kernel
+        bool rows_ok = !tile_pyramid;
+        for (int l = 1; l < ctx->n_levels; l++) rows_ok = rows_ok && ctx->lv[l - 1].w >= 8 && ctx->lv[l - 1].h >= 6 && ctx->lv[l - 1].pitch >= 16;
+        if (rows_ok) {
+            for (int l = 1; l < ctx->n_levels; l++) {
+                icg_prof_scope ps(ctx, "pyrdown_rows");
+                const icg_level &a = ctx->lv[l - 1], &bb = ctx->lv[l];
+                const int n_strips = (bb.w + PR_STRIP_OUT - 1) / PR_STRIP_OUT;
+                // bands: enough waves to fill the chip at the level's size (>= ~4 per SIMD for 64 frames at level 1), 3 halo rows per band
+                const int band_rows = bb.h >= 256 ? 32 : bb.h >= 128 ? 16 : 8;
+                const int n_bands   = (bb.h + band_rows - 1) / band_rows;
+                const int n_tasks   = n_strips * n_bands * m;
+                hipLaunchKernelGGL(k_pyrdown_rows, dim3(icg_xcd_grid(n_tasks)), dim3(64), 0, ctx->stream, ctx->d_frames, ctx->slot_bytes, jobs,
+                                   (unsigned int) a.off, a.w, a.h, a.pitch, (unsigned int) bb.off, bb.w, bb.h, bb.pitch, n_strips, n_bands,
+                                   band_rows, n_tasks);
+            }
+        } else if (ctx->n_levels == 4) {
             icg_prof_scope ps(ctx, "pyramid3");
             const int gx = (ctx->lv[3].w + 15) / 16, gy = (ctx->lv[3].h + 7) / 8, n_tiles = gx * gy * m;
             hipLaunchKernelGGL(k_pyramid3, dim3(icg_xcd_grid(n_tiles)), dim3(256), 0, ctx->stream, icg_make_pyr_desc(ctx), jobs, gx,
