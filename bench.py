@@ -238,14 +238,14 @@ def frontend_valu(pmc_file, streams_per_launch, fps):
         return None
 
 
-def measure_marg_batched(nmb, timeout=180):
+def measure_marg_batched(nmb, timeout=180, n_lm=300, n_kf=10):
     """marg.batched: `nmb` jittered copies of the C2 window marginalized by one MarginalizationBatch (host/marg_batch.h) against
     MarginalizationInfo::marginalization() window after window, measured by profiles/marg_batch_probe.py in a CHILD process — the block is
     outside the headline path and must not be able to take the bench line down.  Returns the block (or {"error": ...})."""
     import subprocess
     try:
-        pr = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "marg_batch_probe.py"), "--windows", str(nmb)],
-                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        pr = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "marg_batch_probe.py"), "--windows", str(nmb), "--lm", str(n_lm),
+                             "--kf", str(n_kf)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
         if pr.returncode != 0:
             raise RuntimeError(f"marg_batch_probe.py exited with {pr.returncode}: {pr.stderr[-200:]}")
         mbp = json.loads(pr.stdout.strip().splitlines()[-1])[str(nmb)]
@@ -556,6 +556,8 @@ def compact_line(full, details_path):
         c["value_withheld"] = full["value_withheld"]
     if "selftest" in full:
         c["selftest"] = full["selftest"]
+    if full.get("n_gpus", 1) > 1 or "selftest" in full:
+        c["ranks"] = full.get("ranks")  # every rank's own frames/s, busy host cores, engine (N = 1: the same numbers are in value / host)
     r = full.get("roofline")
     c["roofline"] = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "peak_measured", "frac_of_measured_peak",
                               "algorithmic_bytes_per_launch", "avg_launch_us", "units_per_launch", "exclusive_us", "achieved_exclusive",
@@ -586,6 +588,9 @@ def compact_line(full, details_path):
                    "reproj": _pick(c4.get("reproj"), ("value", "unit", "kernel_us")), "preint": _pick(c4.get("preint"), ("value", "unit", "kernel_us"))}
         if c4.get("frontend", {}).get("cpu_baseline"):
             c["c4"]["frontend"]["cpu_baseline"] = _pick(c4["frontend"]["cpu_baseline"], ("value", "unit", "cores", "kind"))
+        c["c4"]["solve_batched"] = _pick(c4.get("solve_batched"), ("windows_per_batch", "value", "unit", "batch_ms", "error"))
+        c["c4"]["marg_batched"] = _pick(c4.get("marg_batched"), ("windows_per_batch", "value", "unit", "speedup", "windows_structured_dense",
+                                                                 "max_rel_diff_Hp_vs_one_by_one", "error"))
     c["c1"] = _pick(full.get("c1"), ("value", "unit", "cores", "kind"))
     c["pcie_inclusive"] = _pick(full.get("pcie_inclusive"), ("value", "unit", "config", "host_to_device_GBps", "frac_whole_path"))
     c["engine_twin"] = _pick(full.get("engine_twin"), ("engine", "value", "unit", "streams", "groups", "cpu_cores_busy", "digests_equal_to_headline_run",
@@ -767,6 +772,13 @@ def main():
     (total_frames, total_tracked, total_tracking_states), elapsed_max, all_digests = sharding.terminal_exchange(
         dist, "cpu" if selftest else "cuda", [B * args.steps, fe["tracked"], states_hist[2]], elapsed, [s["digest"] for s in stats])
     fps = total_frames / elapsed_max
+    # what every rank did (rank order): its own frames/s over its own elapsed time, busy host cores, engine, groups
+    rank_rows = sharding.gather_rank_rows(dist, "cpu" if selftest else "cuda",
+                                          [B * args.steps / max(elapsed, 1e-12), host_breakdown.get("cpu_cores_busy", 0.0),
+                                           sharding.ENGINE_CODES.get(args.engine, -1), G, elapsed])
+    engine_names = {v: k for k, v in sharding.ENGINE_CODES.items()}
+    ranks_block = [{"rank": r, "frames_per_s": round(row[0], 1), "cpu_cores_busy": round(row[1], 2), "engine": engine_names.get(int(row[2]), "?"),
+                    "groups": int(row[3]), "elapsed_s": round(row[4], 4)} for r, row in enumerate(rank_rows)]
     parity = None
     if rank == 0 and not args.no_parity:
         try:
@@ -1238,6 +1250,21 @@ def main():
         import preint_data as pdz
         c4["preint"] = pdz.bench_block(icgvins, local_rank, n_streams=256, n_intervals=15, n_samples=40,
                                        cpu=(None if args.no_cpu_baseline else __import__("oracle_lib").load()))
+        # the batched back-end on C4's 15-keyframe windows (97 free camera columns = a 76 KB LDS tile: the round-2..4 caps of 62 / 63 KB kept
+        # them out of WindowSolverBatch / MarginalizationBatch; gfx950 has 160 KiB per CU — csrc/reproj.hip RPJ_LDS_LIMIT)
+        try:
+            import solve_utils as su4
+            P4 = su4.make_problem(500, 15, seed=4, n_outliers=10, perturb=0.2)
+            hl4 = C.CDLL(H.HOST_LIB)
+            su4.host_solve_batch(hl4, [P4] * 4)
+            nb4 = 64
+            _, b4ms = su4.host_solve_batch(hl4, [P4] * nb4)
+            c4["solve_batched"] = {"windows_per_batch": nb4, "factors_per_window": int(P4["obs"].shape[1]), "keyframes": 15,
+                                   "value": round(nb4 / (b4ms * 1e-3), 1), "unit": "windows/s", "batch_ms": round(b4ms, 2),
+                                   "note": "WindowSolverBatch on 15-keyframe windows: the structured (LDS-tile) assembly, no window solved alone"}
+        except Exception as e:
+            c4["solve_batched"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        c4["marg_batched"] = measure_marg_batched(64, n_lm=500, n_kf=15)
         if not args.no_cpu_baseline:
             sc4 = H.SynthScene(C.CDLL(timing_lib), 1920, 1080, H.camera_for(1920, 1080), tex_size=2048, threads=max(1, min(16, ncpu)))
             fr4 = [sc4.render(k, stream=0) for k in range(16)]
@@ -1367,6 +1394,7 @@ def main():
                        "engine": {"table": "track table (host/track_table.h)", "object": "object graph", "core": "tracker core on the host (host/track_core.h)",
                                   "device": "device-resident tracker (csrc/tracker.hip: state in HBM, one launch chain + one wait per step)"}[args.engine]},
             "parity": parity if not args.no_parity else {"ok": None, "skipped": "--no-parity (diagnostic run)"},
+            "ranks": ranks_block,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "cpu_baseline_allcores": cpu_baseline_allcores,

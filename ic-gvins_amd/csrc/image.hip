@@ -62,13 +62,29 @@ __global__ void k_hist256(pre_jobs jobs, int w, int h, unsigned int *hist /*n x 
 struct clahe_geom {
     int w, h, tw, th, clip;
     float lut_scale, inv_tw, inv_th;
+    int legacy; // A/B switch (ICG_CLAHE_LEGACY=1): the round-1..4 forms of the histogram pass and of the staged LUT
 };
 
 // one WAVE per (tile, frame): rows are read as aligned dwords (reflect-101 only on the padded right/bottom border),
 // the 256-bin histogram lives in LDS, and clip / redistribute / prefix-sum run inside the wave (4 bins per lane)
+// (round 5: DPP adds, 2 issue units each, instead of __shfl_xor / __shfl_up — ds_bpermute costs 10, profiles/ubench/valu_cost_r05.txt)
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false); // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false); // row_mirror: every lane holds its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // row_bcast15: rows 1, 3 += rows 0, 2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // row_bcast31: rows 2, 3 += lane 31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// inclusive prefix sum across the wave: Hillis-Steele inside the 16-lane rows (row_shr 1, 2, 4, 8 with zero fill), then the row totals
+__device__ __forceinline__ int wave_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // rows 1, 3 += lane 15 of rows 0, 2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // rows 2, 3 += lane 31
     return v;
 }
 
@@ -101,29 +117,62 @@ __global__ __launch_bounds__(64) void k_clahe_lut(pre_jobs jobs, clahe_geom g, u
         for (int j = 0; j < 4; j++) v |= (unsigned int) row[icg_reflect101(x + j, g.w)] << (8 * j);
         return v;
     };
-    // pass A: the dwords that lie entirely inside the tile (all but the first and last of each row): no per-byte tests
-    {
-        const int nin = ndw - 2, items = g.th * (nin > 0 ? nin : 0);
-        const unsigned int magic = nin > 0 ? ((1u << 20) + (unsigned int) nin - 1u) / (unsigned int) nin : 0u; // i/nin == (i*magic)>>20, i < 43690
-        constexpr int CH = 9; // dwords in flight per lane
-        for (int base = 0; base < items; base += 64 * CH) {
-            unsigned int v[CH];
-            bool ok[CH];
+    // pass A: the dwords that lie entirely inside the tile (all but the first and last of each row): no per-byte tests.
+    // Round 5 (the front-end is bound by VALU issue): a FIXED lane -> (dword column, row phase) mapping — lane = 16 q + d
+    // takes dword d + 1 of rows q, q + 4, q + 8, ... — so an item costs one address add, one load and the four bin addresses
+    // ((v >> (8 j - 2)) & 0x3fc: a shift and a mask each) instead of a division by the row length, a row reflection, a 64-bit
+    // multiply-add and a bounds test per dword (rounds 1-4: ~46 issue units per dword, now ~12).  Tiles wider than 16 interior dwords or
+    // touching the padded right / bottom border (the last tile row and column only) keep the general loop.
+    const int nin = ndw - 2;
+    const bool fast = !g.legacy && nin >= 1 && nin <= 16 && y_begin + g.th <= g.h && xa + 4 * ndw <= g.w; // wave-uniform
+    if (fast) {
+        const int d = lane & 15, q = lane >> 4;
+        const bool on = d < nin;
+        const uint8_t *p = src + (size_t) (y_begin + q) * stride + (xa + 4 * (on ? d + 1 : 1)); // (idle lanes re-read a valid dword)
+        unsigned char *hb = reinterpret_cast<unsigned char *>(hist);
+        const size_t step = 4 * (size_t) stride;
+        for (int r = q; r < g.th; r += 16, p += 4 * step) { // four rows per trip: their loads are in flight together
+            unsigned int v[4];
+            bool ok[4];
 #pragma unroll
-            for (int k = 0; k < CH; k++) {
-                const int i = base + k * 64 + lane;
-                ok[k]       = i < items;
-                v[k]        = 0;
-                if (ok[k]) {
-                    const int r = (int) (((unsigned int) i * magic) >> 20), d = 1 + i - r * nin;
-                    v[k]        = load_row_dword(r, xa + 4 * d);
-                }
+            for (int k = 0; k < 4; k++) {
+                ok[k] = on && r + 4 * k < g.th;
+                v[k]  = r + 4 * k < g.th ? *reinterpret_cast<const unsigned int *>(p + k * step) : 0u;
             }
 #pragma unroll
-            for (int k = 0; k < CH; k++) {
+            for (int k = 0; k < 4; k++) {
                 if (ok[k]) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) atomicAdd(&hist[(v[k] >> (8 * j)) & 0xff], 1u);
+                    atomicAdd(reinterpret_cast<unsigned int *>(hb + ((v[k] << 2) & 0x3fcu)), 1u);
+                    atomicAdd(reinterpret_cast<unsigned int *>(hb + ((v[k] >> 6) & 0x3fcu)), 1u);
+                    atomicAdd(reinterpret_cast<unsigned int *>(hb + ((v[k] >> 14) & 0x3fcu)), 1u);
+                    atomicAdd(reinterpret_cast<unsigned int *>(hb + ((v[k] >> 22) & 0x3fcu)), 1u);
+                }
+            }
+        }
+    } else {
+        {
+            const int items = g.th * (nin > 0 ? nin : 0);
+            const unsigned int magic = nin > 0 ? ((1u << 20) + (unsigned int) nin - 1u) / (unsigned int) nin : 0u; // i/nin == (i*magic)>>20, i < 43690
+            constexpr int CH = 9; // dwords in flight per lane
+            for (int base = 0; base < items; base += 64 * CH) {
+                unsigned int v[CH];
+                bool ok[CH];
+    #pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    const int i = base + k * 64 + lane;
+                    ok[k]       = i < items;
+                    v[k]        = 0;
+                    if (ok[k]) {
+                        const int r = (int) (((unsigned int) i * magic) >> 20), d = 1 + i - r * nin;
+                        v[k]        = load_row_dword(r, xa + 4 * d);
+                    }
+                }
+    #pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    if (ok[k]) {
+    #pragma unroll
+                        for (int j = 0; j < 4; j++) atomicAdd(&hist[(v[k] >> (8 * j)) & 0xff], 1u);
+                    }
                 }
             }
         }
@@ -169,12 +218,7 @@ __global__ __launch_bounds__(64) void k_clahe_lut(pre_jobs jobs, clahe_geom g, u
         hv[j] = run; // inclusive prefix inside the lane
     }
     // exclusive scan of the lane totals across the wave
-    int incl = run;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-    }
+    const int incl = wave_scan_i32(run);
     const int excl = incl - run;
     unsigned int packed = 0;
 #pragma unroll
@@ -189,34 +233,26 @@ __global__ __launch_bounds__(64) void k_clahe_lut(pre_jobs jobs, clahe_geom g, u
 
 #define CLAHE_CHUNK 256 // pixels per workgroup row segment (64 lanes x uchar4)
 #define CLAHE_MAXCOLS 24
+#define CLAHE_FCOLS 8   // column pairs the float form of the staged LUT holds (32 KB of LDS; 1280-wide images touch <= 6 per chunk)
 
-// LDS holds, per interpolation column pair p (= tx1+1) and grey level v, the FOUR LUT values the bilinear blend needs as
-// one dword {L[ty1][c1][v], L[ty1][c2][v], L[ty2][c1][v], L[ty2][c2][v]}: one ds_read_b32 + v_cvt_f32_ubyte0..3 per pixel
+// LDS holds, per interpolation column pair p (= tx1+1) and grey level v, the FOUR LUT values the bilinear blend needs:
+// {L[ty1][c1][v], L[ty1][c2][v], L[ty2][c1][v], L[ty2][c2][v]}.
+//   FLT = true (round 5, every chunk that touches <= CLAHE_FCOLS pairs: all real image sizes): as four FLOATS, one ds_read_b128 per pixel.
+//     The front-end is bound by VALU issue and v_cvt_f32_ubyte is a half-rate instruction: converting the LUT once per
+//     staged entry instead of four times per pixel and row removes 16 of the ~50 VALU instructions a lane spends per 4 pixels; the
+//     result bytes are rounded by the magic constant (res in [0, 255.0001]: the low byte of bits(res + 1.5 * 2^23) is rint(res), ties to even,
+//     no clamp needed) and packed by v_perm: 27 -> ~17 issue units per pixel, same bytes.
+//   FLT = false: as one dword of four bytes, v_cvt_f32_ubyte0..3 per pixel (rounds 1-4; kept for chunks of very narrow tiles).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void k_clahe_apply(pre_jobs jobs, clahe_geom g, const uint8_t *lut, uint8_t *frames,
-                                                     size_t slot_bytes, int dpitch) {
-    __shared__ __attribute__((aligned(16))) unsigned int slut[CLAHE_MAXCOLS * 256];
-    const int strip = blockIdx.x; // ty1_raw = strip-1
-    const int chunk = blockIdx.y;
-    const int b     = blockIdx.z;
-    const int t     = threadIdx.x;
-    const int T     = ICG_CLAHE_TILES;
-    const int dslot = pre_job_slot(jobs, b);
-    if (!jobs.src[b] || dslot < 0) return; // idle job (workgroup-uniform, before the first barrier)
-
+template <bool FLT>
+__device__ __forceinline__ void clahe_apply_body(const pre_jobs &jobs, const clahe_geom &g, const uint8_t *lut, uint8_t *frames, size_t slot_bytes,
+                                                 int dpitch, unsigned int *slut, int strip, int chunk, int b, int t, int dslot, int p_lo, int npairs,
+                                                 int x_begin) {
+    const int T = ICG_CLAHE_TILES;
     int ty1 = strip - 1, ty2 = strip;
     if (ty1 < 0) ty1 = 0;
     if (ty2 > T - 1) ty2 = T - 1;
-
-    const int x_begin = chunk * CLAHE_CHUNK;
-    int x_end         = x_begin + CLAHE_CHUNK;
-    if (x_end > g.w) x_end = g.w;
-    // pair range touched by this chunk: p = floor(x*inv_tw - 0.5) + 1
-    const int p_lo   = (int) floorf(x_begin * g.inv_tw - 0.5f) + 1;
-    const int p_hi   = (int) floorf((x_end - 1) * g.inv_tw - 0.5f) + 1;
-    const int npairs = p_hi - p_lo + 1; // <= CLAHE_MAXCOLS by construction of the launch (checked on host)
-
     const unsigned int *blut = reinterpret_cast<const unsigned int *>(lut + (size_t) b * T * T * 256);
     for (int i = t; i < npairs * 64; i += 256) {
         const int p = p_lo + (i >> 6), v4 = i & 63;
@@ -225,15 +261,25 @@ __global__ __launch_bounds__(256) void k_clahe_apply(pre_jobs jobs, clahe_geom g
         if (c2 > T - 1) c2 = T - 1;
         const unsigned int A = blut[(ty1 * T + c1) * 64 + v4], B = blut[(ty1 * T + c2) * 64 + v4];
         const unsigned int C = blut[(ty2 * T + c1) * 64 + v4], D = blut[(ty2 * T + c2) * 64 + v4];
-        // transpose 4 LUT dwords (4 consecutive grey levels each) into 4 per-level entries
-        const unsigned int ab01 = __builtin_amdgcn_perm(B, A, 0x05010400u), ab23 = __builtin_amdgcn_perm(B, A, 0x07030602u);
-        const unsigned int cd01 = __builtin_amdgcn_perm(D, C, 0x05010400u), cd23 = __builtin_amdgcn_perm(D, C, 0x07030602u);
-        uint4 e;
-        e.x = __builtin_amdgcn_perm(cd01, ab01, 0x05040100u);
-        e.y = __builtin_amdgcn_perm(cd01, ab01, 0x07060302u);
-        e.z = __builtin_amdgcn_perm(cd23, ab23, 0x05040100u);
-        e.w = __builtin_amdgcn_perm(cd23, ab23, 0x07060302u);
-        reinterpret_cast<uint4 *>(slut)[i] = e;
+        if (FLT) { // entries 4 i .. 4 i + 3 (grey levels 4 v4 .. 4 v4 + 3 of pair i >> 6), four floats each
+            float4 *dst = reinterpret_cast<float4 *>(slut) + 4 * i;
+#define CL_F(w, k) ((float) (((w) >> (8 * (k))) & 0xffu))
+            dst[0] = make_float4(CL_F(A, 0), CL_F(B, 0), CL_F(C, 0), CL_F(D, 0));
+            dst[1] = make_float4(CL_F(A, 1), CL_F(B, 1), CL_F(C, 1), CL_F(D, 1));
+            dst[2] = make_float4(CL_F(A, 2), CL_F(B, 2), CL_F(C, 2), CL_F(D, 2));
+            dst[3] = make_float4(CL_F(A, 3), CL_F(B, 3), CL_F(C, 3), CL_F(D, 3));
+#undef CL_F
+        } else {
+            // transpose 4 LUT dwords (4 consecutive grey levels each) into 4 per-level entries
+            const unsigned int ab01 = __builtin_amdgcn_perm(B, A, 0x05010400u), ab23 = __builtin_amdgcn_perm(B, A, 0x07030602u);
+            const unsigned int cd01 = __builtin_amdgcn_perm(D, C, 0x05010400u), cd23 = __builtin_amdgcn_perm(D, C, 0x07030602u);
+            uint4 e;
+            e.x = __builtin_amdgcn_perm(cd01, ab01, 0x05040100u);
+            e.y = __builtin_amdgcn_perm(cd01, ab01, 0x07060302u);
+            e.z = __builtin_amdgcn_perm(cd23, ab23, 0x05040100u);
+            e.w = __builtin_amdgcn_perm(cd23, ab23, 0x07060302u);
+            reinterpret_cast<uint4 *>(slut)[i] = e;
+        }
     }
     __syncthreads();
 
@@ -262,6 +308,28 @@ __global__ __launch_bounds__(256) void k_clahe_apply(pre_jobs jobs, clahe_geom g
     const uint8_t *src = jobs.src[b];
     const int stride   = jobs.stride;
     uint8_t *dst       = frames + (size_t) dslot * slot_bytes;
+    if (FLT) {
+        const float4 *sf = reinterpret_cast<const float4 *>(slut);
+        for (int y = y_lo + wave; y < y_hi; y += 4) {
+            const float tyf = y * g.inv_th - 0.5f;
+            const int tyr   = (int) floorf(tyf);
+            if (tyr != strip - 1) continue;
+            const float ya = tyf - tyr, ya1 = 1.0f - ya;
+            const unsigned int pin = *reinterpret_cast<const unsigned int *>(src + (size_t) y * stride + x0);
+            const float4 e0 = sf[pofs[0] + (pin & 0xff)], e1 = sf[pofs[1] + ((pin >> 8) & 0xff)];
+            const float4 e2 = sf[pofs[2] + ((pin >> 16) & 0xff)], e3 = sf[pofs[3] + (pin >> 24)];
+            // (l11*xa1 + l12*xa)*ya1 + (l21*xa1 + l22*xa)*ya — OpenCV's association order, no contraction
+            const float r0 = (e0.x * xa1[0] + e0.y * xa[0]) * ya1 + (e0.z * xa1[0] + e0.w * xa[0]) * ya;
+            const float r1 = (e1.x * xa1[1] + e1.y * xa[1]) * ya1 + (e1.z * xa1[1] + e1.w * xa[1]) * ya;
+            const float r2 = (e2.x * xa1[2] + e2.y * xa[2]) * ya1 + (e2.z * xa1[2] + e2.w * xa[2]) * ya;
+            const float r3 = (e3.x * xa1[3] + e3.y * xa[3]) * ya1 + (e3.z * xa1[3] + e3.w * xa[3]) * ya;
+            const unsigned int m0 = __float_as_uint(r0 + 12582912.f), m1 = __float_as_uint(r1 + 12582912.f);
+            const unsigned int m2 = __float_as_uint(r2 + 12582912.f), m3 = __float_as_uint(r3 + 12582912.f);
+            const unsigned int lo = __builtin_amdgcn_perm(m1, m0, 0x0c0c0400u), hi = __builtin_amdgcn_perm(m3, m2, 0x0c0c0400u);
+            *reinterpret_cast<unsigned int *>(dst + (size_t) y * dpitch + x0) = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+        }
+        return;
+    }
     const f32x2 XA01 = {xa[0], xa[1]}, XA23 = {xa[2], xa[3]}, XB01 = {xa1[0], xa1[1]}, XB23 = {xa1[2], xa1[3]};
     for (int y = y_lo + wave; y < y_hi; y += 4) {
         const float tyf = y * g.inv_th - 0.5f;
@@ -289,6 +357,30 @@ __global__ __launch_bounds__(256) void k_clahe_apply(pre_jobs jobs, clahe_geom g
         }
         *reinterpret_cast<unsigned int *>(dst + (size_t) y * dpitch + x0) = pout;
     }
+}
+
+__global__ __launch_bounds__(256) void k_clahe_apply(pre_jobs jobs, clahe_geom g, const uint8_t *lut, uint8_t *frames,
+                                                     size_t slot_bytes, int dpitch) {
+    // 32 KB: CLAHE_FCOLS pairs x 256 grey levels x 4 floats, or CLAHE_MAXCOLS pairs x 256 dwords (24 KB) in the byte form
+    __shared__ __attribute__((aligned(16))) unsigned int slut[CLAHE_FCOLS * 256 * 4];
+    static_assert(CLAHE_FCOLS * 4 >= CLAHE_MAXCOLS, "the byte form must fit the same array");
+    const int strip = blockIdx.x; // ty1_raw = strip-1
+    const int chunk = blockIdx.y;
+    const int b     = blockIdx.z;
+    const int t     = threadIdx.x;
+    const int dslot = pre_job_slot(jobs, b);
+    if (!jobs.src[b] || dslot < 0) return; // idle job (workgroup-uniform, before the first barrier)
+    const int x_begin = chunk * CLAHE_CHUNK;
+    int x_end         = x_begin + CLAHE_CHUNK;
+    if (x_end > g.w) x_end = g.w;
+    // pair range touched by this chunk: p = floor(x*inv_tw - 0.5) + 1
+    const int p_lo   = (int) floorf(x_begin * g.inv_tw - 0.5f) + 1;
+    const int p_hi   = (int) floorf((x_end - 1) * g.inv_tw - 0.5f) + 1;
+    const int npairs = p_hi - p_lo + 1; // <= CLAHE_MAXCOLS by construction of the launch (checked on host)
+    if (npairs <= CLAHE_FCOLS && !g.legacy) // workgroup-uniform
+        clahe_apply_body<true>(jobs, g, lut, frames, slot_bytes, dpitch, slut, strip, chunk, b, t, dslot, p_lo, npairs, x_begin);
+    else
+        clahe_apply_body<false>(jobs, g, lut, frames, slot_bytes, dpitch, slut, strip, chunk, b, t, dslot, p_lo, npairs, x_begin);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -640,6 +732,8 @@ static int preprocess_impl(icg_ctx *ctx, int n, const int32_t *slots, const int3
     g.clip      = (int) (3.0 * area / 256);
     if (g.clip < 1) g.clip = 1;
     g.inv_tw = 1.0f / g.tw;
+    static const bool clahe_legacy = getenv("ICG_CLAHE_LEGACY") && getenv("ICG_CLAHE_LEGACY")[0] == '1';
+    g.legacy = clahe_legacy ? 1 : 0;
     g.inv_th = 1.0f / g.th;
     if (CLAHE_CHUNK / g.tw + 3 > CLAHE_MAXCOLS)
         return icg_fail(ctx, ICG_ERR_INVALID, "image too small for CLAHE chunking (tile width %d)", g.tw);

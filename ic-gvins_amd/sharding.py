@@ -25,6 +25,20 @@ def terminal_exchange(dist, device, counters, elapsed, digests):
     return [float(x) for x in c.cpu()], float(t.cpu()[0]), [int(x) for g in gathered for x in g.cpu()]
 
 
+def gather_rank_rows(dist, device, row):
+    """row: list of floats describing THIS rank (frames/s, busy host cores, engine code ...); -> the rows of all ranks in rank order.
+    Part of the terminal exchange (one more all-gather of a few doubles): the gathered bench line shows what every rank did, not only
+    rank 0 — VERDICT r4 item 6."""
+    import torch
+    if dist is None:
+        return [[float(x) for x in row]]
+    t = torch.tensor([float(x) for x in row], dtype=torch.float64, device=device)
+    gathered = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(gathered, t)
+    return [[float(x) for x in g.cpu()] for g in gathered]
+
+
+ENGINE_CODES = {"table": 0, "object": 1, "core": 2, "device": 3}
 STREAMS_PER_GPU = 768  # fixed work per GPU whatever the world size: "scaling": "weak" means exactly this
 
 

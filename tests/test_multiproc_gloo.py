@@ -53,6 +53,30 @@ def test_two_rank_sharding_matches_single_process():
     assert tmax == 1.5  # MAX over ranks
 
 
+def test_eight_rank_sharding_matches_single_process():
+    """the 8-GPU placement (one shard per rank, BASELINE configs[4]) on gloo: eight ranks, one stream each, the terminal exchange of
+    bench.py — the gathered digests equal ONE process owning all eight streams (placement invariance of 8 shards)"""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "ic-gvins_amd"))
+    from stream_utils import ensure_oracle_host, run_streams
+    ensure_oracle_host()
+    world, per_rank, nframes = 8, 1, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nframes, per_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    counters, tmax, digests, _ = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rec, stats, _ = run_streams(ensure_oracle_host(), world * per_rank, 320, 240, nframes, 60)
+    assert digests == [s["digest"] & 0x7fffffffffffffff for s in stats]
+    assert counters[0] == world * per_rank * nframes and counters[1] == sum(s["tracked_sum"] for s in stats)
+    assert tmax == 7.5  # MAX over ranks (0.5 + rank)
+
+
 def test_host_plan_scales_the_polling_threads_with_the_rank_share():
     """bench.py's per-rank host plan (sharding.host_plan): group threads follow the rank's share of the usable cores (never 8 pollers on
     2 cores), and the ranks of a node pin themselves to disjoint CPU slices"""
@@ -120,6 +144,9 @@ def test_bench_main_runs_two_ranks_as_the_driver_launches_it(tmp_path):
     assert one["engine_twin"]["engine"] == "device" and one["engine_twin"]["ok"] is True and one["engine_twin"]["digests_compared"] == 4
     assert two.get("engine_twin") is None  # (N > 1 measures the sharded front-end only)
     assert two["config"]["streams_per_gpu"] == 2 and two["config"]["frames_per_step"] == 4 and "pinned" in two["config"]["cpu_slice_per_rank"]
+    # every rank reports itself in the gathered line: its own rate, busy host cores, engine
+    assert [r["rank"] for r in two["ranks"]] == [0, 1] and all(r["engine"] == "device" and r["groups"] == 2 and r["frames_per_s"] > 0 for r in two["ranks"])
+    assert all(r["cpu_cores_busy"] >= 0 for r in two["ranks"]) and [r["engine"] for r in one["ranks"]] == ["table"]
     # rank order of the gathered digests = global stream order: the same four streams, wherever they ran
     # (the gathered digests travel as int64: 63 bits)
     assert two["selftest"]["digests"] == [d & 0x7fffffffffffffff for d in one["selftest"]["digests"]]
