@@ -564,6 +564,9 @@ def compact_line(full, details_path):
                               "frac_exclusive", "achieved_under_load", "frac_under_load", "frac_whole_path", "bytes_per_frame_algorithmic",
                               "exclusive_us_per_frame_all_kernels", "serialized_frames_per_s", "ceiling_frames_per_s", "value_over_ceiling",
                               "issue_frac", "pmc_stale", "valu_stale"))
+    if r and r.get("trk_stage"):
+        c["roofline"]["trk_stage"] = _pick(r["trk_stage"], ("kernel", "launches_per_step", "exclusive_us_per_frame", "achieved", "unit", "frac",
+                                                              "traffic_per_frame", "valu_wave_instructions_per_frame", "pmc_stale"))
     if r and r.get("valu"):
         c["roofline"]["valu"] = _pick(r["valu"], ("wave_instructions_per_frame", "lk_share", "frac"))
     for k in ("cpu_baseline", "cpu_baseline_allcores", "cpu_baseline_reference_decomposition", "cpu_baseline_reference_tracker"):
@@ -844,10 +847,10 @@ def main():
                 else:
                     roofline["valu"] = frontend_valu(pmc_file, per_launch_streams, fps / max(1, world))  # per GPU: the peak is one chip's
             if dom == "lk_track_fb":
-                roofline["note"] = ("LK keeps its working set in LDS/VGPRs by design (8.5 KB of image per point, ~9.3k VALU instructions on it): HBM "
-                                    "is the wrong roof, and so is raw VALU issue (`valu.frac`): with 48 stream groups on 20 hardware queues every "
-                                    "launch, however small, takes 110-230 us while ~16 others run (profiles/r02_queue_view.json) — the front-end is "
-                                    "bound by launch latency under load x launches per frame, see DESIGN.md section 4")
+                roofline["note"] = ("LK keeps its working set in LDS/VGPRs by design (8.5 KB of image per point): HBM is the wrong roof for it.  The "
+                                    "front-end as a whole is bound by VALU ISSUE of the co-resident kernel mix (round 5: most of its instructions — "
+                                    "dot2, DPP, packed 16-bit, conversions, FP64, everything VOP3 — issue at half rate, profiles/ubench/valu_cost_r05.txt; "
+                                    "cutting instructions in the STREAMING kernels raised frames/s one for one), see DESIGN.md section 4")
         else:
             roofline = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                         "traffic": None}
@@ -869,6 +872,30 @@ def main():
         roofline["achieved_under_load"], roofline["frac_under_load"] = roofline["achieved"], roofline["frac"]
         roofline["achieved"], roofline["frac"] = roofline["achieved_exclusive"], roofline["frac_exclusive"]
         roofline["frac_how"] = "algorithmic bytes per launch / exclusive_us (kernel-only replay, nothing else on the GPU) / peak"
+    if roofline is not None and ceiling and any(k.startswith("trk_stage") for k in ceiling["kernels"]):
+        # the device-resident tracker's stage kernels (csrc/tracker.hip, k_trk_stage): latency chains of one wave per stream over the stream's
+        # block in HBM — their own entry; counters from the committed --pmc summary of this engine when it is fresh
+        st = {k: v for k, v in ceiling["kernels"].items() if k.startswith("trk_stage")}
+        per_launch_streams = B / float(fe["n_groups"])
+        ts = {"kernel": "k_trk_stage", "launches_per_step": round(sum(v["launches_per_step"] for v in st.values()), 2),
+              "exclusive_us_per_frame": round(sum(v["exclusive_us_per_frame"] for v in st.values()), 3),
+              "exclusive_us_per_launch": {k: v["exclusive_us_per_launch"] for k, v in st.items()},
+              "bound": "latency: one wave per stream walks its 2.7 MB block (dependent HBM round trips, LDS-serial container walks); "
+                       "192 waves per launch occupy wave slots, not the chip",
+              "algorithmic_bytes_per_frame": 60000, "unit": "GB/s", "peak": HBM_PEAK_GBS}
+        ts["achieved"] = round(ts["algorithmic_bytes_per_frame"] / max(ts["exclusive_us_per_frame"], 1e-9) / 1e3, 2)
+        ts["frac"] = round(ts["achieved"] / HBM_PEAK_GBS, 6)
+        tp, tp_file = committed_pmc("k_trk_stage", per_launch_streams)
+        t_stale = pmc_provenance(tp_file, per_launch_streams, ["k_trk_stage"]) if tp_file else "no committed counter summary"
+        if t_stale or not tp:
+            ts["pmc_stale"] = t_stale or "no k_trk_stage entry in " + str(tp_file)
+        else:
+            if "hbm_bytes_per_launch" in tp:
+                ts["traffic_per_frame"] = int(tp["hbm_bytes_per_launch"] * ts["launches_per_step"] / per_launch_streams)
+            if tp.get("SQ_INSTS_VALU"):
+                ts["valu_wave_instructions_per_frame"] = int(tp["SQ_INSTS_VALU"] * ts["launches_per_step"] / per_launch_streams)
+            ts["pmc_source"] = "profiles/" + tp_file
+        roofline["trk_stage"] = ts
     if roofline is not None:
         # the whole front-end against the HBM roof: every byte SURVEY 8(d) counts for a frame x the measured frames/s of one GPU
         roofline["bytes_per_frame_algorithmic"] = int(frame_bytes(w, h, nfeat))

@@ -65,8 +65,22 @@ def two_view_points(n, seed, w, h):
     return p1.astype(np.float32), p2.astype(np.float32)
 
 
+def expected_keys():
+    """the keys tests/test_opencv_golden.py reads (per config tag) — printed by `--list-keys` and after a run, so a hand-off needs no second look"""
+    per_tag = ["clahe_a", "clahe_b", "pyr0", "pyr1", "pyr2", "pyr3", "lk_prev", "lk_guess", "lk_next", "lk_status", "lk_err", "undist_in",
+               "undist_out", "det_grid", "det_exist", "det_mask", "det_pts", "det_block", "fm_p1", "fm_p2", "fm_mask", "fm_F"]
+    return ["opencv_version"] + [f"{tag}_{k}" for tag in CONFIGS for k in per_tag]
+
+
 def main():
-    import cv2
+    if "--list-keys" in sys.argv:  # needs neither cv2 nor the inputs
+        print("\n".join(expected_keys()))
+        return
+    try:
+        import cv2
+    except ImportError:
+        sys.exit("make_opencv_golden.py needs only numpy and cv2 (opencv-python >= 4.5, < 5): `import cv2` failed on this box.  Run it where "
+                 "OpenCV is installed and commit tests/golden/opencv_golden.npz; keys: python tests/golden/make_opencv_golden.py --list-keys")
     out = {"opencv_version": np.array(cv2.__version__)}
     for tag, (w, h, nfeat) in CONFIGS.items():
         a = synth.texture(w, h, seed=21)
@@ -139,8 +153,11 @@ def main():
         out[f"{tag}_fm_mask"] = (m.ravel().astype(np.uint8) if m is not None else np.zeros(len(p1), np.uint8))
         out[f"{tag}_fm_F"] = F if F is not None else np.zeros((3, 3))
     path = os.path.join(HERE, "opencv_golden.npz")
+    missing = [k for k in expected_keys() if k not in out]
+    assert not missing, missing
     np.savez_compressed(path, **out)
-    print("wrote", path, "with OpenCV", cv2.__version__)
+    print("wrote", path, "with OpenCV", cv2.__version__, f"({len(out)} arrays; the {len(expected_keys())} the tests read are all present)")
+    print("next: git add tests/golden/opencv_golden.npz && python -m pytest tests/test_opencv_golden.py -q      (CPU: the oracle; -m gpu: the HIP path)")
 
 
 if __name__ == "__main__":

@@ -106,16 +106,52 @@ def test_fm_ransac_mask(oracle, G, tag):
 
 
 @pytest.mark.gpu
-def test_hip_path_against_real_opencv_on_the_gpu_box(G):
-    """Selected by `-m gpu`, so the GPU summary carries the marker too: while the golden is absent this SKIPS (visible as `1 skipped` with the
+@pytest.mark.parametrize("tag", CONFIGS)
+def test_hip_path_against_real_opencv_on_the_gpu_box(G, tag):
+    """Selected by `-m gpu`, so the GPU summary carries the marker too: while the golden is absent this SKIPS (visible as skipped with the
     reason above) — on the GPU lease there is no cv2, no wheel in /opt/wheelhouse, no pip index, no apt source and no network either
-    (profiles/r04_opencv_probe.txt, one gpurun call of round 4).  With the golden present: the HIP preprocessing against OpenCV's CLAHE."""
+    (profiles/r04_opencv_probe.txt, one gpurun call of round 4).  With the golden present the WHOLE HIP front-end is pinned at once, through the C ABI
+    (VERDICT r4 item 7), with the bounds the oracle tests above state per primitive:
+      CLAHE (tracking.cc:63,139) and the LK pyramid levels: bit-exact; calcOpticalFlowPyrLK (:385-393, 487-496): status identical up to
+      threshold decisions, positions within 2e-3 px; undistortPoints (camera.cc:72-74): float bit patterns; goodFeaturesToTrack +
+      cornerSubPix per block (:647-652): corner set, order and block assignment identical, coordinates within 1e-3 px;
+      findFundamentalMat (:548): inlier mask identical — on the host-looped entry point and on the one-launch kernel of the device-resident tracker."""
+    import harness as H
     import icgvins
-    a, b, w, h = _inputs("c2")
-    c = icgvins.Context(w, h, n_slots=2, max_batch=2, max_points=512)
+    a, b, w, h = _inputs(tag)
+    n = {"c1": 100, "c2": 300, "c4": 500}[tag]
+    c = icgvins.Context(w, h, n_slots=2, max_batch=2, max_points=max(1024, 4 * n))
     try:
+        c.set_camera(H.camera_for(w, h))
         c.preprocess([0, 1], [a, b])
-        assert np.array_equal(c.download(0, 0), G["c2_clahe_a"])
-        assert np.array_equal(c.download(1, 0), G["c2_clahe_b"])
+        assert np.array_equal(c.download(0, 0), G[f"{tag}_clahe_a"]) and np.array_equal(c.download(1, 0), G[f"{tag}_clahe_b"])
+        for lvl in (1, 2, 3):
+            assert np.array_equal(c.download(0, lvl), G[f"{tag}_pyr{lvl}"]), f"pyramid level {lvl}"
+        # F2
+        prev, guess = G[f"{tag}_lk_prev"], G[f"{tag}_lk_guess"]
+        zeros, ones = np.zeros(len(prev), np.int32), np.ones(len(prev), np.int32)
+        nxt, st, err = c.lk_track(zeros, ones, prev, guess)
+        exp_st = G[f"{tag}_lk_status"].astype(np.uint8)
+        flips = int((st != exp_st).sum())
+        assert flips <= max(1, len(st) // 200), f"{flips} LK status flips"
+        ok = (st == 1) & (exp_st == 1)
+        assert np.abs(nxt[ok] - G[f"{tag}_lk_next"][ok]).max() < 2e-3
+        assert np.abs(err[ok] - G[f"{tag}_lk_err"][ok]).max() < 1e-3 * max(1.0, float(G[f"{tag}_lk_err"][ok].max()))
+        # F4
+        got = c.undistort(G[f"{tag}_undist_in"])
+        assert np.array_equal(got.view(np.uint32), G[f"{tag}_undist_out"].view(np.uint32))
+        # F7
+        cols, rows, bw, bh, quota, min_dist = [int(v) for v in G[f"{tag}_det_grid"]]
+        exist = np.asarray(G[f"{tag}_det_exist"], np.float32).reshape(-1, 2)
+        cap = cols * rows * quota
+        out, cnt, blk = c.detect([0], [cols, rows, bw, bh, min_dist, quota], [0, len(exist)], exist, np.full(cols * rows, quota, np.int32), cap)
+        exp_blk = G[f"{tag}_det_block"]
+        assert cnt[0] == len(exp_blk) and np.array_equal(blk[0, :cnt[0]], exp_blk)
+        assert np.abs(out[0, :cnt[0]] - G[f"{tag}_det_pts"]).max() < 1e-3
+        # F6
+        p1, p2 = G[f"{tag}_fm_p1"], G[f"{tag}_fm_p2"]
+        off = np.array([0, len(p1)], np.int32)
+        assert np.array_equal(c.fm_ransac(off, p1, p2, 1.5, 0.99), G[f"{tag}_fm_mask"])
+        assert np.array_equal(c.fm_ransac_device(off, p1, p2, 1.5, 0.99), G[f"{tag}_fm_mask"])
     finally:
         c.close()
