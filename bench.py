@@ -405,6 +405,20 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
     tracked = sum(s_["tracked_sum"] for s_ in stats) - tracked_before
     rates = event_rates(sb.counters(reset=True), sum(a["keyframes"] - b["keyframes"] for a, b in zip(stats, stats_before)),
                         sum(a["mappoints_created"] - b["mappoints_created"] for a, b in zip(stats, stats_before)), B * steps)
+    # the timed region continued to 200 steps (report the long-run rate beside `value` instead of tuning the priming for a
+    # 20-step region): the same streams go on from where the timed region stopped; digests / statistics above belong to the timed region
+    extended = None
+    if 0 < steps < 200 and profile and not os.environ.get("ICG_BENCH_SELFTEST_ORACLE"):
+        extra = 200 - steps
+        prep_x = prepare_steps(k, extra)
+        tx = time.perf_counter()
+        run_prepared(extra, prep_x)
+        k += extra
+        dev_sync()
+        tx = time.perf_counter() - tx
+        extended = {"steps": steps + extra, "frames_per_s": round(B * (steps + extra) / (elapsed + tx), 1),
+                    "frames_per_s_extra_steps_only": round(B * extra / tx, 1)}
+        sb.counters(reset=True)
 
     # ---- profiled pass (HIP events on the ABI streams) ---------------------------------------------------------------------
     kernel_table, work = {}, None
@@ -539,7 +553,7 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
             "frames_per_stream_at_digest": prime + warmup + steps, "ring": ring, "rates": rates, "cpu_cores_busy": round(cpu_cores_used, 2),
             "elapsed": elapsed, "states_hist": states_hist, "tracked": tracked, "stats": stats, "step_stats": step_stats,
             "host_breakdown": host_breakdown, "kernel_table": kernel_table, "work": work, "n_groups": n_groups, "setup_s": t_setup,
-            "prime_s": t_prime, "host0": host0, "poses0": poses[0], "cam": cam}
+            "prime_s": t_prime, "host0": host0, "poses0": poses[0], "cam": cam, "extended": extended}
 
 
 def _pick(d, keys):
@@ -556,6 +570,8 @@ def compact_line(full, details_path):
         c["value_withheld"] = full["value_withheld"]
     if "selftest" in full:
         c["selftest"] = full["selftest"]
+    if full.get("value_200steps") is not None:
+        c["value_200steps"] = full["value_200steps"]
     if full.get("n_gpus", 1) > 1 or "selftest" in full:
         c["ranks"] = full.get("ranks")  # every rank's own frames/s, busy host cores, engine (N = 1: the same numbers are in value / host)
     r = full.get("roofline")
@@ -609,9 +625,9 @@ def compact_line(full, details_path):
     rpl = full.get("replay")
     if rpl:
         c["replay"] = _pick(rpl, ("value", "unit", "error"))
-        for k in ("concurrent", "lockstep"):
+        for k in ("concurrent", "lockstep", "lockstep64"):
             if rpl.get(k):
-                c["replay"][k] = _pick(rpl[k], ("value", "estimators"))
+                c["replay"][k] = _pick(rpl[k], ("value", "estimators", "error"))
     c["hbm_peak_measured_GBps"] = full.get("hbm_peak_measured_GBps")
     hb = full.get("host_ms_per_step") or {}
     c["host"] = {"cpu_cores_busy": hb.get("cpu_cores_busy"), "group_step_ms_min_mean_max": hb.get("group_step_ms_min_mean_max")}
@@ -1155,7 +1171,19 @@ def main():
                                   "frames_per_s": round(sum(x["frames_tracked"] for x in SL) / wall_lock, 1),
                                   "window_solves_per_s": round(sum(x["optimizations"] for x in SL) / wall_lock, 1),
                                   "window_solves": shared[0], "batched_solve_rounds": shared[1], "largest_batch": shared[2],
-                                  "note": "only the LM solves are shared inside a group; tracking / INS / culling / marginalization stay per stream on the group's one host thread"}
+                                  "note": "the LM solves and (round 5: MarginalizationBatch on by default) the marginalizations of a tick are shared inside a group; "
+                                          "tracking / INS / culling stay per stream on the group's one host thread"}
+            # 64 estimators in four lock-step groups of 16: wide batches for the shared solves / marginalizations, 4 host threads
+            try:
+                outs64 = [os.path.join(root, "l64_%d" % k) for k in range(64)]
+                S64, wall64, shared64 = gvc.run_replay_lockstep(hostlib, files, outs64, groups=4)
+                replay["lockstep64"] = {"estimators": 64, "groups": 4, "value": round(sum(x["data_seconds"] for x in S64) / wall64, 2),
+                                        "unit": "x real time, summed over the streams", "wall_s": round(wall64, 3),
+                                        "window_solves_per_s": round(sum(x["optimizations"] for x in S64) / wall64, 1),
+                                        "batched_solve_rounds": shared64[1], "largest_batch": shared64[2],
+                                        "marg_batches_windows": list(gvc.lockstep_marg_counts(hostlib))}
+            except Exception as e64:
+                replay["lockstep64"] = {"error": f"{type(e64).__name__}: {e64}"[:200]}
             if not args.no_cpu_baseline:
                 from stream_utils import ensure_oracle_host
                 cpulib = C.CDLL(ensure_oracle_host())
@@ -1422,6 +1450,9 @@ def main():
                                   "device": "device-resident tracker (csrc/tracker.hip: state in HBM, one launch chain + one wait per step)"}[args.engine]},
             "parity": parity if not args.no_parity else {"ok": None, "skipped": "--no-parity (diagnostic run)"},
             "ranks": ranks_block,
+            "value_200steps": ((fe.get("extended") or {}).get("frames_per_s") if (world == 1 and (parity_ok or args.no_parity) and not selftest) else None),
+            "value_200steps_how": ("the timed region continued to 200 steps on the same streams (the driver's 20 steps are 0.12 s): frames of all 200 steps / "
+                                   "their wall time; N = 1 only" if fe.get("extended") else None),
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "cpu_baseline_allcores": cpu_baseline_allcores,

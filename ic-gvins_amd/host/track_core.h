@@ -80,6 +80,8 @@ struct Scratch {
     int32_t tmp_bucket[MAX_BUCKETS];
     u64 key[MAX_ROWS];
     uint32_t want[MAX_ROWS + 2]; // bucket counts after k insertions for the rows an order_extend pass enters (a copy of buckets_after)
+    uint16_t ibkt[MAX_ROWS];     // order_extend: the bucket of row i under the bucket count in effect at ITS insertion (computed in parallel)
+    uint16_t rbkt[MAX_ROWS];     // order_extend: the bucket of node p under the bucket count a rehash moves to (computed in parallel)
 };
 
 enum { TRACK_FIRST_FRAME = 0, TRACK_INITIALIZING = 1, TRACK_TRACKING = 2, TRACK_PASSED = 3, TRACK_LOST = 4 }; // tracking.h:38-44
@@ -773,18 +775,30 @@ TC_FN void order_extend(Frame &f, int n_old, const uint32_t *buckets_after, Scra
     for (int b = lane(); b < nb; b += NL) X.bucket[b] = n_old ? f.bucket[b] : H_EMPTY;
     for (int k = n_old + 1 + lane(); k <= n; k += NL) X.want[k] = buckets_after[k]; // (one HBM load per insertion otherwise: ~1 us each)
     sync();
+    // Round 5: the serial pass below is a chain of dependent LDS accesses per insertion; the 64-bit multiply-high of bucketOf sat on that
+    // chain (once per insertion, once more for the old head, once per node of every rehash: ~0.23 ms for the 250 rows of a new frame).
+    // Every bucket index it needs is known up front — row i enters under the bucket count buckets_after[i + 1], a rehash re-buckets the
+    // nodes inserted so far under its new count — so they are computed a row per lane, and the chain keeps only the list surgery; the
+    // bucket of the current head node is carried along (an insertion at the head moves it to the inserted row's bucket).
+    for (int i = n_old + lane(); i < n; i += NL) {
+        const int w = (int) X.want[i + 1];
+        X.ibkt[i]   = (uint16_t) bucketOf(X.key[i], w, modMagic((u64) w));
+    }
+    sync();
+    int head_bkt = head >= 0 ? bucketOf(X.key[head], nb, M) : 0; // bucket of the node `head` under nb (meaningful while head >= 0)
     for (int i = n_old; i < n; i++) {
         const int want = (int) X.want[i + 1];
         if (want != nb) { // _M_rehash_aux over the i nodes inserted so far
-            for (int b = lane(); b < want; b += NL) X.tmp_bucket[b] = H_EMPTY;
-            sync();
             const u64 M2 = modMagic((u64) want);
+            for (int b = lane(); b < want; b += NL) X.tmp_bucket[b] = H_EMPTY;
+            for (int p = lane(); p < i; p += NL) X.rbkt[p] = (uint16_t) bucketOf(X.key[p], want, M2);
+            sync();
             int p = head;
             head  = -1;
             int bbegin_bkt = 0;
             while (p >= 0) {
                 const int nx = X.next[p];
-                const int b  = bucketOf(X.key[p], want, M2);
+                const int b  = X.rbkt[p];
                 if (X.tmp_bucket[b] == H_EMPTY) {
                     X.next[p]       = head;
                     head            = p;
@@ -806,13 +820,14 @@ TC_FN void order_extend(Frame &f, int n_old, const uint32_t *buckets_after, Scra
             sync();
             for (int b = lane(); b < want; b += NL) X.bucket[b] = X.tmp_bucket[b];
             sync();
-            nb = want;
-            M  = M2;
+            nb       = want;
+            M        = M2;
+            head_bkt = bbegin_bkt; // (the bucket whose first node is the list head)
         }
-        const int b = bucketOf(X.key[i], nb, M);
+        const int b = X.ibkt[i];
         if (X.bucket[b] != H_EMPTY) {
             const int prev = X.bucket[b];
-            if (prev == H_BEFORE_BEGIN) {
+            if (prev == H_BEFORE_BEGIN) { // the head's own bucket: the new node becomes the head, in the same bucket
                 X.next[i] = head;
                 head      = i;
             } else {
@@ -821,9 +836,10 @@ TC_FN void order_extend(Frame &f, int n_old, const uint32_t *buckets_after, Scra
             }
         } else {
             X.next[i] = head;
-            head      = i;
-            if (X.next[i] >= 0) X.bucket[bucketOf(X.key[X.next[i]], nb, M)] = i;
+            if (head >= 0) X.bucket[head_bkt] = i; // the old head's bucket now begins after the new node
+            head        = i;
             X.bucket[b] = H_BEFORE_BEGIN;
+            head_bkt    = b;
         }
     }
     sync();

@@ -284,12 +284,15 @@ bool Replay::runLockstep(const std::vector<ReplayOptions> &options, std::vector<
     auto t0 = std::chrono::steady_clock::now();
     try {
         WindowSolverBatch batch(0, 1.0, solver_host_threads); // huber delta 1 of the reprojection factors (ic_gvins.cc:1773)
-        // ICG_LOCKSTEP_MARG_BATCH=1: the marginalizations of a tick share their device launches too (MarginalizationBatch, host/marg_batch.h;
-        // Huber delta 0: the reference builds the prior from uncorrected reprojection factors, ic_gvins.cc:1600-1606).  Opt-in until the
-        // class has been through a replay on the device (round 4 ended before that could be run).
+        // The marginalizations of a tick share their device launches too (MarginalizationBatch, host/marg_batch.h; Huber delta 0: the
+        // reference builds the prior from uncorrected reprojection factors, ic_gvins.cc:1600-1606).  On by default since round 5 (the class
+        // went through the replays on the MI355X: tests/test_gpu_zz_marg_batch.py, profiles/r05_first_call); ICG_LOCKSTEP_MARG_BATCH=0
+        // gives every estimator its own MarginalizationInfo::marginalization() back.
         std::unique_ptr<MarginalizationBatch> marg_batch;
-        if (const char *e = getenv("ICG_LOCKSTEP_MARG_BATCH"))
-            if (atoi(e) > 0) marg_batch.reset(new MarginalizationBatch(0, 0.0, solver_host_threads));
+        {
+            const char *e = getenv("ICG_LOCKSTEP_MARG_BATCH");
+            if (!e || atoi(e) > 0) marg_batch.reset(new MarginalizationBatch(0, 0.0, solver_host_threads));
+        }
         std::vector<LockstepStream *> due;
         bool any = true;
         while (any) {
