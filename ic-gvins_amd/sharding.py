@@ -66,7 +66,9 @@ def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, 
         # 108.8 k, 8 x 192 (1536 streams) -> 111.8 k; 2 confined CPUs: 4 x 192 -> 106.7 k, 8 x 96 -> 106.1 k
         groups = int(groups_override) if groups_override > 0 else 4
     else:
-        groups = int(groups_override) if groups_override > 0 else int(max(4, min(12, 4 * round(cores_rank))))
+        # round 5 (profiles/r05_call7: with 12 groups no LK launch is in flight 24 % of the time; r05_call5 / r05_call8 sweeps on three boxes:
+        # 12 x 64 -> 131.6-134.7 k, 16 x 48 -> 134.7 k, 16 x 64 -> 135.6-138.2 k, 24 x 32 -> 125.5 k, 24 x 48 -> 134.2 k, 32 x 32 -> 130.8 k)
+        groups = int(groups_override) if groups_override > 0 else int(max(4, min(16, 4 * round(cores_rank))))
     streams = int(streams_override) if streams_override > 0 else STREAMS_PER_GPU
     groups = max(1, min(groups, streams))
     cpu_slice = None

@@ -41,11 +41,20 @@ for t, d in ev:
     cur += d
     last = t
 tot = sum(hist.values())
+# how often the chip-filling kernel runs at all (round 5): LK dispatches in flight over the window
+evl = sorted([(s, 1) for s, e, nm, _ in win if nm.startswith("k_lk_track_fb")] + [(e, -1) for s, e, nm, _ in win if nm.startswith("k_lk_track_fb")])
+curl, lastl, histl = 0, t0, defaultdict(float)
+for t, d in evl:
+    histl[curl] += t - lastl
+    curl += d
+    lastl = t
+totl = sum(histl.values()) or 1.0
 kernels = {k: {"n": len(v), "mean_us": round(sum(v) / len(v) / 1e3, 1), "share_of_queue_time": round(sum(v) / sum(sum(x) for x in per_k.values()), 3)}
            for k, v in sorted(per_k.items(), key=lambda kv: -sum(kv[1]))}
 out = {"window_ms": round(span / 1e6, 2), "lk_launches_in_window": sum(1 for r in win if r[2].startswith("k_lk_track_fb")),
        "queues_seen": len(queues), "mean_queue_busy_frac": round(sum(q["busy_frac"] for q in queues.values()) / max(1, len(queues)), 3),
        "mean_kernels_in_flight": round(sum(k * v for k, v in hist.items()) / tot, 2),
        "in_flight_histogram": {str(k): round(v / tot, 3) for k, v in sorted(hist.items())},
+       "lk_in_flight_histogram": {str(k): round(v / totl, 3) for k, v in sorted(histl.items())},
        "queues": queues, "kernels": kernels}
 print(json.dumps(out, indent=1))
