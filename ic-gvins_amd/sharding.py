@@ -54,13 +54,14 @@ def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, 
       cpu_slice    the contiguous slice of the allowed CPU ids this rank pins itself to (None for a single rank: nothing to separate)
     """
     cores_rank = float(usable_cores) / float(max(1, world))
-    # engine (round 4).  The device-resident tracker (csrc/tracker.hip: the streams' state in HBM, one launch chain + one wait per step) needs
-    # 0.3-0.5 host cores per GPU: 116 k frames/s at the driver's command, 108 k with every thread of the process confined to 2 CPUs, 116 k on ONE.
-    # The track table on the host (rounds 1-3) overlaps its host logic with the other groups' kernels for free and is 3-5 % faster on a GPU that
-    # has the cores for it (119-122 k with 4.3-4.6 cores busy) — and collapses to 44 k on 2 CPUs (profiles/r04_cpu_quota.md).  So: the table where
-    # a rank has >= 6 cores, the device tracker below.  Same results either way, state for state (tests/test_gpu_device_tracker.py,
-    # tests/test_host_engines_cpu.py; the 2-rank bench self-test runs one rank count on each engine and compares the digests).
-    engine = engine_override or ("table" if cores_rank >= 6.0 else "device")
+    # engine.  The device-resident tracker (csrc/tracker.hip: the streams' state in HBM, one launch chain + one wait per step) is THE engine
+    # since round 5, for every rank whatever its share of the host: at the driver's command (20 timed steps) 133.5 k frames/s with 0.56 host
+    # cores busy against 127.6 k with 5.4 cores busy for the track table (profiles/r05_call9: same box, same minute; 137.5 k with every
+    # thread confined to 2 CPUs, 119.0 k on ONE, where the table collapses to 47.5 k); on 200-step runs the two are within +-3 %
+    # (130.9 / 135.2 k).  Rounds 1-3's host engines (track table, object graph, tracker core on the host) stay selectable
+    # (--engine / ICG_TRACK_ENGINE) and run as the bench's engine twin and in the tests: same results, state for state
+    # (tests/test_gpu_device_tracker.py, tests/test_host_engines_cpu.py; the 2-rank bench self-test runs one rank count on each engine).
+    engine = engine_override or "device"
     if engine == "device":
         # wide launches: the stage kernels cost the same whatever the number of streams (a wave per stream).  4 x 192 -> 106.9 k, 12 x 64 ->
         # 108.8 k, 8 x 192 (1536 streams) -> 111.8 k; 2 confined CPUs: 4 x 192 -> 106.7 k, 8 x 96 -> 106.1 k

@@ -83,16 +83,18 @@ def test_host_plan_scales_the_polling_threads_with_the_rank_share():
     sys.path.insert(0, os.path.join(ROOT, "ic-gvins_amd"))
     import sharding
     one = sharding.host_plan(16, 1, 0, cpu_ids=range(256))
-    assert one["groups"] == 16 and one["engine"] == "table" and one["streams"] == 768 and one["cpu_slice"] is None
-    assert sharding.host_plan(16, 1, 0, cpu_ids=range(256), engine_override="device")["groups"] == 4
+    # round 5: the device-resident tracker is the engine of every rank (it needs ~0.5 host cores per GPU); the host engines are overrides
+    assert one["groups"] == 4 and one["engine"] == "device" and one["streams"] == 768 and one["cpu_slice"] is None
+    tab = sharding.host_plan(16, 1, 0, cpu_ids=range(256), engine_override="table")
+    assert tab["groups"] == 16 and tab["engine"] == "table"
     eight = [sharding.host_plan(16, 8, r, cpu_ids=range(256)) for r in range(8)]
-    # weak scaling: the streams of a GPU do not shrink with the world size; only the number of polling threads follows the rank's cores
-    # (2 cores per GPU: the device-resident tracker — the host only issues a launch chain per step — in six wide groups)
+    # weak scaling: the streams of a GPU do not shrink with the world size
     assert all(p["groups"] == 4 and p["engine"] == "device" and p["streams"] == 768 and abs(p["cores_rank"] - 2.0) < 1e-12 for p in eight)
     slices = [set(p["cpu_slice"]) for p in eight]
     assert all(len(s_) == 32 for s_ in slices) and len(set().union(*slices)) == 256  # disjoint, covering
     big = sharding.host_plan(128, 8, 3, cpu_ids=range(128))
-    assert big["groups"] == 16 and big["engine"] == "table" and big["streams"] == 768 and big["cpu_slice"] == list(range(48, 64))
+    assert big["groups"] == 4 and big["engine"] == "device" and big["streams"] == 768 and big["cpu_slice"] == list(range(48, 64))
+    assert sharding.host_plan(128, 8, 3, cpu_ids=range(128), engine_override="table")["groups"] == 16
     four = sharding.host_plan(16, 4, 1, cpu_ids=range(256))
     assert four["engine"] == "device" and four["groups"] == 4 and abs(four["cores_rank"] - 4.0) < 1e-12
     tiny = sharding.host_plan(4, 8, 0, cpu_ids=range(4))
