@@ -314,11 +314,33 @@ int icgh_core_order_selftest(uint64_t seed, int n_first, int n_more, int rounds)
     append(n_first);
     tc::order_extend(*f, old, ba, *X);
     if (!same()) return 1;
+    // the sort form (order_extend_parallel) on a copy of the same rows: same list, same buckets, at every step
+    std::unique_ptr<tc::Frame> fp(new tc::Frame);
+    memset(fp.get(), 0, sizeof(tc::Frame));
+    tc::order_clear(*fp);
+    auto mirror = [&]() {
+        for (int k = fp->n_rows; k < f->n_rows; k++) fp->row[k].id = f->row[k].id;
+        fp->n_rows = f->n_rows;
+    };
+    auto same_as_parallel = [&]() {
+        if (fp->head != f->head || fp->n_buckets != f->n_buckets || fp->magic != f->magic) return false;
+        for (int k = 0; k < f->n_rows; k++)
+            if (fp->next[k] != f->next[k]) return false;
+        for (int b = 0; b < f->n_buckets; b++)
+            if (fp->bucket[b] != f->bucket[b]) return false;
+        return true;
+    };
+    mirror();
+    tc::order_extend_parallel(*fp, 0, ba, *X);
+    if (!same_as_parallel()) return 500;
     for (int r = 0; r < rounds; r++) {
         old = f->n_rows;
         append(n_more);
         tc::order_extend(*f, old, ba, *X);
         if (!same()) return 2 + r;
+        mirror();
+        tc::order_extend_parallel(*fp, old, ba, *X);
+        if (!same_as_parallel()) return 501 + r;
     }
     // and the one-by-one form (order_insert_unique: the path of rows added outside a batch) gives the same list
     std::unique_ptr<tc::Frame> g(new tc::Frame);

@@ -51,6 +51,17 @@ TC_FN u64 wave_sum(u64 v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
+// (round 5) scratch-memory atomics and an inclusive prefix sum over the lanes, for the parallel container-order construction
+TC_FN uint32_t lds_min(uint32_t *p, uint32_t v) { return atomicMin(p, v); }
+TC_FN uint32_t lds_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+TC_FN int32_t lds_exch(int32_t *p, int32_t v) { return atomicExch(p, v); }
+TC_FN uint32_t wave_scan_incl(uint32_t v) {
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(v, o, 64);
+        if (lane() >= o) v += up;
+    }
+    return v;
+}
 #else
 constexpr int NL = 1;
 TC_FN int lane() { return 0; }
@@ -59,6 +70,22 @@ TC_FN int popc(u64 m) { return (int) __builtin_popcountll(m); }
 TC_FN u64 lanes_below() { return 0ull; }
 TC_FN void sync() {}
 TC_FN u64 wave_sum(u64 v) { return v; }
+TC_FN uint32_t lds_min(uint32_t *p, uint32_t v) {
+    const uint32_t o = *p;
+    if (v < o) *p = v;
+    return o;
+}
+TC_FN uint32_t lds_add(uint32_t *p, uint32_t v) {
+    const uint32_t o = *p;
+    *p               = o + v;
+    return o;
+}
+TC_FN int32_t lds_exch(int32_t *p, int32_t v) {
+    const int32_t o = *p;
+    *p              = v;
+    return o;
+}
+TC_FN uint32_t wave_scan_incl(uint32_t v) { return v; }
 #endif
 
 // ---- capacities ------------------------------------------------------------------------------------------------------------------
@@ -82,6 +109,12 @@ struct Scratch {
     uint32_t want[MAX_ROWS + 2]; // bucket counts after k insertions for the rows an order_extend pass enters (a copy of buckets_after)
     uint16_t ibkt[MAX_ROWS];     // order_extend: the bucket of row i under the bucket count in effect at ITS insertion (computed in parallel)
     uint16_t rbkt[MAX_ROWS];     // order_extend: the bucket of node p under the bucket count a rehash moves to (computed in parallel)
+    // order_extend_parallel (round 5): per bucket the head of an (unordered) event list; per event its link, per time the chain sizes /
+    // their suffix sums; the list order as an array, twice (a phase reads one and writes the other)
+    int32_t bhead[MAX_BUCKETS];
+    int32_t lnk[MAX_ROWS];
+    uint32_t tsum[MAX_ROWS + 1];
+    uint16_t ord[2][MAX_ROWS];
 };
 
 enum { TRACK_FIRST_FRAME = 0, TRACK_INITIALIZING = 1, TRACK_TRACKING = 2, TRACK_PASSED = 3, TRACK_LOST = 4 }; // tracking.h:38-44
@@ -850,6 +883,125 @@ TC_FN void order_extend(Frame &f, int n_old, const uint32_t *buckets_after, Scra
     f.magic     = M;
     sync();
 }
+// The same container order WITHOUT the serial chain (round 5; VERDICT r4 item 4: "several lanes for the order insertions").  What
+// _M_insert_bucket_begin does to the node list is the same for every insertion — a node whose bucket is empty goes to the head of the list,
+// any other node to the front of its bucket's chain — and _M_rehash_aux re-enters the nodes in list order under the new bucket function by
+// that very rule.  So after any run of insertions the list is the concatenation of the buckets' chains, chains ordered by the time their
+// bucket received its first node (latest first), nodes inside a chain by their own time (latest first): a SORT of the events, not a walk.
+// A phase = the rows entered under one bucket count (a rehash at its start re-enters the existing list, head first, as the phase's first
+// events; a phase that continues a stored list without a rehash numbers the existing nodes tail first, which is the order they were
+// entered in up to what the rule above can tell apart).  Per phase, a row per lane throughout: bucket of every event, per bucket the earliest
+// event time (atomic min) and the chain size (atomic add), the chains' offsets by a suffix sum over time, the rank inside a chain by a walk of
+// the bucket's short event list.  One new frame of 250 rows: six phases over 13 .. 250 events instead of 250 + 485 dependent steps.
+// Results identical to order_extend (icgh_core_order_selftest against a real std::unordered_map, every engine test).
+TC_FN void order_extend_parallel(Frame &f, int n_old, const uint32_t *buckets_after, Scratch &X) {
+    const int n = f.n_rows;
+    if (n <= n_old) return;
+    int nb = n_old ? f.n_buckets : 1;
+    for (int k = lane(); k < n; k += NL) X.key[k] = f.row[k].id;
+    for (int k = lane(); k < n_old; k += NL) X.next[k] = f.next[k];
+    for (int k = n_old + 1 + lane(); k <= n; k += NL) X.want[k] = buckets_after[k];
+    sync();
+    int cur = 0, m = 0; // list order so far: X.ord[cur][0 .. m), head first
+    for (int q = n_old ? f.head : -1; q >= 0; q = X.next[q]) X.ord[cur][m++] = (uint16_t) q; // (all lanes: same values)
+    sync();
+    bool continued = n_old > 0; // the stored list continues without a rehash (first phase only)
+    int ra         = n_old;
+    while (ra < n) {
+        const int want = (int) X.want[ra + 1];
+        if (want != nb) continued = false; // _M_rehash_aux before row ra enters: the existing nodes are re-entered head first
+        nb = want;
+        int rb = ra + 1;
+        while (rb < n && (int) X.want[rb + 1] == nb) rb++; // rows [ra, rb) enter under nb
+        const u64 M = modMagic((u64) nb);
+        const int E = m + (rb - ra); // events of the phase; event e < m: node ord[e]; else row ra + (e - m); time: see below
+        uint32_t *bfirst = reinterpret_cast<uint32_t *>(X.tmp_bucket), *bcnt = reinterpret_cast<uint32_t *>(X.bucket);
+        for (int b = lane(); b < nb; b += NL) bfirst[b] = 0xffffffffu, bcnt[b] = 0, X.bhead[b] = -1;
+        for (int t = lane(); t <= E; t += NL) X.tsum[t] = 0;
+        sync();
+        for (int e = lane(); e < E; e += NL) {
+            const int node = e < m ? (int) X.ord[cur][e] : ra + (e - m);
+            const int t    = (e < m && continued) ? m - 1 - e : e;
+            const int b    = bucketOf(X.key[node], nb, M);
+            X.rbkt[e]      = (uint16_t) b;
+            X.ibkt[node]   = (uint16_t) b;
+            lds_min(&bfirst[b], (uint32_t) t);
+            lds_add(&bcnt[b], 1u);
+            X.lnk[e] = lds_exch(&X.bhead[b], e);
+        }
+        sync();
+        // tsum[t] := size of the chain whose bucket received its first node at time t (0 for the other times)
+        for (int e = lane(); e < E; e += NL) {
+            const int t = (e < m && continued) ? m - 1 - e : e;
+            const int b = X.rbkt[e];
+            if (bfirst[b] == (uint32_t) t) X.tsum[t] = bcnt[b];
+        }
+        sync();
+        // tsum[t] := number of nodes in chains that started LATER than t (they precede the chain that started at t): suffix sums, a
+        // chunk of NL times per step from the top
+        {
+            uint32_t carry = 0;
+            for (int hi = E; hi > 0; hi -= NL) {
+                const int t      = hi - 1 - lane(); // descending times across the lanes
+                const uint32_t v = t >= 0 ? X.tsum[t] : 0u;
+                const uint32_t inc = wave_scan_incl(v); // sum over times >= t inside the chunk
+                if (t >= 0) X.tsum[t] = carry + inc - v;
+                uint32_t tot = inc; // chunk total = the inclusive sum of the chunk's last lane (or the one value on the host)
+#if defined(__HIP_DEVICE_COMPILE__)
+                tot = (uint32_t) __shfl((int) inc, 63, 64);
+#endif
+                carry += tot;
+                sync();
+            }
+        }
+        sync();
+        const int nxt = cur ^ 1;
+        for (int e = lane(); e < E; e += NL) {
+            const int node = e < m ? (int) X.ord[cur][e] : ra + (e - m);
+            const int t    = (e < m && continued) ? m - 1 - e : e;
+            const int b    = X.rbkt[e];
+            int rank       = 0; // events of the same bucket that entered later (they sit in front)
+            for (int o = X.bhead[b]; o >= 0; o = X.lnk[o]) {
+                const int to = (o < m && continued) ? m - 1 - o : o;
+                rank += to > t ? 1 : 0;
+            }
+            X.ord[nxt][(int) X.tsum[bfirst[b]] + rank] = (uint16_t) node;
+        }
+        sync();
+        cur = nxt, m = E, ra = rb;
+        continued = false;
+    }
+    // node list and bucket heads of the final order
+    for (int b = lane(); b < nb; b += NL) X.bucket[b] = H_EMPTY;
+    sync();
+    for (int p = lane(); p < m; p += NL) {
+        const int node = X.ord[cur][p];
+        X.next[node]   = p + 1 < m ? (int) X.ord[cur][p + 1] : -1;
+        const int b    = X.ibkt[node];
+        if (p == 0)
+            X.bucket[b] = H_BEFORE_BEGIN;
+        else if ((int) X.ibkt[X.ord[cur][p - 1]] != b)
+            X.bucket[b] = (int) X.ord[cur][p - 1];
+    }
+    sync();
+    for (int k = lane(); k < n; k += NL) f.next[k] = X.next[k];
+    for (int b = lane(); b < nb; b += NL) f.bucket[b] = X.bucket[b];
+    f.head      = m > 0 ? (int) X.ord[cur][0] : -1;
+    f.n_buckets = nb;
+    f.magic     = modMagic((u64) nb);
+    sync();
+}
+// rows [n_old, f.n_rows) enter the container order: the sort for batches that are worth it (a new frame's rows, an extension across a
+// rehash of a full frame), the serial list surgery for the handful of rows a triangulation adds
+TC_FN void order_extend_auto(Frame &f, int n_old, const uint32_t *buckets_after, Scratch &X) {
+    const int n = f.n_rows;
+    if (n <= n_old) return;
+    const bool rehash = (int) buckets_after[n] != (n_old ? f.n_buckets : 1);
+    if (n - n_old >= 32 || (rehash && n_old >= 48))
+        order_extend_parallel(f, n_old, buckets_after, X);
+    else
+        order_extend(f, n_old, buckets_after, X);
+}
 // the sum of a parallax average: terms in the order the reference adds them, added one by one.  The terms (X.key as doubles) and their
 // validity (X.next) were filled in parallel into the wave's scratch: the sequential pass reads LDS, not HBM
 TC_FN double key_as_double(u64 v) {
@@ -1130,7 +1282,7 @@ TC_FN bool finish_track_mappoint(Stream &S, const Cfg &C, const Io &io, const ui
     S.n_tracked = kept;
     fc.n_rows   = kept;
     sync();
-    order_extend(fc, 0, buckets_after, X); // the ids of the previous frame's rows are distinct keys
+    order_extend_auto(fc, 0, buckets_after, X); // the ids of the previous frame's rows are distinct keys
     S.parallax_map_counts = parallax_from_reference_mappoints(S, C, S.parallax_map, X); // :450
     return true;
 }
@@ -1482,7 +1634,7 @@ TC_FN void finish_triangulation(Stream &S, const Cfg &C, const Io &io, const uin
         for (int u = 1; u < n_touched; u++) S.frame[touched[u]].n_rows = touched_old[u] + touched_cnt[u];
     }
     sync();
-    for (int u = 0; u < n_touched; u++) order_extend(S.frame[touched[u]], touched_old[u], buckets_after, X);
+    for (int u = 0; u < n_touched; u++) order_extend_auto(S.frame[touched[u]], touched_old[u], buckets_after, X);
     const int nst = S.n_tri_status;
     S.n_ref       = reduce_vector(S.pts2d_ref, S.n_ref, S.tri_status); // :788-793
     S.n_ref_frame = reduce_vector(S.pts2d_ref_frame, S.n_ref_frame, S.tri_status);
