@@ -32,6 +32,11 @@
 
 #include "icg_internal.h"
 #include "../host/track_core.h"
+#if defined(TC_TIMING)
+namespace tc {
+__device__ unsigned long long g_tc_marks[256];
+}
+#endif
 
 static_assert(sizeof(icg_tracker_config) == sizeof(tc::Cfg), "icg_tracker_config mirrors tc::Cfg");
 static_assert(offsetof(icg_tracker_config, track_min_parallax) == offsetof(tc::Cfg, track_min_parallax), "icg_tracker_config mirrors tc::Cfg");
@@ -91,7 +96,7 @@ __device__ void build_rois(const TrkArena &A, const tc::Cfg &C, int s) {
     const bool job   = A.det_slot[s] >= 0;
     det_roi *R       = A.rois + (size_t) s * nblk;
     const int32_t *q = A.det_quota + (size_t) s * tc::MAX_BLOCKS;
-    for (int k = 0; k < nblk; k++) {
+    for (int k = tc::lane(); k < nblk; k += tc::NL) { // a block per lane
         det_roi r;
         const int cols = k % C.block_cols, rows = k / C.block_cols;
         r.job   = s;
@@ -115,23 +120,38 @@ __device__ void build_rois(const TrkArena &A, const tc::Cfg &C, int s) {
 }
 
 // block-order assembly of the refined corners with the block origin added (tracking.cc:669-685; the tail of icg_detect)
+// A block per lane (block_cnts <= MAX_BLOCKS = 64 = the wave): where a block's corners start in the list is the number of corners the blocks
+// before it hand over — an exclusive prefix sum over the lanes —, cut at max_per_job as the one-by-one loop cuts it.
 __device__ void assemble_corners(const TrkArena &A, const tc::Cfg &C, int s) {
+    static_assert(tc::MAX_BLOCKS <= 64, "assemble_corners: a block per lane");
     int cnt = 0;
     if (A.det_slot[s] >= 0) {
         const int nblk = C.block_cnts, max_pb = C.max_block_features;
         float2 *out    = A.det_out + (size_t) s * tc::MAX_ROWS;
-        for (int k = 0; k < nblk; k++) {
-            const det_roi R = A.rois[(size_t) s * nblk + k];
-            if (R.quota <= 0) continue;
-            const int n = A.corner_cnt[(size_t) s * nblk + k];
-            for (int i = 0; i < n; i++) {
-                if (cnt >= C.max_per_job) break;
-                const float2 c = A.corners[((size_t) s * nblk + k) * max_pb + i];
-                out[cnt++]     = make_float2((float) R.rx + c.x, (float) R.ry + c.y);
-            }
+        const int k    = tc::lane();
+        det_roi R{};
+        int n = 0;
+        if (k < nblk) {
+            R = A.rois[(size_t) s * nblk + k];
+            n = R.quota > 0 ? A.corner_cnt[(size_t) s * nblk + k] : 0;
+            if (n < 0) n = 0;
         }
+        const int incl = (int) tc::wave_scan_incl((uint32_t) n);
+        int begin      = incl - n;
+        if (begin > C.max_per_job) begin = C.max_per_job;
+        int take = n;
+        if (begin + take > C.max_per_job) take = C.max_per_job - begin;
+        const float2 *src = A.corners + ((size_t) s * nblk + (k < nblk ? k : 0)) * max_pb;
+        for (int i = 0; i < max_pb; i++) // (every lane walks its own block: <= max_block_features steps for the wave)
+            if (i < take) {
+                const float2 c = src[i];
+                out[begin + i] = make_float2((float) R.rx + c.x, (float) R.ry + c.y);
+            }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        cnt             = total < C.max_per_job ? total : C.max_per_job;
     }
     A.det_count[s] = cnt;
+    tc::sync(); // (the stage body that follows reads the list: every lane, entries other lanes stored)
 }
 
 __device__ void begin_frame(int s, tc::Stream *streams, const TrkArena &A, const TrkInput *in) {
@@ -168,9 +188,11 @@ __global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, 
     const int s = blockIdx.x * TRK_WAVES + wave;
     if (s >= n) return; // all 64 lanes run the stage body (track_core.h "execution model"): redundantly where it is sequential
     tc::Stream &S = streams[s];
+    TC_MARK_START();
     if (stage == 0 || stage == 120) {
         begin_frame(s, streams, A, in);
         tc::sync();
+        TC_MARK(1);
         if (stage == 0) return;
         stage = 12;
     }
@@ -181,7 +203,7 @@ __global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, 
     if (active) {
         switch (stage) {
         case 1:
-            tc::stage_on_preprocess(S, C, io);
+            tc::stage_on_preprocess(S, C, io, X);
             build_rois(A, C, s);
             A.work[4 * s + 1] += A.det_slot[s] >= 0 ? 1 : 0;
             break;
@@ -191,7 +213,8 @@ __global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, 
             A.work[4 * s] = A.lk_count[s];
             break;
         case 12:
-            tc::stage_on_preprocess(S, C, io);
+            tc::stage_on_preprocess(S, C, io, X);
+            TC_MARK(10);
             if (!S.done && A.det_slot[s] >= 0) { // a detection was queued but this step runs without the detection-A launches
                 S.overflow |= tc::OVF_INTERNAL;
                 A.det_slot[s] = -1;
@@ -199,6 +222,7 @@ __global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, 
             }
             A.det_count[s] = 0;
             tc::stage_on_detect_a(S, C, io, X);
+            TC_MARK(13);
             A.work[4 * s] = A.lk_count[s];
             break;
         case 3:
@@ -207,16 +231,21 @@ __global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, 
             break;
         case 4:
             tc::stage_on_ransac(S, C, io, X);
+            TC_MARK(32);
             A.work[4 * s + 3] = A.tri_count[s];
             break;
         case 5:
             tc::stage_on_triangulate(S, C, io, buckets_after, X);
+            TC_MARK(46);
             build_rois(A, C, s);
+            TC_MARK(47);
             A.work[4 * s + 1] += A.det_slot[s] >= 0 ? 1 : 0;
             break;
         case 6:
             assemble_corners(A, C, s);
+            TC_MARK(50);
             tc::stage_on_detect_b(S, C, io);
+            TC_MARK(51);
             // the frame's tracking.txt line (TableTracker::endFrame writes it before the window keeper runs: same condition, same count)
             tc::sync();
             log_ok   = S.log_valid && S.result == tc::TRACK_TRACKING && S.mode == tc::M_TRACK && S.lost_reset != 2;
@@ -229,6 +258,7 @@ __global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, 
         build_rois(A, C, s); // (an idle stream's table entries must read "inactive")
     }
     tc::sync();
+    TC_MARK(100 + (stage > 9 ? 2 : stage));
     if (stage == 6) {
         icg_tracker_result r;
         r.active          = active ? 1 : 0;
@@ -247,6 +277,7 @@ __global__ __launch_bounds__(64 * TRK_WAVES) void k_trk_stage(int stage, int n, 
         r.log_valid = log_ok ? 1 : 0, r.log_features = log_rows;
         for (int k = 0; k < 5; k++) r.log_data[k] = S.log_data[k];
         results[s]      = r;
+        TC_MARK(59);
     }
 }
 
@@ -279,6 +310,15 @@ struct icg_tracker {
 
 extern "C" size_t icg_tracker_block_bytes(void) { return sizeof(tc::Stream); }
 
+#if defined(TC_TIMING)
+// profiling build: time between marks (10 ns ticks) summed over the streams since the library was loaded, printed when the process ends
+static void tc_timing_dump() {
+    unsigned long long h[256];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(tc::g_tc_marks), sizeof h) != hipSuccess) return;
+    for (int k = 0; k < 128; k++)
+        if (h[128 + k]) fprintf(stderr, "[tc timing] mark %3d hits %10llu total_us %12.1f us_per_hit %8.3f\n", k, h[128 + k], h[k] * 0.01, h[k] * 0.01 / h[128 + k]);
+}
+#endif
 extern "C" void icg_tracker_destroy(icg_tracker *t) {
     if (!t) return;
     if (t->ctx) {
@@ -299,6 +339,10 @@ extern "C" int icg_tracker_create(icg_ctx *ctx, int n_streams, const icg_tracker
                                   icg_tracker **out) {
     if (!ctx || !cfg || !buckets_after || !out || n_streams <= 0) return ICG_ERR_INVALID;
     *out = nullptr;
+#if defined(TC_TIMING)
+    static std::once_flag tc_once;
+    std::call_once(tc_once, [] { atexit(tc_timing_dump); });
+#endif
     if (!ctx->has_cam) return icg_fail(ctx, ICG_ERR_INVALID, "icg_tracker_create: camera not set (icg_set_camera)");
     if (n_buckets_after < tc::MAX_ROWS + 2) return icg_fail(ctx, ICG_ERR_INVALID, "buckets_after must cover %d insertions", tc::MAX_ROWS + 1);
     if ((int) buckets_after[tc::MAX_ROWS + 1] > tc::MAX_BUCKETS) return icg_fail(ctx, ICG_ERR_CAPACITY, "bucket table larger than the block's");

@@ -415,6 +415,16 @@ private:
 } // namespace
 
 extern "C" {
+// symmetricEigen (factors.h) on a caller's matrix: A is n x n row-major, evals (n) ascending, evecs (n x n row-major, eigenvector k in
+// column k).  A test hook: tests/test_host_backend_cpu.py pins the bit patterns of the restructured routine to those of the plain form.
+int icgh_symmetric_eigen(int n, const double *A, double *evals, double *evecs) {
+    if (n < 0 || (n > 0 && (!A || !evals || !evecs))) return -1;
+    std::vector<double> a(A, A + (size_t) n * n), ev, V;
+    symmetricEigen(n, a, ev, V);
+    if (n) memcpy(evals, ev.data(), sizeof(double) * (size_t) n), memcpy(evecs, V.data(), sizeof(double) * (size_t) n * n);
+    return 0;
+}
+
 
 // R1 through the ceres::CostFunction surface: factors + EvaluationCallback, one Evaluate() per factor.
 // rc: 0 ok, 1 = an unprepared factor did NOT fail (contract violation), <0 = error.

@@ -62,6 +62,33 @@ TC_FN uint32_t wave_scan_incl(uint32_t v) {
     }
     return v;
 }
+// the value another lane holds; `src` is the same in every lane (v_readlane: no LDS round trip)
+TC_FN int lane_get(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+TC_FN double lane_get(double v, int src) {
+    const u64 b = (u64) __double_as_longlong(v);
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) b, src), hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (b >> 32), src);
+    return __longlong_as_double((long long) (((u64) hi << 32) | lo));
+}
+TC_FN int first_lane(u64 m) { return __ffsll((unsigned long long) m) - 1; }
+#if defined(TC_TIMING)
+// profiling build only (csrc/Makefile EXTRA_HIPFLAGS=-DTC_TIMING, profiles/run_r05_call12.sh): wall-clock (100 MHz) time between marks,
+// summed over the streams by lane 0 — where a stage's latency chain spends its time.  The product build compiles the marks away.
+extern __device__ unsigned long long g_tc_marks[256];
+__shared__ unsigned long long tc_last_mark;
+TC_FN void tc_mark_start() {
+    if (lane() == 0) tc_last_mark = wall_clock64();
+}
+TC_FN void tc_mark(int id) {
+    const unsigned long long t = wall_clock64();
+    if (lane() == 0) {
+        atomicAdd(&g_tc_marks[id], t - tc_last_mark);
+        atomicAdd(&g_tc_marks[128 + id], 1ull);
+        tc_last_mark = t;
+    }
+}
+#define TC_MARK(id) tc::tc_mark(id)
+#define TC_MARK_START() tc::tc_mark_start()
+#endif
 #else
 constexpr int NL = 1;
 TC_FN int lane() { return 0; }
@@ -86,6 +113,14 @@ TC_FN int32_t lds_exch(int32_t *p, int32_t v) {
     return o;
 }
 TC_FN uint32_t wave_scan_incl(uint32_t v) { return v; }
+TC_FN int lane_get(int v, int) { return v; }
+TC_FN double lane_get(double v, int) { return v; }
+TC_FN int first_lane(u64 m) { return __builtin_ctzll(m); }
+#endif
+
+#ifndef TC_MARK
+#define TC_MARK(id) ((void) 0)
+#define TC_MARK_START() ((void) 0)
 #endif
 
 // ---- capacities ------------------------------------------------------------------------------------------------------------------
@@ -514,13 +549,35 @@ TC_FN int frame_alloc(Stream &S) {
     frame_clear_rows(f);
     return h;
 }
+// mp_release for the map points of a frame's unupdated list that the map does not hold (Frame::clearFeatures, frame.h:46-51), in list order:
+// a chunk of entries per step; what the one-by-one loop pushes onto the free list in sequence is a function of the entry's rank among the
+// released ones (the entries of one list are distinct map points)
+TC_FN void release_unupdated(Stream &S, const Frame &f) {
+    const int free0 = S.n_free_mps;
+    int n_rel       = 0;
+    for (int base = 0; base < f.n_unupd; base += NL) {
+        const int k = base + lane();
+        bool rel    = false;
+        uint32_t i  = 0;
+        if (k < f.n_unupd) {
+            i   = f.unupd[k];
+            rel = mp_valid(S, i, f.unupd_gen[k]) && !S.hot[i].in_map;
+        }
+        const u64 m = ballot(rel);
+        if (rel) {
+            S.hot[i].live = 0;
+            S.hot[i].gen++;
+            S.free_mps[free0 + n_rel + popc(m & lanes_below())] = i;
+        }
+        n_rel += popc(m);
+    }
+    S.n_free_mps = free0 + n_rel;
+    sync();
+}
 TC_FN void frame_free(Stream &S, int h) {
     Frame &f = S.frame[h];
     // a map point lives as long as the map or a frame's unupdated list holds it; this frame's list goes away with it
-    for (int k = 0; k < f.n_unupd; k++) {
-        const uint32_t i = f.unupd[k];
-        if (mp_valid(S, i, f.unupd_gen[k]) && !S.hot[i].in_map) mp_release(S, i);
-    }
+    release_unupdated(S, f);
     f.alive = 0;
     f.gen++;
     f.image = 0;
@@ -693,19 +750,45 @@ TC_FN void map_remove_keyframe(Stream &S, int h, bool isremovemappoint) { // map
             n_rm += popc(m);
         }
         sync();
-        for (int q = 0; q < n_rm; q++) {
-            const uint32_t i = (uint32_t) S.order_idx[q];
-            if (!S.hot[i].live || !S.hot[i].in_map) continue; // (a map point held by two rows of the frame cannot exist; kept as a guard)
-            S.hot[i].in_map  = 0;
-            S.hot[i].outlier = 1;
-            log_landmark(S, S.hot[i].id, i, 0);
-            S.n_landmarks--;
-            mp_release(S, i);
+        // ... released in that order, a chunk per step: the history entry and the free-list slot of a landmark are its rank among the released
+        // (the rows of one frame hold distinct map points)
+        const int log0 = S.n_log, free0 = S.n_free_mps;
+        int n_ok = 0;
+        for (int base = 0; base < n_rm; base += NL) {
+            const int q = base + lane();
+            bool ok     = false;
+            uint32_t i  = 0;
+            if (q < n_rm) {
+                i  = (uint32_t) S.order_idx[q];
+                ok = S.hot[i].live && S.hot[i].in_map;
+            }
+            const u64 m = ballot(ok);
+            if (ok) {
+                const int r      = n_ok + popc(m & lanes_below());
+                S.hot[i].in_map  = 0;
+                S.hot[i].outlier = 1;
+                if (log0 + r < LOG_CAP) { // log_landmark(S, id, i, 0)
+                    LmLog e;
+                    e.id = S.hot[i].id, e.mp = i, e.op = 0;
+                    S.log[log0 + r] = e;
+                }
+                S.hot[i].live = 0; // mp_release(S, i)
+                S.hot[i].gen++;
+                S.free_mps[free0 + r] = i;
+            }
+            n_ok += popc(m);
         }
-        for (int k = 0; k < f.n_unupd; k++) { // Frame::clearFeatures (frame.h:46-51)
-            const uint32_t i = f.unupd[k];
-            if (mp_valid(S, i, f.unupd_gen[k]) && !S.hot[i].in_map) mp_release(S, i);
+        if (log0 + n_ok > LOG_CAP) {
+            S.overflow |= OVF_LOG;
+            S.log_dropped += log0 + n_ok - LOG_CAP;
+            S.n_log = LOG_CAP;
+        } else {
+            S.n_log = log0 + n_ok;
         }
+        S.n_landmarks -= n_ok;
+        S.n_free_mps = free0 + n_ok;
+        sync();
+        release_unupdated(S, f); // Frame::clearFeatures (frame.h:46-51)
         frame_clear_rows(f);
     }
     const int at = map_find(S, f.kf_id);
@@ -765,6 +848,44 @@ struct D2 {
     double a, b;
 };
 TC_FN int reduce_vector2(double (*vec)[2], int n, const uint8_t *status) { return reduce_vector(reinterpret_cast<D2 *>(vec), n, status); }
+// Several lists compacted by ONE status vector (the reference calls reduceVector on each in turn, :507-511 / :550-554 / :788-793): a chunk's
+// status is read once, every list's element of the chunk is loaded before any is stored — one memory round trip per chunk instead of one per
+// chunk and list, one sync() instead of one per list.  Each list keeps its own length (k < n of that list, as its own call would).
+template <typename T> struct Compact {
+    T *vec;
+    int n, kept;
+    bool mine;
+    T v;
+    TC_FN void load(int k, bool keep) {
+        mine = keep && k < n;
+        v    = vec[mine ? k : 0];
+    }
+    TC_FN void store(int pos) {
+        if (mine) vec[pos] = v;
+        kept += popc(ballot(mine));
+    }
+};
+template <typename T> TC_FN Compact<T> compact(T *vec, int n) {
+    Compact<T> c;
+    c.vec = vec, c.n = n, c.kept = 0, c.mine = false;
+    return c;
+}
+TC_FN Compact<D2> compact2(double (*vec)[2], int n) { return compact(reinterpret_cast<D2 *>(vec), n); }
+template <typename... C> TC_FN void reduce_vectors(const uint8_t *status, C &...c) {
+    int nmax = 0;
+    ((nmax = c.n > nmax ? c.n : nmax), ...);
+    int index = 0;
+    for (int base = 0; base < nmax; base += NL) {
+        const int k     = base + lane();
+        const bool keep = k < nmax && status[k];
+        const u64 m     = ballot(keep);
+        const int pos   = index + popc(m & lanes_below());
+        (c.load(k, keep), ...);
+        (c.store(pos), ...);
+        index += popc(m);
+    }
+    sync();
+}
 template <typename T> TC_FN void copy_n(T *dst, const T *src, int n) {
     for (int k = lane(); k < n; k += NL) dst[k] = src[k];
     sync();
@@ -786,12 +907,42 @@ TC_FN double keypoint_parallax(const Cfg &C, const P2f &pp0, const P2f &pp1, con
     const double dx = a - x1, dy = b - y1;
     return tc_sqrt(dx * dx + dy * dy) * focalLength(C.cam);
 }
-// order_idx := the rows of f in container order.  The list is copied into the wave's scratch first (parallel), so the walk — a chain of
-// dependent reads by nature — runs through LDS
+// List ranking by pointer jumping: w[k] >> 16 := the number of nodes that follow node k in the list `next` (n nodes, successor -1 at the
+// tail).  A node's word holds (nodes skipped so far, the node reached) — one 32-bit word, so a reader always sees a consistent pair — and
+// every round lets each node adopt its target's pair: the spans double, ceil(log2 n) rounds of a node per lane instead of a walk of n
+// dependent reads.  (Updates in place: a target already updated in this round only makes the span longer.)
+static_assert(MAX_ROWS < 0xffff, "list_rank packs a node index into 16 bits");
+TC_FN void list_rank(uint32_t *w, const int32_t *next, int n) {
+    for (int k = lane(); k < n; k += NL) {
+        const int nx = next[k];
+        w[k]         = nx >= 0 ? (1u << 16) | (uint32_t) nx : 0xffffu;
+    }
+    sync();
+    for (int span = 1; span < n; span <<= 1) {
+        for (int k = lane(); k < n; k += NL) {
+            const uint32_t a = w[k], nx = a & 0xffffu;
+            if (nx != 0xffffu) {
+                const uint32_t b = w[nx];
+                w[k]             = (((a >> 16) + (b >> 16)) << 16) | (b & 0xffffu);
+            }
+        }
+        sync();
+    }
+}
+// order_idx := the rows of f in container order (every row of a frame is a node of its list)
 TC_FN int list_container_order(Stream &S, const Frame &f, Scratch &X) {
-    copy_n(X.next, f.next, f.n_rows);
-    int n = 0;
-    for (int q = f.head; q >= 0; q = X.next[q]) S.order_idx[n++] = q;
+    const int n = f.n_rows;
+    uint32_t *w = reinterpret_cast<uint32_t *>(X.lnk);
+    list_rank(w, f.next, n);
+    if (n > 0 && (f.head < 0 || (int) (w[f.head] >> 16) != n - 1)) { // (cannot happen: the list and the row count disagree) — the plain walk
+        S.overflow |= OVF_INTERNAL;
+        copy_n(X.next, f.next, n);
+        int m = 0;
+        for (int q = f.head; q >= 0 && m < MAX_ROWS; q = X.next[q]) S.order_idx[m++] = q;
+        sync();
+        return m;
+    }
+    for (int k = lane(); k < n; k += NL) S.order_idx[n - 1 - (int) (w[k] >> 16)] = k;
     sync();
     return n;
 }
@@ -903,16 +1054,29 @@ TC_FN void order_extend_parallel(Frame &f, int n_old, const uint32_t *buckets_af
     for (int k = n_old + 1 + lane(); k <= n; k += NL) X.want[k] = buckets_after[k];
     sync();
     int cur = 0, m = 0; // list order so far: X.ord[cur][0 .. m), head first
-    for (int q = n_old ? f.head : -1; q >= 0; q = X.next[q]) X.ord[cur][m++] = (uint16_t) q; // (all lanes: same values)
-    sync();
+    if (n_old) {       // the stored list as an array: a node's place is n_old - 1 - (nodes that follow it)
+        uint32_t *w = reinterpret_cast<uint32_t *>(X.lnk);
+        list_rank(w, X.next, n_old);
+        for (int k = lane(); k < n_old; k += NL) X.ord[cur][n_old - 1 - (int) (w[k] >> 16)] = (uint16_t) k;
+        m = n_old;
+        sync();
+    }
     bool continued = n_old > 0; // the stored list continues without a rehash (first phase only)
     int ra         = n_old;
     while (ra < n) {
         const int want = (int) X.want[ra + 1];
         if (want != nb) continued = false; // _M_rehash_aux before row ra enters: the existing nodes are re-entered head first
         nb = want;
-        int rb = ra + 1;
-        while (rb < n && (int) X.want[rb + 1] == nb) rb++; // rows [ra, rb) enter under nb
+        int rb = ra + 1; // rows [ra, rb) enter under nb: rb = the first row past ra that meets another bucket count (a chunk of rows per step)
+        for (;;) {
+            const int k   = rb + lane();
+            const u64 end = ballot(k >= n || (int) X.want[k + 1] != nb);
+            if (end) {
+                rb += first_lane(end);
+                break;
+            }
+            rb += NL;
+        }
         const u64 M = modMagic((u64) nb);
         const int E = m + (rb - ra); // events of the phase; event e < m: node ord[e]; else row ra + (e - m); time: see below
         uint32_t *bfirst = reinterpret_cast<uint32_t *>(X.tmp_bucket), *bcnt = reinterpret_cast<uint32_t *>(X.bucket);
@@ -1014,14 +1178,23 @@ TC_FN u64 double_as_key(double d) {
     memcpy(&v, &d, sizeof v);
     return v;
 }
+// the mean of the flagged terms, added one by one in list order as the reference does (:896-903, :915-920).  The order of the additions is the
+// result; what need not be serial is fetching the terms: a chunk is loaded a term per lane, then read lane by lane out of the registers.
 TC_FN int sum_parallax_terms(const Scratch &X, int n, double &parallax) {
     parallax   = 0;
     int counts = 0;
-    for (int k = 0; k < n; k++)
-        if (X.next[k]) {
-            parallax += key_as_double(X.key[k]);
-            counts++;
+    for (int base = 0; base < n; base += NL) {
+        const int k    = base + lane();
+        const bool on  = k < n && X.next[k] != 0;
+        const double v = on ? key_as_double(X.key[k]) : 0.0;
+        u64 m          = ballot(on);
+        counts += popc(m);
+        while (m) {
+            const int l = first_lane(m);
+            parallax += lane_get(v, l);
+            m &= m - 1;
         }
+    }
     if (counts != 0) parallax /= counts;
     return counts;
 }
@@ -1032,6 +1205,7 @@ TC_FN int parallax_from_reference_mappoints(Stream &S, const Cfg &C, double &par
     mat_mul_t(fc.pose.R, fr.pose.R, R10);
     const double focal = focalLength(C.cam);
     const int nq       = list_container_order(S, fr, X);
+    TC_MARK(26);
     for (int k = lane(); k < nq; k += NL) {
         const Row &r0    = fr.row[S.order_idx[k]];
         const uint32_t i = r0.mp;
@@ -1054,6 +1228,7 @@ TC_FN int parallax_from_reference_mappoints(Stream &S, const Cfg &C, double &par
         X.key[k]  = double_as_key(term);
     }
     sync();
+    TC_MARK(27);
     return sum_parallax_terms(X, nq, parallax);
 }
 TC_FN int parallax_from_reference_keypoints(Stream &S, const Cfg &C, const P2f *ref, const P2f *cur, double &parallax, Scratch &X) { // :907-922
@@ -1117,26 +1292,24 @@ TC_FN void finish(Stream &S, int st) {
 }
 
 // ---- featuresDetection (:576-688) ------------------------------------------------------------------------------------------------------
-TC_FN bool queue_detection(Stream &S, const Cfg &C, Io &io, int frame, bool ismask) {
+TC_FN bool queue_detection(Stream &S, const Cfg &C, Io &io, int frame, bool ismask, Scratch &X) {
     S.det_job        = -1;
     const Frame &f   = S.frame[frame];
     const int num_features = f.n_rows + S.n_ref; // :579
     if (num_features > (C.track_max_features - 5)) return false; // :580
-    int features_cnts[MAX_BLOCKS];
-    for (int k = 0; k < C.block_cnts; k++) features_cnts[k] = 0;
+    uint32_t *features_cnts = X.tsum; // (a histogram in the wave's scratch memory: a point per lane, one atomic add each)
+    for (int k = lane(); k < C.block_cnts; k += NL) features_cnts[k] = 0;
+    sync();
     const int total = f.n_rows + S.n_new;
-    for (int base = 0; base < total; base += NL) { // a chunk of points per step, a ballot per block
-        const int q = base + lane();
-        long idx    = -1;
-        if (q < total) {
-            const P2f p   = q < f.n_rows ? f.row[q].kp : S.pts2d_new[q - f.n_rows];
-            const int col = (int) (p.x / (float) C.block_w); // :598
-            const int row = (int) (p.y / (float) C.block_h);
-            // hazard H5 (unclamped column of an undistorted key point), reproduced as in tracking_hip.cc
-            idx = (long) row * C.block_cols + col;
-        }
-        for (int b = 0; b < C.block_cnts; b++) features_cnts[b] += popc(ballot(idx == (long) b));
+    for (int q = lane(); q < total; q += NL) {
+        const P2f p   = q < f.n_rows ? f.row[q].kp : S.pts2d_new[q - f.n_rows];
+        const int col = (int) (p.x / (float) C.block_w); // :598
+        const int row = (int) (p.y / (float) C.block_h);
+        // hazard H5 (unclamped column of an undistorted key point), reproduced as in tracking_hip.cc: the index may name another block or none
+        const long idx = (long) row * C.block_cols + col;
+        if (idx >= 0 && idx < (long) C.block_cnts) lds_add(&features_cnts[idx], 1u);
     }
+    sync();
     S.det_job     = 0;
     S.det_ismask  = ismask ? 1 : 0;
     S.det_frame   = frame;
@@ -1149,7 +1322,7 @@ TC_FN bool queue_detection(Stream &S, const Cfg &C, Io &io, int frame, bool isma
         for (int q = lane(); q < nm; q += NL) io.det_mask_pts[q] = q < fc.n_rows ? fc.row[q].kp : S.pts2d_new[q - fc.n_rows];
     }
     *io.det_mask_count = nm;
-    for (int k = lane(); k < C.block_cnts; k += NL) io.det_quota[k] = C.max_block_features - features_cnts[k]; // :629
+    for (int k = lane(); k < C.block_cnts; k += NL) io.det_quota[k] = C.max_block_features - (int) features_cnts[k]; // :629
     sync();
     return true;
 }
@@ -1187,6 +1360,7 @@ TC_FN void queue_track_mappoint(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     const Pose pose_cur = S.frame[S.cur].pose;
     const int cur_slot  = S.frame[S.cur].slot;
     const int nq    = list_container_order(S, fp, X);
+    TC_MARK(14);
     int n           = 0;
     for (int base = 0; base < nq; base += NL) { // rows in container order, a chunk per step; the valid ones are appended in that order
         const int k = base + lane();
@@ -1221,6 +1395,7 @@ TC_FN void queue_track_mappoint(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     S.lk_map_n     = n;
     *io.lk_count   = n;
     sync();
+    TC_MARK(15);
 }
 TC_FN bool finish_track_mappoint(Stream &S, const Cfg &C, const Io &io, const uint32_t *buckets_after, Scratch &X) {
     if (S.lk_map_n == 0) return false;
@@ -1238,6 +1413,7 @@ TC_FN bool finish_track_mappoint(Stream &S, const Cfg &C, const Io &io, const ui
         S.parallax_map_counts = 0;
         return false;
     }
+    TC_MARK(21);
     Frame &fc = S.frame[S.cur];
     frame_clear_rows(fc); // :426
     if (kept > MAX_ROWS) { // (cannot happen: n <= MAX_ROWS)
@@ -1282,8 +1458,11 @@ TC_FN bool finish_track_mappoint(Stream &S, const Cfg &C, const Io &io, const ui
     S.n_tracked = kept;
     fc.n_rows   = kept;
     sync();
+    TC_MARK(22);
     order_extend_auto(fc, 0, buckets_after, X); // the ids of the previous frame's rows are distinct keys
+    TC_MARK(23);
     S.parallax_map_counts = parallax_from_reference_mappoints(S, C, S.parallax_map, X); // :450
+    TC_MARK(24);
     return true;
 }
 
@@ -1334,16 +1513,22 @@ TC_FN bool mid_track_reference(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     }
     S.n_cur = n;
     sync();
+    TC_MARK(60);
     // reduceVector (:507-511): every list by the LK status
-    S.n_cand_lk      = reduce_vector(S.cand_lk_idx, n, S.status);
-    S.n_ref          = reduce_vector(S.pts2d_ref, S.n_ref, S.status);
-    S.n_cur          = reduce_vector(S.pts2d_cur, S.n_cur, S.status);
-    S.n_new          = reduce_vector(S.pts2d_new, S.n_new, S.status);
-    S.n_ref_frame    = reduce_vector(S.pts2d_ref_frame, S.n_ref_frame, S.status);
-    S.n_vel_ref      = reduce_vector2(S.velocity_ref, S.n_vel_ref, S.status);
-    const int n_a    = reduce_vector(S.scratch_a, n, S.status);
-    S.n_ref_undis    = reduce_vector(S.pts2d_ref_undis, S.n_ref_undis, S.status);
-    S.n_new_undis    = reduce_vector(S.pts2d_new_undis, S.n_new_undis, S.status);
+    auto c_lk = compact(S.cand_lk_idx, n);
+    auto c_ref = compact(S.pts2d_ref, S.n_ref);
+    auto c_cur = compact(S.pts2d_cur, S.n_cur);
+    auto c_new = compact(S.pts2d_new, S.n_new);
+    auto c_rf = compact(S.pts2d_ref_frame, S.n_ref_frame);
+    auto c_vr = compact2(S.velocity_ref, S.n_vel_ref);
+    auto c_a = compact(S.scratch_a, n);
+    auto c_ru = compact(S.pts2d_ref_undis, S.n_ref_undis);
+    auto c_nu = compact(S.pts2d_new_undis, S.n_new_undis);
+    reduce_vectors(S.status, c_lk, c_ref, c_cur, c_new, c_rf, c_vr, c_a, c_ru, c_nu);
+    S.n_cand_lk = c_lk.kept, S.n_ref = c_ref.kept, S.n_cur = c_cur.kept, S.n_new = c_new.kept, S.n_ref_frame = c_rf.kept, S.n_vel_ref = c_vr.kept;
+    const int n_a = c_a.kept;
+    S.n_ref_undis = c_ru.kept, S.n_new_undis = c_nu.kept;
+    TC_MARK(61);
     if (S.n_ref == 0) return false; // :513-517 (tr_cur_undis_ keeps what it held, as in the table)
     copy_n(S.tr_cur_undis, S.scratch_a, n_a);
     S.n_tr_cur_undis = n_a;
@@ -1364,7 +1549,9 @@ TC_FN bool mid_track_reference(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     }
     S.n_vel_cur = S.n_tr_cur_undis;
     sync();
+    TC_MARK(62);
     S.parallax_ref_counts = parallax_from_reference_keypoints(S, C, S.pts2d_ref_undis, S.tr_cur_undis, S.parallax_ref, X); // :542-544
+    TC_MARK(63);
 
     if (S.n_cur >= 15) { // :547-548
         S.rs_set = 0;
@@ -1384,14 +1571,17 @@ TC_FN bool finish_track_reference(Stream &S, const Io &io) {
         const int m         = S.n_tr_new_undis; // (the set's size)
         for (int k = lane(); k < m; k += NL) S.status[k] = mask[k];
         sync();
-        S.n_ref          = reduce_vector(S.pts2d_ref, S.n_ref, S.status);
-        S.n_cur          = reduce_vector(S.pts2d_cur, S.n_cur, S.status);
-        S.n_ref_frame    = reduce_vector(S.pts2d_ref_frame, S.n_ref_frame, S.status);
-        S.n_vel_cur      = reduce_vector2(S.velocity_cur, S.n_vel_cur, S.status);
-        S.n_vel_ref      = reduce_vector2(S.velocity_ref, S.n_vel_ref, S.status);
-        S.n_ref_undis    = reduce_vector(S.pts2d_ref_undis, S.n_ref_undis, S.status);
-        S.n_tr_cur_undis = reduce_vector(S.tr_cur_undis, S.n_tr_cur_undis, S.status);
-        S.n_cand_lk      = reduce_vector(S.cand_lk_idx, S.n_cand_lk, S.status);
+        auto c_ref = compact(S.pts2d_ref, S.n_ref);
+        auto c_cur = compact(S.pts2d_cur, S.n_cur);
+        auto c_rf = compact(S.pts2d_ref_frame, S.n_ref_frame);
+        auto c_vc = compact2(S.velocity_cur, S.n_vel_cur);
+        auto c_vr = compact2(S.velocity_ref, S.n_vel_ref);
+        auto c_ru = compact(S.pts2d_ref_undis, S.n_ref_undis);
+        auto c_cu = compact(S.tr_cur_undis, S.n_tr_cur_undis);
+        auto c_lk = compact(S.cand_lk_idx, S.n_cand_lk);
+        reduce_vectors(S.status, c_ref, c_cur, c_rf, c_vc, c_vr, c_ru, c_cu, c_lk);
+        S.n_ref = c_ref.kept, S.n_cur = c_cur.kept, S.n_ref_frame = c_rf.kept, S.n_vel_cur = c_vc.kept, S.n_vel_ref = c_vr.kept;
+        S.n_ref_undis = c_ru.kept, S.n_tr_cur_undis = c_cu.kept, S.n_cand_lk = c_lk.kept;
         S.rs_set         = -1;
     }
     if (S.n_cur == 0) return false; // :557-561
@@ -1439,6 +1629,7 @@ TC_FN bool queue_triangulation(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     sync();
     S.n_tri_index  = 0;
     S.tri_begin    = 0;
+    TC_MARK(33);
 
     int n_tcw = 0, n_tri = 0;
     const int T_cur = n_tcw;
@@ -1476,34 +1667,59 @@ TC_FN bool queue_triangulation(Stream &S, const Cfg &C, Io &io, Scratch &X) {
         X.next[k] = kind;
     }
     sync();
-    // pass 2 (in list order): camera matrices of the distinct reference frames, the triangulation list
+    TC_MARK(34);
+    // pass 2 (a chunk of candidates per step): camera matrices of the distinct reference frames in order of first appearance, the
+    // triangulation list by rank.  The one-by-one loop looks a reference frame up in a table of the first 8 distinct ones and enters it when
+    // absent: per chunk the lanes are served leader first — a frame in the table (or just entered) serves all its lanes at once, a frame the
+    // full table cannot take is handled lane by lane, as the loop would (a fresh camera matrix per occurrence)
     int T_frame[8], T_index[8], n_T = 0;
-    for (int k = 0; k < S.n_cur; k++) {
-        if (X.next[k] != 3) continue;
-        const int frame_ref = S.pts2d_ref_frame[k];
-        int T0 = -1;
-        for (int q = 0; q < n_T; q++)
-            if (T_frame[q] == frame_ref) T0 = T_index[q];
-        if (T0 < 0) {
-            if (n_tcw >= MAX_TCW) {
-                S.overflow |= OVF_TCW;
-                T0 = 0;
-            } else {
-                T0 = n_tcw;
-                pose2Tcw12(S.frame[frame_ref].pose, io.tri_Tcw + 12 * n_tcw);
-                n_tcw++;
+    for (int base = 0; base < S.n_cur; base += NL) {
+        const int k    = base + lane();
+        const bool tri = k < S.n_cur && X.next[k] == 3;
+        const int fr   = tri ? S.pts2d_ref_frame[k] : -1;
+        const u64 m3   = ballot(tri);
+        u64 todo       = m3;
+        int T0         = -1;
+        while (todo) {
+            const int leader = first_lane(todo);
+            const int h      = lane_get(fr, leader);
+            int t0 = -1;
+            for (int q = 0; q < n_T; q++)
+                if (T_frame[q] == h) t0 = T_index[q];
+            u64 grp = ballot(tri && fr == h) & todo;
+            if (t0 < 0) {
+                if (n_tcw >= MAX_TCW) {
+                    S.overflow |= OVF_TCW;
+                    t0 = 0;
+                } else {
+                    t0 = n_tcw;
+                    pose2Tcw12(S.frame[h].pose, io.tri_Tcw + 12 * n_tcw);
+                    n_tcw++;
+                }
+                if (n_T < 8) {
+                    T_frame[n_T] = h, T_index[n_T] = t0, n_T++;
+                } else {
+                    grp = 1ull << leader;
+                }
             }
-            if (n_T < 8) T_frame[n_T] = frame_ref, T_index[n_T] = T0, n_T++;
+            if ((grp >> lane()) & 1ull) T0 = t0;
+            todo &= ~grp;
         }
-        io.tri_T0[n_tri] = T0;
-        io.tri_T1[n_tri] = T_cur;
-        io.tri_pc0[3 * n_tri] = S.tri_tmp[k][0], io.tri_pc0[3 * n_tri + 1] = S.tri_tmp[k][1], io.tri_pc0[3 * n_tri + 2] = 1.0;
-        io.tri_pc1[3 * n_tri] = S.tri_tmp[k][2], io.tri_pc1[3 * n_tri + 1] = S.tri_tmp[k][3], io.tri_pc1[3 * n_tri + 2] = 1.0;
-        S.tri_point_index[S.n_tri_index++] = k;
-        n_tri++;
+        if (tri) {
+            const int at   = n_tri + popc(m3 & lanes_below());
+            io.tri_T0[at]  = T0;
+            io.tri_T1[at]  = T_cur;
+            io.tri_pc0[3 * at] = S.tri_tmp[k][0], io.tri_pc0[3 * at + 1] = S.tri_tmp[k][1], io.tri_pc0[3 * at + 2] = 1.0;
+            io.tri_pc1[3 * at] = S.tri_tmp[k][2], io.tri_pc1[3 * at + 1] = S.tri_tmp[k][3], io.tri_pc1[3 * at + 2] = 1.0;
+            S.tri_point_index[at] = k;
+        }
+        n_tri += popc(m3);
     }
+    S.n_tri_index = n_tri;
+    sync();
     *io.tri_count = n_tri;
     *io.tri_n_tcw = n_tcw;
+    TC_MARK(35);
     return true;
 }
 TC_FN void finish_triangulation(Stream &S, const Cfg &C, const Io &io, const uint32_t *buckets_after, Scratch &X) {
@@ -1527,6 +1743,7 @@ TC_FN void finish_triangulation(Stream &S, const Cfg &C, const Io &io, const uin
         X.bucket[q] = frame_ref;
     }
     sync();
+    TC_MARK(41);
     // the frames that receive rows: the current one and the distinct reference frames of the accepted points, in order of first appearance
     int touched[10], touched_old[10], touched_cnt[10], n_touched = 0;
     touched[0] = S.cur, touched_old[0] = S.frame[S.cur].n_rows, touched_cnt[0] = 0, n_touched = 1;
@@ -1623,6 +1840,7 @@ TC_FN void finish_triangulation(Stream &S, const Cfg &C, const Io &io, const uin
         acc_before += popc(m);
     }
     sync();
+    TC_MARK(42);
     if (!S.overflow) {
         const int total = acc_before;
         const int from_free = total < n_free0 ? total : n_free0;
@@ -1635,26 +1853,33 @@ TC_FN void finish_triangulation(Stream &S, const Cfg &C, const Io &io, const uin
     }
     sync();
     for (int u = 0; u < n_touched; u++) order_extend_auto(S.frame[touched[u]], touched_old[u], buckets_after, X);
+    TC_MARK(43);
     const int nst = S.n_tri_status;
-    S.n_ref       = reduce_vector(S.pts2d_ref, S.n_ref, S.tri_status); // :788-793
-    S.n_ref_frame = reduce_vector(S.pts2d_ref_frame, S.n_ref_frame, S.tri_status);
-    S.n_cur       = reduce_vector(S.pts2d_cur, S.n_cur, S.tri_status);
-    S.n_vel_ref   = reduce_vector2(S.velocity_ref, S.n_vel_ref, S.tri_status);
-    S.n_ref_undis = reduce_vector(S.pts2d_ref_undis, S.n_ref_undis, S.tri_status);
-    S.n_tr_cur_undis = reduce_vector(S.tr_cur_undis, S.n_tr_cur_undis, S.tri_status);
-    if (S.n_cand_lk == nst) S.n_cand_lk = reduce_vector(S.cand_lk_idx, S.n_cand_lk, S.tri_status);
+    const bool with_lk = S.n_cand_lk == nst;
+    auto c_ref = compact(S.pts2d_ref, S.n_ref);
+    auto c_rf = compact(S.pts2d_ref_frame, S.n_ref_frame);
+    auto c_cur = compact(S.pts2d_cur, S.n_cur); // :788-793
+    auto c_vr = compact2(S.velocity_ref, S.n_vel_ref);
+    auto c_ru = compact(S.pts2d_ref_undis, S.n_ref_undis);
+    auto c_cu = compact(S.tr_cur_undis, S.n_tr_cur_undis);
+
+    auto c_lk = compact(S.cand_lk_idx, with_lk ? S.n_cand_lk : 0);
+    reduce_vectors(S.tri_status, c_ref, c_rf, c_cur, c_vr, c_ru, c_cu, c_lk);
+    S.n_ref = c_ref.kept, S.n_ref_frame = c_rf.kept, S.n_cur = c_cur.kept, S.n_vel_ref = c_vr.kept, S.n_ref_undis = c_ru.kept, S.n_tr_cur_undis = c_cu.kept;
+    if (with_lk) S.n_cand_lk = c_lk.kept;
+    TC_MARK(44);
     copy_n(S.pts2d_new, S.pts2d_cur, S.n_cur);
     S.n_new = S.n_cur;
     copy_n(S.pts2d_new_undis, S.tr_cur_undis, S.n_tr_cur_undis);
     S.n_new_undis = S.n_tr_cur_undis;
 }
 
-TC_FN void make_new_frame_queue(Stream &S, const Cfg &C, Io &io, int state) { // :251-261
+TC_FN void make_new_frame_queue(Stream &S, const Cfg &C, Io &io, int state, Scratch &X) { // :251-261
     set_keyframe(S, S.cur, state);
     S.isnewkeyframe = 1;
     if ((state == KEYFRAME_NORMAL) || (state == KEYFRAME_REMOVE_OLDEST)) {
         S.ref = S.cur;
-        queue_detection(S, C, io, S.ref, true);
+        queue_detection(S, C, io, S.ref, true, X);
     }
 }
 
@@ -1689,7 +1914,7 @@ TC_FN void stage_begin_frame(Stream &S, Io &io, double stamp, const Pose &pose, 
     *io.tri_n_tcw      = 0;
 }
 // stage 1 (after preprocess) -> detection A
-TC_FN void stage_on_preprocess(Stream &S, const Cfg &C, Io &io) {
+TC_FN void stage_on_preprocess(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     if (S.done) return;
     if (C.check_histogram) { // :115-133
         const double hist = *io.pre_hist;
@@ -1719,11 +1944,11 @@ TC_FN void stage_on_preprocess(Stream &S, const Cfg &C, Io &io) {
             do_reset_tracking(S);
             S.ref  = S.cur;
             S.mode = M_FIRST;
-            queue_detection(S, C, io, S.ref, false);
+            queue_detection(S, C, io, S.ref, false, X);
             return;
         }
         S.mode = M_INIT;
-        if (S.n_ref == 0) queue_detection(S, C, io, S.ref, false); // :168-170
+        if (S.n_ref == 0) queue_detection(S, C, io, S.ref, false, X); // :168-170
     } else {
         S.mode = M_TRACK;
     }
@@ -1747,12 +1972,14 @@ TC_FN void stage_on_lk(Stream &S, const Cfg &C, Io &io, const uint32_t *buckets_
     if (S.done) return;
     if (S.mode == M_TRACK) finish_track_mappoint(S, C, io, buckets_after, X);
     S.ref_tracked = mid_track_reference(S, C, io, X) ? 1 : 0;
+    TC_MARK(25);
     *io.lk_count  = 0;
 }
 // stage 4 (after RANSAC) -> triangulation
 TC_FN void stage_on_ransac(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     if (S.done) return;
     if (S.ref_tracked) finish_track_reference(S, io);
+    TC_MARK(30);
     *io.rs_count = 0;
     if (S.mode == M_INIT) {
         if (S.parallax_ref < C.track_min_parallax) { // :175-178
@@ -1763,22 +1990,24 @@ TC_FN void stage_on_ransac(Stream &S, const Cfg &C, Io &io, Scratch &X) {
         return;
     }
     S.kf_state = check_keyframe_state(S, C); // :212
+    TC_MARK(31);
     if ((S.kf_state == KEYFRAME_NORMAL) || (S.kf_state == KEYFRAME_REMOVE_OLDEST)) queue_triangulation(S, C, io, X); // :215-217
 }
 // stage 5 (after triangulation) -> detection B
 TC_FN void stage_on_triangulate(Stream &S, const Cfg &C, Io &io, const uint32_t *buckets_after, Scratch &X) {
     if (S.done) return;
     if (S.tri_queued) finish_triangulation(S, C, io, buckets_after, X);
+    TC_MARK(45);
     *io.tri_count = 0;
     if (S.mode == M_INIT) {
         if (do_reset_tracking(S)) { // :184-190
             S.lost_reset = 1;
-            make_new_frame_queue(S, C, io, KEYFRAME_NORMAL);
+            make_new_frame_queue(S, C, io, KEYFRAME_NORMAL, X);
             return;
         }
         S.lost_reset = 0;
         set_keyframe(S, S.ref, KEYFRAME_NORMAL);         // :193
-        make_new_frame_queue(S, C, io, KEYFRAME_NORMAL); // :196
+        make_new_frame_queue(S, C, io, KEYFRAME_NORMAL, X); // :196
         S.last_keyframe  = S.cur;
         S.isinitializing = 0;
         return;
@@ -1787,14 +2016,14 @@ TC_FN void stage_on_triangulate(Stream &S, const Cfg &C, Io &io, const uint32_t 
     if (!S.frame[S.cur].n_rows) { // :224
         do_reset_tracking(S);
         S.lost_reset = 2;
-        make_new_frame_queue(S, C, io, KEYFRAME_NORMAL); // :225
+        make_new_frame_queue(S, C, io, KEYFRAME_NORMAL, X); // :225
         return;
     }
     if ((S.kf_state == KEYFRAME_NORMAL) || (S.kf_state == KEYFRAME_REMOVE_OLDEST)) {
-        make_new_frame_queue(S, C, io, S.kf_state); // :230-232
+        make_new_frame_queue(S, C, io, S.kf_state, X); // :230-232
     } else {
-        queue_detection(S, C, io, S.cur, true); // :220
-        if (S.kf_state != KEYFRAME_NONE) make_new_frame_queue(S, C, io, S.kf_state); // REMOVE_SECOND_NEW: flags only
+        queue_detection(S, C, io, S.cur, true, X); // :220
+        if (S.kf_state != KEYFRAME_NONE) make_new_frame_queue(S, C, io, S.kf_state, X); // REMOVE_SECOND_NEW: flags only
     }
 }
 // stage 6 (after detection B): the frame is done
@@ -1859,10 +2088,12 @@ TC_FN void stage_end_frame(Stream &S, const Cfg &C) {
             fnv(S.digest, &nref, sizeof nref);
         }
     }
+    TC_MARK(52);
     // WindowKeeper::onFrame (ic_gvins.cc:542, 743, 1391-1410, 445-448, 1675)
     const int frame = S.cur;
     if (st != TRACK_PASSED && frame >= 0 && (S.isnewkeyframe || st == TRACK_FIRST_FRAME || st == TRACK_LOST)) {
         map_insert_keyframe(S, C, frame);
+        TC_MARK(53);
         u64 ids[MAX_WINDOW];
         int n = S.n_map_kf;
         for (int k = 0; k < n; k++) ids[k] = S.map_kf_key[k];
@@ -1890,8 +2121,10 @@ TC_FN void stage_end_frame(Stream &S, const Cfg &C) {
                 if (S.map_kf_key[k] < S.map_kf_key[oldest]) oldest = k;
             map_remove_keyframe(S, S.map_kf_frame[oldest], true);
         }
+        TC_MARK(54);
     }
     sweep_frames(S);
+    TC_MARK(55);
 }
 
 // ---- a fresh stream --------------------------------------------------------------------------------------------------------------------

@@ -168,7 +168,7 @@ void TableTracker::coreAdvance(int stage, StageBatch &done, StageBatch &next) {
     switch (stage) {
     case 1:
         if (cfg_.track_check_histogram) arena_.pre_hist = done.pre_hist[(size_t) core_pre_job_];
-        tc::stage_on_preprocess(S, core_cfg_, io);
+        tc::stage_on_preprocess(S, core_cfg_, io, *core_scratch_);
         coreQueueOutputs(next, false, true, false, false, false);
         break;
     case 2:
