@@ -145,6 +145,11 @@ private:
     vector<double> residuals_;
 };
 
+// Destroys factor records off the calling thread: a window's ~1 100 records own ~8 heap blocks each (the reference's residual_block_info.h
+// layout: shared_ptrs and vectors), 0.17 of the 0.54 ms of one marginalization and 45 of the 90 ms of 256 batched ones when freed in line.
+// One process-wide thread takes them in the order given; a small batch, or a queue that has fallen behind, is destroyed by the caller.
+void reapFactorRecords(vector<std::shared_ptr<ResidualBlockInfo>> &&records);
+
 class MarginalizationInfo {
 public:
     MarginalizationInfo() = default;
@@ -196,7 +201,7 @@ private:
     bool finishStructured(StructuredPlan &plan, double min_hll);
     friend class MarginalizationBatch;
     void linearization();
-    void releaseMemory() { factors_.clear(); }
+    void releaseMemory(); // (:99) the factor records go — to the reaper thread when there are many (factors.cc reapFactorRecords)
     // the same, with the records handed to `bin` instead of destroyed here (MarginalizationBatch: ~1 100 records of ~8 heap blocks each per
     // window — 45 ms of free() for 256 windows on the calling thread — go to a reaper thread)
     void releaseMemoryInto(vector<std::shared_ptr<ResidualBlockInfo>> &bin) {

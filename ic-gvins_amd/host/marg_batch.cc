@@ -38,7 +38,6 @@ MarginalizationBatch::MarginalizationBatch(int device, double huber_delta, int h
 
 MarginalizationBatch::~MarginalizationBatch() {
     clear();
-    if (reaper_.valid()) reaper_.wait();
     if (dense_ctx_) icg_ctx_destroy(dense_ctx_);
     icg_ctx_destroy(ctx_);
 }
@@ -313,15 +312,13 @@ bool MarginalizationBatch::marginalize(std::vector<char> *ok) {
     });
     // (:99) the factor records of the windows that went through — the caller allocated them (one arena), so they are freed by ONE thread:
     // from the pool's threads the frees contend on that arena (600 ms instead of 28 ms for 256 C2 windows), on the calling thread they are
-    // 45 of the 90 ms of such a batch.  A reaper thread destroys them while the caller goes on (the records are shared_ptrs: whoever drops the
-    // last reference destroys; the previous batch's reaper is joined first).
+    // 45 of the 90 ms of such a batch.  The reaper thread (factors.h reapFactorRecords) destroys them while the caller goes on (the records are
+    // shared_ptrs: whoever drops the last reference destroys).
     {
         std::vector<std::shared_ptr<ResidualBlockInfo>> bin;
         for (size_t w = 0; w < NW; w++)
             if (good[w]) windows_[w]->info->releaseMemoryInto(bin);
-        if (reaper_.valid()) reaper_.wait();
-        if (bin.size() > 4096 && host_threads_ > 1)
-            reaper_ = std::async(std::launch::async, [b = std::move(bin)]() mutable { b.clear(); });
+        reapFactorRecords(std::move(bin));
     }
     auto t4 = now();
     for (size_t w = 0; w < NW; w++) {

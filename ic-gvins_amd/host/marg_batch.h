@@ -18,7 +18,6 @@
 // reference's dense M2 + M3 on its own (a one-window context created on first use) — the same rule MarginalizationInfo applies alone.
 // Results per window are those of MarginalizationInfo::marginalization() on a ReprojectionBatch of its own (tests: Hp, bp, J0, e0).
 #pragma once
-#include <future>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -95,7 +94,6 @@ private:
     double huber_{1.0};
     int host_threads_{1};
     std::unique_ptr<HostPool> pool_;
-    std::future<void> reaper_; // destroys the factor records of the last marginalize() off the calling thread (one at a time)
     std::vector<std::unique_ptr<Slice>> windows_;
     bool laid_out_{false};
     int n_factors_{0}, n_poses_{0}, n_lm_{0};

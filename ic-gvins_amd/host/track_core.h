@@ -70,6 +70,24 @@ TC_FN double lane_get(double v, int src) {
     return __longlong_as_double((long long) (((u64) hi << 32) | lo));
 }
 TC_FN int first_lane(u64 m) { return __ffsll((unsigned long long) m) - 1; }
+TC_FN u64 wave_min(u64 v) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        const u64 o = (u64) __shfl_xor((long long) v, m, 64);
+        v           = o < v ? o : v;
+    }
+    return v;
+}
+TC_FN u64 wave_max(u64 v) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        const u64 o = (u64) __shfl_xor((long long) v, m, 64);
+        v           = o > v ? o : v;
+    }
+    return v;
+}
+TC_FN uint32_t wave_or(uint32_t v) {
+    for (int m = 32; m >= 1; m >>= 1) v |= (uint32_t) __shfl_xor((int) v, m, 64);
+    return v;
+}
 #if defined(TC_TIMING)
 // profiling build only (csrc/Makefile EXTRA_HIPFLAGS=-DTC_TIMING, profiles/run_r05_call12.sh): wall-clock (100 MHz) time between marks,
 // summed over the streams by lane 0 — where a stage's latency chain spends its time.  The product build compiles the marks away.
@@ -116,8 +134,16 @@ TC_FN uint32_t wave_scan_incl(uint32_t v) { return v; }
 TC_FN int lane_get(int v, int) { return v; }
 TC_FN double lane_get(double v, int) { return v; }
 TC_FN int first_lane(u64 m) { return __builtin_ctzll(m); }
+TC_FN u64 wave_min(u64 v) { return v; }
+TC_FN u64 wave_max(u64 v) { return v; }
+TC_FN uint32_t wave_or(uint32_t v) { return v; }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TC_UNROLL _Pragma("unroll")
+#else
+#define TC_UNROLL
+#endif
 #ifndef TC_MARK
 #define TC_MARK(id) ((void) 0)
 #define TC_MARK_START() ((void) 0)
@@ -594,10 +620,22 @@ TC_FN void sweep_frames(Stream &S) {
     if (S.pending >= 0) mark |= 1u << S.pending;
     if (S.latest_keyframe >= 0) mark |= 1u << S.latest_keyframe;
     if (S.det_frame >= 0) mark |= 1u << S.det_frame;
-    for (int k = 0; k < S.n_map_kf; k++) mark |= 1u << S.map_kf_frame[k];
-    for (int k = 0; k < S.n_ref_frame; k++) mark |= 1u << S.pts2d_ref_frame[k];
-    for (int h = 0; h < S.n_frames; h++)
-        if (S.frame[h].alive && !((mark >> h) & 1u)) frame_free(S, h);
+    // the map's keyframes, the candidates' reference frames (a chunk of entries per step), then the live frames nobody marked
+    for (int base = 0; base < S.n_map_kf; base += NL) {
+        const int k = base + lane();
+        mark |= wave_or(k < S.n_map_kf ? 1u << S.map_kf_frame[k] : 0u);
+    }
+    for (int base = 0; base < S.n_ref_frame; base += NL) {
+        const int k = base + lane();
+        mark |= wave_or(k < S.n_ref_frame ? 1u << S.pts2d_ref_frame[k] : 0u);
+    }
+    uint32_t dead = 0;
+    for (int base = 0; base < S.n_frames; base += NL) {
+        const int h = base + lane();
+        dead |= wave_or((h < S.n_frames && S.frame[h].alive && !((mark >> h) & 1u)) ? 1u << h : 0u);
+    }
+    for (int h = 0; h < S.n_frames; h++) // (in handle order, as the one-by-one scan frees them)
+        if ((dead >> h) & 1u) frame_free(S, h);
 }
 static_assert(MAX_FRAMES <= 32, "sweep_frames marks frames in one 32-bit word");
 
@@ -681,10 +719,19 @@ TC_FN int map_find(const Stream &S, u64 key) {
     return -1;
 }
 TC_FN bool map_is_keyframe_in_map(const Stream &S, int h) { return map_find(S, S.frame[h].kf_id) >= 0; }
+// the same look-up by the whole wave (every lane calls it with the same key): an entry per lane, one memory round trip instead of one per entry
+TC_FN int map_find_wave(const Stream &S, u64 key) {
+    for (int base = 0; base < S.n_map_kf; base += NL) {
+        const int k = base + lane();
+        const u64 m = ballot(k < S.n_map_kf && S.map_kf_key[k] == key);
+        if (m) return base + first_lane(m);
+    }
+    return -1;
+}
 TC_FN void map_insert_keyframe(Stream &S, const Cfg &C, int h) { // map.cc:27-61
     S.latest_keyframe = h;
     Frame &f          = S.frame[h];
-    const int at      = map_find(S, f.kf_id);
+    const int at      = map_find_wave(S, f.kf_id);
     if (at < 0) {
         if (S.n_map_kf >= MAX_WINDOW) {
             S.overflow |= OVF_WINDOW;
@@ -791,13 +838,19 @@ TC_FN void map_remove_keyframe(Stream &S, int h, bool isremovemappoint) { // map
         release_unupdated(S, f); // Frame::clearFeatures (frame.h:46-51)
         frame_clear_rows(f);
     }
-    const int at = map_find(S, f.kf_id);
-    if (at >= 0) { // vector::erase: the later entries move down
-        for (int k = at; k + 1 < S.n_map_kf; k++) {
-            S.map_kf_key[k]   = S.map_kf_key[k + 1];
-            S.map_kf_frame[k] = S.map_kf_frame[k + 1];
+    const int at = map_find_wave(S, f.kf_id);
+    if (at >= 0) { // vector::erase: the later entries move down (a chunk of entries per step: loaded, then stored one place lower)
+        const int n = S.n_map_kf;
+        for (int base = at; base + 1 < n; base += NL) {
+            const int k    = base + lane();
+            const bool mv  = k + 1 < n;
+            const u64 key  = mv ? S.map_kf_key[k + 1] : 0;
+            const int fr   = mv ? S.map_kf_frame[k + 1] : 0;
+            sync(); // (every lane has read its successor before any lane overwrites it)
+            if (mv) S.map_kf_key[k] = key, S.map_kf_frame[k] = fr;
+            sync();
         }
-        S.n_map_kf--;
+        S.n_map_kf = n - 1;
     }
 }
 
@@ -816,16 +869,24 @@ TC_FN void assign_slot(Stream &S, int h) {
     S.pending_slot                = -1;
 }
 TC_FN void release_unused_slots(Stream &S) {
-    int keep = 0;
-    for (int k = 0; k < S.n_owned; k++) {
-        const int s = S.owned_slots[k];
-        const bool used = (S.cur >= 0 && S.frame[S.cur].slot == s) || (S.pre >= 0 && S.frame[S.pre].slot == s) || (S.ref >= 0 && S.frame[S.ref].slot == s);
+    // (the roles' slots are read once: the loop's stores cannot change them, but the compiler must assume they do and would re-read the
+    // handles and the frames — six dependent loads — for every owned slot)
+    const int cur = S.cur, pre = S.pre, ref = S.ref, n_owned = S.n_owned;
+    const int s_cur = cur >= 0 ? S.frame[cur].slot : -1, s_pre = pre >= 0 ? S.frame[pre].slot : -1, s_ref = ref >= 0 ? S.frame[ref].slot : -1;
+    int owned[MAX_SLOTS + 1];
+    for (int k = 0; k < MAX_SLOTS + 1; k++) owned[k] = k < n_owned ? S.owned_slots[k] : -1;
+    int keep = 0, n_free = S.n_free_slots;
+    for (int k = 0; k < MAX_SLOTS + 1; k++) {
+        if (k >= n_owned) break;
+        const int s     = owned[k];
+        const bool used = (cur >= 0 && s_cur == s) || (pre >= 0 && s_pre == s) || (ref >= 0 && s_ref == s);
         if (used)
             S.owned_slots[keep++] = s;
         else
-            slot_free(S, s);
+            S.free_slots[n_free++] = s; // slot_free(S, s)
     }
-    S.n_owned = keep;
+    S.n_free_slots = n_free;
+    S.n_owned      = keep;
 }
 
 // ---- helpers (tracking.cc:813-871) ------------------------------------------------------------------------------------------------------
@@ -1206,26 +1267,50 @@ TC_FN int parallax_from_reference_mappoints(Stream &S, const Cfg &C, double &par
     const double focal = focalLength(C.cam);
     const int nq       = list_container_order(S, fr, X);
     TC_MARK(26);
-    for (int k = lane(); k < nq; k += NL) {
-        const Row &r0    = fr.row[S.order_idx[k]];
-        const uint32_t i = r0.mp;
-        bool ok          = mp_valid(S, i, r0.mpgen) && !S.hot[i].outlier; // getMapPoint() && !isOutlier()
-        double term      = 0;
-        if (ok) {
-            const LastObs lo = S.hot[i].last;                       // observations().back().lock()
-            ok               = lo.frame == S.cur && lo.gen == fc.gen; // feat && feat->getFrame() == frame_cur_
-            if (ok) {
-                const Row &r1 = fc.row[lo.row];
-                ok            = !r1.outlier; // :884
-                if (ok) {
-                    const double x = R10[0] * r0.pcx + R10[1] * r0.pcy + R10[2] * 1.0, y = R10[3] * r0.pcx + R10[4] * r0.pcy + R10[5] * 1.0;
-                    const double dx = x - r1.pcx, dy = y - r1.pcy;
-                    term            = tc_sqrt(dx * dx + dy * dy) * focal;
-                }
-            }
+    // four chunks of rows at a time, level by level: order -> row of the reference frame -> its map point -> the row the map point was
+    // last seen in.  Each level's loads are issued for all four chunks before the first is used (one memory round trip per level, not per
+    // level and chunk); the values and the order of the arithmetic are those of the row-by-row form.
+    constexpr int U = 4;
+    const int cur       = S.cur;
+    const uint32_t cgen = fc.gen;
+    for (int base = 0; base < nq; base += U * NL) {
+        int kk[U], idx[U];
+        TC_UNROLL for (int u = 0; u < U; u++) {
+            kk[u]  = base + u * NL + lane();
+            idx[u] = kk[u] < nq ? S.order_idx[kk[u]] : -1;
         }
-        X.next[k] = ok ? 1 : 0; // (the copy of the node list in X.next has been consumed by list_container_order)
-        X.key[k]  = double_as_key(term);
+        uint32_t mp[U], mpgen[U];
+        double pcx[U], pcy[U];
+        TC_UNROLL for (int u = 0; u < U; u++) {
+            const Row &r0 = fr.row[idx[u] >= 0 ? idx[u] : 0];
+            mp[u] = r0.mp, mpgen[u] = r0.mpgen, pcx[u] = r0.pcx, pcy[u] = r0.pcy;
+        }
+        bool ok[U];
+        LastObs lo[U];
+        TC_UNROLL for (int u = 0; u < U; u++) {
+            const MpHot &h = S.hot[idx[u] >= 0 ? mp[u] : 0];
+            ok[u] = idx[u] >= 0 && h.live && h.gen == mpgen[u] && !h.outlier; // getMapPoint() && !isOutlier()
+            lo[u] = h.last;                                                     // observations().back().lock()
+            ok[u] = ok[u] && lo[u].frame == cur && lo[u].gen == cgen;         // feat && feat->getFrame() == frame_cur_
+        }
+        uint8_t out1[U];
+        double x1[U], y1[U];
+        TC_UNROLL for (int u = 0; u < U; u++) {
+            const Row &r1 = fc.row[ok[u] ? lo[u].row : 0];
+            out1[u] = r1.outlier, x1[u] = r1.pcx, y1[u] = r1.pcy;
+        }
+        TC_UNROLL for (int u = 0; u < U; u++) {
+            if (kk[u] >= nq) continue;
+            const bool good = ok[u] && !out1[u]; // :884
+            double term     = 0;
+            if (good) {
+                const double x = R10[0] * pcx[u] + R10[1] * pcy[u] + R10[2] * 1.0, y = R10[3] * pcx[u] + R10[4] * pcy[u] + R10[5] * 1.0;
+                const double dx = x - x1[u], dy = y - y1[u];
+                term            = tc_sqrt(dx * dx + dy * dy) * focal;
+            }
+            X.next[kk[u]] = good ? 1 : 0;
+            X.key[kk[u]]  = double_as_key(term);
+        }
     }
     sync();
     TC_MARK(27);
@@ -1362,33 +1447,46 @@ TC_FN void queue_track_mappoint(Stream &S, const Cfg &C, Io &io, Scratch &X) {
     const int nq    = list_container_order(S, fp, X);
     TC_MARK(14);
     int n           = 0;
-    for (int base = 0; base < nq; base += NL) { // rows in container order, a chunk per step; the valid ones are appended in that order
-        const int k = base + lane();
-        bool valid  = false;
-        Row r;
-        if (k < nq) {
-            r     = fp.row[S.order_idx[k]];
-            valid = mp_valid(S, r.mp, r.mpgen) && !S.hot[r.mp].outlier; // mappoint && !mappoint->isOutlier() (:360)
+    // rows in container order, four chunks at a time and level by level (order -> row -> its map point: a memory round trip per level, not per
+    // level and chunk); the valid ones are appended in that order
+    constexpr int U   = 4;
+    const int pslot   = fp.slot;
+    for (int base = 0; base < nq; base += U * NL) {
+        int kk[U], idx[U];
+        TC_UNROLL for (int u = 0; u < U; u++) {
+            kk[u]  = base + u * NL + lane();
+            idx[u] = kk[u] < nq ? S.order_idx[kk[u]] : -1;
         }
-        P2f pp;
-        pp.x = pp.y = 0;
-        if (valid) {
-            pp = world2pixel(C.cam, S.hot[r.mp].pos, pose_cur); // INS-aided prediction :367
-            distortPoint(C.cam, pp);                            // :378
+        Row r[U];
+        TC_UNROLL for (int u = 0; u < U; u++) r[u] = fp.row[idx[u] >= 0 ? idx[u] : 0];
+        bool valid[U];
+        double pos[U][3];
+        TC_UNROLL for (int u = 0; u < U; u++) {
+            const MpHot &h = S.hot[idx[u] >= 0 ? r[u].mp : 0];
+            valid[u] = idx[u] >= 0 && h.live && h.gen == r[u].mpgen && !h.outlier; // mappoint && !mappoint->isOutlier() (:360)
+            pos[u][0] = h.pos[0], pos[u][1] = h.pos[1], pos[u][2] = h.pos[2];
         }
-        const u64 m   = ballot(valid);
-        const int pos = n + popc(m & lanes_below());
-        if (valid) {
-            S.tm_pc[pos][0] = r.pcx, S.tm_pc[pos][1] = r.pcy;
-            io.lk_prev_slot[pos] = fp.slot;
-            io.lk_next_slot[pos] = cur_slot;
-            io.lk_prev[pos]      = r.kpd;
-            io.lk_guess[pos]     = pp;
-            MpRef mr;
-            mr.i = r.mp, mr.g = r.mpgen;
-            S.mappoint_matched[pos] = mr;
+        TC_UNROLL for (int u = 0; u < U; u++) {
+            P2f pp;
+            pp.x = pp.y = 0;
+            if (valid[u]) {
+                pp = world2pixel(C.cam, pos[u], pose_cur); // INS-aided prediction :367
+                distortPoint(C.cam, pp);                   // :378
+            }
+            const u64 m   = ballot(valid[u]);
+            const int at  = n + popc(m & lanes_below());
+            if (valid[u]) {
+                S.tm_pc[at][0] = r[u].pcx, S.tm_pc[at][1] = r[u].pcy;
+                io.lk_prev_slot[at] = pslot;
+                io.lk_next_slot[at] = cur_slot;
+                io.lk_prev[at]      = r[u].kpd;
+                io.lk_guess[at]     = pp;
+                MpRef mr;
+                mr.i = r[u].mp, mr.g = r[u].mpgen;
+                S.mappoint_matched[at] = mr;
+            }
+            n += popc(m);
         }
-        n += popc(m);
     }
     S.n_matched    = n;
     S.lk_map_begin = 0;
@@ -1423,37 +1521,62 @@ TC_FN bool finish_track_mappoint(Stream &S, const Cfg &C, const Io &io, const ui
     const double dt     = fc.stamp - S.frame[S.pre].stamp;
     const uint32_t cgen = fc.gen;
     int r0 = 0;
-    for (int base = 0; base < n; base += NL) { // reduceVector (:404-408) and the feature loop (:430-444): the rows of the kept points, in order
-        const int k     = base + lane();
-        const bool keep = k < n && status[k];
-        const u64 mm    = ballot(keep);
-        if (keep) {
-            const int row = r0 + popc(mm & lanes_below());
-            const MpRef m = S.mappoint_matched[k];
-            double pcx, pcy;
-            pixel2cam(C.cam, undis[k], pcx, pcy);
-            Row r;
-            r.id      = S.hot[m.i].id;
-            r.mp      = m.i;
-            r.mpgen   = S.hot[m.i].gen;
-            r.kp      = undis[k];
-            r.kpd     = out[k];
-            r.vel[0]  = (pcx - S.tm_pc[k][0]) / dt; // (pixel2cam(cur) - pixel2cam(pre)) / dt (:434)
-            r.vel[1]  = (pcy - S.tm_pc[k][1]) / dt;
-            r.pcx     = pcx;
-            r.pcy     = pcy;
-            r.lk_idx  = io.lk_base + S.lk_map_begin + k;
-            r.type    = (int8_t) FEATURE_MATCHED;
-            r.outlier = 0;
-            r.pad_[0] = r.pad_[1] = 0;
-            fc.row[row] = r;
-            S.hot[m.i].observed++; // addObservation (mappoint.cc:58-62); the matched map points are distinct
-            LastObs lo;
-            lo.frame = S.cur, lo.gen = cgen, lo.row = row;
-            S.hot[m.i].last          = lo;
-            S.tracked_mappoint[row] = m;
+    // reduceVector (:404-408) and the feature loop (:430-444): the rows of the kept points, in order — four chunks of points at a time, the
+    // LK results and the matched map points of all four loaded before the map points' records are (two memory round trips per four chunks)
+    constexpr int U = 4;
+    const int curh  = S.cur;
+    for (int base = 0; base < n; base += U * NL) {
+        int kk[U];
+        bool keep[U];
+        MpRef mref[U];
+        P2f und[U], o2[U];
+        double pc0[U][2];
+        TC_UNROLL for (int u = 0; u < U; u++) {
+            kk[u]        = base + u * NL + lane();
+            const int k  = kk[u] < n ? kk[u] : 0;
+            keep[u]      = kk[u] < n && status[k];
+            mref[u]      = S.mappoint_matched[k];
+            und[u]       = undis[k];
+            o2[u]        = out[k];
+            pc0[u][0] = S.tm_pc[k][0], pc0[u][1] = S.tm_pc[k][1];
         }
-        r0 += popc(mm);
+        u64 hid[U];
+        uint32_t hgen[U];
+        TC_UNROLL for (int u = 0; u < U; u++) {
+            const MpHot &h = S.hot[keep[u] ? mref[u].i : 0];
+            hid[u] = h.id, hgen[u] = h.gen;
+        }
+        TC_UNROLL for (int u = 0; u < U; u++) {
+            const u64 mm = ballot(keep[u]);
+            if (keep[u]) {
+                const int k   = kk[u];
+                const int row = r0 + popc(mm & lanes_below());
+                const MpRef m = mref[u];
+                double pcx, pcy;
+                pixel2cam(C.cam, und[u], pcx, pcy);
+                Row r;
+                r.id      = hid[u];
+                r.mp      = m.i;
+                r.mpgen   = hgen[u];
+                r.kp      = und[u];
+                r.kpd     = o2[u];
+                r.vel[0]  = (pcx - pc0[u][0]) / dt; // (pixel2cam(cur) - pixel2cam(pre)) / dt (:434)
+                r.vel[1]  = (pcy - pc0[u][1]) / dt;
+                r.pcx     = pcx;
+                r.pcy     = pcy;
+                r.lk_idx  = io.lk_base + S.lk_map_begin + k;
+                r.type    = (int8_t) FEATURE_MATCHED;
+                r.outlier = 0;
+                r.pad_[0] = r.pad_[1] = 0;
+                fc.row[row] = r;
+                S.hot[m.i].observed++; // addObservation (mappoint.cc:58-62); the matched map points are distinct
+                LastObs lo;
+                lo.frame = curh, lo.gen = cgen, lo.row = row;
+                S.hot[m.i].last          = lo;
+                S.tracked_mappoint[row] = m;
+            }
+            r0 += popc(mm);
+        }
     }
     S.n_tracked = kept;
     fc.n_rows   = kept;
@@ -2094,32 +2217,52 @@ TC_FN void stage_end_frame(Stream &S, const Cfg &C) {
     if (st != TRACK_PASSED && frame >= 0 && (S.isnewkeyframe || st == TRACK_FIRST_FRAME || st == TRACK_LOST)) {
         map_insert_keyframe(S, C, frame);
         TC_MARK(53);
-        u64 ids[MAX_WINDOW];
-        int n = S.n_map_kf;
-        for (int k = 0; k < n; k++) ids[k] = S.map_kf_key[k];
-        for (int a = 1; a < n; a++) { // insertion sort (<= 17 keys)
-            const u64 v = ids[a];
-            int b       = a - 1;
-            while (b >= 0 && ids[b] > v) ids[b + 1] = ids[b], b--;
-            ids[b + 1] = v;
-        }
-        for (int q = 0; q < n; q++) {
-            const u64 id = ids[q];
-            const int at = map_find(S, id);
-            if (at < 0) continue;
-            const int h = S.map_kf_frame[at];
-            Frame &f    = S.frame[h];
-            if ((f.kf_state == KEYFRAME_REMOVE_SECOND_NEW) || ((f.n_rows == 0) && (id != ids[n - 1]))) {
-                f.is_kf    = 0; // resetKeyFrame (frame.h:58-63); the keyframe id stays
-                f.kf_state = KEYFRAME_NONE;
-                map_remove_keyframe(S, h, false);
+        // (ic_gvins.cc:1391-1410 walks the keyframes in id order and drops those flagged REMOVE_SECOND_NEW and the empty ones except the newest;
+        // a decision reads its own frame and the newest id only, and erasing an entry keeps the order of the others: the walk's order is
+        // immaterial — an entry per lane)
+        {
+            const int n = S.n_map_kf;
+            u64 newest  = 0;
+            for (int base = 0; base < n; base += NL) {
+                const int k = base + lane();
+                const u64 v = wave_max(k < n ? S.map_kf_key[k] : 0);
+                newest      = v > newest ? v : newest;
             }
+            int kept = 0;
+            for (int base = 0; base < n; base += NL) {
+                const int k = base + lane();
+                bool keep = false, drop = false;
+                u64 id    = 0;
+                int h     = 0;
+                if (k < n) {
+                    id       = S.map_kf_key[k];
+                    h        = S.map_kf_frame[k];
+                    Frame &f = S.frame[h];
+                    drop     = (f.kf_state == KEYFRAME_REMOVE_SECOND_NEW) || ((f.n_rows == 0) && (id != newest));
+                    keep     = !drop;
+                    if (drop) {
+                        f.is_kf    = 0; // resetKeyFrame (frame.h:58-63); the keyframe id stays
+                        f.kf_state = KEYFRAME_NONE;
+                    }
+                }
+                const u64 m = ballot(keep);
+                sync(); // (the chunk is read before its entries move down: map_remove_keyframe(S, h, false) for each dropped one)
+                if (keep) S.map_kf_key[kept + popc(m & lanes_below())] = id, S.map_kf_frame[kept + popc(m & lanes_below())] = h;
+                kept += popc(m);
+                sync();
+            }
+            S.n_map_kf = kept;
         }
         while (S.n_map_kf > C.window_size) {
-            int oldest = 0;
-            for (int k = 1; k < S.n_map_kf; k++)
-                if (S.map_kf_key[k] < S.map_kf_key[oldest]) oldest = k;
-            map_remove_keyframe(S, S.map_kf_frame[oldest], true);
+            const int n = S.n_map_kf;
+            u64 oldest  = ~0ull;
+            for (int base = 0; base < n; base += NL) {
+                const int k = base + lane();
+                const u64 v = wave_min(k < n ? S.map_kf_key[k] : ~0ull);
+                oldest      = v < oldest ? v : oldest;
+            }
+            const int at = map_find_wave(S, oldest); // (keys are distinct; the one-by-one scan keeps the first minimum, the only one)
+            map_remove_keyframe(S, S.map_kf_frame[at], true);
         }
         TC_MARK(54);
     }
