@@ -748,7 +748,7 @@ int icg_tracker_step(icg_tracker *t, const uint8_t *const *images, int stride, i
                 work[1]++;
                 return ICG_OK;
             };
-            tc::stage_on_preprocess(S, C, io);
+            tc::stage_on_preprocess(S, C, io, t->scratch);
             if ((rc = detect())) return rc;
             tc::stage_on_detect_a(S, C, io, t->scratch);
             work[0] = a.lk_count;
