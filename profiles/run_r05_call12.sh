@@ -1,4 +1,5 @@
 #!/bin/bash
+# (profiling build: `make -C ic-gvins_amd/csrc timing` before the call)
 # Round 5, call 12: (a) the whole GPU suite on the tree with the restructured symmetricEigen (host) and the fused list compaction of the tracker
 # stages, (b) the driver's command, (c) where the tracker stages' latency chains spend their time: the profiling build of the library
 # (-DTC_TIMING: wall-clock marks inside the stage bodies, host/track_core.h) under a light bench.
