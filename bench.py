@@ -156,6 +156,10 @@ def csrc_sha1():
         if name.endswith((".hip", ".h")):
             h.update(name.encode())
             h.update(open(os.path.join(src, name), "rb").read())
+    core = os.path.join(ROOT, "ic-gvins_amd", "host", "track_core.h")  # (the stage bodies of k_trk_stage: compiled into tracker.hip)
+    if os.path.exists(core):
+        h.update(b"../host/track_core.h")
+        h.update(open(core, "rb").read())
     return h.hexdigest()
 
 
@@ -169,6 +173,8 @@ def kernel_source_files(kernels):
     for k in kernels:
         hit = [n for n, t in text.items() if ("void " + k + "(") in t]
         files.update(hit if hit else ["?" + k])
+    if "tracker.hip" in files:
+        files.add("../host/track_core.h")  # the tracker kernel's stage bodies (a summary without its record is stale for that kernel)
     return sorted(files)
 
 

@@ -46,6 +46,13 @@ def main(dirs):
             h.update(name.encode())
             h.update(data)
             per_file[name] = hashlib.sha1(data).hexdigest()
+    # (round 5) the tracker kernel's stage bodies live in the host layer's header, compiled into tracker.hip: part of that kernel's sources
+    core = os.path.join(root, "ic-gvins_amd", "host", "track_core.h")
+    if os.path.exists(core):
+        data = open(core, "rb").read()
+        h.update(b"../host/track_core.h")
+        h.update(data)
+        per_file["../host/track_core.h"] = hashlib.sha1(data).hexdigest()
     lk = out.get("k_lk_track_fb")
     pre = out.get("k_pyramid3")
     out["_meta"] = {"csrc_sha1": h.hexdigest(), "csrc_files": per_file, "streams_per_launch": os.environ.get("ICG_PMC_STREAMS_PER_LAUNCH"),
@@ -53,7 +60,7 @@ def main(dirs):
                     # segmented launches (device-resident tracker) size the grid by capacity: the points actually tracked per launch, from the
                     # bench line of the same configuration (roofline.units_per_launch)
                     "lk_active_points_per_launch": float(os.environ["ICG_PMC_LK_ACTIVE_POINTS"]) if os.environ.get("ICG_PMC_LK_ACTIVE_POINTS") else None,
-                    "note": "csrc_sha1 = sha1 over the names and contents of ic-gvins_amd/csrc/*.{hip,h} at collection time; csrc_files = the sha1 of each "
+                    "note": "csrc_sha1 = sha1 over the names and contents of ic-gvins_amd/csrc/*.{hip,h} and host/track_core.h at collection time; csrc_files = the sha1 of each "
                             "of them (bench.py accepts the summary for a kernel while the files that kernel is compiled from are unchanged)"}
     json.dump(out, sys.stdout, indent=1)
 
