@@ -10,7 +10,9 @@ table engine those work on TableTracker::view() and are absorbed back; after eve
 The engine pair defaults to table,object; round 4 adds table,core (the tracker core compiled for the host) and table,device (the
 device-resident tracker's host side on the CPU backend of icg_tracker_*: every map-writing operation goes through download / view / absorb /
 upload; ICG_TRACKER_LOG_DRAIN=30 makes the landmark-history drains frequent).
-Round 3: seeds 1 (24 scenarios) and 2 (24): no divergence.  Round 4: seed 31 (30 scenarios, table,device, ICG_TRACKER_LOG_DRAIN=30) and seed 32 (30, table,core): no divergence."""
+Round 3: seeds 1 (24 scenarios) and 2 (24): no divergence.  Round 4: seed 31 (30 scenarios, table,device, ICG_TRACKER_LOG_DRAIN=30) and seed 32 (30, table,core): no divergence.
+Round 5 (tracker core after the stages' latency diet: fused compaction, parallel releases / triangulation list / window keeper, list ranking): seed 51
+(30, table,device, ICG_TRACKER_LOG_DRAIN=30) and seed 52 (30, table,core): no divergence."""
 import ctypes as C
 import os
 import sys

@@ -7,7 +7,8 @@ tracking.txt rows).
 
     python tests/tools/soak_reference_tracker.py run <seed> <n_scenarios>
 
-Round 2: seeds 1 (12 scenarios), 2 (40) and 3 (40): no divergence.  Round 3 (track-table engine): seeds 11, 12 and 7 (40 each): no divergence."""
+Round 2: seeds 1 (12 scenarios), 2 (40) and 3 (40): no divergence.  Round 3 (track-table engine): seeds 11, 12 and 7 (40 each): no divergence.
+Round 5 (final tree): seed 53 with ICG_TRACK_ENGINE=core and seed 54 with ICG_TRACK_ENGINE=device (30 scenarios each): no divergence."""
 import os
 import subprocess
 import sys
