@@ -267,7 +267,12 @@ bool ResidualBlockInfo::Evaluate() {
 // its own order), and the element-wise loops are vectorised.
 // The element-wise inner loops of symmetricEigen: no reductions, so their vector forms do exactly the scalar arithmetic (no FMA in either
 // clone: "avx2" does not include it, and contraction is off).  The AVX2 clone is picked at load time where the CPU has it.
+// (Sanitizer builds — tests/tsan/run.sh — take the plain build: an instrumented ifunc resolver runs before the sanitizer's runtime is up.)
+#if defined(__SANITIZE_THREAD__) || defined(__SANITIZE_ADDRESS__)
+#define ICG_CLONES __attribute__((optimize("O3", "fp-contract=off")))
+#else
 #define ICG_CLONES __attribute__((target_clones("avx2", "default"), optimize("O3", "fp-contract=off")))
+#endif
 // Givens rotation of two rows (tql2 "accumulate"): element-wise, no reduction -> the vector form does the scalar form's arithmetic
 ICG_CLONES static void eig_rotate(double *__restrict vi, double *__restrict vi1, int n, double c, double s) {
     for (int k = 0; k < n; k++) {
