@@ -151,6 +151,10 @@ extern "C" void icg_ctx_destroy(icg_ctx *ctx) {
         if (ctx->d_lkc[b]) (void) hipFree(ctx->d_lkc[b]);
     if (ctx->d_redS) (void) hipFree(ctx->d_redS);
     if (ctx->d_hostS) (void) hipFree(ctx->d_hostS);
+    for (icg_partition *pt : {&ctx->part_1, &ctx->part_w}) {
+        if (pt->plan.d_buf) (void) hipFree(pt->plan.d_buf);
+        if (pt->plan.d_part) (void) hipFree(pt->plan.d_part);
+    }
 
     if (ctx->h_arena) (void) hipHostFree(ctx->h_arena);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);

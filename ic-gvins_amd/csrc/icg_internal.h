@@ -27,6 +27,37 @@ struct icg_prof_rec {
     double total_ms = 0;
 };
 
+// Deterministic assembly plan of a partition of the resident reprojection factors (reproj.hip).  The order in which every sum of the
+// normal equations is formed is a function of the window's own factor list only — not of launch geometry, batch composition or timing:
+//   runs    factors of a window grouped by their ordered (reference pose, observer pose) pair, list order kept inside a run; every run
+//           is reduced by one wave into the 20 x 20 block [Ji Jj Je Jtd -r]^T [Ji Jj Je Jtd -r] (k_asm_runs);
+//   lrec    factors of a window grouped by landmark, list order kept; the landmark rows (G_l, h_ll, b_l) are gathered from them.
+struct icg_asm_plan {
+    int n_runs = 0, Kmax = 1;
+    std::vector<int32_t> run_off;   // W+1: window w owns runs [run_off[w], run_off[w+1])
+    std::vector<int32_t> pose_off;  // W+1 into pose_glob
+    std::vector<int32_t> pose_glob; // local pose number -> global pose index (ascending inside a window)
+    char *d_buf = nullptr;          // one allocation for the five index arrays below
+    size_t buf_cap = 0;
+    int32_t *d_perm = nullptr;      // n: factor indices, run-major
+    int32_t *d_runs = nullptr;      // n_runs x 4: first (into d_perm), count, local_i | local_j << 16, window
+    int32_t *d_run_off = nullptr;   // W+1
+    int32_t *d_pair_run = nullptr;  // W x Kmax^2: run of the ordered local pose pair, -1 = none
+    int32_t *d_lrec = nullptr;      // n x 4: factor, local_i, local_j, 0 — landmark-major
+    int32_t *d_lm_foff = nullptr;   // n_lm+1: landmark l owns d_lrec[lm_foff[l] .. lm_foff[l+1])
+    double *d_part = nullptr;       // n_runs x 220: the runs' blocks (upper-triangular 2 x 2 tiles)
+    size_t part_cap = 0;            // doubles
+};
+struct icg_partition {
+    int W = 0;
+    bool plan_valid = false;
+    std::vector<int32_t> fac_off, lm_off; // W+1 each
+    std::vector<int64_t> sys_off;         // W+1: start of window w's (H | b | inv) block inside d_sys, in doubles
+    std::vector<double> damp;             // damping that went into each window's inv
+    int sys_P = 0, sys_valid = 0;
+    icg_asm_plan plan;
+};
+
 struct icg_ctx {
     icg_ctx_config cfg{};
     hipStream_t stream = nullptr;
@@ -73,20 +104,18 @@ struct icg_ctx {
     size_t params_cap = 0;
     int last_n_poses = 0, last_n_lm = 0;
     double last_huber = 0.0;
-    // f1: resident normal equations of the visual factors ((P+L)^2 matrix, rhs, 1/(h_ll + damping) per landmark)
+    std::vector<int32_t> h_fidx; // host copy of d_fidx (3 x n): the assembly plans below are derived from it
+    // f1: resident normal equations of the visual factors.  One window: H ((P+L)^2) | b | 1/(h_ll + damping) per landmark; a partition of
+    // the factors into W windows (icg_reproj_set_windows) keeps one such block per window.  part_1 is the implicit partition "all resident
+    // factors are one window" behind the single-window entry points — both run through the SAME kernels, so a window's sums are formed in
+    // the same order alone and inside a batch.  d_sys holds the systems of whichever partition was assembled last.
     double *d_sys = nullptr;
     size_t sys_cap = 0; // doubles
-    int sys_P = 0, sys_L = 0, sys_valid = 0;
-    double sys_damp = 0.0, sys_min_diag = 0.0, sys_max_diag = 0.0;
-    // f1, many windows per launch: partition of the resident factors / landmarks (icg_reproj_set_windows)
-    int n_windows = 0;
-    std::vector<int32_t> w_fac_off, w_lm_off; // W+1 each
-    std::vector<int32_t> w_pose_win;          // window of every pose index used by the resident factors
-    std::vector<int64_t> w_sys_off;           // W+1: start of window w's (H | b | inv) block inside d_sys, in doubles
-    int32_t *d_fwin = nullptr;                // window of every factor (factors_cap)
-    int32_t *d_lmwin = nullptr;               // window of every landmark
-    int lmwin_cap = 0, wsys_P = 0, wsys_valid = 0;
-    std::vector<double> w_damp;               // damping that went into each window's inv
+    double sys_min_diag = 0.0, sys_max_diag = 0.0;
+    icg_partition part_1, part_w;
+    int32_t *d_fwin = nullptr;  // window of every factor (factors_cap), icg_reproj_eval_windows
+    int32_t *d_lmwin = nullptr; // window of every landmark
+    int lmwin_cap = 0;
     // f1, reduced systems solved on the device (icg_reproj_schur_windows_resident / _set_host_part_windows / _solve_backsub_windows):
     double *d_redS = nullptr;  // W x P x P, lower tiles written by k_schur_reduce_w
     size_t redS_cap = 0;       // doubles

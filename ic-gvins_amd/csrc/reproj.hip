@@ -7,6 +7,7 @@
 // doubles of each factor transposed through LDS (row stride 49 to spread banks) so a 64-factor wave writes its
 // r[64x2] and J[64x46] slabs as contiguous 16-B-per-lane stores.
 // Algorithmic bytes per factor with Jacobians: 120 (obs) + 12 (indices) + 384 (out) = 516 B.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -243,10 +244,13 @@ extern "C" int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa
     if (rc) return rc;
     ctx->n_factors_resident = n;
     ctx->rJ_valid           = 0;
-    ctx->sys_valid          = 0;
-    ctx->n_windows          = 0;
-    ctx->wsys_valid         = 0;
+    // a new factor set: the partitions, their assembly plans and resident systems belong to the old one
+    for (icg_partition *pt : {&ctx->part_1, &ctx->part_w}) pt->W = 0, pt->plan_valid = false, pt->sys_valid = 0;
+    ctx->h_fidx.resize(3 * (size_t) n);
     if (n == 0) return ICG_OK;
+    memcpy(ctx->h_fidx.data(), idx_i, sizeof(int32_t) * (size_t) n);
+    memcpy(ctx->h_fidx.data() + n, idx_j, sizeof(int32_t) * (size_t) n);
+    memcpy(ctx->h_fidx.data() + 2 * (size_t) n, idx_lm, sizeof(int32_t) * (size_t) n);
     // component-major obs is already the device layout; indices packed as 3 x n
     ICG_HIP(ctx, hipMemcpyAsync(ctx->d_obs, obs_soa, sizeof(double) * 15 * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
     ICG_HIP(ctx, hipMemcpyAsync(ctx->d_fidx, idx_i, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
@@ -347,632 +351,297 @@ extern "C" int icg_reproj_eval_batch(icg_ctx *ctx, int n, const double *obs_soa,
     return icg_reproj_eval_resident(ctx, n_poses, poses, ext, n_lm, invdepth, td, want_jac, huber_delta, out_r, out_J);
 }
 
-// ---- M2: MarginalizationInfo::constructEquation for the resident reprojection factors -------------------------------
-// Reference: factors/marginalization_info.h:195-230 — H0 += Ji^T Jj over all block pairs of a factor, b0 -= Ji^T e.
-// One lane per factor.  Entries that every factor of the launch shares (extrinsic x extrinsic, extrinsic x td, td x td
-// and their b0 rows) are first reduced in LDS with ds_add_f64 and flushed with ONE global atomic per entry and
-// workgroup; pose / landmark blocks go straight to hardware FP64 atomics (addresses differ between factors).
-// Summation order is not fixed -> results equal the sequential sum to ~1e-15 relative (tolerance-tested, not bit-tested).
-#define NRM_BLOCK 256
+// ---- M2 / f1: the normal equations of the resident reprojection factors, assembled in a fixed order ------------------------------------
+// Reference: factors/marginalization_info.h:195-230 (constructEquation: H0 += Ji^T Jj over the block pairs of a factor, b0 -= Ji^T e) and
+// the DENSE_SCHUR step of GVINS::gvinsOptimization (ic_gvins.cc:1130-1239, 1763-1837): the inverse-depth blocks (1 x 1) go first.
+//
+// System of one window, N = P + L:   H = [Hcc G^T; G diag(h_ll)]  (row-major N x N: Hcc in rows/columns < P, landmark l in row P + l —
+// only its P camera columns and its diagonal element are ever written or read),  b (N),  inv (L) = 1 / (h_ll + d_l).
+//
+// No atomics anywhere: rounds 1-5 scattered every J^T J product with FP64 atomicAdd (LDS + global), which made every sum depend on the
+// arrival order — results equal to rounding only, the lock-step tests could not ask for identical bits, and same-address LDS atomics were
+// the cost of the launch (0.8-1.1 ms for 256 windows of 2 700 factors).  Now every output cell is owned by one thread that adds its
+// contributions in an order fixed by the window's own factor list (icg_asm_plan):
+//   k_asm_runs       one wave per run = the factors of one ordered (reference pose i, observer pose j) pair.  All of them send their
+//                    19 camera columns [Ji | Jj | Je | Jtd] (+ the residual as a 20th column: b = -J^T r) to the SAME cells, so the wave
+//                    keeps the 20 x 20 product A^T A (A = the run's 2 rows per factor) in registers — lane t owns one 2 x 2 tile of the 55 in
+//                    the upper triangle — and walks the run in list order, 16 factors staged in LDS at a time (operands are LDS broadcasts:
+//                    4 ds_read_b128 + 8 v_fma_f64 per factor and lane).  Output: 220 doubles per run, one coalesced 32-B store per lane.
+//   k_asm_camera     one thread per cell of Hcc (and of bc): gathers the cell from the runs that touch it — (i,j) and (j,i) for a cell
+//                    between two poses, row and column p of the pair table for a cell of pose p's diagonal block or against the shared
+//                    extrinsic / td block, every run for the (ext|td)^2 block — and stores it.  Cells nobody touches are stored as zero:
+//                    no memset of the system (the old path cleared 1 MB per window per launch).
+//   k_asm_landmarks  one thread per (landmark, camera column | h_ll | b_l): walks the landmark's factors in list order.
+// Algorithmic traffic per launch: J and r once per kernel that needs them (2 x 384 B per factor), 1.76 KB per run out and in, the system
+// rows once.  Bound: HBM/L2 streaming of J; the FP64 FMAs (420 per factor) are 2 % of the vector peak.
+#define ASM_SUB 16   // factors staged per pass
+#define ASM_ROW 40   // doubles per staged factor: two rows of 20 columns [Ji 0..5 | Jj 6..11 | Je 12..17 | Jtd 18 | -r 19]
+#define ASM_PART 220 // doubles per run: 55 upper-triangular 2 x 2 tiles of the 20 x 20 product
+#define ASM_EXT 0xFFF // owner code of the shared (extrinsic | td) pseudo-block: columns 12..18 of a factor's row
+
+struct win_desc {
+    int32_t fac_begin, fac_end, lm_begin, L;
+    int64_t sys_off;
+    int32_t K, reassemble; // K: poses used by the window's factors (local numbering of the plan)
+    double damp;
+};
 
 // gfx950 has 160 KiB of LDS per CU and one workgroup may own all of it (MI355X_MICROARCH.md, "LDS"); a launch with more dynamic LDS than the
-// 64 KiB default needs the function attribute.  The camera-block tiles of the assembly kernels and the batched Cholesky are sized by the
-// window (97 free columns for the 15-keyframe windows of BASELINE configs[3] = 76 KB), so their launches go through this.
-static constexpr size_t RPJ_LDS_LIMIT = 160 * 1024 - 256; // (- the kernels' few static words)
+// 64 KiB default needs the function attribute.  Only the batched Cholesky below (P^2 + P doubles per window) asks for that; the limit comes
+// from the device the context runs on, so a build for a part with less LDS reports ICG_ERR_CAPACITY instead of failing at launch.
+static size_t rpj_lds_limit(icg_ctx *ctx) {
+    static std::atomic<int> per_dev[16];
+    const int dev = ctx->cfg.device & 15;
+    int v         = per_dev[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int optin = 0;
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->cfg.device) != hipSuccess || optin <= 0) optin = 64 * 1024;
+        v = optin;
+        per_dev[dev].store(v, std::memory_order_relaxed);
+    }
+    return (size_t) v - 256; // (- the kernels' few static words)
+}
 template <typename K> static int rpj_allow_lds(icg_ctx *ctx, K kernel, size_t bytes, int slot) {
     static std::atomic<size_t> granted[4][16];
     if (bytes <= 48 * 1024) return 0;
     const int dev = ctx->cfg.device & 15;
     if (granted[slot][dev].load(std::memory_order_relaxed) >= bytes) return 0;
-    ICG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) RPJ_LDS_LIMIT));
-    granted[slot][dev].store(RPJ_LDS_LIMIT, std::memory_order_relaxed);
+    const size_t lim = rpj_lds_limit(ctx);
+    ICG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lim));
+    granted[slot][dev].store(lim, std::memory_order_relaxed);
     return 0;
 }
 
-__global__ __launch_bounds__(NRM_BLOCK) void k_reproj_normal(int n, const double *r, const double *J, const int32_t *idx_i,
-                                                             const int32_t *idx_j, const int32_t *idx_lm,
-                                                             const int32_t *col_pose, int col_ext, const int32_t *col_lm,
-                                                             int col_td, int L, double *H, double *b, const uint8_t *active,
-                                                             int lm_base) {
-    __shared__ double sh[7 * 7 + 7]; // shared (ext|td) x (ext|td) block and its b rows
-    const int t = threadIdx.x;
-    for (int e = t; e < 56; e += NRM_BLOCK) sh[e] = 0.0;
-    __syncthreads();
-    const int f = blockIdx.x * NRM_BLOCK + t;
-    if (f < n && (!active || active[f])) {
+// index of (la, lb) inside a run's block: tile (la/2, lb/2) of the upper triangle, element (la&1, lb&1); the diagonal tiles hold both halves
+__device__ __forceinline__ int asm_part_index(int la, int lb) {
+    int ba = la >> 1, bb = lb >> 1;
+    if (ba > bb) {
+        const int t = la;
+        la = lb, lb = t;
+        ba = la >> 1, bb = lb >> 1;
+    }
+    return (ba * 10 - ((ba * (ba - 1)) >> 1) + (bb - ba)) * 4 + ((la & 1) << 1) + (lb & 1);
+}
+
+__global__ __launch_bounds__(256) void k_asm_runs(int n_runs, const int4 *runs, const win_desc *wd, const int32_t *perm, const double *r,
+                                                 const double *J, const uint8_t *active, double *part) {
+    __shared__ double tiles[4][ASM_SUB * ASM_ROW];
+    const int wave = threadIdx.x >> 6, t = threadIdx.x & 63;
+    const int ri   = blockIdx.x * 4 + wave;
+    if (ri >= n_runs) return;
+    const int4 R = runs[ri]; // first, count, li | lj << 16, window
+    if (!wd[R.w].reassemble) return;
+    double *tile = tiles[wave];
+    // this lane's tile of the upper triangle (lanes 55..63 idle along on tile 0 and store nothing)
+    int bx = 0, rem = t < 55 ? t : 0, len = 10;
+    while (rem >= len) rem -= len, bx++, len--;
+    const int by = bx + rem;
+    // staging role: lane -> factor t / 4 of the pass, elements (t & 3) + 4 k of its 48 values (J 0..45, r 46..47)
+    const int fi = t >> 2, sub = t & 3;
+    double v[12];
+    auto fetch = [&](int pass) {
+        const int k = pass * ASM_SUB + fi;
+        bool on     = k < R.y;
+        int f       = 0;
+        if (on) {
+            f = perm[R.x + k];
+            if (active && !active[f]) on = false;
+        }
         const double *Jf = J + 46 * (size_t) f;
-        const double r0 = r[2 * (size_t) f], r1 = r[2 * (size_t) f + 1];
-        // col_lm == nullptr: landmark l sits at column lm_base + l (the Schur layout of icg_reproj_schur)
-        const int col[5] = {col_pose[idx_i[f]], col_pose[idx_j[f]], col_ext, col_lm ? col_lm[idx_lm[f]] : lm_base + idx_lm[f], col_td};
-        const int sz[5]  = {6, 6, 6, 1, 1};
-        const int off[5] = {0, 14, 28, 42, 44};
-        const int ld[5]  = {7, 7, 7, 1, 1};
-        const int shoff[5] = {-1, -1, 0, -1, 6}; // position of the block inside the shared 7-vector
 #pragma unroll
-        for (int a = 0; a < 5; a++) {
-            if (col[a] < 0) continue;
+        for (int kk = 0; kk < 11; kk++) v[kk] = on ? Jf[sub + 4 * kk] : 0.0;
+        v[11] = on ? (sub < 2 ? Jf[44 + sub] : -r[2 * (size_t) f + (sub - 2)]) : 0.0;
+    };
+    const int npass = (R.y + ASM_SUB - 1) / ASM_SUB;
+    double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+    fetch(0);
+    for (int pass = 0; pass < npass; pass++) {
+        // registers -> LDS in the padded two-row layout (the 7th, always-zero column of every 2 x 7 block and the landmark column are dropped)
 #pragma unroll
-            for (int bb = 0; bb < 5; bb++) {
-                if (col[bb] < 0) continue;
-                const bool shared_pair = shoff[a] >= 0 && shoff[bb] >= 0;
-                for (int x = 0; x < sz[a]; x++)
-                    for (int y = 0; y < sz[bb]; y++) {
-                        double v = Jf[off[a] + x] * Jf[off[bb] + y] + Jf[off[a] + ld[a] + x] * Jf[off[bb] + ld[bb] + y];
-                        if (shared_pair)
-                            atomicAdd(&sh[(shoff[a] + x) * 7 + shoff[bb] + y], v);
-                        else
-                            unsafeAtomicAdd(&H[(size_t) (col[a] + x) * L + col[bb] + y], v);
-                    }
-            }
-            for (int x = 0; x < sz[a]; x++) {
-                double v = -(Jf[off[a] + x] * r0 + Jf[off[a] + ld[a] + x] * r1);
-                if (shoff[a] >= 0)
-                    atomicAdd(&sh[49 + shoff[a] + x], v);
-                else
-                    unsafeAtomicAdd(&b[col[a] + x], v);
+        for (int kk = 0; kk < 12; kk++) {
+            const int c = sub + 4 * kk;
+            if (c < 42) {
+                const int q = c / 7, x = c - 7 * q;
+                if (x < 6) tile[fi * ASM_ROW + (q & 1) * 20 + (q >> 1) * 6 + x] = v[kk];
+            } else if (c >= 44) {
+                tile[fi * ASM_ROW + (c & 1) * 20 + 18 + ((c - 44) >> 1)] = v[kk];
             }
         }
-    }
-    __syncthreads();
-    // flush the shared block
-    for (int e = t; e < 56; e += NRM_BLOCK) {
-        double v = sh[e];
-        if (v == 0.0) continue;
-        if (e < 49) {
-            int x = e / 7, y = e - x * 7;
-            int cx = x < 6 ? col_ext + x : col_td, cy = y < 6 ? col_ext + y : col_td;
-            if ((x < 6 ? col_ext : col_td) >= 0 && (y < 6 ? col_ext : col_td) >= 0) unsafeAtomicAdd(&H[(size_t) cx * L + cy], v);
-        } else {
-            int x = e - 49;
-            int cx = x < 6 ? col_ext + x : col_td;
-            if ((x < 6 ? col_ext : col_td) >= 0) unsafeAtomicAdd(&b[cx], v);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (pass + 1 < npass) fetch(pass + 1); // in flight while this pass is multiplied
+#pragma unroll
+        for (int g = 0; g < ASM_SUB; g++) {
+            const double2 x0 = *reinterpret_cast<const double2 *>(&tile[g * ASM_ROW + 2 * bx]);
+            const double2 x1 = *reinterpret_cast<const double2 *>(&tile[g * ASM_ROW + 20 + 2 * bx]);
+            const double2 y0 = *reinterpret_cast<const double2 *>(&tile[g * ASM_ROW + 2 * by]);
+            const double2 y1 = *reinterpret_cast<const double2 *>(&tile[g * ASM_ROW + 20 + 2 * by]);
+            a00 = fma(x1.x, y1.x, fma(x0.x, y0.x, a00));
+            a01 = fma(x1.x, y1.y, fma(x0.x, y0.y, a01));
+            a10 = fma(x1.y, y1.x, fma(x0.y, y0.x, a10));
+            a11 = fma(x1.y, y1.y, fma(x0.y, y0.y, a11));
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (t < 55) {
+        double *dst = part + (size_t) ri * ASM_PART + 4 * t;
+        *reinterpret_cast<double2 *>(dst)     = make_double2(a00, a01);
+        *reinterpret_cast<double2 *>(dst + 2) = make_double2(a10, a11);
     }
 }
 
-extern "C" int icg_reproj_accumulate_normal(icg_ctx *ctx, int local_size, const int32_t *col_pose, int32_t col_ext,
-                                            const int32_t *col_lm, int32_t col_td, double *H0, double *b0) {
-    if (!ctx || local_size <= 0 || !col_pose || !col_lm || !H0 || !b0) return ICG_ERR_INVALID;
-    if (!ctx->rJ_valid || !ctx->rJ_has_jac) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Jacobians: call icg_reproj_eval_* with want_jac first");
-    const int n = ctx->n_factors_resident;
-    if (n == 0) return ICG_OK;
-    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    const size_t L = (size_t) local_size;
-    icg_call c(ctx);
-    int rc = c.reserve(sizeof(int32_t) * ((size_t) ctx->last_n_poses + ctx->last_n_lm) + sizeof(double) * (L * L + L) * 2 + 4096);
-    if (rc) return rc;
-    const int32_t *d_cp = c.in(col_pose, (size_t) ctx->last_n_poses);
-    const int32_t *d_cl = c.in(col_lm, (size_t) ctx->last_n_lm);
-    if ((rc = c.seal())) return rc;
-    std::vector<double> hH(L * L), hb(L);
-    double *d_H = c.out(hH.data(), L * L);
-    double *d_b = c.out(hb.data(), L);
-    ICG_HIP(ctx, hipMemsetAsync(d_H, 0, sizeof(double) * L * L, ctx->stream));
-    ICG_HIP(ctx, hipMemsetAsync(d_b, 0, sizeof(double) * L, ctx->stream));
-    ICG_LAUNCH_GUARD(c);
-    {
-        icg_prof_scope ps(ctx, "reproj_normal");
-        hipLaunchKernelGGL(k_reproj_normal, dim3((n + NRM_BLOCK - 1) / NRM_BLOCK), dim3(NRM_BLOCK), 0, ctx->stream, n,
-                           (const double *) ctx->d_rJ, (const double *) (ctx->d_rJ + 2 * (size_t) ctx->factors_cap),
-                           (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n),
-                           (const int32_t *) (ctx->d_fidx + 2 * (size_t) n), d_cp, (int) col_ext, d_cl, (int) col_td, local_size, d_H, d_b,
-                           (const uint8_t *) nullptr, 0);
-    }
-    ICG_HIP(ctx, hipGetLastError());
-    if ((rc = c.finish())) return rc;
-    for (size_t i = 0; i < L * L; i++) H0[i] += hH[i];
-    for (size_t i = 0; i < L; i++) b0[i] += hb[i];
-    return ICG_OK;
-}
-
-
-// ---- f1 (SURVEY.md §8 "next" row): device-side Schur complement of the visual factors ----------------------------------------
-// The Gauss-Newton / Levenberg-Marquardt step of GVINS::gvinsOptimization (ic_gvins.cc:1130-1239, Ceres DENSE_SCHUR) eliminates
-// the inverse-depth blocks (1x1 each) first.  With the robust-corrected r/J of the last icg_reproj_eval_resident call still
-// resident, k_reproj_normal assembles  H = [Hcc G^T; G diag(h_ll)], b = -J^T r  in the column layout (camera columns 0..P-1,
-// landmark l at P+l), and the kernels below reduce it:   S = Hcc - G^T diag(1/(h_ll + d_l)) G,   s = bc - G^T (b_l/(h_ll+d_l)),
-// d_l = clamp(h_ll, min_diag, max_diag) * damp  (the LM diagonal of the eliminated block).  G, h_ll, b_l stay resident for the
-// back-substitution  delta_l = (b_l - G_l . delta_c) / (h_ll + d_l).
-// Sizes: P <= ~160 (10 poses x 6 + extrinsic 6 + td 1 [+ anything the host adds]), L = 300..500: a (P+L)^2 FP64 system of
-// 1.7-3.4 MB that never leaves the device; only S (P x P), s and the diagonal cross PCIe per iteration.
-#define SCH_T 16
-
-__global__ void k_schur_inv(int P, int L, int N, const double *H, double damp, double min_diag, double max_diag, double *inv) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= L) return;
-    const double h = H[(size_t) (P + l) * N + P + l];
-    // a landmark without any active factor has an empty row: it is left where it is (delta_l = 0)
-    inv[l] = h > 0.0 ? 1.0 / (h + fmin(fmax(h, min_diag), max_diag) * damp) : 0.0;
-}
-
-__global__ __launch_bounds__(SCH_T *SCH_T) void k_schur_reduce(int P, int L, int N, const double *H, const double *b, const double *inv,
-                                                               double *S, double *s, double *diag) {
-    __shared__ double gi[SCH_T][SCH_T + 1], gj[SCH_T][SCH_T + 1], w[SCH_T];
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int i = blockIdx.y * SCH_T + ty, j = blockIdx.x * SCH_T + tx;
-    double acc = 0.0, accs = 0.0;
-    for (int l0 = 0; l0 < L; l0 += SCH_T) {
-        // rows l0..l0+15 of G, the 16 columns of this tile's i range and j range (coalesced along the row)
-        const int l = l0 + ty;
-        const int ci = blockIdx.y * SCH_T + tx;
-        gi[ty][tx] = (l < L && ci < P) ? H[(size_t) (P + l) * N + ci] : 0.0;
-        gj[ty][tx] = (l < L && j < P) ? H[(size_t) (P + l) * N + j] : 0.0;
-        if (ty == 0) w[tx] = (l0 + tx < L) ? inv[l0 + tx] : 0.0;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < SCH_T; k++) {
-            acc += gi[k][ty] * w[k] * gj[k][tx];
-            if (blockIdx.x == 0 && tx == 0) accs += gi[k][ty] * w[k] * ((l0 + k < L) ? b[P + l0 + k] : 0.0);
-        }
-        __syncthreads();
-    }
-    if (i < P && j < P) S[(size_t) i * P + j] = H[(size_t) i * N + j] - acc;
-    if (blockIdx.x == 0 && tx == 0 && i < P) {
-        s[i]    = b[i] - accs;
-        diag[i] = H[(size_t) i * N + i];
-    }
-}
-
-// one wave per landmark: delta_l = (b_l - G_l . delta_c) * inv_l
-// terms (2 doubles, pre-zeroed): sum b_l^2 / (h_ll + d_l) and sum d_l delta_l^2 — the landmark part of the LM model decrease
-// 0.5 (delta^T b + delta^T D delta): with the reduced right-hand side s, delta^T b = delta_c^T s + terms[0], so the step-quality
-// ratio can be formed without moving G or b_l to the host
-__global__ __launch_bounds__(64) void k_schur_backsub(int P, int L, int N, const double *H, const double *b, const double *inv,
-                                                      const double *delta_c, double *delta_l, double *terms, double damp, double min_diag,
-                                                      double max_diag) {
-    const int l = blockIdx.x;
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < P; i += 64) acc += H[(size_t) (P + l) * N + i] * delta_c[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (threadIdx.x == 0) {
-        const double bl = b[P + l], w = inv[l];
-        const double d  = (bl - acc) * w;
-        delta_l[l]      = d;
-        if (w > 0.0) {
-            const double dl = fmin(fmax(H[(size_t) (P + l) * N + P + l], min_diag), max_diag) * damp; // the damping that went into inv
-            unsafeAtomicAdd(&terms[0], bl * bl * w);
-            unsafeAtomicAdd(&terms[1], dl * d * d);
-        }
-    }
-}
-
-// 0.5 * sum rho(|r|^2) of the active factors from the resident (possibly Huber-corrected) residuals: the corrector leaves
-// |r_c|^2 = rho'(s) s, i.e. s for inliers and a sqrt(s) > a^2 for outliers, so rho(s) = 2 a sqrt(s) - a^2 = 2 |r_c|^2 - a^2
-__global__ __launch_bounds__(256) void k_reproj_cost(int n, const double *r, const uint8_t *active, double huber, double *out) {
-    __shared__ double sh[4];
-    double acc = 0.0;
-    for (int f = blockIdx.x * 256 + threadIdx.x; f < n; f += gridDim.x * 256) {
-        if (active && !active[f]) continue;
-        const double r0 = r[2 * (size_t) f], r1 = r[2 * (size_t) f + 1];
-        double q = r0 * r0 + r1 * r1;
-        if (huber > 0.0 && q > huber * huber) q = 2.0 * q - huber * huber;
-        acc += 0.5 * q;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
-}
-
-// Assembly for the Schur layout with the camera-camera block privatised in LDS.  k_reproj_normal sends every J^T J entry to a
-// global FP64 atomic; in a sliding window ~270 factors share each pose block and ALL factors share the extrinsic/td block, so
-// those atomics serialise in L2 (measured: ~0.9 ms for 2 651 factors).  Here each workgroup accumulates its 256 factors into an
-// LDS copy of the compact camera system (V = 6 x poses + 7 columns touched by visual factors, V^2 doubles), the fully shared
-// (ext|td)^2 block is first reduced across the wave with shuffles, and one pass of global atomics per workgroup flushes the tile.
-// Landmark rows (G_l, h_ll, b_l: 21 values per factor, <= ~10 factors per landmark) go straight to global atomics.
-__global__ __launch_bounds__(NRM_BLOCK) void k_reproj_normal_schur(int n, const double *r, const double *J, const int32_t *idx_i,
-                                                                   const int32_t *idx_j, const int32_t *idx_lm, const int32_t *vcol_pose,
-                                                                   int vcol_ext, int vcol_td, const int32_t *vmap, int V, int P, int N,
-                                                                   double *H, double *b, const uint8_t *active) {
-    extern __shared__ double sm[]; // Hs[V*V] | bs[V]
-    double *Hs = sm, *bs = sm + (size_t) V * V;
-    const int t = threadIdx.x;
-    for (int e = t; e < V * V + V; e += NRM_BLOCK) sm[e] = 0.0;
-    __syncthreads();
-    const int f   = blockIdx.x * NRM_BLOCK + t;
-    const bool on = f < n && (!active || active[f]);
-    // the factor's 19 camera columns: pose_i (6), pose_j (6), ext (6), td (1); compact column or -1
-    double j0[19], j1[19];
-    int cc[19];
-    double r0 = 0.0, r1 = 0.0, jl0 = 0.0, jl1 = 0.0;
-    int lm = 0;
-    if (on) {
-        const double *Jf = J + 46 * (size_t) f;
-        r0 = r[2 * (size_t) f], r1 = r[2 * (size_t) f + 1];
-        const int ci = vcol_pose[idx_i[f]], cj = vcol_pose[idx_j[f]];
-#pragma unroll
-        for (int x = 0; x < 6; x++) {
-            j0[x] = Jf[x], j1[x] = Jf[7 + x], cc[x] = ci < 0 ? -1 : ci + x;
-            j0[6 + x] = Jf[14 + x], j1[6 + x] = Jf[21 + x], cc[6 + x] = cj < 0 ? -1 : cj + x;
-            j0[12 + x] = Jf[28 + x], j1[12 + x] = Jf[35 + x], cc[12 + x] = vcol_ext < 0 ? -1 : vcol_ext + x;
-        }
-        j0[18] = Jf[44], j1[18] = Jf[45], cc[18] = vcol_td;
-        jl0 = Jf[42], jl1 = Jf[43];
-        lm  = idx_lm[f];
-    } else {
-#pragma unroll
-        for (int x = 0; x < 19; x++) j0[x] = j1[x] = 0.0, cc[x] = -1;
-    }
-    // pose rows against all 19 columns, and the shared rows against the pose columns: LDS atomics
-#pragma unroll
-    for (int x = 0; x < 19; x++) {
-        if (cc[x] < 0) continue;
-#pragma unroll
-        for (int y = 0; y < 19; y++) {
-            if (x >= 12 && y >= 12) continue; // (ext|td)^2: wave-reduced below
-            if (cc[y] < 0) continue;
-            atomicAdd(&Hs[cc[x] * V + cc[y]], j0[x] * j0[y] + j1[x] * j1[y]);
-        }
-        if (x < 12) atomicAdd(&bs[cc[x]], -(j0[x] * r0 + j1[x] * r1));
-    }
-    // shared block: every active lane contributes to the same 49 + 7 addresses -> butterfly over the wave, lane 0 adds
-#pragma unroll
-    for (int x = 12; x < 19; x++) {
-#pragma unroll
-        for (int y = 12; y < 20; y++) { // y == 19: the right-hand side entry
-            double v = (y < 19) ? j0[x] * j0[y] + j1[x] * j1[y] : -(j0[x] * r0 + j1[x] * r1);
-            if (!on) v = 0.0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if ((t & 63) == 0) {
-                const int cx = (x < 18) ? (vcol_ext < 0 ? -1 : vcol_ext + x - 12) : vcol_td;
-                const int cy = (y < 18) ? (vcol_ext < 0 ? -1 : vcol_ext + y - 12) : (y == 18 ? vcol_td : 0);
-                if (cx >= 0 && cy >= 0 && v != 0.0) {
-                    if (y < 19)
-                        atomicAdd(&Hs[cx * V + cy], v);
-                    else
-                        atomicAdd(&bs[cx], v);
-                }
-            }
-        }
-    }
-    // landmark row: G_l (camera columns), h_ll, b_l
-    if (on) {
-        double *row = H + (size_t) (P + lm) * N;
-#pragma unroll
-        for (int x = 0; x < 19; x++)
-            if (cc[x] >= 0) unsafeAtomicAdd(&row[vmap[cc[x]]], jl0 * j0[x] + jl1 * j1[x]);
-        unsafeAtomicAdd(&row[P + lm], jl0 * jl0 + jl1 * jl1);
-        unsafeAtomicAdd(&b[P + lm], -(jl0 * r0 + jl1 * r1));
-    }
-    __syncthreads();
-    for (int e = t; e < V * V; e += NRM_BLOCK) {
-        const double v = Hs[e];
-        if (v != 0.0) unsafeAtomicAdd(&H[(size_t) vmap[e / V] * N + vmap[e % V]], v);
-    }
-    for (int e = t; e < V; e += NRM_BLOCK) {
-        const double v = bs[e];
-        if (v != 0.0) unsafeAtomicAdd(&b[vmap[e]], v);
-    }
-}
-
-static int ensure_sys_capacity(icg_ctx *ctx, size_t doubles) {
-    if (doubles <= ctx->sys_cap) return 0;
-    ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_sys) (void) hipFree(ctx->d_sys);
-    ctx->d_sys   = nullptr;
-    ctx->sys_cap = 0;
-    size_t cap   = doubles + doubles / 4;
-    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_sys, sizeof(double) * cap));
-    ctx->sys_cap = cap;
-    return 0;
-}
-
-extern "C" int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, int32_t col_ext, int32_t col_td, const uint8_t *active,
-                                int reassemble, double damp, double min_diag, double max_diag, double *S, double *s, double *diag_cc,
-                                double *cost) {
-    if (!ctx || P <= 0 || !col_pose || !S || !s) return ICG_ERR_INVALID;
-    if (reassemble && (!ctx->rJ_valid || !ctx->rJ_has_jac))
-        return icg_fail(ctx, ICG_ERR_INVALID, "no resident Jacobians: call icg_reproj_eval_resident with want_jac first");
-    if (!reassemble && (!ctx->sys_valid || ctx->sys_P != P))
-        return icg_fail(ctx, ICG_ERR_INVALID, "no resident normal equations of size %d to re-damp", P);
-    const int n = ctx->n_factors_resident, L = ctx->last_n_lm;
-    if (n == 0) return icg_fail(ctx, ICG_ERR_INVALID, "no resident factors");
-    for (int k = 0; k < ctx->last_n_poses; k++)
-        if (col_pose[k] >= 0 && col_pose[k] + 6 > P) return icg_fail(ctx, ICG_ERR_INVALID, "pose %d: column %d outside the reduced system (%d)", k, col_pose[k], P);
-    if ((col_ext >= 0 && col_ext + 6 > P) || (col_td >= 0 && col_td + 1 > P)) return icg_fail(ctx, ICG_ERR_INVALID, "ext/td column outside the reduced system");
-    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    const size_t N = (size_t) P + L;
-    int rc         = ensure_sys_capacity(ctx, N * N + N + (size_t) L + 8);
-    if (rc) return rc;
-    double *d_H = ctx->d_sys, *d_b = d_H + N * N, *d_inv = d_b + N, *d_cost = d_inv + L;
-    icg_call c(ctx);
-    rc = c.reserve(sizeof(int32_t) * (8 * (size_t) ctx->last_n_poses + 16) + (size_t) n + sizeof(double) * ((size_t) P * P + 2 * (size_t) P + 1) + 4096);
-    if (rc) return rc;
-    const int32_t *d_cp = c.in(col_pose, (size_t) ctx->last_n_poses);
-    const uint8_t *d_act = active ? c.in(active, (size_t) n) : nullptr;
-    // compact camera space of the visual factors: free poses (6 columns each), then ext, then td
-    std::vector<int32_t> vcol_pose((size_t) ctx->last_n_poses, -1), vmap;
-    for (int k = 0; k < ctx->last_n_poses; k++)
-        if (col_pose[k] >= 0) {
-            vcol_pose[(size_t) k] = (int32_t) vmap.size();
-            for (int x = 0; x < 6; x++) vmap.push_back(col_pose[k] + x);
-        }
-    int vcol_ext = -1, vcol_td = -1;
-    if (col_ext >= 0) {
-        vcol_ext = (int) vmap.size();
-        for (int x = 0; x < 6; x++) vmap.push_back(col_ext + x);
-    }
-    if (col_td >= 0) {
-        vcol_td = (int) vmap.size();
-        vmap.push_back(col_td);
-    }
-    const int V = (int) vmap.size();
-    if (V == 0) return icg_fail(ctx, ICG_ERR_INVALID, "every camera block of the visual factors is constant");
-    const int32_t *d_vp = c.in(vcol_pose.data(), vcol_pose.size());
-    const int32_t *d_vm = c.in(vmap.data(), vmap.size());
-    if ((rc = c.seal())) return rc;
-    double *d_S = c.out(S, (size_t) P * P);
-    double *d_s = c.out(s, (size_t) P);
-    double *d_dg = c.out(diag_cc, (size_t) P); // user pointer may be null: still a valid device scratch
-    double *d_co = c.out(cost, 1);
-    const double *d_r = ctx->d_rJ, *d_J = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
-    ICG_LAUNCH_GUARD(c);
-    if (reassemble) {
-        ICG_HIP(ctx, hipMemsetAsync(d_H, 0, sizeof(double) * (N * N + N + (size_t) L + 1), ctx->stream));
-        icg_prof_scope ps(ctx, "reproj_normal");
-        const size_t lds = sizeof(double) * ((size_t) V * V + V);
-        if (lds <= RPJ_LDS_LIMIT) {
-            if ((rc = rpj_allow_lds(ctx, k_reproj_normal_schur, lds, 0))) return rc;
-            hipLaunchKernelGGL(k_reproj_normal_schur, dim3((n + NRM_BLOCK - 1) / NRM_BLOCK), dim3(NRM_BLOCK), lds, ctx->stream, n, d_r, d_J,
-                               (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n), (const int32_t *) (ctx->d_fidx + 2 * (size_t) n),
-                               d_vp, vcol_ext, vcol_td, d_vm, V, P, (int) N, d_H, d_b, d_act);
-        } else { // more than 142 free camera columns (23 free poses): the camera block does not fit a CU's LDS
-            hipLaunchKernelGGL(k_reproj_normal, dim3((n + NRM_BLOCK - 1) / NRM_BLOCK), dim3(NRM_BLOCK), 0, ctx->stream, n, d_r, d_J,
-                               (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n), (const int32_t *) (ctx->d_fidx + 2 * (size_t) n),
-                               d_cp, (int) col_ext, (const int32_t *) nullptr, (int) col_td, (int) N, d_H, d_b, d_act, P);
-        }
-    }
-    {
-        icg_prof_scope ps(ctx, "schur_reduce");
-        hipLaunchKernelGGL(k_schur_inv, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, P, L, (int) N, (const double *) d_H, damp, min_diag,
-                           max_diag, d_inv);
-        hipLaunchKernelGGL(k_schur_reduce, dim3((P + SCH_T - 1) / SCH_T, (P + SCH_T - 1) / SCH_T), dim3(SCH_T, SCH_T), 0, ctx->stream, P, L,
-                           (int) N, (const double *) d_H, (const double *) d_b, (const double *) d_inv, d_S, d_s, d_dg);
-        // the cost belongs to the linearization point: only meaningful while the resident residuals are the ones assembled
-        if (reassemble)
-            hipLaunchKernelGGL(k_reproj_cost, dim3(std::min(64, (n + 255) / 256)), dim3(256), 0, ctx->stream, n, d_r, d_act, ctx->last_huber,
-                               d_cost);
-    }
-    ICG_HIP(ctx, hipGetLastError());
-    ICG_HIP(ctx, hipMemcpyAsync(d_co, d_cost, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    if ((rc = c.finish())) return rc;
-    ctx->sys_P = P, ctx->sys_L = L, ctx->sys_valid = 1;
-    ctx->sys_damp = damp, ctx->sys_min_diag = min_diag, ctx->sys_max_diag = max_diag;
-    return ICG_OK;
-}
-
-extern "C" int icg_reproj_landmark_diag(icg_ctx *ctx, double *h_ll) {
-    if (!ctx || !h_ll) return ICG_ERR_INVALID;
-    if (!ctx->sys_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Schur system: call icg_reproj_schur first");
-    const int P = ctx->sys_P, L = ctx->sys_L;
-    if (L == 0) return ICG_OK;
-    const size_t N = (size_t) P + L;
-    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    // the diagonal (P+l, P+l) of the row-major N x N matrix: one 8-byte column with a pitch of (N+1) doubles
-    ICG_HIP(ctx, hipMemcpy2DAsync(h_ll, sizeof(double), ctx->d_sys + (size_t) P * N + P, sizeof(double) * (N + 1), sizeof(double), (size_t) L,
-                                  hipMemcpyDeviceToHost, ctx->stream));
-    return icg_stream_wait(ctx);
-}
-
-extern "C" int icg_reproj_backsub(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
-    if (!ctx || !delta_c || !delta_l) return ICG_ERR_INVALID;
-    if (!ctx->sys_valid || ctx->sys_P != P) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Schur system of size %d: call icg_reproj_schur first", P);
-    const int L = ctx->sys_L;
-    const size_t N = (size_t) P + L;
-    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    const double *d_H = ctx->d_sys, *d_b = d_H + N * N, *d_inv = d_b + N;
-    icg_call c(ctx);
-    int rc = c.reserve(sizeof(double) * ((size_t) P + L + 2) + 4096);
-    if (rc) return rc;
-    const double *d_dc = c.in(delta_c, (size_t) P);
-    const double zeros[2] = {0.0, 0.0};
-    double *d_tm = c.inout(zeros, lm_terms, 2); // device accumulators, pre-zeroed
-    if ((rc = c.seal())) return rc;
-    double *d_dl = c.out(delta_l, (size_t) L);
-    ICG_LAUNCH_GUARD(c);
-    {
-        icg_prof_scope ps(ctx, "schur_backsub");
-        hipLaunchKernelGGL(k_schur_backsub, dim3(L), dim3(64), 0, ctx->stream, P, L, (int) N, d_H, d_b, d_inv, d_dc, d_dl, d_tm, ctx->sys_damp,
-                           ctx->sys_min_diag, ctx->sys_max_diag);
-    }
-    ICG_HIP(ctx, hipGetLastError());
-    return c.finish();
-}
-
-extern "C" int icg_reproj_cost(icg_ctx *ctx, const uint8_t *active, double *cost) {
-    if (!ctx || !cost) return ICG_ERR_INVALID;
-    if (!ctx->rJ_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident residuals: call icg_reproj_eval_resident first");
-    const int n = ctx->n_factors_resident;
-    *cost       = 0.0;
-    if (n == 0) return ICG_OK;
-    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    icg_call c(ctx);
-    int rc = c.reserve((size_t) n + 64 + 4096);
-    if (rc) return rc;
-    const uint8_t *d_act = active ? c.in(active, (size_t) n) : nullptr;
-    const double zero = 0.0;
-    double *d_acc = c.inout(&zero, cost, 1); // device accumulator, pre-zeroed
-    if ((rc = c.seal())) return rc;
-    ICG_LAUNCH_GUARD(c);
-    {
-        icg_prof_scope ps(ctx, "reproj_cost");
-        hipLaunchKernelGGL(k_reproj_cost, dim3(std::min(64, (n + 255) / 256)), dim3(256), 0, ctx->stream, n, (const double *) ctx->d_rJ, d_act,
-                           ctx->last_huber, d_acc);
-    }
-    ICG_HIP(ctx, hipGetLastError());
-    return c.finish();
-}
-
-
-// ---- f1, many windows per launch ------------------------------------------------------------------------------------------------
-// One solver in flight per stream is bounded by the runtime's rate of small launches and copies (~100 per window and solve, DESIGN.md
-// §6).  Here the windows of many streams advance in lock-step: ONE evaluation, ONE assembly, ONE reduction, ONE back-substitution
-// launch per LM step for all of them.  The resident factor set is partitioned into W windows (factors sorted by window, landmarks
-// contiguous per window, poses indexed globally); every window has its own extrinsic / td, its own reduced system of the common
-// size P and its own damping.  Window w's system lives at d_sys + w_sys_off[w]: H (N_w x N_w, N_w = P + L_w) | b (N_w) | inv (L_w).
-#define LM_SLOTS 64 // landmark slots of one assembly workgroup (256 factors ~ 30 landmarks when the list is landmark-major)
-struct win_desc {
-    int32_t fac_begin, fac_end, lm_begin, L;
-    int64_t sys_off;
-    int32_t vcol_ext, vcol_td, V, reassemble;
-    double damp;
-};
-
-__global__ __launch_bounds__(NRM_BLOCK) void k_reproj_normal_schur_w(const win_desc *wd, const int32_t *blk_win, const int32_t *blk_first,
-                                                                     const double *r, const double *J, const int32_t *idx_i, const int32_t *idx_j,
-                                                                     const int32_t *idx_lm, const int32_t *vcol_pose, const int32_t *vmap_all, int Vmax,
-                                                                     int P, double *sys, const uint8_t *active) {
-    extern __shared__ double sm[]; // Hs[V*V] | bs[V]
-    const win_desc W = wd[blk_win[blockIdx.x]];
-    if (!W.reassemble) return; // uniform per workgroup
-    const int V = W.V, N = P + W.L;
-    const int32_t *vmap = vmap_all + (size_t) blk_win[blockIdx.x] * Vmax;
-    double *H = sys + W.sys_off, *b = H + (size_t) N * N;
-    double *Hs = sm, *bs = sm + (size_t) V * V;
-    const int t = threadIdx.x;
-    for (int e = t; e < V * V + V; e += NRM_BLOCK) sm[e] = 0.0;
-    __syncthreads();
-    const int f   = blk_first[blockIdx.x] + t;
-    const bool on = f < W.fac_end && (!active || active[f]);
-    double j0[19], j1[19];
-    int cc[19];
-    double r0 = 0.0, r1 = 0.0, jl0 = 0.0, jl1 = 0.0;
-    int lm = 0;
-    if (on) {
-        const double *Jf = J + 46 * (size_t) f;
-        r0 = r[2 * (size_t) f], r1 = r[2 * (size_t) f + 1];
-        const int ci = vcol_pose[idx_i[f]], cj = vcol_pose[idx_j[f]];
-#pragma unroll
-        for (int x = 0; x < 6; x++) {
-            j0[x] = Jf[x], j1[x] = Jf[7 + x], cc[x] = ci < 0 ? -1 : ci + x;
-            j0[6 + x] = Jf[14 + x], j1[6 + x] = Jf[21 + x], cc[6 + x] = cj < 0 ? -1 : cj + x;
-            j0[12 + x] = Jf[28 + x], j1[12 + x] = Jf[35 + x], cc[12 + x] = W.vcol_ext < 0 ? -1 : W.vcol_ext + x;
-        }
-        j0[18] = Jf[44], j1[18] = Jf[45], cc[18] = W.vcol_td;
-        jl0 = Jf[42], jl1 = Jf[43];
-        lm  = idx_lm[f] - W.lm_begin;
-    } else {
-#pragma unroll
-        for (int x = 0; x < 19; x++) j0[x] = j1[x] = 0.0, cc[x] = -1;
-    }
-    // J^T J is symmetric: only the pairs x <= y of a factor's 19 camera columns are accumulated (half the LDS atomics, which bound this
-    // kernel); the flush adds every cell and its mirror cell into both halves of the window's matrix
-#pragma unroll
-    for (int x = 0; x < 19; x++) {
-        if (cc[x] < 0) continue;
-#pragma unroll
-        for (int y = x; y < 19; y++) {
-            if (x >= 12 && y >= 12) continue;
-            if (cc[y] < 0) continue;
-            atomicAdd(&Hs[cc[x] * V + cc[y]], j0[x] * j0[y] + j1[x] * j1[y]);
-        }
-        if (x < 12) atomicAdd(&bs[cc[x]], -(j0[x] * r0 + j1[x] * r1));
-    }
-#pragma unroll
-    for (int x = 12; x < 19; x++) {
-#pragma unroll
-        for (int y = x; y < 20; y++) {
-            double v = (y < 19) ? j0[x] * j0[y] + j1[x] * j1[y] : -(j0[x] * r0 + j1[x] * r1);
-            if (!on) v = 0.0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if ((t & 63) == 0) {
-                const int cx = (x < 18) ? (W.vcol_ext < 0 ? -1 : W.vcol_ext + x - 12) : W.vcol_td;
-                const int cy = (y < 18) ? (W.vcol_ext < 0 ? -1 : W.vcol_ext + y - 12) : (y == 18 ? W.vcol_td : 0);
-                if (cx >= 0 && cy >= 0 && v != 0.0) {
-                    if (y < 19)
-                        atomicAdd(&Hs[cx * V + cy], v);
-                    else
-                        atomicAdd(&bs[cx], v);
-                }
-            }
-        }
-    }
-    // Landmark rows (G_l, h_ll, b_l).  A landmark's factors are neighbours in the factor list (the window builder adds them landmark by
-    // landmark) and share its reference pose, the extrinsic and td: those 15 sums (6 reference-pose columns, 6 + 1 shared columns, h_ll,
-    // b_l) are first accumulated in LDS per (landmark, reference pose) slot of this workgroup and flushed with ONE global atomic each —
-    // ~9 factors per landmark made 21 global FP64 atomics per factor the dominant cost of the batched assembly (rocprofv3, round 1).
-    // The observer-pose columns are unique per factor and go straight to memory.  Landmarks outside the workgroup's slot range (an
-    // unsorted factor list) take the direct path: placement only, the sums are the same.
-    double *lrow = bs + V; // LM_SLOTS x 16: [0..5] reference pose, [6..11] ext, [12] td, [13] h_ll, [14] b_l, [15] ci (slot owner check)
-    int *lslot_ci = reinterpret_cast<int *>(lrow + LM_SLOTS * 16);
-    for (int e = t; e < LM_SLOTS * 16; e += NRM_BLOCK) lrow[e] = 0.0;
-    for (int e = t; e < LM_SLOTS; e += NRM_BLOCK) lslot_ci[e] = -2;
-    __shared__ int lm_base;
-    if (t == 0) lm_base = idx_lm[blk_first[blockIdx.x]] - W.lm_begin; // landmark of the workgroup's first factor
-    __syncthreads();
-    const int slot = lm - lm_base;
-    bool in_lds    = false;
-    if (on) {
-        double *row = H + (size_t) (P + lm) * N;
-        const int ci = cc[0]; // compact column of the reference pose (-1: constant)
-        if (slot >= 0 && slot < LM_SLOTS) { // claim the slot for this (landmark, reference pose); a different owner -> direct path
-            const int prev = atomicCAS(&lslot_ci[slot], -2, ci);
-            in_lds         = prev == -2 || prev == ci;
-        }
-        if (in_lds) {
-            double *L = lrow + slot * 16;
-#pragma unroll
-            for (int x = 0; x < 6; x++)
-                if (cc[x] >= 0) atomicAdd(&L[x], jl0 * j0[x] + jl1 * j1[x]);
-#pragma unroll
-            for (int x = 12; x < 19; x++)
-                if (cc[x] >= 0) atomicAdd(&L[x - 6], jl0 * j0[x] + jl1 * j1[x]);
-            atomicAdd(&L[13], jl0 * jl0 + jl1 * jl1);
-            atomicAdd(&L[14], -(jl0 * r0 + jl1 * r1));
-#pragma unroll
-            for (int x = 6; x < 12; x++)
-                if (cc[x] >= 0) unsafeAtomicAdd(&row[vmap[cc[x]]], jl0 * j0[x] + jl1 * j1[x]);
-        } else {
-#pragma unroll
-            for (int x = 0; x < 19; x++)
-                if (cc[x] >= 0) unsafeAtomicAdd(&row[vmap[cc[x]]], jl0 * j0[x] + jl1 * j1[x]);
-            unsafeAtomicAdd(&row[P + lm], jl0 * jl0 + jl1 * jl1);
-            unsafeAtomicAdd(&b[P + lm], -(jl0 * r0 + jl1 * r1));
-        }
-    }
-    __syncthreads();
-    // flush the landmark slots: thread e -> (slot e / 16, value e % 16)
-    for (int e = t; e < LM_SLOTS * 16; e += NRM_BLOCK) {
-        const int sl = e >> 4, k = e & 15, ci = lslot_ci[sl];
-        if (ci == -2 || k == 15) continue;
-        const double v = lrow[e];
-        if (v == 0.0) continue;
-        const int l = lm_base + sl;
-        double *row = H + (size_t) (P + l) * N;
-        if (k < 6) {
-            if (ci >= 0) unsafeAtomicAdd(&row[vmap[ci + k]], v);
-        } else if (k < 12) {
-            unsafeAtomicAdd(&row[vmap[W.vcol_ext + (k - 6)]], v);
-        } else if (k == 12) {
-            unsafeAtomicAdd(&row[vmap[W.vcol_td]], v);
-        } else if (k == 13) {
-            unsafeAtomicAdd(&row[P + l], v);
-        } else {
-            unsafeAtomicAdd(&b[P + l], v);
-        }
-    }
-    for (int e = t; e < V * V; e += NRM_BLOCK) {
-        const int ca = e / V, cb = e - ca * V;
-        const double v = Hs[e] + (ca != cb ? Hs[cb * V + ca] : 0.0); // the cell and its mirror (x <= y accumulation above)
-        if (v != 0.0) unsafeAtomicAdd(&H[(size_t) vmap[ca] * N + vmap[cb]], v);
-    }
-    for (int e = t; e < V; e += NRM_BLOCK) {
-        const double v = bs[e];
-        if (v != 0.0) unsafeAtomicAdd(&b[vmap[e]], v);
-    }
-}
-
-// zeroes the (H | b) part of every window that is re-assembled (one workgroup column per window)
-__global__ void k_sys_clear_w(const win_desc *wd, int P, double *sys) {
-    const win_desc W = wd[blockIdx.y];
+// owner[w * P + a] of a camera column: (local pose << 3) | x for column x of a pose block, (ASM_EXT << 3) | x for the extrinsic (x < 6) and td
+// (x == 6), -1 for a column no visual factor of the window touches (host-only blocks, empty tail columns)
+// grid (ceil((P * P + P) / 256), W)
+__global__ __launch_bounds__(256) void k_asm_camera(const win_desc *wd, const int32_t *run_off, const int32_t *pair_run, int Kmax, const int16_t *owner,
+                                                   int P, const double *part, double *sys) {
+    const int w       = blockIdx.y;
+    const win_desc W = wd[w];
     if (!W.reassemble) return;
-    const size_t N = (size_t) P + W.L, total = N * N + N;
-    double *H = sys + W.sys_off;
-    for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t) gridDim.x * blockDim.x) H[e] = 0.0;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= P * P + P) return;
+    const int N          = P + W.L, K = W.K;
+    double *H            = sys + W.sys_off, *b = H + (size_t) N * N;
+    const int16_t *own   = owner + (size_t) w * P;
+    const int32_t *pr    = pair_run + (size_t) w * Kmax * Kmax;
+    const int r0 = run_off[w], r1 = run_off[w + 1];
+    double acc = 0.0;
+    if (e < P * P) {
+        const int a = e / P, c = e - a * P;
+        const int oa = own[a], oc = own[c];
+        if (oa >= 0 && oc >= 0) {
+            const int pa = oa >> 3, xa = oa & 7, pc = oc >> 3, xc = oc & 7;
+            if (pa == ASM_EXT && pc == ASM_EXT) {
+                const int idx = asm_part_index(12 + xa, 12 + xc);
+                for (int rr = r0; rr < r1; rr++) acc += part[(size_t) rr * ASM_PART + idx];
+            } else if (pa != ASM_EXT && pc != ASM_EXT && pa != pc) {
+                const int r_ac = pr[pa * Kmax + pc], r_ca = pr[pc * Kmax + pa];
+                if (r_ac >= 0) acc += part[(size_t) r_ac * ASM_PART + asm_part_index(xa, 6 + xc)];
+                if (r_ca >= 0) acc += part[(size_t) r_ca * ASM_PART + asm_part_index(6 + xa, xc)];
+            } else {
+                // pose p's diagonal block, or pose p against the shared block: every run with p as reference (row p of the pair table)
+                // or as observer (column p)
+                const int p   = pa != ASM_EXT ? pa : pc;
+                const int i_r = asm_part_index(pa == ASM_EXT ? 12 + xa : xa, pc == ASM_EXT ? 12 + xc : xc);         // p is the run's reference
+                const int i_o = asm_part_index(pa == ASM_EXT ? 12 + xa : 6 + xa, pc == ASM_EXT ? 12 + xc : 6 + xc); // p is the run's observer
+                for (int q = 0; q < K; q++) {
+                    const int rr = pr[p * Kmax + q], ro = pr[q * Kmax + p];
+                    if (rr >= 0) acc += part[(size_t) rr * ASM_PART + i_r];
+                    if (ro >= 0) acc += part[(size_t) ro * ASM_PART + i_o];
+                }
+            }
+        }
+        H[(size_t) a * N + c] = acc;
+    } else {
+        const int a  = e - P * P;
+        const int oa = own[a];
+        if (oa >= 0) {
+            const int pa = oa >> 3, xa = oa & 7;
+            if (pa == ASM_EXT) {
+                const int idx = asm_part_index(12 + xa, 19);
+                for (int rr = r0; rr < r1; rr++) acc += part[(size_t) rr * ASM_PART + idx];
+            } else {
+                const int i_r = asm_part_index(xa, 19), i_o = asm_part_index(6 + xa, 19);
+                for (int q = 0; q < K; q++) {
+                    const int rr = pr[pa * Kmax + q], ro = pr[q * Kmax + pa];
+                    if (rr >= 0) acc += part[(size_t) rr * ASM_PART + i_r];
+                    if (ro >= 0) acc += part[(size_t) ro * ASM_PART + i_o];
+                }
+            }
+        }
+        b[a] = acc;
+    }
+}
+
+// Landmark rows.  A workgroup owns LB consecutive landmarks of one window = LB * (P + 2) cells (cell a < P of landmark l is G_l[a], cell P is
+// h_ll, cell P + 1 is b_l; LB chosen so that a thread owns at most four cells).  The factors of those landmarks are one contiguous range of
+// the landmark-major list: they are staged in LDS 64 at a time (J and r of a factor = 48 doubles, ONE round trip of independent coalesced
+// loads per pass — the first version walked lrec -> J -> J as three dependent global loads per cell and factor and was bound by that latency:
+// 221 us for 256 windows against 100 us for the twenty times heavier k_asm_runs), then every cell adds the staged factors of its landmark
+// in list order.  An inactive factor is staged as zeros.
+#define ASML_FB 64
+// grid (ceil(Lmax / LB), W)
+__global__ __launch_bounds__(256) void k_asm_landmarks(const win_desc *wd, const int16_t *owner, int P, int LB, const int32_t *lm_foff, const int4 *lrec,
+                                                      const double *r, const double *J, const uint8_t *active, double *sys) {
+    __shared__ double st[ASML_FB * 48];
+    __shared__ int st_i[ASML_FB], st_j[ASML_FB];
+    const int w       = blockIdx.y;
+    const win_desc W = wd[w];
+    if (!W.reassemble) return;
+    const int l0 = blockIdx.x * LB;
+    if (l0 >= W.L) return;
+    const int t = threadIdx.x, nl = min(LB, W.L - l0), C = P + 2, ncell = nl * C;
+    const int N = P + W.L;
+    double *H   = sys + W.sys_off, *b = H + (size_t) N * N;
+    int cl[4], ca[4], co[4], fb[4], fe[4];
+    double acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int e = t + 256 * k;
+        cl[k] = e / C, ca[k] = e - cl[k] * C;
+        acc[k] = 0.0;
+        co[k]  = -1, fb[k] = fe[k] = 0;
+        if (e < ncell) {
+            co[k] = ca[k] < P ? (int) owner[(size_t) w * P + ca[k]] : 0; // (-1: a column no visual factor touches — stays zero)
+            fb[k] = lm_foff[W.lm_begin + l0 + cl[k]], fe[k] = lm_foff[W.lm_begin + l0 + cl[k] + 1];
+        }
+    }
+    const int f_begin = lm_foff[W.lm_begin + l0], f_end = lm_foff[W.lm_begin + l0 + nl];
+    const int fi = t >> 2, sub = t & 3;
+    for (int c0 = f_begin; c0 < f_end; c0 += ASML_FB) {
+        const int nc = min(ASML_FB, f_end - c0);
+        __syncthreads(); // (the previous pass has been consumed)
+        if (fi < nc) {
+            const int4 rec = lrec[c0 + fi]; // factor, local_i, local_j
+            const bool on  = !active || active[rec.x];
+            const double *Jf = J + 46 * (size_t) rec.x;
+#pragma unroll
+            for (int kk = 0; kk < 12; kk++) {
+                const int c = sub + 4 * kk;
+                st[fi * 48 + c] = on ? (c < 46 ? Jf[c] : r[2 * (size_t) rec.x + (c - 46)]) : 0.0;
+            }
+            if (sub == 0) st_i[fi] = rec.y, st_j[fi] = rec.z;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (co[k] < 0) continue;
+            const int p = co[k] >> 3, x = co[k] & 7, a = ca[k];
+            const int g1 = min(fe[k], c0 + nc) - c0;
+            for (int g = max(fb[k], c0) - c0; g < g1; g++) {
+                const double *Jf = &st[g * 48];
+                const double jl0 = Jf[42], jl1 = Jf[43];
+                if (a < P) {
+                    int o0, o1;
+                    if (p == ASM_EXT)
+                        o0 = x < 6 ? 28 + x : 44, o1 = x < 6 ? 35 + x : 45;
+                    else if (p == st_i[g])
+                        o0 = x, o1 = 7 + x;
+                    else if (p == st_j[g])
+                        o0 = 14 + x, o1 = 21 + x;
+                    else
+                        continue;
+                    acc[k] = fma(jl1, Jf[o1], fma(jl0, Jf[o0], acc[k]));
+                } else if (a == P) {
+                    acc[k] = fma(jl1, jl1, fma(jl0, jl0, acc[k]));
+                } else {
+                    acc[k] = fma(jl1, -Jf[47], fma(jl0, -Jf[46], acc[k]));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (t + 256 * k >= ncell) continue;
+        const int l = l0 + cl[k], a = ca[k];
+        if (a < P)
+            H[(size_t) (P + l) * N + a] = acc[k];
+        else if (a == P)
+            H[(size_t) (P + l) * N + P + l] = acc[k];
+        else
+            b[P + l] = acc[k];
+    }
 }
 
 __global__ void k_schur_inv_w(const win_desc *wd, int P, double *sys, double min_diag, double max_diag) {
@@ -983,47 +652,100 @@ __global__ void k_schur_inv_w(const win_desc *wd, int P, double *sys, double min
     const double *H = sys + W.sys_off;
     double *inv = sys + W.sys_off + (size_t) N * N + N;
     const double h = H[(size_t) (P + l) * N + P + l];
+    // a landmark without any active factor has an empty row: it is left where it is (delta_l = 0)
     inv[l] = h > 0.0 ? 1.0 / (h + fmin(fmax(h, min_diag), max_diag) * W.damp) : 0.0;
 }
 
-__global__ __launch_bounds__(SCH_T *SCH_T) void k_schur_reduce_w(const win_desc *wd, int P, const double *sys, double *S, double *s, double *diag,
-                                                                int lower_only) {
-    __shared__ double gi[SCH_T][SCH_T + 1], gj[SCH_T][SCH_T + 1], w[SCH_T];
-    // the reduced systems are symmetric and the factorization reads rows >= columns only: the tiles strictly above the diagonal are neither
-    // computed nor written when the caller asks for that (40 % of the tiles, and of the bytes that cross PCIe in the zero-copy form, at P = 67)
-    if (lower_only && blockIdx.x > blockIdx.y) return;
-    const win_desc W = wd[blockIdx.z];
-    const int L = W.L, N = P + L;
+// S = Hcc - G^T diag(inv) G,  s = bc - G^T (inv b_l),  diag = diag(Hcc).
+// Rounds 1-5 ran 16 x 16 output tiles of one thread per element, every tile re-reading its two G panels from memory with two barriers per 16
+// landmarks: 157-199 us for 256 windows of a 0.35 GFLOP contraction.  Now a workgroup owns (up to 256 of) the 4 x 4 register tiles of the
+// LOWER triangle of one window's S: the G rows of 32 landmarks are staged in LDS once per pass and every thread reads its row and column
+// quadruples from there (4 ds_read_b128 per landmark for 16 FMAs).  The upper triangle is the mirror image of the lower one (S is
+// symmetric; the factorizations read rows >= columns): written as such when the caller wants the full matrix, not at all otherwise.
+// Landmarks are added in index order: the value of a window does not depend on the batch it is reduced in.
+#define SCH_LT 32
+// grid (ceil(NT / 256), W), NT = TQ (TQ + 1) / 2 lower tiles, TQ = ceil(P / 4); dynamic LDS: SCH_LT * 4 TQ doubles (G) + 2 SCH_LT (inv, inv b_l)
+__global__ __launch_bounds__(256) void k_schur_reduce_w(const win_desc *wd, int P, const double *sys, double *S, double *s, double *diag,
+                                                       int lower_only) {
+    extern __shared__ double sm[];
+    const win_desc W = wd[blockIdx.y];
+    const int L = W.L, N = P + L, TQ = (P + 3) >> 2, PP = 4 * TQ, NT = (TQ * (TQ + 1)) >> 1;
     const double *H = sys + W.sys_off, *b = H + (size_t) N * N, *inv = b + N;
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    const int i = blockIdx.y * SCH_T + ty, j = blockIdx.x * SCH_T + tx;
-    double acc = 0.0, accs = 0.0;
-    for (int l0 = 0; l0 < L; l0 += SCH_T) {
-        const int l  = l0 + ty;
-        const int ci = blockIdx.y * SCH_T + tx;
-        gi[ty][tx] = (l < L && ci < P) ? H[(size_t) (P + l) * N + ci] : 0.0;
-        gj[ty][tx] = (l < L && j < P) ? H[(size_t) (P + l) * N + j] : 0.0;
-        if (ty == 0) w[tx] = (l0 + tx < L) ? inv[l0 + tx] : 0.0;
-        __syncthreads();
+    double *g = sm, *sw = sm + SCH_LT * PP, *swb = sw + SCH_LT;
+    const int t = threadIdx.x, tid = blockIdx.x * 256 + t;
+    // tile (ti, tj), tj <= ti, from the triangular index
+    int ti = (int) ((sqrtf(8.0f * (float) tid + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= tid) ti++;
+    while (ti * (ti + 1) / 2 > tid) ti--;
+    const int tj     = tid - ti * (ti + 1) / 2;
+    const bool owner = tid < NT;
+    double acc[4][4];
 #pragma unroll
-        for (int k = 0; k < SCH_T; k++) {
-            acc += gi[k][ty] * w[k] * gj[k][tx];
-            if (blockIdx.x == 0 && tx == 0) accs += gi[k][ty] * w[k] * ((l0 + k < L) ? b[P + l0 + k] : 0.0);
+    for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) acc[rr][cc] = 0.0;
+    double accs[2] = {0.0, 0.0}; // s entries t and t + 256 (workgroup 0 of the window; P <= 512 here, the rest by the tail loop below)
+    for (int l0 = 0; l0 < L; l0 += SCH_LT) {
+        const int nl = min(SCH_LT, L - l0);
+        __syncthreads();
+        for (int e = t; e < SCH_LT * PP; e += 256) {
+            const int l = e / PP, c = e - l * PP;
+            g[e] = (l < nl && c < P) ? H[(size_t) (P + l0 + l) * N + c] : 0.0;
+        }
+        if (t < SCH_LT) {
+            const double wv = t < nl ? inv[l0 + t] : 0.0;
+            sw[t] = wv, swb[t] = t < nl ? b[P + l0 + t] : 0.0;
         }
         __syncthreads();
+        if (owner) {
+            for (int l = 0; l < nl; l++) {
+                const double wl  = sw[l];
+                const double2 a0 = *reinterpret_cast<const double2 *>(&g[l * PP + 4 * ti]), a1 = *reinterpret_cast<const double2 *>(&g[l * PP + 4 * ti + 2]);
+                const double2 b0 = *reinterpret_cast<const double2 *>(&g[l * PP + 4 * tj]), b1 = *reinterpret_cast<const double2 *>(&g[l * PP + 4 * tj + 2]);
+                const double av[4] = {a0.x * wl, a0.y * wl, a1.x * wl, a1.y * wl}, bv[4] = {b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) acc[rr][cc] = fma(av[rr], bv[cc], acc[rr][cc]);
+            }
+        }
+        if (blockIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int i = t + 256 * k;
+                if (i < P)
+                    for (int l = 0; l < nl; l++) accs[k] = fma(g[l * PP + i] * sw[l], swb[l], accs[k]);
+            }
+        }
     }
-    double *Sw = S + (size_t) blockIdx.z * P * P;
-    if (i < P && j < P) Sw[(size_t) i * P + j] = H[(size_t) i * N + j] - acc;
-    if (blockIdx.x == 0 && tx == 0 && i < P) {
-        s[(size_t) blockIdx.z * P + i]    = b[i] - accs;
-        diag[(size_t) blockIdx.z * P + i] = H[(size_t) i * N + i];
+    if (owner) {
+        double *Sw = S + (size_t) blockIdx.y * P * P;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                const int i = 4 * ti + rr, j = 4 * tj + cc;
+                if (i >= P || j > i) continue; // (cells above the diagonal inside a diagonal tile are mirrors too)
+                const double v       = H[(size_t) i * N + j] - acc[rr][cc];
+                Sw[(size_t) i * P + j] = v;
+                if (!lower_only && j < i) Sw[(size_t) j * P + i] = v;
+            }
+    }
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = t + 256 * k;
+            if (i < P) s[(size_t) blockIdx.y * P + i] = b[i] - accs[k], diag[(size_t) blockIdx.y * P + i] = H[(size_t) i * N + i];
+        }
     }
 }
 
-// one wave per landmark (global index); terms[w][2] pre-zeroed
-__global__ __launch_bounds__(64) void k_schur_backsub_w(const win_desc *wd, const int32_t *lm_win, int P, const double *sys, const double *delta_c,
-                                                        double *delta_l, double *terms, double min_diag, double max_diag) {
-    const int lg = blockIdx.x, wi = lm_win[lg];
+// one wave per landmark (global index): delta_l = (b_l - G_l . delta_c) * inv_l; lterms[l][2] = b_l^2 / (h_ll + d_l), d_l delta_l^2 — the
+// landmark's part of the LM model decrease 0.5 (delta^T b + delta^T D delta): with the reduced right-hand side s, delta^T b =
+// delta_c^T s + sum lterms[.][0], so the step-quality ratio is formed without moving G or b_l to the host
+__global__ __launch_bounds__(64) void k_schur_backsub_w(const win_desc *wd, const int32_t *lm_win, int lm_base, int P, const double *sys,
+                                                        const double *delta_c, double *delta_l, double *lterms, double min_diag, double max_diag) {
+    const int lg = lm_base + blockIdx.x, wi = lm_win ? lm_win[lg] : 0;
     const win_desc W = wd[wi];
     const int l = lg - W.lm_begin, N = P + W.L;
     const double *H = sys + W.sys_off, *b = H + (size_t) N * N, *inv = b + N;
@@ -1036,37 +758,518 @@ __global__ __launch_bounds__(64) void k_schur_backsub_w(const win_desc *wd, cons
         const double bl = b[P + l], wv = inv[l];
         const double d  = (bl - acc) * wv;
         delta_l[lg]     = d;
+        double t0 = 0.0, t1 = 0.0;
         if (wv > 0.0) {
-            const double dl = fmin(fmax(H[(size_t) (P + l) * N + P + l], min_diag), max_diag) * W.damp;
-            unsafeAtomicAdd(&terms[2 * wi], bl * bl * wv);
-            unsafeAtomicAdd(&terms[2 * wi + 1], dl * d * d);
+            const double dl = fmin(fmax(H[(size_t) (P + l) * N + P + l], min_diag), max_diag) * W.damp; // the damping that went into inv
+            t0 = bl * bl * wv, t1 = dl * d * d;
         }
+        lterms[2 * (size_t) lg] = t0, lterms[2 * (size_t) lg + 1] = t1;
     }
 }
 
-// grid (chunks, W): cost[w] += 0.5 sum rho over the window's active factors
+// sum of 256 per-thread partial sums in a fixed tree: butterfly inside each wave, the four wave sums in order
+__device__ __forceinline__ double block_sum_256(double v, double *sh4) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((sh4[0] + sh4[1]) + sh4[2]) + sh4[3];
+}
+
+// one workgroup per window: terms[w] = the window's landmark terms, thread t adds landmarks t, t + 256, ... in that order
+__global__ __launch_bounds__(256) void k_terms_reduce_w(const win_desc *wd, const double *lterms, double *terms) {
+    __shared__ double sh[2][4];
+    const win_desc W = wd[blockIdx.x];
+    double t0 = 0.0, t1 = 0.0;
+    for (int l = threadIdx.x; l < W.L; l += 256) t0 += lterms[2 * (size_t) (W.lm_begin + l)], t1 += lterms[2 * (size_t) (W.lm_begin + l) + 1];
+    t0 = block_sum_256(t0, sh[0]);
+    t1 = block_sum_256(t1, sh[1]);
+    if (threadIdx.x == 0) terms[2 * blockIdx.x] = t0, terms[2 * blockIdx.x + 1] = t1;
+}
+
+// 0.5 * sum rho(|r|^2) of the window's active factors from the resident (possibly Huber-corrected) residuals: the corrector leaves
+// |r_c|^2 = rho'(s) s, i.e. s for inliers and a sqrt(s) > a^2 for outliers, so rho(s) = 2 a sqrt(s) - a^2 = 2 |r_c|^2 - a^2.
+// One workgroup per window, thread t adds factors fac_begin + t, + 256, ... in that order, then the fixed tree: the value of a window does
+// not depend on the batch it is evaluated in.
 __global__ __launch_bounds__(256) void k_reproj_cost_w(const win_desc *wd, const double *r, const uint8_t *active, double huber, double *out) {
     __shared__ double sh[4];
-    const win_desc W = wd[blockIdx.y];
+    const win_desc W = wd[blockIdx.x];
     double acc = 0.0;
-    for (int f = W.fac_begin + blockIdx.x * 256 + threadIdx.x; f < W.fac_end; f += gridDim.x * 256) {
+    for (int f = W.fac_begin + threadIdx.x; f < W.fac_end; f += 256) {
         if (active && !active[f]) continue;
         const double r0 = r[2 * (size_t) f], r1 = r[2 * (size_t) f + 1];
         double q = r0 * r0 + r1 * r1;
         if (huber > 0.0 && q > huber * huber) q = 2.0 * q - huber * huber;
         acc += 0.5 * q;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(&out[blockIdx.y], sh[0] + sh[1] + sh[2] + sh[3]);
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 
+static int ensure_sys_capacity(icg_ctx *ctx, size_t doubles) {
+    if (doubles <= ctx->sys_cap) return 0;
+    ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_sys) (void) hipFree(ctx->d_sys);
+    ctx->d_sys   = nullptr;
+    ctx->sys_cap = 0;
+    ctx->part_1.sys_valid = ctx->part_w.sys_valid = 0;
+    size_t cap   = doubles + doubles / 4;
+    ICG_HIP(ctx, hipMalloc((void **) &ctx->d_sys, sizeof(double) * cap));
+    ctx->sys_cap = cap;
+    return 0;
+}
+
+// ---- the assembly plan of a partition (host, once per factor set / partition) ---------------------------------------------------------------
+static int asm_plan_build(icg_ctx *ctx, icg_partition &pt) {
+    const int W = pt.W, n = ctx->n_factors_resident, n_lm = pt.lm_off[(size_t) W];
+    icg_asm_plan &pl = pt.plan;
+    pt.plan_valid    = false;
+    if ((int) ctx->h_fidx.size() != 3 * n) return icg_fail(ctx, ICG_ERR_INVALID, "no resident factors");
+    const int32_t *ii = ctx->h_fidx.data(), *jj = ii + n, *ll = jj + n;
+    int max_pose = -1;
+    for (int f = 0; f < n; f++) {
+        if (ii[f] < 0 || jj[f] < 0) return icg_fail(ctx, ICG_ERR_INVALID, "factor %d: negative pose index", f);
+        if (ii[f] == jj[f]) return icg_fail(ctx, ICG_ERR_INVALID, "factor %d: reference and observer pose are the same block (%d)", f, ii[f]);
+        max_pose = std::max(max_pose, std::max((int) ii[f], (int) jj[f]));
+    }
+    std::vector<int32_t> pose_win((size_t) (max_pose + 1), -1), g2l((size_t) (max_pose + 1), -1), used;
+    std::vector<int32_t> perm((size_t) std::max(n, 1)), runs, lrec(4 * (size_t) std::max(n, 1)), lm_foff((size_t) n_lm + 1, 0), cnt;
+    pl.run_off.assign((size_t) W + 1, 0);
+    pl.pose_off.assign((size_t) W + 1, 0);
+    pl.pose_glob.clear();
+    pl.Kmax = 1;
+    for (int w = 0; w < W; w++) {
+        const int f0 = pt.fac_off[(size_t) w], f1 = pt.fac_off[(size_t) w + 1], l0 = pt.lm_off[(size_t) w], l1 = pt.lm_off[(size_t) w + 1];
+        used.clear();
+        for (int f = f0; f < f1; f++)
+            for (int32_t p : {ii[f], jj[f]}) {
+                int32_t &pw = pose_win[(size_t) p];
+                if (pw >= 0 && pw != w) return icg_fail(ctx, ICG_ERR_INVALID, "pose %d is used by windows %d and %d", (int) p, (int) pw, w);
+                if (pw < 0) pw = w, used.push_back(p);
+            }
+        std::sort(used.begin(), used.end());
+        const int K = (int) used.size();
+        if (K >= ASM_EXT) return icg_fail(ctx, ICG_ERR_CAPACITY, "window %d uses %d poses (limit %d)", w, K, ASM_EXT - 1);
+        for (int k = 0; k < K; k++) g2l[(size_t) used[(size_t) k]] = k;
+        pl.pose_glob.insert(pl.pose_glob.end(), used.begin(), used.end());
+        pl.pose_off[(size_t) w + 1] = (int32_t) pl.pose_glob.size();
+        pl.Kmax                      = std::max(pl.Kmax, K);
+        // runs: stable counting sort of the window's factors by the ordered local pose pair
+        cnt.assign((size_t) K * K + 1, 0);
+        for (int f = f0; f < f1; f++) cnt[(size_t) g2l[(size_t) ii[f]] * K + g2l[(size_t) jj[f]] + 1]++;
+        for (size_t k = 0; k < (size_t) K * K; k++) {
+            if (cnt[k + 1] > 0) {
+                runs.push_back(f0 + cnt[k]), runs.push_back(cnt[k + 1]);
+                runs.push_back((int32_t) (k / (size_t) K) | ((int32_t) (k % (size_t) K) << 16)), runs.push_back(w);
+            }
+            cnt[k + 1] += cnt[k];
+        }
+        for (int f = f0; f < f1; f++) perm[(size_t) f0 + (size_t) cnt[(size_t) g2l[(size_t) ii[f]] * K + g2l[(size_t) jj[f]]]++] = f;
+        pl.run_off[(size_t) w + 1] = (int32_t) (runs.size() / 4);
+        // landmark-major records: stable counting sort by landmark
+        for (int f = f0; f < f1; f++) {
+            if (ll[f] < l0 || ll[f] >= l1) return icg_fail(ctx, ICG_ERR_INVALID, "factor %d: landmark %d outside its window's range [%d, %d)", f, (int) ll[f], l0, l1);
+            lm_foff[(size_t) ll[f] + 1]++;
+        }
+    }
+    for (int l = 0; l < n_lm; l++) lm_foff[(size_t) l + 1] += lm_foff[(size_t) l];
+    {
+        std::vector<int32_t> pos(lm_foff.begin(), lm_foff.end() - 1);
+        for (int w = 0; w < W; w++) {
+            // (g2l of a pose is its number inside its own window: poses are not shared between windows)
+            for (int f = pt.fac_off[(size_t) w]; f < pt.fac_off[(size_t) w + 1]; f++) {
+                int32_t *rec = &lrec[4 * (size_t) pos[(size_t) ll[f]]++];
+                rec[0] = f, rec[1] = g2l[(size_t) ii[f]], rec[2] = g2l[(size_t) jj[f]], rec[3] = 0;
+            }
+        }
+    }
+    pl.n_runs = (int) (runs.size() / 4);
+    std::vector<int32_t> pair_run((size_t) W * pl.Kmax * pl.Kmax, -1);
+    for (int k = 0; k < pl.n_runs; k++) {
+        const int32_t lilj = runs[4 * (size_t) k + 2], w = runs[4 * (size_t) k + 3];
+        pair_run[((size_t) w * pl.Kmax + (size_t) (lilj & 0xFFFF)) * pl.Kmax + (size_t) (lilj >> 16)] = k;
+    }
+    // one device allocation, 256-byte aligned sections
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t b_perm = icg_align_up(sizeof(int32_t) * (size_t) std::max(n, 1), 256), b_runs = icg_align_up(sizeof(int32_t) * std::max<size_t>(runs.size(), 4), 256),
+                 b_roff = icg_align_up(sizeof(int32_t) * ((size_t) W + 1), 256), b_pair = icg_align_up(sizeof(int32_t) * pair_run.size(), 256),
+                 b_lrec = icg_align_up(sizeof(int32_t) * lrec.size(), 256), b_lmf = icg_align_up(sizeof(int32_t) * lm_foff.size(), 256);
+    const size_t total = b_perm + b_runs + b_roff + b_pair + b_lrec + b_lmf;
+    if (total > pl.buf_cap) {
+        ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (pl.d_buf) (void) hipFree(pl.d_buf);
+        pl.d_buf = nullptr, pl.buf_cap = 0;
+        ICG_HIP(ctx, hipMalloc((void **) &pl.d_buf, total + total / 4));
+        pl.buf_cap = total + total / 4;
+    }
+    char *p       = pl.d_buf;
+    pl.d_perm     = reinterpret_cast<int32_t *>(p), p += b_perm;
+    pl.d_runs     = reinterpret_cast<int32_t *>(p), p += b_runs;
+    pl.d_run_off  = reinterpret_cast<int32_t *>(p), p += b_roff;
+    pl.d_pair_run = reinterpret_cast<int32_t *>(p), p += b_pair;
+    pl.d_lrec     = reinterpret_cast<int32_t *>(p), p += b_lrec;
+    pl.d_lm_foff  = reinterpret_cast<int32_t *>(p);
+    ICG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (a launch of the previous plan may still read the buffer)
+    if (n) ICG_HIP(ctx, hipMemcpyAsync(pl.d_perm, perm.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+    if (!runs.empty()) ICG_HIP(ctx, hipMemcpyAsync(pl.d_runs, runs.data(), sizeof(int32_t) * runs.size(), hipMemcpyHostToDevice, ctx->stream));
+    ICG_HIP(ctx, hipMemcpyAsync(pl.d_run_off, pl.run_off.data(), sizeof(int32_t) * ((size_t) W + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (!pair_run.empty()) ICG_HIP(ctx, hipMemcpyAsync(pl.d_pair_run, pair_run.data(), sizeof(int32_t) * pair_run.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (n) ICG_HIP(ctx, hipMemcpyAsync(pl.d_lrec, lrec.data(), sizeof(int32_t) * 4 * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+    ICG_HIP(ctx, hipMemcpyAsync(pl.d_lm_foff, lm_foff.data(), sizeof(int32_t) * lm_foff.size(), hipMemcpyHostToDevice, ctx->stream));
+    if ((size_t) pl.n_runs * ASM_PART > pl.part_cap) {
+        if (pl.d_part) (void) hipFree(pl.d_part);
+        pl.d_part = nullptr, pl.part_cap = 0;
+        const size_t cap = (size_t) pl.n_runs * ASM_PART + (size_t) pl.n_runs * ASM_PART / 4;
+        ICG_HIP(ctx, hipMalloc((void **) &pl.d_part, sizeof(double) * cap));
+        pl.part_cap = cap;
+    }
+    ICG_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (the host vectors go out of scope)
+    pt.plan_valid = true;
+    return ICG_OK;
+}
+
+// the implicit partition behind the single-window entry points: every resident factor, landmarks 0 .. n_lm - 1
+static int single_partition(icg_ctx *ctx, int n_lm) {
+    icg_partition &pt = ctx->part_1;
+    const int n       = ctx->n_factors_resident;
+    if (pt.plan_valid && pt.W == 1 && pt.fac_off[1] == n && pt.lm_off[1] == n_lm) return ICG_OK;
+    pt.W = 1;
+    pt.fac_off = {0, n}, pt.lm_off = {0, n_lm};
+    pt.sys_valid = 0;
+    return asm_plan_build(ctx, pt);
+}
+
+static void build_win_desc(const icg_partition &pt, const uint8_t *reassemble, const double *damp, std::vector<win_desc> &out) {
+    const int W = pt.W;
+    out.resize((size_t) W);
+    for (int w = 0; w < W; w++) {
+        win_desc &d = out[(size_t) w];
+        d.fac_begin = pt.fac_off[(size_t) w], d.fac_end = pt.fac_off[(size_t) w + 1];
+        d.lm_begin = pt.lm_off[(size_t) w], d.L = pt.lm_off[(size_t) w + 1] - pt.lm_off[(size_t) w];
+        d.sys_off    = pt.sys_off.size() == (size_t) W + 1 ? pt.sys_off[(size_t) w] : 0;
+        d.K          = pt.plan_valid ? pt.plan.pose_off[(size_t) w + 1] - pt.plan.pose_off[(size_t) w] : 0;
+        d.reassemble = reassemble ? reassemble[w] : 1;
+        d.damp       = damp ? damp[w] : (pt.damp.size() == (size_t) W ? pt.damp[(size_t) w] : 0.0);
+    }
+}
+
+// Assembly (for the windows with reassemble[w] != 0) + landmark elimination of every window of the partition.
+// S_view != nullptr: the reduced systems are written by the reduction kernel straight into the context's pinned staging memory (zero-copy)
+// and *S_view points there — no device-to-host copy and no 9 MB copy-out per LM step at 256 windows; valid until the next call on ctx.
+// S and S_view both null: the reduced systems stay on the device (ctx->d_redS).
+static int schur_impl(icg_ctx *ctx, icg_partition &pt, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
+                      const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, double *S, const double **S_view, bool resident,
+                      double *s, double *diag_cc, double *cost) {
+    const bool tdbg = getenv("ICG_ABI_DEBUG") != nullptr;
+    auto tnow       = [] { return std::chrono::steady_clock::now(); };
+    auto t_begin    = tnow();
+    const int W = pt.W, n = ctx->n_factors_resident;
+    const icg_asm_plan &pl = pt.plan;
+    bool any_new = false;
+    for (int w = 0; w < W; w++) any_new |= reassemble[w] != 0;
+    if (any_new && (!ctx->rJ_valid || !ctx->rJ_has_jac)) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Jacobians: evaluate with want_jac first");
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (P > 512) return icg_fail(ctx, ICG_ERR_CAPACITY, "reduced systems of more than 512 camera columns are not supported (%d)", P);
+    const int TQ = (P + 3) / 4, NT = TQ * (TQ + 1) / 2;
+    const size_t red_lds = sizeof(double) * ((size_t) SCH_LT * 4 * TQ + 2 * SCH_LT); // <= 64.5 KB at P = 512
+    if (int rca = rpj_allow_lds(ctx, k_schur_reduce_w, red_lds, 1)) return rca;
+    // system layout
+    if (!pt.sys_valid || pt.sys_P != P) {
+        for (int w = 0; w < W; w++)
+            if (!reassemble[w]) return icg_fail(ctx, ICG_ERR_INVALID, "window %d: nothing resident of size %d to re-damp", w, P);
+        pt.sys_off.assign((size_t) W + 1, 0);
+        for (int w = 0; w < W; w++) {
+            const int64_t N = P + (pt.lm_off[(size_t) w + 1] - pt.lm_off[(size_t) w]);
+            pt.sys_off[(size_t) w + 1] = pt.sys_off[(size_t) w] + N * N + N + (N - P);
+        }
+        pt.damp.assign((size_t) W, 0.0);
+    }
+    int rc = ensure_sys_capacity(ctx, (size_t) pt.sys_off[(size_t) W] + 8);
+    if (rc) return rc;
+    icg_partition &other = &pt == &ctx->part_1 ? ctx->part_w : ctx->part_1;
+    other.sys_valid      = 0; // (d_sys is shared: whatever the other partition left there is overwritten)
+    pt.sys_valid         = 0;
+    // owner of every camera column of every window (k_asm_camera / k_asm_landmarks)
+    std::vector<int16_t> owner((size_t) W * P, (int16_t) -1);
+    int Lmax = 1;
+    for (int w = 0; w < W; w++) {
+        Lmax        = std::max(Lmax, pt.lm_off[(size_t) w + 1] - pt.lm_off[(size_t) w]);
+        int16_t *ow = &owner[(size_t) w * P];
+        auto claim  = [&](int col, int width, int code, const char *what) -> int {
+            if (col < 0) return 0;
+            if (col + width > P) return icg_fail(ctx, ICG_ERR_INVALID, "window %d: %s column %d outside the reduced system (%d)", w, what, col, P);
+            for (int x = 0; x < width; x++) {
+                if (ow[col + x] != -1) return icg_fail(ctx, ICG_ERR_INVALID, "window %d: camera column %d is claimed by two blocks", w, col + x);
+                ow[col + x] = (int16_t) ((code << 3) | (code == ASM_EXT && width == 1 ? 6 : x));
+            }
+            return 0;
+        };
+        for (int k = pl.pose_off[(size_t) w]; k < pl.pose_off[(size_t) w + 1]; k++) {
+            const int g = pl.pose_glob[(size_t) k];
+            if (g >= ctx->last_n_poses) return icg_fail(ctx, ICG_ERR_INVALID, "pose %d of the factors is beyond the %d evaluated poses", g, ctx->last_n_poses);
+            if ((rc = claim(col_pose[g], 6, k - pl.pose_off[(size_t) w], "pose"))) return rc;
+        }
+        if ((rc = claim(col_ext[w], 6, ASM_EXT, "extrinsic"))) return rc;
+        if ((rc = claim(col_td[w], 1, ASM_EXT, "td"))) return rc;
+    }
+    for (int w = 0; w < W; w++)
+        if (reassemble[w] || damp[w] != pt.damp[(size_t) w]) pt.damp[(size_t) w] = damp[w];
+    std::vector<win_desc> wd;
+    build_win_desc(pt, reassemble, damp, wd);
+    icg_call c(ctx);
+    rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(int16_t) * owner.size() + (size_t) n + sizeof(double) * ((size_t) W * ((size_t) P * P + 2 * (size_t) P + 1)) + 8192);
+    if (rc) return rc;
+    const win_desc *d_wd = c.in(wd.data(), (size_t) W);
+    const int16_t *d_own = c.in(owner.data(), owner.size());
+    const uint8_t *d_act = active ? c.in(active, (size_t) n) : nullptr;
+    auto t_prep = tnow();
+    if ((rc = c.seal())) return rc;
+    // (the zero-copy region is allocated LAST: finish() copies ONE device range back that spans all mirrored outputs, and must not run
+    // over memory the kernel wrote through the host mapping)
+    double *d_cost = c.out(any_new ? cost : (double *) nullptr, (size_t) W);
+    double *d_S    = (S_view || resident) ? nullptr : c.out(S, (size_t) W * P * P);
+    double *d_s    = c.out(s, (size_t) W * P);
+    double *d_dg   = c.out(diag_cc, (size_t) W * P); // user pointer may be null: still a valid device scratch
+    if (S_view) {
+        d_S     = c.out_zc((double *) nullptr, (size_t) W * P * P);
+        *S_view = d_S;
+    }
+    if (resident) {
+        if ((size_t) W * P * P > ctx->redS_cap) {
+            ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_redS) (void) hipFree(ctx->d_redS);
+            ctx->d_redS = nullptr, ctx->redS_cap = 0;
+            ICG_HIP(ctx, hipMalloc((void **) &ctx->d_redS, sizeof(double) * (size_t) W * P * P));
+            ctx->redS_cap = (size_t) W * P * P;
+        }
+        d_S = ctx->d_redS;
+    }
+    const double *d_r = ctx->d_rJ, *d_J = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
+    ICG_LAUNCH_GUARD(c);
+    if (any_new) {
+        icg_prof_scope ps(ctx, "reproj_normal");
+        if (pl.n_runs > 0)
+            hipLaunchKernelGGL(k_asm_runs, dim3((unsigned) ((pl.n_runs + 3) / 4)), dim3(256), 0, ctx->stream, pl.n_runs, reinterpret_cast<const int4 *>(pl.d_runs),
+                               d_wd, (const int32_t *) pl.d_perm, d_r, d_J, d_act, pl.d_part);
+        hipLaunchKernelGGL(k_asm_camera, dim3((unsigned) ((P * P + P + 255) / 256), W), dim3(256), 0, ctx->stream, d_wd, (const int32_t *) pl.d_run_off,
+                           (const int32_t *) pl.d_pair_run, pl.Kmax, d_own, P, (const double *) pl.d_part, ctx->d_sys);
+        const int LB = std::max(1, 1024 / (P + 2)); // landmarks per workgroup: at most four cells per thread
+        hipLaunchKernelGGL(k_asm_landmarks, dim3((unsigned) ((Lmax + LB - 1) / LB), W), dim3(256), 0, ctx->stream, d_wd, d_own, P, LB,
+                           (const int32_t *) pl.d_lm_foff, reinterpret_cast<const int4 *>(pl.d_lrec), d_r, d_J, d_act, ctx->d_sys);
+    }
+    {
+        icg_prof_scope ps(ctx, "schur_reduce");
+        hipLaunchKernelGGL(k_schur_inv_w, dim3((Lmax + 255) / 256, W), dim3(256), 0, ctx->stream, d_wd, P, ctx->d_sys, min_diag, max_diag);
+        hipLaunchKernelGGL(k_schur_reduce_w, dim3((unsigned) ((NT + 255) / 256), W), dim3(256), red_lds, ctx->stream, d_wd, P, (const double *) ctx->d_sys, d_S, d_s,
+                           d_dg, (S_view || resident) ? 1 : 0);
+        // the cost belongs to the linearization point: only meaningful while the resident residuals are the ones assembled
+        if (any_new) hipLaunchKernelGGL(k_reproj_cost_w, dim3(W), dim3(256), 0, ctx->stream, d_wd, d_r, d_act, ctx->last_huber, d_cost);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    auto t_launch = tnow();
+    if (tdbg) (void) hipStreamSynchronize(ctx->stream);
+    auto t_kernels = tnow();
+    if ((rc = c.finish())) return rc;
+    if (tdbg) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[icg_reproj_schur] W=%d: host prep %.3f, h2d+launch %.3f, kernels %.3f, d2h+copy-out %.3f ms\n", W, ms(t_begin, t_prep),
+                ms(t_prep, t_launch), ms(t_launch, t_kernels), ms(t_kernels, tnow()));
+    }
+    pt.sys_P = P, pt.sys_valid = 1;
+    ctx->sys_min_diag = min_diag, ctx->sys_max_diag = max_diag;
+    return ICG_OK;
+}
+
+static int backsub_impl(icg_ctx *ctx, icg_partition &pt, int P, const double *delta_c, double *delta_l, double *lm_terms) {
+    const int W = pt.W, n_lm = pt.lm_off[(size_t) W];
+    if (n_lm == 0) return ICG_OK;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    std::vector<win_desc> wd;
+    build_win_desc(pt, nullptr, nullptr, wd);
+    icg_call c(ctx);
+    int rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(double) * ((size_t) W * P + 3 * (size_t) n_lm + 2 * (size_t) W) + 4096);
+    if (rc) return rc;
+    const win_desc *d_wd = c.in(wd.data(), (size_t) W);
+    const double *d_dc   = c.in(delta_c, (size_t) W * P);
+    if ((rc = c.seal())) return rc;
+    double *d_dl = c.out(delta_l, (size_t) n_lm);
+    double *d_tm = c.out(lm_terms, 2 * (size_t) W);
+    double *d_lt = c.out((double *) nullptr, 2 * (size_t) n_lm);
+    ICG_LAUNCH_GUARD(c);
+    {
+        icg_prof_scope ps(ctx, "schur_backsub");
+        hipLaunchKernelGGL(k_schur_backsub_w, dim3(n_lm), dim3(64), 0, ctx->stream, d_wd, W > 1 ? (const int32_t *) ctx->d_lmwin : (const int32_t *) nullptr, 0, P,
+                           (const double *) ctx->d_sys, d_dc, d_dl, d_lt, ctx->sys_min_diag, ctx->sys_max_diag);
+        hipLaunchKernelGGL(k_terms_reduce_w, dim3(W), dim3(256), 0, ctx->stream, d_wd, (const double *) d_lt, d_tm);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}
+
+static int cost_impl(icg_ctx *ctx, icg_partition &pt, const uint8_t *active, double *cost) {
+    const int W = pt.W, n = ctx->n_factors_resident;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    std::vector<win_desc> wd;
+    build_win_desc(pt, nullptr, nullptr, wd);
+    icg_call c(ctx);
+    int rc = c.reserve(sizeof(win_desc) * (size_t) W + (size_t) n + sizeof(double) * (size_t) W + 4096);
+    if (rc) return rc;
+    const win_desc *d_wd = c.in(wd.data(), (size_t) W);
+    const uint8_t *d_act = active ? c.in(active, (size_t) n) : nullptr;
+    if ((rc = c.seal())) return rc;
+    double *d_cost = c.out(cost, (size_t) W);
+    ICG_LAUNCH_GUARD(c);
+    {
+        icg_prof_scope ps(ctx, "reproj_cost");
+        hipLaunchKernelGGL(k_reproj_cost_w, dim3(W), dim3(256), 0, ctx->stream, d_wd, (const double *) ctx->d_rJ, d_act, ctx->last_huber, d_cost);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}
+
+// h_ll of every landmark (global landmark order of the partition) from the systems left resident by the last assembly: the diagonal
+// element (P + l, P + l) of each window's block
+__global__ void k_lm_diag_w(const win_desc *wd, int P, const double *sys, double *h_ll) {
+    const win_desc W = wd[blockIdx.y];
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= W.L) return;
+    const size_t N = (size_t) P + W.L;
+    h_ll[W.lm_begin + l] = sys[W.sys_off + (size_t) (P + l) * N + P + l];
+}
+
+static int landmark_diag_impl(icg_ctx *ctx, icg_partition &pt, double *h_ll) {
+    const int W = pt.W, P = pt.sys_P, n_lm = pt.lm_off[(size_t) W];
+    if (n_lm == 0) return ICG_OK;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    std::vector<win_desc> wd;
+    build_win_desc(pt, nullptr, nullptr, wd);
+    int Lmax = 1;
+    for (int w = 0; w < W; w++) Lmax = std::max(Lmax, (int) wd[(size_t) w].L);
+    icg_call c(ctx);
+    int rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(double) * (size_t) n_lm + 4096);
+    if (rc) return rc;
+    const win_desc *d_wd = c.in(wd.data(), (size_t) W);
+    if ((rc = c.seal())) return rc;
+    double *d_out = c.out(h_ll, (size_t) n_lm);
+    ICG_LAUNCH_GUARD(c);
+    {
+        icg_prof_scope ps(ctx, "schur_reduce");
+        hipLaunchKernelGGL(k_lm_diag_w, dim3((Lmax + 255) / 256, W), dim3(256), 0, ctx->stream, d_wd, P, (const double *) ctx->d_sys, d_out);
+    }
+    ICG_HIP(ctx, hipGetLastError());
+    return c.finish();
+}
+
+// ---- single window: every resident factor ----------------------------------------------------------------------------------------------
+extern "C" int icg_reproj_schur(icg_ctx *ctx, int P, const int32_t *col_pose, int32_t col_ext, int32_t col_td, const uint8_t *active,
+                                int reassemble, double damp, double min_diag, double max_diag, double *S, double *s, double *diag_cc,
+                                double *cost) {
+    if (!ctx || P <= 0 || !col_pose || !S || !s) return ICG_ERR_INVALID;
+    if (ctx->n_factors_resident == 0) return icg_fail(ctx, ICG_ERR_INVALID, "no resident factors");
+    if (reassemble && (!ctx->rJ_valid || !ctx->rJ_has_jac))
+        return icg_fail(ctx, ICG_ERR_INVALID, "no resident Jacobians: call icg_reproj_eval_resident with want_jac first");
+    if (!reassemble && (!ctx->part_1.sys_valid || ctx->part_1.sys_P != P))
+        return icg_fail(ctx, ICG_ERR_INVALID, "no resident normal equations of size %d to re-damp", P);
+    int rc = single_partition(ctx, ctx->last_n_lm);
+    if (rc) return rc;
+    const uint8_t re = reassemble ? 1 : 0;
+    return schur_impl(ctx, ctx->part_1, P, col_pose, &col_ext, &col_td, active, &re, &damp, min_diag, max_diag, S, nullptr, false, s, diag_cc,
+                      reassemble ? cost : nullptr);
+}
+
+extern "C" int icg_reproj_landmark_diag(icg_ctx *ctx, double *h_ll) {
+    if (!ctx || !h_ll) return ICG_ERR_INVALID;
+    if (!ctx->part_1.sys_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Schur system: call icg_reproj_schur first");
+    return landmark_diag_impl(ctx, ctx->part_1, h_ll);
+}
+
+extern "C" int icg_reproj_backsub(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
+    if (!ctx || !delta_c || !delta_l) return ICG_ERR_INVALID;
+    if (!ctx->part_1.sys_valid || ctx->part_1.sys_P != P) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Schur system of size %d: call icg_reproj_schur first", P);
+    return backsub_impl(ctx, ctx->part_1, P, delta_c, delta_l, lm_terms);
+}
+
+extern "C" int icg_reproj_cost(icg_ctx *ctx, const uint8_t *active, double *cost) {
+    if (!ctx || !cost) return ICG_ERR_INVALID;
+    if (!ctx->rJ_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident residuals: call icg_reproj_eval_resident first");
+    *cost = 0.0;
+    if (ctx->n_factors_resident == 0) return ICG_OK;
+    // (the cost needs the factor range only: a one-window descriptor without a plan)
+    icg_partition &pt = ctx->part_1;
+    if (pt.W != 1 || pt.fac_off.size() != 2 || pt.fac_off[1] != ctx->n_factors_resident) {
+        pt.W = 1, pt.fac_off = {0, ctx->n_factors_resident}, pt.lm_off = {0, ctx->last_n_lm};
+        pt.plan_valid = false, pt.sys_valid = 0;
+    }
+    return cost_impl(ctx, pt, active, cost);
+}
+
+// M2 for a caller-defined dense layout (MarginalizationInfo::constructEquation, factors/marginalization_info.h:195-230): the system is
+// assembled in the compact layout above (free poses in pose order, then extrinsic, then td; landmark l in row V + l) by the same kernels
+// and spread into the caller's local_size x local_size matrix on the host — every cell has one source, no sum is formed there.
+extern "C" int icg_reproj_accumulate_normal(icg_ctx *ctx, int local_size, const int32_t *col_pose, int32_t col_ext,
+                                            const int32_t *col_lm, int32_t col_td, double *H0, double *b0) {
+    if (!ctx || local_size <= 0 || !col_pose || !col_lm || !H0 || !b0) return ICG_ERR_INVALID;
+    if (!ctx->rJ_valid || !ctx->rJ_has_jac) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Jacobians: call icg_reproj_eval_* with want_jac first");
+    const int n = ctx->n_factors_resident, L = ctx->last_n_lm;
+    if (n == 0) return ICG_OK;
+    auto inside = [&](int col, int width) { return col < 0 || col + width <= local_size; };
+    std::vector<int32_t> vcol((size_t) ctx->last_n_poses, -1), vmap;
+    for (int k = 0; k < ctx->last_n_poses; k++)
+        if (col_pose[k] >= 0) {
+            if (!inside(col_pose[k], 6)) return icg_fail(ctx, ICG_ERR_INVALID, "pose %d: column %d outside the system (%d)", k, col_pose[k], local_size);
+            vcol[(size_t) k] = (int32_t) vmap.size();
+            for (int x = 0; x < 6; x++) vmap.push_back(col_pose[k] + x);
+        }
+    if (!inside(col_ext, 6) || !inside(col_td, 1)) return icg_fail(ctx, ICG_ERR_INVALID, "ext/td column outside the system (%d)", local_size);
+    int vext = -1, vtd = -1;
+    if (col_ext >= 0) {
+        vext = (int) vmap.size();
+        for (int x = 0; x < 6; x++) vmap.push_back(col_ext + x);
+    }
+    if (col_td >= 0) vtd = (int) vmap.size(), vmap.push_back(col_td);
+    for (int l = 0; l < L; l++)
+        if (!inside(col_lm[l], 1)) return icg_fail(ctx, ICG_ERR_INVALID, "landmark %d: column %d outside the system (%d)", l, col_lm[l], local_size);
+    const int V = std::max(1, (int) vmap.size());
+    int rc = single_partition(ctx, L);
+    if (rc) return rc;
+    const size_t N = (size_t) V + L;
+    std::vector<double> S((size_t) V * V), s((size_t) V), sys(N * N + N);
+    const uint8_t re  = 1;
+    const double zero = 0.0;
+    if ((rc = schur_impl(ctx, ctx->part_1, V, vcol.data(), &vext, &vtd, nullptr, &re, &zero, 0.0, 0.0, S.data(), nullptr, false, s.data(), nullptr, nullptr))) return rc;
+    ICG_HIP(ctx, hipMemcpyAsync(sys.data(), ctx->d_sys, sizeof(double) * (N * N + N), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = icg_stream_wait(ctx))) return rc;
+    ctx->part_1.sys_valid = 0; // (a by-product: not a system the Schur entry points may re-damp)
+    const size_t LS = (size_t) local_size;
+    const double *H = sys.data(), *b = H + N * N;
+    for (size_t a = 0; a < vmap.size(); a++) {
+        for (size_t c = 0; c < vmap.size(); c++) H0[(size_t) vmap[a] * LS + (size_t) vmap[c]] += H[a * N + c];
+        b0[(size_t) vmap[a]] += b[a];
+    }
+    for (int l = 0; l < L; l++) {
+        if (col_lm[l] < 0) continue;
+        const size_t cl = (size_t) col_lm[l], row = ((size_t) V + (size_t) l) * N;
+        for (size_t a = 0; a < vmap.size(); a++) {
+            H0[cl * LS + (size_t) vmap[a]] += H[row + a];
+            H0[(size_t) vmap[a] * LS + cl] += H[row + a];
+        }
+        H0[cl * LS + cl] += H[row + (size_t) V + (size_t) l];
+        b0[cl] += b[(size_t) V + (size_t) l];
+    }
+    return ICG_OK;
+}
+
+// ---- f1, many windows per launch ------------------------------------------------------------------------------------------------
+// One solver in flight per stream is bounded by the runtime's rate of small launches and copies (~100 per window and solve, DESIGN.md
+// §6).  Here the windows of many streams advance in lock-step: ONE evaluation, ONE assembly, ONE reduction, ONE back-substitution
+// call per LM step for all of them.  The resident factor set is partitioned into W windows (factors sorted by window, landmarks
+// contiguous per window, poses indexed globally); every window has its own extrinsic / td, its own reduced system of the common
+// size P and its own damping.  Window w's system lives at d_sys + sys_off[w]: H (N_w x N_w, N_w = P + L_w) | b (N_w) | inv (L_w).
 extern "C" int icg_reproj_set_windows(icg_ctx *ctx, int n_windows, const int32_t *fac_off, const int32_t *lm_off) {
     if (!ctx || n_windows <= 0 || !fac_off || !lm_off) return ICG_ERR_INVALID;
     const int n = ctx->n_factors_resident;
     if (fac_off[0] != 0 || fac_off[n_windows] != n) return icg_fail(ctx, ICG_ERR_INVALID, "fac_off must cover the %d resident factors", n);
+    if (lm_off[0] != 0) return icg_fail(ctx, ICG_ERR_INVALID, "lm_off must start at 0");
     for (int w = 0; w < n_windows; w++)
         if (fac_off[w + 1] < fac_off[w] || lm_off[w + 1] < lm_off[w]) return icg_fail(ctx, ICG_ERR_INVALID, "window %d: offsets not monotone", w);
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
@@ -1087,37 +1290,23 @@ extern "C" int icg_reproj_set_windows(icg_ctx *ctx, int n_windows, const int32_t
     if (n) ICG_HIP(ctx, hipMemcpyAsync(ctx->d_fwin, fwin.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
     if (n_lm) ICG_HIP(ctx, hipMemcpyAsync(ctx->d_lmwin, lwin.data(), sizeof(int32_t) * (size_t) n_lm, hipMemcpyHostToDevice, ctx->stream));
     ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // pose -> window from the resident index arrays (one read-back per partition)
-    std::vector<int32_t> h_idx((size_t) 2 * std::max(n, 1));
-    if (n) {
-        ICG_HIP(ctx, hipMemcpyAsync(h_idx.data(), ctx->d_fidx, sizeof(int32_t) * 2 * (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
-        ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    int max_pose = -1;
-    for (int f = 0; f < 2 * n; f++) max_pose = std::max(max_pose, (int) h_idx[(size_t) f]);
-    ctx->w_pose_win.assign((size_t) (max_pose + 1), -1);
-    for (int w = 0; w < n_windows; w++)
-        for (int f = fac_off[w]; f < fac_off[w + 1]; f++) {
-            for (int side = 0; side < 2; side++) {
-                int32_t &pw = ctx->w_pose_win[(size_t) h_idx[(size_t) side * n + f]];
-                if (pw >= 0 && pw != w) return icg_fail(ctx, ICG_ERR_INVALID, "pose %d is used by windows %d and %d", (int) h_idx[(size_t) side * n + f], pw, w);
-                pw = w;
-            }
-        }
-    ctx->n_windows = n_windows;
-    ctx->w_fac_off.assign(fac_off, fac_off + n_windows + 1);
-    ctx->w_lm_off.assign(lm_off, lm_off + n_windows + 1);
-    ctx->wsys_valid = 0;
-    return ICG_OK;
+    icg_partition &pt = ctx->part_w;
+    pt.W              = n_windows;
+    pt.fac_off.assign(fac_off, fac_off + n_windows + 1);
+    pt.lm_off.assign(lm_off, lm_off + n_windows + 1);
+    pt.sys_valid = 0;
+    int rc       = asm_plan_build(ctx, pt);
+    if (rc) pt.W = 0;
+    return rc;
 }
 
 extern "C" int icg_reproj_eval_windows(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm, const double *invdepth,
                                        const double *td, int want_jac, double huber_delta) {
     if (!ctx || !poses || !ext || !invdepth || !td || n_poses <= 0 || n_lm <= 0) return ICG_ERR_INVALID;
-    if (ctx->n_windows <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition: call icg_reproj_set_windows first");
-    if (n_lm != ctx->w_lm_off[(size_t) ctx->n_windows]) return icg_fail(ctx, ICG_ERR_INVALID, "n_lm does not match the window partition");
+    if (ctx->part_w.W <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition: call icg_reproj_set_windows first");
+    if (n_lm != ctx->part_w.lm_off[(size_t) ctx->part_w.W]) return icg_fail(ctx, ICG_ERR_INVALID, "n_lm does not match the window partition");
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    const int n = ctx->n_factors_resident, W = ctx->n_windows;
+    const int n = ctx->n_factors_resident, W = ctx->part_w.W;
     if (n == 0) return ICG_OK;
     icg_call c(ctx);
     int rc = c.reserve(sizeof(double) * ((size_t) n_poses * 7 + 8 * (size_t) W + (size_t) n_lm) + 4096);
@@ -1153,170 +1342,10 @@ extern "C" int icg_reproj_eval_windows(icg_ctx *ctx, int n_poses, const double *
     return c.finish();
 }
 
-// builds the per-window descriptors (host) for the current partition; reassemble / damp may be null (all re-assembled / keep damping)
-static void build_win_desc(icg_ctx *ctx, int P, const int32_t *vcol_ext, const int32_t *vcol_td, const int32_t *V, const uint8_t *reassemble,
-                           const double *damp, std::vector<win_desc> &out) {
-    const int W = ctx->n_windows;
-    out.resize((size_t) W);
-    for (int w = 0; w < W; w++) {
-        win_desc &d = out[(size_t) w];
-        d.fac_begin = ctx->w_fac_off[(size_t) w], d.fac_end = ctx->w_fac_off[(size_t) w + 1];
-        d.lm_begin = ctx->w_lm_off[(size_t) w], d.L = ctx->w_lm_off[(size_t) w + 1] - ctx->w_lm_off[(size_t) w];
-        d.sys_off    = ctx->w_sys_off[(size_t) w];
-        d.vcol_ext   = vcol_ext ? vcol_ext[w] : -1;
-        d.vcol_td    = vcol_td ? vcol_td[w] : -1;
-        d.V          = V ? V[w] : 0;
-        d.reassemble = reassemble ? reassemble[w] : 1;
-        d.damp       = damp ? damp[w] : ctx->w_damp[(size_t) w];
-    }
-}
-
-// S_view != nullptr: the reduced systems are written by the reduction kernel straight into the context's pinned staging memory (zero-copy)
-// and *S_view points there — no device-to-host copy and no 9 MB copy-out per LM step at 256 windows; valid until the next call on ctx
-// S and S_view both null: the reduced systems stay on the device (ctx->d_redS)
-static int schur_windows_impl(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
-                              const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, double *S, const double **S_view,
-                              double *s, double *diag_cc, double *cost) {
+static int windows_args_ok(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *reassemble,
+                           const double *damp, double *s) {
     if (!ctx || P <= 0 || !col_pose || !col_ext || !col_td || !reassemble || !damp || !s) return ICG_ERR_INVALID;
-    const bool tdbg = getenv("ICG_ABI_DEBUG") != nullptr;
-    auto tnow       = [] { return std::chrono::steady_clock::now(); };
-    auto t_begin    = tnow();
-    const int W = ctx->n_windows, n = ctx->n_factors_resident;
-    if (W <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition: call icg_reproj_set_windows first");
-    bool any_new = false;
-    for (int w = 0; w < W; w++) any_new |= reassemble[w] != 0;
-    if (any_new && (!ctx->rJ_valid || !ctx->rJ_has_jac)) return icg_fail(ctx, ICG_ERR_INVALID, "no resident Jacobians: call icg_reproj_eval_windows first");
-    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    // system layout
-    if (!ctx->wsys_valid || ctx->wsys_P != P) {
-        for (int w = 0; w < W; w++)
-            if (!reassemble[w]) return icg_fail(ctx, ICG_ERR_INVALID, "window %d: nothing resident to re-damp", w);
-        ctx->w_sys_off.assign((size_t) W + 1, 0);
-        for (int w = 0; w < W; w++) {
-            const int64_t N = P + (ctx->w_lm_off[(size_t) w + 1] - ctx->w_lm_off[(size_t) w]);
-            ctx->w_sys_off[(size_t) w + 1] = ctx->w_sys_off[(size_t) w] + N * N + N + (N - P);
-        }
-        ctx->w_damp.assign((size_t) W, 0.0);
-    }
-    int rc = ensure_sys_capacity(ctx, (size_t) ctx->w_sys_off[(size_t) W] + 8);
-    if (rc) return rc;
-    // compact camera space per window (free poses in pose order, then ext, then td)
-    std::vector<int32_t> vcol_pose((size_t) ctx->last_n_poses, -1), Vw((size_t) W, 0), vce((size_t) W, -1), vct((size_t) W, -1);
-    std::vector<std::vector<int32_t>> vmaps((size_t) W);
-    // window of every pose (recorded at icg_reproj_set_windows from the resident index arrays): a pose column is compact within
-    // the window whose factors use the pose
-    std::vector<int32_t> pose_win((size_t) ctx->last_n_poses, -1);
-    for (int k = 0; k < ctx->last_n_poses && k < (int) ctx->w_pose_win.size(); k++) pose_win[(size_t) k] = ctx->w_pose_win[(size_t) k];
-    for (int k = 0; k < ctx->last_n_poses; k++) {
-        const int w = pose_win[(size_t) k];
-        if (w < 0 || col_pose[k] < 0) continue;
-        if (col_pose[k] + 6 > P) return icg_fail(ctx, ICG_ERR_INVALID, "pose %d: column %d outside the reduced system (%d)", k, col_pose[k], P);
-        vcol_pose[(size_t) k] = (int32_t) vmaps[(size_t) w].size();
-        for (int x = 0; x < 6; x++) vmaps[(size_t) w].push_back(col_pose[k] + x);
-    }
-    int Vmax = 1;
-    for (int w = 0; w < W; w++) {
-        if ((col_ext[w] >= 0 && col_ext[w] + 6 > P) || (col_td[w] >= 0 && col_td[w] + 1 > P))
-            return icg_fail(ctx, ICG_ERR_INVALID, "window %d: ext/td column outside the reduced system", w);
-        if (col_ext[w] >= 0) {
-            vce[(size_t) w] = (int32_t) vmaps[(size_t) w].size();
-            for (int x = 0; x < 6; x++) vmaps[(size_t) w].push_back(col_ext[w] + x);
-        }
-        if (col_td[w] >= 0) {
-            vct[(size_t) w] = (int32_t) vmaps[(size_t) w].size();
-            vmaps[(size_t) w].push_back(col_td[w]);
-        }
-        Vw[(size_t) w] = (int32_t) vmaps[(size_t) w].size();
-        Vmax           = std::max(Vmax, (int) Vw[(size_t) w]);
-    }
-    const size_t lds = sizeof(double) * ((size_t) Vmax * Vmax + Vmax + LM_SLOTS * 16) + sizeof(int) * LM_SLOTS;
-    if (lds > RPJ_LDS_LIMIT)
-        return icg_fail(ctx, ICG_ERR_CAPACITY, "a window has %d free camera columns: more than the LDS tile of the batched assembly holds (138)", Vmax);
-    if ((rc = rpj_allow_lds(ctx, k_reproj_normal_schur_w, lds, 1))) return rc;
-    std::vector<int32_t> vmap_all((size_t) W * Vmax, 0);
-    for (int w = 0; w < W; w++) std::copy(vmaps[(size_t) w].begin(), vmaps[(size_t) w].end(), vmap_all.begin() + (size_t) w * Vmax);
-    for (int w = 0; w < W; w++)
-        if (reassemble[w] || damp[w] != ctx->w_damp[(size_t) w]) ctx->w_damp[(size_t) w] = damp[w];
-    std::vector<win_desc> wd;
-    build_win_desc(ctx, P, vce.data(), vct.data(), Vw.data(), reassemble, damp, wd);
-    // block tables of the assembly launch
-    std::vector<int32_t> blk_win, blk_first;
-    int Lmax = 1;
-    for (int w = 0; w < W; w++) {
-        Lmax = std::max(Lmax, (int) wd[(size_t) w].L);
-        if (!reassemble[w]) continue;
-        for (int f = wd[(size_t) w].fac_begin; f < wd[(size_t) w].fac_end; f += NRM_BLOCK) {
-            blk_win.push_back(w);
-            blk_first.push_back(f);
-        }
-    }
-    icg_call c(ctx);
-    rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(int32_t) * (vcol_pose.size() + vmap_all.size() + 2 * blk_win.size() + 16) + (size_t) n +
-                   sizeof(double) * ((size_t) W * ((size_t) P * P + 2 * (size_t) P + 1)) + 8192);
-    if (rc) return rc;
-    const win_desc *d_wd  = c.in(wd.data(), (size_t) W);
-    const int32_t *d_vp   = c.in(vcol_pose.data(), vcol_pose.size());
-    const int32_t *d_vm   = c.in(vmap_all.data(), vmap_all.size());
-    const int32_t *d_bw   = blk_win.empty() ? nullptr : c.in(blk_win.data(), blk_win.size());
-    const int32_t *d_bf   = blk_first.empty() ? nullptr : c.in(blk_first.data(), blk_first.size());
-    const uint8_t *d_act  = active ? c.in(active, (size_t) n) : nullptr;
-    std::vector<double> zeros((size_t) W, 0.0);
-    double *d_cost = c.inout(zeros.data(), any_new ? cost : (double *) nullptr, (size_t) W);
-    auto t_prep = tnow();
-    if ((rc = c.seal())) return rc;
-    // (the zero-copy region is allocated LAST: finish() copies ONE device range back that spans all mirrored outputs, and must not run
-    // over memory the kernel wrote through the host mapping)
-    const bool resident = !S && !S_view; // the reduced systems stay on the device (solved there: icg_reproj_solve_backsub_windows)
-    double *d_S  = (S_view || resident) ? nullptr : c.out(S, (size_t) W * P * P);
-    double *d_s  = c.out(s, (size_t) W * P);
-    double *d_dg = c.out(diag_cc, (size_t) W * P);
-    if (S_view) {
-        d_S     = c.out_zc((double *) nullptr, (size_t) W * P * P);
-        *S_view = d_S;
-    }
-    if (resident) {
-        if ((size_t) W * P * P > ctx->redS_cap) {
-            ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->d_redS) (void) hipFree(ctx->d_redS);
-            ctx->d_redS = nullptr, ctx->redS_cap = 0;
-            ICG_HIP(ctx, hipMalloc((void **) &ctx->d_redS, sizeof(double) * (size_t) W * P * P));
-            ctx->redS_cap = (size_t) W * P * P;
-        }
-        d_S = ctx->d_redS;
-    }
-    const double *d_r = ctx->d_rJ, *d_J = ctx->d_rJ + 2 * (size_t) ctx->factors_cap;
-    ICG_LAUNCH_GUARD(c);
-    if (any_new) {
-        icg_prof_scope ps(ctx, "reproj_normal");
-        hipLaunchKernelGGL(k_sys_clear_w, dim3(32, W), dim3(256), 0, ctx->stream, d_wd, P, ctx->d_sys);
-        hipLaunchKernelGGL(k_reproj_normal_schur_w, dim3((unsigned) blk_win.size()), dim3(NRM_BLOCK), lds, ctx->stream, d_wd, d_bw, d_bf, d_r, d_J,
-                           (const int32_t *) ctx->d_fidx, (const int32_t *) (ctx->d_fidx + n), (const int32_t *) (ctx->d_fidx + 2 * (size_t) n), d_vp,
-                           d_vm, Vmax, P, ctx->d_sys, d_act);
-    }
-    {
-        icg_prof_scope ps(ctx, "schur_reduce");
-        hipLaunchKernelGGL(k_schur_inv_w, dim3((Lmax + 255) / 256, W), dim3(256), 0, ctx->stream, d_wd, P, ctx->d_sys, min_diag, max_diag);
-        hipLaunchKernelGGL(k_schur_reduce_w, dim3((P + SCH_T - 1) / SCH_T, (P + SCH_T - 1) / SCH_T, W), dim3(SCH_T, SCH_T), 0, ctx->stream, d_wd, P,
-                           (const double *) ctx->d_sys, d_S, d_s, d_dg, (S_view || resident) ? 1 : 0);
-        if (any_new) {
-            // cost only of the windows that were re-assembled is meaningful; the others keep their previous value on the host side
-            hipLaunchKernelGGL(k_reproj_cost_w, dim3(4, W), dim3(256), 0, ctx->stream, d_wd, d_r, d_act, ctx->last_huber, d_cost);
-        }
-    }
-    ICG_HIP(ctx, hipGetLastError());
-    auto t_launch = tnow();
-    if (tdbg) {
-        (void) hipStreamSynchronize(ctx->stream);
-    }
-    auto t_kernels = tnow();
-    if ((rc = c.finish())) return rc;
-    if (tdbg) {
-        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[icg_reproj_schur_windows] W=%d: host prep %.3f, h2d+launch %.3f, kernels %.3f, d2h+copy-out %.3f ms\n", W, ms(t_begin, t_prep),
-                ms(t_prep, t_launch), ms(t_launch, t_kernels), ms(t_kernels, tnow()));
-    }
-    ctx->wsys_P = P, ctx->wsys_valid = 1;
-    ctx->sys_min_diag = min_diag, ctx->sys_max_diag = max_diag;
+    if (ctx->part_w.W <= 0 || !ctx->part_w.plan_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition: call icg_reproj_set_windows first");
     return ICG_OK;
 }
 
@@ -1325,39 +1354,43 @@ static int schur_windows_impl(icg_ctx *ctx, int P, const int32_t *col_pose, cons
 // allocation and a pinned re-allocation (4 ms at 256 C2 windows).  A hint: the calls themselves still grow what they need.
 extern "C" int icg_reproj_reserve_windows(icg_ctx *ctx, int P) {
     if (!ctx || P <= 0) return ICG_ERR_INVALID;
-    const int W = ctx->n_windows, n = ctx->n_factors_resident;
+    const icg_partition &pt = ctx->part_w;
+    const int W = pt.W, n = ctx->n_factors_resident;
     if (W <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition: call icg_reproj_set_windows first");
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
     size_t doubles = 0;
     for (int w = 0; w < W; w++) {
-        const size_t N = (size_t) P + (size_t) (ctx->w_lm_off[(size_t) w + 1] - ctx->w_lm_off[(size_t) w]);
+        const size_t N = (size_t) P + (size_t) (pt.lm_off[(size_t) w + 1] - pt.lm_off[(size_t) w]);
         doubles += N * N + N + (N - (size_t) P);
     }
     int rc = ensure_sys_capacity(ctx, doubles + 8);
     if (rc) return rc;
     icg_call c(ctx);
-    return c.reserve(sizeof(win_desc) * (size_t) W + sizeof(int32_t) * ((size_t) ctx->last_n_poses + (size_t) W * (size_t) P + 2 * ((size_t) n / NRM_BLOCK + (size_t) W) + 16) +
-                     (size_t) n + sizeof(double) * ((size_t) W * ((size_t) P * P + 2 * (size_t) P + 1)) + 8192);
+    return c.reserve(sizeof(win_desc) * (size_t) W + sizeof(int16_t) * (size_t) W * (size_t) P + (size_t) n +
+                     sizeof(double) * ((size_t) W * ((size_t) P * P + 2 * (size_t) P + 1)) + 8192);
 }
 
 extern "C" int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td,
                                         const uint8_t *active, const uint8_t *reassemble, const double *damp, double min_diag, double max_diag,
                                         double *S, double *s, double *diag_cc, double *cost) {
     if (!S) return ICG_ERR_INVALID;
-    return schur_windows_impl(ctx, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, S, nullptr, s, diag_cc, cost);
+    if (int rc = windows_args_ok(ctx, P, col_pose, col_ext, col_td, reassemble, damp, s)) return rc;
+    return schur_impl(ctx, ctx->part_w, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, S, nullptr, false, s, diag_cc, cost);
 }
 
 extern "C" int icg_reproj_schur_windows_view(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td,
                                              const uint8_t *active, const uint8_t *reassemble, const double *damp, double min_diag,
                                              double max_diag, const double **S_view, double *s, double *diag_cc, double *cost) {
     if (!S_view) return ICG_ERR_INVALID;
-    return schur_windows_impl(ctx, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, nullptr, S_view, s, diag_cc, cost);
+    if (int rc = windows_args_ok(ctx, P, col_pose, col_ext, col_td, reassemble, damp, s)) return rc;
+    return schur_impl(ctx, ctx->part_w, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, nullptr, S_view, false, s, diag_cc, cost);
 }
 
 extern "C" int icg_reproj_schur_windows_resident(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td,
                                                  const uint8_t *active, const uint8_t *reassemble, const double *damp, double min_diag,
                                                  double max_diag, double *s, double *diag_cc, double *cost) {
-    return schur_windows_impl(ctx, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, nullptr, nullptr, s, diag_cc, cost);
+    if (int rc = windows_args_ok(ctx, P, col_pose, col_ext, col_td, reassemble, damp, s)) return rc;
+    return schur_impl(ctx, ctx->part_w, P, col_pose, col_ext, col_td, active, reassemble, damp, min_diag, max_diag, nullptr, nullptr, true, s, diag_cc, cost);
 }
 
 // ---- reduced systems solved on the device -------------------------------------------------------------------------------------------
@@ -1444,7 +1477,7 @@ __global__ __launch_bounds__(256) void k_chol_solve_w(int P, const int32_t *Pw, 
 // win_idx[k]; stays on the device until replaced (a re-damped step re-uses it)
 extern "C" int icg_reproj_set_host_part_windows(icg_ctx *ctx, int P, int n_upd, const int32_t *win_idx, const double *packed) {
     if (!ctx || P <= 0 || n_upd < 0 || (n_upd > 0 && (!win_idx || !packed))) return ICG_ERR_INVALID;
-    const int W = ctx->n_windows;
+    const int W = ctx->part_w.W;
     if (W <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition: call icg_reproj_set_windows first");
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
     const size_t tri = (size_t) P * (P + 1) / 2;
@@ -1478,138 +1511,74 @@ extern "C" int icg_reproj_set_host_part_windows(icg_ctx *ctx, int P, int n_upd, 
 }
 
 // For every window with stepped[w] != 0: (S_w + hostS_w + diag(dd_w)) delta_c_w = rhs_w on the leading Pw[w] columns (batched Cholesky in
-// LDS, P <= 142), then the landmark back-substitution of icg_reproj_backsub_windows with those steps, in one call: per LM step only rhs, dd
-// go up and delta_c, ok, delta_l and the two model-decrease sums come back; the P x P systems never leave the device.
+// LDS: P^2 + P doubles per window have to fit one workgroup's LDS — P <= 142 on gfx950), then the landmark back-substitution of
+// icg_reproj_backsub_windows with those steps, in one call: per LM step only rhs, dd go up and delta_c, ok, delta_l and the two
+// model-decrease sums come back; the P x P systems never leave the device.
 extern "C" int icg_reproj_solve_backsub_windows(icg_ctx *ctx, int P, const int32_t *Pw, const uint8_t *stepped, const double *rhs,
                                                 const double *dd, double *delta_c, uint8_t *ok, double *delta_l, double *lm_terms) {
     if (!ctx || P <= 0 || !Pw || !stepped || !rhs || !dd || !delta_c || !ok) return ICG_ERR_INVALID;
-    if (!ctx->wsys_valid || ctx->wsys_P != P || !ctx->d_redS)
+    icg_partition &pt = ctx->part_w;
+    if (!pt.sys_valid || pt.sys_P != P || !ctx->d_redS)
         return icg_fail(ctx, ICG_ERR_INVALID, "no resident reduced systems of size %d: call icg_reproj_schur_windows_resident first", P);
-    const int W = ctx->n_windows, n_lm = ctx->w_lm_off[(size_t) W];
+    const int W = pt.W, n_lm = pt.lm_off[(size_t) W];
     const size_t lds = sizeof(double) * ((size_t) P * P + (size_t) P);
-    if (lds > RPJ_LDS_LIMIT) return icg_fail(ctx, ICG_ERR_CAPACITY, "reduced system of %d columns does not fit the LDS tile of the batched Cholesky (<= 142)", P);
+    if (lds > rpj_lds_limit(ctx))
+        return icg_fail(ctx, ICG_ERR_CAPACITY, "reduced system of %d columns does not fit the LDS tile of the batched Cholesky (%zu bytes per workgroup)", P, rpj_lds_limit(ctx));
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
     if (int rca = rpj_allow_lds(ctx, k_chol_solve_w, lds, 2)) return rca;
     int rc = icg_reproj_set_host_part_windows(ctx, P, 0, nullptr, nullptr); // (allocates a zero host part if none was ever set)
     if (rc) return rc;
     std::vector<win_desc> wd;
-    build_win_desc(ctx, P, nullptr, nullptr, nullptr, nullptr, nullptr, wd);
+    build_win_desc(pt, nullptr, nullptr, wd);
     icg_call c(ctx);
-    rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(int32_t) * (size_t) W + 2 * (size_t) W + sizeof(double) * (3 * (size_t) W * P + (size_t) n_lm + 2 * (size_t) W) + 8192);
+    rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(int32_t) * (size_t) W + 2 * (size_t) W + sizeof(double) * (3 * (size_t) W * P + 3 * (size_t) n_lm + 2 * (size_t) W) + 8192);
     if (rc) return rc;
     const win_desc *d_wd = c.in(wd.data(), (size_t) W);
     const int32_t *d_pw  = c.in(Pw, (size_t) W);
     const uint8_t *d_st  = c.in(stepped, (size_t) W);
     const double *d_rhs  = c.in(rhs, (size_t) W * P);
     const double *d_dd   = c.in(dd, (size_t) W * P);
-    std::vector<double> zeros(2 * (size_t) W, 0.0);
-    double *d_tm = c.inout(zeros.data(), lm_terms, 2 * (size_t) W);
     if ((rc = c.seal())) return rc;
-    double *d_dl   = n_lm > 0 && delta_l ? c.out(delta_l, (size_t) n_lm) : nullptr;
+    const bool want_l = n_lm > 0 && delta_l;
+    double *d_dl   = want_l ? c.out(delta_l, (size_t) n_lm) : nullptr;
+    double *d_tm   = c.out(want_l ? lm_terms : (double *) nullptr, 2 * (size_t) W);
     double *d_dco  = c.out(delta_c, (size_t) W * P);
     uint8_t *d_ok  = c.out(ok, (size_t) W);
+    double *d_lt   = want_l ? c.out((double *) nullptr, 2 * (size_t) n_lm) : nullptr;
     ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "schur_cholesky");
         hipLaunchKernelGGL(k_chol_solve_w, dim3(W), dim3(256), lds, ctx->stream, P, d_pw, d_st, (const double *) ctx->d_redS, (const double *) ctx->d_hostS,
                            d_rhs, d_dd, d_dco, d_ok);
     }
-    if (d_dl) {
+    if (want_l) {
         icg_prof_scope ps(ctx, "schur_backsub");
-        hipLaunchKernelGGL(k_schur_backsub_w, dim3(n_lm), dim3(64), 0, ctx->stream, d_wd, (const int32_t *) ctx->d_lmwin, P, (const double *) ctx->d_sys,
-                           (const double *) d_dco, d_dl, d_tm, ctx->sys_min_diag, ctx->sys_max_diag);
+        hipLaunchKernelGGL(k_schur_backsub_w, dim3(n_lm), dim3(64), 0, ctx->stream, d_wd, (const int32_t *) ctx->d_lmwin, 0, P, (const double *) ctx->d_sys,
+                           (const double *) d_dco, d_dl, d_lt, ctx->sys_min_diag, ctx->sys_max_diag);
+        hipLaunchKernelGGL(k_terms_reduce_w, dim3(W), dim3(256), 0, ctx->stream, d_wd, (const double *) d_lt, d_tm);
     }
     ICG_HIP(ctx, hipGetLastError());
     return c.finish();
-}
-
-// h_ll of every landmark (global landmark order of the partition) from the window systems left resident by the last
-// icg_reproj_schur_windows*: the diagonal (P + l, P + l) of each window's N x N block
-__global__ void k_lm_diag_w(const win_desc *wd, int P, const double *sys, double *h_ll) {
-    const win_desc W = wd[blockIdx.y];
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= W.L) return;
-    const size_t N = (size_t) P + W.L;
-    h_ll[W.lm_begin + l] = sys[W.sys_off + (size_t) (P + l) * N + P + l];
 }
 
 extern "C" int icg_reproj_landmark_diag_windows(icg_ctx *ctx, double *h_ll) {
     if (!ctx || !h_ll) return ICG_ERR_INVALID;
-    if (!ctx->wsys_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident window systems: call icg_reproj_schur_windows first");
-    const int W = ctx->n_windows, P = ctx->wsys_P, n_lm = ctx->w_lm_off[(size_t) W];
-    if (n_lm == 0) return ICG_OK;
-    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    std::vector<win_desc> wd;
-    build_win_desc(ctx, P, nullptr, nullptr, nullptr, nullptr, nullptr, wd);
-    int Lmax = 1;
-    for (int w = 0; w < W; w++) Lmax = std::max(Lmax, (int) wd[(size_t) w].L);
-    icg_call c(ctx);
-    int rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(double) * (size_t) n_lm + 4096);
-    if (rc) return rc;
-    const win_desc *d_wd = c.in(wd.data(), (size_t) W);
-    if ((rc = c.seal())) return rc;
-    double *d_out = c.out(h_ll, (size_t) n_lm);
-    ICG_LAUNCH_GUARD(c);
-    {
-        icg_prof_scope ps(ctx, "schur_reduce");
-        hipLaunchKernelGGL(k_lm_diag_w, dim3((Lmax + 255) / 256, W), dim3(256), 0, ctx->stream, d_wd, P, (const double *) ctx->d_sys, d_out);
-    }
-    ICG_HIP(ctx, hipGetLastError());
-    return c.finish();
+    if (!ctx->part_w.sys_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident window systems: call icg_reproj_schur_windows first");
+    return landmark_diag_impl(ctx, ctx->part_w, h_ll);
 }
 
 extern "C" int icg_reproj_backsub_windows(icg_ctx *ctx, int P, const double *delta_c, double *delta_l, double *lm_terms) {
     if (!ctx || !delta_c || !delta_l) return ICG_ERR_INVALID;
-    if (!ctx->wsys_valid || ctx->wsys_P != P) return icg_fail(ctx, ICG_ERR_INVALID, "no resident window systems of size %d: call icg_reproj_schur_windows first", P);
-    const int W = ctx->n_windows, n_lm = ctx->w_lm_off[(size_t) W];
-    if (n_lm == 0) return ICG_OK;
-    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    std::vector<win_desc> wd;
-    build_win_desc(ctx, P, nullptr, nullptr, nullptr, nullptr, nullptr, wd);
-    icg_call c(ctx);
-    int rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(double) * ((size_t) W * P + (size_t) n_lm + 2 * (size_t) W) + 4096);
-    if (rc) return rc;
-    const win_desc *d_wd = c.in(wd.data(), (size_t) W);
-    const double *d_dc   = c.in(delta_c, (size_t) W * P);
-    std::vector<double> zeros(2 * (size_t) W, 0.0);
-    double *d_tm = c.inout(zeros.data(), lm_terms, 2 * (size_t) W);
-    if ((rc = c.seal())) return rc;
-    double *d_dl = c.out(delta_l, (size_t) n_lm);
-    ICG_LAUNCH_GUARD(c);
-    {
-        icg_prof_scope ps(ctx, "schur_backsub");
-        hipLaunchKernelGGL(k_schur_backsub_w, dim3(n_lm), dim3(64), 0, ctx->stream, d_wd, (const int32_t *) ctx->d_lmwin, P, (const double *) ctx->d_sys, d_dc,
-                           d_dl, d_tm, ctx->sys_min_diag, ctx->sys_max_diag);
-    }
-    ICG_HIP(ctx, hipGetLastError());
-    return c.finish();
+    if (!ctx->part_w.sys_valid || ctx->part_w.sys_P != P)
+        return icg_fail(ctx, ICG_ERR_INVALID, "no resident window systems of size %d: call icg_reproj_schur_windows first", P);
+    return backsub_impl(ctx, ctx->part_w, P, delta_c, delta_l, lm_terms);
 }
 
 extern "C" int icg_reproj_cost_windows(icg_ctx *ctx, const uint8_t *active, double *cost) {
     if (!ctx || !cost) return ICG_ERR_INVALID;
     if (!ctx->rJ_valid) return icg_fail(ctx, ICG_ERR_INVALID, "no resident residuals: call icg_reproj_eval_windows first");
-    const int W = ctx->n_windows, n = ctx->n_factors_resident;
-    if (W <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition");
-    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    if (ctx->w_sys_off.size() != (size_t) W + 1) ctx->w_sys_off.assign((size_t) W + 1, 0);
-    if (ctx->w_damp.size() != (size_t) W) ctx->w_damp.assign((size_t) W, 0.0);
-    std::vector<win_desc> wd;
-    build_win_desc(ctx, 0, nullptr, nullptr, nullptr, nullptr, nullptr, wd);
-    icg_call c(ctx);
-    int rc = c.reserve(sizeof(win_desc) * (size_t) W + (size_t) n + sizeof(double) * (size_t) W + 4096);
-    if (rc) return rc;
-    const win_desc *d_wd = c.in(wd.data(), (size_t) W);
-    const uint8_t *d_act = active ? c.in(active, (size_t) n) : nullptr;
-    std::vector<double> zeros((size_t) W, 0.0);
-    double *d_cost = c.inout(zeros.data(), cost, (size_t) W);
-    if ((rc = c.seal())) return rc;
-    ICG_LAUNCH_GUARD(c);
-    {
-        icg_prof_scope ps(ctx, "reproj_cost");
-        hipLaunchKernelGGL(k_reproj_cost_w, dim3(4, W), dim3(256), 0, ctx->stream, d_wd, (const double *) ctx->d_rJ, d_act, ctx->last_huber, d_cost);
-    }
-    ICG_HIP(ctx, hipGetLastError());
-    return c.finish();
+    if (ctx->part_w.W <= 0) return icg_fail(ctx, ICG_ERR_INVALID, "no window partition");
+    return cost_impl(ctx, ctx->part_w, active, cost);
 }
 
 // the resident residuals of the last evaluation (n x 2), e.g. for the per-factor chi-square test after icg_reproj_eval_windows

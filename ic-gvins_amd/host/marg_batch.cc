@@ -241,9 +241,8 @@ bool MarginalizationBatch::marginalize(std::vector<char> *ok) {
     auto t2 = now();
 
     // ---- 3: assembly + landmark elimination of every planned window, one launch sequence; the landmark diagonals --------------------------
-    // (the batched assembly holds a window's camera block in LDS — csrc/reproj.hip, schur_windows_impl: V^2 + V + 1 024 doubles within the
-    // 160 KiB of a gfx950 CU — i.e. at most 138 free camera columns: 21 poses + extrinsic + td, so the 15-keyframe windows of BASELINE
-    // configs[3] (97 columns) are batched; a wider window takes the dense path on its own, whose one-window assembly has no such limit)
+    // (csrc/reproj.hip, schur_impl: reduced systems of up to WindowSolverBatch::kMaxCameraColumns columns; a wider window takes the dense
+    // path on its own)
     const int max_camera_columns = WindowSolverBatch::kMaxCameraColumns;
     for (size_t w = 0; w < NW; w++) {
         if (!st[w].planned) continue;

@@ -21,11 +21,10 @@ class WindowSolverBatch {
 public:
     typedef WindowSolver::Options Options;
     typedef WindowSolver::Summary Summary;
-    // The batched assembly holds a window's free camera columns (6 per free pose, 6 extrinsic, 1 td) as an LDS tile: V^2 + V + 1 024 doubles
-    // within the 160 KiB of a gfx950 CU (csrc/reproj.hip, schur_windows_impl / RPJ_LDS_LIMIT) — at most 138 columns, i.e. 21 free poses with
-    // the calibration blocks (rounds 2-4 sized the tile for 64 KiB: 82 columns, which kept the 15-keyframe windows of BASELINE configs[3]
-    // out).  A window that can exceed it is the caller's to solve on a WindowSolver of its own, whose assembly falls back to global atomics.
-    static constexpr int kMaxCameraColumns = 138;
+    // Widest reduced system of the device path: the assembly (csrc/reproj.hip k_asm_*) keeps no per-window tile in LDS any more — rounds 2-5
+    // held the camera block there (82, then 138 columns) — and the reduction kernel stages 32 landmark rows of 4 ceil(P/4) doubles (64.5 KB at
+    // 512).  A window that can exceed it is the caller's to solve on the host.
+    static constexpr int kMaxCameraColumns = 512;
 
     // host_threads: the per-window host phases (host factors, reduced solves, cost bookkeeping) are spread over this many threads
     explicit WindowSolverBatch(int device = 0, double huber_delta = 1.0, int host_threads = 0 /* 0 = hardware concurrency, at most 16 */);

@@ -239,8 +239,8 @@ int icg_reproj_schur_windows(icg_ctx *ctx, int P, const int32_t *col_pose, const
                              double *diag_cc, double *cost);
 /* the same call with the W x P x P reduced systems left where the reduction kernel writes them (the context's pinned staging memory):
  * *S_view is valid until the next call on ctx.  Saves the device-to-host copy and the copy-out of 9 MB per LM step at 256 C2 windows.
- * Only the 16 x 16 tiles on and below the diagonal are written (the systems are symmetric; a Cholesky factorization reads rows >= columns):
- * the elements above those tiles are undefined. */
+ * Only the lower triangle (rows >= columns) is written (the systems are symmetric; a Cholesky factorization reads nothing else): the
+ * elements above the diagonal are undefined. */
 int icg_reproj_schur_windows_view(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *active,
                                   const uint8_t *reassemble, const double *damp, double min_diag, double max_diag, const double **S_view, double *s,
                                   double *diag_cc, double *cost);

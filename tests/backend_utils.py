@@ -66,25 +66,28 @@ def backend_marginalize(lib, P, huber=1.0, prior_weight=100.0, x_eval=None):
                 J0=J0[:r * r].reshape(r, r), e0=e0[:r], res=res[:r])
 
 
-def check_marginalization(lib, oracle):
-    P = md.make_problem(n_lm=80, n_kf=6, seed=2)
-    w = P["w"]
-    out = backend_marginalize(lib, P, huber=1.0, prior_weight=100.0)
-    # rebuild the same system with the oracle in OUR column layout, then permute to the library's retained order
-    r_, J_ = oracle.reproj_eval(P["obs"], P["ii"], P["jj"], P["ll"], w["poses"], w["ext"], w["invdepth"], w["td"], huber=1.0)
+def oracle_marginalized_system(oracle, P, w, out, huber=1.0, prior_weight=100.0, scalar_prior=None):
+    """(Hp, bp) of the marginalization scenario of capi.cc (reprojection factors + PosePriorFactor on pose 0 [+ a ScalarPriorFactor
+    (landmark, x0, weight)]) at the parameter values `w`, from the ORACLE: orc_reproj per factor, orc_marg's constructEquation and Schur
+    complement (factors/marginalization_info.h:170-230), permuted from this file's column layout to the library's retained order
+    (`out`: ids / index / size / m of a library run of the same structure)."""
+    r_, J_ = oracle.reproj_eval(P["obs"], P["ii"], P["jj"], P["ll"], w["poses"], w["ext"], w["invdepth"], w["td"], huber=huber)
     H, b = oracle.reproj_accumulate_normal(r_, J_, P["ii"], P["jj"], P["ll"], P["col_pose"], P["col_ext"], P["col_lm"], P["col_td"], P["local_size"])
     # PosePriorFactor of capi.cc: residual w*[dp ; 2 vec(dq)], prior translated by +0.01 in x -> r = (-w*0.01, 0, ...)
-    wgt = 100.0
     Jp = np.zeros((6, 6))
-    Jp[:3, :3] = wgt * np.eye(3)
-    Jp[3:, 3:] = wgt * np.eye(3)
+    Jp[:3, :3] = prior_weight * np.eye(3)
+    Jp[3:, 3:] = prior_weight * np.eye(3)
     rp = np.zeros(6)
-    rp[0] = wgt * -0.01
+    rp[0] = prior_weight * -0.01
     c0 = P["col_pose"][0]
     H[c0:c0 + 6, c0:c0 + 6] += Jp.T @ Jp
     b[c0:c0 + 6] -= Jp.T @ rp
+    if scalar_prior is not None:  # ScalarPriorFactor of capi.cc: r = weight (x - x0)
+        l, x0, wgt = scalar_prior
+        cl = P["col_lm"][l]
+        H[cl, cl] += wgt * wgt
+        b[cl] -= wgt * (wgt * (w["invdepth"][l] - x0))
     m = P["m"]
-    assert out["m"] == m and out["r"] == P["local_size"] - m
     _, _, Hp_o, bp_o = oracle.marginalize(H, b, m)
     # our retained column of each id
     def our_col(i):
@@ -93,18 +96,46 @@ def check_marginalization(lib, oracle):
         if i < 900000:
             return P["col_lm"][i - 100000]
         return P["col_ext"] if i == 900000 else P["col_td"]
-    perm = []
-    for i, idx, sz in zip(out["ids"], out["index"], out["size"]):
-        ls = 6 if sz == 7 else sz
-        perm.append((idx - out["m"], our_col(int(i)) - m, ls))
     r = out["r"]
     Pm = np.zeros((r, r))  # lib index <- our index
-    for li, oi, ls in perm:
+    for i, idx, sz in zip(out["ids"], out["index"], out["size"]):
+        ls = 6 if sz == 7 else sz
         for k in range(ls):
-            Pm[li + k, oi + k] = 1.0
+            Pm[idx - out["m"] + k, our_col(int(i)) - m + k] = 1.0
     assert np.allclose(Pm.sum(0), 1) and np.allclose(Pm.sum(1), 1)
-    Hp_exp = Pm @ Hp_o @ Pm.T
-    bp_exp = Pm @ bp_o
+    return Pm @ Hp_o @ Pm.T, Pm @ bp_o
+
+
+def batch_window_parameters(P, n_windows, jitter=1e-3):
+    """the parameter values icgh_backend_marginalize_batch (capi.cc) gives its n_windows copies of problem P: window 0 as it is, every
+    further window with positions moved by jitter * u and inverse depths scaled by 1 + jitter * u, u from the 64-bit LCG of capi.cc"""
+    state, mask = [0x9E3779B97F4A7C15], (1 << 64) - 1
+
+    def rnd():
+        state[0] = (state[0] * 6364136223846793005 + 1442695040888963407) & mask
+        return float((state[0] >> 11) & ((1 << 53) - 1)) / float(1 << 52) - 1.0
+
+    out = []
+    for k in range(n_windows):
+        w = dict(P["w"])
+        w["poses"], w["invdepth"] = np.array(P["w"]["poses"], np.float64), np.array(P["w"]["invdepth"], np.float64)
+        if k > 0:
+            for p in range(w["poses"].shape[0]):
+                for c in range(3):
+                    w["poses"][p, c] += jitter * rnd()
+            for l in range(len(w["invdepth"])):
+                w["invdepth"][l] *= 1.0 + jitter * rnd()
+        out.append(w)
+    return out
+
+
+def check_marginalization(lib, oracle):
+    P = md.make_problem(n_lm=80, n_kf=6, seed=2)
+    w = P["w"]
+    out = backend_marginalize(lib, P, huber=1.0, prior_weight=100.0)
+    m = P["m"]
+    assert out["m"] == m and out["r"] == P["local_size"] - m
+    Hp_exp, bp_exp = oracle_marginalized_system(oracle, P, w, out)
     scale = np.abs(Hp_exp).max()
     assert np.abs(out["Hp"] - Hp_exp).max() < 1e-8 * scale
     assert np.abs(out["bp"] - bp_exp).max() < 1e-8 * max(1.0, np.abs(bp_exp).max())
@@ -261,19 +292,37 @@ def backend_marginalize_batch(lib, P, n_windows, mode, dense_window=-1, jitter=1
                 e0=e0[:W * r].reshape(W, r), structured=int(counts[0]), dense=int(counts[1]), seconds=float(seconds[0]))
 
 
-def check_marginalization_batch(lib):
+def check_marginalization_batch(lib, oracle=None, bitwise=False):
     """M2 + M3 for the windows of many streams in one pass (host/marg_batch.h): every window's Schur complement and
     linearization equal what MarginalizationInfo::marginalization() gives the same window on its own (marginalization_info.h:73-101) —
     all windows on the landmark-eliminated path; one window with a host factor on an inverse depth (dense M2 + M3 for that window only);
-    the process-wide dense switch; window 0 (no jitter) equals the single-window entry point the reference-code golden is checked on."""
+    the process-wide dense switch; window 0 (no jitter) equals the single-window entry point the reference-code golden is checked on.
+    oracle: EVERY window of the batch is additionally checked against the oracle's own assembly + Schur complement of that window's
+    (jittered) parameters — not only against the library's per-window path.
+    bitwise: batch and per-window path agree bit for bit (the device assembles in a fixed order since round 6; the CPU backend always did)."""
     for (n_lm, n_kf, seed), W in (((80, 6, 2), 5), ((300, 10, 3), 12), ((40, 4, 7), 1)):
         P = md.make_problem(n_lm=n_lm, n_kf=n_kf, seed=seed)
+        layout = backend_marginalize(lib, P) if oracle is not None else None
+        params = batch_window_parameters(P, W) if oracle is not None else None
         for dense_window in (-1, min(2, W - 1)):
             a = backend_marginalize_batch(lib, P, W, 0, dense_window)
             b = backend_marginalize_batch(lib, P, W, 1, dense_window)
             assert a["m"] == b["m"] and a["r"] == b["r"]
             assert (a["structured"], a["dense"]) == (b["structured"], b["dense"]) == ((W, 0) if dense_window < 0 else (W - 1, 1))
+            if bitwise:
+                assert np.array_equal(a["Hp"], b["Hp"]) and np.array_equal(a["bp"], b["bp"]), (W, dense_window)
             for k in range(W):
+                if oracle is not None:
+                    assert layout["r"] == a["r"] and layout["m"] == a["m"]
+                    sp = None
+                    if k == dense_window:
+                        l0 = int(P["ll"][0])
+                        sp = (l0, params[k]["invdepth"][l0] * 1.01, 50.0)
+                    Hp_exp, bp_exp = oracle_marginalized_system(oracle, P, params[k], layout, scalar_prior=sp)
+                    sc = np.abs(Hp_exp).max()
+                    for got in (a, b):
+                        assert np.abs(got["Hp"][k] - Hp_exp).max() < 1e-8 * sc, (W, dense_window, k, np.abs(got["Hp"][k] - Hp_exp).max() / sc)
+                        assert np.abs(got["bp"][k] - bp_exp).max() < 1e-8 * max(1.0, np.abs(bp_exp).max()), (W, dense_window, k)
                 scale = np.abs(b["Hp"][k]).max()
                 assert np.abs(a["Hp"][k] - b["Hp"][k]).max() < 1e-9 * scale, (k, np.abs(a["Hp"][k] - b["Hp"][k]).max() / scale)
                 assert np.abs(a["bp"][k] - b["bp"][k]).max() < 1e-9 * max(1.0, np.abs(b["bp"][k]).max())

@@ -153,11 +153,10 @@ def check_schur_windows(make_ctx, tol=1e-9):
     ctxb.reproj_set_windows(fac_off, lm_off)
     ctxb.reproj_eval_windows(poses, ext, inv, td, huber=huber)
     S, s, dg, cost = ctxb.reproj_schur_windows(P, col_pose, col_ext, col_td, active=active, damp=damp1)
-    # the zero-copy form of the same call: the tiles on and below the diagonal, s, diag and the costs equal the copying form
+    # the zero-copy form of the same call: the lower triangle, s, diag and the costs equal the copying form
     ctxb.reproj_reserve_windows(P)
     Sv, sv, dgv, costv = ctxb.reproj_schur_windows_view(P, col_pose, col_ext, col_td, active=active, damp=damp1)
-    tile = np.arange(P) // 16
-    lower_tiles = tile[:, None] >= tile[None, :]
+    lower_tiles = np.arange(P)[:, None] >= np.arange(P)[None, :]  # (the view defines rows >= columns only)
     for k in range(W):
         sc = max(1.0, np.abs(S[k]).max())
         assert np.abs(np.where(lower_tiles, Sv[k] - S[k], 0.0)).max() < tol * sc, k

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_replay_gnss_imu_camera_sequence_on_gpu(tmp_path):
-    gc.check_replay(H.HOST_LIB, tmp_path, bitwise=False)
+    gc.check_replay(H.HOST_LIB, tmp_path, bitwise=True)
 
 
 def test_replay_online_calibration_and_earth_rotation_on_gpu(tmp_path):
@@ -24,15 +24,15 @@ def test_replay_online_calibration_and_earth_rotation_on_gpu(tmp_path):
 
 
 def test_replay_concurrent_estimators_on_gpu(tmp_path):
-    """four camera streams' estimators side by side on one GPU (poll waits): each equals the stream run alone to the rounding of the
-    FP64-atomic assembly, with identical discrete decisions and an identical tracking log"""
-    gc.check_replay_concurrent(H.HOST_LIB, tmp_path, n=4, bitwise=False, wait_poll_us=50)
+    """four camera streams' estimators side by side on one GPU (poll waits): each equals the stream run alone bit for bit, with an
+    identical tracking log"""
+    gc.check_replay_concurrent(H.HOST_LIB, tmp_path, n=4, bitwise=True, wait_poll_us=50)
 
 
 def test_replay_lockstep_shared_window_solves_on_gpu(tmp_path):
-    """four estimators in lock-step, every window solve of a tick through ONE batched launch sequence (k_reproj_eval, k_reproj_normal_schur_w,
-    k_schur_*_w): each stream equals the stream replayed alone to the rounding of the FP64-atomic assembly"""
-    gc.check_replay_lockstep(H.HOST_LIB, tmp_path, n=4, bitwise=False, groups=2)
+    """four estimators in lock-step, every window solve of a tick through ONE batched launch sequence (k_reproj_eval, k_asm_*, k_schur_*_w):
+    each stream equals the stream replayed alone bit for bit"""
+    gc.check_replay_lockstep(H.HOST_LIB, tmp_path, n=4, bitwise=True, groups=2)
 
 
 def test_replay_tracking_loss_and_reinitialization_on_gpu(tmp_path):

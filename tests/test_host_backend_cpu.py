@@ -22,9 +22,10 @@ def test_marginalization_structured_path_equals_dense():
     bu.check_marginalization_paths(_lib())
 
 
-def test_marginalization_batch_equals_per_window():
-    """the marginalizations of many streams in one pass (MarginalizationBatch) == each window marginalized on its own"""
-    bu.check_marginalization_batch(_lib())
+def test_marginalization_batch_equals_per_window(oracle):
+    """the marginalizations of many streams in one pass (MarginalizationBatch) == each window marginalized on its own, bit for bit, and
+    every window == the oracle's assembly + Schur complement of that window's parameters"""
+    bu.check_marginalization_batch(_lib(), oracle, bitwise=True)
 
 
 def test_preintegration_factor(oracle):
