@@ -198,6 +198,14 @@ int icg_arena_reserve(icg_ctx *ctx, size_t bytes) {
     return 0;
 }
 
+int icg_arena_drain(icg_ctx *ctx) {
+    if (ctx->arena_inflight == 0) return 0;
+    int rc = icg_hip_check(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    ctx->arena_inflight = 0;
+    ctx->arena_off      = 0;
+    return rc;
+}
+
 size_t icg_arena_alloc(icg_ctx *ctx, size_t bytes) {
     size_t off = icg_align_up(ctx->arena_off, 256);
     if (off + bytes > ctx->arena_cap) {

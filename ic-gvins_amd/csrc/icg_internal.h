@@ -92,6 +92,7 @@ struct icg_ctx {
     char *h_arena = nullptr;
     char *d_arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
+    size_t arena_inflight = 0; // end of the inputs staged by calls that returned without waiting (icg_call::finish_async): the next call stages behind them
     bool arena_overflow = false; // an allocation did not fit (sticky until the call's seal()/finish() reports it)
 
     // reprojection back-end resident state
@@ -166,6 +167,7 @@ template <typename T> static inline T *icg_d(icg_ctx *ctx, size_t off) { return 
 int icg_arena_overflow_check(icg_ctx *ctx); // ICG_ERR_NOMEM (and the flag cleared) if an allocation since the last check did not fit
 int icg_arena_h2d(icg_ctx *ctx, size_t begin, size_t end);
 int icg_arena_d2h(icg_ctx *ctx, size_t begin, size_t end);
+int icg_arena_drain(icg_ctx *ctx); // waits for calls that returned without waiting (arena_inflight) before the arena is reset or replaced
 
 // profiling -----------------------------------------------------------------------------------------------
 struct icg_prof_scope {
@@ -250,8 +252,12 @@ struct icg_call {
     };
     std::vector<outrec> outs;
     std::vector<std::pair<size_t, size_t>> zc_regions; // [begin, end) of every zero-copy output: written by kernels through the host mapping
-    explicit icg_call(icg_ctx *c) : ctx(c) { ctx->arena_off = 0; }
-    int reserve(size_t bytes) { return icg_arena_reserve(ctx, bytes + 8192); }
+    explicit icg_call(icg_ctx *c) : ctx(c) { ctx->arena_off = ctx->arena_inflight; }
+    int reserve(size_t bytes) {
+        if (ctx->arena_inflight + bytes + 8192 <= ctx->arena_cap) return 0;
+        if (int rc = icg_arena_drain(ctx)) return rc; // (growing replaces the arena: nothing may still be read from it)
+        return icg_arena_reserve(ctx, bytes + 8192);
+    }
     template <typename T> T *in(const T *src, size_t n) {
         size_t off = icg_arena_alloc(ctx, sizeof(T) * n);
         if (n) memcpy(ctx->h_arena + off, src, sizeof(T) * n);
@@ -317,7 +323,16 @@ struct icg_call {
         if (rc) return rc;
         icg_prof_collect(ctx);
         for (auto &o : outs) memcpy(o.user, ctx->h_arena + o.off, o.bytes);
-        ctx->arena_off = 0;
+        ctx->arena_off = ctx->arena_inflight = 0;
+        return 0;
+    }
+    // A call without outputs (results stay resident: icg_reproj_eval_windows) returns as soon as its copies and kernels are enqueued — the
+    // next call on the context is stream-ordered behind them and stages its inputs BEHIND this call's, which the H2D copy may still be
+    // reading; the first call that waits (finish()) releases the arena.  Saves a host-device round trip per call (2 of 5 per LM step).
+    int finish_async() {
+        if (ctx->arena_overflow || !outs.empty() || !zc_regions.empty()) return finish();
+        ctx->arena_inflight = icg_align_up(ctx->arena_off, 256);
+        ctx->arena_off      = ctx->arena_inflight;
         return 0;
     }
 };

@@ -742,6 +742,7 @@ static int preprocess_impl(icg_ctx *ctx, int n, const int32_t *slots, const int3
     hipMemcpyKind kind     = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     unsigned int *d_hist   = nullptr;
     if (want_hist) {
+        if (int rcd = icg_arena_drain(ctx)) return rcd;
         ctx->arena_off = 0;
         int rc         = icg_arena_reserve(ctx, sizeof(unsigned int) * 256 * (size_t) n + 4096);
         if (rc) return rc;

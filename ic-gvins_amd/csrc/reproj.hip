@@ -271,6 +271,7 @@ static int eval_resident_impl(icg_ctx *ctx, int n_poses, const double *poses, co
     // parameters: poses | ext | invdepth  packed in the staging arena
     size_t pbytes = sizeof(double) * ((size_t) n_poses * 7 + 7 + (size_t) n_lm);
     size_t rbytes = sizeof(double) * 2 * (size_t) n, jbytes = want_jac ? sizeof(double) * 46 * (size_t) n : 0;
+    if (int rcd = icg_arena_drain(ctx)) return rcd;
     ctx->arena_off = 0;
     int rc         = icg_arena_reserve(ctx, pbytes + rbytes + jbytes + 4096);
     if (rc) return rc;
@@ -384,6 +385,7 @@ struct win_desc {
     int64_t sys_off;
     int32_t K, reassemble; // K: poses used by the window's factors (local numbering of the plan)
     double damp;
+    int32_t NB, pad; // column blocks of the landmark rows (k_asm_landmarks)
 };
 
 // gfx950 has 160 KiB of LDS per CU and one workgroup may own all of it (MI355X_MICROARCH.md, "LDS"); a launch with more dynamic LDS than the
@@ -492,7 +494,34 @@ __global__ __launch_bounds__(256) void k_asm_runs(int n_runs, const int4 *runs, 
 }
 
 // owner[w * P + a] of a camera column: (local pose << 3) | x for column x of a pose block, (ASM_EXT << 3) | x for the extrinsic (x < 6) and td
-// (x == 6), -1 for a column no visual factor of the window touches (host-only blocks, empty tail columns)
+// (x == 6), -1 for a column no visual factor of the window touches (host-only blocks, empty tail columns).
+// The gathers are chains of additions in a fixed order, but their loads are independent: they are issued eight at a time (a missing run
+// contributes +0.0, which leaves every partial sum as it is) — one thread walks up to K^2 runs, and a dependent L2 round trip per run made
+// the (ext|td)^2 cells the critical path of the launch.
+__device__ __forceinline__ double asm_gather_all(const double *part, int r0, int r1, int idx, double acc) {
+    for (int rr = r0; rr < r1; rr += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = rr + u < r1 ? part[(size_t) (rr + u) * ASM_PART + idx] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u];
+    }
+    return acc;
+}
+// every run with local pose p as reference (row p of the pair table, element i_r of the run's block) or as observer (column p, element i_o)
+__device__ __forceinline__ double asm_gather_pose(const double *part, const int32_t *pr, int Kmax, int K, int p, int i_r, int i_o, double acc) {
+    for (int q = 0; q < K; q += 4) {
+        int rr[4], ro[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) rr[u] = q + u < K ? pr[p * Kmax + q + u] : -1, ro[u] = q + u < K ? pr[(q + u) * Kmax + p] : -1;
+        double vr[4], vo[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) vr[u] = rr[u] >= 0 ? part[(size_t) rr[u] * ASM_PART + i_r] : 0.0, vo[u] = ro[u] >= 0 ? part[(size_t) ro[u] * ASM_PART + i_o] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc += vr[u], acc += vo[u];
+    }
+    return acc;
+}
 // grid (ceil((P * P + P) / 256), W)
 __global__ __launch_bounds__(256) void k_asm_camera(const win_desc *wd, const int32_t *run_off, const int32_t *pair_run, int Kmax, const int16_t *owner,
                                                    int P, const double *part, double *sys) {
@@ -513,23 +542,18 @@ __global__ __launch_bounds__(256) void k_asm_camera(const win_desc *wd, const in
         if (oa >= 0 && oc >= 0) {
             const int pa = oa >> 3, xa = oa & 7, pc = oc >> 3, xc = oc & 7;
             if (pa == ASM_EXT && pc == ASM_EXT) {
-                const int idx = asm_part_index(12 + xa, 12 + xc);
-                for (int rr = r0; rr < r1; rr++) acc += part[(size_t) rr * ASM_PART + idx];
+                acc = asm_gather_all(part, r0, r1, asm_part_index(12 + xa, 12 + xc), acc);
             } else if (pa != ASM_EXT && pc != ASM_EXT && pa != pc) {
                 const int r_ac = pr[pa * Kmax + pc], r_ca = pr[pc * Kmax + pa];
-                if (r_ac >= 0) acc += part[(size_t) r_ac * ASM_PART + asm_part_index(xa, 6 + xc)];
-                if (r_ca >= 0) acc += part[(size_t) r_ca * ASM_PART + asm_part_index(6 + xa, xc)];
+                const double v_ac = r_ac >= 0 ? part[(size_t) r_ac * ASM_PART + asm_part_index(xa, 6 + xc)] : 0.0;
+                const double v_ca = r_ca >= 0 ? part[(size_t) r_ca * ASM_PART + asm_part_index(6 + xa, xc)] : 0.0;
+                acc = v_ac + v_ca;
             } else {
-                // pose p's diagonal block, or pose p against the shared block: every run with p as reference (row p of the pair table)
-                // or as observer (column p)
+                // pose p's diagonal block, or pose p against the shared block
                 const int p   = pa != ASM_EXT ? pa : pc;
                 const int i_r = asm_part_index(pa == ASM_EXT ? 12 + xa : xa, pc == ASM_EXT ? 12 + xc : xc);         // p is the run's reference
                 const int i_o = asm_part_index(pa == ASM_EXT ? 12 + xa : 6 + xa, pc == ASM_EXT ? 12 + xc : 6 + xc); // p is the run's observer
-                for (int q = 0; q < K; q++) {
-                    const int rr = pr[p * Kmax + q], ro = pr[q * Kmax + p];
-                    if (rr >= 0) acc += part[(size_t) rr * ASM_PART + i_r];
-                    if (ro >= 0) acc += part[(size_t) ro * ASM_PART + i_o];
-                }
+                acc = asm_gather_pose(part, pr, Kmax, K, p, i_r, i_o, acc);
             }
         }
         H[(size_t) a * N + c] = acc;
@@ -538,32 +562,28 @@ __global__ __launch_bounds__(256) void k_asm_camera(const win_desc *wd, const in
         const int oa = own[a];
         if (oa >= 0) {
             const int pa = oa >> 3, xa = oa & 7;
-            if (pa == ASM_EXT) {
-                const int idx = asm_part_index(12 + xa, 19);
-                for (int rr = r0; rr < r1; rr++) acc += part[(size_t) rr * ASM_PART + idx];
-            } else {
-                const int i_r = asm_part_index(xa, 19), i_o = asm_part_index(6 + xa, 19);
-                for (int q = 0; q < K; q++) {
-                    const int rr = pr[pa * Kmax + q], ro = pr[q * Kmax + pa];
-                    if (rr >= 0) acc += part[(size_t) rr * ASM_PART + i_r];
-                    if (ro >= 0) acc += part[(size_t) ro * ASM_PART + i_o];
-                }
-            }
+            if (pa == ASM_EXT)
+                acc = asm_gather_all(part, r0, r1, asm_part_index(12 + xa, 19), acc);
+            else
+                acc = asm_gather_pose(part, pr, Kmax, K, pa, asm_part_index(xa, 19), asm_part_index(6 + xa, 19), acc);
         }
         b[a] = acc;
     }
 }
 
-// Landmark rows.  A workgroup owns LB consecutive landmarks of one window = LB * (P + 2) cells (cell a < P of landmark l is G_l[a], cell P is
-// h_ll, cell P + 1 is b_l; LB chosen so that a thread owns at most four cells).  The factors of those landmarks are one contiguous range of
-// the landmark-major list: they are staged in LDS 64 at a time (J and r of a factor = 48 doubles, ONE round trip of independent coalesced
-// loads per pass — the first version walked lrec -> J -> J as three dependent global loads per cell and factor and was bound by that latency:
-// 221 us for 256 windows against 100 us for the twenty times heavier k_asm_runs), then every cell adds the staged factors of its landmark
-// in list order.  An inactive factor is staged as zeros.
+// Landmark rows.  The P camera columns of a window are cut into blocks (host, per call): the six columns of a free pose, the six of the
+// extrinsic, runs of up to six columns that no visual factor touches (stored as zeros), and one block for (td column, h_ll, b_l).  A thread
+// owns one (landmark, block) pair and walks the landmark's factors ONCE for the whole block — the first version owned single cells and walked
+// them once per column (70 % of its iterations found a pose that is neither the factor's reference nor its observer).  A workgroup owns LB
+// consecutive landmarks (LB * blocks <= 256); their factors are one contiguous range of the landmark-major list, staged in LDS 64 at a
+// time (J and r of a factor = 48 doubles: ONE round trip of independent coalesced loads per pass instead of the dependent lrec -> J -> J
+// chain per cell), then added in list order.  An inactive factor is staged as zeros.
 #define ASML_FB 64
-// grid (ceil(Lmax / LB), W)
-__global__ __launch_bounds__(256) void k_asm_landmarks(const win_desc *wd, const int16_t *owner, int P, int LB, const int32_t *lm_foff, const int4 *lrec,
-                                                      const double *r, const double *J, const uint8_t *active, double *sys) {
+#define ASM_BLK_TD 0xFFE  // (td column or 0xFFF = none, h_ll, b_l)
+#define ASM_BLK_GAP 0xFFD // columns of host-only blocks: zeros
+// blocks[w * NBmax + k] = col0 | width << 12 | code << 16 (code: local pose, ASM_EXT, ASM_BLK_TD, ASM_BLK_GAP); grid (ceil(Lmax / LB), W)
+__global__ __launch_bounds__(256) void k_asm_landmarks(const win_desc *wd, const int32_t *blocks, int NBmax, int P, int LB, const int32_t *lm_foff,
+                                                      const int4 *lrec, const double *r, const double *J, const uint8_t *active, double *sys) {
     __shared__ double st[ASML_FB * 48];
     __shared__ int st_i[ASML_FB], st_j[ASML_FB];
     const int w       = blockIdx.y;
@@ -571,22 +591,18 @@ __global__ __launch_bounds__(256) void k_asm_landmarks(const win_desc *wd, const
     if (!W.reassemble) return;
     const int l0 = blockIdx.x * LB;
     if (l0 >= W.L) return;
-    const int t = threadIdx.x, nl = min(LB, W.L - l0), C = P + 2, ncell = nl * C;
+    const int t = threadIdx.x, nl = min(LB, W.L - l0), NB = W.NB;
     const int N = P + W.L;
     double *H   = sys + W.sys_off, *b = H + (size_t) N * N;
-    int cl[4], ca[4], co[4], fb[4], fe[4];
-    double acc[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int e = t + 256 * k;
-        cl[k] = e / C, ca[k] = e - cl[k] * C;
-        acc[k] = 0.0;
-        co[k]  = -1, fb[k] = fe[k] = 0;
-        if (e < ncell) {
-            co[k] = ca[k] < P ? (int) owner[(size_t) w * P + ca[k]] : 0; // (-1: a column no visual factor touches — stays zero)
-            fb[k] = lm_foff[W.lm_begin + l0 + cl[k]], fe[k] = lm_foff[W.lm_begin + l0 + cl[k] + 1];
-        }
+    const int il = t / NB, ib = t - il * NB;
+    const bool has = il < nl;
+    int col0 = 0, width = 0, code = ASM_BLK_GAP, fb = 0, fe = 0;
+    if (has) {
+        const int blk = blocks[(size_t) w * NBmax + ib];
+        col0 = blk & 0xFFF, width = (blk >> 12) & 0xF, code = blk >> 16;
+        fb = lm_foff[W.lm_begin + l0 + il], fe = lm_foff[W.lm_begin + l0 + il + 1];
     }
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     const int f_begin = lm_foff[W.lm_begin + l0], f_end = lm_foff[W.lm_begin + l0 + nl];
     const int fi = t >> 2, sub = t & 3;
     for (int c0 = f_begin; c0 < f_end; c0 += ASML_FB) {
@@ -604,43 +620,41 @@ __global__ __launch_bounds__(256) void k_asm_landmarks(const win_desc *wd, const
             if (sub == 0) st_i[fi] = rec.y, st_j[fi] = rec.z;
         }
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (co[k] < 0) continue;
-            const int p = co[k] >> 3, x = co[k] & 7, a = ca[k];
-            const int g1 = min(fe[k], c0 + nc) - c0;
-            for (int g = max(fb[k], c0) - c0; g < g1; g++) {
-                const double *Jf = &st[g * 48];
-                const double jl0 = Jf[42], jl1 = Jf[43];
-                if (a < P) {
-                    int o0, o1;
-                    if (p == ASM_EXT)
-                        o0 = x < 6 ? 28 + x : 44, o1 = x < 6 ? 35 + x : 45;
-                    else if (p == st_i[g])
-                        o0 = x, o1 = 7 + x;
-                    else if (p == st_j[g])
-                        o0 = 14 + x, o1 = 21 + x;
-                    else
-                        continue;
-                    acc[k] = fma(jl1, Jf[o1], fma(jl0, Jf[o0], acc[k]));
-                } else if (a == P) {
-                    acc[k] = fma(jl1, jl1, fma(jl0, jl0, acc[k]));
-                } else {
-                    acc[k] = fma(jl1, -Jf[47], fma(jl0, -Jf[46], acc[k]));
-                }
+        if (code == ASM_BLK_GAP) continue;
+        const int g1 = min(fe, c0 + nc) - c0;
+        for (int g = max(fb, c0) - c0; g < g1; g++) {
+            const double *Jf = &st[g * 48];
+            const double jl0 = Jf[42], jl1 = Jf[43];
+            if (code == ASM_BLK_TD) {
+                acc[0] = fma(jl1, Jf[45], fma(jl0, Jf[44], acc[0]));
+                acc[1] = fma(jl1, jl1, fma(jl0, jl0, acc[1]));
+                acc[2] = fma(jl1, -Jf[47], fma(jl0, -Jf[46], acc[2]));
+                continue;
             }
+            int o;
+            if (code == ASM_EXT)
+                o = 28;
+            else if (code == st_i[g])
+                o = 0;
+            else if (code == st_j[g])
+                o = 14;
+            else
+                continue;
+#pragma unroll
+            for (int x = 0; x < 6; x++) acc[x] = fma(jl1, Jf[o + 7 + x], fma(jl0, Jf[o + x], acc[x]));
         }
     }
+    if (!has) return;
+    const int l = l0 + il;
+    double *row = H + (size_t) (P + l) * N;
+    if (code == ASM_BLK_TD) {
+        if (col0 != 0xFFF) row[col0] = acc[0];
+        row[P + l] = acc[1];
+        b[P + l]   = acc[2];
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (t + 256 * k >= ncell) continue;
-        const int l = l0 + cl[k], a = ca[k];
-        if (a < P)
-            H[(size_t) (P + l) * N + a] = acc[k];
-        else if (a == P)
-            H[(size_t) (P + l) * N + P + l] = acc[k];
-        else
-            b[P + l] = acc[k];
+        for (int x = 0; x < 6; x++)
+            if (x < width) row[col0 + x] = acc[x];
     }
 }
 
@@ -663,15 +677,16 @@ __global__ void k_schur_inv_w(const win_desc *wd, int P, double *sys, double min
 // quadruples from there (4 ds_read_b128 per landmark for 16 FMAs).  The upper triangle is the mirror image of the lower one (S is
 // symmetric; the factorizations read rows >= columns): written as such when the caller wants the full matrix, not at all otherwise.
 // Landmarks are added in index order: the value of a window does not depend on the batch it is reduced in.
-#define SCH_LT 32
-// grid (ceil(NT / 256), W), NT = TQ (TQ + 1) / 2 lower tiles, TQ = ceil(P / 4); dynamic LDS: SCH_LT * 4 TQ doubles (G) + 2 SCH_LT (inv, inv b_l)
-__global__ __launch_bounds__(256) void k_schur_reduce_w(const win_desc *wd, int P, const double *sys, double *S, double *s, double *diag,
+#define SCH_LT 32 // landmark rows per pass (fewer for wide systems: LT * 4 TQ <= 3 072 elements, twelve per thread)
+#define SCH_PRE 12
+// grid (ceil(NT / 256), W), NT = TQ (TQ + 1) / 2 lower tiles, TQ = ceil(P / 4); dynamic LDS: LT * 4 TQ doubles (G) + 2 LT (inv, b_l)
+__global__ __launch_bounds__(256) void k_schur_reduce_w(const win_desc *wd, int P, int LT, const double *sys, double *S, double *s, double *diag,
                                                        int lower_only) {
     extern __shared__ double sm[];
     const win_desc W = wd[blockIdx.y];
     const int L = W.L, N = P + L, TQ = (P + 3) >> 2, PP = 4 * TQ, NT = (TQ * (TQ + 1)) >> 1;
     const double *H = sys + W.sys_off, *b = H + (size_t) N * N, *inv = b + N;
-    double *g = sm, *sw = sm + SCH_LT * PP, *swb = sw + SCH_LT;
+    double *g = sm, *sw = sm + LT * PP, *swb = sw + LT;
     const int t = threadIdx.x, tid = blockIdx.x * 256 + t;
     // tile (ti, tj), tj <= ti, from the triangular index
     int ti = (int) ((sqrtf(8.0f * (float) tid + 1.0f) - 1.0f) * 0.5f);
@@ -684,19 +699,34 @@ __global__ __launch_bounds__(256) void k_schur_reduce_w(const win_desc *wd, int 
     for (int rr = 0; rr < 4; rr++)
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) acc[rr][cc] = 0.0;
-    double accs[2] = {0.0, 0.0}; // s entries t and t + 256 (workgroup 0 of the window; P <= 512 here, the rest by the tail loop below)
-    for (int l0 = 0; l0 < L; l0 += SCH_LT) {
-        const int nl = min(SCH_LT, L - l0);
-        __syncthreads();
-        for (int e = t; e < SCH_LT * PP; e += 256) {
-            const int l = e / PP, c = e - l * PP;
-            g[e] = (l < nl && c < P) ? H[(size_t) (P + l0 + l) * N + c] : 0.0;
+    double accs[2] = {0.0, 0.0}; // s entries t and t + 256 (the window's first workgroup; P <= 512)
+    // staging: element e = t + 256 k of a pass is row e / PP, column e % PP of the slice; the next pass is fetched into registers while
+    // this one is multiplied (one workgroup per CU at 256 windows: nobody else would hide the round trip)
+    int pl[SCH_PRE], pc[SCH_PRE];
+    double pre[SCH_PRE];
+#pragma unroll
+    for (int k = 0; k < SCH_PRE; k++) {
+        const int e = t + 256 * k;
+        pl[k] = e / PP, pc[k] = e - pl[k] * PP;
+        if (e >= LT * PP) pl[k] = -1;
+    }
+    auto fetch = [&](int l0) {
+#pragma unroll
+        for (int k = 0; k < SCH_PRE; k++) {
+            pre[k] = 0.0;
+            if (pl[k] >= 0 && l0 + pl[k] < L && pc[k] < P) pre[k] = H[(size_t) (P + l0 + pl[k]) * N + pc[k]];
         }
-        if (t < SCH_LT) {
-            const double wv = t < nl ? inv[l0 + t] : 0.0;
-            sw[t] = wv, swb[t] = t < nl ? b[P + l0 + t] : 0.0;
-        }
+    };
+    fetch(0);
+    for (int l0 = 0; l0 < L; l0 += LT) {
+        const int nl = min(LT, L - l0);
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SCH_PRE; k++)
+            if (pl[k] >= 0) g[t + 256 * k] = pre[k];
+        if (t < LT) sw[t] = t < nl ? inv[l0 + t] : 0.0, swb[t] = t < nl ? b[P + l0 + t] : 0.0;
+        __syncthreads();
+        if (l0 + LT < L) fetch(l0 + LT);
         if (owner) {
             for (int l = 0; l < nl; l++) {
                 const double wl  = sw[l];
@@ -950,6 +980,7 @@ static void build_win_desc(const icg_partition &pt, const uint8_t *reassemble, c
         d.K          = pt.plan_valid ? pt.plan.pose_off[(size_t) w + 1] - pt.plan.pose_off[(size_t) w] : 0;
         d.reassemble = reassemble ? reassemble[w] : 1;
         d.damp       = damp ? damp[w] : (pt.damp.size() == (size_t) W ? pt.damp[(size_t) w] : 0.0);
+        d.NB = d.pad = 0;
     }
 }
 
@@ -971,7 +1002,8 @@ static int schur_impl(icg_ctx *ctx, icg_partition &pt, int P, const int32_t *col
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
     if (P > 512) return icg_fail(ctx, ICG_ERR_CAPACITY, "reduced systems of more than 512 camera columns are not supported (%d)", P);
     const int TQ = (P + 3) / 4, NT = TQ * (TQ + 1) / 2;
-    const size_t red_lds = sizeof(double) * ((size_t) SCH_LT * 4 * TQ + 2 * SCH_LT); // <= 64.5 KB at P = 512
+    const int red_LT     = std::max(1, std::min(SCH_LT, (256 * SCH_PRE) / (4 * TQ)));
+    const size_t red_lds = sizeof(double) * ((size_t) red_LT * 4 * TQ + 2 * (size_t) red_LT); // <= 24.5 KB
     if (int rca = rpj_allow_lds(ctx, k_schur_reduce_w, red_lds, 1)) return rca;
     // system layout
     if (!pt.sys_valid || pt.sys_P != P) {
@@ -1016,11 +1048,40 @@ static int schur_impl(icg_ctx *ctx, icg_partition &pt, int P, const int32_t *col
         if (reassemble[w] || damp[w] != pt.damp[(size_t) w]) pt.damp[(size_t) w] = damp[w];
     std::vector<win_desc> wd;
     build_win_desc(pt, reassemble, damp, wd);
+    // column blocks of the landmark rows: owned blocks start where their owner's column 0 sits, unowned columns in runs of up to six
+    std::vector<std::vector<int32_t>> blk((size_t) W);
+    int NBmax = 1;
+    for (int w = 0; w < W; w++) {
+        const int16_t *ow = &owner[(size_t) w * P];
+        std::vector<int32_t> &B = blk[(size_t) w];
+        for (int a = 0; a < P;) {
+            const int o = ow[a];
+            if (o < 0) {
+                int wdt = 1;
+                while (a + wdt < P && wdt < 6 && ow[a + wdt] < 0) wdt++;
+                B.push_back(a | (wdt << 12) | (ASM_BLK_GAP << 16));
+                a += wdt;
+            } else if ((o >> 3) == ASM_EXT && (o & 7) == 6) {
+                a += 1; // td: part of the (td, h_ll, b_l) block below
+            } else {
+                B.push_back(a | (6 << 12) | ((o >> 3) << 16)); // (claim() laid the six columns of a pose / the extrinsic down contiguously)
+                a += 6;
+            }
+        }
+        B.push_back((col_td[w] >= 0 ? col_td[w] : 0xFFF) | (1 << 12) | (ASM_BLK_TD << 16));
+        wd[(size_t) w].NB = (int32_t) B.size();
+        NBmax             = std::max(NBmax, (int) B.size());
+    }
+    if (NBmax > 256) return icg_fail(ctx, ICG_ERR_CAPACITY, "a window's camera columns fall into %d blocks (limit 256)", NBmax);
+    std::vector<int32_t> blocks((size_t) W * NBmax, 0);
+    for (int w = 0; w < W; w++) std::copy(blk[(size_t) w].begin(), blk[(size_t) w].end(), blocks.begin() + (size_t) w * NBmax);
     icg_call c(ctx);
-    rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(int16_t) * owner.size() + (size_t) n + sizeof(double) * ((size_t) W * ((size_t) P * P + 2 * (size_t) P + 1)) + 8192);
+    rc = c.reserve(sizeof(win_desc) * (size_t) W + sizeof(int16_t) * owner.size() + sizeof(int32_t) * blocks.size() + (size_t) n +
+                   sizeof(double) * ((size_t) W * ((size_t) P * P + 2 * (size_t) P + 1)) + 8192);
     if (rc) return rc;
     const win_desc *d_wd = c.in(wd.data(), (size_t) W);
     const int16_t *d_own = c.in(owner.data(), owner.size());
+    const int32_t *d_blk = c.in(blocks.data(), blocks.size());
     const uint8_t *d_act = active ? c.in(active, (size_t) n) : nullptr;
     auto t_prep = tnow();
     if ((rc = c.seal())) return rc;
@@ -1053,14 +1114,14 @@ static int schur_impl(icg_ctx *ctx, icg_partition &pt, int P, const int32_t *col
                                d_wd, (const int32_t *) pl.d_perm, d_r, d_J, d_act, pl.d_part);
         hipLaunchKernelGGL(k_asm_camera, dim3((unsigned) ((P * P + P + 255) / 256), W), dim3(256), 0, ctx->stream, d_wd, (const int32_t *) pl.d_run_off,
                            (const int32_t *) pl.d_pair_run, pl.Kmax, d_own, P, (const double *) pl.d_part, ctx->d_sys);
-        const int LB = std::max(1, 1024 / (P + 2)); // landmarks per workgroup: at most four cells per thread
-        hipLaunchKernelGGL(k_asm_landmarks, dim3((unsigned) ((Lmax + LB - 1) / LB), W), dim3(256), 0, ctx->stream, d_wd, d_own, P, LB,
+        const int LB = std::max(1, 256 / NBmax); // landmarks per workgroup: one (landmark, block) pair per thread
+        hipLaunchKernelGGL(k_asm_landmarks, dim3((unsigned) ((Lmax + LB - 1) / LB), W), dim3(256), 0, ctx->stream, d_wd, d_blk, NBmax, P, LB,
                            (const int32_t *) pl.d_lm_foff, reinterpret_cast<const int4 *>(pl.d_lrec), d_r, d_J, d_act, ctx->d_sys);
     }
     {
         icg_prof_scope ps(ctx, "schur_reduce");
         hipLaunchKernelGGL(k_schur_inv_w, dim3((Lmax + 255) / 256, W), dim3(256), 0, ctx->stream, d_wd, P, ctx->d_sys, min_diag, max_diag);
-        hipLaunchKernelGGL(k_schur_reduce_w, dim3((unsigned) ((NT + 255) / 256), W), dim3(256), red_lds, ctx->stream, d_wd, P, (const double *) ctx->d_sys, d_S, d_s,
+        hipLaunchKernelGGL(k_schur_reduce_w, dim3((unsigned) ((NT + 255) / 256), W), dim3(256), red_lds, ctx->stream, d_wd, P, red_LT, (const double *) ctx->d_sys, d_S, d_s,
                            d_dg, (S_view || resident) ? 1 : 0);
         // the cost belongs to the linearization point: only meaningful while the resident residuals are the ones assembled
         if (any_new) hipLaunchKernelGGL(k_reproj_cost_w, dim3(W), dim3(256), 0, ctx->stream, d_wd, d_r, d_act, ctx->last_huber, d_cost);
@@ -1339,7 +1400,7 @@ extern "C" int icg_reproj_eval_windows(icg_ctx *ctx, int n_poses, const double *
     ctx->last_huber   = huber_delta;
     ctx->last_n_poses = n_poses;
     ctx->last_n_lm    = n_lm;
-    return c.finish();
+    return c.finish_async(); // nothing comes back: the assembly / cost call that follows is stream-ordered behind the evaluation
 }
 
 static int windows_args_ok(icg_ctx *ctx, int P, const int32_t *col_pose, const int32_t *col_ext, const int32_t *col_td, const uint8_t *reassemble,
@@ -1366,7 +1427,7 @@ extern "C" int icg_reproj_reserve_windows(icg_ctx *ctx, int P) {
     int rc = ensure_sys_capacity(ctx, doubles + 8);
     if (rc) return rc;
     icg_call c(ctx);
-    return c.reserve(sizeof(win_desc) * (size_t) W + sizeof(int16_t) * (size_t) W * (size_t) P + (size_t) n +
+    return c.reserve(sizeof(win_desc) * (size_t) W + (sizeof(int16_t) + sizeof(int32_t)) * (size_t) W * (size_t) P + (size_t) n +
                      sizeof(double) * ((size_t) W * ((size_t) P * P + 2 * (size_t) P + 1)) + 8192);
 }
 

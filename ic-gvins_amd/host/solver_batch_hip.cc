@@ -207,6 +207,14 @@ void WindowSolverBatch::gather(std::vector<double> &poses, std::vector<double> &
 }
 
 namespace {
+struct ThreadJoiner { // a helper thread that is joined on every way out of the scope
+    std::thread t;
+    template <typename F> explicit ThreadJoiner(F &&f) : t(std::forward<F>(f)) {}
+    void join() {
+        if (t.joinable()) t.join();
+    }
+    ~ThreadJoiner() { join(); }
+};
 struct BatchClock { // ICG_SOLVER_DEBUG=1: wall time per phase of the lock-step loop
     bool on = getenv("ICG_SOLVER_DEBUG") != nullptr;
     double ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -261,6 +269,7 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
     const double *S = nullptr; // W x P x P reduced systems, left in the context's pinned staging memory by the reduction kernel (valid until
                                // the next call on ctx_: consumed by the reduced solves below, before the back-substitution call)
     std::vector<uint8_t> reassemble(NW);
+    std::vector<double> host_cost(NW, 0.0);
     auto fail = [&](const char *what) {
         error_ = std::string(what) + ": " + icg_last_error(ctx_);
         return false;
@@ -283,31 +292,42 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
             clk.stop(0);
         }
         if (any_sys) {
+            // The device half (assembly + landmark elimination of every window: one call) and the host half (the host-evaluated factors of
+            // every window that is re-linearized: priors, preintegration, marginalization prior — on the pool) do not depend on each other:
+            // the call runs on a helper thread while this one drives the pool (what WindowSolver::linearize does per window with
+            // runHalves); the sums that need both are formed after the join.
             clk.start();
-            if (dev_solve) {
-                if (icg_reproj_schur_windows_resident(ctx_, P, col_pose_.data(), col_ext_.data(), col_td_.data(), active_.data(), reassemble.data(),
-                                                      damp.data(), o.min_lm_diagonal, o.max_lm_diagonal, s.data(), diag.data(), cost.data()) != ICG_OK)
-                    return fail("icg_reproj_schur_windows_resident");
-            } else if (icg_reproj_schur_windows_view(ctx_, P, col_pose_.data(), col_ext_.data(), col_td_.data(), active_.data(), reassemble.data(), damp.data(),
-                                                     o.min_lm_diagonal, o.max_lm_diagonal, &S, s.data(), diag.data(), cost.data()) != ICG_OK)
-                return fail("icg_reproj_schur_windows_view");
-            clk.stop(1);
-            clk.start();
+            int dev_rc = ICG_OK;
+            ThreadJoiner dev([&] {
+                dev_rc = dev_solve ? icg_reproj_schur_windows_resident(ctx_, P, col_pose_.data(), col_ext_.data(), col_td_.data(), active_.data(), reassemble.data(),
+                                                                       damp.data(), o.min_lm_diagonal, o.max_lm_diagonal, s.data(), diag.data(), cost.data())
+                                   : icg_reproj_schur_windows_view(ctx_, P, col_pose_.data(), col_ext_.data(), col_td_.data(), active_.data(), reassemble.data(),
+                                                                   damp.data(), o.min_lm_diagonal, o.max_lm_diagonal, &S, s.data(), diag.data(), cost.data());
+            });
             std::atomic<int> host_failed{0};
+            host_cost.assign(NW, 0.0);
+            forEachWindow(NW, [&](size_t w) {
+                if (st[w].done || !st[w].relinearize) return;
+                Window &W = windows_[w];
+                W.host_S.assign((size_t) P * P, 0.0), W.host_s.assign((size_t) P, 0.0), W.host_diag.assign((size_t) P, 0.0);
+                if (!solver_detail::hostFactors(W.blocks, W.block_of, W.residuals, P, W.host_S.data(), W.host_s.data(), W.host_diag.data(), &host_cost[w])) host_failed++;
+            });
+            clk.stop(2);
+            clk.start();
+            dev.join();
+            clk.stop(1); // (what is left of the device call once the host half is through)
+            if (dev_rc != ICG_OK) return fail(dev_solve ? "icg_reproj_schur_windows_resident" : "icg_reproj_schur_windows_view");
+            if (host_failed.load()) {
+                error_ = "a host cost function failed to evaluate";
+                return false;
+            }
+            clk.start();
             forEachWindow(NW, [&](size_t w) {
                 if (st[w].done || !(st[w].relinearize || st[w].redamp)) return;
                 Window &W = windows_[w];
-                if (st[w].relinearize) {
-                    W.host_S.assign((size_t) P * P, 0.0), W.host_s.assign((size_t) P, 0.0), W.host_diag.assign((size_t) P, 0.0);
-                    double hc = 0;
-                    if (!solver_detail::hostFactors(W.blocks, W.block_of, W.residuals, P, W.host_S.data(), W.host_s.data(), W.host_diag.data(), &hc)) {
-                        host_failed++;
-                        return;
-                    }
-                    // the cost at the linearization point initialises the window on the first pass; afterwards it equals the accepted
-                    // trial cost and is kept (the same bookkeeping as WindowSolver)
-                    if (first) st[w].cost = cost[w] + hc, sum[w].initial_cost = st[w].cost;
-                }
+                // the cost at the linearization point initialises the window on the first pass; afterwards it equals the accepted
+                // trial cost and is kept (the same bookkeeping as WindowSolver)
+                if (st[w].relinearize && first) st[w].cost = cost[w] + host_cost[w], sum[w].initial_cost = st[w].cost;
                 // the window's reduced system is used where it arrived (S, s, diag of the batched call) plus the host factors' part: no
                 // per-window copy of the P x P block (9 MB per step at 256 windows)
                 st[w].s.resize((size_t) P), st[w].diag.resize((size_t) P);
@@ -317,10 +337,6 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
                 }
                 st[w].relinearize = st[w].redamp = false;
             });
-            if (host_failed.load()) {
-                error_ = "a host cost function failed to evaluate";
-                return false;
-            }
             if (dev_solve) { // the host factors' part of every window that was just linearized: packed lower triangles, one upload
                 upd_idx.clear();
                 for (size_t w = 0; w < NW; w++)
@@ -464,23 +480,33 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
         for (size_t w = 0; w < NW; w++) any_trial |= st[w].stepped;
         clk.stop(5);
         if (!any_trial) continue;
+        // the trial costs: the visual factors' on the device (evaluation + cost reduction, one call each) beside the host factors' on the pool
         clk.start();
         gather(poses, ext, inv, td);
-        if (icg_reproj_eval_windows(ctx_, n_poses_, poses.data(), ext.data(), n_lm_, inv.data(), td.data(), 0, huber_) != ICG_OK)
-            return fail("icg_reproj_eval_windows");
-        if (icg_reproj_cost_windows(ctx_, active_.data(), cost.data()) != ICG_OK) return fail("icg_reproj_cost_windows");
+        const char *dev_fail = nullptr;
+        ThreadJoiner trial([&] {
+            if (icg_reproj_eval_windows(ctx_, n_poses_, poses.data(), ext.data(), n_lm_, inv.data(), td.data(), 0, huber_) != ICG_OK)
+                dev_fail = "icg_reproj_eval_windows";
+            else if (icg_reproj_cost_windows(ctx_, active_.data(), cost.data()) != ICG_OK)
+                dev_fail = "icg_reproj_cost_windows";
+        });
+        std::atomic<int> trial_failed{0};
+        host_cost.assign(NW, 0.0);
+        forEachWindow(NW, [&](size_t w) {
+            if (!st[w].stepped) return;
+            Window &W = windows_[w];
+            if (!solver_detail::hostFactors(W.blocks, W.block_of, W.residuals, P, nullptr, nullptr, nullptr, &host_cost[w])) trial_failed++;
+        });
+        trial.join();
+        if (dev_fail) return fail(dev_fail);
         clk.stop(6);
         clk.start();
-        std::atomic<int> trial_failed{0};
         forEachWindow(NW, [&](size_t w) {
             State &T = st[w];
             if (!T.stepped) return;
             Window &W = windows_[w];
-            double hc = 0;
-            if (!solver_detail::hostFactors(W.blocks, W.block_of, W.residuals, P, nullptr, nullptr, nullptr, &hc)) {
-                trial_failed++;
-                return;
-            }
+            const double hc = host_cost[w];
+            if (trial_failed.load()) return;
             T.new_cost       = cost[w] + hc;
             const double rho = (T.cost - T.new_cost) / T.model;
             if (rho > o.min_relative_decrease) {
@@ -510,7 +536,7 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
         clk.stop(7);
     }
     if (clk.on)
-        fprintf(stderr, "[WindowSolverBatch] %zu windows: eval+jac %.2f, schur %.2f, host linearize %.2f, reduced solves %.2f, backsub %.2f, model+apply %.2f, "
+        fprintf(stderr, "[WindowSolverBatch] %zu windows: eval+jac %.2f, schur beyond the host half %.2f, host linearize (beside the device call) %.2f, reduced solves %.2f, backsub %.2f, model+apply %.2f, "
                         "trial eval+cost %.2f, trial host %.2f ms\n",
                 NW, clk.ms[0], clk.ms[1], clk.ms[2], clk.ms[3], clk.ms[4], clk.ms[5], clk.ms[6], clk.ms[7]);
     for (size_t w = 0; w < NW; w++) sum[w].final_cost = st[w].cost;
