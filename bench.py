@@ -543,19 +543,11 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
                    "how": "device engine: steps in which only ONE group's streams receive frames, HIP events around every kernel of its launch chain "
                           "(stage kernels of the tracker included): exclusive device time per kernel, nothing else on the GPU.  There is no separate "
                           "device-only ceiling: the timed run itself has no tracker logic on the host"}
-    # template set-up reuse in the LK calls (icg_lk_track_fb_reuse): points tracked / points whose hint passed the entry point's checks
-    lk_reuse = [0, 0]
-    for c in ctx_all:
-        o2 = (C.c_uint64 * 2)()
-        if hip.icg_lk_reuse_stats(c, o2) == 0:
-            lk_reuse[0] += int(o2[0])
-            lk_reuse[1] += int(o2[1])
     n_groups = sb.n_groups()
     sb.close()
     for p in dev_ptrs:
         hip.icg_dev_free(ctxh, p)
-    return {"lk_reuse": {"points": lk_reuse[0], "hinted": lk_reuse[1], "fraction": round(lk_reuse[1] / max(1, lk_reuse[0]), 4)},
-            "ceiling": ceiling, "witness": {s: {"frames": host_keep[s], "poses": poses[s], "digest": stats[s]["digest"], "stream_id": sids[s]} for s in witness},
+    return {"ceiling": ceiling, "witness": {s: {"frames": host_keep[s], "poses": poses[s], "digest": stats[s]["digest"], "stream_id": sids[s]} for s in witness},
             "frames_per_stream_at_digest": prime + warmup + steps, "ring": ring, "rates": rates, "cpu_cores_busy": round(cpu_cores_used, 2),
             "elapsed": elapsed, "states_hist": states_hist, "tracked": tracked, "stats": stats, "step_stats": step_stats,
             "host_breakdown": host_breakdown, "kernel_table": kernel_table, "work": work, "n_groups": n_groups, "setup_s": t_setup,
@@ -1479,7 +1471,6 @@ def main():
             "rates": fe["rates"],
             "hbm_peak_measured_GBps": round(hbm_peak_measured, 1) if hbm_peak_measured else None,
             "kernel_ceiling": ceiling,
-            "lk_setup_reuse": fe.get("lk_reuse"),
             "kernels": kernel_table,
             "host_ms_per_step": host_breakdown,
             "step_stats": step_stats,

@@ -117,6 +117,13 @@ extern "C" int icg_ctx_create(const icg_ctx_config *cfg, icg_ctx **out) {
         ctx->n_levels++;
     }
     ctx->slot_bytes = off;
+    // what k_pyrdown_rows (image.hip) reads a source level with: aligned dwords, 12-byte windows that may end 8 bytes past a row
+    for (int l = 0; l + 1 < ctx->n_levels; l++)
+        if (ctx->lv[l].pitch % 4 != 0 || ctx->lv[l].off % 4 != 0 || ctx->lv[l].off + (size_t) ctx->lv[l].pitch * ctx->lv[l].h + 8 > ctx->slot_bytes ||
+            ctx->lv[l].w < 8 || ctx->lv[l].h < 6 || ctx->lv[l].pitch < 16) {
+            ctx->err = "icg_ctx_create: pyramid layout does not meet the row-stream kernel's invariants";
+            return bail(ICG_ERR_INVALID);
+        }
     ctx->raw_pitch  = ctx->lv[0].pitch;
     size_t tiles2   = (size_t) ICG_CLAHE_TILES * ICG_CLAHE_TILES;
     if ((rc = icg_hip_check(ctx, hipMalloc(&ctx->d_frames, ctx->slot_bytes * (size_t) cfg->n_slots), "hipMalloc frames")))
@@ -147,8 +154,6 @@ extern "C" void icg_ctx_destroy(icg_ctx *ctx) {
                    ctx->d_fwin,   ctx->d_lmwin};
     for (void *p : dev)
         if (p) (void) hipFree(p);
-    for (int b = 0; b < 2; b++)
-        if (ctx->d_lkc[b]) (void) hipFree(ctx->d_lkc[b]);
     if (ctx->d_redS) (void) hipFree(ctx->d_redS);
     if (ctx->d_hostS) (void) hipFree(ctx->d_hostS);
     for (icg_partition *pt : {&ctx->part_1, &ctx->part_w}) {
@@ -185,8 +190,8 @@ int icg_arena_reserve(icg_ctx *ctx, size_t bytes) {
     if (ctx->arena_off != 0) return icg_fail(ctx, ICG_ERR_NOMEM, "arena grow requested mid-call");
     size_t cap = icg_align_up(bytes + bytes / 2, 1 << 16);
     ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // only the staging arena pair is replaced here: the LK set-up cache (d_lkc), the resident reduced systems (d_redS) and the
-    // packed host parts (d_hostS) are independent allocations that live until icg_ctx_destroy
+    // only the staging arena pair is replaced here: the resident reduced systems (d_redS) and the packed host parts (d_hostS) are
+    // independent allocations that live until icg_ctx_destroy
     if (ctx->h_arena) (void) hipHostFree(ctx->h_arena);
     if (ctx->d_arena) (void) hipFree(ctx->d_arena);
     ctx->h_arena = nullptr;

@@ -125,15 +125,6 @@ struct icg_ctx {
     int hostS_P = 0, hostS_W = 0;
 
 
-    // LK template set-up cache (lk.hip, icg_lk_track_fb_reuse): two buffers of one block per point, alternating per call, and what
-    // every block of each buffer was written for (slot + slot generation); slot_gen counts the preprocess calls per frame slot
-    unsigned int *d_lkc[2] = {nullptr, nullptr};
-    size_t lkc_cap = 0;
-    int lkc_cur = 0, lkc_last_n = 0;
-    std::vector<int32_t> lkc_slot[2];
-    std::vector<uint32_t> lkc_gen[2], slot_gen;
-    uint64_t lkc_hits_hinted = 0, lkc_points = 0;
-
     icg_camera cam{};
     bool has_cam = false;
 

@@ -11,8 +11,7 @@
 //                 redistribute, 256-bin block scan -> LUT (441 x 256 B per frame, stays in L2)
 //   k_clahe_apply one workgroup per (interpolation strip, 256-px chunk, frame): the <=2x8 LUTs the chunk needs are
 //                 staged in LDS, rows are read/written as coalesced uchar4 per lane
-//   k_pyramid3    all three pyrDown steps of the usual 4-level pyramid in one launch (LDS -> LDS, see below)
-//   k_pyrdown     single step, used only when the image is too small for 4 levels
+//   k_pyrdown_rows one pyrDown step as a row stream: no LDS, 12-byte source windows per lane, SWAR vertical sums (see below)
 // Algorithmic bytes per frame: CLAHE 3*W*H, pyramid 1.640625*W*H.
 #include <algorithm>
 
@@ -62,7 +61,6 @@ __global__ void k_hist256(pre_jobs jobs, int w, int h, unsigned int *hist /*n x 
 struct clahe_geom {
     int w, h, tw, th, clip;
     float lut_scale, inv_tw, inv_th;
-    int legacy; // A/B switch (ICG_CLAHE_LEGACY=1): the round-1..4 forms of the histogram pass and of the staged LUT
 };
 
 // one WAVE per (tile, frame): rows are read as aligned dwords (reflect-101 only on the padded right/bottom border),
@@ -124,7 +122,7 @@ __global__ __launch_bounds__(64) void k_clahe_lut(pre_jobs jobs, clahe_geom g, u
     // multiply-add and a bounds test per dword (rounds 1-4: ~46 issue units per dword, now ~12).  Tiles wider than 16 interior dwords or
     // touching the padded right / bottom border (the last tile row and column only) keep the general loop.
     const int nin = ndw - 2;
-    const bool fast = !g.legacy && nin >= 1 && nin <= 16 && y_begin + g.th <= g.h && xa + 4 * ndw <= g.w; // wave-uniform
+    const bool fast = nin >= 1 && nin <= 16 && y_begin + g.th <= g.h && xa + 4 * ndw <= g.w; // wave-uniform
     if (fast) {
         const int d = lane & 15, q = lane >> 4;
         const bool on = d < nin;
@@ -377,58 +375,16 @@ __global__ __launch_bounds__(256) void k_clahe_apply(pre_jobs jobs, clahe_geom g
     const int p_lo   = (int) floorf(x_begin * g.inv_tw - 0.5f) + 1;
     const int p_hi   = (int) floorf((x_end - 1) * g.inv_tw - 0.5f) + 1;
     const int npairs = p_hi - p_lo + 1; // <= CLAHE_MAXCOLS by construction of the launch (checked on host)
-    if (npairs <= CLAHE_FCOLS && !g.legacy) // workgroup-uniform
+    if (npairs <= CLAHE_FCOLS) // workgroup-uniform
         clahe_apply_body<true>(jobs, g, lut, frames, slot_bytes, dpitch, slut, strip, chunk, b, t, dslot, p_lo, npairs, x_begin);
     else
         clahe_apply_body<false>(jobs, g, lut, frames, slot_bytes, dpitch, slut, strip, chunk, b, t, dslot, p_lo, npairs, x_begin);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-#define PD_TW 64
-#define PD_TH 16
-#define PD_IW (2 * PD_TW + 3)
-#define PD_IH (2 * PD_TH + 3)
-
-__global__ __launch_bounds__(256) void k_pyrdown(uint8_t *frames, size_t slot_bytes, pre_jobs jobs,
-                                                 unsigned int src_off, int sw, int sh, int spitch,
-                                                 unsigned int dst_off, int dw, int dh, int dpitch) {
-    __shared__ uint8_t in[PD_IH][PD_IW + 1];
-    __shared__ int tmp[PD_IH][PD_TW];
-    const int b      = blockIdx.z;
-    const int dslot  = pre_job_slot(jobs, b);
-    if (dslot < 0) return; // idle job (workgroup-uniform)
-    uint8_t *slot    = frames + (size_t) dslot * slot_bytes;
-    const uint8_t *s = slot + src_off;
-    uint8_t *d       = slot + dst_off;
-    const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH; // output tile origin
-    const int ix0 = 2 * ox - 2, iy0 = 2 * oy - 2;
-    const int t = threadIdx.x;
-    for (int i = t; i < PD_IH * PD_IW; i += 256) {
-        int r = i / PD_IW, c = i - r * PD_IW;
-        int sx = icg_reflect101(ix0 + c, sw), sy = icg_reflect101(iy0 + r, sh);
-        in[r][c] = s[(size_t) sy * spitch + sx];
-    }
-    __syncthreads();
-    for (int i = t; i < PD_IH * PD_TW; i += 256) {
-        int r = i / PD_TW, c = i - r * PD_TW;
-        const uint8_t *p = &in[r][2 * c];
-        tmp[r][c]        = p[0] + p[4] + 4 * (p[1] + p[3]) + 6 * p[2];
-    }
-    __syncthreads();
-    for (int i = t; i < PD_TH * PD_TW; i += 256) {
-        int r = i / PD_TW, c = i - r * PD_TW;
-        int x = ox + c, y = oy + r;
-        if (x < dw && y < dh) {
-            int v = tmp[2 * r][c] + tmp[2 * r + 4][c] + 4 * (tmp[2 * r + 1][c] + tmp[2 * r + 3][c]) + 6 * tmp[2 * r + 2][c];
-            d[(size_t) y * dpitch + x] = (uint8_t) ((v + 128) >> 8);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// One pyrDown step as a ROW STREAM (round 5; replaces k_pyramid3 on the default path).  The front-end as a whole is bound by VALU issue
+// One pyrDown step as a ROW STREAM (round 5; the LDS tile kernels of rounds 1-4, k_pyramid3 / k_pyrdown, are gone since round 6).  The front-end as a whole is bound by VALU issue
 // (~88 % of the issue slots of the co-resident kernel mix are taken), so what a streaming kernel costs the frame rate is
-// its instruction count, not its HBM fraction — and the tile kernel below spends 24 VALU + 16 SALU instructions per level-0 pixel
+// its instruction count, not its HBM fraction — and the tile kernel spent 24 VALU + 16 SALU instructions per level-0 pixel
 // (rocprofv3, profiles/r04_pmc_summary.json): 1.74x / 1.6x halo recomputation per level, per-item index arithmetic, three LDS round trips.
 // Here a wave owns 128 output columns (a lane: output columns 2l, 2l+1 <- the 12 source bytes x-4 .. x+7, ONE global_load_dwordx3 per source
 // row) and a band of output rows, and streams down the band with the horizontal [1 4 6 4 1] sums of the last five source rows in registers
@@ -437,8 +393,12 @@ __global__ __launch_bounds__(256) void k_pyrdown(uint8_t *frames, size_t slot_by
 // (the neighbours' bytes come with the lane's own 12-byte load).  ~5 issue units per source pixel and level instead of ~40.
 // Borders: BORDER_REFLECT_101 of the level's own image — rows by a scalar reflect of the row index; columns by per-lane byte selectors
 // computed once (v_perm picks the reflected partner out of the same 12-byte window: every partner a valid output needs lies inside it),
-// only in the waves that touch the left or right image edge (wave-uniform branch).  Exact integers; results identical to k_pyramid3 /
-// k_pyrdown (tests/test_gpu_frontend.py: all levels at 4 sizes incl. 333 x 257 and 1278 x 1022).
+// only in the waves that touch the left or right image edge (wave-uniform branch).  Exact integers (tests/test_gpu_frontend.py: all levels
+// against the oracle at 4 sizes incl. 333 x 257 and 1278 x 1022).
+// Layout the loads rely on (static in csrc/ctx.hip, checked at icg_ctx_create): every level's pitch and slot offset are multiples of 4 (the
+// 12-byte windows are read as three aligned dwords) and a source level is never the last region of a slot — the window of the last pixels of
+// a row reaches up to 8 bytes past the row, on the last row of a level whose pitch equals its width into the NEXT level's region, which
+// this launch may be writing: those bytes are never selected (benign for the result, worth knowing under a race detector).
 #define PR_STRIP_OUT 128 // output columns per wave
 struct pr_sel {
     unsigned int a, b, t, v; // selectors of (V-2 V-1 V0 V1), (V0 V1 V2 V3), the (E1, E0) candidate of V4, and V4 out of (E2, candidate)
@@ -529,160 +489,6 @@ __global__ __launch_bounds__(64) void k_pyrdown_rows(uint8_t *frames, size_t slo
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Fused 3-step pyramid (the common 4-level case): one workgroup owns a 16x8 tile of level 3 and everything below it
-// (32x16 of level 2, 64x32 of level 1); the 164x85 level-0 neighbourhood is staged once as dwords and the three
-// pyrDown steps run LDS -> LDS, so level 0 is read ~1.7x (mostly L2 hits) instead of the per-level kernels' three
-// dependent launches.  Exact integers throughout: the horizontal [1 4 6 4 1] sums (<= 4080) are kept as packed u16
-// pairs and the vertical pass is plain 32-bit SWAR arithmetic on those pairs (<= 65408 per field: no cross-field carry).
-//
-// Region geometry, columns chosen so that every level's OWNED columns start on a dword of both its LDS tile and its
-// image row (X3 = 16*blockIdx.x, Y3 = 8*blockIdx.y):
-//   level 3 tile  16 x 8    x3 = X3 + c            y3 = Y3 + r
-//   level 2 tile  40 x 19   x2 = 2*X3 - 4 + c      y2 = 2*Y3 - 2 + r    (owned: c 4..35, r 2..17)
-//   level 1 tile  80 x 41   x1 = 4*X3 - 12 + c     y1 = 4*Y3 - 6 + r    (owned: c 12..75, r 6..37)
-//   level 0 tile 168 x 85   x0 = 8*X3 - 28 + c     y0 = 8*Y3 - 14 + r
-// so output column j of a step reads input columns 2j+2 .. 2j+6 (D = 2) and output row i reads input rows 2i .. 2i+4.
-// Tile entries that fall outside their level's image are replaced by their reflect-101 partner before the next step
-// (pyrDown's BORDER_REFLECT_101 applies to each level's own image).
-#define P3_L0S 168
-#define P3_L0H 85
-#define P3_L1S 88
-#define P3_L1W 80
-#define P3_L1H 41
-#define P3_L2S 40
-#define P3_L2H 19
-
-__device__ __forceinline__ unsigned int p3_load4(const uint8_t *row, int x, int w) {
-    if (x >= 0 && x + 3 < w) return *reinterpret_cast<const unsigned int *>(row + x); // x % 4 == 0 by construction
-    unsigned int v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) v |= (unsigned int) row[icg_reflect101(x + k, w)] << (8 * k);
-    return v;
-}
-
-template <int IH, int IS, int OH, int OS, int OWQ>
-__device__ __forceinline__ void p3_step(const unsigned int *in, unsigned int *tmp, unsigned int *out, int t, uint8_t *dst,
-                                        int dpitch, int dw, int dh, int gx0, int gy0, int own_q0, int own_q1, int own_r0,
-                                        int own_r1) {
-    constexpr int TS = 2 * OWQ; // packed pairs per tmp row
-    static_assert(IS % 4 == 0 && IS / 4 >= TS + 2, "input tile too narrow");
-    static_assert(IH >= 2 * OH + 3 && OS % 4 == 0 && OS / 4 >= OWQ, "tile geometry");
-    // horizontal [1 4 6 4 1] at even input columns: pair m = output columns 2m, 2m+1 <- input bytes 4m+2 .. 4m+8.
-    // Fixed (row, pair) mapping per thread (no per-item division); the 4 inner taps are one v_dot4_u32_u8 each:
-    //   h0 = [1 4 6 4].(b2..b5) + b6,   h1 = [1 4 6 4].(b4..b7) + b8     (b0..b11 = bytes of dwords m, m+1, m+2)
-    {
-        constexpr int RPP = 256 / TS, NP = (IH + RPP - 1) / RPP; // rows per pass, passes (fully unrolled: constant offsets)
-        const int rr = t / TS, m = t - rr * TS;
-        if (rr < RPP) {
-            const unsigned int *pin = in + rr * (IS / 4) + m;
-            unsigned int *pout      = tmp + rr * TS + m;
-#pragma unroll
-            for (int k = 0; k < NP; k++) {
-                if (k < IH / RPP || rr + k * RPP < IH) { // only the last pass is partial (compile-time for the others)
-                    const unsigned int *p = pin + k * RPP * (IS / 4);
-                    const unsigned int d0 = p[0], d1 = p[1], d2 = p[2];
-                    const unsigned int lo = __builtin_amdgcn_alignbyte(d1, d0, 2), hi = __builtin_amdgcn_alignbyte(d2, d1, 2);
-                    const unsigned int h0 = __builtin_amdgcn_udot4(lo, 0x04060401u, hi & 0xffu, false);
-                    const unsigned int h1 = __builtin_amdgcn_udot4(d1, 0x04060401u, (hi >> 16) & 0xffu, false);
-                    pout[k * RPP * TS] = h0 | (h1 << 16);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // vertical pass on packed pairs, 4 output columns per item; (v + 128) >> 8 as in OpenCV's u8 pyrDown
-    {
-        constexpr int RPP = 256 / OWQ, NP = (OH + RPP - 1) / RPP;
-        const int rr = t / OWQ, q = t - rr * OWQ;
-        if (rr < RPP) {
-#pragma unroll
-            for (int k = 0; k < NP; k++) {
-                const int r = rr + k * RPP;
-                if (k >= OH / RPP && r >= OH) break; // only the last pass is partial
-                const uint2 *c = reinterpret_cast<const uint2 *>(tmp + (2 * r) * TS + 2 * q);
-                const uint2 t0 = c[0], t1 = c[TS / 2], t2 = c[TS], t3 = c[3 * TS / 2], t4 = c[2 * TS];
-                const unsigned int a = t0.x + t4.x + ((t1.x + t3.x) << 2) + (t2.x << 2) + (t2.x << 1) + 0x00800080u;
-                const unsigned int b = t0.y + t4.y + ((t1.y + t3.y) << 2) + (t2.y << 2) + (t2.y << 1) + 0x00800080u;
-                const unsigned int v = __builtin_amdgcn_perm(b >> 8, a >> 8, 0x06040200u);
-                out[r * (OS / 4) + q] = v;
-                const int x = gx0 + 4 * q, y = gy0 + r;
-                if (q >= own_q0 && q < own_q1 && r >= own_r0 && r < own_r1 && x < dw && y < dh)
-                    *reinterpret_cast<unsigned int *>(dst + (size_t) y * dpitch + x) = v; // row padding absorbs x+3 >= dw
-            }
-        }
-    }
-    __syncthreads();
-}
-
-template <int OH, int OS, int OW>
-__device__ __forceinline__ void p3_reflect_fix(unsigned int *tile32, int t, int gx0, int gy0, int dw, int dh) {
-    if (gx0 >= 0 && gy0 >= 0 && gx0 + OW <= dw && gy0 + OH <= dh) return; // workgroup-uniform
-    uint8_t *tile = reinterpret_cast<uint8_t *>(tile32);
-    for (int i = t; i < OH * OW; i += 256) {
-        const int r = i / OW, c = i - r * OW;
-        const int x = gx0 + c, y = gy0 + r;
-        if (x < 0 || x >= dw || y < 0 || y >= dh) {
-            const int rx = icg_reflect101(x, dw) - gx0, ry = icg_reflect101(y, dh) - gy0;
-            // a partner outside the tile is only ever needed by entries that are themselves out of range one level up
-            tile[r * OS + c] = (rx >= 0 && rx < OW && ry >= 0 && ry < OH) ? tile[ry * OS + rx] : (uint8_t) 0;
-        }
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void k_pyramid3(icg_pyr_desc P, pre_jobs jobs, int gx, int gy, int n_tiles, unsigned int m_tile, unsigned int m_gx) {
-    __shared__ __attribute__((aligned(16))) unsigned int L0[P3_L0H * P3_L0S / 4];
-    __shared__ __attribute__((aligned(16))) unsigned int TMP[P3_L0H * (P3_L1W / 2)];
-    __shared__ __attribute__((aligned(16))) unsigned int L1[P3_L1H * P3_L1S / 4];
-    __shared__ __attribute__((aligned(16))) unsigned int L2[P3_L2H * P3_L2S / 4];
-    __shared__ __attribute__((aligned(16))) unsigned int L3[8 * 16 / 4];
-    const int t   = threadIdx.x;
-    // 1-D launch, XCD-chunked: every XCD gets whole frames, so the 1.7x halo overlap of neighbouring tiles hits its L2
-    const int b = icg_xcd_chunked(blockIdx.x, n_tiles);
-    if (b >= n_tiles) return;
-    const int job = icg_div_by_magic(b, m_tile), rem = b - job * (gx * gy);
-    const int by = icg_div_by_magic(rem, m_gx), bx = rem - by * gx;
-    const int dslot = pre_job_slot(jobs, job);
-    if (dslot < 0) return; // idle job (workgroup-uniform, before the first barrier)
-    uint8_t *slot = P.base + (size_t) dslot * P.slot_bytes;
-    const int X3 = bx * 16, Y3 = by * 8;
-
-    {
-        const uint8_t *s = slot + P.off[0];
-        const int w = P.w[0], h = P.h[0], pitch = P.pitch[0];
-        const int x0 = 8 * X3 - 28, y0 = 8 * Y3 - 14;
-        constexpr int DW = P3_L0S / 4, RPP = 256 / DW, NP = (P3_L0H + RPP - 1) / RPP; // 42 dwords/row, 6 rows/pass, 15 passes
-        const int rr = t / DW, d = t - rr * DW;
-        const bool inside = x0 >= 0 && x0 + P3_L0S <= w && y0 >= 0 && y0 + P3_L0H <= h; // workgroup-uniform
-        unsigned int v[NP]; // all loads in flight before the first LDS write (one memory round trip per workgroup)
-#pragma unroll
-        for (int k = 0; k < NP; k++) {
-            const int r = rr + k * RPP;
-            v[k]        = 0;
-            if (rr < RPP && (k < P3_L0H / RPP || r < P3_L0H)) {
-                if (inside)
-                    v[k] = *reinterpret_cast<const unsigned int *>(s + (size_t) (y0 + r) * pitch + (x0 + 4 * d));
-                else
-                    v[k] = p3_load4(s + (size_t) icg_reflect101(y0 + r, h) * pitch, x0 + 4 * d, w);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NP; k++) {
-            const int r = rr + k * RPP;
-            if (rr < RPP && (k < P3_L0H / RPP || r < P3_L0H)) L0[r * DW + d] = v[k];
-        }
-        __syncthreads();
-    }
-    p3_step<P3_L0H, P3_L0S, P3_L1H, P3_L1S, P3_L1W / 4>(L0, TMP, L1, t, slot + P.off[1], P.pitch[1], P.w[1], P.h[1], 4 * X3 - 12,
-                                                       4 * Y3 - 6, 3, 19, 6, 38);
-    p3_reflect_fix<P3_L1H, P3_L1S, P3_L1W>(L1, t, 4 * X3 - 12, 4 * Y3 - 6, P.w[1], P.h[1]);
-    p3_step<P3_L1H, P3_L1S, P3_L2H, P3_L2S, P3_L2S / 4>(L1, TMP, L2, t, slot + P.off[2], P.pitch[2], P.w[2], P.h[2], 2 * X3 - 4,
-                                                       2 * Y3 - 2, 1, 9, 2, 18);
-    p3_reflect_fix<P3_L2H, P3_L2S, P3_L2S>(L2, t, 2 * X3 - 4, 2 * Y3 - 2, P.w[2], P.h[2]);
-    p3_step<P3_L2H, P3_L2S, 8, 16, 4>(L2, TMP, L3, t, slot + P.off[3], P.pitch[3], P.w[3], P.h[3], X3, Y3, 0, 4, 0, 8);
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // tracking.cc:98-102 on the device (segmented preprocess only): float histogram, (float)k product in float, /256.0 and accumulation in
 // double, sequentially — a lane per job
 __global__ void k_hist_mean(int n, const unsigned int *hist, int w, int h, double *mean) {
@@ -710,9 +516,6 @@ static int preprocess_impl(icg_ctx *ctx, int n, const int32_t *slots, const int3
     for (int k = 0; k < n && slots; k++)
         if (slots[k] < 0 || slots[k] >= ctx->cfg.n_slots || !images[k]) return icg_fail(ctx, ICG_ERR_INVALID, "bad slot/image %d", k);
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    if (ctx->slot_gen.size() != (size_t) ctx->cfg.n_slots) ctx->slot_gen.assign((size_t) ctx->cfg.n_slots, 0);
-    for (int k = 0; k < n && slots; k++) ctx->slot_gen[(size_t) slots[k]]++; // the slot holds a new image: set-ups cached for the old one are void
-    if (!slots) ctx->lkc_last_n = 0; // (which slots were rewritten is only known on the device: no set-up survives)
     const bool want_hist = hist_mean || d_hist_mean;
 
     // CLAHE geometry
@@ -732,8 +535,6 @@ static int preprocess_impl(icg_ctx *ctx, int n, const int32_t *slots, const int3
     g.clip      = (int) (3.0 * area / 256);
     if (g.clip < 1) g.clip = 1;
     g.inv_tw = 1.0f / g.tw;
-    static const bool clahe_legacy = getenv("ICG_CLAHE_LEGACY") && getenv("ICG_CLAHE_LEGACY")[0] == '1';
-    g.legacy = clahe_legacy ? 1 : 0;
     g.inv_th = 1.0f / g.th;
     if (CLAHE_CHUNK / g.tw + 3 > CLAHE_MAXCOLS)
         return icg_fail(ctx, ICG_ERR_INVALID, "image too small for CLAHE chunking (tile width %d)", g.tw);
@@ -810,35 +611,17 @@ static int preprocess_impl(icg_ctx *ctx, int n, const int32_t *slots, const int3
             hipLaunchKernelGGL(k_clahe_apply, dim3(T + 1, (w + CLAHE_CHUNK - 1) / CLAHE_CHUNK, m), dim3(256), 0, ctx->stream, jobs,
                                g, lut, ctx->d_frames, ctx->slot_bytes, ctx->lv[0].pitch);
         }
-        static const bool tile_pyramid = getenv("ICG_PYRAMID_TILES") && getenv("ICG_PYRAMID_TILES")[0] == '1'; // A/B switch: the round-1..4 tile kernel
-        bool rows_ok = !tile_pyramid;
-        for (int l = 1; l < ctx->n_levels; l++) rows_ok = rows_ok && ctx->lv[l - 1].w >= 8 && ctx->lv[l - 1].h >= 6 && ctx->lv[l - 1].pitch >= 16;
-        if (rows_ok) {
-            for (int l = 1; l < ctx->n_levels; l++) {
-                icg_prof_scope ps(ctx, "pyrdown_rows");
-                const icg_level &a = ctx->lv[l - 1], &bb = ctx->lv[l];
-                const int n_strips = (bb.w + PR_STRIP_OUT - 1) / PR_STRIP_OUT;
-                // bands: enough waves to fill the chip at the level's size (>= ~4 per SIMD for 64 frames at level 1), 3 halo rows per band
-                const int band_rows = bb.h >= 256 ? 32 : bb.h >= 128 ? 16 : 8;
-                const int n_bands   = (bb.h + band_rows - 1) / band_rows;
-                const int n_tasks   = n_strips * n_bands * m;
-                hipLaunchKernelGGL(k_pyrdown_rows, dim3(icg_xcd_grid(n_tasks)), dim3(64), 0, ctx->stream, ctx->d_frames, ctx->slot_bytes, jobs,
-                                   (unsigned int) a.off, a.w, a.h, a.pitch, (unsigned int) bb.off, bb.w, bb.h, bb.pitch, n_strips, n_bands,
-                                   band_rows, n_tasks);
-            }
-        } else if (ctx->n_levels == 4) {
-            icg_prof_scope ps(ctx, "pyramid3");
-            const int gx = (ctx->lv[3].w + 15) / 16, gy = (ctx->lv[3].h + 7) / 8, n_tiles = gx * gy * m;
-            hipLaunchKernelGGL(k_pyramid3, dim3(icg_xcd_grid(n_tiles)), dim3(256), 0, ctx->stream, icg_make_pyr_desc(ctx), jobs, gx,
-                               gy, n_tiles, icg_div_magic(gx * gy), icg_div_magic(gx));
-        } else {
-            for (int l = 1; l < ctx->n_levels; l++) {
-                icg_prof_scope ps(ctx, "pyrdown");
-                const icg_level &a = ctx->lv[l - 1], &bb = ctx->lv[l];
-                hipLaunchKernelGGL(k_pyrdown, dim3((bb.w + PD_TW - 1) / PD_TW, (bb.h + PD_TH - 1) / PD_TH, m), dim3(256), 0,
-                                   ctx->stream, ctx->d_frames, ctx->slot_bytes, jobs, (unsigned int) a.off, a.w, a.h, a.pitch,
-                                   (unsigned int) bb.off, bb.w, bb.h, bb.pitch);
-            }
+        for (int l = 1; l < ctx->n_levels; l++) { // (every source level is at least 43 x 43 with a pitch of 128: icg_ctx_create)
+            icg_prof_scope ps(ctx, "pyrdown_rows");
+            const icg_level &a = ctx->lv[l - 1], &bb = ctx->lv[l];
+            const int n_strips = (bb.w + PR_STRIP_OUT - 1) / PR_STRIP_OUT;
+            // bands: enough waves to fill the chip at the level's size (>= ~4 per SIMD for 64 frames at level 1), 3 halo rows per band
+            const int band_rows = bb.h >= 256 ? 32 : bb.h >= 128 ? 16 : 8;
+            const int n_bands   = (bb.h + band_rows - 1) / band_rows;
+            const int n_tasks   = n_strips * n_bands * m;
+            hipLaunchKernelGGL(k_pyrdown_rows, dim3(icg_xcd_grid(n_tasks)), dim3(64), 0, ctx->stream, ctx->d_frames, ctx->slot_bytes, jobs,
+                               (unsigned int) a.off, a.w, a.h, a.pitch, (unsigned int) bb.off, bb.w, bb.h, bb.pitch, n_strips, n_bands, band_rows,
+                               n_tasks);
         }
     }
     if (d_hist_mean) hipLaunchKernelGGL(k_hist_mean, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, n, d_hist, w, h, d_hist_mean);

@@ -37,9 +37,8 @@ using namespace icgd;
 #define LK_JS 36   // J tile row stride in bytes (9 dwords: 3 aligned dwords cover any 8-byte run)
 #define LK_JM 5    // J tile margin around the 22x22 support
 #define LK_MAX_ITERS 30
-#define ICG_MAX_LK_LEVELS_CACHED 4
 #ifndef LK_WAVES_PER_EU
-#define LK_WAVES_PER_EU 5 // second __launch_bounds__ argument of k_lk_track_fb: 95 VGPRs, no scratch (6 would spill; 4, 5 and 6 measured equal in the bench)
+#define LK_WAVES_PER_EU 5 // second __launch_bounds__ argument of k_lk_track_fb (the resource remarks of the build are quoted in DESIGN.md section 4)
 #endif
 
 struct lk_smem {
@@ -252,6 +251,13 @@ __device__ __forceinline__ int dot2_keep(unsigned int a, unsigned int b, int c) 
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// the same with a wave-uniform accumulator from a scalar register (one SGPR operand is allowed on the constant bus): the rounding constants
+// of the set-up's blends cost no VGPR this way (round 6: pinned in VGPRs they were the two registers k_lk_track_fb spilled at 5 waves)
+__device__ __forceinline__ int dot2_keep_s(unsigned int a, unsigned int b, int c_uniform) {
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+    return d;
+}
 // (lo16(a), lo16(b)) as one packed register
 __device__ __forceinline__ unsigned int pk_lo16(int a, int b) {
     return __builtin_amdgcn_perm((unsigned int) b, (unsigned int) a, 0x05040100u);
@@ -277,26 +283,9 @@ __device__ __forceinline__ void lk_fetch_J(const lk_smem &S, int row0, int o, un
     }
 }
 
-// ---- template set-up cache (round 3) ---------------------------------------------------------------------------------------------------
-// 44 % of the instructions of a track are the per-level SET-UP of the template: staging the 24x24 neighbourhood, the Scharr stencil, the
-// bilinear I / Ix / Iy samples of the lane's run, three exact reductions and the minimum-eigenvalue test.  That set-up depends only on
-// (image, point).  The BACKWARD pass of frame k (template = image k at the forward result) and the FORWARD pass of frame k+1 (template =
-// image k at the feature's position, which IS that forward result, bit for bit) compute the same set-up: the backward pass stores it —
-// per level 15 dwords per lane (c0[7], IXP[4], IYP[4]), the three window sums and the outcome of the eigenvalue test — and the next
-// call's forward pass loads it instead of recomputing (icg_lk_track_fb_reuse: the caller says which point of the previous call a point
-// continues; the entry point checks slot and slot generation, the kernel checks the point's bit pattern and the block's completeness,
-// so a wrong hint is a miss, never a wrong value).  Block: 32 header dwords + 4 levels x 15 x 64 dwords = 15 488 bytes per point.
-#define LKC_HDR 32
-#define LKC_LEVEL (15 * 64)
-#define LKC_DWORDS (LKC_HDR + ICG_MAX_LK_LEVELS_CACHED * LKC_LEVEL)
-#define LKC_ST_MINEIG 2u // the level ended at the minimum-eigenvalue / determinant test
-#define LKC_ST_DATA 3u   // A11, A12, A22 and the lane data are valid
-
 // One calcOpticalFlowPyrLK point, executed cooperatively by a full wave. Returns status.
-// rd: set-up block to take the template set-up from (its header has been validated by the caller), or null;  wr: block to store it to, or null
 __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI, const unsigned char *slotJ,
-                              float2 prevPt, float2 &nextIO, lk_smem &S, int lane, float *err_out, const unsigned int *rd = nullptr,
-                              unsigned int *wr = nullptr) {
+                              float2 prevPt, float2 &nextIO, lk_smem &S, int lane, float *err_out) {
     const float FLT_SCALE = 1.f / (1 << 20);
     const double eps2     = 0.01 * 0.01;
     bool status           = true;
@@ -307,9 +296,9 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
     const int ly          = active ? lane / 3 : 0;
     const int lx0         = active ? (lane - ly * 3) * 7 : 0;
     const unsigned int am = active ? ~0u : 0u; // lane 63 owns no pixels: its derivative weights are zeroed (Ix = Iy = 0 -> no contribution to any sum)
-    // rounding constants of the set-up's blends, kept in registers for dot2_keep (opaque to the optimizer: not re-materialised per use)
+    // rounding constants of the set-up's blends, kept in scalar registers for dot2_keep_s (opaque to the optimizer: not re-materialised per use)
     int rnd13 = 1 << 13, rnd8 = 1 << 8;
-    asm volatile("" : "+v"(rnd13), "+v"(rnd8));
+    asm volatile("" : "+s"(rnd13), "+s"(rnd8));
 
     for (int level = maxLevel; level >= 0; --level) {
         const int W = P.w[level], H = P.h[level], pitch = P.pitch[level];
@@ -335,7 +324,6 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                 status = false;
                 errv   = 0.f;
             }
-            if (wr != nullptr && level < ICG_MAX_LK_LEVELS_CACHED && lane == 0) wr[4 + 4 * level] = 0; // nothing to reuse (the reader skips the level by the same test)
             continue;
         }
         unsigned int W0, W1;
@@ -344,24 +332,19 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
         // ---- stage the 24x24 neighbourhood of the previous image AND the 32x32 tile of the next image around the
         //      level's starting estimate in one go (both address sets are known here) ----
         int jx0 = -1000000, jy0 = -1000000;
-        const bool cached = rd != nullptr && level < ICG_MAX_LK_LEVELS_CACHED; // wave-uniform
-        unsigned int cst  = 0;                                                  // outcome stored for this level by the pass that wrote rd
-        if (cached) cst = rd[4 + 4 * level];
-        const bool use_cache = cached && (cst == LKC_ST_MINEIG || cst == LKC_ST_DATA);
         {
             const int inx0 = (int) floorf(nptx - (float) ICG_LK_HALF), iny0 = (int) floorf(npty - (float) ICG_LK_HALF);
             const bool jok = !(inx0 < -ICG_LK_WIN || inx0 >= W || iny0 < -ICG_LK_WIN || iny0 >= H); // else iteration 0 bails out
             unsigned int vi[3] = {0, 0, 0}, vj[4] = {0, 0, 0, 0};
-            const bool need_j  = jok && !(use_cache && cst == LKC_ST_MINEIG);
-            if (!use_cache) lk_load_I(vi, I, W, H, pitch, ipx, ipy, lane); // (a cached template needs no pixels of the previous image)
-            if (need_j) {
+            lk_load_I(vi, I, W, H, pitch, ipx, ipy, lane);
+            if (jok) {
                 jx0 = inx0 - LK_JM;
                 jy0 = iny0 - LK_JM;
                 lk_load_J(vj, J, W, H, pitch, jx0, jy0, lane);
             }
             __syncthreads(); // previous level's LDS readers are done
-            if (!use_cache) lk_store_I(S, vi, lane);
-            if (need_j) lk_store_J(S, vj, lane);
+            lk_store_I(S, vi, lane);
+            if (jok) lk_store_J(S, vj, lane);
             __syncthreads();
         }
 
@@ -373,24 +356,7 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
         unsigned int IXP[4], IYP[4];
         int sA11 = 0, sA12 = 0, sA22 = 0;
         float A11, A12, A22;
-        if (use_cache) {
-            if (cst == LKC_ST_MINEIG) { // the same template failed the eigenvalue / determinant test when it was set up
-                if (level == 0) status = false;
-                continue;
-            }
-            // (streamed once: non-temporal, so that the blocks do not push the pyramid tiles out of the XCD's L2)
-            const unsigned int *blk = rd + LKC_HDR + level * LKC_LEVEL + lane;
-#pragma unroll
-            for (int k = 0; k < 7; k++) c0[k] = (int) __builtin_nontemporal_load(blk + k * 64);
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                IXP[m] = __builtin_nontemporal_load(blk + (7 + m) * 64);
-                IYP[m] = __builtin_nontemporal_load(blk + (11 + m) * 64);
-            }
-            A11 = __uint_as_float(rd[4 + 4 * level + 1]);
-            A12 = __uint_as_float(rd[4 + 4 * level + 2]);
-            A22 = __uint_as_float(rd[4 + 4 * level + 3]);
-        } else {
+        {
             const int idx = lx0 >> 2, sh = lx0 & 3;
             unsigned int Pp[4][5]; // pixel pairs (col 2m, 2m+1) of tile rows ly..ly+3, cols lx0..lx0+9
 #pragma unroll
@@ -452,9 +418,9 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                 const int m1 = (k + 1) >> 1;
                 const unsigned int i1 = ((k + 1) & 1) ? pk_shift(Pp[1][m1], Pp[1][m1 + 1]) : Pp[1][m1];
                 const unsigned int i2 = ((k + 1) & 1) ? pk_shift(Pp[2][m1], Pp[2][m1 + 1]) : Pp[2][m1];
-                ix[k]        = dot2(dx1, W1d, dot2_keep(dx0, W0d, rnd13)) >> 14;
-                iy[k]        = dot2(dy1, W1d, dot2_keep(dy0, W0d, rnd13)) >> 14;
-                const int iv = dot2(i2, W1, dot2_keep(i1, W0, rnd8)) >> 9;
+                ix[k]        = dot2(dx1, W1d, dot2_keep_s(dx0, W0d, rnd13)) >> 14;
+                iy[k]        = dot2(dy1, W1d, dot2_keep_s(dy0, W0d, rnd13)) >> 14;
+                const int iv = dot2(i2, W1, dot2_keep_s(i1, W0, rnd8)) >> 9;
                 c0[k]        = 256 - 512 * iv;
             }
 #pragma unroll
@@ -472,24 +438,6 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
         float D            = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float) (2 * ICG_LK_WIN * ICG_LK_WIN);
         const bool weak    = minEig < 1e-4f || D < FLT_EPSILON;
-        if (wr != nullptr && level < ICG_MAX_LK_LEVELS_CACHED) { // this pass's template is the next call's forward template
-            if (!weak) {
-                unsigned int *blk = wr + LKC_HDR + level * LKC_LEVEL + lane;
-#pragma unroll
-                for (int k = 0; k < 7; k++) __builtin_nontemporal_store((unsigned int) c0[k], blk + k * 64);
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    __builtin_nontemporal_store(IXP[m], blk + (7 + m) * 64);
-                    __builtin_nontemporal_store(IYP[m], blk + (11 + m) * 64);
-                }
-            }
-            if (lane == 0) {
-                wr[4 + 4 * level]     = weak ? LKC_ST_MINEIG : LKC_ST_DATA;
-                wr[4 + 4 * level + 1] = __float_as_uint(A11);
-                wr[4 + 4 * level + 2] = __float_as_uint(A12);
-                wr[4 + 4 * level + 3] = __float_as_uint(A22);
-            }
-        }
         if (weak) {
             if (level == 0) status = false;
             continue;
@@ -616,338 +564,6 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
     return status;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// TWO FEATURES PER WAVE (round 3).  A Gauss-Newton iteration of one feature is ~105 wave instructions of which the two exact wave
-// reductions, the 2x2 solve, the weights and the convergence tests (~70) do not depend on how many pixels a lane owns.  Here lanes 0..31
-// track feature A and lanes 32..63 feature B; a lane owns TWO of the 63 seven-pixel runs of its feature's 21x21 window (runs 2l and 2l+1;
-// lane 31 only run 62), so the pixel work per lane doubles while the reductions (now over 32 lanes: quad and row stages + row_bcast15,
-// lanes 31 / 63 hold the two totals), the solve and the tests are shared by both features: ~145 wave instructions per iteration for two
-// features instead of 2 x 105.  Every "wave-uniform" quantity of lk_track_wave is uniform per HALF here (a half never diverges inside);
-// the halves diverge from each other freely (levels skipped, iteration counts, tile re-staging) — the cost is max() of the two, which is
-// why consecutive points (same stream, similar motion) are paired.  Per feature the arithmetic is that of lk_track_wave operation by
-// operation: exact integer window sums (any partition of an exact sum is exact), one conversion to float, the same float solve.
-struct lk_smem2 {
-    lk_smem h[2];
-};
-
-// one wave = one workgroup: LDS ordering inside the wave only needs the compiler not to reorder (and the LDS queue is in order)
-#define LK_WAVE_SYNC()                                          \
-    do {                                                        \
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  \
-        __builtin_amdgcn_wave_barrier();                        \
-    } while (0)
-
-// exact sum over the 32 lanes of each half, returned to every lane of the half as (float) of the exact integer
-__device__ __forceinline__ float half_sum_tail_f32(int hi, int lo, bool upper) {
-    hi += __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false); // row_bcast15: rows 1,3 += lane 15 of rows 0,2
-    lo += __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);
-    const int h0 = __builtin_amdgcn_readlane(hi, 31), h1 = __builtin_amdgcn_readlane(hi, 63);
-    const int l0 = __builtin_amdgcn_readlane(lo, 31), l1 = __builtin_amdgcn_readlane(lo, 63);
-    const int th = upper ? h1 : h0, tl = upper ? l1 : l0;
-    return (float) ((double) th * 65536.0 + (double) tl);
-}
-// |per-lane partial| < 2^28: sums of 8 lanes fit in int32
-__device__ __forceinline__ float half_sum_i32x8_f32(int v, bool upper) {
-    v = dpp_add_xor1(v);
-    v = dpp_add_xor2(v);
-    v = dpp_add_half_mirror(v);
-    int hi = v >> 16, lo = v & 0xffff;
-    hi     = dpp_add_mirror(hi);
-    lo     = dpp_add_mirror(lo);
-    return half_sum_tail_f32(hi, lo, upper);
-}
-// |per-lane partial| < 2^29: sums of 4 lanes fit in int32
-__device__ __forceinline__ float half_sum_i32x4_f32(int v, bool upper) {
-    v = dpp_add_xor1(v);
-    v = dpp_add_xor2(v);
-    int hi = v >> 16, lo = v & 0xffff;
-    hi     = dpp_add_half_mirror(hi);
-    lo     = dpp_add_half_mirror(lo);
-    hi     = dpp_add_mirror(hi);
-    lo     = dpp_add_mirror(lo);
-    return half_sum_tail_f32(hi, lo, upper);
-}
-
-// 24x24 I tile by the 32 lanes of a half: dword i = l + 32*q -> (row i/6, dword column i%6)
-__device__ __forceinline__ void lk2_load_I(unsigned int (&v)[5], const unsigned char *I, int W, int H, int pitch, int ipx, int ipy, int l) {
-    const bool inside = ipx - 1 >= 0 && ipx - 1 + LK_IT <= W && ipy - 1 >= 0 && ipy - 1 + LK_IT <= H; // half-uniform
-#pragma unroll
-    for (int q = 0; q < 5; q++) {
-        const int i = l + 32 * q;
-        const int r = i / 6, cd = i - r * 6;
-        v[q] = 0;
-        if (i < LK_IT * 6) {
-            if (inside)
-                v[q] = *reinterpret_cast<const lk_u32u *>(I + (size_t) (ipy - 1 + r) * pitch + (ipx - 1 + 4 * cd));
-            else
-                v[q] = lk_load4(I + (size_t) icg_reflect101(ipy - 1 + r, H) * pitch, ipx - 1 + 4 * cd, W);
-        }
-    }
-}
-__device__ __forceinline__ void lk2_store_I(lk_smem &S, const unsigned int (&v)[5], int l) {
-#pragma unroll
-    for (int q = 0; q < 5; q++) {
-        const int i = l + 32 * q;
-        const int r = i / 6, cd = i - r * 6;
-        if (i < LK_IT * 6) S.I[(r * LK_IS >> 2) + cd] = v[q];
-    }
-}
-// 32x32 J tile by the 32 lanes of a half: lane l -> row l, 8 packed dwords
-__device__ __forceinline__ void lk2_load_J(unsigned int (&v)[8], const unsigned char *J, int W, int H, int pitch, int jx0, int jy0, int l) {
-    const bool inside = jx0 >= 0 && jx0 + LK_JT <= W && jy0 >= 0 && jy0 + LK_JT <= H; // half-uniform
-    if (inside) {
-        const unsigned char *row = J + (size_t) (jy0 + l) * pitch + jx0;
-#pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const lk_u32u *>(row + 4 * q);
-    } else {
-        const unsigned char *row = J + (size_t) icg_reflect101(jy0 + l, H) * pitch;
-#pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = lk_load4(row, jx0 + 4 * q, W);
-    }
-}
-__device__ __forceinline__ void lk2_store_J(lk_smem &S, const unsigned int (&v)[8], int l) {
-    unsigned int *dst = &S.J[(l * LK_JS) >> 2];
-#pragma unroll
-    for (int q = 0; q < 8; q++) dst[q] = v[q];
-}
-
-// One calcOpticalFlowPyrLK point per HALF wave (see above).  `on`: this half has a point to track (half-uniform).
-__device__ __forceinline__ bool lk_track_pair(const icg_pyr_desc &P, const unsigned char *slotI, const unsigned char *slotJ, float2 prevPt,
-                                              float2 &nextIO, lk_smem &S, int lane) {
-    const float FLT_SCALE = 1.f / (1 << 20);
-    const double eps2     = 0.01 * 0.01;
-    bool status           = true;
-    float2 nextStore      = nextIO;
-    const int maxLevel    = P.n_levels - 1;
-    const bool upper      = lane >= 32;
-    const int l           = lane & 31;
-    // the lane's two runs of the 21x21 window: run r -> row r/3, columns (r%3)*7 .. +6
-    const int ra = 2 * l, rb = 2 * l + 1;
-    const bool has_b = rb < 63;
-    int ly[2], lx0[2];
-    ly[0]  = ra / 3;
-    lx0[0] = (ra - ly[0] * 3) * 7;
-    ly[1]  = has_b ? rb / 3 : 0;
-    lx0[1] = has_b ? (rb - ly[1] * 3) * 7 : 0;
-
-    for (int level = maxLevel; level >= 0; --level) {
-        const int W = P.w[level], H = P.h[level], pitch = P.pitch[level];
-        const unsigned char *I = slotI + P.off[level];
-        const unsigned char *J = slotJ + P.off[level];
-        const float scale      = (float) (1. / (1 << level));
-        float prevx = prevPt.x * scale, prevy = prevPt.y * scale;
-        float nptx, npty;
-        if (level == maxLevel) {
-            nptx = nextStore.x * scale;
-            npty = nextStore.y * scale;
-        } else {
-            nptx = nextStore.x * 2.f;
-            npty = nextStore.y * 2.f;
-        }
-        nextStore = make_float2(nptx, npty);
-
-        prevx -= (float) ICG_LK_HALF;
-        prevy -= (float) ICG_LK_HALF;
-        const int ipx = (int) floorf(prevx), ipy = (int) floorf(prevy);
-        if (ipx < -ICG_LK_WIN || ipx >= W || ipy < -ICG_LK_WIN || ipy >= H) {
-            if (level == 0) status = false;
-            continue;
-        }
-        int w00, w01, w10, w11;
-        lk_weights(prevx - ipx, prevy - ipy, w00, w01, w10, w11);
-        unsigned int W0 = pk_lo16(w00, w01), W1 = pk_lo16(w10, w11);
-
-        int jx0 = -1000000, jy0 = -1000000;
-        {
-            const int inx0 = (int) floorf(nptx - (float) ICG_LK_HALF), iny0 = (int) floorf(npty - (float) ICG_LK_HALF);
-            const bool jok = !(inx0 < -ICG_LK_WIN || inx0 >= W || iny0 < -ICG_LK_WIN || iny0 >= H); // else iteration 0 bails out
-            unsigned int vi[5], vj[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            lk2_load_I(vi, I, W, H, pitch, ipx, ipy, l);
-            if (jok) {
-                jx0 = inx0 - LK_JM;
-                jy0 = iny0 - LK_JM;
-                lk2_load_J(vj, J, W, H, pitch, jx0, jy0, l);
-            }
-            LK_WAVE_SYNC(); // the previous level's LDS readers are done
-            lk2_store_I(S, vi, l);
-            if (jok) lk2_store_J(S, vj, l);
-            LK_WAVE_SYNC();
-        }
-
-        // ---- per lane and run: 4 rows x 10 bytes -> I samples and on-the-fly Scharr derivatives of the 7-pixel run (as lk_track_wave) ----
-        int c0[2][7];
-        unsigned int IXP[2][4], IYP[2][4];
-        int sA11 = 0, sA12 = 0, sA22 = 0;
-        const bool all_in = ipx >= 0 && ipx + 22 <= W && ipy >= 0 && ipy + 22 <= H; // half-uniform fast path
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int idx = lx0[u] >> 2, sh = lx0[u] & 3;
-            unsigned int Pp[4][5];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const unsigned int *p = &S.I[((ly[u] + r) * LK_IS >> 2) + idx];
-                const unsigned int d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-                const unsigned int b0 = __builtin_amdgcn_alignbyte(d1, d0, sh), b1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-                const unsigned int b2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-                Pp[r][0] = __builtin_amdgcn_perm(0u, b0, 0x0c010c00u);
-                Pp[r][1] = __builtin_amdgcn_perm(0u, b0, 0x0c030c02u);
-                Pp[r][2] = __builtin_amdgcn_perm(0u, b1, 0x0c010c00u);
-                Pp[r][3] = __builtin_amdgcn_perm(0u, b1, 0x0c030c02u);
-                Pp[r][4] = __builtin_amdgcn_perm(0u, b2, 0x0c010c00u);
-            }
-            unsigned int CM[4] = {~0u, ~0u, ~0u, ~0u};
-            if (!all_in) {
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const int X0 = ipx + lx0[u] + 2 * m, X1 = X0 + 1;
-                    CM[m] = ((X0 >= 0 && X0 < W) ? 0x0000ffffu : 0u) | ((X1 >= 0 && X1 < W) ? 0xffff0000u : 0u);
-                }
-            }
-            unsigned int DX[2][4], DY[2][4];
-#pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
-                unsigned int T0[5], T1[5];
-#pragma unroll
-                for (int m = 0; m < 5; m++) {
-                    T0[m] = pk_add(pk_mul(pk_add(Pp[rr][m], Pp[rr + 2][m]), 3), pk_mul(Pp[rr + 1][m], 10)); // 3*(p0+p2) + 10*p1
-                    T1[m] = pk_sub(Pp[rr + 2][m], Pp[rr][m]);                                                // p2 - p0
-                }
-                unsigned int RM = ~0u;
-                if (!all_in) {
-                    const int Y = ipy + ly[u] + rr;
-                    RM          = (Y >= 0 && Y < H) ? ~0u : 0u;
-                }
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    DX[rr][m] = pk_sub(T0[m + 1], T0[m]);
-                    DY[rr][m] = pk_add(pk_mul(pk_add(T1[m], T1[m + 1]), 3), pk_mul(pk_shift(T1[m], T1[m + 1]), 10));
-                    if (!all_in) {
-                        DX[rr][m] &= CM[m] & RM;
-                        DY[rr][m] &= CM[m] & RM;
-                    }
-                }
-            }
-            int ix[7], iy[7];
-            const bool run_on = u == 0 || has_b;
-#pragma unroll
-            for (int k = 0; k < 7; k++) {
-                const int m = k >> 1;
-                const unsigned int dx0 = (k & 1) ? pk_shift(DX[0][m], DX[0][m + 1]) : DX[0][m];
-                const unsigned int dx1 = (k & 1) ? pk_shift(DX[1][m], DX[1][m + 1]) : DX[1][m];
-                const unsigned int dy0 = (k & 1) ? pk_shift(DY[0][m], DY[0][m + 1]) : DY[0][m];
-                const unsigned int dy1 = (k & 1) ? pk_shift(DY[1][m], DY[1][m + 1]) : DY[1][m];
-                const int m1 = (k + 1) >> 1;
-                const unsigned int i1 = ((k + 1) & 1) ? pk_shift(Pp[1][m1], Pp[1][m1 + 1]) : Pp[1][m1];
-                const unsigned int i2 = ((k + 1) & 1) ? pk_shift(Pp[2][m1], Pp[2][m1 + 1]) : Pp[2][m1];
-                ix[k]        = dot2(dx1, W1, dot2(dx0, W0, 1 << 13)) >> 14;
-                iy[k]        = dot2(dy1, W1, dot2(dy0, W0, 1 << 13)) >> 14;
-                const int iv = dot2(i2, W1, dot2(i1, W0, 1 << 8)) >> 9;
-                c0[u][k]     = 256 - 512 * iv;
-                if (!run_on) {
-                    ix[k] = 0;
-                    iy[k] = 0;
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                IXP[u][m] = pk_lo16(ix[2 * m], m < 3 ? ix[2 * m + 1] : 0);
-                IYP[u][m] = pk_lo16(iy[2 * m], m < 3 ? iy[2 * m + 1] : 0);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                sA11 = dot2(IXP[u][m], IXP[u][m], sA11);
-                sA12 = dot2(IXP[u][m], IYP[u][m], sA12);
-                sA22 = dot2(IYP[u][m], IYP[u][m], sA22);
-            }
-        }
-        const float A11 = half_sum_i32x8_f32(sA11, upper) * FLT_SCALE, A12 = half_sum_i32x8_f32(sA12, upper) * FLT_SCALE;
-        const float A22 = half_sum_i32x8_f32(sA22, upper) * FLT_SCALE;
-        float D            = A11 * A22 - A12 * A12;
-        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float) (2 * ICG_LK_WIN * ICG_LK_WIN);
-        if (minEig < 1e-4f || D < FLT_EPSILON) {
-            if (level == 0) status = false;
-            continue;
-        }
-        D = 1.f / D;
-        nptx -= (float) ICG_LK_HALF;
-        npty -= (float) ICG_LK_HALF;
-        float pdx = 0.f, pdy = 0.f;
-        unsigned int JA[2][7], JB[2][7];
-
-        // Gauss-Newton iterations as epochs of constant integer window position (see lk_track_wave)
-        int j = 0;
-        bool more = true;
-        while (more) {
-            const int inx = (int) floorf(nptx), iny = (int) floorf(npty);
-            if (inx < -ICG_LK_WIN || inx >= W || iny < -ICG_LK_WIN || iny >= H) {
-                if (level == 0) status = false;
-                break;
-            }
-            if (!(inx >= jx0 && inx <= jx0 + (LK_JT - 22) && iny >= jy0 && iny <= jy0 + (LK_JT - 22))) {
-                jx0 = inx - LK_JM;
-                jy0 = iny - LK_JM;
-                unsigned int vj[8];
-                lk2_load_J(vj, J, W, H, pitch, jx0, jy0, l);
-                LK_WAVE_SYNC();
-                lk2_store_J(S, vj, l);
-                LK_WAVE_SYNC();
-            }
-#pragma unroll
-            for (int u = 0; u < 2; u++) lk_fetch_J(S, iny - jy0 + ly[u], (inx - jx0) + lx0[u], JA[u], JB[u]);
-            for (;;) {
-                lk_weights(nptx - inx, npty - iny, w00, w01, w10, w11);
-                W0 = pk_lo16(w00, w01);
-                W1 = pk_lo16(w10, w11);
-                int sb1 = 0, sb2 = 0;
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    int diff[7];
-#pragma unroll
-                    for (int k = 0; k < 7; k++) diff[k] = dot2(JB[u][k], W1, dot2(JA[u][k], W0, c0[u][k])) >> 9;
-#pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        const unsigned int dp = m < 3 ? pk_lo16(diff[2 * m], diff[2 * m + 1]) : (unsigned int) diff[6]; // IXP[.][3].hi == 0
-                        sb1 = dot2(dp, IXP[u][m], sb1);
-                        sb2 = dot2(dp, IYP[u][m], sb2);
-                    }
-                }
-                const float b1 = half_sum_i32x4_f32(sb1, upper) * FLT_SCALE, b2 = half_sum_i32x4_f32(sb2, upper) * FLT_SCALE;
-                const float dx = (float) ((A12 * b2 - A22 * b1) * D);
-                const float dy = (float) ((A12 * b1 - A11 * b2) * D);
-                nptx += dx;
-                npty += dy;
-                nextStore = make_float2(nptx + (float) ICG_LK_HALF, npty + (float) ICG_LK_HALF);
-                if ((double) dx * dx + (double) dy * dy <= eps2) {
-                    more = false;
-                    break;
-                }
-                if (j > 0 && fabs((double) (dx + pdx)) < 0.01 && fabs((double) (dy + pdy)) < 0.01) {
-                    nextStore.x -= dx * 0.5f;
-                    nextStore.y -= dy * 0.5f;
-                    more = false;
-                    break;
-                }
-                pdx = dx;
-                pdy = dy;
-                if (++j >= LK_MAX_ITERS) {
-                    more = false;
-                    break;
-                }
-                if ((int) floorf(nptx) != inx || (int) floorf(npty) != iny) break; // next epoch: bounds test, tile, fetch
-            }
-        }
-
-        if (status && level == 0) {
-            // OpenCV >= 3.4 epilogue: the final position must still be inside (the err value itself is not used by the fused caller)
-            const float ex = nextStore.x - (float) ICG_LK_HALF, ey = nextStore.y - (float) ICG_LK_HALF;
-            const int inx = (int) floorf(ex), iny = (int) floorf(ey);
-            if (inx < -ICG_LK_WIN || inx >= W || iny < -ICG_LK_WIN || iny >= H) status = false;
-        }
-    }
-    nextIO = nextStore;
-    return status;
-}
-
 __global__ __launch_bounds__(64) void k_lk_track(icg_pyr_desc P, int n, const int32_t *prev_slot, const int32_t *next_slot,
                                                  const float2 *prev_pts, float2 *next_pts, unsigned char *status, float *err) {
     __shared__ lk_smem S;
@@ -968,7 +584,6 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_des
                                                     const int32_t *next_slot, const float2 *prev_pts,
                                                     const float2 *guess_pts, float2 *out_pts, unsigned char *status,
                                                     int has_cam, icg_camera cam, float2 *out_undist, int img_w, int img_h,
-                                                    const int32_t *reuse_idx, const unsigned int *cache_rd, unsigned int *cache_wr,
                                                     int seg_cap, const int32_t *seg_count) {
     __shared__ lk_smem S;
     const int i = icg_xcd_chunked(blockIdx.x, n);
@@ -986,21 +601,6 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_des
     float2 fwd      = guess_pts[i];
     float2 bwd      = p0;
     bool st_f = false, st_b = false;
-    // template set-up cache (see LKC_*): the block this point's backward pass fills for the next call, and the block of the point it
-    // continues — usable only if it was completed and was set up at exactly this point (the entry point already matched slot + generation)
-    unsigned int *wr       = nullptr;
-    const unsigned int *rd = nullptr;
-    if (cache_wr) {
-        wr = cache_wr + (size_t) i * LKC_DWORDS;
-        if (lane == 0) wr[2] = 0; // not complete (yet)
-    }
-    if (cache_rd && reuse_idx) {
-        const int j = reuse_idx[i];
-        if (j >= 0) {
-            const unsigned int *b = cache_rd + (size_t) j * LKC_DWORDS;
-            if (b[2] == 1u && b[0] == __float_as_uint(p0.x) && b[1] == __float_as_uint(p0.y)) rd = b;
-        }
-    }
     // forward then backward through ONE copy of the tracker body (16 KB of code instead of 32 KB in the shared I-cache)
     for (int dir = 0; dir < 2; dir++) {
         if (dir) {
@@ -1012,15 +612,10 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_des
         const unsigned char *a = dir ? sN : sP, *b = dir ? sP : sN;
         const float2 from      = dir ? fwd : p0;
         float2 io              = dir ? bwd : fwd;
-        const bool st          = lk_track_wave(P, a, b, from, io, S, lane, nullptr, dir ? nullptr : rd, dir ? wr : nullptr);
+        const bool st          = lk_track_wave(P, a, b, from, io, S, lane, nullptr);
         if (dir) {
             bwd  = io;
             st_b = st;
-            if (wr && lane == 0) { // the backward template = next image at the forward result: what the next frame tracks FROM
-                wr[0] = __float_as_uint(fwd.x);
-                wr[1] = __float_as_uint(fwd.y);
-                wr[2] = 1u;
-            }
         } else {
             fwd  = io;
             st_f = st;
@@ -1044,57 +639,6 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_des
             status[i]  = (unsigned char) st;
             if (out_undist) out_undist[i] = und;
         }
-    }
-}
-
-// the same with two features per wave (lk_track_pair): workgroup p tracks points 2p (lanes 0..31) and 2p+1 (lanes 32..63)
-#ifndef LK2_WAVES_PER_EU
-#define LK2_WAVES_PER_EU 3
-#endif
-__global__ __launch_bounds__(64, LK2_WAVES_PER_EU) void k_lk_track_fb2(icg_pyr_desc P, int n, const int32_t *prev_slot,
-                                                     const int32_t *next_slot, const float2 *prev_pts,
-                                                     const float2 *guess_pts, float2 *out_pts, unsigned char *status,
-                                                     int has_cam, icg_camera cam, float2 *out_undist, int img_w, int img_h) {
-    __shared__ lk_smem2 S2;
-    const int n_pairs = (n + 1) >> 1;
-    const int p       = icg_xcd_chunked(blockIdx.x, n_pairs);
-    if (p >= n_pairs) return;
-    const int lane = threadIdx.x, half = lane >> 5;
-    const int i    = 2 * p + half;
-    if (i >= n) return; // the odd tail: the upper half of the last wave has nothing to do
-    lk_smem &S              = S2.h[half];
-    const unsigned char *sP = P.base + (size_t) prev_slot[i] * P.slot_bytes;
-    const unsigned char *sN = P.base + (size_t) next_slot[i] * P.slot_bytes;
-    const float2 p0 = prev_pts[i];
-    float2 fwd      = guess_pts[i];
-    float2 bwd      = p0;
-    bool st_f = false, st_b = false;
-    for (int dir = 0; dir < 2; dir++) {
-        if (dir) {
-            const bool border = (double) fwd.x < 5.0 || (double) fwd.y < 5.0 || ((double) fwd.x > (img_w - 5.0)) ||
-                                ((double) fwd.y > (img_h - 5.0));
-            if (!st_f || border) break; // half-uniform
-        }
-        const unsigned char *a = dir ? sN : sP, *b = dir ? sP : sN;
-        const float2 from      = dir ? fwd : p0;
-        float2 io              = dir ? bwd : fwd;
-        const bool st          = lk_track_pair(P, a, b, from, io, S, lane);
-        if (dir) {
-            bwd  = io;
-            st_b = st;
-        } else {
-            fwd  = io;
-            st_f = st;
-        }
-    }
-    if ((lane & 31) == 0) {
-        const bool border = (double) fwd.x < 5.0 || (double) fwd.y < 5.0 || ((double) fwd.x > (img_w - 5.0)) ||
-                            ((double) fwd.y > (img_h - 5.0));
-        const double ddx = (double) (bwd.x - p0.x), ddy = (double) (bwd.y - p0.y);
-        const double dist = sqrt(ddx * ddx + ddy * ddy);
-        out_pts[i]        = fwd;
-        status[i]         = (st_f && st_b && !border && dist < 0.5) ? 1 : 0;
-        if (out_undist) out_undist[i] = has_cam ? cam_undistort(cam, fwd) : fwd;
     }
 }
 
@@ -1190,102 +734,16 @@ extern "C" int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, co
     int32_t *d_nkeep    = keep_idx ? c.out_zc(n_keep, 1) : nullptr;
     ICG_LAUNCH_GUARD(c);
     {
-        // ICG_LK_PAIR=1: two features per wave (k_lk_track_fb2).  Measured on MI355X (profiles/r03_lk_pair.md): 28 % fewer instructions per
-        // Gauss-Newton iteration and 16 % fewer per level set-up, but a wave runs max() of its two features' iteration counts and keeps only
-        // 3 waves per SIMD: SQ_INSTS_VALU -7 %, kernel time +2 % isolated, bench unchanged — so one feature per wave stays the default.
-        static const bool pair = getenv("ICG_LK_PAIR") && getenv("ICG_LK_PAIR")[0] == '1';
         icg_prof_scope ps(ctx, "lk_track_fb");
-        if (pair)
-            hipLaunchKernelGGL(k_lk_track_fb2, dim3(icg_xcd_grid((n + 1) / 2)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns,
-                               d_pp, d_gs, d_out, d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height);
-        else
-            hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp,
-                               d_gs, d_out, d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height,
-                               (const int32_t *) nullptr, (const unsigned int *) nullptr, (unsigned int *) nullptr, 0, (const int32_t *) nullptr);
+        hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp, d_gs, d_out,
+                           d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height, 0, (const int32_t *) nullptr);
     }
     if (keep_idx) {
         icg_prof_scope ps(ctx, "keep_indices");
         hipLaunchKernelGGL(k_keep_indices, dim3(1), dim3(1024), 0, ctx->stream, n, d_st, d_keep, d_nkeep);
     }
     ICG_HIP(ctx, hipGetLastError());
-    ctx->lkc_last_n = 0; // a call without the set-up cache breaks the chain of icg_lk_track_fb_reuse calls
     return c.finish();
-}
-
-extern "C" int icg_lk_track_fb_reuse(icg_ctx *ctx, int n, const int32_t *prev_slot, const int32_t *next_slot, const float *prev_pts,
-                                     const float *guess_pts, const int32_t *prev_index, float *out_pts, uint8_t *status, float *out_undist) {
-    if (!ctx || n < 0) return ICG_ERR_INVALID;
-    if (n == 0) return ICG_OK;
-    if (!prev_slot || !next_slot || !prev_pts || !guess_pts || !out_pts || !status) return ICG_ERR_INVALID;
-    if (out_undist && !ctx->has_cam) return icg_fail(ctx, ICG_ERR_INVALID, "out_undist requested but camera not set");
-    if (n > ctx->cfg.max_points) return icg_fail(ctx, ICG_ERR_CAPACITY, "%d points > max_points %d", n, ctx->cfg.max_points);
-    int rc = check_slots(ctx, n, prev_slot, next_slot);
-    if (rc) return rc;
-    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    if (ctx->n_levels > ICG_MAX_LK_LEVELS_CACHED) return icg_fail(ctx, ICG_ERR_INVALID, "set-up cache holds %d levels", ICG_MAX_LK_LEVELS_CACHED);
-    // two blocks per point slot of the context, alternating per call: this call reads what the previous call wrote
-    if ((size_t) n > ctx->lkc_cap) {
-        ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const size_t cap = std::min<size_t>((size_t) ctx->cfg.max_points, std::max<size_t>(1024, (size_t) n + (size_t) n / 2));
-        for (int b = 0; b < 2; b++) {
-            if (ctx->d_lkc[b]) (void) hipFree(ctx->d_lkc[b]);
-            ctx->d_lkc[b] = nullptr;
-            ICG_HIP(ctx, hipMalloc((void **) &ctx->d_lkc[b], cap * LKC_DWORDS * sizeof(unsigned int)));
-            ctx->lkc_slot[b].assign(cap, -1);
-            ctx->lkc_gen[b].assign(cap, 0);
-        }
-        ctx->lkc_cap    = cap;
-        ctx->lkc_last_n = 0; // (the blocks are gone)
-    }
-    const int rdb = ctx->lkc_cur, wrb = rdb ^ 1;
-    icg_call c(ctx);
-    if ((rc = c.reserve((size_t) n * 112))) return rc;
-    const int32_t *d_ps = c.in_zc(prev_slot, (size_t) n);
-    const int32_t *d_ns = c.in_zc(next_slot, (size_t) n);
-    const float2 *d_pp  = (const float2 *) c.in_zc(prev_pts, 2 * (size_t) n);
-    const float2 *d_gs  = (const float2 *) c.in_zc(guess_pts, 2 * (size_t) n);
-    // the hint of point i is honoured when the block it names was written for the image this point is tracked FROM: same slot, and the
-    // slot has not been preprocessed again since (the kernel then compares the point's bit pattern and the block's completeness flag)
-    std::vector<int32_t> ri((size_t) n);
-    int hinted = 0;
-    if (ctx->slot_gen.size() != (size_t) ctx->cfg.n_slots) ctx->slot_gen.assign((size_t) ctx->cfg.n_slots, 0);
-    for (int i = 0; i < n; i++) {
-        int j = prev_index ? prev_index[i] : -1;
-        if (j < 0 || j >= ctx->lkc_last_n || ctx->lkc_slot[rdb][(size_t) j] != prev_slot[i] ||
-            ctx->lkc_gen[rdb][(size_t) j] != ctx->slot_gen[(size_t) prev_slot[i]])
-            j = -1;
-        hinted += j >= 0;
-        ri[(size_t) i] = j;
-    }
-    const int32_t *h_ri = c.in_zc(ri.data(), (size_t) n);
-    float2 *d_out       = (float2 *) c.out_zc(out_pts, 2 * (size_t) n);
-    unsigned char *d_st = c.out_zc(status, (size_t) n);
-    float2 *d_und       = out_undist ? (float2 *) c.out_zc(out_undist, 2 * (size_t) n) : nullptr;
-    ICG_LAUNCH_GUARD(c);
-    {
-        icg_prof_scope ps(ctx, "lk_track_fb");
-        hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp, d_gs,
-                           d_out, d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height, h_ri,
-                           (const unsigned int *) (hinted ? ctx->d_lkc[rdb] : nullptr), ctx->d_lkc[wrb], 0, (const int32_t *) nullptr);
-    }
-    ICG_HIP(ctx, hipGetLastError());
-    // what the blocks just written belong to (the NEXT image of every point, at its generation)
-    for (int i = 0; i < n; i++) {
-        ctx->lkc_slot[wrb][(size_t) i] = next_slot[i];
-        ctx->lkc_gen[wrb][(size_t) i]  = ctx->slot_gen[(size_t) next_slot[i]];
-    }
-    ctx->lkc_cur         = wrb;
-    ctx->lkc_last_n      = n;
-    ctx->lkc_hits_hinted += (uint64_t) hinted;
-    ctx->lkc_points      += (uint64_t) n;
-    return c.finish();
-}
-
-extern "C" int icg_lk_reuse_stats(icg_ctx *ctx, uint64_t *out2) {
-    if (!ctx || !out2) return ICG_ERR_INVALID;
-    out2[0] = ctx->lkc_points;
-    out2[1] = ctx->lkc_hits_hinted;
-    return ICG_OK;
 }
 
 // Segmented launch for the device-resident tracker (tracker.hip): every array is device memory laid out as n_seg segments of seg_cap
@@ -1296,9 +754,7 @@ int icg_lk_launch_segments(icg_ctx *ctx, int n_seg, int seg_cap, const int32_t *
     const int n = n_seg * seg_cap;
     icg_prof_scope ps(ctx, "lk_track_fb");
     hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_prev_slot, d_next_slot, d_prev,
-                       d_guess, d_out, d_status, 1, ctx->cam, d_undist, ctx->cfg.width, ctx->cfg.height, (const int32_t *) nullptr,
-                       (const unsigned int *) nullptr, (unsigned int *) nullptr, seg_cap, d_count);
+                       d_guess, d_out, d_status, 1, ctx->cam, d_undist, ctx->cfg.width, ctx->cfg.height, seg_cap, d_count);
     ICG_HIP(ctx, hipGetLastError());
-    ctx->lkc_last_n = 0;
     return ICG_OK;
 }

@@ -558,7 +558,7 @@ namespace {
 thread_local double g_marg_phase_ms[4] = {0, 0, 0, 0};
 thread_local bool g_marg_structured   = false;
 // process-wide switch (diagnostics / tests): force the reference's dense M2 + M3 even where the structured path applies
-std::atomic<int> g_marg_force_dense{getenv("ICG_MARG_DENSE") != nullptr ? 1 : 0};
+std::atomic<int> g_marg_force_dense{0};
 }
 const double *MarginalizationInfo::lastPhaseMs() { return g_marg_phase_ms; }
 bool MarginalizationInfo::lastWasStructured() { return g_marg_structured; }

@@ -207,13 +207,15 @@ void WindowSolverBatch::gather(std::vector<double> &poses, std::vector<double> &
 }
 
 namespace {
-struct ThreadJoiner { // a helper thread that is joined on every way out of the scope
-    std::thread t;
-    template <typename F> explicit ThreadJoiner(F &&f) : t(std::forward<F>(f)) {}
+struct SideCall { // a call on the solver's side thread that is waited for on every way out of the scope
+    SideThread &t;
+    bool pending = true;
+    template <typename F> SideCall(SideThread &side, F &&f) : t(side) { t.start(std::forward<F>(f)); }
     void join() {
-        if (t.joinable()) t.join();
+        if (pending) t.wait();
+        pending = false;
     }
-    ~ThreadJoiner() { join(); }
+    ~SideCall() { join(); }
 };
 struct BatchClock { // ICG_SOLVER_DEBUG=1: wall time per phase of the lock-step loop
     bool on = getenv("ICG_SOLVER_DEBUG") != nullptr;
@@ -298,7 +300,8 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
             // runHalves); the sums that need both are formed after the join.
             clk.start();
             int dev_rc = ICG_OK;
-            ThreadJoiner dev([&] {
+            if (!side_) side_.reset(new SideThread());
+            SideCall dev(*side_, [&] {
                 dev_rc = dev_solve ? icg_reproj_schur_windows_resident(ctx_, P, col_pose_.data(), col_ext_.data(), col_td_.data(), active_.data(), reassemble.data(),
                                                                        damp.data(), o.min_lm_diagonal, o.max_lm_diagonal, s.data(), diag.data(), cost.data())
                                    : icg_reproj_schur_windows_view(ctx_, P, col_pose_.data(), col_ext_.data(), col_td_.data(), active_.data(), reassemble.data(),
@@ -484,7 +487,8 @@ bool WindowSolverBatch::solve(const Options &o, std::vector<Summary> *summaries)
         clk.start();
         gather(poses, ext, inv, td);
         const char *dev_fail = nullptr;
-        ThreadJoiner trial([&] {
+        if (!side_) side_.reset(new SideThread());
+        SideCall trial(*side_, [&] {
             if (icg_reproj_eval_windows(ctx_, n_poses_, poses.data(), ext.data(), n_lm_, inv.data(), td.data(), 0, huber_) != ICG_OK)
                 dev_fail = "icg_reproj_eval_windows";
             else if (icg_reproj_cost_windows(ctx_, active_.data(), cost.data()) != ICG_OK)

@@ -85,6 +85,7 @@ private:
     double huber_;
     int host_threads_;
     std::unique_ptr<HostPool> pool_;
+    std::unique_ptr<SideThread> side_; // runs the device call of a phase beside the pool's host half
     std::vector<Window> windows_;
     std::vector<uint8_t> active_;
     std::vector<int32_t> col_pose_, col_ext_, col_td_;

@@ -861,9 +861,6 @@ void TableTracker::queueTrackMappoint(StageBatch &next) {
     next.lk_guess.resize(2 * (at + (size_t) lk_map_n_));
     memcpy(next.lk_prev.data() + 2 * at, tm_pts2d_map_.data(), (size_t) lk_map_n_ * sizeof(Point2f));
     memcpy(next.lk_guess.data() + 2 * at, tm_pred_.data(), (size_t) lk_map_n_ * sizeof(Point2f));
-    // the distorted key point of a row IS the forward result of the LK point that produced it: its template can be reused
-    next.lk_prev_index.resize(at, -1);
-    next.lk_prev_index.insert(next.lk_prev_index.end(), tm_hint_.begin(), tm_hint_.end());
 }
 
 bool TableTracker::finishTrackMappoint(StageBatch &done) {
@@ -931,11 +928,6 @@ void TableTracker::queueTrackReference(StageBatch &next) {
     next.lk_guess.resize(2 * (at + (size_t) lk_ref_n_));
     memcpy(next.lk_prev.data() + 2 * at, pts2d_new_.data(), (size_t) lk_ref_n_ * sizeof(Point2f));
     memcpy(next.lk_guess.data() + 2 * at, pts2d_cur_.data(), (size_t) lk_ref_n_ * sizeof(Point2f));
-    next.lk_prev_index.resize(at, -1);
-    if (cand_lk_idx_.size() == pts2d_new_.size())
-        next.lk_prev_index.insert(next.lk_prev_index.end(), cand_lk_idx_.begin(), cand_lk_idx_.end());
-    else
-        next.lk_prev_index.resize(at + (size_t) lk_ref_n_, -1);
 }
 
 bool TableTracker::midTrackReference(StageBatch &done, StageBatch &next) {

@@ -47,10 +47,7 @@ struct StageBatch {
     vector<int32_t> lk_prev_slot, lk_next_slot;
     vector<float> lk_prev, lk_guess, lk_out, lk_undist;
     vector<uint8_t> lk_status;
-    // template set-up reuse (icg_lk_track_fb_reuse): per point the index it had in the stream group's PREVIOUS LK call, or -1; empty = no
-    // hints (the plain entry point is used).  lk_base: where this stream's points start in the concatenated call (set when results are
-    // split back), so that a tracker can name its points in the next call.
-    vector<int32_t> lk_prev_index;
+    // lk_base: where this stream's points start in the concatenated call (set when results are split back)
     int lk_base{0};
     // F6 RANSAC
     vector<int32_t> rs_off{0};

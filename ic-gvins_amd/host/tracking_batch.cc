@@ -196,7 +196,6 @@ template <typename T> static void append(vector<T> &dst, const vector<T> &src) {
 void TrackingBatch::gather(int cur, StageBatch &g, vector<std::array<int, 8>> &bases) {
     g.clear();
     bases.assign(streams_.size(), {});
-    bool any_hints = false;
     for (size_t i = 0; i < streams_.size(); i++) {
         const StageBatch &b = streams_[i].box[cur];
         auto &B             = bases[i];
@@ -227,12 +226,6 @@ void TrackingBatch::gather(int cur, StageBatch &g, vector<std::array<int, 8>> &b
             append(g.lk_next_slot, b.lk_next_slot);
             append(g.lk_prev, b.lk_prev);
             append(g.lk_guess, b.lk_guess);
-            // set-up reuse hints (indices into the group's previous LK call); a stream without hints contributes -1
-            if (b.lk_prev_index.size() == b.lk_prev_slot.size()) {
-                append(g.lk_prev_index, b.lk_prev_index);
-                any_hints = true;
-            } else
-                g.lk_prev_index.resize(g.lk_prev_slot.size(), -1);
         }
         if (b.rs_off.size() > 1) {
             append(g.rs_p1, b.rs_p1);
@@ -249,7 +242,6 @@ void TrackingBatch::gather(int cur, StageBatch &g, vector<std::array<int, 8>> &b
         }
         append(g.tri_Tcw, b.tri_Tcw);
     }
-    if (!any_hints) g.lk_prev_index.clear(); // (the object engine names no predecessors: the plain entry point, no cache traffic)
 }
 
 void TrackingBatch::scatter(int cur, const StageBatch &g, const vector<std::array<int, 8>> &bases) {

@@ -64,7 +64,6 @@ void StageBatch::clear() {
     lk_out.clear();
     lk_undist.clear();
     lk_status.clear();
-    lk_prev_index.clear();
     rs_off.assign(1, 0);
     rs_p1.clear();
     rs_p2.clear();
@@ -142,34 +141,19 @@ void DeviceContext::execute(StageBatch &b, const icg_detect_grid &grid, int max_
         b.lk_out.assign((size_t) n * 2, 0.f);
         b.lk_undist.assign((size_t) n * 2, 0.f);
         b.lk_status.assign((size_t) n, 0);
-        // ICG_LK_REUSE=1: icg_lk_track_fb_reuse with the track table's hints.  Off by default: the template set-up cache cuts the isolated LK
-        // launch by 15.7 % but the frame rate does not move (the front-end is bound by the latencies of its small launches, DESIGN.md
-        // section 4), while the set-up blocks double the HBM traffic per frame (11.0 -> 19.8 MB): profiles/r03_lk_setup_reuse.md
-        static const bool reuse = getenv("ICG_LK_REUSE") && getenv("ICG_LK_REUSE")[0] == '1';
-        if (reuse && (int) b.lk_prev_index.size() == n)
-            abi_check(ctx_,
-                      icg_lk_track_fb_reuse(ctx_, n, b.lk_prev_slot.data(), b.lk_next_slot.data(), b.lk_prev.data(), b.lk_guess.data(),
-                                            b.lk_prev_index.data(), b.lk_out.data(), b.lk_status.data(), b.lk_undist.data()),
-                      "icg_lk_track_fb_reuse");
-        else
-            abi_check(ctx_,
-                      icg_lk_track_fb(ctx_, n, b.lk_prev_slot.data(), b.lk_next_slot.data(), b.lk_prev.data(), b.lk_guess.data(),
-                                      b.lk_out.data(), b.lk_status.data(), b.lk_undist.data(), nullptr, nullptr),
-                      "icg_lk_track_fb");
+        abi_check(ctx_,
+                  icg_lk_track_fb(ctx_, n, b.lk_prev_slot.data(), b.lk_next_slot.data(), b.lk_prev.data(), b.lk_guess.data(), b.lk_out.data(),
+                                  b.lk_status.data(), b.lk_undist.data(), nullptr, nullptr),
+                  "icg_lk_track_fb");
     }
     if (b.rs_off.size() > 1) {
         hostprof::Scope hp(hostprof::DEV_RANSAC);
         int n = (int) b.rs_off.size() - 1;
         b.rs_mask.assign((size_t) b.rs_off.back(), 1);
-        // ICG_RANSAC_DEVICE_LOOP=1: the one-launch form (every set's whole run inside its workgroup, the kernel of the device-resident
-        // tracker) instead of one launch + one wait per RANSAC chunk; identical masks (tests/test_gpu_geometry.py)
-        static const bool device_loop = getenv("ICG_RANSAC_DEVICE_LOOP") && getenv("ICG_RANSAC_DEVICE_LOOP")[0] == '1';
-        if (device_loop)
-            abi_check(ctx_, icg_fm_ransac_device(ctx_, n, b.rs_off.data(), b.rs_p1.data(), b.rs_p2.data(), b.rs_thresh, b.rs_conf, b.rs_mask.data()),
-                      "icg_fm_ransac_device");
-        else
-            abi_check(ctx_, icg_fm_ransac(ctx_, n, b.rs_off.data(), b.rs_p1.data(), b.rs_p2.data(), b.rs_thresh, b.rs_conf, b.rs_mask.data()),
-                      "icg_fm_ransac");
+        // the one-launch form (every set's whole run inside its workgroup — the kernel of the device-resident tracker) rather than one
+        // launch + one wait per RANSAC chunk (icg_fm_ransac): identical masks (tests/test_gpu_geometry.py), one round trip
+        abi_check(ctx_, icg_fm_ransac_device(ctx_, n, b.rs_off.data(), b.rs_p1.data(), b.rs_p2.data(), b.rs_thresh, b.rs_conf, b.rs_mask.data()),
+                  "icg_fm_ransac_device");
     }
     if (!b.tri_T0.empty()) {
         hostprof::Scope hp(hostprof::DEV_TRIANGULATE);

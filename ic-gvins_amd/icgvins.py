@@ -15,7 +15,7 @@ EXPORTS = [
     "icg_ctx_create", "icg_ctx_destroy", "icg_last_error", "icg_ctx_sync", "icg_ctx_set_wait_mode", "icg_ctx_stream", "icg_set_camera",
     "icg_version", "icg_pyramid_levels", "icg_prof_enable", "icg_prof_get", "icg_prof_names", "icg_dev_alloc",
     "icg_dev_free", "icg_dev_upload", "icg_dev_download", "icg_frames_preprocess", "icg_frame_download",
-    "icg_lk_track", "icg_lk_track_fb", "icg_lk_track_fb_reuse", "icg_lk_reuse_stats", "icg_undistort_points", "icg_distort_points", "icg_predict_mappoints",
+    "icg_lk_track", "icg_lk_track_fb", "icg_undistort_points", "icg_distort_points", "icg_predict_mappoints",
     "icg_predict_rotation", "icg_fm_ransac", "icg_fm_ransac_device", "icg_detect", "icg_triangulate", "icg_reproj_eval_batch",
     "icg_reproj_set_factors", "icg_reproj_eval_resident", "icg_reproj_accumulate_normal", "icg_preint_batch",
     "icg_ins_mechanize_batch", "icg_ins_camera_pose_batch", "icg_reproj_schur", "icg_reproj_backsub", "icg_reproj_cost", "icg_reproj_landmark_diag",
@@ -179,23 +179,6 @@ class Context:
         ns = _i32(np.broadcast_to(next_slot, (n,)))
         self._ck(self.lib.icg_lk_track(self.h, n, _p(ps), _p(ns), _p(prev_pts), _p(nxt), _p(st), _p(err)), "icg_lk_track")
         return nxt, st, err
-
-    def lk_track_fb_reuse(self, prev_slot, next_slot, prev_pts, guess, prev_index=None, want_undist=False):
-        """icg_lk_track_fb_reuse: as lk_track_fb, with the template set-up cache (prev_index: per point the index it had in the previous call)"""
-        n = len(prev_slot)
-        ps, ns = np.ascontiguousarray(prev_slot, np.int32), np.ascontiguousarray(next_slot, np.int32)
-        prev_pts, guess = np.ascontiguousarray(prev_pts, np.float32), np.ascontiguousarray(guess, np.float32)
-        pi = None if prev_index is None else np.ascontiguousarray(prev_index, np.int32)
-        out, st = np.zeros((n, 2), np.float32), np.zeros(n, np.uint8)
-        und = np.zeros((n, 2), np.float32) if want_undist else None
-        self._ck(self.lib.icg_lk_track_fb_reuse(self.h, n, _p(ps), _p(ns), _p(prev_pts), _p(guess), _p(pi), _p(out), _p(st), _p(und)),
-                 "icg_lk_track_fb_reuse")
-        return (out, st, und) if want_undist else (out, st)
-
-    def lk_reuse_stats(self):
-        out = np.zeros(2, np.uint64)
-        self._ck(self.lib.icg_lk_reuse_stats(self.h, _p(out)), "icg_lk_reuse_stats")
-        return int(out[0]), int(out[1])
 
     def lk_track_fb(self, prev_slot, next_slot, prev_pts, guess, want_undist=False, want_keep=False):
         prev_pts = _f32(prev_pts).reshape(-1, 2)

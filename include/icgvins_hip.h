@@ -110,19 +110,6 @@ int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, const int32_t
                     const float *guess_pts, float *out_pts, uint8_t *status, float *out_undist, int32_t *keep_idx,
                     int32_t *n_keep);
 
-/* The same forward/backward track for a STREAM of frames: every frame the reference calls calcOpticalFlowPyrLK twice per point set
- * (tracking.cc:385-393: previous -> current, then current -> previous) and OpenCV sets the template of each call up from scratch
- * (window sums, Scharr samples: lkpyramid.cpp LKTrackerInvoker).  The backward call's template — the current image at the tracked
- * position — is the forward call's template one frame later, so this entry point keeps it: prev_index[i] names the point of the PREVIOUS
- * icg_lk_track_fb_reuse call on this context whose forward result is this point's prev_pts[i] (or -1 / NULL: none).  A hint is only a
- * hint: a block is used when it was stored for the same frame slot, the slot has not been preprocessed since, the stored position has
- * the bit pattern of prev_pts[i] and its backward pass completed; otherwise the set-up is computed as icg_lk_track_fb does.  Results are
- * bit-identical to icg_lk_track_fb in either case.  Device memory: 2 x 15 488 B per point of the largest call. */
-int icg_lk_track_fb_reuse(icg_ctx *ctx, int n, const int32_t *prev_slot, const int32_t *next_slot, const float *prev_pts,
-                          const float *guess_pts, const int32_t *prev_index, float *out_pts, uint8_t *status, float *out_undist);
-/* out2[0] = points tracked by icg_lk_track_fb_reuse so far, out2[1] = those whose hint passed the host-side checks */
-int icg_lk_reuse_stats(icg_ctx *ctx, uint64_t *out2);
-
 /* ---- F4: Camera point maps (tracking/camera.cc) -------------------------------------------------------- */
 int icg_undistort_points(icg_ctx *ctx, int n, float *pts);                 /* camera.cc:72-74  in place */
 int icg_distort_points(icg_ctx *ctx, int n, float *pts);                   /* camera.cc:76-89  in place */

@@ -182,16 +182,6 @@ int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, const int32_t
     return ICG_OK;
 }
 
-// the template set-up cache is a device optimisation with bit-identical results: the CPU shim tracks every point from scratch
-int icg_lk_track_fb_reuse(icg_ctx *ctx, int n, const int32_t *prev_slot, const int32_t *next_slot, const float *prev_pts,
-                          const float *guess_pts, const int32_t *, float *out_pts, uint8_t *status, float *out_undist) {
-    return icg_lk_track_fb(ctx, n, prev_slot, next_slot, prev_pts, guess_pts, out_pts, status, out_undist, nullptr, nullptr);
-}
-int icg_lk_reuse_stats(icg_ctx *, uint64_t *out2) {
-    out2[0] = out2[1] = 0;
-    return ICG_OK;
-}
-
 int icg_undistort_points(icg_ctx *ctx, int n, float *pts) {
     orc_undistort_points(&ctx->cam.fx, n, pts);
     return ICG_OK;
