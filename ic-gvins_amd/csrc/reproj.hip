@@ -1356,8 +1356,12 @@ extern "C" int icg_reproj_set_windows(icg_ctx *ctx, int n_windows, const int32_t
     pt.fac_off.assign(fac_off, fac_off + n_windows + 1);
     pt.lm_off.assign(lm_off, lm_off + n_windows + 1);
     pt.sys_valid = 0;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc       = asm_plan_build(ctx, pt);
     if (rc) pt.W = 0;
+    if (getenv("ICG_ABI_DEBUG"))
+        fprintf(stderr, "[icg_reproj_set_windows] W=%d n=%d: assembly plan %.3f ms\n", n_windows, n,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return rc;
 }
 

@@ -483,64 +483,6 @@ void symmetricEigen(int n, const vector<double> &A, vector<double> &evals, vecto
     }
 }
 
-// ---- the reaper of factor records ------------------------------------------------------------------------------------------
-namespace {
-class FactorReaper {
-public:
-    static FactorReaper &get() {
-        static FactorReaper r;
-        return r;
-    }
-    bool give(vector<std::shared_ptr<ResidualBlockInfo>> &&v) {
-        {
-            std::lock_guard<std::mutex> lock(m_);
-            if (stop_ || q_.size() >= 64) return false; // (fallen behind, or the process is ending: the caller destroys them)
-            q_.push_back(std::move(v));
-        }
-        cv_.notify_one();
-        return true;
-    }
-
-private:
-    FactorReaper() : t_([this] { loop(); }) {}
-    ~FactorReaper() {
-        {
-            std::lock_guard<std::mutex> lock(m_);
-            stop_ = true;
-        }
-        cv_.notify_one();
-        t_.join();
-    }
-    void loop() {
-        for (;;) {
-            vector<std::shared_ptr<ResidualBlockInfo>> v;
-            {
-                std::unique_lock<std::mutex> lock(m_);
-                cv_.wait(lock, [&] { return stop_ || !q_.empty(); });
-                if (q_.empty()) return; // (stop: what is queued has been destroyed)
-                v.swap(q_.front());
-                q_.pop_front();
-            }
-            v.clear();
-        }
-    }
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::deque<vector<std::shared_ptr<ResidualBlockInfo>>> q_;
-    bool stop_{false};
-    std::thread t_; // (last member: the thread starts when everything it touches exists)
-};
-} // namespace
-
-void reapFactorRecords(vector<std::shared_ptr<ResidualBlockInfo>> &&records) {
-    if (records.size() < 256 || !FactorReaper::get().give(std::move(records))) records.clear();
-}
-
-void MarginalizationInfo::releaseMemory() {
-    reapFactorRecords(std::move(factors_));
-    factors_.clear();
-}
-
 // ---- MarginalizationInfo ------------------------------------------------------------------------------------------------
 MarginalizationInfo::~MarginalizationInfo() {
     for (auto &block : parameter_block_data_) delete[] block.second;

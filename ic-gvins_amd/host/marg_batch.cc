@@ -46,6 +46,7 @@ void MarginalizationBatch::clear() {
     for (auto &W : windows_)
         if (W->info && W->info->batch_ == W.get()) W->info->batch_ = nullptr; // (an info may outlive the batch: it keeps only its results)
     windows_.clear();
+    retired_.clear(); // (the factor records of the windows marginalized since the last clear())
     laid_out_  = false;
     n_factors_ = n_poses_ = n_lm_ = 0;
 }
@@ -190,11 +191,13 @@ bool MarginalizationBatch::marginalize(std::vector<char> *ok) {
     error_.clear();
     window_error_.clear();
     if (NW == 0) return true;
-    if (!laid_out_ && !layout()) return false;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms  = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
     };
+    const auto t_layout = now();
+    if (!laid_out_ && !layout()) return false;
+    const double layout_ms = ms(t_layout, now());
     auto fail = [&](const std::string &what) {
         error_ = what;
         for (auto &W : windows_) W->evaluated = false;
@@ -309,16 +312,10 @@ bool MarginalizationBatch::marginalize(std::vector<char> *ok) {
         I.linearization();
         good[w] = 1;
     });
-    // (:99) the factor records of the windows that went through — the caller allocated them (one arena), so they are freed by ONE thread:
-    // from the pool's threads the frees contend on that arena (600 ms instead of 28 ms for 256 C2 windows), on the calling thread they are
-    // 45 of the 90 ms of such a batch.  The reaper thread (factors.h reapFactorRecords) destroys them while the caller goes on (the records are
-    // shared_ptrs: whoever drops the last reference destroys).
-    {
-        std::vector<std::shared_ptr<ResidualBlockInfo>> bin;
-        for (size_t w = 0; w < NW; w++)
-            if (good[w]) windows_[w]->info->releaseMemoryInto(bin);
-        reapFactorRecords(std::move(bin));
-    }
+    // (:99) the factor records of the windows that went through are retired: kept by this batch until clear() / destruction (factors.h
+    // MarginalizationInfo::releaseMemory: freeing ~3 300 heap blocks per window in line is 45 of the 90 ms of 256 C2 windows)
+    for (size_t w = 0; w < NW; w++)
+        if (good[w]) windows_[w]->info->releaseMemoryInto(retired_);
     auto t4 = now();
     for (size_t w = 0; w < NW; w++) {
         windows_[w]->evaluated = false;
@@ -331,8 +328,8 @@ bool MarginalizationBatch::marginalize(std::vector<char> *ok) {
     }
     phase_ms_[0] = ms(t0, t1), phase_ms_[1] = ms(t1, t2), phase_ms_[2] = ms(t2, t3), phase_ms_[3] = ms(t3, t4);
     if (getenv("ICG_MARG_DEBUG"))
-        fprintf(stderr, "[marginalization batch] %zu windows (%d structured, %d dense): evaluate %.3f ms, bookkeeping + host factors %.3f ms, assemble + eliminate %.3f ms, M3 + linearize %.3f ms\n",
-                NW, n_structured_, n_dense_, phase_ms_[0], phase_ms_[1], phase_ms_[2], phase_ms_[3]);
+        fprintf(stderr, "[marginalization batch] %zu windows (%d structured, %d dense): evaluate %.3f ms, bookkeeping + host factors %.3f ms, assemble + eliminate %.3f ms, M3 + linearize %.3f ms; layout (factor upload + partition) %.3f ms\n",
+                NW, n_structured_, n_dense_, phase_ms_[0], phase_ms_[1], phase_ms_[2], phase_ms_[3], layout_ms);
     return true; // (false above: a launch all windows share failed)
 }
 

@@ -96,6 +96,7 @@ private:
     std::unique_ptr<HostPool> pool_;
     std::vector<std::unique_ptr<Slice>> windows_;
     bool laid_out_{false};
+    std::vector<std::shared_ptr<ResidualBlockInfo>> retired_; // factor records of marginalized windows, freed by clear() / the destructor
     int n_factors_{0}, n_poses_{0}, n_lm_{0};
     int n_structured_{0}, n_dense_{0};
     double phase_ms_[4]{0, 0, 0, 0};
