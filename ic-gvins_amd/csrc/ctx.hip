@@ -162,6 +162,7 @@ extern "C" void icg_ctx_destroy(icg_ctx *ctx) {
     }
 
     if (ctx->h_arena) (void) hipHostFree(ctx->h_arena);
+    if (ctx->h_fstage) (void) hipHostFree(ctx->h_fstage);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

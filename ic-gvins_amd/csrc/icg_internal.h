@@ -106,6 +106,10 @@ struct icg_ctx {
     int last_n_poses = 0, last_n_lm = 0;
     double last_huber = 0.0;
     std::vector<int32_t> h_fidx; // host copy of d_fidx (3 x n): the assembly plans below are derived from it
+    // pinned host memory a caller fills with a factor set before icg_reproj_commit_factors (icg_reproj_stage_factors): obs (15 x n doubles) | idx (3 x n)
+    char *h_fstage = nullptr;
+    size_t fstage_cap = 0;
+    int fstage_n = -1;
     // f1: resident normal equations of the visual factors.  One window: H ((P+L)^2) | b | 1/(h_ll + damping) per landmark; a partition of
     // the factors into W windows (icg_reproj_set_windows) keeps one such block per window.  part_1 is the implicit partition "all resident
     // factors are one window" behind the single-window entry points — both run through the SAME kernels, so a window's sums are formed in

@@ -236,9 +236,34 @@ static int ensure_factor_capacity(icg_ctx *ctx, int n) {
     return 0;
 }
 
-extern "C" int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa, const int32_t *idx_i,
-                                      const int32_t *idx_j, const int32_t *idx_lm) {
-    if (!ctx || n < 0 || (n > 0 && (!obs_soa || !idx_i || !idx_j || !idx_lm))) return ICG_ERR_INVALID;
+// The factor set goes up from PINNED memory: the classic entry point copies the caller's arrays into the context's staging block first,
+// icg_reproj_stage_factors hands the block out so that a caller with many windows fills it in place from its own threads (34 MB of
+// observations for 256 marginalization windows: as a pageable hipMemcpy they were 9 of the 13 ms MarginalizationBatch::layout took).
+static size_t fstage_idx_offset(int n) { return icg_align_up(sizeof(double) * 15 * (size_t) n, 256); }
+
+extern "C" int icg_reproj_stage_factors(icg_ctx *ctx, int n, double **obs_soa, int32_t **idx3) {
+    if (!ctx || n < 0 || !obs_soa || !idx3) return ICG_ERR_INVALID;
+    ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t bytes = fstage_idx_offset(n) + sizeof(int32_t) * 3 * (size_t) n + 256;
+    if (bytes > ctx->fstage_cap) {
+        ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_fstage) (void) hipHostFree(ctx->h_fstage);
+        ctx->h_fstage = nullptr, ctx->fstage_cap = 0;
+        const size_t cap = bytes + bytes / 4;
+        ICG_HIP(ctx, hipHostMalloc((void **) &ctx->h_fstage, cap, hipHostMallocDefault));
+        ctx->fstage_cap = cap;
+    }
+    ctx->fstage_n = n;
+    *obs_soa      = reinterpret_cast<double *>(ctx->h_fstage);
+    *idx3         = reinterpret_cast<int32_t *>(ctx->h_fstage + fstage_idx_offset(n));
+    return ICG_OK;
+}
+
+extern "C" int icg_reproj_commit_factors(icg_ctx *ctx) {
+    if (!ctx) return ICG_ERR_INVALID;
+    const int n = ctx->fstage_n;
+    if (n < 0) return icg_fail(ctx, ICG_ERR_INVALID, "no staged factor set: call icg_reproj_stage_factors first");
+    ctx->fstage_n = -1;
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
     int rc = ensure_factor_capacity(ctx, n);
     if (rc) return rc;
@@ -246,18 +271,30 @@ extern "C" int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa
     ctx->rJ_valid           = 0;
     // a new factor set: the partitions, their assembly plans and resident systems belong to the old one
     for (icg_partition *pt : {&ctx->part_1, &ctx->part_w}) pt->W = 0, pt->plan_valid = false, pt->sys_valid = 0;
-    ctx->h_fidx.resize(3 * (size_t) n);
+    const int32_t *idx3 = reinterpret_cast<const int32_t *>(ctx->h_fstage + fstage_idx_offset(n));
+    ctx->h_fidx.assign(idx3, idx3 + 3 * (size_t) n);
     if (n == 0) return ICG_OK;
-    memcpy(ctx->h_fidx.data(), idx_i, sizeof(int32_t) * (size_t) n);
-    memcpy(ctx->h_fidx.data() + n, idx_j, sizeof(int32_t) * (size_t) n);
-    memcpy(ctx->h_fidx.data() + 2 * (size_t) n, idx_lm, sizeof(int32_t) * (size_t) n);
     // component-major obs is already the device layout; indices packed as 3 x n
-    ICG_HIP(ctx, hipMemcpyAsync(ctx->d_obs, obs_soa, sizeof(double) * 15 * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
-    ICG_HIP(ctx, hipMemcpyAsync(ctx->d_fidx, idx_i, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
-    ICG_HIP(ctx, hipMemcpyAsync(ctx->d_fidx + n, idx_j, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
-    ICG_HIP(ctx, hipMemcpyAsync(ctx->d_fidx + 2 * (size_t) n, idx_lm, sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    ICG_HIP(ctx, hipMemcpyAsync(ctx->d_obs, ctx->h_fstage, sizeof(double) * 15 * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+    ICG_HIP(ctx, hipMemcpyAsync(ctx->d_fidx, idx3, sizeof(int32_t) * 3 * (size_t) n, hipMemcpyHostToDevice, ctx->stream));
     ICG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ICG_OK;
+}
+
+extern "C" int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa, const int32_t *idx_i,
+                                      const int32_t *idx_j, const int32_t *idx_lm) {
+    if (!ctx || n < 0 || (n > 0 && (!obs_soa || !idx_i || !idx_j || !idx_lm))) return ICG_ERR_INVALID;
+    double *so   = nullptr;
+    int32_t *si  = nullptr;
+    int rc = icg_reproj_stage_factors(ctx, n, &so, &si);
+    if (rc) return rc;
+    if (n > 0) {
+        memcpy(so, obs_soa, sizeof(double) * 15 * (size_t) n);
+        memcpy(si, idx_i, sizeof(int32_t) * (size_t) n);
+        memcpy(si + n, idx_j, sizeof(int32_t) * (size_t) n);
+        memcpy(si + 2 * (size_t) n, idx_lm, sizeof(int32_t) * (size_t) n);
+    }
+    return icg_reproj_commit_factors(ctx);
 }
 
 // r_view / J_view != nullptr: the results are left in the context's pinned staging memory after the device-to-host copy and the views point

@@ -124,9 +124,16 @@ bool WindowSolverBatch::finalize() {
         error_ = "no reprojection factors";
         return false;
     }
-    std::vector<double> obs((size_t) 15 * n_factors_);
-    std::vector<int32_t> ii((size_t) n_factors_), jj((size_t) n_factors_), ll((size_t) n_factors_);
-    for (const Window &W : windows_)
+    // (written by the pool's threads straight into the context's pinned staging block: icg_reproj_stage_factors)
+    double *obs   = nullptr;
+    int32_t *idx3 = nullptr;
+    if (icg_reproj_stage_factors(ctx_, n_factors_, &obs, &idx3) != ICG_OK) {
+        error_ = icg_last_error(ctx_);
+        return false;
+    }
+    int32_t *ii = idx3, *jj = idx3 + n_factors_, *ll = idx3 + 2 * (size_t) n_factors_;
+    forEachWindow(windows_.size(), [&](size_t w) {
+        const Window &W = windows_[w];
         for (size_t k = 0; k < W.visual.size(); k++) {
             const size_t f = (size_t) W.fac_begin + k;
             for (int c = 0; c < 15; c++) obs[(size_t) c * n_factors_ + f] = W.visual[k].obs[c];
@@ -134,7 +141,8 @@ bool WindowSolverBatch::finalize() {
             jj[f] = W.pose_begin + W.pose_index.at(W.visual[k].pose_j);
             ll[f] = W.lm_begin + W.lm_index.at(W.visual[k].invdepth);
         }
-    if (icg_reproj_set_factors(ctx_, n_factors_, obs.data(), ii.data(), jj.data(), ll.data()) != ICG_OK ||
+    });
+    if (icg_reproj_commit_factors(ctx_) != ICG_OK ||
         icg_reproj_set_windows(ctx_, (int) windows_.size(), fac_off.data(), lm_off.data()) != ICG_OK) {
         error_ = icg_last_error(ctx_);
         return false;

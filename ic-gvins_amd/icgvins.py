@@ -17,7 +17,7 @@ EXPORTS = [
     "icg_dev_free", "icg_dev_upload", "icg_dev_download", "icg_frames_preprocess", "icg_frame_download",
     "icg_lk_track", "icg_lk_track_fb", "icg_undistort_points", "icg_distort_points", "icg_predict_mappoints",
     "icg_predict_rotation", "icg_fm_ransac", "icg_fm_ransac_device", "icg_detect", "icg_triangulate", "icg_reproj_eval_batch",
-    "icg_reproj_set_factors", "icg_reproj_eval_resident", "icg_reproj_accumulate_normal", "icg_preint_batch",
+    "icg_reproj_set_factors", "icg_reproj_stage_factors", "icg_reproj_commit_factors", "icg_reproj_eval_resident", "icg_reproj_accumulate_normal", "icg_preint_batch",
     "icg_ins_mechanize_batch", "icg_ins_camera_pose_batch", "icg_reproj_schur", "icg_reproj_backsub", "icg_reproj_cost", "icg_reproj_landmark_diag",
     "icg_reproj_error_batch", "icg_reproj_set_windows", "icg_reproj_eval_windows", "icg_reproj_schur_windows",
     "icg_reproj_schur_windows_view", "icg_reproj_reserve_windows", "icg_reproj_eval_resident_view", "icg_reproj_backsub_windows", "icg_reproj_schur_windows_resident", "icg_reproj_set_host_part_windows", "icg_reproj_solve_backsub_windows", "icg_reproj_cost_windows", "icg_reproj_fetch_residuals", "icg_reproj_chi2_cull",

@@ -171,6 +171,12 @@ int icg_reproj_eval_batch(icg_ctx *ctx, int n, const double *obs_soa, const int3
 /* Same with the static part (obs, indices) already resident: upload once per Ceres problem, evaluate many times. */
 int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa, const int32_t *idx_i, const int32_t *idx_j,
                            const int32_t *idx_lm);
+/* The same upload in two steps for callers that assemble a large factor set from many threads (the windows of many streams): the context
+ * hands out PINNED host memory for n factors — *obs_soa: 15 x n doubles, component-major as above; *idx3: 3 x n int32, idx_i | idx_j |
+ * idx_lm — the caller fills it in place, icg_reproj_commit_factors uploads it (equivalent to icg_reproj_set_factors on the same content).
+ * The pointers are valid until the next stage / set call on ctx. */
+int icg_reproj_stage_factors(icg_ctx *ctx, int n, double **obs_soa, int32_t **idx3);
+int icg_reproj_commit_factors(icg_ctx *ctx);
 int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm,
                              const double *invdepth, double td, int want_jac, double huber_delta, double *out_r,
                              double *out_J);

@@ -257,6 +257,9 @@ struct shim_backend {
     int n = 0, n_poses = 0, n_lm = 0;
     std::vector<double> obs, r, J;
     std::vector<int32_t> ii, jj, ll;
+    std::vector<double> stage_obs; // icg_reproj_stage_factors / _commit_factors
+    std::vector<int32_t> stage_idx;
+    int stage_n = -1;
     double huber = 0.0;
     // f1: resident normal equations
     int P = 0;
@@ -294,6 +297,23 @@ int icg_reproj_set_factors(icg_ctx *ctx, int n, const double *obs_soa, const int
     B.jj.assign(idx_j, idx_j + n);
     B.ll.assign(idx_lm, idx_lm + n);
     return ICG_OK;
+}
+
+int icg_reproj_stage_factors(icg_ctx *ctx, int n, double **obs_soa, int32_t **idx3) {
+    if (!ctx || n < 0 || !obs_soa || !idx3) return ICG_ERR_INVALID;
+    shim_backend &B = g_backend[ctx];
+    B.stage_obs.assign(15 * (size_t) n + 1, 0.0);
+    B.stage_idx.assign(3 * (size_t) n + 1, 0);
+    B.stage_n = n;
+    *obs_soa = B.stage_obs.data(), *idx3 = B.stage_idx.data();
+    return ICG_OK;
+}
+int icg_reproj_commit_factors(icg_ctx *ctx) {
+    shim_backend &B = g_backend[ctx];
+    if (B.stage_n < 0) return ICG_ERR_INVALID;
+    const int n = B.stage_n;
+    B.stage_n   = -1;
+    return icg_reproj_set_factors(ctx, n, B.stage_obs.data(), B.stage_idx.data(), B.stage_idx.data() + n, B.stage_idx.data() + 2 * (size_t) n);
 }
 
 int icg_reproj_eval_resident(icg_ctx *ctx, int n_poses, const double *poses, const double *ext, int n_lm, const double *invdepth,
