@@ -335,7 +335,7 @@ def run_frontend(torch, hip, *, w, h, nfeat, window, B, G, ring, prime, warmup, 
             raise RuntimeError("icgh_batch_run failed: " + sb._err.value.decode())
         return states
 
-    # diagnostic (profiles/r03_cpu_quota.md): ICG_BENCH_TIMED_CPUS=N confines EVERY thread of the process (group threads, HIP runtime
+    # diagnostic (profiles/archive/r03_cpu_quota.md): ICG_BENCH_TIMED_CPUS=N confines EVERY thread of the process (group threads, HIP runtime
     # threads) to the first N allowed CPUs from here on — priming, warm-up and the timed region run on N cores, only the set-up
     # (rendering, uploads) used them all.  What one rank of an 8-rank run on a 16-core box has is N = 2.
     if os.environ.get("ICG_BENCH_TIMED_CPUS"):
@@ -681,7 +681,7 @@ def main():
                          "the reference's state machine (first frame, initialization, a full 10-keyframe window), every arena / pool has "
                          "its steady-state size, and the DEVICE has reached its steady state whatever --warmup is: after the seconds of "
                          "rendering during set-up an MI355X needs > 1 s of sustained load before a step takes its steady 6.6-6.9 ms (round 4, "
-                         "profiles/r04_device_tracker.md: 20 timed steps after 48 / 120 / 200 priming frames = 97.5 / 97.0 / 108.1 k frames/s, "
+                         "profiles/archive/r04_device_tracker.md: 20 timed steps after 48 / 120 / 200 priming frames = 97.5 / 97.0 / 108.1 k frames/s, "
                          "on either engine); the 5 warm-up steps of the driver's command are 35 ms")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("ICG_BENCH_STREAMS", "0")),
                     help="camera streams per GPU (0 = 8 per stream group)")

@@ -47,16 +47,16 @@ def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, 
       cores_rank   the rank's share of the usable host cores
       streams      768 camera streams per GPU, the same for every world size (weak scaling: per-GPU work is fixed)
       groups       stream groups (one host thread + HIP stream each).  With the track-table engine a frame costs the host ~20 us of logic, so
-                   a group can carry 32-64 streams; round-3 sweep on one MI355X (profiles/r03_group_sweep.txt): 48 x 8 -> 78 k, 24 x 16 -> 92 k,
+                   a group can carry 32-64 streams; round-3 sweep on one MI355X (profiles/archive/r03_group_sweep.txt): 48 x 8 -> 78 k, 24 x 16 -> 92 k,
                    16 x 24 -> 98.6 k, 12 x 32 -> 99.9 k, 8 x 48 -> 100.7 k frames/s with 3.3-3.9 host cores busy; larger launches have shorter
                    tails: 12 x 64 -> 111.0 k, 16 x 64 -> 111.7 k, 8 x 96 -> 105.5 k (4.2 cores busy).  4 groups per core of the share, between
-                   4 and 12 (every thread confined to 2 CPUs, profiles/r03_cpu_quota.md: 8 x 96 -> 44.4 k, 6 x 128 -> 42.1 k frames/s).
+                   4 and 12 (every thread confined to 2 CPUs, profiles/archive/r03_cpu_quota.md: 8 x 96 -> 44.4 k, 6 x 128 -> 42.1 k frames/s).
       cpu_slice    the contiguous slice of the allowed CPU ids this rank pins itself to (None for a single rank: nothing to separate)
     """
     cores_rank = float(usable_cores) / float(max(1, world))
     # engine.  The device-resident tracker (csrc/tracker.hip: the streams' state in HBM, one launch chain + one wait per step) is THE engine
     # since round 5, for every rank whatever its share of the host: at the driver's command (20 timed steps) 133.5 k frames/s with 0.56 host
-    # cores busy against 127.6 k with 5.4 cores busy for the track table (profiles/r05_call9: same box, same minute; 137.5 k with every
+    # cores busy against 127.6 k with 5.4 cores busy for the track table (profiles/archive/r05_call9: same box, same minute; 137.5 k with every
     # thread confined to 2 CPUs, 119.0 k on ONE, where the table collapses to 47.5 k); on 200-step runs the two are within +-3 %
     # (130.9 / 135.2 k).  Rounds 1-3's host engines (track table, object graph, tracker core on the host) stay selectable
     # (--engine / ICG_TRACK_ENGINE) and run as the bench's engine twin and in the tests: same results, state for state
@@ -67,7 +67,7 @@ def host_plan(usable_cores, world, local_rank, cpu_ids=None, groups_override=0, 
         # 108.8 k, 8 x 192 (1536 streams) -> 111.8 k; 2 confined CPUs: 4 x 192 -> 106.7 k, 8 x 96 -> 106.1 k
         groups = int(groups_override) if groups_override > 0 else 4
     else:
-        # round 5 (profiles/r05_call7: with 12 groups no LK launch is in flight 24 % of the time; r05_call5 / r05_call8 sweeps on three boxes:
+        # round 5 (profiles/archive/r05_call7: with 12 groups no LK launch is in flight 24 % of the time; r05_call5 / r05_call8 sweeps on three boxes:
         # 12 x 64 -> 131.6-134.7 k, 16 x 48 -> 134.7 k, 16 x 64 -> 135.6-138.2 k, 24 x 32 -> 125.5 k, 24 x 48 -> 134.2 k, 32 x 32 -> 130.8 k)
         groups = int(groups_override) if groups_override > 0 else int(max(4, min(16, 4 * round(cores_rank))))
     streams = int(streams_override) if streams_override > 0 else STREAMS_PER_GPU

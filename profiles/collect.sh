@@ -31,7 +31,8 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCL
 for CNT in $( [ -z "$ENGINE" ] && echo FETCH_SIZE WRITE_SIZE ); do
   rocprofv3 --pmc $CNT --output-format csv -d $OUT/${TAG}_pmc_reproj_$CNT -o p -- python $R/profiles/run_reproj_only.py > /dev/null 2> $OUT/${TAG}_pmc_reproj_$CNT.err
 done
-export ICG_PMC_STREAMS_PER_LAUNCH=$(python -c "import json; c=json.load(open('$OUT/${TAG}${ESUF}_kt_bench.json'))['config']; print(c['streams_per_gpu'] / c['groups_per_gpu'])")
+# (the contract line is the LAST line that starts with "{": native libraries may print banners before it)
+export ICG_PMC_STREAMS_PER_LAUNCH=$(python -c "import json; c=json.loads([l for l in open('$OUT/${TAG}${ESUF}_kt_bench.json').read().splitlines() if l.startswith('{')][-1])['config']; print(c['streams_per_gpu'] / c['groups_per_gpu'])")
 export ICG_PMC_LK_ACTIVE_POINTS=$(python -c "import json; print(json.load(open('$OUT/${TAG}${ESUF}_kt_bench_details.json'))['roofline']['units_per_launch'])")
 python $R/profiles/summarize_pmc.py $OUT/${TAG}${ESUF}_pmc_fetch $OUT/${TAG}${ESUF}_pmc_write $OUT/${TAG}${ESUF}_pmc_sq $OUT/${TAG}_pmc_reproj_FETCH_SIZE $OUT/${TAG}_pmc_reproj_WRITE_SIZE > $OUT/${TAG}_pmc_summary${ESUF}.json
 [ -d $OUT/${TAG}_kt ] && find $OUT/${TAG}_kt -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;

@@ -4,7 +4,7 @@
 # 1. the back-end GPU tests with bitwise=True (lock-step replays, marginalization batch incl. the per-window oracle check)
 # 2. WindowSolverBatch phase split at 256 C2 windows + rocprofv3 kernel stats of the same
 # 3. the whole GPU suite
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c1
 mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 10: layout() and the chi-square count on the pool; whole-solve clock
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c10
 mkdir -p $O
 cd $R

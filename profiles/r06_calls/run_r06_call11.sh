@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, call 11: the LK launch on a lowest-priority stream of its own (ICG_LK_STREAM_PRIORITY=low), or the group's
 # stream raised above it (=high), against the default — same box, interleaved, 100 timed steps each
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c11
 mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 12: RCCL exchange on one GPU (test + driver command), C4 roofline / parity witness / preint baseline in the line
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c12
 mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 13: launch shape of the device engine re-swept on the round-6 kernels (768 streams, groups x streams per launch), 60 timed steps
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c13
 mkdir -p $O
 cd $R

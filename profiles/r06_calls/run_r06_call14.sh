@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 14: MarginalizationBatch phase split at 256 C2 windows on the round-6 tree (allocator policy default = glibc's, and =raise)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c14
 mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 15: where the 13 ms outside the four phases of a 256-window MarginalizationBatch go (layout: factor upload, partition, assembly plan)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c15
 mkdir -p $O
 cd $R

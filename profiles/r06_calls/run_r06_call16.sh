@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 16: GPU suite + marg probe after the reaper thread went
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c16
 mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 2: k_asm_landmarks (LDS-staged) and k_schur_reduce_w (4 x 4 register tiles, lower triangle) — back-end tests + solver profile
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c2
 mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 3: where the reduction kernel's time goes (zero-copy S over PCIe vs S resident + batched Cholesky on the device)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c3
 mkdir -p $O
 cd $R

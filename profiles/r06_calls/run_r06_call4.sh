@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 4: async evaluation calls, k_asm_landmarks by (landmark, block), batched gathers in k_asm_camera, prefetching reduction
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c4
 mkdir -p $O
 cd $R

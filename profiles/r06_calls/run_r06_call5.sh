@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 5: device call beside the host half of a linearization (WindowSolverBatch)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c5
 mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 6: WindowSolverBatch wall time over repetitions and host thread counts
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c6
 mkdir -p $O
 cd $R

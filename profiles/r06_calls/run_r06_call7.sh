@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 7: the serial part of a batched solve — per-call split of the assembly / reduction entry point (ICG_ABI_DEBUG)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c7
 mkdir -p $O
 cd $R

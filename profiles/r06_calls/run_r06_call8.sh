@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6, call 8: dead kernel variants deleted (LK pair / set-up cache, tile pyramid, CLAHE legacy), LK at 96 VGPRs without scratch:
 # whole GPU suite (incl. tests/test_gpu_switches.py) and the driver's command
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c8
 mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, call 9: the batched solve inside the bench process (light front-end) against the stand-alone probe — the side thread is persistent now
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out/r6c9
 mkdir -p $O
 cd $R

@@ -110,7 +110,7 @@ def test_fm_ransac_mask(oracle, G, tag):
 def test_hip_path_against_real_opencv_on_the_gpu_box(G, tag):
     """Selected by `-m gpu`, so the GPU summary carries the marker too: while the golden is absent this SKIPS (visible as skipped with the
     reason above) — on the GPU lease there is no cv2, no wheel in /opt/wheelhouse, no pip index, no apt source and no network either
-    (profiles/r04_opencv_probe.txt, one gpurun call of round 4).  With the golden present the WHOLE HIP front-end is pinned at once, through the C ABI
+    (profiles/archive/r04_opencv_probe.txt, one gpurun call of round 4).  With the golden present the WHOLE HIP front-end is pinned at once, through the C ABI
     (VERDICT r4 item 7), with the bounds the oracle tests above state per primitive:
       CLAHE (tracking.cc:63,139) and the LK pyramid levels: bit-exact; calcOpticalFlowPyrLK (:385-393, 487-496): status identical up to
       threshold decisions, positions within 2e-3 px; undistortPoints (camera.cc:72-74): float bit patterns; goodFeaturesToTrack +
