@@ -297,6 +297,20 @@ class Context:
                  "icg_reproj_set_factors")
         self._nfac = n
 
+    def reproj_set_factors_staged(self, obs_soa, idx_i, idx_j, idx_lm):
+        """the same upload through icg_reproj_stage_factors / icg_reproj_commit_factors: the factor set is written into the context's pinned
+        staging block in place (what the host layer does from its pool threads)"""
+        obs_soa = _f64(obs_soa)
+        n = obs_soa.shape[1]
+        po, pi = C.c_void_p(), C.c_void_p()
+        self._ck(self.lib.icg_reproj_stage_factors(self.h, n, C.byref(po), C.byref(pi)), "icg_reproj_stage_factors")
+        if n:
+            np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_double)), shape=(15, n))[:] = obs_soa
+            idx = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_int32)), shape=(3, n))
+            idx[0], idx[1], idx[2] = _i32(idx_i), _i32(idx_j), _i32(idx_lm)
+        self._ck(self.lib.icg_reproj_commit_factors(self.h), "icg_reproj_commit_factors")
+        self._nfac = n
+
     def reproj_eval_resident(self, poses, ext, invdepth, td, want_jac=True, huber=0.0, fetch=True):
         poses = _f64(poses).reshape(-1, 7)
         invdepth = _f64(invdepth).reshape(-1)

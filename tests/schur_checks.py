@@ -91,6 +91,64 @@ def check_schur(ctx, oracle, tol=1e-9):
         assert abs(ctx.reproj_cost(active) - cost2) < tol * max(1.0, cost2)
 
 
+def check_schur_any_factor_order(ctx, oracle, tol=1e-9, refuses_same_block=True):
+    """The assembly makes no assumption about the factor list (csrc/reproj.hip, asm_plan_build sorts by pose pair and by landmark itself):
+    a shuffled list, a landmark whose factors name DIFFERENT reference poses, the same (landmark, observer) pair twice, poses used as
+    reference by some factors and as observer by others — all equal the numpy assembly of the same list; and a commit through the staged
+    upload equals the classic upload bit for bit.  A factor whose reference and observer are the same block is refused."""
+    w = rd.make_window(60, 6, seed=9, pixel_noise=2.0)
+    rng = np.random.RandomState(4)
+    n0 = w["obs_soa"].shape[1]
+    perm = rng.permutation(n0)
+    dup = perm[:7]  # seven factors once more (same landmark, same pose pair, same observation)
+    order = np.concatenate([perm, dup])
+    w2 = dict(w, obs_soa=np.ascontiguousarray(w["obs_soa"][:, order]), idx_i=w["idx_i"][order].copy(), idx_j=w["idx_j"][order].copy(), idx_lm=w["idx_lm"][order].copy())
+    # landmark 3's factors get another reference pose here and there (any pose that is not the observer)
+    K, L = w["poses"].shape[0], len(w["invdepth"])
+    for f in np.nonzero(w2["idx_lm"] == 3)[0][::2]:
+        w2["idx_i"][f] = (w2["idx_j"][f] + 1 + rng.randint(0, K - 1)) % K
+        assert w2["idx_i"][f] != w2["idx_j"][f]
+    n = len(order)
+    col_pose = np.arange(K, dtype=np.int32) * 6
+    col_pose[2] = -1  # one constant pose in the middle
+    col_pose[3:] -= 6
+    P = 6 * (K - 1) + 7
+    col_ext, col_td = 6 * (K - 1), 6 * (K - 1) + 6
+    active = (rng.uniform(0, 1, n) > 0.1).astype(np.uint8)
+    out = []
+    for upload in (ctx.reproj_set_factors, ctx.reproj_set_factors_staged):
+        upload(w2["obs_soa"], w2["idx_i"], w2["idx_j"], w2["idx_lm"])
+        ctx.reproj_eval_resident(w2["poses"], w2["ext"], w2["invdepth"], w2["td"], huber=1.0, fetch=False)
+        out.append(ctx.reproj_schur(P, col_pose, col_ext, col_td, active=active, damp=1e-4))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))  # same kernels on the same resident data: the same bits
+    S, s, dg, cst = out[0]
+    H, b, cost = full_system(oracle, w2, col_pose, col_ext, col_td, P, 1.0, active)
+    hll = np.diag(H)[P:]
+    inv = np.where(hll > 0, 1.0 / (hll + np.clip(hll, 1e-6, 1e32) * 1e-4), 0.0)
+    G = H[P:, :P]
+    S_exp = H[:P, :P] - G.T @ (inv[:, None] * G)
+    s_exp = b[:P] - G.T @ (inv * b[P:])
+    sc = max(1.0, np.abs(S_exp).max())
+    assert np.abs(S - S_exp).max() < tol * sc, np.abs(S - S_exp).max() / sc
+    assert np.abs(s - s_exp).max() < tol * max(1.0, np.abs(s_exp).max())
+    assert np.abs(dg - np.diag(H)[:P]).max() < tol * sc and abs(cst - cost) < tol * max(1.0, cost)
+    if refuses_same_block:  # (the device path; the CPU shim forms both triangles on their own)
+        assert np.array_equal(S, S.T)  # the upper triangle is the mirror image of the lower one
+    if not refuses_same_block:  # (the CPU shim sums whatever it is given; Ceres itself refuses duplicate blocks in a residual)
+        return
+    bad = dict(w2, idx_i=w2["idx_i"].copy())
+    bad["idx_i"][5] = bad["idx_j"][5]
+    ctx.reproj_set_factors(bad["obs_soa"], bad["idx_i"], bad["idx_j"], bad["idx_lm"])
+    ctx.reproj_eval_resident(bad["poses"], bad["ext"], bad["invdepth"], bad["td"], huber=1.0, fetch=False)
+    try:
+        ctx.reproj_schur(P, col_pose, col_ext, col_td, active=active, damp=1e-4)
+    except Exception as e:  # icgvins.IcgError
+        assert "same block" in str(e), e
+    else:
+        raise AssertionError("a factor with reference == observer was assembled")
+
+
 def check_schur_windows(make_ctx, tol=1e-9):
     """the many-windows-per-launch entry points against per-window calls of the single-window entry points on the same library
     (those are checked against numpy above): different window sizes, per-window extrinsic / td, constant blocks, a factor mask, a

@@ -17,6 +17,7 @@ def test_schur_entry_points_on_gpu(oracle):
     import icgvins
     ctx = icgvins.Context(640, 480, n_slots=1, max_batch=1, max_points=64)
     sc.check_schur(ctx, oracle)
+    sc.check_schur_any_factor_order(ctx, oracle)
     with pytest.raises(icgvins.IcgError):  # a pose column outside the reduced system
         ctx.reproj_schur(6, np.array([0, 6, 12, 18, 24, 30, 36], np.int32), -1, -1)
     ctx.close()

@@ -20,6 +20,7 @@ def test_schur_entry_points_on_oracle_shim(host_lib, oracle):
     import icgvins
     ctx = icgvins.Context(640, 480, n_slots=1, max_batch=1, max_points=64, lib=icgvins.load_library(host_lib))
     sc.check_schur(ctx, oracle)
+    sc.check_schur_any_factor_order(ctx, oracle, refuses_same_block=False)
     ctx.close()
 
 
