@@ -129,8 +129,8 @@ def test_contract_line_carries_the_round4_honesty_fields():
     """frac on the exclusive duration with the under-load figure beside it, frac_whole_path, the forward-only control with both runs' event
     rates, and pcie_inclusive as a named configuration variant — all in the compact line, which still fits the driver's 8 KB tail."""
     b = _bench()
-    committed = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("r02_bench_driver_command"))
-    full = json.load(open(os.path.join(ROOT, "profiles", committed[-1])))
+    committed = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles", "archive")) if f.startswith("r02_bench_driver_command"))
+    full = json.load(open(os.path.join(ROOT, "profiles", "archive", committed[-1])))
     full["parity"] = {"ok": True}
     rates = {"keyframes_per_frame": 0.5, "detections_per_frame": 1.0, "ransac_sets_per_frame": 1.0, "triangulated_points_per_frame": 20.0,
              "mappoints_created_per_frame": 18.0, "lk_points_per_frame": 290.0}
@@ -170,8 +170,8 @@ def test_marg_batch_probe_child_process_schema():
     try:
         blk = b.measure_marg_batched(4)
         assert blk.get("error") is None and blk["windows_per_batch"] == 4 and blk["value"] > 0 and blk["windows_structured_dense"] == [4, 0]
-        committed = sorted(f for f in os.listdir(os.path.join(root, "profiles")) if f.startswith("r02_bench_driver_command"))
-        full = json.load(open(os.path.join(root, "profiles", committed[-1])))  # a real full record
+        committed = sorted(f for f in os.listdir(os.path.join(root, "profiles", "archive")) if f.startswith("r02_bench_driver_command"))
+        full = json.load(open(os.path.join(root, "profiles", "archive", committed[-1])))  # a real full record
         full["parity"] = {"ok": True}
         full["marg"] = dict(full.get("marg") or {"value": 1.0, "unit": "ms per marginalization"}, batched=blk)
         assert b.compact_line(full, "details.json")["marg"]["batched"]["windows_per_batch"] == 4
