@@ -24,7 +24,7 @@ rm -rf $O/kt
 python3 - <<PY
 import csv, json
 d = json.loads([l for l in open("$O/hr_line.json").read().splitlines() if l.startswith("{")][-1])
-print("bench under the tracer:", d["value"], "avg_launch_us", d["roofline"]["avg_launch_us"])
+print("bench under the tracer:", d["value"], d["ms_per_step"])
 for r in list(csv.DictReader(open("$O/kernel_stats_headline_region.csv")))[:10]:
     print(r["Name"][:36], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1))
 PY
