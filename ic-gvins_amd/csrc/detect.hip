@@ -65,6 +65,9 @@ __device__ __forceinline__ float f32_from_order_key(unsigned int k) {
 #define FE_TH 16    // NMS output rows per wave
 #define FE_WAVES 4  // waves per workgroup, stacked vertically
 #define FE_MAX_RADIUS 1022 // largest disc radius the LDS span table holds (min_dist; 45 at C2)
+#ifndef FE_RESIDENT_PER_XCD
+#define FE_RESIDENT_PER_XCD 192 // resident workgroups of k_min_eig_nms per XCD (x 8 XCDs x 4 waves; fewer when the grid is smaller)
+#endif
 
 // lane i <- lane i-1 / lane i+1 across the whole wave (wave_shr:1 / wave_shl:1); the edge lanes receive 0 and are halo
 __device__ __forceinline__ float from_left(float v) {
@@ -74,28 +77,18 @@ __device__ __forceinline__ float from_right(float v) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130, 0xF, 0xF, true));
 }
 
-__global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
-                                                               const int32_t *slots, int pitch, int w, int h, const float2 *mask_pts,
-                                                               const int32_t *mask_begin, const int32_t *mask_cnt /* per job */, int radius,
-                                                               const int32_t *vspan /*radius+2*/,
-                                                               unsigned int *roi_max,
-                                                               unsigned long long *cand, size_t cand_plane, int32_t *cand_cnt,
-                                                               int gx, int gy, int n_blocks, unsigned int m_roi, unsigned int m_gx) {
-    // 1-D launch, ROI-major and XCD-chunked: the tiles of a ROI (and of a frame) share one XCD's L2
-    const int bl = icg_xcd_chunked(blockIdx.x, n_blocks);
-    if (bl >= n_blocks) return;
-    // vh[a], a = 0..radius, and vh[radius+1] = -1 for every column further away; staged before the first wave may leave (the only barrier)
-    __shared__ int vh[FE_MAX_RADIUS + 2];
-    for (int a = threadIdx.x; a < radius + 2; a += 64 * FE_WAVES) vh[a] = vspan[a];
-    __syncthreads();
+// one 60 x 16 tile: block bl = (roi, bx, by) of the ROI-major tile grid, tile wv of its four vertically stacked ones
+__device__ __forceinline__ void fe_tile(const int bl, const int wv, const int *vh, const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
+                                        const int32_t *slots, int pitch, int w, int h, const float2 *mask_pts, const int32_t *mask_begin,
+                                        const int32_t *mask_cnt, int radius, unsigned int *roi_max, unsigned long long *cand, size_t cand_plane,
+                                        int32_t *cand_cnt, int gx, int gy, unsigned int m_roi, unsigned int m_gx) {
     const int roi = icg_div_by_magic(bl, m_roi), rem = bl - roi * (gx * gy);
     const int by = icg_div_by_magic(rem, m_gx), bx = rem - by * gx;
     const det_roi R = rois[roi];
-    if (R.quota <= 0) return; // inactive entry of a dense (job, block) table (device-resident tracker); workgroup-uniform
+    if (R.quota <= 0) return; // inactive entry of a dense (job, block) table (device-resident tracker); wave-uniform
     const int lane = threadIdx.x & 63;
-    const int wv   = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // wave-uniform by construction: keep it in an SGPR
     const int tx0 = bx * FE_TW, ty0 = (by * FE_WAVES + wv) * FE_TH;
-    if (tx0 >= R.rw || ty0 >= R.rh) return; // wave-uniform; there is no barrier below this line
+    if (tx0 >= R.rw || ty0 >= R.rh) return; // wave-uniform
     const uint8_t *img = frames + (size_t) slots[R.job] * slot_bytes;
     const float s      = (float) (1.0 / 3060.0);
 
@@ -232,6 +225,32 @@ __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *ro
         key                  = o > key ? o : key;
     }
     if (lane == 0 && key) atomicMax(&roi_max[roi], key);
+}
+
+// RESIDENT waves (round 6): rounds 2-5 launched one workgroup per block of four tiles — 55 k workgroups per launch of 192 frames, 72 % of
+// whose waves leave after the mask test.  Here a fixed number of workgroups walks the ROI-major tile grid: workgroup b belongs to XCD
+// b & 7 (the dispatcher's round-robin) and takes blocks j, j + G, j + 2 G, ... of that XCD's contiguous eighth of the grid
+// (icg_xcd_chunked's partition: the tiles of a ROI and of a frame keep sharing one L2), wave wv the block's tile wv; the span table is
+// staged once per workgroup.  (A dynamic form — every wave pulling tiles from a per-XCD counter — was measured first: 221 k atomics on eight
+// addresses serialise in L2, 3.1 ms per launch against 0.27-0.45: profiles/r06_detector_resident_waves.txt.)
+__global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
+                                                               const int32_t *slots, int pitch, int w, int h, const float2 *mask_pts,
+                                                               const int32_t *mask_begin, const int32_t *mask_cnt /* per job */, int radius,
+                                                               const int32_t *vspan /*radius+2*/,
+                                                               unsigned int *roi_max,
+                                                               unsigned long long *cand, size_t cand_plane, int32_t *cand_cnt,
+                                                               int gx, int gy, int n_blocks, unsigned int m_roi, unsigned int m_gx) {
+    // vh[a], a = 0..radius, and vh[radius+1] = -1 for every column further away; staged before any wave starts (the only barrier)
+    __shared__ int vh[FE_MAX_RADIUS + 2];
+    for (int a = threadIdx.x; a < radius + 2; a += 64 * FE_WAVES) vh[a] = vspan[a];
+    __syncthreads();
+    const int chunk = (n_blocks + 7) >> 3;                       // blocks per XCD range
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3, G = gridDim.x >> 3; // (the grid is a multiple of 8)
+    const int wv  = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // wave-uniform by construction: keep it in an SGPR
+    const int end = min((x + 1) * chunk, n_blocks);
+    for (int bl = x * chunk + j; bl < end; bl += G)
+        fe_tile(bl, wv, vh, rois, frames, slot_bytes, slots, pitch, w, h, mask_pts, mask_begin, mask_cnt, radius, roi_max, cand, cand_plane, cand_cnt, gx, gy,
+                m_roi, m_gx);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -581,7 +600,7 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     {
         icg_prof_scope ps(ctx, "detect_min_eig_nms");
         const int gx = (grid->block_w + FE_TW - 1) / FE_TW, gy = (grid->block_h + FE_TH * FE_WAVES - 1) / (FE_TH * FE_WAVES);
-        hipLaunchKernelGGL(k_min_eig_nms, dim3(icg_xcd_grid(gx * gy * n_roi)), dim3(64 * FE_WAVES), 0, ctx->stream, d_rois, ctx->d_frames,
+        hipLaunchKernelGGL(k_min_eig_nms, dim3(std::min(icg_xcd_grid(gx * gy * n_roi), 8 * FE_RESIDENT_PER_XCD)), dim3(64 * FE_WAVES), 0, ctx->stream, d_rois, ctx->d_frames,
                            ctx->slot_bytes, d_slots, pitch, w, h, d_mpts, d_moff, d_mcnt, grid->min_dist, d_vh, d_rmax, ctx->d_cand, cand_plane, d_ccnt,
                            gx, gy, gx * gy * n_roi, icg_div_magic(gx * gy), icg_div_magic(gx));
     }
@@ -640,7 +659,7 @@ int icg_detect_launch_ind(icg_ctx *ctx, int n_jobs, const icg_detect_grid *grid,
     {
         icg_prof_scope ps(ctx, "detect_min_eig_nms");
         const int gx = (grid->block_w + FE_TW - 1) / FE_TW, gy = (grid->block_h + FE_TH * FE_WAVES - 1) / (FE_TH * FE_WAVES);
-        hipLaunchKernelGGL(k_min_eig_nms, dim3(icg_xcd_grid(gx * gy * n_roi)), dim3(64 * FE_WAVES), 0, ctx->stream, (const det_roi *) d_rois, ctx->d_frames,
+        hipLaunchKernelGGL(k_min_eig_nms, dim3(std::min(icg_xcd_grid(gx * gy * n_roi), 8 * FE_RESIDENT_PER_XCD)), dim3(64 * FE_WAVES), 0, ctx->stream, (const det_roi *) d_rois, ctx->d_frames,
                            ctx->slot_bytes, d_slots, pitch, w, h, d_mask_pts, d_mask_begin, d_mask_cnt, grid->min_dist, d_vh, ctx->d_roi_max, ctx->d_cand,
                            cand_plane, ctx->d_cand_cnt, gx, gy, gx * gy * n_roi, icg_div_magic(gx * gy), icg_div_magic(gx));
     }
