@@ -66,7 +66,7 @@ __device__ __forceinline__ float f32_from_order_key(unsigned int k) {
 #define FE_WAVES 4  // waves per workgroup, stacked vertically
 #define FE_MAX_RADIUS 1022 // largest disc radius the LDS span table holds (min_dist; 45 at C2)
 #ifndef FE_RESIDENT_PER_XCD
-#define FE_RESIDENT_PER_XCD 192 // resident workgroups of k_min_eig_nms per XCD (x 8 XCDs x 4 waves; fewer when the grid is smaller)
+#define FE_RESIDENT_PER_XCD 192 // workgroups of k_min_eig_nms per XCD (x 8 XCDs x 4 waves = the kernel's residency; fewer when the grid is smaller)
 #endif
 
 // lane i <- lane i-1 / lane i+1 across the whole wave (wave_shr:1 / wave_shl:1); the edge lanes receive 0 and are halo
@@ -77,18 +77,140 @@ __device__ __forceinline__ float from_right(float v) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130, 0xF, 0xF, true));
 }
 
-// one 60 x 16 tile: block bl = (roi, bx, by) of the ROI-major tile grid, tile wv of its four vertically stacked ones
-__device__ __forceinline__ void fe_tile(const int bl, const int wv, const int *vh, const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
-                                        const int32_t *slots, int pitch, int w, int h, const float2 *mask_pts, const int32_t *mask_begin,
-                                        const int32_t *mask_cnt, int radius, unsigned int *roi_max, unsigned long long *cand, size_t cand_plane,
-                                        int32_t *cand_cnt, int gx, int gy, unsigned int m_roi, unsigned int m_gx) {
+// wave-wide OR, total in lane 63: xor 1, xor 2, row_half_mirror, row_mirror inside every row of 16 lanes, then row_bcast15 / row_bcast31 (one
+// fused DPP operand each; lanes a broadcast does not reach OR in 0)
+__device__ __forceinline__ unsigned int wave_or_to_lane63(unsigned int v) {
+    v |= (unsigned int) __builtin_amdgcn_update_dpp(0, (int) v, 0xB1, 0xF, 0xF, false);
+    v |= (unsigned int) __builtin_amdgcn_update_dpp(0, (int) v, 0x4E, 0xF, 0xF, false);
+    v |= (unsigned int) __builtin_amdgcn_update_dpp(0, (int) v, 0x141, 0xF, 0xF, false);
+    v |= (unsigned int) __builtin_amdgcn_update_dpp(0, (int) v, 0x140, 0xF, 0xF, false);
+    v |= (unsigned int) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xA, 0xF, false);
+    v |= (unsigned int) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
+// one 60 x 64 BLOCK per wave (round 6; rounds 2-5 and the first half of round 6 gave every 60 x 16 tile a wave of its own):
+//   1. the mask of the whole block from the disc list — ONE pass over the job's centres for 64 rows (a 64-bit row set per lane) instead of
+//      four passes for 16 rows each: the bounding-box chunks fall from 16 to 4 per block and the (lane, disc) interval updates from ~44 to
+//      ~16, and the wave leaves as soon as every owned pixel is masked;
+//   2. the rows that hold an unmasked owned pixel, as RUNS (gaps of up to FE_GAP rows are streamed through: re-priming the rolling
+//      windows costs six rows); each run [a, b] is streamed from image row a - 3 to b + 3 in chunks of FE_CH rows; a row's register is
+//      reloaded with the same row of the next chunk as soon as it has been consumed.  The row step is the same for every row: the first rows of a run prime the
+//      windows with values nobody reads (every output is gated by the run's own unmasked bits).
+#ifndef FE_CH
+#define FE_CH 4   // image rows per load chunk (and the length of a run's priming chunk: keep it 4)
+#endif
+#define FE_GAP 6  // masked rows between two needed rows that are streamed rather than skipped
+
+// v_max_f32 without the two canonicalising v_max x, x the compiler puts in front of fmaxf for values that arrive through DPP (no NaN here)
+__device__ __forceinline__ float fe_max(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// the rolling windows of one run of rows and the step that consumes FE_CH image rows
+enum { FE_PLAIN = 0, FE_MIRRORS = 1, FE_PRIME = 2 };
+struct fe_rows {
+    int d0 = 0, d1 = 0, s0 = 0, s1 = 0;                                    // Sobel differences of the two image rows before
+    double hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0, hC0 = 0, hC1 = 0;           // horizontal 3-sums of the two product rows before
+    float eC = 0.f, sideC = 0.f, m3T = 0.f, m3C = 0.f;                     // response rows: centre and top of the NMS window
+    bool unmC = false;
+    float emax = -INFINITY;                                                // maximum of the unmasked owned responses (its key is formed once)
+
+    // image row y (ROI coordinate) -> product row y - 1 -> response row y - 2 -> NMS row y - 3.
+    // FE_PRIME: the first chunk of a run — its two first rows only start the Sobel differences, the other two only the product windows; no
+    // response of these rows is ever read.  FE_MIRRORS: the chunk holds one of the two mirrored product rows of the ROI (row -1 := row 1 when
+    // image row 2 is consumed, row rh := row rh-2 when row rh+1 is): as run-time tests in the only copy they cost eight 64-bit moves per row.
+    template <int MODE>
+    __device__ __forceinline__ void chunk(unsigned int (&pix)[FE_CH], int y_last /* last image row of the run */, const uint8_t *img,
+                                          int base /* the lane's column offset */, int pitch, int ry, int h, unsigned int uc, int y0, int rh, int rw,
+                                          unsigned int sel, float s, bool nms_col, int lane, int roi, int xcol, int32_t *cand_cnt,
+                                          unsigned long long *cbase) {
+        typedef unsigned int __attribute__((aligned(1))) u32u;
+#pragma unroll
+        for (int i = 0; i < FE_CH; i++) {
+            const int y = y0 + i; // wave-uniform
+            // the lane's three pixels as bytes 0, 1, 2 (one v_perm with the lane's selector; the byte operands below are SDWA selects)
+            const unsigned int v = __builtin_amdgcn_perm(0u, pix[i], sel);
+            // the register is free: the same row of the NEXT chunk goes into it now and has FE_CH - 1 rows of arithmetic to arrive
+            {   // (wave-uniform row base + per-lane 32-bit column offset; past the run's last row the last row again: no branch, a cache hit)
+                const uint8_t *rowp = img + (size_t) icg_reflect1(min(max(ry + min(y + FE_CH, y_last), -1), h), h) * pitch;
+                unsigned int vb = (unsigned int) base;
+                asm("" : "+v"(vb)); // (opaque per row: hoisted out of the loop, img + base becomes a 64-bit address per lane and every row a 64-bit mad)
+                pix[i] = *reinterpret_cast<const u32u *>(rowp + vb);
+            }
+            const int a3 = (int) (v & 0xffu), b3 = (int) ((v >> 8) & 0xffu), c3 = (int) ((v >> 16) & 0xffu);
+            const int dN = c3 - a3, sN = a3 + 2 * b3 + c3;
+            if (MODE != FE_PRIME || i >= 2) {
+                const int gxv = d0 + 2 * d1 + dN, gyv = sN - s0;
+                const float dx = (float) gxv * s, dy = (float) gyv * s;
+                const float cx = dx * dx, cm = dx * dy, cy = dy * dy;
+                double hAn = ((double) from_left(cx) + (double) cx) + (double) from_right(cx);
+                double hBn = ((double) from_left(cm) + (double) cm) + (double) from_right(cm);
+                double hCn = ((double) from_left(cy) + (double) cy) + (double) from_right(cy);
+                if (MODE != FE_PRIME) {
+                    double tA = hA0, tB = hB0, tC = hC0;
+                    if (MODE == FE_MIRRORS) {
+                        if (y - 1 == rh) { // product row rh := row rh-2 (wave-uniform: a real branch)
+                            asm volatile("");
+                            hAn = hA0, hBn = hB0, hCn = hC0;
+                        }
+                        if (y == 2) { // product row -1 := row 1 (the first response row of the ROI)
+                            asm volatile("");
+                            tA = hAn, tB = hBn, tC = hCn;
+                        }
+                    }
+                    const double sa = (tA + hA1) + hAn, sb = (tB + hB1) + hBn, sc = (tC + hC1) + hCn;
+                    const float fa = (float) sa * 0.5f, fb = (float) sb, fc = (float) sc * 0.5f;
+                    // (the argument: fa, fc, fb are multiples of 2^-48, so it is zero or at least 2^-96 — icg_sqrt_unscaled's domain)
+                    const float e  = (fa + fc) - icg_sqrt_unscaled((fa - fc) * (fa - fc) + fb * fb);
+                    const bool unm = (uc >> i) & 1u;
+                    emax           = fmaxf(emax, unm ? e : -INFINITY);
+                    const float el = from_left(e), er = from_right(e);
+                    const float side = fe_max(el, er), m3 = fe_max(side, e);
+                    {
+                        // NMS: centre = response row y - 3
+                        const int yc = y - 3;
+                        const bool is_cand = (yc >= 1 && yc < rh - 1) && nms_col && unmC && eC != 0.f && eC >= fmaxf(fmaxf(m3T, sideC), m3);
+                        // wave-aggregated append: one atomic per wavefront and row
+                        const unsigned long long m = __ballot(is_cand);
+                        if (m != 0) {
+                            int slot0 = 0;
+                            const int leader = __ffsll((long long) m) - 1;
+                            if (lane == leader) slot0 = atomicAdd(&cand_cnt[roi], __popcll(m));
+                            slot0 = __shfl(slot0, leader, 64);
+                            if (is_cand)
+                                cbase[slot0 + __popcll(m & ((1ull << lane) - 1ull))] =
+                                    ((unsigned long long) f32_order_key(eC) << 32) | (unsigned int) (yc * rw + xcol);
+                        }
+                    }
+                    m3T   = m3C;
+                    m3C   = m3;
+                    eC    = e;
+                    sideC = side;
+                    unmC  = unm;
+                }
+                hA0 = hA1, hA1 = hAn;
+                hB0 = hB1, hB1 = hBn;
+                hC0 = hC1, hC1 = hCn;
+            }
+            d0 = d1, d1 = dN;
+            s0 = s1, s1 = sN;
+        }
+    }
+};
+__device__ __forceinline__ void fe_block(const int bl, const int *vh, const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
+                                         const int32_t *slots, int pitch, int w, int h, const float2 *mask_pts, const int32_t *mask_begin,
+                                         const int32_t *mask_cnt, int radius, unsigned int *roi_max, unsigned long long *cand, size_t cand_plane,
+                                         int32_t *cand_cnt, int gx, int gy, unsigned int m_roi, unsigned int m_gx) {
     const int roi = icg_div_by_magic(bl, m_roi), rem = bl - roi * (gx * gy);
     const int by = icg_div_by_magic(rem, m_gx), bx = rem - by * gx;
     const det_roi R = rois[roi];
     if (R.quota <= 0) return; // inactive entry of a dense (job, block) table (device-resident tracker); wave-uniform
     const int lane = threadIdx.x & 63;
-    const int tx0 = bx * FE_TW, ty0 = (by * FE_WAVES + wv) * FE_TH;
-    if (tx0 >= R.rw || ty0 >= R.rh) return; // wave-uniform
+    const int tx0 = bx * FE_TW, by0 = by * (FE_TH * FE_WAVES);
+    if (tx0 >= R.rw || by0 >= R.rh) return; // wave-uniform
     const uint8_t *img = frames + (size_t) slots[R.job] * slot_bytes;
     const float s      = (float) (1.0 / 3060.0);
 
@@ -98,20 +220,20 @@ __device__ __forceinline__ void fe_tile(const int bl, const int wv, const int *v
     const int X    = R.rx + icg_reflect1(min(max(xcol, -1), R.rw), R.rw);
     const int ca = icg_reflect1(X - 1, w), cc = icg_reflect1(X + 1, w);
     const int base = min(max(X - 1, 0), w - 4);
-    const unsigned int sha = 8u * (unsigned int) (ca - base), shb = 8u * (unsigned int) (X - base), shc = 8u * (unsigned int) (cc - base);
-    const bool own_col  = lane >= 2 && lane <= FE_TW + 1 && xcol < R.rw;   // columns whose responses this tile owns
+    const unsigned int sel = 0x0c000000u | (unsigned int) (ca - base) | ((unsigned int) (X - base) << 8) | ((unsigned int) (cc - base) << 16); // v_perm selector
+    const bool own_col  = lane >= 2 && lane <= FE_TW + 1 && xcol < R.rw;   // columns whose responses this block owns
     const bool nms_col  = own_col && xcol >= 1 && xcol < R.rw - 1;
     const int mx        = R.rx + xcol; // image column of the lane
     unsigned long long *cbase = cand + (size_t) R.job * cand_plane + R.cand_base;
 
-    // the mask first: existing features blank discs of radius min_dist, which cover most of a tracked image — a tile whose owned pixels
-    // are ALL masked can neither raise the ROI maximum nor produce a candidate and leaves before any image byte is read
-    unsigned int unmasked = 0; // bit k: the owned response of tile row k is not masked
+    // ---- 1. the mask: existing features blank discs of radius min_dist, which cover most of a tracked image ----
+    const int rows = min(R.rh - by0, FE_TH * FE_WAVES); // block rows inside the ROI (>= 1 here)
+    const unsigned long long rowset = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
+    unsigned long long unmasked = own_col ? rowset : 0ull; // bit k: the owned response of block row k is not masked
     {
-        const int ytop = R.ry + ty0;                          // image row of tile row 0
+        const int ytop = R.ry + by0;                          // image row of block row 0
         const int xl = R.rx + tx0, xr = xl + FE_TW - 1;        // image columns of the owned lanes
         const int p0 = mask_begin[R.job], p1 = p0 + mask_cnt[R.job];
-        unsigned int masked = 0;
         for (int pb = p0; pb < p1; pb += 64) {
             const int i = pb + lane;
             int cx = 0, cy = 0;
@@ -120,7 +242,7 @@ __device__ __forceinline__ void fe_tile(const int bl, const int wv, const int *v
                 const float2 p = mask_pts[i];
                 cx  = (int) rintf(p.x); // cvRound of the key point (tracking.cc:613, 618)
                 cy  = (int) rintf(p.y);
-                hit = cx + radius >= xl && cx - radius <= xr && cy + radius >= ytop && cy - radius <= ytop + FE_TH - 1;
+                hit = cx + radius >= xl && cx - radius <= xr && cy + radius >= ytop && cy - radius <= ytop + rows - 1;
             }
             unsigned long long m = __ballot(hit);
             while (m) { // wave-uniform
@@ -129,96 +251,62 @@ __device__ __forceinline__ void fe_tile(const int bl, const int wv, const int *v
                 const int ccx = __builtin_amdgcn_readlane(cx, l), ccy = __builtin_amdgcn_readlane(cy, l);
                 const int adx = abs(mx - ccx);
                 const int v   = vh[min(adx, radius + 1)]; // rows |y - ccy| <= v of this column are inside the disc (-1: none)
-                const int lo = max(ccy - v - ytop, 0), hi = min(ccy + v - ytop, FE_TH - 1);
-                if (v >= 0 && lo <= hi) masked |= ((2u << hi) - 1u) & ~((1u << lo) - 1u);
+                const int lo = max(ccy - v - ytop, 0), hi = min(ccy + v - ytop, 63);
+                if (v >= 0 && lo <= hi) unmasked &= ~(((2ull << hi) - 1ull) & ~((1ull << lo) - 1ull));
             }
+            if (__ballot(unmasked != 0ull) == 0) return; // every owned pixel is masked: no maximum to raise, no candidate (wave-uniform)
         }
-        const int rows  = min(R.rh - ty0, FE_TH); // tile rows inside the ROI (>= 1 here)
-        unmasked        = ~masked & ((1u << rows) - 1u);
-        if (!own_col) unmasked = 0;
     }
-    if (__ballot(unmasked != 0) == 0) return; // wave-uniform
-    // all image loads of the tile are issued up front (22 dwords per lane in flight together): the streaming loop runs from registers
+    // ---- 2. the rows somebody needs (wave-wide OR of the lanes' sets, both halves through one DPP tree each) ----
+    unsigned long long need;
+    {
+        unsigned int lo = (unsigned int) unmasked, hi = (unsigned int) (unmasked >> 32);
+        lo = wave_or_to_lane63(lo);
+        hi = wave_or_to_lane63(hi);
+        need = ((unsigned long long) (unsigned int) __builtin_amdgcn_readlane((int) hi, 63) << 32) | (unsigned int) __builtin_amdgcn_readlane((int) lo, 63);
+    }
+    if (need == 0ull) return;
     typedef unsigned int __attribute__((aligned(1))) u32u;
-    unsigned int pix[FE_TH + 6];
+    float emax = -INFINITY;
+    while (need) { // wave-uniform: one run of rows per pass
+        const int a = __ffsll((long long) need) - 1;
+        // close gaps of up to FE_GAP rows above every needed row, take the run of the closed set that starts at a, then its last NEEDED row
+        unsigned long long closed = need;
 #pragma unroll
-    for (int t = 0; t < FE_TH + 6; t++) {
-        // image row R.ry + ty0 - 3 + t (rows further than one past the image only feed partial tiles)
-        const int Yr        = icg_reflect1(min(max(R.ry + ty0 - 3 + t, -1), h), h);
-        const uint8_t *rowp = img + (size_t) Yr * pitch; // wave-uniform row base + per-lane 32-bit column offset
-        pix[t]              = *reinterpret_cast<const u32u *>(rowp + base);
-    }
-    int d0 = 0, d1 = 0, s0 = 0, s1 = 0;                                    // Sobel differences of image rows t-2, t-1
-    double hA0 = 0, hA1 = 0, hB0 = 0, hB1 = 0, hC0 = 0, hC1 = 0;           // horizontal 3-sums of product rows r-2, r-1
-    float eC = 0.f, sideC = 0.f, m3T = 0.f, m3C = 0.f;                     // response rows q-1 (centre) and q-2 (top)
-    bool unmC = false;
-    unsigned int key = 0;
+        for (int g = 1; g <= FE_GAP; g++) closed |= need << g;
+        const unsigned long long from_a = closed >> a;
+        const int len                   = (~from_a == 0ull) ? 64 : __ffsll((long long) ~from_a) - 1; // rows a .. a+len-1 of the closed set
+        const unsigned long long runset = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << a;
+        const unsigned long long inrun  = need & runset;
+        const int b                     = 63 - __builtin_clzll(inrun);
+        need &= ~runset;
+        // the lane's unmasked rows of this run, aligned so that bit t belongs to the response row of streamed row t
+        // (streamed row t = ROI row by0 + a - 3 + t carries response row by0 + a - 5 + t: block row a at t = 5)
+        const unsigned long long urun = (unmasked & inrun) >> a;
+        const int y_first = by0 + a - 3, n_rows = b - a + 7;
+
+        fe_rows st;
+        st.emax = emax;
+        unsigned int pix[FE_CH];
 #pragma unroll
-    for (int t = 0; t < FE_TH + 6; t++) {
-        const unsigned int v = pix[t];
-        const int a = (int) ((v >> sha) & 0xffu), b = (int) ((v >> shb) & 0xffu), c = (int) ((v >> shc) & 0xffu);
-        const int dN = c - a, sN = a + 2 * b + c;
-        if (t >= 2) {
-            // product row ty0 - 2 + (t-2)
-            const int gxv = d0 + 2 * d1 + dN, gyv = sN - s0;
-            const float dx = (float) gxv * s, dy = (float) gyv * s;
-            const float cx = dx * dx, cm = dx * dy, cy = dy * dy;
-            double hAn = ((double) from_left(cx) + (double) cx) + (double) from_right(cx);
-            double hBn = ((double) from_left(cm) + (double) cm) + (double) from_right(cm);
-            double hCn = ((double) from_left(cy) + (double) cy) + (double) from_right(cy);
-            if (ty0 - 4 + t == R.rh) { // product row rh := row rh-2 (wave-uniform, at most once per tile: a real branch)
-                asm volatile("");
-                hAn = hA0, hBn = hB0, hCn = hC0;
-            }
-            if (t >= 4) {
-                // response row q = t-4; the window is the product rows above, at and below it = (h?0, h?1, h?n)
-                const int q = t - 4; // ROI row ty0 - 1 + q
-                double tA = hA0, tB = hB0, tC = hC0;
-                if (q == 1 && ty0 == 0) { // product row -1 := row 1 (only the first response row of the first tile row)
-                    asm volatile("");
-                    tA = hAn, tB = hBn, tC = hCn;
-                }
-                const double sa = (tA + hA1) + hAn, sb = (tB + hB1) + hBn, sc = (tC + hC1) + hCn;
-                const float fa = (float) sa * 0.5f, fb = (float) sb, fc = (float) sc * 0.5f;
-                const float e = (fa + fc) - sqrtf((fa - fc) * (fa - fc) + fb * fb);
-                bool unm = false;
-                if (q >= 1 && q <= FE_TH) { // the response rows this tile owns
-                    unm                   = (unmasked >> (q - 1)) & 1u;
-                    const unsigned int ke = unm ? f32_order_key(e) : 0u;
-                    key                   = ke > key ? ke : key;
-                }
-                const float el = from_left(e), er = from_right(e);
-                const float side = fmaxf(el, er), m3 = fmaxf(side, e);
-                if (t >= 6) {
-                    // NMS row k = t-6: centre = response row q-1 at ROI row y
-                    const int y = ty0 + (t - 6);
-                    const bool is_cand = (y >= 1 && y < R.rh - 1) && nms_col && unmC && eC != 0.f &&
-                                         eC >= fmaxf(fmaxf(m3T, sideC), m3);
-                    // wave-aggregated append: one atomic per wavefront and row
-                    const unsigned long long m = __ballot(is_cand);
-                    if (m != 0) {
-                        int slot0 = 0;
-                        const int leader = __ffsll((long long) m) - 1;
-                        if (lane == leader) slot0 = atomicAdd(&cand_cnt[roi], __popcll(m));
-                        slot0 = __shfl(slot0, leader, 64);
-                        if (is_cand)
-                            cbase[slot0 + __popcll(m & ((1ull << lane) - 1ull))] =
-                                ((unsigned long long) f32_order_key(eC) << 32) | (unsigned int) (y * R.rw + xcol);
-                    }
-                }
-                m3T   = m3C;
-                m3C   = m3;
-                eC    = e;
-                sideC = side;
-                unmC  = unm;
-            }
-            hA0 = hA1, hA1 = hAn;
-            hB0 = hB1, hB1 = hBn;
-            hC0 = hC1, hC1 = hCn;
+        for (int i = 0; i < FE_CH; i++) { // image row R.ry + y (rows further than one past the image only feed rows nobody reads)
+            const uint8_t *rowp = img + (size_t) icg_reflect1(min(max(R.ry + y_first + i, -1), h), h) * pitch; // wave-uniform
+            pix[i] = *reinterpret_cast<const u32u *>(rowp + (unsigned int) base);
         }
-        d0 = d1, d1 = dN;
-        s0 = s1, s1 = sN;
+        const int y_last = y_first + n_rows - 1;
+        st.chunk<FE_PRIME>(pix, y_last, img, base, pitch, R.ry, h, 0u, y_first, R.rh, R.rw, sel, s, nms_col, lane, roi, xcol, cand_cnt, cbase);
+        for (int t0 = FE_CH; t0 < n_rows; t0 += FE_CH) { // wave-uniform
+            // bits t0-5 .. of urun: the unmasked flags of the response rows of this chunk
+            const unsigned int uc = t0 >= 5 ? (unsigned int) (urun >> (t0 - 5)) : (unsigned int) urun << (5 - t0);
+            const int y0 = y_first + t0; // ROI row of the chunk's first image row
+            if ((y0 <= 2 && 2 < y0 + FE_CH) || (y0 <= R.rh + 1 && R.rh + 1 < y0 + FE_CH))
+                st.chunk<FE_MIRRORS>(pix, y_last, img, base, pitch, R.ry, h, uc, y0, R.rh, R.rw, sel, s, nms_col, lane, roi, xcol, cand_cnt, cbase);
+            else
+                st.chunk<FE_PLAIN>(pix, y_last, img, base, pitch, R.ry, h, uc, y0, R.rh, R.rw, sel, s, nms_col, lane, roi, xcol, cand_cnt, cbase);
+        }
+        emax = st.emax;
     }
+    unsigned int key = emax == -INFINITY ? 0u : f32_order_key(emax); // (no unmasked owned pixel met: nothing to report)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const unsigned int o = __shfl_xor(key, m, 64);
@@ -227,12 +315,12 @@ __device__ __forceinline__ void fe_tile(const int bl, const int wv, const int *v
     if (lane == 0 && key) atomicMax(&roi_max[roi], key);
 }
 
-// RESIDENT waves (round 6): rounds 2-5 launched one workgroup per block of four tiles — 55 k workgroups per launch of 192 frames, 72 % of
-// whose waves leave after the mask test.  Here a fixed number of workgroups walks the ROI-major tile grid: workgroup b belongs to XCD
-// b & 7 (the dispatcher's round-robin) and takes blocks j, j + G, j + 2 G, ... of that XCD's contiguous eighth of the grid
-// (icg_xcd_chunked's partition: the tiles of a ROI and of a frame keep sharing one L2), wave wv the block's tile wv; the span table is
-// staged once per workgroup.  (A dynamic form — every wave pulling tiles from a per-XCD counter — was measured first: 221 k atomics on eight
-// addresses serialise in L2, 3.1 ms per launch against 0.27-0.45: profiles/r06_detector_resident_waves.txt.)
+// One wave per block; a workgroup of FE_WAVES waves takes FE_WAVES consecutive blocks of the ROI-major block grid (neighbours in a block
+// row: they share image rows and the job's disc list in L2).  At most 8 x FE_RESIDENT_PER_XCD workgroups are launched: workgroup b belongs
+// to XCD b & 7 (the dispatcher's round-robin) and walks that XCD's contiguous eighth of the grid (icg_xcd_chunked's partition) at a fixed
+// stride.  (Rounds 2-5: one workgroup per block, a wave per 60 x 16 tile — 221 k waves per launch of 192 frames, 72 % of which left after
+// the mask test.  A dynamic form — every wave pulling tiles from a per-XCD counter — was measured too: 221 k atomics on eight addresses
+// serialise in L2, 3.1 ms per launch against 0.27-0.45: profiles/r06_detector_resident_waves.txt.)
 __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
                                                                const int32_t *slots, int pitch, int w, int h, const float2 *mask_pts,
                                                                const int32_t *mask_begin, const int32_t *mask_cnt /* per job */, int radius,
@@ -244,13 +332,17 @@ __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *ro
     __shared__ int vh[FE_MAX_RADIUS + 2];
     for (int a = threadIdx.x; a < radius + 2; a += 64 * FE_WAVES) vh[a] = vspan[a];
     __syncthreads();
-    const int chunk = (n_blocks + 7) >> 3;                       // blocks per XCD range
+    const int n_items = (n_blocks + FE_WAVES - 1) / FE_WAVES;    // groups of FE_WAVES blocks
+    const int chunk   = (n_items + 7) >> 3;                      // items per XCD range
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3, G = gridDim.x >> 3; // (the grid is a multiple of 8)
     const int wv  = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // wave-uniform by construction: keep it in an SGPR
-    const int end = min((x + 1) * chunk, n_blocks);
-    for (int bl = x * chunk + j; bl < end; bl += G)
-        fe_tile(bl, wv, vh, rois, frames, slot_bytes, slots, pitch, w, h, mask_pts, mask_begin, mask_cnt, radius, roi_max, cand, cand_plane, cand_cnt, gx, gy,
-                m_roi, m_gx);
+    const int end = min((x + 1) * chunk, n_items);
+    for (int it = x * chunk + j; it < end; it += G) {
+        const int bl = it * FE_WAVES + wv;
+        if (bl < n_blocks)
+            fe_block(bl, vh, rois, frames, slot_bytes, slots, pitch, w, h, mask_pts, mask_begin, mask_cnt, radius, roi_max, cand, cand_plane, cand_cnt, gx, gy,
+                     m_roi, m_gx);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -600,7 +692,7 @@ extern "C" int icg_detect(icg_ctx *ctx, int n, const int32_t *slots, const icg_d
     {
         icg_prof_scope ps(ctx, "detect_min_eig_nms");
         const int gx = (grid->block_w + FE_TW - 1) / FE_TW, gy = (grid->block_h + FE_TH * FE_WAVES - 1) / (FE_TH * FE_WAVES);
-        hipLaunchKernelGGL(k_min_eig_nms, dim3(std::min(icg_xcd_grid(gx * gy * n_roi), 8 * FE_RESIDENT_PER_XCD)), dim3(64 * FE_WAVES), 0, ctx->stream, d_rois, ctx->d_frames,
+        hipLaunchKernelGGL(k_min_eig_nms, dim3(std::min(icg_xcd_grid((gx * gy * n_roi + FE_WAVES - 1) / FE_WAVES), 8 * FE_RESIDENT_PER_XCD)), dim3(64 * FE_WAVES), 0, ctx->stream, d_rois, ctx->d_frames,
                            ctx->slot_bytes, d_slots, pitch, w, h, d_mpts, d_moff, d_mcnt, grid->min_dist, d_vh, d_rmax, ctx->d_cand, cand_plane, d_ccnt,
                            gx, gy, gx * gy * n_roi, icg_div_magic(gx * gy), icg_div_magic(gx));
     }
@@ -659,7 +751,7 @@ int icg_detect_launch_ind(icg_ctx *ctx, int n_jobs, const icg_detect_grid *grid,
     {
         icg_prof_scope ps(ctx, "detect_min_eig_nms");
         const int gx = (grid->block_w + FE_TW - 1) / FE_TW, gy = (grid->block_h + FE_TH * FE_WAVES - 1) / (FE_TH * FE_WAVES);
-        hipLaunchKernelGGL(k_min_eig_nms, dim3(std::min(icg_xcd_grid(gx * gy * n_roi), 8 * FE_RESIDENT_PER_XCD)), dim3(64 * FE_WAVES), 0, ctx->stream, (const det_roi *) d_rois, ctx->d_frames,
+        hipLaunchKernelGGL(k_min_eig_nms, dim3(std::min(icg_xcd_grid((gx * gy * n_roi + FE_WAVES - 1) / FE_WAVES), 8 * FE_RESIDENT_PER_XCD)), dim3(64 * FE_WAVES), 0, ctx->stream, (const det_roi *) d_rois, ctx->d_frames,
                            ctx->slot_bytes, d_slots, pitch, w, h, d_mask_pts, d_mask_begin, d_mask_cnt, grid->min_dist, d_vh, ctx->d_roi_max, ctx->d_cand,
                            cand_plane, ctx->d_cand_cnt, gx, gy, gx * gy * n_roi, icg_div_magic(gx * gy), icg_div_magic(gx));
     }

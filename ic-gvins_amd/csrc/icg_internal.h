@@ -200,6 +200,20 @@ static inline unsigned int icg_div_magic(int d) { return (unsigned int) ((0x1000
 __device__ static inline int icg_div_by_magic(int b, unsigned int magic) { return (int) __umulhi((unsigned int) b, magic); }
 #endif
 
+#ifdef __HIPCC__
+// sqrtf for x = 0 or x >= 2^-96 (no denormal argument or result): v_sqrt_f32 and the two residual tests of the compiler's own expansion of
+// sqrtf — candidates r - 1 ulp, r, r + 1 ulp by the signs of the fused residuals x - c r — without the range scaling in front of it and behind
+// it (5 of its 16 instructions).  Correctly rounded like the library's; the callers state why their argument is never a small non-zero value.
+// (x = 0: r = 0, the pattern below it is a NaN whose test is false, the residual of the one above it is 0: the result is 0.)
+__device__ static inline float icg_sqrt_unscaled(float x) {
+    const float r  = __builtin_amdgcn_sqrtf(x);
+    const float rm = __uint_as_float(__float_as_uint(r) - 1u), rp = __uint_as_float(__float_as_uint(r) + 1u);
+    float q        = __builtin_fmaf(-rm, r, x) <= 0.f ? rm : r;
+    q              = __builtin_fmaf(-rp, r, x) > 0.f ? rp : q;
+    return q;
+}
+#endif
+
 // single reflection, branch-free: valid for -n < i < 2n-1 (all stencil halos here overshoot by a few pixels at most)
 __host__ __device__ static inline int icg_reflect1(int i, int n) {
     i = i < 0 ? -i : i;

@@ -131,6 +131,28 @@ __device__ __forceinline__ void wave_sum2_i32x16_f32(int v1, int v2, float &f1, 
     wave_sum2_finish_f32(hi, lo, f1, f2);
 }
 
+// THREE exact wave-wide sums from ONE reduction tree (round 6): after v_permlane32_swap has put v1 | v2 and v3 | 0 side by side,
+// v_permlane16_swap (gfx950) interleaves the two registers by rows of 16 lanes — row 0 carries v1, row 1 v3, row 2 v2 — and the four DPP
+// stages that are left work on all of them at once; every lane of a row ends with the total of its row.  20 instructions for the three
+// window sums of the level set-up (were 31).  |per-lane partial| <= 2^27: sums of 16 lanes fit in int32.
+__device__ __forceinline__ void wave_sum3_i32x16_f32(int v1, int v2, int v3, float &f1, float &f2, float &f3) {
+    const int x       = lk_fold32(v1, v2); // lanes 0..31: 2-lane sums of v1, lanes 32..63: of v2
+    const int y       = lk_fold32(v3, 0);  // lanes 0..31: 2-lane sums of v3, lanes 32..63: 0
+    const lk_u2 r     = __builtin_amdgcn_permlane16_swap((unsigned int) x, (unsigned int) y, false, false); // odd rows of x <-> even rows of y
+    int v             = (int) (r.x + r.y); // rows: v1, v3, v2, 0 (4-lane sums)
+    v                 = dpp_add_xor1(v);
+    v                 = dpp_add_xor2(v);   // 16-lane sums
+    int hi = v >> 16, lo = v & 0xffff;
+    hi                = dpp_add_half_mirror(hi);
+    lo                = dpp_add_half_mirror(lo);
+    hi                = dpp_add_mirror(hi);
+    lo                = dpp_add_mirror(lo);
+    const float t     = lk_combine_f32(hi, lo);
+    f1                = lk_readlane_f32(t, 0);
+    f3                = lk_readlane_f32(t, 16);
+    f2                = lk_readlane_f32(t, 32);
+}
+
 __device__ __forceinline__ int lk_descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
 
 // The Q14 weights as the packed pairs the blends consume, W0 = (w00, w01), W1 = (w10, w11) (round 5).  rint() by the magic constant: for
@@ -262,6 +284,10 @@ __device__ __forceinline__ int dot2_keep_s(unsigned int a, unsigned int b, int c
 __device__ __forceinline__ unsigned int pk_lo16(int a, int b) {
     return __builtin_amdgcn_perm((unsigned int) b, (unsigned int) a, 0x05040100u);
 }
+// (hi16(a), hi16(b)) as one packed register
+__device__ __forceinline__ unsigned int pk_hi16(int a, int b) {
+    return __builtin_amdgcn_perm((unsigned int) b, (unsigned int) a, 0x07060302u);
+}
 // the pair one 16-bit element further: (a.hi, b.lo)
 __device__ __forceinline__ unsigned int pk_shift(unsigned int a, unsigned int b) { return __builtin_amdgcn_alignbit(b, a, 16); }
 
@@ -297,8 +323,8 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
     const int lx0         = active ? (lane - ly * 3) * 7 : 0;
     const unsigned int am = active ? ~0u : 0u; // lane 63 owns no pixels: its derivative weights are zeroed (Ix = Iy = 0 -> no contribution to any sum)
     // rounding constants of the set-up's blends, kept in scalar registers for dot2_keep_s (opaque to the optimizer: not re-materialised per use)
-    int rnd13 = 1 << 13, rnd8 = 1 << 8;
-    asm volatile("" : "+s"(rnd13), "+s"(rnd8));
+    int rnd15 = 1 << 15, rnd8 = 1 << 8;
+    asm volatile("" : "+s"(rnd15), "+s"(rnd8));
 
     for (int level = maxLevel; level >= 0; --level) {
         const int W = P.w[level], H = P.h[level], pitch = P.pitch[level];
@@ -359,17 +385,19 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
         {
             const int idx = lx0 >> 2, sh = lx0 & 3;
             unsigned int Pp[4][5]; // pixel pairs (col 2m, 2m+1) of tile rows ly..ly+3, cols lx0..lx0+9
+            // pair m = bytes sh + 2m, sh + 2m + 1 of the row's four dwords: for every sh in 0..3 it lies inside ONE pair of adjacent dwords that
+            // does not depend on sh — (d1:d0) for m = 0, 1, (d2:d1) for m = 2, 3, (d3:d2) for m = 4 — so v_perm takes it straight from the
+            // loaded dwords with two per-lane selectors (round 6: the three v_alignbyte per row that normalised the row first are gone)
+            const unsigned int sel0 = 0x0c000c00u | (unsigned int) sh | ((unsigned int) (sh + 1) << 16), sel1 = sel0 + 0x00020002u;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const unsigned int *p = &S.I[((ly + r) * LK_IS >> 2) + idx];
                 const unsigned int d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-                const unsigned int b0 = __builtin_amdgcn_alignbyte(d1, d0, sh), b1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-                const unsigned int b2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-                Pp[r][0] = __builtin_amdgcn_perm(0u, b0, 0x0c010c00u);
-                Pp[r][1] = __builtin_amdgcn_perm(0u, b0, 0x0c030c02u);
-                Pp[r][2] = __builtin_amdgcn_perm(0u, b1, 0x0c010c00u);
-                Pp[r][3] = __builtin_amdgcn_perm(0u, b1, 0x0c030c02u);
-                Pp[r][4] = __builtin_amdgcn_perm(0u, b2, 0x0c010c00u);
+                Pp[r][0] = __builtin_amdgcn_perm(d1, d0, sel0);
+                Pp[r][1] = __builtin_amdgcn_perm(d1, d0, sel1);
+                Pp[r][2] = __builtin_amdgcn_perm(d2, d1, sel0);
+                Pp[r][3] = __builtin_amdgcn_perm(d2, d1, sel1);
+                Pp[r][4] = __builtin_amdgcn_perm(d3, d2, sel0);
             }
             // derivative at support position (c = lx0+j, r = ly+rr): 3x3 neighbourhood = tile rows rr..rr+2, cols j..j+2.
             // The derivative plane is ZERO outside the image: X = ipx+lx0+j in [0,W), Y = ipy+ly+rr in [0,H).
@@ -380,13 +408,13 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                 unsigned int T0[5], T1[5];
 #pragma unroll
                 for (int m = 0; m < 5; m++) {
-                    T0[m] = pk_add(pk_mul(pk_add(Pp[rr][m], Pp[rr + 2][m]), 3), pk_mul(Pp[rr + 1][m], 10)); // 3*(p0+p2) + 10*p1
+                    T0[m] = pk_add(pk_mul(pk_add(Pp[rr][m], Pp[rr + 2][m]), 12), pk_mul(Pp[rr + 1][m], 40)); // 4 * (3*(p0+p2) + 10*p1)
                     T1[m] = pk_sub(Pp[rr + 2][m], Pp[rr][m]);                                                // p2 - p0
                 }
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    DX[rr][m] = pk_sub(T0[m + 1], T0[m]);                                                       // t0[j+2] - t0[j]
-                    DY[rr][m] = pk_add(pk_mul(pk_add(T1[m], T1[m + 1]), 3), pk_mul(pk_shift(T1[m], T1[m + 1]), 10)); // 3*(t1[j]+t1[j+2]) + 10*t1[j+1]
+                    DX[rr][m] = pk_sub(T0[m + 1], T0[m]);                                                       // 4 * (t0[j+2] - t0[j])
+                    DY[rr][m] = pk_add(pk_mul(pk_add(T1[m], T1[m + 1]), 12), pk_mul(pk_shift(T1[m], T1[m + 1]), 40)); // 4 * (3*(t1[j]+t1[j+2]) + 10*t1[j+1])
                 }
             }
             if (!all_in) { // windows that reach over the image border: a real (wave-uniform) branch — written as masks on the common path the
@@ -405,8 +433,10 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                     }
                 }
             }
-            int ix[7], iy[7];
-            const unsigned int W0d = W0 & am, W1d = W1 & am; // (lane 63: (0 + 2^13) >> 14 = 0)
+            // The Scharr terms above carry a factor 4 (12, 40 for 3, 10: |4 d| <= 16 320 still fits 16 bits), so the blended derivative
+            // (sum w d + 2^13) >> 14 is the HIGH half of sum w (4 d) + 2^15: one v_perm packs two of them, no shift (round 6: 14 shifts per level).
+            int bx[7], by[7];
+            const unsigned int W0d = W0 & am, W1d = W1 & am; // (lane 63: (0 + 2^15) >> 16 = 0)
 #pragma unroll
             for (int k = 0; k < 7; k++) {
                 const int m = k >> 1;
@@ -418,26 +448,30 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                 const int m1 = (k + 1) >> 1;
                 const unsigned int i1 = ((k + 1) & 1) ? pk_shift(Pp[1][m1], Pp[1][m1 + 1]) : Pp[1][m1];
                 const unsigned int i2 = ((k + 1) & 1) ? pk_shift(Pp[2][m1], Pp[2][m1 + 1]) : Pp[2][m1];
-                ix[k]        = dot2(dx1, W1d, dot2_keep_s(dx0, W0d, rnd13)) >> 14;
-                iy[k]        = dot2(dy1, W1d, dot2_keep_s(dy0, W0d, rnd13)) >> 14;
-                const int iv = dot2(i2, W1, dot2_keep_s(i1, W0, rnd8)) >> 9;
-                c0[k]        = 256 - 512 * iv;
+                bx[k]        = dot2(dx1, W1d, dot2_keep_s(dx0, W0d, rnd15));
+                by[k]        = dot2(dy1, W1d, dot2_keep_s(dy0, W0d, rnd15));
+                // c0 = 256 - 512 * ((blend + 256) >> 9) = 256 - ((blend + 256) & ~511)
+                c0[k]        = 256 - (dot2(i2, W1, dot2_keep_s(i1, W0, rnd8)) & ~511);
             }
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                IXP[m] = pk_lo16(ix[2 * m], m < 3 ? ix[2 * m + 1] : 0);
-                IYP[m] = pk_lo16(iy[2 * m], m < 3 ? iy[2 * m + 1] : 0);
+                IXP[m] = m < 3 ? pk_hi16(bx[2 * m], bx[2 * m + 1]) : (unsigned int) bx[6] >> 16;
+                IYP[m] = m < 3 ? pk_hi16(by[2 * m], by[2 * m + 1]) : (unsigned int) by[6] >> 16;
             }
             sA11 = dot2(IXP[3], IXP[3], dot2(IXP[2], IXP[2], dot2(IXP[1], IXP[1], dot2(IXP[0], IXP[0], 0))));
             sA12 = dot2(IXP[3], IYP[3], dot2(IXP[2], IYP[2], dot2(IXP[1], IYP[1], dot2(IXP[0], IYP[0], 0))));
             sA22 = dot2(IYP[3], IYP[3], dot2(IYP[2], IYP[2], dot2(IYP[1], IYP[1], dot2(IYP[0], IYP[0], 0))));
-            wave_sum2_i32x16_f32(sA11, sA12, A11, A12);
-            A11 *= FLT_SCALE, A12 *= FLT_SCALE;
-            A22 = wave_sum_i32x16_f32(sA22) * FLT_SCALE;
+            wave_sum3_i32x16_f32(sA11, sA12, sA22, A11, A12, A22);
+            A11 *= FLT_SCALE, A12 *= FLT_SCALE, A22 *= FLT_SCALE;
         }
         float D            = A11 * A22 - A12 * A12;
-        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float) (2 * ICG_LK_WIN * ICG_LK_WIN);
-        const bool weak    = minEig < 1e-4f || D < FLT_EPSILON;
+        // (the argument of the root: A = n 2^-20 rounded to 24 bits, so a difference is zero or at least 2^-20 — zero or >= 2^-40, icg_sqrt_unscaled's domain)
+        const float eig2 = A22 + A11 - icg_sqrt_unscaled((A11 - A22) * (A11 - A22) + 4.f * A12 * A12);
+        // minEig = eig2 / (2 * 21 * 21) < 1e-4f, without the division (round 6: ten instructions per level): a correctly rounded quotient is
+        // non-decreasing in its numerator, so the test is eig2 < T with T the smallest float whose quotient by 882 reaches 1e-4f —
+        // T = 0x3DB4A233 (0.088199995; fl(T / 882) = 1e-4f, fl(pred(T) / 882) = 9.999998e-5: searched over the floats around 0.0882)
+        static_assert(ICG_LK_WIN == 21, "the threshold constant below is for a 21 x 21 window");
+        const bool weak = eig2 < __uint_as_float(0x3DB4A233u) || D < FLT_EPSILON;
         if (weak) {
             if (level == 0) status = false;
             continue;
@@ -583,7 +617,7 @@ __global__ __launch_bounds__(64) void k_lk_track(icg_pyr_desc P, int n, const in
 __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_desc P, int n, const int32_t *prev_slot,
                                                     const int32_t *next_slot, const float2 *prev_pts,
                                                     const float2 *guess_pts, float2 *out_pts, unsigned char *status,
-                                                    int has_cam, icg_camera cam, float2 *out_undist, int img_w, int img_h,
+                                                    float2 *out_bwd, int img_w, int img_h,
                                                     int seg_cap, const int32_t *seg_count) {
     __shared__ lk_smem S;
     const int i = icg_xcd_chunked(blockIdx.x, n);
@@ -605,8 +639,9 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_des
     for (int dir = 0; dir < 2; dir++) {
         if (dir) {
             // the cull of tracking.cc:396-403 needs the backward track only for points that are still alive
-            const bool border = (double) fwd.x < 5.0 || (double) fwd.y < 5.0 || ((double) fwd.x > (img_w - 5.0)) ||
-                                ((double) fwd.y > (img_h - 5.0));
+            // (isOnBorder compares in double: (double) f < 5.0 <=> f < 5.0f and (double) f > w - 5.0 <=> f > (float) (w - 5) for a float f and
+            // an image narrower than 2^24 — the float form keeps two FP64 constants out of the registers for the whole forward pass)
+            const bool border = fwd.x < 5.f || fwd.y < 5.f || fwd.x > (float) (img_w - 5) || fwd.y > (float) (img_h - 5);
             if (!st_f || border) break; // wave-uniform
         }
         const unsigned char *a = dir ? sN : sP, *b = dir ? sP : sN;
@@ -621,25 +656,35 @@ __global__ __launch_bounds__(64, LK_WAVES_PER_EU) void k_lk_track_fb(icg_pyr_des
             st_f = st;
         }
     }
-    {
-        // isOnBorder (tracking.cc:847-849) and ptsDistance (tracking.cc:841-845), then undistortPoints of the result.
-        // EVERY lane computes these (uniform) values and lane 0 stores them: conversions, FP64 and every other half-rate VALU instruction
-        // take ~5x longer when 16 lanes or fewer are active (measured on the MI355X, profiles/ubench/valu_cost_r05.txt: 1.7 -> 8.9 ns per
-        // wave-instruction) — under `if (lane == 0)` these ~320 instructions were 13 % of the kernel's time (round 5).
-        const bool border = (double) fwd.x < 5.0 || (double) fwd.y < 5.0 || ((double) fwd.x > (img_w - 5.0)) ||
-                            ((double) fwd.y > (img_h - 5.0));
-        const double ddx = (double) (bwd.x - p0.x), ddy = (double) (bwd.y - p0.y);
-        const double dist = sqrt(ddx * ddx + ddy * ddy);
-        unsigned int st = (st_f && st_b && !border && dist < 0.5) ? 1u : 0u;
-        float2 und      = fwd;
-        if (out_undist && has_cam) und = cam_undistort(cam, fwd); // wave-uniform
-        asm volatile("" : "+v"(st), "+v"(und.x), "+v"(und.y));   // (keeps the compiler from sinking the computation into the one-lane branch)
-        if (lane == 0) {
-            out_pts[i] = fwd;
-            status[i]  = (unsigned char) st;
-            if (out_undist) out_undist[i] = und;
-        }
+    // The verdict on the point — isOnBorder, ptsDistance, undistortPoints — is k_lk_finish's, a THREAD per point: as the tail of this kernel it
+    // was ~390 wave-instructions per point that every lane computed alike, most of them FP64 (five divisions of the undistortion's fixed-point
+    // iteration, a square root): 5.5 % of the kernel's vector instructions and more of its time (round 6).
+    if (lane == 0) {
+        out_pts[i] = fwd;
+        out_bwd[i] = bwd;
+        status[i]  = (unsigned char) ((st_f && st_b) ? 1u : 0u); // (the backward pass is skipped for a lost or border point: st_b stays false)
     }
+}
+
+// isOnBorder (tracking.cc:847-849) and ptsDistance (tracking.cc:841-845) on the forward / backward results of k_lk_track_fb, then
+// undistortPoints of the forward result; one thread per point.  bwd_undist holds the backward result on entry and, when the caller asked for
+// undistorted points, the undistorted point on exit (the segmented tracker passes its undistorted-point array; the C entry point a scratch
+// array or the caller's).
+__global__ __launch_bounds__(256) void k_lk_finish(int n, const float2 *prev_pts, const float2 *out_pts, float2 *bwd_undist, unsigned char *status,
+                                                   int want_undist, int has_cam, icg_camera cam, int img_w, int img_h, int seg_cap,
+                                                   const int32_t *seg_count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (seg_count) {
+        const int s = i / seg_cap;
+        if (i - s * seg_cap >= seg_count[s]) return;
+    }
+    const float2 p0 = prev_pts[i], fwd = out_pts[i], bwd = bwd_undist[i];
+    const bool border = (double) fwd.x < 5.0 || (double) fwd.y < 5.0 || ((double) fwd.x > (img_w - 5.0)) || ((double) fwd.y > (img_h - 5.0));
+    const double ddx = (double) (bwd.x - p0.x), ddy = (double) (bwd.y - p0.y);
+    const double dist = sqrt(ddx * ddx + ddy * ddy);
+    status[i] = (unsigned char) ((status[i] && !border && dist < 0.5) ? 1u : 0u);
+    if (want_undist) bwd_undist[i] = has_cam ? cam_undistort(cam, fwd) : fwd;
 }
 
 // order-preserving compaction indices (what reduceVector keeps, tracking.cc:831-839); single workgroup scan.
@@ -722,21 +767,27 @@ extern "C" int icg_lk_track_fb(icg_ctx *ctx, int n, const int32_t *prev_slot, co
     if (rc) return rc;
     ICG_HIP(ctx, hipSetDevice(ctx->cfg.device));
     icg_call c(ctx);
-    if ((rc = c.reserve((size_t) n * 96))) return rc;
+    if ((rc = c.reserve((size_t) n * 104))) return rc;
     const int32_t *d_ps = c.in_zc(prev_slot, (size_t) n);
     const int32_t *d_ns = c.in_zc(next_slot, (size_t) n);
     const float2 *d_pp  = (const float2 *) c.in_zc(prev_pts, 2 * (size_t) n);
     const float2 *d_gs  = (const float2 *) c.in_zc(guess_pts, 2 * (size_t) n);
     float2 *d_out       = (float2 *) c.out_zc(out_pts, 2 * (size_t) n);
     unsigned char *d_st = c.out_zc(status, (size_t) n);
-    float2 *d_und       = out_undist ? (float2 *) c.out_zc(out_undist, 2 * (size_t) n) : nullptr;
+    // (the backward results travel from k_lk_track_fb to k_lk_finish in the undistorted-point array, or in device scratch when none was asked for)
+    float2 *d_und       = out_undist ? (float2 *) c.out_zc(out_undist, 2 * (size_t) n) : (float2 *) c.out<float>(nullptr, 2 * (size_t) n);
     int32_t *d_keep     = keep_idx ? c.out_zc(keep_idx, (size_t) n) : nullptr;
     int32_t *d_nkeep    = keep_idx ? c.out_zc(n_keep, 1) : nullptr;
     ICG_LAUNCH_GUARD(c);
     {
         icg_prof_scope ps(ctx, "lk_track_fb");
         hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_ps, d_ns, d_pp, d_gs, d_out,
-                           d_st, ctx->has_cam ? 1 : 0, ctx->cam, d_und, ctx->cfg.width, ctx->cfg.height, 0, (const int32_t *) nullptr);
+                           d_st, d_und, ctx->cfg.width, ctx->cfg.height, 0, (const int32_t *) nullptr);
+    }
+    {
+        icg_prof_scope ps(ctx, "lk_finish");
+        hipLaunchKernelGGL(k_lk_finish, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_pp, (const float2 *) d_out, d_und, d_st,
+                           out_undist ? 1 : 0, ctx->has_cam ? 1 : 0, ctx->cam, ctx->cfg.width, ctx->cfg.height, 0, (const int32_t *) nullptr);
     }
     if (keep_idx) {
         icg_prof_scope ps(ctx, "keep_indices");
@@ -752,9 +803,16 @@ int icg_lk_launch_segments(icg_ctx *ctx, int n_seg, int seg_cap, const int32_t *
                            const float2 *d_prev, const float2 *d_guess, float2 *d_out, uint8_t *d_status, float2 *d_undist) {
     if (!ctx->has_cam) return icg_fail(ctx, ICG_ERR_INVALID, "camera not set");
     const int n = n_seg * seg_cap;
-    icg_prof_scope ps(ctx, "lk_track_fb");
-    hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_prev_slot, d_next_slot, d_prev,
-                       d_guess, d_out, d_status, 1, ctx->cam, d_undist, ctx->cfg.width, ctx->cfg.height, seg_cap, d_count);
+    {
+        icg_prof_scope ps(ctx, "lk_track_fb");
+        hipLaunchKernelGGL(k_lk_track_fb, dim3(icg_xcd_grid(n)), dim3(64), 0, ctx->stream, icg_make_pyr_desc(ctx), n, d_prev_slot, d_next_slot, d_prev,
+                           d_guess, d_out, d_status, d_undist, ctx->cfg.width, ctx->cfg.height, seg_cap, d_count);
+    }
+    {
+        icg_prof_scope ps(ctx, "lk_finish");
+        hipLaunchKernelGGL(k_lk_finish, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_prev, (const float2 *) d_out, d_undist, d_status, 1, 1,
+                           ctx->cam, ctx->cfg.width, ctx->cfg.height, seg_cap, d_count);
+    }
     ICG_HIP(ctx, hipGetLastError());
     return ICG_OK;
 }
