@@ -280,6 +280,12 @@ __device__ __forceinline__ int dot2_keep_s(unsigned int a, unsigned int b, int c
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
     return d;
 }
+// a.lo*b.lo + a.hi*b.hi with the accumulator 0 as an inline constant
+__device__ __forceinline__ int dot2_zero(unsigned int a, unsigned int b) {
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 // (lo16(a), lo16(b)) as one packed register
 __device__ __forceinline__ unsigned int pk_lo16(int a, int b) {
     return __builtin_amdgcn_perm((unsigned int) b, (unsigned int) a, 0x05040100u);
@@ -527,8 +533,9 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
                     const unsigned int dp = m < 3 ? pk_lo16(diff[2 * m], diff[2 * m + 1]) : (unsigned int) diff[6]; // IXP[3].hi == 0
-                    sb1 = dot2(dp, IXP[m], sb1);
-                    sb2 = dot2(dp, IYP[m], sb2);
+                    // (the first product takes its zero accumulator as an inline constant: v_dot2c's tied accumulator cost a v_mov 0 per sum)
+                    sb1 = m ? dot2(dp, IXP[m], sb1) : dot2_zero(dp, IXP[m]);
+                    sb2 = m ? dot2(dp, IYP[m], sb2) : dot2_zero(dp, IYP[m]);
                 }
                 float b1, b2;
                 wave_sum2_i32x8_f32(sb1, sb2, b1, b2);
@@ -537,8 +544,16 @@ __device__ bool lk_track_wave(const icg_pyr_desc &P, const unsigned char *slotI,
                 nptx += dx;
                 npty += dy;
                 nextStore = make_float2(nptx + (float) ICG_LK_HALF, npty + (float) ICG_LK_HALF);
-                // dx^2 is exact in double, so the fused form rounds the same sum once, as the two-step form does
-                if (__builtin_fma((double) dx, (double) dx, (double) dy * (double) dy) <= eps2) {
+                // ddx^2 + ddy^2 <= eps^2 in double (dx^2 is exact in double, so the fused form rounds the same sum once, as the two-step form
+                // does).  Round 6: the float sum of the float squares is within 2^-22 of it, relatively — outside a band of 1e-5 around eps^2
+                // it decides the test, and only inside the band the FP64 form runs (four half-rate instructions of every iteration before).
+                const float n2 = dx * dx + dy * dy;
+                bool converged = n2 < 9.9999e-5f;
+                if (!converged && !(n2 > 1.00001e-4f)) { // wave-uniform; a real branch (the empty asm keeps the compiler from computing both forms always)
+                    asm volatile("");
+                    converged = __builtin_fma((double) dx, (double) dx, (double) dy * (double) dy) <= eps2;
+                }
+                if (converged) {
                     more = false;
                     break;
                 }
