@@ -9,10 +9,11 @@
 // selection; sub-pixel refinement with sequential double accumulation (bit-identical to the CPU restatement).
 //
 // Kernels (HBM/L2-bound stencils, no MFMA shape):
-//   k_min_eig_nms 60x16 tile per wave streamed down the image columns: the mask of the tile from the DISC LIST (no mask plane: the
-//                 existing features whose discs reach the tile are found by the wave itself), response (separable exact box
-//                 sums), per-ROI masked maximum by an order-preserving uint atomicMax, 3x3 NMS + mask in registers -> every local
-//                 maximum (key = response bits << 32 | raster index) appended per ROI; no response plane in HBM
+//   k_min_eig_nms one wave per 60 x 64 block of a ROI: the mask of the block from the DISC LIST (no mask plane: the existing features whose
+//                 discs reach the block are found by the wave itself, a 64-bit row set per lane), then only the RUNS of rows that hold an
+//                 unmasked pixel are streamed down the image columns: response (separable exact box sums), per-ROI masked maximum by an
+//                 order-preserving uint atomicMax, 3x3 NMS + mask in registers -> every local maximum (key = response bits << 32 | raster
+//                 index) appended per ROI; no response plane in HBM
 //   k_select      one workgroup per ROI: quality threshold 0.01*max, then repeated block-wide arg-max over live candidates +
 //                 min-distance kill (equivalent to sort + greedy grid test, needs no sort and no capacity cap)
 //   k_subpix      one wavefront per corner: 13x13 bilinear patch and the 121 gradient terms in parallel through LDS,
@@ -34,12 +35,12 @@ __device__ __forceinline__ float f32_from_order_key(unsigned int k) {
 // ---------------------------------------------------------------------------------------------------------
 // The mask (tracking.cc:609-620: a 255-plane with a filled cv::circle of radius track_min_pixel_distance_ zeroed at every existing feature)
 // is never materialised.  Rounds 1-3 wrote it as a byte plane (k_mask_discs: 0.9 MB per frame written in spans and read back by the
-// detector, 1.4-1.6 us per frame of pure HBM time and a launch); now every wave of k_min_eig_nms tests its 60 x 16 tile against the
+// detector, 1.4-1.6 us per frame of pure HBM time and a launch); now every wave of k_min_eig_nms tests its 60 x 64 block against the
 // discs directly.  A pixel (x, y) is masked iff some feature centre (cx, cy) = (rint(px), rint(py)) has |x - cx| <= halfw[|y - cy|],
 // halfw = the span table of OpenCV's midpoint circle (drawing.cpp Circle(), circle_halfwidths below).  That table is non-increasing in
 // |dy| (checked on the host when it is built), so per COLUMN distance a = |x - cx| the masked rows are the interval |y - cy| <= vh[a] with
-// vh[a] = max{dy : halfw[dy] >= a}: one LDS lookup and a 16-bit interval mask per (lane, disc) instead of 16 span tests.  The wave finds
-// the discs that reach its tile itself: the job's ~300 centres in chunks of 64 (a lane each, bounding-box test, ballot), then a
+// vh[a] = max{dy : halfw[dy] >= a}: one LDS lookup and a 64-bit interval mask per (lane, disc) instead of 64 span tests.  The wave finds
+// the discs that reach its block itself: the job's ~300 centres in chunks of 64 (a lane each, bounding-box test, ballot), then a
 // wave-uniform loop over the hits with the centre moved to SGPRs by readlane.
 // ---------------------------------------------------------------------------------------------------------
 // k_min_eig_nms: Shi-Tomasi response, masked per-ROI maximum AND the 3x3 non-maximum test in ONE pass over the u8 image —
@@ -49,10 +50,11 @@ __device__ __forceinline__ float f32_from_order_key(unsigned int k) {
 // RAW neighbour: a neighbour at or below the threshold is below v, one above it keeps its value), so the kernel appends every
 // unmasked, non-zero local maximum and k_select drops the ones at or below the threshold.
 //
-// One WAVE per 60 x 16 tile of NMS outputs, a lane per image column (64 lanes = 60 outputs + 2 halo columns each side), the
-// wave STREAMS down its columns (22 image rows -> 20 rows of covariance products -> 18 response rows -> 16 NMS rows) with
-// three-row rolling windows in registers; the left/right neighbours' values move through wave-shift DPP, no LDS, no barrier:
-//   image row t      one dword per lane (3 pixels by per-lane byte selects: reflect-101 at true image borders folded in),
+// One WAVE per 60 x 64 block of NMS outputs (fe_block below), a lane per image column (64 lanes = 60 outputs + 2 halo columns each side);
+// for every run [a, b] of rows that hold an unmasked owned pixel the wave STREAMS down its columns (image rows a-3 .. b+3 -> product rows
+// a-2 .. b+2 -> response rows a-1 .. b+1 -> NMS rows a .. b) with three-row rolling windows in registers; the left/right neighbours' values
+// move through wave-shift DPP, no LDS, no barrier:
+//   image row        one dword per lane (3 pixels by one v_perm with the lane's selector: reflect-101 at true image borders folded in),
 //                    running Sobel differences d = p[x+1]-p[x-1], s = p[x-1]+2p[x]+p[x+1]
 //   product row      gx = d0+2d1+d2, gy = s2-s0, the three float products; horizontal 3-sums in double
 //   response row     vertical 3-sum in double (exact in any order: every term is a float in [s^2,(1020 s)^2], s = 1/3060, so all
@@ -60,10 +62,10 @@ __device__ __forceinline__ float f32_from_order_key(unsigned int k) {
 //   NMS row          centre >= max of the 8 raw neighbours, unmasked, non-zero -> wave-aggregated append
 // Reflect-101 at the ROI edge (the covariance maps are ROI-sized Mats in OpenCV): a lane left/right of the ROI computes the
 // products of the mirrored column (same Sobel, bit-identical), the product row above/below the ROI is the mirrored row of the
-// rolling window.  Coordinates further out belong to partial tiles: clamped, their results never used.
+// rolling window.  Coordinates further out belong to partial blocks: clamped, their results never used.
 #define FE_TW 60    // NMS output columns per wave
-#define FE_TH 16    // NMS output rows per wave
-#define FE_WAVES 4  // waves per workgroup, stacked vertically
+#define FE_TH 16    // FE_TH * FE_WAVES = 64 NMS output rows per wave (the block height; the two factors are what is left of the
+#define FE_WAVES 4  // 60 x 16 tiles of rounds 2-5) — and FE_WAVES waves = FE_WAVES neighbouring blocks per workgroup
 #define FE_MAX_RADIUS 1022 // largest disc radius the LDS span table holds (min_dist; 45 at C2)
 #ifndef FE_RESIDENT_PER_XCD
 #define FE_RESIDENT_PER_XCD 192 // workgroups of k_min_eig_nms per XCD (x 8 XCDs x 4 waves = the kernel's residency; fewer when the grid is smaller)

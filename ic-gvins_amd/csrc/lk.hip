@@ -22,6 +22,11 @@
 //     pixels, Scharr terms and Q14 weights all fit 16 bits -> v_pk_{add,sub,mul_lo}_u16 for the derivative stencil and
 //     v_dot2_i32_i16 for every bilinear blend (2 taps per instruction) and for the window products; the patch sample is
 //     folded into the blend's rounding constant (c0 = 256 - 512*I) so a residual costs 2 dot2 + 1 shift.
+//   * (round 6) the Scharr terms carry a factor 4 so that a blended derivative is the HIGH half of its dot2 result (packed by one v_perm, no
+//     shift); the three window sums of a level come out of one reduction tree (v_permlane32_swap + v_permlane16_swap); the eigenvalue test
+//     needs no division (threshold on the numerator) and the square root no range scaling; the verdict on a point (border, forward-backward
+//     distance, undistortion: FP64 that every lane of the wave computed alike) is k_lk_finish's, a thread per point.
+//     6.3 k vector instructions per tracked point (7.1 k in rounds 4-5), 93 VGPRs, no scratch, 5 waves per SIMD.
 // Algorithmic HBM bytes per point and direction: 4 levels x (24^2 + 22^2) B; everything else is
 // LDS/VGPR traffic.
 #include <cfloat>

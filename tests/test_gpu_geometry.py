@@ -237,6 +237,47 @@ def test_detect_dense_mask_and_fully_masked_blocks(oracle, ctx1280):
     assert 0 < cnt[0] < 200 and cnt[1] == 0
 
 
+def test_detect_row_slivers_between_disc_bands(oracle):
+    """k_min_eig_nms streams only the RUNS of rows that hold an unmasked pixel (round 6: one wave per 60 x 64 block; gaps of up to six
+    masked rows are streamed through, longer ones are skipped and the rolling windows primed again).  Bands of closely spaced discs leave
+    slivers of 1..12 unmasked rows between them — at every phase against the 64-row blocks, against the 4-row load chunks and against the
+    ROI edges (the two mirrored product rows of a ROI live in a separate copy of the row step) — and sparse discs leave long runs; every
+    pattern must give the oracle's corners, bit for bit, in the oracle's order."""
+    import icgvins
+    w, h = 640, 480
+    c = icgvins.Context(w, h, n_slots=1, max_batch=1, max_points=4096)
+    try:
+        img = synth.texture(w, h, seed=85)
+        c.preprocess([0], [img])
+        clahe = oracle.clahe(img)
+        grid = grid_for(w, h, 100)
+        q = np.full(6, grid[5], np.int32)
+        r = grid[4]  # disc radius = min distance (40)
+        xs = np.arange(0, w + 8, 8, dtype=np.float32)
+        for first, gaps in ((0, (1, 2, 3, 5, 6)), (17, (7, 8, 12, 1, 4)), (38, (3, 3, 9, 2, 6)), (-25, (2, 13, 1, 7, 5)), (60, (4, 6, 7, 1, 1))):
+            cys, y = [], float(first)
+            for g in gaps:
+                cys.append(y)
+                y += 2 * r + 1 + g  # a band of discs covers 2 r + 1 rows at its centre columns: g rows stay free before the next band
+            m = np.array([(x, cy) for cy in cys for x in xs], np.float32)
+            out, cnt, blk = c.detect([0], grid, [0, len(m)], m, q, 300)
+            exp_pts, exp_blk = oracle.detect(clahe, grid, m, q, 300)
+            assert cnt[0] == len(exp_pts) and cnt[0] > 0, (first, cnt[0], len(exp_pts))
+            assert np.array_equal(blk[0, :cnt[0]], exp_blk), first
+            assert np.array_equal(out[0, :cnt[0]].view(np.uint32), exp_pts.view(np.uint32)), first
+        # sparse discs: long runs, blocks without any masked pixel next to blocks that are fully masked
+        rng = np.random.RandomState(11)
+        for n in (1, 6, 25):
+            m = rng.uniform([0, 0], [w, h], (n, 2)).astype(np.float32)
+            out, cnt, blk = c.detect([0], grid, [0, len(m)], m, q, 300)
+            exp_pts, exp_blk = oracle.detect(clahe, grid, m, q, 300)
+            assert cnt[0] == len(exp_pts) and cnt[0] > 0
+            assert np.array_equal(blk[0, :cnt[0]], exp_blk), n
+            assert np.array_equal(out[0, :cnt[0]].view(np.uint32), exp_pts.view(np.uint32)), n
+    finally:
+        c.close()
+
+
 def test_fm_ransac_check_subset_on_lattice_points(oracle, ctx1280):
     """FMEstimatorCallback::checkSubset on the device path: lattice points have many collinear triples, so subsets are rejected and
     redrawn (the RNG keeps advancing) — the mask must still equal the oracle's; a set on ONE line has no valid subset at all"""
