@@ -322,7 +322,7 @@ __device__ __forceinline__ void fe_block(const int bl, const int *vh, const det_
 // to XCD b & 7 (the dispatcher's round-robin) and walks that XCD's contiguous eighth of the grid (icg_xcd_chunked's partition) at a fixed
 // stride.  (Rounds 2-5: one workgroup per block, a wave per 60 x 16 tile — 221 k waves per launch of 192 frames, 72 % of which left after
 // the mask test.  A dynamic form — every wave pulling tiles from a per-XCD counter — was measured too: 221 k atomics on eight addresses
-// serialise in L2, 3.1 ms per launch against 0.27-0.45: profiles/r06_detector_resident_waves.txt.)
+// serialise in L2, 3.1 ms per launch against 0.27-0.45: profiles/r06_detector_and_lk_diet.txt.)
 __global__ __launch_bounds__(64 * FE_WAVES) void k_min_eig_nms(const det_roi *rois, const uint8_t *frames, size_t slot_bytes,
                                                                const int32_t *slots, int pitch, int w, int h, const float2 *mask_pts,
                                                                const int32_t *mask_begin, const int32_t *mask_cnt /* per job */, int radius,
